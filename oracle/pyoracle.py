@@ -1,0 +1,532 @@
+"""ctypes bindings for the CPU checkers -- TEST INFRASTRUCTURE ONLY.
+
+* ``Oracle``  -> oracle/liboracle.so   (plain-C restatement, oracle/slam_oracle.c)
+* ``Ref``     -> oracle/_ref/libslamref.so (unmodified reference headers compiled in place by
+  oracle/ref_harness.cpp; exists only where it was built from /root/reference).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package (slam-constructor_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CELL_OCC, CELL_TBM, CELL_GMAPPING = 0, 1, 2
+OOPE_OBSTACLE, OOPE_MAX, OOPE_MEAN, OOPE_OVERLAP, OOPE_GMAPPING = range(5)
+OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
+TRIG_RAW, TRIG_CACHED = 0, 1
+SUM_SEQUENTIAL, SUM_TREE256 = 0, 1
+SM_MC, SM_HC, SM_BF = 0, 1, 2
+STRIDE = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}
+
+# reference-harness cell kinds (ref_harness.cpp) -> device payload model
+REF_CELL_MEAN, REF_CELL_TBM, REF_CELL_GMAPPING, REF_CELL_AFFINE, REF_CELL_MOCK = range(5)
+REF_TO_MODEL = {0: CELL_OCC, 1: CELL_TBM, 2: CELL_GMAPPING, 3: CELL_OCC, 4: CELL_OCC}
+MAP_PLAIN, MAP_UNBOUNDED_PLAIN, MAP_LAZY_TILED, MAP_UNBOUNDED_LAZY_TILED = range(4)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_uint)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class OrcMap(C.Structure):
+    _fields_ = [("cell_model", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("origin_x", C.c_int), ("origin_y", C.c_int), ("scale", C.c_double),
+                ("payload", _dp), ("unknown", C.c_double * 4), ("bounded", C.c_int)]
+
+
+class OrcScan(C.Structure):
+    _fields_ = [("n", C.c_int), ("range", _dp), ("angle", _dp), ("weight", _dp), ("factor", _dp),
+                ("trig_mode", C.c_int), ("a_min", C.c_double), ("a_delta", C.c_double),
+                ("table_n", C.c_int), ("tab_sin", _dp), ("tab_cos", _dp)]
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [("oope", C.c_int), ("oie", C.c_int), ("area", C.c_double * 4),
+                ("gm_fullness_th", C.c_double), ("gm_window", C.c_int), ("sum_order", C.c_int)]
+
+
+class OrcGmCache(C.Structure):
+    _fields_ = [("cx", C.c_int), ("cy", C.c_int), ("prob", C.c_double)]
+
+
+class OrcMt(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
+
+
+class OrcNormal(C.Structure):
+    _fields_ = [("mean", C.c_double), ("stddev", C.c_double), ("saved", C.c_double),
+                ("has_saved", C.c_int)]
+
+
+class OrcEnum(C.Structure):
+    _fields_ = [("kind", C.c_int), ("eng", OrcMt), ("rv", OrcNormal * 3),
+                ("max_failed", C.c_uint), ("max_poses", C.c_uint), ("failed", C.c_uint),
+                ("poses_nm", C.c_uint), ("base_td", C.c_double), ("base_rd", C.c_double),
+                ("td", C.c_double), ("rd", C.c_double), ("max_failed_rounds", C.c_uint),
+                ("failed_rounds", C.c_uint), ("base_dt", C.c_double), ("base_dr", C.c_double),
+                ("dt", C.c_double), ("dr", C.c_double), ("action_id", C.c_uint),
+                ("base_set", C.c_int), ("round_failed", C.c_int), ("base_pose", C.c_double * 3),
+                ("bf", C.c_double * 9), ("bx", C.c_double), ("by", C.c_double),
+                ("bt", C.c_double), ("bf_base_set", C.c_int)]
+
+
+def build_oracle(force=False):
+    so = os.path.join(HERE, "liboracle.so")
+    src = os.path.join(HERE, "slam_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class GridMapData:
+    """A dense window of a grid map + geometry (the flat mirror both checkers and the HIP
+    library consume).  payload: float64 [height, width, stride]."""
+
+    def __init__(self, cell_model, payload, origin, scale, unknown, bounded=False):
+        self.cell_model = int(cell_model)
+        st = STRIDE[self.cell_model]
+        payload = f64(payload)
+        if payload.ndim == 2:
+            payload = payload[:, :, None]
+        assert payload.shape[2] == st, (payload.shape, st)
+        self.payload = np.ascontiguousarray(payload)
+        self.height, self.width = payload.shape[:2]
+        self.origin = (int(origin[0]), int(origin[1]))
+        self.scale = float(scale)
+        unk = np.zeros(4)
+        unk[:st] = np.asarray(unknown, dtype=np.float64).ravel()[:st]
+        self.unknown = unk
+        self.bounded = bool(bounded)
+
+    def c_struct(self):
+        m = OrcMap()
+        m.cell_model = self.cell_model
+        m.width, m.height = self.width, self.height
+        m.origin_x, m.origin_y = self.origin
+        m.scale = self.scale
+        m.payload = _d(self.payload)
+        for k in range(4):
+            m.unknown[k] = self.unknown[k]
+        m.bounded = int(self.bounded)
+        return m
+
+
+class ScanData:
+    """Filtered scan in the flat form the scorer consumes."""
+
+    def __init__(self, rng, ang, weight=None, factor=None, trig_mode=TRIG_RAW, a_min=0.0,
+                 a_delta=1.0, tab_sin=None, tab_cos=None):
+        self.range = f64(rng)
+        self.angle = f64(ang)
+        n = self.range.size
+        self.weight = f64(weight) if weight is not None else np.full(n, 1.0 / max(n, 1))
+        self.factor = f64(factor) if factor is not None else np.ones(n)
+        self.trig_mode = int(trig_mode)
+        self.a_min, self.a_delta = float(a_min), float(a_delta)
+        self.tab_sin = f64(tab_sin) if tab_sin is not None else np.zeros(1)
+        self.tab_cos = f64(tab_cos) if tab_cos is not None else np.zeros(1)
+
+    @property
+    def n(self):
+        return int(self.range.size)
+
+    def c_struct(self):
+        s = OrcScan()
+        s.n = self.n
+        s.range, s.angle = _d(self.range), _d(self.angle)
+        s.weight, s.factor = _d(self.weight), _d(self.factor)
+        s.trig_mode = self.trig_mode
+        s.a_min, s.a_delta = self.a_min, self.a_delta
+        s.table_n = int(self.tab_sin.size)
+        s.tab_sin, s.tab_cos = _d(self.tab_sin), _d(self.tab_cos)
+        return s
+
+    def beam_trig(self):
+        """Per-beam (cos a_i, sin a_i) exactly as the reference trig provider would see them:
+        libm for the raw provider, table entries for the cached one."""
+        if self.trig_mode == TRIG_CACHED:
+            idx = np.round((self.angle - self.a_min) / self.a_delta).astype(np.int64)
+            return self.tab_cos[idx].copy(), self.tab_sin[idx].copy()
+        return np.cos(self.angle), np.sin(self.angle)
+
+
+def make_cfg(oope=OOPE_OBSTACLE, oie=OIE_DISCREPANCY, area=(0, 0, 0, 0), gm_th=0.1, gm_window=1,
+             sum_order=SUM_SEQUENTIAL):
+    c = OrcCfg()
+    c.oope, c.oie = oope, oie
+    for k in range(4):
+        c.area[k] = float(area[k])
+    c.gm_fullness_th, c.gm_window, c.sum_order = gm_th, gm_window, sum_order
+    return c
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = L = C.CDLL(build_oracle())
+        L.orc_canonical.restype = C.c_double
+        L.orc_normal_sample.restype = C.c_double
+        L.orc_uniform_real.restype = C.c_double
+        L.orc_uniform_real.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_mt_next.restype = C.c_uint32
+        L.orc_oope_probability.restype = C.c_double
+        L.orc_oope_probability.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, _dp,
+                                           C.c_void_p]
+        L.orc_build_trig_table.argtypes = [C.c_double, C.c_double, C.c_double, _dp, _dp, C.c_int]
+        L.orc_filter_scan.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, C.c_uint,
+                                      C.c_double, C.c_void_p, _ip]
+        L.orc_enum_init_mc.argtypes = [C.c_void_p, C.c_uint, C.c_double, C.c_double, C.c_uint,
+                                       C.c_uint]
+        L.orc_enum_init_hc.argtypes = [C.c_void_p, C.c_uint, C.c_double, C.c_double]
+        L.orc_world_to_cells.argtypes = [C.c_double] * 5 + [C.c_int, _ip]
+        L.orc_resample.argtypes = [C.c_int, _dp, C.c_uint32, _up]
+
+    # -- trig / filter / weights
+    def trig_table(self, a_min, a_max, a_inc):
+        n = self.lib.orc_build_trig_table(a_min, a_max, a_inc, None, None, 0)
+        s, c = np.zeros(n), np.zeros(n)
+        self.lib.orc_build_trig_table(a_min, a_max, a_inc, _d(s), _d(c), n)
+        return s, c
+
+    def filter_scan(self, gmap, rng, ang, is_occ, pose, skip_rate=0, max_range=-1.0, trig=None):
+        rng, ang = f64(rng), f64(ang)
+        occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+        trig = trig or ScanData(rng, ang)
+        ts = trig.c_struct()
+        kept = np.zeros(rng.size, np.int32)
+        m = gmap.c_struct()
+        pose = f64(pose)
+        n = self.lib.orc_filter_scan(C.byref(m), rng.size, _d(rng), _d(ang), _i(occ), _d(pose),
+                                     skip_rate, max_range, C.byref(ts), _i(kept))
+        return kept[:n].copy()
+
+    def weights(self, kind, rng, ang):
+        rng, ang = f64(rng), f64(ang)
+        out = np.zeros(rng.size)
+        if kind == "even":
+            self.lib.orc_weights_even(rng.size, _d(out))
+        elif kind == "viny":
+            self.lib.orc_weights_viny(rng.size, _d(rng), _d(ang), _d(out))
+        elif kind == "ahr":
+            self.lib.orc_weights_ahr(rng.size, _d(rng), _d(ang), _d(out))
+        else:
+            raise ValueError(kind)
+        return out
+
+    # -- scoring
+    def score_poses(self, gmap, scan, cfg, poses, cache=None):
+        poses = f64(poses).reshape(-1, 3)
+        out = np.zeros(poses.shape[0])
+        m, s = gmap.c_struct(), scan.c_struct()
+        self.lib.orc_score_poses(C.byref(m), C.byref(s), C.byref(cfg), poses.shape[0], _d(poses),
+                                 _d(out), C.byref(cache) if cache is not None else None)
+        return out
+
+    def oope_probability(self, gmap, cfg, ox, oy, area4, cache=None):
+        m = gmap.c_struct()
+        a = f64(area4)
+        return self.lib.orc_oope_probability(C.byref(m), C.byref(cfg), ox, oy, _d(a),
+                                             C.byref(cache) if cache is not None else None)
+
+    @staticmethod
+    def new_gm_cache():
+        return OrcGmCache(0, 0, -1.0)
+
+    # -- enumerators / matchers
+    def enumerator(self, kind, params):
+        e = OrcEnum()
+        if kind == SM_MC:
+            self.lib.orc_enum_init_mc(C.byref(e), int(params[0]), params[1], params[2],
+                                      int(params[3]), int(params[4]))
+        elif kind == SM_HC:
+            self.lib.orc_enum_init_hc(C.byref(e), int(params[0]), params[1], params[2])
+        else:
+            p = f64(params)
+            self.lib.orc_enum_init_bf(C.byref(e), _d(p))
+        return e
+
+    def enumerate_all_rejected(self, kind, params, base, cap=4096):
+        e = self.enumerator(kind, params)
+        base = f64(base)
+        out = []
+        q = np.zeros(3)
+        while self.lib.orc_enum_has_next(C.byref(e)) and len(out) < cap:
+            self.lib.orc_enum_next(C.byref(e), _d(base), _d(q))
+            out.append(q.copy())
+            self.lib.orc_enum_feedback(C.byref(e), 0)
+        return np.array(out)
+
+    def process_scan(self, enum, gmap, scan, cfg, init_pose, cap=1 << 16, cache=None):
+        m, s = gmap.c_struct(), scan.c_struct()
+        res = np.zeros(4)
+        trp, trs, tra = np.zeros((cap, 3)), np.zeros(cap), np.zeros(cap, np.int32)
+        ip = f64(init_pose)
+        n = self.lib.orc_process_scan(C.byref(enum), C.byref(m), C.byref(s), C.byref(cfg), _d(ip),
+                                      _d(res), cap, _d(trp), _d(trs), _i(tra),
+                                      C.byref(cache) if cache is not None else None)
+        k = min(n, cap)
+        return dict(prob=res[0], delta=res[1:4].copy(), n_calls=n, poses=trp[:k].copy(),
+                    scores=trs[:k].copy(), accepted=tra[:k].copy())
+
+    # -- particle filter
+    def normalize_weights(self, w):
+        w = f64(w).copy()
+        self.lib.orc_normalize_weights(w.size, _d(w))
+        return w
+
+    def resampling_is_required(self, w):
+        w = f64(w)
+        return bool(self.lib.orc_resampling_is_required(w.size, _d(w)))
+
+    def resample(self, w, seed):
+        w = f64(w)
+        out = np.zeros(w.size, np.uint32)
+        self.lib.orc_resample(w.size, _d(w), seed, out.ctypes.data_as(_up))
+        return out
+
+    def heaviest(self, w):
+        w = f64(w)
+        return int(self.lib.orc_heaviest(w.size, _d(w)))
+
+    def world_to_cells(self, scale, x0, y0, x1, y1, cap=1 << 16):
+        out = np.zeros((cap, 2), np.int32)
+        n = self.lib.orc_world_to_cells(scale, x0, y0, x1, y1, cap, _i(out))
+        return out[:n].copy()
+
+    # -- RNG
+    def rng(self, seed):
+        g = OrcMt()
+        self.lib.orc_mt_seed(C.byref(g), seed)
+        return g
+
+
+# ------------------------------------------------------------------------------------------
+def ref_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libslamref.so"))
+
+
+class Ref:
+    """Compiled reference (oracle/_ref/libslamref.so)."""
+
+    def __init__(self):
+        self.lib = L = C.CDLL(os.path.join(HERE, "_ref", "libslamref.so"))
+        vp, d, i, u = C.c_void_p, C.c_double, C.c_int, C.c_uint
+        L.ref_map_create.restype = vp
+        L.ref_map_create.argtypes = [i, i, i, i, d, d]
+        L.ref_map_destroy.argtypes = [vp]
+        L.ref_map_geometry.argtypes = [vp, _ip, _dp]
+        L.ref_map_update.argtypes = [vp, i, i, i, d, d, d, d, d]
+        L.ref_map_stamp_text.argtypes = [vp, C.c_char_p, i, i, i, i]
+        L.ref_cecum_text.argtypes = [i, i, i, C.c_char_p, i]
+        L.ref_map_export.argtypes = [vp, i, i, i, i, _dp]
+        L.ref_map_export_all.argtypes = [vp, _dp]
+        L.ref_map_unknown_payload.argtypes = [vp, _dp]
+        L.ref_scan_create.restype = vp
+        L.ref_scan_create.argtypes = [i, _dp, _dp, _ip, i, d, d, d]
+        L.ref_scan_destroy.argtypes = [vp]
+        L.ref_scan_size.argtypes = [vp]
+        L.ref_scan_get.argtypes = [vp, _dp, _dp, _ip, _dp]
+        L.ref_scan_set_factor.argtypes = [vp, i, d]
+        L.ref_scan_trig_table.argtypes = [vp, _dp, _dp, i]
+        L.ref_scan_generate.restype = vp
+        L.ref_scan_generate.argtypes = [vp, d, d, d, d, d, u, d]
+        L.ref_spe_create.restype = vp
+        L.ref_spe_create.argtypes = [i, i, i, u, d, d, u]
+        L.ref_spe_destroy.argtypes = [vp]
+        L.ref_filter_scan.restype = vp
+        L.ref_filter_scan.argtypes = [vp, vp, d, d, d, vp]
+        L.ref_scan_weights.argtypes = [vp, vp, _dp]
+        L.ref_score.argtypes = [vp, vp, vp, i, _dp, _dp, _dp]
+        L.ref_oope_probability.restype = d
+        L.ref_oope_probability.argtypes = [i, i, vp, d, d, _dp]
+        L.ref_matcher_create.restype = vp
+        L.ref_matcher_create.argtypes = [i, vp, _dp]
+        L.ref_matcher_destroy.argtypes = [vp]
+        L.ref_matcher_reset_state.argtypes = [vp]
+        L.ref_process_scan.argtypes = [vp, vp, d, d, d, vp, _dp, i, _dp, _dp, _ip, _ip]
+        L.ref_enumerate_all_rejected.argtypes = [i, _dp, d, d, d, i, _dp]
+        L.ref_append_scan.argtypes = [vp, vp, d, d, d, d, i, _dp, d, d]
+        L.ref_world_to_cells.argtypes = [vp, d, d, d, d, i, _ip]
+        L.ref_resample.argtypes = [i, _dp, u, _up]
+        L.ref_gmapping_create.restype = vp
+        L.ref_gmapping_create.argtypes = [u, i, i, d, _dp, _up, u, d, i, _dp, d, d, u, d, d]
+        L.ref_gmapping_destroy.argtypes = [vp]
+        L.ref_gmapping_map.restype = vp
+        L.ref_gmapping_map.argtypes = [vp]
+        L.ref_gmapping_step.argtypes = [vp, vp, d, d, d, u, u, _up, _dp, _dp, _ip, _ip]
+        L.ref_gmapping_gate.argtypes = [vp, _dp, _dp]
+
+    # maps
+    def map_create(self, cell, map_type, w, h, scale, mock_prob=0.5):
+        h_ = self.lib.ref_map_create(cell, map_type, w, h, scale, mock_prob)
+        assert h_
+        return RefMapHandle(self, h_, cell, map_type)
+
+    def cecum_text(self, w, h, bnd_pos):
+        buf = C.create_string_buffer(w * h + h + 64)
+        n = self.lib.ref_cecum_text(w, h, bnd_pos, buf, len(buf))
+        assert n >= 0
+        return buf.value.decode()
+
+    # scans
+    def scan_create(self, rng, ang, is_occ=None, trig_mode=TRIG_RAW, a_min=0.0, a_max=0.0,
+                    a_inc=1.0):
+        rng, ang = f64(rng), f64(ang)
+        occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+        return RefScanHandle(self, self.lib.ref_scan_create(rng.size, _d(rng), _d(ang), _i(occ),
+                                                            trig_mode, a_min, a_max, a_inc))
+
+    def scan_generate(self, m, pose, max_dist, fov_deg, pts_nm, occ_threshold=1.0):
+        return RefScanHandle(self, self.lib.ref_scan_generate(m.h, pose[0], pose[1], pose[2],
+                                                              max_dist, fov_deg, pts_nm,
+                                                              occ_threshold))
+
+    def spe_create(self, oope=OOPE_OBSTACLE, oie=OIE_DISCREPANCY, weighting=0, skip_rate=0,
+                   max_range=-1.0, gm_th=0.1, gm_window=1):
+        return RefHandle(self, self.lib.ref_spe_create(oope, oie, weighting, skip_rate, max_range,
+                                                       gm_th, gm_window), "ref_spe_destroy")
+
+    def filter_scan(self, spe, scan, pose, m):
+        return RefScanHandle(self, self.lib.ref_filter_scan(spe.h, scan.h, pose[0], pose[1],
+                                                            pose[2], m.h))
+
+    def scan_weights(self, spe, scan):
+        out = np.zeros(scan.size())
+        self.lib.ref_scan_weights(spe.h, scan.h, _d(out))
+        return out
+
+    def score(self, spe, scan, m, poses, area=None):
+        poses = f64(poses).reshape(-1, 3)
+        out = np.zeros(poses.shape[0])
+        a = f64(area) if area is not None else None
+        self.lib.ref_score(spe.h, scan.h, m.h, poses.shape[0], _d(poses),
+                           _d(a) if a is not None else None, _d(out))
+        return out
+
+    def oope_probability(self, oope, oie, m, ox, oy, range4):
+        r = f64(range4)
+        return self.lib.ref_oope_probability(oope, oie, m.h, ox, oy, _d(r))
+
+    def matcher_create(self, kind, spe, params):
+        p = f64(params)
+        return RefHandle(self, self.lib.ref_matcher_create(kind, spe.h, _d(p)),
+                         "ref_matcher_destroy")
+
+    def process_scan(self, matcher, scan, pose, m, cap=1 << 16):
+        res = np.zeros(4)
+        trp, trs, tra = np.zeros((cap, 3)), np.zeros(cap), np.zeros(cap, np.int32)
+        fn = C.c_int(0)
+        n = self.lib.ref_process_scan(matcher.h, scan.h, pose[0], pose[1], pose[2], m.h, _d(res),
+                                      cap, _d(trp), _d(trs), _i(tra), C.byref(fn))
+        k = min(n, cap)
+        return dict(prob=res[0], delta=res[1:4].copy(), n_calls=n, poses=trp[:k].copy(),
+                    scores=trs[:k].copy(), accepted=tra[:k].copy(), filtered_n=fn.value)
+
+    def enumerate_all_rejected(self, kind, params, base, cap=4096):
+        p = f64(params)
+        out = np.zeros((cap, 3))
+        n = self.lib.ref_enumerate_all_rejected(kind, _d(p), base[0], base[1], base[2], cap,
+                                                _d(out))
+        return out[:n].copy()
+
+    def append_scan(self, m, scan, pose, quality=1.0, occ_est=0, base=(0.95, 1.0, 0.01, 1.0),
+                    blur=0.0, max_range=float("inf")):
+        b = f64(base)
+        self.lib.ref_append_scan(m.h, scan.h, pose[0], pose[1], pose[2], quality, occ_est, _d(b),
+                                 blur, max_range)
+
+    def world_to_cells(self, m, x0, y0, x1, y1, cap=1 << 16):
+        out = np.zeros((cap, 2), np.int32)
+        n = self.lib.ref_world_to_cells(m.h, x0, y0, x1, y1, cap, _i(out))
+        return out[:n].copy()
+
+    def resample(self, w, seed):
+        w = f64(w)
+        out = np.zeros(w.size, np.uint32)
+        req = self.lib.ref_resample(w.size, _d(w), seed, out.ctypes.data_as(_up))
+        return bool(req), out
+
+
+class RefHandle:
+    def __init__(self, ref, h, dtor):
+        assert h
+        self.ref, self.h, self._dtor = ref, h, dtor
+
+    def __del__(self):
+        try:
+            getattr(self.ref.lib, self._dtor)(self.h)
+        except Exception:
+            pass
+
+
+class RefScanHandle(RefHandle):
+    def __init__(self, ref, h):
+        super().__init__(ref, h, "ref_scan_destroy")
+
+    def size(self):
+        return self.ref.lib.ref_scan_size(self.h)
+
+    def get(self):
+        n = self.size()
+        r, a, o, f = np.zeros(n), np.zeros(n), np.zeros(n, np.int32), np.zeros(n)
+        self.ref.lib.ref_scan_get(self.h, _d(r), _d(a), _i(o), _d(f))
+        return r, a, o, f
+
+    def trig_table(self):
+        n = self.ref.lib.ref_scan_trig_table(self.h, None, None, 0)
+        s, c = np.zeros(n), np.zeros(n)
+        if n:
+            self.ref.lib.ref_scan_trig_table(self.h, _d(s), _d(c), n)
+        return s, c
+
+
+class RefMapHandle(RefHandle):
+    def __init__(self, ref, h, cell, map_type):
+        super().__init__(ref, h, "ref_map_destroy")
+        self.cell, self.map_type = cell, map_type
+
+    def geometry(self):
+        g = np.zeros(4, np.int32)
+        s = C.c_double()
+        self.ref.lib.ref_map_geometry(self.h, _i(g), C.byref(s))
+        return dict(width=int(g[0]), height=int(g[1]), origin=(int(g[2]), int(g[3])),
+                    scale=s.value)
+
+    def update(self, x, y, prob, qual=1.0, is_occ=True, obst=(0.0, 0.0), quality=1.0):
+        self.ref.lib.ref_map_update(self.h, x, y, int(is_occ), prob, qual, obst[0], obst[1],
+                                    quality)
+
+    def stamp_text(self, text, off, w_zoom=1, h_zoom=1):
+        self.ref.lib.ref_map_stamp_text(self.h, text.encode(), off[0], off[1], w_zoom, h_zoom)
+
+    def to_data(self):
+        """Flat mirror of the whole map window (what the adapter uploads)."""
+        g = self.geometry()
+        model = REF_TO_MODEL[self.cell]
+        st = STRIDE[model]
+        out = np.zeros((g["height"], g["width"], st))
+        self.ref.lib.ref_map_export_all(self.h, _d(out))
+        unk = np.zeros(4)
+        self.ref.lib.ref_map_unknown_payload(self.h, _d(unk))
+        bounded = self.map_type in (MAP_PLAIN, MAP_LAZY_TILED)
+        return GridMapData(model, out, g["origin"], g["scale"], unk[:st], bounded)

@@ -1,0 +1,134 @@
+/* oracle/slam_oracle.h -- TEST INFRASTRUCTURE ONLY (see slam_oracle.c header).
+ *
+ * Plain-C restatement of the slam-constructor scan-matching / particle-filter hot path.
+ * Every function cites the reference file:line it restates (paths relative to the
+ * reference root, slam_constructor 0.9.1).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.
+ */
+#ifndef SLAM_ORACLE_H
+#define SLAM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cell payload models (same values as include/slamhip.h) */
+enum { ORC_CELL_OCC = 0, ORC_CELL_TBM = 1, ORC_CELL_GMAPPING = 2 };
+enum { ORC_OOPE_OBSTACLE = 0, ORC_OOPE_MAX = 1, ORC_OOPE_MEAN = 2, ORC_OOPE_OVERLAP = 3,
+       ORC_OOPE_GMAPPING = 4 };
+enum { ORC_OIE_DISCREPANCY = 0, ORC_OIE_OCCUPANCY = 1 };
+enum { ORC_TRIG_RAW = 0, ORC_TRIG_CACHED = 1 };
+enum { ORC_SUM_SEQUENTIAL = 0, ORC_SUM_TREE256 = 1 };
+enum { ORC_SM_MC = 0, ORC_SM_HC = 1, ORC_SM_BF = 2 };
+
+/* Dense window of a GridMap: internal cell (ix,iy) = external + origin; payload is
+ * row-major [height][width][stride], stride = 1 (OCC: prob_occ), 4 (TBM: u,e,o,c),
+ * 3 (GMAPPING: prob_occ, obst.x, obst.y). */
+typedef struct {
+  int cell_model;
+  int width, height;
+  int origin_x, origin_y;
+  double scale;
+  const double *payload;
+  double unknown[4]; /* payload of the prototype / out-of-window cell */
+  int bounded;       /* 1: has_cell() tests the window (PlainGridMap); 0: Unbounded* */
+} orc_map;
+
+typedef struct {
+  int n;
+  const double *range, *angle;   /* polar scan points */
+  const double *weight, *factor; /* per-point weight (ScanPointWeighting) and factor */
+  int trig_mode;
+  double a_min, a_delta;         /* cached provider: index = round((a - a_min)/a_delta) */
+  int table_n;
+  const double *tab_sin, *tab_cos;
+} orc_scan;
+
+typedef struct {
+  int oope, oie;
+  double area[4];        /* SPEParams::sp_analysis_area (bot, top, left, right) */
+  double gm_fullness_th; /* GmappingOccupancyObservationPE */
+  int gm_window;
+  int sum_order;
+} orc_spe_cfg;
+
+typedef struct { int cx, cy; double prob; } orc_gm_cache; /* init: {0,0,-1} */
+
+/* ---- RNG (libstdc++ <random> restated) ---- */
+typedef struct { uint32_t mt[624]; int idx; } orc_mt19937;
+void orc_mt_seed(orc_mt19937 *g, uint32_t seed);
+uint32_t orc_mt_next(orc_mt19937 *g);
+double orc_canonical(orc_mt19937 *g);
+typedef struct { double mean, stddev, saved; int has_saved; } orc_normal;
+void orc_normal_init(orc_normal *d, double mean, double stddev);
+double orc_normal_sample(orc_normal *d, orc_mt19937 *g);
+double orc_uniform_real(orc_mt19937 *g, double a, double b);
+
+/* ---- trig table, filter, weights ---- */
+int orc_build_trig_table(double a_min, double a_max, double a_inc, double *sin_out,
+                         double *cos_out, int cap);
+int orc_filter_scan(const orc_map *map, int n, const double *range, const double *angle,
+                    const int *is_occ, const double *pose, unsigned skip_rate, double max_range,
+                    const orc_scan *trig, int *kept_idx);
+void orc_weights_even(int n, double *out);
+void orc_weights_viny(int n, const double *range, const double *angle, double *out);
+void orc_weights_ahr(int n, const double *range, const double *angle, double *out);
+
+/* ---- scoring ---- */
+void orc_endpoint(const orc_scan *scan, int i, const double *pose, double sin_b, double cos_b,
+                  double *wx, double *wy);
+double orc_oope_probability(const orc_map *map, const orc_spe_cfg *cfg, double ox, double oy,
+                            const double *area4, orc_gm_cache *cache);
+void orc_score_poses(const orc_map *map, const orc_scan *scan, const orc_spe_cfg *cfg, int n_poses,
+                     const double *poses, double *scores, orc_gm_cache *cache);
+
+/* ---- pose enumerators + accept loop ---- */
+typedef struct {
+  int kind;
+  /* MC (monte_carlo_scan_matcher.h:10-82) */
+  orc_mt19937 eng;
+  orc_normal rv[3];
+  unsigned max_failed, max_poses, failed, poses_nm;
+  double base_td, base_rd, td, rd;
+  /* HC (hill_climbing_scan_matcher.h:10-126) */
+  unsigned max_failed_rounds, failed_rounds;
+  double base_dt, base_dr, dt, dr;
+  unsigned action_id;
+  int base_set, round_failed;
+  double base_pose[3];
+  /* BF (brute_force_scan_matcher.h:10-64) */
+  double bf[9], bx, by, bt;
+  int bf_base_set;
+} orc_enumerator;
+
+void orc_enum_init_mc(orc_enumerator *e, unsigned seed, double sigma_t, double sigma_r,
+                      unsigned max_failed, unsigned max_poses);
+void orc_enum_init_hc(orc_enumerator *e, unsigned max_failed_rounds, double dt, double dr);
+void orc_enum_init_bf(orc_enumerator *e, const double *p9);
+void orc_enum_reset(orc_enumerator *e);
+int orc_enum_has_next(const orc_enumerator *e);
+void orc_enum_next(orc_enumerator *e, const double *best_pose, double *out_pose);
+void orc_enum_feedback(orc_enumerator *e, int ok);
+
+/* PoseEnumerationScanMatcher::process_scan on an already *filtered* scan.
+ * Returns number of scorer calls; trace arrays may be NULL; res = {prob, dx, dy, dth}. */
+int orc_process_scan(orc_enumerator *e, const orc_map *map, const orc_scan *scan,
+                     const orc_spe_cfg *cfg, const double *init_pose, double *res, int cap,
+                     double *tr_poses, double *tr_scores, int *tr_accepted, orc_gm_cache *cache);
+
+/* ---- particle filter ---- */
+void orc_normalize_weights(int n, double *w);
+int orc_resampling_is_required(int n, const double *w);
+void orc_resample(int n, const double *w, uint32_t seed, unsigned *out_idx);
+int orc_heaviest(int n, const double *w);
+
+/* ---- map update ---- */
+int orc_world_to_cells(double scale, double x0, double y0, double x1, double y1, int cap,
+                       int *out_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
