@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the scan-matching hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload hc|mc|sweep]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one
+GridScanMatcher::process_scan (the whole accept/reject chain of one scan match) on the
+BASELINE.json configuration the metric is quoted on.  Default workload (N=1): configs[1] --
+tinySLAM HC scan matcher, 1080-beam scan, 2000x2000 @ 0.05 m occupancy grid, 6-direction
+hill-climb with a 128-failed-rounds limit.  The map, the filtered scan and the matcher live in
+HBM / on the host before the timed region starts; candidate poses go up and scores come back
+inside it (they are part of the path).
+
+value = (scorer calls the reference would make = on_scan_test events) x (filtered beams) / s,
+summed over all ranks; speculative evaluations that the replay discards are NOT counted.
+For N > 1 single-hypothesis matchers do not shard ("replicas only"): every rank runs
+its own independent match, there is no data-path collective, scaling is "weak".
+
+One JSON line on rank 0 with the extra objects `roofline` (dominant kernel, algorithmic bytes /
+HIP-event kernel time against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU checker timed on
+this box's host cores on a bounded sample of the same workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_UNIT = {"occ": 24, "tbm": 56, "gmapping": 232}  # SURVEY 8d algorithmic bytes / (pose, beam)
+
+WORKLOADS = {
+    # name: (cell model, weighting, matcher kind, params, bytes key, description)
+    "hc": (0, "even", "HC", [128, 0.1, 0.1], "occ",
+           "cfg2: tinySLAM HC(dt 0.1, dr 0.1, failed-rounds 128), 1080 beams, 2000x2000 @0.05 m, occupancy cell"),
+    "mc": (1, "viny", "MC", [666666, 0.2, 0.1, 4096, 4096], "tbm",
+           "cfg3: vinySLAM MC(seed 666666, 4096 attempts), 1080 beams, TBM cell, viny weights, 2000x2000 @0.05 m"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="hc", choices=["hc", "mc", "sweep"])
+    ap.add_argument("--size", type=int, default=2000)
+    ap.add_argument("--scale", type=float, default=0.05)
+    ap.add_argument("--beams", type=int, default=1080)
+    ap.add_argument("--sweep-poses", type=int, default=4096)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--strict", action="store_true",
+                    help="bit-exact mode (sequential sum + host pose trig) instead of the default")
+    return ap.parse_args()
+
+
+def cpu_baseline(sc, kind, params, seconds):
+    """Single-thread CPU checker on the same scene: whole process_scan calls, bounded to ~seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    O = po.Oracle()
+    okind = {"HC": po.SM_HC, "MC": po.SM_MC}[kind]
+    cfg = po.make_cfg()
+    units, t_used, reps = 0, 0.0, 0
+    e = O.enumerator(okind, params)
+    t_end = time.perf_counter() + seconds
+    while True:
+        t0 = time.perf_counter()
+        r = O.process_scan(e, sc["map"], sc["scan"], cfg, sc["init_pose"], cap=8)
+        t_used += time.perf_counter() - t0
+        units += r["n_calls"] * sc["scan"].n
+        reps += 1
+        if time.perf_counter() > t_end or reps >= 2000:
+            break
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "port",
+            "sample": "%d x process_scan (%s %s) on the same scene, %.1f s, oracle/slam_oracle.c -O2, "
+                      "flat-array map; host CPU: %s, %d logical cores visible"
+                      % (reps, kind, params, t_used, model, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus,
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    from synth import make_scene
+    pkg = ge.load_package()
+
+    wl = "hc" if args.workload == "sweep" else args.workload
+    cell, weighting, kind, params, bkey, desc = WORKLOADS[wl]
+    sc = make_scene(cell_model=cell, size=args.size, scale=args.scale, n_beams=args.beams,
+                    seed=100 + rank, weighting=weighting)
+    scan = sc["scan"]
+    ctx = pkg.Context(local_rank)
+    ctx.upload_map(0, sc["map"])
+    cos_a, sin_a = pkg.beam_trig(scan.angle)
+    ctx.scan_upload(scan.range, cos_a, sin_a, scan.weight, scan.factor)
+    cfg = pkg.spe_cfg(sum_order=pkg.SUM_SEQUENTIAL, pose_trig=pkg.POSE_TRIG_HOST) if args.strict \
+        else pkg.spe_cfg()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    extra = {}
+    if args.workload == "sweep":
+        # kernel ceiling: flat batch of P device-resident poses, no host round trip
+        P = args.sweep_poses
+        rs = np.random.RandomState(7 + rank)
+        poses = torch.from_numpy(sc["init_pose"] + rs.randn(P, 3) * [0.2, 0.2, 0.1]).cuda()
+        scores = torch.empty(P, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+
+        def step():
+            ctx.score_poses_device(0, cfg, P, poses.data_ptr(), scores.data_ptr())
+            return P
+
+        desc = "sweep: %d device-resident poses x %d beams per launch, %s" % (P, scan.n, desc)
+    else:
+        m = pkg.Matcher(ctx, kind, cfg, params)
+
+        def step():
+            m.process_scan(0, sc["init_pose"])
+            return m.stats()["scorer_calls"]
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    calls = 0
+    for _ in range(args.steps):
+        calls += step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    k_ms, k_launches, k_units = ctx.profile_read(reset=True)
+    if args.workload != "sweep":
+        st = m.stats()
+        extra.update(scorer_calls_per_step=st["scorer_calls"], poses_evaluated_per_step=st["poses_evaluated"],
+                     launches_per_step=st["launches"])
+
+    units = float(calls) * scan.n
+    t_max, units_all = dt, units
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        uu = torch.tensor([units], dtype=torch.float64, device="cuda")
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        t_max, units_all = tt.item(), uu.item()
+
+    if rank == 0:
+        bpu = BYTES_PER_UNIT[bkey]
+        achieved = (k_units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "pose-candidates*beams/sec (1080-beam scan, 2000^2 grid)",
+            "value": units_all / t_max,
+            "unit": "pose-candidates*beams/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc, "beams_after_filter": scan.n,
+                       "mode": "strict (sequential sum, host trig)" if args.strict else
+                               "default (canonical tree sum, device sincos)",
+                       "parallelism": "replicas x%d (no collective)" % world if world > 1 else "1 gpu",
+                       **extra},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_score_point", "bytes_per_unit": bpu,
+                         "launches": k_launches, "units_launched": k_units,
+                         "avg_launch_us": 1e3 * k_ms / max(k_launches, 1)},
+        }
+        if world == 1 and not args.no_cpu and args.workload != "sweep":
+            out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds)
+        elif world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,208 @@
+/* include/slamhip.h -- C-ABI of the MI355X (gfx950) scan-matching / particle-likelihood engine.
+ *
+ * Drop-in boundary for ONE hot path of OSLL/slam-constructor: the GridScanMatcher (MC/HC/BF)
+ * accept loop and the ScanProbabilityEstimator scoring it calls for every candidate pose and
+ * every GMapping particle, plus the particle weight/normalise/resample step.
+ *
+ * The reference has no FFI: the path sits behind C++ virtual interfaces in headers.  Each entry
+ * point below names the reference interface (file:line, relative to the reference root) whose
+ * work it replaces; INTEGRATION.md shows the adapter classes (deriving from the reference's
+ * GridScanMatcher / ScanProbabilityEstimator) that bind them.
+ *
+ * Conventions: plain C, pointers + sizes, no C++/torch types.  Every function returns 0 on
+ * success or a negative slamhip_status; slamhip_last_error() gives the text.  One context =
+ * one GPU + one HIP stream + one caller thread (the reference is single-threaded:
+ * src/ros/single_hypoth_slam_node.cpp:63); contexts are independent (one per GPU when
+ * particles are sharded).  There is NO CPU fallback: without a usable GPU the calls fail.
+ *
+ * All arithmetic is IEEE double in the reference's operation order (built with
+ * -ffp-contract=off); see DESIGN.md for the exact-parity contract.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMHIP_VERSION 100
+
+typedef enum {
+  SLAMHIP_OK = 0,
+  SLAMHIP_ERR_INVALID = -1,   /* bad argument / unknown id */
+  SLAMHIP_ERR_HIP = -2,       /* HIP runtime error (text in slamhip_last_error) */
+  SLAMHIP_ERR_NO_DEVICE = -3, /* no usable GPU: the product path never falls back to the CPU */
+  SLAMHIP_ERR_STATE = -4,     /* call order (e.g. scoring before a scan/map was uploaded) */
+  SLAMHIP_ERR_UNSUPPORTED = -5
+} slamhip_status;
+
+/* Cell payload models mirrored in HBM:
+ *  OCC      1 x f64  prob_occ            GridCell / MeanProbabilityCell / AffineQualityMergeCell
+ *                                        (src/core/maps/grid_cell.h:33-35, naive_grid_cells.h:6-44)
+ *  TBM      4 x f64  (u, e, o, c)        TbmBaseCell belief (src/core/maps/tbm_grid_cells.h:21-35)
+ *  GMAPPING 3 x f64  (prob_occ, obst.x, obst.y)  GmappingBaseCell
+ *                                        (src/slams/gmapping/gmapping_grid_cell.h:9-43) */
+enum { SLAMHIP_CELL_OCC = 0, SLAMHIP_CELL_TBM = 1, SLAMHIP_CELL_GMAPPING = 2 };
+/* OccupancyObservationProbabilityEstimator kinds
+ * (src/core/scan_matchers/occupancy_observation_probability.h:12-99,
+ *  src/slams/gmapping/gmapping_occupancy_observation_pe.h:11-45) */
+enum { SLAMHIP_OOPE_OBSTACLE = 0, SLAMHIP_OOPE_MAX = 1, SLAMHIP_OOPE_MEAN = 2,
+       SLAMHIP_OOPE_OVERLAP = 3, SLAMHIP_OOPE_GMAPPING = 4 };
+/* ObservationImpactEstimator kinds (src/core/scan_matchers/observation_impact_estimators.h:14-28) */
+enum { SLAMHIP_OIE_DISCREPANCY = 0, SLAMHIP_OIE_OCCUPANCY = 1 };
+/* Per-pose summation order of sum_i p_i*w_i*factor_i (weighted_mean_point_probability_spe.h:124):
+ *  TREE256    canonical, launch-shape independent tree (default; ~1e-16 from the reference)
+ *  SEQUENTIAL the reference's beam-order sum, bit-exact (slower: second pass) */
+enum { SLAMHIP_SUM_TREE256 = 0, SLAMHIP_SUM_SEQUENTIAL = 1 };
+/* Where sin/cos of the pose heading come from (TrigonometryProvider::set_base_angle,
+ * src/core/trigonometry_utils.h:31-33,57-60): host libm (bit-exact with the reference) or the
+ * device's sincos (default for throughput; differs from glibc in the last ulp at most). */
+enum { SLAMHIP_POSE_TRIG_DEVICE = 0, SLAMHIP_POSE_TRIG_HOST = 1 };
+enum { SLAMHIP_TRIG_RAW = 0, SLAMHIP_TRIG_CACHED = 1 };
+
+typedef struct slamhip_ctx slamhip_ctx;
+typedef struct slamhip_matcher slamhip_matcher;
+
+/* ScanProbabilityEstimator configuration = what init_spe/init_oope/init_oie build
+ * (src/utils/init_scan_matching.h:27-113) + ScanProbabilityEstimator::SPEParams
+ * (src/core/scan_matchers/grid_scan_matcher.h:87-91). */
+typedef struct {
+  int oope;              /* SLAMHIP_OOPE_* */
+  int oie;               /* SLAMHIP_OIE_* */
+  double area[4];        /* sp_analysis_area: bot, top, left, right (all 0 = point) */
+  double gm_fullness_th; /* GmappingOccupancyObservationPE(fullness_th, window) */
+  int gm_window;
+  int sum_order;         /* SLAMHIP_SUM_* */
+  int pose_trig;         /* SLAMHIP_POSE_TRIG_* */
+} slamhip_spe_cfg;
+
+/* ---------------------------------------------------------------- context */
+const char *slamhip_last_error(void);
+int slamhip_device_count(int *count);
+int slamhip_ctx_create(int device, slamhip_ctx **out);
+int slamhip_ctx_destroy(slamhip_ctx *ctx);
+int slamhip_ctx_synchronize(slamhip_ctx *ctx);
+/* hipStream_t of the context, for callers that enqueue their own work around ours */
+void *slamhip_ctx_stream(slamhip_ctx *ctx);
+
+/* ---------------------------------------------------------------- map mirror
+ * Replaces GridMap::operator[] on the scoring path (src/core/maps/grid_map.h:62,
+ * plain_grid_map.h:27-42,69-73, lazy_tiled_grid_map.h:47-55,140-147): the adapter mirrors the
+ * cells into a dense pitched HBM window.  Coordinates are INTERNAL (external + origin,
+ * regular_squares_grid.h:141-143); reads outside the window return `unknown_payload`, exactly
+ * like Unbounded*GridMap::operator[] returns its prototype cell. */
+int slamhip_map_bind(slamhip_ctx *ctx, int map_id, int cell_model, int width, int height,
+                     int origin_x, int origin_y, double scale, const double *unknown_payload);
+/* payload: host, row-major [h][w][stride]; window at internal (x0, y0) */
+int slamhip_map_upload_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h,
+                              const double *payload);
+/* GridMap::update / reset (src/core/maps/grid_map.h:41-60) forwarded as a dirty-cell log:
+ * n cells, coords_xy internal (2 ints each), payloads n*stride doubles */
+int slamhip_map_apply_dirty(slamhip_ctx *ctx, int map_id, int n, const int *coords_xy,
+                            const double *payloads);
+/* Unbounded maps move their origin when they grow (plain_grid_map.h:133-173): re-bind keeps
+ * the old cells at their shifted place. */
+int slamhip_map_release(slamhip_ctx *ctx, int map_id);
+/* read back a window (tests / debugging) */
+int slamhip_map_download_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h,
+                                double *payload_out);
+
+/* ---------------------------------------------------------------- scan
+ * The FILTERED scan the scorer iterates (LaserScan2D after
+ * WeightedMeanPointProbabilitySPE::filter_scan, weighted_mean_point_probability_spe.h:75-95),
+ * flattened: per point range, cos/sin of its own angle as the scan's TrigonometryProvider
+ * tabulates them, weight (ScanPointWeighting::weight, :21-60) and factor (sensor_data.h:74-75). */
+int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const double *cos_a,
+                        const double *sin_a, const double *weight, const double *factor);
+/* host helpers building cos_a/sin_a: RawTrigonometryProvider (trigonometry_utils.h:17-35) ... */
+int slamhip_beam_trig_raw(int n, const double *angle, double *cos_out, double *sin_out);
+/* ... and CachedTrigonometryProvider::update + index lookup (trigonometry_utils.h:45-78) */
+int slamhip_beam_trig_cached(int n, const double *angle, double a_min, double a_max, double a_inc,
+                             double *cos_out, double *sin_out);
+/* WeightedMeanPointProbabilitySPE::filter_scan on the host (once per scan, :75-95,136-141).
+ * bounded: 1 for PlainGridMap/LazyTiledGridMap (has_cell tests the window), 0 for Unbounded*.
+ * cos_a/sin_a as above for the RAW scan; kept_idx receives the raw indices kept. */
+int slamhip_filter_scan(int n, const double *range, const double *angle, const int *is_occ,
+                        int trig_mode, double a_min, double a_delta, int table_n,
+                        const double *tab_sin, const double *tab_cos, const double pose[3],
+                        unsigned skip_rate, double max_range, int bounded, int width, int height,
+                        int origin_x, int origin_y, double scale, int *kept_idx, int *kept_n);
+/* ScanPointWeighting::weight for a filtered scan: kind 0 even, 1 viny, 2 ahr */
+int slamhip_scan_weights(int kind, int n, const double *range, const double *angle, double *out);
+
+/* ---------------------------------------------------------------- scoring (kernels K1/K2/K3)
+ * Replaces ScanProbabilityEstimator::estimate_scan_probability
+ * (src/core/scan_matchers/grid_scan_matcher.h:128-131; WMPP implementation
+ * weighted_mean_point_probability_spe.h:97-133) for a BATCH of poses: poses_xyt = n_poses x
+ * (x, y, theta) host doubles, scores_out n_poses host doubles (NaN when sum of weights is 0). */
+int slamhip_score_poses(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
+                        const double *poses_xyt, double *scores_out);
+/* Same with device-resident poses/scores, asynchronous on the context stream (sweep mode) */
+int slamhip_score_poses_device(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg,
+                               int n_poses, const double *d_poses_xyt, double *d_scores_out);
+/* GMapping OOPE run-cache state carried between calls (gmapping_occupancy_observation_pe.h:21-24,
+ * 36-37,43-44): {cell x, cell y} + cached probability (-1 = empty).  Used by score_poses when
+ * cfg->oope == SLAMHIP_OOPE_GMAPPING: poses are scored as ONE call sequence in the given order. */
+int slamhip_gm_cache_reset(slamhip_ctx *ctx);
+int slamhip_gm_cache_get(slamhip_ctx *ctx, int *cell_xy, double *prob);
+
+/* kernel timing of the scoring launches since the last reset (HIP events on the ctx stream) */
+int slamhip_profile_enable(slamhip_ctx *ctx, int on);
+int slamhip_profile_read(slamhip_ctx *ctx, double *kernel_ms_total, long long *launches,
+                         long long *units /* poses x beams launched */, int reset);
+
+/* ---------------------------------------------------------------- matchers
+ * Replace GridScanMatcher::process_scan (src/core/scan_matchers/grid_scan_matcher.h:153-156) of
+ *   MonteCarloScanMatcher   (monte_carlo_scan_matcher.h:84-100; enumerator :10-82)
+ *   HillClimbingScanMatcher (hill_climbing_scan_matcher.h:128-170; enumerators :10-126)
+ *   BruteForceScanMatcher   (brute_force_scan_matcher.h:66-80; enumerator :10-64)
+ * through PoseEnumerationScanMatcher::process_scan (pose_enumeration_scan_matcher.h:31-77).
+ * The accept/reject chain is evaluated in speculative batches on the GPU and replayed on the
+ * host in the reference's order, so observers see exactly the reference's event sequence. */
+typedef struct {
+  void *user;
+  /* GridScanMatcherObserver (grid_scan_matcher.h:16-32) */
+  void (*on_scan_test)(void *user, const double pose[3], double score);
+  void (*on_pose_update)(void *user, const double pose[3], double score);
+  void (*on_matching_end)(void *user, const double delta[3], double best_score);
+} slamhip_observer;
+
+int slamhip_matcher_create_mc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, unsigned seed,
+                              double translation_dispersion, double rotation_dispersion,
+                              unsigned failed_attempts_limit, unsigned attempts_limit,
+                              slamhip_matcher **out);
+int slamhip_matcher_create_hc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg,
+                              unsigned failed_rounds_limit, double translation_delta,
+                              double rotation_delta, slamhip_matcher **out);
+int slamhip_matcher_create_bf(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, const double range9[9],
+                              slamhip_matcher **out);
+int slamhip_matcher_destroy(slamhip_matcher *m);
+/* GridScanMatcher::reset_state (grid_scan_matcher.h:158) */
+int slamhip_matcher_reset_state(slamhip_matcher *m);
+int slamhip_matcher_set_observer(slamhip_matcher *m, const slamhip_observer *obs);
+/* max speculative poses per launch (0 = default) */
+int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
+/* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
+int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],
+                                 double out_delta[3], double *out_prob);
+/* counters of the last process_scan: scorer calls the reference would have made
+ * (= on_scan_test events), poses actually evaluated on the GPU, launches */
+int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long *poses_evaluated,
+                          long long *launches);
+
+/* ---------------------------------------------------------------- particle filter (K4/K5)
+ * ParticleFilter::normalize_weights / UniformResamling (src/core/particle_filter.h:34-66,108-121)
+ * in the reference's summation order (host; N <= a few hundred).  Sharded runs all-gather the raw
+ * weights first (RCCL) and call these on every rank so indices are bit-identical. */
+int slamhip_pf_normalize(int n, double *weights);
+int slamhip_pf_resampling_is_required(int n, const double *weights, int *required);
+int slamhip_pf_resample(int n, const double *weights, uint32_t seed, unsigned *out_idx);
+int slamhip_pf_heaviest(int n, const double *weights, int *index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

@@ -171,6 +171,43 @@ class ScanData:
         return np.cos(self.angle), np.sin(self.angle)
 
 
+def _map_struct(g):
+    """OrcMap from any object with cell_model/payload/width/height/origin/scale/unknown[/bounded]."""
+    m = OrcMap()
+    m.cell_model = int(g.cell_model)
+    m.width, m.height = int(g.width), int(g.height)
+    m.origin_x, m.origin_y = int(g.origin[0]), int(g.origin[1])
+    m.scale = float(g.scale)
+    assert g.payload.dtype == np.float64 and g.payload.flags["C_CONTIGUOUS"]
+    m.payload = _d(g.payload)
+    for k in range(4):
+        m.unknown[k] = float(g.unknown[k]) if k < len(g.unknown) else 0.0
+    m.bounded = int(bool(getattr(g, "bounded", False)))
+    return m
+
+
+def _scan_struct(sc):
+    """OrcScan from any object with range/angle/weight/factor (+ optional cached-trig fields)."""
+    s = OrcScan()
+    s.n = int(sc.range.size)
+    for name in ("range", "angle", "weight", "factor"):
+        a = getattr(sc, name)
+        assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], name
+    s.range, s.angle = _d(sc.range), _d(sc.angle)
+    s.weight, s.factor = _d(sc.weight), _d(sc.factor)
+    s.trig_mode = int(getattr(sc, "trig_mode", TRIG_RAW))
+    s.a_min, s.a_delta = float(getattr(sc, "a_min", 0.0)), float(getattr(sc, "a_delta", 1.0))
+    ts, tc = getattr(sc, "tab_sin", None), getattr(sc, "tab_cos", None)
+    if ts is None or tc is None:
+        ts = tc = _ZERO1
+    s.table_n = int(ts.size)
+    s.tab_sin, s.tab_cos = _d(ts), _d(tc)
+    return s
+
+
+_ZERO1 = np.zeros(1)
+
+
 def make_cfg(oope=OOPE_OBSTACLE, oie=OIE_DISCREPANCY, area=(0, 0, 0, 0), gm_th=0.1, gm_window=1,
              sum_order=SUM_SEQUENTIAL):
     c = OrcCfg()
@@ -212,9 +249,9 @@ class Oracle:
         rng, ang = f64(rng), f64(ang)
         occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
         trig = trig or ScanData(rng, ang)
-        ts = trig.c_struct()
+        ts = _scan_struct(trig)
         kept = np.zeros(rng.size, np.int32)
-        m = gmap.c_struct()
+        m = _map_struct(gmap)
         pose = f64(pose)
         n = self.lib.orc_filter_scan(C.byref(m), rng.size, _d(rng), _d(ang), _i(occ), _d(pose),
                                      skip_rate, max_range, C.byref(ts), _i(kept))
@@ -237,13 +274,13 @@ class Oracle:
     def score_poses(self, gmap, scan, cfg, poses, cache=None):
         poses = f64(poses).reshape(-1, 3)
         out = np.zeros(poses.shape[0])
-        m, s = gmap.c_struct(), scan.c_struct()
+        m, s = _map_struct(gmap), _scan_struct(scan)
         self.lib.orc_score_poses(C.byref(m), C.byref(s), C.byref(cfg), poses.shape[0], _d(poses),
                                  _d(out), C.byref(cache) if cache is not None else None)
         return out
 
     def oope_probability(self, gmap, cfg, ox, oy, area4, cache=None):
-        m = gmap.c_struct()
+        m = _map_struct(gmap)
         a = f64(area4)
         return self.lib.orc_oope_probability(C.byref(m), C.byref(cfg), ox, oy, _d(a),
                                              C.byref(cache) if cache is not None else None)
@@ -277,7 +314,7 @@ class Oracle:
         return np.array(out)
 
     def process_scan(self, enum, gmap, scan, cfg, init_pose, cap=1 << 16, cache=None):
-        m, s = gmap.c_struct(), scan.c_struct()
+        m, s = _map_struct(gmap), _scan_struct(scan)
         res = np.zeros(4)
         trp, trs, tra = np.zeros((cap, 3)), np.zeros(cap), np.zeros(cap, np.int32)
         ip = f64(init_pose)

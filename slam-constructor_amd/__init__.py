@@ -1,0 +1,378 @@
+"""slam-constructor_amd -- MI355X-native scan-matching / particle-likelihood engine.
+
+Thin ctypes binding over the C-ABI shared library (include/slamhip.h, built in-tree as
+slam-constructor_amd/libslamhip.so from csrc/).  The directory name carries a hyphen, so load it
+with ``load_package()`` from ``__graft_entry__`` (module name ``slam_constructor_amd``).
+
+There is NO CPU fallback in here: if the HIP library is missing or no GPU is usable, ``load()``
+/ ``Context()`` raise.  The CPU oracle under oracle/ is test infrastructure and is never imported
+from this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libslamhip.so")
+CSRC = os.path.join(PKG_DIR, "csrc")
+
+CELL_OCC, CELL_TBM, CELL_GMAPPING = 0, 1, 2
+OOPE_OBSTACLE, OOPE_MAX, OOPE_MEAN, OOPE_OVERLAP, OOPE_GMAPPING = range(5)
+OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
+SUM_TREE256, SUM_SEQUENTIAL = 0, 1
+POSE_TRIG_DEVICE, POSE_TRIG_HOST = 0, 1
+TRIG_RAW, TRIG_CACHED = 0, 1
+STRIDE = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}
+
+EXPORTS = """slamhip_last_error slamhip_device_count slamhip_ctx_create slamhip_ctx_destroy
+slamhip_ctx_synchronize slamhip_ctx_stream slamhip_map_bind slamhip_map_upload_window
+slamhip_map_apply_dirty slamhip_map_release slamhip_map_download_window slamhip_scan_upload
+slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_weights
+slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get
+slamhip_profile_enable slamhip_profile_read slamhip_matcher_create_mc slamhip_matcher_create_hc
+slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
+slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_process_scan
+slamhip_matcher_stats slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
+slamhip_pf_heaviest""".split()
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class SlamHipError(RuntimeError):
+    pass
+
+
+class SpeCfg(C.Structure):
+    _fields_ = [("oope", C.c_int), ("oie", C.c_int), ("area", C.c_double * 4),
+                ("gm_fullness_th", C.c_double), ("gm_window", C.c_int), ("sum_order", C.c_int),
+                ("pose_trig", C.c_int)]
+
+
+OBS_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_double)
+
+
+class Observer(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("on_scan_test", OBS_FN), ("on_pose_update", OBS_FN),
+                ("on_matching_end", OBS_FN)]
+
+
+def spe_cfg(oope=OOPE_OBSTACLE, oie=OIE_DISCREPANCY, area=(0, 0, 0, 0), gm_th=0.1, gm_window=1,
+            sum_order=SUM_TREE256, pose_trig=POSE_TRIG_DEVICE):
+    c = SpeCfg()
+    c.oope, c.oie = oope, oie
+    for k in range(4):
+        c.area[k] = float(area[k])
+    c.gm_fullness_th, c.gm_window = gm_th, gm_window
+    c.sum_order, c.pose_trig = sum_order, pose_trig
+    return c
+
+
+def build(verbose=False):
+    """Compile the HIP kernels + C-ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen libslamhip.so and declare the prototypes.  Raises if it is missing: the product
+    path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlamHipError("libslamhip.so is not built (run __graft_entry__.build()); "
+                           "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, d, i, u = C.c_void_p, C.c_double, C.c_int, C.c_uint
+    L.slamhip_last_error.restype = C.c_char_p
+    L.slamhip_ctx_create.argtypes = [i, C.POINTER(vp)]
+    L.slamhip_ctx_destroy.argtypes = [vp]
+    L.slamhip_ctx_synchronize.argtypes = [vp]
+    L.slamhip_ctx_stream.restype = vp
+    L.slamhip_ctx_stream.argtypes = [vp]
+    L.slamhip_map_bind.argtypes = [vp, i, i, i, i, i, i, d, _dp]
+    L.slamhip_map_upload_window.argtypes = [vp, i, i, i, i, i, _dp]
+    L.slamhip_map_download_window.argtypes = [vp, i, i, i, i, i, _dp]
+    L.slamhip_map_apply_dirty.argtypes = [vp, i, i, _ip, _dp]
+    L.slamhip_map_release.argtypes = [vp, i]
+    L.slamhip_scan_upload.argtypes = [vp, i, _dp, _dp, _dp, _dp, _dp]
+    L.slamhip_beam_trig_raw.argtypes = [i, _dp, _dp, _dp]
+    L.slamhip_beam_trig_cached.argtypes = [i, _dp, d, d, d, _dp, _dp]
+    L.slamhip_filter_scan.argtypes = [i, _dp, _dp, _ip, i, d, d, i, _dp, _dp, _dp, u, d, i, i, i,
+                                      i, i, d, _ip, _ip]
+    L.slamhip_scan_weights.argtypes = [i, i, _dp, _dp, _dp]
+    L.slamhip_score_poses.argtypes = [vp, i, C.POINTER(SpeCfg), i, _dp, _dp]
+    L.slamhip_score_poses_device.argtypes = [vp, i, C.POINTER(SpeCfg), i, vp, vp]
+    L.slamhip_gm_cache_reset.argtypes = [vp]
+    L.slamhip_gm_cache_get.argtypes = [vp, _ip, _dp]
+    L.slamhip_profile_enable.argtypes = [vp, i]
+    L.slamhip_profile_read.argtypes = [vp, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i]
+    L.slamhip_matcher_create_mc.argtypes = [vp, C.POINTER(SpeCfg), u, d, d, u, u, C.POINTER(vp)]
+    L.slamhip_matcher_create_hc.argtypes = [vp, C.POINTER(SpeCfg), u, d, d, C.POINTER(vp)]
+    L.slamhip_matcher_create_bf.argtypes = [vp, C.POINTER(SpeCfg), _dp, C.POINTER(vp)]
+    L.slamhip_matcher_destroy.argtypes = [vp]
+    L.slamhip_matcher_reset_state.argtypes = [vp]
+    L.slamhip_matcher_set_observer.argtypes = [vp, C.POINTER(Observer)]
+    L.slamhip_matcher_set_batch.argtypes = [vp, i]
+    L.slamhip_matcher_process_scan.argtypes = [vp, i, _dp, _dp, _dp]
+    L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
+    L.slamhip_pf_normalize.argtypes = [i, _dp]
+    L.slamhip_pf_resampling_is_required.argtypes = [i, _dp, _ip]
+    L.slamhip_pf_resample.argtypes = [i, _dp, C.c_uint32, C.POINTER(C.c_uint)]
+    L.slamhip_pf_heaviest.argtypes = [i, _dp, _ip]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SlamHipError("slamhip error %d: %s" % (rc, load().slamhip_last_error().decode()))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+# ---- host-side pieces of the path (no GPU needed) ------------------------------------------
+def beam_trig(angle, trig_mode=TRIG_RAW, a_min=0.0, a_max=0.0, a_inc=1.0):
+    """(cos a_i, sin a_i) as the scan's TrigonometryProvider tabulates them."""
+    L = load()
+    angle = _f64(angle)
+    c, s = np.zeros(angle.size), np.zeros(angle.size)
+    if trig_mode == TRIG_CACHED:
+        _check(L.slamhip_beam_trig_cached(angle.size, _d(angle), a_min, a_max, a_inc, _d(c), _d(s)))
+    else:
+        _check(L.slamhip_beam_trig_raw(angle.size, _d(angle), _d(c), _d(s)))
+    return c, s
+
+
+def filter_scan(rng, ang, is_occ, pose, geom, skip_rate=0, max_range=-1.0, trig_mode=TRIG_RAW,
+                a_min=0.0, a_delta=1.0, tab_sin=None, tab_cos=None):
+    """WeightedMeanPointProbabilitySPE::filter_scan; geom = dict(width, height, origin, scale,
+    bounded).  Returns the kept raw indices."""
+    L = load()
+    rng, ang, pose = _f64(rng), _f64(ang), _f64(pose)
+    occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+    ts = _f64(tab_sin) if tab_sin is not None else np.zeros(1)
+    tc = _f64(tab_cos) if tab_cos is not None else np.zeros(1)
+    kept = np.zeros(max(rng.size, 1), np.int32)
+    n = C.c_int(0)
+    _check(L.slamhip_filter_scan(rng.size, _d(rng), _d(ang), occ.ctypes.data_as(_ip), trig_mode,
+                                 a_min, a_delta, ts.size, _d(ts), _d(tc), _d(pose), skip_rate,
+                                 max_range, int(bool(geom.get("bounded", False))), geom["width"],
+                                 geom["height"], geom["origin"][0], geom["origin"][1],
+                                 geom["scale"], kept.ctypes.data_as(_ip), C.byref(n)))
+    return kept[:n.value].copy()
+
+
+def scan_weights(kind, rng, ang):
+    L = load()
+    rng, ang = _f64(rng), _f64(ang)
+    out = np.zeros(rng.size)
+    _check(L.slamhip_scan_weights({"even": 0, "viny": 1, "ahr": 2}[kind], rng.size, _d(rng),
+                                  _d(ang), _d(out)))
+    return out
+
+
+def pf_normalize(w):
+    w = _f64(w).copy()
+    _check(load().slamhip_pf_normalize(w.size, _d(w)))
+    return w
+
+
+def pf_resampling_is_required(w):
+    w = _f64(w)
+    r = C.c_int(0)
+    _check(load().slamhip_pf_resampling_is_required(w.size, _d(w), C.byref(r)))
+    return bool(r.value)
+
+
+def pf_resample(w, seed):
+    w = _f64(w)
+    out = np.zeros(w.size, np.uint32)
+    _check(load().slamhip_pf_resample(w.size, _d(w), seed, out.ctypes.data_as(C.POINTER(C.c_uint))))
+    return out
+
+
+def pf_heaviest(w):
+    w = _f64(w)
+    r = C.c_int(0)
+    _check(load().slamhip_pf_heaviest(w.size, _d(w), C.byref(r)))
+    return r.value
+
+
+# ---- GPU objects ---------------------------------------------------------------------------------
+class Context:
+    """One GPU + one HIP stream (slamhip_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        _check(self.L.slamhip_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.slamhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self.L.slamhip_ctx_synchronize(self.h))
+
+    def stream(self):
+        return self.L.slamhip_ctx_stream(self.h)
+
+    # map mirror
+    def map_bind(self, map_id, cell_model, width, height, origin, scale, unknown):
+        unk = np.zeros(4)
+        unk[:STRIDE[cell_model]] = np.asarray(unknown, dtype=np.float64).ravel()[:STRIDE[cell_model]]
+        _check(self.L.slamhip_map_bind(self.h, map_id, cell_model, width, height, origin[0],
+                                       origin[1], scale, _d(unk)))
+
+    def map_upload_window(self, map_id, x0, y0, payload):
+        p = _f64(payload)
+        h, w = p.shape[:2]
+        _check(self.L.slamhip_map_upload_window(self.h, map_id, x0, y0, w, h, _d(p)))
+
+    def map_download_window(self, map_id, x0, y0, w, h, stride):
+        out = np.zeros((h, w, stride))
+        _check(self.L.slamhip_map_download_window(self.h, map_id, x0, y0, w, h, _d(out)))
+        return out
+
+    def map_apply_dirty(self, map_id, coords_xy, payloads):
+        xy = np.ascontiguousarray(coords_xy, dtype=np.int32).reshape(-1, 2)
+        p = _f64(payloads)
+        _check(self.L.slamhip_map_apply_dirty(self.h, map_id, xy.shape[0],
+                                              xy.ctypes.data_as(_ip), _d(p)))
+
+    def map_release(self, map_id):
+        _check(self.L.slamhip_map_release(self.h, map_id))
+
+    def upload_map(self, map_id, m):
+        """m: any object with cell_model, payload[h,w,stride], origin, scale, unknown."""
+        self.map_bind(map_id, m.cell_model, m.width, m.height, m.origin, m.scale, m.unknown)
+        self.map_upload_window(map_id, 0, 0, m.payload)
+
+    # scan
+    def scan_upload(self, rng, cos_a, sin_a, weight, factor=None):
+        rng, cos_a, sin_a, weight = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(weight)
+        fac = _f64(factor) if factor is not None else np.ones(rng.size)
+        _check(self.L.slamhip_scan_upload(self.h, rng.size, _d(rng), _d(cos_a), _d(sin_a),
+                                          _d(weight), _d(fac)))
+
+    # scoring
+    def score_poses(self, map_id, cfg, poses):
+        poses = _f64(poses).reshape(-1, 3)
+        out = np.zeros(poses.shape[0])
+        _check(self.L.slamhip_score_poses(self.h, map_id, C.byref(cfg), poses.shape[0], _d(poses),
+                                          _d(out)))
+        return out
+
+    def score_poses_device(self, map_id, cfg, n, d_poses_ptr, d_scores_ptr):
+        _check(self.L.slamhip_score_poses_device(self.h, map_id, C.byref(cfg), n,
+                                                 C.c_void_p(d_poses_ptr), C.c_void_p(d_scores_ptr)))
+
+    def gm_cache_reset(self):
+        _check(self.L.slamhip_gm_cache_reset(self.h))
+
+    def gm_cache_get(self):
+        xy = np.zeros(2, np.int32)
+        p = C.c_double()
+        _check(self.L.slamhip_gm_cache_get(self.h, xy.ctypes.data_as(_ip), C.byref(p)))
+        return int(xy[0]), int(xy[1]), p.value
+
+    def profile_enable(self, on=True):
+        _check(self.L.slamhip_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        ms, la, un = C.c_double(), C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_profile_read(self.h, C.byref(ms), C.byref(la), C.byref(un), int(reset)))
+        return ms.value, la.value, un.value
+
+
+class Matcher:
+    """GridScanMatcher counterpart: MC / HC / BF over a Context (slamhip_matcher)."""
+
+    def __init__(self, ctx, kind, cfg, params):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        if kind == "MC":
+            _check(self.L.slamhip_matcher_create_mc(ctx.h, C.byref(cfg), int(params[0]), params[1],
+                                                    params[2], int(params[3]), int(params[4]),
+                                                    C.byref(h)))
+        elif kind == "HC":
+            _check(self.L.slamhip_matcher_create_hc(ctx.h, C.byref(cfg), int(params[0]), params[1],
+                                                    params[2], C.byref(h)))
+        elif kind == "BF":
+            p = _f64(params)
+            _check(self.L.slamhip_matcher_create_bf(ctx.h, C.byref(cfg), _d(p), C.byref(h)))
+        else:
+            raise ValueError(kind)
+        self.h = h
+        self._obs = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.slamhip_matcher_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def reset_state(self):
+        _check(self.L.slamhip_matcher_reset_state(self.h))
+
+    def set_batch(self, n):
+        _check(self.L.slamhip_matcher_set_batch(self.h, n))
+
+    def process_scan(self, map_id, init_pose, trace=False):
+        """Returns dict(prob, delta[, poses, scores, accepted, n_calls]) -- the trace is what a
+        GridScanMatcherObserver sees (on_scan_test / on_pose_update)."""
+        ip = _f64(init_pose)
+        delta, prob = np.zeros(3), C.c_double()
+        rec = None
+        if trace:
+            rec = dict(poses=[], scores=[], accepted=[])
+
+            def on_test(_u, p, s):
+                rec["poses"].append((p[0], p[1], p[2]))
+                rec["scores"].append(s)
+                rec["accepted"].append(0)
+
+            def on_update(_u, p, s):
+                rec["accepted"][-1] = 1
+
+            self._obs = Observer(None, OBS_FN(on_test), OBS_FN(on_update), OBS_FN(0))
+            _check(self.L.slamhip_matcher_set_observer(self.h, C.byref(self._obs)))
+        else:
+            _check(self.L.slamhip_matcher_set_observer(self.h, None))
+        _check(self.L.slamhip_matcher_process_scan(self.h, map_id, _d(ip), _d(delta), C.byref(prob)))
+        out = dict(prob=prob.value, delta=delta)
+        if rec is not None:
+            out.update(poses=np.array(rec["poses"]).reshape(-1, 3), scores=np.array(rec["scores"]),
+                       accepted=np.array(rec["accepted"], dtype=np.int32),
+                       n_calls=len(rec["scores"]))
+        return out
+
+    def stats(self):
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_matcher_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value)

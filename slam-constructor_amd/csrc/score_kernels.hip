@@ -1,0 +1,471 @@
+// score_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+// K1  k_score_point     poses x beams, 1-cell ("obstacle") OOPE over OCC / TBM payloads
+// K3  k_score_gmapping  poses x beams, 3x3 Gaussian-endpoint OOPE + run-cache resolution
+// K1s k_sum_sequential  optional second pass: the reference's beam-order sum, bit-exact
+// plus map-mirror maintenance kernels (fill / repack / scatter).
+//
+// What they restate (paths relative to the reference root):
+//   WeightedMeanPointProbabilitySPE::estimate_scan_probability
+//       src/core/scan_matchers/weighted_mean_point_probability_spe.h:97-133
+//   ScanPoint2D::move_origin + CachedTrigonometryProvider angle addition
+//       src/core/states/sensor_data.h:83-88, src/core/trigonometry_utils.h:45-55
+//   RegularSquaresGrid::world_to_cell      src/core/maps/regular_squares_grid.h:40-46
+//   ObstacleBasedOccupancyObservationPE    src/core/scan_matchers/occupancy_observation_probability.h:12-27
+//   DiscrepancyOIE / OccupancyOIE          src/core/scan_matchers/observation_impact_estimators.h:14-28
+//   GridCell::discrepancy                  src/core/maps/grid_cell.h:33-35
+//   TbmBaseCell::discrepancy + conjunctive src/core/maps/tbm_grid_cells.h:21-35,
+//                                          src/core/maps/transferable_belief_model.h:102-143
+//   GmappingOccupancyObservationPE         src/slams/gmapping/gmapping_occupancy_observation_pe.h:17-38
+//   GmappingBaseCell::discrepancy          src/slams/gmapping/gmapping_grid_cell.h:35-38
+//
+// Design (DESIGN.md has the long form):
+//  * gather + reduction, no MFMA.  All arithmetic is FP64 in the reference's operation order;
+//    this file is compiled with -ffp-contract=off so no FMA is formed (the reference's x86-64
+//    build has none), which makes per-beam terms bit-identical to the CPU path.
+//  * one workgroup = 256 threads = 4 wave64; thread t owns beams t, t+256, ... whose constants
+//    (range, cos a, sin a, weight, factor) are loaded ONCE per workgroup into VGPRs with coalesced
+//    512-byte-per-wave loads and reused for every pose the workgroup scores; pose constants
+//    (x, y, sin th, cos th) are staged in LDS (sincos evaluated once per pose, not per beam).
+//  * per-pose sum in a CANONICAL order that does not depend on the launch shape: 256 strided
+//    partials (thread t adds its beams in ascending order), a wave64 xor-butterfly (32..1) and
+//    (g0+g1)+(g2+g3) across the 4 waves through LDS.  Two launches that score the same pose
+//    return bit-identical values, so the matcher's strict `best < candidate` test behaves like
+//    the reference's on ties.
+//  * map window = pitched row-major HBM array; out-of-window reads return the prototype payload
+//    (UnboundedPlainGridMap::operator[], src/core/maps/plain_grid_map.h:69-73).
+
+#include <algorithm>
+
+#include "slamhip_internal.h"
+
+namespace slamhip {
+
+static constexpr int kBlock = 256;
+static constexpr int kMaxPosesPerBlock = 16;
+
+// ---- helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_xor_sum(double v) {
+  // fixed butterfly: every lane ends with the same bits (a+b == b+a in IEEE)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+
+// world_to_cell: int(floor(x / scale)) with a TRUE division (Q15: multiplying by 1/scale flips
+// cells at boundaries).
+__device__ __forceinline__ int to_cell(double v, double scale) { return (int)floor(v / scale); }
+
+template <int MODEL>
+__device__ __forceinline__ double point_probability(const MapView &m, int oie, int cx, int cy) {
+  const int ix = cx + m.origin_x, iy = cy + m.origin_y;
+  const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+  if (MODEL == SLAMHIP_CELL_OCC) {
+    double occ = m.unknown[0];
+    if (inb) occ = m.payload[(size_t)iy * m.pitch + ix];
+    if (oie == SLAMHIP_OIE_OCCUPANCY) return occ;
+    return 1.0 - fabs(occ - 1.0);
+  } else {
+    double U = m.unknown[0], E = m.unknown[1], O = m.unknown[2], Cc = m.unknown[3];
+    if (inb) {
+      const double4 *p = reinterpret_cast<const double4 *>(m.payload) + ((size_t)iy * m.pitch + ix);
+      const double4 v = *p;
+      U = v.x; E = v.y; O = v.z; Cc = v.w;
+    }
+    // that = aoo2tbm(obstacle AOO) = (u,e,o,c) = (0,0,1,0); conjunctive(that, cell) before
+    // normalisation = (0, 0, U+O, E+C); normalize() divides by the total mass.
+    const double d_occ = fabs(1.0 - O);
+    const double t2 = U + O, t3 = E + Cc;
+    const double tot = t2 + t3;
+    const double conflict = (tot == 0.0) ? 0.0 : t3 / tot;
+    const double unknown = U / 2.0;
+    const double known = 1 - unknown;
+    const double known_discrepancy = known * (conflict + d_occ) / 2.0;
+    return 1.0 - (unknown / 2 + known_discrepancy);
+  }
+}
+
+// ---- K1 ----------------------------------------------------------------------------------------
+// KB > 0: beams per thread known at compile time (n <= 256*KB), constants live in VGPRs.
+// KB == 0: generic (any n): constants re-read from L1/L2 in the pose loop.
+template <int MODEL, int KB, bool WRITE_TERMS>
+__global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
+  __shared__ double s_pose[kMaxPosesPerBlock][4];
+  __shared__ double s_part[kMaxPosesPerBlock][4];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int n = a.scan.n;
+  const int p0 = blockIdx.x * a.poses_per_block;
+  const int npb = min(a.poses_per_block, a.n_poses - p0);
+
+  if (t < npb) {
+    const int p = p0 + t;
+    const double th = a.poses[3 * p + 2];
+    double sn, cs;
+    if (a.pose_sc) {
+      sn = a.pose_sc[2 * p];
+      cs = a.pose_sc[2 * p + 1];
+    } else {
+      sincos(th, &sn, &cs);
+    }
+    s_pose[t][0] = a.poses[3 * p];
+    s_pose[t][1] = a.poses[3 * p + 1];
+    s_pose[t][2] = sn;
+    s_pose[t][3] = cs;
+  }
+
+  constexpr int KR = KB > 0 ? KB : 1;
+  double br[KR], bc[KR], bs[KR], bw[KR], bf[KR];
+  if (KB > 0) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int b = t + kBlock * k;
+      const bool ok = b < n;
+      br[k] = ok ? a.scan.range[b] : 0.0;
+      bc[k] = ok ? a.scan.cos_a[b] : 0.0;
+      bs[k] = ok ? a.scan.sin_a[b] : 0.0;
+      bw[k] = ok ? a.scan.weight[b] : 0.0;
+      bf[k] = ok ? a.scan.factor[b] : 0.0;
+    }
+  }
+  __syncthreads();
+
+  const double scale = a.map.scale;
+  for (int j = 0; j < npb; ++j) {
+    const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
+    double acc = 0.0;
+    if (KB > 0) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        const int b = t + kBlock * k;
+        if (b < n) {
+          const double c = cs * bc[k] - sn * bs[k];
+          const double s = sn * bc[k] + cs * bs[k];
+          const double wx = x + br[k] * c;
+          const double wy = y + br[k] * s;
+          const double pr = point_probability<MODEL>(a.map, a.oie, to_cell(wx, scale), to_cell(wy, scale));
+          const double term = pr * bw[k] * bf[k];
+          if (WRITE_TERMS) a.terms[(size_t)(p0 + j) * n + b] = term;
+          acc = acc + term;
+        }
+      }
+    } else {
+      for (int b = t; b < n; b += kBlock) {
+        const double ca = a.scan.cos_a[b], sa = a.scan.sin_a[b], r = a.scan.range[b];
+        const double c = cs * ca - sn * sa;
+        const double s = sn * ca + cs * sa;
+        const double wx = x + r * c;
+        const double wy = y + r * s;
+        const double pr = point_probability<MODEL>(a.map, a.oie, to_cell(wx, scale), to_cell(wy, scale));
+        const double term = pr * a.scan.weight[b] * a.scan.factor[b];
+        if (WRITE_TERMS) a.terms[(size_t)(p0 + j) * n + b] = term;
+        acc = acc + term;
+      }
+    }
+    acc = wave_xor_sum(acc);
+    if (lane == 0) s_part[j][wave] = acc;
+  }
+  __syncthreads();
+  if (t < npb) {
+    const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
+    a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+  }
+}
+
+// ---- K1s: the reference's sequential beam-order sum (bit-exact), one lane per pose -------------
+__global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int n_poses, int n,
+                                                      double tot_w, double *scores) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_poses) return;
+  const double *row = terms + (size_t)p * n;
+  double acc = 0.0;
+  for (int b = 0; b < n; ++b) acc = acc + row[b];
+  scores[p] = (tot_w == 0.0) ? __builtin_nan("") : acc / tot_w;
+}
+
+// ---- K3: GMapping OOPE -------------------------------------------------------------------------
+// value of one endpoint: max over the (2w+1)^2 window of cells with prob_occ >= th of
+// exp(-|cell.obst - endpoint|^2 / 0.05); the window order of the reference (dx outer, dy inner)
+// does not matter for a max of finite values.
+__device__ __forceinline__ double gm_fresh_value(const MapView &m, const GmParams &gp, int cx, int cy,
+                                                 double ox, double oy) {
+  double best = 0.0;
+  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
+  for (int dx = -gp.window; dx <= gp.window; ++dx) {
+    for (int dy = -gp.window; dy <= gp.window; ++dy) {
+      const int ix = cx + dx + m.origin_x, iy = cy + dy + m.origin_y;
+      const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+      double occ = m.unknown[0], obx = m.unknown[1], oby = m.unknown[2];
+      if (inb) {
+        const double4 v = cells[(size_t)iy * m.pitch + ix];
+        occ = v.x; obx = v.y; oby = v.z;
+      }
+      if (occ < gp.fullness_th) continue;
+      const double ddx = obx - ox, ddy = oby - oy;
+      const double similarity = exp(-(ddx * ddx + ddy * ddy) / 0.05);
+      const double v = 1.0 - (1.0 - similarity);
+      best = best < v ? v : best;
+    }
+  }
+  return best;
+}
+
+// Run-cache quirk (Q19): in beam order every maximal run of equal endpoint cells takes the value
+// computed for the run's first beam.  Thread t owns beams t + 256k, so for a fixed k one wave
+// holds 64 CONSECUTIVE beams (group g = 4k + wave): run heads come from a ballot + clz inside
+// the group and a short backward walk over per-group summaries in LDS across groups.
+template <int KB>
+__global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
+  extern __shared__ double s_dyn[];  // val[n] | grp_last_cell (int2 as double) [G] | grp_last_start [G]
+  __shared__ double s_pose[kMaxPosesPerBlock][4];
+  __shared__ double s_part[kMaxPosesPerBlock][4];
+  __shared__ int s_run0_len;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int n = a.scan.n;
+  const int G = (n + 63) >> 6;
+  double *s_val = s_dyn;
+  int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kBlock);
+  int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
+  const int p0 = blockIdx.x * a.poses_per_block;
+  const int npb = min(a.poses_per_block, a.n_poses - p0);
+
+  if (t < npb) {
+    const int p = p0 + t;
+    const double th = a.poses[3 * p + 2];
+    double sn, cs;
+    if (a.pose_sc) {
+      sn = a.pose_sc[2 * p];
+      cs = a.pose_sc[2 * p + 1];
+    } else {
+      sincos(th, &sn, &cs);
+    }
+    s_pose[t][0] = a.poses[3 * p];
+    s_pose[t][1] = a.poses[3 * p + 1];
+    s_pose[t][2] = sn;
+    s_pose[t][3] = cs;
+  }
+  double br[KB], bc[KB], bs[KB], bw[KB], bf[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kBlock * k;
+    const bool ok = b < n;
+    br[k] = ok ? a.scan.range[b] : 0.0;
+    bc[k] = ok ? a.scan.cos_a[b] : 0.0;
+    bs[k] = ok ? a.scan.sin_a[b] : 0.0;
+    bw[k] = ok ? a.scan.weight[b] : 0.0;
+    bf[k] = ok ? a.scan.factor[b] : 0.0;
+  }
+  __syncthreads();
+
+  const double scale = a.map.scale;
+  for (int j = 0; j < npb; ++j) {
+    const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
+    int ccx[KB], ccy[KB];
+    if (t == 0) s_run0_len = n;
+    // phase A: endpoint cell + fresh value per beam
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int b = t + kBlock * k;
+      ccx[k] = 0;
+      ccy[k] = 0;
+      if (b < n) {
+        const double c = cs * bc[k] - sn * bs[k];
+        const double s = sn * bc[k] + cs * bs[k];
+        const double wx = x + br[k] * c;
+        const double wy = y + br[k] * s;
+        ccx[k] = to_cell(wx, scale);
+        ccy[k] = to_cell(wy, scale);
+        s_val[b] = gm_fresh_value(a.map, a.gm, ccx[k], ccy[k], wx, wy);
+        if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
+      }
+    }
+    __syncthreads();
+    // phase B: run starts
+    unsigned long long mask[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int b = t + kBlock * k;
+      const int g = 4 * k + wave;
+      int pcx = __shfl_up(ccx[k], 1, 64), pcy = __shfl_up(ccy[k], 1, 64);
+      if (lane == 0 && g > 0 && b < n) {
+        const int2 pc = s_grp_cell[g - 1];
+        pcx = pc.x;
+        pcy = pc.y;
+      }
+      const bool start = (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
+      mask[k] = __ballot(start);
+      if (lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
+      if (start && b > 0) atomicMin(&s_run0_len, b);
+    }
+    __syncthreads();
+    // phase C: resolve run heads, accumulate in the canonical order
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int b = t + kBlock * k;
+      if (b < n) {
+        const int g = 4 * k + wave;
+        const unsigned long long upto = mask[k] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        int head;
+        if (upto) {
+          head = 64 * g + 63 - __clzll(upto);
+        } else {
+          int gg = g - 1;
+          head = s_grp_start[gg];
+          while (head < 0) head = s_grp_start[--gg];  // beam 0 is always a start
+        }
+        const double v = s_val[head];
+        const double term = v * bw[k] * bf[k];
+        acc = acc + term;
+        if (b == n - 1 && a.gm_info) {
+          GmPoseInfo &gi = a.gm_info[p0 + j];
+          gi.last_cx = ccx[k];
+          gi.last_cy = ccy[k];
+          gi.last_v = v;
+          gi.last_head = head;
+        }
+        if (b == 0 && a.gm_info) {
+          GmPoseInfo &gi = a.gm_info[p0 + j];
+          gi.first_cx = ccx[k];
+          gi.first_cy = ccy[k];
+          gi.v0 = v;
+        }
+      }
+    }
+    acc = wave_xor_sum(acc);
+    if (lane == 0) s_part[j][wave] = acc;
+    __syncthreads();
+    if (t == 0 && a.gm_info) a.gm_info[p0 + j].run0_len = s_run0_len;
+  }
+  __syncthreads();
+  if (t < npb) {
+    const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
+    a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+  }
+}
+
+// ---- launch ------------------------------------------------------------------------------------
+template <int MODEL, bool WT>
+static hipError_t launch_point_kb(const ScoreArgs &a, int kb, dim3 grid, hipStream_t st) {
+  switch (kb) {
+    case 1: hipLaunchKernelGGL((k_score_point<MODEL, 1, WT>), grid, dim3(kBlock), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_score_point<MODEL, 2, WT>), grid, dim3(kBlock), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_score_point<MODEL, 3, WT>), grid, dim3(kBlock), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_score_point<MODEL, 4, WT>), grid, dim3(kBlock), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_score_point<MODEL, 5, WT>), grid, dim3(kBlock), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_score_point<MODEL, 0, WT>), grid, dim3(kBlock), 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+
+static int pick_poses_per_block(int n_poses) {
+  // enough workgroups to fill 256 CUs several times over, while amortising the per-workgroup
+  // beam-constant loads (40 B/beam) over several poses once there are plenty of poses.
+  if (n_poses >= 8192) return 8;
+  if (n_poses >= 2048) return 4;
+  if (n_poses >= 1024) return 2;
+  return 1;
+}
+
+hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum_order,
+                        hipStream_t stream) {
+  ScoreArgs a = args;
+  if (a.n_poses <= 0) return hipSuccess;
+  if (a.poses_per_block <= 0) a.poses_per_block = pick_poses_per_block(a.n_poses);
+  if (a.poses_per_block > kMaxPosesPerBlock) a.poses_per_block = kMaxPosesPerBlock;
+  const dim3 grid((a.n_poses + a.poses_per_block - 1) / a.poses_per_block);
+  const int kb = (a.scan.n + kBlock - 1) / kBlock;
+  const bool wt = sum_order == SLAMHIP_SUM_SEQUENTIAL;
+  hipError_t e = hipSuccess;
+  if (oope == SLAMHIP_OOPE_GMAPPING) {
+    if (kb > 8) return hipErrorInvalidValue;
+    const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
+#define GM_CASE(K)                                                                              \
+  case K:                                                                                       \
+    hipLaunchKernelGGL((k_score_gmapping<K>), grid, dim3(kBlock), shm, stream, a);              \
+    break;
+    switch (kb < 1 ? 1 : kb) {
+      GM_CASE(1) GM_CASE(2) GM_CASE(3) GM_CASE(4) GM_CASE(5) GM_CASE(6) GM_CASE(7) GM_CASE(8)
+    }
+#undef GM_CASE
+    return hipGetLastError();
+  }
+  if (cell_model == SLAMHIP_CELL_OCC) {
+    e = wt ? launch_point_kb<SLAMHIP_CELL_OCC, true>(a, kb, grid, stream)
+           : launch_point_kb<SLAMHIP_CELL_OCC, false>(a, kb, grid, stream);
+  } else if (cell_model == SLAMHIP_CELL_TBM) {
+    e = wt ? launch_point_kb<SLAMHIP_CELL_TBM, true>(a, kb, grid, stream)
+           : launch_point_kb<SLAMHIP_CELL_TBM, false>(a, kb, grid, stream);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  if (wt) {
+    hipLaunchKernelGGL(k_sum_sequential, dim3((a.n_poses + 63) / 64), dim3(64), 0, stream, a.terms,
+                       a.n_poses, a.scan.n, a.scan.tot_w, a.scores);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// ---- map mirror maintenance --------------------------------------------------------------------
+__global__ void k_fill_cells(double *dst, size_t n_cells, int cell_dbl, double u0, double u1,
+                             double u2, double u3) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t c = i; c < n_cells; c += stride) {
+    if (cell_dbl == 1) {
+      dst[c] = u0;
+    } else {
+      reinterpret_cast<double4 *>(dst)[c] = make_double4(u0, u1, u2, u3);
+    }
+  }
+}
+
+__global__ void k_repack_window(double *dst, int dst_pitch, int cell_dbl, const double *src,
+                                int stride_host, int x0, int y0, int w, int h) {
+  const size_t total = (size_t)w * h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int yy = (int)(i / w), xx = (int)(i % w);
+    double *d = dst + ((size_t)(y0 + yy) * dst_pitch + (x0 + xx)) * cell_dbl;
+    const double *s = src + i * stride_host;
+    for (int k = 0; k < cell_dbl; ++k) d[k] = k < stride_host ? s[k] : 0.0;
+  }
+}
+
+__global__ void k_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
+                                const int *coords, const double *vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double *d = payload + ((size_t)coords[2 * i + 1] * pitch + coords[2 * i]) * cell_dbl;
+  for (int k = 0; k < cell_dbl; ++k) d[k] = k < stride_host ? vals[(size_t)i * stride_host + k] : 0.0;
+}
+
+hipError_t launch_fill_cells(double *dst, size_t n_cells, int cell_dbl, const double *u,
+                             hipStream_t stream) {
+  const int blocks = (int)std::min<size_t>((n_cells + 255) / 256, (size_t)4096);
+  hipLaunchKernelGGL(k_fill_cells, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, n_cells,
+                     cell_dbl, u[0], u[1], u[2], u[3]);
+  return hipGetLastError();
+}
+
+hipError_t launch_repack_window(double *dst, int dst_pitch, int cell_dbl, const double *src,
+                                int stride_host, int x0, int y0, int w, int h, hipStream_t stream) {
+  const size_t total = (size_t)w * h;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)4096);
+  hipLaunchKernelGGL(k_repack_window, dim3(blocks ? blocks : 1), dim3(256), 0, stream, dst, dst_pitch,
+                     cell_dbl, src, stride_host, x0, y0, w, h);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
+                                const int *d_coords, const double *d_vals, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scatter_cells, dim3((n + 255) / 256), dim3(256), 0, stream, payload, pitch,
+                     cell_dbl, stride_host, n, d_coords, d_vals);
+  return hipGetLastError();
+}
+
+}  // namespace slamhip

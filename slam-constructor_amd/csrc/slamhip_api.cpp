@@ -1,0 +1,690 @@
+// slamhip_api.cpp -- host side of the C-ABI (include/slamhip.h): context, map mirror, scan
+// upload, batched scoring, host-resident pieces of the path (filter_scan, weights, particle
+// filter bookkeeping).  Device work is in score_kernels.hip; matchers in matchers.cpp.
+//
+// There is deliberately no CPU implementation of the scorer here: if HIP is unavailable every
+// entry point that needs the GPU returns SLAMHIP_ERR_NO_DEVICE / SLAMHIP_ERR_HIP.
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <random>
+
+#include "slamhip_internal.h"
+
+namespace slamhip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorNoDevice ? SLAMHIP_ERR_NO_DEVICE : SLAMHIP_ERR_HIP;
+}
+
+static int invalid(const char *msg) {
+  g_last_error = msg;
+  return SLAMHIP_ERR_INVALID;
+}
+
+static DeviceMap *get_map(slamhip_ctx *ctx, int map_id) {
+  if (!ctx || map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound)
+    return nullptr;
+  return &ctx->maps[map_id];
+}
+
+int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
+  if (n <= ctx->pose_cap) return SLAMHIP_OK;
+  int cap = 256;
+  while (cap < n) cap *= 2;
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_poses) {
+    hipFree(ctx->d_poses);
+    hipFree(ctx->d_scores);
+    hipFree(ctx->d_pose_sc);
+    hipFree(ctx->d_gm_info);
+    hipHostFree(ctx->h_poses);
+    hipHostFree(ctx->h_scores);
+    hipHostFree(ctx->h_pose_sc);
+    hipHostFree(ctx->h_gm_info);
+    ctx->d_poses = nullptr;
+    ctx->pose_cap = 0;
+  }
+  SLAMHIP_CHECK(hipMalloc(&ctx->d_poses, sizeof(double) * 3 * cap));
+  SLAMHIP_CHECK(hipMalloc(&ctx->d_scores, sizeof(double) * cap));
+  SLAMHIP_CHECK(hipMalloc(&ctx->d_pose_sc, sizeof(double) * 2 * cap));
+  SLAMHIP_CHECK(hipMalloc(&ctx->d_gm_info, sizeof(GmPoseInfo) * cap));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_poses, sizeof(double) * 3 * cap, hipHostMallocDefault));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scores, sizeof(double) * cap, hipHostMallocDefault));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_sc, sizeof(double) * 2 * cap, hipHostMallocDefault));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_gm_info, sizeof(GmPoseInfo) * cap, hipHostMallocDefault));
+  ctx->pose_cap = cap;
+  return SLAMHIP_OK;
+}
+
+static int check_cfg(const DeviceMap &m, const slamhip_spe_cfg *cfg) {
+  if (!cfg) return invalid("null spe cfg");
+  if (cfg->oope == SLAMHIP_OOPE_GMAPPING) {
+    if (m.cell_model != SLAMHIP_CELL_GMAPPING)
+      return invalid("GMAPPING OOPE needs a SLAMHIP_CELL_GMAPPING map");
+    if (cfg->gm_window < 0 || cfg->gm_window > 4) return invalid("gm_window out of range");
+    return SLAMHIP_OK;
+  }
+  if (cfg->oope != SLAMHIP_OOPE_OBSTACLE) {
+    g_last_error = "window OOPEs (max/mean/overlap) are not built yet (SURVEY 8f N4)";
+    return SLAMHIP_ERR_UNSUPPORTED;
+  }
+  if (m.cell_model == SLAMHIP_CELL_GMAPPING)
+    return invalid("obstacle OOPE over a GMAPPING payload: upload prob_occ as an OCC map");
+  if (m.cell_model == SLAMHIP_CELL_TBM && cfg->oie != SLAMHIP_OIE_DISCREPANCY)
+    return invalid("OccupancyOIE over TBM cells: upload occupancy().prob_occ as an OCC map");
+  return SLAMHIP_OK;
+}
+
+static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg *cfg, int n_poses,
+                     const double *d_poses, const double *d_pose_sc, double *d_scores,
+                     ScoreArgs *a) {
+  if (ctx->scan_n <= 0) {
+    g_last_error = "no scan uploaded";
+    return SLAMHIP_ERR_STATE;
+  }
+  std::memset(a, 0, sizeof(*a));
+  a->map.payload = m.d_payload;
+  a->map.width = m.width;
+  a->map.height = m.height;
+  a->map.pitch = m.pitch;
+  a->map.origin_x = m.origin_x;
+  a->map.origin_y = m.origin_y;
+  a->map.scale = m.scale;
+  for (int k = 0; k < 4; ++k) a->map.unknown[k] = m.unknown[k];
+  const size_t c = ctx->scan_cap;
+  a->scan.range = ctx->d_scan;
+  a->scan.cos_a = ctx->d_scan + c;
+  a->scan.sin_a = ctx->d_scan + 2 * c;
+  a->scan.weight = ctx->d_scan + 3 * c;
+  a->scan.factor = ctx->d_scan + 4 * c;
+  a->scan.n = ctx->scan_n;
+  a->scan.tot_w = ctx->scan_tot_w;
+  a->poses = d_poses;
+  a->pose_sc = d_pose_sc;
+  a->scores = d_scores;
+  a->n_poses = n_poses;
+  a->poses_per_block = 0;
+  a->oie = cfg->oie;
+  for (int k = 0; k < 4; ++k) a->area[k] = cfg->area[k];
+  a->gm.fullness_th = cfg->gm_fullness_th;
+  a->gm.window = cfg->gm_window;
+  a->gm_info = nullptr;
+  a->terms = nullptr;
+  if (cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL && cfg->oope != SLAMHIP_OOPE_GMAPPING) {
+    const size_t need = (size_t)n_poses * ctx->scan_n;
+    if (need > ctx->terms_cap) {
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (ctx->d_terms) hipFree(ctx->d_terms);
+      ctx->d_terms = nullptr;
+      ctx->terms_cap = 0;
+      SLAMHIP_CHECK(hipMalloc(&ctx->d_terms, sizeof(double) * need));
+      ctx->terms_cap = need;
+    }
+    a->terms = ctx->d_terms;
+  }
+  return SLAMHIP_OK;
+}
+
+static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m,
+                        const slamhip_spe_cfg *cfg) {
+  const int order = cfg->oope == SLAMHIP_OOPE_GMAPPING ? SLAMHIP_SUM_TREE256 : cfg->sum_order;
+  if (ctx->profile) SLAMHIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+  SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, ctx->stream));
+  if (ctx->profile) {
+    SLAMHIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    SLAMHIP_CHECK(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    SLAMHIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->prof_ms += ms;
+    ctx->prof_launches += 1;
+    ctx->prof_units += (long long)a.n_poses * a.scan.n;
+  }
+  return SLAMHIP_OK;
+}
+
+// GMapping OOPE cache carried ACROSS poses (Q19): the kernel resolves runs inside each pose; a
+// pose whose first beam lands in the cell the previous call ended in re-uses that cached value
+// for its whole first run.  Applied in call order on the host.
+static void gm_carry_fixup(slamhip_ctx *ctx, int n_poses) {
+  const double tot_w = ctx->scan_tot_w;
+  for (int p = 0; p < n_poses; ++p) {
+    GmPoseInfo &gi = ctx->h_gm_info[p];
+    double last_v = gi.last_v;
+    if (ctx->gm_prob != -1.0 && gi.first_cx == ctx->gm_cx && gi.first_cy == ctx->gm_cy) {
+      const double c = ctx->gm_prob;
+      if (c != gi.v0) {
+        double delta = 0.0;
+        for (int b = 0; b < gi.run0_len; ++b)
+          delta += (c * ctx->h_weight[b]) * ctx->h_factor[b] - (gi.v0 * ctx->h_weight[b]) * ctx->h_factor[b];
+        if (tot_w != 0.0) ctx->h_scores[p] += delta / tot_w;
+      }
+      if (gi.last_head == 0) last_v = c;
+    }
+    ctx->gm_cx = gi.last_cx;
+    ctx->gm_cy = gi.last_cy;
+    ctx->gm_prob = last_v;
+  }
+}
+
+int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  int rc = check_cfg(*m, cfg);
+  if (rc) return rc;
+  if (n_poses <= 0) return SLAMHIP_OK;
+  const bool host_trig = cfg->pose_trig == SLAMHIP_POSE_TRIG_HOST;
+  if (host_trig) {
+    for (int p = 0; p < n_poses; ++p) {
+      // one sincos call per pose: the reference build (g++ -O3) fuses the sin/cos pair of
+      // set_base_angle (trigonometry_utils.h:57-60) into glibc's sincos, whose last bit can
+      // differ from separate sin()/cos() calls
+      ::sincos(ctx->h_poses[3 * p + 2], &ctx->h_pose_sc[2 * p], &ctx->h_pose_sc[2 * p + 1]);
+    }
+    SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_pose_sc, ctx->h_pose_sc, sizeof(double) * 2 * n_poses,
+                                 hipMemcpyHostToDevice, ctx->stream));
+  }
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_poses, ctx->h_poses, sizeof(double) * 3 * n_poses,
+                               hipMemcpyHostToDevice, ctx->stream));
+  ScoreArgs a;
+  rc = fill_args(ctx, *m, cfg, n_poses, ctx->d_poses, host_trig ? ctx->d_pose_sc : nullptr,
+                 ctx->d_scores, &a);
+  if (rc) return rc;
+  const bool gm = cfg->oope == SLAMHIP_OOPE_GMAPPING;
+  if (gm) a.gm_info = ctx->d_gm_info;
+  rc = launch_timed(ctx, a, *m, cfg);
+  if (rc) return rc;
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->h_scores, ctx->d_scores, sizeof(double) * n_poses,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  if (gm)
+    SLAMHIP_CHECK(hipMemcpyAsync(ctx->h_gm_info, ctx->d_gm_info, sizeof(GmPoseInfo) * n_poses,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return SLAMHIP_OK;
+}
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+extern "C" {
+
+const char *slamhip_last_error(void) { return g_last_error.c_str(); }
+
+int slamhip_device_count(int *count) {
+  if (!count) return invalid("null count");
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return hip_fail(e, "hipGetDeviceCount");
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_ctx_create(int device, slamhip_ctx **out) {
+  if (!out) return invalid("null out");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_last_error = "no HIP device available (the scorer has no CPU fallback)";
+    return SLAMHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) return invalid("device index out of range");
+  SLAMHIP_CHECK(hipSetDevice(device));
+  auto *ctx = new slamhip_ctx;
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return hip_fail(e, "hipStreamCreate");
+  }
+  hipEventCreate(&ctx->ev0);
+  hipEventCreate(&ctx->ev1);
+  *out = ctx;
+  return SLAMHIP_OK;
+}
+
+int slamhip_ctx_destroy(slamhip_ctx *ctx) {
+  if (!ctx) return SLAMHIP_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto &m : ctx->maps)
+    if (m.d_payload) hipFree(m.d_payload);
+  if (ctx->d_scan) hipFree(ctx->d_scan);
+  if (ctx->d_poses) {
+    hipFree(ctx->d_poses);
+    hipFree(ctx->d_scores);
+    hipFree(ctx->d_pose_sc);
+    hipFree(ctx->d_gm_info);
+    hipHostFree(ctx->h_poses);
+    hipHostFree(ctx->h_scores);
+    hipHostFree(ctx->h_pose_sc);
+    hipHostFree(ctx->h_gm_info);
+  }
+  if (ctx->d_terms) hipFree(ctx->d_terms);
+  if (ctx->d_dirty_xy) hipFree(ctx->d_dirty_xy);
+  if (ctx->d_dirty_val) hipFree(ctx->d_dirty_val);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SLAMHIP_OK;
+}
+
+int slamhip_ctx_synchronize(slamhip_ctx *ctx) {
+  if (!ctx) return invalid("null ctx");
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return SLAMHIP_OK;
+}
+
+void *slamhip_ctx_stream(slamhip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------- map mirror
+int slamhip_map_bind(slamhip_ctx *ctx, int map_id, int cell_model, int width, int height,
+                     int origin_x, int origin_y, double scale, const double *unknown_payload) {
+  if (!ctx) return invalid("null ctx");
+  if (map_id < 0 || map_id > 4095) return invalid("map_id out of range [0, 4095]");
+  if (cell_model < SLAMHIP_CELL_OCC || cell_model > SLAMHIP_CELL_GMAPPING)
+    return invalid("unknown cell model");
+  if (width <= 0 || height <= 0 || !(scale > 0) || !unknown_payload)
+    return invalid("bad map geometry");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  if ((int)ctx->maps.size() <= map_id) ctx->maps.resize(map_id + 1);
+  DeviceMap old = ctx->maps[map_id];
+  DeviceMap nm;
+  nm.bound = true;
+  nm.cell_model = cell_model;
+  nm.width = width;
+  nm.height = height;
+  nm.pitch = (width + 15) & ~15;
+  nm.origin_x = origin_x;
+  nm.origin_y = origin_y;
+  nm.scale = scale;
+  const int sh = cell_stride_host(cell_model), cd = cell_doubles(cell_model);
+  for (int k = 0; k < 4; ++k) nm.unknown[k] = k < sh ? unknown_payload[k] : 0.0;
+  nm.bytes = (size_t)nm.pitch * height * cd * sizeof(double);
+  SLAMHIP_CHECK(hipMalloc(&nm.d_payload, nm.bytes));
+  SLAMHIP_CHECK(launch_fill_cells(nm.d_payload, (size_t)nm.pitch * height, cd, nm.unknown, ctx->stream));
+  if (old.bound && old.cell_model == cell_model && old.d_payload) {
+    // growth of an unbounded map: the old window keeps its EXTERNAL coordinates, i.e. it moves by
+    // the origin shift in internal coordinates (plain_grid_map.h:133-173)
+    const int dx = origin_x - old.origin_x, dy = origin_y - old.origin_y;
+    const int sx0 = std::max(0, -dx), sy0 = std::max(0, -dy);
+    const int sx1 = std::min(old.width, width - dx), sy1 = std::min(old.height, height - dy);
+    if (sx1 > sx0 && sy1 > sy0) {
+      const size_t cb = cd * sizeof(double);
+      SLAMHIP_CHECK(hipMemcpy2DAsync(
+          nm.d_payload + ((size_t)(sy0 + dy) * nm.pitch + (sx0 + dx)) * cd, nm.pitch * cb,
+          old.d_payload + ((size_t)sy0 * old.pitch + sx0) * cd, old.pitch * cb,
+          (size_t)(sx1 - sx0) * cb, sy1 - sy0, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (old.d_payload) hipFree(old.d_payload);
+  ctx->maps[map_id] = nm;
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_release(slamhip_ctx *ctx, int map_id) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (m->d_payload) hipFree(m->d_payload);
+  *m = DeviceMap{};
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_upload_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h,
+                              const double *payload) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  if (!payload || w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > m->width || y0 + h > m->height)
+    return invalid("window outside the bound map");
+  const int sh = cell_stride_host(m->cell_model), cd = cell_doubles(m->cell_model);
+  const size_t bytes = (size_t)w * h * sh * sizeof(double);
+  double *d_tmp = nullptr;
+  SLAMHIP_CHECK(hipMalloc(&d_tmp, bytes));
+  hipError_t e = hipMemcpyAsync(d_tmp, payload, bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess)
+    e = launch_repack_window(m->d_payload, m->pitch, cd, d_tmp, sh, x0, y0, w, h, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_tmp);
+  if (e != hipSuccess) return hip_fail(e, "map_upload_window");
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_download_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h,
+                                double *out) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  if (!out || w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > m->width || y0 + h > m->height)
+    return invalid("window outside the bound map");
+  const int sh = cell_stride_host(m->cell_model), cd = cell_doubles(m->cell_model);
+  std::vector<double> tmp((size_t)w * h * cd);
+  const size_t cb = cd * sizeof(double);
+  SLAMHIP_CHECK(hipMemcpy2DAsync(tmp.data(), w * cb, m->d_payload + ((size_t)y0 * m->pitch + x0) * cd,
+                                 m->pitch * cb, w * cb, h, hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < (size_t)w * h; ++i)
+    for (int k = 0; k < sh; ++k) out[i * sh + k] = tmp[i * cd + k];
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_apply_dirty(slamhip_ctx *ctx, int map_id, int n, const int *coords_xy,
+                            const double *payloads) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  if (n < 0 || (n > 0 && (!coords_xy || !payloads))) return invalid("bad dirty log");
+  if (n == 0) return SLAMHIP_OK;
+  for (int i = 0; i < n; ++i)
+    if (coords_xy[2 * i] < 0 || coords_xy[2 * i] >= m->width || coords_xy[2 * i + 1] < 0 ||
+        coords_xy[2 * i + 1] >= m->height)
+      return invalid("dirty cell outside the bound window (re-bind the grown map first)");
+  const int sh = cell_stride_host(m->cell_model), cd = cell_doubles(m->cell_model);
+  if (n > ctx->dirty_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_dirty_xy) hipFree(ctx->d_dirty_xy);
+    if (ctx->d_dirty_val) hipFree(ctx->d_dirty_val);
+    ctx->d_dirty_xy = nullptr;
+    ctx->d_dirty_val = nullptr;
+    ctx->dirty_cap = 0;
+    int cap = 1024;
+    while (cap < n) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&ctx->d_dirty_xy, sizeof(int) * 2 * cap));
+    SLAMHIP_CHECK(hipMalloc(&ctx->d_dirty_val, sizeof(double) * 4 * cap));
+    ctx->dirty_cap = cap;
+  }
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_dirty_xy, coords_xy, sizeof(int) * 2 * n, hipMemcpyHostToDevice,
+                               ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_dirty_val, payloads, sizeof(double) * sh * n,
+                               hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(launch_scatter_cells(m->d_payload, m->pitch, cd, sh, n, ctx->d_dirty_xy,
+                                     ctx->d_dirty_val, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return SLAMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------- scan
+int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const double *cos_a,
+                        const double *sin_a, const double *weight, const double *factor) {
+  if (!ctx) return invalid("null ctx");
+  if (n <= 0 || !range || !cos_a || !sin_a || !weight) return invalid("bad scan");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  if (n > ctx->scan_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_scan) hipFree(ctx->d_scan);
+    ctx->d_scan = nullptr;
+    ctx->scan_cap = 0;
+    int cap = 2048;
+    while (cap < n) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&ctx->d_scan, sizeof(double) * 5 * cap));
+    ctx->scan_cap = cap;
+  }
+  ctx->h_weight.assign(weight, weight + n);
+  if (factor)
+    ctx->h_factor.assign(factor, factor + n);
+  else
+    ctx->h_factor.assign(n, 1.0);
+  // total_weight accumulates in beam order and does not depend on the pose
+  // (weighted_mean_point_probability_spe.h:125)
+  double tot_w = 0;
+  for (int i = 0; i < n; ++i) tot_w += weight[i];
+  ctx->scan_tot_w = tot_w;
+  ctx->scan_n = n;
+  const size_t c = ctx->scan_cap, bytes = sizeof(double) * n;
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan, range, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + c, cos_a, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + 2 * c, sin_a, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + 3 * c, weight, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + 4 * c, ctx->h_factor.data(), bytes, hipMemcpyHostToDevice,
+                               ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return SLAMHIP_OK;
+}
+
+int slamhip_beam_trig_raw(int n, const double *angle, double *cos_out, double *sin_out) {
+  if (n < 0 || !angle || !cos_out || !sin_out) return invalid("bad arguments");
+  for (int i = 0; i < n; ++i) ::sincos(angle[i], &sin_out[i], &cos_out[i]);
+  return SLAMHIP_OK;
+}
+
+int slamhip_beam_trig_cached(int n, const double *angle, double a_min, double a_max, double a_inc,
+                             double *cos_out, double *sin_out) {
+  if (n < 0 || !angle || !cos_out || !sin_out || !(a_inc > 0)) return invalid("bad arguments");
+  std::vector<double> ts, tc;
+  for (double a = a_min; a < a_max; a += a_inc) {  // accumulating loop, as the provider builds it
+    double sv, cv;
+    ::sincos(a, &sv, &cv);  // fused pair, as in the reference build (see score_staged)
+    ts.push_back(sv);
+    tc.push_back(cv);
+  }
+  for (int i = 0; i < n; ++i) {
+    const int idx = (int)std::round((angle[i] - a_min) / a_inc);
+    if (idx < 0 || idx >= (int)ts.size()) return invalid("scan angle outside the trig table");
+    cos_out[i] = tc[idx];
+    sin_out[i] = ts[idx];
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_filter_scan(int n, const double *range, const double *angle, const int *is_occ,
+                        int trig_mode, double a_min, double a_delta, int table_n,
+                        const double *tab_sin, const double *tab_cos, const double pose[3],
+                        unsigned skip_rate, double max_range, int bounded, int width, int height,
+                        int origin_x, int origin_y, double scale, int *kept_idx, int *kept_n) {
+  if (n < 0 || !range || !angle || !pose || !kept_idx || !kept_n) return invalid("bad arguments");
+  if (trig_mode == SLAMHIP_TRIG_CACHED && (!tab_sin || !tab_cos || table_n <= 0))
+    return invalid("cached trig mode needs the table");
+  constexpr double eps = std::numeric_limits<double>::epsilon();
+  double sb, cb;
+  ::sincos(pose[2], &sb, &cb);
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (skip_rate && (unsigned(i) % skip_rate)) continue;  // keeps every k-th point (Q8)
+    double c, s;
+    if (trig_mode == SLAMHIP_TRIG_CACHED) {
+      const int idx = (int)std::round((angle[i] - a_min) / a_delta);
+      if (idx < 0 || idx >= table_n) return invalid("scan angle outside the trig table");
+      c = cb * tab_cos[idx] - sb * tab_sin[idx];
+      s = sb * tab_cos[idx] + cb * tab_sin[idx];
+    } else {
+      ::sincos(pose[2] + angle[i], &s, &c);
+    }
+    const double wx = pose[0] + range[i] * c, wy = pose[1] + range[i] * s;
+    const int cx = (int)std::floor(wx / scale), cy = (int)std::floor(wy / scale);
+    bool has_cell = true;
+    if (bounded) {
+      const int ix = cx + origin_x, iy = cy + origin_y;
+      has_cell = 0 <= ix && ix < width && 0 <= iy && iy < height;
+    }
+    const bool too_far = (0.0 < max_range + eps) && (max_range < range[i] + eps);
+    if ((is_occ && !is_occ[i]) || !has_cell || too_far) continue;
+    kept_idx[kept++] = i;
+  }
+  *kept_n = kept;
+  return SLAMHIP_OK;
+}
+
+int slamhip_scan_weights(int kind, int n, const double *range, const double *angle, double *out) {
+  if (n < 0 || !range || !angle || !out) return invalid("bad arguments");
+  if (kind == 0) {
+    const double w = 1.0 / n;
+    for (int i = 0; i < n; ++i) out[i] = w;
+    return SLAMHIP_OK;
+  }
+  if (kind == 1) {
+    for (int i = 0; i < n; ++i) {
+      double sv, cv;
+      ::sincos(angle[i], &sv, &cv);
+      const double ac = std::abs(cv);
+      double w = std::abs(sv) + ac;
+      if (0.9 < ac) w = 3;
+      else if (0.8 < ac) w = 2;
+      out[i] = w * std::sqrt(range[i]);
+    }
+    return SLAMHIP_OK;
+  }
+  if (kind == 2) {
+    constexpr int NB = 20;
+    unsigned hist[NB] = {0};
+    std::vector<double> dirs(n > 0 ? n : 1, 0.0);
+    const double step = (180 * M_PI / 180) / NB;
+    for (int i = 1; i < n; ++i) {
+      double s1, c1, s0, c0;
+      ::sincos(angle[i], &s1, &c1);
+      ::sincos(angle[i - 1], &s0, &c0);
+      const double d_x = range[i] * c1 - range[i - 1] * c0;
+      const double d_y = range[i] * s1 - range[i - 1] * s0;
+      double a = 0;
+      if (d_y != 0) {
+        a = std::acos(d_x / std::sqrt(d_x * d_x + d_y * d_y));
+        if (d_y < 0 && d_x != 0) a = M_PI - a;
+      }
+      const size_t bin = (size_t)std::floor(a / step);
+      if (bin >= NB) return invalid("angle histogram bin out of range (reference asserts here)");
+      hist[bin]++;
+      dirs[i] = a;
+    }
+    for (int i = 0; i < n; ++i) {
+      const unsigned v = i == 0 ? (unsigned)n : hist[(size_t)std::floor(dirs[i] / step)];
+      out[i] = 1.0 / v;
+    }
+    return SLAMHIP_OK;
+  }
+  return invalid("unknown weighting kind");
+}
+
+// ---------------------------------------------------------------------------------- scoring
+int slamhip_score_poses(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
+                        const double *poses_xyt, double *scores_out) {
+  if (!ctx) return invalid("null ctx");
+  if (n_poses < 0 || (n_poses > 0 && (!poses_xyt || !scores_out))) return invalid("bad pose batch");
+  if (n_poses == 0) return SLAMHIP_OK;
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  int rc = ensure_pose_capacity(ctx, n_poses);
+  if (rc) return rc;
+  std::memcpy(ctx->h_poses, poses_xyt, sizeof(double) * 3 * n_poses);
+  rc = score_staged(ctx, map_id, cfg, n_poses);
+  if (rc) return rc;
+  if (cfg->oope == SLAMHIP_OOPE_GMAPPING) gm_carry_fixup(ctx, n_poses);
+  std::memcpy(scores_out, ctx->h_scores, sizeof(double) * n_poses);
+  return SLAMHIP_OK;
+}
+
+int slamhip_score_poses_device(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg,
+                               int n_poses, const double *d_poses_xyt, double *d_scores_out) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  int rc = check_cfg(*m, cfg);
+  if (rc) return rc;
+  if (n_poses <= 0) return SLAMHIP_OK;
+  if (!d_poses_xyt || !d_scores_out) return invalid("null device buffers");
+  if (cfg->pose_trig == SLAMHIP_POSE_TRIG_HOST)
+    return invalid("device-resident poses use device sincos (pose_trig = DEVICE)");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  ScoreArgs a;
+  rc = fill_args(ctx, *m, cfg, n_poses, d_poses_xyt, nullptr, d_scores_out, &a);
+  if (rc) return rc;
+  if (cfg->oope == SLAMHIP_OOPE_GMAPPING) {
+    rc = ensure_pose_capacity(ctx, n_poses);
+    if (rc) return rc;
+    a.gm_info = nullptr;  // in-pose runs only; cross-pose carry needs the host path
+  }
+  return launch_timed(ctx, a, *m, cfg);
+}
+
+int slamhip_gm_cache_reset(slamhip_ctx *ctx) {
+  if (!ctx) return invalid("null ctx");
+  ctx->gm_cx = ctx->gm_cy = 0;
+  ctx->gm_prob = -1.0;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gm_cache_get(slamhip_ctx *ctx, int *cell_xy, double *prob) {
+  if (!ctx || !cell_xy || !prob) return invalid("bad arguments");
+  cell_xy[0] = ctx->gm_cx;
+  cell_xy[1] = ctx->gm_cy;
+  *prob = ctx->gm_prob;
+  return SLAMHIP_OK;
+}
+
+int slamhip_profile_enable(slamhip_ctx *ctx, int on) {
+  if (!ctx) return invalid("null ctx");
+  ctx->profile = on != 0;
+  return SLAMHIP_OK;
+}
+
+int slamhip_profile_read(slamhip_ctx *ctx, double *kernel_ms_total, long long *launches,
+                         long long *units, int reset) {
+  if (!ctx) return invalid("null ctx");
+  if (kernel_ms_total) *kernel_ms_total = ctx->prof_ms;
+  if (launches) *launches = ctx->prof_launches;
+  if (units) *units = ctx->prof_units;
+  if (reset) {
+    ctx->prof_ms = 0;
+    ctx->prof_launches = 0;
+    ctx->prof_units = 0;
+  }
+  return SLAMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------- particle filter
+int slamhip_pf_normalize(int n, double *w) {
+  if (n < 0 || (n > 0 && !w)) return invalid("bad arguments");
+  double total = 0;
+  for (int i = 0; i < n; ++i) total += w[i];
+  for (int i = 0; i < n; ++i) w[i] = w[i] / total;
+  return SLAMHIP_OK;
+}
+
+int slamhip_pf_resampling_is_required(int n, const double *w, int *required) {
+  if (n < 0 || (n > 0 && !w) || !required) return invalid("bad arguments");
+  double sq_sum = 0;
+  for (int i = 0; i < n; ++i) sq_sum += w[i] * w[i];
+  const double effective = 1.0 / sq_sum;
+  *required = effective * 2 < (double)(size_t)n;
+  return SLAMHIP_OK;
+}
+
+int slamhip_pf_resample(int n, const double *w, uint32_t seed, unsigned *out_idx) {
+  if (n < 0 || (n > 0 && (!w || !out_idx))) return invalid("bad arguments");
+  // same libstdc++ machinery as the reference: mt19937 + uniform_real_distribution<>(0, 1),
+  // linear CDF scan, index stays 0 when the draw is not below the total (Q24)
+  std::mt19937 engine(seed);
+  std::uniform_real_distribution<> uniform(0, 1);
+  for (int i = 0; i < n; ++i) {
+    out_idx[i] = 0;
+    const double sample = uniform(engine);
+    double total_w = 0;
+    for (int j = 0; j < n; ++j) {
+      total_w += w[j];
+      if (sample < total_w) {
+        out_idx[i] = (unsigned)j;
+        break;
+      }
+    }
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_pf_heaviest(int n, const double *w, int *index) {
+  if (n <= 0 || !w || !index) return invalid("bad arguments");
+  int h = -1;
+  for (int i = 0; i < n; ++i) {
+    if (h >= 0 && w[i] < w[h]) continue;  // last of equal maxima wins
+    h = i;
+  }
+  *index = h;
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// Internal declarations shared by the HIP kernels (score_kernels.hip) and the host side
+// of the C-ABI (slamhip_api.cpp, matchers.cpp).  Not installed; the public ABI is include/slamhip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "slamhip.h"
+
+namespace slamhip {
+
+// ---- views passed to kernels by value -----------------------------------------------------
+// Map window in HBM: row-major [height][pitch] cells, each cell CELL_DOUBLES(model) doubles
+// (OCC 1, TBM 4, GMAPPING 4 = prob_occ, obst.x, obst.y, pad -> 32-byte aligned gathers).
+struct MapView {
+  const double *payload;
+  int width, height, pitch;
+  int origin_x, origin_y;
+  double scale;
+  double unknown[4];
+};
+
+// Filtered scan, structure-of-arrays (coalesced per-beam loads), tot_w = sequential sum of
+// weights in beam order computed once on the host (pose independent).
+struct ScanView {
+  const double *range, *cos_a, *sin_a, *weight, *factor;
+  int n;
+  double tot_w;
+};
+
+struct GmParams {
+  double fullness_th;
+  int window;
+};
+
+// per-pose side outputs of the GMapping kernel for the host carry-in fix-up
+struct GmPoseInfo {
+  int first_cx, first_cy;  // cell of beam 0
+  int last_cx, last_cy;    // cell of the last beam
+  double v0;               // fresh value of the first run
+  double last_v;           // resolved value of the last run (before any carry-in)
+  int run0_len;            // beams in the first run (they all hold v0)
+  int last_head;           // beam index heading the last run (0 => the last run is run 0)
+};
+
+struct ScoreArgs {
+  MapView map;
+  ScanView scan;
+  const double *poses;  // n_poses x 3 (x, y, theta)
+  const double *pose_sc;  // optional n_poses x 2 (sin, cos) computed by the host; null = device
+  double *scores;
+  int n_poses;
+  int poses_per_block;
+  int oie;
+  double area[4];
+  GmParams gm;
+  GmPoseInfo *gm_info;  // GMAPPING only
+  double *terms;        // SEQUENTIAL order only: n_poses x scan.n scratch
+};
+
+inline int cell_doubles(int model) { return model == SLAMHIP_CELL_OCC ? 1 : 4; }
+inline int cell_stride_host(int model) {
+  return model == SLAMHIP_CELL_TBM ? 4 : (model == SLAMHIP_CELL_GMAPPING ? 3 : 1);
+}
+
+// ---- launchers (score_kernels.hip) ---------------------------------------------------------
+hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_order,
+                        hipStream_t stream);
+hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
+                                const int *d_coords, const double *d_vals, hipStream_t stream);
+hipError_t launch_repack_window(double *dst, int dst_pitch, int cell_dbl, const double *src,
+                                int stride_host, int x0, int y0, int w, int h, hipStream_t stream);
+hipError_t launch_fill_cells(double *dst, size_t n_cells, int cell_dbl, const double *unknown4,
+                             hipStream_t stream);
+
+// ---- host state ------------------------------------------------------------------------------
+struct DeviceMap {
+  bool bound = false;
+  int cell_model = 0;
+  int width = 0, height = 0, pitch = 0;
+  int origin_x = 0, origin_y = 0;
+  double scale = 1.0;
+  double unknown[4] = {0, 0, 0, 0};
+  double *d_payload = nullptr;
+  size_t bytes = 0;
+};
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+}  // namespace slamhip
+
+#define SLAMHIP_CHECK(expr)                                        \
+  do {                                                             \
+    hipError_t _e = (expr);                                        \
+    if (_e != hipSuccess) return slamhip::hip_fail(_e, #expr);     \
+  } while (0)
+
+struct slamhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<slamhip::DeviceMap> maps;
+  // scan
+  double *d_scan = nullptr;  // 5 arrays of scan_cap doubles
+  int scan_cap = 0, scan_n = 0;
+  double scan_tot_w = 0.0;
+  std::vector<double> h_weight, h_factor;  // host copies for GMapping carry-in fix-ups
+  // pose / score staging
+  double *d_poses = nullptr, *d_scores = nullptr, *d_pose_sc = nullptr;
+  double *h_poses = nullptr, *h_scores = nullptr, *h_pose_sc = nullptr;  // pinned
+  slamhip::GmPoseInfo *d_gm_info = nullptr, *h_gm_info = nullptr;
+  int pose_cap = 0;
+  double *d_terms = nullptr;
+  size_t terms_cap = 0;
+  // dirty-cell staging
+  int *d_dirty_xy = nullptr;
+  double *d_dirty_val = nullptr;
+  int dirty_cap = 0;
+  // GMapping OOPE cache (gmapping_occupancy_observation_pe.h:43-44)
+  int gm_cx = 0, gm_cy = 0;
+  double gm_prob = -1.0;
+  // profiling
+  bool profile = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double prof_ms = 0.0;
+  long long prof_launches = 0, prof_units = 0;
+};
+
+namespace slamhip {
+int ensure_pose_capacity(slamhip_ctx *ctx, int n);
+// scores n poses whose (x,y,theta) sit in ctx->h_poses; results land in ctx->h_scores (synchronous)
+int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses);
+}  // namespace slamhip

@@ -1,0 +1,250 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI (libslamhip.so), against
+ (1) the golden vectors captured from the compiled reference (tests/golden/),
+ (2) the CPU oracle on the same seeded inputs at BASELINE.json sizes,
+ (3) size-independent properties (batch-shape independence, tie consistency, permutation).
+
+Parity bars: per-pose scores within 1e-5 relative is the contract of north_star; what
+these tests actually demand is much tighter --
+  * SLAMHIP_SUM_SEQUENTIAL + host pose trig : bit-exact scores, traces, deltas
+  * default (canonical tree sum, device sincos): scores within 1e-12 relative, identical accept
+    traces / candidate poses / deltas, and bit-exact equality with the oracle's tree-order mode
+  * GMapping OOPE (device exp): 1e-11 relative
+"""
+import numpy as np
+import pytest
+from helpers import SCENES, assert_trace_equal, filtered_scan, load, map_from, trace
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def po():
+    import pyoracle
+    return pyoracle
+
+
+def upload_scene(pkg, ctx, m, scan, map_id=0):
+    ctx.upload_map(map_id, m)
+    if getattr(scan, "trig_mode", 0) == 1:
+        idx = np.round((scan.angle - scan.a_min) / scan.a_delta).astype(np.int64)
+        cos_a, sin_a = scan.tab_cos[idx], scan.tab_sin[idx]
+    else:
+        cos_a, sin_a = pkg.beam_trig(scan.angle)
+    ctx.scan_upload(scan.range, cos_a, sin_a, scan.weight, scan.factor)
+
+
+STRICT = dict(sum_order=1, pose_trig=1)  # SLAMHIP_SUM_SEQUENTIAL, SLAMHIP_POSE_TRIG_HOST
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_scores_vs_reference_golden(pkg, ctx, po, oracle, scene):
+    g = load("scene_%s.npz" % scene)
+    m, scan = map_from(g), filtered_scan(g)
+    upload_scene(pkg, ctx, m, scan)
+    strict = ctx.score_poses(0, pkg.spe_cfg(**STRICT), g["poses"])
+    np.testing.assert_array_equal(strict, g["scores"])  # bit-exact with the reference
+    tree_host = ctx.score_poses(0, pkg.spe_cfg(pose_trig=1), g["poses"])
+    want_tree = oracle.score_poses(m, scan, po.make_cfg(sum_order=po.SUM_TREE256), g["poses"])
+    np.testing.assert_array_equal(tree_host, want_tree)  # canonical order restated on the CPU
+    dflt = ctx.score_poses(0, pkg.spe_cfg(), g["poses"])
+    np.testing.assert_allclose(dflt, g["scores"], rtol=1e-12, atol=0)
+    assert dflt[0] == dflt[1] and strict[0] == strict[1]  # identical poses -> identical bits
+
+
+@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("matcher", ["mc", "mc_long", "hc6", "hc128"])
+def test_matcher_traces_vs_reference_golden(pkg, ctx, scene, matcher):
+    g = load("scene_%s.npz" % scene)
+    m, scan = map_from(g), filtered_scan(g)
+    upload_scene(pkg, ctx, m, scan)
+    kind = {0: "MC", 1: "HC"}[int(g[matcher + "_kind"])]
+    ref = trace(g, matcher + "_")
+    mt = pkg.Matcher(ctx, kind, pkg.spe_cfg(**STRICT), g[matcher + "_params"])
+    t = mt.process_scan(0, g["init_pose"], trace=True)
+    assert_trace_equal(t, ref)  # bit-exact: poses, scores, accept flags, delta, prob
+    st = mt.stats()
+    assert st["scorer_calls"] == ref["n_calls"] and st["poses_evaluated"] >= ref["n_calls"]
+    if matcher == "mc":  # the engine is not reseeded between process_scan calls (Q7)
+        t2 = mt.process_scan(0, g["init_pose"], trace=True)
+        assert_trace_equal(t2, trace(g, "mc_second_"))
+    # default mode: same decisions, scores to 1e-12
+    md = pkg.Matcher(ctx, kind, pkg.spe_cfg(), g[matcher + "_params"])
+    td = md.process_scan(0, g["init_pose"], trace=True)
+    assert_trace_equal(td, ref, exact_scores=False, rtol=1e-12)
+    # speculation depth must not change the result
+    for batch in (1, 7, 64):
+        mb = pkg.Matcher(ctx, kind, pkg.spe_cfg(**STRICT), g[matcher + "_params"])
+        mb.set_batch(batch)
+        assert_trace_equal(mb.process_scan(0, g["init_pose"], trace=True), ref)
+
+
+def test_hc_smoke_cases_of_the_reference(pkg, ctx, po, oracle):
+    """hill_climbing_sm_smoke_test.cpp:72-105 through the HIP matcher."""
+    g = load("hc_smoke.npz")
+    m = map_from(g)
+    ctx.upload_map(0, m)
+    geom = dict(width=m.width, height=m.height, origin=m.origin, scale=m.scale, bounded=False)
+    for i, nz in enumerate(g["noises"]):
+        pose = g["rpose"] + nz
+        kept = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], pose, geom)
+        r, a = g["raw_range"][kept], g["raw_angle"][kept]
+        c, s = pkg.beam_trig(a)
+        ctx.scan_upload(r, c, s, pkg.scan_weights("even", r, a))
+        mt = pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), g["params"])
+        t = mt.process_scan(0, pose, trace=True)
+        assert_trace_equal(t, trace(g, "case%d_" % i))
+
+
+def test_gmapping_scores_and_trace_vs_reference_golden(pkg, ctx, po, oracle):
+    g = load("gmapping_scene.npz")
+    m, scan = map_from(g), filtered_scan(g)
+    upload_scene(pkg, ctx, m, scan)
+    cfg = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING, pose_trig=1)
+    ctx.gm_cache_reset()
+    s = ctx.score_poses(0, cfg, g["poses"])  # ONE call sequence: the cache carries across poses
+    np.testing.assert_allclose(s, g["scores"], rtol=1e-11, atol=1e-300)
+    # cache state after the sequence equals the oracle's
+    cache = po.Oracle.new_gm_cache()
+    oracle.score_poses(m, scan, po.make_cfg(oope=po.OOPE_GMAPPING), g["poses"], cache)
+    cx, cy, pr = ctx.gm_cache_get()
+    assert (cx, cy) == (cache.cx, cache.cy) and abs(pr - cache.prob) <= 1e-11 * max(pr, 1e-300)
+    # split into two calls: same answers (carry survives the call boundary)
+    ctx.gm_cache_reset()
+    s2 = np.concatenate([ctx.score_poses(0, cfg, g["poses"][:17]), ctx.score_poses(0, cfg, g["poses"][17:])])
+    np.testing.assert_array_equal(s, s2)
+    # HC(6, 0.1, 0.1) with sp_skip_rate = 3 (launch/gmapping_mit_run.launch)
+    r3, a3 = g["skip3_range"], g["skip3_angle"]
+    c, sn = pkg.beam_trig(a3)
+    ctx.scan_upload(r3, c, sn, pkg.scan_weights("even", r3, a3))
+    ctx.gm_cache_reset()
+    mt = pkg.Matcher(ctx, "HC", cfg, [6, 0.1, 0.1])
+    t = mt.process_scan(0, g["init_pose"], trace=True)
+    assert_trace_equal(t, trace(g, "hc6_skip3_"), exact_scores=False, rtol=1e-11)
+
+
+@pytest.mark.parametrize("cell,weighting,size,scale,beams", [
+    (0, "even", 2000, 0.05, 1080),   # BASELINE cfg 2 shape (tinySLAM, occupancy cell)
+    (1, "viny", 2000, 0.05, 1080),   # cfg 3 shape (vinySLAM, TBM cell)
+    (0, "even", 1000, 0.1, 720),     # cfg 1 shape
+])
+def test_full_size_against_oracle_and_properties(pkg, ctx, po, oracle, cell, weighting, size, scale, beams):
+    from synth import make_scene
+    sc = make_scene(cell_model=cell, size=size, scale=scale, n_beams=beams, seed=5, weighting=weighting)
+    m, scan = sc["map"], sc["scan"]
+    upload_scene(pkg, ctx, m, scan)
+    rs = np.random.RandomState(9)
+    P = 4096
+    poses = sc["init_pose"] + rs.randn(P, 3) * [0.2, 0.2, 0.1]
+    poses[0] = sc["init_pose"]
+    strict = ctx.score_poses(0, pkg.spe_cfg(**STRICT), poses)
+    tree = ctx.score_poses(0, pkg.spe_cfg(pose_trig=1), poses)
+    dflt = ctx.score_poses(0, pkg.spe_cfg(), poses)
+    sub = rs.choice(P, 256, replace=False)
+    want = oracle.score_poses(m, scan, po.make_cfg(), poses[sub])
+    np.testing.assert_array_equal(strict[sub], want)
+    want_tree = oracle.score_poses(m, scan, po.make_cfg(sum_order=po.SUM_TREE256), poses[sub])
+    np.testing.assert_array_equal(tree[sub], want_tree)
+    np.testing.assert_allclose(dflt, strict, rtol=1e-12, atol=0)
+    # batch-shape independence: any split of the batch gives the same bits (canonical order)
+    for cfgk in (dict(), STRICT):
+        full = ctx.score_poses(0, pkg.spe_cfg(**cfgk), poses)
+        parts = np.concatenate([ctx.score_poses(0, pkg.spe_cfg(**cfgk), poses[a:b])
+                                for a, b in [(0, 1), (1, 8), (8, 1000), (1000, 3333), (3333, P)]])
+        np.testing.assert_array_equal(full, parts)
+    # permutation of the batch permutes the scores
+    perm = rs.permutation(P)
+    np.testing.assert_array_equal(ctx.score_poses(0, pkg.spe_cfg(), poses[perm]), dflt[perm])
+    # matcher at full size: exact trace vs the oracle's accept loop
+    for kind, okind, prm in (("HC", po.SM_HC, [128, 0.1, 0.1]), ("MC", po.SM_MC, [666666, 0.2, 0.1, 64, 512])):
+        mt = pkg.Matcher(ctx, kind, pkg.spe_cfg(**STRICT), prm)
+        t = mt.process_scan(0, sc["init_pose"], trace=True)
+        e = oracle.enumerator(okind, prm)
+        r = oracle.process_scan(e, m, scan, po.make_cfg(), sc["init_pose"])
+        assert_trace_equal(t, r)
+        td = pkg.Matcher(ctx, kind, pkg.spe_cfg(), prm).process_scan(0, sc["init_pose"], trace=True)
+        assert_trace_equal(td, r, exact_scores=False, rtol=1e-12)
+
+
+def test_edge_cases(pkg, ctx, po, oracle):
+    from synth import MapData, Scan
+    rs = np.random.RandomState(2)
+    pay = rs.rand(37, 53)
+    m = MapData(0, pay[:, :, None], (20, 11), 0.25, [0.5])
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 1081, 1300, 2500):  # KB=1..5 and the generic path
+        r = rs.uniform(0.2, 6.0, n)
+        a = np.sort(rs.uniform(-2.3, 2.3, n))
+        w = rs.rand(n) + 0.1
+        f = np.where(rs.rand(n) < 0.2, rs.rand(n), 1.0)
+        scan = Scan(r, a, w, f)
+        upload_scene(pkg, ctx, m, scan)
+        poses = rs.randn(33, 3) * [2.0, 2.0, 1.5]
+        poses[0] = [1e3, -1e3, 0.1]  # everything outside the window -> unknown cell
+        got = ctx.score_poses(0, pkg.spe_cfg(**STRICT), poses)
+        want = oracle.score_poses(m, scan, po.make_cfg(), poses)
+        np.testing.assert_array_equal(got, want)
+        occ = ctx.score_poses(0, pkg.spe_cfg(oie=pkg.OIE_OCCUPANCY, **STRICT), poses)
+        want_occ = oracle.score_poses(m, scan, po.make_cfg(oie=po.OIE_OCCUPANCY), poses)
+        np.testing.assert_array_equal(occ, want_occ)
+    # zero total weight -> quiet NaN (weighted_mean_point_probability_spe.h:127-131)
+    scan = Scan([1.0, 2.0], [0.0, 0.1], [0.0, 0.0])
+    upload_scene(pkg, ctx, m, scan)
+    assert np.all(np.isnan(ctx.score_poses(0, pkg.spe_cfg(), np.zeros((3, 3)))))
+    # endpoints exactly on cell boundaries: floor(x / scale) with a true division
+    scan = Scan([0.25, 0.5, 0.75, 1.0], [0.0, 0.0, np.pi / 2, np.pi], np.full(4, 0.25))
+    upload_scene(pkg, ctx, m, scan)
+    poses = np.array([[0.0, 0.0, 0.0], [0.25, -0.25, 0.0], [-0.75, 0.5, 0.0]])
+    np.testing.assert_array_equal(ctx.score_poses(0, pkg.spe_cfg(**STRICT), poses),
+                                  oracle.score_poses(m, scan, po.make_cfg(), poses))
+
+
+def test_map_mirror_dirty_log_and_growth(pkg, ctx, po, oracle):
+    from synth import MapData, Scan
+    rs = np.random.RandomState(4)
+    pay = rs.rand(40, 48, 4)
+    pay /= pay.sum(axis=2, keepdims=True)
+    m = MapData(1, pay, (24, 20), 0.1, [1.0, 0.0, 0.0, 0.0])
+    scan = Scan(rs.uniform(0.3, 2.0, 300), np.sort(rs.uniform(-2, 2, 300)), np.full(300, 1 / 300))
+    upload_scene(pkg, ctx, m, scan, map_id=3)
+    poses = rs.randn(40, 3) * [0.5, 0.5, 1.0]
+    np.testing.assert_array_equal(ctx.score_poses(3, pkg.spe_cfg(**STRICT), poses),
+                                  oracle.score_poses(m, scan, po.make_cfg(), poses))
+    # GridMap::update forwarded as a dirty log
+    xy = np.stack([rs.randint(0, 48, 200), rs.randint(0, 40, 200)], axis=1)
+    _, first = np.unique(xy[:, 1] * 48 + xy[:, 0], return_index=True)
+    xy = xy[np.sort(first)]
+    vals = rs.rand(len(xy), 4)
+    m.payload[xy[:, 1], xy[:, 0]] = vals
+    ctx.map_apply_dirty(3, xy, vals)
+    np.testing.assert_array_equal(ctx.map_download_window(3, 0, 0, 48, 40, 4), m.payload)
+    np.testing.assert_array_equal(ctx.score_poses(3, pkg.spe_cfg(**STRICT), poses),
+                                  oracle.score_poses(m, scan, po.make_cfg(), poses))
+    # growth of an unbounded map: more cells on every side, origin shifts, old cells keep their
+    # external coordinates (plain_grid_map.h:133-173)
+    big = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (60, 70, 1))
+    big[7:47, 9:57] = m.payload
+    m2 = MapData(1, big, (24 + 9, 20 + 7), 0.1, [1.0, 0.0, 0.0, 0.0])
+    ctx.map_bind(3, 1, 70, 60, m2.origin, 0.1, m2.unknown)
+    np.testing.assert_array_equal(ctx.map_download_window(3, 0, 0, 70, 60, 4), big)
+    np.testing.assert_array_equal(ctx.score_poses(3, pkg.spe_cfg(**STRICT), poses),
+                                  oracle.score_poses(m2, scan, po.make_cfg(), poses))
+    ctx.map_release(3)
+    with pytest.raises(pkg.SlamHipError):
+        ctx.score_poses(3, pkg.spe_cfg(), poses)
+
+
+def test_smoke_entry(pkg):
+    ge.smoke()
