@@ -171,7 +171,8 @@ def main():
     if args.workload != "sweep":
         st = m.stats()
         extra.update(scorer_calls_per_step=st["scorer_calls"], poses_evaluated_per_step=st["poses_evaluated"],
-                     launches_per_step=st["launches"])
+                     launches_per_step=st["launches"],
+                     host_us_last_step={k: round(st[k], 1) for k in ("build_us", "stage_us", "score_us", "replay_us")})
 
     units = float(calls) * scan.n
     t_max, units_all = dt, units

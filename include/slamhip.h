@@ -193,6 +193,11 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
 int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long *poses_evaluated,
                           long long *launches);
 
+/* host-side time split of the last process_scan in microseconds: building the speculation DAG,
+ * staging poses, launch + wait for scores, replay of the accept chain */
+int slamhip_matcher_timing(slamhip_matcher *m, double *build_us, double *stage_us, double *score_us,
+                           double *replay_us);
+
 /* ---------------------------------------------------------------- particle filter (K4/K5)
  * ParticleFilter::normalize_weights / UniformResamling (src/core/particle_filter.h:34-66,108-121)
  * in the reference's summation order (host; N <= a few hundred).  Sharded runs all-gather the raw

@@ -34,7 +34,7 @@ slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm
 slamhip_profile_enable slamhip_profile_read slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_process_scan
-slamhip_matcher_stats slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
+slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest""".split()
 
 _dp = C.POINTER(C.c_double)
@@ -123,6 +123,7 @@ def load():
     L.slamhip_matcher_set_batch.argtypes = [vp, i]
     L.slamhip_matcher_process_scan.argtypes = [vp, i, _dp, _dp, _dp]
     L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
+    L.slamhip_matcher_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.slamhip_pf_normalize.argtypes = [i, _dp]
     L.slamhip_pf_resampling_is_required.argtypes = [i, _dp, _ip]
     L.slamhip_pf_resample.argtypes = [i, _dp, C.c_uint32, C.POINTER(C.c_uint)]
@@ -375,4 +376,8 @@ class Matcher:
     def stats(self):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
         _check(self.L.slamhip_matcher_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value)
+        t = [C.c_double() for _ in range(4)]
+        _check(self.L.slamhip_matcher_timing(self.h, *[C.byref(x) for x in t]))
+        return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value,
+                    build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
+                    replay_us=t[3].value)

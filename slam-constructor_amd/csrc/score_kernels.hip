@@ -52,6 +52,21 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
   return v;
 }
 
+// Completion signal for the low-latency host path: scoring kernels write their results straight
+// into pinned, coherent host memory with plain stores; this 1-thread kernel, queued right behind
+// them on the same stream, publishes the launch sequence number where the host spins.  The kernel
+// boundary orders it after every store of the preceding kernel (measured on MI355X: 12 us per
+// round trip against 15 us for hipStreamSynchronize and 65 us for per-workgroup system fences;
+// tools/latency_probe.hip, 0 stale words in 2000 x 768 hand-offs).
+__global__ void k_publish(unsigned *flag, unsigned seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream) {
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, flag, seq);
+  return hipGetLastError();
+}
+
 // world_to_cell: int(floor(x / scale)) with a TRUE division (Q15: multiplying by 1/scale flips
 // cells at boundaries).
 __device__ __forceinline__ int to_cell(double v, double scale) { return (int)floor(v / scale); }
@@ -176,11 +191,12 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
 __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int n_poses, int n,
                                                       double tot_w, double *scores) {
   const int p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= n_poses) return;
-  const double *row = terms + (size_t)p * n;
-  double acc = 0.0;
-  for (int b = 0; b < n; ++b) acc = acc + row[b];
-  scores[p] = (tot_w == 0.0) ? __builtin_nan("") : acc / tot_w;
+  if (p < n_poses) {
+    const double *row = terms + (size_t)p * n;
+    double acc = 0.0;
+    for (int b = 0; b < n; ++b) acc = acc + row[b];
+    scores[p] = (tot_w == 0.0) ? __builtin_nan("") : acc / tot_w;
+  }
 }
 
 // ---- K3: GMapping OOPE -------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -28,6 +29,10 @@ static int invalid(const char *msg) {
   g_last_error = msg;
   return SLAMHIP_ERR_INVALID;
 }
+
+// staging buffers are pinned, mapped into the GPU's address space and coherent: kernels read
+// poses from them and write scores into them directly (no copy engine round trip)
+static constexpr unsigned kPinned = hipHostMallocMapped | hipHostMallocCoherent;
 
 static DeviceMap *get_map(slamhip_ctx *ctx, int map_id) {
   if (!ctx || map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound)
@@ -56,10 +61,10 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
   SLAMHIP_CHECK(hipMalloc(&ctx->d_scores, sizeof(double) * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_pose_sc, sizeof(double) * 2 * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_gm_info, sizeof(GmPoseInfo) * cap));
-  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_poses, sizeof(double) * 3 * cap, hipHostMallocDefault));
-  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scores, sizeof(double) * cap, hipHostMallocDefault));
-  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_sc, sizeof(double) * 2 * cap, hipHostMallocDefault));
-  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_gm_info, sizeof(GmPoseInfo) * cap, hipHostMallocDefault));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_poses, sizeof(double) * 3 * cap, kPinned));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scores, sizeof(double) * cap, kPinned));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_sc, sizeof(double) * 2 * cap, kPinned));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_gm_info, sizeof(GmPoseInfo) * cap, kPinned));
   ctx->pose_cap = cap;
   return SLAMHIP_OK;
 }
@@ -136,17 +141,37 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
 static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m,
                         const slamhip_spe_cfg *cfg) {
   const int order = cfg->oope == SLAMHIP_OOPE_GMAPPING ? SLAMHIP_SUM_TREE256 : cfg->sum_order;
-  if (ctx->profile) SLAMHIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profile) {
+    // event pairs are only RECORDED here; elapsed times are read in slamhip_profile_read so the
+    // timed path never waits on an event
+    if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+      const size_t old_n = ctx->ev_pool.size();
+      ctx->ev_pool.resize(old_n + 512, nullptr);
+      for (size_t i = old_n; i < ctx->ev_pool.size(); ++i) SLAMHIP_CHECK(hipEventCreate(&ctx->ev_pool[i]));
+    }
+    e0 = ctx->ev_pool[ctx->ev_used++];
+    e1 = ctx->ev_pool[ctx->ev_used++];
+    SLAMHIP_CHECK(hipEventRecord(e0, ctx->stream));
+  }
   SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, ctx->stream));
   if (ctx->profile) {
-    SLAMHIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
-    SLAMHIP_CHECK(hipEventSynchronize(ctx->ev1));
-    float ms = 0.f;
-    SLAMHIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->prof_ms += ms;
+    SLAMHIP_CHECK(hipEventRecord(e1, ctx->stream));
     ctx->prof_launches += 1;
     ctx->prof_units += (long long)a.n_poses * a.scan.n;
   }
+  return SLAMHIP_OK;
+}
+
+static int profile_resolve(slamhip_ctx *ctx) {
+  if (ctx->ev_used == 0) return SLAMHIP_OK;
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+    float ms = 0.f;
+    SLAMHIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+    ctx->prof_ms += ms;
+  }
+  ctx->ev_used = 0;
   return SLAMHIP_OK;
 }
 
@@ -188,16 +213,56 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
       // differ from separate sin()/cos() calls
       ::sincos(ctx->h_poses[3 * p + 2], &ctx->h_pose_sc[2 * p], &ctx->h_pose_sc[2 * p + 1]);
     }
+  }
+  const bool gm = cfg->oope == SLAMHIP_OOPE_GMAPPING;
+  ScoreArgs a;
+  if (ctx->low_latency) {
+    // zero-copy: the kernel reads poses from / writes scores to the pinned staging buffers; a
+    // 1-thread kernel behind it publishes the launch number in pinned memory; the host spins.
+    const double *poses_src = ctx->h_poses, *sc_src = host_trig ? ctx->h_pose_sc : nullptr;
+    if (ctx->stage_poses) {
+      SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_poses, ctx->h_poses, sizeof(double) * 3 * n_poses,
+                                   hipMemcpyHostToDevice, ctx->stream));
+      poses_src = ctx->d_poses;
+      if (host_trig) {
+        SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_pose_sc, ctx->h_pose_sc, sizeof(double) * 2 * n_poses,
+                                     hipMemcpyHostToDevice, ctx->stream));
+        sc_src = ctx->d_pose_sc;
+      }
+    }
+    rc = fill_args(ctx, *m, cfg, n_poses, poses_src, sc_src, ctx->h_scores, &a);
+    if (rc) return rc;
+    if (gm) a.gm_info = ctx->h_gm_info;
+    unsigned seq = ++ctx->seq;
+    if (seq == 0) seq = ++ctx->seq;
+    rc = launch_timed(ctx, a, *m, cfg);
+    if (rc) return rc;
+    SLAMHIP_CHECK(launch_publish(ctx->h_done_flag, seq, ctx->stream));
+    volatile unsigned *flag = ctx->h_done_flag;
+    unsigned long long spins = 0;
+    while (*flag != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffffull) == 0) {
+        // ~every few ms: make sure the launch did not fail asynchronously
+        hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "scoring kernel");
+        if (q == hipSuccess && *flag != seq) {
+          set_error("scoring kernel finished without publishing its completion flag");
+          return SLAMHIP_ERR_HIP;
+        }
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return SLAMHIP_OK;
+  }
+  if (host_trig)
     SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_pose_sc, ctx->h_pose_sc, sizeof(double) * 2 * n_poses,
                                  hipMemcpyHostToDevice, ctx->stream));
-  }
   SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_poses, ctx->h_poses, sizeof(double) * 3 * n_poses,
                                hipMemcpyHostToDevice, ctx->stream));
-  ScoreArgs a;
   rc = fill_args(ctx, *m, cfg, n_poses, ctx->d_poses, host_trig ? ctx->d_pose_sc : nullptr,
                  ctx->d_scores, &a);
   if (rc) return rc;
-  const bool gm = cfg->oope == SLAMHIP_OOPE_GMAPPING;
   if (gm) a.gm_info = ctx->d_gm_info;
   rc = launch_timed(ctx, a, *m, cfg);
   if (rc) return rc;
@@ -247,8 +312,17 @@ int slamhip_ctx_create(int device, slamhip_ctx **out) {
     delete ctx;
     return hip_fail(e, "hipStreamCreate");
   }
-  hipEventCreate(&ctx->ev0);
-  hipEventCreate(&ctx->ev1);
+  e = hipHostMalloc(&ctx->h_done_flag, sizeof(unsigned), kPinned);
+  if (e != hipSuccess) {
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return hip_fail(e, "completion flag allocation");
+  }
+  *ctx->h_done_flag = 0;
+  const char *ll = getenv("SLAMHIP_LOW_LATENCY");
+  ctx->low_latency = !(ll && ll[0] == '0');
+  const char *sp = getenv("SLAMHIP_STAGE_POSES");
+  ctx->stage_poses = sp && sp[0] == '1';
   *out = ctx;
   return SLAMHIP_OK;
 }
@@ -273,8 +347,9 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   if (ctx->d_terms) hipFree(ctx->d_terms);
   if (ctx->d_dirty_xy) hipFree(ctx->d_dirty_xy);
   if (ctx->d_dirty_val) hipFree(ctx->d_dirty_val);
-  if (ctx->ev0) hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  for (hipEvent_t ev : ctx->ev_pool)
+    if (ev) hipEventDestroy(ev);
+  if (ctx->h_done_flag) hipHostFree(ctx->h_done_flag);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return SLAMHIP_OK;
@@ -626,6 +701,8 @@ int slamhip_profile_enable(slamhip_ctx *ctx, int on) {
 int slamhip_profile_read(slamhip_ctx *ctx, double *kernel_ms_total, long long *launches,
                          long long *units, int reset) {
   if (!ctx) return invalid("null ctx");
+  int rc = profile_resolve(ctx);
+  if (rc) return rc;
   if (kernel_ms_total) *kernel_ms_total = ctx->prof_ms;
   if (launches) *launches = ctx->prof_launches;
   if (units) *units = ctx->prof_units;

@@ -69,6 +69,7 @@ inline int cell_stride_host(int model) {
 // ---- launchers (score_kernels.hip) ---------------------------------------------------------
 hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_order,
                         hipStream_t stream);
+hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream);
 hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
                                 const int *d_coords, const double *d_vals, hipStream_t stream);
 hipError_t launch_repack_window(double *dst, int dst_pitch, int cell_dbl, const double *src,
@@ -122,9 +123,15 @@ struct slamhip_ctx {
   // GMapping OOPE cache (gmapping_occupancy_observation_pe.h:43-44)
   int gm_cx = 0, gm_cy = 0;
   double gm_prob = -1.0;
-  // profiling
+  // low-latency completion flag (k_publish in score_kernels.hip)
+  unsigned *h_done_flag = nullptr;  // pinned, coherent
+  unsigned seq = 0;
+  bool low_latency = true;
+  bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
+  // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read
   bool profile = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
   double prof_ms = 0.0;
   long long prof_launches = 0, prof_units = 0;
 };

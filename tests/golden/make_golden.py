@@ -212,6 +212,10 @@ def gen_hc_smoke(R):
     md = crop(m.to_data(), 30, (0, -13), (15, 0))
     out = dict(raw_range=r, raw_angle=a, raw_occ=o, rpose=rpose, noises=noises,
                params=np.array([10, step, ang]), **map_fields(md))
+    # the generator's angles accumulate from -hsector by inc (laser_scan_generator.h:47), exactly
+    # like CachedTrigonometryProvider::update builds its table, so the cached provider is usable
+    hs, inc = np.deg2rad(270 / 2.0), np.deg2rad(270 / 10)
+    out["a_min"], out["a_inc"], out["a_max_passed"] = np.array(-hs), np.array(inc), np.array(hs + 2 * inc)
     for i, nz in enumerate(noises):
         mt = R.matcher_create(SM_HC, spe, [10, step, ang])
         scan = R.scan_create(r, a, o)
@@ -221,6 +225,12 @@ def gen_hc_smoke(R):
         res_noise = nz + t["delta"]
         out["case%d_prob_true" % i] = R.score(spe, fs, m, rpose)
         out["case%d_prob_result" % i] = R.score(spe, fs, m, rpose + res_noise)
+        # same case with the reference's CachedTrigonometryProvider (use_trig_cache=true)
+        mt = R.matcher_create(SM_HC, spe, [10, step, ang])
+        cscan = R.scan_create(r, a, o, TRIG_CACHED, -hs, hs + 2 * inc, inc)
+        out.update(trace_fields(R.process_scan(mt, cscan, rpose + nz, m), "cached%d_" % i))
+        if i == 0:
+            out["tab_sin"], out["tab_cos"] = cscan.trig_table()
     save("hc_smoke.npz", **out)
 
 

@@ -93,20 +93,46 @@ def test_matcher_traces_vs_reference_golden(pkg, ctx, scene, matcher):
 
 
 def test_hc_smoke_cases_of_the_reference(pkg, ctx, po, oracle):
-    """hill_climbing_sm_smoke_test.cpp:72-105 through the HIP matcher."""
+    """hill_climbing_sm_smoke_test.cpp:72-105 through the HIP matcher.
+
+    The fixture geometry puts endpoints EXACTLY on cell boundaries (robot on a cell centre, steps
+    of half a cell), so with the raw trig provider the last ulp of libm's sin(theta + a) decides
+    the cell.  The device evaluates the angle-addition form (= the reference's own
+    CachedTrigonometryProvider arithmetic), hence:
+      * cached provider: the whole trace is bit-exact with the reference;
+      * raw provider: the reference test's OWN acceptance rule is applied (recovered pose exact
+        or equal scan probability, scan_matcher_test_utils.h:46-80)."""
     g = load("hc_smoke.npz")
     m = map_from(g)
     ctx.upload_map(0, m)
     geom = dict(width=m.width, height=m.height, origin=m.origin, scale=m.scale, bounded=False)
+    a_min, a_inc = float(g["a_min"]), float(g["a_inc"])
     for i, nz in enumerate(g["noises"]):
         pose = g["rpose"] + nz
+        # -- cached provider: exact trace
+        kept = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], pose, geom,
+                               trig_mode=pkg.TRIG_CACHED, a_min=a_min, a_delta=a_inc,
+                               tab_sin=g["tab_sin"], tab_cos=g["tab_cos"])
+        r, a = g["raw_range"][kept], g["raw_angle"][kept]
+        c, s = pkg.beam_trig(a, pkg.TRIG_CACHED, a_min, float(g["a_max_passed"]), a_inc)
+        ctx.scan_upload(r, c, s, pkg.scan_weights("even", r, a))
+        mt = pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), g["params"])
+        assert_trace_equal(mt.process_scan(0, pose, trace=True), trace(g, "cached%d_" % i))
+        # -- raw provider: the reference test's acceptance rule
         kept = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], pose, geom)
         r, a = g["raw_range"][kept], g["raw_angle"][kept]
         c, s = pkg.beam_trig(a)
         ctx.scan_upload(r, c, s, pkg.scan_weights("even", r, a))
         mt = pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), g["params"])
         t = mt.process_scan(0, pose, trace=True)
-        assert_trace_equal(t, trace(g, "case%d_" % i))
+        result_noise = nz + t["delta"]
+        k0 = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], g["rpose"], geom)
+        r0, a0 = g["raw_range"][k0], g["raw_angle"][k0]
+        c0, s0 = pkg.beam_trig(a0)
+        ctx.scan_upload(r0, c0, s0, pkg.scan_weights("even", r0, a0))
+        p_true, p_res = ctx.score_poses(0, pkg.spe_cfg(**STRICT), np.stack([g["rpose"], g["rpose"] + result_noise]))
+        same_prob = abs(p_true - p_res) <= 1e-7 * max(1.0, abs(p_true), abs(p_res))
+        assert same_prob or np.all(np.abs(result_noise) <= np.finfo(np.float64).eps), (i, result_noise)
 
 
 def test_gmapping_scores_and_trace_vs_reference_golden(pkg, ctx, po, oracle):

@@ -91,6 +91,15 @@ def test_hc_smoke_cases(oracle):
         assert p_res == float(g["case%d_prob_result" % i][0])
         same_prob = abs(p_true - p_res) <= 1e-7 * max(1.0, abs(p_true), abs(p_res))
         assert same_prob or np.all(np.abs(result_noise) <= np.finfo(np.float64).eps)
+        # same case through the cached trig provider
+        from pyoracle import TRIG_CACHED
+        tr = ScanData(g["raw_range"], g["raw_angle"], None, None, TRIG_CACHED, float(g["a_min"]),
+                      float(g["a_inc"]), g["tab_sin"], g["tab_cos"])
+        kc = oracle.filter_scan(m, g["raw_range"], g["raw_angle"], g["raw_occ"], rpose + nz, trig=tr)
+        sc = ScanData(g["raw_range"][kc], g["raw_angle"][kc], None, None, TRIG_CACHED,
+                      float(g["a_min"]), float(g["a_inc"]), g["tab_sin"], g["tab_cos"])
+        e = oracle.enumerator(SM_HC, g["params"])
+        assert_trace_equal(oracle.process_scan(e, m, sc, make_cfg(), rpose + nz), trace(g, "cached%d_" % i))
 
 
 def test_gmapping_scene(oracle):
