@@ -1,0 +1,172 @@
+// oracle/ref_adapter_harness.cpp -- TEST INFRASTRUCTURE ONLY (built where /root/reference exists).
+//
+// Drop-in proof: the reference-side adapter (slam-constructor_amd/host/slamhip_reference_adapter.h,
+// a GridScanMatcher subclass calling the C-ABI) is compiled against the UNMODIFIED reference
+// headers and run next to the reference's own MonteCarloScanMatcher / HillClimbingScanMatcher on the
+// same reference GridMap object and the same scan; both are observed through the reference's
+// GridScanMatcherObserver and the event streams are compared.
+// Output: oracle/_ref/libslamref_adapter.so (links slam-constructor_amd/libslamhip.so).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "core/maps/plain_grid_map.h"
+#include "core/maps/naive_grid_cells.h"
+#include "core/maps/tbm_grid_cells.h"
+#include "core/maps/grid_map_scan_adders.h"
+#include "core/maps/const_occupancy_estimator.h"
+#include "core/scan_matchers/observation_impact_estimators.h"
+#include "core/scan_matchers/occupancy_observation_probability.h"
+#include "core/scan_matchers/weighted_mean_point_probability_spe.h"
+#include "core/scan_matchers/monte_carlo_scan_matcher.h"
+#include "core/scan_matchers/hill_climbing_scan_matcher.h"
+#include "utils/data_generation/map_primitives.h"
+#include "utils/data_generation/grid_map_patcher.h"
+#include "utils/data_generation/laser_scan_generator.h"
+#include "../test/core/mock_grid_cell.h"
+
+#include "slamhip_reference_adapter.h"
+
+namespace {
+struct Trace : public GridScanMatcherObserver {
+  std::vector<double> poses, scores;
+  std::vector<int> accepted;
+  int starts = 0, ends = 0;
+  void on_matching_start(const RobotPose &, const TransformedLaserScan &, const GridMap &) override { ++starts; }
+  void on_scan_test(const RobotPose &p, const LaserScan2D &, double s) override {
+    poses.insert(poses.end(), {p.x, p.y, p.theta});
+    scores.push_back(s);
+    accepted.push_back(0);
+  }
+  void on_pose_update(const RobotPose &, const LaserScan2D &, double) override { accepted.back() = 1; }
+  void on_matching_end(const RobotPose &, const LaserScan2D &, double) override { ++ends; }
+};
+}  // namespace
+
+extern "C" {
+
+// cell: 0 MeanProbabilityCell (tinySLAM), 1 TbmOccConsistentCell (vinySLAM, viny weights)
+// kind: 0 MC {seed, sigma_t, sigma_r, failed, attempts}, 1 HC {failed_rounds, dt, dr}
+// strict: 1 = SLAMHIP_SUM_SEQUENTIAL + host pose trig (bit-exact bar), 0 = default mode
+// out = {ref_calls, hip_calls, accept_mismatches, pose_mismatches, max_rel_score_diff,
+//        ref_prob, hip_prob, |delta diff| max, filtered beams, observers start/end ok}
+int refad_compare(int cell, int kind, const double *p, int n_beams, int strict, int repeat,
+                  double *out) {
+  const double scale = 0.1;
+  auto gt = std::make_shared<UnboundedPlainGridMap>(std::make_shared<MockGridCell>(0.0),
+                                                    GridMapParams{200, 200, scale});
+  {
+    using C = CecumTextRasterMapPrimitive;
+    C c1{61, 45, C::BoundPosition::Top}, c2{25, 17, C::BoundPosition::Bot};
+    GridMapPatcher{}.apply_text_raster(*gt, c1.to_stream(), DiscretePoint2D{-30, 20}, 1, 1);
+    GridMapPatcher{}.apply_text_raster(*gt, c2.to_stream(), DiscretePoint2D{-12, -8}, 1, 1);
+  }
+  RobotPose pose{scale / 2, scale / 2 - 3 * scale, deg2rad(90)};
+  TransformedLaserScan ts;
+  ts.scan = LaserScanGenerator{to_lsp(15, 270, n_beams)}.laser_scan_2D(*gt, pose, 1);
+  ts.quality = 1.0;
+  std::shared_ptr<GridCell> proto;
+  Occupancy bo{0.95, 1.0}, be{0.01, 1.0};
+  int weighting = 0, model = SLAMHIP_CELL_OCC;
+  if (cell == 1) {
+    proto = std::make_shared<TbmOccConsistentCell>();
+    bo = {0.95, 0.04};
+    be = {0.01, 0.003};
+    weighting = 1;
+    model = SLAMHIP_CELL_TBM;
+  } else {
+    proto = std::make_shared<MeanProbabilityCell>();
+  }
+  auto map = std::make_shared<UnboundedPlainGridMap>(proto, GridMapParams{200, 200, scale});
+  auto adder = WallDistanceBlurringScanAdder::builder()
+                   .set_occupancy_estimator(std::make_shared<ConstOccupancyEstimator>(bo, be))
+                   .set_observation_quality_estimator(std::make_shared<IdleOMQE>())
+                   .set_blur_distance(0.3)
+                   .set_max_usable_range(std::numeric_limits<double>::infinity())
+                   .build();
+  for (int k = 0; k < 5; ++k) adder->append_scan(*map, pose, ts.scan, 0.9, 0);
+
+  auto make_spe = [&] {
+    std::shared_ptr<ScanPointWeighting> spw;
+    if (weighting == 1) spw = std::make_shared<VinySlamSPW>();
+    else spw = std::make_shared<EvenSPW>();
+    return std::make_shared<WeightedMeanPointProbabilitySPE>(
+        std::make_shared<ObstacleBasedOccupancyObservationPE>(std::make_shared<DiscrepancyOIE>()), spw);
+  };
+  std::shared_ptr<GridScanMatcher> ref;
+  if (kind == 0)
+    ref = std::make_shared<MonteCarloScanMatcher>(make_spe(), unsigned(p[0]), p[1], p[2], unsigned(p[3]), unsigned(p[4]));
+  else
+    ref = std::make_shared<HillClimbingScanMatcher>(make_spe(), unsigned(p[0]), p[1], p[2]);
+
+  slamhip_ctx *ctx = nullptr;
+  if (slamhip_ctx_create(0, &ctx) != SLAMHIP_OK) {
+    std::cerr << "refad: " << slamhip_last_error() << std::endl;
+    return -1;
+  }
+  slamhip_spe_cfg cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  cfg.oope = SLAMHIP_OOPE_OBSTACLE;
+  cfg.oie = SLAMHIP_OIE_DISCREPANCY;
+  cfg.sum_order = strict ? SLAMHIP_SUM_SEQUENTIAL : SLAMHIP_SUM_TREE256;
+  cfg.pose_trig = strict ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_DEVICE;
+  slamhip_matcher *hm = nullptr;
+  if (kind == 0)
+    slamhip_or_die(slamhip_matcher_create_mc(ctx, &cfg, unsigned(p[0]), p[1], p[2], unsigned(p[3]), unsigned(p[4]), &hm), "create_mc");
+  else
+    slamhip_or_die(slamhip_matcher_create_hc(ctx, &cfg, unsigned(p[0]), p[1], p[2], &hm), "create_hc");
+  auto mirror = std::make_shared<HipMapMirror>(ctx, 0, model, false);
+  std::shared_ptr<GridScanMatcher> hip =
+      std::make_shared<HipGridScanMatcher>(make_spe(), ctx, hm, mirror, weighting);
+
+  RobotPose noisy{pose.x + 0.07, pose.y - 0.04, pose.theta + 0.03};
+  double worst_rel = 0, worst_delta = 0;
+  long acc_mis = 0, pose_mis = 0, ref_calls = 0, hip_calls = 0;
+  double ref_prob = 0, hip_prob = 0;
+  int obs_ok = 1;
+  for (int rep = 0; rep < repeat; ++rep) {
+    auto t_ref = std::make_shared<Trace>(), t_hip = std::make_shared<Trace>();
+    ref->subscribe(t_ref);
+    hip->subscribe(t_hip);
+    RobotPoseDelta d_ref, d_hip;
+    ref_prob = ref->process_scan(ts, noisy, *map, d_ref);
+    hip_prob = hip->process_scan(ts, noisy, *map, d_hip);
+    ref->unsubscribe(t_ref);
+    hip->unsubscribe(t_hip);
+    ref_calls += t_ref->scores.size();
+    hip_calls += t_hip->scores.size();
+    const size_t n = std::min(t_ref->scores.size(), t_hip->scores.size());
+    for (size_t i = 0; i < n; ++i) {
+      if (t_ref->accepted[i] != t_hip->accepted[i]) ++acc_mis;
+      if (std::memcmp(&t_ref->poses[3 * i], &t_hip->poses[3 * i], 3 * sizeof(double)) != 0) ++pose_mis;
+      const double rel = std::fabs(t_ref->scores[i] - t_hip->scores[i]) / std::max(std::fabs(t_ref->scores[i]), 1e-300);
+      worst_rel = std::max(worst_rel, rel);
+    }
+    worst_delta = std::max({worst_delta, std::fabs(d_ref.x - d_hip.x), std::fabs(d_ref.y - d_hip.y),
+                            std::fabs(d_ref.theta - d_hip.theta)});
+    if (t_hip->starts != 1 || t_hip->ends != 1) obs_ok = 0;
+    // the SLAM would now move on: perturb the pose so that repeated matches differ
+    noisy = RobotPose{noisy.x + 0.013, noisy.y - 0.007, noisy.theta + 0.004};
+  }
+  out[0] = double(ref_calls);
+  out[1] = double(hip_calls);
+  out[2] = double(acc_mis);
+  out[3] = double(pose_mis);
+  out[4] = worst_rel;
+  out[5] = ref_prob;
+  out[6] = hip_prob;
+  out[7] = worst_delta;
+  out[8] = double(ts.scan.points().size());
+  out[9] = obs_ok;
+  hip.reset();
+  slamhip_ctx_destroy(ctx);
+  return 0;
+}
+
+}  // extern "C"

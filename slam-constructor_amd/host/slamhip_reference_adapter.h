@@ -1,0 +1,264 @@
+// slamhip_reference_adapter.h -- the reference-side binding of the C-ABI (include/slamhip.h).
+//
+// This header is what a slam-constructor maintainer adds to the reference tree (see
+// INTEGRATION.md).  It is compiled ONLY with the reference headers on the include path
+// (-I<reference>/src) and is not part of libslamhip.so.  It contains no reference code: it
+// derives from the reference's own plugin interfaces
+//   GridScanMatcher              src/core/scan_matchers/grid_scan_matcher.h:138-227
+//   ScanProbabilityEstimator     src/core/scan_matchers/grid_scan_matcher.h:85-136
+//   GridMap                      src/core/maps/grid_map.h:22-74
+// and forwards the hot path to the GPU library.
+//
+//   HipMirroredGridMap     GridMap decorator: forwards everything to the wrapped map and logs the
+//                          cells touched by update()/reset() (same idea as
+//                          RescalableCachingGridMap::update, rescalable_caching_grid_map.h:100-105)
+//   HipMapMirror           keeps the dense HBM window of one GridMap in sync (full upload on first
+//                          use / growth, dirty log afterwards)
+//   HipGridScanMatcher     GridScanMatcher whose process_scan runs the MC / HC / BF accept chain
+//                          through slamhip_matcher_process_scan; observers are fed from the replay
+//   HipScanProbabilityEstimator  ScanProbabilityEstimator whose estimate_scan_probability is one
+//                          slamhip_score_poses call (used by code that scores single poses)
+//
+// Error convention of the reference (no exceptions; bad config -> message + std::exit(-1),
+// init_scan_matching.h:39-43): a failing slamhip call prints slamhip_last_error() and exits.
+#ifndef SLAMHIP_REFERENCE_ADAPTER_H
+#define SLAMHIP_REFERENCE_ADAPTER_H
+
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <utility>
+#include <vector>
+
+#include "core/maps/grid_map.h"
+#include "core/maps/tbm_grid_cells.h"
+#include "core/scan_matchers/grid_scan_matcher.h"
+#include "core/scan_matchers/weighted_mean_point_probability_spe.h"
+#include "slamhip.h"
+
+#ifndef SLAMHIP_GMAPPING_OBSTACLE
+// GmappingBaseCell keeps its mean obstacle point private (gmapping_grid_cell.h:40-42); the
+// integration adds `const Point2D &obstacle() const { return obst; }` there and defines this
+// macro as `(cell).obstacle()`.
+#define SLAMHIP_GMAPPING_OBSTACLE(cell) Point2D{0, 0}
+#endif
+
+inline void slamhip_or_die(int rc, const char *what) {
+  if (rc == SLAMHIP_OK) return;
+  std::cerr << "[slamhip] " << what << ": " << slamhip_last_error() << std::endl;
+  std::exit(-1);
+}
+
+// ------------------------------------------------------------------------------------------------
+class HipMirroredGridMap : public GridMap {
+public:
+  HipMirroredGridMap(std::shared_ptr<GridMap> wrapped, std::shared_ptr<GridCell> prototype)
+      : GridMap{prototype, GridMapParams{wrapped->width(), wrapped->height(), wrapped->scale()}},
+        _map{wrapped} {}
+
+  void update(const Coord &c, const AreaOccupancyObservation &aoo) override {
+    _map->update(c, aoo);
+    _dirty.push_back(c);
+  }
+  void reset(const Coord &c, const GridCell &cell) override {
+    _map->reset(c, cell);
+    _dirty.push_back(c);
+  }
+  const GridCell &operator[](const Coord &c) const override { return (*_map)[c]; }
+  int width() const override { return _map->width(); }
+  int height() const override { return _map->height(); }
+  double scale() const override { return _map->scale(); }
+  DiscretePoint2D origin() const override { return _map->origin(); }
+  bool has_cell(const Coord &c) const override { return _map->has_cell(c); }
+
+  std::vector<Coord> take_dirty() { return std::exchange(_dirty, {}); }
+
+private:
+  std::shared_ptr<GridMap> _map;
+  std::vector<Coord> _dirty;
+};
+
+// ------------------------------------------------------------------------------------------------
+class HipMapMirror {
+public:
+  HipMapMirror(slamhip_ctx *ctx, int map_id, int cell_model, bool bounded)
+      : _ctx{ctx}, _id{map_id}, _model{cell_model}, _bounded{bounded} {}
+
+  int id() const { return _id; }
+  bool bounded() const { return _bounded; }
+
+  // full upload when the geometry changed (first use, growth), dirty log otherwise
+  void sync(const GridMap &map, HipMirroredGridMap *dirty_source = nullptr) {
+    const auto org = map.origin();
+    const bool same = _w == map.width() && _h == map.height() && _ox == org.x && _oy == org.y &&
+                      _scale == map.scale();
+    const int st = stride();
+    if (!same) {
+      double unk[4] = {0, 0, 0, 0};
+      payload(*map.new_cell(), unk);
+      slamhip_or_die(slamhip_map_bind(_ctx, _id, _model, map.width(), map.height(), org.x, org.y,
+                                      map.scale(), unk), "map_bind");
+      std::vector<double> buf(size_t(map.width()) * map.height() * st);
+      for (int y = 0; y < map.height(); ++y)
+        for (int x = 0; x < map.width(); ++x)
+          payload(map[{x - org.x, y - org.y}], &buf[(size_t(y) * map.width() + x) * st]);
+      slamhip_or_die(slamhip_map_upload_window(_ctx, _id, 0, 0, map.width(), map.height(), buf.data()),
+                     "map_upload_window");
+      _w = map.width(); _h = map.height(); _ox = org.x; _oy = org.y; _scale = map.scale();
+      if (dirty_source) dirty_source->take_dirty();
+      return;
+    }
+    if (!dirty_source) return;
+    auto dirty = dirty_source->take_dirty();
+    if (dirty.empty()) return;
+    std::vector<int> xy;
+    std::vector<double> vals;
+    for (const auto &c : dirty) {
+      xy.push_back(c.x + org.x);
+      xy.push_back(c.y + org.y);
+      double p[4];
+      payload(map[c], p);
+      vals.insert(vals.end(), p, p + st);
+    }
+    slamhip_or_die(slamhip_map_apply_dirty(_ctx, _id, int(dirty.size()), xy.data(), vals.data()),
+                   "map_apply_dirty");
+  }
+
+private:
+  int stride() const { return _model == SLAMHIP_CELL_TBM ? 4 : (_model == SLAMHIP_CELL_GMAPPING ? 3 : 1); }
+  void payload(const GridCell &c, double *out) const {
+    if (_model == SLAMHIP_CELL_TBM) {
+      const auto &b = static_cast<const TbmBaseCell &>(c).belief();
+      out[0] = b.unknown(); out[1] = b.empty(); out[2] = b.occupied(); out[3] = b.conflict();
+    } else if (_model == SLAMHIP_CELL_GMAPPING) {
+      const Point2D o = SLAMHIP_GMAPPING_OBSTACLE(c);
+      out[0] = c.occupancy().prob_occ; out[1] = o.x; out[2] = o.y;
+    } else {
+      out[0] = c.occupancy().prob_occ;
+    }
+  }
+  slamhip_ctx *_ctx;
+  int _id, _model;
+  bool _bounded;
+  int _w = -1, _h = -1, _ox = 0, _oy = 0;
+  double _scale = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Uploads the filtered scan the way the scorer iterates it.  `weighting`: 0 even, 1 viny, 2 ahr
+// (init_swp, src/utils/init_scan_matching.h:74-92).  Only RawTrigonometryProvider scans carry no
+// table; for CachedTrigonometryProvider pass its update() arguments.
+struct HipScanTrig {
+  int mode = SLAMHIP_TRIG_RAW;
+  double a_min = 0, a_max = 0, a_inc = 1;
+};
+
+inline void hip_upload_filtered_scan(slamhip_ctx *ctx, const LaserScan2D &scan, int weighting,
+                                     const HipScanTrig &trig) {
+  const auto &pts = scan.points();
+  const int n = int(pts.size());
+  std::vector<double> r(n), a(n), f(n), w(n), c(n), s(n);
+  for (int i = 0; i < n; ++i) {
+    r[i] = pts[i].range();
+    a[i] = pts[i].angle();
+    f[i] = pts[i].factor();
+  }
+  slamhip_or_die(slamhip_scan_weights(weighting, n, r.data(), a.data(), w.data()), "scan_weights");
+  if (trig.mode == SLAMHIP_TRIG_CACHED)
+    slamhip_or_die(slamhip_beam_trig_cached(n, a.data(), trig.a_min, trig.a_max, trig.a_inc, c.data(),
+                                            s.data()), "beam_trig_cached");
+  else
+    slamhip_or_die(slamhip_beam_trig_raw(n, a.data(), c.data(), s.data()), "beam_trig_raw");
+  slamhip_or_die(slamhip_scan_upload(ctx, n, r.data(), c.data(), s.data(), w.data(), f.data()),
+                 "scan_upload");
+}
+
+// ------------------------------------------------------------------------------------------------
+class HipGridScanMatcher : public GridScanMatcher {
+public:
+  // `spe` is the reference estimator the SLAM was configured with: it still does filter_scan on
+  // the host (once per scan); scoring goes to the GPU.  `matcher` was created with
+  // slamhip_matcher_create_{mc,hc,bf} using the same parameters init_scan_matcher would pass.
+  HipGridScanMatcher(SPE spe, slamhip_ctx *ctx, slamhip_matcher *matcher,
+                     std::shared_ptr<HipMapMirror> mirror, int weighting, HipScanTrig trig = {})
+      : GridScanMatcher{spe}, _ctx{ctx}, _m{matcher}, _mirror{mirror}, _weighting{weighting},
+        _trig{trig} {}
+  ~HipGridScanMatcher() override { slamhip_matcher_destroy(_m); }
+
+  void reset_state() override { slamhip_or_die(slamhip_matcher_reset_state(_m), "reset_state"); }
+  void set_dirty_source(HipMirroredGridMap *src) { _dirty_source = src; }
+
+  double process_scan(const TransformedLaserScan &raw_scan, const RobotPose &init_pose,
+                      const GridMap &map, RobotPoseDelta &pose_delta) override {
+    do_for_each_observer([&](ObsPtr obs) { obs->on_matching_start(init_pose, raw_scan, map); });
+    _scan = filter_scan(raw_scan.scan, init_pose, map);
+    _mirror->sync(map, _dirty_source);
+    hip_upload_filtered_scan(_ctx, _scan, _weighting, _trig);
+    slamhip_observer o{this, &on_test, &on_update, nullptr};
+    slamhip_or_die(slamhip_matcher_set_observer(_m, &o), "set_observer");
+    const double p0[3] = {init_pose.x, init_pose.y, init_pose.theta};
+    double d[3], prob = 0;
+    slamhip_or_die(slamhip_matcher_process_scan(_m, _mirror->id(), p0, d, &prob), "process_scan");
+    pose_delta = RobotPoseDelta{d[0], d[1], d[2]};
+    do_for_each_observer([&](ObsPtr obs) { obs->on_matching_end(pose_delta, _scan, prob); });
+    return prob;
+  }
+
+private:
+  static void on_test(void *self, const double p[3], double score) {
+    auto *t = static_cast<HipGridScanMatcher *>(self);
+    t->do_for_each_observer([&](ObsPtr obs) { obs->on_scan_test(RobotPose{p[0], p[1], p[2]}, t->_scan, score); });
+  }
+  static void on_update(void *self, const double p[3], double score) {
+    auto *t = static_cast<HipGridScanMatcher *>(self);
+    t->do_for_each_observer([&](ObsPtr obs) { obs->on_pose_update(RobotPose{p[0], p[1], p[2]}, t->_scan, score); });
+  }
+  slamhip_ctx *_ctx;
+  slamhip_matcher *_m;
+  std::shared_ptr<HipMapMirror> _mirror;
+  int _weighting;
+  HipScanTrig _trig;
+  HipMirroredGridMap *_dirty_source = nullptr;
+  LaserScan2D _scan;
+};
+
+// ------------------------------------------------------------------------------------------------
+class HipScanProbabilityEstimator : public ScanProbabilityEstimator {
+public:
+  HipScanProbabilityEstimator(std::shared_ptr<WeightedMeanPointProbabilitySPE> host_spe,
+                              slamhip_ctx *ctx, slamhip_spe_cfg cfg,
+                              std::shared_ptr<HipMapMirror> mirror, int weighting, HipScanTrig trig = {})
+      : ScanProbabilityEstimator{host_spe->occupancy_observation_probability_estimator()},
+        _host{host_spe}, _ctx{ctx}, _cfg{cfg}, _mirror{mirror}, _weighting{weighting}, _trig{trig} {}
+
+  LaserScan2D filter_scan(const LaserScan2D &scan, const RobotPose &pose, const GridMap &map) override {
+    auto filtered = _host->filter_scan(scan, pose, map);
+    _mirror->sync(map);
+    hip_upload_filtered_scan(_ctx, filtered, _weighting, _trig);
+    return filtered;
+  }
+
+  // the scan must be the one returned by the last filter_scan (it is what sits in HBM)
+  double estimate_scan_probability(const LaserScan2D &, const RobotPose &pose, const GridMap &,
+                                   const SPEParams &params) const override {
+    slamhip_spe_cfg cfg = _cfg;
+    cfg.area[0] = params.sp_analysis_area.bot();
+    cfg.area[1] = params.sp_analysis_area.top();
+    cfg.area[2] = params.sp_analysis_area.left();
+    cfg.area[3] = params.sp_analysis_area.right();
+    const double p[3] = {pose.x, pose.y, pose.theta};
+    double score = unknown_probability();
+    slamhip_or_die(slamhip_score_poses(_ctx, _mirror->id(), &cfg, 1, p, &score), "score_poses");
+    return score;
+  }
+
+private:
+  std::shared_ptr<WeightedMeanPointProbabilitySPE> _host;
+  slamhip_ctx *_ctx;
+  slamhip_spe_cfg _cfg;
+  std::shared_ptr<HipMapMirror> _mirror;
+  int _weighting;
+  HipScanTrig _trig;
+};
+
+#endif  // SLAMHIP_REFERENCE_ADAPTER_H

@@ -1,0 +1,43 @@
+"""GPU suite: drop-in proof.  The reference-side adapter (a GridScanMatcher subclass,
+slam-constructor_amd/host/slamhip_reference_adapter.h) is compiled against the UNMODIFIED reference
+headers (oracle/_ref/libslamref_adapter.so, built where /root/reference exists) and run next to the
+reference's own MC / HC matchers on the same reference GridMap and scan; both are watched through
+the reference's GridScanMatcherObserver.  Skipped when the prebuilt harness did not travel."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                  "libslamref_adapter.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(SO):
+        pytest.skip("oracle/_ref/libslamref_adapter.so not present")
+    L = C.CDLL(SO)
+    L.refad_compare.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                                C.POINTER(C.c_double)]
+    return L
+
+
+CASES = [(0, 0, [666666, 0.2, 0.1, 20, 100]), (0, 1, [6, 0.1, 0.1]), (0, 1, [128, 0.1, 0.1]),
+         (1, 0, [666666, 0.2, 0.1, 60, 300]), (1, 1, [128, 0.1, 0.1])]
+
+
+@pytest.mark.parametrize("cell,kind,params", CASES)
+@pytest.mark.parametrize("strict", [1, 0])
+def test_adapter_matches_reference_matcher(lib, cell, kind, params, strict):
+    p = (C.c_double * len(params))(*params)
+    out = (C.c_double * 10)()
+    assert lib.refad_compare(cell, kind, p, 720, strict, 3, out) == 0
+    ref_calls, hip_calls, acc_mis, pose_mis, rel, ref_prob, hip_prob, ddelta, beams, obs_ok = list(out)
+    assert beams > 600 and obs_ok == 1
+    assert ref_calls == hip_calls and acc_mis == 0 and pose_mis == 0
+    if strict:
+        assert rel == 0.0 and ref_prob == hip_prob and ddelta == 0.0
+    else:
+        assert rel <= 1e-12 and ddelta == 0.0 and abs(ref_prob - hip_prob) <= 1e-12 * abs(ref_prob)
