@@ -207,6 +207,65 @@ int slamhip_pf_resampling_is_required(int n, const double *weights, int *require
 int slamhip_pf_resample(int n, const double *weights, uint32_t seed, unsigned *out_idx);
 int slamhip_pf_heaviest(int n, const double *weights, int *index);
 
+/* ---------------------------------------------------------------- GMapping particle filter
+ * Replaces LaserScanGridWorld::handle_sensor_data of GmappingParticleFilter
+ * (src/slams/gmapping/gmapping_particle_filter.h:45-50; per particle GmappingWorld::update_robot_pose
+ * / handle_observation, src/slams/gmapping/gmapping_world.h:57-101) for the likelihood part of
+ * the step: odometry, matching gate, pose noise, HC(6, 0.1, 0.1) scan matching of all particles in
+ * lock-step on the GPU, weight update, normalisation, N_eff test, multinomial resampling with
+ * duplicated particles and master hand-over.  The map update inside the step is not built yet.
+ *
+ * A filter object holds the particles [first, first + count) of n_total (one object per GPU when
+ * particles are sharded).  Sharded step:
+ *   1. every rank:  slamhip_gmapping_predict_match(...)            -> raw weights of its shard
+ *   2. caller:      all-gather the raw weights (n_total doubles)      [the one collective, RCCL]
+ *   3. every rank:  slamhip_gmapping_plan_resample(all weights)    -> identical decision + indices
+ *   4. if required: slamhip_gmapping_export -> all-gather n_total records -> slamhip_gmapping_import
+ * slamhip_gmapping_step does 1-4 for an unsharded filter. */
+typedef struct slamhip_gmapping slamhip_gmapping;
+typedef struct {
+  /* GMappingParams (src/slams/gmapping/gmapping_world.h:16-34, defaults init_gmapping.h:15-34) */
+  double mean_sample_xy, sigma_sample_xy, mean_sample_th, sigma_sample_th;
+  double min_sm_lim_xy, max_sm_lim_xy, min_sm_lim_th, max_sm_lim_th;
+  /* HillClimbingScanMatcher(6, 0.1, 0.1) hard-wired in init_gmapping.h:58-60 */
+  unsigned hc_failed_rounds_limit;
+  double hc_translation, hc_rotation;
+  /* WeightedMeanPointProbabilitySPE(oope, EvenSPW, skip_rate, max_range), init_scan_matching.h:94-109 */
+  unsigned sp_skip_rate;
+  double sp_max_usable_range;
+  /* GmappingOccupancyObservationPE(fullness_th, window), init_gmapping.h:36-45 */
+  double oope_fullness_th;
+  int oope_window;
+  int pose_trig; /* SLAMHIP_POSE_TRIG_* */
+} slamhip_gmapping_params;
+
+/* seeds: one per LOCAL particle = what std::random_device hands the GmappingWorld ctor
+ * (gmapping_world.h:51).  ctx may be NULL for host-only bookkeeping (steps 3-4). */
+int slamhip_gmapping_create(slamhip_ctx *ctx, const slamhip_gmapping_params *prm, int n_total,
+                            int first, int count, const uint32_t *seeds, slamhip_gmapping **out);
+int slamhip_gmapping_destroy(slamhip_gmapping *g);
+/* raw scan (unfiltered); raw_weights_out: count doubles (weight * scan probability, unnormalised) */
+int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                   const double *angle, const int *is_occ, const double odom_delta[3],
+                                   double *raw_weights_out);
+/* ParticleFilter::normalize_weights + the try_resample gates (gmapping_particle_filter.h:88-99,
+ * particle_filter.h:34-43) + UniformResamling::resample (:45-66) over ALL n_total weights;
+ * idx_out (n_total) is written when *required becomes 1 */
+int slamhip_gmapping_plan_resample(slamhip_gmapping *g, const double *all_raw_weights,
+                                   uint32_t resample_seed, int *required, unsigned *idx_out);
+size_t slamhip_gmapping_blob_size(void);
+int slamhip_gmapping_export(slamhip_gmapping *g, void *blobs_out /* count records */);
+/* ParticleFilter::try_resample body (particle_filter.h:88-105) + ensure_master_exists */
+int slamhip_gmapping_import(slamhip_gmapping *g, const void *all_blobs /* n_total records */,
+                            const unsigned *idx /* n_total */);
+int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                          const double *angle, const int *is_occ, const double odom_delta[3],
+                          uint32_t resample_seed, int *resampled, unsigned *idx_out);
+int slamhip_gmapping_set(slamhip_gmapping *g, const double *poses, const double *weights);
+int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, int *is_master);
+int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
+                           long long *launches, long long *carry_reruns);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,11 +350,57 @@ class Oracle:
         n = self.lib.orc_world_to_cells(scale, x0, y0, x1, y1, cap, _i(out))
         return out[:n].copy()
 
+    # -- GMapping particle filter (no map update)
+    def gmapping_create(self, n, gp8, seeds, hc=(6, 0.1, 0.1), skip_rate=0, max_range=-1.0):
+        L = self.lib
+        L.orc_gmapping_create.restype = C.c_void_p
+        L.orc_gmapping_create.argtypes = [C.c_int, _dp, C.POINTER(C.c_uint32), C.c_uint, C.c_double,
+                                          C.c_double, C.c_uint, C.c_double]
+        L.orc_gmapping_destroy.argtypes = [C.c_void_p]
+        L.orc_gmapping_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _ip, _dp,
+                                        C.c_uint32, C.c_int, C.POINTER(C.c_uint32), _up]
+        L.orc_gmapping_get.argtypes = [C.c_void_p, _dp, _dp, _ip]
+        L.orc_gmapping_scorer_calls.restype = C.c_longlong
+        L.orc_gmapping_scorer_calls.argtypes = [C.c_void_p]
+        gp = f64(gp8)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        h = L.orc_gmapping_create(n, _d(gp), sd.ctypes.data_as(C.POINTER(C.c_uint32)), int(hc[0]),
+                                  hc[1], hc[2], skip_rate, max_range)
+        return OrcGmappingHandle(self, h, n)
+
     # -- RNG
     def rng(self, seed):
         g = OrcMt()
         self.lib.orc_mt_seed(C.byref(g), seed)
         return g
+
+
+class OrcGmappingHandle:
+    def __init__(self, oracle, h, n):
+        self.o, self.h, self.n = oracle, h, n
+
+    def __del__(self):
+        try:
+            self.o.lib.orc_gmapping_destroy(self.h)
+        except Exception:
+            pass
+
+    def step(self, gmap, rng, ang, is_occ, odom_delta, resample_seed, extra_seeds=()):
+        rng, ang, d = f64(rng), f64(ang), f64(odom_delta)
+        occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+        m = _map_struct(gmap)
+        ex = np.ascontiguousarray(extra_seeds if len(extra_seeds) else [0], dtype=np.uint32)
+        idx = np.zeros(self.n, np.uint32)
+        res = self.o.lib.orc_gmapping_step(self.h, C.byref(m), rng.size, _d(rng), _d(ang), _i(occ),
+                                           _d(d), resample_seed, len(extra_seeds),
+                                           ex.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                           idx.ctypes.data_as(_up))
+        return bool(res), idx
+
+    def state(self):
+        poses, w, ms = np.zeros((self.n, 3)), np.zeros(self.n), np.zeros(self.n, np.int32)
+        self.o.lib.orc_gmapping_get(self.h, _d(poses), _d(w), _i(ms))
+        return poses, w, ms
 
 
 # ------------------------------------------------------------------------------------------
@@ -502,6 +548,40 @@ class Ref:
         out = np.zeros(w.size, np.uint32)
         req = self.lib.ref_resample(w.size, _d(w), seed, out.ctypes.data_as(_up))
         return bool(req), out
+
+
+class RefGmapping:
+    """GmappingParticleFilter of the compiled reference (shared map, seeds injected)."""
+
+    def __init__(self, ref, n, w, h, scale, gp8, seeds, skip_rate=0, max_range=-1.0, occ_est=0,
+                 base=(0.95, 1.0, 0.01, 1.0), blur=0.0, map_max_range=float("inf"),
+                 hc=(6, 0.1, 0.1)):
+        self.ref, self.n = ref, n
+        gp, b = f64(gp8), f64(base)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        self.h = ref.lib.ref_gmapping_create(n, w, h, scale, _d(gp), sd.ctypes.data_as(_up), skip_rate,
+                                             max_range, occ_est, _d(b), blur, map_max_range,
+                                             int(hc[0]), hc[1], hc[2])
+        assert self.h
+
+    def __del__(self):
+        try:
+            self.ref.lib.ref_gmapping_destroy(self.h)
+        except Exception:
+            pass
+
+    def map(self):
+        return RefMapHandle(self.ref, self.ref.lib.ref_gmapping_map(self.h), REF_CELL_GMAPPING,
+                            MAP_UNBOUNDED_LAZY_TILED)
+
+    def step(self, scan, odom_delta, resample_seed, extra_seeds=()):
+        poses, w, ms = np.zeros((self.n, 3)), np.zeros(self.n), np.zeros(self.n, np.int32)
+        flags = np.zeros(1, np.int32)
+        ex = np.ascontiguousarray(extra_seeds if len(extra_seeds) else [0], dtype=np.uint32)
+        self.ref.lib.ref_gmapping_step(self.h, scan.h, odom_delta[0], odom_delta[1], odom_delta[2],
+                                       resample_seed, len(extra_seeds), ex.ctypes.data_as(_up),
+                                       _d(poses), _d(w), _i(ms), _i(flags))
+        return bool(flags[0]), poses, w, ms
 
 
 class RefHandle:

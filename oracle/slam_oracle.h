@@ -124,6 +124,44 @@ int orc_resampling_is_required(int n, const double *w);
 void orc_resample(int n, const double *w, uint32_t seed, unsigned *out_idx);
 int orc_heaviest(int n, const double *w);
 
+/* ---- GMapping particle filter (src/slams/gmapping/gmapping_world.h, gmapping_particle_filter.h,
+ *      src/core/particle_filter.h) WITHOUT the map update (the reference run it is pinned against
+ *      uses slam/mapping/max_range = 0, which turns append_scan into a no-op) ---- */
+typedef struct {
+  double pose[3], raw_odom[3], weight;
+  int is_master, scan_is_first;
+  orc_mt19937 eng;
+  orc_normal guess[3];          /* _pose_guess_rv */
+  int nsd_is_normal;            /* _next_sm_delta_rv: 0 = UniformRV1D(a,b), 1 = GaussianRV1D(0,0) */
+  double nsd_a[3], nsd_b[3];
+  orc_normal nsd_norm[3];
+  double dsl[3], nsd[3];        /* _delta_since_last_sm, _next_sm_delta */
+} orc_particle;
+
+typedef struct {
+  int n;
+  orc_particle *p;
+  double traversed[3];          /* _traversed_since_last_resample */
+  double gp[8];                 /* GMappingParams ctor arguments */
+  unsigned hc_limit; double hc_dt, hc_dr;
+  unsigned skip_rate; double max_range;
+  orc_spe_cfg cfg;
+  orc_gm_cache cache;           /* ONE OOPE shared by all particles (Q20) */
+  long long scorer_calls;       /* of the last step */
+} orc_gmapping;
+
+orc_gmapping *orc_gmapping_create(int n, const double *gp8, const uint32_t *seeds, unsigned hc_limit,
+                                  double hc_dt, double hc_dr, unsigned skip_rate, double max_range);
+void orc_gmapping_destroy(orc_gmapping *g);
+/* one handle_sensor_data; returns 1 if resampling happened; idx_out (n) receives the resampling
+ * indices when it did.  extra_seeds feed the GmappingWorld ctor of every duplicated particle. */
+int orc_gmapping_step(orc_gmapping *g, const orc_map *map, int n_raw, const double *range,
+                      const double *angle, const int *is_occ, const double *odom_delta,
+                      uint32_t resample_seed, int n_extra, const uint32_t *extra_seeds,
+                      unsigned *idx_out);
+void orc_gmapping_get(const orc_gmapping *g, double *poses, double *weights, int *is_master);
+long long orc_gmapping_scorer_calls(const orc_gmapping *g);
+
 /* ---- map update ---- */
 int orc_world_to_cells(double scale, double x0, double y0, double x1, double y1, int cap,
                        int *out_xy);

@@ -35,7 +35,10 @@ slamhip_profile_enable slamhip_profile_read slamhip_matcher_create_mc slamhip_ma
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_process_scan
 slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
-slamhip_pf_heaviest""".split()
+slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
+slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
+slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
+slamhip_gmapping_stats""".split()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -49,6 +52,29 @@ class SpeCfg(C.Structure):
     _fields_ = [("oope", C.c_int), ("oie", C.c_int), ("area", C.c_double * 4),
                 ("gm_fullness_th", C.c_double), ("gm_window", C.c_int), ("sum_order", C.c_int),
                 ("pose_trig", C.c_int)]
+
+
+class GmappingParams(C.Structure):
+    _fields_ = [("mean_sample_xy", C.c_double), ("sigma_sample_xy", C.c_double),
+                ("mean_sample_th", C.c_double), ("sigma_sample_th", C.c_double),
+                ("min_sm_lim_xy", C.c_double), ("max_sm_lim_xy", C.c_double),
+                ("min_sm_lim_th", C.c_double), ("max_sm_lim_th", C.c_double),
+                ("hc_failed_rounds_limit", C.c_uint), ("hc_translation", C.c_double),
+                ("hc_rotation", C.c_double), ("sp_skip_rate", C.c_uint),
+                ("sp_max_usable_range", C.c_double), ("oope_fullness_th", C.c_double),
+                ("oope_window", C.c_int), ("pose_trig", C.c_int)]
+
+
+def gmapping_params(gp8=(0.0, 0.1, 0.0, 0.03, 0.6, 0.8, 0.3, 0.4), hc=(6, 0.1, 0.1), skip_rate=0,
+                    max_range=-1.0, fullness_th=0.1, window=1, pose_trig=POSE_TRIG_DEVICE):
+    """Defaults of init_gmapping (src/slams/gmapping/init_gmapping.h:15-60)."""
+    p = GmappingParams()
+    (p.mean_sample_xy, p.sigma_sample_xy, p.mean_sample_th, p.sigma_sample_th, p.min_sm_lim_xy,
+     p.max_sm_lim_xy, p.min_sm_lim_th, p.max_sm_lim_th) = [float(v) for v in gp8]
+    p.hc_failed_rounds_limit, p.hc_translation, p.hc_rotation = int(hc[0]), hc[1], hc[2]
+    p.sp_skip_rate, p.sp_max_usable_range = skip_rate, max_range
+    p.oope_fullness_th, p.oope_window, p.pose_trig = fullness_th, window, pose_trig
+    return p
 
 
 OBS_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_double)
@@ -128,6 +154,20 @@ def load():
     L.slamhip_pf_resampling_is_required.argtypes = [i, _dp, _ip]
     L.slamhip_pf_resample.argtypes = [i, _dp, C.c_uint32, C.POINTER(C.c_uint)]
     L.slamhip_pf_heaviest.argtypes = [i, _dp, _ip]
+    up = C.POINTER(C.c_uint)
+    ll = C.POINTER(C.c_longlong)
+    L.slamhip_gmapping_create.argtypes = [vp, C.POINTER(GmappingParams), i, i, i,
+                                          C.POINTER(C.c_uint32), C.POINTER(vp)]
+    L.slamhip_gmapping_destroy.argtypes = [vp]
+    L.slamhip_gmapping_predict_match.argtypes = [vp, i, i, _dp, _dp, _ip, _dp, _dp]
+    L.slamhip_gmapping_plan_resample.argtypes = [vp, _dp, C.c_uint32, _ip, up]
+    L.slamhip_gmapping_blob_size.restype = C.c_size_t
+    L.slamhip_gmapping_export.argtypes = [vp, vp]
+    L.slamhip_gmapping_import.argtypes = [vp, vp, up]
+    L.slamhip_gmapping_step.argtypes = [vp, i, i, _dp, _dp, _ip, _dp, C.c_uint32, _ip, up]
+    L.slamhip_gmapping_set.argtypes = [vp, _dp, _dp]
+    L.slamhip_gmapping_get.argtypes = [vp, _dp, _dp, _ip]
+    L.slamhip_gmapping_stats.argtypes = [vp, ll, ll, ll, ll]
     _lib = L
     return L
 
@@ -381,3 +421,88 @@ class Matcher:
         return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value,
                     build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
                     replay_us=t[3].value)
+
+
+class GmappingFilter:
+    """GmappingParticleFilter counterpart (slamhip_gmapping): the particles [first, first+count) of
+    n_total.  ctx may be None for host-only bookkeeping (weights / resampling of a shard)."""
+
+    def __init__(self, ctx, params, n_total, seeds, first=0, count=None):
+        self.L = load()
+        self.ctx = ctx
+        self.n_total, self.first = n_total, first
+        self.count = n_total - first if count is None else count
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        assert sd.size == self.count, "one seed per local particle"
+        h = C.c_void_p()
+        _check(self.L.slamhip_gmapping_create(ctx.h if ctx is not None else None, C.byref(params),
+                                              n_total, first, self.count,
+                                              sd.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.slamhip_gmapping_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def predict_match(self, map_id, rng, ang, is_occ, odom_delta):
+        rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
+        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        raw = np.zeros(self.count)
+        _check(self.L.slamhip_gmapping_predict_match(self.h, map_id, rng.size, _d(rng), _d(ang),
+                                                     occ.ctypes.data_as(_ip), _d(d), _d(raw)))
+        return raw
+
+    def plan_resample(self, all_raw_weights, seed):
+        w = _f64(all_raw_weights)
+        assert w.size == self.n_total
+        req = C.c_int(0)
+        idx = np.zeros(self.n_total, np.uint32)
+        _check(self.L.slamhip_gmapping_plan_resample(self.h, _d(w), seed, C.byref(req),
+                                                     idx.ctypes.data_as(C.POINTER(C.c_uint))))
+        return bool(req.value), idx
+
+    def blob_size(self):
+        return int(self.L.slamhip_gmapping_blob_size())
+
+    def export(self):
+        buf = np.zeros(self.count * self.blob_size(), np.uint8)
+        _check(self.L.slamhip_gmapping_export(self.h, buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
+    def import_(self, all_blobs, idx):
+        b = np.ascontiguousarray(all_blobs, dtype=np.uint8)
+        assert b.size == self.n_total * self.blob_size()
+        ix = np.ascontiguousarray(idx, dtype=np.uint32)
+        _check(self.L.slamhip_gmapping_import(self.h, b.ctypes.data_as(C.c_void_p),
+                                              ix.ctypes.data_as(C.POINTER(C.c_uint))))
+
+    def step(self, map_id, rng, ang, is_occ, odom_delta, resample_seed):
+        rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
+        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        res = C.c_int(0)
+        idx = np.zeros(self.n_total, np.uint32)
+        _check(self.L.slamhip_gmapping_step(self.h, map_id, rng.size, _d(rng), _d(ang),
+                                            occ.ctypes.data_as(_ip), _d(d), resample_seed,
+                                            C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_uint))))
+        return bool(res.value), idx
+
+    def set(self, poses=None, weights=None):
+        p = _f64(poses) if poses is not None else None
+        w = _f64(weights) if weights is not None else None
+        _check(self.L.slamhip_gmapping_set(self.h, _d(p) if p is not None else None,
+                                           _d(w) if w is not None else None))
+
+    def state(self):
+        poses, w, ms = np.zeros((self.count, 3)), np.zeros(self.count), np.zeros(self.count, np.int32)
+        _check(self.L.slamhip_gmapping_get(self.h, _d(poses), _d(w), ms.ctypes.data_as(_ip)))
+        return poses, w, ms
+
+    def stats(self):
+        v = [C.c_longlong() for _ in range(4)]
+        _check(self.L.slamhip_gmapping_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(scorer_calls=v[0].value, poses_evaluated=v[1].value, launches=v[2].value,
+                    carry_reruns=v[3].value)

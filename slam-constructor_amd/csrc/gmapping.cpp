@@ -1,0 +1,425 @@
+// gmapping.cpp -- GMapping particle-filter step over the GPU scorer.
+//
+// Reference behaviour restated (paths relative to the reference root):
+//   GmappingWorld                 src/slams/gmapping/gmapping_world.h:36-127
+//     update_robot_pose :57-71, handle_observation :73-101, mark_master :103-110,
+//     reset_scan_matching_delta :116-119
+//   GmappingParticleFilter        src/slams/gmapping/gmapping_particle_filter.h:29-118
+//     handle_sensor_data :45-50, update_robot_pose :52-57, handle_observation :70-77,
+//     try_resample :88-99 (fabs of a bool, Q23), ensure_master_exists :102-113
+//   ParticleFilter / UniformResamling  src/core/particle_filter.h:34-66,70-121
+//   init_gmapping                 src/slams/gmapping/init_gmapping.h:49-65 (HC(6, 0.1, 0.1), WMPP with
+//                                 even weights, GmappingOccupancyObservationPE(0.1, 1))
+//
+// What runs where: the per-particle state machines (gate, pose noise, RNG streams, weights,
+// N_eff, resampling, master hand-over) stay on the host, bit for bit; every particle that takes the
+// scan-matching branch owns a MatchJob (matchers.h) and ALL jobs advance in lock-step through
+// shared launches of the GMapping kernel (K3).  Particles are independent between the odometry
+// update and the weight normalisation, so a filter object may hold just a shard [first,
+// first+count) of the particles: the caller all-gathers the raw weights (and, when a resampling
+// happens, the particle records) between predict_match and plan_resample/import.
+//
+// The reference shares ONE OOPE cache among all particles (Q20) and evaluates them one after
+// another; in lock-step a particle's predecessor is not finished when it starts, so every job
+// starts without a carry-in and the chain is verified afterwards: a particle whose first run would
+// have hit its predecessor's final cache entry is re-matched alone with that carry (counted in
+// `carry_reruns`; rare: it needs the same endpoint cell AND a different cached value).
+//
+// The map update (append_scan, gmapping_world.h:93-97) is not built yet: the step is
+// the "without map update" variant, exactly the reference run with slam/mapping/max_range = 0.
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "matchers.h"
+
+namespace slamhip {
+
+struct GmParticle {
+  double pose[3], raw_odom[3], weight;
+  int is_master, scan_is_first;
+  std::mt19937 eng;
+  NormalRV guess[3];  // _pose_guess_rv
+  int nsd_is_normal;  // _next_sm_delta_rv: UniformRV1D(a, b) or, for a master, GaussianRV1D(0, 0)
+  double nsd_a[3], nsd_b[3];
+  NormalRV nsd_norm[3];
+  double dsl[3], nsd[3];  // _delta_since_last_sm, _next_sm_delta
+};
+static_assert(std::is_trivially_copyable<GmParticle>::value, "particle records travel as raw bytes");
+
+static void reset_sm_delta(GmParticle &p) {
+  p.dsl[0] = p.dsl[1] = p.dsl[2] = 0;
+  for (int k = 0; k < 3; ++k)
+    p.nsd[k] = p.nsd_is_normal ? p.nsd_norm[k](p.eng) : canonical(p.eng) * (p.nsd_b[k] - p.nsd_a[k]) + p.nsd_a[k];
+}
+
+static void init_particle(GmParticle &p, const slamhip_gmapping_params &gp, uint32_t seed, double weight) {
+  std::memset(static_cast<void *>(&p), 0, sizeof(p));
+  p.weight = weight;
+  p.scan_is_first = 1;
+  p.eng = std::mt19937(seed);
+  p.guess[0] = NormalRV(gp.mean_sample_xy, gp.sigma_sample_xy);
+  p.guess[1] = NormalRV(gp.mean_sample_xy, gp.sigma_sample_xy);
+  p.guess[2] = NormalRV(gp.mean_sample_th, gp.sigma_sample_th);
+  p.nsd_is_normal = 0;
+  p.nsd_a[0] = p.nsd_a[1] = gp.min_sm_lim_xy;
+  p.nsd_b[0] = p.nsd_b[1] = gp.max_sm_lim_xy;
+  p.nsd_a[2] = gp.min_sm_lim_th;
+  p.nsd_b[2] = gp.max_sm_lim_th;
+  for (int k = 0; k < 3; ++k) p.nsd_norm[k] = NormalRV(0, 0);
+  reset_sm_delta(p);
+}
+
+static void mark_master(GmParticle &p) {
+  p.is_master = 1;
+  for (int k = 0; k < 3; ++k) {
+    p.guess[k] = NormalRV(0, 0);
+    p.nsd_norm[k] = NormalRV(0, 0);
+  }
+  p.nsd_is_normal = 1;
+}
+
+// `*new_particle = *sampled; new_particle->sample()` (particle_filter.h:94-96): everything is
+// copied, the RobotPoseDeltaRV members through clone(), i.e. fresh distributions with the same
+// parameters (robot_pose.h:72-81), and the master flag is cleared
+static void copy_as_duplicate(GmParticle &dst, const GmParticle &src) {
+  dst = src;
+  for (int k = 0; k < 3; ++k) {
+    dst.guess[k] = NormalRV(src.guess[k].mean, src.guess[k].stddev);
+    dst.nsd_norm[k] = NormalRV(src.nsd_norm[k].mean, src.nsd_norm[k].stddev);
+  }
+  dst.is_master = 0;
+}
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+struct slamhip_gmapping {
+  slamhip_ctx *ctx = nullptr;
+  slamhip_gmapping_params prm{};
+  slamhip_spe_cfg cfg{};
+  int n_total = 0, first = 0, count = 0;
+  std::vector<GmParticle> p;  // local shard
+  double traversed[3] = {0, 0, 0};
+  GmCarry carry;  // the shared OOPE cache as this shard sees it
+  std::vector<MatchJob> jobs;
+  std::vector<HillClimbingPoseEnumerator> pes;
+  std::vector<double> all_w;  // normalised weights of all particles (after plan_resample)
+  long long scorer_calls = 0, poses_evaluated = 0, launches = 0, carry_reruns = 0;
+};
+
+namespace {
+
+int bad(const char *msg) {
+  set_error(msg);
+  return SLAMHIP_ERR_INVALID;
+}
+
+int heaviest(const std::vector<double> &w) {
+  int h = -1;
+  for (int i = 0; i < (int)w.size(); ++i) {
+    if (h >= 0 && w[i] < w[h]) continue;
+    h = i;
+  }
+  return h;
+}
+
+// drives a set of jobs to completion through shared launches
+int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int per_job_budget) {
+  slamhip_ctx *ctx = g->ctx;
+  std::vector<int> off(act.size()), cnt(act.size());
+  int rc = ensure_pose_capacity(ctx, (per_job_budget + 1) * (int)act.size());
+  if (rc) return rc;
+  while (true) {
+    int total = 0;
+    for (size_t k = 0; k < act.size(); ++k) {
+      off[k] = total;
+      cnt[k] = act[k]->done ? 0 : act[k]->plan(per_job_budget, ctx->h_poses + 3 * (size_t)total);
+      total += cnt[k];
+    }
+    if (total == 0) break;
+    rc = score_staged(ctx, map_id, &g->cfg, total);
+    if (rc) return rc;
+    g->launches += 1;
+    g->poses_evaluated += total;
+    for (size_t k = 0; k < act.size(); ++k) {
+      if (cnt[k] == 0) continue;
+      rc = act[k]->consume(ctx->h_scores + off[k], ctx->h_gm_info + off[k], ctx);
+      if (rc) return rc;
+    }
+  }
+  return SLAMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t slamhip_gmapping_blob_size(void) { return sizeof(GmParticle); }
+
+int slamhip_gmapping_create(slamhip_ctx *ctx, const slamhip_gmapping_params *prm, int n_total, int first,
+                            int count, const uint32_t *seeds, slamhip_gmapping **out) {
+  // ctx may be null for host-only use (weights / resampling bookkeeping of a shard); matching then
+  // fails loudly
+  if (!prm || !seeds || !out) return bad("null argument");
+  if (n_total <= 0 || first < 0 || count <= 0 || first + count > n_total) return bad("bad particle shard");
+  auto *g = new slamhip_gmapping;
+  g->ctx = ctx;
+  g->prm = *prm;
+  std::memset(&g->cfg, 0, sizeof(g->cfg));
+  g->cfg.oope = SLAMHIP_OOPE_GMAPPING;
+  g->cfg.oie = SLAMHIP_OIE_DISCREPANCY;
+  g->cfg.gm_fullness_th = prm->oope_fullness_th;
+  g->cfg.gm_window = prm->oope_window;
+  g->cfg.sum_order = SLAMHIP_SUM_TREE256;
+  g->cfg.pose_trig = prm->pose_trig;
+  g->n_total = n_total;
+  g->first = first;
+  g->count = count;
+  g->p.resize(count);
+  for (int i = 0; i < count; ++i) init_particle(g->p[i], *prm, seeds[i], 1.0 / n_total);
+  // the heaviest particle becomes the master; with equal weights that is the LAST one
+  // (particle_filter.h:114-121, gmapping_particle_filter.h:39-42)
+  if (first + count == n_total) mark_master(g->p[count - 1]);
+  g->jobs.resize(count);
+  g->all_w.assign(n_total, 1.0 / n_total);
+  *out = g;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_destroy(slamhip_gmapping *g) {
+  delete g;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                   const double *angle, const int *is_occ, const double odom_delta[3],
+                                   double *raw_weights_out) {
+  if (!g || !range || !angle || !odom_delta) return bad("null argument");
+  slamhip_ctx *ctx = g->ctx;
+  if (!ctx) {
+    set_error("this filter was created without a GPU context; there is no CPU scorer");
+    return SLAMHIP_ERR_NO_DEVICE;
+  }
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  g->scorer_calls = g->poses_evaluated = g->launches = g->carry_reruns = 0;
+  const double *d = odom_delta;
+  // update_robot_pose: the odometry delta is rotated by the particle's accumulated heading correction
+  for (auto &p : g->p) {
+    double s, c;
+    ::sincos(p.pose[2] - p.raw_odom[2], &s, &c);
+    const double cx = c * d[0] - s * d[1], cy = s * d[0] + c * d[1], ct = d[2];
+    for (int k = 0; k < 3; ++k) p.raw_odom[k] += d[k];
+    p.dsl[0] += std::fabs(cx);
+    p.dsl[1] += std::fabs(cy);
+    p.dsl[2] += std::fabs(ct);
+    p.pose[0] += cx;
+    p.pose[1] += cy;
+    p.pose[2] += ct;
+  }
+  for (int k = 0; k < 3; ++k) g->traversed[k] += std::fabs(d[k]);
+
+  // gate + pose noise, in particle order
+  std::vector<int> act_idx;
+  for (int i = 0; i < g->count; ++i) {
+    GmParticle &p = g->p[i];
+    if (p.dsl[0] * p.dsl[0] + p.dsl[1] * p.dsl[1] < p.nsd[0] * p.nsd[0] + p.nsd[1] * p.nsd[1] &&
+        std::fabs(p.dsl[2]) < p.nsd[2])
+      continue;
+    if (!p.scan_is_first) {
+      const double nx = p.guess[0](p.eng);
+      const double ny = p.guess[1](p.eng);
+      const double nt = p.guess[2](p.eng);
+      p.pose[0] += nx;
+      p.pose[1] += ny;
+      p.pose[2] += nt;
+    }
+    act_idx.push_back(i);
+  }
+  if (!act_idx.empty()) {
+    // filter_scan: GMapping maps are unbounded (has_cell is always true, lazy_tiled_grid_map.h:150),
+    // so the filtered scan does not depend on the particle
+    std::vector<int> kept(n_raw > 0 ? n_raw : 1);
+    int nk = 0;
+    int rc = slamhip_filter_scan(n_raw, range, angle, is_occ, SLAMHIP_TRIG_RAW, 0, 1, 0, nullptr, nullptr,
+                                 g->p[act_idx[0]].pose, g->prm.sp_skip_rate, g->prm.sp_max_usable_range,
+                                 /*bounded*/ 0, 0, 0, 0, 0, 1.0, kept.data(), &nk);
+    if (rc) return rc;
+    if (nk <= 0) return bad("no usable scan points");
+    std::vector<double> fr(nk), fa(nk), fw(nk), fc(nk), fs(nk);
+    for (int k = 0; k < nk; ++k) {
+      fr[k] = range[kept[k]];
+      fa[k] = angle[kept[k]];
+    }
+    slamhip_scan_weights(0, nk, fr.data(), fa.data(), fw.data());
+    slamhip_beam_trig_raw(nk, fa.data(), fc.data(), fs.data());
+    rc = slamhip_scan_upload(ctx, nk, fr.data(), fc.data(), fs.data(), fw.data(), nullptr);
+    if (rc) return rc;
+
+    g->pes.clear();
+    g->pes.reserve(act_idx.size());
+    std::vector<MatchJob *> act;
+    for (size_t k = 0; k < act_idx.size(); ++k) {
+      g->pes.emplace_back(g->prm.hc_failed_rounds_limit, g->prm.hc_translation, g->prm.hc_rotation);
+      GmParticle &p = g->p[act_idx[k]];
+      MatchJob &job = g->jobs[act_idx[k]];
+      job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr,
+                k == 0 ? g->carry : GmCarry{}, 0.25);
+      act.push_back(&job);
+    }
+    const int per_job = std::max(6, std::min(126, 12288 / (int)act.size() / 6 * 6));
+    rc = run_jobs(g, map_id, act, per_job);
+    if (rc) return rc;
+    // verify the shared-cache chain in the reference's particle order; re-match on a hit
+    GmCarry prev = act[0]->carry;
+    for (size_t k = 1; k < act.size(); ++k) {
+      MatchJob &job = *act[k];
+      const GmPoseInfo &fi = job.first_info;
+      if (prev.prob != -1.0 && fi.first_cx == prev.cx && fi.first_cy == prev.cy && prev.prob != fi.v0) {
+        g->pes[k] = HillClimbingPoseEnumerator(g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
+                                               g->prm.hc_rotation);
+        const GmParticle &p = g->p[act_idx[k]];
+        job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, prev, 0.25);
+        std::vector<MatchJob *> one{&job};
+        rc = run_jobs(g, map_id, one, 126);
+        if (rc) return rc;
+        g->carry_reruns += 1;
+      }
+      prev = job.carry;
+    }
+    g->carry = prev;
+    for (size_t k = 0; k < act_idx.size(); ++k) {
+      GmParticle &p = g->p[act_idx[k]];
+      const MatchJob &job = *act[k];
+      double dl[3];
+      job.delta(dl);
+      for (int c = 0; c < 3; ++c) p.pose[c] += dl[c];
+      if (0.0 < job.best_prob || p.scan_is_first) p.scan_is_first = 0;  // (map update: SURVEY K6)
+      p.weight = job.best_prob * p.weight;
+      reset_sm_delta(p);
+      g->scorer_calls += job.scorer_calls;
+    }
+  }
+  if (raw_weights_out)
+    for (int i = 0; i < g->count; ++i) raw_weights_out[i] = g->p[i].weight;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_plan_resample(slamhip_gmapping *g, const double *all_raw_weights,
+                                   uint32_t resample_seed, int *required, unsigned *idx_out) {
+  if (!g || !all_raw_weights || !required) return bad("null argument");
+  // normalize_weights over ALL particles in particle order: every rank does the same sums
+  double total = 0;
+  for (int i = 0; i < g->n_total; ++i) total += all_raw_weights[i];
+  for (int i = 0; i < g->n_total; ++i) g->all_w[i] = all_raw_weights[i] / total;
+  for (int i = 0; i < g->count; ++i) g->p[i].weight = g->all_w[g->first + i];
+  *required = 0;
+  if (g->traversed[0] * g->traversed[0] + g->traversed[1] * g->traversed[1] <= 0.5 &&
+      std::fabs(double(g->traversed[2] <= 0.2)))
+    return SLAMHIP_OK;
+  int req = 0;
+  int rc = slamhip_pf_resampling_is_required(g->n_total, g->all_w.data(), &req);
+  if (rc || !req) return rc;
+  if (!idx_out) return bad("resampling is required: idx_out is null");
+  rc = slamhip_pf_resample(g->n_total, g->all_w.data(), resample_seed, idx_out);
+  if (rc) return rc;
+  *required = 1;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_export(slamhip_gmapping *g, void *blobs_out) {
+  if (!g || !blobs_out) return bad("null argument");
+  std::memcpy(blobs_out, g->p.data(), sizeof(GmParticle) * g->count);
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_import(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx) {
+  if (!g || !all_blobs || !idx) return bad("null argument");
+  const GmParticle *all = static_cast<const GmParticle *>(all_blobs);
+  const int n = g->n_total;
+  std::vector<char> seen(n, 0), dup(n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (idx[i] >= (unsigned)n) return bad("resampling index out of range");
+    dup[i] = seen[idx[i]];
+    seen[idx[i]] = 1;
+  }
+  // weights of the new set, renormalised in particle order (particle_filter.h:104)
+  std::vector<double> w(n);
+  double total = 0;
+  for (int i = 0; i < n; ++i) {
+    w[i] = all[idx[i]].weight;
+    total += w[i];
+  }
+  for (int i = 0; i < n; ++i) w[i] = w[i] / total;
+  bool has_master = false;
+  for (int i = 0; i < n; ++i) has_master |= (!dup[i] && all[idx[i]].is_master);
+  const int hv = heaviest(w);
+  std::vector<GmParticle> np(g->count);
+  for (int l = 0; l < g->count; ++l) {
+    const int i = g->first + l;
+    if (dup[i])
+      copy_as_duplicate(np[l], all[idx[i]]);
+    else
+      np[l] = all[idx[i]];
+    np[l].weight = w[i];
+    if (!has_master && i == hv) mark_master(np[l]);  // ensure_master_exists
+  }
+  g->p.swap(np);
+  g->all_w = w;
+  g->traversed[0] = g->traversed[1] = g->traversed[2] = 0;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                          const double *angle, const int *is_occ, const double odom_delta[3],
+                          uint32_t resample_seed, int *resampled, unsigned *idx_out) {
+  if (!g) return bad("null filter");
+  if (g->count != g->n_total) return bad("slamhip_gmapping_step needs the whole filter on one context");
+  std::vector<double> raw(g->n_total);
+  int rc = slamhip_gmapping_predict_match(g, map_id, n_raw, range, angle, is_occ, odom_delta, raw.data());
+  if (rc) return rc;
+  std::vector<unsigned> idx(g->n_total);
+  int req = 0;
+  rc = slamhip_gmapping_plan_resample(g, raw.data(), resample_seed, &req, idx.data());
+  if (rc) return rc;
+  if (req) {
+    std::vector<GmParticle> all(g->p);
+    rc = slamhip_gmapping_import(g, all.data(), idx.data());
+    if (rc) return rc;
+    if (idx_out) std::memcpy(idx_out, idx.data(), sizeof(unsigned) * g->n_total);
+  }
+  if (resampled) *resampled = req;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_set(slamhip_gmapping *g, const double *poses, const double *weights) {
+  if (!g) return bad("null filter");
+  for (int i = 0; i < g->count; ++i) {
+    if (poses) std::memcpy(g->p[i].pose, poses + 3 * i, sizeof(double) * 3);
+    if (weights) g->p[i].weight = weights[i];
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, int *is_master) {
+  if (!g) return bad("null filter");
+  for (int i = 0; i < g->count; ++i) {
+    if (poses) std::memcpy(poses + 3 * i, g->p[i].pose, sizeof(double) * 3);
+    if (weights) weights[i] = g->p[i].weight;
+    if (is_master) is_master[i] = g->p[i].is_master;
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
+                           long long *launches, long long *carry_reruns) {
+  if (!g) return bad("null filter");
+  if (scorer_calls) *scorer_calls = g->scorer_calls;
+  if (poses_evaluated) *poses_evaluated = g->poses_evaluated;
+  if (launches) *launches = g->launches;
+  if (carry_reruns) *carry_reruns = g->carry_reruns;
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"

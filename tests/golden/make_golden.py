@@ -18,6 +18,8 @@ Fixtures written (np.savez_compressed):
                     trig in raw|cached)
   hc_smoke.npz      the 7 cases of test/core/scan_matchers/hill_climbing_sm_smoke_test.cpp:72-105
   gmapping_scene.npz G1 for the GMapping 3x3 OOPE incl. the run-cache quirk, + HC(6,0.1,0.1) trace
+  gmapping_pf.npz   G5: multi-step GmappingParticleFilter runs (poses, weights, master flags,
+                    resampling decisions per step) with seeds injected
   resample.npz      G5: weights + seeds -> N_eff decision and resampling indices
   weights_ahr.npz   G4: angle-histogram weights on a noisy scan
   world_to_cells.npz  A16 ray-walk cell lists for random + axis-aligned + diagonal segments
@@ -268,6 +270,69 @@ def gen_gmapping_scene(R):
     save("gmapping_scene.npz", **out)
 
 
+def gen_gmapping_pf(R):
+    """G5: multi-step GmappingParticleFilter runs of the compiled reference with the map update
+    switched off through the reference's own parameter (slam/mapping/max_range = 0 makes
+    WallDistanceBlurringScanAdder::handle_scan_point return at once, grid_map_scan_adders.h:140-142),
+    so that particles only read the (pre-built) shared map."""
+    from pyoracle import RefGmapping
+    scale, n_cells = 0.05, 400
+    gt, pose0 = build_world(R, scale=scale, n=n_cells)
+    out = {}
+    scenarios = {
+        # default GMapping parameters (init_gmapping.h:15-34): big rotations pass the matching gate
+        "default": dict(gp=[0.0, 0.1, 0.0, 0.03, 0.6, 0.8, 0.3, 0.4],
+                        deltas=[[0.0, 0.0, 0.0], [0.02, 0.01, 0.45], [0.03, -0.02, -0.47],
+                                [0.01, 0.02, 0.5], [-0.02, 0.0, -0.44], [0.0, 0.01, 0.46]], n=12),
+        # gate forced open (sm_delta_lim min = max = 0, SURVEY 8d metric 2), small motions
+        "nogate": dict(gp=[0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0],
+                       deltas=[[0.0, 0.0, 0.0], [0.15, 0.05, 0.05], [0.2, -0.1, 0.08], [0.25, 0.1, -0.1],
+                               [0.1, 0.2, 0.12], [0.3, 0.05, 0.1], [0.2, 0.1, 0.05]], n=20),
+        # wide pose noise: weights diverge, N_eff drops and resampling (with duplicated particles,
+        # master hand-over) happens
+        "wide": dict(gp=[0.0, 0.3, 0.0, 0.12, 0.0, 0.0, 0.0, 0.0],
+                     deltas=[[0.0, 0.0, 0.0], [0.3, 0.2, 0.1], [0.35, -0.2, 0.15], [0.3, 0.3, -0.2],
+                             [0.4, 0.2, 0.25], [0.3, -0.3, 0.2], [0.35, 0.25, -0.15], [0.3, 0.3, 0.2],
+                             [0.4, -0.2, 0.25]], n=16),
+    }
+    for name, sc in scenarios.items():
+        n = sc["n"]
+        seeds = np.arange(1000, 1000 + n, dtype=np.uint32)
+        g = RefGmapping(R, n, n_cells, n_cells, scale, sc["gp"], seeds, skip_rate=3, map_max_range=0.0)
+        mview = g.map()
+        raw = R.scan_generate(gt, pose0, 15, 270, 720)
+        rs = np.random.RandomState(77)
+        for _k in range(5):
+            jit = np.array(pose0) + rs.randn(3) * [0.01, 0.01, 0.002]
+            R.append_scan(mview, raw, jit, quality=1.0, blur=0.0)
+        md = crop(mview.to_data(), 80, (-35, -30), (35, 30))
+        out.update({name + "_" + k: v for k, v in map_fields(md).items()})
+        out[name + "_gp"] = np.array(sc["gp"])
+        out[name + "_seeds"] = seeds
+        out[name + "_deltas"] = np.array(sc["deltas"])
+        true = np.zeros(3)  # particles start at the origin; the robot's true pose is pose0 + odometry
+        for k, d in enumerate(sc["deltas"]):
+            true = true + np.array(d)
+            tp = np.array(pose0) + true - np.array([0, 0, 0])
+            # cell-boundary poses are rejected by the generator: nudge by a fraction of a cell
+            tp[:2] = (np.floor(tp[:2] / scale) + 0.5) * scale
+            scan = R.scan_generate(gt, tp, 15, 270, 720)
+            r, a, o, _ = scan.get()
+            # the filter believes odometry: first delta places the particles at pose0
+            dd = np.array(pose0) if k == 0 else np.array(d)
+            extra = np.arange(5000 + 100 * k, 5000 + 100 * k + n, dtype=np.uint32)
+            res, poses, w, ms = g.step(scan, dd, 7 + k, extra)
+            out["%s_step%d_range" % (name, k)] = r
+            out["%s_step%d_angle" % (name, k)] = a
+            out["%s_step%d_delta" % (name, k)] = dd
+            out["%s_step%d_resampled" % (name, k)] = np.array(int(res))
+            out["%s_step%d_poses" % (name, k)] = poses
+            out["%s_step%d_weights" % (name, k)] = w
+            out["%s_step%d_master" % (name, k)] = ms
+        out[name + "_n_steps"] = np.array(len(sc["deltas"]))
+    save("gmapping_pf.npz", **out)
+
+
 def gen_resample(R):
     rs = np.random.RandomState(5)
     out = {}
@@ -347,6 +412,7 @@ def main():
     gen_scene(R, REF_CELL_AFFINE, "affine", 0, "even", TRIG_RAW, "raw", std_base)
     gen_hc_smoke(R)
     gen_gmapping_scene(R)
+    gen_gmapping_pf(R)
     gen_resample(R)
     gen_weights_ahr(R)
     gen_world_to_cells(R)

@@ -274,3 +274,57 @@ def test_map_mirror_dirty_log_and_growth(pkg, ctx, po, oracle):
 
 def test_smoke_entry(pkg):
     ge.smoke()
+
+
+@pytest.mark.parametrize("scenario", ["default", "nogate", "wide"])
+def test_gmapping_filter_vs_reference_golden(pkg, ctx, scenario):
+    """G5 through the C-ABI: several GmappingParticleFilter::handle_sensor_data steps (gate, pose
+    noise, lock-step HC matching with the shared OOPE cache, weights, N_eff, resampling with
+    duplicated particles, master hand-over) against the compiled reference."""
+    g = load("gmapping_pf.npz")
+    m = map_from(g, scenario + "_map_")
+    ctx.upload_map(5, m)
+    n = len(g[scenario + "_seeds"])
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g[scenario + "_gp"], skip_rate=3, pose_trig=1),
+                            n, g[scenario + "_seeds"])
+    resampled_any = False
+    for k in range(int(g[scenario + "_n_steps"])):
+        pre = "%s_step%d_" % (scenario, k)
+        res, _idx = pf.step(5, g[pre + "range"], g[pre + "angle"], None, g[pre + "delta"], 7 + k)
+        poses, w, ms = pf.state()
+        assert res == bool(int(g[pre + "resampled"])), k
+        np.testing.assert_array_equal(ms, g[pre + "master"])
+        np.testing.assert_allclose(poses, g[pre + "poses"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(w, g[pre + "weights"], rtol=1e-9, atol=0)
+        resampled_any |= res
+    assert resampled_any == (scenario == "wide")
+    ctx.map_release(5)
+
+
+def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle):
+    """BASELINE cfg-4 shape (100 particles, 1080 beams, GMapping cell/OOPE, HC(6, 0.1, 0.1)) on a
+    2000x2000 @0.05 m map: the lock-step GPU filter against the sequential CPU oracle."""
+    from synth import make_scene
+    sc = make_scene(cell_model=2, size=2000, scale=0.05, n_beams=1080, seed=11)
+    m, scan = sc["map"], sc["scan"]
+    ctx.upload_map(6, m)
+    n = 100
+    seeds = np.arange(1000, 1000 + n, dtype=np.uint32)
+    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]  # gate open: every particle matches (SURVEY 8d)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, pose_trig=1), n, seeds)
+    opf = oracle.gmapping_create(n, gp, seeds)
+    deltas = [sc["true_pose"], [0.02, 0.01, 0.01], [0.4, 0.5, 0.3], [0.01, -0.02, 0.02]]
+    for k, d in enumerate(deltas):
+        res, idx = pf.step(6, scan.range, scan.angle, None, d, 7 + k)
+        ores, oidx = opf.step(m, scan.range, scan.angle, None, d, 7 + k)
+        poses, w, ms = pf.state()
+        oposes, ow, oms = opf.state()
+        assert res == ores
+        if res:
+            np.testing.assert_array_equal(idx, oidx)  # resampling indices bit-exact
+        np.testing.assert_array_equal(ms, oms)
+        np.testing.assert_allclose(poses, oposes, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(w, ow, rtol=1e-9, atol=0)
+        st = pf.stats()
+        assert st["scorer_calls"] == opf.o.lib.orc_gmapping_scorer_calls(opf.h)
+    ctx.map_release(6)

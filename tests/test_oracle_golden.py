@@ -145,3 +145,27 @@ def test_world_to_cells_golden(oracle):
     for i, s in enumerate(g["segments"]):
         got = oracle.world_to_cells(float(g["scale"]), *s)
         np.testing.assert_array_equal(got, g["cells"][g["offsets"][i]:g["offsets"][i + 1]])
+
+
+@pytest.mark.parametrize("scenario", ["default", "nogate", "wide"])
+def test_gmapping_particle_filter_steps(oracle, scenario):
+    """G5: GmappingParticleFilter::handle_sensor_data over several scans (gate, pose noise, HC
+    match with the shared OOPE cache, weights, N_eff test, resampling with duplicated particles and
+    master hand-over) against the compiled reference; map update off via max_range = 0."""
+    g = load("gmapping_pf.npz")
+    m = map_from(g, scenario + "_map_")
+    n = len(g[scenario + "_seeds"])
+    pf = oracle.gmapping_create(n, g[scenario + "_gp"], g[scenario + "_seeds"], skip_rate=3)
+    any_resampled = False
+    for k in range(int(g[scenario + "_n_steps"])):
+        pre = "%s_step%d_" % (scenario, k)
+        extra = np.arange(5000 + 100 * k, 5000 + 100 * k + n, dtype=np.uint32)
+        res, _idx = pf.step(m, g[pre + "range"], g[pre + "angle"], None, g[pre + "delta"], 7 + k, extra)
+        poses, w, ms = pf.state()
+        assert res == bool(int(g[pre + "resampled"])), k
+        np.testing.assert_array_equal(ms, g[pre + "master"])
+        np.testing.assert_allclose(poses, g[pre + "poses"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(w, g[pre + "weights"], rtol=1e-10, atol=0)
+        any_resampled |= res
+    if scenario == "wide":
+        assert any_resampled
