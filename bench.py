@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--sweep-poses", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--particles", type=int, default=100)
+    ap.add_argument("--pf-size", type=int, default=4000)
+    ap.add_argument("--pf-steps", type=int, default=10)
+    ap.add_argument("--no-pf", action="store_true", help="skip the GMapping particle-filter leg")
     ap.add_argument("--strict", action="store_true",
                     help="bit-exact mode (sequential sum + host pose trig) instead of the default")
     return ap.parse_args()
@@ -91,6 +95,106 @@ def cpu_baseline(sc, kind, params, seconds):
             "sample": "%d x process_scan (%s %s) on the same scene, %.1f s, oracle/slam_oracle.c -O2, "
                       "flat-array map; host CPU: %s, %d logical cores visible"
                       % (reps, kind, params, t_used, model, os.cpu_count() or 0)}
+
+
+def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
+    """BASELINE cfg 4: GMapping filter, `--particles` particles sharded over the ranks (contiguous
+    blocks), 1080-beam scan, 4000x4000 @0.05 m GMapping-cell map replicated per GPU (the reference's
+    particles share one map), HC(6, 0.1, 0.1), gate open so every particle matches on every scan.
+    One collective per step: all-gather of the raw weights over RCCL (plus the particle records
+    when a resampling happens).  Strong scaling: the particle count is fixed."""
+    from synth import make_scene
+    n = args.particles
+    if n % world:
+        return {"skipped": "particles %d not divisible by %d ranks" % (n, world)}
+    sc = make_scene(cell_model=2, size=args.pf_size, scale=args.scale, n_beams=args.beams, seed=4)
+    ctx.upload_map(1, sc["map"])
+    count = n // world
+    first = rank * count
+    seeds = np.arange(1000, 1000 + n, dtype=np.uint32)[first:first + count]
+    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
+    scan = sc["scan"]
+    dev = torch.device("cuda", local_rank)
+
+    def gather(a, dtype):
+        if world == 1:
+            return np.asarray(a)
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        out = torch.empty(world * t.numel(), dtype=dtype, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+
+    rs = np.random.RandomState(5)
+    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(args.pf_steps + 2)]
+    calls = 0
+    resamplings = 0
+
+    def one(k):
+        nonlocal calls, resamplings
+        raw = pf.predict_match(1, scan.range, scan.angle, None, deltas[k])
+        calls += pf.stats()["scorer_calls"]
+        allw = gather(raw, torch.float64)
+        req, idx = pf.plan_resample(allw, 7 + k)
+        if req:
+            resamplings += 1
+            pf.import_(gather(pf.export(), torch.uint8), idx)
+
+    for k in range(2):
+        one(k)
+    calls = 0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(2, 2 + args.pf_steps):
+        one(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = pf.stats()
+    if world > 1:
+        tt = torch.tensor([dt, float(calls)], dtype=torch.float64, device=dev)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, calls = mx[0].item(), sm[1].item()
+    ctx.map_release(1)
+    return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
+            "ms_per_step": 1e3 * dt / args.pf_steps, "steps": args.pf_steps, "scaling": "strong",
+            "pose_candidates_beams_per_s": calls * scan.n / dt,
+            "workload": "cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "
+                        "GMapping cell, HC(6,0.1,0.1), likelihood step without map update"
+                        % (n, world, scan.n, args.pf_size, args.pf_size, args.scale),
+            "collective": "all_gather(raw weights) over RCCL per step" if world > 1 else "none (1 rank)",
+            "launches_last_step": st["launches"], "carry_reruns_last_step": st["carry_reruns"],
+            "resamplings": resamplings}
+
+
+def pf_cpu_baseline(args, seconds):
+    """The oracle's sequential filter step on a small particle sample of the same scene."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from synth import make_scene
+    sc = make_scene(cell_model=2, size=min(args.pf_size, 2000), scale=args.scale, n_beams=args.beams, seed=4)
+    O = po.Oracle()
+    n = 8
+    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+    pf = O.gmapping_create(n, gp, np.arange(1000, 1000 + n, dtype=np.uint32))
+    scan = sc["scan"]
+    pf.step(sc["map"], scan.range, scan.angle, None, sc["true_pose"], 7)
+    rs = np.random.RandomState(5)
+    steps, t_used = 0, 0.0
+    while t_used < seconds and steps < 50:
+        t0 = time.perf_counter()
+        pf.step(sc["map"], scan.range, scan.angle, None, rs.randn(3) * [0.05, 0.05, 0.02], 8 + steps)
+        t_used += time.perf_counter() - t0
+        steps += 1
+    return {"value": n * steps / t_used, "unit": "particles/s", "cores": 1, "kind": "port",
+            "sample": "%d filter steps of %d particles (oracle, sequential, 2000^2 map window), %.1f s"
+                      % (steps, n, t_used)}
 
 
 def main():
@@ -183,6 +287,10 @@ def main():
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
         t_max, units_all = tt.item(), uu.item()
 
+    pf_out = None
+    if not args.no_pf and args.workload != "sweep":
+        pf_out = particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch)
+
     if rank == 0:
         bpu = BYTES_PER_UNIT[bkey]
         achieved = (k_units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -210,10 +318,12 @@ def main():
                          "launches": k_launches, "units_launched": k_units,
                          "avg_launch_us": 1e3 * k_ms / max(k_launches, 1)},
         }
-        if world == 1 and not args.no_cpu and args.workload != "sweep":
+        if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds)
-        elif world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds)
+        if pf_out is not None:
+            out["particle_filter"] = pf_out
+            if world == 1 and not args.no_cpu and "value" in pf_out:
+                pf_out["cpu_baseline"] = pf_cpu_baseline(args, min(args.cpu_seconds, 8.0))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

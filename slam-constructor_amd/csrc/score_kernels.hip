@@ -361,6 +361,133 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   }
 }
 
+// ---- K2: window OOPEs (max / mean / overlap) ------------------------------------------------------
+// MaxOccupancyObservationPE / MeanOccupancyObservationPE / OverlapWeightedOccupancyObservationPE
+// (src/core/scan_matchers/occupancy_observation_probability.h:29-99) over GridRasterizedRectangle
+// (src/core/maps/grid_rasterization.h:26-64: x outer, y inner) and LightWeightRectangle::overlap /
+// intersect_internal (src/core/geometry_primitives.h:205-310) with the reference's fuzzy
+// comparisons (src/core/math_utils.h:15-25,37-51).  Sums run in the reference's cell order, so
+// per-beam values are bit-identical to the CPU path.
+struct Lwr {
+  double bot, top, left, right;
+};
+__device__ __forceinline__ bool fz_equal(double a, double b) {
+  const double m = fmax(fabs(a), fabs(b));
+  return fabs(a - b) <= 1e-7 * fmax(1.0, m);
+}
+__device__ __forceinline__ bool fz_less(double a, double b) { return a < b + 2.220446049250313e-16; }
+__device__ __forceinline__ bool fz_le(double a, double b) { return fz_equal(a, b) || fz_less(a, b); }
+__device__ __forceinline__ bool fz_ordered(double a, double b, double c) { return fz_le(a, b) && fz_le(b, c); }
+__device__ __forceinline__ double lwr_area(const Lwr &r) { return (r.top - r.bot) * (r.right - r.left); }
+__device__ __forceinline__ bool lwr_contains(const Lwr &r, double x, double y) {
+  return fz_ordered(r.left, x, r.right) && fz_ordered(r.bot, y, r.top);
+}
+__device__ Lwr lwr_intersect(const Lwr &self, const Lwr &that, bool reversed) {
+  unsigned nm = 0;
+  double cl = self.left, cr = self.right, ct = self.top, cb = self.bot;
+  if (lwr_contains(self, that.left, that.bot)) { ++nm; cl = that.left; cb = that.bot; }
+  if (lwr_contains(self, that.right, that.bot)) { ++nm; cr = that.right; cb = that.bot; }
+  if (lwr_contains(self, that.left, that.top)) { ++nm; cl = that.left; ct = that.top; }
+  if (lwr_contains(self, that.right, that.top)) { ++nm; cr = that.right; ct = that.top; }
+  if (nm == 0) {
+    if (reversed) return Lwr{0, 0, 0, 0};
+    return lwr_intersect(that, self, true);
+  }
+  return Lwr{cb, ct, cl, cr};
+}
+__device__ double lwr_overlap(const Lwr &self, const Lwr &that) {
+  if (lwr_area(self) != 0) return lwr_area(lwr_intersect(self, that, false)) / lwr_area(self);
+  if (lwr_area(that) != 0) return lwr_contains(that, self.left, self.bot) ? 1.0 : 0.0;
+  return (fz_equal(self.top, that.top) && fz_equal(self.bot, that.bot) && fz_equal(self.left, that.left) &&
+          fz_equal(self.right, that.right)) ? 1.0 : 0.0;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) {
+  __shared__ double s_pose[kMaxPosesPerBlock][4];
+  __shared__ double s_part[kMaxPosesPerBlock][4];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int n = a.scan.n;
+  const int p0 = blockIdx.x * a.poses_per_block;
+  const int npb = min(a.poses_per_block, a.n_poses - p0);
+  if (t < npb) {
+    const int p = p0 + t;
+    double sn, cs;
+    if (a.pose_sc) {
+      sn = a.pose_sc[2 * p];
+      cs = a.pose_sc[2 * p + 1];
+    } else {
+      sincos(a.poses[3 * p + 2], &sn, &cs);
+    }
+    s_pose[t][0] = a.poses[3 * p];
+    s_pose[t][1] = a.poses[3 * p + 1];
+    s_pose[t][2] = sn;
+    s_pose[t][3] = cs;
+  }
+  __syncthreads();
+  const double scale = a.map.scale;
+  const double half_v = (a.area[1] - a.area[0]) / 2, half_h = (a.area[3] - a.area[2]) / 2;
+  for (int j = 0; j < npb; ++j) {
+    const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
+    double acc = 0.0;
+    for (int b = t; b < n; b += kBlock) {
+      const double ca = a.scan.cos_a[b], sa = a.scan.sin_a[b], r = a.scan.range[b];
+      const double c = cs * ca - sn * sa;
+      const double s = sn * ca + cs * sa;
+      const double ox = x + r * c, oy = y + r * s;
+      const Lwr area{oy - half_v, oy + half_v, ox - half_h, ox + half_h};
+      const double ar = lwr_area(area);
+      int lbx, lby, rtx, rty;
+      if (ar != 0 && ar != __builtin_inf()) {
+        lbx = to_cell(area.left, scale);
+        lby = to_cell(area.bot, scale);
+        rtx = to_cell(area.right, scale);
+        rty = to_cell(area.top, scale);
+      } else if (ar == 0) {
+        lbx = rtx = to_cell(area.left, scale);
+        lby = rty = to_cell(area.bot, scale);
+      } else {
+        lbx = -a.map.origin_x;
+        lby = -a.map.origin_y;
+        rtx = a.map.width - 1 - a.map.origin_x;
+        rty = a.map.height - 1 - a.map.origin_y;
+      }
+      double tot_p = 0, tot_w = 0, mx = 0;
+      unsigned cnt = 0;
+      for (int cx = lbx; cx <= rtx; ++cx)
+        for (int cy = lby; cy <= rty; ++cy) {
+          const double impact = point_probability<MODEL>(a.map, a.oie, cx, cy);
+          if (oope == SLAMHIP_OOPE_MAX) {
+            mx = impact < mx ? mx : impact;
+          } else if (oope == SLAMHIP_OOPE_MEAN) {
+            tot_p += impact;
+            cnt += 1;
+          } else {
+            const Lwr cb{scale * cy, scale * (cy + 1), scale * cx, scale * (cx + 1)};
+            const double w = lwr_overlap(area, cb);
+            tot_p += impact * w;
+            tot_w += w;
+          }
+        }
+      double pr;
+      if (oope == SLAMHIP_OOPE_MAX) pr = mx;
+      else if (oope == SLAMHIP_OOPE_MEAN) pr = cnt ? tot_p / cnt : 0.5;
+      else pr = tot_w != 0 ? tot_p / tot_w : 0.5;
+      const double term = pr * a.scan.weight[b] * a.scan.factor[b];
+      if (a.terms) a.terms[(size_t)(p0 + j) * n + b] = term;
+      acc = acc + term;
+    }
+    acc = wave_xor_sum(acc);
+    if (lane == 0) s_part[j][wave] = acc;
+  }
+  __syncthreads();
+  if (t < npb) {
+    const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
+    a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+  }
+}
+
 // ---- launch ------------------------------------------------------------------------------------
 template <int MODEL, bool WT>
 static hipError_t launch_point_kb(const ScoreArgs &a, int kb, dim3 grid, hipStream_t st) {
@@ -407,7 +534,16 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
 #undef GM_CASE
     return hipGetLastError();
   }
-  if (cell_model == SLAMHIP_CELL_OCC) {
+  if (oope == SLAMHIP_OOPE_MAX || oope == SLAMHIP_OOPE_MEAN || oope == SLAMHIP_OOPE_OVERLAP) {
+    if (!wt) a.terms = nullptr;
+    if (cell_model == SLAMHIP_CELL_OCC)
+      hipLaunchKernelGGL((k_score_window<SLAMHIP_CELL_OCC>), grid, dim3(kBlock), 0, stream, a, oope);
+    else if (cell_model == SLAMHIP_CELL_TBM)
+      hipLaunchKernelGGL((k_score_window<SLAMHIP_CELL_TBM>), grid, dim3(kBlock), 0, stream, a, oope);
+    else
+      return hipErrorInvalidValue;
+    e = hipGetLastError();
+  } else if (cell_model == SLAMHIP_CELL_OCC) {
     e = wt ? launch_point_kb<SLAMHIP_CELL_OCC, true>(a, kb, grid, stream)
            : launch_point_kb<SLAMHIP_CELL_OCC, false>(a, kb, grid, stream);
   } else if (cell_model == SLAMHIP_CELL_TBM) {

@@ -77,9 +77,16 @@ static int check_cfg(const DeviceMap &m, const slamhip_spe_cfg *cfg) {
     if (cfg->gm_window < 0 || cfg->gm_window > 4) return invalid("gm_window out of range");
     return SLAMHIP_OK;
   }
+  if (cfg->oope < SLAMHIP_OOPE_OBSTACLE || cfg->oope > SLAMHIP_OOPE_GMAPPING)
+    return invalid("unknown OOPE kind");
   if (cfg->oope != SLAMHIP_OOPE_OBSTACLE) {
-    g_last_error = "window OOPEs (max/mean/overlap) are not built yet (SURVEY 8f N4)";
-    return SLAMHIP_ERR_UNSUPPORTED;
+    if (!(cfg->area[0] <= cfg->area[1] && cfg->area[2] <= cfg->area[3]))
+      return invalid("sp_analysis_area needs bot <= top and left <= right");
+    const double cells = ((cfg->area[1] - cfg->area[0]) / m.scale + 2) * ((cfg->area[3] - cfg->area[2]) / m.scale + 2);
+    if (!(cells < 1e4)) {
+      g_last_error = "sp_analysis_area covers more than 10^4 cells per beam";
+      return SLAMHIP_ERR_UNSUPPORTED;
+    }
   }
   if (m.cell_model == SLAMHIP_CELL_GMAPPING)
     return invalid("obstacle OOPE over a GMAPPING payload: upload prob_occ as an OCC map");

@@ -328,3 +328,50 @@ def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle):
         st = pf.stats()
         assert st["scorer_calls"] == opf.o.lib.orc_gmapping_scorer_calls(opf.h)
     ctx.map_release(6)
+
+
+def test_window_oopes_vs_reference(pkg, ctx, po, oracle):
+    """K2: max / mean / overlap OOPEs -- the 18 known-answer cases of the reference
+    (occupancy_observation_probability_test.cpp:59-207) as one-beam scans, and the scene goldens."""
+    from synth import Scan
+    g = load("oope_known.npz")
+    m = map_from(g)
+    ctx.upload_map(0, m)
+    one = Scan([0.0], [0.0], [1.0])
+    upload_scene(pkg, ctx, m, one)
+    eps = np.finfo(np.float64).eps
+    for kind, lit, ref_out, obst, r in zip(g["kinds"], g["expected_literal"], g["reference_out"],
+                                          g["obstacle"], g["range4"]):
+        cfg = pkg.spe_cfg(oope=int(kind), area=r, **STRICT)
+        got = ctx.score_poses(0, cfg, [[obst[0], obst[1], 0.0]])[0]
+        assert got == ref_out and abs(got - lit) <= eps, (kind, obst, r, got, ref_out)
+    for scene in ("mean_raw", "tbm_cached"):
+        g = load("scene_%s.npz" % scene)
+        m, scan = map_from(g), filtered_scan(g)
+        upload_scene(pkg, ctx, m, scan)
+        for name, kind in (("max", pkg.OOPE_MAX), ("mean", pkg.OOPE_MEAN), ("overlap", pkg.OOPE_OVERLAP)):
+            got = ctx.score_poses(0, pkg.spe_cfg(oope=kind, area=g["win_area"], **STRICT), g["poses"][:24])
+            if name == "overlap" and scene.endswith("raw"):
+                # overlap weights depend continuously on the endpoint: with the raw trig provider
+                # the reference's libm sin(theta + a) and the device's angle-addition form differ
+                # in the last ulp (DESIGN.md section 5); exact with the cached provider
+                np.testing.assert_allclose(got, g["win_%s_scores" % name], rtol=1e-13, atol=0)
+            else:
+                np.testing.assert_array_equal(got, g["win_%s_scores" % name], err_msg=name + scene)
+            dflt = ctx.score_poses(0, pkg.spe_cfg(oope=kind, area=g["win_area"]), g["poses"][:24])
+            np.testing.assert_allclose(dflt, g["win_%s_scores" % name], rtol=1e-12, atol=0)
+
+
+def test_brute_force_matcher_vs_oracle(pkg, ctx, po, oracle):
+    """N1: BruteForceScanMatcher (brute_force_scan_matcher.h:10-81) -- the embarrassingly parallel
+    caller of the same scorer; p2D_ss_evaluator-style sweep."""
+    g = load("scene_mean_raw.npz")
+    m, scan = map_from(g), filtered_scan(g)
+    upload_scene(pkg, ctx, m, scan)
+    rng9 = [-0.3, 0.3, 0.05, -0.2, 0.2, 0.05, -0.06, 0.06, 0.02]
+    mt = pkg.Matcher(ctx, "BF", pkg.spe_cfg(**STRICT), rng9)
+    t = mt.process_scan(0, g["init_pose"], trace=True)
+    e = oracle.enumerator(po.SM_BF, rng9)
+    r = oracle.process_scan(e, m, scan, po.make_cfg(), g["init_pose"])
+    assert_trace_equal(t, r)
+    assert mt.stats()["launches"] <= 2 and t["n_calls"] > 500
