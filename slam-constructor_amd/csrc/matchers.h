@@ -352,6 +352,11 @@ struct SpecTree {
   // chain builds only: the enumerator state after every chain candidate was rejected
   std::unique_ptr<PoseEnumerator> chain_end;
 
+  // reach probability below which a round instance is not worth speculating: a lone matcher trades
+  // ~20 us round trips against cheap evaluations (1 %); a filter that shares every launch among
+  // all its particles pays per evaluation instead and wants a much higher bar
+  double min_reach = 0.01;
+
   void build(const PoseEnumerator &real, const Pose &best, int budget, double p_accept) {
     nodes.clear();
     evals.clear();
@@ -431,7 +436,7 @@ private:
     while (!heap_.empty() && (int)evals.size() + 6 <= budget) {
       // an instance reached with probability P saves ~P round trips (~20 us each) and costs host
       // time plus six evaluations: not worth it below ~1 %
-      if (!evals.empty() && heap_.front().prio < 0.01) break;
+      if (!evals.empty() && heap_.front().prio < min_reach) break;
       std::pop_heap(heap_.begin(), heap_.end());
       Inst in = std::move(heap_.back());
       heap_.pop_back();

@@ -68,8 +68,21 @@ hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream) {
 }
 
 // world_to_cell: int(floor(x / scale)) with a TRUE division (Q15: multiplying by 1/scale flips
-// cells at boundaries).
-__device__ __forceinline__ int to_cell(double v, double scale) { return (int)floor(v / scale); }
+// cells at boundaries).  The division is the most expensive thing in the per-beam body, so it is
+// only executed when it can matter: with t = v/scale, RN(t) is within 2^-53 |t| of t and
+// q = RN(v * RN(1/scale)) within 2^-52 |t|, hence no integer separates q from RN(t) unless q lies
+// within 1.5 * 2^-52 |q| of one.  Outside a 2^-49 |q| band around integers floor(q) IS the
+// reference's cell; inside it (endpoints exactly on cell boundaries do occur, e.g. the reference's
+// HC smoke fixture) the true quotient is evaluated.  The absolute term sends underflowing products
+// to the exact path as well.
+__device__ __forceinline__ int to_cell(double v, double scale, double inv_scale) {
+  const double q = v * inv_scale;
+  const double f = floor(q);
+  const double d = q - f;
+  const double tol = fabs(q) * 0x1p-49 + 0x1p-1000;
+  if (__builtin_expect(d < tol || (1.0 - d) < tol, 0)) return (int)floor(v / scale);
+  return (int)f;
+}
 
 template <int MODEL>
 __device__ __forceinline__ double point_probability(const MapView &m, int oie, int cx, int cy) {
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
   }
   __syncthreads();
 
-  const double scale = a.map.scale;
+  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
     double acc = 0.0;
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
           const double s = sn * bc[k] + cs * bs[k];
           const double wx = x + br[k] * c;
           const double wy = y + br[k] * s;
-          const double pr = point_probability<MODEL>(a.map, a.oie, to_cell(wx, scale), to_cell(wy, scale));
+          const double pr = point_probability<MODEL>(a.map, a.oie, to_cell(wx, scale, inv_scale), to_cell(wy, scale, inv_scale));
           const double term = pr * bw[k] * bf[k];
           if (WRITE_TERMS) a.terms[(size_t)(p0 + j) * n + b] = term;
           acc = acc + term;
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
         const double s = sn * ca + cs * sa;
         const double wx = x + r * c;
         const double wy = y + r * s;
-        const double pr = point_probability<MODEL>(a.map, a.oie, to_cell(wx, scale), to_cell(wy, scale));
+        const double pr = point_probability<MODEL>(a.map, a.oie, to_cell(wx, scale, inv_scale), to_cell(wy, scale, inv_scale));
         const double term = pr * a.scan.weight[b] * a.scan.factor[b];
         if (WRITE_TERMS) a.terms[(size_t)(p0 + j) * n + b] = term;
         acc = acc + term;
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   }
   __syncthreads();
 
-  const double scale = a.map.scale;
+  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
     int ccx[KB], ccy[KB];
@@ -290,8 +303,8 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
         const double s = sn * bc[k] + cs * bs[k];
         const double wx = x + br[k] * c;
         const double wy = y + br[k] * s;
-        ccx[k] = to_cell(wx, scale);
-        ccy[k] = to_cell(wy, scale);
+        ccx[k] = to_cell(wx, scale, inv_scale);
+        ccy[k] = to_cell(wy, scale, inv_scale);
         s_val[b] = gm_fresh_value(a.map, a.gm, ccx[k], ccy[k], wx, wy);
         if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
       }
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
     s_pose[t][3] = cs;
   }
   __syncthreads();
-  const double scale = a.map.scale;
+  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   const double half_v = (a.area[1] - a.area[0]) / 2, half_h = (a.area[3] - a.area[2]) / 2;
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
@@ -440,13 +453,13 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
       const double ar = lwr_area(area);
       int lbx, lby, rtx, rty;
       if (ar != 0 && ar != __builtin_inf()) {
-        lbx = to_cell(area.left, scale);
-        lby = to_cell(area.bot, scale);
-        rtx = to_cell(area.right, scale);
-        rty = to_cell(area.top, scale);
+        lbx = to_cell(area.left, scale, inv_scale);
+        lby = to_cell(area.bot, scale, inv_scale);
+        rtx = to_cell(area.right, scale, inv_scale);
+        rty = to_cell(area.top, scale, inv_scale);
       } else if (ar == 0) {
-        lbx = rtx = to_cell(area.left, scale);
-        lby = rty = to_cell(area.bot, scale);
+        lbx = rtx = to_cell(area.left, scale, inv_scale);
+        lby = rty = to_cell(area.bot, scale, inv_scale);
       } else {
         lbx = -a.map.origin_x;
         lby = -a.map.origin_y;

@@ -110,6 +110,7 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
   a->map.origin_x = m.origin_x;
   a->map.origin_y = m.origin_y;
   a->map.scale = m.scale;
+  a->map.inv_scale = 1.0 / m.scale;
   for (int k = 0; k < 4; ++k) a->map.unknown[k] = m.unknown[k];
   const size_t c = ctx->scan_cap;
   a->scan.range = ctx->d_scan;

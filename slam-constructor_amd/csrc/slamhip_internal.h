@@ -19,7 +19,7 @@ struct MapView {
   const double *payload;
   int width, height, pitch;
   int origin_x, origin_y;
-  double scale;
+  double scale, inv_scale;  // inv_scale = RN(1 / scale), see to_cell()
   double unknown[4];
 };
 

@@ -375,3 +375,28 @@ def test_brute_force_matcher_vs_oracle(pkg, ctx, po, oracle):
     r = oracle.process_scan(e, m, scan, po.make_cfg(), g["init_pose"])
     assert_trace_equal(t, r)
     assert mt.stats()["launches"] <= 2 and t["n_calls"] > 500
+
+
+@pytest.mark.parametrize("scale", [0.05, 0.1, 0.025, 1.0 / 3.0, 0.07])
+def test_cell_index_on_boundaries_matches_true_division(pkg, ctx, po, oracle, scale):
+    """to_cell() multiplies by 1/scale and falls back to the true quotient near integers: every
+    cell of the map holds a different value, endpoints sit exactly on (or one ulp off) cell
+    boundaries, so one wrong floor(x / scale) changes a score."""
+    from synth import MapData, Scan
+    rs = np.random.RandomState(int(scale * 1000))
+    pay = rs.rand(96, 96)
+    m = MapData(0, pay[:, :, None], (48, 48), scale, [0.5])
+    k = rs.randint(1, 30, 512)
+    r = k * scale  # ranges that are whole numbers of cells
+    a = rs.choice([0.0, np.pi / 2, np.pi, -np.pi / 2, np.pi / 4], 512)
+    scan = Scan(r, a, np.full(512, 1 / 512))
+    upload_scene(pkg, ctx, m, scan)
+    base = rs.randint(-10, 10, (256, 2)) * scale
+    poses = np.zeros((256 * 3, 3))
+    poses[:256, :2] = base
+    poses[256:512, :2] = np.nextafter(base, np.inf)
+    poses[512:, :2] = np.nextafter(base, -np.inf)
+    poses[:, 2] = rs.choice([0.0, np.pi / 2, -np.pi / 2], 768)
+    got = ctx.score_poses(0, pkg.spe_cfg(**STRICT), poses)
+    want = oracle.score_poses(m, scan, po.make_cfg(), poses)
+    np.testing.assert_array_equal(got, want)

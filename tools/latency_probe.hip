@@ -51,6 +51,24 @@ __global__ void k_io_plain(const double *in, double *out, int spin) {
 __global__ void k_publish(unsigned *flag, unsigned seq) {
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// in-kernel completion with RELAXED agent-scope arrival counting: every workgroup drains its own
+// stores (s_waitcnt vmcnt(0)), the last one to arrive publishes the flag
+__global__ void k_io_count(const double *in, double *out, unsigned *counter, unsigned *flag, unsigned seq, int spin) {
+  __shared__ double s[3];
+  if (threadIdx.x < 3) s[threadIdx.x] = in[3 * blockIdx.x + threadIdx.x];
+  __syncthreads();
+  double v = s[0] + s[1] + s[2];
+  for (int i = 0; i < spin; ++i) v = v * 1.0000001 + 1e-9;
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = v;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main() {
@@ -97,6 +115,18 @@ int main() {
       for (int b = 0; b < P; ++b) if (h_out[b] != 3.0 * it + 9.0 * b + 3.0) ++bad;
     }
     printf("publish-kernel hand-off: %d stale words in 2000 x %d\n", bad, P);
+  }
+  run("count io host-in/host-out relaxed arrivals + spin", [&] { ++seq; hipLaunchKernelGGL(k_io_count, dim3(P), dim3(256), 0, st, h_in, h_out, counter, flag, seq, 0); while (*vf != seq) __builtin_ia32_pause(); });
+  {
+    int bad = 0;
+    for (int it = 0; it < 4000; ++it) {
+      ++seq;
+      for (int i = 0; i < 3 * P; ++i) h_in[i] = it + i;
+      hipLaunchKernelGGL(k_io_count, dim3(P), dim3(256), 0, st, h_in, h_out, counter, flag, seq, (it % 7) * 50);
+      while (*vf != seq) __builtin_ia32_pause();
+      for (int b = 0; b < P; ++b) if (h_out[b] < 3.0 * it + 9.0 * b + 3.0 - 1e-6) ++bad;
+    }
+    printf("relaxed-arrival hand-off: %d stale words in 4000 x %d\n", bad, P);
   }
   // host writes straight into device memory through the BAR?
   double *fg = nullptr;
