@@ -1,0 +1,161 @@
+/* oracle/map_update_oracle.c -- TEST INFRASTRUCTURE ONLY (part of liboracle.so).
+ *
+ * CPU restatement of the map update (const occupancy estimator):
+ *   GridMapScanAdder::append_scan                 src/core/maps/grid_map_scan_adders.h:54-75
+ *   WallDistanceBlurringScanAdder::handle_scan_point  :138-172, blur_cell_dist :176-189
+ *   ConstOccupancyEstimator                       src/core/maps/const_occupancy_estimator.h:6-17
+ *   cell updates: GridCell::operator+= (grid_cell.h:27-30), AffineQualityMergeCell (naive_grid_cells.h:14-20),
+ *     MeanProbabilityCell (:33-40), TbmBaseCell (tbm_grid_cells.h:12-19, aoo2tbm :57-66,
+ *     transferable_belief_model.h:102-143), GmappingBaseCell (src/slams/gmapping/gmapping_grid_cell.h:20-33)
+ * The ray walk is orc_world_to_cells (slam_oracle.c).  Pinned by tests/golden/map_update.npz
+ * (payloads and update counters exported from the compiled reference after every scan).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "slam_oracle.h"
+
+static void tbm_conj(const double *lhs, const double *rhs, double *out) {
+  double tmp[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) tmp[a | b] += lhs[a] * rhs[b];
+  double tot = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  if (tot == 0.0) {
+    out[0] = 1.0;
+    out[1] = out[2] = out[3] = 0.0;
+  } else {
+    for (int i = 0; i < 4; ++i) out[i] = tmp[i] / tot;
+  }
+}
+
+/* cell += AreaOccupancyObservation{is_occupied, {prob, est_qual}, obstacle, quality} */
+static void cell_update(int rule, double *cell, double *aux, double prob, double est_qual,
+                        double quality, double obx, double oby) {
+  if (isnan(prob) || isnan(est_qual)) {
+    if (rule != ORC_RULE_LAST) return; /* every model but the base cell skips invalid occupancy */
+  }
+  switch (rule) {
+    case ORC_RULE_LAST:
+      cell[0] = prob;
+      break;
+    case ORC_RULE_AFFINE:
+      cell[0] = (1.0 - quality) * cell[0] + quality * prob;
+      break;
+    case ORC_RULE_MEAN: {
+      aux[0] += 1;
+      double that_p = 0.5 + (prob - 0.5) * quality;
+      cell[0] = (cell[0] * (aux[0] - 1) + that_p) / aux[0];
+      break;
+    }
+    case ORC_RULE_TBM: {
+      double eq = est_qual * quality;
+      double occupied = prob * eq, empty = (1 - prob) * eq;
+      double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
+      double b[4];
+      tbm_conj(cell, that, b);
+      double weight = b[0] + b[1] + b[2];
+      if (weight == 0.0) {
+        cell[0] = 1.0;
+        cell[1] = cell[2] = cell[3] = 0.0;
+      } else {
+        cell[0] = b[0] / weight;
+        cell[1] = b[1] / weight;
+        cell[2] = b[2] / weight;
+        cell[3] = 0.0;
+      }
+      break;
+    }
+    case ORC_RULE_GMAPPING: {
+      int hits = (int)aux[0], tries = (int)aux[1];
+      ++tries;
+      int is_free = prob <= 0.5;
+      double aoo_p = is_free ? 0.0 : prob;
+      cell[0] = (cell[0] * (tries - 1) + aoo_p) / tries;
+      if (!is_free) {
+        ++hits;
+        cell[1] = (cell[1] * (hits - 1) + obx) / hits;
+        cell[2] = (cell[2] * (hits - 1) + oby) / hits;
+      }
+      aux[0] = hits;
+      aux[1] = tries;
+      break;
+    }
+  }
+}
+
+/* returns the number of cell updates, or -1 when a touched cell lies outside the window */
+long long orc_append_scan(const orc_map *map, double *payload, double *aux, int rule, const double *pose,
+                          int n, const double *range, const double *angle, const int *is_occ,
+                          const orc_scan *trig, double scan_quality, const double *base4, double blur,
+                          double max_range) {
+  if (n <= 0) return 0;
+  orc_scan s = *trig;
+  s.range = range;
+  s.angle = angle;
+  double sin_b, cos_b;
+  sincos(pose[2], &sin_b, &cos_b);
+  const int st = map->cell_model == ORC_CELL_TBM ? 4 : (map->cell_model == ORC_CELL_GMAPPING ? 3 : 1);
+  const int ast = rule == ORC_RULE_MEAN ? 1 : (rule == ORC_RULE_GMAPPING ? 2 : 0);
+  const double scale = map->scale;
+  const double max_range_sq = max_range * max_range; /* std::pow(max_usable_range, 2) */
+  int cap = 4 * (map->width + map->height) + 16;
+  int *cells = (int *)malloc(sizeof(int) * 2 * (size_t)cap);
+  long long updates = 0;
+  for (int i = 0; i < n; ++i) {
+    double wx, wy;
+    orc_endpoint(&s, i, pose, sin_b, cos_b, &wx, &wy);
+    const int occ = is_occ ? is_occ[i] : 1;
+    const double quality = scan_quality * 1.0; /* IdleOMQE */
+    const double ddx = wx - pose[0], ddy = wy - pose[1];
+    if (max_range_sq < ddx * ddx + ddy * ddy) continue; /* Segment2D::length_sq */
+    const int rcx = (int)floor(pose[0] / scale), rcy = (int)floor(pose[1] / scale);
+    const int ocx = (int)floor(wx / scale), ocy = (int)floor(wy / scale);
+    const double odx = rcx - ocx, ody = rcy - ocy;
+    const double obst_dist_sq = odx * odx + ody * ody;
+    double blur_dist = 0;
+    if (occ) {
+      blur_dist = blur / scale;
+      if (blur_dist < 0) blur_dist *= -(ddx * ddx + ddy * ddy);
+    }
+    const double hole_dist_sq = blur_dist * blur_dist;
+    int nc = orc_world_to_cells(scale, pose[0], pose[1], wx, wy, cap, cells);
+    if (nc > cap) {
+      free(cells);
+      return -1;
+    }
+    /* obstacle cell first (grid_map_scan_adders.h:159-162), then the rest in walk order */
+    const double base_prob = occ ? base4[0] : base4[2], base_qual = occ ? base4[1] : base4[3];
+    for (int pass = 0; pass < 2; ++pass) {
+      const int lo = pass == 0 ? nc - 1 : 0, hi = pass == 0 ? nc : nc - 1;
+      for (int k = lo; k < hi; ++k) {
+        const int cx = cells[2 * k], cy = cells[2 * k + 1];
+        const int ix = cx + map->origin_x, iy = cy + map->origin_y;
+        if (ix < 0 || ix >= map->width || iy < 0 || iy >= map->height) {
+          free(cells);
+          return -1;
+        }
+        double prob, qual;
+        if (pass == 0) {
+          prob = base_prob;
+          qual = base_qual;
+        } else {
+          prob = base4[2];
+          qual = base4[3];
+          const double cdx = cx - ocx, cdy = cy - ocy;
+          const double dist_sq = cdx * cdx + cdy * cdy;
+          if (dist_sq < hole_dist_sq && hole_dist_sq < obst_dist_sq) {
+            const double prob_scale = 1.0 - dist_sq / hole_dist_sq;
+            prob = base_prob * prob_scale;
+          }
+        }
+        const size_t ci = (size_t)iy * map->width + ix;
+        cell_update(rule, payload + ci * st, aux ? aux + ci * ast : NULL, prob, qual, quality, wx, wy);
+        ++updates;
+      }
+    }
+  }
+  free(cells);
+  return updates;
+}

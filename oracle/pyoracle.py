@@ -94,7 +94,8 @@ class OrcEnum(C.Structure):
 def build_oracle(force=False):
     so = os.path.join(HERE, "liboracle.so")
     src = os.path.join(HERE, "slam_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    src2 = os.path.join(HERE, "map_update_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -424,6 +425,7 @@ class Ref:
         L.ref_map_export.argtypes = [vp, i, i, i, i, _dp]
         L.ref_map_export_all.argtypes = [vp, _dp]
         L.ref_map_unknown_payload.argtypes = [vp, _dp]
+        L.ref_map_export_aux.argtypes = [vp, _dp]
         L.ref_scan_create.restype = vp
         L.ref_scan_create.argtypes = [i, _dp, _dp, _ip, i, d, d, d]
         L.ref_scan_destroy.argtypes = [vp]
@@ -635,6 +637,16 @@ class RefMapHandle(RefHandle):
 
     def stamp_text(self, text, off, w_zoom=1, h_zoom=1):
         self.ref.lib.ref_map_stamp_text(self.h, text.encode(), off[0], off[1], w_zoom, h_zoom)
+
+    def aux(self):
+        """Update-only cell state: MEAN -> n [h, w, 1]; GMAPPING -> (hits, tries) [h, w, 2]."""
+        g = self.geometry()
+        st = {REF_CELL_MEAN: 1, REF_CELL_GMAPPING: 2}.get(self.cell, 0)
+        if not st:
+            return None
+        out = np.zeros((g["height"], g["width"], st))
+        self.ref.lib.ref_map_export_aux(self.h, _d(out))
+        return out
 
     def to_data(self):
         """Flat mirror of the whole map window (what the adapter uploads)."""

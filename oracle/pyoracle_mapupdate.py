@@ -1,0 +1,28 @@
+"""ctypes binding of orc_append_scan (oracle/map_update_oracle.c) -- TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+from pyoracle import (OrcScan, _d, _dp, _i, _ip, _map_struct, _scan_struct, f64, i32, ScanData)
+
+RULE_LAST, RULE_AFFINE, RULE_MEAN, RULE_TBM, RULE_GMAPPING = range(5)
+AUX_STRIDE = {RULE_MEAN: 1, RULE_GMAPPING: 2}
+
+
+def append_scan(oracle, gmap, aux, rule, pose, rng, ang, is_occ=None, quality=1.0,
+                base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), trig=None):
+    """In-place GridMapScanAdder::append_scan on gmap.payload (and aux).  Returns #cell updates."""
+    L = oracle.lib
+    L.orc_append_scan.restype = C.c_longlong
+    L.orc_append_scan.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _ip,
+                                  C.c_void_p, C.c_double, _dp, C.c_double, C.c_double]
+    rng, ang, pose, b = f64(rng), f64(ang), f64(pose), f64(base)
+    occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+    m = _map_struct(gmap)
+    ts = _scan_struct(trig or ScanData(rng, ang))
+    assert gmap.payload.flags["C_CONTIGUOUS"] and gmap.payload.flags["WRITEABLE"]
+    res = L.orc_append_scan(C.byref(m), _d(gmap.payload), _d(aux) if aux is not None else None, rule,
+                            _d(pose), rng.size, _d(rng), _d(ang), _i(occ), C.byref(ts), quality, _d(b),
+                            blur, max_range)
+    if res < 0:
+        raise ValueError("a touched cell lies outside the map window")
+    return int(res)

@@ -264,6 +264,28 @@ void ref_map_export_all(void *h, double *out) {
   ref_map_export(h, -m.origin().x, -m.origin().y, m.width(), m.height(), out);
 }
 
+// per-cell update state that is not part of the scoring payload: MeanProbabilityCell::_n
+// (naive_grid_cells.h:43) -> 1 double; GmappingBaseCell::_hits/_tries (gmapping_grid_cell.h:41) -> 2
+int ref_map_export_aux(void *h, double *out) {
+  auto *rm = static_cast<RefMap *>(h);
+  auto &m = *rm->map;
+  const int w = m.width(), hh = m.height(), ox = m.origin().x, oy = m.origin().y;
+  if (rm->cell_model != CELL_MEAN && rm->cell_model != CELL_GMAPPING) return 0;
+  const int st = rm->cell_model == CELL_MEAN ? 1 : 2;
+  for (int y = 0; y < hh; ++y)
+    for (int x = 0; x < w; ++x) {
+      const GridCell &c = m[{x - ox, y - oy}];
+      double *o = out + (size_t(y) * w + x) * st;
+      if (rm->cell_model == CELL_MEAN) {
+        o[0] = static_cast<const MeanProbabilityCell &>(c)._n;
+      } else {
+        o[0] = static_cast<const GmappingBaseCell &>(c)._hits;
+        o[1] = static_cast<const GmappingBaseCell &>(c)._tries;
+      }
+    }
+  return st;
+}
+
 void ref_map_unknown_payload(void *h, double *out) {
   auto *rm = static_cast<RefMap *>(h);
   auto c = rm->map->new_cell();

@@ -162,7 +162,17 @@ int orc_gmapping_step(orc_gmapping *g, const orc_map *map, int n_raw, const doub
 void orc_gmapping_get(const orc_gmapping *g, double *poses, double *weights, int *is_master);
 long long orc_gmapping_scorer_calls(const orc_gmapping *g);
 
-/* ---- map update ---- */
+/* ---- map update (map_update_oracle.c) ---- */
+/* cell update rules = the reference's GridCell subclasses' operator+= */
+enum { ORC_RULE_LAST = 0, ORC_RULE_AFFINE = 1, ORC_RULE_MEAN = 2, ORC_RULE_TBM = 3, ORC_RULE_GMAPPING = 4 };
+/* GridMapScanAdder::append_scan with the const occupancy estimator on a mutable window.
+ * payload: [h][w][stride] of map->cell_model; aux: MEAN -> n [h][w], GMAPPING -> (hits, tries)
+ * [h][w][2], else NULL; base4 = {occ prob, occ qual, empty prob, empty qual}.  Returns the number
+ * of cell updates, -1 if a touched cell lies outside the window. */
+long long orc_append_scan(const orc_map *map, double *payload, double *aux, int rule, const double *pose,
+                          int n, const double *range, const double *angle, const int *is_occ,
+                          const orc_scan *trig, double scan_quality, const double *base4, double blur,
+                          double max_range);
 int orc_world_to_cells(double scale, double x0, double y0, double x1, double y1, int cap,
                        int *out_xy);
 

@@ -1,0 +1,39 @@
+"""CPU suite: the map-update restatement (oracle/map_update_oracle.c) against payloads and update
+counters exported from the compiled reference after every append_scan (tests/golden/map_update.npz,
+tests/golden/make_golden_mapupdate.py).  Bit-exact for all five cell update rules."""
+import numpy as np
+import pytest
+from helpers import load
+from pyoracle import CELL_GMAPPING, CELL_OCC, CELL_TBM, GridMapData
+from pyoracle_mapupdate import (AUX_STRIDE, RULE_AFFINE, RULE_GMAPPING, RULE_LAST, RULE_MEAN, RULE_TBM,
+                                append_scan)
+
+MODELS = {"mean": (CELL_OCC, RULE_MEAN), "affine": (CELL_OCC, RULE_AFFINE), "last": (CELL_OCC, RULE_LAST),
+          "tbm": (CELL_TBM, RULE_TBM), "gmapping": (CELL_GMAPPING, RULE_GMAPPING)}
+
+
+def fresh_map(g, name):
+    cell_model, rule = MODELS[name]
+    w, h = g[name + "_size"]
+    st = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}[cell_model]
+    unk = g[name + "_unknown"]
+    payload = np.tile(unk[:st], (h, w, 1)).astype(np.float64)
+    m = GridMapData(cell_model, payload, g[name + "_origin"], float(g["scale"]), unk[:st])
+    aux = np.zeros((h, w, AUX_STRIDE[rule])) if rule in AUX_STRIDE else None
+    return m, aux, rule
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_append_scan_vs_reference(oracle, name):
+    g = load("map_update.npz")
+    m, aux, rule = fresh_map(g, name)
+    lo, hi = g["crop"]
+    for k in range(int(g["n_steps"])):
+        q, blur, max_range = g["step%d_params" % k]
+        n_upd = append_scan(oracle, m, aux, rule, g["step%d_pose" % k], g["step%d_range" % k],
+                            g["step%d_angle" % k], g["step%d_occ" % k], quality=q, base=g[name + "_base"],
+                            blur=blur, max_range=max_range)
+        assert n_upd > 1000
+        np.testing.assert_array_equal(m.payload[lo:hi, lo:hi], g["%s_step%d_payload" % (name, k)], err_msg="step %d" % k)
+        if aux is not None:
+            np.testing.assert_array_equal(aux[lo:hi, lo:hi], g["%s_step%d_aux" % (name, k)])
