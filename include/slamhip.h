@@ -110,6 +110,35 @@ int slamhip_map_release(slamhip_ctx *ctx, int map_id);
 int slamhip_map_download_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h,
                                 double *payload_out);
 
+/* ---------------------------------------------------------------- map update (kernel K6)
+ * Replaces GridMapScanAdder::append_scan (src/core/maps/grid_map_scan_adders.h:54-75) with
+ * WallDistanceBlurringScanAdder::handle_scan_point (:138-172) and ConstOccupancyEstimator
+ * (const_occupancy_estimator.h:6-17) on the HBM mirror: per beam the 4-connected ray walk
+ * (regular_squares_grid.h:56-101), per cell the `cell += observation` of the map's cell class, in
+ * the reference's update order (records sorted by cell, stable in beam order).
+ * rule = which GridCell subclass the OCC/TBM/GMAPPING payload belongs to. */
+enum { SLAMHIP_RULE_LAST = 0,     /* GridCell::operator+= (grid_cell.h:27-30): last write wins */
+       SLAMHIP_RULE_AFFINE = 1,   /* AffineQualityMergeCell (naive_grid_cells.h:14-20) */
+       SLAMHIP_RULE_MEAN = 2,     /* MeanProbabilityCell (naive_grid_cells.h:33-40) */
+       SLAMHIP_RULE_TBM = 3,      /* TbmBaseCell (tbm_grid_cells.h:12-19) */
+       SLAMHIP_RULE_GMAPPING = 4  /* GmappingBaseCell (gmapping_grid_cell.h:20-33) */ };
+typedef struct {
+  int rule;
+  double scan_quality;                           /* append_scan's scan_quality (x IdleOMQE = 1) */
+  double base_occupied_prob, base_occupied_qual; /* slam/occupancy_estimator/base_occupied/{prob,qual} */
+  double base_empty_prob, base_empty_qual;       /* .../base_empty/{prob,qual} (init_occupancy_mapping.h:48-51) */
+  double blur;                                   /* slam/mapping/blur, metres; < 0 = dynamic */
+  double max_range;                              /* slam/mapping/max_range (infinity = unlimited) */
+} slamhip_scan_adder_cfg;
+/* RAW scan points (range, cos/sin of their angle as for slamhip_scan_upload, is_occupied flag; may
+ * be NULL = all occupied).  Every touched cell must lie inside the bound window (grow it with
+ * slamhip_map_bind first), otherwise SLAMHIP_ERR_STATE.  n_updates = number of cell updates. */
+int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
+                            const double pose[3], int n, const double *range, const double *cos_a,
+                            const double *sin_a, const int *is_occ, long long *n_updates);
+/* update counters of a window (MEAN: n; GMAPPING: hits, tries) -- tests / debugging */
+int slamhip_map_download_aux(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h, double *out);
+
 /* ---------------------------------------------------------------- scan
  * The FILTERED scan the scorer iterates (LaserScan2D after
  * WeightedMeanPointProbabilitySPE::filter_scan, weighted_mean_point_probability_spe.h:75-95),

@@ -38,7 +38,7 @@ slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_res
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
-slamhip_gmapping_stats""".split()
+slamhip_gmapping_stats slamhip_map_append_scan slamhip_map_download_aux""".split()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -52,6 +52,15 @@ class SpeCfg(C.Structure):
     _fields_ = [("oope", C.c_int), ("oie", C.c_int), ("area", C.c_double * 4),
                 ("gm_fullness_th", C.c_double), ("gm_window", C.c_int), ("sum_order", C.c_int),
                 ("pose_trig", C.c_int)]
+
+
+RULE_LAST, RULE_AFFINE, RULE_MEAN, RULE_TBM, RULE_GMAPPING = range(5)
+
+
+class ScanAdderCfg(C.Structure):
+    _fields_ = [("rule", C.c_int), ("scan_quality", C.c_double), ("base_occupied_prob", C.c_double),
+                ("base_occupied_qual", C.c_double), ("base_empty_prob", C.c_double),
+                ("base_empty_qual", C.c_double), ("blur", C.c_double), ("max_range", C.c_double)]
 
 
 class GmappingParams(C.Structure):
@@ -129,6 +138,9 @@ def load():
     L.slamhip_map_apply_dirty.argtypes = [vp, i, i, _ip, _dp]
     L.slamhip_map_release.argtypes = [vp, i]
     L.slamhip_scan_upload.argtypes = [vp, i, _dp, _dp, _dp, _dp, _dp]
+    L.slamhip_map_append_scan.argtypes = [vp, i, C.POINTER(ScanAdderCfg), _dp, i, _dp, _dp, _dp, _ip,
+                                          C.POINTER(C.c_longlong)]
+    L.slamhip_map_download_aux.argtypes = [vp, i, i, i, i, i, _dp]
     L.slamhip_beam_trig_raw.argtypes = [i, _dp, _dp, _dp]
     L.slamhip_beam_trig_cached.argtypes = [i, _dp, d, d, d, _dp, _dp]
     L.slamhip_filter_scan.argtypes = [i, _dp, _dp, _ip, i, d, d, i, _dp, _dp, _dp, u, d, i, i, i,
@@ -303,6 +315,24 @@ class Context:
         p = _f64(payloads)
         _check(self.L.slamhip_map_apply_dirty(self.h, map_id, xy.shape[0],
                                               xy.ctypes.data_as(_ip), _d(p)))
+
+    def map_append_scan(self, map_id, rule, pose, rng, cos_a, sin_a, is_occ=None, quality=1.0,
+                        base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf")):
+        """GridMapScanAdder::append_scan on the HBM mirror; returns the number of cell updates."""
+        cfg = ScanAdderCfg(rule, quality, base[0], base[1], base[2], base[3], blur, max_range)
+        rng, cos_a, sin_a, pose = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(pose)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        nu = C.c_longlong(0)
+        _check(self.L.slamhip_map_append_scan(self.h, map_id, C.byref(cfg), _d(pose), rng.size, _d(rng),
+                                              _d(cos_a), _d(sin_a),
+                                              occ.ctypes.data_as(_ip) if occ is not None else None,
+                                              C.byref(nu)))
+        return nu.value
+
+    def map_download_aux(self, map_id, x0, y0, w, h, stride):
+        out = np.zeros((h, w, stride))
+        _check(self.L.slamhip_map_download_aux(self.h, map_id, x0, y0, w, h, _d(out)))
+        return out
 
     def map_release(self, map_id):
         _check(self.L.slamhip_map_release(self.h, map_id))

@@ -1,0 +1,516 @@
+// map_update.hip -- K6: the map update of one scan on the GPU, in the reference's update order.
+//
+// Restates (paths relative to the reference root):
+//   GridMapScanAdder::append_scan                     src/core/maps/grid_map_scan_adders.h:54-75
+//   WallDistanceBlurringScanAdder::handle_scan_point  :138-172, blur_cell_dist :176-189
+//   RegularSquaresGrid::world_to_cells                src/core/maps/regular_squares_grid.h:56-101
+//   DiscreteSegment2D (Bresenham fail-over)           src/core/geometry_discrete_primitives.h:55-104
+//   ConstOccupancyEstimator                           src/core/maps/const_occupancy_estimator.h:6-17
+//   cell updates: GridCell (grid_cell.h:27-30), AffineQualityMergeCell / MeanProbabilityCell
+//     (naive_grid_cells.h:14-20,33-40), TbmBaseCell (tbm_grid_cells.h:12-19,57-66;
+//     transferable_belief_model.h:102-143), GmappingBaseCell (src/slams/gmapping/gmapping_grid_cell.h:20-33)
+//
+// The cell update is order dependent (running means, TBM conjunction + normalisation) and the beams
+// of one scan overlap near the robot, so atomics cannot reproduce the sequential result.
+// Exact scheme:
+//   1. k_mu_count   one thread per beam: endpoint, range gate, upper bound |dx|+|dy|+1 of its cells
+//   2. k_mu_offsets exclusive scan of the bounds (one workgroup; <= 8192 beams)
+//   3. k_mu_emit    one thread per beam: the 4-connected walk with the reference's fuzzy tie rule and
+//                   Bresenham fail-over; one record (cell key, observation) per cell, beam-major
+//   4. rocprim::radix_sort_pairs (stable) by cell key: every cell's records end up contiguous and
+//      still in beam order -- within a beam a cell is visited once, so beam order IS the
+//      reference's update order for that cell
+//   5. k_mu_apply   one thread per distinct cell applies its records sequentially
+// HBM traffic: per (beam, cell) one 24-byte record written, sorted and read once, plus one
+// read-modify-write of the cell (8-48 bytes) per distinct cell.
+
+#include <string.h>  // rocprim's texture iterator calls ::memset without including it
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include <rocprim/rocprim.hpp>
+
+#include "slamhip_internal.h"
+
+namespace slamhip {
+
+static constexpr unsigned kInvalidKey = 0xffffffffu;
+
+struct MuArgs {
+  // map
+  double *payload;
+  double *aux;
+  int width, height, pitch, origin_x, origin_y, cell_dbl, aux_stride;
+  double scale;
+  // scan
+  const double *range, *cos_a, *sin_a;
+  const int *is_occ;
+  int n;
+  double px, py, sn, cs;  // pose, sin/cos of its heading (host sincos)
+  // adder
+  int rule;
+  double quality, base_occ_prob, base_occ_qual, base_empty_prob, base_empty_qual, blur, max_range_sq;
+  // work buffers
+  unsigned *counts, *offsets;  // per beam
+  unsigned *keys;
+  double *rec_prob, *rec_qual;
+  unsigned *rec_beam;
+  double *beam_end;  // 2 per beam (the obstacle point of its observations)
+  int *error_flag;   // set when a touched cell lies outside the window
+};
+
+__device__ __forceinline__ bool mu_are_equal(double a, double b) {
+  const double m = fmax(fabs(a), fabs(b));
+  return fabs(a - b) <= 1e-7 * fmax(1.0, m);
+}
+
+__device__ __forceinline__ void mu_endpoint(const MuArgs &a, int b, double *wx, double *wy) {
+  const double c = a.cs * a.cos_a[b] - a.sn * a.sin_a[b];
+  const double s = a.sn * a.cos_a[b] + a.cs * a.sin_a[b];
+  *wx = a.px + a.range[b] * c;
+  *wy = a.py + a.range[b] * s;
+}
+
+__global__ void k_mu_count(MuArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.n) return;
+  double wx, wy;
+  mu_endpoint(a, b, &wx, &wy);
+  a.beam_end[2 * b] = wx;
+  a.beam_end[2 * b + 1] = wy;
+  const double ddx = wx - a.px, ddy = wy - a.py;
+  unsigned cnt = 0;
+  if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
+    const int rcx = (int)floor(a.px / a.scale), rcy = (int)floor(a.py / a.scale);
+    const int ocx = (int)floor(wx / a.scale), ocy = (int)floor(wy / a.scale);
+    cnt = (unsigned)(abs(ocx - rcx) + abs(ocy - rcy) + 1);
+  }
+  a.counts[b] = cnt;
+}
+
+// exclusive scan of counts[n] by one workgroup of 1024 threads; offsets[n] = total
+__global__ __launch_bounds__(1024) void k_mu_offsets(const unsigned *counts, unsigned *offsets, int n) {
+  __shared__ unsigned s_part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = t * per, hi = min(n, lo + per);
+  unsigned sum = 0;
+  for (int i = lo; i < hi; ++i) sum += counts[i];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const unsigned v = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  unsigned run = s_part[t] - sum;
+  for (int i = lo; i < hi; ++i) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+  if (t == 1023) offsets[n] = s_part[1023];
+}
+
+__device__ __forceinline__ void mu_record(const MuArgs &a, unsigned slot, int b, int cx, int cy, int ocx,
+                                          int ocy, bool obstacle_cell, bool occ, double hole_dist_sq,
+                                          double obst_dist_sq) {
+  const int ix = cx + a.origin_x, iy = cy + a.origin_y;
+  if ((unsigned)ix >= (unsigned)a.width || (unsigned)iy >= (unsigned)a.height) {
+    *a.error_flag = 1;
+    a.keys[slot] = kInvalidKey;
+    return;
+  }
+  const double base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
+  double prob, qual;
+  if (obstacle_cell) {
+    prob = base_prob;
+    qual = occ ? a.base_occ_qual : a.base_empty_qual;
+  } else {
+    prob = a.base_empty_prob;
+    qual = a.base_empty_qual;
+    const double cdx = cx - ocx, cdy = cy - ocy;
+    const double dist_sq = cdx * cdx + cdy * cdy;
+    if (dist_sq < hole_dist_sq && hole_dist_sq < obst_dist_sq) {
+      const double prob_scale = 1.0 - dist_sq / hole_dist_sq;
+      prob = base_prob * prob_scale;
+    }
+  }
+  a.keys[slot] = (unsigned)iy * (unsigned)a.pitch + (unsigned)ix;
+  a.rec_prob[slot] = prob;
+  a.rec_qual[slot] = qual;
+  a.rec_beam[slot] = (unsigned)b;
+}
+
+__global__ void k_mu_emit(MuArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.n) return;
+  const unsigned cap = a.counts[b];
+  if (cap == 0) return;
+  const unsigned base = a.offsets[b];
+  const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
+  const bool occ = a.is_occ ? a.is_occ[b] != 0 : true;
+  const double scale = a.scale;
+  const double d_x = wx - a.px, d_y = wy - a.py;
+  const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
+  int px = (int)floor(a.px / scale), py = (int)floor(a.py / scale);
+  const int bx = px, by = py;
+  const int ex = (int)floor(wx / scale), ey = (int)floor(wy / scale);
+  const double odx = bx - ex, ody = by - ey;
+  const double obst_dist_sq = odx * odx + ody * ody;
+  double blur_dist = 0;
+  if (occ) {
+    blur_dist = a.blur / scale;
+    if (blur_dist < 0) blur_dist *= -(d_x * d_x + d_y * d_y);
+  }
+  const double hole_dist_sq = blur_dist * blur_dist;
+  const double mid_x = (px + 0.5) * scale, mid_y = (py + 0.5) * scale;
+  const double mid_cell_seg_y = d_x * a.py + (mid_x - a.px) * d_y;
+  double e = mid_cell_seg_y - mid_y * d_x;
+  const double e_x_inc = inc_x * scale * d_y;
+  const double e_y_inc = -inc_y * scale * d_x;
+  unsigned n = 0;
+  bool failover = false;
+  while (true) {
+    if (n < cap) mu_record(a, base + n, b, px, py, ex, ey, px == ex && py == ey, occ, hole_dist_sq, obst_dist_sq);
+    ++n;
+    if (px == ex && py == ey) break;
+    if (cap < n) {  // fp rounding sent the walk astray: the reference restarts with Bresenham
+      failover = true;
+      break;
+    }
+    const double e_x = e + e_x_inc, e_y = e + e_y_inc;
+    const double abs_err_diff = fabs(e_y) - fabs(e_x);
+    if (mu_are_equal(abs_err_diff, 0)) {
+      if (px == ex) py += inc_y;
+      else if (py == ey) px += inc_x;
+      else { px += inc_x; py += inc_y; }
+      e = 0;
+    } else if (0 < abs_err_diff) {
+      px += inc_x;
+      e = e_x;
+    } else {
+      py += inc_y;
+      e = e_y;
+    }
+  }
+  if (failover) {
+    const int dxx = ex - bx, dyy = ey - by;
+    const bool y_is_primary = abs(dxx) < abs(dyy);
+    const int limit = y_is_primary ? ey : ex;
+    int primary = y_is_primary ? by : bx, secondary = y_is_primary ? bx : by;
+    const int d_primary = y_is_primary ? dyy : dxx, d_secondary = y_is_primary ? dxx : dyy;
+    const int inc_primary = 0 < d_primary ? 1 : -1, inc_secondary = 0 < d_secondary ? 1 : -1;
+    int error = 0;
+    n = 0;
+    while (true) {
+      const int cx = y_is_primary ? secondary : primary, cy = y_is_primary ? primary : secondary;
+      if (n < cap) mu_record(a, base + n, b, cx, cy, ex, ey, cx == ex && cy == ey, occ, hole_dist_sq, obst_dist_sq);
+      ++n;
+      if (primary == limit) break;
+      const int err_inc_primary = error + inc_primary * d_secondary;
+      const int err_inc_both = err_inc_primary - inc_secondary * d_primary;
+      primary += inc_primary;
+      if (abs(err_inc_primary) < abs(err_inc_both)) {
+        error = err_inc_primary;
+      } else {
+        secondary += inc_secondary;
+        error = err_inc_both;
+      }
+    }
+  }
+  for (unsigned k = n; k < cap; ++k) a.keys[base + k] = kInvalidKey;
+}
+
+__device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs, double *out) {
+  double tmp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tmp[i | j] += lhs[i] * rhs[j];
+  const double tot = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  if (tot == 0.0) {
+    out[0] = 1.0;
+    out[1] = out[2] = out[3] = 0.0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = tmp[i] / tot;
+  }
+}
+
+__global__ void k_mu_apply(MuArgs a, const unsigned *keys, const unsigned *order, unsigned total,
+                           unsigned long long *n_updates) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned key = keys[i];
+  if (key == kInvalidKey) return;
+  if (i > 0 && keys[i - 1] == key) return;  // not the head of this cell's run
+  double *cell = a.payload + (size_t)key * a.cell_dbl;
+  double *aux = a.aux ? a.aux + (size_t)key * a.aux_stride : nullptr;
+  double c0 = cell[0], c1 = 0, c2 = 0, c3 = 0;
+  if (a.cell_dbl == 4) {
+    c1 = cell[1];
+    c2 = cell[2];
+    c3 = cell[3];
+  }
+  double x0 = aux ? aux[0] : 0, x1 = (aux && a.aux_stride > 1) ? aux[1] : 0;
+  unsigned cnt = 0;
+  for (unsigned j = i; j < total && keys[j] == key; ++j, ++cnt) {
+    const unsigned r = order[j];
+    const double prob = a.rec_prob[r], est_qual = a.rec_qual[r];
+    const unsigned b = a.rec_beam[r];
+    const bool invalid = isnan(prob) || isnan(est_qual);
+    if (invalid && a.rule != 0) continue;
+    switch (a.rule) {
+      case 0:  // GridCell / MockGridCell: last write wins
+        c0 = prob;
+        break;
+      case 1:  // AffineQualityMergeCell
+        c0 = (1.0 - a.quality) * c0 + a.quality * prob;
+        break;
+      case 2: {  // MeanProbabilityCell
+        x0 += 1;
+        const double that_p = 0.5 + (prob - 0.5) * a.quality;
+        c0 = (c0 * (x0 - 1) + that_p) / x0;
+        break;
+      }
+      case 3: {  // TbmBaseCell
+        const double eq = est_qual * a.quality;
+        const double occupied = prob * eq, empty = (1 - prob) * eq;
+        const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
+        const double cur[4] = {c0, c1, c2, c3};
+        double nb[4];
+        mu_tbm_conj(cur, that, nb);
+        const double weight = nb[0] + nb[1] + nb[2];
+        if (weight == 0.0) {
+          c0 = 1.0;
+          c1 = c2 = c3 = 0.0;
+        } else {
+          c0 = nb[0] / weight;
+          c1 = nb[1] / weight;
+          c2 = nb[2] / weight;
+          c3 = 0.0;
+        }
+        break;
+      }
+      default: {  // GmappingBaseCell: x0 = hits, x1 = tries
+        int hits = (int)x0, tries = (int)x1;
+        ++tries;
+        const bool is_free = prob <= 0.5;
+        const double aoo_p = is_free ? 0.0 : prob;
+        c0 = (c0 * (tries - 1) + aoo_p) / tries;
+        if (!is_free) {
+          ++hits;
+          c1 = (c1 * (hits - 1) + a.beam_end[2 * b]) / hits;
+          c2 = (c2 * (hits - 1) + a.beam_end[2 * b + 1]) / hits;
+        }
+        x0 = hits;
+        x1 = tries;
+        break;
+      }
+    }
+  }
+  cell[0] = c0;
+  if (a.cell_dbl == 4) {
+    cell[1] = c1;
+    cell[2] = c2;
+    cell[3] = c3;
+  }
+  if (aux) {
+    aux[0] = x0;
+    if (a.aux_stride > 1) aux[1] = x1;
+  }
+  atomicAdd(n_updates, (unsigned long long)cnt);
+}
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+namespace {
+struct MuScratch {
+  size_t cap_records = 0, cap_beams = 0, temp_bytes = 0;
+  unsigned *counts = nullptr, *offsets = nullptr, *keys = nullptr, *keys_sorted = nullptr;
+  unsigned *order = nullptr, *order_sorted = nullptr, *rec_beam = nullptr;
+  double *rec_prob = nullptr, *rec_qual = nullptr, *beam_end = nullptr, *scan = nullptr;
+  int *occ = nullptr, *error_flag = nullptr;
+  unsigned long long *n_updates = nullptr;
+  void *temp = nullptr;
+};
+// one scratch set per context, keyed by the context pointer (contexts are few and long-lived)
+std::vector<std::pair<slamhip_ctx *, MuScratch>> g_scratch;
+
+MuScratch &scratch_of(slamhip_ctx *ctx) {
+  for (auto &p : g_scratch)
+    if (p.first == ctx) return p.second;
+  g_scratch.emplace_back(ctx, MuScratch{});
+  return g_scratch.back().second;
+}
+
+__global__ void k_iota(unsigned *p, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+int fail(const char *msg, int code = SLAMHIP_ERR_INVALID) {
+  set_error(msg);
+  return code;
+}
+}  // namespace
+
+extern "C" {
+
+int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
+                            const double pose[3], int n, const double *range, const double *cos_a,
+                            const double *sin_a, const int *is_occ, long long *n_updates_out) {
+  if (!ctx || !cfg || !pose || !range || !cos_a || !sin_a) return fail("null argument");
+  if (map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound) return fail("unknown map id");
+  if (n <= 0) {
+    if (n_updates_out) *n_updates_out = 0;
+    return SLAMHIP_OK;
+  }
+  if (n > 8192 * 1024) return fail("too many scan points");
+  DeviceMap &m = ctx->maps[map_id];
+  const int rule = cfg->rule;
+  if (rule < SLAMHIP_RULE_LAST || rule > SLAMHIP_RULE_GMAPPING) return fail("unknown cell update rule");
+  const bool ok_model = (rule == SLAMHIP_RULE_TBM && m.cell_model == SLAMHIP_CELL_TBM) ||
+                        (rule == SLAMHIP_RULE_GMAPPING && m.cell_model == SLAMHIP_CELL_GMAPPING) ||
+                        (rule <= SLAMHIP_RULE_MEAN && m.cell_model == SLAMHIP_CELL_OCC);
+  if (!ok_model) return fail("cell update rule does not fit the map's payload model");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  const int aux_stride = rule == SLAMHIP_RULE_MEAN ? 1 : (rule == SLAMHIP_RULE_GMAPPING ? 2 : 0);
+  if (aux_stride && (m.aux_stride != aux_stride || !m.d_aux)) {
+    if (m.d_aux) hipFree(m.d_aux);
+    m.d_aux = nullptr;
+    const size_t bytes = (size_t)m.pitch * m.height * aux_stride * sizeof(double);
+    SLAMHIP_CHECK(hipMalloc(&m.d_aux, bytes));
+    SLAMHIP_CHECK(hipMemsetAsync(m.d_aux, 0, bytes, ctx->stream));
+    m.aux_stride = aux_stride;
+  }
+  MuScratch &sc = scratch_of(ctx);
+  if ((size_t)n > sc.cap_beams) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (void *p : {(void *)sc.counts, (void *)sc.offsets, (void *)sc.beam_end, (void *)sc.scan, (void *)sc.occ})
+      if (p) hipFree(p);
+    size_t cap = 2048;
+    while (cap < (size_t)n) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&sc.counts, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.offsets, sizeof(unsigned) * (cap + 1)));
+    SLAMHIP_CHECK(hipMalloc(&sc.beam_end, sizeof(double) * 2 * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
+    if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
+    if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+    sc.cap_beams = cap;
+  }
+  const size_t cb = sc.cap_beams;
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cb, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cb, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), ctx->stream));
+  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long), ctx->stream));
+
+  MuArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.payload = m.d_payload;
+  a.aux = aux_stride ? m.d_aux : nullptr;
+  a.width = m.width;
+  a.height = m.height;
+  a.pitch = m.pitch;
+  a.origin_x = m.origin_x;
+  a.origin_y = m.origin_y;
+  a.cell_dbl = cell_doubles(m.cell_model);
+  a.aux_stride = aux_stride;
+  a.scale = m.scale;
+  a.range = sc.scan;
+  a.cos_a = sc.scan + cb;
+  a.sin_a = sc.scan + 2 * cb;
+  a.is_occ = is_occ ? sc.occ : nullptr;
+  a.n = n;
+  a.px = pose[0];
+  a.py = pose[1];
+  ::sincos(pose[2], &a.sn, &a.cs);  // set_base_angle(pose.theta), grid_map_scan_adders.h:61
+  a.rule = rule;
+  a.quality = cfg->scan_quality * 1.0;  // IdleOMQE
+  a.base_occ_prob = cfg->base_occupied_prob;
+  a.base_occ_qual = cfg->base_occupied_qual;
+  a.base_empty_prob = cfg->base_empty_prob;
+  a.base_empty_qual = cfg->base_empty_qual;
+  a.blur = cfg->blur;
+  a.max_range_sq = cfg->max_range * cfg->max_range;
+  a.counts = sc.counts;
+  a.offsets = sc.offsets;
+  a.beam_end = sc.beam_end;
+  a.error_flag = sc.error_flag;
+
+  const dim3 bgrid((n + 255) / 256);
+  hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, ctx->stream, sc.counts, sc.offsets, n);
+  unsigned total = 0;
+  SLAMHIP_CHECK(hipMemcpyAsync(&total, sc.offsets + n, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (total == 0) {
+    if (n_updates_out) *n_updates_out = 0;
+    return SLAMHIP_OK;
+  }
+  if (total > sc.cap_records) {
+    for (void *p : {(void *)sc.keys, (void *)sc.keys_sorted, (void *)sc.order, (void *)sc.order_sorted,
+                    (void *)sc.rec_beam, (void *)sc.rec_prob, (void *)sc.rec_qual, sc.temp})
+      if (p) hipFree(p);
+    size_t cap = 1 << 16;
+    while (cap < total) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&sc.keys, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.keys_sorted, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.order, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.order_sorted, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.rec_beam, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.rec_prob, sizeof(double) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.rec_qual, sizeof(double) * cap));
+    sc.temp_bytes = 0;
+    SLAMHIP_CHECK(rocprim::radix_sort_pairs(nullptr, sc.temp_bytes, sc.keys, sc.keys_sorted, sc.order,
+                                            sc.order_sorted, cap, 0, 32, ctx->stream));
+    SLAMHIP_CHECK(hipMalloc(&sc.temp, sc.temp_bytes));
+    sc.cap_records = cap;
+  }
+  a.keys = sc.keys;
+  a.rec_prob = sc.rec_prob;
+  a.rec_qual = sc.rec_qual;
+  a.rec_beam = sc.rec_beam;
+  hipLaunchKernelGGL(k_mu_emit, bgrid, dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sc.order, total);
+  size_t tb = sc.temp_bytes;
+  SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted,
+                                          total, 0, 32, ctx->stream));
+  hipLaunchKernelGGL(k_mu_apply, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a, sc.keys_sorted,
+                     sc.order_sorted, total, sc.n_updates);
+  SLAMHIP_CHECK(hipGetLastError());
+  int err = 0;
+  unsigned long long nu = 0;
+  SLAMHIP_CHECK(hipMemcpyAsync(&err, sc.error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(&nu, sc.n_updates, sizeof(nu), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (n_updates_out) *n_updates_out = (long long)nu;
+  if (err)
+    return fail("a beam leaves the bound map window: grow the map (slamhip_map_bind) before updating; "
+                "cells inside the window were updated", SLAMHIP_ERR_STATE);
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_download_aux(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h, double *out) {
+  if (!ctx || !out) return fail("null argument");
+  if (map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound) return fail("unknown map id");
+  DeviceMap &m = ctx->maps[map_id];
+  if (!m.d_aux || !m.aux_stride) return fail("this map holds no update counters", SLAMHIP_ERR_STATE);
+  if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || x0 + w > m.width || y0 + h > m.height)
+    return fail("window outside the bound map");
+  const size_t cb = m.aux_stride * sizeof(double);
+  SLAMHIP_CHECK(hipMemcpy2DAsync(out, w * cb, m.d_aux + ((size_t)y0 * m.pitch + x0) * m.aux_stride, m.pitch * cb,
+                                 w * cb, h, hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"

@@ -339,8 +339,10 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   if (!ctx) return SLAMHIP_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  for (auto &m : ctx->maps)
+  for (auto &m : ctx->maps) {
     if (m.d_payload) hipFree(m.d_payload);
+    if (m.d_aux) hipFree(m.d_aux);
+  }
   if (ctx->d_scan) hipFree(ctx->d_scan);
   if (ctx->d_poses) {
     hipFree(ctx->d_poses);
@@ -411,8 +413,26 @@ int slamhip_map_bind(slamhip_ctx *ctx, int map_id, int cell_model, int width, in
           (size_t)(sx1 - sx0) * cb, sy1 - sy0, hipMemcpyDeviceToDevice, ctx->stream));
     }
   }
+  if (old.bound && old.cell_model == cell_model && old.d_aux && old.aux_stride) {
+    // the update counters move with their cells
+    const size_t ab = (size_t)nm.pitch * height * old.aux_stride * sizeof(double);
+    SLAMHIP_CHECK(hipMalloc(&nm.d_aux, ab));
+    SLAMHIP_CHECK(hipMemsetAsync(nm.d_aux, 0, ab, ctx->stream));
+    nm.aux_stride = old.aux_stride;
+    const int dx = origin_x - old.origin_x, dy = origin_y - old.origin_y;
+    const int sx0 = std::max(0, -dx), sy0 = std::max(0, -dy);
+    const int sx1 = std::min(old.width, width - dx), sy1 = std::min(old.height, height - dy);
+    if (sx1 > sx0 && sy1 > sy0) {
+      const size_t cb = old.aux_stride * sizeof(double);
+      SLAMHIP_CHECK(hipMemcpy2DAsync(
+          nm.d_aux + ((size_t)(sy0 + dy) * nm.pitch + (sx0 + dx)) * old.aux_stride, nm.pitch * cb,
+          old.d_aux + ((size_t)sy0 * old.pitch + sx0) * old.aux_stride, old.pitch * cb,
+          (size_t)(sx1 - sx0) * cb, sy1 - sy0, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (old.d_payload) hipFree(old.d_payload);
+  if (old.d_aux) hipFree(old.d_aux);
   ctx->maps[map_id] = nm;
   return SLAMHIP_OK;
 }
@@ -422,6 +442,7 @@ int slamhip_map_release(slamhip_ctx *ctx, int map_id) {
   if (!m) return invalid("unknown map id");
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (m->d_payload) hipFree(m->d_payload);
+  if (m->d_aux) hipFree(m->d_aux);
   *m = DeviceMap{};
   return SLAMHIP_OK;
 }

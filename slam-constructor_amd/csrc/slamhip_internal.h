@@ -87,6 +87,10 @@ struct DeviceMap {
   double unknown[4] = {0, 0, 0, 0};
   double *d_payload = nullptr;
   size_t bytes = 0;
+  // update-only cell state, allocated by the first map update (map_update.hip):
+  // MeanProbabilityCell::_n (1 double) or GmappingBaseCell::_hits/_tries (2 doubles) per cell
+  double *d_aux = nullptr;
+  int aux_stride = 0;
 };
 
 void set_error(const std::string &msg);

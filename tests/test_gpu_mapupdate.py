@@ -1,0 +1,88 @@
+"""GPU suite: K6 map update (slamhip_map_append_scan) through the C-ABI against the payloads and
+update counters exported from the compiled reference after every append_scan
+(tests/golden/map_update.npz), and against the oracle at BASELINE size.  Bit-exact."""
+import numpy as np
+import pytest
+from helpers import load
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"mean": (0, 2), "affine": (0, 1), "last": (0, 0), "tbm": (1, 3), "gmapping": (2, 4)}  # (cell model, rule)
+STRIDE = {0: 1, 1: 4, 2: 3}
+AUX = {2: 1, 4: 2}
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_append_scan_vs_reference_golden(pkg, ctx, name):
+    g = load("map_update.npz")
+    cell_model, rule = MODELS[name]
+    w, h = [int(v) for v in g[name + "_size"]]
+    st = STRIDE[cell_model]
+    unk = g[name + "_unknown"]
+    ctx.map_bind(2, cell_model, w, h, g[name + "_origin"], float(g["scale"]), unk[:st])
+    lo, hi = [int(v) for v in g["crop"]]
+    for k in range(int(g["n_steps"])):
+        q, blur, max_range = g["step%d_params" % k]
+        c, s = pkg.beam_trig(g["step%d_angle" % k])
+        nu = ctx.map_append_scan(2, rule, g["step%d_pose" % k], g["step%d_range" % k], c, s, g["step%d_occ" % k],
+                                 quality=q, base=g[name + "_base"], blur=blur, max_range=max_range)
+        assert nu > 1000
+        got = ctx.map_download_window(2, lo, lo, hi - lo, hi - lo, st)
+        want = g["%s_step%d_payload" % (name, k)]
+        if name == "gmapping":
+            # obstacle means accumulate endpoints: the raw trig provider's libm sin(theta + a) and the
+            # device's angle-addition form differ in the last ulp
+            np.testing.assert_array_equal(got[..., 0], want[..., 0])
+            np.testing.assert_allclose(got[..., 1:], want[..., 1:], rtol=1e-13, atol=1e-15)
+        else:
+            np.testing.assert_array_equal(got, want, err_msg="%s step %d" % (name, k))
+        if rule in AUX:
+            np.testing.assert_array_equal(ctx.map_download_aux(2, lo, lo, hi - lo, hi - lo, AUX[rule]),
+                                          g["%s_step%d_aux" % (name, k)])
+    ctx.map_release(2)
+
+
+def test_append_scan_full_size_vs_oracle_and_rescoring(pkg, ctx):
+    """1080 beams on a 2000x2000 @0.05 m map: update on the GPU == update by the oracle, the updated
+    map scores like the oracle's, and a beam leaving the window is reported."""
+    import pyoracle as po
+    from pyoracle_mapupdate import RULE_MEAN, append_scan
+    from synth import make_scene
+    O = po.Oracle()
+    sc = make_scene(cell_model=0, size=2000, scale=0.05, n_beams=1080, seed=21)
+    m, scan = sc["map"], sc["scan"]
+    ctx.upload_map(2, m)
+    aux = np.zeros((m.height, m.width, 1))
+    rs = np.random.RandomState(3)
+    for k in range(3):
+        pose = sc["true_pose"] + rs.randn(3) * [0.2, 0.2, 0.05]
+        c, s = pkg.beam_trig(scan.angle)
+        # cached-provider arithmetic on both sides: tabulate the provider with one entry per beam
+        tr = po.ScanData(scan.range, scan.angle, None, None, po.TRIG_CACHED, 0.0, 1.0, s, c)
+        tr.angle = np.arange(scan.n, dtype=np.float64)  # index == beam
+        nu_o = append_scan(O, m, aux, RULE_MEAN, pose, scan.range, tr.angle, None, quality=0.9, blur=0.3, trig=tr)
+        nu = ctx.map_append_scan(2, pkg.RULE_MEAN, pose, scan.range, c, s, None, quality=0.9, blur=0.3)
+        assert nu == nu_o
+    np.testing.assert_array_equal(ctx.map_download_window(2, 0, 0, m.width, m.height, 1), m.payload)
+    np.testing.assert_array_equal(ctx.map_download_aux(2, 0, 0, m.width, m.height, 1), aux)
+    ctx.scan_upload(scan.range, c, s, scan.weight, scan.factor)
+    poses = sc["init_pose"] + rs.randn(64, 3) * [0.1, 0.1, 0.05]
+    got = ctx.score_poses(2, pkg.spe_cfg(sum_order=1, pose_trig=1), poses)
+    np.testing.assert_array_equal(got, O.score_poses(m, scan, po.make_cfg(), poses))
+    with pytest.raises(pkg.SlamHipError):
+        ctx.map_append_scan(2, pkg.RULE_MEAN, [49.0, 0.0, 0.0], scan.range, c, s)
+    ctx.map_release(2)
