@@ -65,15 +65,73 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sc, kind, params, seconds):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_reference(sc, kind, params, seconds, weighting):
+    """The compiled reference itself (oracle/_ref/libslamref.so = the unmodified reference headers
+    built in place; travels to the GPU box prebuilt): the synthetic map is rebuilt as a reference
+    UnboundedPlainGridMap (pointer-chasing cells, virtual calls) and the reference's own
+    HillClimbingScanMatcher / MonteCarloScanMatcher::process_scan is timed on one thread."""
+    import ctypes as C
+    import pyoracle as po
+    m = sc["map"]
+    if m.cell_model != 0 or not po.ref_available():
+        return None
+    R = po.Ref()
+    R.lib.ref_map_update_bulk.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    rm = R.map_create(po.REF_CELL_AFFINE, po.MAP_UNBOUNDED_PLAIN, m.width, m.height, m.scale)
+    geo = rm.geometry()
+    if geo["origin"] != tuple(m.origin):
+        return None
+    pay = m.payload[..., 0]
+    iy, ix = np.nonzero(pay != m.unknown[0])
+    xy = np.ascontiguousarray(np.stack([ix - m.origin[0], iy - m.origin[1]], axis=1), dtype=np.int32)
+    vals = np.ascontiguousarray(pay[iy, ix])
+    R.lib.ref_map_update_bulk(rm.h, len(vals), xy.ctypes.data_as(C.POINTER(C.c_int)),
+                              vals.ctypes.data_as(C.POINTER(C.c_double)))
+    scan = R.scan_create(sc["scan"].range, sc["scan"].angle)
+    spe = R.spe_create(po.OOPE_OBSTACLE, po.OIE_DISCREPANCY, 1 if weighting == "viny" else 0)
+    mt = R.matcher_create({"HC": po.SM_HC, "MC": po.SM_MC}[kind], spe, params)
+    units, t_used, reps = 0, 0.0, 0
+    t_end = time.perf_counter() + seconds
+    while True:
+        t0 = time.perf_counter()
+        r = R.process_scan(mt, scan, sc["init_pose"], rm, cap=4)
+        t_used += time.perf_counter() - t0
+        units += r["n_calls"] * r["filtered_n"]
+        reps += 1
+        if time.perf_counter() > t_end or reps >= 2000:
+            break
+    return {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "reference",
+            "sample": "%d x %s %s process_scan of the compiled reference (oracle/_ref, g++ -O3) on the same "
+                      "scene rebuilt as UnboundedPlainGridMap<AffineQualityMergeCell>, %.1f s; host CPU: %s, "
+                      "%d logical cores visible" % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0)}
+
+
+def cpu_baseline(sc, kind, params, seconds, weighting="even"):
     """Single-thread CPU checker on the same scene: whole process_scan calls, bounded to ~seconds."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    try:
+        ref = cpu_baseline_reference(sc, kind, params, seconds, weighting)
+    except Exception as e:  # noqa: BLE001  (a missing/foreign prebuilt .so must not kill the bench)
+        print("bench.py: reference baseline unavailable (%s); using the port" % e, file=sys.stderr)
+        ref = None
     O = po.Oracle()
     okind = {"HC": po.SM_HC, "MC": po.SM_MC}[kind]
     cfg = po.make_cfg()
     units, t_used, reps = 0, 0.0, 0
     e = O.enumerator(okind, params)
+    if ref is not None:
+        seconds = min(seconds, 3.0)
     t_end = time.perf_counter() + seconds
     while True:
         t0 = time.perf_counter()
@@ -83,18 +141,14 @@ def cpu_baseline(sc, kind, params, seconds):
         reps += 1
         if time.perf_counter() > t_end or reps >= 2000:
             break
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "port",
+    port = {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "port",
             "sample": "%d x process_scan (%s %s) on the same scene, %.1f s, oracle/slam_oracle.c -O2, "
                       "flat-array map; host CPU: %s, %d logical cores visible"
-                      % (reps, kind, params, t_used, model, os.cpu_count() or 0)}
+                      % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0)}
+    if ref is not None:
+        ref["port_value"] = port["value"]  # the flat-array C restatement, for context
+        return ref
+    return port
 
 
 def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
@@ -319,7 +373,7 @@ def main():
                          "avg_launch_us": 1e3 * k_ms / max(k_launches, 1)},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds, weighting)
         if pf_out is not None:
             out["particle_filter"] = pf_out
             if world == 1 and not args.no_cpu and "value" in pf_out:

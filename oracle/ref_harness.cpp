@@ -286,6 +286,15 @@ int ref_map_export_aux(void *h, double *out) {
   return st;
 }
 
+// bulk GridMap::update of n external cells with {occupied, {prob, 1}, (0,0), quality 1}.  On an
+// AffineQualityMergeCell map this sets prob_occ to exactly `prob` ((1-1)*old + 1*new), which lets
+// bench.py rebuild its synthetic occupancy map as a reference map for the "reference" CPU baseline.
+void ref_map_update_bulk(void *h, int n, const int *xy, const double *prob) {
+  auto &m = *static_cast<RefMap *>(h)->map;
+  for (int i = 0; i < n; ++i)
+    m.update({xy[2 * i], xy[2 * i + 1]}, AreaOccupancyObservation{true, {prob[i], 1.0}, {0, 0}, 1.0});
+}
+
 void ref_map_unknown_payload(void *h, double *out) {
   auto *rm = static_cast<RefMap *>(h);
   auto c = rm->map->new_cell();

@@ -1,6 +1,8 @@
 // matchers.cpp -- C-ABI of the matcher tier (include/slamhip.h): MC / HC / BF process_scan over the
 // speculative drivers of matchers.h.
 
+#include <cstdlib>
+
 #include "matchers.h"
 
 struct slamhip_matcher {
@@ -121,6 +123,8 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   carry.cy = ctx->gm_cy;
   carry.prob = ctx->gm_prob;
   MatchJob &job = m->job;
+  if (const char *e = getenv("SLAMHIP_HC_BOOST")) job.tree.repeat_boost = atof(e);
+  if (const char *e = getenv("SLAMHIP_MIN_REACH")) job.tree.min_reach = atof(e);
   job.start(m->pe.get(), Pose{init_pose[0], init_pose[1], init_pose[2]}, gm, m->has_obs ? &m->obs : nullptr,
             carry, m->p_accept0);
   while (!job.done) {

@@ -207,6 +207,7 @@ private:
 // candidate is evaluated after the last failed round (Q3).  frame rotation is always 0 (Q5).
 class HillClimbingPoseEnumerator : public PoseEnumerator {
 public:
+  HillClimbingPoseEnumerator() : HillClimbingPoseEnumerator(0, 0, 0) {}
   HillClimbingPoseEnumerator(unsigned max_failed_rounds, double dt, double dr)
       : max_failed_rounds_(max_failed_rounds), base_dt_(dt), base_dr_(dr) {
     reset();
@@ -355,7 +356,7 @@ struct SpecTree {
   // reach probability below which a round instance is not worth speculating: a lone matcher trades
   // ~20 us round trips against cheap evaluations (1 %); a filter that shares every launch among
   // all its particles pays per evaluation instead and wants a much higher bar
-  double min_reach = 0.01;
+  double min_reach = 0.02;
 
   void build(const PoseEnumerator &real, const Pose &best, int budget, double p_accept) {
     nodes.clear();
@@ -414,62 +415,89 @@ private:
   // seven outcomes (none accepted, or candidate j accepted last); in-round node (k, j) = "about to
   // evaluate candidate k, candidate j-1 accepted last (j = 0: none)".  Round instances are expanded
   // best-first by outcome probability until the evaluation budget is spent.
-  struct Inst {
-    double prio;
-    HillClimbingPoseEnumerator st;  // at a round boundary
-    Pose best;
-    int n_sites;
-    int site_node[6], site_branch[6];  // edges to patch with this instance's first node
-    bool operator<(const Inst &o) const { return prio < o.prio; }
+  // expanded round instance: the two possible end-of-round enumerator states, its six candidates
+  // and where its nodes start; children are (parent, outcome) pairs, so the heap moves 16 bytes
+  struct Round {
+    HillClimbingPoseEnumerator e_fail, e_ok;
+    Pose best, c[6];
+    int first;
+    int outcome;  // the outcome of the PARENT round that led here (-1: root)
   };
-  std::vector<Inst> heap_;
+  struct Cand {
+    double prio;
+    int parent, outcome;
+    bool operator<(const Cand &o) const { return prio < o.prio; }
+  };
+  std::vector<Round> rounds_;
+  std::vector<Cand> heap_;
 
   void build_rounds(const HillClimbingPoseEnumerator &real, const Pose &best, int budget,
                     double p_accept) {
     heap_.clear();
-    Inst r{1.0, real, best, 0, {0}, {0}};
-    heap_.push_back(r);
+    rounds_.clear();
+    heap_.push_back(Cand{1.0, -1, -1});
     const double q = 1.0 - p_accept;
     double p_out[7];
     p_out[0] = std::pow(q, 6);
     for (int j = 1; j <= 6; ++j) p_out[j] = p_accept * std::pow(q, 6 - j);
     while (!heap_.empty() && (int)evals.size() + 6 <= budget) {
       // an instance reached with probability P saves ~P round trips (~20 us each) and costs host
-      // time plus six evaluations: not worth it below ~1 %
+      // time plus six evaluations: not worth it below min_reach
       if (!evals.empty() && heap_.front().prio < min_reach) break;
       std::pop_heap(heap_.begin(), heap_.end());
-      Inst in = std::move(heap_.back());
+      const Cand cd = heap_.back();
       heap_.pop_back();
+      const HillClimbingPoseEnumerator *st = &real;
+      Pose in_best = best;
+      if (cd.parent >= 0) {
+        const Round &pr = rounds_[cd.parent];
+        st = cd.outcome == 0 ? &pr.e_fail : &pr.e_ok;
+        in_best = cd.outcome == 0 ? pr.best : pr.c[cd.outcome - 1];
+      }
       const int first = (int)nodes.size();
       auto patch = [&](int target) {
-        if (in.n_sites == 0) root = target;
-        for (int s = 0; s < in.n_sites; ++s) nodes[in.site_node[s]].child[in.site_branch[s]] = target;
+        if (cd.parent < 0) {
+          root = target;
+          return;
+        }
+        const int last = rounds_[cd.parent].first + 15;  // node(5, j) of the parent round
+        if (cd.outcome < 6) {
+          nodes[last + cd.outcome].child[0] = target;  // candidate 5 rejected, outcome-1 accepted last
+        } else {
+          for (int t = 0; t < 6; ++t) nodes[last + t].child[1] = target;  // candidate 5 accepted
+        }
       };
-      if (!in.st.has_next()) {
+      if (!st->has_next()) {
         patch(kEnd);
         continue;
       }
-      HillClimbingPoseEnumerator e_fail = in.st, e_ok = in.st;
-      Pose c[6];
-      c[0] = e_fail.next(in.best);
-      e_fail.feedback(false);
-      (void)e_ok.next(in.best);
-      e_ok.feedback(true);
-      if (!e_fail.has_next()) {
+      rounds_.emplace_back();
+      Round &rd = rounds_.back();
+      rd.e_fail = *st;
+      rd.e_ok = *st;
+      rd.best = in_best;
+      rd.first = first;
+      rd.outcome = cd.outcome;
+      rd.c[0] = rd.e_fail.next(in_best);
+      rd.e_fail.feedback(false);
+      (void)rd.e_ok.next(in_best);
+      rd.e_ok.feedback(true);
+      if (!rd.e_fail.has_next()) {
         // trailing candidate after the last failed round (Q3): evaluated, then the loop ends
-        evals.push_back(c[0]);
+        evals.push_back(rd.c[0]);
         nodes.push_back(Node{(int)evals.size() - 1, {kEnd, kEnd}});
         patch(first);
+        rounds_.pop_back();
         continue;
       }
       for (int k = 1; k < 6; ++k) {
-        c[k] = e_fail.next(in.best);
-        e_fail.feedback(false);
-        (void)e_ok.next(in.best);
-        e_ok.feedback(false);
+        rd.c[k] = rd.e_fail.next(in_best);
+        rd.e_fail.feedback(false);
+        (void)rd.e_ok.next(in_best);
+        rd.e_ok.feedback(false);
       }
       const int e0 = (int)evals.size();
-      for (int k = 0; k < 6; ++k) evals.push_back(c[k]);
+      for (int k = 0; k < 6; ++k) evals.push_back(rd.c[k]);
       // node(k, j) -> first + k(k+1)/2 + j,  j in [0, k]
       for (int k = 0; k < 6; ++k)
         for (int j = 0; j <= k; ++j) {
@@ -482,25 +510,23 @@ private:
           nodes.push_back(nd);
         }
       patch(first);
-      const int last = first + 15;  // node(5, j)
+      const int me = (int)rounds_.size() - 1;
+      // a hill climb keeps moving the way it just moved: the outcome that repeats the parent's
+      // move gets `repeat_boost` times its share (renormalised)
+      double w[7], tot = 0;
       for (int j = 0; j <= 6; ++j) {
-        Inst nx{in.prio * p_out[j], j == 0 ? e_fail : e_ok, j == 0 ? in.best : c[j - 1], 0, {0}, {0}};
-        if (j < 6) {
-          nx.n_sites = 1;
-          nx.site_node[0] = last + j;  // candidate 5 rejected, j-1 accepted last
-          nx.site_branch[0] = 0;
-        } else {
-          nx.n_sites = 6;  // candidate 5 accepted, whatever came before
-          for (int t = 0; t < 6; ++t) {
-            nx.site_node[t] = last + t;
-            nx.site_branch[t] = 1;
-          }
-        }
-        heap_.push_back(nx);
+        w[j] = p_out[j] * ((j > 0 && j == cd.outcome) ? repeat_boost : 1.0);
+        tot += w[j];
+      }
+      for (int j = 0; j <= 6; ++j) {
+        heap_.push_back(Cand{cd.prio * w[j] / tot, me, j});
         std::push_heap(heap_.begin(), heap_.end());
       }
     }
   }
+
+public:
+  double repeat_boost = 1.0;
 };
 
 }  // namespace slamhip
