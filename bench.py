@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--pf-size", type=int, default=4000)
     ap.add_argument("--pf-steps", type=int, default=10)
     ap.add_argument("--no-pf", action="store_true", help="skip the GMapping particle-filter leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo lets several ranks share one GPU (path testing)")
     ap.add_argument("--strict", action="store_true",
                     help="bit-exact mode (sequential sum + host pose trig) instead of the default")
     return ap.parse_args()
@@ -169,7 +171,7 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
     pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
     scan = sc["scan"]
-    dev = torch.device("cuda", local_rank)
+    dev = args.coll_device
 
     def gather(a, dtype):
         if world == 1:
@@ -265,10 +267,16 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU under gloo
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    args.coll_device = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     import __graft_entry__ as ge
     from synth import make_scene
@@ -335,9 +343,9 @@ def main():
     units = float(calls) * scan.n
     t_max, units_all = dt, units
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        uu = torch.tensor([units], dtype=torch.float64, device="cuda")
+        uu = torch.tensor([units], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
         t_max, units_all = tt.item(), uu.item()
 
@@ -365,6 +373,7 @@ def main():
                        "mode": "strict (sequential sum, host trig)" if args.strict else
                                "default (canonical tree sum, device sincos)",
                        "parallelism": "replicas x%d (no collective)" % world if world > 1 else "1 gpu",
+                       "backend": args.backend if world > 1 else None,
                        **extra},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -129,6 +129,11 @@ typedef struct {
   double base_empty_prob, base_empty_qual;       /* .../base_empty/{prob,qual} (init_occupancy_mapping.h:48-51) */
   double blur;                                   /* slam/mapping/blur, metres; < 0 = dynamic */
   double max_range;                              /* slam/mapping/max_range (infinity = unlimited) */
+  int occupancy_estimator;  /* slam/occupancy_estimator/type: 0 const (const_occupancy_estimator.h:6-17),
+                             * 1 area (AreaOccupancyEstimator, area_occupancy_estimator.h:27-240) */
+  double area_shift_amount; /* Q27: the area estimator freezes low_qual * side of the FIRST cell it
+                             * ever sees in a function-local static (area_occupancy_estimator.h:68-72);
+                             * 0 = 0.01 * scale */
 } slamhip_scan_adder_cfg;
 /* RAW scan points (range, cos/sin of their angle as for slamhip_scan_upload, is_occupied flag; may
  * be NULL = all occupied).  Every touched cell must lie inside the bound window (grow it with

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "slam_oracle.h"
+#include "area_estimator.h"
 
 static void tbm_conj(const double *lhs, const double *rhs, double *out) {
   double tmp[4] = {0.0, 0.0, 0.0, 0.0};
@@ -90,6 +91,15 @@ long long orc_append_scan(const orc_map *map, double *payload, double *aux, int 
                           int n, const double *range, const double *angle, const int *is_occ,
                           const orc_scan *trig, double scan_quality, const double *base4, double blur,
                           double max_range) {
+  return orc_append_scan_ex(map, payload, aux, rule, pose, n, range, angle, is_occ, trig, scan_quality,
+                            base4, blur, max_range, 0, 0.0);
+}
+
+/* est_kind 0: ConstOccupancyEstimator, 1: AreaOccupancyEstimator (area_estimator.h) */
+long long orc_append_scan_ex(const orc_map *map, double *payload, double *aux, int rule, const double *pose,
+                             int n, const double *range, const double *angle, const int *is_occ,
+                             const orc_scan *trig, double scan_quality, const double *base4, double blur,
+                             double max_range, int est_kind, double shift_amount) {
   if (n <= 0) return 0;
   orc_scan s = *trig;
   s.range = range;
@@ -126,7 +136,15 @@ long long orc_append_scan(const orc_map *map, double *payload, double *aux, int 
       return -1;
     }
     /* obstacle cell first (grid_map_scan_adders.h:159-162), then the rest in walk order */
-    const double base_prob = occ ? base4[0] : base4[2], base_qual = occ ? base4[1] : base4[3];
+    double base_prob = occ ? base4[0] : base4[2], base_qual = occ ? base4[1] : base4[3];
+    const ae_pt bbeg = {pose[0], pose[1]}, bend = {wx, wy};
+    if (est_kind == 1) {
+      const int lx = cells[2 * (nc - 1)], ly = cells[2 * (nc - 1) + 1];
+      const ae_rect cb = {scale * ly, scale * (ly + 1), scale * lx, scale * (lx + 1)};
+      const ae_occ o = ae_estimate(bbeg, bend, cb, occ, base4, shift_amount);
+      base_prob = o.prob;
+      base_qual = o.qual;
+    }
     for (int pass = 0; pass < 2; ++pass) {
       const int lo = pass == 0 ? nc - 1 : 0, hi = pass == 0 ? nc : nc - 1;
       for (int k = lo; k < hi; ++k) {
@@ -143,6 +161,12 @@ long long orc_append_scan(const orc_map *map, double *payload, double *aux, int 
         } else {
           prob = base4[2];
           qual = base4[3];
+          if (est_kind == 1) {
+            const ae_rect cb = {scale * cy, scale * (cy + 1), scale * cx, scale * (cx + 1)};
+            const ae_occ o = ae_estimate(bbeg, bend, cb, 0, base4, shift_amount);
+            prob = o.prob;
+            qual = o.qual;
+          }
           const double cdx = cx - ocx, cdy = cy - ocy;
           const double dist_sq = cdx * cdx + cdy * cdy;
           if (dist_sq < hole_dist_sq && hole_dist_sq < obst_dist_sq) {

@@ -26,3 +26,24 @@ def append_scan(oracle, gmap, aux, rule, pose, rng, ang, is_occ=None, quality=1.
     if res < 0:
         raise ValueError("a touched cell lies outside the map window")
     return int(res)
+
+
+def append_scan_ex(oracle, gmap, aux, rule, pose, rng, ang, is_occ=None, quality=1.0,
+                   base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), trig=None,
+                   est_kind=0, shift_amount=0.0):
+    """append_scan with the const (0) or the area (1) occupancy estimator."""
+    L = oracle.lib
+    L.orc_append_scan_ex.restype = C.c_longlong
+    L.orc_append_scan_ex.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _ip,
+                                     C.c_void_p, C.c_double, _dp, C.c_double, C.c_double, C.c_int,
+                                     C.c_double]
+    rng, ang, pose, b = f64(rng), f64(ang), f64(pose), f64(base)
+    occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+    m = _map_struct(gmap)
+    ts = _scan_struct(trig or ScanData(rng, ang))
+    res = L.orc_append_scan_ex(C.byref(m), _d(gmap.payload), _d(aux) if aux is not None else None, rule,
+                               _d(pose), rng.size, _d(rng), _d(ang), _i(occ), C.byref(ts), quality, _d(b),
+                               blur, max_range, est_kind, shift_amount)
+    if res < 0:
+        raise ValueError("a touched cell lies outside the map window")
+    return int(res)

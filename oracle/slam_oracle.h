@@ -173,6 +173,12 @@ long long orc_append_scan(const orc_map *map, double *payload, double *aux, int 
                           int n, const double *range, const double *angle, const int *is_occ,
                           const orc_scan *trig, double scan_quality, const double *base4, double blur,
                           double max_range);
+/* est_kind 0 = ConstOccupancyEstimator, 1 = AreaOccupancyEstimator (oracle/area_estimator.h);
+ * shift_amount = the function-local static of ensure_segment_not_on_edge (Q27) */
+long long orc_append_scan_ex(const orc_map *map, double *payload, double *aux, int rule, const double *pose,
+                             int n, const double *range, const double *angle, const int *is_occ,
+                             const orc_scan *trig, double scan_quality, const double *base4, double blur,
+                             double max_range, int est_kind, double shift_amount);
 int orc_world_to_cells(double scale, double x0, double y0, double x1, double y1, int cap,
                        int *out_xy);
 

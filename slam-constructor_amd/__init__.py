@@ -60,7 +60,8 @@ RULE_LAST, RULE_AFFINE, RULE_MEAN, RULE_TBM, RULE_GMAPPING = range(5)
 class ScanAdderCfg(C.Structure):
     _fields_ = [("rule", C.c_int), ("scan_quality", C.c_double), ("base_occupied_prob", C.c_double),
                 ("base_occupied_qual", C.c_double), ("base_empty_prob", C.c_double),
-                ("base_empty_qual", C.c_double), ("blur", C.c_double), ("max_range", C.c_double)]
+                ("base_empty_qual", C.c_double), ("blur", C.c_double), ("max_range", C.c_double),
+                ("occupancy_estimator", C.c_int), ("area_shift_amount", C.c_double)]
 
 
 class GmappingParams(C.Structure):
@@ -317,9 +318,12 @@ class Context:
                                               xy.ctypes.data_as(_ip), _d(p)))
 
     def map_append_scan(self, map_id, rule, pose, rng, cos_a, sin_a, is_occ=None, quality=1.0,
-                        base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf")):
-        """GridMapScanAdder::append_scan on the HBM mirror; returns the number of cell updates."""
-        cfg = ScanAdderCfg(rule, quality, base[0], base[1], base[2], base[3], blur, max_range)
+                        base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), estimator=0,
+                        shift_amount=0.0):
+        """GridMapScanAdder::append_scan on the HBM mirror (estimator 0 const, 1 area); returns the
+        number of cell updates."""
+        cfg = ScanAdderCfg(rule, quality, base[0], base[1], base[2], base[3], blur, max_range,
+                           estimator, shift_amount)
         rng, cos_a, sin_a, pose = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(pose)
         occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
         nu = C.c_longlong(0)

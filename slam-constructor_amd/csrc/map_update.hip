@@ -33,6 +33,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "slamhip_internal.h"
+#include "area_estimator_device.h"
 
 namespace slamhip {
 
@@ -51,6 +52,8 @@ struct MuArgs {
   double px, py, sn, cs;  // pose, sin/cos of its heading (host sincos)
   // adder
   int rule;
+  int est_kind;         // 0 ConstOccupancyEstimator, 1 AreaOccupancyEstimator
+  double shift_amount;  // Q27: the estimator's function-local static (low_qual x first cell side)
   double quality, base_occ_prob, base_occ_qual, base_empty_prob, base_empty_qual, blur, max_range_sq;
   // work buffers
   unsigned *counts, *offsets;  // per beam
@@ -115,22 +118,29 @@ __global__ __launch_bounds__(1024) void k_mu_offsets(const unsigned *counts, uns
 }
 
 __device__ __forceinline__ void mu_record(const MuArgs &a, unsigned slot, int b, int cx, int cy, int ocx,
-                                          int ocy, bool obstacle_cell, bool occ, double hole_dist_sq,
-                                          double obst_dist_sq) {
+                                          int ocy, bool obstacle_cell, double base_prob, double base_qual,
+                                          double hole_dist_sq, double obst_dist_sq) {
   const int ix = cx + a.origin_x, iy = cy + a.origin_y;
   if ((unsigned)ix >= (unsigned)a.width || (unsigned)iy >= (unsigned)a.height) {
     *a.error_flag = 1;
     a.keys[slot] = kInvalidKey;
     return;
   }
-  const double base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
   double prob, qual;
   if (obstacle_cell) {
     prob = base_prob;
-    qual = occ ? a.base_occ_qual : a.base_empty_qual;
+    qual = base_qual;
   } else {
     prob = a.base_empty_prob;
     qual = a.base_empty_qual;
+    if (a.est_kind == 1) {
+      const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
+      const ae::ae_rect cb{a.scale * cy, a.scale * (cy + 1), a.scale * cx, a.scale * (cx + 1)};
+      const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{a.px, a.py}, ae::ae_pt{a.beam_end[2 * b], a.beam_end[2 * b + 1]},
+                                           cb, 0, base4, a.shift_amount);
+      prob = o.prob;
+      qual = o.qual;
+    }
     const double cdx = cx - ocx, cdy = cy - ocy;
     const double dist_sq = cdx * cdx + cdy * cdy;
     if (dist_sq < hole_dist_sq && hole_dist_sq < obst_dist_sq) {
@@ -166,6 +176,17 @@ __global__ void k_mu_emit(MuArgs a) {
     if (blur_dist < 0) blur_dist *= -(d_x * d_x + d_y * d_y);
   }
   const double hole_dist_sq = blur_dist * blur_dist;
+  // occupancy of the obstacle cell (= the end cell of the walk), estimated first like the reference
+  double base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
+  double base_qual = occ ? a.base_occ_qual : a.base_empty_qual;
+  if (a.est_kind == 1) {
+    const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
+    const ae::ae_rect cb{scale * ey, scale * (ey + 1), scale * ex, scale * (ex + 1)};
+    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{a.px, a.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
+                                         a.shift_amount);
+    base_prob = o.prob;
+    base_qual = o.qual;
+  }
   const double mid_x = (px + 0.5) * scale, mid_y = (py + 0.5) * scale;
   const double mid_cell_seg_y = d_x * a.py + (mid_x - a.px) * d_y;
   double e = mid_cell_seg_y - mid_y * d_x;
@@ -174,7 +195,7 @@ __global__ void k_mu_emit(MuArgs a) {
   unsigned n = 0;
   bool failover = false;
   while (true) {
-    if (n < cap) mu_record(a, base + n, b, px, py, ex, ey, px == ex && py == ey, occ, hole_dist_sq, obst_dist_sq);
+    if (n < cap) mu_record(a, base + n, b, px, py, ex, ey, px == ex && py == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
     ++n;
     if (px == ex && py == ey) break;
     if (cap < n) {  // fp rounding sent the walk astray: the reference restarts with Bresenham
@@ -207,7 +228,7 @@ __global__ void k_mu_emit(MuArgs a) {
     n = 0;
     while (true) {
       const int cx = y_is_primary ? secondary : primary, cy = y_is_primary ? primary : secondary;
-      if (n < cap) mu_record(a, base + n, b, cx, cy, ex, ey, cx == ex && cy == ey, occ, hole_dist_sq, obst_dist_sq);
+      if (n < cap) mu_record(a, base + n, b, cx, cy, ex, ey, cx == ex && cy == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
       ++n;
       if (primary == limit) break;
       const int err_inc_primary = error + inc_primary * d_secondary;
@@ -375,6 +396,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   DeviceMap &m = ctx->maps[map_id];
   const int rule = cfg->rule;
   if (rule < SLAMHIP_RULE_LAST || rule > SLAMHIP_RULE_GMAPPING) return fail("unknown cell update rule");
+  if (cfg->occupancy_estimator != 0 && cfg->occupancy_estimator != 1) return fail("unknown occupancy estimator");
   const bool ok_model = (rule == SLAMHIP_RULE_TBM && m.cell_model == SLAMHIP_CELL_TBM) ||
                         (rule == SLAMHIP_RULE_GMAPPING && m.cell_model == SLAMHIP_CELL_GMAPPING) ||
                         (rule <= SLAMHIP_RULE_MEAN && m.cell_model == SLAMHIP_CELL_OCC);
@@ -434,6 +456,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.py = pose[1];
   ::sincos(pose[2], &a.sn, &a.cs);  // set_base_angle(pose.theta), grid_map_scan_adders.h:61
   a.rule = rule;
+  a.est_kind = cfg->occupancy_estimator;
+  a.shift_amount = cfg->area_shift_amount > 0 ? cfg->area_shift_amount : 0.01 * m.scale;
   a.quality = cfg->scan_quality * 1.0;  // IdleOMQE
   a.base_occ_prob = cfg->base_occupied_prob;
   a.base_occ_qual = cfg->base_occupied_qual;

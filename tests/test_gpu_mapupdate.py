@@ -86,3 +86,29 @@ def test_append_scan_full_size_vs_oracle_and_rescoring(pkg, ctx):
     with pytest.raises(pkg.SlamHipError):
         ctx.map_append_scan(2, pkg.RULE_MEAN, [49.0, 0.0, 0.0], scan.range, c, s)
     ctx.map_release(2)
+
+
+@pytest.mark.parametrize("name", ["mean", "tbm", "gmapping"])
+def test_append_scan_area_estimator_vs_reference_golden(pkg, ctx, name):
+    """AreaOccupancyEstimator on the GPU (slam/occupancy_estimator/type = area, BASELINE cfg 5)."""
+    g = load("map_update_area.npz")
+    cell_model, rule = MODELS[name]
+    w, h = [int(v) for v in g[name + "_size"]]
+    st = STRIDE[cell_model]
+    ctx.map_bind(2, cell_model, w, h, g[name + "_origin"], float(g["scale"]), g[name + "_unknown"][:st])
+    lo, hi = [int(v) for v in g["crop"]]
+    for k in range(int(g["n_steps"])):
+        q, blur, max_range = g["step%d_params" % k]
+        c, s = pkg.beam_trig(g["step%d_angle" % k])
+        ctx.map_append_scan(2, rule, g["step%d_pose" % k], g["step%d_range" % k], c, s, g["step%d_occ" % k],
+                            quality=q, base=g[name + "_base"], blur=blur, max_range=max_range, estimator=1,
+                            shift_amount=float(g["shift_amount"]))
+        got = ctx.map_download_window(2, lo, lo, hi - lo, hi - lo, st)
+        want = g["%s_step%d_payload" % (name, k)]
+        # the area split depends continuously on the endpoint: raw-provider endpoints differ from the
+        # reference's libm sin(theta + a) in the last ulp (DESIGN.md section 5) -> 1e-12, not bits
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13, err_msg="%s step %d" % (name, k))
+        if rule in AUX:
+            np.testing.assert_array_equal(ctx.map_download_aux(2, lo, lo, hi - lo, hi - lo, AUX[rule]),
+                                          g["%s_step%d_aux" % (name, k)])
+    ctx.map_release(2)

@@ -37,3 +37,22 @@ def test_append_scan_vs_reference(oracle, name):
         np.testing.assert_array_equal(m.payload[lo:hi, lo:hi], g["%s_step%d_payload" % (name, k)], err_msg="step %d" % k)
         if aux is not None:
             np.testing.assert_array_equal(aux[lo:hi, lo:hi], g["%s_step%d_aux" % (name, k)])
+
+
+@pytest.mark.parametrize("name", ["mean", "tbm", "gmapping"])
+def test_append_scan_area_estimator_vs_reference(oracle, name):
+    """AreaOccupancyEstimator (area_occupancy_estimator.h:27-240): triangle / trapezoid area split,
+    segment classification with fuzzy comparisons, the edge-shift static (Q27)."""
+    from pyoracle_mapupdate import append_scan_ex
+    g = load("map_update_area.npz")
+    m, aux, rule = fresh_map(g, name)
+    lo, hi = g["crop"]
+    for k in range(int(g["n_steps"])):
+        q, blur, max_range = g["step%d_params" % k]
+        append_scan_ex(oracle, m, aux, rule, g["step%d_pose" % k], g["step%d_range" % k], g["step%d_angle" % k],
+                       g["step%d_occ" % k], quality=q, base=g[name + "_base"], blur=blur, max_range=max_range,
+                       est_kind=1, shift_amount=float(g["shift_amount"]))
+        np.testing.assert_array_equal(m.payload[lo:hi, lo:hi], g["%s_step%d_payload" % (name, k)],
+                                      err_msg="step %d" % k)
+        if aux is not None:
+            np.testing.assert_array_equal(aux[lo:hi, lo:hi], g["%s_step%d_aux" % (name, k)])
