@@ -296,6 +296,11 @@ int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const doub
                           const double *angle, const int *is_occ, const double odom_delta[3],
                           uint32_t resample_seed, int *resampled, unsigned *idx_out);
 int slamhip_gmapping_set(slamhip_gmapping *g, const double *poses, const double *weights);
+/* cfg != NULL: every matching particle appends its scan to the map (scan adder of init_gmapping,
+ * init_occupancy_mapping.h:82-92; rule and scan_quality are overridden: GmappingBaseCell, 1.0) right
+ * after its match, BEFORE the next particle matches -- the reference's particles share one map
+ * object (Q20), which makes this step sequential and unshardable.  NULL switches it off. */
+int slamhip_gmapping_set_map_update(slamhip_gmapping *g, const slamhip_scan_adder_cfg *cfg);
 int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, int *is_master);
 int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
                            long long *launches, long long *carry_reruns);

@@ -47,3 +47,21 @@ def append_scan_ex(oracle, gmap, aux, rule, pose, rng, ang, is_occ=None, quality
     if res < 0:
         raise ValueError("a touched cell lies outside the map window")
     return int(res)
+
+
+class OrcAdder(C.Structure):
+    _fields_ = [("base4", C.c_double * 4), ("blur", C.c_double), ("max_range", C.c_double),
+                ("est_kind", C.c_int), ("shift_amount", C.c_double)]
+
+
+def gmapping_enable_update(oracle, pf, gmap, aux, base=(0.95, 1.0, 0.01, 1.0), blur=0.0,
+                           max_range=float("inf"), est_kind=0, shift_amount=0.0):
+    """Switch on the map update inside OrcGmappingHandle.step: every matching particle appends its
+    scan to gmap.payload / aux (the shared map) before the next particle matches."""
+    L = oracle.lib
+    L.orc_gmapping_set_update.argtypes = [C.c_void_p, C.c_void_p, _dp, _dp]
+    a = OrcAdder()
+    for k in range(4):
+        a.base4[k] = float(base[k])
+    a.blur, a.max_range, a.est_kind, a.shift_amount = blur, max_range, est_kind, shift_amount
+    L.orc_gmapping_set_update(pf.h, C.byref(a), _d(gmap.payload), _d(aux))

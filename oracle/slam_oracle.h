@@ -127,6 +127,13 @@ int orc_heaviest(int n, const double *w);
 /* ---- GMapping particle filter (src/slams/gmapping/gmapping_world.h, gmapping_particle_filter.h,
  *      src/core/particle_filter.h) WITHOUT the map update (the reference run it is pinned against
  *      uses slam/mapping/max_range = 0, which turns append_scan into a no-op) ---- */
+typedef struct orc_adder_s {
+  double base4[4]; /* occupied prob, qual, empty prob, qual */
+  double blur, max_range;
+  int est_kind;    /* 0 const, 1 area */
+  double shift_amount;
+} orc_adder;
+
 typedef struct {
   double pose[3], raw_odom[3], weight;
   int is_master, scan_is_first;
@@ -147,6 +154,10 @@ typedef struct {
   unsigned skip_rate; double max_range;
   orc_spe_cfg cfg;
   orc_gm_cache cache;           /* ONE OOPE shared by all particles (Q20) */
+  /* optional map update inside the step (gmapping_world.h:93-97): scan adder parameters and the
+   * MUTABLE payload / (hits, tries) arrays of the window the `map` argument of the step views */
+  const struct orc_adder_s *upd;
+  double *upd_payload, *upd_aux;
   long long scorer_calls;       /* of the last step */
 } orc_gmapping;
 
@@ -161,6 +172,7 @@ int orc_gmapping_step(orc_gmapping *g, const orc_map *map, int n_raw, const doub
                       unsigned *idx_out);
 void orc_gmapping_get(const orc_gmapping *g, double *poses, double *weights, int *is_master);
 long long orc_gmapping_scorer_calls(const orc_gmapping *g);
+void orc_gmapping_set_update(orc_gmapping *g, const orc_adder *upd, double *payload, double *aux);
 
 /* ---- map update (map_update_oracle.c) ---- */
 /* cell update rules = the reference's GridCell subclasses' operator+= */

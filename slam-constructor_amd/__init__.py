@@ -38,7 +38,7 @@ slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_res
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
-slamhip_gmapping_stats slamhip_map_append_scan slamhip_map_download_aux""".split()
+slamhip_gmapping_stats slamhip_gmapping_set_map_update slamhip_map_append_scan slamhip_map_download_aux""".split()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -179,6 +179,7 @@ def load():
     L.slamhip_gmapping_import.argtypes = [vp, vp, up]
     L.slamhip_gmapping_step.argtypes = [vp, i, i, _dp, _dp, _ip, _dp, C.c_uint32, _ip, up]
     L.slamhip_gmapping_set.argtypes = [vp, _dp, _dp]
+    L.slamhip_gmapping_set_map_update.argtypes = [vp, C.POINTER(ScanAdderCfg)]
     L.slamhip_gmapping_get.argtypes = [vp, _dp, _dp, _ip]
     L.slamhip_gmapping_stats.argtypes = [vp, ll, ll, ll, ll]
     _lib = L
@@ -523,6 +524,16 @@ class GmappingFilter:
                                             occ.ctypes.data_as(_ip), _d(d), resample_seed,
                                             C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_uint))))
         return bool(res.value), idx
+
+    def set_map_update(self, enable=True, base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"),
+                       estimator=0, shift_amount=0.0):
+        """The reference's full step: each matching particle appends its scan to the shared map."""
+        if not enable:
+            _check(self.L.slamhip_gmapping_set_map_update(self.h, None))
+            return
+        cfg = ScanAdderCfg(RULE_GMAPPING, 1.0, base[0], base[1], base[2], base[3], blur, max_range,
+                           estimator, shift_amount)
+        _check(self.L.slamhip_gmapping_set_map_update(self.h, C.byref(cfg)))
 
     def set(self, poses=None, weights=None):
         p = _f64(poses) if poses is not None else None

@@ -25,8 +25,11 @@
 // have hit its predecessor's final cache entry is re-matched alone with that carry (counted in
 // `carry_reruns`; rare: it needs the same endpoint cell AND a different cached value).
 //
-// The map update (append_scan, gmapping_world.h:93-97) is not built yet: the step is
-// the "without map update" variant, exactly the reference run with slam/mapping/max_range = 0.
+// Map update (append_scan, gmapping_world.h:93-97): off by default -- the lock-step step equals the
+// reference run with slam/mapping/max_range = 0.  slamhip_gmapping_set_map_update switches to the
+// reference's full semantics: the particles share ONE map (Q20) and each appends its scan before
+// the next one matches, so the step runs particle after particle (GPU match, then K6 on the same
+// HBM map); that mode cannot be sharded.
 
 #include <cstdlib>
 #include <type_traits>
@@ -107,6 +110,10 @@ struct slamhip_gmapping {
   std::vector<HillClimbingPoseEnumerator> pes;
   std::vector<double> all_w;  // normalised weights of all particles (after plan_resample)
   long long scorer_calls = 0, poses_evaluated = 0, launches = 0, carry_reruns = 0;
+  // map update inside the step (gmapping_world.h:93-97): sequential, unsharded filters only
+  bool update = false;
+  slamhip_scan_adder_cfg upd{};
+  long long cell_updates = 0;
 };
 
 namespace {
@@ -203,7 +210,7 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
     return SLAMHIP_ERR_NO_DEVICE;
   }
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
-  g->scorer_calls = g->poses_evaluated = g->launches = g->carry_reruns = 0;
+  g->scorer_calls = g->poses_evaluated = g->launches = g->carry_reruns = g->cell_updates = 0;
   const double *d = odom_delta;
   // update_robot_pose: the odometry delta is rotated by the particle's accumulated heading correction
   for (auto &p : g->p) {
@@ -257,6 +264,47 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
     rc = slamhip_scan_upload(ctx, nk, fr.data(), fc.data(), fs.data(), fw.data(), nullptr);
     if (rc) return rc;
 
+    if (g->update) {
+      // The reference's full step: every matching particle appends its scan to the ONE shared map
+      // before the next particle matches (gmapping_world.h:88-99, Q20), so the particles are
+      // strictly sequential: match on the GPU (lone-matcher speculation), then K6 on the same map.
+      std::vector<double> rc_all(n_raw), rs_all(n_raw);
+      slamhip_beam_trig_raw(n_raw, angle, rc_all.data(), rs_all.data());
+      g->pes.clear();
+      g->pes.emplace_back(g->prm.hc_failed_rounds_limit, g->prm.hc_translation, g->prm.hc_rotation);
+      for (int idx : act_idx) {
+        GmParticle &p = g->p[idx];
+        MatchJob &job = g->jobs[idx];
+        g->pes[0] = HillClimbingPoseEnumerator(g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
+                                               g->prm.hc_rotation);
+        job.tree.min_reach = 0.02;
+        job.start(&g->pes[0], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, g->carry, 0.25);
+        std::vector<MatchJob *> one{&job};
+        rc = run_jobs(g, map_id, one, 126);
+        if (rc) return rc;
+        g->carry = job.carry;
+        double dl[3];
+        job.delta(dl);
+        for (int c = 0; c < 3; ++c) p.pose[c] += dl[c];
+        if (0.0 < job.best_prob || p.scan_is_first) {
+          slamhip_scan_adder_cfg cfg = g->upd;
+          cfg.rule = SLAMHIP_RULE_GMAPPING;
+          cfg.scan_quality = 1.0;  // scan.quality handed to append_scan (gmapping_world.h:95)
+          long long nu = 0;
+          rc = slamhip_map_append_scan(ctx, map_id, &cfg, p.pose, n_raw, range, rc_all.data(), rs_all.data(),
+                                       is_occ, &nu);
+          if (rc) return rc;
+          g->cell_updates += nu;
+          p.scan_is_first = 0;
+        }
+        p.weight = job.best_prob * p.weight;
+        reset_sm_delta(p);
+        g->scorer_calls += job.scorer_calls;
+      }
+      if (raw_weights_out)
+        for (int i = 0; i < g->count; ++i) raw_weights_out[i] = g->p[i].weight;
+      return SLAMHIP_OK;
+    }
     g->pes.clear();
     g->pes.reserve(act_idx.size());
     std::vector<MatchJob *> act;
@@ -394,6 +442,16 @@ int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const doub
     if (idx_out) std::memcpy(idx_out, idx.data(), sizeof(unsigned) * g->n_total);
   }
   if (resampled) *resampled = req;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_set_map_update(slamhip_gmapping *g, const slamhip_scan_adder_cfg *cfg) {
+  if (!g) return bad("null filter");
+  if (cfg && g->count != g->n_total)
+    return bad("the map update inside the step needs the whole filter on one context: the reference's "
+               "particles share one map and update it one after another");
+  g->update = cfg != nullptr;
+  if (cfg) g->upd = *cfg;
   return SLAMHIP_OK;
 }
 

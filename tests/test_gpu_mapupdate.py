@@ -112,3 +112,27 @@ def test_append_scan_area_estimator_vs_reference_golden(pkg, ctx, name):
             np.testing.assert_array_equal(ctx.map_download_aux(2, lo, lo, hi - lo, hi - lo, AUX[rule]),
                                           g["%s_step%d_aux" % (name, k)])
     ctx.map_release(2)
+
+
+def test_gmapping_filter_with_map_update_vs_reference_golden(pkg, ctx):
+    """The reference's FULL GMapping step through the C-ABI: every matching particle appends its scan
+    to the one shared map before the next particle matches (slamhip_gmapping_set_map_update)."""
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+    n = len(g["seeds"])
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n, g["seeds"])
+    pf.set_map_update(True)
+    for k in range(int(g["n_steps"])):
+        res, _ = pf.step(4, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + k)
+        poses, wts, ms = pf.state()
+        assert res == bool(int(g["step%d_resampled" % k]))
+        np.testing.assert_array_equal(ms, g["step%d_master" % k])
+        np.testing.assert_allclose(poses, g["step%d_poses" % k], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(wts, g["step%d_weights" % k], rtol=1e-9, atol=0)
+        got = ctx.map_download_window(4, 0, 0, w, h, 3)
+        want = g["step%d_payload" % k]
+        np.testing.assert_array_equal(got[..., 0], want[..., 0])  # occupancy: bit-exact
+        np.testing.assert_allclose(got[..., 1:], want[..., 1:], rtol=1e-12, atol=1e-14)  # obstacle means
+        np.testing.assert_array_equal(ctx.map_download_aux(4, 0, 0, w, h, 2), g["step%d_aux" % k])
+    ctx.map_release(4)

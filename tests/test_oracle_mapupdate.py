@@ -56,3 +56,28 @@ def test_append_scan_area_estimator_vs_reference(oracle, name):
                                       err_msg="step %d" % k)
         if aux is not None:
             np.testing.assert_array_equal(aux[lo:hi, lo:hi], g["%s_step%d_aux" % (name, k)])
+
+
+def test_gmapping_filter_with_map_update_vs_reference(oracle):
+    """The full GMapping step of the reference (every particle appends its scan to the ONE shared
+    map before the next particle matches) over five scans: poses, weights, master flags and the
+    map's payload + (hits, tries) after every step."""
+    from pyoracle_mapupdate import gmapping_enable_update
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    payload = np.tile(g["unknown"][:3], (h, w, 1)).astype(np.float64)
+    m = GridMapData(CELL_GMAPPING, payload, g["origin"], float(g["scale"]), g["unknown"][:3])
+    aux = np.zeros((h, w, 2))
+    n = len(g["seeds"])
+    pf = oracle.gmapping_create(n, g["gp"], g["seeds"], skip_rate=3)
+    gmapping_enable_update(oracle, pf, m, aux)
+    for k in range(int(g["n_steps"])):
+        extra = np.arange(9000 + 100 * k, 9000 + 100 * k + n, dtype=np.uint32)
+        res, _ = pf.step(m, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + k, extra)
+        poses, wts, ms = pf.state()
+        assert res == bool(int(g["step%d_resampled" % k]))
+        np.testing.assert_array_equal(ms, g["step%d_master" % k])
+        np.testing.assert_array_equal(poses, g["step%d_poses" % k])
+        np.testing.assert_array_equal(wts, g["step%d_weights" % k])
+        np.testing.assert_array_equal(m.payload, g["step%d_payload" % k])
+        np.testing.assert_array_equal(aux, g["step%d_aux" % k])
