@@ -217,14 +217,33 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
         sm = tt.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, calls = mx[0].item(), sm[1].item()
+    with_update = None
+    if world == 1:
+        # the reference's full step: each particle appends its scan to the shared map before the
+        # next one matches (sequential by construction) -- a few steps are enough
+        pfu = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds)
+        pfu.set_map_update(True)
+        pfu.step(1, scan.range, scan.angle, None, deltas[0], 7)
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        ksteps = 3
+        for k in range(1, 1 + ksteps):
+            pfu.step(1, scan.range, scan.angle, None, deltas[k], 7 + k)
+        torch.cuda.synchronize()
+        du = time.perf_counter() - tu
+        with_update = {"value": n * ksteps / du, "unit": "particles/s", "ms_per_step": 1e3 * du / ksteps,
+                       "steps": ksteps, "note": "sequential particles: GPU match then K6 map update on the "
+                                                "shared map, as the reference does"}
     ctx.map_release(1)
     return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
+            "with_map_update": with_update,
             "ms_per_step": 1e3 * dt / args.pf_steps, "steps": args.pf_steps, "scaling": "strong",
             "pose_candidates_beams_per_s": calls * scan.n / dt,
             "workload": "cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "
                         "GMapping cell, HC(6,0.1,0.1), likelihood step without map update"
                         % (n, world, scan.n, args.pf_size, args.pf_size, args.scale),
-            "collective": "all_gather(raw weights) over RCCL per step" if world > 1 else "none (1 rank)",
+            "collective": ("all_gather(raw weights) per step over %s" %
+                           ("RCCL" if args.backend == "nccl" else "gloo")) if world > 1 else "none (1 rank)",
             "launches_last_step": st["launches"], "carry_reruns_last_step": st["carry_reruns"],
             "resamplings": resamplings}
 

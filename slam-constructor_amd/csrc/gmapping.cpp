@@ -272,6 +272,11 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
       slamhip_beam_trig_raw(n_raw, angle, rc_all.data(), rs_all.data());
       g->pes.clear();
       g->pes.emplace_back(g->prm.hc_failed_rounds_limit, g->prm.hc_translation, g->prm.hc_rotation);
+      struct ReuseGuard {
+        slamhip_ctx *c;
+        explicit ReuseGuard(slamhip_ctx *cc) : c(cc) { mu_allow_scan_reuse(c, true); }
+        ~ReuseGuard() { mu_allow_scan_reuse(c, false); }
+      } reuse_guard(ctx);
       for (int idx : act_idx) {
         GmParticle &p = g->p[idx];
         MatchJob &job = g->jobs[idx];

@@ -58,7 +58,8 @@ struct MuArgs {
   // work buffers
   unsigned *counts, *offsets;  // per beam
   unsigned *keys;
-  double *rec_prob, *rec_qual;
+  double *rec_prob, *rec_qual;   // emit: rec_prob holds interleaved (prob, qual) pairs; apply: sorted arrays
+  const double *rec_ox, *rec_oy;  // apply: the obstacle point of each sorted record
   unsigned *rec_beam;
   double *beam_end;  // 2 per beam (the obstacle point of its observations)
   int *error_flag;   // set when a touched cell lies outside the window
@@ -148,10 +149,10 @@ __device__ __forceinline__ void mu_record(const MuArgs &a, unsigned slot, int b,
       prob = base_prob * prob_scale;
     }
   }
+  // two scattered stores per step (lanes write to different beams' slots): the 4-byte key and one
+  // 16-byte (prob, qual) pair; the beam index is recovered from `offsets` in k_mu_gather
   a.keys[slot] = (unsigned)iy * (unsigned)a.pitch + (unsigned)ix;
-  a.rec_prob[slot] = prob;
-  a.rec_qual[slot] = qual;
-  a.rec_beam[slot] = (unsigned)b;
+  reinterpret_cast<double2 *>(a.rec_prob)[slot] = make_double2(prob, qual);
 }
 
 __global__ void k_mu_emit(MuArgs a) {
@@ -261,6 +262,29 @@ __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs
   }
 }
 
+// records into sorted order, so that a cell's (possibly long: every beam crosses the robot's cell)
+// sequential chain in k_mu_apply streams through contiguous memory instead of chasing order[j]
+__global__ void k_mu_gather(const unsigned *order, unsigned total, const double *rec_pq, const unsigned *offsets,
+                            int n_beams, const double *beam_end, double *srt_prob, double *srt_qual,
+                            double *srt_ox, double *srt_oy) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned r = order[i];
+  const double2 pq = reinterpret_cast<const double2 *>(rec_pq)[r];
+  srt_prob[i] = pq.x;
+  srt_qual[i] = pq.y;
+  // the beam owning slot r: the last b with offsets[b] <= r (records are beam-major)
+  int lo = 0, hi = n_beams - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (offsets[mid] <= r) lo = mid;
+    else hi = mid - 1;
+  }
+  srt_ox[i] = beam_end[2 * lo];
+  srt_oy[i] = beam_end[2 * lo + 1];
+}
+
+// `a.rec_*` point at the SORTED record arrays here (k_mu_gather)
 __global__ void k_mu_apply(MuArgs a, const unsigned *keys, const unsigned *order, unsigned total,
                            unsigned long long *n_updates) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,10 +302,32 @@ __global__ void k_mu_apply(MuArgs a, const unsigned *keys, const unsigned *order
   }
   double x0 = aux ? aux[0] : 0, x1 = (aux && a.aux_stride > 1) ? aux[1] : 0;
   unsigned cnt = 0;
-  for (unsigned j = i; j < total && keys[j] == key; ++j, ++cnt) {
-    const unsigned r = order[j];
-    const double prob = a.rec_prob[r], est_qual = a.rec_qual[r];
-    const unsigned b = a.rec_beam[r];
+  (void)order;
+  // The chain is sequential (each update reads the previous result), but its INPUTS are not: they are
+  // fetched eight records ahead so that the in-order wave pays memory latency once per chunk.
+  constexpr int CH = 8;
+  bool more = true;
+  for (unsigned j0 = i; more && j0 < total; j0 += CH) {
+    unsigned kk[CH];
+    double pp[CH], qq[CH], oxs[CH], oys[CH];
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const unsigned j = min(j0 + t, total - 1);
+      kk[t] = (j0 + t < total) ? keys[j] : kInvalidKey;
+      pp[t] = a.rec_prob[j];
+      qq[t] = a.rec_qual[j];
+      oxs[t] = a.rec_ox[j];
+      oys[t] = a.rec_oy[j];
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+    if (!more) continue;
+    if (kk[t] != key) {
+      more = false;
+      continue;
+    }
+    ++cnt;
+    const double prob = pp[t], est_qual = qq[t], obx = oxs[t], oby = oys[t];
     const bool invalid = isnan(prob) || isnan(est_qual);
     if (invalid && a.rule != 0) continue;
     switch (a.rule) {
@@ -324,15 +370,16 @@ __global__ void k_mu_apply(MuArgs a, const unsigned *keys, const unsigned *order
         c0 = (c0 * (tries - 1) + aoo_p) / tries;
         if (!is_free) {
           ++hits;
-          c1 = (c1 * (hits - 1) + a.beam_end[2 * b]) / hits;
-          c2 = (c2 * (hits - 1) + a.beam_end[2 * b + 1]) / hits;
+          c1 = (c1 * (hits - 1) + obx) / hits;
+          c2 = (c2 * (hits - 1) + oby) / hits;
         }
         x0 = hits;
         x1 = tries;
         break;
       }
     }
-  }
+    }  // records of this chunk
+  }    // chunks
   cell[0] = c0;
   if (a.cell_dbl == 4) {
     cell[1] = c1;
@@ -356,9 +403,15 @@ struct MuScratch {
   unsigned *counts = nullptr, *offsets = nullptr, *keys = nullptr, *keys_sorted = nullptr;
   unsigned *order = nullptr, *order_sorted = nullptr, *rec_beam = nullptr;
   double *rec_prob = nullptr, *rec_qual = nullptr, *beam_end = nullptr, *scan = nullptr;
+  double *srt_prob = nullptr, *srt_qual = nullptr, *srt_ox = nullptr, *srt_oy = nullptr;  // sorted records
   int *occ = nullptr, *error_flag = nullptr;
   unsigned long long *n_updates = nullptr;
   void *temp = nullptr;
+  // scan re-use (see slamhip_map_append_scan)
+  bool reuse_ok = false;
+  const double *last_range = nullptr, *last_cos = nullptr, *last_sin = nullptr;
+  const int *last_occ = nullptr;
+  int last_n = -1;
 };
 // one scratch set per context, keyed by the context pointer (contexts are few and long-lived)
 std::vector<std::pair<slamhip_ctx *, MuScratch>> g_scratch;
@@ -370,6 +423,19 @@ MuScratch &scratch_of(slamhip_ctx *ctx) {
   return g_scratch.back().second;
 }
 
+}  // namespace
+
+namespace slamhip {
+// internal: while enabled, consecutive slamhip_map_append_scan calls that pass the very same host
+// arrays upload them once (the caller guarantees their contents do not change in between)
+void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on) {
+  MuScratch &sc = scratch_of(ctx);
+  sc.reuse_ok = on;
+  sc.last_n = -1;
+}
+}  // namespace slamhip
+
+namespace {
 __global__ void k_iota(unsigned *p, unsigned n) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -428,10 +494,21 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     sc.cap_beams = cap;
   }
   const size_t cb = sc.cap_beams;
-  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cb, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cb, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  // the GMapping filter appends the SAME raw scan once per particle: it brackets its loop with
+  // mu_allow_scan_reuse(), and identical host arrays are then uploaded only once
+  const bool reuse = sc.reuse_ok && sc.last_range == range && sc.last_cos == cos_a && sc.last_sin == sin_a &&
+                     sc.last_occ == is_occ && sc.last_n == n;
+  if (!reuse) {
+    SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cb, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cb, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    sc.last_range = range;
+    sc.last_cos = cos_a;
+    sc.last_sin = sin_a;
+    sc.last_occ = is_occ;
+    sc.last_n = n;
+  }
   SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), ctx->stream));
   SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long), ctx->stream));
 
@@ -473,9 +550,21 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   const dim3 bgrid((n + 255) / 256);
   hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, ctx->stream, sc.counts, sc.offsets, n);
+  // the record count is needed on the host to size the buffers: the same IEEE operations as
+  // k_mu_count (no contraction on either side) give the same bounds without a device round trip
   unsigned total = 0;
-  SLAMHIP_CHECK(hipMemcpyAsync(&total, sc.offsets + n, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  {
+    const int rcx = (int)std::floor(a.px / a.scale), rcy = (int)std::floor(a.py / a.scale);
+    for (int b = 0; b < n; ++b) {
+      const double c = a.cs * cos_a[b] - a.sn * sin_a[b];
+      const double s = a.sn * cos_a[b] + a.cs * sin_a[b];
+      const double wx = a.px + range[b] * c, wy = a.py + range[b] * s;
+      const double ddx = wx - a.px, ddy = wy - a.py;
+      if (a.max_range_sq < ddx * ddx + ddy * ddy) continue;
+      const int ocx = (int)std::floor(wx / a.scale), ocy = (int)std::floor(wy / a.scale);
+      total += (unsigned)(std::abs(ocx - rcx) + std::abs(ocy - rcy) + 1);
+    }
+  }
   if (total == 0) {
     if (n_updates_out) *n_updates_out = 0;
     return SLAMHIP_OK;
@@ -491,8 +580,14 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.order, sizeof(unsigned) * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.order_sorted, sizeof(unsigned) * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.rec_beam, sizeof(unsigned) * cap));
-    SLAMHIP_CHECK(hipMalloc(&sc.rec_prob, sizeof(double) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.rec_prob, sizeof(double) * 2 * cap));  // interleaved (prob, qual)
     SLAMHIP_CHECK(hipMalloc(&sc.rec_qual, sizeof(double) * cap));
+    for (void *p : {(void *)sc.srt_prob, (void *)sc.srt_qual, (void *)sc.srt_ox, (void *)sc.srt_oy})
+      if (p) hipFree(p);
+    SLAMHIP_CHECK(hipMalloc(&sc.srt_prob, sizeof(double) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.srt_qual, sizeof(double) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.srt_ox, sizeof(double) * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.srt_oy, sizeof(double) * cap));
     sc.temp_bytes = 0;
     SLAMHIP_CHECK(rocprim::radix_sort_pairs(nullptr, sc.temp_bytes, sc.keys, sc.keys_sorted, sc.order,
                                             sc.order_sorted, cap, 0, 32, ctx->stream));
@@ -506,8 +601,18 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   hipLaunchKernelGGL(k_mu_emit, bgrid, dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sc.order, total);
   size_t tb = sc.temp_bytes;
+  // sort only the bits a cell key can occupy; the invalid key (all ones) still sorts last because
+  // every valid key is < 2^nbits - 1
+  unsigned nbits = 1;
+  while (nbits < 32 && ((1ull << nbits) - 1) <= (unsigned long long)m.pitch * m.height) ++nbits;
   SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted,
-                                          total, 0, 32, ctx->stream));
+                                          total, 0, nbits, ctx->stream));
+  hipLaunchKernelGGL(k_mu_gather, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sc.order_sorted, total,
+                     sc.rec_prob, sc.offsets, n, sc.beam_end, sc.srt_prob, sc.srt_qual, sc.srt_ox, sc.srt_oy);
+  a.rec_prob = sc.srt_prob;
+  a.rec_qual = sc.srt_qual;
+  a.rec_ox = sc.srt_ox;
+  a.rec_oy = sc.srt_oy;
   hipLaunchKernelGGL(k_mu_apply, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a, sc.keys_sorted,
                      sc.order_sorted, total, sc.n_updates);
   SLAMHIP_CHECK(hipGetLastError());

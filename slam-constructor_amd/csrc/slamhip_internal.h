@@ -93,6 +93,7 @@ struct DeviceMap {
   int aux_stride = 0;
 };
 
+void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 
