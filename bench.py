@@ -67,6 +67,47 @@ def parse():
     return ap.parse_args()
 
 
+def load_traffic(workload):
+    """HBM bytes per scoring launch from the newest committed PMC summary
+    (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py from separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  PMC counters cannot be
+    collected from inside the benchmark, so this is the one roofline field not measured live."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    w = d.get("workloads", {}).get(workload)
+    if not w or "bytes_per_launch" not in w:
+        return None, None
+    return w["bytes_per_launch"], "%s (%s)" % (os.path.relpath(files[-1], ROOT), w["correction"])
+
+
+def sweep_ceiling(pkg, ctx, cfg, sc, scan_n, n_poses, launches, bpu, torch):
+    """Kernel ceiling beside the matcher-mode number: the same scoring kernel on flat batches of
+    device-resident poses (no host round trip, launches back to back)."""
+    rs = np.random.RandomState(11)
+    poses = torch.from_numpy(sc["init_pose"] + rs.randn(n_poses, 3) * [0.2, 0.2, 0.1]).cuda()
+    scores = torch.empty(n_poses, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(5):
+        ctx.score_poses_device(0, cfg, n_poses, poses.data_ptr(), scores.data_ptr())
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    for _ in range(launches):
+        ctx.score_poses_device(0, cfg, n_poses, poses.data_ptr(), scores.data_ptr())
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    ms, n, units = ctx.profile_read(reset=True)
+    achieved = units * bpu / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, src = load_traffic("sweep")
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "kernel": "k_score_point", "bytes_per_unit": bpu, "launches": n,
+            "poses_per_launch": n_poses, "beams": scan_n, "avg_launch_us": 1e3 * ms / max(n, 1)}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -368,6 +409,10 @@ def main():
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
         t_max, units_all = tt.item(), uu.item()
 
+    ceiling = None
+    if rank == 0 and args.workload != "sweep" and not args.strict:  # outside the timed region
+        ceiling = sweep_ceiling(pkg, ctx, cfg, sc, scan.n, args.sweep_poses, 50, BYTES_PER_UNIT[bkey], torch)
+
     pf_out = None
     if not args.no_pf and args.workload != "sweep":
         pf_out = particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch)
@@ -375,6 +420,7 @@ def main():
     if rank == 0:
         bpu = BYTES_PER_UNIT[bkey]
         achieved = (k_units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src = load_traffic(args.workload)
         out = {
             "metric": "pose-candidates*beams/sec (1080-beam scan, 2000^2 grid)",
             "value": units_all / t_max,
@@ -395,11 +441,13 @@ def main():
                        "backend": args.backend if world > 1 else None,
                        **extra},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_score_point", "bytes_per_unit": bpu,
                          "launches": k_launches, "units_launched": k_units,
                          "avg_launch_us": 1e3 * k_ms / max(k_launches, 1)},
         }
+        if ceiling is not None:
+            out["roofline_sweep"] = ceiling
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds, weighting)
         if pf_out is not None:

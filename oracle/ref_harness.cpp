@@ -295,6 +295,16 @@ void ref_map_update_bulk(void *h, int n, const int *xy, const double *prob) {
     m.update({xy[2 * i], xy[2 * i + 1]}, AreaOccupancyObservation{true, {prob[i], 1.0}, {0, 0}, 1.0});
 }
 
+// GridMap::save_state (plain_grid_map.h:79-99) to a file: the `.map` fixture format of
+// lslam2D_bag_runner's dump_state / sm_runner (src/utils/sm_runner.cpp:36-50)
+int ref_map_save_state(void *h, const char *path) {
+  auto &m = *static_cast<RefMap *>(h)->map;
+  auto buf = m.save_state();
+  std::ofstream f(path, std::ios::binary);
+  f.write(buf.data(), buf.size());
+  return (int)buf.size();
+}
+
 void ref_map_unknown_payload(void *h, double *out) {
   auto *rm = static_cast<RefMap *>(h);
   auto c = rm->map->new_cell();

@@ -35,6 +35,8 @@
 //  * map window = pitched row-major HBM array; out-of-window reads return the prototype payload
 //    (UnboundedPlainGridMap::operator[], src/core/maps/plain_grid_map.h:69-73).
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 #include "slamhip_internal.h"
@@ -502,15 +504,23 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
 }
 
 // ---- launch ------------------------------------------------------------------------------------
+// Scoring launches go through hipExtLaunchKernelGGL so that slamhip_profile_* can attach its
+// HIP events to the dispatch itself: the elapsed time is then the kernel's own begin..end (what
+// rocprofv3 --kernel-trace reports), not record-to-record on an idle stream which adds ~4 us of
+// queue processing per isolated launch (tools/event_probe.hip).  Null events = a plain launch.
+#define SLAMHIP_LAUNCH(kernel, grid, block, shm, st, e0, e1, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__)
+
 template <int MODEL, bool WT>
-static hipError_t launch_point_kb(const ScoreArgs &a, int kb, dim3 grid, hipStream_t st) {
+static hipError_t launch_point_kb(const ScoreArgs &a, int kb, dim3 grid, hipStream_t st,
+                                  hipEvent_t e0, hipEvent_t e1) {
   switch (kb) {
-    case 1: hipLaunchKernelGGL((k_score_point<MODEL, 1, WT>), grid, dim3(kBlock), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_score_point<MODEL, 2, WT>), grid, dim3(kBlock), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((k_score_point<MODEL, 3, WT>), grid, dim3(kBlock), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((k_score_point<MODEL, 4, WT>), grid, dim3(kBlock), 0, st, a); break;
-    case 5: hipLaunchKernelGGL((k_score_point<MODEL, 5, WT>), grid, dim3(kBlock), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_score_point<MODEL, 0, WT>), grid, dim3(kBlock), 0, st, a); break;
+    case 1: SLAMHIP_LAUNCH((k_score_point<MODEL, 1, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 2: SLAMHIP_LAUNCH((k_score_point<MODEL, 2, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 3: SLAMHIP_LAUNCH((k_score_point<MODEL, 3, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 4: SLAMHIP_LAUNCH((k_score_point<MODEL, 4, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 5: SLAMHIP_LAUNCH((k_score_point<MODEL, 5, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    default: SLAMHIP_LAUNCH((k_score_point<MODEL, 0, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
   }
   return hipGetLastError();
 }
@@ -525,7 +535,7 @@ static int pick_poses_per_block(int n_poses) {
 }
 
 hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum_order,
-                        hipStream_t stream) {
+                        hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   ScoreArgs a = args;
   if (a.n_poses <= 0) return hipSuccess;
   if (a.poses_per_block <= 0) a.poses_per_block = pick_poses_per_block(a.n_poses);
@@ -533,13 +543,15 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   const dim3 grid((a.n_poses + a.poses_per_block - 1) / a.poses_per_block);
   const int kb = (a.scan.n + kBlock - 1) / kBlock;
   const bool wt = sum_order == SLAMHIP_SUM_SEQUENTIAL;
+  if (wt && oope != SLAMHIP_OOPE_GMAPPING && (ev_start || ev_stop)) return hipErrorInvalidValue;
+  const hipEvent_t stop1 = ev_stop;
   hipError_t e = hipSuccess;
   if (oope == SLAMHIP_OOPE_GMAPPING) {
     if (kb > 8) return hipErrorInvalidValue;
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
 #define GM_CASE(K)                                                                              \
   case K:                                                                                       \
-    hipLaunchKernelGGL((k_score_gmapping<K>), grid, dim3(kBlock), shm, stream, a);              \
+    SLAMHIP_LAUNCH((k_score_gmapping<K>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a); \
     break;
     switch (kb < 1 ? 1 : kb) {
       GM_CASE(1) GM_CASE(2) GM_CASE(3) GM_CASE(4) GM_CASE(5) GM_CASE(6) GM_CASE(7) GM_CASE(8)
@@ -550,25 +562,25 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   if (oope == SLAMHIP_OOPE_MAX || oope == SLAMHIP_OOPE_MEAN || oope == SLAMHIP_OOPE_OVERLAP) {
     if (!wt) a.terms = nullptr;
     if (cell_model == SLAMHIP_CELL_OCC)
-      hipLaunchKernelGGL((k_score_window<SLAMHIP_CELL_OCC>), grid, dim3(kBlock), 0, stream, a, oope);
+      SLAMHIP_LAUNCH((k_score_window<SLAMHIP_CELL_OCC>), grid, dim3(kBlock), 0, stream, ev_start, stop1, a, oope);
     else if (cell_model == SLAMHIP_CELL_TBM)
-      hipLaunchKernelGGL((k_score_window<SLAMHIP_CELL_TBM>), grid, dim3(kBlock), 0, stream, a, oope);
+      SLAMHIP_LAUNCH((k_score_window<SLAMHIP_CELL_TBM>), grid, dim3(kBlock), 0, stream, ev_start, stop1, a, oope);
     else
       return hipErrorInvalidValue;
     e = hipGetLastError();
   } else if (cell_model == SLAMHIP_CELL_OCC) {
-    e = wt ? launch_point_kb<SLAMHIP_CELL_OCC, true>(a, kb, grid, stream)
-           : launch_point_kb<SLAMHIP_CELL_OCC, false>(a, kb, grid, stream);
+    e = wt ? launch_point_kb<SLAMHIP_CELL_OCC, true>(a, kb, grid, stream, ev_start, stop1)
+           : launch_point_kb<SLAMHIP_CELL_OCC, false>(a, kb, grid, stream, ev_start, stop1);
   } else if (cell_model == SLAMHIP_CELL_TBM) {
-    e = wt ? launch_point_kb<SLAMHIP_CELL_TBM, true>(a, kb, grid, stream)
-           : launch_point_kb<SLAMHIP_CELL_TBM, false>(a, kb, grid, stream);
+    e = wt ? launch_point_kb<SLAMHIP_CELL_TBM, true>(a, kb, grid, stream, ev_start, stop1)
+           : launch_point_kb<SLAMHIP_CELL_TBM, false>(a, kb, grid, stream, ev_start, stop1);
   } else {
     return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  if (wt) {
-    hipLaunchKernelGGL(k_sum_sequential, dim3((a.n_poses + 63) / 64), dim3(64), 0, stream, a.terms,
-                       a.n_poses, a.scan.n, a.scan.tot_w, a.scores);
+  if (wt) {  // strict order is two kernels: the caller times the pair with recorded events instead
+    SLAMHIP_LAUNCH(k_sum_sequential, dim3((a.n_poses + 63) / 64), dim3(64), 0, stream, (hipEvent_t) nullptr,
+                   (hipEvent_t) nullptr, a.terms, a.n_poses, a.scan.n, a.scan.tot_w, a.scores);
     e = hipGetLastError();
   }
   return e;

@@ -160,11 +160,15 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
     }
     e0 = ctx->ev_pool[ctx->ev_used++];
     e1 = ctx->ev_pool[ctx->ev_used++];
-    SLAMHIP_CHECK(hipEventRecord(e0, ctx->stream));
   }
-  SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, ctx->stream));
+  // one kernel: the events ride on the dispatch (kernel begin..end, as rocprofv3 sees it);
+  // strict order is two kernels and is bracketed by recorded events instead
+  const bool bracket = ctx->profile && order == SLAMHIP_SUM_SEQUENTIAL;
+  if (bracket) SLAMHIP_CHECK(hipEventRecord(e0, ctx->stream));
+  SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, ctx->stream, bracket ? nullptr : e0,
+                             bracket ? nullptr : e1));
   if (ctx->profile) {
-    SLAMHIP_CHECK(hipEventRecord(e1, ctx->stream));
+    if (bracket) SLAMHIP_CHECK(hipEventRecord(e1, ctx->stream));
     ctx->prof_launches += 1;
     ctx->prof_units += (long long)a.n_poses * a.scan.n;
   }

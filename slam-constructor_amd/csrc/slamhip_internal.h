@@ -67,8 +67,10 @@ inline int cell_stride_host(int model) {
 }
 
 // ---- launchers (score_kernels.hip) ---------------------------------------------------------
+// ev_start / ev_stop (optional, single-kernel orders only): attached to the scoring dispatch
 hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_order,
-                        hipStream_t stream);
+                        hipStream_t stream, hipEvent_t ev_start = nullptr,
+                        hipEvent_t ev_stop = nullptr);
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream);
 hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
                                 const int *d_coords, const double *d_vals, hipStream_t stream);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 summaries of gpurun_out/<tag>/ (made by tools/profile.sh on the GPU box) into
-profiles/ and write profiles/<tag>_summary.md."""
+profiles/ and write profiles/<tag>_summary.md + profiles/<tag>_traffic.json (per-launch HBM bytes of
+the scoring kernel from the PMC passes; bench.py reports it as roofline.traffic)."""
 import collections
 import csv
 import json
@@ -13,9 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+KERNEL = "k_score_point"
 lines = ["# rocprofv3 summaries, round tag `%s`\n" % tag,
          "Commands: `tools/profile.sh %s` (rocprofv3 --kernel-trace --stats of `bench.py`, of "
-         "`bench.py --workload sweep` and `--workload mc`; separate --pmc passes).\n" % tag]
+         "`bench.py --workload sweep` and `--workload mc`; separate --pmc passes for hc and sweep).\n" % tag]
 for name in ("hc", "sweep", "mc"):
     st = os.path.join(src, name, "%s_kernel_stats.csv" % name)
     if not os.path.exists(st):
@@ -23,7 +25,8 @@ for name in ("hc", "sweep", "mc"):
     shutil.copy(st, os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))
     lines.append("## %s — kernel stats (`%s_%s_kernel_stats.csv`)\n" % (name, tag, name))
     lines.append("| kernel | calls | avg ns | min | max | % |\n|---|---|---|---|---|---|")
-    for r in list(csv.DictReader(open(st)))[:4]:
+    rows = list(csv.DictReader(open(st)))
+    for r in rows[:6]:
         lines.append("| `%s` | %s | %.0f | %s | %s | %s |" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]),
                                                            r["MinNs"], r["MaxNs"], r["Percentage"]))
     bj = os.path.join(src, "%s.bench.json" % name)
@@ -31,27 +34,46 @@ for name in ("hc", "sweep", "mc"):
         d = json.load(open(bj))
         shutil.copy(bj, os.path.join(dst, "%s_%s_bench.json" % (tag, name)))
         r = d["roofline"]
+        prof = [float(x["AverageNs"]) for x in rows if KERNEL in x["Name"]]
         lines.append("\nbench line of the same (profiled) run: value %.4g %s, %.4f ms/step; HIP-event kernel "
-                     "time %.2f us/launch over %d launches -> %.0f GB/s algorithmic = %.3f of 8 TB/s.\n"
-                     % (d["value"], d["unit"], d["ms_per_step"], r["avg_launch_us"], r["launches"],
-                        r["achieved"], r["frac"]))
+                     "time %.2f us/launch over %d launches (rocprofv3 average for %s in this run: %s us) "
+                     "-> %.0f GB/s algorithmic = %.3f of 8 TB/s.\n"
+                     % (d["value"], d["unit"], d["ms_per_step"], r["avg_launch_us"], r["launches"], KERNEL,
+                        ", ".join("%.2f" % (p / 1e3) for p in prof), r["achieved"], r["frac"]))
     except Exception as e:  # noqa: BLE001
         lines.append("\n(bench line not captured: %s)\n" % e)
-for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
-    f = os.path.join(src, "pmc_%s" % c, "pmc_counter_collection.csv")
-    if not os.path.exists(f):
-        continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "k_score_point" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    lines.append("## PMC pass %s (sweep: 4096 poses x 1080 beams per launch, k_score_point)\n" % c)
-    for k, v in acc.items():
-        lines.append("* %s: mean %.6g over %d dispatches" % (k, sum(v) / len(v), len(v)))
-    lines.append("")
-    with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, c)), "w") as out:
-        out.write("counter,dispatches,mean\n")
+
+traffic = {}
+for wl in ("hc", "sweep"):
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
+        f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        lines.append("## PMC pass %s, workload %s (%s dispatches)\n" % (c, wl, KERNEL))
         for k, v in acc.items():
-            out.write("%s,%d,%.6g\n" % (k, len(v), sum(v) / len(v)))
+            lines.append("* %s: mean %.6g over %d dispatches" % (k, sum(v) / len(v), len(v)))
+            if k in ("FETCH_SIZE", "WRITE_SIZE"):
+                traffic.setdefault(wl, {})[k + "_kb_raw"] = sum(v) / len(v)
+                traffic[wl][k + "_dispatches"] = len(v)
+        lines.append("")
+        with open(os.path.join(dst, "%s_pmc_%s_%s.csv" % (tag, wl, c)), "w") as out:
+            out.write("counter,dispatches,mean\n")
+            for k, v in acc.items():
+                out.write("%s,%d,%.6g\n" % (k, len(v), sum(v) / len(v)))
+for wl, t in traffic.items():
+    if "FETCH_SIZE_kb_raw" in t and "WRITE_SIZE_kb_raw" in t:
+        # MI355X_MICROARCH.md, HBM: rocprofv3 reports KB; on gfx950 FETCH_SIZE tallies 128-B
+        # requests at 64 B -> x2; WRITE_SIZE taken as reported (uncalibrated, and tiny here)
+        t["bytes_per_launch"] = 1024.0 * (2.0 * t["FETCH_SIZE_kb_raw"] + t["WRITE_SIZE_kb_raw"])
+        t["correction"] = "FETCH_SIZE KB x2 (gfx950), WRITE_SIZE KB as reported; separate --pmc passes"
+        lines.append("* %s: HBM traffic per %s launch = %.0f bytes (%s)" % (wl, KERNEL, t["bytes_per_launch"],
+                                                                          t["correction"]))
+if traffic:
+    json.dump({"tag": tag, "kernel": KERNEL, "workloads": traffic},
+              open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
