@@ -84,6 +84,7 @@ struct slamref_fixed_random_device {
 #include "utils/data_generation/map_primitives.h"
 #include "utils/data_generation/grid_map_patcher.h"
 #include "utils/data_generation/laser_scan_generator.h"
+#include "utils/map_dumpers.h"
 #include "../test/core/mock_grid_cell.h"
 
 #undef private
@@ -295,8 +296,17 @@ void ref_map_update_bulk(void *h, int n, const int *xy, const double *prob) {
     m.update({xy[2 * i], xy[2 * i + 1]}, AreaOccupancyObservation{true, {prob[i], 1.0}, {0, 0}, 1.0});
 }
 
+// GridMapToPgmDumber::dump_map (src/utils/map_dumpers.h:65-90) of the map to `path`
+int ref_map_dump_pgm(void *h, const char *path) {
+  auto &m = *static_cast<RefMap *>(h)->map;
+  std::ofstream f(path, std::ios::binary | std::ios::out);
+  GridMapToPgmDumber::dump_map(f, m);
+  return f.good() ? 0 : -1;
+}
+
 // GridMap::save_state (plain_grid_map.h:79-99) to a file: the `.map` fixture format of
 // lslam2D_bag_runner's dump_state / sm_runner (src/utils/sm_runner.cpp:36-50)
+
 int ref_map_save_state(void *h, const char *path) {
   auto &m = *static_cast<RefMap *>(h)->map;
   auto buf = m.save_state();

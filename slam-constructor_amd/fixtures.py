@@ -53,7 +53,9 @@ def read_map(path, cell="base"):
     else:
         payload = np.stack([cells["u"], cells["e"], cells["o"], cells["c"]], axis=2)
         model = 1
-    return MapFile(model, payload, (ox, oy), scale, cells["qual"].copy(), cells["unk"].astype(bool))
+    mf = MapFile(model, payload, (ox, oy), scale, cells["qual"].copy(), cells["unk"].astype(bool))
+    mf.prob = cells["prob"].copy()  # Occupancy::prob_occ plane (what the PGM dump shows)
+    return mf
 
 
 def write_map(path, m, quality=None, is_unknown=None):
@@ -131,10 +133,66 @@ def read_properties(path, _glob=None, _depth=0):
     return glob
 
 
+def pgm_bytes(prob):
+    """GridMapToPgmDumber::dump_map (src/utils/map_dumpers.h:65-90): header 'P5\\nW\\nH\\n255\\n',
+    rows from the top (largest y) down, intensity = (unsigned char)(255 * (1 - clamp(prob, 0, 1)))."""
+    prob = np.asarray(prob, dtype=np.float64)
+    val = 1.0 - np.clip(prob, 0.0, 1.0)
+    img = (255 * val).astype(np.uint8)[::-1]  # float -> integer conversion truncates, like the cast
+    return b"P5\n%d\n%d\n255\n" % (img.shape[1], img.shape[0]) + img.tobytes()
+
+
 def write_pgm(path, m):
-    """Grey occupancy picture: unknown cells mid-grey, occupied dark (src/utils/map_dumpers.h:57-89)."""
-    prob = m.payload[..., 0] if m.cell_model == 0 else m.payload[..., 2]
-    img = np.clip(255.0 * (1.0 - prob), 0, 255).astype(np.uint8)[::-1]
+    """PGM of a map window (occupancy probability plane)."""
+    if m.cell_model == 0:
+        prob = m.payload[..., 0]
+    else:
+        prob = getattr(m, "prob", None)
+        if prob is None:
+            raise ValueError("TBM window without its prob_occ plane")
     with open(path, "wb") as f:
-        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
-        f.write(img.tobytes())
+        f.write(pgm_bytes(prob))
+
+
+class UnboundedWindow:
+    """Geometry of an UnboundedPlainGridMap as updates grow it: ensure_inside
+    (src/core/maps/plain_grid_map.h:133-176) with its Expansion_Rate = 1.2 rule, unsigned
+    arithmetic and the integer quotient `prep / (new - dim)` (1 when cells are prepended, 0 when
+    appended).  Host-side mirror for tools that must reproduce the reference's map geometry
+    (PGM size, `.map` header); the device window itself can be any superset."""
+    EXPANSION_RATE = 1.2
+
+    def __init__(self, width, height, origin=None):
+        self.width, self.height = int(width), int(height)
+        # RegularSquaresGrid starts with the origin in the middle (regular_squares_grid.h:120-122)
+        self.origin = (self.width // 2, self.height // 2) if origin is None else (int(origin[0]), int(origin[1]))
+
+    @staticmethod
+    def _cells_nm(val, hi):
+        if val < 0:
+            return -val, 0
+        if hi <= val:
+            return 0, val - hi + 1
+        return 0, 0
+
+    def _grow_dim(self, dim, prep, app):
+        new = prep + dim + app
+        if dim < new and new < self.EXPANSION_RATE * dim:
+            scale = float(prep // (new - dim))
+            prep = int(prep + (self.EXPANSION_RATE * dim - new) * scale)
+            new = int(self.EXPANSION_RATE * dim)
+            app = new - (prep + dim)
+        return new, prep, app
+
+    def ensure_inside(self, cx, cy):
+        """True when the window had to grow to hold external cell (cx, cy)."""
+        ix, iy = cx + self.origin[0], cy + self.origin[1]
+        if 0 <= ix < self.width and 0 <= iy < self.height:
+            return False
+        px, ax = self._cells_nm(ix, self.width)
+        py, ay = self._cells_nm(iy, self.height)
+        new_w, px, ax = self._grow_dim(self.width, px, ax)
+        new_h, py, ay = self._grow_dim(self.height, py, ay)
+        self.width, self.height = new_w, new_h
+        self.origin = (self.origin[0] + px, self.origin[1] + py)
+        return True

@@ -1,0 +1,179 @@
+"""N1: brute-force matcher against the compiled reference -- the 8 smoke cases of
+test/core/scan_matchers/brute_force_sm_smoke_test.cpp and the search-space maps of
+src/utils/pose2D_search_space_evaluator.cpp (goldens: tests/golden/make_golden_search_space.py)."""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+from helpers import load, map_from
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = ["closed", "open", "several"]
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+fx = _load(os.path.join(ROOT, "slam-constructor_amd", "fixtures.py"), "slamhip_fixtures")
+tool = _load(os.path.join(ROOT, "tools", "p2d_ss_evaluator_hip.py"), "p2d_ss_evaluator_hip")
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+# ------------------------------------------------------------------ host logic (CPU)
+def test_unbounded_window_growth_matches_the_reference():
+    g = load("map_growth.npz")
+    k = 0
+    while "seq%d_cells" % k in g:
+        w, h, ox, oy = g["seq%d_start" % k]
+        win = fx.UnboundedWindow(w, h)
+        assert win.origin == (ox, oy)
+        for c, geo in zip(g["seq%d_cells" % k], g["seq%d_geometry" % k]):
+            win.ensure_inside(int(c[0]), int(c[1]))
+            assert (win.width, win.height, win.origin[0], win.origin[1]) == tuple(geo), (k, c)
+        k += 1
+    assert k == 4
+
+
+def test_pgm_dump_is_byte_identical_to_the_reference_dumper():
+    g = load("search_space.npz")
+    for s in SCENES:
+        assert fx.pgm_bytes(g[s + "_map_payload"][..., 0]) == g[s + "_input_pgm"].tobytes()
+
+
+# ------------------------------------------------------------------ oracle vs reference (CPU)
+def _smoke_scan(g, oracle, po, m, pose, cached):
+    if cached:
+        trig = po.ScanData(g["raw_range"], g["raw_angle"], None, None, po.TRIG_CACHED, float(g["a_min"]),
+                           float(g["a_inc"]), g["tab_sin"], g["tab_cos"])
+        kept = oracle.filter_scan(m, g["raw_range"], g["raw_angle"], g["raw_occ"], pose, trig=trig)
+        return po.ScanData(g["raw_range"][kept], g["raw_angle"][kept], None, None, po.TRIG_CACHED,
+                           float(g["a_min"]), float(g["a_inc"]), g["tab_sin"], g["tab_cos"])
+    kept = oracle.filter_scan(m, g["raw_range"], g["raw_angle"], g["raw_occ"], pose)
+    return po.ScanData(g["raw_range"][kept], g["raw_angle"][kept])
+
+
+def _check_smoke_trace(t, g, p, exact=True):
+    assert t["n_calls"] == int(g[p + "n_calls"])
+    np.testing.assert_array_equal(np.nonzero(t["accepted"])[0], g[p + "accepted_idx"])
+    np.testing.assert_array_equal(sha(t["poses"]), g[p + "poses_sha256"])
+    np.testing.assert_array_equal(t["delta"], g[p + "delta"])
+    if exact:
+        np.testing.assert_array_equal(sha(t["scores"]), g[p + "scores_sha256"])
+        assert t["prob"] == float(g[p + "prob"])
+    if p + "scores" in g:
+        np.testing.assert_allclose(t["scores"], g[p + "scores"], rtol=0 if exact else 1e-12, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["raw", "cached"])
+def test_oracle_bf_smoke_cases(oracle, tag):
+    import pyoracle as po
+    g = load("bf_smoke.npz")
+    m = map_from(g)
+    for i, nz in enumerate(g["noises"]):
+        pose = g["rpose"] + nz
+        scan = _smoke_scan(g, oracle, po, m, pose, tag == "cached")
+        t = oracle.process_scan(oracle.enumerator(po.SM_BF, g["params"]), m, scan, po.make_cfg(), pose)
+        _check_smoke_trace(t, g, "%s%d_" % (tag, i))
+        if tag == "raw":  # the reference test's own acceptance rule (scan_matcher_test_utils.h:46-80)
+            p_true, p_res = float(g["case%d_prob_true" % i][0]), float(g["case%d_prob_result" % i][0])
+            res_noise = nz + t["delta"]
+            same = abs(p_true - p_res) <= 1e-7 * max(1.0, abs(p_true), abs(p_res))
+            assert same or np.all(np.abs(res_noise) <= np.finfo(np.float64).eps)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_oracle_search_space_scores(oracle, scene):
+    """40402 scorer calls x 1000 beams per scene, hash-compared with the reference's trace."""
+    import pyoracle as po
+    g = load("search_space.npz")
+    m = po.GridMapData(0, g[scene + "_map_payload"], g[scene + "_map_origin"], 0.1, np.array([0.5]), False)
+    rng, ang, occ = g[scene + "_scan"]
+    kept = oracle.filter_scan(m, rng, ang, occ.astype(np.int32), g["pose"])
+    scan = po.ScanData(rng[kept], ang[kept])
+    t = oracle.process_scan(oracle.enumerator(po.SM_BF, g["params"]), m, scan, po.make_cfg(), g["pose"],
+                            cap=1 << 17)
+    assert t["n_calls"] == int(g[scene + "_n_calls"]) == 201 * 201 + 1
+    np.testing.assert_array_equal(sha(t["scores"]), g[scene + "_scores_sha256"])
+    np.testing.assert_array_equal(np.nonzero(t["accepted"])[0], g[scene + "_accepted_idx"])
+    assert t["prob"] == float(g[scene + "_prob"])
+
+
+# ------------------------------------------------------------------ HIP path (GPU)
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    return ge.load_package()
+
+
+@pytest.mark.gpu
+def test_hip_bf_smoke_cases(pkg):
+    g = load("bf_smoke.npz")
+    m = map_from(g)
+    ctx = pkg.Context(0)
+    ctx.upload_map(0, m)
+    geom = dict(width=m.width, height=m.height, origin=m.origin, scale=m.scale, bounded=False)
+    strict = dict(sum_order=pkg.SUM_SEQUENTIAL, pose_trig=pkg.POSE_TRIG_HOST)
+    a_min, a_inc = float(g["a_min"]), float(g["a_inc"])
+    for i, nz in enumerate(g["noises"]):
+        pose = g["rpose"] + nz
+        # cached provider: bit-exact trace (hash of all 9262 scores and poses)
+        kept = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], pose, geom, trig_mode=pkg.TRIG_CACHED,
+                               a_min=a_min, a_delta=a_inc, tab_sin=g["tab_sin"], tab_cos=g["tab_cos"])
+        r, a = g["raw_range"][kept], g["raw_angle"][kept]
+        c, s = pkg.beam_trig(a, pkg.TRIG_CACHED, a_min, float(g["a_max_passed"]), a_inc)
+        ctx.scan_upload(r, c, s, pkg.scan_weights("even", r, a))
+        mt = pkg.Matcher(ctx, "BF", pkg.spe_cfg(**strict), g["params"])
+        t = mt.process_scan(0, pose, trace=True)
+        _check_smoke_trace(t, g, "cached%d_" % i)
+        assert mt.stats()["launches"] <= 3
+        # raw provider: the reference test's acceptance rule
+        kept = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], pose, geom)
+        r, a = g["raw_range"][kept], g["raw_angle"][kept]
+        c, s = pkg.beam_trig(a)
+        ctx.scan_upload(r, c, s, pkg.scan_weights("even", r, a))
+        t = pkg.Matcher(ctx, "BF", pkg.spe_cfg(**strict), g["params"]).process_scan(0, pose)
+        res_noise = nz + t["delta"]
+        k0 = pkg.filter_scan(g["raw_range"], g["raw_angle"], g["raw_occ"], g["rpose"], geom)
+        r0, a0 = g["raw_range"][k0], g["raw_angle"][k0]
+        c0, s0 = pkg.beam_trig(a0)
+        ctx.scan_upload(r0, c0, s0, pkg.scan_weights("even", r0, a0))
+        p_true, p_res = ctx.score_poses(0, pkg.spe_cfg(**strict), np.stack([g["rpose"], g["rpose"] + res_noise]))
+        same = abs(p_true - p_res) <= 1e-7 * max(1.0, abs(p_true), abs(p_res))
+        assert same or np.all(np.abs(res_noise) <= np.finfo(np.float64).eps), (i, res_noise)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("strict", [True, False])
+def test_hip_search_space_map(pkg, scene, strict):
+    """201 x 201 search-space map of the evaluator: scores within 1e-12 of the reference's (raw trig
+    provider: sin(theta + a) on the CPU against the angle-addition form on the device), same best
+    pose, same map geometry after the unbounded map grew, PGM equal to the reference dump up to one
+    grey level on a handful of pixels."""
+    g = load("search_space.npz")
+    ctx = pkg.Context(0)
+    t = tool.evaluate(pkg, fx, ctx, g, scene, strict=strict)
+    assert t["n_calls"] == int(g[scene + "_n_calls"])
+    if scene + "_scores" in g:
+        np.testing.assert_allclose(t["scores"], g[scene + "_scores"], rtol=1e-12, atol=0)
+    else:
+        np.testing.assert_allclose(t["scores"][::4], g[scene + "_scores_every4"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(t["prob"], float(g[scene + "_prob"]), rtol=1e-12)
+    np.testing.assert_array_equal(t["delta"], g[scene + "_delta"])
+    assert t["sss_geometry"] == tuple(g[scene + "_sss_final"])
+    mine = np.frombuffer(fx.pgm_bytes(t["sss_prob"]), np.uint8)
+    ref = g[scene + "_sss_pgm"]
+    assert mine.size == ref.size
+    hdr = len(b"P5\n%d\n%d\n255\n" % (t["sss_geometry"][0], t["sss_geometry"][1]))
+    assert mine[:hdr].tobytes() == ref[:hdr].tobytes()
+    diff = np.abs(mine[hdr:].astype(np.int32) - ref[hdr:].astype(np.int32))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 20, (diff.max(), np.count_nonzero(diff))
