@@ -113,8 +113,12 @@ def test_pgm_dump(gold, tmp_path):
     m = fx.read_map(paths[2])
     fx.write_pgm(str(tmp_path / "m.pgm"), m)
     raw = (tmp_path / "m.pgm").read_bytes()
-    assert raw.startswith(b"P5\n%d %d\n255\n" % (m.width, m.height))
-    assert len(raw) == len(b"P5\n%d %d\n255\n" % (m.width, m.height)) + m.width * m.height
+    hdr = b"P5\n%d\n%d\n255\n" % (m.width, m.height)  # byte identity with the reference dumper:
+    assert raw.startswith(hdr)                         # tests/test_search_space.py
+    assert len(raw) == len(hdr) + m.width * m.height
+    mt = fx.read_map(unpack(gold, "mc_tbm", tmp_path)[2], "tbm")
+    fx.write_pgm(str(tmp_path / "t.pgm"), mt)  # TBM windows dump their prob_occ plane
+    assert (tmp_path / "t.pgm").stat().st_size == len(b"P5\n%d\n%d\n255\n" % (mt.width, mt.height)) + mt.width * mt.height
 
 
 _NUM = re.compile(r"x: (\S+), y: (\S+), th: (\S+)} with probability (\S+)")
