@@ -301,6 +301,25 @@ int slamhip_gmapping_set(slamhip_gmapping *g, const double *poses, const double 
  * after its match, BEFORE the next particle matches -- the reference's particles share one map
  * object (Q20), which makes this step sequential and unshardable.  NULL switches it off. */
 int slamhip_gmapping_set_map_update(slamhip_gmapping *g, const slamhip_scan_adder_cfg *cfg);
+/* Per-particle maps: every particle gets its OWN map, a copy-on-write copy of the bound
+ * GMAPPING window `map_id`, held as 128x128-cell tiles in a device pool with the sharing semantics of
+ * UnboundedLazyTiledGridMap (src/core/maps/lazy_tiled_grid_map.h:18-187: a map copy copies tile
+ * references :40-45, untouched area is one shared unknown tile :28-34, a write clones a shared tile
+ * first :57-71).  This is what GmappingWorld's per-particle map member is for
+ * (gmapping_world.h:36-55); the reference revision never separates them (Q20), so the mode has no
+ * reference run -- parity is against the oracle with per-particle maps.  The step then keeps the
+ * lock-step matching and appends the scans of all matched particles in ONE batched K6; a resampling
+ * copies tile tables (particle_filter.h:92-96).  extent_tiles: side of the fixed virtual extent in
+ * tiles (cells outside read as unknown and cannot be written); pool_tiles: capacity (768 KiB each).
+ * Whole filter on one context only. */
+int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const slamhip_scan_adder_cfg *cfg,
+                                          int extent_tiles, int pool_tiles);
+/* external window of one particle's map: payload3 = (prob_occ, obstacle x, obstacle y) per cell,
+ * aux2 = (hits, tries) per cell; either may be NULL */
+int slamhip_gmapping_particle_map_download(slamhip_gmapping *g, int particle, int x0, int y0, int w, int h,
+                                           double *payload3, double *aux2);
+int slamhip_gmapping_particle_map_stats(slamhip_gmapping *g, long long *tiles_in_use, long long *tiles_shared,
+                                        long long *bytes, long long *cow_copies, long long *cell_updates);
 int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, int *is_master);
 int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
                            long long *launches, long long *carry_reruns);

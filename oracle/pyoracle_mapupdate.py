@@ -65,3 +65,31 @@ def gmapping_enable_update(oracle, pf, gmap, aux, base=(0.95, 1.0, 0.01, 1.0), b
         a.base4[k] = float(base[k])
     a.blur, a.max_range, a.est_kind, a.shift_amount = blur, max_range, est_kind, shift_amount
     L.orc_gmapping_set_update(pf.h, C.byref(a), _d(gmap.payload), _d(aux))
+
+
+def gmapping_enable_particle_maps(oracle, pf, gmap, aux=None, base=(0.95, 1.0, 0.01, 1.0), blur=0.0,
+                                  max_range=float("inf"), est_kind=0, shift_amount=0.0):
+    """Every particle of the OrcGmappingHandle gets its own copy of gmap.payload (+ aux: hits, tries);
+    the step's map argument keeps describing the geometry."""
+    L = oracle.lib
+    L.orc_gmapping_set_particle_maps.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, C.c_size_t]
+    a = OrcAdder()
+    for k in range(4):
+        a.base4[k] = float(base[k])
+    a.blur, a.max_range, a.est_kind, a.shift_amount = blur, max_range, est_kind, shift_amount
+    pay = f64(gmap.payload)
+    n_cells = pay.shape[0] * pay.shape[1]
+    ax = f64(aux) if aux is not None else None
+    L.orc_gmapping_set_particle_maps(pf.h, C.byref(a), _d(pay), pay.size, _d(ax) if ax is not None else None,
+                                     2 * n_cells)
+    pf._pm_shape = pay.shape
+
+
+def gmapping_particle_map(oracle, pf, particle):
+    """(payload[h, w, 3], counters[h, w, 2]) of one particle's own map."""
+    L = oracle.lib
+    L.orc_gmapping_copy_particle_map.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    h, w, st = pf._pm_shape
+    pay, aux = np.zeros((h, w, st)), np.zeros((h, w, 2))
+    L.orc_gmapping_copy_particle_map(pf.h, particle, _d(pay), _d(aux))
+    return pay, aux

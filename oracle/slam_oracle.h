@@ -8,6 +8,7 @@
 #ifndef SLAM_ORACLE_H
 #define SLAM_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -158,6 +159,11 @@ typedef struct {
    * MUTABLE payload / (hits, tries) arrays of the window the `map` argument of the step views */
   const struct orc_adder_s *upd;
   double *upd_payload, *upd_aux;
+  /* per-particle maps (what GmappingWorld's own map member is for; the reference revision shares
+   * one object, Q20): particle i reads and updates pm_payload[i] / pm_aux[i], windows of the geometry
+   * the step's `map` argument describes; a resampling copies them (particle_filter.h:92-96) */
+  double **pm_payload, **pm_aux;
+  size_t pm_payload_doubles, pm_aux_doubles;
   long long scorer_calls;       /* of the last step */
 } orc_gmapping;
 
@@ -173,6 +179,10 @@ int orc_gmapping_step(orc_gmapping *g, const orc_map *map, int n_raw, const doub
 void orc_gmapping_get(const orc_gmapping *g, double *poses, double *weights, int *is_master);
 long long orc_gmapping_scorer_calls(const orc_gmapping *g);
 void orc_gmapping_set_update(orc_gmapping *g, const orc_adder *upd, double *payload, double *aux);
+/* every particle gets its own copy of (payload, aux); updates inside the step go to the copies */
+void orc_gmapping_set_particle_maps(orc_gmapping *g, const orc_adder *upd, const double *payload,
+                                    size_t payload_doubles, const double *aux, size_t aux_doubles);
+void orc_gmapping_copy_particle_map(const orc_gmapping *g, int particle, double *payload_out, double *aux_out);
 
 /* ---- map update (map_update_oracle.c) ---- */
 /* cell update rules = the reference's GridCell subclasses' operator+= */

@@ -38,7 +38,9 @@ slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_res
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
-slamhip_gmapping_stats slamhip_gmapping_set_map_update slamhip_map_append_scan slamhip_map_download_aux""".split()
+slamhip_gmapping_stats slamhip_gmapping_set_map_update slamhip_map_append_scan slamhip_map_download_aux
+slamhip_gmapping_enable_particle_maps slamhip_gmapping_particle_map_download
+slamhip_gmapping_particle_map_stats""".split()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -182,6 +184,9 @@ def load():
     L.slamhip_gmapping_set_map_update.argtypes = [vp, C.POINTER(ScanAdderCfg)]
     L.slamhip_gmapping_get.argtypes = [vp, _dp, _dp, _ip]
     L.slamhip_gmapping_stats.argtypes = [vp, ll, ll, ll, ll]
+    L.slamhip_gmapping_enable_particle_maps.argtypes = [vp, i, C.POINTER(ScanAdderCfg), i, i]
+    L.slamhip_gmapping_particle_map_download.argtypes = [vp, i, i, i, i, i, _dp, _dp]
+    L.slamhip_gmapping_particle_map_stats.argtypes = [vp, ll, ll, ll, ll, ll]
     _lib = L
     return L
 
@@ -534,6 +539,26 @@ class GmappingFilter:
         cfg = ScanAdderCfg(RULE_GMAPPING, 1.0, base[0], base[1], base[2], base[3], blur, max_range,
                            estimator, shift_amount)
         _check(self.L.slamhip_gmapping_set_map_update(self.h, C.byref(cfg)))
+
+    def enable_particle_maps(self, map_id, extent_tiles, pool_tiles, base=(0.95, 1.0, 0.01, 1.0), blur=0.0,
+                             max_range=float("inf"), estimator=0, shift_amount=0.0):
+        """Per-particle copy-on-write maps (tile pool) seeded from the bound dense window `map_id`."""
+        cfg = ScanAdderCfg(RULE_GMAPPING, 1.0, base[0], base[1], base[2], base[3], blur, max_range,
+                           estimator, shift_amount)
+        _check(self.L.slamhip_gmapping_enable_particle_maps(self.h, map_id, C.byref(cfg), extent_tiles,
+                                                            pool_tiles))
+
+    def particle_map(self, particle, x0, y0, w, h):
+        """(payload[h, w, 3], counters[h, w, 2]) of the external window of one particle's map."""
+        pay, aux = np.zeros((h, w, 3)), np.zeros((h, w, 2))
+        _check(self.L.slamhip_gmapping_particle_map_download(self.h, particle, x0, y0, w, h, _d(pay), _d(aux)))
+        return pay, aux
+
+    def particle_map_stats(self):
+        v = [C.c_longlong() for _ in range(5)]
+        _check(self.L.slamhip_gmapping_particle_map_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(tiles_in_use=v[0].value, tiles_shared=v[1].value, bytes=v[2].value, cow_copies=v[3].value,
+                    cell_updates=v[4].value)
 
     def set(self, poses=None, weights=None):
         p = _f64(poses) if poses is not None else None

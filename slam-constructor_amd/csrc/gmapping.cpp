@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "matchers.h"
+#include "tile_pool.h"
 
 namespace slamhip {
 
@@ -114,6 +115,10 @@ struct slamhip_gmapping {
   bool update = false;
   slamhip_scan_adder_cfg upd{};
   long long cell_updates = 0;
+  // per-particle copy-on-write maps: particle i owns slot i of the pool; matching stays
+  // in lock-step and the map updates of all matched particles run as ONE batched K6
+  TilePool *tp = nullptr;
+  TiledTarget tt{};
 };
 
 namespace {
@@ -133,20 +138,25 @@ int heaviest(const std::vector<double> &w) {
 }
 
 // drives a set of jobs to completion through shared launches
-int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int per_job_budget) {
+// `slots` (per-particle maps only): the map slot of every job
+int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int per_job_budget,
+             const int *slots = nullptr) {
   slamhip_ctx *ctx = g->ctx;
   std::vector<int> off(act.size()), cnt(act.size());
   int rc = ensure_pose_capacity(ctx, (per_job_budget + 1) * (int)act.size());
   if (rc) return rc;
+  if (g->tp) g->tt.tables = g->tp->d_table();  // the table buffer flips on resampling
   while (true) {
     int total = 0;
     for (size_t k = 0; k < act.size(); ++k) {
       off[k] = total;
       cnt[k] = act[k]->done ? 0 : act[k]->plan(per_job_budget, ctx->h_poses + 3 * (size_t)total);
+      if (slots)
+        for (int q = 0; q < cnt[k]; ++q) ctx->h_pose_slot[total + q] = slots[k];
       total += cnt[k];
     }
     if (total == 0) break;
-    rc = score_staged(ctx, map_id, &g->cfg, total);
+    rc = score_staged(ctx, map_id, &g->cfg, total, slots ? &g->tt : nullptr);
     if (rc) return rc;
     g->launches += 1;
     g->poses_evaluated += total;
@@ -196,6 +206,7 @@ int slamhip_gmapping_create(slamhip_ctx *ctx, const slamhip_gmapping_params *prm
 }
 
 int slamhip_gmapping_destroy(slamhip_gmapping *g) {
+  if (g && g->tp) tile_pool_destroy(g->tp);
   delete g;
   return SLAMHIP_OK;
 }
@@ -326,7 +337,7 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
     if (const char *e = getenv("SLAMHIP_PF_BUDGET")) per_job = std::max(6, atoi(e));
     if (const char *e = getenv("SLAMHIP_PF_MIN_REACH")) min_reach = atof(e);
     for (MatchJob *j : act) j->tree.min_reach = min_reach;
-    rc = run_jobs(g, map_id, act, per_job);
+    rc = run_jobs(g, map_id, act, per_job, g->tp ? act_idx.data() : nullptr);  // slot = particle index
     if (rc) return rc;
     // verify the shared-cache chain in the reference's particle order; re-match on a hit
     GmCarry prev = act[0]->carry;
@@ -339,23 +350,45 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
         const GmParticle &p = g->p[act_idx[k]];
         job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, prev, 0.25);
         std::vector<MatchJob *> one{&job};
-        rc = run_jobs(g, map_id, one, 126);
+        rc = run_jobs(g, map_id, one, 126, g->tp ? &act_idx[k] : nullptr);
         if (rc) return rc;
         g->carry_reruns += 1;
       }
       prev = job.carry;
     }
     g->carry = prev;
+    std::vector<double> upd_pose;
+    std::vector<int> upd_slot;
     for (size_t k = 0; k < act_idx.size(); ++k) {
       GmParticle &p = g->p[act_idx[k]];
       const MatchJob &job = *act[k];
       double dl[3];
       job.delta(dl);
       for (int c = 0; c < 3; ++c) p.pose[c] += dl[c];
-      if (0.0 < job.best_prob || p.scan_is_first) p.scan_is_first = 0;  // (map update: SURVEY K6)
+      if (0.0 < job.best_prob || p.scan_is_first) {
+        // gmapping_world.h:93-97: the particle appends the scan to ITS map from the corrected pose
+        if (g->tp) {
+          upd_pose.insert(upd_pose.end(), p.pose, p.pose + 3);
+          upd_slot.push_back(act_idx[k]);
+        }
+        p.scan_is_first = 0;
+      }
       p.weight = job.best_prob * p.weight;
       reset_sm_delta(p);
       g->scorer_calls += job.scorer_calls;
+    }
+    if (g->tp && !upd_slot.empty()) {
+      // own maps: no particle reads another's update, so all appends of the step form one batch
+      std::vector<double> rc_all(n_raw), rs_all(n_raw);
+      slamhip_beam_trig_raw(n_raw, angle, rc_all.data(), rs_all.data());
+      slamhip_scan_adder_cfg cfg = g->upd;
+      cfg.rule = SLAMHIP_RULE_GMAPPING;
+      cfg.scan_quality = 1.0;
+      long long nu = 0;
+      rc = mu_append_batch(ctx, g->tp, &cfg, (int)upd_slot.size(), upd_pose.data(), upd_slot.data(), n_raw, range,
+                           rc_all.data(), rs_all.data(), is_occ, &nu);
+      if (rc) return rc;
+      g->cell_updates += nu;
     }
   }
   if (raw_weights_out)
@@ -425,6 +458,68 @@ int slamhip_gmapping_import(slamhip_gmapping *g, const void *all_blobs, const un
   g->p.swap(np);
   g->all_w = w;
   g->traversed[0] = g->traversed[1] = g->traversed[2] = 0;
+  if (g->tp) {
+    // `*new_particle = *sampled` copies the map too: with the tiled map that is a table copy, the tiles
+    // get shared until one of the copies writes (lazy_tiled_grid_map.h:40-45,57-71)
+    std::vector<int> src(n);
+    for (int i = 0; i < n; ++i) src[i] = (int)idx[i];
+    int rc = tile_pool_assign(g->tp, src.data());
+    if (rc) return rc;
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const slamhip_scan_adder_cfg *cfg,
+                                          int extent_tiles, int pool_tiles) {
+  if (!g || !cfg) return bad("null argument");
+  if (!g->ctx) {
+    set_error("this filter was created without a GPU context");
+    return SLAMHIP_ERR_NO_DEVICE;
+  }
+  if (g->count != g->n_total)
+    return bad("per-particle maps need the whole filter on one context (tile migration between GPUs is not built)");
+  if (map_id < 0 || map_id >= (int)g->ctx->maps.size() || !g->ctx->maps[map_id].bound) return bad("unknown map id");
+  if (extent_tiles <= 0 || pool_tiles < 2) return bad("bad tile pool shape");
+  SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
+  const DeviceMap &m = g->ctx->maps[map_id];
+  if (g->tp) tile_pool_destroy(g->tp);
+  g->tp = nullptr;
+  int rc = tile_pool_create(g->ctx, g->n_total, extent_tiles, extent_tiles, m.scale, m.unknown, pool_tiles, &g->tp);
+  if (rc) return rc;
+  rc = tile_pool_init_from_dense(g->tp, m);
+  if (rc) {
+    tile_pool_destroy(g->tp);
+    g->tp = nullptr;
+    return rc;
+  }
+  g->upd = *cfg;
+  g->update = false;  // the sequential shared-map mode and this one exclude each other
+  TiledTarget &t = g->tt;
+  t.pool = g->tp->d_pool;
+  t.tables = g->tp->d_table();
+  t.table_stride = g->tp->table_stride();
+  t.tiles_x = g->tp->tiles_x;
+  t.width = g->tp->width();
+  t.height = g->tp->height();
+  t.origin_x = g->tp->origin_x;
+  t.origin_y = g->tp->origin_y;
+  t.scale = m.scale;
+  for (int k = 0; k < 4; ++k) t.unknown[k] = m.unknown[k];
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_particle_map_download(slamhip_gmapping *g, int particle, int x0, int y0, int w, int h,
+                                           double *payload3, double *aux2) {
+  if (!g || !g->tp) return bad("per-particle maps are not enabled");
+  if (particle < 0 || particle >= g->count) return bad("particle index out of range");
+  return tile_pool_download(g->tp, particle, x0, y0, w, h, payload3, aux2);
+}
+
+int slamhip_gmapping_particle_map_stats(slamhip_gmapping *g, long long *tiles_in_use, long long *tiles_shared,
+                                        long long *bytes, long long *cow_copies, long long *cell_updates) {
+  if (!g || !g->tp) return bad("per-particle maps are not enabled");
+  tile_pool_stats(g->tp, tiles_in_use, tiles_shared, bytes, cow_copies);
+  if (cell_updates) *cell_updates = g->cell_updates;
   return SLAMHIP_OK;
 }
 
@@ -452,6 +547,7 @@ int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const doub
 
 int slamhip_gmapping_set_map_update(slamhip_gmapping *g, const slamhip_scan_adder_cfg *cfg) {
   if (!g) return bad("null filter");
+  if (cfg && g->tp) return bad("per-particle maps are enabled: the shared-map update mode excludes them");
   if (cfg && g->count != g->n_total)
     return bad("the map update inside the step needs the whole filter on one context: the reference's "
                "particles share one map and update it one after another");

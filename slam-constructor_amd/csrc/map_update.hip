@@ -38,8 +38,22 @@
 namespace slamhip {
 
 static constexpr unsigned kInvalidKey = 0xffffffffu;
+static constexpr unsigned long long kInvalidKey64 = ~0ull;
+
+// one scan appended from one pose into one map slot; a batch appends the SAME scan from many poses
+// (the particles of the filter), each into its own copy-on-write map (tile_pool.h)
+struct MuJob {
+  double px, py, sn, cs;
+  int slot, pad;
+};
 
 struct MuArgs {
+  // batch (null: the single pose below, 32-bit keys, dense window)
+  const MuJob *jobs;
+  int n_jobs;
+  const int *tables;  // tile tables of all slots: payload / aux are then the tile pools
+  int table_stride, tiles_x, cell_bits;
+  unsigned long long *keys64;
   // map
   double *payload;
   double *aux;
@@ -70,28 +84,35 @@ __device__ __forceinline__ bool mu_are_equal(double a, double b) {
   return fabs(a - b) <= 1e-7 * fmax(1.0, m);
 }
 
-__device__ __forceinline__ void mu_endpoint(const MuArgs &a, int b, double *wx, double *wy) {
-  const double c = a.cs * a.cos_a[b] - a.sn * a.sin_a[b];
-  const double s = a.sn * a.cos_a[b] + a.cs * a.sin_a[b];
-  *wx = a.px + a.range[b] * c;
-  *wy = a.py + a.range[b] * s;
+// thread g of the beam kernels handles beam g % n of job g / n (a plain call is one job)
+__device__ __forceinline__ MuJob mu_job(const MuArgs &a, int g) {
+  if (a.jobs) return a.jobs[g / a.n];
+  return MuJob{a.px, a.py, a.sn, a.cs, 0, 0};
+}
+
+__device__ __forceinline__ void mu_endpoint(const MuArgs &a, const MuJob &j, int b, double *wx, double *wy) {
+  const double c = j.cs * a.cos_a[b] - j.sn * a.sin_a[b];
+  const double s = j.sn * a.cos_a[b] + j.cs * a.sin_a[b];
+  *wx = j.px + a.range[b] * c;
+  *wy = j.py + a.range[b] * s;
 }
 
 __global__ void k_mu_count(MuArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.n) return;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.n * a.n_jobs) return;
+  const MuJob j = mu_job(a, g);
   double wx, wy;
-  mu_endpoint(a, b, &wx, &wy);
-  a.beam_end[2 * b] = wx;
-  a.beam_end[2 * b + 1] = wy;
-  const double ddx = wx - a.px, ddy = wy - a.py;
+  mu_endpoint(a, j, g % a.n, &wx, &wy);
+  a.beam_end[2 * g] = wx;
+  a.beam_end[2 * g + 1] = wy;
+  const double ddx = wx - j.px, ddy = wy - j.py;
   unsigned cnt = 0;
   if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
-    const int rcx = (int)floor(a.px / a.scale), rcy = (int)floor(a.py / a.scale);
+    const int rcx = (int)floor(j.px / a.scale), rcy = (int)floor(j.py / a.scale);
     const int ocx = (int)floor(wx / a.scale), ocy = (int)floor(wy / a.scale);
     cnt = (unsigned)(abs(ocx - rcx) + abs(ocy - rcy) + 1);
   }
-  a.counts[b] = cnt;
+  a.counts[g] = cnt;
 }
 
 // exclusive scan of counts[n] by one workgroup of 1024 threads; offsets[n] = total
@@ -118,13 +139,14 @@ __global__ __launch_bounds__(1024) void k_mu_offsets(const unsigned *counts, uns
   if (t == 1023) offsets[n] = s_part[1023];
 }
 
-__device__ __forceinline__ void mu_record(const MuArgs &a, unsigned slot, int b, int cx, int cy, int ocx,
-                                          int ocy, bool obstacle_cell, double base_prob, double base_qual,
+__device__ __forceinline__ void mu_record(const MuArgs &a, const MuJob &jb, unsigned slot, int b, int cx, int cy,
+                                          int ocx, int ocy, bool obstacle_cell, double base_prob, double base_qual,
                                           double hole_dist_sq, double obst_dist_sq) {
   const int ix = cx + a.origin_x, iy = cy + a.origin_y;
   if ((unsigned)ix >= (unsigned)a.width || (unsigned)iy >= (unsigned)a.height) {
     *a.error_flag = 1;
-    a.keys[slot] = kInvalidKey;
+    if (a.keys64) a.keys64[slot] = kInvalidKey64;
+    else a.keys[slot] = kInvalidKey;
     return;
   }
   double prob, qual;
@@ -137,7 +159,7 @@ __device__ __forceinline__ void mu_record(const MuArgs &a, unsigned slot, int b,
     if (a.est_kind == 1) {
       const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
       const ae::ae_rect cb{a.scale * cy, a.scale * (cy + 1), a.scale * cx, a.scale * (cx + 1)};
-      const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{a.px, a.py}, ae::ae_pt{a.beam_end[2 * b], a.beam_end[2 * b + 1]},
+      const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{a.beam_end[2 * b], a.beam_end[2 * b + 1]},
                                            cb, 0, base4, a.shift_amount);
       prob = o.prob;
       qual = o.qual;
@@ -151,22 +173,28 @@ __device__ __forceinline__ void mu_record(const MuArgs &a, unsigned slot, int b,
   }
   // two scattered stores per step (lanes write to different beams' slots): the 4-byte key and one
   // 16-byte (prob, qual) pair; the beam index is recovered from `offsets` in k_mu_gather
-  a.keys[slot] = (unsigned)iy * (unsigned)a.pitch + (unsigned)ix;
+  if (a.keys64) {  // batch: (job, cell of the virtual extent)
+    const unsigned long long job = (unsigned long long)(b / a.n);
+    a.keys64[slot] = (job << a.cell_bits) | ((unsigned long long)iy * (unsigned)a.width + (unsigned)ix);
+  } else {
+    a.keys[slot] = (unsigned)iy * (unsigned)a.pitch + (unsigned)ix;
+  }
   reinterpret_cast<double2 *>(a.rec_prob)[slot] = make_double2(prob, qual);
 }
 
 __global__ void k_mu_emit(MuArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.n) return;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;  // global beam index: job * n + beam
+  if (b >= a.n * a.n_jobs) return;
   const unsigned cap = a.counts[b];
   if (cap == 0) return;
+  const MuJob jb = mu_job(a, b);
   const unsigned base = a.offsets[b];
   const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
-  const bool occ = a.is_occ ? a.is_occ[b] != 0 : true;
+  const bool occ = a.is_occ ? a.is_occ[b % a.n] != 0 : true;
   const double scale = a.scale;
-  const double d_x = wx - a.px, d_y = wy - a.py;
+  const double d_x = wx - jb.px, d_y = wy - jb.py;
   const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
-  int px = (int)floor(a.px / scale), py = (int)floor(a.py / scale);
+  int px = (int)floor(jb.px / scale), py = (int)floor(jb.py / scale);
   const int bx = px, by = py;
   const int ex = (int)floor(wx / scale), ey = (int)floor(wy / scale);
   const double odx = bx - ex, ody = by - ey;
@@ -183,20 +211,20 @@ __global__ void k_mu_emit(MuArgs a) {
   if (a.est_kind == 1) {
     const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
     const ae::ae_rect cb{scale * ey, scale * (ey + 1), scale * ex, scale * (ex + 1)};
-    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{a.px, a.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
+    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
                                          a.shift_amount);
     base_prob = o.prob;
     base_qual = o.qual;
   }
   const double mid_x = (px + 0.5) * scale, mid_y = (py + 0.5) * scale;
-  const double mid_cell_seg_y = d_x * a.py + (mid_x - a.px) * d_y;
+  const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
   double e = mid_cell_seg_y - mid_y * d_x;
   const double e_x_inc = inc_x * scale * d_y;
   const double e_y_inc = -inc_y * scale * d_x;
   unsigned n = 0;
   bool failover = false;
   while (true) {
-    if (n < cap) mu_record(a, base + n, b, px, py, ex, ey, px == ex && py == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
+    if (n < cap) mu_record(a, jb, base + n, b, px, py, ex, ey, px == ex && py == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
     ++n;
     if (px == ex && py == ey) break;
     if (cap < n) {  // fp rounding sent the walk astray: the reference restarts with Bresenham
@@ -229,7 +257,7 @@ __global__ void k_mu_emit(MuArgs a) {
     n = 0;
     while (true) {
       const int cx = y_is_primary ? secondary : primary, cy = y_is_primary ? primary : secondary;
-      if (n < cap) mu_record(a, base + n, b, cx, cy, ex, ey, cx == ex && cy == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
+      if (n < cap) mu_record(a, jb, base + n, b, cx, cy, ex, ey, cx == ex && cy == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
       ++n;
       if (primary == limit) break;
       const int err_inc_primary = error + inc_primary * d_secondary;
@@ -243,7 +271,10 @@ __global__ void k_mu_emit(MuArgs a) {
       }
     }
   }
-  for (unsigned k = n; k < cap; ++k) a.keys[base + k] = kInvalidKey;
+  for (unsigned k = n; k < cap; ++k) {
+    if (a.keys64) a.keys64[base + k] = kInvalidKey64;
+    else a.keys[base + k] = kInvalidKey;
+  }
 }
 
 __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs, double *out) {
@@ -285,15 +316,25 @@ __global__ void k_mu_gather(const unsigned *order, unsigned total, const double 
 }
 
 // `a.rec_*` point at the SORTED record arrays here (k_mu_gather)
-__global__ void k_mu_apply(MuArgs a, const unsigned *keys, const unsigned *order, unsigned total,
+template <typename Key>
+__global__ void k_mu_apply(MuArgs a, const Key *keys, const unsigned *order, unsigned total,
                            unsigned long long *n_updates) {
+  constexpr Key kInvalid = ~Key(0);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const unsigned key = keys[i];
-  if (key == kInvalidKey) return;
+  const Key key = keys[i];
+  if (key == kInvalid) return;
   if (i > 0 && keys[i - 1] == key) return;  // not the head of this cell's run
-  double *cell = a.payload + (size_t)key * a.cell_dbl;
-  double *aux = a.aux ? a.aux + (size_t)key * a.aux_stride : nullptr;
+  size_t at = (size_t)key;
+  if (a.tables) {  // (job, virtual cell) -> the job's slot -> tile -> cell of the pool
+    const unsigned long long cellkey = (unsigned long long)key & ((1ull << a.cell_bits) - 1ull);
+    const int job = (int)((unsigned long long)key >> a.cell_bits);
+    const int ix = (int)(cellkey % (unsigned)a.width), iy = (int)(cellkey / (unsigned)a.width);
+    const int tile = a.tables[(size_t)a.jobs[job].slot * a.table_stride + (iy >> kTileShift) * a.tiles_x + (ix >> kTileShift)];
+    at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+  }
+  double *cell = a.payload + at * a.cell_dbl;
+  double *aux = a.aux ? a.aux + at * a.aux_stride : nullptr;
   double c0 = cell[0], c1 = 0, c2 = 0, c3 = 0;
   if (a.cell_dbl == 4) {
     c1 = cell[1];
@@ -308,12 +349,12 @@ __global__ void k_mu_apply(MuArgs a, const unsigned *keys, const unsigned *order
   constexpr int CH = 8;
   bool more = true;
   for (unsigned j0 = i; more && j0 < total; j0 += CH) {
-    unsigned kk[CH];
+    Key kk[CH];
     double pp[CH], qq[CH], oxs[CH], oys[CH];
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
       const unsigned j = min(j0 + t, total - 1);
-      kk[t] = (j0 + t < total) ? keys[j] : kInvalidKey;
+      kk[t] = (j0 + t < total) ? keys[j] : kInvalid;
       pp[t] = a.rec_prob[j];
       qq[t] = a.rec_qual[j];
       oxs[t] = a.rec_ox[j];
@@ -514,6 +555,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
 
   MuArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.n_jobs = 1;
   a.payload = m.d_payload;
   a.aux = aux_stride ? m.d_aux : nullptr;
   a.width = m.width;
@@ -613,8 +655,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.rec_qual = sc.srt_qual;
   a.rec_ox = sc.srt_ox;
   a.rec_oy = sc.srt_oy;
-  hipLaunchKernelGGL(k_mu_apply, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a, sc.keys_sorted,
-                     sc.order_sorted, total, sc.n_updates);
+  hipLaunchKernelGGL(k_mu_apply<unsigned>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                     (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.n_updates);
   SLAMHIP_CHECK(hipGetLastError());
   int err = 0;
   unsigned long long nu = 0;
@@ -643,3 +685,231 @@ int slamhip_map_download_aux(slamhip_ctx *ctx, int map_id, int x0, int y0, int w
 }
 
 }  // extern "C"
+
+// ---- batch: the same scan appended from many poses, each into its own copy-on-write map ----------
+#include "tile_pool.h"
+
+namespace {
+struct MuBatchScratch {
+  size_t cap_beams = 0, cap_records = 0, cap_jobs = 0, cap_scan = 0, temp_bytes = 0;
+  unsigned *counts = nullptr, *offsets = nullptr, *order = nullptr, *order_sorted = nullptr;
+  unsigned long long *keys = nullptr, *keys_sorted = nullptr;
+  double *rec_pq = nullptr, *beam_end = nullptr, *scan = nullptr;
+  double *srt_prob = nullptr, *srt_qual = nullptr, *srt_ox = nullptr, *srt_oy = nullptr;
+  int *occ = nullptr, *error_flag = nullptr;
+  MuJob *d_jobs = nullptr;
+  unsigned long long *n_updates = nullptr;
+  void *temp = nullptr;
+};
+std::vector<std::pair<slamhip_ctx *, MuBatchScratch>> g_bscratch;
+
+MuBatchScratch &bscratch_of(slamhip_ctx *ctx) {
+  for (auto &p : g_bscratch)
+    if (p.first == ctx) return p.second;
+  g_bscratch.emplace_back(ctx, MuBatchScratch{});
+  return g_bscratch.back().second;
+}
+
+template <typename T>
+hipError_t regrow(T *&p, size_t count) {
+  if (p) hipFree(p);
+  p = nullptr;
+  return hipMalloc(&p, sizeof(T) * count);
+}
+}  // namespace
+
+namespace slamhip {
+
+// GridMapScanAdder::append_scan of ONE scan from n_jobs poses (the matched particles of a filter step),
+// job k into slot slots[k] of the tile pool: one count / scan / emit / sort / gather / apply pipeline
+// over all (job, beam) pairs; the sort key is (job, cell) so every cell chain of every map is
+// contiguous and in beam order.  Tiles a job may write are made private first (copy-on-write).
+int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg *cfg, int n_jobs,
+                    const double *poses, const int *slots, int n, const double *range, const double *cos_a,
+                    const double *sin_a, const int *is_occ, long long *n_updates_out) {
+  if (!ctx || !tp || !cfg || !poses || !slots || !range || !cos_a || !sin_a) return fail("null argument");
+  if (n_updates_out) *n_updates_out = 0;
+  if (n_jobs <= 0 || n <= 0) return SLAMHIP_OK;
+  if (cfg->rule != SLAMHIP_RULE_GMAPPING) return fail("particle maps hold GMapping cells");
+  if (cfg->occupancy_estimator != 0 && cfg->occupancy_estimator != 1) return fail("unknown occupancy estimator");
+  if ((long long)n_jobs * n > (1ll << 30)) return fail("batch too large");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  MuBatchScratch &sc = bscratch_of(ctx);
+  const double scale = tp->scale;
+  const double max_range_sq = cfg->max_range * cfg->max_range;
+
+  // host pass: job records (pose + sincos), record count (same IEEE operations as k_mu_count), the
+  // cell rectangle each job can touch -> copy-on-write of the tiles under it
+  std::vector<MuJob> jobs(n_jobs);
+  unsigned long long total64 = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    MuJob &j = jobs[k];
+    j.px = poses[3 * k];
+    j.py = poses[3 * k + 1];
+    ::sincos(poses[3 * k + 2], &j.sn, &j.cs);
+    j.slot = slots[k];
+    j.pad = 0;
+    const int rcx = (int)std::floor(j.px / scale), rcy = (int)std::floor(j.py / scale);
+    int lo_x = rcx, hi_x = rcx, lo_y = rcy, hi_y = rcy;
+    bool any = false;
+    for (int b = 0; b < n; ++b) {
+      const double c = j.cs * cos_a[b] - j.sn * sin_a[b];
+      const double s = j.sn * cos_a[b] + j.cs * sin_a[b];
+      const double wx = j.px + range[b] * c, wy = j.py + range[b] * s;
+      const double ddx = wx - j.px, ddy = wy - j.py;
+      if (max_range_sq < ddx * ddx + ddy * ddy) continue;
+      const int ocx = (int)std::floor(wx / scale), ocy = (int)std::floor(wy / scale);
+      total64 += (unsigned)(std::abs(ocx - rcx) + std::abs(ocy - rcy) + 1);
+      lo_x = std::min(lo_x, ocx);
+      hi_x = std::max(hi_x, ocx);
+      lo_y = std::min(lo_y, ocy);
+      hi_y = std::max(hi_y, ocy);
+      any = true;
+    }
+    if (any) {
+      int rc = tile_pool_make_private(tp, j.slot, lo_x + tp->origin_x, lo_y + tp->origin_y, hi_x + tp->origin_x,
+                                      hi_y + tp->origin_y);
+      if (rc) return rc;
+    }
+  }
+  int rc = tile_pool_flush(tp);
+  if (rc) return rc;
+  if (total64 == 0) return SLAMHIP_OK;
+  if (total64 >= 0xfffffff0ull) return fail("more than 2^32 cell updates in one batch: split the batch");
+  const unsigned total = (unsigned)total64;
+
+  const size_t beams = (size_t)n_jobs * n;
+  if ((size_t)n > sc.cap_scan) {
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+    size_t cap = 2048;
+    while (cap < (size_t)n) cap *= 2;
+    SLAMHIP_CHECK(regrow(sc.scan, 3 * cap));
+    SLAMHIP_CHECK(regrow(sc.occ, cap));
+    sc.cap_scan = cap;
+  }
+  if (beams > sc.cap_beams) {
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+    size_t cap = 4096;
+    while (cap < beams) cap *= 2;
+    SLAMHIP_CHECK(regrow(sc.counts, cap));
+    SLAMHIP_CHECK(regrow(sc.offsets, cap + 1));
+    SLAMHIP_CHECK(regrow(sc.beam_end, 2 * cap));
+    sc.cap_beams = cap;
+  }
+  if ((size_t)n_jobs > sc.cap_jobs) {
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+    size_t cap = 64;
+    while (cap < (size_t)n_jobs) cap *= 2;
+    SLAMHIP_CHECK(regrow(sc.d_jobs, cap));
+    sc.cap_jobs = cap;
+  }
+  if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
+  if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+  if (total > sc.cap_records) {
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+    size_t cap = 1 << 18;
+    while (cap < total) cap *= 2;
+    SLAMHIP_CHECK(regrow(sc.keys, cap));
+    SLAMHIP_CHECK(regrow(sc.keys_sorted, cap));
+    SLAMHIP_CHECK(regrow(sc.order, cap));
+    SLAMHIP_CHECK(regrow(sc.order_sorted, cap));
+    SLAMHIP_CHECK(regrow(sc.rec_pq, 2 * cap));
+    SLAMHIP_CHECK(regrow(sc.srt_prob, cap));
+    SLAMHIP_CHECK(regrow(sc.srt_qual, cap));
+    SLAMHIP_CHECK(regrow(sc.srt_ox, cap));
+    SLAMHIP_CHECK(regrow(sc.srt_oy, cap));
+    if (sc.temp) hipFree(sc.temp);
+    sc.temp = nullptr;
+    sc.temp_bytes = 0;
+    SLAMHIP_CHECK(rocprim::radix_sort_pairs(nullptr, sc.temp_bytes, sc.keys, sc.keys_sorted, sc.order,
+                                            sc.order_sorted, cap, 0, 64, st));
+    SLAMHIP_CHECK(hipMalloc(&sc.temp, sc.temp_bytes));
+    sc.cap_records = cap;
+  }
+  const size_t cs = sc.cap_scan;
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cs, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cs, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.d_jobs, jobs.data(), sizeof(MuJob) * n_jobs, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), st));
+  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long), st));
+
+  MuArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.jobs = sc.d_jobs;
+  a.n_jobs = n_jobs;
+  a.tables = tp->d_table();
+  a.table_stride = tp->table_stride();
+  a.tiles_x = tp->tiles_x;
+  unsigned cell_bits = 1;
+  while ((1ull << cell_bits) < (unsigned long long)tp->width() * tp->height()) ++cell_bits;
+  a.cell_bits = (int)cell_bits;
+  a.payload = tp->d_pool;
+  a.aux = tp->d_aux;
+  a.width = tp->width();
+  a.height = tp->height();
+  a.pitch = tp->width();
+  a.origin_x = tp->origin_x;
+  a.origin_y = tp->origin_y;
+  a.cell_dbl = 4;
+  a.aux_stride = 2;
+  a.scale = scale;
+  a.range = sc.scan;
+  a.cos_a = sc.scan + cs;
+  a.sin_a = sc.scan + 2 * cs;
+  a.is_occ = is_occ ? sc.occ : nullptr;
+  a.n = n;
+  a.rule = SLAMHIP_RULE_GMAPPING;
+  a.est_kind = cfg->occupancy_estimator;
+  a.shift_amount = cfg->area_shift_amount > 0 ? cfg->area_shift_amount : 0.01 * scale;
+  a.quality = cfg->scan_quality * 1.0;
+  a.base_occ_prob = cfg->base_occupied_prob;
+  a.base_occ_qual = cfg->base_occupied_qual;
+  a.base_empty_prob = cfg->base_empty_prob;
+  a.base_empty_qual = cfg->base_empty_qual;
+  a.blur = cfg->blur;
+  a.max_range_sq = max_range_sq;
+  a.counts = sc.counts;
+  a.offsets = sc.offsets;
+  a.beam_end = sc.beam_end;
+  a.error_flag = sc.error_flag;
+  a.keys64 = sc.keys;
+  a.rec_prob = sc.rec_pq;
+
+  const dim3 bgrid((unsigned)((beams + 255) / 256));
+  hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, st, sc.counts, sc.offsets, (int)beams);
+  hipLaunchKernelGGL(k_mu_emit, bgrid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, st, sc.order, total);
+  unsigned job_bits = 1;
+  while ((1u << job_bits) < (unsigned)n_jobs) ++job_bits;
+  size_t tb = sc.temp_bytes;
+  // the invalid key (all ones) must still sort last: include one more bit than the valid keys use
+  const unsigned end_bit = std::min(64u, cell_bits + job_bits + 1);
+  SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted, total, 0,
+                                          end_bit, st));
+  hipLaunchKernelGGL(k_mu_gather, dim3((total + 255) / 256), dim3(256), 0, st, sc.order_sorted, total, sc.rec_pq,
+                     sc.offsets, (int)beams, sc.beam_end, sc.srt_prob, sc.srt_qual, sc.srt_ox, sc.srt_oy);
+  a.rec_prob = sc.srt_prob;
+  a.rec_qual = sc.srt_qual;
+  a.rec_ox = sc.srt_ox;
+  a.rec_oy = sc.srt_oy;
+  hipLaunchKernelGGL(k_mu_apply<unsigned long long>, dim3((total + 255) / 256), dim3(256), 0, st, a,
+                     (const unsigned long long *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total,
+                     sc.n_updates);
+  SLAMHIP_CHECK(hipGetLastError());
+  int err = 0;
+  unsigned long long nu = 0;
+  SLAMHIP_CHECK(hipMemcpyAsync(&err, sc.error_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(&nu, sc.n_updates, sizeof(nu), hipMemcpyDeviceToHost, st));
+  SLAMHIP_CHECK(hipStreamSynchronize(st));
+  if (n_updates_out) *n_updates_out = (long long)nu;
+  if (err)
+    return fail("a beam leaves the tile extent of the particle maps: create them with a larger extent; cells "
+                "inside it were updated", SLAMHIP_ERR_STATE);
+  return SLAMHIP_OK;
+}
+
+}  // namespace slamhip

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int 
 // value of one endpoint: max over the (2w+1)^2 window of cells with prob_occ >= th of
 // exp(-|cell.obst - endpoint|^2 / 0.05); the window order of the reference (dx outer, dy inner)
 // does not matter for a max of finite values.
-__device__ __forceinline__ double gm_fresh_value(const MapView &m, const GmParams &gp, int cx, int cy,
-                                                 double ox, double oy) {
+// `tiles`: null = dense window (m.pitch); else the tile table of the pose's own copy-on-write map
+// (tile_pool.h): m.payload is then the tile pool and m.width/height the virtual extent.
+__device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *tiles, const GmParams &gp,
+                                                 int cx, int cy, double ox, double oy) {
   double best = 0.0;
   const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
   for (int dx = -gp.window; dx <= gp.window; ++dx) {
@@ -228,7 +230,14 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const GmParam
       const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
       double occ = m.unknown[0], obx = m.unknown[1], oby = m.unknown[2];
       if (inb) {
-        const double4 v = cells[(size_t)iy * m.pitch + ix];
+        size_t at;
+        if (tiles) {
+          const int tile = tiles[(iy >> kTileShift) * m.pitch + (ix >> kTileShift)];  // pitch = tiles per row
+          at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+        } else {
+          at = (size_t)iy * m.pitch + ix;
+        }
+        const double4 v = cells[at];
         occ = v.x; obx = v.y; oby = v.z;
       }
       if (occ < gp.fullness_th) continue;
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
+    const int *tiles = a.tables ? a.tables + (size_t)a.pose_slot[p0 + j] * a.table_stride : nullptr;
     int ccx[KB], ccy[KB];
     if (t == 0) s_run0_len = n;
     // phase A: endpoint cell + fresh value per beam
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
         const double wy = y + br[k] * s;
         ccx[k] = to_cell(wx, scale, inv_scale);
         ccy[k] = to_cell(wy, scale, inv_scale);
-        s_val[b] = gm_fresh_value(a.map, a.gm, ccx[k], ccy[k], wx, wy);
+        s_val[b] = gm_fresh_value(a.map, tiles, a.gm, ccx[k], ccy[k], wx, wy);
         if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
       }
     }

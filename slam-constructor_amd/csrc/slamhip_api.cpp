@@ -54,9 +54,11 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
     hipHostFree(ctx->h_scores);
     hipHostFree(ctx->h_pose_sc);
     hipHostFree(ctx->h_gm_info);
+    hipHostFree(ctx->h_pose_slot);
     ctx->d_poses = nullptr;
     ctx->pose_cap = 0;
   }
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_slot, sizeof(int) * cap, kPinned));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_poses, sizeof(double) * 3 * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_scores, sizeof(double) * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_pose_sc, sizeof(double) * 2 * cap));
@@ -211,8 +213,28 @@ static void gm_carry_fixup(slamhip_ctx *ctx, int n_poses) {
   }
 }
 
-int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses) {
-  DeviceMap *m = get_map(ctx, map_id);
+int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
+                 const TiledTarget *tiled) {
+  DeviceMap tiled_view;
+  DeviceMap *m = nullptr;
+  if (tiled) {
+    // the kernels see the tile pool as "payload" and the tiles-per-row count as "pitch" (K3 only)
+    if (!cfg || cfg->oope != SLAMHIP_OOPE_GMAPPING || !ctx->low_latency)
+      return invalid("per-particle maps are scored by the GMapping kernel on the zero-copy path only");
+    tiled_view.bound = true;
+    tiled_view.cell_model = SLAMHIP_CELL_GMAPPING;
+    tiled_view.width = tiled->width;
+    tiled_view.height = tiled->height;
+    tiled_view.pitch = tiled->tiles_x;
+    tiled_view.origin_x = tiled->origin_x;
+    tiled_view.origin_y = tiled->origin_y;
+    tiled_view.scale = tiled->scale;
+    for (int k = 0; k < 4; ++k) tiled_view.unknown[k] = tiled->unknown[k];
+    tiled_view.d_payload = const_cast<double *>(tiled->pool);
+    m = &tiled_view;
+  } else {
+    m = get_map(ctx, map_id);
+  }
   if (!m) return invalid("unknown map id");
   int rc = check_cfg(*m, cfg);
   if (rc) return rc;
@@ -245,6 +267,11 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
     rc = fill_args(ctx, *m, cfg, n_poses, poses_src, sc_src, ctx->h_scores, &a);
     if (rc) return rc;
     if (gm) a.gm_info = ctx->h_gm_info;
+    if (tiled) {
+      a.tables = tiled->tables;
+      a.pose_slot = ctx->h_pose_slot;
+      a.table_stride = tiled->table_stride;
+    }
     unsigned seq = ++ctx->seq;
     if (seq == 0) seq = ++ctx->seq;
     rc = launch_timed(ctx, a, *m, cfg);
@@ -357,6 +384,7 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
     hipHostFree(ctx->h_scores);
     hipHostFree(ctx->h_pose_sc);
     hipHostFree(ctx->h_gm_info);
+    hipHostFree(ctx->h_pose_slot);
   }
   if (ctx->d_terms) hipFree(ctx->d_terms);
   if (ctx->d_dirty_xy) hipFree(ctx->d_dirty_xy);

@@ -59,7 +59,20 @@ struct ScoreArgs {
   GmParams gm;
   GmPoseInfo *gm_info;  // GMAPPING only
   double *terms;        // SEQUENTIAL order only: n_poses x scan.n scratch
+  // per-particle copy-on-write maps (K3 only, tile_pool.h): tile tables of all slots, the slot of
+  // every pose; then map.payload = tile pool, map.pitch = tiles per table row, map.width/height =
+  // the virtual extent in cells.  null = one dense window for all poses.
+  const int *tables;
+  const int *pose_slot;
+  int table_stride;
 };
+
+// tiles of the copy-on-write maps: 128 x 128 cells like the reference's LazyTiledGridMap
+// (src/core/maps/lazy_tiled_grid_map.h:24-26), row-major inside a tile
+constexpr int kTileShift = 7;
+constexpr int kTileSide = 1 << kTileShift;
+constexpr int kTileMask = kTileSide - 1;
+constexpr int kTileCells = kTileSide * kTileSide;
 
 inline int cell_doubles(int model) { return model == SLAMHIP_CELL_OCC ? 1 : 4; }
 inline int cell_stride_host(int model) {
@@ -120,6 +133,7 @@ struct slamhip_ctx {
   double *d_poses = nullptr, *d_scores = nullptr, *d_pose_sc = nullptr;
   double *h_poses = nullptr, *h_scores = nullptr, *h_pose_sc = nullptr;  // pinned
   slamhip::GmPoseInfo *d_gm_info = nullptr, *h_gm_info = nullptr;
+  int *h_pose_slot = nullptr;  // pinned: map slot of every staged pose (per-particle maps only)
   int pose_cap = 0;
   double *d_terms = nullptr;
   size_t terms_cap = 0;
@@ -144,7 +158,17 @@ struct slamhip_ctx {
 };
 
 namespace slamhip {
+// scoring target made of per-slot copy-on-write maps (tile_pool.h) instead of a bound dense window;
+// pose p reads the map of slot ctx->h_pose_slot[p]
+struct TiledTarget {
+  const double *pool;
+  const int *tables;
+  int table_stride, tiles_x, width, height, origin_x, origin_y;
+  double scale;
+  double unknown[4];
+};
 int ensure_pose_capacity(slamhip_ctx *ctx, int n);
 // scores n poses whose (x,y,theta) sit in ctx->h_poses; results land in ctx->h_scores (synchronous)
-int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses);
+int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
+                 const TiledTarget *tiled = nullptr);
 }  // namespace slamhip

@@ -1,0 +1,70 @@
+// tile_pool.h -- device tile pool for per-particle copy-on-write maps.
+//
+// Mirrors the sharing semantics of the reference's LazyTiledGridMap / UnboundedLazyTiledGridMap
+// (src/core/maps/lazy_tiled_grid_map.h:18-187): a map is a table of tile references; copying a map
+// copies the table (tiles shared, :40-45); all never-touched area is ONE shared unknown tile (:28-34);
+// a write first makes the tile private (Tile::update -> clone when shared, :57-71,88-104).  Here a
+// "map" is a SLOT of the pool (one per particle), tiles are 128 x 128 cells of 4 doubles (GMapping
+// payload: prob_occ, obstacle x, obstacle y, pad) plus 2 doubles of update counters (hits, tries) in
+// a parallel array, refcounts and the free list live on the host, and the copy itself is one kernel
+// over (src, dst) tile pairs.  The extent is fixed at creation (tiles_x x tiles_y tiles around the
+// origin); cells outside it read as unknown and cannot be written.
+#pragma once
+
+#include <vector>
+
+#include "slamhip_internal.h"
+
+namespace slamhip {
+
+struct TilePool {
+  slamhip_ctx *ctx = nullptr;
+  int n_slots = 0, tiles_x = 0, tiles_y = 0;
+  int origin_x = 0, origin_y = 0;  // internal (virtual) cell = external cell + origin
+  double scale = 1.0;
+  double unknown[4] = {0, 0, 0, 0};
+  int capacity = 0;                // tiles
+  double *d_pool = nullptr;        // [capacity][kTileCells][4]
+  double *d_aux = nullptr;         // [capacity][kTileCells][2]
+  int *d_tables[2] = {nullptr, nullptr};  // [n_slots][tiles_x * tiles_y]; double-buffered for resampling
+  int cur = 0;
+  std::vector<int> h_tables;       // host mirror of d_tables[cur]
+  std::vector<int> refcnt;         // per tile; tile 0 = the shared unknown tile (never written, never freed)
+  std::vector<int> free_list;
+  int next_unused = 1;
+  // pending work of the current batch (pinned, read by the kernels over PCIe)
+  int *h_pairs = nullptr;          // (src, dst) per copy
+  int *h_patches = nullptr;        // (slot, index, tile) per table patch
+  int *h_assign = nullptr;         // source slot per new slot
+  int cap_pairs = 0, cap_patches = 0, n_pairs = 0, n_patches = 0;
+  long long cow_copies = 0;        // tiles copied so far
+
+  int table_stride() const { return tiles_x * tiles_y; }
+  int width() const { return tiles_x * kTileSide; }
+  int height() const { return tiles_y * kTileSide; }
+  const int *d_table() const { return d_tables[cur]; }
+};
+
+int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, double scale, const double unknown[4],
+                     int capacity, TilePool **out);
+void tile_pool_destroy(TilePool *tp);
+// every slot starts as a copy of the bound dense GMAPPING window `m` (payload and, if present, counters)
+int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m);
+// make the tiles of `slot` that intersect internal cells [x0, x1] x [y0, y1] private (queued)
+int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y1);
+// run the queued copies and table patches on the context's stream
+int tile_pool_flush(TilePool *tp);
+// resampling: new slot i becomes a copy of old slot src[i] (tables only; tiles get shared)
+int tile_pool_assign(TilePool *tp, const int *src_of_new);
+// external window [x0, x0+w) x [y0, y0+h) of a slot: payload (3 doubles per cell: prob, obst.x, obst.y)
+// and counters (2 per cell: hits, tries); either may be null
+int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, double *payload3, double *aux2);
+void tile_pool_stats(const TilePool *tp, long long *tiles_in_use, long long *tiles_shared, long long *bytes,
+                     long long *cow_copies);
+
+// map_update.hip: GridMapScanAdder::append_scan of one scan from n_jobs poses, job k into slot slots[k]
+int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg *cfg, int n_jobs,
+                    const double *poses, const int *slots, int n, const double *range, const double *cos_a,
+                    const double *sin_a, const int *is_occ, long long *n_updates_out);
+
+}  // namespace slamhip

@@ -1,0 +1,344 @@
+// tile_pool.hip -- see tile_pool.h.  Kernels: tile copy (copy-on-write), table patch / assign,
+// dense window <-> tiles.
+
+#include <algorithm>
+#include <cstring>
+
+#include "tile_pool.h"
+
+namespace slamhip {
+
+namespace {
+
+constexpr int kChunksPerTile = 64;  // workgroups per tile copy: 256 cells each
+
+// one (src, dst) pair per 64 workgroups: payload 512 KB + counters 256 KB, 16-byte accesses
+__global__ __launch_bounds__(256) void k_tile_copy(double *pool, double *aux, const int *pairs, int n_pairs) {
+  const int pair = blockIdx.x / kChunksPerTile, chunk = blockIdx.x % kChunksPerTile;
+  if (pair >= n_pairs) return;
+  const size_t src = (size_t)pairs[2 * pair] * kTileCells, dst = (size_t)pairs[2 * pair + 1] * kTileCells;
+  const size_t cell = (size_t)chunk * 256 + threadIdx.x;
+  const double4 *ps = reinterpret_cast<const double4 *>(pool) + src;
+  double4 *pd = reinterpret_cast<double4 *>(pool) + dst;
+  pd[cell] = ps[cell];
+  const double2 *as = reinterpret_cast<const double2 *>(aux) + src;
+  double2 *ad = reinterpret_cast<double2 *>(aux) + dst;
+  ad[cell] = as[cell];
+}
+
+__global__ void k_table_patch(int *tables, int stride, const int *patches, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  tables[(size_t)patches[3 * i] * stride + patches[3 * i + 1]] = patches[3 * i + 2];
+}
+
+__global__ void k_table_assign(int *dst, const int *src, const int *src_of_new, int stride) {
+  const int slot = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < stride) dst[(size_t)slot * stride + i] = src[(size_t)src_of_new[slot] * stride + i];
+}
+
+__global__ void k_table_fill(int *tables, size_t n, int v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tables[i] = v;
+}
+
+__global__ void k_tile_fill_unknown(double *pool, double *aux, int tile, double u0, double u1, double u2, double u3) {
+  const size_t cell = (size_t)tile * kTileCells + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  reinterpret_cast<double4 *>(pool)[cell] = make_double4(u0, u1, u2, u3);
+  reinterpret_cast<double2 *>(aux)[cell] = make_double2(0.0, 0.0);
+}
+
+// tiles (tx0.., ty0..) x (ntx, nty) of the pool <- dense window placed at virtual (vx0, vy0)
+__global__ __launch_bounds__(256) void k_tiles_from_dense(double *pool, double *aux, const int *tile_ids, int tx0,
+                                                          int ty0, int ntx, const double *dense,
+                                                          const double *dense_aux, int pitch, int w, int h, int vx0,
+                                                          int vy0, double u0, double u1, double u2, double u3) {
+  const int t = blockIdx.x / kChunksPerTile, chunk = blockIdx.x % kChunksPerTile;
+  const int tx = tx0 + t % ntx, ty = ty0 + t / ntx;
+  const int in_tile = chunk * 256 + threadIdx.x;
+  const int vx = tx * kTileSide + (in_tile & kTileMask), vy = ty * kTileSide + (in_tile >> kTileShift);
+  const int dx = vx - vx0, dy = vy - vy0;
+  double4 v = make_double4(u0, u1, u2, u3);
+  double2 c = make_double2(0.0, 0.0);
+  if ((unsigned)dx < (unsigned)w && (unsigned)dy < (unsigned)h) {
+    v = reinterpret_cast<const double4 *>(dense)[(size_t)dy * pitch + dx];
+    if (dense_aux) c = reinterpret_cast<const double2 *>(dense_aux)[(size_t)dy * pitch + dx];
+  }
+  const size_t at = (size_t)tile_ids[t] * kTileCells + in_tile;
+  reinterpret_cast<double4 *>(pool)[at] = v;
+  reinterpret_cast<double2 *>(aux)[at] = c;
+}
+
+__global__ void k_tiles_to_dense(const double *pool, const double *aux, const int *table, int tiles_x, int tiles_y,
+                                 int vx0, int vy0, int w, int h, double *payload3, double *aux2, double u0,
+                                 double u1, double u2) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const int vx = vx0 + x, vy = vy0 + y;
+  double p0 = u0, p1 = u1, p2 = u2, a0 = 0, a1 = 0;
+  if ((unsigned)vx < (unsigned)(tiles_x * kTileSide) && (unsigned)vy < (unsigned)(tiles_y * kTileSide)) {
+    const int tile = table[(vy >> kTileShift) * tiles_x + (vx >> kTileShift)];
+    const size_t at = (size_t)tile * kTileCells + ((size_t)(vy & kTileMask) << kTileShift) + (vx & kTileMask);
+    const double4 v = reinterpret_cast<const double4 *>(pool)[at];
+    const double2 c = reinterpret_cast<const double2 *>(aux)[at];
+    p0 = v.x; p1 = v.y; p2 = v.z; a0 = c.x; a1 = c.y;
+  }
+  const size_t o = (size_t)y * w + x;
+  if (payload3) {
+    payload3[3 * o] = p0;
+    payload3[3 * o + 1] = p1;
+    payload3[3 * o + 2] = p2;
+  }
+  if (aux2) {
+    aux2[2 * o] = a0;
+    aux2[2 * o + 1] = a1;
+  }
+}
+
+int tp_fail(const char *msg, int code = SLAMHIP_ERR_INVALID) {
+  set_error(msg);
+  return code;
+}
+
+int alloc_tile(TilePool *tp, int *out) {
+  if (!tp->free_list.empty()) {
+    *out = tp->free_list.back();
+    tp->free_list.pop_back();
+    return SLAMHIP_OK;
+  }
+  if (tp->next_unused >= tp->capacity)
+    return tp_fail("tile pool exhausted: create the particle maps with a larger capacity", SLAMHIP_ERR_STATE);
+  *out = tp->next_unused++;
+  return SLAMHIP_OK;
+}
+
+int ensure_staging(TilePool *tp, int pairs, int patches) {
+  constexpr unsigned kPinned = hipHostMallocMapped | hipHostMallocCoherent;
+  if (pairs > tp->cap_pairs) {
+    int cap = std::max(1024, tp->cap_pairs);
+    while (cap < pairs) cap *= 2;
+    int *n = nullptr;
+    SLAMHIP_CHECK(hipHostMalloc(&n, sizeof(int) * 2 * cap, kPinned));
+    if (tp->h_pairs) {
+      std::memcpy(n, tp->h_pairs, sizeof(int) * 2 * tp->n_pairs);
+      SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+      hipHostFree(tp->h_pairs);
+    }
+    tp->h_pairs = n;
+    tp->cap_pairs = cap;
+  }
+  if (patches > tp->cap_patches) {
+    int cap = std::max(1024, tp->cap_patches);
+    while (cap < patches) cap *= 2;
+    int *n = nullptr;
+    SLAMHIP_CHECK(hipHostMalloc(&n, sizeof(int) * 3 * cap, kPinned));
+    if (tp->h_patches) {
+      std::memcpy(n, tp->h_patches, sizeof(int) * 3 * tp->n_patches);
+      SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+      hipHostFree(tp->h_patches);
+    }
+    tp->h_patches = n;
+    tp->cap_patches = cap;
+  }
+  return SLAMHIP_OK;
+}
+
+}  // namespace
+
+int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, double scale, const double unknown[4],
+                     int capacity, TilePool **out) {
+  if (!ctx || !out || n_slots <= 0 || tiles_x <= 0 || tiles_y <= 0 || capacity < 2) return tp_fail("bad tile pool shape");
+  if ((long long)tiles_x * tiles_y > (1 << 20)) return tp_fail("tile table too large");
+  auto *tp = new TilePool;
+  tp->ctx = ctx;
+  tp->n_slots = n_slots;
+  tp->tiles_x = tiles_x;
+  tp->tiles_y = tiles_y;
+  tp->origin_x = tiles_x * kTileSide / 2;
+  tp->origin_y = tiles_y * kTileSide / 2;
+  tp->scale = scale;
+  for (int k = 0; k < 4; ++k) tp->unknown[k] = unknown[k];
+  tp->capacity = capacity;
+  const size_t cells = (size_t)capacity * kTileCells;
+  const size_t tab = (size_t)n_slots * tiles_x * tiles_y;
+  hipError_t e = hipMalloc(&tp->d_pool, cells * 4 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&tp->d_aux, cells * 2 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&tp->d_tables[0], tab * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&tp->d_tables[1], tab * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&tp->h_assign, sizeof(int) * n_slots, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) {
+    tile_pool_destroy(tp);
+    return hip_fail(e, "tile pool allocation");
+  }
+  tp->h_tables.assign(tab, 0);
+  tp->refcnt.assign(capacity, 0);
+  tp->refcnt[0] = 1 << 30;
+  hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((tab + 255) / 256)), dim3(256), 0, ctx->stream, tp->d_tables[0], tab, 0);
+  hipLaunchKernelGGL(k_tile_fill_unknown, dim3(kTileCells / 256), dim3(256), 0, ctx->stream, tp->d_pool, tp->d_aux, 0,
+                     unknown[0], unknown[1], unknown[2], unknown[3]);
+  SLAMHIP_CHECK(hipGetLastError());
+  *out = tp;
+  return SLAMHIP_OK;
+}
+
+void tile_pool_destroy(TilePool *tp) {
+  if (!tp) return;
+  if (tp->ctx) hipStreamSynchronize(tp->ctx->stream);
+  if (tp->d_pool) hipFree(tp->d_pool);
+  if (tp->d_aux) hipFree(tp->d_aux);
+  if (tp->d_tables[0]) hipFree(tp->d_tables[0]);
+  if (tp->d_tables[1]) hipFree(tp->d_tables[1]);
+  if (tp->h_pairs) hipHostFree(tp->h_pairs);
+  if (tp->h_patches) hipHostFree(tp->h_patches);
+  if (tp->h_assign) hipHostFree(tp->h_assign);
+  delete tp;
+}
+
+int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m) {
+  if (m.cell_model != SLAMHIP_CELL_GMAPPING) return tp_fail("particle maps need a SLAMHIP_CELL_GMAPPING window");
+  if (m.aux_stride != 0 && m.aux_stride != 2) return tp_fail("unexpected counter layout");
+  // virtual position of the dense window: same external coordinates
+  const int vx0 = tp->origin_x - m.origin_x, vy0 = tp->origin_y - m.origin_y;
+  if (vx0 < 0 || vy0 < 0 || vx0 + m.width > tp->width() || vy0 + m.height > tp->height())
+    return tp_fail("the dense window does not fit the tile extent");
+  const int tx0 = vx0 >> kTileShift, ty0 = vy0 >> kTileShift;
+  const int tx1 = (vx0 + m.width - 1) >> kTileShift, ty1 = (vy0 + m.height - 1) >> kTileShift;
+  const int ntx = tx1 - tx0 + 1, nty = ty1 - ty0 + 1, nt = ntx * nty;
+  std::vector<int> ids(nt);
+  for (int k = 0; k < nt; ++k) {
+    int rc = alloc_tile(tp, &ids[k]);
+    if (rc) return rc;
+    tp->refcnt[ids[k]] = tp->n_slots;
+  }
+  int *d_ids = nullptr;
+  SLAMHIP_CHECK(hipMalloc(&d_ids, sizeof(int) * nt));
+  SLAMHIP_CHECK(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nt, hipMemcpyHostToDevice, tp->ctx->stream));
+  hipLaunchKernelGGL(k_tiles_from_dense, dim3(nt * kChunksPerTile), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_aux,
+                     d_ids, tx0, ty0, ntx, m.d_payload, m.aux_stride == 2 ? m.d_aux : nullptr, m.pitch, m.width,
+                     m.height, vx0, vy0, tp->unknown[0], tp->unknown[1], tp->unknown[2], tp->unknown[3]);
+  const int stride = tp->table_stride();
+  for (int s = 0; s < tp->n_slots; ++s)
+    for (int k = 0; k < nt; ++k)
+      tp->h_tables[(size_t)s * stride + (ty0 + k / ntx) * tp->tiles_x + tx0 + k % ntx] = ids[k];
+  SLAMHIP_CHECK(hipMemcpyAsync(tp->d_tables[tp->cur], tp->h_tables.data(), sizeof(int) * tp->h_tables.size(),
+                               hipMemcpyHostToDevice, tp->ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  hipFree(d_ids);
+  return SLAMHIP_OK;
+}
+
+int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y1) {
+  if (slot < 0 || slot >= tp->n_slots) return tp_fail("bad slot");
+  x0 = std::max(x0, 0);
+  y0 = std::max(y0, 0);
+  x1 = std::min(x1, tp->width() - 1);
+  y1 = std::min(y1, tp->height() - 1);
+  if (x1 < x0 || y1 < y0) return SLAMHIP_OK;
+  const int tx0 = x0 >> kTileShift, ty0 = y0 >> kTileShift, tx1 = x1 >> kTileShift, ty1 = y1 >> kTileShift;
+  int *row = tp->h_tables.data() + (size_t)slot * tp->table_stride();
+  int rc = ensure_staging(tp, tp->n_pairs + (tx1 - tx0 + 1) * (ty1 - ty0 + 1),
+                          tp->n_patches + (tx1 - tx0 + 1) * (ty1 - ty0 + 1));
+  if (rc) return rc;
+  for (int ty = ty0; ty <= ty1; ++ty) {
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int idx = ty * tp->tiles_x + tx;
+      const int old = row[idx];
+      if (old != 0 && tp->refcnt[old] == 1) continue;  // already private
+      int fresh = 0;
+      rc = alloc_tile(tp, &fresh);
+      if (rc) return rc;
+      tp->refcnt[fresh] = 1;
+      if (old != 0) tp->refcnt[old] -= 1;
+      row[idx] = fresh;
+      tp->h_pairs[2 * tp->n_pairs] = old;
+      tp->h_pairs[2 * tp->n_pairs + 1] = fresh;
+      tp->n_pairs += 1;
+      tp->h_patches[3 * tp->n_patches] = slot;
+      tp->h_patches[3 * tp->n_patches + 1] = idx;
+      tp->h_patches[3 * tp->n_patches + 2] = fresh;
+      tp->n_patches += 1;
+    }
+  }
+  return SLAMHIP_OK;
+}
+
+int tile_pool_flush(TilePool *tp) {
+  hipStream_t st = tp->ctx->stream;
+  if (tp->n_pairs) {
+    hipLaunchKernelGGL(k_tile_copy, dim3(tp->n_pairs * kChunksPerTile), dim3(256), 0, st, tp->d_pool, tp->d_aux,
+                       tp->h_pairs, tp->n_pairs);
+    tp->cow_copies += tp->n_pairs;
+  }
+  if (tp->n_patches)
+    hipLaunchKernelGGL(k_table_patch, dim3((tp->n_patches + 255) / 256), dim3(256), 0, st, tp->d_tables[tp->cur],
+                       tp->table_stride(), tp->h_patches, tp->n_patches);
+  SLAMHIP_CHECK(hipGetLastError());
+  if (tp->n_pairs || tp->n_patches) {
+    // the kernels read the pinned lists: they must be done before the host reuses them
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+  }
+  tp->n_pairs = tp->n_patches = 0;
+  return SLAMHIP_OK;
+}
+
+int tile_pool_assign(TilePool *tp, const int *src_of_new) {
+  const int stride = tp->table_stride();
+  std::vector<int> nt((size_t)tp->n_slots * stride);
+  for (int s = 0; s < tp->n_slots; ++s) {
+    if (src_of_new[s] < 0 || src_of_new[s] >= tp->n_slots) return tp_fail("bad source slot");
+    std::memcpy(nt.data() + (size_t)s * stride, tp->h_tables.data() + (size_t)src_of_new[s] * stride,
+                sizeof(int) * stride);
+    tp->h_assign[s] = src_of_new[s];
+  }
+  // refcounts of the new generation; tiles nobody references any more return to the free list
+  std::vector<int> rc(tp->refcnt.size(), 0);
+  for (int t : nt) rc[t] += 1;
+  for (int t = 1; t < tp->next_unused; ++t)
+    if (tp->refcnt[t] > 0 && rc[t] == 0) tp->free_list.push_back(t);
+  rc[0] = 1 << 30;
+  tp->refcnt.swap(rc);
+  tp->h_tables.swap(nt);
+  hipLaunchKernelGGL(k_table_assign, dim3((stride + 255) / 256, tp->n_slots), dim3(256), 0, tp->ctx->stream,
+                     tp->d_tables[tp->cur ^ 1], tp->d_tables[tp->cur], tp->h_assign, stride);
+  SLAMHIP_CHECK(hipGetLastError());
+  SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  tp->cur ^= 1;
+  return SLAMHIP_OK;
+}
+
+int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, double *payload3, double *aux2) {
+  if (slot < 0 || slot >= tp->n_slots || w <= 0 || h <= 0) return tp_fail("bad window");
+  double *d_p = nullptr, *d_a = nullptr;
+  const size_t cells = (size_t)w * h;
+  if (payload3) SLAMHIP_CHECK(hipMalloc(&d_p, cells * 3 * sizeof(double)));
+  if (aux2) SLAMHIP_CHECK(hipMalloc(&d_a, cells * 2 * sizeof(double)));
+  hipLaunchKernelGGL(k_tiles_to_dense, dim3((w + 255) / 256, h), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_aux,
+                     tp->d_table() + (size_t)slot * tp->table_stride(), tp->tiles_x, tp->tiles_y, x0 + tp->origin_x,
+                     y0 + tp->origin_y, w, h, d_p, d_a, tp->unknown[0], tp->unknown[1], tp->unknown[2]);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && payload3)
+    e = hipMemcpyAsync(payload3, d_p, cells * 3 * sizeof(double), hipMemcpyDeviceToHost, tp->ctx->stream);
+  if (e == hipSuccess && aux2)
+    e = hipMemcpyAsync(aux2, d_a, cells * 2 * sizeof(double), hipMemcpyDeviceToHost, tp->ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(tp->ctx->stream);
+  if (d_p) hipFree(d_p);
+  if (d_a) hipFree(d_a);
+  if (e != hipSuccess) return hip_fail(e, "tile download");
+  return SLAMHIP_OK;
+}
+
+void tile_pool_stats(const TilePool *tp, long long *tiles_in_use, long long *tiles_shared, long long *bytes,
+                     long long *cow_copies) {
+  long long used = 0, shared = 0;
+  for (int t = 1; t < tp->next_unused; ++t) {
+    if (tp->refcnt[t] > 0) ++used;
+    if (tp->refcnt[t] > 1) ++shared;
+  }
+  if (tiles_in_use) *tiles_in_use = used;
+  if (tiles_shared) *tiles_shared = shared;
+  if (bytes) *bytes = used * (long long)kTileCells * 6 * (long long)sizeof(double);
+  if (cow_copies) *cow_copies = tp->cow_copies;
+}
+
+}  // namespace slamhip

@@ -1,0 +1,123 @@
+"""GPU suite, SURVEY 8f N2: GMapping filter with per-particle copy-on-write maps (device tile pool).
+
+There is no reference run for this mode -- the reference revision shares one map object among all
+particles (Q20) -- so parity is against the oracle running the same filter with one private dense map
+per particle (oracle/slam_oracle.c: orc_gmapping_set_particle_maps; the oracle's shared-map mode is
+pinned to the compiled reference by tests/test_oracle_mapupdate.py).  The sharing semantics themselves
+(copy = table copy, write clones a shared tile, untouched area is one unknown tile) are the
+reference's LazyTiledGridMap rules and are checked as invariants of the pool statistics.
+
+The common ancestor map is the first scan appended from the true pose (an empty one gives every
+particle probability 0 and NaN weights -- the reference's shared map only escapes that because
+particle 0 writes before particle 1 reads)."""
+import numpy as np
+import pytest
+from helpers import load
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None):
+    import pyoracle as po
+    from pyoracle_mapupdate import (RULE_GMAPPING, append_scan_ex, gmapping_enable_particle_maps,
+                                    gmapping_particle_map)
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    scale = float(g["scale"])
+    unknown = g["unknown"][:3]
+    gp = g["gp"] if gp is None else np.asarray(gp, dtype=np.float64)
+    seeds = np.arange(seed0, seed0 + n, dtype=np.uint32)
+    ox, oy = [int(v) for v in g["origin"]]
+    r0, a0, pose0 = g["step0_range"], g["step0_angle"], g["step0_delta"]
+    # HIP side: dense ancestor (K6, pinned to the reference elsewhere) -> tile pool
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, w, h, g["origin"], scale, unknown)
+    c0, s0 = pkg.beam_trig(a0)
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, pose0, r0, c0, s0)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, skip_rate=3, pose_trig=1), n, seeds)
+    pf.enable_particle_maps(4, extent_tiles=8, pool_tiles=16 + 24 * n)
+    # oracle side
+    payload = np.tile(unknown, (h, w, 1)).astype(np.float64)
+    m = po.GridMapData(po.CELL_GMAPPING, payload, g["origin"], scale, unknown)
+    aux = np.zeros((h, w, 2))
+    append_scan_ex(oracle, m, aux, RULE_GMAPPING, pose0, r0, a0)
+    opf = oracle.gmapping_create(n, gp, seeds, skip_rate=3)
+    gmapping_enable_particle_maps(oracle, opf, m, aux)
+    got_p, got_a = pf.particle_map(n // 2, -ox, -oy, w, h)  # the ancestor went into the tiles intact
+    np.testing.assert_array_equal(got_p[..., 0], m.payload[..., 0])
+    np.testing.assert_array_equal(got_a, aux)
+
+    n_base = int(g["n_steps"])
+    steps = list(range(n_base)) + [1 + (k % (n_base - 1)) for k in range(n_steps_extra)]  # replay scans
+    log = []
+    for it, k in enumerate(steps):
+        extra = np.arange(9000 + 100 * it, 9000 + 100 * it + n, dtype=np.uint32)
+        rng, ang, d = g["step%d_range" % k], g["step%d_angle" % k], g["step%d_delta" % k]
+        res, idx = pf.step(4, rng, ang, None, d, 7 + it)
+        ores, oidx = opf.step(m, rng, ang, None, d, 7 + it, extra)
+        poses, wts, ms = pf.state()
+        oposes, owts, oms = opf.state()
+        assert res == ores, it
+        if res:
+            np.testing.assert_array_equal(idx, oidx)
+        assert np.all(np.isfinite(owts))
+        np.testing.assert_array_equal(ms, oms)
+        np.testing.assert_allclose(poses, oposes, rtol=0, atol=1e-10, err_msg="step %d" % it)
+        np.testing.assert_allclose(wts, owts, rtol=1e-9, atol=0)
+        for i in range(n):
+            got_p, got_a = pf.particle_map(i, -ox, -oy, w, h)
+            want_p, want_a = gmapping_particle_map(oracle, opf, i)
+            np.testing.assert_array_equal(got_p[..., 0], want_p[..., 0], err_msg="step %d particle %d" % (it, i))
+            np.testing.assert_allclose(got_p[..., 1:], want_p[..., 1:], rtol=1e-12, atol=1e-14)
+            np.testing.assert_array_equal(got_a, want_a)
+        log.append((res, pf.particle_map_stats()))
+    return pf, log, (ox, oy, w, h)
+
+
+def test_particle_maps_filter_vs_oracle(pkg, oracle):
+    n = 8
+    pf, log, (ox, oy, w, h) = run_both(pkg, oracle, n=n)
+    st = log[-1][1]
+    assert st["cell_updates"] > 0 and st["tiles_in_use"] > 16
+    # the maps of different particles really differ (pose noise -> different cells updated)
+    a, _ = pf.particle_map(0, -ox, -oy, w, h)
+    b, _ = pf.particle_map(n - 1, -ox, -oy, w, h)
+    assert np.count_nonzero(a[..., 0] != b[..., 0]) > 0
+
+
+def test_particle_maps_resampling_shares_then_clones_tiles(pkg, oracle):
+    """A run long enough to resample twice (the oracle alone was used to find it): right after a
+    resampling the duplicates share tiles and nothing was copied for it; the next update clones
+    only what it writes."""
+    pf, log, _ = run_both(pkg, oracle, n_steps_extra=20, n=8, seed0=3000, gp=[0, 0.1, 0, 0.05, 0, 0, 0, 0])
+    resampled_at = [i for i, (res, _) in enumerate(log) if res]
+    assert len(resampled_at) >= 1, "the sequence was meant to trigger a resampling"
+    i = resampled_at[0]
+    before, after = log[i - 1][1], log[i][1]
+    assert after["tiles_shared"] > 0
+    nxt = log[i + 1][1]
+    assert nxt["cow_copies"] > after["cow_copies"]  # duplicates wrote -> their tiles were cloned
+    assert nxt["tiles_shared"] <= after["tiles_shared"]
+    # the pool does not leak: tiles of dropped particles return to the free list
+    assert log[-1][1]["tiles_in_use"] <= 16 + 24 * 8
+
+
+def test_particle_maps_need_the_whole_filter(pkg):
+    ctx = pkg.Context(0)
+    ctx.map_bind(1, 2, 256, 256, (128, 128), 0.05, [0.5, 0, 0])
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), 8, np.arange(4, dtype=np.uint32), first=0, count=4)
+    with pytest.raises(pkg.SlamHipError):
+        pf.enable_particle_maps(1, 4, 64)
+    whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(), 4, np.arange(4, dtype=np.uint32))
+    with pytest.raises(pkg.SlamHipError):  # window larger than the tile extent
+        whole.enable_particle_maps(1, 1, 64)
+    whole.enable_particle_maps(1, 4, 64)
+    with pytest.raises(pkg.SlamHipError):  # shared-map mode and particle maps exclude each other
+        whole.set_map_update(True)
