@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--pf-size", type=int, default=4000)
     ap.add_argument("--pf-steps", type=int, default=10)
+    ap.add_argument("--pf-tiles-per-particle", type=int, default=420,
+                    help="tile-pool budget per particle of the per-particle-maps leg (768 KiB each)")
     ap.add_argument("--no-pf", action="store_true", help="skip the GMapping particle-filter leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (path testing)")
@@ -275,9 +277,36 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
         with_update = {"value": n * ksteps / du, "unit": "particles/s", "ms_per_step": 1e3 * du / ksteps,
                        "steps": ksteps, "note": "sequential particles: GPU match then K6 map update on the "
                                                 "shared map, as the reference does"}
+    with_maps = None
+    if world == 1:
+        # per-particle copy-on-write maps (tile pool): lock-step matching on every
+        # particle's own map + ONE batched K6 for all appends of the step
+        try:
+            pfm = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds)
+            ext = (args.pf_size + 127) // 128 + 1
+            pfm.enable_particle_maps(1, extent_tiles=ext, pool_tiles=ext * ext + n * args.pf_tiles_per_particle)
+            pfm.step(1, scan.range, scan.angle, None, deltas[0], 7)  # first step clones every touched tile
+            first_stats = pfm.particle_map_stats()
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            msteps = max(3, args.pf_steps)
+            for k in range(1, 1 + msteps):
+                pfm.step(1, scan.range, scan.angle, None, deltas[k % len(deltas)], 7 + k)
+            torch.cuda.synchronize()
+            dm = time.perf_counter() - tm
+            stt = pfm.particle_map_stats()
+            with_maps = {"value": n * msteps / dm, "unit": "particles/s", "ms_per_step": 1e3 * dm / msteps,
+                         "steps": msteps, "tiles_in_use": stt["tiles_in_use"], "pool_bytes": stt["bytes"],
+                         "cow_copies_first_step": first_stats["cow_copies"], "cow_copies_total": stt["cow_copies"],
+                         "cell_updates_last_step": stt["cell_updates"],
+                         "note": "every particle owns a copy-on-write map (128x128-cell tiles); matching in "
+                                 "lock-step, map updates of all particles in one batched K6"}
+            del pfm
+        except pkg.SlamHipError as e:  # e.g. the pool does not fit: report, do not hide
+            with_maps = {"error": str(e)}
     ctx.map_release(1)
     return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
-            "with_map_update": with_update,
+            "with_map_update": with_update, "with_particle_maps": with_maps,
             "ms_per_step": 1e3 * dt / args.pf_steps, "steps": args.pf_steps, "scaling": "strong",
             "pose_candidates_beams_per_s": calls * scan.n / dt,
             "workload": "cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "

@@ -26,6 +26,7 @@
 
 #include <string.h>  // rocprim's texture iterator calls ::memset without including it
 
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -39,6 +40,7 @@ namespace slamhip {
 
 static constexpr unsigned kInvalidKey = 0xffffffffu;
 static constexpr unsigned long long kInvalidKey64 = ~0ull;
+static constexpr int kNuSlots = 1024;  // update counters (summed on the host)
 
 // one scan appended from one pose into one map slot; a batch appends the SAME scan from many poses
 // (the particles of the filter), each into its own copy-on-write map (tile_pool.h)
@@ -54,6 +56,7 @@ struct MuArgs {
   const int *tables;  // tile tables of all slots: payload / aux are then the tile pools
   int table_stride, tiles_x, cell_bits;
   unsigned long long *keys64;
+  int *job_bbox;  // per job (lo_x, lo_y, hi_x, hi_y) in external cells, reduced by k_mu_count
   // map
   double *payload;
   double *aux;
@@ -99,20 +102,55 @@ __device__ __forceinline__ void mu_endpoint(const MuArgs &a, const MuJob &j, int
 
 __global__ void k_mu_count(MuArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= a.n * a.n_jobs) return;
-  const MuJob j = mu_job(a, g);
-  double wx, wy;
-  mu_endpoint(a, j, g % a.n, &wx, &wy);
-  a.beam_end[2 * g] = wx;
-  a.beam_end[2 * g + 1] = wy;
-  const double ddx = wx - j.px, ddy = wy - j.py;
+  const bool in = g < a.n * a.n_jobs;
   unsigned cnt = 0;
-  if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
-    const int rcx = (int)floor(j.px / a.scale), rcy = (int)floor(j.py / a.scale);
-    const int ocx = (int)floor(wx / a.scale), ocy = (int)floor(wy / a.scale);
-    cnt = (unsigned)(abs(ocx - rcx) + abs(ocy - rcy) + 1);
+  int ocx = 0, ocy = 0;
+  if (in) {
+    const MuJob j = mu_job(a, g);
+    double wx, wy;
+    mu_endpoint(a, j, g % a.n, &wx, &wy);
+    a.beam_end[2 * g] = wx;
+    a.beam_end[2 * g + 1] = wy;
+    const double ddx = wx - j.px, ddy = wy - j.py;
+    if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
+      const int rcx = (int)floor(j.px / a.scale), rcy = (int)floor(j.py / a.scale);
+      ocx = (int)floor(wx / a.scale);
+      ocy = (int)floor(wy / a.scale);
+      cnt = (unsigned)(abs(ocx - rcx) + abs(ocy - rcy) + 1);
+    }
+    a.counts[g] = cnt;
   }
-  a.counts[g] = cnt;
+  if (!a.job_bbox) return;
+  // cells a job can touch lie between its robot cell (host-initialised) and its endpoints: min / max of
+  // the endpoint cells per job.  One atomic per wave when the wave holds a single job (a thousand
+  // same-address atomics per job made this kernel 450 us), per lane otherwise.
+  const int job = in ? g / a.n : -1;
+  const int job0 = __shfl(job, 0, 64);
+  const bool uniform = __all(job == job0 || job < 0);
+  int lo_x = cnt ? ocx : INT_MAX, lo_y = cnt ? ocy : INT_MAX, hi_x = cnt ? ocx : INT_MIN, hi_y = cnt ? ocy : INT_MIN;
+  if (uniform) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo_x = min(lo_x, __shfl_xor(lo_x, off, 64));
+      lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+      hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
+      hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+    }
+    if ((threadIdx.x & 63) != 0) return;
+  } else if (!cnt) {
+    return;
+  }
+  if (lo_x == INT_MAX || (job0 < 0 && uniform)) return;
+  int *bb = a.job_bbox + 4 * (uniform ? job0 : job);
+  atomicMin(bb, lo_x);
+  atomicMin(bb + 1, lo_y);
+  atomicMax(bb + 2, hi_x);
+  atomicMax(bb + 3, hi_y);
+}
+
+// total number of records = exclusive offset of the last beam + its count
+__global__ void k_mu_total(const unsigned *counts, const unsigned *offsets, size_t beams, unsigned long long *out) {
+  out[0] = (unsigned long long)offsets[beams - 1] + counts[beams - 1];
 }
 
 // exclusive scan of counts[n] by one workgroup of 1024 threads; offsets[n] = total
@@ -431,7 +469,9 @@ __global__ void k_mu_apply(MuArgs a, const Key *keys, const unsigned *order, uns
     aux[0] = x0;
     if (a.aux_stride > 1) aux[1] = x1;
   }
-  atomicAdd(n_updates, (unsigned long long)cnt);
+  // the update count is spread over kNuSlots counters: one shared word made every wave of the grid
+  // queue on the same L2 line (2.9 of 3.4 ms in a 100-particle batch, profiles/r01)
+  atomicAdd(&n_updates[blockIdx.x & (kNuSlots - 1)], (unsigned long long)cnt);
 }
 
 }  // namespace slamhip
@@ -531,7 +571,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
     if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
-    if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+    if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long) * kNuSlots));
     sc.cap_beams = cap;
   }
   const size_t cb = sc.cap_beams;
@@ -551,7 +591,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     sc.last_n = n;
   }
   SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), ctx->stream));
-  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long), ctx->stream));
+  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long) * kNuSlots, ctx->stream));
 
   MuArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -659,10 +699,11 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
                      (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.n_updates);
   SLAMHIP_CHECK(hipGetLastError());
   int err = 0;
-  unsigned long long nu = 0;
+  unsigned long long nus[kNuSlots], nu = 0;
   SLAMHIP_CHECK(hipMemcpyAsync(&err, sc.error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(&nu, sc.n_updates, sizeof(nu), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(nus, sc.n_updates, sizeof(nus), hipMemcpyDeviceToHost, ctx->stream));
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < kNuSlots; ++k) nu += nus[k];
   if (n_updates_out) *n_updates_out = (long long)nu;
   if (err)
     return fail("a beam leaves the bound map window: grow the map (slamhip_map_bind) before updating; "
@@ -698,8 +739,10 @@ struct MuBatchScratch {
   double *srt_prob = nullptr, *srt_qual = nullptr, *srt_ox = nullptr, *srt_oy = nullptr;
   int *occ = nullptr, *error_flag = nullptr;
   MuJob *d_jobs = nullptr;
-  unsigned long long *n_updates = nullptr;
-  void *temp = nullptr;
+  int *d_bbox = nullptr;
+  unsigned long long *n_updates = nullptr, *d_total = nullptr;
+  void *temp = nullptr, *scan_temp = nullptr;
+  size_t scan_temp_bytes = 0;
 };
 std::vector<std::pair<slamhip_ctx *, MuBatchScratch>> g_bscratch;
 
@@ -739,10 +782,12 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   const double scale = tp->scale;
   const double max_range_sq = cfg->max_range * cfg->max_range;
 
-  // host pass: job records (pose + sincos), record count (same IEEE operations as k_mu_count), the
-  // cell rectangle each job can touch -> copy-on-write of the tiles under it
+  // job records (pose + sincos of the heading, as set_base_angle does) and the rectangle of cells each
+  // job can touch, seeded with its robot cell; k_mu_count widens it by the endpoints' cells.  The record
+  // count and the rectangles come back from the device in one small read (a host loop over
+  // jobs x beams cost 0.5 ms per 100-particle step).
   std::vector<MuJob> jobs(n_jobs);
-  unsigned long long total64 = 0;
+  std::vector<int> bbox(4 * (size_t)n_jobs);
   for (int k = 0; k < n_jobs; ++k) {
     MuJob &j = jobs[k];
     j.px = poses[3 * k];
@@ -751,33 +796,15 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
     j.slot = slots[k];
     j.pad = 0;
     const int rcx = (int)std::floor(j.px / scale), rcy = (int)std::floor(j.py / scale);
-    int lo_x = rcx, hi_x = rcx, lo_y = rcy, hi_y = rcy;
-    bool any = false;
-    for (int b = 0; b < n; ++b) {
-      const double c = j.cs * cos_a[b] - j.sn * sin_a[b];
-      const double s = j.sn * cos_a[b] + j.cs * sin_a[b];
-      const double wx = j.px + range[b] * c, wy = j.py + range[b] * s;
-      const double ddx = wx - j.px, ddy = wy - j.py;
-      if (max_range_sq < ddx * ddx + ddy * ddy) continue;
-      const int ocx = (int)std::floor(wx / scale), ocy = (int)std::floor(wy / scale);
-      total64 += (unsigned)(std::abs(ocx - rcx) + std::abs(ocy - rcy) + 1);
-      lo_x = std::min(lo_x, ocx);
-      hi_x = std::max(hi_x, ocx);
-      lo_y = std::min(lo_y, ocy);
-      hi_y = std::max(hi_y, ocy);
-      any = true;
-    }
-    if (any) {
-      int rc = tile_pool_make_private(tp, j.slot, lo_x + tp->origin_x, lo_y + tp->origin_y, hi_x + tp->origin_x,
-                                      hi_y + tp->origin_y);
-      if (rc) return rc;
-    }
+    bbox[4 * k] = bbox[4 * k + 2] = rcx;
+    bbox[4 * k + 1] = bbox[4 * k + 3] = rcy;
   }
-  int rc = tile_pool_flush(tp);
-  if (rc) return rc;
-  if (total64 == 0) return SLAMHIP_OK;
-  if (total64 >= 0xfffffff0ull) return fail("more than 2^32 cell updates in one batch: split the batch");
-  const unsigned total = (unsigned)total64;
+  {  // 32-bit record offsets: a beam of range r crosses at most |dx| + |dy| + 1 <= sqrt(2) r / scale + 3 cells
+    double bound = 0;
+    for (int b = 0; b < n; ++b) bound += 1.4143 * std::min(std::fabs(range[b]), cfg->max_range) / scale + 3.0;
+    if (bound * n_jobs >= 4.0e9) return fail("more than 2^32 cell updates in one batch: split the batch");
+  }
+  unsigned total = 0;
 
   const size_t beams = (size_t)n_jobs * n;
   if ((size_t)n > sc.cap_scan) {
@@ -802,14 +829,17 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
     size_t cap = 64;
     while (cap < (size_t)n_jobs) cap *= 2;
     SLAMHIP_CHECK(regrow(sc.d_jobs, cap));
+    SLAMHIP_CHECK(regrow(sc.d_bbox, 4 * cap));
     sc.cap_jobs = cap;
   }
   if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
-  if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
-  if (total > sc.cap_records) {
+  if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long) * kNuSlots));
+  if (!sc.d_total) SLAMHIP_CHECK(hipMalloc(&sc.d_total, sizeof(unsigned long long)));
+  auto ensure_records = [&](unsigned need_records) -> int {
+    if (need_records <= sc.cap_records) return SLAMHIP_OK;
     SLAMHIP_CHECK(hipStreamSynchronize(st));
     size_t cap = 1 << 18;
-    while (cap < total) cap *= 2;
+    while (cap < need_records) cap *= 2;
     SLAMHIP_CHECK(regrow(sc.keys, cap));
     SLAMHIP_CHECK(regrow(sc.keys_sorted, cap));
     SLAMHIP_CHECK(regrow(sc.order, cap));
@@ -826,15 +856,17 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
                                             sc.order_sorted, cap, 0, 64, st));
     SLAMHIP_CHECK(hipMalloc(&sc.temp, sc.temp_bytes));
     sc.cap_records = cap;
-  }
+    return SLAMHIP_OK;
+  };
   const size_t cs = sc.cap_scan;
   SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, st));
   SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cs, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, st));
   SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cs, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, st));
   if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, st));
   SLAMHIP_CHECK(hipMemcpyAsync(sc.d_jobs, jobs.data(), sizeof(MuJob) * n_jobs, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(sc.d_bbox, bbox.data(), sizeof(int) * 4 * n_jobs, hipMemcpyHostToDevice, st));
   SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), st));
-  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long), st));
+  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long) * kNuSlots, st));
 
   MuArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -879,8 +911,42 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   a.rec_prob = sc.rec_pq;
 
   const dim3 bgrid((unsigned)((beams + 255) / 256));
+  a.job_bbox = sc.d_bbox;
   hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, st, sc.counts, sc.offsets, (int)beams);
+  {  // offsets: device-wide exclusive scan (the one-workgroup scan of the single-scan path takes 160 us
+     // for 100 x 1080 beams)
+    size_t need = 0;
+    SLAMHIP_CHECK(rocprim::exclusive_scan(nullptr, need, sc.counts, sc.offsets, 0u, beams, rocprim::plus<unsigned>(), st));
+    if (need > sc.scan_temp_bytes) {
+      SLAMHIP_CHECK(hipStreamSynchronize(st));
+      if (sc.scan_temp) hipFree(sc.scan_temp);
+      sc.scan_temp = nullptr;
+      SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, need));
+      sc.scan_temp_bytes = need;
+    }
+    SLAMHIP_CHECK(rocprim::exclusive_scan(sc.scan_temp, need, sc.counts, sc.offsets, 0u, beams, rocprim::plus<unsigned>(), st));
+  }
+  hipLaunchKernelGGL(k_mu_total, dim3(1), dim3(1), 0, st, sc.counts, sc.offsets, beams, sc.d_total);
+  unsigned long long total64 = 0;
+  SLAMHIP_CHECK(hipMemcpyAsync(&total64, sc.d_total, sizeof(total64), hipMemcpyDeviceToHost, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(bbox.data(), sc.d_bbox, sizeof(int) * 4 * n_jobs, hipMemcpyDeviceToHost, st));
+  SLAMHIP_CHECK(hipStreamSynchronize(st));
+  if (total64 == 0) return SLAMHIP_OK;
+  if (total64 >= 0xfffffff0ull) return fail("more than 2^32 cell updates in one batch: split the batch");
+  total = (unsigned)total64;
+  // copy-on-write of the tiles under every job's rectangle, then room for the records
+  for (int k = 0; k < n_jobs; ++k) {
+    int rc = tile_pool_make_private(tp, jobs[k].slot, bbox[4 * k] + tp->origin_x, bbox[4 * k + 1] + tp->origin_y,
+                                    bbox[4 * k + 2] + tp->origin_x, bbox[4 * k + 3] + tp->origin_y);
+    if (rc) return rc;
+  }
+  int rc = tile_pool_flush(tp);
+  if (rc) return rc;
+  a.tables = tp->d_table();
+  rc = ensure_records(total);
+  if (rc) return rc;
+  a.keys64 = sc.keys;
+  a.rec_prob = sc.rec_pq;
   hipLaunchKernelGGL(k_mu_emit, bgrid, dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_iota, dim3((total + 255) / 256), dim3(256), 0, st, sc.order, total);
   unsigned job_bits = 1;
@@ -901,10 +967,11 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
                      sc.n_updates);
   SLAMHIP_CHECK(hipGetLastError());
   int err = 0;
-  unsigned long long nu = 0;
+  unsigned long long nus[kNuSlots], nu = 0;
   SLAMHIP_CHECK(hipMemcpyAsync(&err, sc.error_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-  SLAMHIP_CHECK(hipMemcpyAsync(&nu, sc.n_updates, sizeof(nu), hipMemcpyDeviceToHost, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(nus, sc.n_updates, sizeof(nus), hipMemcpyDeviceToHost, st));
   SLAMHIP_CHECK(hipStreamSynchronize(st));
+  for (int k = 0; k < kNuSlots; ++k) nu += nus[k];
   if (n_updates_out) *n_updates_out = (long long)nu;
   if (err)
     return fail("a beam leaves the tile extent of the particle maps: create them with a larger extent; cells "
