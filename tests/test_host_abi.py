@@ -40,11 +40,19 @@ def test_no_gpu_means_loud_failure(pkg):
 
 
 def test_product_package_never_imports_the_oracle(pkg):
-    src = open(os.path.join(ROOT, "slam-constructor_amd", "__init__.py")).read()
-    assert "pyoracle" not in src and "liboracle" not in src
-    for f in os.listdir(os.path.join(ROOT, "slam-constructor_amd", "csrc")):
-        body = open(os.path.join(ROOT, "slam-constructor_amd", "csrc", f)).read()
-        assert "slam_oracle" not in body and "liboracle" not in body, f
+    for py in ("__init__.py", "fixtures.py"):
+        src = open(os.path.join(ROOT, "slam-constructor_amd", py)).read()
+        assert "pyoracle" not in src and "liboracle" not in src, py
+    for tool in ("sm_runner_hip.py", "p2d_ss_evaluator_hip.py"):
+        src = open(os.path.join(ROOT, "tools", tool)).read()
+        assert "pyoracle" not in src and "liboracle" not in src and "oracle" not in src.replace("the oracle", ""), tool
+    for sub in ("csrc", "host"):
+        d = os.path.join(ROOT, "slam-constructor_amd", sub)
+        for f in os.listdir(d):
+            if not os.path.isfile(os.path.join(d, f)):
+                continue
+            body = open(os.path.join(d, f), errors="replace").read()
+            assert "slam_oracle" not in body and "liboracle" not in body, f
 
 
 def test_filter_weights_trig_vs_golden(pkg):
