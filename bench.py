@@ -342,6 +342,34 @@ def pf_cpu_baseline(args, seconds):
                       % (steps, n, t_used)}
 
 
+def pf_cpu_baseline_reference(args, seconds):
+    """The compiled reference's own GmappingParticleFilter (oracle/_ref: shared map, map update inside
+    the step -- the reference's default behaviour) on the same scan sequence, a few particles."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from synth import make_scene
+    if not po.ref_available():
+        return None
+    sc = make_scene(cell_model=2, size=min(args.pf_size, 2000), scale=args.scale, n_beams=args.beams, seed=4)
+    R = po.Ref()
+    n = 8
+    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+    g = po.RefGmapping(R, n, 1000, 1000, args.scale, gp, np.arange(1000, 1000 + n, dtype=np.uint32))
+    scan = R.scan_create(sc["scan"].range, sc["scan"].angle)
+    g.step(scan, sc["true_pose"], 7, np.arange(5000, 5000 + n, dtype=np.uint32))  # builds the map
+    rs = np.random.RandomState(5)
+    steps, t_used = 0, 0.0
+    while t_used < seconds and steps < 20:
+        d = rs.randn(3) * [0.05, 0.05, 0.02]
+        t0 = time.perf_counter()
+        g.step(scan, d, 8 + steps, np.arange(6000 + 100 * steps, 6000 + 100 * steps + n, dtype=np.uint32))
+        t_used += time.perf_counter() - t0
+        steps += 1
+    return {"value": n * steps / t_used, "unit": "particles/s", "cores": 1, "kind": "reference",
+            "sample": "%d GmappingParticleFilter steps of %d particles of the compiled reference (oracle/_ref), "
+                      "map update inside the step, %.1f s" % (steps, n, t_used)}
+
+
 def main():
     args = parse()
     import torch
@@ -499,6 +527,12 @@ def main():
             out["particle_filter"] = pf_out
             if world == 1 and not args.no_cpu and "value" in pf_out:
                 pf_out["cpu_baseline"] = pf_cpu_baseline(args, min(args.cpu_seconds, 8.0))
+                try:  # the full step (with map update) of the compiled reference, beside with_map_update
+                    refb = pf_cpu_baseline_reference(args, min(args.cpu_seconds, 6.0))
+                except Exception as e:  # noqa: BLE001
+                    refb = {"error": str(e)}
+                if refb is not None and pf_out.get("with_map_update"):
+                    pf_out["with_map_update"]["cpu_baseline"] = refb
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
