@@ -471,10 +471,14 @@ private:
         patch(kEnd);
         continue;
       }
+      // `st` may point INTO rounds_: copy the state before emplace_back can reallocate the vector
+      // (a dangling read here made the plan -- and, through a garbage enumerator, the accept chain --
+      // depend on what the allocator had done with the freed block)
+      const HillClimbingPoseEnumerator from = *st;
       rounds_.emplace_back();
       Round &rd = rounds_.back();
-      rd.e_fail = *st;
-      rd.e_ok = *st;
+      rd.e_fail = from;
+      rd.e_ok = from;
       rd.best = in_best;
       rd.first = first;
       rd.outcome = cd.outcome;
@@ -705,6 +709,8 @@ public:
     out[1] = best.y - init.y;
     out[2] = best.theta - init.theta;
   }
+
+  double p_accept() const { return p_accept_; }
 
   static double now_us() {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -517,9 +517,15 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
 // Scoring launches go through hipExtLaunchKernelGGL so that slamhip_profile_* can attach its
 // HIP events to the dispatch itself: the elapsed time is then the kernel's own begin..end (what
 // rocprofv3 --kernel-trace reports), not record-to-record on an idle stream which adds ~4 us of
-// queue processing per isolated launch (tools/event_probe.hip).  Null events = a plain launch.
-#define SLAMHIP_LAUNCH(kernel, grid, block, shm, st, e0, e1, ...) \
-  hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__)
+// queue processing per isolated launch (tools/event_probe.hip).  Without events the ordinary launch
+// is used.
+#define SLAMHIP_LAUNCH(kernel, grid, block, shm, st, e0, e1, ...)                          \
+  do {                                                                                     \
+    if ((e0) || (e1))                                                                      \
+      hipExtLaunchKernelGGL(kernel, grid, block, shm, st, e0, e1, 0, __VA_ARGS__);         \
+    else                                                                                   \
+      hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__);                       \
+  } while (0)
 
 template <int MODEL, bool WT>
 static hipError_t launch_point_kb(const ScoreArgs &a, int kb, dim3 grid, hipStream_t st,
