@@ -253,6 +253,21 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     st = pf.stats()
+    # second, instrumented pass (HIP events attached to every K3 dispatch; never in the timed pass)
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    for k in range(2 + args.pf_steps, 2 + args.pf_steps + 3):
+        one(k % len(deltas))
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    g_ms, g_launches, g_units = ctx.profile_read(reset=True)
+    bpu = BYTES_PER_UNIT["gmapping"]
+    g_achieved = g_units * bpu / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+    pf_roofline = {"bound": "hbm", "achieved": g_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": g_achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_score_gmapping",
+                   "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,
+                   "avg_launch_us": 1e3 * g_ms / max(g_launches, 1),
+                   "timing": "HIP events attached to each dispatch, 3 extra steps after the timed pass"}
     if world > 1:
         tt = torch.tensor([dt, float(calls)], dtype=torch.float64, device=dev)
         mx = tt.clone()
@@ -306,7 +321,7 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
             with_maps = {"error": str(e)}
     ctx.map_release(1)
     return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
-            "with_map_update": with_update, "with_particle_maps": with_maps,
+            "with_map_update": with_update, "with_particle_maps": with_maps, "roofline": pf_roofline,
             "ms_per_step": 1e3 * dt / args.pf_steps, "steps": args.pf_steps, "scaling": "strong",
             "pose_candidates_beams_per_s": calls * scan.n / dt,
             "workload": "cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "

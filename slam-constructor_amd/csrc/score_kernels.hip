@@ -254,7 +254,10 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *ti
 // computed for the run's first beam.  Thread t owns beams t + 256k, so for a fixed k one wave
 // holds 64 CONSECUTIVE beams (group g = 4k + wave): run heads come from a ballot + clz inside
 // the group and a short backward walk over per-group summaries in LDS across groups.
-template <int KB>
+// ONE: the workgroup scores exactly one pose (every launch below 1024 poses, i.e. all matcher and
+// filter launches): without the pose loop the beam constants die after phase A / C instead of
+// staying live for a next iteration -- 163 -> fewer VGPRs, more waves to hide the 9-cell gathers.
+template <int KB, bool ONE>
 __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   extern __shared__ double s_dyn[];  // val[n] | grp_last_cell (int2 as double) [G] | grp_last_start [G]
   __shared__ double s_pose[kMaxPosesPerBlock][4];
@@ -267,8 +270,8 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   double *s_val = s_dyn;
   int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kBlock);
   int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
-  const int p0 = blockIdx.x * a.poses_per_block;
-  const int npb = min(a.poses_per_block, a.n_poses - p0);
+  const int p0 = ONE ? (int)blockIdx.x : blockIdx.x * a.poses_per_block;
+  const int npb = ONE ? 1 : min(a.poses_per_block, a.n_poses - p0);
 
   if (t < npb) {
     const int p = p0 + t;
@@ -293,8 +296,10 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
     br[k] = ok ? a.scan.range[b] : 0.0;
     bc[k] = ok ? a.scan.cos_a[b] : 0.0;
     bs[k] = ok ? a.scan.sin_a[b] : 0.0;
-    bw[k] = ok ? a.scan.weight[b] : 0.0;
-    bf[k] = ok ? a.scan.factor[b] : 0.0;
+    // one pose: weight and factor are read where they are used (phase C) instead of occupying
+    // 4 KB of VGPRs across the gathers
+    bw[k] = (ok && !ONE) ? a.scan.weight[b] : 0.0;
+    bf[k] = (ok && !ONE) ? a.scan.factor[b] : 0.0;
   }
   __syncthreads();
 
@@ -357,7 +362,8 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
           while (head < 0) head = s_grp_start[--gg];  // beam 0 is always a start
         }
         const double v = s_val[head];
-        const double term = v * bw[k] * bf[k];
+        const double wk = ONE ? a.scan.weight[b] : bw[k], fk = ONE ? a.scan.factor[b] : bf[k];
+        const double term = v * wk * fk;
         acc = acc + term;
         if (b == n - 1 && a.gm_info) {
           GmPoseInfo &gi = a.gm_info[p0 + j];
@@ -565,9 +571,12 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   if (oope == SLAMHIP_OOPE_GMAPPING) {
     if (kb > 8) return hipErrorInvalidValue;
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
-#define GM_CASE(K)                                                                              \
-  case K:                                                                                       \
-    SLAMHIP_LAUNCH((k_score_gmapping<K>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a); \
+#define GM_CASE(K)                                                                                            \
+  case K:                                                                                                     \
+    if (a.poses_per_block == 1)                                                                               \
+      SLAMHIP_LAUNCH((k_score_gmapping<K, true>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);     \
+    else                                                                                                      \
+      SLAMHIP_LAUNCH((k_score_gmapping<K, false>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);    \
     break;
     switch (kb < 1 ? 1 : kb) {
       GM_CASE(1) GM_CASE(2) GM_CASE(3) GM_CASE(4) GM_CASE(5) GM_CASE(6) GM_CASE(7) GM_CASE(8)
