@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--pf-tiles-per-particle", type=int, default=420,
                     help="tile-pool budget per particle of the per-particle-maps leg (768 KiB each)")
     ap.add_argument("--no-pf", action="store_true", help="skip the GMapping particle-filter leg")
+    ap.add_argument("--pf-sigma-xy", type=float, default=0.1, help="slam/particles/sample/xy/sigma (init_gmapping.h:17)")
+    ap.add_argument("--pf-sigma-th", type=float, default=0.03, help="slam/particles/sample/theta/sigma (:19-20)")
+    ap.add_argument("--pf-maps-sharded", action="store_true",
+                    help="N > 1 only: also run the per-particle-maps filter sharded over the ranks (maps "
+                         "migrate between ranks on resampling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (path testing)")
     ap.add_argument("--strict", action="store_true",
@@ -196,6 +201,77 @@ def cpu_baseline(sc, kind, params, seconds, weighting="even"):
     return port
 
 
+def sharded_particle_maps_leg(args, pkg, ctx, blob_size, gp, seeds, n, first, count, rank, world, scan, deltas, dist,
+                              torch, dev):
+    """Per-particle copy-on-write maps with the particles sharded over the ranks (opt-in:
+    --pf-maps-sharded).  Per step: local lock-step match + batched K6, all-gather of the raw weights,
+    identical resampling plan everywhere; on a resampling the particle records are all-gathered and the
+    maps of particles drawn from another rank travel point to point (sizes first, then the buffers)."""
+    pfm = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
+    ext = (args.pf_size + 127) // 128 + 1
+    pfm.enable_particle_maps(1, extent_tiles=ext, pool_tiles=ext * ext + 2 * count * args.pf_tiles_per_particle)
+    owner = lambda j: int(j) // count  # noqa: E731  (contiguous blocks)
+    moved_bytes = 0
+    resamplings = 0
+
+    def gather(a, dtype):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        out = torch.empty(world * t.numel(), dtype=dtype, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+
+    def one(k):
+        nonlocal moved_bytes, resamplings
+        raw = pfm.predict_match(1, scan.range, scan.angle, None, deltas[k % len(deltas)])
+        req, idx = pfm.plan_resample(gather(raw, torch.float64), 7 + k)
+        if not req:
+            return
+        resamplings += 1
+        blobs = gather(pfm.export(), torch.uint8)
+        # (source particle j, destination rank r) pairs, identical on every rank
+        pairs = sorted({(int(idx[i]), owner(i)) for i in range(n) if owner(idx[i]) != owner(i)})
+        mine = {j: pfm.export_particle_map(j - first) for j in sorted({j for j, _ in pairs if owner(j) == rank})}
+        sizes = np.zeros(n, np.int64)
+        for j, b in mine.items():
+            sizes[j] = b.size
+        sizes = gather(sizes[first:first + count], torch.int64)
+        ops, recv = [], {}
+        for j, r in pairs:
+            if owner(j) == rank:
+                t = torch.from_numpy(mine[j]).to(dev)
+                ops.append(dist.P2POp(dist.isend, t, r))
+                moved_bytes += int(t.numel())
+            elif r == rank:
+                recv[j] = torch.empty(int(sizes[j]), dtype=torch.uint8, device=dev)
+                ops.append(dist.P2POp(dist.irecv, recv[j], owner(j)))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        pfm.import_maps(blobs, idx, {j: t.cpu().numpy() for j, t in recv.items()})
+
+    one(0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    msteps = max(3, args.pf_steps)
+    for k in range(1, 1 + msteps):
+        one(k)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dm = time.perf_counter() - t0
+    tt = torch.tensor([dm, float(moved_bytes)], dtype=torch.float64, device=dev)
+    mx = tt.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = tt.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    st = pfm.particle_map_stats()
+    return {"value": n * msteps / mx[0].item(), "unit": "particles/s", "ms_per_step": 1e3 * mx[0].item() / msteps,
+            "steps": msteps, "resamplings": resamplings, "map_bytes_moved_between_ranks": sm[1].item(),
+            "tiles_in_use_rank0": st["tiles_in_use"],
+            "note": "particles and their copy-on-write maps sharded over %d ranks; maps migrate point to point "
+                    "on resampling" % world}
+
+
 def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     """BASELINE cfg 4: GMapping filter, `--particles` particles sharded over the ranks (contiguous
     blocks), 1080-beam scan, 4000x4000 @0.05 m GMapping-cell map replicated per GPU (the reference's
@@ -211,7 +287,7 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     count = n // world
     first = rank * count
     seeds = np.arange(1000, 1000 + n, dtype=np.uint32)[first:first + count]
-    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+    gp = [0.0, args.pf_sigma_xy, 0.0, args.pf_sigma_th, 0.0, 0.0, 0.0, 0.0]
     pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
     scan = sc["scan"]
     dev = args.coll_device
@@ -319,6 +395,9 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
             del pfm
         except pkg.SlamHipError as e:  # e.g. the pool does not fit: report, do not hide
             with_maps = {"error": str(e)}
+    if world > 1 and args.pf_maps_sharded:
+        with_maps = sharded_particle_maps_leg(args, pkg, ctx, pf.blob_size(), gp, seeds, n, first, count, rank, world,
+                                              scan, deltas, dist, torch, dev)
     ctx.map_release(1)
     return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
             "with_map_update": with_update, "with_particle_maps": with_maps, "roofline": pf_roofline,

@@ -311,7 +311,8 @@ int slamhip_gmapping_set_map_update(slamhip_gmapping *g, const slamhip_scan_adde
  * lock-step matching and appends the scans of all matched particles in ONE batched K6; a resampling
  * copies tile tables (particle_filter.h:92-96).  extent_tiles: side of the fixed virtual extent in
  * tiles (cells outside read as unknown and cannot be written); pool_tiles: capacity (768 KiB each).
- * Whole filter on one context only. */
+ * A shard [first, first+count) of the filter holds the maps of its own particles; when a resampling
+ * draws a particle that lives on another rank its map travels as one exported buffer (below). */
 int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const slamhip_scan_adder_cfg *cfg,
                                           int extent_tiles, int pool_tiles);
 /* external window of one particle's map: payload3 = (prob_occ, obstacle x, obstacle y) per cell,
@@ -320,6 +321,18 @@ int slamhip_gmapping_particle_map_download(slamhip_gmapping *g, int particle, in
                                            double *payload3, double *aux2);
 int slamhip_gmapping_particle_map_stats(slamhip_gmapping *g, long long *tiles_in_use, long long *tiles_shared,
                                         long long *bytes, long long *cow_copies, long long *cell_updates);
+/* Migration of a particle's map to another rank (the "moving a duplicated particle to another GPU"
+ * step of SURVEY 8e).  Export: every tile the LOCAL particle references (except the unknown tile) into a
+ * host buffer: int64 n_tiles, n_tiles int32 table indices padded to 8 bytes, then per tile 16384 x 4
+ * payload and 16384 x 2 counter doubles.  Exports must be taken before any rank imports. */
+int slamhip_gmapping_particle_map_export_size(slamhip_gmapping *g, int particle, size_t *bytes);
+int slamhip_gmapping_particle_map_export(slamhip_gmapping *g, int particle, void *host_buf, size_t cap);
+/* slamhip_gmapping_import for a filter with per-particle maps: new local particle l takes the map of
+ * old particle idx[first + l] -- a table copy when that one is local, otherwise the exported buffer
+ * remote_bufs[k] with remote_src[k] == idx[first + l] (GLOBAL particle index; a source used by several
+ * new particles is listed and imported once, its tiles are then shared copy-on-write). */
+int slamhip_gmapping_import_maps(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx, int n_remote,
+                                 const int *remote_src, const void *const *remote_bufs);
 int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, int *is_master);
 int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
                            long long *launches, long long *carry_reruns);

@@ -40,7 +40,8 @@ slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_expor
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
 slamhip_gmapping_stats slamhip_gmapping_set_map_update slamhip_map_append_scan slamhip_map_download_aux
 slamhip_gmapping_enable_particle_maps slamhip_gmapping_particle_map_download
-slamhip_gmapping_particle_map_stats""".split()
+slamhip_gmapping_particle_map_stats slamhip_gmapping_particle_map_export_size
+slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps""".split()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -187,6 +188,9 @@ def load():
     L.slamhip_gmapping_enable_particle_maps.argtypes = [vp, i, C.POINTER(ScanAdderCfg), i, i]
     L.slamhip_gmapping_particle_map_download.argtypes = [vp, i, i, i, i, i, _dp, _dp]
     L.slamhip_gmapping_particle_map_stats.argtypes = [vp, ll, ll, ll, ll, ll]
+    L.slamhip_gmapping_particle_map_export_size.argtypes = [vp, i, C.POINTER(C.c_size_t)]
+    L.slamhip_gmapping_particle_map_export.argtypes = [vp, i, vp, C.c_size_t]
+    L.slamhip_gmapping_import_maps.argtypes = [vp, vp, up, i, _ip, C.POINTER(vp)]
     _lib = L
     return L
 
@@ -553,6 +557,28 @@ class GmappingFilter:
         pay, aux = np.zeros((h, w, 3)), np.zeros((h, w, 2))
         _check(self.L.slamhip_gmapping_particle_map_download(self.h, particle, x0, y0, w, h, _d(pay), _d(aux)))
         return pay, aux
+
+    def export_particle_map(self, particle):
+        """The LOCAL particle's map as one uint8 array (tiles + table indices) for another rank."""
+        sz = C.c_size_t(0)
+        _check(self.L.slamhip_gmapping_particle_map_export_size(self.h, particle, C.byref(sz)))
+        buf = np.zeros(sz.value, np.uint8)
+        _check(self.L.slamhip_gmapping_particle_map_export(self.h, particle, buf.ctypes.data_as(C.c_void_p),
+                                                           buf.size))
+        return buf
+
+    def import_maps(self, all_blobs, idx, remote):
+        """Resampling with per-particle maps: `remote` = {global source particle: exported uint8 array}
+        for every source that lives on another rank."""
+        b = np.ascontiguousarray(all_blobs, dtype=np.uint8)
+        ix = np.ascontiguousarray(idx, dtype=np.uint32)
+        keys = sorted(remote)
+        src = np.ascontiguousarray(keys, dtype=np.int32)
+        bufs = [np.ascontiguousarray(remote[k], dtype=np.uint8) for k in keys]
+        ptrs = (C.c_void_p * max(len(bufs), 1))(*[bb.ctypes.data for bb in bufs])
+        _check(self.L.slamhip_gmapping_import_maps(self.h, b.ctypes.data_as(C.c_void_p),
+                                                   ix.ctypes.data_as(C.POINTER(C.c_uint)), len(keys),
+                                                   src.ctypes.data_as(_ip), ptrs))
 
     def particle_map_stats(self):
         v = [C.c_longlong() for _ in range(5)]

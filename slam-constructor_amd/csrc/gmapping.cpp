@@ -119,6 +119,7 @@ struct slamhip_gmapping {
   // in lock-step and the map updates of all matched particles run as ONE batched K6
   TilePool *tp = nullptr;
   TiledTarget tt{};
+  bool maps_handled_by_caller = false;  // set by slamhip_gmapping_import_maps around the particle import
 };
 
 namespace {
@@ -458,15 +459,56 @@ int slamhip_gmapping_import(slamhip_gmapping *g, const void *all_blobs, const un
   g->p.swap(np);
   g->all_w = w;
   g->traversed[0] = g->traversed[1] = g->traversed[2] = 0;
-  if (g->tp) {
+  if (g->tp && !g->maps_handled_by_caller) {
     // `*new_particle = *sampled` copies the map too: with the tiled map that is a table copy, the tiles
     // get shared until one of the copies writes (lazy_tiled_grid_map.h:40-45,57-71)
+    if (g->count != g->n_total)
+      return bad("a sharded filter with per-particle maps resamples through slamhip_gmapping_import_maps");
     std::vector<int> src(n);
     for (int i = 0; i < n; ++i) src[i] = (int)idx[i];
     int rc = tile_pool_assign(g->tp, src.data());
     if (rc) return rc;
   }
   return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_particle_map_export_size(slamhip_gmapping *g, int particle, size_t *bytes) {
+  if (!g || !g->tp || !bytes) return bad("per-particle maps are not enabled");
+  if (particle < 0 || particle >= g->count) return bad("particle index out of range");
+  *bytes = tile_pool_export_size(g->tp, particle);
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_particle_map_export(slamhip_gmapping *g, int particle, void *host_buf, size_t cap) {
+  if (!g || !g->tp) return bad("per-particle maps are not enabled");
+  if (particle < 0 || particle >= g->count) return bad("particle index out of range");
+  SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
+  return tile_pool_export(g->tp, particle, host_buf, cap);
+}
+
+int slamhip_gmapping_import_maps(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx, int n_remote,
+                                 const int *remote_src, const void *const *remote_bufs) {
+  if (!g || !g->tp) return bad("per-particle maps are not enabled");
+  if (!all_blobs || !idx || n_remote < 0 || (n_remote > 0 && (!remote_src || !remote_bufs))) return bad("null argument");
+  SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
+  // where every new local particle's map comes from: an old local slot, or one of the exported maps
+  std::vector<int> src(g->count);
+  for (int l = 0; l < g->count; ++l) {
+    const int j = (int)idx[g->first + l];
+    if (j >= g->first && j < g->first + g->count) {
+      src[l] = j - g->first;
+      continue;
+    }
+    int k = 0;
+    while (k < n_remote && remote_src[k] != j) ++k;
+    if (k == n_remote) return bad("the map of a particle resampled from another rank was not supplied");
+    src[l] = -k - 1;
+  }
+  g->maps_handled_by_caller = true;
+  int rc = slamhip_gmapping_import(g, all_blobs, idx);
+  g->maps_handled_by_caller = false;
+  if (rc) return rc;
+  return tile_pool_assign_mixed(g->tp, src.data(), n_remote, remote_bufs);
 }
 
 int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const slamhip_scan_adder_cfg *cfg,
@@ -476,15 +518,14 @@ int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const
     set_error("this filter was created without a GPU context");
     return SLAMHIP_ERR_NO_DEVICE;
   }
-  if (g->count != g->n_total)
-    return bad("per-particle maps need the whole filter on one context (tile migration between GPUs is not built)");
   if (map_id < 0 || map_id >= (int)g->ctx->maps.size() || !g->ctx->maps[map_id].bound) return bad("unknown map id");
   if (extent_tiles <= 0 || pool_tiles < 2) return bad("bad tile pool shape");
   SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
   const DeviceMap &m = g->ctx->maps[map_id];
   if (g->tp) tile_pool_destroy(g->tp);
   g->tp = nullptr;
-  int rc = tile_pool_create(g->ctx, g->n_total, extent_tiles, extent_tiles, m.scale, m.unknown, pool_tiles, &g->tp);
+  // one slot per LOCAL particle: a shard of the filter holds the maps of its own particles only
+  int rc = tile_pool_create(g->ctx, g->count, extent_tiles, extent_tiles, m.scale, m.unknown, pool_tiles, &g->tp);
   if (rc) return rc;
   rc = tile_pool_init_from_dense(g->tp, m);
   if (rc) {

@@ -38,6 +38,10 @@ struct TilePool {
   int *h_assign = nullptr;         // source slot per new slot
   int cap_pairs = 0, cap_patches = 0, n_pairs = 0, n_patches = 0;
   long long cow_copies = 0;        // tiles copied so far
+  // tiles of the common ancestor map (tile_pool_init_from_dense): never freed, so that a migrating map
+  // can name them by ordinal instead of carrying their 768 KiB -- every rank builds the same ancestor
+  std::vector<int> ancestor;       // ordinal -> tile id
+  std::vector<int> ancestor_of;    // tile id -> ordinal or -1
 
   int table_stride() const { return tiles_x * tiles_y; }
   int width() const { return tiles_x * kTileSide; }
@@ -56,6 +60,17 @@ int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y
 int tile_pool_flush(TilePool *tp);
 // resampling: new slot i becomes a copy of old slot src[i] (tables only; tiles get shared)
 int tile_pool_assign(TilePool *tp, const int *src_of_new);
+// ---- migration between pools (particles that move to another GPU on resampling) --------------------
+// A slot's map leaves as one host buffer: int64 n_tiles, n_tiles int32 table indices (padded to 8
+// bytes), then per tile 16384 x 4 payload doubles and 16384 x 2 counter doubles.  Every tile the slot
+// references except the unknown tile is included (the receiving pool cannot know which of them equal
+// its own ancestor tiles).
+size_t tile_pool_export_size(const TilePool *tp, int slot);
+int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap);
+// new generation with remote sources: new slot s becomes a copy of old local slot src[s] when
+// src[s] >= 0, or of the exported map remote_bufs[-src[s] - 1] otherwise (imported once, shared by
+// every new slot that names it -- the tiles are then shared like after a local copy)
+int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs);
 // external window [x0, x0+w) x [y0, y0+h) of a slot: payload (3 doubles per cell: prob, obst.x, obst.y)
 // and counters (2 per cell: hits, tries); either may be null
 int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, double *payload3, double *aux2);

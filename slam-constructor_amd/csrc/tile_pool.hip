@@ -174,6 +174,7 @@ int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, do
   tp->h_tables.assign(tab, 0);
   tp->refcnt.assign(capacity, 0);
   tp->refcnt[0] = 1 << 30;
+  tp->ancestor_of.assign(capacity, -1);
   hipLaunchKernelGGL(k_table_fill, dim3((unsigned)((tab + 255) / 256)), dim3(256), 0, ctx->stream, tp->d_tables[0], tab, 0);
   hipLaunchKernelGGL(k_tile_fill_unknown, dim3(kTileCells / 256), dim3(256), 0, ctx->stream, tp->d_pool, tp->d_aux, 0,
                      unknown[0], unknown[1], unknown[2], unknown[3]);
@@ -210,6 +211,8 @@ int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m) {
     int rc = alloc_tile(tp, &ids[k]);
     if (rc) return rc;
     tp->refcnt[ids[k]] = tp->n_slots;
+    tp->ancestor.push_back(ids[k]);
+    tp->ancestor_of[ids[k]] = (int)tp->ancestor.size() - 1;
   }
   int *d_ids = nullptr;
   SLAMHIP_CHECK(hipMalloc(&d_ids, sizeof(int) * nt));
@@ -244,7 +247,8 @@ int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y
     for (int tx = tx0; tx <= tx1; ++tx) {
       const int idx = ty * tp->tiles_x + tx;
       const int old = row[idx];
-      if (old != 0 && tp->refcnt[old] == 1) continue;  // already private
+      // already private -- ancestor tiles never are: they stay intact for maps that arrive by ordinal
+      if (old != 0 && tp->refcnt[old] == 1 && tp->ancestor_of[old] < 0) continue;
       int fresh = 0;
       rc = alloc_tile(tp, &fresh);
       if (rc) return rc;
@@ -295,7 +299,7 @@ int tile_pool_assign(TilePool *tp, const int *src_of_new) {
   std::vector<int> rc(tp->refcnt.size(), 0);
   for (int t : nt) rc[t] += 1;
   for (int t = 1; t < tp->next_unused; ++t)
-    if (tp->refcnt[t] > 0 && rc[t] == 0) tp->free_list.push_back(t);
+    if (tp->refcnt[t] > 0 && rc[t] == 0 && tp->ancestor_of[t] < 0) tp->free_list.push_back(t);
   rc[0] = 1 << 30;
   tp->refcnt.swap(rc);
   tp->h_tables.swap(nt);
@@ -303,6 +307,123 @@ int tile_pool_assign(TilePool *tp, const int *src_of_new) {
                      tp->d_tables[tp->cur ^ 1], tp->d_tables[tp->cur], tp->h_assign, stride);
   SLAMHIP_CHECK(hipGetLastError());
   SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  tp->cur ^= 1;
+  return SLAMHIP_OK;
+}
+
+namespace {
+constexpr size_t kTilePayloadBytes = (size_t)kTileCells * 4 * sizeof(double);
+constexpr size_t kTileAuxBytes = (size_t)kTileCells * 2 * sizeof(double);
+// header: int64 n_entries, then n_entries x (int32 table index, int32 ancestor ordinal or -1)
+size_t export_header_bytes(long long n_entries) { return 8 + (size_t)n_entries * 8; }
+}  // namespace
+
+size_t tile_pool_export_size(const TilePool *tp, int slot) {
+  if (slot < 0 || slot >= tp->n_slots) return 0;
+  const int *row = tp->h_tables.data() + (size_t)slot * tp->table_stride();
+  long long n = 0, with_content = 0;
+  for (int i = 0; i < tp->table_stride(); ++i) {
+    if (row[i] == 0) continue;
+    ++n;
+    with_content += tp->ancestor_of[row[i]] < 0;
+  }
+  return export_header_bytes(n) + (size_t)with_content * (kTilePayloadBytes + kTileAuxBytes);
+}
+
+int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap) {
+  if (slot < 0 || slot >= tp->n_slots || !host_buf) return tp_fail("bad export arguments");
+  const size_t need = tile_pool_export_size(tp, slot);
+  if (cap < need) return tp_fail("export buffer too small");
+  const int *row = tp->h_tables.data() + (size_t)slot * tp->table_stride();
+  std::vector<int> idx;
+  for (int i = 0; i < tp->table_stride(); ++i)
+    if (row[i] != 0) idx.push_back(i);
+  char *out = static_cast<char *>(host_buf);
+  const long long n = (long long)idx.size();
+  std::memcpy(out, &n, 8);
+  int *ent = reinterpret_cast<int *>(out + 8);
+  for (size_t k = 0; k < idx.size(); ++k) {
+    ent[2 * k] = idx[k];
+    ent[2 * k + 1] = tp->ancestor_of[row[idx[k]]];  // an untouched ancestor tile travels as its ordinal
+  }
+  char *p = out + export_header_bytes(n);
+  for (int i : idx) {
+    const size_t tile = (size_t)row[i];
+    if (tp->ancestor_of[tile] >= 0) continue;
+    SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_pool + tile * kTileCells * 4, kTilePayloadBytes, hipMemcpyDeviceToHost,
+                                 tp->ctx->stream));
+    p += kTilePayloadBytes;
+    SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_aux + tile * kTileCells * 2, kTileAuxBytes, hipMemcpyDeviceToHost,
+                                 tp->ctx->stream));
+    p += kTileAuxBytes;
+  }
+  SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  return SLAMHIP_OK;
+}
+
+int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs) {
+  const int stride = tp->table_stride();
+  std::vector<int> nt((size_t)tp->n_slots * stride, 0);
+  // tiles nobody will reference after this generation change can be reused for the imports: recount
+  // the surviving local references first
+  std::vector<int> rc(tp->refcnt.size(), 0);
+  for (int s = 0; s < tp->n_slots; ++s) {
+    if (src[s] >= tp->n_slots || src[s] < -n_remote) return tp_fail("bad source slot");
+    if (src[s] < 0) continue;
+    const int *from = tp->h_tables.data() + (size_t)src[s] * stride;
+    std::memcpy(nt.data() + (size_t)s * stride, from, sizeof(int) * stride);
+    for (int i = 0; i < stride; ++i) rc[from[i]] += 1;
+  }
+  for (int t = 1; t < tp->next_unused; ++t)
+    if (tp->refcnt[t] > 0 && rc[t] == 0 && tp->ancestor_of[t] < 0) tp->free_list.push_back(t);
+  rc[0] = 1 << 30;
+  tp->refcnt.swap(rc);
+  // import every remote map once
+  std::vector<std::vector<int>> imported(n_remote);  // table row of the imported map
+  hipStream_t st = tp->ctx->stream;
+  for (int r = 0; r < n_remote; ++r) {
+    bool used = false;
+    for (int s = 0; s < tp->n_slots; ++s) used |= (src[s] == -r - 1);
+    if (!used) continue;
+    const char *in = static_cast<const char *>(remote_bufs[r]);
+    if (!in) return tp_fail("missing exported map");
+    long long n = 0;
+    std::memcpy(&n, in, 8);
+    if (n < 0 || n > stride) return tp_fail("corrupt exported map");
+    const int *ent = reinterpret_cast<const int *>(in + 8);
+    const char *p = in + export_header_bytes(n);
+    imported[r].assign(stride, 0);
+    for (long long k = 0; k < n; ++k) {
+      const int ti = ent[2 * k], ord = ent[2 * k + 1];
+      if (ti < 0 || ti >= stride) return tp_fail("corrupt exported map (table index)");
+      if (ord >= 0) {  // the sender's untouched ancestor tile = this pool's ancestor tile of the same ordinal
+        if (ord >= (int)tp->ancestor.size()) return tp_fail("exported map names an ancestor tile this pool lacks");
+        imported[r][ti] = tp->ancestor[ord];
+        continue;
+      }
+      int fresh = 0;
+      int rcode = alloc_tile(tp, &fresh);
+      if (rcode) return rcode;
+      tp->refcnt[fresh] = 0;  // counted below, once per new slot that takes this map
+      SLAMHIP_CHECK(hipMemcpyAsync(tp->d_pool + (size_t)fresh * kTileCells * 4, p, kTilePayloadBytes,
+                                   hipMemcpyHostToDevice, st));
+      p += kTilePayloadBytes;
+      SLAMHIP_CHECK(hipMemcpyAsync(tp->d_aux + (size_t)fresh * kTileCells * 2, p, kTileAuxBytes, hipMemcpyHostToDevice, st));
+      p += kTileAuxBytes;
+      imported[r][ti] = fresh;
+    }
+  }
+  for (int s = 0; s < tp->n_slots; ++s) {
+    if (src[s] >= 0) continue;
+    const std::vector<int> &row = imported[-src[s] - 1];
+    std::memcpy(nt.data() + (size_t)s * stride, row.data(), sizeof(int) * stride);
+    for (int i = 0; i < stride; ++i)
+      if (row[i] != 0) tp->refcnt[row[i]] += 1;
+  }
+  tp->h_tables.swap(nt);
+  SLAMHIP_CHECK(hipMemcpyAsync(tp->d_tables[tp->cur ^ 1], tp->h_tables.data(), sizeof(int) * tp->h_tables.size(),
+                               hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipStreamSynchronize(st));  // the caller's host buffers may go away now
   tp->cur ^= 1;
   return SLAMHIP_OK;
 }

@@ -109,12 +109,71 @@ def test_particle_maps_resampling_shares_then_clones_tiles(pkg, oracle):
     assert log[-1][1]["tiles_in_use"] <= 16 + 24 * 8
 
 
-def test_particle_maps_need_the_whole_filter(pkg):
+def test_sharded_particle_maps_migrate_on_resampling(pkg):
+    """Two shards of the filter (two tile pools, as on two GPUs) against the unsharded filter: the raw
+    weights are concatenated (the all-gather), every shard plans the same resampling, maps of
+    particles drawn from the other shard travel as exported buffers.  Poses, weights and every
+    particle's map must equal the unsharded run bit for bit, through two resamplings."""
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    scale, unknown = float(g["scale"]), g["unknown"][:3]
+    ox, oy = [int(v) for v in g["origin"]]
+    n, half = 8, 4
+    gp = [0, 0.1, 0, 0.05, 0, 0, 0, 0]
+    seeds = np.arange(3000, 3000 + n, dtype=np.uint32)
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, w, h, g["origin"], scale, unknown)
+    c0, s0 = pkg.beam_trig(g["step0_angle"])
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["step0_delta"], g["step0_range"], c0, s0)
+    prm = pkg.gmapping_params(gp8=gp, skip_rate=3, pose_trig=1)
+    whole = pkg.GmappingFilter(ctx, prm, n, seeds)
+    whole.enable_particle_maps(4, 8, 16 + 24 * n)
+    shards = [pkg.GmappingFilter(ctx, prm, n, seeds[r * half:(r + 1) * half], first=r * half, count=half)
+              for r in range(2)]
+    for s in shards:
+        s.enable_particle_maps(4, 8, 16 + 24 * n)
+    n_base = int(g["n_steps"])
+    steps = list(range(n_base)) + [1 + (k % (n_base - 1)) for k in range(20)]
+    resamplings = migrations = 0
+    for it, k in enumerate(steps):
+        rng, ang, d = g["step%d_range" % k], g["step%d_angle" % k], g["step%d_delta" % k]
+        res, idx = whole.step(4, rng, ang, None, d, 7 + it)
+        raw = np.concatenate([s.predict_match(4, rng, ang, None, d) for s in shards])
+        plans = [s.plan_resample(raw, 7 + it) for s in shards]
+        assert plans[0][0] == plans[1][0] == res
+        if res:
+            resamplings += 1
+            np.testing.assert_array_equal(plans[0][1], idx)
+            np.testing.assert_array_equal(plans[1][1], idx)
+            blobs = np.concatenate([s.export() for s in shards])
+            # exports first (every rank), imports afterwards
+            needed = [{int(j) for j in idx[r * half:(r + 1) * half] if not (r * half <= j < (r + 1) * half)}
+                      for r in range(2)]
+            exported = {j: shards[j // half].export_particle_map(j % half) for j in set().union(*needed)}
+            migrations += len(exported)
+            for r, s in enumerate(shards):
+                s.import_maps(blobs, idx, {j: exported[j] for j in needed[r]})
+        poses, wts, ms = whole.state()
+        sp = [s.state() for s in shards]
+        np.testing.assert_array_equal(np.concatenate([x[0] for x in sp]), poses)
+        np.testing.assert_array_equal(np.concatenate([x[1] for x in sp]), wts)
+        np.testing.assert_array_equal(np.concatenate([x[2] for x in sp]), ms)
+        if res or it % 6 == 0 or it == len(steps) - 1:
+            for i in range(n):
+                a_p, a_a = whole.particle_map(i, -ox, -oy, w, h)
+                b_p, b_a = shards[i // half].particle_map(i % half, -ox, -oy, w, h)
+                np.testing.assert_array_equal(b_p, a_p, err_msg="step %d particle %d" % (it, i))
+                np.testing.assert_array_equal(b_a, a_a)
+    assert resamplings >= 2 and migrations >= 1
+
+
+def test_particle_maps_argument_checks(pkg):
     ctx = pkg.Context(0)
     ctx.map_bind(1, 2, 256, 256, (128, 128), 0.05, [0.5, 0, 0])
     pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), 8, np.arange(4, dtype=np.uint32), first=0, count=4)
-    with pytest.raises(pkg.SlamHipError):
-        pf.enable_particle_maps(1, 4, 64)
+    pf.enable_particle_maps(1, 4, 64)  # a shard holds the maps of its own particles
+    with pytest.raises(pkg.SlamHipError):  # ... and resamples through import_maps, not import_
+        pf.import_(np.zeros(8 * pf.blob_size(), np.uint8), np.arange(8, dtype=np.uint32))
     whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(), 4, np.arange(4, dtype=np.uint32))
     with pytest.raises(pkg.SlamHipError):  # window larger than the tile extent
         whole.enable_particle_maps(1, 1, 64)
