@@ -339,8 +339,10 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     g_ms, g_launches, g_units = ctx.profile_read(reset=True)
     bpu = BYTES_PER_UNIT["gmapping"]
     g_achieved = g_units * bpu / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+    pf_traffic, pf_traffic_src = load_traffic("pf")
     pf_roofline = {"bound": "hbm", "achieved": g_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": g_achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_score_gmapping",
+                   "frac": g_achieved / HBM_PEAK_GBS, "traffic": pf_traffic, "traffic_source": pf_traffic_src,
+                   "kernel": "k_score_gmapping",
                    "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,
                    "avg_launch_us": 1e3 * g_ms / max(g_launches, 1),
                    "timing": "HIP events attached to each dispatch, 3 extra steps after the timed pass"}

@@ -35,25 +35,38 @@ for name in ("hc", "sweep", "mc"):
         shutil.copy(bj, os.path.join(dst, "%s_%s_bench.json" % (tag, name)))
         r = d["roofline"]
         prof = [float(x["AverageNs"]) for x in rows if KERNEL in x["Name"]]
-        lines.append("\nbench line of the same (profiled) run: value %.4g %s, %.4f ms/step; HIP-event kernel "
-                     "time %.2f us/launch over %d launches (rocprofv3 average for %s in this run: %s us) "
-                     "-> %.0f GB/s algorithmic = %.3f of 8 TB/s.\n"
-                     % (d["value"], d["unit"], d["ms_per_step"], r["avg_launch_us"], r["launches"], KERNEL,
-                        ", ".join("%.2f" % (p / 1e3) for p in prof), r["achieved"], r["frac"]))
+        lines.append("\nrocprofv3 average for %s in the profiled run: %s us.  The profiled run's own bench line "
+                     "(`%s_%s_bench.json`) is perturbed by the profiler (value %.4g %s, %.4f ms/step, attached HIP "
+                     "events read %.2f us/launch)."
+                     % (KERNEL, ", ".join("%.2f" % (p / 1e3) for p in prof), tag, name, d["value"], d["unit"],
+                        d["ms_per_step"], r["avg_launch_us"]))
+        pj = os.path.join(src, "%s.plain.json" % name)
+        if os.path.exists(pj) and os.path.getsize(pj) > 2:
+            pd_ = json.load(open(pj))
+            shutil.copy(pj, os.path.join(dst, "%s_%s_bench_unprofiled.json" % (tag, name)))
+            pr = pd_["roofline"]
+            lines.append("Same command without the profiler (`%s_%s_bench_unprofiled.json`): value %.4g %s, %.4f "
+                         "ms/step; HIP events attached to the dispatches: **%.2f us/launch** over %d launches -> "
+                         "%.0f GB/s algorithmic = %.3f of 8 TB/s.\n"
+                         % (tag, name, pd_["value"], pd_["unit"], pd_["ms_per_step"], pr["avg_launch_us"],
+                            pr["launches"], pr["achieved"], pr["frac"]))
     except Exception as e:  # noqa: BLE001
         lines.append("\n(bench line not captured: %s)\n" % e)
 
 traffic = {}
-for wl in ("hc", "sweep"):
+PMC_KERNEL = {"hc": "k_score_point", "sweep": "k_score_point", "pf": "k_score_gmapping"}
+for wl in ("hc", "sweep", "pf"):
     for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
         f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
         if not os.path.exists(f):
             continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if KERNEL in r["Kernel_Name"]:
+            if PMC_KERNEL[wl] in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        lines.append("## PMC pass %s, workload %s (%s dispatches)\n" % (c, wl, KERNEL))
+        if not acc:
+            continue
+        lines.append("## PMC pass %s, workload %s (%s dispatches)\n" % (c, wl, PMC_KERNEL[wl]))
         for k, v in acc.items():
             lines.append("* %s: mean %.6g over %d dispatches" % (k, sum(v) / len(v), len(v)))
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -70,10 +83,11 @@ for wl, t in traffic.items():
         # requests at 64 B -> x2; WRITE_SIZE taken as reported (uncalibrated, and tiny here)
         t["bytes_per_launch"] = 1024.0 * (2.0 * t["FETCH_SIZE_kb_raw"] + t["WRITE_SIZE_kb_raw"])
         t["correction"] = "FETCH_SIZE KB x2 (gfx950), WRITE_SIZE KB as reported; separate --pmc passes"
-        lines.append("* %s: HBM traffic per %s launch = %.0f bytes (%s)" % (wl, KERNEL, t["bytes_per_launch"],
+        t["kernel"] = PMC_KERNEL[wl]
+        lines.append("* %s: HBM traffic per %s launch = %.0f bytes (%s)" % (wl, PMC_KERNEL[wl], t["bytes_per_launch"],
                                                                           t["correction"]))
 if traffic:
-    json.dump({"tag": tag, "kernel": KERNEL, "workloads": traffic},
+    json.dump({"tag": tag, "kernels": PMC_KERNEL, "workloads": traffic},
               open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
