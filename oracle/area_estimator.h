@@ -142,10 +142,17 @@ AE_FN ae_occ ae_area_rate(double chunk, double total, int is_occ, const double *
 /* AreaOccupancyEstimator::estimate_occupancy.  shift_amount = the function-local static of
  * ensure_segment_not_on_edge (low_qual 0.01 x side of the FIRST cell ever estimated, Q27);
  * unknown_qual = 0.5.  Invalid occupancy = (NaN, NaN). */
+AE_FN ae_occ ae_estimate_ex(ae_pt beg, ae_pt end, ae_rect cell, int is_occ, const double *base4,
+                            double shift_amount, double unknown_qual);
 AE_FN ae_occ ae_estimate(ae_pt beg, ae_pt end, ae_rect cell, int is_occ, const double *base4,
                          double shift_amount) {
+  return ae_estimate_ex(beg, end, cell, is_occ, base4, shift_amount, 0.5);
+}
+/* unknown_qual: the 4th constructor argument (area_occupancy_estimator.h:19-21, default 0.5; the
+ * reference's own tests use 0.7) */
+AE_FN ae_occ ae_estimate_ex(ae_pt beg, ae_pt end, ae_rect cell, int is_occ, const double *base4,
+                            double shift_amount, double unknown_qual) {
   const ae_occ invalid = {NAN, NAN};
-  const double unknown_qual = 0.5;
   ae_seg s = ae_make_seg(beg, end);
   if (ae_on_edge_line(cell, s)) {
     ae_pt sh = {0, 0};

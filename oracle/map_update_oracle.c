@@ -18,6 +18,19 @@
 #include "slam_oracle.h"
 #include "area_estimator.h"
 
+/* AreaOccupancyEstimator::estimate_occupancy on its own (area_occupancy_estimator.h:27-64), for the
+ * known answers of test/core/maps/area_occupancy_estimator_test.cpp: beam (x0, y0, x1, y1), cell
+ * (bot, top, left, right), base4 = occupied (prob, qual), empty (prob, qual); out = (prob, qual) */
+void orc_area_estimate(const double *beam4, const double *cell4, int is_occ, const double *base4,
+                       double low_qual, double unknown_qual, double *out2) {
+  ae_pt b = {beam4[0], beam4[1]}, e = {beam4[2], beam4[3]};
+  ae_rect c = {cell4[0], cell4[1], cell4[2], cell4[3]};
+  /* Shift_Amount = low_qual * cell.side() of the first cell seen (Q27): every test fixture has one cell */
+  ae_occ o = ae_estimate_ex(b, e, c, is_occ, base4, low_qual * (c.top - c.bot), unknown_qual);
+  out2[0] = o.prob;
+  out2[1] = o.qual;
+}
+
 static void tbm_conj(const double *lhs, const double *rhs, double *out) {
   double tmp[4] = {0.0, 0.0, 0.0, 0.0};
   for (int a = 0; a < 4; ++a)

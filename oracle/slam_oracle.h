@@ -201,6 +201,12 @@ long long orc_append_scan_ex(const orc_map *map, double *payload, double *aux, i
                              int n, const double *range, const double *angle, const int *is_occ,
                              const orc_scan *trig, double scan_quality, const double *base4, double blur,
                              double max_range, int est_kind, double shift_amount);
+/* pieces exposed for the known answers of the reference's own unit tests
+ * (tests/golden/make_golden_ref_tests.py -> reference_test_vectors.json) */
+int orc_discrete_segment(int bx, int by, int ex, int ey, int cap, int *out_xy);
+double orc_ah_angle(double base_x, double base_y, double sp_x, double sp_y);
+void orc_area_estimate(const double *beam4, const double *cell4, int is_occ, const double *base4,
+                       double low_qual, double unknown_qual, double *out2);
 int orc_world_to_cells(double scale, double x0, double y0, double x1, double y1, int cap,
                        int *out_xy);
 
