@@ -354,6 +354,146 @@ __global__ void k_mu_gather(const unsigned *order, unsigned total, const double 
 }
 
 // `a.rec_*` point at the SORTED record arrays here (k_mu_gather)
+// one observation applied to one cell: the reference's `cell += aoo` for the five cell kinds
+__device__ __forceinline__ void mu_apply_one(const MuArgs &a, double &c0, double &c1, double &c2, double &c3,
+                                             double &x0, double &x1, double prob, double est_qual, double obx,
+                                             double oby) {
+  const bool invalid = isnan(prob) || isnan(est_qual);
+  if (invalid && a.rule != 0) return;
+  switch (a.rule) {
+    case 0:  // GridCell / MockGridCell: last write wins
+      c0 = prob;
+      break;
+    case 1:  // AffineQualityMergeCell
+      c0 = (1.0 - a.quality) * c0 + a.quality * prob;
+      break;
+    case 2: {  // MeanProbabilityCell
+      x0 += 1;
+      const double that_p = 0.5 + (prob - 0.5) * a.quality;
+      c0 = (c0 * (x0 - 1) + that_p) / x0;
+      break;
+    }
+    case 3: {  // TbmBaseCell
+      const double eq = est_qual * a.quality;
+      const double occupied = prob * eq, empty = (1 - prob) * eq;
+      const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
+      const double cur[4] = {c0, c1, c2, c3};
+      double nb[4];
+      mu_tbm_conj(cur, that, nb);
+      const double weight = nb[0] + nb[1] + nb[2];
+      if (weight == 0.0) {
+        c0 = 1.0;
+        c1 = c2 = c3 = 0.0;
+      } else {
+        c0 = nb[0] / weight;
+        c1 = nb[1] / weight;
+        c2 = nb[2] / weight;
+        c3 = 0.0;
+      }
+      break;
+    }
+    default: {  // GmappingBaseCell: x0 = hits, x1 = tries
+      int hits = (int)x0, tries = (int)x1;
+      ++tries;
+      const bool is_free = prob <= 0.5;
+      const double aoo_p = is_free ? 0.0 : prob;
+      c0 = (c0 * (tries - 1) + aoo_p) / tries;
+      if (!is_free) {
+        ++hits;
+        c1 = (c1 * (hits - 1) + obx) / hits;
+        c2 = (c2 * (hits - 1) + oby) / hits;
+      }
+      x0 = hits;
+      x1 = tries;
+      break;
+    }
+  }
+}
+
+// where a sorted key's cell lives: dense window, or (job, virtual cell) -> the job's slot -> tile
+template <typename Key>
+__device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
+  if (!a.tables) return (size_t)key;
+  const unsigned long long cellkey = (unsigned long long)key & ((1ull << a.cell_bits) - 1ull);
+  const int job = (int)((unsigned long long)key >> a.cell_bits);
+  const int ix = (int)(cellkey % (unsigned)a.width), iy = (int)(cellkey / (unsigned)a.width);
+  const int tile = a.tables[(size_t)a.jobs[job].slot * a.table_stride + (iy >> kTileShift) * a.tiles_x + (ix >> kTileShift)];
+  return ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+}
+
+static constexpr unsigned kLongChain = 64;  // chains at least this long go to k_mu_apply_long
+
+__device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Long chains (the robot's own cell takes one update per beam, its neighbours hundreds): one thread
+// walking such a chain pays a memory round trip per 8 records (330 us for 1080 updates).  Here the
+// WAVE that holds the chain's head streams it: 64 records per coalesced load, then every lane applies
+// them in order from broadcast values -- the same sequential arithmetic, executed redundantly by all
+// lanes, so the result is bit-identical to the one-thread walk.
+template <typename Key>
+__global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys, unsigned total,
+                                                       unsigned long long *n_updates) {
+  constexpr Key kInvalid = ~Key(0);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  Key key = kInvalid;
+  bool is_long = false;
+  if (i < total) {
+    key = keys[i];
+    const bool head = key != kInvalid && !(i > 0 && keys[i - 1] == key);
+    is_long = head && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key;
+  }
+  unsigned long long todo = __ballot(is_long);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)i, src);
+    const Key hkey = keys[hi];
+    const size_t at = mu_cell_index<Key>(a, hkey);
+    double *cell = a.payload + at * a.cell_dbl;
+    double *aux = a.aux ? a.aux + at * a.aux_stride : nullptr;
+    double c0 = cell[0], c1 = 0, c2 = 0, c3 = 0;
+    if (a.cell_dbl == 4) {
+      c1 = cell[1];
+      c2 = cell[2];
+      c3 = cell[3];
+    }
+    double x0 = aux ? aux[0] : 0, x1 = (aux && a.aux_stride > 1) ? aux[1] : 0;
+    unsigned cnt = 0;
+    for (unsigned j0 = hi;; j0 += 64) {
+      const unsigned j = j0 + lane;
+      const bool in = j < total;
+      const Key k = in ? keys[j] : kInvalid;
+      const double p = in ? a.rec_prob[j] : 0.0, q = in ? a.rec_qual[j] : 0.0;
+      const double ox = in ? a.rec_ox[j] : 0.0, oy = in ? a.rec_oy[j] : 0.0;
+      const unsigned long long m = __ballot(in && k == hkey);
+      const int n_here = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
+      for (int t = 0; t < n_here; ++t)
+        mu_apply_one(a, c0, c1, c2, c3, x0, x1, mu_readlane(p, t), mu_readlane(q, t), mu_readlane(ox, t),
+                     mu_readlane(oy, t));
+      cnt += (unsigned)n_here;
+      if (n_here < 64) break;
+    }
+    if (lane == src) {
+      cell[0] = c0;
+      if (a.cell_dbl == 4) {
+        cell[1] = c1;
+        cell[2] = c2;
+        cell[3] = c3;
+      }
+      if (aux) {
+        aux[0] = x0;
+        if (a.aux_stride > 1) aux[1] = x1;
+      }
+      atomicAdd(&n_updates[blockIdx.x & (kNuSlots - 1)], (unsigned long long)cnt);
+    }
+  }
+}
+
 template <typename Key>
 __global__ void k_mu_apply(MuArgs a, const Key *keys, const unsigned *order, unsigned total,
                            unsigned long long *n_updates) {
@@ -363,14 +503,8 @@ __global__ void k_mu_apply(MuArgs a, const Key *keys, const unsigned *order, uns
   const Key key = keys[i];
   if (key == kInvalid) return;
   if (i > 0 && keys[i - 1] == key) return;  // not the head of this cell's run
-  size_t at = (size_t)key;
-  if (a.tables) {  // (job, virtual cell) -> the job's slot -> tile -> cell of the pool
-    const unsigned long long cellkey = (unsigned long long)key & ((1ull << a.cell_bits) - 1ull);
-    const int job = (int)((unsigned long long)key >> a.cell_bits);
-    const int ix = (int)(cellkey % (unsigned)a.width), iy = (int)(cellkey / (unsigned)a.width);
-    const int tile = a.tables[(size_t)a.jobs[job].slot * a.table_stride + (iy >> kTileShift) * a.tiles_x + (ix >> kTileShift)];
-    at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
-  }
+  if (i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) return;  // k_mu_apply_long's
+  const size_t at = mu_cell_index<Key>(a, key);
   double *cell = a.payload + at * a.cell_dbl;
   double *aux = a.aux ? a.aux + at * a.aux_stride : nullptr;
   double c0 = cell[0], c1 = 0, c2 = 0, c3 = 0;
@@ -407,56 +541,7 @@ __global__ void k_mu_apply(MuArgs a, const Key *keys, const unsigned *order, uns
     }
     ++cnt;
     const double prob = pp[t], est_qual = qq[t], obx = oxs[t], oby = oys[t];
-    const bool invalid = isnan(prob) || isnan(est_qual);
-    if (invalid && a.rule != 0) continue;
-    switch (a.rule) {
-      case 0:  // GridCell / MockGridCell: last write wins
-        c0 = prob;
-        break;
-      case 1:  // AffineQualityMergeCell
-        c0 = (1.0 - a.quality) * c0 + a.quality * prob;
-        break;
-      case 2: {  // MeanProbabilityCell
-        x0 += 1;
-        const double that_p = 0.5 + (prob - 0.5) * a.quality;
-        c0 = (c0 * (x0 - 1) + that_p) / x0;
-        break;
-      }
-      case 3: {  // TbmBaseCell
-        const double eq = est_qual * a.quality;
-        const double occupied = prob * eq, empty = (1 - prob) * eq;
-        const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
-        const double cur[4] = {c0, c1, c2, c3};
-        double nb[4];
-        mu_tbm_conj(cur, that, nb);
-        const double weight = nb[0] + nb[1] + nb[2];
-        if (weight == 0.0) {
-          c0 = 1.0;
-          c1 = c2 = c3 = 0.0;
-        } else {
-          c0 = nb[0] / weight;
-          c1 = nb[1] / weight;
-          c2 = nb[2] / weight;
-          c3 = 0.0;
-        }
-        break;
-      }
-      default: {  // GmappingBaseCell: x0 = hits, x1 = tries
-        int hits = (int)x0, tries = (int)x1;
-        ++tries;
-        const bool is_free = prob <= 0.5;
-        const double aoo_p = is_free ? 0.0 : prob;
-        c0 = (c0 * (tries - 1) + aoo_p) / tries;
-        if (!is_free) {
-          ++hits;
-          c1 = (c1 * (hits - 1) + obx) / hits;
-          c2 = (c2 * (hits - 1) + oby) / hits;
-        }
-        x0 = hits;
-        x1 = tries;
-        break;
-      }
-    }
+    mu_apply_one(a, c0, c1, c2, c3, x0, x1, prob, est_qual, obx, oby);
     }  // records of this chunk
   }    // chunks
   cell[0] = c0;
@@ -695,6 +780,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.rec_qual = sc.srt_qual;
   a.rec_ox = sc.srt_ox;
   a.rec_oy = sc.srt_oy;
+  hipLaunchKernelGGL(k_mu_apply_long<unsigned>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                     (const unsigned *)sc.keys_sorted, total, sc.n_updates);
   hipLaunchKernelGGL(k_mu_apply<unsigned>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
                      (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.n_updates);
   SLAMHIP_CHECK(hipGetLastError());
@@ -962,6 +1049,8 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   a.rec_qual = sc.srt_qual;
   a.rec_ox = sc.srt_ox;
   a.rec_oy = sc.srt_oy;
+  hipLaunchKernelGGL(k_mu_apply_long<unsigned long long>, dim3((total + 255) / 256), dim3(256), 0, st, a,
+                     (const unsigned long long *)sc.keys_sorted, total, sc.n_updates);
   hipLaunchKernelGGL(k_mu_apply<unsigned long long>, dim3((total + 255) / 256), dim3(256), 0, st, a,
                      (const unsigned long long *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total,
                      sc.n_updates);

@@ -203,6 +203,38 @@ int main() {
         printf("per-batch work %d us  n %5d           : median %7.2f us  p90 %7.2f  min %7.2f\n", work_us, n,
                lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[0]);
       }
+      // launch-per-batch, completion published by a stream memory operation instead of a kernel
+      {
+        std::vector<double> lat;
+        bool ok = true;
+        for (int r = 1; r <= rounds && ok; ++r) {
+          const double t0 = now_us();
+          for (int i = 0; i < 3 * n; ++i) hm->poses[i] = r + i;
+          hipLaunchKernelGGL(k_batch, dim3(n), dim3(256), 0, st, hm->poses, hm->scores, work_us * 100);
+          hipError_t e = hipStreamWriteValue32(st, (void *)&hm->done_seq, (uint32_t)(r + 200000), 0);
+          if (e != hipSuccess) {
+            printf("hipStreamWriteValue32: %s\n", hipGetErrorString(e));
+            ok = false;
+            break;
+          }
+          while (*done != (unsigned)(r + 200000)) {
+            if (now_us() - t0 > 1e6) {
+              printf("write-value TIMEOUT\n");
+              ok = false;
+              break;
+            }
+          }
+          lat.push_back(now_us() - t0);
+          if (ok && hm->scores[n - 1] != 3.0 * r + 9.0 * (n - 1) + 3.0) {
+            printf("write-value STALE score round %d\n", r);
+            ok = false;
+          }
+        }
+        std::sort(lat.begin(), lat.end());
+        if (ok)
+          printf("write-val work %d us  n %5d           : median %7.2f us  p90 %7.2f  min %7.2f\n", work_us, n,
+                 lat[lat.size() / 2], lat[lat.size() * 9 / 10], lat[0]);
+      }
     }
   }
   return 0;
