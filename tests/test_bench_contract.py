@@ -1,0 +1,54 @@
+"""bench.py's output contract, checked on the lines committed under profiles/ (produced on the GPU box
+by tools/profile.sh): one JSON object with the driver's keys, BASELINE.json's metric, the `roofline`
+and `cpu_baseline` objects, null vs_baseline, no model keys."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hc_bench_unprofiled.json")))
+
+
+@pytest.mark.skipif(not LINES, reason="no committed bench line yet")
+def test_headline_bench_line_contract():
+    d = json.load(open(LINES[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "pose-candidates" in d["metric"] and "pose-candidates" in base["metric"]
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"] and "2000x2000" in d["config"]["workload"]
+    assert abs(d["value"] - d["config"]["scorer_calls_per_step"] * d["config"]["beams_after_filter"]
+               / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # achieved = algorithmic bytes of the launched units / the kernel time measured with HIP events
+    assert abs(r["achieved"] - r["units_launched"] * r["bytes_per_unit"] / (r["avg_launch_us"] * 1e-6 * r["launches"]) / 1e9) \
+        <= 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == d["unit"]
+    pf = d["particle_filter"]
+    assert pf["unit"] == "particles/s" and pf["scaling"] == "strong" and pf["roofline"]["kernel"] == "k_score_gmapping"
+
+
+@pytest.mark.skipif(not LINES, reason="no committed bench line yet")
+def test_rocprof_summary_agrees_with_the_live_kernel_time():
+    """The committed rocprofv3 --kernel-trace --stats average of k_score_point and the HIP-event average of
+    the un-profiled run of the same command must agree (within 15 %)."""
+    import csv
+    tag = os.path.basename(LINES[-1]).split("_")[0]
+    d = json.load(open(LINES[-1]))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_hc_kernel_stats.csv" % tag))))
+    prof = [float(r["AverageNs"]) / 1e3 for r in rows if "k_score_point" in r["Name"]]
+    assert prof
+    live = d["roofline"]["avg_launch_us"]
+    assert abs(live - prof[0]) <= 0.15 * prof[0], (live, prof)
