@@ -213,8 +213,30 @@ static void gm_carry_fixup(slamhip_ctx *ctx, int n_poses) {
   }
 }
 
+int score_wait(slamhip_ctx *ctx, unsigned seq) {
+  if (seq == 0) return SLAMHIP_OK;  // the launch was synchronous
+  volatile unsigned *flag = ctx->h_done_flag;
+  unsigned long long spins = 0;
+  // launches publish increasing numbers on one stream: "reached seq" = the signed distance is >= 0
+  while ((int)(*flag - seq) < 0) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffffull) == 0) {
+      // ~every few ms: make sure the launch did not fail asynchronously
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "scoring kernel");
+      if (q == hipSuccess && (int)(*flag - seq) < 0) {
+        set_error("scoring kernel finished without publishing its completion flag");
+        return SLAMHIP_ERR_HIP;
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return SLAMHIP_OK;
+}
+
 int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
-                 const TiledTarget *tiled) {
+                 const TiledTarget *tiled, int off, unsigned *async_seq) {
+  if (async_seq) *async_seq = 0;
   DeviceMap tiled_view;
   DeviceMap *m = nullptr;
   if (tiled) {
@@ -240,8 +262,11 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
   if (rc) return rc;
   if (n_poses <= 0) return SLAMHIP_OK;
   const bool host_trig = cfg->pose_trig == SLAMHIP_POSE_TRIG_HOST;
+  if (off < 0 || off + n_poses > ctx->pose_cap) return invalid("staging window outside the pose capacity");
+  if (off != 0 && (!ctx->low_latency || ctx->stage_poses))
+    return invalid("staging windows need the zero-copy path");
   if (host_trig) {
-    for (int p = 0; p < n_poses; ++p) {
+    for (int p = off; p < off + n_poses; ++p) {
       // one sincos call per pose: the reference build (g++ -O3) fuses the sin/cos pair of
       // set_base_angle (trigonometry_utils.h:57-60) into glibc's sincos, whose last bit can
       // differ from separate sin()/cos() calls
@@ -253,7 +278,10 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
   if (ctx->low_latency) {
     // zero-copy: the kernel reads poses from / writes scores to the pinned staging buffers; a
     // 1-thread kernel behind it publishes the launch number in pinned memory; the host spins.
-    const double *poses_src = ctx->h_poses, *sc_src = host_trig ? ctx->h_pose_sc : nullptr;
+    // `off` selects a window of the staging buffers, so two launches can be in flight (the filter
+    // plans one half of its particles while the GPU scores the other).
+    const double *poses_src = ctx->h_poses + 3 * (size_t)off;
+    const double *sc_src = host_trig ? ctx->h_pose_sc + 2 * (size_t)off : nullptr;
     if (ctx->stage_poses) {
       SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_poses, ctx->h_poses, sizeof(double) * 3 * n_poses,
                                    hipMemcpyHostToDevice, ctx->stream));
@@ -264,12 +292,12 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
         sc_src = ctx->d_pose_sc;
       }
     }
-    rc = fill_args(ctx, *m, cfg, n_poses, poses_src, sc_src, ctx->h_scores, &a);
+    rc = fill_args(ctx, *m, cfg, n_poses, poses_src, sc_src, ctx->h_scores + off, &a);
     if (rc) return rc;
-    if (gm) a.gm_info = ctx->h_gm_info;
+    if (gm) a.gm_info = ctx->h_gm_info + off;
     if (tiled) {
       a.tables = tiled->tables;
-      a.pose_slot = ctx->h_pose_slot;
+      a.pose_slot = ctx->h_pose_slot + off;
       a.table_stride = tiled->table_stride;
     }
     unsigned seq = ++ctx->seq;
@@ -277,22 +305,11 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
     rc = launch_timed(ctx, a, *m, cfg);
     if (rc) return rc;
     SLAMHIP_CHECK(launch_publish(ctx->h_done_flag, seq, ctx->stream));
-    volatile unsigned *flag = ctx->h_done_flag;
-    unsigned long long spins = 0;
-    while (*flag != seq) {
-      __builtin_ia32_pause();
-      if ((++spins & 0xfffffull) == 0) {
-        // ~every few ms: make sure the launch did not fail asynchronously
-        hipError_t q = hipStreamQuery(ctx->stream);
-        if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "scoring kernel");
-        if (q == hipSuccess && *flag != seq) {
-          set_error("scoring kernel finished without publishing its completion flag");
-          return SLAMHIP_ERR_HIP;
-        }
-      }
+    if (async_seq) {
+      *async_seq = seq;
+      return SLAMHIP_OK;
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return SLAMHIP_OK;
+    return score_wait(ctx, seq);
   }
   if (host_trig)
     SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_pose_sc, ctx->h_pose_sc, sizeof(double) * 2 * n_poses,

@@ -169,6 +169,10 @@ struct TiledTarget {
 };
 int ensure_pose_capacity(slamhip_ctx *ctx, int n);
 // scores n poses whose (x,y,theta) sit in ctx->h_poses; results land in ctx->h_scores (synchronous)
+// `off`: window of the staging buffers (poses at h_poses + 3 off, results at h_scores + off, ...);
+// `async_seq` != null: return right after the launch with the number score_wait() takes (0 = the
+// call was synchronous after all, nothing to wait for)
 int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
-                 const TiledTarget *tiled = nullptr);
+                 const TiledTarget *tiled = nullptr, int off = 0, unsigned *async_seq = nullptr);
+int score_wait(slamhip_ctx *ctx, unsigned seq);
 }  // namespace slamhip
