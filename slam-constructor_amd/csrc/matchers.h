@@ -523,7 +523,9 @@ private:
         tot += w[j];
       }
       for (int j = 0; j <= 6; ++j) {
-        heap_.push_back(Cand{cd.prio * w[j] / tot, me, j});
+        const double prio = cd.prio * w[j] / tot;
+        if (prio < min_reach) continue;  // would never be popped (the loop stops below min_reach)
+        heap_.push_back(Cand{prio, me, j});
         std::push_heap(heap_.begin(), heap_.end());
       }
     }
