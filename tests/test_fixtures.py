@@ -126,6 +126,30 @@ _NUM = re.compile(r"x: (\S+), y: (\S+), th: (\S+)} with probability (\S+)")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
+def test_reference_sm_runner_with_the_hip_factory(gold, case, tmp_path):
+    """oracle/_ref/sm_runner_hip = the reference's own sm_runner (its properties parser, map loader,
+    scan reader, printers) with init_hip_scan_matcher in place of init_scan_matcher, next to the
+    unmodified oracle/_ref/sm_runner on the same four files."""
+    import subprocess
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "sm_runner")
+    hip_bin = os.path.join(ROOT, "oracle", "_ref", "sm_runner_hip")
+    if not (os.path.exists(ref_bin) and os.path.exists(hip_bin)):
+        pytest.skip("prebuilt oracle/_ref runners did not travel")
+    unpack(gold, case, tmp_path)
+    args = ["cfg.properties", "p.pose2D", "m.map", "s.scan2D"]
+    ref = subprocess.run([ref_bin] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    hip = subprocess.run([hip_bin] + args, cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert ref.returncode == 0 and hip.returncode == 0, hip.stdout + hip.stderr
+    assert ref.stdout == gold[case + "/stdout"].tobytes().decode()  # the committed golden is this very output
+    rl, hl = ref.stdout.splitlines(), hip.stdout.splitlines()
+    assert hl[:-1] == rl[:-1]  # every console line of the factories, in order
+    a = np.array([float(v) for v in _NUM.search(hl[-1]).groups()])
+    b = np.array([float(v) for v in _NUM.search(rl[-1]).groups()])
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("strict", [False, True])
 def test_sm_runner_hip_matches_the_reference_tool(gold, case, strict, tmp_path):
     paths = unpack(gold, case, tmp_path)
