@@ -131,7 +131,11 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
     const int n = job.plan(budget, ctx->h_poses);
     if (n == 0) break;
     const double t0 = MatchJob::now_us();
-    rc = score_staged(ctx, map_id, &m->cfg, n);
+    unsigned seq = 0;
+    rc = score_staged(ctx, map_id, &m->cfg, n, nullptr, 0, &seq);
+    if (rc) return rc;
+    m->pe->idle_work();  // outcome-independent host work while the batch is on the GPU (MC: polar pairs)
+    rc = score_wait(ctx, seq);
     if (rc) return rc;
     m->t_score_us += MatchJob::now_us() - t0;
     rc = job.consume(ctx->h_scores, ctx->h_gm_info, ctx);

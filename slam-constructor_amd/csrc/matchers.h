@@ -59,37 +59,14 @@ public:
   virtual bool cheap_step() const { return true; }
   // become a copy of `other` (same dynamic type)
   virtual void assign(const PoseEnumerator &other) = 0;
+  // called while a batch is on the GPU: work that does not depend on its outcome
+  virtual void idle_work() {}
 };
 
 template <typename T>
 static void put(std::string &out, const T &v) {
   out.append(reinterpret_cast<const char *>(&v), sizeof(T));
 }
-
-// The engine's raw output stream does not depend on accept/reject decisions, so speculative
-// copies of the Monte-Carlo enumerator share one growing tape of mt19937 words and only carry a
-// read position (a 2.5 KB engine copy per tree node would dominate the host time).
-struct EngineTape {
-  explicit EngineTape(unsigned seed) : engine(seed) {}
-  std::mt19937 engine;
-  std::vector<std::mt19937::result_type> words;
-  size_t base = 0;  // absolute index of words[0]
-  std::mt19937::result_type at(size_t i) {
-    while (i - base >= words.size()) words.push_back(engine());
-    return words[i - base];
-  }
-  void trim(size_t consumed) {
-    if (consumed - base < (1u << 16)) return;
-    words.erase(words.begin(), words.begin() + (consumed - base));
-    base = consumed;
-  }
-};
-
-struct TapeEngine {
-  std::mt19937::result_type operator()() { return tape->at(pos++); }
-  std::shared_ptr<EngineTape> tape;
-  size_t pos = 0;
-};
 
 // std::generate_canonical<double, 53> over a 32-bit engine: two words, low word first
 // (libstdc++ bits/random.tcc)
@@ -135,6 +112,67 @@ struct NormalRV {
   }
 };
 
+// The Monte-Carlo enumerator's three distributions share one engine, and every engine word they
+// consume is consumed inside one Marsaglia polar pair.  The k-th pair drawn -- by whichever
+// distribution, whatever the accept/reject history, whether or not a reset_shift dropped a saved value
+// in between -- is therefore a pure function of the seed.  The pairs (a log and a sqrt each) live on a
+// shared tape: computed once, read by every speculative copy of the enumerator through an index (a
+// 2.5 KB engine copy per tree node would dominate the host time), and filled AHEAD by the matcher
+// while it waits for the GPU.
+struct PairTape {
+  explicit PairTape(unsigned seed) : engine(seed) {}
+  struct Pair {
+    double ret, saved;  // unit normals in the order the distribution hands them out: y*mult, then x*mult
+  };
+  std::mt19937 engine;
+  std::vector<Pair> pairs;
+  size_t base = 0;  // absolute index of pairs[0]
+  void generate() {
+    double x, y, r2;
+    do {
+      x = 2.0 * canonical(engine) - 1.0;
+      y = 2.0 * canonical(engine) - 1.0;
+      r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    const double mult = std::sqrt(-2 * std::log(r2) / r2);
+    pairs.push_back(Pair{y * mult, x * mult});
+  }
+  const Pair &at(size_t i) {
+    while (i - base >= pairs.size()) generate();
+    return pairs[i - base];
+  }
+  // make sure pairs up to absolute index `upto` exist, at most `max_new` new ones per call
+  void prefetch(size_t upto, int max_new) {
+    while (max_new-- > 0 && base + pairs.size() < upto) generate();
+  }
+  void trim(size_t consumed) {
+    if (consumed - base < (1u << 15)) return;
+    pairs.erase(pairs.begin(), pairs.begin() + (consumed - base));
+    base = consumed;
+  }
+};
+
+// NormalRV over the pair tape: same hand-out order and the same `ret * stddev + mean`
+struct TapeNormal {
+  double mean = 0, stddev = 1, saved = 0;
+  bool has_saved = false;
+  TapeNormal() = default;
+  TapeNormal(double m, double s) : mean(m), stddev(s) {}
+  double draw(PairTape &tape, size_t &pos) {
+    double ret;
+    if (has_saved) {
+      has_saved = false;
+      ret = saved;
+    } else {
+      const PairTape::Pair &p = tape.at(pos++);
+      saved = p.saved;
+      has_saved = true;
+      ret = p.ret;
+    }
+    return ret * stddev + mean;
+  }
+};
+
 // Monte-Carlo: candidate = best + N(0, sigma) per axis from three distributions sharing one
 // engine; sigma halves on an acceptance that follows more than max_failed/3 failures (the
 // `factor` argument of the reference's reset_shift is ignored there, so it always halves).
@@ -142,16 +180,22 @@ class GaussianPoseEnumerator : public PoseEnumerator {
 public:
   GaussianPoseEnumerator(unsigned seed, double td, double rd, unsigned max_failed, unsigned max_poses)
       : max_failed_(max_failed), max_poses_(max_poses), base_td_(td), base_rd_(rd) {
-    engine_.tape = std::make_shared<EngineTape>(seed);
+    tape_ = std::make_shared<PairTape>(seed);
     reset();
   }
   bool has_next() const override { return failed_ < max_failed_ && poses_ < max_poses_; }
   Pose next(const Pose &prev) override {
     // draw order x, y, theta -- braced-init-list evaluation order in RobotPoseDeltaRV::sample
-    const double dx = rv_x_(engine_);
-    const double dy = rv_y_(engine_);
-    const double dth = rv_t_(engine_);
+    const double dx = rv_x_.draw(*tape_, pos_);
+    const double dy = rv_y_.draw(*tape_, pos_);
+    const double dth = rv_t_.draw(*tape_, pos_);
     return Pose{prev.x + dx, prev.y + dy, prev.theta + dth};
+  }
+  // host idle time (the GPU is scoring): polar pairs for the candidates still to come -- two poses
+  // take three pairs
+  void idle_work() override {
+    const size_t left = max_poses_ > poses_ ? max_poses_ - poses_ : 0;
+    tape_->prefetch(pos_ + (3 * left) / 2 + 8, 384);
   }
   void reset() override {
     poses_ = 0;
@@ -170,18 +214,18 @@ public:
     return std::make_unique<GaussianPoseEnumerator>(*this);
   }
   void key(std::string &out) const override {
-    put(out, engine_.pos);
+    put(out, pos_);
     put(out, failed_);
     put(out, poses_);
     put(out, td_);
     put(out, rd_);
     // a distribution's pending second Marsaglia value is part of the state
-    for (const NormalRV *d : {&rv_x_, &rv_y_, &rv_t_}) {
+    for (const TapeNormal *d : {&rv_x_, &rv_y_, &rv_t_}) {
       put(out, d->has_saved);
       if (d->has_saved) put(out, d->saved);
     }
   }
-  void trim() override { engine_.tape->trim(engine_.pos); }
+  void trim() override { tape_->trim(pos_); }
   bool cheap_step() const override { return false; }
   void assign(const PoseEnumerator &o) override { *this = static_cast<const GaussianPoseEnumerator &>(o); }
 
@@ -191,14 +235,15 @@ private:
     td_ = td;
     rd_ = rd;
     // fresh distribution objects: a saved second Marsaglia value is dropped here
-    rv_x_ = NormalRV(0, td_);
-    rv_y_ = NormalRV(0, td_);
-    rv_t_ = NormalRV(0, rd_);
+    rv_x_ = TapeNormal(0, td_);
+    rv_y_ = TapeNormal(0, td_);
+    rv_t_ = TapeNormal(0, rd_);
   }
   unsigned max_failed_, max_poses_, failed_ = 0, poses_ = 0;
   double base_td_, base_rd_, td_ = 0, rd_ = 0;
-  NormalRV rv_x_, rv_y_, rv_t_;
-  TapeEngine engine_;
+  TapeNormal rv_x_, rv_y_, rv_t_;
+  std::shared_ptr<PairTape> tape_;
+  size_t pos_ = 0;  // next pair of the tape
 };
 
 // Hill climbing: rounds of six candidates base +X, -Y, +Th, -X, +Y, -Th (action id % 3 picks the
