@@ -392,6 +392,138 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   }
 }
 
+// K3, one pose per workgroup of 512 threads.  The filter's launches hold a few hundred poses: with four
+// waves per pose the CUs run ~2.6 waves per SIMD and the waves wait on the 3x3 gathers 68 % of the
+// time (SQ_WAIT_ANY / SQ_WAVE_CYCLES, r01).  Here the expensive phase A (endpoint, nine gathers, exp)
+// is spread over EIGHT waves -- beam b goes to thread b % 512 -- while the run resolution and the sum
+// keep the canonical 256-thread layout (thread t < 256 owns beams t + 256k, read back from LDS), so
+// scores are bit-identical to k_score_gmapping's (the whole GPU suite passes with it).  Measured: no
+// faster (41.5 vs 41.1 us per filter launch) -- the waits are not hidden by more waves, the launch is
+// bound by the per-pose phase chain -- so it is opt-in (SLAMHIP_K3_WIDE=1), kept as the record of the
+// experiment.
+template <int KB>
+__global__ __launch_bounds__(512) void k_score_gmapping_wide(ScoreArgs a) {
+  extern __shared__ double s_dyn[];  // val[256 KB] | grp_cell int2 [4 KB] | grp_start int [4 KB] | cx, cy int [256 KB]
+  __shared__ double s_pose1[4];
+  __shared__ double s_part1[4];
+  __shared__ int s_run0_len;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int n = a.scan.n;
+  const int G = (n + 63) >> 6;
+  double *s_val = s_dyn;
+  int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kBlock);
+  int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
+  int *s_cx = s_grp_start + 4 * KB;
+  int *s_cy = s_cx + KB * kBlock;
+  const int p = blockIdx.x;
+  if (t == 0) {
+    const double th = a.poses[3 * p + 2];
+    double sn, cs;
+    if (a.pose_sc) {
+      sn = a.pose_sc[2 * p];
+      cs = a.pose_sc[2 * p + 1];
+    } else {
+      sincos(th, &sn, &cs);
+    }
+    s_pose1[0] = a.poses[3 * p];
+    s_pose1[1] = a.poses[3 * p + 1];
+    s_pose1[2] = sn;
+    s_pose1[3] = cs;
+    s_run0_len = n;
+  }
+  __syncthreads();
+  const double x = s_pose1[0], y = s_pose1[1], sn = s_pose1[2], cs = s_pose1[3];
+  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
+  const int *tiles = a.tables ? a.tables + (size_t)a.pose_slot[p] * a.table_stride : nullptr;
+  // phase A over all 512 threads
+  for (int b = t; b < n; b += 512) {
+    const double r = a.scan.range[b], ca = a.scan.cos_a[b], sa = a.scan.sin_a[b];
+    const double c = cs * ca - sn * sa;
+    const double s = sn * ca + cs * sa;
+    const double wx = x + r * c;
+    const double wy = y + r * s;
+    const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
+    s_val[b] = gm_fresh_value(a.map, tiles, a.gm, cx, cy, wx, wy);
+    s_cx[b] = cx;
+    s_cy[b] = cy;
+  }
+  __syncthreads();
+  // canonical layout from here on; waves 4..7 only keep the barriers company
+  const bool act = t < kBlock;
+  int ccx[KB], ccy[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kBlock * k;
+    ccx[k] = 0;
+    ccy[k] = 0;
+    if (act && b < n) {
+      ccx[k] = s_cx[b];
+      ccy[k] = s_cy[b];
+      if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
+    }
+  }
+  __syncthreads();
+  unsigned long long mask[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kBlock * k;
+    const int g = 4 * k + wave;
+    int pcx = __shfl_up(ccx[k], 1, 64), pcy = __shfl_up(ccy[k], 1, 64);
+    if (act && lane == 0 && g > 0 && b < n) {
+      const int2 pc = s_grp_cell[g - 1];
+      pcx = pc.x;
+      pcy = pc.y;
+    }
+    const bool start = act && (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
+    mask[k] = __ballot(start);
+    if (act && lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
+    if (start && b > 0) atomicMin(&s_run0_len, b);
+  }
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kBlock * k;
+    if (act && b < n) {
+      const int g = 4 * k + wave;
+      const unsigned long long upto = mask[k] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+      int head;
+      if (upto) {
+        head = 64 * g + 63 - __clzll(upto);
+      } else {
+        int gg = g - 1;
+        head = s_grp_start[gg];
+        while (head < 0) head = s_grp_start[--gg];  // beam 0 is always a start
+      }
+      const double v = s_val[head];
+      const double term = v * a.scan.weight[b] * a.scan.factor[b];
+      acc = acc + term;
+      if (b == n - 1 && a.gm_info) {
+        GmPoseInfo &gi = a.gm_info[p];
+        gi.last_cx = ccx[k];
+        gi.last_cy = ccy[k];
+        gi.last_v = v;
+        gi.last_head = head;
+      }
+      if (b == 0 && a.gm_info) {
+        GmPoseInfo &gi = a.gm_info[p];
+        gi.first_cx = ccx[k];
+        gi.first_cy = ccy[k];
+        gi.v0 = v;
+      }
+    }
+  }
+  acc = wave_xor_sum(acc);
+  if (act && lane == 0) s_part1[wave] = acc;
+  __syncthreads();
+  if (t == 0) {
+    if (a.gm_info) a.gm_info[p].run0_len = s_run0_len;
+    const double total = (s_part1[0] + s_part1[1]) + (s_part1[2] + s_part1[3]);
+    a.scores[p] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+  }
+}
+
 // ---- K2: window OOPEs (max / mean / overlap) ------------------------------------------------------
 // MaxOccupancyObservationPE / MeanOccupancyObservationPE / OverlapWeightedOccupancyObservationPE
 // (src/core/scan_matchers/occupancy_observation_probability.h:29-99) over GridRasterizedRectangle
@@ -571,9 +703,15 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   if (oope == SLAMHIP_OOPE_GMAPPING) {
     if (kb > 8) return hipErrorInvalidValue;
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
+    // SLAMHIP_K3_WIDE=1 selects the 512-thread variant for one-pose launches (measured equal: kept
+    // for experiments, off by default)
+    static const bool wide_ok = getenv("SLAMHIP_K3_WIDE") && getenv("SLAMHIP_K3_WIDE")[0] == '1';
+    const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int);
 #define GM_CASE(K)                                                                                            \
   case K:                                                                                                     \
-    if (a.poses_per_block == 1)                                                                               \
+    if (a.poses_per_block == 1 && wide_ok)                                                                    \
+      SLAMHIP_LAUNCH((k_score_gmapping_wide<K>), grid, dim3(512), shm_wide, stream, ev_start, ev_stop, a);    \
+    else if (a.poses_per_block == 1)                                                                          \
       SLAMHIP_LAUNCH((k_score_gmapping<K, true>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);     \
     else                                                                                                      \
       SLAMHIP_LAUNCH((k_score_gmapping<K, false>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);    \
