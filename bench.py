@@ -201,8 +201,8 @@ def cpu_baseline(sc, kind, params, seconds, weighting="even"):
     return port
 
 
-def sharded_particle_maps_leg(args, pkg, ctx, blob_size, gp, seeds, n, first, count, rank, world, scan, deltas, dist,
-                              torch, dev):
+def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count, rank, world, scan, deltas,
+                              dist, torch, dev):
     """Per-particle copy-on-write maps with the particles sharded over the ranks (opt-in:
     --pf-maps-sharded).  Per step: local lock-step match + batched K6, all-gather of the raw weights,
     identical resampling plan everywhere; on a resampling the particle records are all-gathered and the
@@ -210,15 +210,10 @@ def sharded_particle_maps_leg(args, pkg, ctx, blob_size, gp, seeds, n, first, co
     pfm = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
     ext = (args.pf_size + 127) // 128 + 1
     pfm.enable_particle_maps(1, extent_tiles=ext, pool_tiles=ext * ext + 2 * count * args.pf_tiles_per_particle)
-    owner = lambda j: int(j) // count  # noqa: E731  (contiguous blocks)
+    bounds = np.cumsum(counts)
+    owner = lambda j: int(np.searchsorted(bounds, int(j), side="right"))  # noqa: E731  (contiguous blocks)
     moved_bytes = 0
     resamplings = 0
-
-    def gather(a, dtype):
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        out = torch.empty(world * t.numel(), dtype=dtype, device=dev)
-        dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
 
     def one(k):
         nonlocal moved_bytes, resamplings
@@ -280,12 +275,14 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     when a resampling happens).  Strong scaling: the particle count is fixed."""
     from synth import make_scene
     n = args.particles
-    if n % world:
-        return {"skipped": "particles %d not divisible by %d ranks" % (n, world)}
+    if n < world:
+        return {"skipped": "fewer particles (%d) than ranks (%d)" % (n, world)}
     sc = make_scene(cell_model=2, size=args.pf_size, scale=args.scale, n_beams=args.beams, seed=4)
     ctx.upload_map(1, sc["map"])
-    count = n // world
-    first = rank * count
+    # contiguous blocks; the first n % world ranks hold one particle more (100 particles on 8 GPUs: 13 x 4 + 12 x 4)
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    firsts = [sum(counts[:r]) for r in range(world)]
+    count, first = counts[rank], firsts[rank]
     seeds = np.arange(1000, 1000 + n, dtype=np.uint32)[first:first + count]
     gp = [0.0, args.pf_sigma_xy, 0.0, args.pf_sigma_th, 0.0, 0.0, 0.0, 0.0]
     pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
@@ -293,12 +290,18 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     dev = args.coll_device
 
     def gather(a, dtype):
+        """all-gather of per-particle rows (uneven shards are padded to the largest one)"""
         if world == 1:
             return np.asarray(a)
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        a = np.ascontiguousarray(a)
+        per = a.size // count
+        padded = np.zeros(max(counts) * per, dtype=a.dtype)
+        padded[:a.size] = a.ravel()
+        t = torch.from_numpy(padded).to(dev)
         out = torch.empty(world * t.numel(), dtype=dtype, device=dev)
         dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
+        out = out.cpu().numpy().reshape(world, -1)
+        return np.concatenate([out[r, :counts[r] * per] for r in range(world)])
 
     rs = np.random.RandomState(5)
     deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(args.pf_steps + 2)]
@@ -398,7 +401,7 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
         except pkg.SlamHipError as e:  # e.g. the pool does not fit: report, do not hide
             with_maps = {"error": str(e)}
     if world > 1 and args.pf_maps_sharded:
-        with_maps = sharded_particle_maps_leg(args, pkg, ctx, pf.blob_size(), gp, seeds, n, first, count, rank, world,
+        with_maps = sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count, rank, world,
                                               scan, deltas, dist, torch, dev)
     ctx.map_release(1)
     return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
