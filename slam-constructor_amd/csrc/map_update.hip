@@ -1068,4 +1068,30 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   return SLAMHIP_OK;
 }
 
+// called by slamhip_ctx_destroy: the K6 scratch buffers of a context live as long as it does
+void mu_release(slamhip_ctx *ctx) {
+  for (size_t i = 0; i < g_scratch.size(); ++i) {
+    if (g_scratch[i].first != ctx) continue;
+    MuScratch &s = g_scratch[i].second;
+    for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.keys, (void *)s.keys_sorted, (void *)s.order,
+                    (void *)s.order_sorted, (void *)s.rec_beam, (void *)s.rec_prob, (void *)s.rec_qual,
+                    (void *)s.beam_end, (void *)s.scan, (void *)s.srt_prob, (void *)s.srt_qual, (void *)s.srt_ox,
+                    (void *)s.srt_oy, (void *)s.occ, (void *)s.error_flag, (void *)s.n_updates, s.temp})
+      if (p) hipFree(p);
+    g_scratch.erase(g_scratch.begin() + i);
+    break;
+  }
+  for (size_t i = 0; i < g_bscratch.size(); ++i) {
+    if (g_bscratch[i].first != ctx) continue;
+    MuBatchScratch &s = g_bscratch[i].second;
+    for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.order, (void *)s.order_sorted, (void *)s.keys,
+                    (void *)s.keys_sorted, (void *)s.rec_pq, (void *)s.beam_end, (void *)s.scan, (void *)s.srt_prob,
+                    (void *)s.srt_qual, (void *)s.srt_ox, (void *)s.srt_oy, (void *)s.occ, (void *)s.error_flag,
+                    (void *)s.d_jobs, (void *)s.d_bbox, (void *)s.n_updates, (void *)s.d_total, s.temp, s.scan_temp})
+      if (p) hipFree(p);
+    g_bscratch.erase(g_bscratch.begin() + i);
+    break;
+  }
+}
+
 }  // namespace slamhip

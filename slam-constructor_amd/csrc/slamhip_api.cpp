@@ -409,6 +409,7 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) hipEventDestroy(ev);
   if (ctx->h_done_flag) hipHostFree(ctx->h_done_flag);
+  mu_release(ctx);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return SLAMHIP_OK;

@@ -109,6 +109,7 @@ struct DeviceMap {
 };
 
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip
+void mu_release(slamhip_ctx *ctx);                    // map_update.hip: frees the context's K6 scratch
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 
