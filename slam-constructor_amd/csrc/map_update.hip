@@ -177,9 +177,10 @@ __global__ __launch_bounds__(1024) void k_mu_offsets(const unsigned *counts, uns
   if (t == 1023) offsets[n] = s_part[1023];
 }
 
-__device__ __forceinline__ void mu_record(const MuArgs &a, const MuJob &jb, unsigned slot, int b, int cx, int cy,
-                                          int ocx, int ocy, bool obstacle_cell, double base_prob, double base_qual,
-                                          double hole_dist_sq, double obst_dist_sq) {
+// What the walk (k_mu_emit) leaves behind per visited cell: only the sort key.  The observation itself
+// (occupancy estimate, blur) is a pure function of (beam, cell) and is computed later, one thread per
+// record, in k_mu_gather -- the sequential walk of a beam stays as short as its dependency chain.
+__device__ __forceinline__ void mu_key(const MuArgs &a, unsigned slot, int b, int cx, int cy) {
   const int ix = cx + a.origin_x, iy = cy + a.origin_y;
   if ((unsigned)ix >= (unsigned)a.width || (unsigned)iy >= (unsigned)a.height) {
     *a.error_flag = 1;
@@ -187,6 +188,57 @@ __device__ __forceinline__ void mu_record(const MuArgs &a, const MuJob &jb, unsi
     else a.keys[slot] = kInvalidKey;
     return;
   }
+  if (a.keys64) {  // batch: (job, cell of the virtual extent)
+    const unsigned long long job = (unsigned long long)(b / a.n);
+    a.keys64[slot] = (job << a.cell_bits) | ((unsigned long long)iy * (unsigned)a.width + (unsigned)ix);
+  } else {
+    a.keys[slot] = (unsigned)iy * (unsigned)a.pitch + (unsigned)ix;
+  }
+}
+
+// per-beam quantities of WallDistanceBlurringScanAdder::handle_scan_point (grid_map_scan_adders.h:138-172)
+struct MuBeam {
+  double base_prob, base_qual;  // occupancy of the obstacle cell, estimated first like the reference
+  double hole_dist_sq, obst_dist_sq;
+  int ex, ey;  // obstacle (end) cell
+};
+
+__device__ __forceinline__ MuBeam mu_beam(const MuArgs &a, const MuJob &jb, int g) {
+  MuBeam m;
+  const double wx = a.beam_end[2 * g], wy = a.beam_end[2 * g + 1];
+  const bool occ = a.is_occ ? a.is_occ[g % a.n] != 0 : true;
+  const double scale = a.scale;
+  const double d_x = wx - jb.px, d_y = wy - jb.py;
+  const int bx = (int)floor(jb.px / scale), by = (int)floor(jb.py / scale);
+  m.ex = (int)floor(wx / scale);
+  m.ey = (int)floor(wy / scale);
+  const double odx = bx - m.ex, ody = by - m.ey;
+  m.obst_dist_sq = odx * odx + ody * ody;
+  double blur_dist = 0;
+  if (occ) {
+    blur_dist = a.blur / scale;
+    if (blur_dist < 0) blur_dist *= -(d_x * d_x + d_y * d_y);
+  }
+  m.hole_dist_sq = blur_dist * blur_dist;
+  m.base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
+  m.base_qual = occ ? a.base_occ_qual : a.base_empty_qual;
+  if (a.est_kind == 1) {
+    const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
+    const ae::ae_rect cb{scale * m.ey, scale * (m.ey + 1), scale * m.ex, scale * (m.ex + 1)};
+    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
+                                         a.shift_amount);
+    m.base_prob = o.prob;
+    m.base_qual = o.qual;
+  }
+  return m;
+}
+
+// the observation a beam makes of one of its cells: (prob, qual)
+__device__ __forceinline__ double2 mu_value(const MuArgs &a, const MuJob &jb, int b, int cx, int cy, const MuBeam &bm) {
+  const int ocx = bm.ex, ocy = bm.ey;
+  const bool obstacle_cell = cx == ocx && cy == ocy;
+  const double base_prob = bm.base_prob, base_qual = bm.base_qual;
+  const double hole_dist_sq = bm.hole_dist_sq, obst_dist_sq = bm.obst_dist_sq;
   double prob, qual;
   if (obstacle_cell) {
     prob = base_prob;
@@ -209,15 +261,7 @@ __device__ __forceinline__ void mu_record(const MuArgs &a, const MuJob &jb, unsi
       prob = base_prob * prob_scale;
     }
   }
-  // two scattered stores per step (lanes write to different beams' slots): the 4-byte key and one
-  // 16-byte (prob, qual) pair; the beam index is recovered from `offsets` in k_mu_gather
-  if (a.keys64) {  // batch: (job, cell of the virtual extent)
-    const unsigned long long job = (unsigned long long)(b / a.n);
-    a.keys64[slot] = (job << a.cell_bits) | ((unsigned long long)iy * (unsigned)a.width + (unsigned)ix);
-  } else {
-    a.keys[slot] = (unsigned)iy * (unsigned)a.pitch + (unsigned)ix;
-  }
-  reinterpret_cast<double2 *>(a.rec_prob)[slot] = make_double2(prob, qual);
+  return make_double2(prob, qual);
 }
 
 __global__ void k_mu_emit(MuArgs a) {
@@ -228,32 +272,12 @@ __global__ void k_mu_emit(MuArgs a) {
   const MuJob jb = mu_job(a, b);
   const unsigned base = a.offsets[b];
   const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
-  const bool occ = a.is_occ ? a.is_occ[b % a.n] != 0 : true;
   const double scale = a.scale;
   const double d_x = wx - jb.px, d_y = wy - jb.py;
   const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
   int px = (int)floor(jb.px / scale), py = (int)floor(jb.py / scale);
   const int bx = px, by = py;
   const int ex = (int)floor(wx / scale), ey = (int)floor(wy / scale);
-  const double odx = bx - ex, ody = by - ey;
-  const double obst_dist_sq = odx * odx + ody * ody;
-  double blur_dist = 0;
-  if (occ) {
-    blur_dist = a.blur / scale;
-    if (blur_dist < 0) blur_dist *= -(d_x * d_x + d_y * d_y);
-  }
-  const double hole_dist_sq = blur_dist * blur_dist;
-  // occupancy of the obstacle cell (= the end cell of the walk), estimated first like the reference
-  double base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
-  double base_qual = occ ? a.base_occ_qual : a.base_empty_qual;
-  if (a.est_kind == 1) {
-    const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
-    const ae::ae_rect cb{scale * ey, scale * (ey + 1), scale * ex, scale * (ex + 1)};
-    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
-                                         a.shift_amount);
-    base_prob = o.prob;
-    base_qual = o.qual;
-  }
   const double mid_x = (px + 0.5) * scale, mid_y = (py + 0.5) * scale;
   const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
   double e = mid_cell_seg_y - mid_y * d_x;
@@ -262,7 +286,7 @@ __global__ void k_mu_emit(MuArgs a) {
   unsigned n = 0;
   bool failover = false;
   while (true) {
-    if (n < cap) mu_record(a, jb, base + n, b, px, py, ex, ey, px == ex && py == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
+    if (n < cap) mu_key(a, base + n, b, px, py);
     ++n;
     if (px == ex && py == ey) break;
     if (cap < n) {  // fp rounding sent the walk astray: the reference restarts with Bresenham
@@ -295,7 +319,7 @@ __global__ void k_mu_emit(MuArgs a) {
     n = 0;
     while (true) {
       const int cx = y_is_primary ? secondary : primary, cy = y_is_primary ? primary : secondary;
-      if (n < cap) mu_record(a, jb, base + n, b, cx, cy, ex, ey, cx == ex && cy == ey, base_prob, base_qual, hole_dist_sq, obst_dist_sq);
+      if (n < cap) mu_key(a, base + n, b, cx, cy);
       ++n;
       if (primary == limit) break;
       const int err_inc_primary = error + inc_primary * d_secondary;
@@ -331,26 +355,40 @@ __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs
   }
 }
 
-// records into sorted order, so that a cell's (possibly long: every beam crosses the robot's cell)
-// sequential chain in k_mu_apply streams through contiguous memory instead of chasing order[j]
-__global__ void k_mu_gather(const unsigned *order, unsigned total, const double *rec_pq, const unsigned *offsets,
-                            int n_beams, const double *beam_end, double *srt_prob, double *srt_qual,
-                            double *srt_ox, double *srt_oy) {
+// The observations in SORTED order, one thread per record: which beam made it (the walk wrote records
+// beam-major, so the beam is the last b with offsets[b] <= r), which cell (from the key), then the
+// occupancy estimate and blur of mu_value.  A cell's (possibly long: every beam crosses the robot's
+// cell) sequential chain in k_mu_apply then streams through contiguous memory.
+template <typename Key>
+__global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *order, unsigned total, int n_beams,
+                            double *srt_prob, double *srt_qual, double *srt_ox, double *srt_oy) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  const Key key = keys_sorted[i];
+  if (key == ~Key(0)) return;  // padding of a walk that ended early: never applied
   const unsigned r = order[i];
-  const double2 pq = reinterpret_cast<const double2 *>(rec_pq)[r];
-  srt_prob[i] = pq.x;
-  srt_qual[i] = pq.y;
-  // the beam owning slot r: the last b with offsets[b] <= r (records are beam-major)
   int lo = 0, hi = n_beams - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (offsets[mid] <= r) lo = mid;
+    if (a.offsets[mid] <= r) lo = mid;
     else hi = mid - 1;
   }
-  srt_ox[i] = beam_end[2 * lo];
-  srt_oy[i] = beam_end[2 * lo + 1];
+  const MuJob jb = mu_job(a, lo);
+  int ix, iy;
+  if (a.keys64) {
+    const unsigned long long cellkey = (unsigned long long)key & ((1ull << a.cell_bits) - 1ull);
+    ix = (int)(cellkey % (unsigned)a.width);
+    iy = (int)(cellkey / (unsigned)a.width);
+  } else {
+    ix = (int)((unsigned)key % (unsigned)a.pitch);
+    iy = (int)((unsigned)key / (unsigned)a.pitch);
+  }
+  const MuBeam bm = mu_beam(a, jb, lo);
+  const double2 pq = mu_value(a, jb, lo, ix - a.origin_x, iy - a.origin_y, bm);
+  srt_prob[i] = pq.x;
+  srt_qual[i] = pq.y;
+  srt_ox[i] = a.beam_end[2 * lo];
+  srt_oy[i] = a.beam_end[2 * lo + 1];
 }
 
 // `a.rec_*` point at the SORTED record arrays here (k_mu_gather)
@@ -774,8 +812,9 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   while (nbits < 32 && ((1ull << nbits) - 1) <= (unsigned long long)m.pitch * m.height) ++nbits;
   SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted,
                                           total, 0, nbits, ctx->stream));
-  hipLaunchKernelGGL(k_mu_gather, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sc.order_sorted, total,
-                     sc.rec_prob, sc.offsets, n, sc.beam_end, sc.srt_prob, sc.srt_qual, sc.srt_ox, sc.srt_oy);
+  hipLaunchKernelGGL(k_mu_gather<unsigned>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                     (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, n, sc.srt_prob,
+                     sc.srt_qual, sc.srt_ox, sc.srt_oy);
   a.rec_prob = sc.srt_prob;
   a.rec_qual = sc.srt_qual;
   a.rec_ox = sc.srt_ox;
@@ -1043,8 +1082,9 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   const unsigned end_bit = std::min(64u, cell_bits + job_bits + 1);
   SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted, total, 0,
                                           end_bit, st));
-  hipLaunchKernelGGL(k_mu_gather, dim3((total + 255) / 256), dim3(256), 0, st, sc.order_sorted, total, sc.rec_pq,
-                     sc.offsets, (int)beams, sc.beam_end, sc.srt_prob, sc.srt_qual, sc.srt_ox, sc.srt_oy);
+  hipLaunchKernelGGL(k_mu_gather<unsigned long long>, dim3((total + 255) / 256), dim3(256), 0, st, a,
+                     (const unsigned long long *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, (int)beams,
+                     sc.srt_prob, sc.srt_qual, sc.srt_ox, sc.srt_oy);
   a.rec_prob = sc.srt_prob;
   a.rec_qual = sc.srt_qual;
   a.rec_ox = sc.srt_ox;

@@ -401,8 +401,8 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
 // faster (41.5 vs 41.1 us per filter launch) -- the waits are not hidden by more waves, the launch is
 // bound by the per-pose phase chain -- so it is opt-in (SLAMHIP_K3_WIDE=1), kept as the record of the
 // experiment.
-template <int KB>
-__global__ __launch_bounds__(512) void k_score_gmapping_wide(ScoreArgs a) {
+template <int KB, int NT>
+__global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
   extern __shared__ double s_dyn[];  // val[256 KB] | grp_cell int2 [4 KB] | grp_start int [4 KB] | cx, cy int [256 KB]
   __shared__ double s_pose1[4];
   __shared__ double s_part1[4];
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512) void k_score_gmapping_wide(ScoreArgs a) {
   const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   const int *tiles = a.tables ? a.tables + (size_t)a.pose_slot[p] * a.table_stride : nullptr;
   // phase A over all 512 threads
-  for (int b = t; b < n; b += 512) {
+  for (int b = t; b < n; b += NT) {
     const double r = a.scan.range[b], ca = a.scan.cos_a[b], sa = a.scan.sin_a[b];
     const double c = cs * ca - sn * sa;
     const double s = sn * ca + cs * sa;
@@ -705,12 +705,21 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
     // SLAMHIP_K3_WIDE=1 selects the 512-thread variant for one-pose launches (measured equal: kept
     // for experiments, off by default)
-    static const bool wide_ok = getenv("SLAMHIP_K3_WIDE") && getenv("SLAMHIP_K3_WIDE")[0] == '1';
+    // SLAMHIP_K3_WIDE: 0 = never, 1 = 512 threads for every one-pose launch, unset = 1024 threads for
+    // launches of at most SLAMHIP_K3_WIDE_BELOW poses (a lone matcher's batches: a few dozen poses
+    // leave the GPU empty, so the per-pose chain is the whole kernel time)
+    static const char *wide_env = getenv("SLAMHIP_K3_WIDE");
+    static const int wide_below = getenv("SLAMHIP_K3_WIDE_BELOW") ? atoi(getenv("SLAMHIP_K3_WIDE_BELOW")) : 160;
+    const int wide = (wide_env && wide_env[0] == '0') ? 0
+                     : (wide_env && wide_env[0] == '1') ? 512
+                     : (a.n_poses <= wide_below ? 1024 : 0);
     const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int);
 #define GM_CASE(K)                                                                                            \
   case K:                                                                                                     \
-    if (a.poses_per_block == 1 && wide_ok)                                                                    \
-      SLAMHIP_LAUNCH((k_score_gmapping_wide<K>), grid, dim3(512), shm_wide, stream, ev_start, ev_stop, a);    \
+    if (a.poses_per_block == 1 && wide == 1024)                                                               \
+      SLAMHIP_LAUNCH((k_score_gmapping_wide<K, 1024>), grid, dim3(1024), shm_wide, stream, ev_start, ev_stop, a); \
+    else if (a.poses_per_block == 1 && wide == 512)                                                           \
+      SLAMHIP_LAUNCH((k_score_gmapping_wide<K, 512>), grid, dim3(512), shm_wide, stream, ev_start, ev_stop, a); \
     else if (a.poses_per_block == 1)                                                                          \
       SLAMHIP_LAUNCH((k_score_gmapping<K, true>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);     \
     else                                                                                                      \
