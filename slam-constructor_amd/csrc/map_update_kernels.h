@@ -1,0 +1,618 @@
+// map_update_kernels.h -- the device side of K6 (included by map_update.hip only; see its header for
+// the reference lines restated and the scheme).
+#pragma once
+
+namespace slamhip {
+
+// per-beam quantities of WallDistanceBlurringScanAdder::handle_scan_point (grid_map_scan_adders.h:138-172),
+// computed once per beam by k_mu_count and read by the walk and by every record of the beam
+struct MuBeam {
+  double base_prob, base_qual;  // occupancy of the obstacle cell, estimated first like the reference
+  double hole_dist_sq, obst_dist_sq;
+  int ex, ey;  // obstacle (end) cell
+};
+
+struct MuArgs {
+  // batch (null: the single pose below, 32-bit keys, dense window)
+  const MuJob *jobs;
+  int n_jobs;
+  const int *tables;  // tile tables of all slots: payload / aux are then the tile pools
+  int table_stride, tiles_x;
+  // sort key of a record: (job << cell_bits) | cell of the key window, row-major.  The window is the
+  // rectangle of internal cells (external + origin) the batch can touch -- a few metres around the
+  // particles, not the map extent -- so that job and cell fit 32 bits and the radix sort runs over 4-byte
+  // keys in as few passes as the window needs.  A plain call: the window is the bound map itself.
+  int cell_bits, key_x0, key_y0, key_w;
+  void *keys;  // unsigned or unsigned long long per record (the kernels' Key parameter)
+  int *job_bbox;  // per job (lo_x, lo_y, hi_x, hi_y) in external cells, reduced by k_mu_count
+  // map
+  double *payload;
+  double *aux;
+  int width, height, pitch, origin_x, origin_y, cell_dbl, aux_stride;
+  double scale;
+  // scan
+  const double *range, *cos_a, *sin_a;
+  const int *is_occ;
+  int n;
+  double px, py, sn, cs;  // pose, sin/cos of its heading (host sincos)
+  // adder
+  int rule;
+  int est_kind;         // 0 ConstOccupancyEstimator, 1 AreaOccupancyEstimator
+  double shift_amount;  // Q27: the estimator's function-local static (low_qual x first cell side)
+  double quality, base_occ_prob, base_occ_qual, base_empty_prob, base_empty_qual, blur, max_range_sq;
+  // work buffers
+  unsigned *counts, *offsets;  // per beam
+  MuBeam *beam_info;  // per beam
+  double *beam_end;   // 2 per beam (the obstacle point of its observations)
+  int *error_flag;    // set when a touched cell lies outside the window
+  // the SORTED records (k_mu_gather -> k_mu_apply*): observation, TBM only its quality, the beam
+  const double *rec_prob, *rec_qual;
+  const unsigned *rec_beam;
+};
+
+__device__ __forceinline__ bool mu_are_equal(double a, double b) {
+  const double m = fmax(fabs(a), fabs(b));
+  return fabs(a - b) <= 1e-7 * fmax(1.0, m);
+}
+
+// thread g of the beam kernels handles beam g % n of job g / n (a plain call is one job)
+__device__ __forceinline__ MuJob mu_job(const MuArgs &a, int g) {
+  if (a.jobs) return a.jobs[g / a.n];
+  return MuJob{a.px, a.py, a.sn, a.cs, 0, 0};
+}
+
+__device__ __forceinline__ void mu_endpoint(const MuArgs &a, const MuJob &j, int b, double *wx, double *wy) {
+  const double c = j.cs * a.cos_a[b] - j.sn * a.sin_a[b];
+  const double s = j.sn * a.cos_a[b] + j.cs * a.sin_a[b];
+  *wx = j.px + a.range[b] * c;
+  *wy = j.py + a.range[b] * s;
+}
+
+__device__ __forceinline__ MuBeam mu_beam(const MuArgs &a, const MuJob &jb, int g, double wx, double wy) {
+  MuBeam m;
+  const bool occ = a.is_occ ? a.is_occ[g % a.n] != 0 : true;
+  const double scale = a.scale;
+  const double d_x = wx - jb.px, d_y = wy - jb.py;
+  const int bx = (int)floor(jb.px / scale), by = (int)floor(jb.py / scale);
+  m.ex = (int)floor(wx / scale);
+  m.ey = (int)floor(wy / scale);
+  const double odx = bx - m.ex, ody = by - m.ey;
+  m.obst_dist_sq = odx * odx + ody * ody;
+  double blur_dist = 0;
+  if (occ) {
+    blur_dist = a.blur / scale;
+    if (blur_dist < 0) blur_dist *= -(d_x * d_x + d_y * d_y);
+  }
+  m.hole_dist_sq = blur_dist * blur_dist;
+  m.base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
+  m.base_qual = occ ? a.base_occ_qual : a.base_empty_qual;
+  if (a.est_kind == 1) {
+    const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
+    const ae::ae_rect cb{scale * m.ey, scale * (m.ey + 1), scale * m.ex, scale * (m.ex + 1)};
+    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
+                                         a.shift_amount);
+    m.base_prob = o.prob;
+    m.base_qual = o.qual;
+  }
+  return m;
+}
+
+__global__ void k_mu_count(MuArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = g < a.n * a.n_jobs;
+  unsigned cnt = 0;
+  int ocx = 0, ocy = 0;
+  if (in) {
+    const MuJob j = mu_job(a, g);
+    double wx, wy;
+    mu_endpoint(a, j, g % a.n, &wx, &wy);
+    a.beam_end[2 * g] = wx;
+    a.beam_end[2 * g + 1] = wy;
+    const double ddx = wx - j.px, ddy = wy - j.py;
+    if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
+      const int rcx = (int)floor(j.px / a.scale), rcy = (int)floor(j.py / a.scale);
+      ocx = (int)floor(wx / a.scale);
+      ocy = (int)floor(wy / a.scale);
+      cnt = (unsigned)(abs(ocx - rcx) + abs(ocy - rcy) + 1);
+      a.beam_info[g] = mu_beam(a, j, g, wx, wy);
+    }
+    a.counts[g] = cnt;
+  }
+  if (!a.job_bbox) return;
+  // cells a job can touch lie between its robot cell (host-initialised) and its endpoints: min / max of
+  // the endpoint cells per job.  One atomic per wave when the wave holds a single job (a thousand
+  // same-address atomics per job made this kernel 450 us), per lane otherwise.
+  const int job = in ? g / a.n : -1;
+  const int job0 = __shfl(job, 0, 64);
+  const bool uniform = __all(job == job0 || job < 0);
+  int lo_x = cnt ? ocx : INT_MAX, lo_y = cnt ? ocy : INT_MAX, hi_x = cnt ? ocx : INT_MIN, hi_y = cnt ? ocy : INT_MIN;
+  if (uniform) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo_x = min(lo_x, __shfl_xor(lo_x, off, 64));
+      lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+      hi_x = max(hi_x, __shfl_xor(hi_x, off, 64));
+      hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+    }
+    if ((threadIdx.x & 63) != 0) return;
+  } else if (!cnt) {
+    return;
+  }
+  if (lo_x == INT_MAX || (job0 < 0 && uniform)) return;
+  int *bb = a.job_bbox + 4 * (uniform ? job0 : job);
+  atomicMin(bb, lo_x);
+  atomicMin(bb + 1, lo_y);
+  atomicMax(bb + 2, hi_x);
+  atomicMax(bb + 3, hi_y);
+}
+
+// total number of records = exclusive offset of the last beam + its count
+__global__ void k_mu_total(const unsigned *counts, const unsigned *offsets, size_t beams, unsigned long long *out) {
+  out[0] = (unsigned long long)offsets[beams - 1] + counts[beams - 1];
+}
+
+// exclusive scan of counts[n] by one workgroup of 1024 threads; offsets[n] = total
+__global__ __launch_bounds__(1024) void k_mu_offsets(const unsigned *counts, unsigned *offsets, int n) {
+  __shared__ unsigned s_part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = t * per, hi = min(n, lo + per);
+  unsigned sum = 0;
+  for (int i = lo; i < hi; ++i) sum += counts[i];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const unsigned v = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  unsigned run = s_part[t] - sum;
+  for (int i = lo; i < hi; ++i) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+  if (t == 1023) offsets[n] = s_part[1023];
+}
+
+// The value sorted along with a record's cell key is the beam that made it: one wave per beam fills its
+// (contiguous, beam-major) range of records.  The sort is stable and a beam visits a cell once, so the
+// records of a cell come out in beam order -- the reference's update order -- and still name their beam.
+__global__ __launch_bounds__(256) void k_mu_beam_ids(const unsigned *counts, const unsigned *offsets, unsigned beams,
+                                                      unsigned *beam_of) {
+  const unsigned b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= beams) return;
+  const unsigned cnt = counts[b], base = offsets[b];
+  for (unsigned k = threadIdx.x & 63; k < cnt; k += 64) beam_of[base + k] = b;
+}
+
+// The walk of one beam (RegularSquaresGrid::world_to_cells, regular_squares_grid.h:56-101, with the
+// Bresenham fail-over of DiscreteSegment2D): one thread per beam, inherently sequential (the error term
+// accumulates roundings), so its body is kept to the dependency chain -- the step is select-based, and
+// all it leaves behind per visited cell is the sort key.  The observation itself (occupancy estimate,
+// blur) is a pure function of (beam, cell) and is computed later, one thread per record, in k_mu_gather.
+template <typename KeyT>
+__global__ void k_mu_emit(MuArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;  // global beam index: job * n + beam
+  if (b >= a.n * a.n_jobs) return;
+  const unsigned cap = a.counts[b];
+  if (cap == 0) return;
+  const MuJob jb = mu_job(a, b);
+  const unsigned base = a.offsets[b];
+  const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
+  const double scale = a.scale;
+  const double d_x = wx - jb.px, d_y = wy - jb.py;
+  const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
+  int px = (int)floor(jb.px / scale), py = (int)floor(jb.py / scale);
+  const int bx = px, by = py;
+  const int ex = a.beam_info[b].ex, ey = a.beam_info[b].ey;
+  const double mid_x = (px + 0.5) * scale, mid_y = (py + 0.5) * scale;
+  const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
+  double e = mid_cell_seg_y - mid_y * d_x;
+  const double e_x_inc = inc_x * scale * d_y;
+  const double e_y_inc = -inc_y * scale * d_x;
+  const KeyT job_part = a.jobs ? (KeyT)(b / a.n) << a.cell_bits : KeyT(0);
+  const unsigned row = (unsigned)a.key_w;
+  const unsigned w = (unsigned)a.width, h = (unsigned)a.height;
+  KeyT *out = (KeyT *)a.keys + base;
+  bool bad = false;
+  auto put = [&](unsigned k, int cx, int cy) {
+    const unsigned ix = (unsigned)(cx + a.origin_x), iy = (unsigned)(cy + a.origin_y);
+    const bool oob = ix >= w || iy >= h;
+    bad |= oob;
+    out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
+  };
+  // The main walk, one exit test per cell.  Position, key and bounds test advance incrementally; the step
+  // is computed before the exit test (and discarded with it), so the loop body has no inner branch.
+  // The reference's loop (regular_squares_grid.h:74-98) emits at most `cap` cells, then takes one more
+  // step and gives up unless that lands on the end cell: `astray` below.
+  unsigned ix = (unsigned)(px + a.origin_x), iy = (unsigned)(py + a.origin_y);
+  KeyT key = job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
+  const KeyT key_dx = (KeyT)(long long)inc_x, key_dy = (KeyT)((long long)inc_y * (long long)row);
+  unsigned n = 0;
+  bool reached;
+  do {
+    const bool oob = ix >= w || iy >= h;
+    bad |= oob;
+    out[n] = oob ? ~KeyT(0) : key;
+    ++n;
+    const double e_x = e + e_x_inc, e_y = e + e_y_inc;
+    const double abs_err_diff = fabs(e_y) - fabs(e_x);
+    const bool tie = mu_are_equal(abs_err_diff, 0);
+    const bool x_wins = 0 < abs_err_diff;
+    // tie: the diagonal step, degenerating to the one open axis at the end row / column
+    // (bitwise on purpose: selects, not branches)
+    const bool at_x = px == ex, at_y = py == ey;
+    reached = at_x & at_y;
+    const bool move_x = (tie & !at_x) | (!tie & x_wins);
+    const bool move_y = (tie & (at_x | !at_y)) | (!tie & !x_wins);
+    px += move_x ? inc_x : 0;
+    py += move_y ? inc_y : 0;
+    ix += move_x ? (unsigned)inc_x : 0u;
+    iy += move_y ? (unsigned)inc_y : 0u;
+    key += (move_x ? key_dx : KeyT(0)) + (move_y ? key_dy : KeyT(0));
+    e = tie ? 0.0 : (x_wins ? e_x : e_y);
+  } while (!reached && n < cap);
+  // fp rounding sent the walk astray: the reference restarts with Bresenham
+  const bool failover = !reached && !(px == ex && py == ey);
+  if (failover) {
+    bad = false;  // the discarded walk touched nothing
+    const int dxx = ex - bx, dyy = ey - by;
+    const bool y_is_primary = abs(dxx) < abs(dyy);
+    const int limit = y_is_primary ? ey : ex;
+    int primary = y_is_primary ? by : bx, secondary = y_is_primary ? bx : by;
+    const int d_primary = y_is_primary ? dyy : dxx, d_secondary = y_is_primary ? dxx : dyy;
+    const int inc_primary = 0 < d_primary ? 1 : -1, inc_secondary = 0 < d_secondary ? 1 : -1;
+    int error = 0;
+    n = 0;
+    while (true) {
+      const int cx = y_is_primary ? secondary : primary, cy = y_is_primary ? primary : secondary;
+      if (n < cap) put(n, cx, cy);
+      ++n;
+      if (primary == limit) break;
+      const int err_inc_primary = error + inc_primary * d_secondary;
+      const int err_inc_both = err_inc_primary - inc_secondary * d_primary;
+      primary += inc_primary;
+      if (abs(err_inc_primary) < abs(err_inc_both)) {
+        error = err_inc_primary;
+      } else {
+        secondary += inc_secondary;
+        error = err_inc_both;
+      }
+    }
+  }
+  for (unsigned k = n; k < cap; ++k) out[k] = ~KeyT(0);
+  if (bad) *a.error_flag = 1;
+}
+
+// the internal cell (and the job) a sort key names
+template <typename Key>
+__device__ __forceinline__ int mu_key_cell(const MuArgs &a, Key key, int *ix, int *iy) {
+  const Key cellkey = a.jobs ? key & (Key)((1ull << a.cell_bits) - 1ull) : key;
+  *ix = (int)(cellkey % (unsigned)a.key_w) + a.key_x0;
+  *iy = (int)(cellkey / (unsigned)a.key_w) + a.key_y0;
+  return a.jobs ? (int)(key >> a.cell_bits) : 0;
+}
+
+// the observation a beam makes of one of its cells: (prob, qual)
+__device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int cy, const MuBeam &bm) {
+  const int ocx = bm.ex, ocy = bm.ey;
+  if (cx == ocx && cy == ocy) return make_double2(bm.base_prob, bm.base_qual);
+  double prob = a.base_empty_prob, qual = a.base_empty_qual;
+  if (a.est_kind == 1) {
+    const MuJob jb = mu_job(a, b);
+    const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
+    const ae::ae_rect cb{a.scale * cy, a.scale * (cy + 1), a.scale * cx, a.scale * (cx + 1)};
+    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{a.beam_end[2 * b], a.beam_end[2 * b + 1]},
+                                         cb, 0, base4, a.shift_amount);
+    prob = o.prob;
+    qual = o.qual;
+  }
+  const double cdx = cx - ocx, cdy = cy - ocy;
+  const double dist_sq = cdx * cdx + cdy * cdy;
+  if (dist_sq < bm.hole_dist_sq && bm.hole_dist_sq < bm.obst_dist_sq) {
+    const double prob_scale = 1.0 - dist_sq / bm.hole_dist_sq;
+    prob = bm.base_prob * prob_scale;
+  }
+  return make_double2(prob, qual);
+}
+
+// The observations in SORTED order, one thread per record: the cell comes from the key, the beam from the
+// sorted value, then the occupancy estimate and blur of mu_value.  A record is 8 bytes (the observed
+// probability; TBM cells also take the estimate's quality): an observation whose quality is NaN is
+// dropped by every cell kind but GridCell, which never looks at it -- that is folded into a NaN
+// probability here so that the chains of k_mu_apply read one double per record.
+template <typename Key>
+__global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *beam_sorted, unsigned total,
+                            double *srt_prob, double *srt_qual) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const Key key = keys_sorted[i];
+  if (key == ~Key(0)) return;  // padding of a walk that ended early: never applied
+  const int b = (int)beam_sorted[i];
+  int ix, iy;
+  mu_key_cell<Key>(a, key, &ix, &iy);
+  const MuBeam bm = a.beam_info[b];
+  double2 pq = mu_value(a, b, ix - a.origin_x, iy - a.origin_y, bm);
+  if (a.rule == 3) srt_qual[i] = pq.y;
+  else if (a.rule != 0 && isnan(pq.y)) pq.x = pq.y;
+  srt_prob[i] = pq.x;
+}
+
+__device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs, double *out) {
+  double tmp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tmp[i | j] += lhs[i] * rhs[j];
+  const double tot = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  if (tot == 0.0) {
+    out[0] = 1.0;
+    out[1] = out[2] = out[3] = 0.0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = tmp[i] / tot;
+  }
+}
+
+// the state of one cell while its chain is applied: payload c0..c3, update counters x0, x1 (kept as
+// doubles: they are integers far below 2^53, so x + 1 and the products below equal the reference's
+// int arithmetic converted to double)
+struct MuCell {
+  double c0, c1, c2, c3, x0, x1;
+};
+
+// one observation applied to one cell: the reference's `cell += aoo` for the five cell kinds
+// (GridCell grid_cell.h:27-30, AffineQualityMergeCell / MeanProbabilityCell naive_grid_cells.h:14-20,33-40,
+// TbmBaseCell tbm_grid_cells.h:57-66, GmappingBaseCell gmapping_grid_cell.h:20-33).  `qual` is read for
+// TBM cells only; `obst(&x, &y)` fetches the observation's obstacle point, GMapping hits only.
+template <int RULE, typename Obst>
+__device__ __forceinline__ void mu_step(const MuArgs &a, MuCell &c, double prob, double qual, Obst obst) {
+  if (RULE == 0) {  // GridCell / MockGridCell: last write wins
+    c.c0 = prob;
+  } else if (RULE == 1) {  // AffineQualityMergeCell
+    if (isnan(prob)) return;
+    c.c0 = (1.0 - a.quality) * c.c0 + a.quality * prob;
+  } else if (RULE == 2) {  // MeanProbabilityCell: x0 = _n
+    if (isnan(prob)) return;
+    const double n1 = c.x0 + 1;
+    const double that_p = 0.5 + (prob - 0.5) * a.quality;
+    c.c0 = (c.c0 * c.x0 + that_p) / n1;
+    c.x0 = n1;
+  } else if (RULE == 3) {  // TbmBaseCell
+    if (isnan(prob) || isnan(qual)) return;
+    const double eq = qual * a.quality;
+    const double occupied = prob * eq, empty = (1 - prob) * eq;
+    const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
+    const double cur[4] = {c.c0, c.c1, c.c2, c.c3};
+    double nb[4];
+    mu_tbm_conj(cur, that, nb);
+    const double weight = nb[0] + nb[1] + nb[2];
+    if (weight == 0.0) {
+      c.c0 = 1.0;
+      c.c1 = c.c2 = c.c3 = 0.0;
+    } else {
+      c.c0 = nb[0] / weight;
+      c.c1 = nb[1] / weight;
+      c.c2 = nb[2] / weight;
+      c.c3 = 0.0;
+    }
+  } else {  // GmappingBaseCell: x0 = _hits, x1 = _tries
+    if (isnan(prob)) return;
+    const double tries = c.x1 + 1;
+    if (prob <= 0.5) {
+      // a free observation of a cell whose mean is 0 leaves it at +0: (0 * k + 0) / (k + 1).  Most cells
+      // of a scan are like that (free space never hit), and their chains then cost no division.
+      if (c.c0 != 0.0) c.c0 = (c.c0 * c.x1 + 0.0) / tries;
+      else c.c0 = 0.0;
+    } else {
+      c.c0 = (c.c0 * c.x1 + prob) / tries;
+      double obx, oby;
+      obst(&obx, &oby);
+      const double hits = c.x0 + 1;
+      c.c1 = (c.c1 * c.x0 + obx) / hits;
+      c.c2 = (c.c2 * c.x0 + oby) / hits;
+      c.x0 = hits;
+    }
+    c.x1 = tries;
+  }
+}
+
+// where a sorted key's cell lives: dense window, or (job, virtual cell) -> the job's slot -> tile
+template <typename Key>
+__device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
+  if (!a.tables) return (size_t)key;  // the window of a plain call is the bound map, pitch wide
+  int ix, iy;
+  const int job = mu_key_cell<Key>(a, key, &ix, &iy);
+  const int tile = a.tables[(size_t)a.jobs[job].slot * a.table_stride + (iy >> kTileShift) * a.tiles_x + (ix >> kTileShift)];
+  return ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+}
+
+template <int RULE>
+__device__ __forceinline__ MuCell mu_cell_load(const MuArgs &a, size_t at) {
+  const double *cell = a.payload + at * a.cell_dbl;
+  MuCell c{cell[0], 0, 0, 0, 0, 0};
+  if (RULE >= 3) {
+    c.c1 = cell[1];
+    c.c2 = cell[2];
+    c.c3 = cell[3];
+  }
+  if (RULE == 2) c.x0 = a.aux[at];
+  if (RULE == 4) {
+    c.x0 = a.aux[2 * at];
+    c.x1 = a.aux[2 * at + 1];
+  }
+  return c;
+}
+
+template <int RULE>
+__device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const MuCell &c) {
+  double *cell = a.payload + at * a.cell_dbl;
+  cell[0] = c.c0;
+  if (RULE >= 3) {
+    cell[1] = c.c1;
+    cell[2] = c.c2;
+    cell[3] = c.c3;
+  }
+  if (RULE == 2) a.aux[at] = c.x0;
+  if (RULE == 4) {
+    a.aux[2 * at] = c.x0;
+    a.aux[2 * at + 1] = c.x1;
+  }
+}
+
+static constexpr unsigned kLongChain = 64;  // chains at least this long go to k_mu_apply_long
+
+__device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Long chains (the robot's own cell takes one update per beam, its neighbours hundreds): one thread
+// walking such a chain pays a memory round trip per 8 records (330 us for 1080 updates).  Here the
+// WAVE that holds the chain's head streams it: 64 records per coalesced load, then every lane applies
+// them in order from broadcast values -- the same sequential arithmetic, executed redundantly by all
+// lanes, so the result is bit-identical to the one-thread walk.  GMapping cells: a run of free
+// observations of a cell whose mean is 0 only counts tries (see mu_step), so the run is skipped in one
+// step from the ballot of the hits -- the chains around the robot are nothing but such runs.
+template <typename Key, int RULE>
+__global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys, unsigned total,
+                                                       unsigned long long *n_updates) {
+  constexpr Key kInvalid = ~Key(0);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  Key key = kInvalid;
+  bool is_long = false;
+  if (i < total) {
+    key = keys[i];
+    const bool head = key != kInvalid && !(i > 0 && keys[i - 1] == key);
+    is_long = head && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key;
+  }
+  unsigned long long todo = __ballot(is_long);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)i, src);
+    const Key hkey = keys[hi];
+    const size_t at = mu_cell_index<Key>(a, hkey);
+    MuCell c = mu_cell_load<RULE>(a, at);
+    unsigned cnt = 0;
+    for (unsigned j0 = hi;; j0 += 64) {
+      const unsigned j = j0 + lane;
+      const bool in = j < total;
+      const Key k = in ? keys[j] : kInvalid;
+      const double p = in ? a.rec_prob[j] : 0.0;
+      const double q = (RULE == 3 && in) ? a.rec_qual[j] : 0.0;
+      const unsigned long long m = __ballot(in && k == hkey);
+      const int n_here = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
+      double ox = 0.0, oy = 0.0;
+      unsigned long long busy = ~0ull;  // records that need arithmetic
+      if (RULE == 4) {
+        const bool hit = in && !(p <= 0.5);  // hits and NaNs
+        if (hit && !isnan(p)) {
+          const unsigned b = a.rec_beam[j];
+          ox = a.beam_end[2 * b];
+          oy = a.beam_end[2 * b + 1];
+        }
+        busy = __ballot(hit);
+      }
+      int t = 0;
+      while (t < n_here) {
+        // (every lane holds the same cell state; the first lane's test keeps `t` wave-uniform)
+        if (RULE == 4 && __builtin_amdgcn_readfirstlane((int)(c.c0 == 0.0))) {  // skip the free run ahead
+          const unsigned long long ahead = busy >> t;
+          const int stop = ahead ? min(n_here, t + __ffsll((long long)ahead) - 1) : n_here;
+          if (stop > t) {
+            c.x1 += (double)(stop - t);
+            c.c0 = 0.0;
+            t = stop;
+            continue;
+          }
+        }
+        mu_step<RULE>(a, c, mu_readlane(p, t), RULE == 3 ? mu_readlane(q, t) : 0.0, [&](double *x, double *y) {
+          *x = mu_readlane(ox, t);
+          *y = mu_readlane(oy, t);
+        });
+        ++t;
+      }
+      cnt += (unsigned)n_here;
+      if (n_here < 64) break;
+    }
+    if (lane == src) {
+      mu_cell_store<RULE>(a, at, c);
+      atomicAdd(&n_updates[blockIdx.x & (kNuSlots - 1)], (unsigned long long)cnt);
+    }
+  }
+}
+
+// chains shorter than kLongChain: one thread per distinct cell applies its records sequentially
+template <typename Key, int RULE>
+__global__ void k_mu_apply(MuArgs a, const Key *keys, unsigned total, unsigned long long *n_updates) {
+  constexpr Key kInvalid = ~Key(0);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const Key key = keys[i];
+  if (key == kInvalid) return;
+  if (i > 0 && keys[i - 1] == key) return;  // not the head of this cell's run
+  if (i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) return;  // k_mu_apply_long's
+  const size_t at = mu_cell_index<Key>(a, key);
+  MuCell c = mu_cell_load<RULE>(a, at);
+  unsigned cnt = 0;
+  // The chain is sequential (each update reads the previous result), but its INPUTS are not: they are
+  // fetched eight records ahead so that the in-order wave pays memory latency once per chunk.
+  constexpr int CH = 8;
+  bool more = true;
+  for (unsigned j0 = i; more && j0 < total; j0 += CH) {
+    Key kk[CH];
+    double pp[CH], qq[CH];
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const unsigned j = min(j0 + t, total - 1);
+      kk[t] = (j0 + t < total) ? keys[j] : kInvalid;
+      pp[t] = a.rec_prob[j];
+      qq[t] = RULE == 3 ? a.rec_qual[j] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      if (!more) continue;
+      if (kk[t] != key) {
+        more = false;
+        continue;
+      }
+      ++cnt;
+      mu_step<RULE>(a, c, pp[t], qq[t], [&](double *x, double *y) {
+        const unsigned b = a.rec_beam[j0 + t];
+        *x = a.beam_end[2 * b];
+        *y = a.beam_end[2 * b + 1];
+      });
+    }
+  }
+  mu_cell_store<RULE>(a, at, c);
+  // the update count is spread over kNuSlots counters: one shared word made every wave of the grid
+  // queue on the same L2 line (2.9 of 3.4 ms in a 100-particle batch, profiles/r01)
+  atomicAdd(&n_updates[blockIdx.x & (kNuSlots - 1)], (unsigned long long)cnt);
+}
+
+// both apply kernels for the cell kind of `a.rule`
+template <typename Key>
+void mu_launch_apply(const MuArgs &a, const Key *keys, unsigned total, unsigned long long *n_updates,
+                     hipStream_t stream) {
+  const dim3 grid((total + 255) / 256), block(256);
+#define SLAMHIP_MU_RULE(R)                                                                                   \
+  case R:                                                                                                    \
+    hipLaunchKernelGGL((k_mu_apply_long<Key, R>), grid, block, 0, stream, a, keys, total, n_updates);        \
+    hipLaunchKernelGGL((k_mu_apply<Key, R>), grid, block, 0, stream, a, keys, total, n_updates);             \
+    break;
+  switch (a.rule) {
+    SLAMHIP_MU_RULE(0)
+    SLAMHIP_MU_RULE(1)
+    SLAMHIP_MU_RULE(2)
+    SLAMHIP_MU_RULE(3)
+    default:
+      SLAMHIP_MU_RULE(4)
+  }
+#undef SLAMHIP_MU_RULE
+}
+
+}  // namespace slamhip
