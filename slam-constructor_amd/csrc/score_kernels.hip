@@ -270,7 +270,15 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   double *s_val = s_dyn;
   int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kBlock);
   int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
-  const int p0 = ONE ? (int)blockIdx.x : blockIdx.x * a.poses_per_block;
+  // Per-particle maps: workgroups go to the 8 XCDs round-robin by index, and consecutive poses read the
+  // same particle's tiles.  Handing XCD x the x-th CONTIGUOUS eighth of the poses keeps a particle's
+  // tiles in one L2 instead of all eight (the launch rounds the grid up to a multiple of 8).
+  int vb = (int)blockIdx.x;
+  if (a.xcd_blocks) {
+    vb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (vb >= a.xcd_blocks) return;
+  }
+  const int p0 = ONE ? vb : vb * a.poses_per_block;
   const int npb = ONE ? 1 : min(a.poses_per_block, a.n_poses - p0);
 
   if (t < npb) {
@@ -692,11 +700,19 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
                         hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   ScoreArgs a = args;
   if (a.n_poses <= 0) return hipSuccess;
-  if (a.poses_per_block <= 0) a.poses_per_block = pick_poses_per_block(a.n_poses);
+  if (a.poses_per_block <= 0) {
+    a.poses_per_block = pick_poses_per_block(a.n_poses);
+    // K3 up to a couple of thousand poses does not fill the chip's wave slots, and the poses of a
+    // workgroup run one after the other: one pose per workgroup (100-particle filter step 1.69 -> 1.66 ms)
+    static const int gm_one_below = getenv("SLAMHIP_K3_ONE_BELOW") ? atoi(getenv("SLAMHIP_K3_ONE_BELOW")) : 2048;
+    if (oope == SLAMHIP_OOPE_GMAPPING && a.n_poses < gm_one_below) a.poses_per_block = 1;
+  }
   if (a.poses_per_block > kMaxPosesPerBlock) a.poses_per_block = kMaxPosesPerBlock;
   const dim3 grid((a.n_poses + a.poses_per_block - 1) / a.poses_per_block);
   const int kb = (a.scan.n + kBlock - 1) / kBlock;
   const bool wt = sum_order == SLAMHIP_SUM_SEQUENTIAL;
+  static const bool xcd_off = getenv("SLAMHIP_K3_XCD") && getenv("SLAMHIP_K3_XCD")[0] == '0';
+  a.xcd_blocks = 0;
   if (wt && oope != SLAMHIP_OOPE_GMAPPING && (ev_start || ev_stop)) return hipErrorInvalidValue;
   const hipEvent_t stop1 = ev_stop;
   hipError_t e = hipSuccess;
@@ -714,6 +730,11 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
                      : (wide_env && wide_env[0] == '1') ? 512
                      : (a.n_poses <= wide_below ? 1024 : 0);
     const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int);
+    dim3 grid_gm = grid;  // k_score_gmapping only: the XCD-chunked block order (see the kernel)
+    if (a.tables && !xcd_off && grid.x >= 16 && !(a.poses_per_block == 1 && wide)) {
+      a.xcd_blocks = (int)grid.x;
+      grid_gm.x = (grid.x + 7) / 8 * 8;
+    }
 #define GM_CASE(K)                                                                                            \
   case K:                                                                                                     \
     if (a.poses_per_block == 1 && wide == 1024)                                                               \
@@ -721,9 +742,9 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
     else if (a.poses_per_block == 1 && wide == 512)                                                           \
       SLAMHIP_LAUNCH((k_score_gmapping_wide<K, 512>), grid, dim3(512), shm_wide, stream, ev_start, ev_stop, a); \
     else if (a.poses_per_block == 1)                                                                          \
-      SLAMHIP_LAUNCH((k_score_gmapping<K, true>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);     \
+      SLAMHIP_LAUNCH((k_score_gmapping<K, true>), grid_gm, dim3(kBlock), shm, stream, ev_start, ev_stop, a);  \
     else                                                                                                      \
-      SLAMHIP_LAUNCH((k_score_gmapping<K, false>), grid, dim3(kBlock), shm, stream, ev_start, ev_stop, a);    \
+      SLAMHIP_LAUNCH((k_score_gmapping<K, false>), grid_gm, dim3(kBlock), shm, stream, ev_start, ev_stop, a); \
     break;
     switch (kb < 1 ? 1 : kb) {
       GM_CASE(1) GM_CASE(2) GM_CASE(3) GM_CASE(4) GM_CASE(5) GM_CASE(6) GM_CASE(7) GM_CASE(8)

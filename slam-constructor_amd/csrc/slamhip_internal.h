@@ -65,6 +65,7 @@ struct ScoreArgs {
   const int *tables;
   const int *pose_slot;
   int table_stride;
+  int xcd_blocks;  // set by launch_score: > 0 = the real block count of an XCD-chunked grid
 };
 
 // tiles of the copy-on-write maps: 128 x 128 cells like the reference's LazyTiledGridMap
