@@ -324,11 +324,16 @@ __device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int 
 // probability here so that the chains of k_mu_apply read one double per record.
 template <typename Key>
 __global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *beam_sorted, unsigned total,
-                            double *srt_prob, double *srt_qual) {
+                            double *srt_prob, double *srt_qual, unsigned long long *n_padding) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const Key key = keys_sorted[i];
-  if (key == ~Key(0)) return;  // padding of a walk that ended early: never applied
+  if (key == ~Key(0)) {  // padding of a walk that ended early, or a cell outside the map: never applied
+    // (counted: the number of cell updates is the number of records that are not padding -- counting
+    // them in k_mu_apply instead cost one atomic per cell, 2/3 of that kernel)
+    atomicAdd(&n_padding[blockIdx.x & (kNuSlots - 1)], 1ull);
+    return;
+  }
   const int b = (int)beam_sorted[i];
   int ix, iy;
   mu_key_cell<Key>(a, key, &ix, &iy);
@@ -430,35 +435,31 @@ __device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
 
 template <int RULE>
 __device__ __forceinline__ MuCell mu_cell_load(const MuArgs &a, size_t at) {
-  const double *cell = a.payload + at * a.cell_dbl;
-  MuCell c{cell[0], 0, 0, 0, 0, 0};
-  if (RULE >= 3) {
-    c.c1 = cell[1];
-    c.c2 = cell[2];
-    c.c3 = cell[3];
+  MuCell c{0, 0, 0, 0, 0, 0};
+  if (RULE >= 3) {  // 4 doubles per cell: one 32-byte load
+    const double4 v = reinterpret_cast<const double4 *>(a.payload)[at];
+    c.c0 = v.x;
+    c.c1 = v.y;
+    c.c2 = v.z;
+    c.c3 = v.w;
+  } else {
+    c.c0 = a.payload[at];
   }
   if (RULE == 2) c.x0 = a.aux[at];
   if (RULE == 4) {
-    c.x0 = a.aux[2 * at];
-    c.x1 = a.aux[2 * at + 1];
+    const double2 x = reinterpret_cast<const double2 *>(a.aux)[at];
+    c.x0 = x.x;
+    c.x1 = x.y;
   }
   return c;
 }
 
 template <int RULE>
 __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const MuCell &c) {
-  double *cell = a.payload + at * a.cell_dbl;
-  cell[0] = c.c0;
-  if (RULE >= 3) {
-    cell[1] = c.c1;
-    cell[2] = c.c2;
-    cell[3] = c.c3;
-  }
+  if (RULE >= 3) reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
+  else a.payload[at] = c.c0;
   if (RULE == 2) a.aux[at] = c.x0;
-  if (RULE == 4) {
-    a.aux[2 * at] = c.x0;
-    a.aux[2 * at + 1] = c.x1;
-  }
+  if (RULE == 4) reinterpret_cast<double2 *>(a.aux)[at] = make_double2(c.x0, c.x1);
 }
 
 static constexpr unsigned kLongChain = 64;  // chains at least this long go to k_mu_apply_long
@@ -477,8 +478,7 @@ __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is 
 // observations of a cell whose mean is 0 only counts tries (see mu_step), so the run is skipped in one
 // step from the ballot of the hits -- the chains around the robot are nothing but such runs.
 template <typename Key, int RULE>
-__global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys, unsigned total,
-                                                       unsigned long long *n_updates) {
+__global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys, unsigned total) {
   constexpr Key kInvalid = ~Key(0);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -497,7 +497,6 @@ __global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys
     const Key hkey = keys[hi];
     const size_t at = mu_cell_index<Key>(a, hkey);
     MuCell c = mu_cell_load<RULE>(a, at);
-    unsigned cnt = 0;
     for (unsigned j0 = hi;; j0 += 64) {
       const unsigned j = j0 + lane;
       const bool in = j < total;
@@ -536,73 +535,90 @@ __global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys
         });
         ++t;
       }
-      cnt += (unsigned)n_here;
       if (n_here < 64) break;
     }
-    if (lane == src) {
-      mu_cell_store<RULE>(a, at, c);
-      atomicAdd(&n_updates[blockIdx.x & (kNuSlots - 1)], (unsigned long long)cnt);
-    }
+    if (lane == src) mu_cell_store<RULE>(a, at, c);
   }
 }
 
-// chains shorter than kLongChain: one thread per distinct cell applies its records sequentially
+// Chains shorter than kLongChain: one thread per distinct cell -- the one holding the chain's first record --
+// applies its records in order.  The records of a chain sit in the lanes behind their head: every lane
+// loads its own key and observation (coalesced), the heads pull them across with a lane shuffle per
+// step, and only a chain that runs past the end of its wave reads the rest from memory.
 template <typename Key, int RULE>
-__global__ void k_mu_apply(MuArgs a, const Key *keys, unsigned total, unsigned long long *n_updates) {
+__global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, unsigned total) {
   constexpr Key kInvalid = ~Key(0);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const Key key = keys[i];
-  if (key == kInvalid) return;
-  if (i > 0 && keys[i - 1] == key) return;  // not the head of this cell's run
-  if (i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) return;  // k_mu_apply_long's
-  const size_t at = mu_cell_index<Key>(a, key);
-  MuCell c = mu_cell_load<RULE>(a, at);
-  unsigned cnt = 0;
-  // The chain is sequential (each update reads the previous result), but its INPUTS are not: they are
-  // fetched eight records ahead so that the in-order wave pays memory latency once per chunk.
-  constexpr int CH = 8;
-  bool more = true;
-  for (unsigned j0 = i; more && j0 < total; j0 += CH) {
-    Key kk[CH];
-    double pp[CH], qq[CH];
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const unsigned j = min(j0 + t, total - 1);
-      kk[t] = (j0 + t < total) ? keys[j] : kInvalid;
-      pp[t] = a.rec_prob[j];
-      qq[t] = RULE == 3 ? a.rec_qual[j] : 0.0;
-    }
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      if (!more) continue;
-      if (kk[t] != key) {
-        more = false;
-        continue;
-      }
-      ++cnt;
-      mu_step<RULE>(a, c, pp[t], qq[t], [&](double *x, double *y) {
-        const unsigned b = a.rec_beam[j0 + t];
+  const int lane = threadIdx.x & 63;
+  const bool in = i < total;
+  const Key key = in ? keys[i] : kInvalid;
+  const double p = in ? a.rec_prob[i] : 0.0;
+  const double q = (RULE == 3 && in) ? a.rec_qual[i] : 0.0;
+  Key prev = __shfl_up(key, 1, 64);
+  if (lane == 0) prev = (in && i > 0) ? keys[i - 1] : kInvalid;
+  const bool start = !in || i == 0 || prev != key;  // first record of a run of equal keys
+  const unsigned long long starts = __ballot(start);
+  bool head = start && key != kInvalid;
+  // the run ends in front of the next start; none behind this lane: it reaches the end of the wave
+  const unsigned long long behind = lane == 63 ? 0ull : starts >> (lane + 1);
+  const int len_here = behind ? __ffsll((long long)behind) : 64 - lane;
+  const bool open_end = !behind;  // may continue in the next wave
+  if (head && open_end && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) head = false;  // k_mu_apply_long's
+  size_t at = 0;
+  MuCell c{0, 0, 0, 0, 0, 0};
+  if (head) {
+    at = mu_cell_index<Key>(a, key);
+    c = mu_cell_load<RULE>(a, at);
+  }
+  for (int t = 0; __any(head && t < len_here); ++t) {
+    const double pt = __shfl(p, lane + t, 64);
+    const double qt = RULE == 3 ? __shfl(q, lane + t, 64) : 0.0;
+    if (head && t < len_here)
+      mu_step<RULE>(a, c, pt, qt, [&](double *x, double *y) {
+        const unsigned b = a.rec_beam[i + t];
         *x = a.beam_end[2 * b];
         *y = a.beam_end[2 * b + 1];
       });
+  }
+  if (head && open_end) {  // the rest of a chain that crosses into the next wave(s), eight records ahead
+    constexpr int CH = 8;
+    bool more = true;
+    for (unsigned j0 = i + len_here; more && j0 < total; j0 += CH) {
+      Key kk[CH];
+      double pp[CH], qq[CH];
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        const unsigned j = min(j0 + t, total - 1);
+        kk[t] = (j0 + t < total) ? keys[j] : kInvalid;
+        pp[t] = a.rec_prob[j];
+        qq[t] = RULE == 3 ? a.rec_qual[j] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < CH; ++t) {
+        if (!more) continue;
+        if (kk[t] != key) {
+          more = false;
+          continue;
+        }
+        mu_step<RULE>(a, c, pp[t], qq[t], [&](double *x, double *y) {
+          const unsigned b = a.rec_beam[j0 + t];
+          *x = a.beam_end[2 * b];
+          *y = a.beam_end[2 * b + 1];
+        });
+      }
     }
   }
-  mu_cell_store<RULE>(a, at, c);
-  // the update count is spread over kNuSlots counters: one shared word made every wave of the grid
-  // queue on the same L2 line (2.9 of 3.4 ms in a 100-particle batch, profiles/r01)
-  atomicAdd(&n_updates[blockIdx.x & (kNuSlots - 1)], (unsigned long long)cnt);
+  if (head) mu_cell_store<RULE>(a, at, c);
 }
 
 // both apply kernels for the cell kind of `a.rule`
 template <typename Key>
-void mu_launch_apply(const MuArgs &a, const Key *keys, unsigned total, unsigned long long *n_updates,
-                     hipStream_t stream) {
+void mu_launch_apply(const MuArgs &a, const Key *keys, unsigned total, hipStream_t stream) {
   const dim3 grid((total + 255) / 256), block(256);
 #define SLAMHIP_MU_RULE(R)                                                                                   \
   case R:                                                                                                    \
-    hipLaunchKernelGGL((k_mu_apply_long<Key, R>), grid, block, 0, stream, a, keys, total, n_updates);        \
-    hipLaunchKernelGGL((k_mu_apply<Key, R>), grid, block, 0, stream, a, keys, total, n_updates);             \
+    hipLaunchKernelGGL((k_mu_apply_long<Key, R>), grid, block, 0, stream, a, keys, total);                   \
+    hipLaunchKernelGGL((k_mu_apply<Key, R>), grid, block, 0, stream, a, keys, total);                        \
     break;
   switch (a.rule) {
     SLAMHIP_MU_RULE(0)

@@ -65,7 +65,7 @@ int main() {
   CK(hipMalloc(&k_out, 8 * n));
   CK(hipMalloc(&v_in, 4 * n));
   CK(hipMalloc(&v_out, 4 * n));
-  for (unsigned bits : {28u, 29u, 32u}) {
+  for (unsigned bits : {29u}) {
     fill<unsigned><<<(n + 255) / 256, 256>>>(k_in, v_in, n, bits);
     hipDeviceSynchronize();
     if (run<rocprim::default_config, unsigned>("default", n, bits, k_in, k_out, v_in, v_out)) return 1;
@@ -82,6 +82,35 @@ int main() {
     hipDeviceSynchronize();
     if (run<rocprim::default_config, unsigned long long>("default", n, 36, k64, k64o, v_in, v_out)) return 1;
     if (run<Cfg<8, 256, 12>, unsigned long long>("rb8 256x12", n, 36, k64, k64o, v_in, v_out)) return 1;
+  }
+  {  // the batch as 100 segments (the records arrive grouped by job): segmented sort by the 21 cell bits,
+     // against one global stable sort by the cell bits alone (chains then come out as (cell, job))
+    const unsigned segs = 100;
+    std::vector<unsigned> h_off(segs + 1);
+    for (unsigned k = 0; k <= segs; ++k) h_off[k] = (unsigned)((unsigned long long)n * k / segs);
+    unsigned *d_off;
+    CK(hipMalloc(&d_off, sizeof(unsigned) * (segs + 1)));
+    CK(hipMemcpy(d_off, h_off.data(), sizeof(unsigned) * (segs + 1), hipMemcpyHostToDevice));
+    fill<unsigned><<<(n + 255) / 256, 256>>>(k_in, v_in, n, 21);
+    hipDeviceSynchronize();
+    size_t tb = 0;
+    CK(rocprim::segmented_radix_sort_pairs(nullptr, tb, k_in, k_out, v_in, v_out, n, segs, d_off, d_off + 1, 0, 21, 0));
+    void *tmp;
+    CK(hipMalloc(&tmp, tb));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    CK(rocprim::segmented_radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, n, segs, d_off, d_off + 1, 0, 21, 0));
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < 5; ++r)
+      CK(rocprim::segmented_radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, n, segs, d_off, d_off + 1, 0, 21, 0));
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("segmented 100 x %zu, 21 bits: %8.1f us\n", n / segs, ms / 5 * 1e3);
+    if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("global, cell bits only", n, 21, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<7, 1024, 8, kMatch>, unsigned>("global rb7, cell bits only", n, 21, k_in, k_out, v_in, v_out)) return 1;
   }
   // the single-scan size: merge sort (default below 1M items) against onesweep
   for (size_t m : {(size_t)200000, (size_t)600000}) {
