@@ -1,0 +1,193 @@
+"""GPU suite: K6 map update on crafted scans -- the corners of the walk and of the chain kernels that a
+random scene seldom visits -- against the oracle, all five cell kinds, bit-exact:
+  * poses on cell corners / centres with beams along the axes and diagonals and endpoints on grid lines
+    (the fuzzy tie rule of world_to_cells, regular_squares_grid.h:74-98; diagonal steps; the Bresenham
+    fail-over when rounding sends the walk astray);
+  * a bundle of identical beams (every cell of the bundle is a chain of several hundred records:
+    k_mu_apply_long, chains that cross wave boundaries, GMapping free runs interrupted by hits);
+  * zero-length beams, beams beyond max_range, empty observations, negative (range-proportional) blur;
+  * beams whose walk goes astray and is redone by DiscreteSegment2D (found by a seeded search with a plain
+    Python restatement of the walk: end points a hair off grid corners)."""
+import math
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+# name -> (cell model, rule, host stride, aux doubles)
+KINDS = {"last": (0, 0, 1, 0), "affine": (0, 1, 1, 0), "mean": (0, 2, 1, 1), "tbm": (1, 3, 4, 0), "gmapping": (2, 4, 3, 2)}
+SCALE = 0.1
+SIZE = 400
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def crafted_scans():
+    """(pose, range, angle, is_occ, blur, max_range) tuples."""
+    out = []
+    dirs = np.deg2rad(np.arange(0, 360, 45.0))
+    r2 = np.sqrt(2.0)
+    # 1. corner / centre poses, axis and diagonal beams, endpoints on grid lines and cell centres
+    for px, py in [(0.0, 0.0), (SCALE / 2, SCALE / 2), (3 * SCALE, -2 * SCALE), (0.05, 0.0), (1.0, 1.0)]:
+        ang, rng = [], []
+        for a in dirs:
+            diag = abs(np.sin(2 * a)) > 0.5
+            for cells in (0, 1, 7, 30, 77):
+                ang.append(a)
+                rng.append(cells * SCALE * (r2 if diag else 1.0))
+        out.append((np.array([px, py, 0.0]), np.array(rng), np.array(ang), np.ones(len(rng), np.int32), 0.0, np.inf))
+        out.append((np.array([px, py, np.deg2rad(45.0)]), np.array(rng), np.array(ang),
+                    (np.arange(len(rng)) % 3 != 0).astype(np.int32), 0.25, np.inf))
+    # 2. bundles of identical beams: chains of 200 / 333 records on every cell of the bundle, free and
+    #    occupied observations mixed, blur on; a second bundle ends INSIDE the first one's free run
+    for n, a_deg, rr in [(200, 30.0, 9.0), (333, 200.0, 12.3)]:
+        ang = np.full(n, np.deg2rad(a_deg))
+        rng = np.full(n, rr)
+        rng[n // 3::7] = rr * 0.5          # hits on cells the other beams pass through
+        occ = (np.arange(n) % 5 != 0).astype(np.int32)
+        out.append((np.array([0.31, -0.17, 0.2]), rng, ang, occ, 0.3, np.inf))
+    # 3. a dense fan (every beam crosses the robot's cell and its neighbours: long and short chains mixed)
+    ang = np.linspace(-np.pi, np.pi, 720, endpoint=False)
+    rs = np.random.RandomState(5)
+    rng = 2.0 + 14.0 * rs.rand(720)
+    out.append((np.array([-1.234, 2.345, 1.0]), rng, ang, (rs.rand(720) < 0.8).astype(np.int32), 0.2, np.inf))
+    # 4. zero-length beams, beams beyond max_range (dropped), negative blur = proportional to range^2
+    rng = np.array([0.0, 0.0, 5.0, 25.0, 1e-9, 7.5, 19.99, 20.01])
+    ang = np.deg2rad(np.array([0.0, 90.0, 10.0, 20.0, 30.0, 40.0, 50.0, 60.0]))
+    out.append((np.array([0.2, 0.2, 0.0]), rng, ang, np.ones(8, np.int32), -0.004, 20.0))
+    return out
+
+
+def _walk_goes_astray(scale, x0, y0, x1, y1):
+    """world_to_cells (regular_squares_grid.h:56-101) up to its decision to fall back to Bresenham."""
+    def eq(a, b):
+        return abs(a - b) <= 1e-7 * max(1.0, abs(a), abs(b))
+    dx, dy = x1 - x0, y1 - y0
+    ix, iy = (1 if 0 < dx else -1), (1 if 0 < dy else -1)
+    px, py = math.floor(x0 / scale), math.floor(y0 / scale)
+    ex, ey = math.floor(x1 / scale), math.floor(y1 / scale)
+    cells = abs(ex - px) + abs(ey - py) + 1
+    e = (dx * y0 + ((px + 0.5) * scale - x0) * dy) - (py + 0.5) * scale * dx
+    exi, eyi = ix * scale * dy, -iy * scale * dx
+    n = 0
+    while True:
+        n += 1
+        if px == ex and py == ey:
+            return False
+        if cells < n:
+            return True
+        e_x, e_y = e + exi, e + eyi
+        d = abs(e_y) - abs(e_x)
+        if eq(d, 0):
+            if px == ex:
+                py += iy
+            elif py == ey:
+                px += ix
+            else:
+                px, py = px + ix, py + iy
+            e = 0
+        elif 0 < d:
+            px, e = px + ix, e_x
+        else:
+            py, e = py + iy, e_y
+
+
+def astray_scans(n_scans=4, beams=64):
+    """Scans (pose with heading 0, unit ranges, the beam's `cos` / `sin` entries carrying the end point's
+    offset) whose every beam makes the walk fall back to Bresenham."""
+    rs = np.random.RandomState(3)
+    tiny = [0, 1e-17, -1e-17, 1e-15, -1e-15, 1e-13, -1e-13, 1e-9, -1e-9, 1e-7, -1e-7, 3e-8, -3e-8, 1e-6, -1e-6]
+    out = []
+    while len(out) < n_scans:
+        x0 = rs.randint(-40, 40) * SCALE * rs.choice([1, 0.5]) + rs.choice(tiny)
+        y0 = rs.randint(-40, 40) * SCALE * rs.choice([1, 0.5]) + rs.choice(tiny)
+        dxs, dys = [], []
+        for _ in range(20000):
+            dx = rs.randint(-150, 150) * SCALE + rs.choice(tiny) - x0
+            dy = rs.randint(-150, 150) * SCALE + rs.choice(tiny) - y0
+            if _walk_goes_astray(SCALE, x0, y0, x0 + 1.0 * dx, y0 + 1.0 * dy):
+                dxs.append(dx)
+                dys.append(dy)
+                if len(dxs) == beams:
+                    break
+        if len(dxs) == beams:
+            out.append((np.array([x0, y0, 0.0]), np.array(dxs), np.array(dys)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["mean", "gmapping"])
+def test_astray_walks_vs_oracle(pkg, ctx, name):
+    import pyoracle as po
+    from pyoracle_mapupdate import append_scan_ex
+    O = po.Oracle()
+    cell_model, rule, st, n_aux = KINDS[name]
+    unknown = {0: [0.5], 2: [-1.0, 0.0, 0.0]}[cell_model]
+    payload = np.empty((SIZE, SIZE, st))
+    payload[:] = unknown
+    m = po.GridMapData(cell_model, payload, (SIZE // 2, SIZE // 2), SCALE, unknown)
+    aux = np.zeros((SIZE, SIZE, n_aux))
+    ctx.upload_map(3, m)
+    scans = astray_scans()
+    assert len(scans) == 4
+    for pose, c, s in scans:
+        rng = np.ones(c.size)
+        tr = po.ScanData(rng, np.zeros(c.size), None, None, po.TRIG_CACHED, 0.0, 1.0, s, c)
+        tr.angle = np.arange(c.size, dtype=np.float64)
+        nu_o = append_scan_ex(O, m, aux, rule, pose, rng, tr.angle, None, quality=0.8, blur=0.0, trig=tr)
+        nu = ctx.map_append_scan(3, rule, pose, rng, c, s, None, quality=0.8, blur=0.0)
+        assert nu == nu_o
+        got = ctx.map_download_window(3, 0, 0, SIZE, SIZE, st)
+        np.testing.assert_array_equal(got[..., 0], m.payload[..., 0])
+        np.testing.assert_allclose(got, m.payload, rtol=1e-13, atol=1e-15)
+        np.testing.assert_array_equal(ctx.map_download_aux(3, 0, 0, SIZE, SIZE, n_aux), aux)
+    ctx.map_release(3)
+
+
+@pytest.mark.parametrize("name", list(KINDS))
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_crafted_scans_vs_oracle(pkg, ctx, name, estimator):
+    import pyoracle as po
+    from pyoracle_mapupdate import append_scan_ex
+    O = po.Oracle()
+    cell_model, rule, st, n_aux = KINDS[name]
+    unknown = {0: [0.5], 1: [1.0, 0.0, 0.0, 0.0], 2: [-1.0, 0.0, 0.0]}[cell_model]
+    payload = np.empty((SIZE, SIZE, st))
+    payload[:] = unknown
+    m = po.GridMapData(cell_model, payload, (SIZE // 2, SIZE // 2), SCALE, unknown)
+    aux = np.zeros((SIZE, SIZE, max(n_aux, 1)))
+    ctx.upload_map(3, m)
+    for k, (pose, rng, ang, occ, blur, max_range) in enumerate(crafted_scans()):
+        for rep in range(2):  # twice: the second pass meets non-trivial cell states (hits, counters)
+            c, s = pkg.beam_trig(ang)
+            tr = po.ScanData(rng, ang, None, None, po.TRIG_CACHED, 0.0, 1.0, s, c)
+            tr.angle = np.arange(rng.size, dtype=np.float64)
+            nu_o = append_scan_ex(O, m, aux if n_aux else None, rule, pose, rng, tr.angle, occ, quality=0.8, blur=blur,
+                                  max_range=max_range, trig=tr, est_kind=estimator, shift_amount=0.01 * SCALE)
+            nu = ctx.map_append_scan(3, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range,
+                                     estimator=estimator, shift_amount=0.01 * SCALE)
+            assert nu == nu_o, "scan %d pass %d" % (k, rep)
+            got = ctx.map_download_window(3, 0, 0, SIZE, SIZE, st)
+            if estimator == 1 or name == "gmapping":
+                # obstacle means / area splits depend continuously on the endpoint: same tolerance as the
+                # reference-golden tests; occupancy of const-estimator cells is exact
+                if estimator == 0:
+                    np.testing.assert_array_equal(got[..., 0], m.payload[..., 0], err_msg="scan %d pass %d" % (k, rep))
+                np.testing.assert_allclose(got, m.payload, rtol=1e-11, atol=1e-13, err_msg="scan %d pass %d" % (k, rep))
+            else:
+                np.testing.assert_array_equal(got, m.payload, err_msg="scan %d pass %d" % (k, rep))
+            if n_aux:
+                np.testing.assert_array_equal(ctx.map_download_aux(3, 0, 0, SIZE, SIZE, n_aux), aux[..., :n_aux])
+    ctx.map_release(3)

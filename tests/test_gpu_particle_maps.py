@@ -81,7 +81,12 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None):
     return pf, log, (ox, oy, w, h)
 
 
-def test_particle_maps_filter_vs_oracle(pkg, oracle):
+@pytest.mark.parametrize("key64", [False, True])
+def test_particle_maps_filter_vs_oracle(pkg, oracle, key64, monkeypatch):
+    """key64: the batched map update with 8-byte (particle, cell) sort keys -- the fall-back for batches
+    whose particle and key-window bits exceed 32 -- forced through SLAMHIP_K6_KEY64."""
+    if key64:
+        monkeypatch.setenv("SLAMHIP_K6_KEY64", "1")
     n = 8
     pf, log, (ox, oy, w, h) = run_both(pkg, oracle, n=n)
     st = log[-1][1]
