@@ -222,7 +222,13 @@ __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int 
 // (tile_pool.h): m.payload is then the tile pool and m.width/height the virtual extent.
 __device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *tiles, const GmParams &gp,
                                                  int cx, int cy, double ox, double oy) {
-  double best = 0.0;
+  // The value is the maximum over the window's full cells of 1 - (1 - exp(-d^2 / 0.05)), d = distance
+  // from the cell's obstacle mean to the beam's end point.  That function falls with d^2, so the
+  // maximum belongs to the smallest d^2: the window only tracks that, and ONE exp is evaluated per beam.
+  // (An exp per full cell -- up to nine per beam next to a wall, executed by the whole wave as soon as
+  // one lane needs it -- was 4.5 of the 10 us of this phase in a lone launch.)
+  double best_d2 = __builtin_inf();
+  bool any = false;
   const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
   for (int dx = -gp.window; dx <= gp.window; ++dx) {
     for (int dy = -gp.window; dy <= gp.window; ++dy) {
@@ -242,12 +248,17 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *ti
       }
       if (occ < gp.fullness_th) continue;
       const double ddx = obx - ox, ddy = oby - oy;
-      const double similarity = exp(-(ddx * ddx + ddy * ddy) / 0.05);
-      const double v = 1.0 - (1.0 - similarity);
-      best = best < v ? v : best;
+      const double d2 = ddx * ddx + ddy * ddy;
+      if (d2 < best_d2) {  // (a NaN obstacle never wins, like `best < v` before)
+        best_d2 = d2;
+        any = true;
+      }
     }
   }
-  return best;
+  if (!any) return 0.0;
+  const double similarity = exp(-best_d2 / 0.05);
+  const double v = 1.0 - (1.0 - similarity);
+  return 0.0 < v ? v : 0.0;
 }
 
 // Run-cache quirk (Q19): in beam order every maximal run of equal endpoint cells takes the value
@@ -350,7 +361,11 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
       const bool start = (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
       mask[k] = __ballot(start);
       if (lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
-      if (start && b > 0) atomicMin(&s_run0_len, b);
+      // first run start behind beam 0: one LDS atomic per wave, from the ballot (one per starting beam --
+      // in a real scan nearly every beam -- queued a thousand lanes on the one word: 8 of a lone
+      // launch's 21 us)
+      const unsigned long long later = g == 0 ? mask[k] & ~1ull : mask[k];
+      if (lane == 0 && later) atomicMin(&s_run0_len, 64 * g + __ffsll((long long)later) - 1);
     }
     __syncthreads();
     // phase C: resolve run heads, accumulate in the canonical order
@@ -486,7 +501,8 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
     const bool start = act && (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
     mask[k] = __ballot(start);
     if (act && lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
-    if (start && b > 0) atomicMin(&s_run0_len, b);
+    const unsigned long long later = g == 0 ? mask[k] & ~1ull : mask[k];  // see k_score_gmapping
+    if (lane == 0 && later) atomicMin(&s_run0_len, 64 * g + __ffsll((long long)later) - 1);
   }
   __syncthreads();
   double acc = 0.0;
