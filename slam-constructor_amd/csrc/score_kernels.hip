@@ -220,6 +220,60 @@ __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int 
 // does not matter for a max of finite values.
 // `tiles`: null = dense window (m.pitch); else the tile table of the pose's own copy-on-write map
 // (tile_pool.h): m.payload is then the tile pool and m.width/height the virtual extent.
+// The 3 x 3 window (slam/scmtch/oope/window = 1, every shipped configuration).  A thread's time in K3 is
+// its chain of dependent loads: the generic loop below pays one round trip per window cell (two with a
+// tile table in front), one after the other -- 9 x KB round trips per pose, ~30 of a launch's 37 us.
+// Here the nine cells are fetched whole (32 bytes) with independent loads, behind at most four
+// tile-table entries (the window's corners), and reduced with selects: two round trips per beam.
+__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const int *tiles, const GmParams &gp,
+                                                    int cx, int cy, double ox, double oy) {
+  const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+  int t00 = 0, t01 = 0, t10 = 0, t11 = 0, txl = 0, tyl = 0;
+  if (tiles) {
+    const int tiles_y = m.height >> kTileShift;
+    txl = min(max(ix0 - 1, 0) >> kTileShift, m.pitch - 1);
+    tyl = min(max(iy0 - 1, 0) >> kTileShift, tiles_y - 1);
+    const int txh = min(max(ix0 + 1, 0) >> kTileShift, m.pitch - 1);
+    const int tyh = min(max(iy0 + 1, 0) >> kTileShift, tiles_y - 1);
+    t00 = tiles[tyl * m.pitch + txl];
+    t01 = tiles[tyl * m.pitch + txh];
+    t10 = tiles[tyh * m.pitch + txl];
+    t11 = tiles[tyh * m.pitch + txh];
+  }
+  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
+  const double4 unknown = make_double4(m.unknown[0], m.unknown[1], m.unknown[2], 0.0);
+  double4 v[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
+    const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+    size_t at;
+    if (tiles) {
+      const bool lo_x = (ix >> kTileShift) == txl, lo_y = (iy >> kTileShift) == tyl;
+      const int tile = lo_y ? (lo_x ? t00 : t01) : (lo_x ? t10 : t11);
+      at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+    } else {
+      at = (size_t)iy * m.pitch + ix;
+    }
+    v[i] = unknown;
+    if (inb) v[i] = cells[at];
+  }
+  double best_d2 = __builtin_inf();
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double ddx = v[i].y - ox, ddy = v[i].z - oy;
+    const double d2 = ddx * ddx + ddy * ddy;
+    const bool better = !(v[i].x < gp.fullness_th) && d2 < best_d2;
+    best_d2 = better ? d2 : best_d2;
+    any |= better;
+  }
+  if (!any) return 0.0;
+  const double similarity = exp(-best_d2 / 0.05);
+  const double r = 1.0 - (1.0 - similarity);
+  return 0.0 < r ? r : 0.0;
+}
+
 __device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *tiles, const GmParams &gp,
                                                  int cx, int cy, double ox, double oy) {
   // The value is the maximum over the window's full cells of 1 - (1 - exp(-d^2 / 0.05)), d = distance
@@ -227,6 +281,7 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *ti
   // maximum belongs to the smallest d^2: the window only tracks that, and ONE exp is evaluated per beam.
   // (An exp per full cell -- up to nine per beam next to a wall, executed by the whole wave as soon as
   // one lane needs it -- was 4.5 of the 10 us of this phase in a lone launch.)
+  if (gp.window == 1) return gm_fresh_value_w1(m, tiles, gp, cx, cy, ox, oy);
   double best_d2 = __builtin_inf();
   bool any = false;
   const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
