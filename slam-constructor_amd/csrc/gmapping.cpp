@@ -148,19 +148,21 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
   int rc = ensure_pose_capacity(ctx, (per_job_budget + 1) * n_jobs);
   if (rc) return rc;
   if (g->tp) g->tt.tables = g->tp->d_table();  // the table buffer flips on resampling
-  // Optional (SLAMHIP_PF_PIPELINE=1): two groups of jobs take turns -- while the GPU scores one
-  // group's batch the host replays and re-plans the other.  Each group owns one window of the staging
-  // buffers; jobs are independent, so the interleaving changes no result.  Measured at 100 particles:
-  // 1.82 -> 1.73 ms per step only, because two half-size K3 launches take 2 x 33 us against 40 us for
-  // the full one (the launches are latency-bound), and the kernel's roofline fraction drops from 0.41
-  // to 0.26 -- so the default stays one full launch per round.
-  static const bool pipeline_ok = getenv("SLAMHIP_PF_PIPELINE") && getenv("SLAMHIP_PF_PIPELINE")[0] == '1';
-  const int n_groups = (pipeline_ok && ctx->low_latency && !ctx->stage_poses && n_jobs >= 16) ? 2 : 1;
+  // Groups of jobs take turns (SLAMHIP_PF_PIPELINE = number of groups, default 2; 1 = one launch per
+  // round): while the GPU scores one group's batch the host replays and re-plans another.  Each group
+  // owns one window of the staging buffers; jobs are independent, so the interleaving changes no
+  // result.  Measured at 100 particles: with the first K3 (40 us per full launch, two half launches
+  // 2 x 33 us) the pipeline gained 5 % and stayed off; with the present K3 (25 us per full launch against
+  // ~35 us of host work per round) it hides most of the host: 1.24 -> 0.98 ms per step.
+  static const int groups_env = getenv("SLAMHIP_PF_PIPELINE") ? atoi(getenv("SLAMHIP_PF_PIPELINE")) : 2;
+  constexpr int kMaxGroups = 4;
+  const int n_groups = (ctx->low_latency && !ctx->stage_poses && n_jobs >= 16)
+                           ? std::max(1, std::min(kMaxGroups, groups_env)) : 1;
   struct Group {
     int lo, hi, base, total;
     unsigned seq;
     bool in_flight;
-  } grp[2];
+  } grp[kMaxGroups];
   for (int q = 0; q < n_groups; ++q) {
     grp[q].lo = q * n_jobs / n_groups;
     grp[q].hi = (q + 1) * n_jobs / n_groups;
@@ -187,7 +189,12 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
     rc = plan_and_submit(grp[q]);
     if (rc) return rc;
   }
-  while (grp[0].in_flight || (n_groups > 1 && grp[1].in_flight)) {
+  auto any_in_flight = [&]() {
+    for (int q = 0; q < n_groups; ++q)
+      if (grp[q].in_flight) return true;
+    return false;
+  };
+  while (any_in_flight()) {
     for (int q = 0; q < n_groups; ++q) {
       Group &G = grp[q];
       if (!G.in_flight) continue;
