@@ -128,20 +128,18 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
   const int p0 = blockIdx.x * a.poses_per_block;
   const int npb = min(a.poses_per_block, a.n_poses - p0);
 
+  // the pose comes over PCIe from the pinned staging buffer: its loads are issued first and the scan
+  // constants' (HBM) right behind them, so the two latencies overlap; sincos waits for the pose only
+  double pose_x = 0.0, pose_y = 0.0, pose_th = 0.0, pose_sn = 0.0, pose_cs = 0.0;
   if (t < npb) {
     const int p = p0 + t;
-    const double th = a.poses[3 * p + 2];
-    double sn, cs;
+    pose_th = a.poses[3 * p + 2];
+    pose_x = a.poses[3 * p];
+    pose_y = a.poses[3 * p + 1];
     if (a.pose_sc) {
-      sn = a.pose_sc[2 * p];
-      cs = a.pose_sc[2 * p + 1];
-    } else {
-      sincos(th, &sn, &cs);
+      pose_sn = a.pose_sc[2 * p];
+      pose_cs = a.pose_sc[2 * p + 1];
     }
-    s_pose[t][0] = a.poses[3 * p];
-    s_pose[t][1] = a.poses[3 * p + 1];
-    s_pose[t][2] = sn;
-    s_pose[t][3] = cs;
   }
 
   constexpr int KR = KB > 0 ? KB : 1;
@@ -157,6 +155,13 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
       bw[k] = ok ? a.scan.weight[b] : 0.0;
       bf[k] = ok ? a.scan.factor[b] : 0.0;
     }
+  }
+  if (t < npb) {
+    if (!a.pose_sc) sincos(pose_th, &pose_sn, &pose_cs);
+    s_pose[t][0] = pose_x;
+    s_pose[t][1] = pose_y;
+    s_pose[t][2] = pose_sn;
+    s_pose[t][3] = pose_cs;
   }
   __syncthreads();
 
@@ -347,20 +352,17 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   const int p0 = ONE ? vb : vb * a.poses_per_block;
   const int npb = ONE ? 1 : min(a.poses_per_block, a.n_poses - p0);
 
+  // pose loads (PCIe) first, the scan constants' right behind them: see k_score_point
+  double pose_x = 0.0, pose_y = 0.0, pose_th = 0.0, pose_sn = 0.0, pose_cs = 0.0;
   if (t < npb) {
     const int p = p0 + t;
-    const double th = a.poses[3 * p + 2];
-    double sn, cs;
+    pose_th = a.poses[3 * p + 2];
+    pose_x = a.poses[3 * p];
+    pose_y = a.poses[3 * p + 1];
     if (a.pose_sc) {
-      sn = a.pose_sc[2 * p];
-      cs = a.pose_sc[2 * p + 1];
-    } else {
-      sincos(th, &sn, &cs);
+      pose_sn = a.pose_sc[2 * p];
+      pose_cs = a.pose_sc[2 * p + 1];
     }
-    s_pose[t][0] = a.poses[3 * p];
-    s_pose[t][1] = a.poses[3 * p + 1];
-    s_pose[t][2] = sn;
-    s_pose[t][3] = cs;
   }
   double br[KB], bc[KB], bs[KB], bw[KB], bf[KB];
 #pragma unroll
@@ -374,6 +376,13 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
     // 4 KB of VGPRs across the gathers
     bw[k] = (ok && !ONE) ? a.scan.weight[b] : 0.0;
     bf[k] = (ok && !ONE) ? a.scan.factor[b] : 0.0;
+  }
+  if (t < npb) {
+    if (!a.pose_sc) sincos(pose_th, &pose_sn, &pose_cs);
+    s_pose[t][0] = pose_x;
+    s_pose[t][1] = pose_y;
+    s_pose[t][2] = pose_sn;
+    s_pose[t][3] = pose_cs;
   }
   __syncthreads();
 
@@ -495,28 +504,34 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
   int *s_cx = s_grp_start + 4 * KB;
   int *s_cy = s_cx + KB * kBlock;
   const int p = blockIdx.x;
+  // pose loads (PCIe) first, every thread's first beam right behind them: see k_score_point
+  double pose_x = 0.0, pose_y = 0.0, pose_th = 0.0, pose_sn = 0.0, pose_cs = 0.0;
   if (t == 0) {
-    const double th = a.poses[3 * p + 2];
-    double sn, cs;
+    pose_th = a.poses[3 * p + 2];
+    pose_x = a.poses[3 * p];
+    pose_y = a.poses[3 * p + 1];
     if (a.pose_sc) {
-      sn = a.pose_sc[2 * p];
-      cs = a.pose_sc[2 * p + 1];
-    } else {
-      sincos(th, &sn, &cs);
+      pose_sn = a.pose_sc[2 * p];
+      pose_cs = a.pose_sc[2 * p + 1];
     }
-    s_pose1[0] = a.poses[3 * p];
-    s_pose1[1] = a.poses[3 * p + 1];
-    s_pose1[2] = sn;
-    s_pose1[3] = cs;
+  }
+  const bool has0 = t < n;
+  const double r0 = has0 ? a.scan.range[t] : 0.0, ca0 = has0 ? a.scan.cos_a[t] : 0.0, sa0 = has0 ? a.scan.sin_a[t] : 0.0;
+  if (t == 0) {
+    if (!a.pose_sc) sincos(pose_th, &pose_sn, &pose_cs);
+    s_pose1[0] = pose_x;
+    s_pose1[1] = pose_y;
+    s_pose1[2] = pose_sn;
+    s_pose1[3] = pose_cs;
     s_run0_len = n;
   }
   __syncthreads();
   const double x = s_pose1[0], y = s_pose1[1], sn = s_pose1[2], cs = s_pose1[3];
   const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   const int *tiles = a.tables ? a.tables + (size_t)a.pose_slot[p] * a.table_stride : nullptr;
-  // phase A over all 512 threads
+  // phase A over all threads
   for (int b = t; b < n; b += NT) {
-    const double r = a.scan.range[b], ca = a.scan.cos_a[b], sa = a.scan.sin_a[b];
+    const double r = b == t ? r0 : a.scan.range[b], ca = b == t ? ca0 : a.scan.cos_a[b], sa = b == t ? sa0 : a.scan.sin_a[b];
     const double c = cs * ca - sn * sa;
     const double s = sn * ca + cs * sa;
     const double wx = x + r * c;
