@@ -264,9 +264,14 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   while (nbits < 32 && ((1ull << nbits) - 1) <= (unsigned long long)m.pitch * m.height) ++nbits;
   SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted,
                                           total, 0, nbits, ctx->stream));
-  hipLaunchKernelGGL(k_mu_gather<unsigned>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
-                     (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
-                     sc.srt_qual, sc.n_updates);
+  if (a.est_kind == 1)
+    hipLaunchKernelGGL((k_mu_gather<unsigned, 1>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                       (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
+                       sc.srt_qual, sc.n_updates);
+  else
+    hipLaunchKernelGGL((k_mu_gather<unsigned, 0>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                       (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
+                       sc.srt_qual, sc.n_updates);
   a.rec_prob = sc.srt_prob;
   a.rec_qual = sc.srt_qual;
   a.rec_beam = sc.order_sorted;
@@ -365,8 +370,12 @@ int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t be
   SLAMHIP_CHECK(rocprim::radix_sort_pairs<BatchSortConfig<Key>>(sc.temp, tb, keys, keys_sorted, sc.order,
                                                                 sc.order_sorted, total, 0,
                                                                 std::min(end_bit, (unsigned)(8 * sizeof(Key))), st));
-  hipLaunchKernelGGL(k_mu_gather<Key>, rgrid, dim3(256), 0, st, a, (const Key *)keys_sorted,
-                     (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr, sc.n_updates);
+  if (a.est_kind == 1)
+    hipLaunchKernelGGL((k_mu_gather<Key, 1>), rgrid, dim3(256), 0, st, a, (const Key *)keys_sorted,
+                       (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr, sc.n_updates);
+  else
+    hipLaunchKernelGGL((k_mu_gather<Key, 0>), rgrid, dim3(256), 0, st, a, (const Key *)keys_sorted,
+                       (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr, sc.n_updates);
   mu_launch_apply<Key>(a, (const Key *)keys_sorted, total, st);
   return SLAMHIP_OK;
 }

@@ -7,9 +7,10 @@ namespace slamhip {
 // per-beam quantities of WallDistanceBlurringScanAdder::handle_scan_point (grid_map_scan_adders.h:138-172),
 // computed once per beam by k_mu_count and read by the walk and by every record of the beam
 struct MuBeam {
-  double base_prob, base_qual;  // occupancy of the obstacle cell, estimated first like the reference
-  double hole_dist_sq, obst_dist_sq;
-  int ex, ey;  // obstacle (end) cell
+  int ex, ey;        // obstacle (end) cell
+  double base_prob;  // occupancy of the obstacle cell, estimated first like the reference
+  double base_qual;
+  double hole_dist_sq, obst_dist_sq;  // (read only when the adder blurs: the first 16 bytes serve the rest)
 };
 
 struct MuArgs {
@@ -295,11 +296,14 @@ __device__ __forceinline__ int mu_key_cell(const MuArgs &a, Key key, int *ix, in
 }
 
 // the observation a beam makes of one of its cells: (prob, qual)
-__device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int cy, const MuBeam &bm) {
-  const int ocx = bm.ex, ocy = bm.ey;
+template <int EST>
+__device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int cy, const MuBeam *pbm) {
+  const int2 oc = *reinterpret_cast<const int2 *>(&pbm->ex);
+  const int ocx = oc.x, ocy = oc.y;
+  const MuBeam &bm = *pbm;
   if (cx == ocx && cy == ocy) return make_double2(bm.base_prob, bm.base_qual);
   double prob = a.base_empty_prob, qual = a.base_empty_qual;
-  if (a.est_kind == 1) {
+  if (EST == 1) {
     const MuJob jb = mu_job(a, b);
     const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
     const ae::ae_rect cb{a.scale * cy, a.scale * (cy + 1), a.scale * cx, a.scale * (cx + 1)};
@@ -308,11 +312,13 @@ __device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int 
     prob = o.prob;
     qual = o.qual;
   }
-  const double cdx = cx - ocx, cdy = cy - ocy;
-  const double dist_sq = cdx * cdx + cdy * cdy;
-  if (dist_sq < bm.hole_dist_sq && bm.hole_dist_sq < bm.obst_dist_sq) {
-    const double prob_scale = 1.0 - dist_sq / bm.hole_dist_sq;
-    prob = bm.base_prob * prob_scale;
+  if (a.blur != 0.0) {  // (no blur: hole_dist_sq is 0 and the test below never holds)
+    const double cdx = cx - ocx, cdy = cy - ocy;
+    const double dist_sq = cdx * cdx + cdy * cdy;
+    if (dist_sq < bm.hole_dist_sq && bm.hole_dist_sq < bm.obst_dist_sq) {
+      const double prob_scale = 1.0 - dist_sq / bm.hole_dist_sq;
+      prob = bm.base_prob * prob_scale;
+    }
   }
   return make_double2(prob, qual);
 }
@@ -322,7 +328,9 @@ __device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int 
 // probability; TBM cells also take the estimate's quality): an observation whose quality is NaN is
 // dropped by every cell kind but GridCell, which never looks at it -- that is folded into a NaN
 // probability here so that the chains of k_mu_apply read one double per record.
-template <typename Key>
+// (EST: the occupancy estimator is a template parameter -- the area estimator's rectangle clipping needs
+// 208 bytes of scratch per lane, which the const estimator's instance should not carry)
+template <typename Key, int EST>
 __global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *beam_sorted, unsigned total,
                             double *srt_prob, double *srt_qual, unsigned long long *n_padding) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,8 +345,7 @@ __global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *be
   const int b = (int)beam_sorted[i];
   int ix, iy;
   mu_key_cell<Key>(a, key, &ix, &iy);
-  const MuBeam bm = a.beam_info[b];
-  double2 pq = mu_value(a, b, ix - a.origin_x, iy - a.origin_y, bm);
+  double2 pq = mu_value<EST>(a, b, ix - a.origin_x, iy - a.origin_y, a.beam_info + b);
   if (a.rule == 3) srt_qual[i] = pq.y;
   else if (a.rule != 0 && isnan(pq.y)) pq.x = pq.y;
   srt_prob[i] = pq.x;
