@@ -24,8 +24,8 @@
 //      reference's update order for that cell
 //   5. k_mu_gather  one thread per sorted record: the observation (occupancy estimate, blur) of its
 //                   (beam, cell) pair -- 8 bytes per record, TBM cells 16
-//   6. k_mu_apply   one thread per distinct cell applies its records sequentially; k_mu_apply_long
-//                   streams chains of >= 64 records through a whole wave
+//   6. k_mu_apply   one thread per distinct cell applies its records sequentially; chains of >= 64
+//                   records are then streamed through the whole wave that holds their head
 // HBM traffic: per (beam, cell) an 8-byte (key, beam) pair written, sorted and read, one 8-byte
 // observation written and read, plus one read-modify-write of the cell (8-48 bytes) per distinct cell.
 // The kernels live in map_update_kernels.h; this file holds the two host drivers (one scan into a bound

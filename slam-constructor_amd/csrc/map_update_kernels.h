@@ -469,7 +469,7 @@ __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const 
   if (RULE == 4) reinterpret_cast<double2 *>(a.aux)[at] = make_double2(c.x0, c.x1);
 }
 
-static constexpr unsigned kLongChain = 64;  // chains at least this long go to k_mu_apply_long
+static constexpr unsigned kLongChain = 64;  // chains at least this long are streamed by a whole wave
 
 __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -479,23 +479,15 @@ __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is 
 
 // Long chains (the robot's own cell takes one update per beam, its neighbours hundreds): one thread
 // walking such a chain pays a memory round trip per 8 records (330 us for 1080 updates).  Here the
-// WAVE that holds the chain's head streams it: 64 records per coalesced load, then every lane applies
+// WAVE that holds the chain's head streams it (at the end of k_mu_apply, after its short chains): 64 records per coalesced load, then every lane applies
 // them in order from broadcast values -- the same sequential arithmetic, executed redundantly by all
 // lanes, so the result is bit-identical to the one-thread walk.  GMapping cells: a run of free
 // observations of a cell whose mean is 0 only counts tries (see mu_step), so the run is skipped in one
 // step from the ballot of the hits -- the chains around the robot are nothing but such runs.
 template <typename Key, int RULE>
-__global__ __launch_bounds__(256) void k_mu_apply_long(MuArgs a, const Key *keys, unsigned total) {
+__device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key *keys, unsigned total, unsigned i,
+                                                     int lane, bool is_long) {
   constexpr Key kInvalid = ~Key(0);
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  Key key = kInvalid;
-  bool is_long = false;
-  if (i < total) {
-    key = keys[i];
-    const bool head = key != kInvalid && !(i > 0 && keys[i - 1] == key);
-    is_long = head && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key;
-  }
   unsigned long long todo = __ballot(is_long);
   while (todo) {
     const int src = __ffsll((long long)todo) - 1;
@@ -570,7 +562,11 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
   const unsigned long long behind = lane == 63 ? 0ull : starts >> (lane + 1);
   const int len_here = behind ? __ffsll((long long)behind) : 64 - lane;
   const bool open_end = !behind;  // may continue in the next wave
-  if (head && open_end && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) head = false;  // k_mu_apply_long's
+  bool is_long = false;
+  if (head && open_end && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) {
+    head = false;  // a long chain: streamed by the whole wave below
+    is_long = true;
+  }
   size_t at = 0;
   MuCell c{0, 0, 0, 0, 0, 0};
   if (head) {
@@ -616,15 +612,15 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
     }
   }
   if (head) mu_cell_store<RULE>(a, at, c);
+  mu_apply_long_chains<Key, RULE>(a, keys, total, i, lane, is_long);
 }
 
-// both apply kernels for the cell kind of `a.rule`
+// the apply kernel for the cell kind of `a.rule`
 template <typename Key>
 void mu_launch_apply(const MuArgs &a, const Key *keys, unsigned total, hipStream_t stream) {
   const dim3 grid((total + 255) / 256), block(256);
 #define SLAMHIP_MU_RULE(R)                                                                                   \
   case R:                                                                                                    \
-    hipLaunchKernelGGL((k_mu_apply_long<Key, R>), grid, block, 0, stream, a, keys, total);                   \
     hipLaunchKernelGGL((k_mu_apply<Key, R>), grid, block, 0, stream, a, keys, total);                        \
     break;
   switch (a.rule) {
