@@ -223,39 +223,51 @@ __global__ void k_mu_emit(MuArgs a) {
     bad |= oob;
     out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
   };
-  // The main walk, one exit test per cell.  Position, key and bounds test advance incrementally; the step
-  // is computed before the exit test (and discarded with it), so the loop body has no inner branch.
+  // The main walk, one exit test per cell.  Position and key advance incrementally; the step is computed
+  // before the exit test (and discarded with it) and built from selects, so the loop body is one basic
+  // block.  A beam whose two end cells lie inside the map cannot leave it (the walk is monotone between
+  // them; an astray walk is discarded), so only the others carry the per-cell bounds test.
   // The reference's loop (regular_squares_grid.h:74-98) emits at most `cap` cells, then takes one more
-  // step and gives up unless that lands on the end cell: `astray` below.
+  // step and gives up unless that lands on the end cell: `failover` below.
   unsigned ix = (unsigned)(px + a.origin_x), iy = (unsigned)(py + a.origin_y);
+  const unsigned exi = (unsigned)(ex + a.origin_x), eyi = (unsigned)(ey + a.origin_y);
   KeyT key = job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
   const KeyT key_dx = (KeyT)(long long)inc_x, key_dy = (KeyT)((long long)inc_y * (long long)row);
+  const unsigned uinc_x = (unsigned)inc_x, uinc_y = (unsigned)inc_y;
   unsigned n = 0;
-  bool reached;
-  do {
-    const bool oob = ix >= w || iy >= h;
-    bad |= oob;
-    out[n] = oob ? ~KeyT(0) : key;
-    ++n;
-    const double e_x = e + e_x_inc, e_y = e + e_y_inc;
-    const double abs_err_diff = fabs(e_y) - fabs(e_x);
-    const bool tie = mu_are_equal(abs_err_diff, 0);
-    const bool x_wins = 0 < abs_err_diff;
-    // tie: the diagonal step, degenerating to the one open axis at the end row / column
-    // (bitwise on purpose: selects, not branches)
-    const bool at_x = px == ex, at_y = py == ey;
-    reached = at_x & at_y;
-    const bool move_x = (tie & !at_x) | (!tie & x_wins);
-    const bool move_y = (tie & (at_x | !at_y)) | (!tie & !x_wins);
-    px += move_x ? inc_x : 0;
-    py += move_y ? inc_y : 0;
-    ix += move_x ? (unsigned)inc_x : 0u;
-    iy += move_y ? (unsigned)inc_y : 0u;
-    key += (move_x ? key_dx : KeyT(0)) + (move_y ? key_dy : KeyT(0));
-    e = tie ? 0.0 : (x_wins ? e_x : e_y);
-  } while (!reached && n < cap);
+  bool reached = false;
+  auto walk = [&](auto checked) {
+    constexpr bool CHECK = decltype(checked)::value;
+    do {
+      if (CHECK) {
+        const bool oob = ix >= w || iy >= h;
+        bad |= oob;
+        out[n] = oob ? ~KeyT(0) : key;
+      } else {
+        out[n] = key;
+      }
+      ++n;
+      const double e_x = e + e_x_inc, e_y = e + e_y_inc;
+      const double abs_err_diff = fabs(e_y) - fabs(e_x);
+      const bool tie = mu_are_equal(abs_err_diff, 0);
+      const bool x_wins = 0 < abs_err_diff;
+      const bool at_x = ix == exi, at_y = iy == eyi;
+      reached = at_x & at_y;
+      // 0 / all-ones step masks; tie: the diagonal step, degenerating to the one open axis at the end
+      // row / column
+      const unsigned tie_x = at_x ? 0u : ~0u, tie_y = (at_x | !at_y) ? ~0u : 0u;
+      const unsigned win_x = x_wins ? ~0u : 0u;
+      const unsigned mx = tie ? tie_x : win_x, my = tie ? tie_y : ~win_x;
+      ix += mx & uinc_x;
+      iy += my & uinc_y;
+      key += ((KeyT)(long long)(int)mx & key_dx) + ((KeyT)(long long)(int)my & key_dy);
+      e = tie ? 0.0 : (x_wins ? e_x : e_y);
+    } while (!reached && n < cap);
+  };
+  if (ix < w && iy < h && exi < w && eyi < h) walk(std::false_type{});
+  else walk(std::true_type{});
   // fp rounding sent the walk astray: the reference restarts with Bresenham
-  const bool failover = !reached && !(px == ex && py == ey);
+  const bool failover = !reached && !(ix == exi && iy == eyi);
   if (failover) {
     bad = false;  // the discarded walk touched nothing
     const int dxx = ex - bx, dyy = ey - by;
