@@ -51,11 +51,6 @@ struct MuArgs {
   const unsigned *rec_beam;
 };
 
-__device__ __forceinline__ bool mu_are_equal(double a, double b) {
-  const double m = fmax(fabs(a), fabs(b));
-  return fabs(a - b) <= 1e-7 * fmax(1.0, m);
-}
-
 // thread g of the beam kernels handles beam g % n of job g / n (a plain call is one job)
 __device__ __forceinline__ MuJob mu_job(const MuArgs &a, int g) {
   if (a.jobs) return a.jobs[g / a.n];
@@ -249,7 +244,8 @@ __global__ void k_mu_emit(MuArgs a) {
       ++n;
       const double e_x = e + e_x_inc, e_y = e + e_y_inc;
       const double abs_err_diff = fabs(e_y) - fabs(e_x);
-      const bool tie = mu_are_equal(abs_err_diff, 0);
+      // are_equal(d, 0) = |d| <= 1e-7 max(1, |d|) (math_utils.h:15-25): for finite d that is |d| <= 1e-7
+      const bool tie = fabs(abs_err_diff) <= 1e-7;
       const bool x_wins = 0 < abs_err_diff;
       const bool at_x = ix == exi, at_y = iy == eyi;
       reached = at_x & at_y;
