@@ -46,8 +46,6 @@
 
 namespace slamhip {
 
-static constexpr int kNuSlots = 1024;  // update counters (summed on the host)
-
 // one scan appended from one pose into one map slot; a batch appends the SAME scan from many poses
 // (the particles of the filter), each into its own copy-on-write map (tile_pool.h)
 struct MuJob {
@@ -70,7 +68,8 @@ struct MuScratch {
   MuBeam *beam_info = nullptr;
   double *srt_prob = nullptr, *srt_qual = nullptr;  // sorted records
   int *occ = nullptr, *error_flag = nullptr;
-  unsigned long long *n_updates = nullptr;
+  unsigned long long *n_updates = nullptr;  // one word: padding records of the update
+  unsigned long long *h_status = nullptr;   // pinned: (error flag, padding records) of the last update
   void *temp = nullptr;
   // scan re-use (see slamhip_map_append_scan)
   bool reuse_ok = false;
@@ -104,6 +103,31 @@ namespace {
 int fail(const char *msg, int code = SLAMHIP_ERR_INVALID) {
   set_error(msg);
   return code;
+}
+
+// waits for the update queued on the context's stream and returns its status words
+int mu_finish(slamhip_ctx *ctx, const int *d_error_flag, const unsigned long long *d_n_padding,
+              unsigned long long *h_status, int *err, unsigned long long *n_padding) {
+  if (ctx->low_latency) {
+    unsigned seq = ++ctx->seq;
+    if (seq == 0) seq = ++ctx->seq;
+    hipLaunchKernelGGL(k_mu_finish, dim3(1), dim3(1), 0, ctx->stream, d_error_flag, d_n_padding, h_status,
+                       ctx->h_done_flag, seq);
+    SLAMHIP_CHECK(hipGetLastError());
+    const int rc = score_wait(ctx, seq);
+    if (rc) return rc;
+    *err = (int)((volatile unsigned long long *)h_status)[0];
+    *n_padding = ((volatile unsigned long long *)h_status)[1];
+    return SLAMHIP_OK;
+  }
+  int e = 0;
+  unsigned long long np = 0;
+  SLAMHIP_CHECK(hipMemcpyAsync(&e, d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(&np, d_n_padding, sizeof(np), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *err = e;
+  *n_padding = np;
+  return SLAMHIP_OK;
 }
 }  // namespace
 
@@ -152,7 +176,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
     if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
-    if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long) * kNuSlots));
+    if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+    if (!sc.h_status) SLAMHIP_CHECK(hipHostMalloc(&sc.h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault));
     sc.cap_beams = cap;
   }
   const size_t cb = sc.cap_beams;
@@ -171,8 +196,6 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     sc.last_occ = is_occ;
     sc.last_n = n;
   }
-  SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), ctx->stream));
-  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long) * kNuSlots, ctx->stream));
 
   MuArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -210,6 +233,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.beam_end = sc.beam_end;
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
+  a.n_padding = sc.n_updates;
 
   const dim3 bgrid((n + 255) / 256);
   hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, ctx->stream, a);
@@ -267,22 +291,22 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   if (a.est_kind == 1)
     hipLaunchKernelGGL((k_mu_gather<unsigned, 1>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
                        (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
-                       sc.srt_qual, sc.n_updates);
+                       sc.srt_qual);
   else
     hipLaunchKernelGGL((k_mu_gather<unsigned, 0>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
                        (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
-                       sc.srt_qual, sc.n_updates);
+                       sc.srt_qual);
   a.rec_prob = sc.srt_prob;
   a.rec_qual = sc.srt_qual;
   a.rec_beam = sc.order_sorted;
   mu_launch_apply<unsigned>(a, (const unsigned *)sc.keys_sorted, total, ctx->stream);
   SLAMHIP_CHECK(hipGetLastError());
   int err = 0;
-  unsigned long long nus[kNuSlots], nu = 0;
-  SLAMHIP_CHECK(hipMemcpyAsync(&err, sc.error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(nus, sc.n_updates, sizeof(nus), hipMemcpyDeviceToHost, ctx->stream));
-  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < kNuSlots; ++k) nu += nus[k];  // padding records
+  unsigned long long nu = 0;  // padding records
+  {
+    const int rc = mu_finish(ctx, sc.error_flag, sc.n_updates, sc.h_status, &err, &nu);
+    if (rc) return rc;
+  }
   nu = (unsigned long long)total - nu;
   if (n_updates_out) *n_updates_out = (long long)nu;
   if (err)
@@ -321,7 +345,7 @@ struct MuBatchScratch {
   int *occ = nullptr, *error_flag = nullptr;
   MuJob *d_jobs = nullptr;
   int *d_bbox = nullptr;
-  unsigned long long *n_updates = nullptr, *d_total = nullptr;
+  unsigned long long *n_updates = nullptr, *d_total = nullptr, *h_status = nullptr;
   void *temp = nullptr, *scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
 };
@@ -372,10 +396,10 @@ int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t be
                                                                 std::min(end_bit, (unsigned)(8 * sizeof(Key))), st));
   if (a.est_kind == 1)
     hipLaunchKernelGGL((k_mu_gather<Key, 1>), rgrid, dim3(256), 0, st, a, (const Key *)keys_sorted,
-                       (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr, sc.n_updates);
+                       (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr);
   else
     hipLaunchKernelGGL((k_mu_gather<Key, 0>), rgrid, dim3(256), 0, st, a, (const Key *)keys_sorted,
-                       (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr, sc.n_updates);
+                       (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr);
   mu_launch_apply<Key>(a, (const Key *)keys_sorted, total, st);
   return SLAMHIP_OK;
 }
@@ -454,7 +478,8 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
     sc.cap_jobs = cap;
   }
   if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
-  if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long) * kNuSlots));
+  if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+  if (!sc.h_status) SLAMHIP_CHECK(hipHostMalloc(&sc.h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault));
   if (!sc.d_total) SLAMHIP_CHECK(hipMalloc(&sc.d_total, sizeof(unsigned long long)));
   auto ensure_records = [&](unsigned need_records) -> int {
     if (need_records <= sc.cap_records) return SLAMHIP_OK;
@@ -486,8 +511,6 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, st));
   SLAMHIP_CHECK(hipMemcpyAsync(sc.d_jobs, jobs.data(), sizeof(MuJob) * n_jobs, hipMemcpyHostToDevice, st));
   SLAMHIP_CHECK(hipMemcpyAsync(sc.d_bbox, bbox.data(), sizeof(int) * 4 * n_jobs, hipMemcpyHostToDevice, st));
-  SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), st));
-  SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long) * kNuSlots, st));
 
   MuArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -526,6 +549,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   a.beam_end = sc.beam_end;
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
+  a.n_padding = sc.n_updates;
 
   const dim3 bgrid((unsigned)((beams + 255) / 256));
   a.job_bbox = sc.d_bbox;
@@ -594,11 +618,9 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   if (rc) return rc;
   SLAMHIP_CHECK(hipGetLastError());
   int err = 0;
-  unsigned long long nus[kNuSlots], nu = 0;
-  SLAMHIP_CHECK(hipMemcpyAsync(&err, sc.error_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-  SLAMHIP_CHECK(hipMemcpyAsync(nus, sc.n_updates, sizeof(nus), hipMemcpyDeviceToHost, st));
-  SLAMHIP_CHECK(hipStreamSynchronize(st));
-  for (int k = 0; k < kNuSlots; ++k) nu += nus[k];  // padding records
+  unsigned long long nu = 0;  // padding records
+  rc = mu_finish(ctx, sc.error_flag, sc.n_updates, sc.h_status, &err, &nu);
+  if (rc) return rc;
   nu = (unsigned long long)total - nu;
   if (n_updates_out) *n_updates_out = (long long)nu;
   if (err)
@@ -617,6 +639,7 @@ void mu_release(slamhip_ctx *ctx) {
                     (void *)s.srt_prob, (void *)s.srt_qual, (void *)s.occ, (void *)s.error_flag,
                     (void *)s.n_updates, s.temp})
       if (p) hipFree(p);
+    if (s.h_status) hipHostFree(s.h_status);
     g_scratch.erase(g_scratch.begin() + i);
     break;
   }
@@ -628,6 +651,7 @@ void mu_release(slamhip_ctx *ctx) {
                     (void *)s.srt_prob, (void *)s.occ, (void *)s.error_flag,
                     (void *)s.d_jobs, (void *)s.d_bbox, (void *)s.n_updates, (void *)s.d_total, s.temp, s.scan_temp})
       if (p) hipFree(p);
+    if (s.h_status) hipHostFree(s.h_status);
     g_bscratch.erase(g_bscratch.begin() + i);
     break;
   }

@@ -45,7 +45,8 @@ struct MuArgs {
   unsigned *counts, *offsets;  // per beam
   MuBeam *beam_info;  // per beam
   double *beam_end;   // 2 per beam (the obstacle point of its observations)
-  int *error_flag;    // set when a touched cell lies outside the window
+  int *error_flag;    // set when a touched cell lies outside the window (k_mu_count clears both)
+  unsigned long long *n_padding;  // records that are padding or outside the map: not cell updates
   // the SORTED records (k_mu_gather -> k_mu_apply*): observation, TBM only its quality, the beam
   const double *rec_prob, *rec_qual;
   const unsigned *rec_beam;
@@ -95,6 +96,10 @@ __device__ __forceinline__ MuBeam mu_beam(const MuArgs &a, const MuJob &jb, int 
 
 __global__ void k_mu_count(MuArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g == 0) {  // the status words of this update (later kernels of the stream set them)
+    *a.error_flag = 0;
+    *a.n_padding = 0;
+  }
   const bool in = g < a.n * a.n_jobs;
   unsigned cnt = 0;
   int ocx = 0, ocy = 0;
@@ -340,14 +345,14 @@ __device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int 
 // 208 bytes of scratch per lane, which the const estimator's instance should not carry)
 template <typename Key, int EST>
 __global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *beam_sorted, unsigned total,
-                            double *srt_prob, double *srt_qual, unsigned long long *n_padding) {
+                            double *srt_prob, double *srt_qual) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const Key key = keys_sorted[i];
   if (key == ~Key(0)) {  // padding of a walk that ended early, or a cell outside the map: never applied
     // (counted: the number of cell updates is the number of records that are not padding -- counting
-    // them in k_mu_apply instead cost one atomic per cell, 2/3 of that kernel)
-    atomicAdd(&n_padding[blockIdx.x & (kNuSlots - 1)], 1ull);
+    // them in k_mu_apply instead cost one atomic per cell; padding is rare, one word takes it)
+    atomicAdd(a.n_padding, 1ull);
     return;
   }
   const int b = (int)beam_sorted[i];
@@ -621,6 +626,16 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
   }
   if (head) mu_cell_store<RULE>(a, at, c);
   mu_apply_long_chains<Key, RULE>(a, keys, total, i, lane, is_long);
+}
+
+// Last kernel of an update on the low-latency path: the status words go to pinned host memory and the
+// launch number is published where the host spins (k_publish, score_kernels.hip) -- no copy engine, no
+// hipStreamSynchronize.
+__global__ void k_mu_finish(const int *error_flag, const unsigned long long *n_padding,
+                            unsigned long long *h_status, unsigned *flag, unsigned seq) {
+  h_status[0] = (unsigned long long)*error_flag;
+  h_status[1] = *n_padding;
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the apply kernel for the cell kind of `a.rule`
