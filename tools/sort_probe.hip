@@ -1,5 +1,12 @@
-// sort_probe.hip -- which rocprim onesweep configuration sorts K6's (key, beam) pairs fastest on gfx950?
-// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/sort_probe.hip -o /tmp/sort_probe && /tmp/sort_probe
+// sort_probe.hip -- which rocprim configuration sorts K6's (key, beam) pairs fastest on gfx950?
+// build here, run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/sort_probe.hip -o tools/_build/sort_probe
+// Results of r01 (MI355X), 21.6 M random (4-byte key, 4-byte value) pairs, 29 key bits:
+//   rocprim default 764 us | onesweep 8 bits, 1024x8, match 627 us (used by the batch) | 512x12 match 692 |
+//   256x12 match 952 | 7 bits 512x16 1818 | basic ranking 256x12 3586; 8-byte keys, 36 bits: default 1025 us
+//   21 bits only: 492 us; segmented sort over 100 segments of 216 k: 3152 us
+//   single scan, 22 bits: 170 k pairs merge sort (default) 58 us, onesweep 118 us, merge sort with 4096-item
+//   sort blocks 55 us; 600 k: 139 / 135 / 119 us
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -33,8 +40,7 @@ int run(const char *name, size_t n, unsigned bits, Key *k_in, Key *k_out, unsign
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  printf("%-28s key %zuB n %zu bits %u: %8.1f us  (%.2f TB/s per 2x(key+value) pass-equivalent)\n", name, sizeof(Key), n,
-         bits, ms / reps * 1e3, 0.0);
+  printf("%-28s key %zuB n %zu bits %u: %8.1f us\n", name, sizeof(Key), n, bits, ms / reps * 1e3);
   hipFree(tmp);
   return 0;
 }
@@ -58,62 +64,24 @@ using Cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default
                                                                            rocprim::kernel_config<BS, IPT>, RB, ALG>>;
 constexpr auto kMatch = rocprim::block_radix_rank_algorithm::match;
 
-int main() {
+int main(int argc, char **argv) {
+  const bool big = argc > 1;  // any argument: the batch-size experiments too
   const size_t n = 21600000;
   unsigned *k_in, *k_out, *v_in, *v_out;
   CK(hipMalloc(&k_in, 8 * n));
   CK(hipMalloc(&k_out, 8 * n));
   CK(hipMalloc(&v_in, 4 * n));
   CK(hipMalloc(&v_out, 4 * n));
-  for (unsigned bits : {29u}) {
-    fill<unsigned><<<(n + 255) / 256, 256>>>(k_in, v_in, n, bits);
+  if (big) {
+    fill<unsigned><<<(n + 255) / 256, 256>>>(k_in, v_in, n, 29);
     hipDeviceSynchronize();
-    if (run<rocprim::default_config, unsigned>("default", n, bits, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<8, 256, 12>, unsigned>("rb8 256x12", n, bits, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<8, 256, 16>, unsigned>("rb8 256x16", n, bits, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<8, 512, 12, kMatch>, unsigned>("rb8 512x12 match", n, bits, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("rb8 1024x8 match", n, bits, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<7, 512, 16>, unsigned>("rb7 512x16", n, bits, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<8, 256, 12, kMatch>, unsigned>("rb8 256x12 match", n, bits, k_in, k_out, v_in, v_out)) return 1;
+    if (run<rocprim::default_config, unsigned>("default", n, 29, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<8, 512, 12, kMatch>, unsigned>("rb8 512x12 match", n, 29, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("rb8 1024x8 match", n, 29, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("rb8 1024x8 match", n, 21, k_in, k_out, v_in, v_out)) return 1;
   }
-  {
-    unsigned long long *k64 = (unsigned long long *)k_in, *k64o = (unsigned long long *)k_out;
-    fill<unsigned long long><<<(n + 255) / 256, 256>>>(k64, v_in, n, 36);
-    hipDeviceSynchronize();
-    if (run<rocprim::default_config, unsigned long long>("default", n, 36, k64, k64o, v_in, v_out)) return 1;
-    if (run<Cfg<8, 256, 12>, unsigned long long>("rb8 256x12", n, 36, k64, k64o, v_in, v_out)) return 1;
-  }
-  {  // the batch as 100 segments (the records arrive grouped by job): segmented sort by the 21 cell bits,
-     // against one global stable sort by the cell bits alone (chains then come out as (cell, job))
-    const unsigned segs = 100;
-    std::vector<unsigned> h_off(segs + 1);
-    for (unsigned k = 0; k <= segs; ++k) h_off[k] = (unsigned)((unsigned long long)n * k / segs);
-    unsigned *d_off;
-    CK(hipMalloc(&d_off, sizeof(unsigned) * (segs + 1)));
-    CK(hipMemcpy(d_off, h_off.data(), sizeof(unsigned) * (segs + 1), hipMemcpyHostToDevice));
-    fill<unsigned><<<(n + 255) / 256, 256>>>(k_in, v_in, n, 21);
-    hipDeviceSynchronize();
-    size_t tb = 0;
-    CK(rocprim::segmented_radix_sort_pairs(nullptr, tb, k_in, k_out, v_in, v_out, n, segs, d_off, d_off + 1, 0, 21, 0));
-    void *tmp;
-    CK(hipMalloc(&tmp, tb));
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    CK(rocprim::segmented_radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, n, segs, d_off, d_off + 1, 0, 21, 0));
-    hipEventRecord(e0, 0);
-    for (int r = 0; r < 5; ++r)
-      CK(rocprim::segmented_radix_sort_pairs(tmp, tb, k_in, k_out, v_in, v_out, n, segs, d_off, d_off + 1, 0, 21, 0));
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    printf("segmented 100 x %zu, 21 bits: %8.1f us\n", n / segs, ms / 5 * 1e3);
-    if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("global, cell bits only", n, 21, k_in, k_out, v_in, v_out)) return 1;
-    if (run<Cfg<7, 1024, 8, kMatch>, unsigned>("global rb7, cell bits only", n, 21, k_in, k_out, v_in, v_out)) return 1;
-  }
-  // the single-scan size: merge sort (default below 1M items) against onesweep
-  for (size_t m : {(size_t)200000, (size_t)600000}) {
+  // the single-scan size: merge sort (default below 1 M items) against onesweep and bigger sort blocks
+  for (size_t m : {(size_t)170000, (size_t)600000}) {
     fill<unsigned><<<(m + 255) / 256, 256>>>(k_in, v_in, m, 22);
     hipDeviceSynchronize();
     if (run<rocprim::default_config, unsigned>("default (merge)", m, 22, k_in, k_out, v_in, v_out)) return 1;
@@ -122,11 +90,15 @@ int main() {
                                                                                  rocprim::kernel_config<256, 12>, 8>,
                                              4096>;
     if (run<Force, unsigned>("onesweep rb8 256x12", m, 22, k_in, k_out, v_in, v_out)) return 1;
-    using Force2 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 4>,
-                                                                                  rocprim::kernel_config<256, 4>, 8>,
-                                              4096>;
-    if (run<Force2, unsigned>("onesweep rb8 256x4", m, 22, k_in, k_out, v_in, v_out)) return 1;
+    using M1 = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 8>>;
+    if (run<M1, unsigned>("merge 512x8", m, 22, k_in, k_out, v_in, v_out)) return 1;
+    using M2 = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<1024, 1024, 4>>;
+    if (run<M2, unsigned>("merge 1024x4", m, 22, k_in, k_out, v_in, v_out)) return 1;
+    using M3 = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<256, 256, 16>>;
+    if (run<M3, unsigned>("merge 256x16", m, 22, k_in, k_out, v_in, v_out)) return 1;
+    using M5 = rocprim::radix_sort_config<rocprim::default_config,
+                                          rocprim::merge_sort_config<512, 512, 8, 128, 256, 8, 1 << 14>>;
+    if (run<M5, unsigned>("merge 512x8 mergepath", m, 22, k_in, k_out, v_in, v_out)) return 1;
   }
   return 0;
 }
