@@ -159,15 +159,23 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
   const int n_groups = (ctx->low_latency && !ctx->stage_poses && n_jobs >= 16)
                            ? std::max(1, std::min(kMaxGroups, groups_env)) : 1;
   struct Group {
-    int lo, hi, base, total;
+    int lo, hi, base, total, lane;
     unsigned seq;
     bool in_flight;
   } grp[kMaxGroups];
+  // odd groups launch on the context's second stream: their kernel starts while the even group's is
+  // still draining and publishing (SLAMHIP_PF_LANES=1: everything on one stream)
+  static const bool two_lanes = !(getenv("SLAMHIP_PF_LANES") && getenv("SLAMHIP_PF_LANES")[0] == '1');
+  if (n_groups > 1 && two_lanes) {
+    rc = lane_fork(ctx);
+    if (rc) return rc;
+  }
   for (int q = 0; q < n_groups; ++q) {
     grp[q].lo = q * n_jobs / n_groups;
     grp[q].hi = (q + 1) * n_jobs / n_groups;
     grp[q].base = grp[q].lo * (per_job_budget + 1);
     grp[q].in_flight = false;
+    grp[q].lane = (n_groups > 1 && two_lanes) ? (q & 1) : 0;
   }
   auto plan_and_submit = [&](Group &G) -> int {
     int total = 0;
@@ -183,7 +191,7 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
     if (!total) return SLAMHIP_OK;
     g->launches += 1;
     g->poses_evaluated += total;
-    return score_staged(ctx, map_id, &g->cfg, total, slots ? &g->tt : nullptr, G.base, &G.seq);
+    return score_staged(ctx, map_id, &g->cfg, total, slots ? &g->tt : nullptr, G.base, &G.seq, G.lane);
   };
   for (int q = 0; q < n_groups; ++q) {
     rc = plan_and_submit(grp[q]);
@@ -198,7 +206,7 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
     for (int q = 0; q < n_groups; ++q) {
       Group &G = grp[q];
       if (!G.in_flight) continue;
-      rc = score_wait(ctx, G.seq);
+      rc = score_wait(ctx, G.seq, G.lane);
       if (rc) return rc;
       for (int k = G.lo; k < G.hi; ++k) {
         if (cnt[k] == 0) continue;

@@ -149,7 +149,7 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
 }
 
 static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m,
-                        const slamhip_spe_cfg *cfg) {
+                        const slamhip_spe_cfg *cfg, hipStream_t stream) {
   const int order = cfg->oope == SLAMHIP_OOPE_GMAPPING ? SLAMHIP_SUM_TREE256 : cfg->sum_order;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profile) {
@@ -166,11 +166,11 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
   // one kernel: the events ride on the dispatch (kernel begin..end, as rocprofv3 sees it);
   // strict order is two kernels and is bracketed by recorded events instead
   const bool bracket = ctx->profile && order == SLAMHIP_SUM_SEQUENTIAL;
-  if (bracket) SLAMHIP_CHECK(hipEventRecord(e0, ctx->stream));
-  SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, ctx->stream, bracket ? nullptr : e0,
+  if (bracket) SLAMHIP_CHECK(hipEventRecord(e0, stream));
+  SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, stream, bracket ? nullptr : e0,
                              bracket ? nullptr : e1));
   if (ctx->profile) {
-    if (bracket) SLAMHIP_CHECK(hipEventRecord(e1, ctx->stream));
+    if (bracket) SLAMHIP_CHECK(hipEventRecord(e1, stream));
     ctx->prof_launches += 1;
     ctx->prof_units += (long long)a.n_poses * a.scan.n;
   }
@@ -180,6 +180,7 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
 static int profile_resolve(slamhip_ctx *ctx) {
   if (ctx->ev_used == 0) return SLAMHIP_OK;
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
   for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
     float ms = 0.f;
     SLAMHIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
@@ -213,16 +214,29 @@ static void gm_carry_fixup(slamhip_ctx *ctx, int n_poses) {
   }
 }
 
-int score_wait(slamhip_ctx *ctx, unsigned seq) {
+int lane_fork(slamhip_ctx *ctx) {
+  if (!ctx->stream_b) {
+    SLAMHIP_CHECK(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
+    SLAMHIP_CHECK(hipHostMalloc(&ctx->h_done_flag_b, sizeof(unsigned), kPinned));
+    *ctx->h_done_flag_b = 0;
+    SLAMHIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  }
+  SLAMHIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+  SLAMHIP_CHECK(hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
+  return SLAMHIP_OK;
+}
+
+int score_wait(slamhip_ctx *ctx, unsigned seq, int lane) {
   if (seq == 0) return SLAMHIP_OK;  // the launch was synchronous
-  volatile unsigned *flag = ctx->h_done_flag;
+  volatile unsigned *flag = lane ? ctx->h_done_flag_b : ctx->h_done_flag;
+  const hipStream_t stream = lane ? ctx->stream_b : ctx->stream;
   unsigned long long spins = 0;
   // launches publish increasing numbers on one stream: "reached seq" = the signed distance is >= 0
   while ((int)(*flag - seq) < 0) {
     __builtin_ia32_pause();
     if ((++spins & 0xfffffull) == 0) {
       // ~every few ms: make sure the launch did not fail asynchronously
-      hipError_t q = hipStreamQuery(ctx->stream);
+      hipError_t q = hipStreamQuery(stream);
       if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "scoring kernel");
       if (q == hipSuccess && (int)(*flag - seq) < 0) {
         set_error("scoring kernel finished without publishing its completion flag");
@@ -235,8 +249,10 @@ int score_wait(slamhip_ctx *ctx, unsigned seq) {
 }
 
 int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
-                 const TiledTarget *tiled, int off, unsigned *async_seq) {
+                 const TiledTarget *tiled, int off, unsigned *async_seq, int lane) {
   if (async_seq) *async_seq = 0;
+  if (lane && (!ctx->low_latency || ctx->stage_poses || !ctx->stream_b))
+    return invalid("the second launch lane needs the zero-copy path and lane_fork()");
   DeviceMap tiled_view;
   DeviceMap *m = nullptr;
   if (tiled) {
@@ -300,16 +316,18 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
       a.pose_slot = ctx->h_pose_slot + off;
       a.table_stride = tiled->table_stride;
     }
-    unsigned seq = ++ctx->seq;
-    if (seq == 0) seq = ++ctx->seq;
-    rc = launch_timed(ctx, a, *m, cfg);
+    unsigned &counter = lane ? ctx->seq_b : ctx->seq;
+    unsigned seq = ++counter;
+    if (seq == 0) seq = ++counter;
+    const hipStream_t stream = lane ? ctx->stream_b : ctx->stream;
+    rc = launch_timed(ctx, a, *m, cfg, stream);
     if (rc) return rc;
-    SLAMHIP_CHECK(launch_publish(ctx->h_done_flag, seq, ctx->stream));
+    SLAMHIP_CHECK(launch_publish(lane ? ctx->h_done_flag_b : ctx->h_done_flag, seq, stream));
     if (async_seq) {
       *async_seq = seq;
       return SLAMHIP_OK;
     }
-    return score_wait(ctx, seq);
+    return score_wait(ctx, seq, lane);
   }
   if (host_trig)
     SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_pose_sc, ctx->h_pose_sc, sizeof(double) * 2 * n_poses,
@@ -320,7 +338,7 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
                  ctx->d_scores, &a);
   if (rc) return rc;
   if (gm) a.gm_info = ctx->d_gm_info;
-  rc = launch_timed(ctx, a, *m, cfg);
+  rc = launch_timed(ctx, a, *m, cfg, ctx->stream);
   if (rc) return rc;
   SLAMHIP_CHECK(hipMemcpyAsync(ctx->h_scores, ctx->d_scores, sizeof(double) * n_poses,
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -409,6 +427,12 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) hipEventDestroy(ev);
   if (ctx->h_done_flag) hipHostFree(ctx->h_done_flag);
+  if (ctx->stream_b) {
+    hipStreamSynchronize(ctx->stream_b);
+    hipStreamDestroy(ctx->stream_b);
+    hipHostFree(ctx->h_done_flag_b);
+    hipEventDestroy(ctx->ev_fork);
+  }
   mu_release(ctx);
   hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -753,7 +777,7 @@ int slamhip_score_poses_device(slamhip_ctx *ctx, int map_id, const slamhip_spe_c
     if (rc) return rc;
     a.gm_info = nullptr;  // in-pose runs only; cross-pose carry needs the host path
   }
-  return launch_timed(ctx, a, *m, cfg);
+  return launch_timed(ctx, a, *m, cfg, ctx->stream);
 }
 
 int slamhip_gm_cache_reset(slamhip_ctx *ctx) {

@@ -149,6 +149,12 @@ struct slamhip_ctx {
   // low-latency completion flag (k_publish in score_kernels.hip)
   unsigned *h_done_flag = nullptr;  // pinned, coherent
   unsigned seq = 0;
+  // second launch lane (stream + completion flag): the filter's two job groups score on one lane each,
+  // so that one group's kernel can start while the other's is still draining / publishing
+  hipStream_t stream_b = nullptr;
+  unsigned *h_done_flag_b = nullptr;
+  unsigned seq_b = 0;
+  hipEvent_t ev_fork = nullptr;
   bool low_latency = true;
   bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
   // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read
@@ -174,7 +180,10 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n);
 // `off`: window of the staging buffers (poses at h_poses + 3 off, results at h_scores + off, ...);
 // `async_seq` != null: return right after the launch with the number score_wait() takes (0 = the
 // call was synchronous after all, nothing to wait for)
+// `lane` 1: launch on the context's second stream / completion flag (zero-copy path only)
 int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
-                 const TiledTarget *tiled = nullptr, int off = 0, unsigned *async_seq = nullptr);
-int score_wait(slamhip_ctx *ctx, unsigned seq);
+                 const TiledTarget *tiled = nullptr, int off = 0, unsigned *async_seq = nullptr, int lane = 0);
+int score_wait(slamhip_ctx *ctx, unsigned seq, int lane = 0);
+// orders the second lane behind everything queued on the first so far (scan upload, map updates)
+int lane_fork(slamhip_ctx *ctx);
 }  // namespace slamhip
