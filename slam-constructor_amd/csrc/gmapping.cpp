@@ -387,7 +387,10 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
     double min_reach = 0.3;  // measured on MI355X, 100 particles: 1.9 ms/step at 0.3 vs 6.7 ms at 0.01
     if (const char *e = getenv("SLAMHIP_PF_BUDGET")) per_job = std::max(6, atoi(e));
     if (const char *e = getenv("SLAMHIP_PF_MIN_REACH")) min_reach = atof(e);
-    for (MatchJob *j : act) j->tree.min_reach = min_reach;
+    for (MatchJob *j : act) {
+      j->tree.min_reach = min_reach;
+      j->timed = false;
+    }
     rc = run_jobs(g, map_id, act, per_job, g->tp ? act_idx.data() : nullptr);  // slot = particle index
     if (rc) return rc;
     // verify the shared-cache chain in the reference's particle order; re-match on a hit
