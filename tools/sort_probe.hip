@@ -4,7 +4,8 @@
 // Results of r01 (MI355X), 21.6 M random (4-byte key, 4-byte value) pairs, 29 key bits:
 //   rocprim default 764 us | onesweep 8 bits, 1024x8, match 627 us (used by the batch) | 512x12 match 692 |
 //   256x12 match 952 | 7 bits 512x16 1818 | basic ranking 256x12 3586; 8-byte keys, 36 bits: default 1025 us
-//   21 bits only: 492 us; segmented sort over 100 segments of 216 k: 3152 us
+//   21 bits only: 492 us; segmented sort over 100 segments of 216 k: 3152 us; 28 bits in three passes of
+//   10 bits: 712 us (1024x8), 1067 (512x8), 1406 (256x16) against 625 us for four passes of 8
 //   single scan, 22 bits: 170 k pairs merge sort (default) 58 us, onesweep 118 us, merge sort with 4096-item
 //   sort blocks 55 us; 600 k: 139 / 135 / 119 us
 #include <hip/hip_runtime.h>
@@ -79,6 +80,11 @@ int main(int argc, char **argv) {
     if (run<Cfg<8, 512, 12, kMatch>, unsigned>("rb8 512x12 match", n, 29, k_in, k_out, v_in, v_out)) return 1;
     if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("rb8 1024x8 match", n, 29, k_in, k_out, v_in, v_out)) return 1;
     if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("rb8 1024x8 match", n, 21, k_in, k_out, v_in, v_out)) return 1;
+    // 28 bits in three passes?
+    if (run<Cfg<8, 1024, 8, kMatch>, unsigned>("rb8 1024x8 match", n, 28, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<10, 1024, 8, kMatch>, unsigned>("rb10 1024x8 match", n, 28, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<10, 512, 8, kMatch>, unsigned>("rb10 512x8 match", n, 28, k_in, k_out, v_in, v_out)) return 1;
+    if (run<Cfg<10, 256, 16, kMatch>, unsigned>("rb10 256x16 match", n, 28, k_in, k_out, v_in, v_out)) return 1;
   }
   // the single-scan size: merge sort (default below 1 M items) against onesweep and bigger sort blocks
   for (size_t m : {(size_t)170000, (size_t)600000}) {
