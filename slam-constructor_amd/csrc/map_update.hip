@@ -597,7 +597,9 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   }
   a.key_x0 = lo_x + tp->origin_x - 1;
   a.key_y0 = lo_y + tp->origin_y - 1;
-  a.key_w = hi_x - lo_x + 3;
+  a.key_shift = 1;
+  while ((1 << a.key_shift) < hi_x - lo_x + 3) ++a.key_shift;
+  a.key_w = 1 << a.key_shift;  // padded to a power of two: keys decode with shift and mask
   const unsigned long long key_cells = (unsigned long long)a.key_w * (unsigned long long)(hi_y - lo_y + 3);
   unsigned cell_bits = 1, job_bits = 1;
   while ((1ull << cell_bits) < key_cells) ++cell_bits;

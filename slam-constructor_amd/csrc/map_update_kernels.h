@@ -24,6 +24,7 @@ struct MuArgs {
   // particles, not the map extent -- so that job and cell fit 32 bits and the radix sort runs over 4-byte
   // keys in as few passes as the window needs.  A plain call: the window is the bound map itself.
   int cell_bits, key_x0, key_y0, key_w;
+  int key_shift;  // > 0: key_w = 1 << key_shift (a batch pads its window: the key decodes with shift and mask)
   void *keys;  // unsigned or unsigned long long per record (the kernels' Key parameter)
   int *job_bbox;  // per job (lo_x, lo_y, hi_x, hi_y) in external cells, reduced by k_mu_count
   // map
@@ -303,8 +304,13 @@ __global__ void k_mu_emit(MuArgs a) {
 template <typename Key>
 __device__ __forceinline__ int mu_key_cell(const MuArgs &a, Key key, int *ix, int *iy) {
   const Key cellkey = a.jobs ? key & (Key)((1ull << a.cell_bits) - 1ull) : key;
-  *ix = (int)(cellkey % (unsigned)a.key_w) + a.key_x0;
-  *iy = (int)(cellkey / (unsigned)a.key_w) + a.key_y0;
+  if (a.key_shift) {
+    *ix = (int)((unsigned)cellkey & ((1u << a.key_shift) - 1u)) + a.key_x0;
+    *iy = (int)(cellkey >> a.key_shift) + a.key_y0;
+  } else {
+    *ix = (int)(cellkey % (unsigned)a.key_w) + a.key_x0;
+    *iy = (int)(cellkey / (unsigned)a.key_w) + a.key_y0;
+  }
   return a.jobs ? (int)(key >> a.cell_bits) : 0;
 }
 
@@ -596,8 +602,9 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
         *y = a.beam_end[2 * b + 1];
       });
   }
-  if (head && open_end) {  // the rest of a chain that crosses into the next wave(s), eight records ahead
-    constexpr int CH = 8;
+  // the rest of a chain that crosses into the next wave(s): most chains end with their wave, one key tells
+  if (head && open_end && i + len_here < total && keys[i + len_here] == key) {
+    constexpr int CH = 8;  // records fetched ahead
     bool more = true;
     for (unsigned j0 = i + len_here; more && j0 < total; j0 += CH) {
       Key kk[CH];

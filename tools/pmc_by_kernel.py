@@ -15,5 +15,5 @@ for r in csv.DictReader(open(sys.argv[1])):
     acc[k][0] += float(r["Counter_Value"])
     acc[k][1] += 1
 for (name, grid, ctr), (s, n) in sorted(acc.items()):
-    if n >= 3:
+    if n >= int(__import__("os").environ.get("PMC_MIN_N", "3")):
         print(f"{name:50s} grid {grid:>9s} {ctr:22s} mean {s / n:14.1f} over {n}")
