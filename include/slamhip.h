@@ -309,8 +309,9 @@ int slamhip_gmapping_set_map_update(slamhip_gmapping *g, const slamhip_scan_adde
  * (gmapping_world.h:36-55); the reference revision never separates them (Q20), so the mode has no
  * reference run -- parity is against the oracle with per-particle maps.  The step then keeps the
  * lock-step matching and appends the scans of all matched particles in ONE batched K6; a resampling
- * copies tile tables (particle_filter.h:92-96).  extent_tiles: side of the fixed virtual extent in
- * tiles (cells outside read as unknown and cannot be written); pool_tiles: capacity (768 KiB each).
+ * copies tile tables (particle_filter.h:92-96).  extent_tiles: side of the initial virtual extent in
+ * tiles; it grows by whole tiles when a scan reaches beyond it, like the reference's unbounded maps
+ * (lazy_tiled_grid_map.h:128-187; cells outside read as unknown); pool_tiles: capacity (768 KiB each).
  * A shard [first, first+count) of the filter holds the maps of its own particles; when a resampling
  * draws a particle that lives on another rank its map travels as one exported buffer (below). */
 int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const slamhip_scan_adder_cfg *cfg,

@@ -140,6 +140,22 @@ int heaviest(const std::vector<double> &w) {
 
 // drives a set of jobs to completion through shared launches
 // `slots` (per-particle maps only): the map slot of every job
+// the scoring view of the filter's per-particle maps as they are now
+void bind_tiled_target(slamhip_gmapping *g) {
+  TiledTarget &t = g->tt;
+  const TilePool *tp = g->tp;
+  t.pool = tp->d_pool;
+  t.tables = tp->d_table();
+  t.table_stride = tp->table_stride();
+  t.tiles_x = tp->tiles_x;
+  t.width = tp->width();
+  t.height = tp->height();
+  t.origin_x = tp->origin_x;
+  t.origin_y = tp->origin_y;
+  t.scale = tp->scale;
+  for (int k = 0; k < 4; ++k) t.unknown[k] = tp->unknown[k];
+}
+
 int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int per_job_budget,
              const int *slots = nullptr) {
   slamhip_ctx *ctx = g->ctx;
@@ -147,7 +163,7 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
   std::vector<int> off(n_jobs), cnt(n_jobs);
   int rc = ensure_pose_capacity(ctx, (per_job_budget + 1) * n_jobs);
   if (rc) return rc;
-  if (g->tp) g->tt.tables = g->tp->d_table();  // the table buffer flips on resampling
+  if (g->tp) bind_tiled_target(g);  // the table buffer flips on resampling, the extent grows with the maps
   // Groups of jobs take turns (SLAMHIP_PF_PIPELINE = number of groups, default 2; 1 = one launch per
   // round): while the GPU scores one group's batch the host replays and re-plans another.  Each group
   // owns one window of the staging buffers; jobs are independent, so the interleaving changes no
@@ -588,17 +604,7 @@ int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const
   }
   g->upd = *cfg;
   g->update = false;  // the sequential shared-map mode and this one exclude each other
-  TiledTarget &t = g->tt;
-  t.pool = g->tp->d_pool;
-  t.tables = g->tp->d_table();
-  t.table_stride = g->tp->table_stride();
-  t.tiles_x = g->tp->tiles_x;
-  t.width = g->tp->width();
-  t.height = g->tp->height();
-  t.origin_x = g->tp->origin_x;
-  t.origin_y = g->tp->origin_y;
-  t.scale = m.scale;
-  for (int k = 0; k < 4; ++k) t.unknown[k] = m.unknown[k];
+  bind_tiled_target(g);
   return SLAMHIP_OK;
 }
 

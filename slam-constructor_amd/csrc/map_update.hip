@@ -516,16 +516,19 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   std::memset(&a, 0, sizeof(a));
   a.jobs = sc.d_jobs;
   a.n_jobs = n_jobs;
-  a.tables = tp->d_table();
-  a.table_stride = tp->table_stride();
-  a.tiles_x = tp->tiles_x;
+  auto bind_extent = [&]() {  // (again after the extent grew)
+    a.tables = tp->d_table();
+    a.table_stride = tp->table_stride();
+    a.tiles_x = tp->tiles_x;
+    a.width = tp->width();
+    a.height = tp->height();
+    a.pitch = tp->width();
+    a.origin_x = tp->origin_x;
+    a.origin_y = tp->origin_y;
+  };
+  bind_extent();
   a.payload = tp->d_pool;
   a.aux = tp->d_aux;
-  a.width = tp->width();
-  a.height = tp->height();
-  a.pitch = tp->width();
-  a.origin_x = tp->origin_x;
-  a.origin_y = tp->origin_y;
   a.cell_dbl = 4;
   a.aux_stride = 2;
   a.scale = scale;
@@ -575,6 +578,21 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   if (total64 == 0) return SLAMHIP_OK;
   if (total64 >= 0xfffffff0ull) return fail("more than 2^32 cell updates in one batch: split the batch");
   total = (unsigned)total64;
+  // the cells any job of the batch can touch (the walks stay inside the rectangle of their end cells); the
+  // particle maps grow to hold them, like the reference's unbounded maps
+  int lo_x = INT_MAX, lo_y = INT_MAX, hi_x = INT_MIN, hi_y = INT_MIN;
+  for (int k = 0; k < n_jobs; ++k) {
+    lo_x = std::min(lo_x, bbox[4 * k]);
+    lo_y = std::min(lo_y, bbox[4 * k + 1]);
+    hi_x = std::max(hi_x, bbox[4 * k + 2]);
+    hi_y = std::max(hi_y, bbox[4 * k + 3]);
+  }
+  {
+    const long long grown = tp->growths;
+    const int rc_g = tile_pool_grow(tp, lo_x + tp->origin_x, lo_y + tp->origin_y, hi_x + tp->origin_x, hi_y + tp->origin_y);
+    if (rc_g) return rc_g;
+    if (tp->growths != grown) bind_extent();
+  }
   // copy-on-write of the tiles under every job's rectangle, then room for the records
   for (int k = 0; k < n_jobs; ++k) {
     int rc = tile_pool_make_private(tp, jobs[k].slot, bbox[4 * k] + tp->origin_x, bbox[4 * k + 1] + tp->origin_y,
@@ -586,15 +604,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   a.tables = tp->d_table();
   rc = ensure_records(total);
   if (rc) return rc;
-  // key window: the cells any job of the batch can touch (the walks stay inside the rectangle of their
-  // end cells), one cell of margin, in internal coordinates
-  int lo_x = INT_MAX, lo_y = INT_MAX, hi_x = INT_MIN, hi_y = INT_MIN;
-  for (int k = 0; k < n_jobs; ++k) {
-    lo_x = std::min(lo_x, bbox[4 * k]);
-    lo_y = std::min(lo_y, bbox[4 * k + 1]);
-    hi_x = std::max(hi_x, bbox[4 * k + 2]);
-    hi_y = std::max(hi_y, bbox[4 * k + 3]);
-  }
+  // key window: that rectangle with one cell of margin, in internal coordinates
   a.key_x0 = lo_x + tp->origin_x - 1;
   a.key_y0 = lo_y + tp->origin_y - 1;
   a.key_shift = 1;

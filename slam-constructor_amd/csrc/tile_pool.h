@@ -7,8 +7,8 @@
 // "map" is a SLOT of the pool (one per particle), tiles are 128 x 128 cells of 4 doubles (GMapping
 // payload: prob_occ, obstacle x, obstacle y, pad) plus 2 doubles of update counters (hits, tries) in
 // a parallel array, refcounts and the free list live on the host, and the copy itself is one kernel
-// over (src, dst) tile pairs.  The extent is fixed at creation (tiles_x x tiles_y tiles around the
-// origin); cells outside it read as unknown and cannot be written.
+// over (src, dst) tile pairs.  The extent starts as tiles_x x tiles_y tiles around the origin and grows by
+// whole tiles when a scan reaches beyond it (tile_pool_grow); cells outside it read as unknown.
 #pragma once
 
 #include <vector>
@@ -38,6 +38,7 @@ struct TilePool {
   int *h_assign = nullptr;         // source slot per new slot
   int cap_pairs = 0, cap_patches = 0, n_pairs = 0, n_patches = 0;
   long long cow_copies = 0;        // tiles copied so far
+  long long growths = 0;           // times the extent grew
   // tiles of the common ancestor map (tile_pool_init_from_dense): never freed, so that a migrating map
   // can name them by ordinal instead of carrying their 768 KiB -- every rank builds the same ancestor
   std::vector<int> ancestor;       // ordinal -> tile id
@@ -54,6 +55,9 @@ int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, do
 void tile_pool_destroy(TilePool *tp);
 // every slot starts as a copy of the bound dense GMAPPING window `m` (payload and, if present, counters)
 int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m);
+// make internal cells [x0, x1] x [y0, y1] (possibly negative / beyond the extent) part of the extent.
+// Nothing may be queued (tile_pool_flush first); TiledTarget views must be rebuilt afterwards.
+int tile_pool_grow(TilePool *tp, int x0, int y0, int x1, int y1);
 // make the tiles of `slot` that intersect internal cells [x0, x1] x [y0, y1] private (queued)
 int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y1);
 // run the queued copies and table patches on the context's stream
@@ -61,8 +65,9 @@ int tile_pool_flush(TilePool *tp);
 // resampling: new slot i becomes a copy of old slot src[i] (tables only; tiles get shared)
 int tile_pool_assign(TilePool *tp, const int *src_of_new);
 // ---- migration between pools (particles that move to another GPU on resampling) --------------------
-// A slot's map leaves as one host buffer: int64 n_tiles, n_tiles int32 table indices (padded to 8
-// bytes), then per tile 16384 x 4 payload doubles and 16384 x 2 counter doubles.  Every tile the slot
+// A slot's map leaves as one host buffer: int64 n_tiles, per tile (int32 x, y of its first cell in
+// EXTERNAL coordinates, int32 ancestor ordinal or -1, int32 0), then per tile that is not an ancestor
+// tile 16384 x 4 payload doubles and 16384 x 2 counter doubles.  Every tile the slot
 // references except the unknown tile is included (the receiving pool cannot know which of them equal
 // its own ancestor tiles).
 size_t tile_pool_export_size(const TilePool *tp, int slot);

@@ -231,6 +231,57 @@ int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m) {
   return SLAMHIP_OK;
 }
 
+// UnboundedLazyTiledGridMap::ensure_inside (lazy_tiled_grid_map.h:128-187): the extent grows by whole tiles on
+// the sides that a write reaches beyond; new area is the shared unknown tile.  Every slot's table is
+// re-laid out (host mirror, one upload); tile ids, refcounts and the pool itself do not move.  Growth is
+// generous -- at least a quarter of the current extent on a side that grows -- so that a robot driving
+// off does not re-lay the tables every scan.
+int tile_pool_grow(TilePool *tp, int x0, int y0, int x1, int y1) {
+  auto tiles_for = [](int cells) { return (cells + kTileSide - 1) >> kTileShift; };
+  int add_l = x0 < 0 ? tiles_for(-x0) : 0, add_r = x1 >= tp->width() ? tiles_for(x1 - tp->width() + 1) : 0;
+  int add_t = y0 < 0 ? tiles_for(-y0) : 0, add_b = y1 >= tp->height() ? tiles_for(y1 - tp->height() + 1) : 0;
+  if (!(add_l | add_r | add_t | add_b)) return SLAMHIP_OK;
+  if (tp->n_pairs || tp->n_patches) return tp_fail("tile pool growth with queued copies", SLAMHIP_ERR_STATE);
+  if (add_l) add_l = std::max(add_l, (tp->tiles_x + 3) / 4);
+  if (add_r) add_r = std::max(add_r, (tp->tiles_x + 3) / 4);
+  if (add_t) add_t = std::max(add_t, (tp->tiles_y + 3) / 4);
+  if (add_b) add_b = std::max(add_b, (tp->tiles_y + 3) / 4);
+  const int ntx = tp->tiles_x + add_l + add_r, nty = tp->tiles_y + add_t + add_b;
+  if ((long long)ntx * nty > (1 << 20)) return tp_fail("tile table too large: the particle maps cannot grow that far");
+  const size_t tab = (size_t)tp->n_slots * ntx * nty;
+  std::vector<int> nt(tab, 0);
+  for (int s = 0; s < tp->n_slots; ++s) {
+    const int *from = tp->h_tables.data() + (size_t)s * tp->table_stride();
+    int *to = nt.data() + (size_t)s * ntx * nty;
+    for (int ty = 0; ty < tp->tiles_y; ++ty)
+      std::memcpy(to + (size_t)(ty + add_t) * ntx + add_l, from + (size_t)ty * tp->tiles_x, sizeof(int) * tp->tiles_x);
+  }
+  hipStream_t st = tp->ctx->stream;
+  SLAMHIP_CHECK(hipStreamSynchronize(st));
+  if (tp->ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream_b));
+  int *fresh[2] = {nullptr, nullptr};
+  hipError_t e = hipMalloc(&fresh[0], tab * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&fresh[1], tab * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(fresh[tp->cur], nt.data(), tab * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    if (fresh[0]) hipFree(fresh[0]);
+    if (fresh[1]) hipFree(fresh[1]);
+    return hip_fail(e, "tile table growth");
+  }
+  hipFree(tp->d_tables[0]);
+  hipFree(tp->d_tables[1]);
+  tp->d_tables[0] = fresh[0];
+  tp->d_tables[1] = fresh[1];
+  tp->h_tables.swap(nt);
+  tp->tiles_x = ntx;
+  tp->tiles_y = nty;
+  tp->origin_x += add_l * kTileSide;
+  tp->origin_y += add_t * kTileSide;
+  tp->growths += 1;
+  return SLAMHIP_OK;
+}
+
 int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y1) {
   if (slot < 0 || slot >= tp->n_slots) return tp_fail("bad slot");
   x0 = std::max(x0, 0);
@@ -314,8 +365,9 @@ int tile_pool_assign(TilePool *tp, const int *src_of_new) {
 namespace {
 constexpr size_t kTilePayloadBytes = (size_t)kTileCells * 4 * sizeof(double);
 constexpr size_t kTileAuxBytes = (size_t)kTileCells * 2 * sizeof(double);
-// header: int64 n_entries, then n_entries x (int32 table index, int32 ancestor ordinal or -1)
-size_t export_header_bytes(long long n_entries) { return 8 + (size_t)n_entries * 8; }
+// header: int64 n_entries, then n_entries x (int32 x, int32 y: EXTERNAL cell of the tile's first cell -- pools
+// grown differently still agree on those --, int32 ancestor ordinal or -1, int32 0)
+size_t export_header_bytes(long long n_entries) { return 8 + (size_t)n_entries * 16; }
 }  // namespace
 
 size_t tile_pool_export_size(const TilePool *tp, int slot) {
@@ -343,8 +395,10 @@ int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap) {
   std::memcpy(out, &n, 8);
   int *ent = reinterpret_cast<int *>(out + 8);
   for (size_t k = 0; k < idx.size(); ++k) {
-    ent[2 * k] = idx[k];
-    ent[2 * k + 1] = tp->ancestor_of[row[idx[k]]];  // an untouched ancestor tile travels as its ordinal
+    ent[4 * k] = (idx[k] % tp->tiles_x) * kTileSide - tp->origin_x;
+    ent[4 * k + 1] = (idx[k] / tp->tiles_x) * kTileSide - tp->origin_y;
+    ent[4 * k + 2] = tp->ancestor_of[row[idx[k]]];  // an untouched ancestor tile travels as its ordinal
+    ent[4 * k + 3] = 0;
   }
   char *p = out + export_header_bytes(n);
   for (int i : idx) {
@@ -362,6 +416,24 @@ int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap) {
 }
 
 int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs) {
+  // a map that arrives from a pool grown further than this one: grow first (tables are re-laid out)
+  for (int r = 0; r < n_remote; ++r) {
+    bool used = false;
+    for (int s = 0; s < tp->n_slots; ++s) used |= (src[s] == -r - 1);
+    if (!used) continue;
+    const char *in = static_cast<const char *>(remote_bufs[r]);
+    if (!in) return tp_fail("missing exported map");
+    long long n = 0;
+    std::memcpy(&n, in, 8);
+    if (n < 0 || n > (1 << 20)) return tp_fail("corrupt exported map");
+    const int *ent = reinterpret_cast<const int *>(in + 8);
+    for (long long k = 0; k < n; ++k) {
+      const int ix = ent[4 * k] + tp->origin_x, iy = ent[4 * k + 1] + tp->origin_y;
+      if ((ix & kTileMask) || (iy & kTileMask)) return tp_fail("exported map from a pool with another tile grid");
+      const int rc = tile_pool_grow(tp, ix, iy, ix + kTileSide - 1, iy + kTileSide - 1);
+      if (rc) return rc;
+    }
+  }
   const int stride = tp->table_stride();
   std::vector<int> nt((size_t)tp->n_slots * stride, 0);
   // tiles nobody will reference after this generation change can be reused for the imports: recount
@@ -394,8 +466,10 @@ int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const voi
     const char *p = in + export_header_bytes(n);
     imported[r].assign(stride, 0);
     for (long long k = 0; k < n; ++k) {
-      const int ti = ent[2 * k], ord = ent[2 * k + 1];
-      if (ti < 0 || ti >= stride) return tp_fail("corrupt exported map (table index)");
+      const int tx = (ent[4 * k] + tp->origin_x) >> kTileShift, ty = (ent[4 * k + 1] + tp->origin_y) >> kTileShift;
+      const int ord = ent[4 * k + 2];
+      if (tx < 0 || tx >= tp->tiles_x || ty < 0 || ty >= tp->tiles_y) return tp_fail("corrupt exported map (tile position)");
+      const int ti = ty * tp->tiles_x + tx;
       if (ord >= 0) {  // the sender's untouched ancestor tile = this pool's ancestor tile of the same ordinal
         if (ord >= (int)tp->ancestor.size()) return tp_fail("exported map names an ancestor tile this pool lacks");
         imported[r][ti] = tp->ancestor[ord];

@@ -97,6 +97,61 @@ def test_particle_maps_filter_vs_oracle(pkg, oracle, key64, monkeypatch):
     assert np.count_nonzero(a[..., 0] != b[..., 0]) > 0
 
 
+def test_particle_maps_grow_with_the_scans(pkg, oracle):
+    """UnboundedLazyTiledGridMap grows when a scan reaches beyond it (lazy_tiled_grid_map.h:128-187).  Here
+    the ancestor is a small dense window holding a range-gated first scan (2.5 m), the tile extent starts as
+    ONE tile (6.4 m across), and the filter's own updates (no gate) reach further: the extent must grow mid-run, in
+    front of every later lookup (K3 through the tile tables, K6, download), without changing a result."""
+    import pyoracle as po
+    from pyoracle_mapupdate import RULE_GMAPPING, append_scan_ex, gmapping_enable_particle_maps, gmapping_particle_map
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    scale = float(g["scale"])
+    unknown = g["unknown"][:3]
+    gp, n = g["gp"], 6
+    seeds = np.arange(3000, 3000 + n, dtype=np.uint32)
+    ox, oy = [int(v) for v in g["origin"]]
+    r0, a0, pose0 = g["step0_range"], g["step0_angle"], g["step0_delta"]
+    small, gate = 128, 2.5
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, small, small, [small // 2, small // 2], scale, unknown)
+    c0, s0 = pkg.beam_trig(a0)
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, pose0, r0, c0, s0, max_range=gate)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, skip_rate=3, pose_trig=1), n, seeds)
+    pf.enable_particle_maps(4, extent_tiles=1, pool_tiles=16 + 40 * n)
+    payload = np.tile(unknown, (h, w, 1)).astype(np.float64)
+    m = po.GridMapData(po.CELL_GMAPPING, payload, g["origin"], scale, unknown)
+    aux = np.zeros((h, w, 2))
+    append_scan_ex(oracle, m, aux, RULE_GMAPPING, pose0, r0, a0, max_range=gate)
+    opf = oracle.gmapping_create(n, gp, seeds, skip_rate=3)
+    gmapping_enable_particle_maps(oracle, opf, m, aux)
+    tiles0 = pf.particle_map_stats()["tiles_in_use"]
+    for it in range(int(g["n_steps"])):
+        extra = np.arange(9000 + 100 * it, 9000 + 100 * it + n, dtype=np.uint32)
+        rng, ang, d = g["step%d_range" % it], g["step%d_angle" % it], g["step%d_delta" % it]
+        res, idx = pf.step(4, rng, ang, None, d, 7 + it)
+        ores, oidx = opf.step(m, rng, ang, None, d, 7 + it, extra)
+        assert res == ores
+        if res:
+            np.testing.assert_array_equal(idx, oidx)
+        poses, wts, ms = pf.state()
+        oposes, owts, oms = opf.state()
+        np.testing.assert_allclose(poses, oposes, rtol=0, atol=1e-10, err_msg="step %d" % it)
+        np.testing.assert_allclose(wts, owts, rtol=1e-9, atol=0)
+        for i in range(n):
+            got_p, got_a = pf.particle_map(i, -ox, -oy, w, h)  # the oracle's window: beyond the first extent
+            want_p, want_a = gmapping_particle_map(oracle, opf, i)
+            np.testing.assert_array_equal(got_p[..., 0], want_p[..., 0], err_msg="step %d particle %d" % (it, i))
+            np.testing.assert_allclose(got_p[..., 1:], want_p[..., 1:], rtol=1e-12, atol=1e-14)
+            np.testing.assert_array_equal(got_a, want_a)
+    # cells were written beyond the 128-cell start extent
+    far = np.ones((h, w), bool)
+    far[oy - 64:oy + 64, ox - 64:ox + 64] = False
+    _, a_last = pf.particle_map(0, -ox, -oy, w, h)
+    assert np.count_nonzero(a_last[..., 1][far]) > 500
+    assert pf.particle_map_stats()["tiles_in_use"] > tiles0
+
+
 def test_particle_maps_resampling_shares_then_clones_tiles(pkg, oracle):
     """A run long enough to resample twice (the oracle alone was used to find it): right after a
     resampling the duplicates share tiles and nothing was copied for it; the next update clones
