@@ -482,9 +482,13 @@ private:
     rounds_.clear();
     heap_.push_back(Cand{1.0, -1, -1});
     const double q = 1.0 - p_accept;
-    double p_out[7];
-    p_out[0] = std::pow(q, 6);
-    for (int j = 1; j <= 6; ++j) p_out[j] = p_accept * std::pow(q, 6 - j);
+    // outcome probabilities of a round (only speculation priorities: products instead of seven pow()
+    // calls per plan, which were a third of the filter's planning time)
+    double qk[7], p_out[7];
+    qk[0] = 1.0;
+    for (int k = 1; k <= 6; ++k) qk[k] = qk[k - 1] * q;
+    p_out[0] = qk[6];
+    for (int j = 1; j <= 6; ++j) p_out[j] = p_accept * qk[6 - j];
     while (!heap_.empty() && (int)evals.size() + 6 <= budget) {
       // an instance reached with probability P saves ~P round trips (~20 us each) and costs host
       // time plus six evaluations: not worth it below min_reach
