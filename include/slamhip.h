@@ -324,8 +324,11 @@ int slamhip_gmapping_particle_map_stats(slamhip_gmapping *g, long long *tiles_in
                                         long long *bytes, long long *cow_copies, long long *cell_updates);
 /* Migration of a particle's map to another rank (the "moving a duplicated particle to another GPU"
  * step of SURVEY 8e).  Export: every tile the LOCAL particle references (except the unknown tile) into a
- * host buffer: int64 n_tiles, n_tiles int32 table indices padded to 8 bytes, then per tile 16384 x 4
- * payload and 16384 x 2 counter doubles.  Exports must be taken before any rank imports. */
+ * host buffer: int64 n_tiles, per tile four int32 (x, y of its first cell in external coordinates -- so
+ * that pools whose extents grew differently still agree --, ordinal of the common ancestor tile it
+ * still is or -1, 0), then per non-ancestor tile 16384 x 4 payload and 16384 x 2 counter doubles.
+ * The receiving pool grows first if the map reaches beyond it.  Exports must be taken before any rank
+ * imports. */
 int slamhip_gmapping_particle_map_export_size(slamhip_gmapping *g, int particle, size_t *bytes);
 int slamhip_gmapping_particle_map_export(slamhip_gmapping *g, int particle, void *host_buf, size_t cap);
 /* slamhip_gmapping_import for a filter with per-particle maps: new local particle l takes the map of

@@ -559,7 +559,7 @@ class GmappingFilter:
         return pay, aux
 
     def export_particle_map(self, particle):
-        """The LOCAL particle's map as one uint8 array (tiles + table indices) for another rank."""
+        """The LOCAL particle's map as one uint8 array (tile positions + tiles) for another rank."""
         sz = C.c_size_t(0)
         _check(self.L.slamhip_gmapping_particle_map_export_size(self.h, particle, C.byref(sz)))
         buf = np.zeros(sz.value, np.uint8)
