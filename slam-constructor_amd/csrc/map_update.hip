@@ -236,7 +236,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.n_padding = sc.n_updates;
 
   const dim3 bgrid((n + 255) / 256);
-  hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, ctx->stream, a);
+  if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, ctx->stream, sc.counts, sc.offsets, n);
   // the record count is needed on the host to size the buffers: the same IEEE operations as
   // k_mu_count (no contraction on either side) give the same bounds without a device round trip
@@ -556,7 +557,8 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
 
   const dim3 bgrid((unsigned)((beams + 255) / 256));
   a.job_bbox = sc.d_bbox;
-  hipLaunchKernelGGL(k_mu_count, bgrid, dim3(256), 0, st, a);
+  if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, st, a);
   {  // offsets: device-wide exclusive scan (the one-workgroup scan of the single-scan path takes 160 us
      // for 100 x 1080 beams)
     size_t need = 0;

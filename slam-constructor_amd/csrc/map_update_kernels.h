@@ -66,6 +66,7 @@ __device__ __forceinline__ void mu_endpoint(const MuArgs &a, const MuJob &j, int
   *wy = j.py + a.range[b] * s;
 }
 
+template <int EST>
 __device__ __forceinline__ MuBeam mu_beam(const MuArgs &a, const MuJob &jb, int g, double wx, double wy) {
   MuBeam m;
   const bool occ = a.is_occ ? a.is_occ[g % a.n] != 0 : true;
@@ -84,7 +85,7 @@ __device__ __forceinline__ MuBeam mu_beam(const MuArgs &a, const MuJob &jb, int 
   m.hole_dist_sq = blur_dist * blur_dist;
   m.base_prob = occ ? a.base_occ_prob : a.base_empty_prob;
   m.base_qual = occ ? a.base_occ_qual : a.base_empty_qual;
-  if (a.est_kind == 1) {
+  if (EST == 1) {
     const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
     const ae::ae_rect cb{scale * m.ey, scale * (m.ey + 1), scale * m.ex, scale * (m.ex + 1)};
     const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{wx, wy}, cb, occ ? 1 : 0, base4,
@@ -95,6 +96,8 @@ __device__ __forceinline__ MuBeam mu_beam(const MuArgs &a, const MuJob &jb, int 
   return m;
 }
 
+// (EST: occupancy estimator as a template parameter, see k_mu_gather)
+template <int EST>
 __global__ void k_mu_count(MuArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g == 0) {  // the status words of this update (later kernels of the stream set them)
@@ -116,7 +119,7 @@ __global__ void k_mu_count(MuArgs a) {
       ocx = (int)floor(wx / a.scale);
       ocy = (int)floor(wy / a.scale);
       cnt = (unsigned)(abs(ocx - rcx) + abs(ocy - rcy) + 1);
-      a.beam_info[g] = mu_beam(a, j, g, wx, wy);
+      a.beam_info[g] = mu_beam<EST>(a, j, g, wx, wy);
     }
     a.counts[g] = cnt;
   }
