@@ -1,0 +1,185 @@
+// oracle/ref_world_harness.cpp -- TEST INFRASTRUCTURE ONLY (built where /root/reference exists).
+//
+// Drop-in proof over a multi-scan loop: the reference's own single-hypothesis world
+// (SingleStateHypothesisLaserScanGridWorld built by init_1h_slam, src/utils/init_slam.h:12-25) and the
+// same world built by init_hip_1h_slam (slam-constructor_amd/host/slamhip_init_slam.h: reference world,
+// map and scan adder, HIP scan matcher) are fed the same scans.  After every scan the reference scan
+// adder updates the host map (single_state_hypothesis_laser_scan_grid_world.h:52-65), so the HIP
+// matcher has to see those updates in HBM before its next match; the pose after every scan and the
+// final maps are compared.
+// Output: oracle/_ref/libslamref_world.so (links slam-constructor_amd/libslamhip.so).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "utils/init_slam.h"
+#include "utils/data_generation/map_primitives.h"
+#include "utils/data_generation/grid_map_patcher.h"
+#include "utils/data_generation/laser_scan_generator.h"
+#include "../test/core/mock_grid_cell.h"
+
+#include "slamhip_init_slam.h"
+
+namespace {
+
+// preset 0: config/slams/tiny_slam_base.properties (+ tiny_mean_cell, monte_carlo_scan_matching)
+// preset 1: config/slams/viny_slam_base.properties
+void fill_props(MapPropertiesProvider &p, int preset, int matcher, unsigned seed, int strict, double size_m) {
+  auto S = [&](const char *k, const std::string &v) { p.set_property(k, v); };
+  if (preset == 0) {
+    S("slam/mapping/blur", "0.5");
+    S("slam/occupancy_estimator/type", "const");
+    S("slam/occupancy_estimator/base_occupied/prob", "0.95");
+    S("slam/occupancy_estimator/base_empty/prob", "0.01");
+    S("slam/mapping/grid/area/type", "mean_probability");
+    S("slam/mapping/corrected_pose_quality", "0.9");
+    S("slam/mapping/raw_pose_quality", "0.6");
+    S("slam/scmtch/spe/wmpp/weighting/type", "even");
+  } else {
+    S("slam/mapping/blur", "0.3");
+    S("slam/occupancy_estimator/type", "const");
+    S("slam/occupancy_estimator/base_occupied/prob", "0.95");
+    S("slam/occupancy_estimator/base_occupied/qual", "0.04");
+    S("slam/occupancy_estimator/base_empty/prob", "0.01");
+    S("slam/occupancy_estimator/base_empty/qual", "0.003");
+    S("slam/mapping/grid/area/type", "tbm_consistent");
+    S("slam/mapping/corrected_pose_quality", "0.9");
+    S("slam/mapping/raw_pose_quality", "0.6");
+    S("slam/scmtch/spe/wmpp/weighting/type", "viny");
+  }
+  S("slam/mapping/grid/type", "unbounded_plain");
+  S("slam/map/height_in_meters", std::to_string(size_m));
+  S("slam/map/width_in_meters", std::to_string(size_m));
+  S("slam/map/meters_per_cell", "0.1");
+  S("slam/scmtch/spe/type", "wmpp");
+  if (matcher == 0) {
+    S("slam/scmtch/type", "MC");
+    S("slam/scmtch/MC/dispersion/translation", "0.2");
+    S("slam/scmtch/MC/dispersion/rotation", "0.1");
+    S("slam/scmtch/MC/dispersion/failed_attempts_limit", "20");
+    S("slam/scmtch/MC/attempts_limit", "100");
+    S("slam/scmtch/MC/seed", std::to_string(seed));
+  } else {
+    S("slam/scmtch/type", "HC");
+    S("slam/scmtch/HC/distortion/translation", "0.1");
+    S("slam/scmtch/HC/distortion/rotation", "0.1");
+    S("slam/scmtch/HC/distortion/failed_attempts_limit", "6");
+  }
+  S("slam/scmtch/hip/strict", strict ? "true" : "false");
+}
+
+struct Calls : public GridScanMatcherObserver {
+  long tests = 0, updates = 0;
+  void on_scan_test(const RobotPose &, const LaserScan2D &, double) override { ++tests; }
+  void on_pose_update(const RobotPose &, const LaserScan2D &, double) override { ++updates; }
+};
+
+}  // namespace
+
+extern "C" {
+
+// preset: 0 tinySLAM, 1 vinySLAM; matcher: 0 MC, 1 HC; wrap: 1 = map wrapped in HipMirroredGridMap
+// (dirty log), 0 = bare reference map (full compare before every match)
+// poses_out: n_scans x 6 (reference x, y, theta, HIP x, y, theta) after every scan
+// out = {pose mismatches (bitwise), max |pose diff|, map cells compared, map cell mismatches,
+//        max |occupancy diff|, ref scorer calls, hip scorer calls, ref accepted, hip accepted,
+//        geometry equal, full uploads, re-binds, cells sent through the dirty path, final map width, height}
+int refworld_compare(int preset, int matcher, int wrap, int n_scans, int n_beams, int strict, double size_m,
+                     double *poses_out, double *out) {
+  const double scale = 0.1;
+  auto gt = std::make_shared<UnboundedPlainGridMap>(std::make_shared<MockGridCell>(0.0),
+                                                    GridMapParams{300, 300, scale});
+  {
+    using C = CecumTextRasterMapPrimitive;
+    C c1{81, 60, C::BoundPosition::Top}, c2{31, 21, C::BoundPosition::Bot};
+    GridMapPatcher{}.apply_text_raster(*gt, c1.to_stream(), DiscretePoint2D{-40, 35}, 1, 1);
+    GridMapPatcher{}.apply_text_raster(*gt, c2.to_stream(), DiscretePoint2D{-15, -6}, 1, 1);
+  }
+  MapPropertiesProvider props;
+  fill_props(props, preset, matcher, 424242u, strict, size_m);
+  auto ref = init_1h_slam(props);
+  slamhip_ctx *ctx = nullptr;
+  if (slamhip_ctx_create(0, &ctx) != SLAMHIP_OK) {
+    std::cerr << "refworld: " << slamhip_last_error() << std::endl;
+    return -1;
+  }
+  auto hip = init_hip_1h_slam(props, ctx, 0, wrap != 0);
+  auto c_ref = std::make_shared<Calls>(), c_hip = std::make_shared<Calls>();
+  ref->add_sm_observer(c_ref);
+  hip->add_sm_observer(c_hip);
+
+  // the robot drives up the corridor and turns a little; odometry carries a deterministic error that
+  // the matcher has to take out again
+  RobotPose truth{scale / 2, scale / 2 - 6 * scale, deg2rad(90)};
+  RobotPose prev_odom{0, 0, 0};
+  long pose_mis = 0;
+  double worst_pose = 0;
+  for (int k = 0; k < n_scans; ++k) {
+    TransformedLaserScan ts;
+    ts.scan = LaserScanGenerator{to_lsp(15, 270, n_beams)}.laser_scan_2D(*gt, truth, 1);
+    ts.quality = 1.0;
+    const double ex = 0.03 * std::sin(1.7 * k), ey = -0.025 * std::cos(0.9 * k), et = 0.02 * std::sin(0.6 * k + 1);
+    RobotPose odom{truth.x + ex, truth.y + ey, truth.theta + et};
+    ts.pose_delta = k == 0 ? RobotPoseDelta{truth.x, truth.y, truth.theta}
+                           : RobotPoseDelta{odom.x - prev_odom.x, odom.y - prev_odom.y, odom.theta - prev_odom.theta};
+    prev_odom = k == 0 ? truth : odom;
+    TransformedLaserScan ts_hip = ts;
+    ref->handle_sensor_data(ts);
+    hip->handle_sensor_data(ts_hip);
+    const RobotPose pr = ref->pose(), ph = hip->pose();
+    poses_out[6 * k + 0] = pr.x; poses_out[6 * k + 1] = pr.y; poses_out[6 * k + 2] = pr.theta;
+    poses_out[6 * k + 3] = ph.x; poses_out[6 * k + 4] = ph.y; poses_out[6 * k + 5] = ph.theta;
+    if (std::memcmp(&poses_out[6 * k], &poses_out[6 * k + 3], 3 * sizeof(double)) != 0) ++pose_mis;
+    worst_pose = std::max({worst_pose, std::fabs(pr.x - ph.x), std::fabs(pr.y - ph.y), std::fabs(pr.theta - ph.theta)});
+    // next true pose
+    truth = RobotPose{truth.x + 0.04 * std::cos(0.35 * k), truth.y + 0.09, truth.theta + 0.015 * std::sin(0.8 * k)};
+    // keep the generator's "not on a cell boundary" precondition
+    if (std::fabs(truth.x / scale - std::round(truth.x / scale)) < 1e-3) truth.x += 0.013;
+    if (std::fabs(truth.y / scale - std::round(truth.y / scale)) < 1e-3) truth.y += 0.013;
+  }
+  const GridMap &mr = ref->map(), &mh = hip->map();
+  const bool geom = mr.width() == mh.width() && mr.height() == mh.height() && mr.origin() == mh.origin() &&
+                    mr.scale() == mh.scale();
+  long cells = 0, cell_mis = 0;
+  double worst_occ = 0;
+  if (geom) {
+    const auto org = mr.origin();
+    for (int y = 0; y < mr.height(); ++y)
+      for (int x = 0; x < mr.width(); ++x) {
+        const GridMap::Coord c{x - org.x, y - org.y};
+        const Occupancy a = mr[c].occupancy(), b = mh[c].occupancy();
+        ++cells;
+        if (std::memcmp(&a.prob_occ, &b.prob_occ, sizeof(double)) != 0 ||
+            std::memcmp(&a.estimation_quality, &b.estimation_quality, sizeof(double)) != 0) {
+          ++cell_mis;
+          worst_occ = std::max(worst_occ, std::fabs(a.prob_occ - b.prob_occ));
+        }
+      }
+  }
+  auto hgsm = std::dynamic_pointer_cast<HipGridScanMatcher>(hip->scan_matcher());
+  out[0] = double(pose_mis);
+  out[1] = worst_pose;
+  out[2] = double(cells);
+  out[3] = double(cell_mis);
+  out[4] = worst_occ;
+  out[5] = double(c_ref->tests);
+  out[6] = double(c_hip->tests);
+  out[7] = double(c_ref->updates);
+  out[8] = double(c_hip->updates);
+  out[9] = geom ? 1 : 0;
+  out[10] = hgsm ? double(hgsm->mirror().full_uploads()) : -1;
+  out[11] = hgsm ? double(hgsm->mirror().rebinds()) : -1;
+  out[12] = hgsm ? double(hgsm->mirror().cells_sent()) : -1;
+  out[13] = mr.width();
+  out[14] = mr.height();
+  hip.reset();
+  hgsm.reset();
+  slamhip_ctx_destroy(ctx);
+  return 0;
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@
 #define SLAMHIP_REFERENCE_ADAPTER_H
 
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <utility>
@@ -50,35 +51,92 @@ inline void slamhip_or_die(int rc, const char *what) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// GridMap decorator that remembers which cells update()/reset() touched since the mirror last looked.
+// Every cell is logged once per interval (a scan touches the robot's own cell once per beam).
 class HipMirroredGridMap : public GridMap {
 public:
+  explicit HipMirroredGridMap(std::shared_ptr<GridMap> wrapped)
+      : GridMap{std::shared_ptr<GridCell>(wrapped->new_cell().release()),
+                GridMapParams{wrapped->width(), wrapped->height(), wrapped->scale()}},
+        _map{wrapped} {}
   HipMirroredGridMap(std::shared_ptr<GridMap> wrapped, std::shared_ptr<GridCell> prototype)
       : GridMap{prototype, GridMapParams{wrapped->width(), wrapped->height(), wrapped->scale()}},
         _map{wrapped} {}
 
   void update(const Coord &c, const AreaOccupancyObservation &aoo) override {
     _map->update(c, aoo);
-    _dirty.push_back(c);
+    log(c);
   }
   void reset(const Coord &c, const GridCell &cell) override {
     _map->reset(c, cell);
-    _dirty.push_back(c);
+    log(c);
   }
   const GridCell &operator[](const Coord &c) const override { return (*_map)[c]; }
   int width() const override { return _map->width(); }
   int height() const override { return _map->height(); }
   double scale() const override { return _map->scale(); }
+  void rescale(double s) override { _map->rescale(s); }
   DiscretePoint2D origin() const override { return _map->origin(); }
   bool has_cell(const Coord &c) const override { return _map->has_cell(c); }
+  bool validate() const override { return _map->validate(); }
+  std::vector<char> save_state() const override { return _map->save_state(); }
+  void load_state(const std::vector<char> &d) override {
+    _map->load_state(d);
+    _everything = true;
+  }
+  const std::shared_ptr<GridMap> &wrapped() const { return _map; }
 
-  std::vector<Coord> take_dirty() { return std::exchange(_dirty, {}); }
+  // the cells (external coordinates) touched since the last call; *everything = the whole map must
+  // be taken anew (load_state)
+  std::vector<Coord> take_dirty(bool *everything = nullptr) const {
+    if (everything) *everything = _everything;
+    _everything = false;
+    ++_epoch;
+    return std::exchange(_dirty, {});
+  }
 
 private:
+  void log(const Coord &c) {
+    // the stamp grid follows the wrapped map's geometry (an unbounded map grows inside update())
+    const auto org = _map->origin();
+    const int w = _map->width(), h = _map->height();
+    if (w != _sw || h != _sh || org.x != _sox || org.y != _soy) {
+      std::vector<unsigned> ns(size_t(w) * h, 0u);
+      for (int y = 0; y < _sh; ++y) {
+        const int ny = y - _soy + org.y;
+        if (ny < 0 || ny >= h) continue;
+        for (int x = 0; x < _sw; ++x) {
+          const int nx = x - _sox + org.x;
+          if (0 <= nx && nx < w) ns[size_t(ny) * w + nx] = _stamp[size_t(y) * _sw + x];
+        }
+      }
+      _stamp.swap(ns);
+      _sw = w; _sh = h; _sox = org.x; _soy = org.y;
+    }
+    const int ix = c.x + org.x, iy = c.y + org.y;
+    if (ix < 0 || ix >= w || iy < 0 || iy >= h) {  // a bounded map ignores nothing: log it plainly
+      _dirty.push_back(c);
+      return;
+    }
+    unsigned &st = _stamp[size_t(iy) * w + ix];
+    if (st == _epoch) return;
+    st = _epoch;
+    _dirty.push_back(c);
+  }
   std::shared_ptr<GridMap> _map;
-  std::vector<Coord> _dirty;
+  mutable std::vector<Coord> _dirty;
+  mutable unsigned _epoch = 1;
+  mutable bool _everything = false;
+  std::vector<unsigned> _stamp;
+  int _sw = 0, _sh = 0, _sox = 0, _soy = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
+// Keeps the dense HBM window of one GridMap equal to the host map.  Correct for ANY GridMap: with a
+// HipMirroredGridMap the cells its log names are re-sent; without one the whole map is compared with
+// a host shadow of what the GPU holds and the cells that differ are re-sent (one virtual call per
+// cell and scan -- wrap the map to avoid it).  Growth of an unbounded map is a re-bind (the device
+// moves the old window by the origin shift, plain_grid_map.h:133-173), not a re-upload.
 class HipMapMirror {
 public:
   HipMapMirror(slamhip_ctx *ctx, int map_id, int cell_model, bool bounded)
@@ -86,41 +144,63 @@ public:
 
   int id() const { return _id; }
   bool bounded() const { return _bounded; }
+  // counters for tests / logs: full uploads, re-binds on growth, cells sent through the dirty path
+  long full_uploads() const { return _n_full; }
+  long rebinds() const { return _n_rebind; }
+  long cells_sent() const { return _n_cells; }
 
-  // full upload when the geometry changed (first use, growth), dirty log otherwise
-  void sync(const GridMap &map, HipMirroredGridMap *dirty_source = nullptr) {
+  void sync(const GridMap &map, const HipMirroredGridMap *dirty_source = nullptr) {
+    if (!dirty_source) dirty_source = dynamic_cast<const HipMirroredGridMap *>(&map);
     const auto org = map.origin();
     const bool same = _w == map.width() && _h == map.height() && _ox == org.x && _oy == org.y &&
                       _scale == map.scale();
     const int st = stride();
+    bool everything = false;
+    std::vector<GridMap::Coord> dirty;
+    if (dirty_source) dirty = dirty_source->take_dirty(&everything);
     if (!same) {
       double unk[4] = {0, 0, 0, 0};
       payload(*map.new_cell(), unk);
+      const bool grown = _w > 0 && _scale == map.scale() && !everything;
       slamhip_or_die(slamhip_map_bind(_ctx, _id, _model, map.width(), map.height(), org.x, org.y,
                                       map.scale(), unk), "map_bind");
-      std::vector<double> buf(size_t(map.width()) * map.height() * st);
-      for (int y = 0; y < map.height(); ++y)
-        for (int x = 0; x < map.width(); ++x)
-          payload(map[{x - org.x, y - org.y}], &buf[(size_t(y) * map.width() + x) * st]);
-      slamhip_or_die(slamhip_map_upload_window(_ctx, _id, 0, 0, map.width(), map.height(), buf.data()),
-                     "map_upload_window");
+      if (!dirty_source) reshape_shadow(map, org, grown, unk);
       _w = map.width(); _h = map.height(); _ox = org.x; _oy = org.y; _scale = map.scale();
-      if (dirty_source) dirty_source->take_dirty();
+      if (!grown) {
+        upload_all(map, org, !dirty_source);
+        return;
+      }
+      ++_n_rebind;
+    } else if (everything) {
+      upload_all(map, org, !dirty_source);
       return;
     }
-    if (!dirty_source) return;
-    auto dirty = dirty_source->take_dirty();
-    if (dirty.empty()) return;
+    if (dirty_source) {
+      _shadow.clear();
+      send(map, org, dirty);
+      return;
+    }
+    if (_shadow.size() != size_t(_w) * _h * st) {  // the map used to come with a log
+      upload_all(map, org, true);
+      return;
+    }
+    // no log: find the cells that differ from what the GPU holds
     std::vector<int> xy;
     std::vector<double> vals;
-    for (const auto &c : dirty) {
-      xy.push_back(c.x + org.x);
-      xy.push_back(c.y + org.y);
-      double p[4];
-      payload(map[c], p);
-      vals.insert(vals.end(), p, p + st);
-    }
-    slamhip_or_die(slamhip_map_apply_dirty(_ctx, _id, int(dirty.size()), xy.data(), vals.data()),
+    double p[4];
+    for (int y = 0; y < _h; ++y)
+      for (int x = 0; x < _w; ++x) {
+        payload(map[{x - org.x, y - org.y}], p);
+        double *sh = &_shadow[(size_t(y) * _w + x) * st];
+        if (std::memcmp(sh, p, st * sizeof(double)) == 0) continue;
+        std::memcpy(sh, p, st * sizeof(double));
+        xy.push_back(x);
+        xy.push_back(y);
+        vals.insert(vals.end(), p, p + st);
+      }
+    if (xy.empty()) return;
+    _n_cells += long(xy.size() / 2);
+    slamhip_or_die(slamhip_map_apply_dirty(_ctx, _id, int(xy.size() / 2), xy.data(), vals.data()),
                    "map_apply_dirty");
   }
 
@@ -137,11 +217,61 @@ private:
       out[0] = c.occupancy().prob_occ;
     }
   }
+  void upload_all(const GridMap &map, const DiscretePoint2D &org, bool keep_shadow) {
+    const int st = stride();
+    std::vector<double> buf(size_t(_w) * _h * st);
+    for (int y = 0; y < _h; ++y)
+      for (int x = 0; x < _w; ++x) payload(map[{x - org.x, y - org.y}], &buf[(size_t(y) * _w + x) * st]);
+    slamhip_or_die(slamhip_map_upload_window(_ctx, _id, 0, 0, _w, _h, buf.data()), "map_upload_window");
+    if (keep_shadow) _shadow.swap(buf);
+    else _shadow.clear();
+    ++_n_full;
+  }
+  void send(const GridMap &map, const DiscretePoint2D &org, const std::vector<GridMap::Coord> &dirty) {
+    if (dirty.empty()) return;
+    const int st = stride();
+    std::vector<int> xy;
+    std::vector<double> vals;
+    xy.reserve(dirty.size() * 2);
+    vals.reserve(dirty.size() * st);
+    for (const auto &c : dirty) {
+      xy.push_back(c.x + org.x);
+      xy.push_back(c.y + org.y);
+      double p[4];
+      payload(map[c], p);
+      vals.insert(vals.end(), p, p + st);
+    }
+    _n_cells += long(dirty.size());
+    slamhip_or_die(slamhip_map_apply_dirty(_ctx, _id, int(dirty.size()), xy.data(), vals.data()),
+                   "map_apply_dirty");
+  }
+  // the shadow follows a re-bind the way the device window does: old cells keep their external place,
+  // new area holds the prototype payload
+  void reshape_shadow(const GridMap &map, const DiscretePoint2D &org, bool grown, const double *unk) {
+    const int st = stride(), nw = map.width(), nh = map.height();
+    std::vector<double> ns(size_t(nw) * nh * st);
+    for (size_t i = 0; i < size_t(nw) * nh; ++i) std::memcpy(&ns[i * st], unk, st * sizeof(double));
+    if (grown && !_shadow.empty()) {
+      const int dx = org.x - _ox, dy = org.y - _oy;
+      for (int y = 0; y < _h; ++y) {
+        const int ny = y + dy;
+        if (ny < 0 || ny >= nh) continue;
+        for (int x = 0; x < _w; ++x) {
+          const int nx = x + dx;
+          if (0 <= nx && nx < nw)
+            std::memcpy(&ns[(size_t(ny) * nw + nx) * st], &_shadow[(size_t(y) * _w + x) * st], st * sizeof(double));
+        }
+      }
+    }
+    _shadow.swap(ns);
+  }
   slamhip_ctx *_ctx;
   int _id, _model;
   bool _bounded;
   int _w = -1, _h = -1, _ox = 0, _oy = 0;
   double _scale = 0;
+  std::vector<double> _shadow;  // only kept for maps without a dirty log
+  long _n_full = 0, _n_rebind = 0, _n_cells = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -186,7 +316,10 @@ public:
   ~HipGridScanMatcher() override { slamhip_matcher_destroy(_m); }
 
   void reset_state() override { slamhip_or_die(slamhip_matcher_reset_state(_m), "reset_state"); }
-  void set_dirty_source(HipMirroredGridMap *src) { _dirty_source = src; }
+  // optional: a log kept somewhere else than in the map handed to process_scan (a map that IS a
+  // HipMirroredGridMap is recognised by itself; any other map is compared cell by cell)
+  void set_dirty_source(const HipMirroredGridMap *src) { _dirty_source = src; }
+  const HipMapMirror &mirror() const { return *_mirror; }
 
   double process_scan(const TransformedLaserScan &raw_scan, const RobotPose &init_pose,
                       const GridMap &map, RobotPoseDelta &pose_delta) override {
@@ -218,7 +351,7 @@ private:
   std::shared_ptr<HipMapMirror> _mirror;
   int _weighting;
   HipScanTrig _trig;
-  HipMirroredGridMap *_dirty_source = nullptr;
+  const HipMirroredGridMap *_dirty_source = nullptr;
   LaserScan2D _scan;
 };
 
