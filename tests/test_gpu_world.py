@@ -26,7 +26,7 @@ def lib():
     return L
 
 
-def run(lib, preset, matcher, wrap, strict, n_scans=12, n_beams=360, size_m=10.0):
+def run(lib, preset, matcher, wrap, strict, n_scans=12, n_beams=360, size_m=4.0):
     poses = (C.c_double * (6 * n_scans))()
     out = (C.c_double * 15)()
     assert lib.refworld_compare(preset, matcher, wrap, n_scans, n_beams, strict, size_m, poses, out) == 0
@@ -50,7 +50,7 @@ def test_world_loop_matches_reference_world(lib, preset, matcher, wrap, strict):
     assert r["pose_mis"] == 0, "trajectories differ by up to %g" % r["worst_pose"]
     assert r["cell_mis"] == 0, "final maps differ in %d cells (max %g)" % (r["cell_mis"], r["worst_occ"])
     # one full upload, afterwards only the cells the scan adder touched (or, unwrapped, the cells that
-    # differ); the 10 m map grows while the robot drives, which is a re-bind, not a re-upload
+    # differ); the 4 m map grows while the robot drives, which is a re-bind, not a re-upload
     assert r["full_uploads"] == 1 and r["rebinds"] >= 1 and r["cells_sent"] > 0
 
 
