@@ -71,6 +71,10 @@ def parse():
                     help="collective backend; gloo lets several ranks share one GPU (path testing)")
     ap.add_argument("--strict", action="store_true",
                     help="bit-exact mode (sequential sum + host pose trig) instead of the default")
+    ap.add_argument("--seq-sum", action="store_true",
+                    help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
+    ap.add_argument("--chain", type=int, default=-1,
+                    help="hill climbing on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
     return ap.parse_args()
 
 
@@ -516,7 +520,7 @@ def main():
     cos_a, sin_a = pkg.beam_trig(scan.angle)
     ctx.scan_upload(scan.range, cos_a, sin_a, scan.weight, scan.factor)
     cfg = pkg.spe_cfg(sum_order=pkg.SUM_SEQUENTIAL, pose_trig=pkg.POSE_TRIG_HOST) if args.strict \
-        else pkg.spe_cfg()
+        else (pkg.spe_cfg(sum_order=pkg.SUM_SEQUENTIAL) if args.seq_sum else pkg.spe_cfg())
 
     def barrier():
         if world > 1:
@@ -540,6 +544,8 @@ def main():
         desc = "sweep: %d device-resident poses x %d beams per launch, %s" % (P, scan.n, desc)
     else:
         m = pkg.Matcher(ctx, kind, cfg, params)
+        if args.chain >= 0 and kind == "HC":
+            m.set_device_chain(1 if args.chain else 0, args.chain if args.chain > 1 else 0)
 
         def step():
             m.process_scan(0, sc["init_pose"])

@@ -219,6 +219,13 @@ int slamhip_matcher_reset_state(slamhip_matcher *m);
 int slamhip_matcher_set_observer(slamhip_matcher *m, const slamhip_observer *obs);
 /* max speculative poses per launch (0 = default) */
 int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
+/* Hill climbing over the 1-cell OOPE in the default mode (TREE256 sum, device pose trig) runs its whole
+ * accept chain on the device: one process_scan = a chain of kernels with no host in between, each
+ * replaying the previous one's speculation tree (csrc/hc_chain.h).  mode: 1 on (default), 0 = the
+ * host-driven speculative batches every other configuration uses; threads: workgroup size 256 / 512 /
+ * 1024, 0 = default.  Results are identical either way (same scores bit for bit, same observer
+ * sequence). */
+int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],
                                  double out_delta[3], double *out_prob);

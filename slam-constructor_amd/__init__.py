@@ -33,7 +33,7 @@ slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_
 slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get
 slamhip_profile_enable slamhip_profile_read slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
-slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_process_scan
+slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_process_scan
 slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
@@ -112,7 +112,7 @@ def spe_cfg(oope=OOPE_OBSTACLE, oie=OIE_DISCREPANCY, area=(0, 0, 0, 0), gm_th=0.
 def build(verbose=False):
     """Compile the HIP kernels + C-ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", CSRC], stdout=out)
+    subprocess.check_call(["make", "-j8", "-C", CSRC], stdout=out)
     return LIB_PATH
 
 
@@ -163,6 +163,7 @@ def load():
     L.slamhip_matcher_reset_state.argtypes = [vp]
     L.slamhip_matcher_set_observer.argtypes = [vp, C.POINTER(Observer)]
     L.slamhip_matcher_set_batch.argtypes = [vp, i]
+    L.slamhip_matcher_set_device_chain.argtypes = [vp, i, i]
     L.slamhip_matcher_process_scan.argtypes = [vp, i, _dp, _dp, _dp]
     L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
     L.slamhip_matcher_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
@@ -427,6 +428,10 @@ class Matcher:
 
     def set_batch(self, n):
         _check(self.L.slamhip_matcher_set_batch(self.h, n))
+
+    def set_device_chain(self, mode, threads=0):
+        """Hill climbing on the device (1) or through host-driven speculative batches (0)."""
+        _check(self.L.slamhip_matcher_set_device_chain(self.h, int(mode), int(threads)))
 
     def process_scan(self, map_id, init_pose, trace=False):
         """Returns dict(prob, delta[, poses, scores, accepted, n_calls]) -- the trace is what a

@@ -1,0 +1,382 @@
+// hc_chain.hip -- one hill-climbing process_scan as a chain of kernels with no host in between
+// (design and the functions shared with the CPU test: hc_chain.h).
+//
+// Kernel k_hc_chain_step, launched K times back to back on the context's stream with k = 0, 1, 2, ...:
+//   prologue (k > 0)  replay of super-step k-1: every workgroup's wave 0 walks the scores of the previous
+//                     tree (one lane per round instance) and derives the root state of this super-step;
+//                     the last workgroup also stores it (for kernel k+1), writes the trace entries of the
+//                     walked rounds and, when the enumerator has run out, publishes the result to the host
+//   body              workgroup w scores ONE pose: candidate w % 6 of round instance w / 6 of this
+//                     super-step's tree (the last workgroup: the initial pose, first super-step only) with
+//                     the arithmetic of k_score_point (score_device.h) and the canonical 256-partial sum,
+//                     so its bits equal the host-driven matcher's
+// Kernels launched past the end of the chain see `done_epoch == epoch` and return.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "hc_chain_device.h"
+#include "score_device.h"
+
+namespace slamhip {
+
+static constexpr int kSumLanes = 256;  // the canonical sum's partials (= k_score_point's block)
+
+// value of lane `lane` (uniform) in every lane: v_readlane, no trip through the LDS crossbar
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ long long bcast_ll(long long v, int lane) {
+  const int lo = bcast_i((int)(unsigned)(unsigned long long)v, lane);
+  const int hi = bcast_i((int)(unsigned)((unsigned long long)v >> 32), lane);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double bcast(double v, int lane) {
+  return __longlong_as_double(bcast_ll(__double_as_longlong(v), lane));
+}
+// Kernel arguments are fetched where they are first used: a scalar load in the middle of the replay that
+// misses the scalar cache stalls its wave for hundreds of nanoseconds (three of them made half of the
+// replay's 1.9 us).  PIN makes the value exist in a scalar register HERE, i.e. next to the staging loads
+// at kernel entry, whose latency hides it.
+#define HC_PIN32(x) asm volatile("" ::"s"(x))
+#define HC_PIN64(x) asm volatile("" ::"s"((unsigned long long)(x)))
+#define HC_PINF(x) asm volatile("" ::"s"(__double_as_longlong(x)))
+
+// LDS copy of the previous tree's round instances: 17-word (136-byte) stride -- 128 would put the same
+// word of every lane's record in one bank
+static constexpr int kWalkStride = 17;
+
+template <int MODEL, int NT, bool SEQ>
+__global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
+  extern __shared__ double s_term[];            // one term per beam
+  __shared__ double s_sc[kHcSlots + 7];         // scores of the previous tree
+  __shared__ unsigned long long s_walk[kHcMaxInst * kWalkStride];
+  __shared__ HcState s_prev;                    // root state of the previous super-step
+  __shared__ HcInst s_mine[kHcShapes];          // this workgroup's round instance in every shape
+  __shared__ double s_pose[4];                  // x, y, sin, cos of the pose this workgroup scores
+  __shared__ int s_go;
+  __shared__ double s_part[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int slot = blockIdx.x;
+  HcChainCtl *ctl = a.ctl;
+  // ---- loads that depend on nothing: issued first, they overlap the replay below (the done test waits
+  // for its word only after everything else is in flight)
+  const bool stamp = a.stamps && slot == 1 && t == 0 && k < 64;
+  if (stamp) a.stamps[8 * k + 0] = wall_clock64();
+  const unsigned done_epoch = __hip_atomic_load(&ctl->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int n = a.scan.n;
+  const int inst_of_slot = slot / 6, cand = slot - 6 * inst_of_slot;
+  const bool init_slot = slot == kHcSlots - 1;
+  double br = 0.0, bc = 0.0, bs = 0.0, bw = 0.0, bf = 0.0;
+  if (t < n) {
+    br = a.scan.range[t];
+    bc = a.scan.cos_a[t];
+    bs = a.scan.sin_a[t];
+    bw = a.scan.weight[t];
+    bf = a.scan.factor[t];
+  }
+  if (wave == 1 && lane < kHcShapes && !init_slot) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(&a.shapes[lane].inst[inst_of_slot]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_mine[lane]);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
+  }
+  HC_PIN32(a.max_failed);
+  HC_PIN64(a.n_inst);
+  HC_PIN64(a.host);
+  HC_PIN64(a.trace);
+  HC_PIN32(a.trace_cap);
+  HC_PIN64(a.stamps);
+  HC_PIN64(a.map.payload);
+  HC_PIN32(a.map.width);
+  HC_PIN32(a.map.height);
+  HC_PIN32(a.map.pitch);
+  HC_PIN32(a.map.origin_x);
+  HC_PIN32(a.map.origin_y);
+  HC_PINF(a.map.scale);
+  HC_PINF(a.map.inv_scale);
+  HC_PINF(a.map.unknown[0]);
+  HC_PINF(a.map.unknown[1]);
+  HC_PINF(a.map.unknown[2]);
+  HC_PINF(a.map.unknown[3]);
+  HC_PIN32(a.oie);
+  HC_PINF(a.scan.tot_w);
+  const int pb = (k - 1) & 1;
+  if (k > 0) {
+    const double *sc_prev = ctl->scores[pb];
+    for (int i = t; i < kHcSlots; i += NT) s_sc[i] = sc_prev[i];
+    const unsigned long long *wsrc = &ctl->walk[pb][0].w[0];
+    for (int q = t; q < kHcMaxInst * 16; q += NT) s_walk[(q >> 4) * kWalkStride + (q & 15)] = wsrc[q];
+    if (t < (int)(sizeof(HcState) / 8))
+      reinterpret_cast<double *>(&s_prev)[t] = reinterpret_cast<const double *>(&ctl->state[pb])[t];
+  }
+  if (done_epoch == a.epoch) return;  // launched past the end of the chain (uniform: before any barrier)
+  __syncthreads();
+  if (stamp) a.stamps[8 * k + 1] = wall_clock64();
+
+  if (wave == 0) {
+    HcState st;
+    if (k == 0) {
+      st = HcState{};
+      st.x = a.init[0];
+      st.y = a.init[1];
+      st.theta = a.init[2];
+      st.dt = a.dt0;
+      st.dr = a.dr0;
+      st.shape = a.shape0;
+      st.first = 1;
+      if (init_slot) {
+        if (lane == 0) {
+          ctl->state[0] = st;
+          __hip_atomic_store(&a.host->progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        ctl->walk[0][lane] = a.shapes[a.shape0].inst[lane];
+      }
+    } else {
+      // ---- replay of the previous tree, lane = round instance
+      const HcState sp = s_prev;
+      HcInst me;  // the whole record at once: sixteen LDS loads in flight, fields by shifts
+#pragma unroll
+      for (int q = 0; q < 16; ++q) me.w[q] = s_walk[lane * kWalkStride + q];
+      if (stamp) a.stamps[8 * k + 6] = wall_clock64();
+      const int n_inst = (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
+      const double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
+      const bool active = lane < n_inst;
+      const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
+      const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), a.max_failed);
+      const int bpi = hc_bp_inst(me);
+      const double enter = (!active || bpi < 0) ? root_prob : s_sc[6 * bpi + hc_bp_cand(me)];
+      double s6[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s6[c] = s_sc[6 * lane + c];
+      double run;
+      int nacc;
+      const int out = hc_round_outcome(enter, s6, trailing ? 1 : 6, &run, &nacc);
+      bool valid = reach;
+#pragma unroll
+      for (int o = 0; o < 7; ++o) {
+        const unsigned long long has = __ballot(reach && out == o);
+        valid = valid && (me.w[o] & ~has) == 0ull;
+      }
+      const bool terminal = valid && (trailing || hc_child(me, out) < 0);
+      const unsigned long long tmask = __ballot(terminal);
+      // exactly one lane is terminal: the walk's last round
+      const int tl = tmask ? __ffsll((long long)tmask) - 1 : 0;
+      // acceptances on the walked path: a round has at most six, so six ballots and popcounts add them up
+      long long batch_acc = 0;
+#pragma unroll
+      for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
+      if (stamp) a.stamps[8 * k + 7] = wall_clock64();
+      HcState next = sp;
+      if (terminal) {
+        const HcRound r = hc_round_of(sp, me);
+        const long long batch_calls = 6ll * hc_depth(me) + (trailing ? 1 : 6);
+        hc_advance(sp, me, r, out, run, a.max_failed, batch_calls, batch_acc,
+                   6ll * n_inst + (sp.first ? 1 : 0), &next);
+      }
+      // hand the new root state to every lane
+      next.x = bcast(next.x, tl);
+      next.y = bcast(next.y, tl);
+      next.theta = bcast(next.theta, tl);
+      next.best_prob = bcast(next.best_prob, tl);
+      next.dt = bcast(next.dt, tl);
+      next.dr = bcast(next.dr, tl);
+      next.recent_acc = bcast(next.recent_acc, tl);
+      next.recent_n = bcast(next.recent_n, tl);
+      next.calls = bcast_ll(next.calls, tl);
+      next.evaluated = bcast_ll(next.evaluated, tl);
+      next.failed = (unsigned)bcast_i((int)next.failed, tl);
+      next.shape = bcast_i(next.shape, tl);
+      next.done = bcast_i(next.done, tl);
+      next.first = 0;
+      next.steps = sp.steps + 1;
+      if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
+        next.done = 1;
+        if (init_slot && lane == 0) a.host->error = 1;
+      }
+      st = next;
+      if (init_slot) {
+        // ---- the last workgroup keeps the books (it scores nothing after the first super-step, so the
+        // dependent loads and stores below are on no pose's critical path)
+        if (a.trace) {
+          const long long base = sp.calls + (sp.first ? 1 : 0);
+          if (sp.first && lane == 0 && a.trace_cap > 0) {
+            HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};
+            a.trace[0] = e;
+          }
+          if (valid) {
+            const HcRound r = hc_round_of(sp, me);
+            double b = enter;
+            const int nc = trailing ? 1 : 6;
+            for (int c = 0; c < nc; ++c) {
+              HcTraceEntry e;
+              hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, c, &e.x, &e.y, &e.theta);
+              e.score = s_sc[6 * lane + c];
+              e.accepted = b < e.score ? 1 : 0;
+              e.pad = 0;
+              if (e.accepted) b = e.score;
+              const long long at = base + 6ll * hc_depth(me) + c;
+              if (at < a.trace_cap) a.trace[at] = e;
+              else a.host->error = 2;
+            }
+          }
+        }
+        if (lane == 0) ctl->state[k & 1] = next;
+        if (!next.done) ctl->walk[k & 1][lane] = a.shapes[next.shape].inst[lane];
+        if (next.done) {
+          // every lane's trace stores first, then the result, then the flag the host spins on
+          __threadfence_system();
+          if (lane == 0) {
+            ctl->done_epoch = a.epoch;
+            HcHostOut *h = a.host;
+            h->pose[0] = next.x;
+            h->pose[1] = next.y;
+            h->pose[2] = next.theta;
+            h->best_prob = next.best_prob;
+            h->calls = next.calls;
+            h->evaluated = next.evaluated;
+            h->steps = next.steps;
+            __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        } else if (lane == 0) {
+          __hip_atomic_store(&a.host->progress, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    if (stamp) a.stamps[8 * k + 2] = wall_clock64();
+    // ---- this workgroup's pose
+    bool go = !st.done;
+    double px = st.x, py = st.y, pth = st.theta;
+    if (init_slot) {
+      go = go && st.first;
+    } else if (go) {
+      HcInst in;
+#pragma unroll
+      for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
+      go = inst_of_slot < (int)((a.n_inst >> (8 * st.shape)) & 0xffull) &&
+           (hc_is_root(in) || st.failed + hc_nfail_parent(in) < a.max_failed);  // else: behind the end of the chain
+      if (go) {
+        const HcRound r = hc_round_of(st, in);
+        go = !(hc_trailing(r.failed, a.max_failed) && cand > 0);  // a trailing round has one candidate
+        hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, cand, &px, &py, &pth);
+      }
+    }
+    if (go) {
+      double sn, cs;
+      sincos(pth, &sn, &cs);
+      if (lane == 0) {
+        s_pose[0] = px;
+        s_pose[1] = py;
+        s_pose[2] = sn;
+        s_pose[3] = cs;
+      }
+    }
+    if (lane == 0) s_go = go ? 1 : 0;
+  }
+  __syncthreads();
+  if (stamp) a.stamps[8 * k + 3] = wall_clock64();
+  if (!s_go) return;
+  const double px = s_pose[0], py = s_pose[1], sn = s_pose[2], cs = s_pose[3];
+
+  // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order,
+  // wave butterfly, (g0+g1)+(g2+g3)) -- k_score_point's order
+  // up to four beams per thread at a time: their cell gathers are issued together (a clamped index keeps the
+  // code free of branches), the probabilities follow when the values arrive
+  for (int base = t; base < n; base += 4 * NT) {
+    double4 cell[4];
+    double w_[4], f_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = base + j * NT;
+      w_[j] = 0.0;
+      f_[j] = 0.0;
+      cell[j] = make_double4(0.0, 0.0, 0.0, 0.0);
+      if ((base - lane) + j * NT >= n) continue;  // no lane of this wave has a beam in this slot
+      const int bc_ = b < n ? b : n - 1;
+      double r_ = br, ca = bc, sa = bs;
+      w_[j] = bw;
+      f_[j] = bf;
+      if (j > 0 || base != t) {
+        r_ = a.scan.range[bc_];
+        ca = a.scan.cos_a[bc_];
+        sa = a.scan.sin_a[bc_];
+        w_[j] = a.scan.weight[bc_];
+        f_[j] = a.scan.factor[bc_];
+      }
+      cell[j] = beam_cell<MODEL>(a.map, px, py, sn, cs, r_, ca, sa);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int b = base + j * NT;
+      if (b < n) s_term[b] = cell_probability<MODEL>(a.oie, cell[j]) * w_[j] * f_[j];
+    }
+  }
+  __syncthreads();
+  if (stamp) a.stamps[8 * k + 4] = wall_clock64();
+  if (SEQ) {
+    // the reference's own order: one running sum over the beams (weighted_mean_point_probability_spe.h:108-124)
+    if (t == 0) {
+      double acc = 0.0;
+      int b = 0;
+      for (; b + 8 <= n; b += 8) {
+        const double t0 = s_term[b], t1 = s_term[b + 1], t2 = s_term[b + 2], t3 = s_term[b + 3];
+        const double t4 = s_term[b + 4], t5 = s_term[b + 5], t6 = s_term[b + 6], t7 = s_term[b + 7];
+        acc = acc + t0;
+        acc = acc + t1;
+        acc = acc + t2;
+        acc = acc + t3;
+        acc = acc + t4;
+        acc = acc + t5;
+        acc = acc + t6;
+        acc = acc + t7;
+      }
+      for (; b < n; ++b) acc = acc + s_term[b];
+      ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : acc / a.scan.tot_w;
+    }
+    return;
+  }
+  if (t < kSumLanes) {
+    double acc = 0.0;
+    for (int b = t; b < n; b += kSumLanes) acc = acc + s_term[b];
+    acc = wave_xor_sum(acc);
+    if (lane == 0) s_part[wave] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+    if (stamp) a.stamps[8 * k + 5] = wall_clock64();
+  }
+}
+
+// e0 / e1 (optional): HIP events attached to the dispatch (kernel begin .. end), see SLAMHIP_LAUNCH in
+// score_kernels.hip
+#define HC_LAUNCH(NTV)                                                                                          \
+  do {                                                                                                          \
+    if (e0 || e1)                                                                                               \
+      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ>), dim3(kHcSlots), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ>), dim3(kHcSlots), dim3(NTV), shm, stream, a, k);      \
+  } while (0)
+
+template <int MODEL, bool SEQ>
+static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
+  switch (nt) {
+    case 256: HC_LAUNCH(256); break;
+    case 1024: HC_LAUNCH(1024); break;
+    default: HC_LAUNCH(512); break;
+  }
+  return hipGetLastError();
+}
+#undef HC_LAUNCH
+
+hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
+                                hipEvent_t e0, hipEvent_t e1) {
+  if (cell_model == SLAMHIP_CELL_OCC)
+    return a.seq ? launch_nt<SLAMHIP_CELL_OCC, true>(a, k, nt, stream, e0, e1)
+                 : launch_nt<SLAMHIP_CELL_OCC, false>(a, k, nt, stream, e0, e1);
+  if (cell_model == SLAMHIP_CELL_TBM)
+    return a.seq ? launch_nt<SLAMHIP_CELL_TBM, true>(a, k, nt, stream, e0, e1)
+                 : launch_nt<SLAMHIP_CELL_TBM, false>(a, k, nt, stream, e0, e1);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace slamhip

@@ -1,0 +1,58 @@
+// hc_chain_device.h -- what the chain kernel (hc_chain.hip) and its host driver (matchers.cpp) share.
+#pragma once
+
+#include "hc_chain.h"
+#include "slamhip_internal.h"
+
+namespace slamhip {
+
+// one scorer call of the walked path, in the reference's order (what GridScanMatcherObserver sees)
+struct HcTraceEntry {
+  double x, y, theta, score;
+  int accepted, pad;
+};
+
+// pinned, host-coherent: written by workgroup 0, read by the spinning host
+struct HcHostOut {
+  double pose[3];
+  double best_prob;
+  long long calls, evaluated;
+  int steps;
+  int error;           // 1: replay found no terminal round (bug), 2: trace buffer too small
+  unsigned progress;   // super-steps started so far in this process_scan
+  unsigned done_seq;   // = epoch of the process_scan whose result is above
+};
+
+// device memory of one matcher
+struct HcChainCtl {
+  HcState state[2];               // root state of super-step k at [k & 1]
+  HcInst walk[2][kHcMaxInst];     // the round instances of super-step k's tree, same parity
+  double scores[2][kHcSlots + 7];
+  unsigned done_epoch;            // epoch of the last process_scan that ran to its end
+};
+
+struct HcChainArgs {
+  MapView map;
+  ScanView scan;
+  int oie;
+  int seq;  // 1: the reference's beam-order sum instead of the canonical tree (SLAMHIP_SUM_SEQUENTIAL)
+  HcChainCtl *ctl;
+  const HcShape *shapes;  // kHcShapes of them
+  unsigned long long n_inst;  // round instances of shape b in byte b (a dynamic index into an array of
+                              // kernel arguments is a global load: 1 us on the replay's critical path)
+  double init[3];
+  double dt0, dr0;
+  unsigned max_failed;
+  int shape0;
+  unsigned epoch;
+  HcHostOut *host;
+  HcTraceEntry *trace;  // pinned; null = no observer
+  int trace_cap;
+  long long *stamps;    // debugging: 8 wall-clock stamps (100 MHz) per super-step of workgroup 1, or null
+};
+
+// threads per workgroup: 256, 512 or 1024
+hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
+}  // namespace slamhip

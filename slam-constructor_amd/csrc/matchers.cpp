@@ -3,6 +3,8 @@
 
 #include <cstdlib>
 
+#include "hc_chain_device.h"
+#include "hc_shape.h"
 #include "matchers.h"
 
 struct slamhip_matcher {
@@ -15,6 +17,23 @@ struct slamhip_matcher {
   double p_accept0 = 0.25;  // prior per-candidate acceptance rate of a fresh match
   slamhip::MatchJob job;
   double t_stage_us = 0, t_score_us = 0;
+  // hill climbing kept on the device (hc_chain.h): parameters of the enumerator, device / pinned blocks
+  bool is_hc = false;
+  int device = 0;
+  unsigned hc_max_failed = 0;
+  double hc_dt = 0, hc_dr = 0;
+  slamhip::HcChainCtl *d_chain = nullptr;
+  slamhip::HcShape *d_shapes = nullptr;
+  slamhip::HcHostOut *h_chain = nullptr;
+  slamhip::HcTraceEntry *h_trace = nullptr;
+  int trace_cap = 0;
+  int shape_n_inst[slamhip::kHcShapes] = {0};
+  unsigned chain_epoch = 0;
+  double chain_steps_avg = 12.0;
+  int chain_mode = -1;  // -1 = decide from the environment at the first match, 0 off, 1 on
+  int chain_nt = 512, chain_ahead = 3;
+  long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
+  long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
 };
 
 using namespace slamhip;
@@ -31,10 +50,181 @@ int make_matcher(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, std::unique_ptr<P
   if (!ctx || !cfg || !out) return invalid_arg("null argument");
   auto *m = new slamhip_matcher;
   m->ctx = ctx;
+  m->device = ctx->device;
   m->cfg = *cfg;
   m->pe = std::move(pe);
   m->max_batch = default_batch;
   *out = m;
+  return SLAMHIP_OK;
+}
+
+// ---- hill climbing on the device ------------------------------------------------------------------
+}  // namespace
+
+namespace slamhip {
+
+}  // namespace slamhip
+
+namespace {
+
+int chain_release(slamhip_matcher *m) {
+  if (m->d_chain) hipFree(m->d_chain);
+  if (m->d_shapes) hipFree(m->d_shapes);
+  if (m->h_chain) hipHostFree(m->h_chain);
+  if (m->h_trace) hipHostFree(m->h_trace);
+  if (m->d_stamps) hipFree(m->d_stamps);
+  m->d_stamps = nullptr;
+  m->d_chain = nullptr;
+  m->d_shapes = nullptr;
+  m->h_chain = nullptr;
+  m->h_trace = nullptr;
+  return SLAMHIP_OK;
+}
+
+// the chain covers what the shipped single-hypothesis configurations use: hill climbing over the 1-cell
+// OOPE in the default mode; everything else (strict order, host trigonometry, window OOPEs, GMapping,
+// staged copies) keeps the host-driven path
+bool chain_eligible(slamhip_matcher *m) {
+  if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
+  if (m->cfg.oope != SLAMHIP_OOPE_OBSTACLE || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
+  if (m->max_batch < 6 * kHcMaxInst) return false;  // slamhip_matcher_set_batch asked for small batches
+  if (m->chain_mode < 0) {
+    const char *e = getenv("SLAMHIP_HC_CHAIN");
+    m->chain_mode = (e && e[0] == '0') ? 0 : 1;
+    if (const char *t = getenv("SLAMHIP_HC_CHAIN_THREADS")) m->chain_nt = atoi(t);
+    if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
+  }
+  return m->chain_mode == 1;
+}
+
+int chain_prepare(slamhip_matcher *m) {
+  if (m->d_chain) return SLAMHIP_OK;
+  SLAMHIP_CHECK(hipMalloc(&m->d_chain, sizeof(HcChainCtl)));
+  SLAMHIP_CHECK(hipMemset(m->d_chain, 0, sizeof(HcChainCtl)));
+  SLAMHIP_CHECK(hipMalloc(&m->d_shapes, sizeof(HcShape) * kHcShapes));
+  std::vector<HcShape> shapes(kHcShapes);
+  const double boost = getenv("SLAMHIP_HC_BOOST") ? atof(getenv("SLAMHIP_HC_BOOST")) : 1.0;
+  const double reach = getenv("SLAMHIP_HC_CHAIN_REACH") ? atof(getenv("SLAMHIP_HC_CHAIN_REACH")) : 0.002;
+  const int max_inst = getenv("SLAMHIP_HC_CHAIN_INST") ? atoi(getenv("SLAMHIP_HC_CHAIN_INST")) : kHcMaxInst;
+  for (int b = 0; b < kHcShapes; ++b) {
+    hc_build_shape(hc_bucket_rate(b), boost, reach, max_inst, &shapes[b]);
+    m->shape_n_inst[b] = shapes[b].n_inst;
+  }
+  SLAMHIP_CHECK(hipMemcpy(m->d_shapes, shapes.data(), sizeof(HcShape) * kHcShapes, hipMemcpyHostToDevice));
+  const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
+  SLAMHIP_CHECK(hipHostMalloc(&m->h_chain, sizeof(HcHostOut), pinned));
+  std::memset(m->h_chain, 0, sizeof(HcHostOut));
+  return SLAMHIP_OK;
+}
+
+int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3], double out_delta[3],
+                       double *out_prob) {
+  slamhip_ctx *ctx = m->ctx;
+  int rc = chain_prepare(m);
+  if (rc) return rc;
+  HcChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  int cell_model = 0;
+  rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
+  if (rc) return rc;
+  if (m->has_obs && !m->h_trace) {
+    m->trace_cap = 1 << 16;
+    SLAMHIP_CHECK(hipHostMalloc(&m->h_trace, sizeof(HcTraceEntry) * m->trace_cap,
+                                hipHostMallocMapped | hipHostMallocCoherent));
+  }
+  a.oie = m->cfg.oie;
+  a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
+  a.ctl = m->d_chain;
+  a.shapes = m->d_shapes;
+  a.n_inst = 0;
+  for (int b = 0; b < kHcShapes; ++b) a.n_inst |= (unsigned long long)(m->shape_n_inst[b] & 0xff) << (8 * b);
+  for (int k = 0; k < 3; ++k) a.init[k] = init_pose[k];
+  a.dt0 = m->hc_dt;
+  a.dr0 = m->hc_dr;
+  a.max_failed = m->hc_max_failed;
+  a.shape0 = hc_bucket_of(m->p_accept0);
+  unsigned epoch = ++m->chain_epoch;
+  if (epoch == 0) epoch = ++m->chain_epoch;
+  a.epoch = epoch;
+  a.host = m->h_chain;
+  a.trace = m->has_obs ? m->h_trace : nullptr;
+  a.trace_cap = m->has_obs ? m->trace_cap : 0;
+  a.stamps = m->d_stamps;
+  volatile HcHostOut *h = m->h_chain;
+  h->error = 0;
+  h->progress = 0;
+  const double t0 = MatchJob::now_us();
+  int launched = 0;
+  auto launch_one = [&]() -> int {
+    hipEvent_t e0, e1;
+    int r = profile_event_pair(ctx, &e0, &e1);
+    if (r) return r;
+    SLAMHIP_CHECK(launch_hc_chain_step(a, cell_model, launched, m->chain_nt, ctx->stream, e0, e1));
+    ++launched;
+    return SLAMHIP_OK;
+  };
+  // the expected number of super-steps goes out at once; afterwards the host stays a few launches ahead of
+  // the step the GPU reports (a launch costs the host ~3.5 us, a super-step the GPU ~5 us)
+  const int first = std::max(2, std::min(256, (int)(m->chain_steps_avg * 0.75)));
+  for (int i = 0; i < first; ++i) {
+    rc = launch_one();
+    if (rc) return rc;
+  }
+  unsigned long long spins = 0;
+  while (h->done_seq != epoch) {
+    const int started = (int)h->progress;
+    if (launched - started < m->chain_ahead) {
+      if (launched >= (1 << 20)) {
+        set_error("hill-climbing chain did not end");
+        return SLAMHIP_ERR_STATE;
+      }
+      rc = launch_one();
+      if (rc) return rc;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffffull) == 0) {
+      hipError_t qe = hipStreamQuery(ctx->stream);
+      if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "hill-climbing chain kernel");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (h->error == 1) {
+    set_error("internal: the device replay found no terminal round (hill-climbing chain bug)");
+    return SLAMHIP_ERR_STATE;
+  }
+  if (h->error == 2) {
+    set_error("hill-climbing chain: more scorer calls than the trace buffer holds");
+    return SLAMHIP_ERR_UNSUPPORTED;
+  }
+  MatchJob &job = m->job;
+  job.scorer_calls = h->calls;
+  job.poses_evaluated = h->evaluated;
+  job.launches = h->steps;
+  job.t_build_us = job.t_replay_us = 0;
+  m->chain_launched = launched;
+  m->chain_steps_avg = 0.75 * m->chain_steps_avg + 0.25 * (double)h->steps;
+  if (ctx->profile) {
+    ctx->prof_launches += h->steps;
+    ctx->prof_units += h->evaluated * (long long)a.scan.n;
+  }
+  out_delta[0] = h->pose[0] - init_pose[0];
+  out_delta[1] = h->pose[1] - init_pose[1];
+  out_delta[2] = h->pose[2] - init_pose[2];
+  *out_prob = h->best_prob;
+  m->t_score_us = MatchJob::now_us() - t0;
+  if (m->has_obs) {
+    const double t1 = MatchJob::now_us();
+    for (long long i = 0; i < h->calls; ++i) {
+      const HcTraceEntry &e = m->h_trace[i];
+      const double p3[3] = {e.x, e.y, e.theta};
+      if (m->obs.on_scan_test) m->obs.on_scan_test(m->obs.user, p3, e.score);
+      if (e.accepted && m->obs.on_pose_update) m->obs.on_pose_update(m->obs.user, p3, e.score);
+    }
+    job.t_replay_us = MatchJob::now_us() - t1;
+    if (m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, out_delta, *out_prob);
+  }
   return SLAMHIP_OK;
 }
 
@@ -52,8 +242,14 @@ int slamhip_matcher_create_mc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, unsi
 
 int slamhip_matcher_create_hc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, unsigned failed_rounds_limit,
                               double dt, double dr, slamhip_matcher **out) {
-  return make_matcher(ctx, cfg, std::make_unique<HillClimbingPoseEnumerator>(failed_rounds_limit, dt, dr),
-                      1024, out);
+  int rc = make_matcher(ctx, cfg, std::make_unique<HillClimbingPoseEnumerator>(failed_rounds_limit, dt, dr),
+                        1024, out);
+  if (rc) return rc;
+  (*out)->is_hc = true;
+  (*out)->hc_max_failed = failed_rounds_limit;
+  (*out)->hc_dt = dt;
+  (*out)->hc_dr = dr;
+  return SLAMHIP_OK;
 }
 
 int slamhip_matcher_create_bf(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, const double range9[9],
@@ -66,6 +262,15 @@ int slamhip_matcher_create_bf(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, cons
 }
 
 int slamhip_matcher_destroy(slamhip_matcher *m) {
+  if (m) {
+    if (m->d_chain) {
+      // run-ahead kernels of the last chain may still read the blocks; the context may already be gone
+      // (destroying it synchronised its stream), so wait on the device, not on the context's stream
+      hipSetDevice(m->device);
+      hipDeviceSynchronize();
+    }
+    chain_release(m);
+  }
   delete m;
   return SLAMHIP_OK;
 }
@@ -86,6 +291,30 @@ int slamhip_matcher_set_observer(slamhip_matcher *m, const slamhip_observer *obs
 int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch) {
   if (!m || max_batch < 0) return invalid_arg("bad batch");
   if (max_batch > 0) m->max_batch = max_batch;
+  return SLAMHIP_OK;
+}
+
+int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads) {
+  if (!m || (mode != 0 && mode != 1) || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
+    return invalid_arg("bad device-chain setting");
+  (void)chain_eligible(m);  // environment defaults first, then the explicit setting
+  m->chain_mode = mode;
+  if (threads) m->chain_nt = threads;
+  return SLAMHIP_OK;
+}
+
+// debugging aid, not part of include/slamhip.h: wall-clock stamps (100 MHz) of workgroup 1 inside the
+// first 64 super-steps of the following process_scan calls: kernel entry, staged, replayed, pose ready,
+// terms ready, score stored, two spare
+int slamhip_matcher_debug_stamps(slamhip_matcher *m, long long *out512) {
+  if (!m) return invalid_arg("null matcher");
+  if (!m->d_stamps) {
+    SLAMHIP_CHECK(hipMalloc(&m->d_stamps, sizeof(long long) * 512));
+    SLAMHIP_CHECK(hipMemset(m->d_stamps, 0, sizeof(long long) * 512));
+    return SLAMHIP_OK;
+  }
+  SLAMHIP_CHECK(hipDeviceSynchronize());
+  if (out512) SLAMHIP_CHECK(hipMemcpy(out512, m->d_stamps, sizeof(long long) * 512, hipMemcpyDeviceToHost));
   return SLAMHIP_OK;
 }
 
@@ -113,6 +342,7 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   if (!m || !init_pose || !out_delta || !out_prob) return invalid_arg("null argument");
   slamhip_ctx *ctx = m->ctx;
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  if (chain_eligible(m)) return chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   const int budget = m->max_batch > 0 ? m->max_batch : 256;
   int rc = ensure_pose_capacity(ctx, budget + 1);

@@ -39,20 +39,12 @@
 
 #include <algorithm>
 
-#include "slamhip_internal.h"
+#include "score_device.h"
 
 namespace slamhip {
 
 static constexpr int kBlock = 256;
 static constexpr int kMaxPosesPerBlock = 16;
-
-// ---- helpers ---------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_xor_sum(double v) {
-  // fixed butterfly: every lane ends with the same bits (a+b == b+a in IEEE)
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
-}
 
 // Completion signal for the low-latency host path: scoring kernels write their results straight
 // into pinned, coherent host memory with plain stores; this 1-thread kernel, queued right behind
@@ -67,52 +59,6 @@ __global__ void k_publish(unsigned *flag, unsigned seq) {
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, flag, seq);
   return hipGetLastError();
-}
-
-// world_to_cell: int(floor(x / scale)) with a TRUE division (Q15: multiplying by 1/scale flips
-// cells at boundaries).  The division is the most expensive thing in the per-beam body, so it is
-// only executed when it can matter: with t = v/scale, RN(t) is within 2^-53 |t| of t and
-// q = RN(v * RN(1/scale)) within 2^-52 |t|, hence no integer separates q from RN(t) unless q lies
-// within 1.5 * 2^-52 |q| of one.  Outside a 2^-49 |q| band around integers floor(q) IS the
-// reference's cell; inside it (endpoints exactly on cell boundaries do occur, e.g. the reference's
-// HC smoke fixture) the true quotient is evaluated.  The absolute term sends underflowing products
-// to the exact path as well.
-__device__ __forceinline__ int to_cell(double v, double scale, double inv_scale) {
-  const double q = v * inv_scale;
-  const double f = floor(q);
-  const double d = q - f;
-  const double tol = fabs(q) * 0x1p-49 + 0x1p-1000;
-  if (__builtin_expect(d < tol || (1.0 - d) < tol, 0)) return (int)floor(v / scale);
-  return (int)f;
-}
-
-template <int MODEL>
-__device__ __forceinline__ double point_probability(const MapView &m, int oie, int cx, int cy) {
-  const int ix = cx + m.origin_x, iy = cy + m.origin_y;
-  const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
-  if (MODEL == SLAMHIP_CELL_OCC) {
-    double occ = m.unknown[0];
-    if (inb) occ = m.payload[(size_t)iy * m.pitch + ix];
-    if (oie == SLAMHIP_OIE_OCCUPANCY) return occ;
-    return 1.0 - fabs(occ - 1.0);
-  } else {
-    double U = m.unknown[0], E = m.unknown[1], O = m.unknown[2], Cc = m.unknown[3];
-    if (inb) {
-      const double4 *p = reinterpret_cast<const double4 *>(m.payload) + ((size_t)iy * m.pitch + ix);
-      const double4 v = *p;
-      U = v.x; E = v.y; O = v.z; Cc = v.w;
-    }
-    // that = aoo2tbm(obstacle AOO) = (u,e,o,c) = (0,0,1,0); conjunctive(that, cell) before
-    // normalisation = (0, 0, U+O, E+C); normalize() divides by the total mass.
-    const double d_occ = fabs(1.0 - O);
-    const double t2 = U + O, t3 = E + Cc;
-    const double tot = t2 + t3;
-    const double conflict = (tot == 0.0) ? 0.0 : t3 / tot;
-    const double unknown = U / 2.0;
-    const double known = 1 - unknown;
-    const double known_discrepancy = known * (conflict + d_occ) / 2.0;
-    return 1.0 - (unknown / 2 + known_discrepancy);
-  }
 }
 
 // ---- K1 ----------------------------------------------------------------------------------------

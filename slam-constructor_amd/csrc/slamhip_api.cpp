@@ -177,6 +177,37 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
   return SLAMHIP_OK;
 }
 
+// views of the bound map and the uploaded scan for kernels that are not launched through launch_score
+// (the hill-climbing chain); same checks as a scoring call
+int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
+                int *cell_model) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  int rc = check_cfg(*m, cfg);
+  if (rc) return rc;
+  ScoreArgs a;
+  rc = fill_args(ctx, *m, cfg, 1, nullptr, nullptr, nullptr, &a);
+  if (rc) return rc;
+  *map = a.map;
+  *scan = a.scan;
+  *cell_model = m->cell_model;
+  return SLAMHIP_OK;
+}
+
+// an event pair of the profiling pool (resolved in slamhip_profile_read); null, null when profiling is off
+int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1) {
+  *e0 = *e1 = nullptr;
+  if (!ctx->profile) return SLAMHIP_OK;
+  if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+    const size_t old_n = ctx->ev_pool.size();
+    ctx->ev_pool.resize(old_n + 512, nullptr);
+    for (size_t i = old_n; i < ctx->ev_pool.size(); ++i) SLAMHIP_CHECK(hipEventCreate(&ctx->ev_pool[i]));
+  }
+  *e0 = ctx->ev_pool[ctx->ev_used++];
+  *e1 = ctx->ev_pool[ctx->ev_used++];
+  return SLAMHIP_OK;
+}
+
 static int profile_resolve(slamhip_ctx *ctx) {
   if (ctx->ev_used == 0) return SLAMHIP_OK;
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -186,4 +186,7 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
 int score_wait(slamhip_ctx *ctx, unsigned seq, int lane = 0);
 // orders the second lane behind everything queued on the first so far (scan upload, map updates)
 int lane_fork(slamhip_ctx *ctx);
+int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
+                int *cell_model);
+int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);
 }  // namespace slamhip

@@ -1,0 +1,149 @@
+"""GPU suite: hill climbing kept on the device (csrc/hc_chain.hip) against the host-driven matcher and the
+oracle.  The chain kernel scores with the arithmetic of k_score_point and replays the reference's accept
+loop (pose_enumeration_scan_matcher.h:31-77) itself, so
+  * its observer trace (poses, scores, accepted flags), result pose and score must equal the host-driven
+    default mode BIT FOR BIT (same sincos, same canonical sum, same enumerator arithmetic);
+  * against the oracle's strict accept loop the trace must be identical with scores within 1e-12;
+  * a fuzz over random scenes counts accept-trace divergences between the default mode (device chain) and
+    the strict mode (SLAMHIP_SUM_SEQUENTIAL + host trig, bit-exact with the reference): none allowed."""
+import numpy as np
+import pytest
+from helpers import assert_trace_equal
+from synth import CELL_OCC, CELL_TBM, make_scene
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+STRICT = dict(sum_order=1, pose_trig=1)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def po():
+    import pyoracle
+    return pyoracle
+
+
+def upload(pkg, ctx, sc):
+    ctx.upload_map(0, sc["map"])
+    cos_a, sin_a = pkg.beam_trig(sc["scan"].angle)
+    ctx.scan_upload(sc["scan"].range, cos_a, sin_a, sc["scan"].weight, sc["scan"].factor)
+
+
+def matchers(pkg, ctx, prm, threads=0):
+    dev = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    dev.set_device_chain(1, threads)
+    host = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    host.set_device_chain(0)
+    return dev, host
+
+
+@pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
+@pytest.mark.parametrize("prm", [[1, 0.1, 0.1], [6, 0.1, 0.1], [128, 0.1, 0.1], [250, 0.3, 0.05]])
+def test_chain_equals_host_driven_matcher(pkg, ctx, po, oracle, cell, weighting, prm):
+    sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=5, weighting=weighting)
+    upload(pkg, ctx, sc)
+    dev, host = matchers(pkg, ctx, prm)
+    init = sc["init_pose"]
+    for rep in range(3):  # repeated matches on one matcher: run-ahead kernels of the last chain, new epoch
+        td = dev.process_scan(0, init, trace=True)
+        th = host.process_scan(0, init, trace=True)
+        assert_trace_equal(td, th)  # bit for bit
+        sd, sh = dev.stats(), host.stats()
+        assert sd["scorer_calls"] == sh["scorer_calls"] == td["n_calls"]
+        assert sd["launches"] >= 1
+        # without an observer: same result, no trace buffer involved
+        q = dev.process_scan(0, init)
+        assert q["prob"] == td["prob"] and np.array_equal(q["delta"], td["delta"])
+        init = init + np.array([0.013, -0.007, 0.004])
+    # the oracle's strict loop: identical trace, scores to 1e-12
+    e = oracle.enumerator(po.SM_HC, prm)
+    r = oracle.process_scan(e, sc["map"], sc["scan"], po.make_cfg(), sc["init_pose"])
+    t = dev.process_scan(0, sc["init_pose"], trace=True)
+    assert_trace_equal(t, r, exact_scores=False, rtol=1e-12)
+
+
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+def test_chain_workgroup_sizes_and_beam_counts(pkg, ctx, threads):
+    rs = np.random.RandomState(3)
+    for n_beams in (1, 63, 257, 1080, 1500, 2300):
+        sc = make_scene(cell_model=CELL_OCC, size=400, scale=0.1, n_beams=max(n_beams, 8), seed=7)
+        s = sc["scan"]
+        keep = np.sort(rs.choice(s.n, min(n_beams, s.n), replace=False))
+        s.range, s.angle, s.weight, s.factor = s.range[keep], s.angle[keep], s.weight[keep], s.factor[keep]
+        upload(pkg, ctx, sc)
+        dev, host = matchers(pkg, ctx, [20, 0.1, 0.1], threads)
+        assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True),
+                           host.process_scan(0, sc["init_pose"], trace=True))
+
+
+def test_chain_zero_weight_scan_and_far_pose(pkg, ctx):
+    sc = make_scene(cell_model=CELL_OCC, size=400, scale=0.1, n_beams=360, seed=9)
+    sc["scan"].weight[:] = 0.0  # total weight 0: every score is NaN, nothing is ever accepted
+    upload(pkg, ctx, sc)
+    dev, host = matchers(pkg, ctx, [6, 0.1, 0.1])
+    td, th = dev.process_scan(0, sc["init_pose"], trace=True), host.process_scan(0, sc["init_pose"], trace=True)
+    assert td["n_calls"] == th["n_calls"] == 1 + 6 * 6 + 1 and not td["accepted"][1:].any()
+    assert np.isnan(td["scores"]).all() and np.array_equal(td["poses"], th["poses"])
+    sc = make_scene(cell_model=CELL_OCC, size=400, scale=0.1, n_beams=360, seed=9)
+    upload(pkg, ctx, sc)
+    far = np.array([1e4, -1e4, 0.3])  # every end point outside the window: unknown cells, all scores equal
+    assert_trace_equal(dev.process_scan(0, far, trace=True), host.process_scan(0, far, trace=True))
+
+
+def test_fuzz_default_and_sequential_sum_modes_against_strict_mode(pkg, ctx):
+    """how often does the default mode (canonical tree sum + device sincos; for hill
+    climbing the device chain) take another accept path than the bit-exact strict mode (beam-order sum +
+    host trig)?  200 matches over 40 random scenes.
+      * the device chain with the reference's beam-order sum (sum_order = SEQUENTIAL, device sincos): never --
+        the device sincos is not what flips a comparison;
+      * the default mode: only where the strict mode's `best < candidate` compares two sums that are equal or
+        one ulp apart (mathematically tied candidates: the same multiset of beam terms met in another beam
+        order), never anywhere else."""
+    div_seq, div_tree, matches, calls = 0, 0, 0, 0
+    for seed in range(40):
+        cell = CELL_TBM if seed % 3 == 0 else CELL_OCC
+        sc = make_scene(cell_model=cell, size=500, scale=0.05, n_beams=360 + 90 * (seed % 5), seed=100 + seed,
+                        weighting="viny" if cell == CELL_TBM else "even")
+        upload(pkg, ctx, sc)
+        rs = np.random.RandomState(seed)
+        prm = [6 + 7 * (seed % 4), 0.1, 0.1]
+        dev = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+        seq = pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm)  # runs on the device chain too
+        strict = pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), prm)
+        for rep in range(5):
+            init = sc["true_pose"] + rs.randn(3) * [0.08, 0.08, 0.04]
+            b = strict.process_scan(0, init, trace=True)
+            matches += 1
+            calls += b["n_calls"]
+            for which, m in (("seq", seq), ("tree", dev)):
+                a = m.process_scan(0, init, trace=True)
+                n = min(a["n_calls"], b["n_calls"])
+                bad = np.nonzero((a["accepted"][:n] != b["accepted"][:n]) | (a["poses"][:n] != b["poses"][:n]).any(1))[0]
+                if a["n_calls"] == b["n_calls"] and len(bad) == 0:
+                    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-12, atol=0)
+                    continue
+                if which == "seq":
+                    div_seq += 1
+                    continue
+                div_tree += 1
+                i = int(bad[0]) if len(bad) else n
+                assert i < n and np.array_equal(a["poses"][i], b["poses"][i])  # same candidate, other decision
+                acc = np.nonzero(b["accepted"][:i])[0]
+                best = b["scores"][acc[-1]]
+                assert abs(b["scores"][i] - best) <= 2 * np.spacing(best), \
+                    "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
+    assert matches == 200 and calls > 200 * 40
+    assert div_seq == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div_seq, matches)
+    assert div_tree <= 10, "%d of %d default-mode matches diverged at tied comparisons" % (div_tree, matches)
