@@ -345,6 +345,65 @@ int slamhip_gmapping_particle_map_export(slamhip_gmapping *g, int particle, void
 int slamhip_gmapping_import_maps(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx, int n_remote,
                                  const int *remote_src, const void *const *remote_bufs);
 int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, int *is_master);
+
+/* ---------------------------------------------------------------- sharding over GPUs (RCCL over xGMI)
+ * What gets distributed is ParticleFilter's particle loop (src/core/particle_filter.h:108-112 over
+ * GmappingWorld::handle_sensor_data) -- one shard [first, first + count) of the particles per GPU, one
+ * process (or thread) per GPU, one context each -- and what has to be collected is what
+ * normalize_weights / UniformResamling read: ALL raw weights, in particle order (:34-66).  The one
+ * collective of a step is therefore an all-gather of n_total doubles; an all-reduce of (sum w, sum w^2)
+ * would be smaller but adds in another order than the reference does, and resampling indices must stay
+ * bit-exact.  RCCL is loaded when the first of these functions is called (librccl.so is not a link
+ * dependency of libslamhip.so).
+ *   rank 0:      slamhip_shard_unique_id(id)          -> hand the 128 bytes to the other ranks (MPI, a
+ *                                                        file, a socket: whatever started the processes)
+ *   every rank:  slamhip_shard_init(ctx, rank, world, id)
+ *   per scan:    slamhip_gmapping_step_sharded(...)   = match_begin, the carry exchange, match_finish,
+ *                                                        all-gather of the raw weights, plan_resample and,
+ *                                                        when a resampling happens, all-gather of the
+ *                                                        particle records + import */
+#define SLAMHIP_SHARD_ID_BYTES 128
+int slamhip_shard_unique_id(void *id_out);
+int slamhip_shard_init(slamhip_ctx *ctx, int rank, int world, const void *id);
+int slamhip_shard_destroy(slamhip_ctx *ctx);
+int slamhip_shard_info(slamhip_ctx *ctx, int *rank, int *world);
+/* all-gather of per-rank blocks: rank r contributes counts[r] elements of elem_bytes bytes (host memory,
+ * `local`); `all_out` (host) receives the blocks in rank order.  Blocks are padded to the largest one on
+ * the wire (100 particles on 8 GPUs are 13 x 4 + 12 x 4). */
+int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *counts, int elem_bytes,
+                            void *all_out);
+/* bytes moved through RCCL and collectives issued since slamhip_shard_init */
+int slamhip_shard_stats(slamhip_ctx *ctx, long long *collectives, long long *bytes);
+
+/* A step in phases, for callers that bring their own collective: match_begin = odometry, gate, pose noise
+ * and the lock-step matching of the local shard; match_finish = poses, weights (and the batched map
+ * update of per-particle maps); slamhip_gmapping_predict_match is begin + finish.
+ * Between them, sharded steps repair the ONE OOPE cache the reference's particles hand from one to the
+ * next (gmapping_occupancy_observation_pe.h:21-24,36-37,43-44): every shard starts its
+ * first job without a carry (slamhip_gmapping_set_shard_chain), publishes a slamhip_carry_record, and
+ * checks its first job against the final cache entry of the shard before it -- re-matching on a hit --
+ * until no record changes any more (at most `world` rounds; none in practice). */
+typedef struct {
+  int has_active;                 /* some particle of the shard matched in this step */
+  int first_cx, first_cy;         /* end-point cell of the first beam of its first scored pose ... */
+  double first_v0;                /* ... and the fresh value of that beam */
+  int carry_cx, carry_cy;         /* the cache entry the shard's last job ended with */
+  double carry_prob;
+} slamhip_carry_record;
+int slamhip_gmapping_set_shard_chain(slamhip_gmapping *g, int on);
+int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                 const double *angle, const int *is_occ, const double odom_delta[3]);
+int slamhip_gmapping_carry_record(slamhip_gmapping *g, slamhip_carry_record *rec);
+int slamhip_gmapping_carry_fix(slamhip_gmapping *g, const slamhip_carry_record *all, int world, int rank,
+                               int *changed);
+int slamhip_gmapping_carry_commit(slamhip_gmapping *g, const slamhip_carry_record *all, int world);
+int slamhip_gmapping_match_finish(slamhip_gmapping *g, double *raw_weights_out);
+/* one scan on a shard, collectives included (needs slamhip_shard_init on the filter's context; a filter
+ * with per-particle maps resamples through slamhip_gmapping_import_maps and is not covered here).
+ * resampled / idx_out as in slamhip_gmapping_step; idx_out holds n_total indices. */
+int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                  const double *angle, const int *is_occ, const double odom_delta[3],
+                                  uint32_t resample_seed, int *resampled, unsigned *idx_out);
 int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
                            long long *launches, long long *carry_reruns);
 

@@ -41,7 +41,13 @@ slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapp
 slamhip_gmapping_stats slamhip_gmapping_set_map_update slamhip_map_append_scan slamhip_map_download_aux
 slamhip_gmapping_enable_particle_maps slamhip_gmapping_particle_map_download
 slamhip_gmapping_particle_map_stats slamhip_gmapping_particle_map_export_size
-slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps""".split()
+slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps
+slamhip_shard_unique_id slamhip_shard_init slamhip_shard_destroy slamhip_shard_info slamhip_shard_allgather
+slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begin slamhip_gmapping_carry_record
+slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
+slamhip_gmapping_step_sharded""".split()
+
+SHARD_ID_BYTES = 128
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -49,6 +55,11 @@ _ip = C.POINTER(C.c_int)
 
 class SlamHipError(RuntimeError):
     pass
+
+
+class CarryRecord(C.Structure):
+    _fields_ = [("has_active", C.c_int), ("first_cx", C.c_int), ("first_cy", C.c_int), ("first_v0", C.c_double),
+                ("carry_cx", C.c_int), ("carry_cy", C.c_int), ("carry_prob", C.c_double)]
 
 
 class SpeCfg(C.Structure):
@@ -192,8 +203,28 @@ def load():
     L.slamhip_gmapping_particle_map_export_size.argtypes = [vp, i, C.POINTER(C.c_size_t)]
     L.slamhip_gmapping_particle_map_export.argtypes = [vp, i, vp, C.c_size_t]
     L.slamhip_gmapping_import_maps.argtypes = [vp, vp, up, i, _ip, C.POINTER(vp)]
+    L.slamhip_shard_unique_id.argtypes = [vp]
+    L.slamhip_shard_init.argtypes = [vp, i, i, vp]
+    L.slamhip_shard_destroy.argtypes = [vp]
+    L.slamhip_shard_info.argtypes = [vp, _ip, _ip]
+    L.slamhip_shard_allgather.argtypes = [vp, vp, _ip, i, vp]
+    L.slamhip_shard_stats.argtypes = [vp, ll, ll]
+    L.slamhip_gmapping_set_shard_chain.argtypes = [vp, i]
+    L.slamhip_gmapping_match_begin.argtypes = [vp, i, i, _dp, _dp, _ip, _dp]
+    L.slamhip_gmapping_carry_record.argtypes = [vp, C.POINTER(CarryRecord)]
+    L.slamhip_gmapping_carry_fix.argtypes = [vp, C.POINTER(CarryRecord), i, i, _ip]
+    L.slamhip_gmapping_carry_commit.argtypes = [vp, C.POINTER(CarryRecord), i]
+    L.slamhip_gmapping_match_finish.argtypes = [vp, _dp]
+    L.slamhip_gmapping_step_sharded.argtypes = [vp, i, i, _dp, _dp, _ip, _dp, C.c_uint32, _ip, up]
     _lib = L
     return L
+
+
+def shard_unique_id():
+    """128 bytes that rank 0 creates and every rank hands to Context.shard_init (ncclGetUniqueId)."""
+    buf = np.zeros(SHARD_ID_BYTES, np.uint8)
+    _check(load().slamhip_shard_unique_id(buf.ctypes.data_as(C.c_void_p)))
+    return buf
 
 
 def _check(rc):
@@ -376,6 +407,39 @@ class Context:
         _check(self.L.slamhip_score_poses_device(self.h, map_id, C.byref(cfg), n,
                                                  C.c_void_p(d_poses_ptr), C.c_void_p(d_scores_ptr)))
 
+    def shard_init(self, rank, world, unique_id):
+        """Joins the RCCL group of `world` contexts (one per GPU)."""
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == SHARD_ID_BYTES
+        _check(self.L.slamhip_shard_init(self.h, rank, world, uid.ctypes.data_as(C.c_void_p)))
+
+    def shard_destroy(self):
+        _check(self.L.slamhip_shard_destroy(self.h))
+
+    def shard_info(self):
+        r, w = C.c_int(), C.c_int()
+        _check(self.L.slamhip_shard_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def shard_allgather(self, local, counts):
+        """All-gather of per-rank blocks of counts[r] rows (RCCL); returns the rows of all ranks in rank order."""
+        a = np.ascontiguousarray(local)
+        cn = np.ascontiguousarray(counts, dtype=np.int32)
+        rank, world = self.shard_info()
+        assert cn.size == world
+        row = a.size // max(int(cn[rank]), 1) if cn[rank] else 0
+        assert cn[rank] == 0 or a.size == row * cn[rank]
+        row = max(row, 1)
+        out = np.zeros((int(cn.sum()), row) if row > 1 else int(cn.sum()), dtype=a.dtype)
+        _check(self.L.slamhip_shard_allgather(self.h, a.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(_ip),
+                                              a.dtype.itemsize * row, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def shard_stats(self):
+        a, b = C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_shard_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(collectives=a.value, bytes=b.value)
+
     def gm_cache_reset(self):
         _check(self.L.slamhip_gm_cache_reset(self.h))
 
@@ -538,6 +602,47 @@ class GmappingFilter:
                                             occ.ctypes.data_as(_ip), _d(d), resample_seed,
                                             C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_uint))))
         return bool(res.value), idx
+
+    def step_sharded(self, map_id, rng, ang, is_occ, odom_delta, resample_seed):
+        """One scan on this shard, RCCL collectives included (Context.shard_init first)."""
+        rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
+        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        res = C.c_int(0)
+        idx = np.zeros(self.n_total, np.uint32)
+        _check(self.L.slamhip_gmapping_step_sharded(self.h, map_id, rng.size, _d(rng), _d(ang),
+                                                    occ.ctypes.data_as(_ip), _d(d), resample_seed,
+                                                    C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_uint))))
+        return bool(res.value), idx
+
+    # a step in phases (sharded filters with a caller-side collective)
+    def set_shard_chain(self, on=True):
+        _check(self.L.slamhip_gmapping_set_shard_chain(self.h, 1 if on else 0))
+
+    def match_begin(self, map_id, rng, ang, is_occ, odom_delta):
+        rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
+        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        _check(self.L.slamhip_gmapping_match_begin(self.h, map_id, rng.size, _d(rng), _d(ang),
+                                                   occ.ctypes.data_as(_ip), _d(d)))
+
+    def carry_record(self):
+        r = CarryRecord()
+        _check(self.L.slamhip_gmapping_carry_record(self.h, C.byref(r)))
+        return r
+
+    def carry_fix(self, records, rank):
+        arr = (CarryRecord * len(records))(*records)
+        ch = C.c_int(0)
+        _check(self.L.slamhip_gmapping_carry_fix(self.h, arr, len(records), rank, C.byref(ch)))
+        return bool(ch.value)
+
+    def carry_commit(self, records):
+        arr = (CarryRecord * len(records))(*records)
+        _check(self.L.slamhip_gmapping_carry_commit(self.h, arr, len(records)))
+
+    def match_finish(self):
+        raw = np.zeros(self.count)
+        _check(self.L.slamhip_gmapping_match_finish(self.h, _d(raw)))
+        return raw
 
     def set_map_update(self, enable=True, base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"),
                        estimator=0, shift_amount=0.0):

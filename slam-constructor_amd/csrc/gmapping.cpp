@@ -107,6 +107,7 @@ struct slamhip_gmapping {
   std::vector<GmParticle> p;  // local shard
   double traversed[3] = {0, 0, 0};
   GmCarry carry;  // the shared OOPE cache as this shard sees it
+  GmCarry step_carry;  // sharded steps: the cache entry the previous step ended with (on every shard)
   std::vector<MatchJob> jobs;
   std::vector<HillClimbingPoseEnumerator> pes;
   std::vector<double> all_w;  // normalised weights of all particles (after plan_resample)
@@ -123,6 +124,19 @@ struct slamhip_gmapping {
   TilePool *tp = nullptr;
   TiledTarget tt{};
   bool maps_handled_by_caller = false;  // set by slamhip_gmapping_import_maps around the particle import
+  // a step in three phases (slamhip_gmapping_match_begin / _carry_fix / _match_finish): what the first
+  // leaves for the others
+  std::vector<int> act_idx;
+  std::vector<MatchJob *> act;
+  bool pending = false;      // begin ran, finish did not yet
+  bool chained = false;      // the jobs of this step ran in lock-step (the carry chain can be re-checked)
+  bool shard_chain = false;  // sharded step: the first job starts WITHOUT a carry and is checked afterwards
+                             // against the predecessor shard's final cache entry (carry_fix)
+  int pending_map = 0;
+  std::vector<int> shard_counts;   // particles per rank (slamhip_gmapping_step_sharded)
+  std::vector<double> scan_range;  // the raw scan of the step in flight (finish appends it to the maps)
+  std::vector<int> scan_occ;
+  bool scan_has_occ = false;
 };
 
 namespace {
@@ -291,10 +305,38 @@ int slamhip_gmapping_destroy(slamhip_gmapping *g) {
   return SLAMHIP_OK;
 }
 
-int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
-                                   const double *angle, const int *is_occ, const double odom_delta[3],
-                                   double *raw_weights_out) {
+// the shared-cache chain in the reference's particle order, from job `from` on: a particle whose first
+// run would have hit its predecessor's final cache entry with another value is re-matched alone with
+// that carry
+static int verify_chain(slamhip_gmapping *g, int map_id, size_t from) {
+  std::vector<MatchJob *> &act = g->act;
+  const std::vector<int> &act_idx = g->act_idx;
+  if (act.empty()) return SLAMHIP_OK;
+  int rc;
+  GmCarry prev = act[from - 1]->carry;
+  for (size_t k = from; k < act.size(); ++k) {
+    MatchJob &job = *act[k];
+    const GmPoseInfo &fi = job.first_info;
+    if (prev.prob != -1.0 && fi.first_cx == prev.cx && fi.first_cy == prev.cy && prev.prob != fi.v0) {
+      g->pes[k] = HillClimbingPoseEnumerator(g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
+                                             g->prm.hc_rotation);
+      const GmParticle &p = g->p[act_idx[k]];
+      job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, prev, 0.25);
+      std::vector<MatchJob *> one{&job};
+      rc = run_jobs(g, map_id, one, 126, g->tp ? &act_idx[k] : nullptr);
+      if (rc) return rc;
+      g->carry_reruns += 1;
+    }
+    prev = job.carry;
+  }
+  g->carry = prev;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                 const double *angle, const int *is_occ, const double odom_delta[3]) {
   if (!g || !range || !angle || !odom_delta) return bad("null argument");
+  if (g->pending) return bad("the previous step was not finished (slamhip_gmapping_match_finish)");
   slamhip_ctx *ctx = g->ctx;
   if (!ctx) {
     set_error("this filter was created without a GPU context; there is no CPU scorer");
@@ -319,7 +361,15 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
   for (int k = 0; k < 3; ++k) g->traversed[k] += std::fabs(d[k]);
 
   // gate + pose noise, in particle order
-  std::vector<int> act_idx;
+  std::vector<int> &act_idx = g->act_idx;
+  act_idx.clear();
+  g->act.clear();
+  g->chained = false;
+  g->pending = true;
+  g->pending_map = map_id;
+  g->scan_range.assign(range, range + n_raw);
+  g->scan_has_occ = is_occ != nullptr;
+  if (is_occ) g->scan_occ.assign(is_occ, is_occ + n_raw);
   for (int i = 0; i < g->count; ++i) {
     GmParticle &p = g->p[i];
     if (p.dsl[0] * p.dsl[0] + p.dsl[1] * p.dsl[1] < p.nsd[0] * p.nsd[0] + p.nsd[1] * p.nsd[1] &&
@@ -398,19 +448,18 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
         reset_sm_delta(p);
         g->scorer_calls += job.scorer_calls;
       }
-      if (raw_weights_out)
-        for (int i = 0; i < g->count; ++i) raw_weights_out[i] = g->p[i].weight;
+      act_idx.clear();  // everything is applied already: nothing left for match_finish
       return SLAMHIP_OK;
     }
     g->pes.clear();
     g->pes.reserve(act_idx.size());
-    std::vector<MatchJob *> act;
+    std::vector<MatchJob *> &act = g->act;
     for (size_t k = 0; k < act_idx.size(); ++k) {
       g->pes.emplace_back(g->prm.hc_failed_rounds_limit, g->prm.hc_translation, g->prm.hc_rotation);
       GmParticle &p = g->p[act_idx[k]];
       MatchJob &job = g->jobs[act_idx[k]];
       job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr,
-                k == 0 ? g->carry : GmCarry{}, 0.25);
+                (k == 0 && !g->shard_chain) ? g->carry : GmCarry{}, 0.25);
       act.push_back(&job);
     }
     int per_job = std::max(6, std::min(126, 12288 / (int)act.size() / 6 * 6));
@@ -423,24 +472,26 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
     }
     rc = run_jobs(g, map_id, act, per_job, g->tp ? act_idx.data() : nullptr);  // slot = particle index
     if (rc) return rc;
-    // verify the shared-cache chain in the reference's particle order; re-match on a hit
-    GmCarry prev = act[0]->carry;
-    for (size_t k = 1; k < act.size(); ++k) {
-      MatchJob &job = *act[k];
-      const GmPoseInfo &fi = job.first_info;
-      if (prev.prob != -1.0 && fi.first_cx == prev.cx && fi.first_cy == prev.cy && prev.prob != fi.v0) {
-        g->pes[k] = HillClimbingPoseEnumerator(g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
-                                               g->prm.hc_rotation);
-        const GmParticle &p = g->p[act_idx[k]];
-        job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, prev, 0.25);
-        std::vector<MatchJob *> one{&job};
-        rc = run_jobs(g, map_id, one, 126, g->tp ? &act_idx[k] : nullptr);
-        if (rc) return rc;
-        g->carry_reruns += 1;
-      }
-      prev = job.carry;
-    }
-    g->carry = prev;
+    g->chained = true;
+    rc = verify_chain(g, map_id, 1);
+    if (rc) return rc;
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_match_finish(slamhip_gmapping *g, double *raw_weights_out) {
+  if (!g) return bad("null filter");
+  if (!g->pending) return bad("no step in flight (slamhip_gmapping_match_begin)");
+  slamhip_ctx *ctx = g->ctx;
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  g->pending = false;
+  const std::vector<int> &act_idx = g->act_idx;
+  std::vector<MatchJob *> &act = g->act;
+  const int n_raw = (int)g->scan_range.size();
+  const double *range = g->scan_range.data();
+  const int *is_occ = g->scan_has_occ ? g->scan_occ.data() : nullptr;
+  int rc;
+  if (!act.empty()) {
     std::vector<double> upd_pose;
     std::vector<int> upd_slot;
     for (size_t k = 0; k < act_idx.size(); ++k) {
@@ -476,6 +527,93 @@ int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, c
   }
   if (raw_weights_out)
     for (int i = 0; i < g->count; ++i) raw_weights_out[i] = g->p[i].weight;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_predict_match(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                   const double *angle, const int *is_occ, const double odom_delta[3],
+                                   double *raw_weights_out) {
+  if (!g) return bad("null filter");
+  int rc = slamhip_gmapping_match_begin(g, map_id, n_raw, range, angle, is_occ, odom_delta);
+  if (rc) {
+    g->pending = false;
+    return rc;
+  }
+  return slamhip_gmapping_match_finish(g, raw_weights_out);
+}
+
+// ---- the shared OOPE cache across shards (Q20) ------------------------------------------------------
+// In the reference ONE cache object is handed from particle to particle; a shard's first matching
+// particle therefore continues the cache of the last matching particle BEFORE it -- on the previous
+// shard, or, for the first one of a step, the last one of the previous step.  Sharded steps start every
+// shard's first job without a carry; afterwards the shards exchange these records and each one checks its
+// first job against its predecessor's final entry (re-matching on a hit, like verify_chain does inside a
+// shard) until nothing changes any more.
+int slamhip_gmapping_carry_record(slamhip_gmapping *g, slamhip_carry_record *rec) {
+  if (!g || !rec) return bad("null argument");
+  std::memset(rec, 0, sizeof(*rec));
+  rec->has_active = (g->pending && g->chained && !g->act.empty()) ? 1 : 0;
+  if (rec->has_active) {
+    const GmPoseInfo &fi = g->act[0]->first_info;
+    rec->first_cx = fi.first_cx;
+    rec->first_cy = fi.first_cy;
+    rec->first_v0 = fi.v0;
+  }
+  rec->carry_cx = g->carry.cx;
+  rec->carry_cy = g->carry.cy;
+  rec->carry_prob = g->carry.prob;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_carry_fix(slamhip_gmapping *g, const slamhip_carry_record *all, int world, int rank,
+                               int *changed) {
+  if (!g || !all || !changed || rank < 0 || rank >= world) return bad("bad argument");
+  *changed = 0;
+  // the cache as it reaches this shard: the final entry of the nearest earlier shard that matched, or
+  // what the previous step left (every shard keeps that in `step_carry`)
+  GmCarry pred = g->step_carry;
+  for (int r = 0; r < rank; ++r)
+    if (all[r].has_active) pred = GmCarry{all[r].carry_cx, all[r].carry_cy, all[r].carry_prob};
+  if (!(g->pending && g->chained) || g->act.empty()) {
+    g->carry = pred;  // nothing matched here: the cache passes through
+    return SLAMHIP_OK;
+  }
+  MatchJob &job = *g->act[0];
+  const GmPoseInfo &fi = job.first_info;
+  const bool same_in = job.carry_in.prob == pred.prob && job.carry_in.cx == pred.cx && job.carry_in.cy == pred.cy;
+  const bool hit = pred.prob != -1.0 && fi.first_cx == pred.cx && fi.first_cy == pred.cy && pred.prob != fi.v0;
+  const bool had_hit = job.carry_in.prob != -1.0 && fi.first_cx == job.carry_in.cx && fi.first_cy == job.carry_in.cy &&
+                       job.carry_in.prob != fi.v0;
+  if (same_in || (!hit && !had_hit)) return SLAMHIP_OK;  // the job ran with an equivalent cache
+  slamhip_ctx *ctx = g->ctx;
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  const GmCarry before = g->carry;
+  g->pes[0] = HillClimbingPoseEnumerator(g->prm.hc_failed_rounds_limit, g->prm.hc_translation, g->prm.hc_rotation);
+  const GmParticle &p = g->p[g->act_idx[0]];
+  job.start(&g->pes[0], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, pred, 0.25);
+  std::vector<MatchJob *> one{&job};
+  int rc = run_jobs(g, g->pending_map, one, 126, g->tp ? &g->act_idx[0] : nullptr);
+  if (rc) return rc;
+  g->carry_reruns += 1;
+  rc = verify_chain(g, g->pending_map, 1);
+  if (rc) return rc;
+  *changed = (before.cx != g->carry.cx || before.cy != g->carry.cy || before.prob != g->carry.prob) ? 1 : 0;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_set_shard_chain(slamhip_gmapping *g, int on) {
+  if (!g) return bad("null filter");
+  if (g->pending) return bad("a step is in flight");
+  g->shard_chain = on != 0;
+  if (on) g->step_carry = g->carry;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_carry_commit(slamhip_gmapping *g, const slamhip_carry_record *all, int world) {
+  if (!g || !all) return bad("null argument");
+  // what the next step starts from: the final entry of the last shard that matched
+  for (int r = 0; r < world; ++r)
+    if (all[r].has_active) g->step_carry = GmCarry{all[r].carry_cx, all[r].carry_cy, all[r].carry_prob};
   return SLAMHIP_OK;
 }
 
@@ -651,6 +789,80 @@ int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const doub
   if (req) {
     std::vector<GmParticle> all(g->p);
     rc = slamhip_gmapping_import(g, all.data(), idx.data());
+    if (rc) return rc;
+    if (idx_out) std::memcpy(idx_out, idx.data(), sizeof(unsigned) * g->n_total);
+  }
+  if (resampled) *resampled = req;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
+                                  const double *angle, const int *is_occ, const double odom_delta[3],
+                                  uint32_t resample_seed, int *resampled, unsigned *idx_out) {
+  if (!g) return bad("null filter");
+  if (!g->ctx) return bad("a sharded step needs a GPU context");
+  if (g->tp) return bad("per-particle maps resample through slamhip_gmapping_import_maps: drive the phases yourself");
+  if (g->update) return bad("the shared-map update is sequential over all particles and cannot be sharded");
+  int rank = 0, world = 1;
+  int rc = slamhip_shard_info(g->ctx, &rank, &world);
+  if (rc) return rc;
+  // contiguous blocks in rank order: every rank learns the others' block sizes once
+  if ((int)g->shard_counts.size() != world) {
+    std::vector<int> ones(world, 1), cnt(world, 0);
+    const int mine = g->count;
+    rc = slamhip_shard_allgather(g->ctx, &mine, ones.data(), (int)sizeof(int), cnt.data());
+    if (rc) return rc;
+    int at = 0;
+    for (int r = 0; r < world; ++r) {
+      if (r == rank && at != g->first) return bad("shards are not contiguous blocks in rank order");
+      at += cnt[r];
+    }
+    if (at != g->n_total) return bad("the shards do not add up to n_total particles");
+    g->shard_counts = cnt;
+    rc = slamhip_gmapping_set_shard_chain(g, 1);
+    if (rc) return rc;
+  }
+  rc = slamhip_gmapping_match_begin(g, map_id, n_raw, range, angle, is_occ, odom_delta);
+  if (rc) {
+    g->pending = false;
+    return rc;
+  }
+  // the shared OOPE cache across shards: exchange, re-check, until no shard changes its final entry
+  std::vector<slamhip_carry_record> recs(world);
+  const std::vector<int> ones(world, 1);
+  for (int round = 0; round <= world; ++round) {
+    slamhip_carry_record mine;
+    rc = slamhip_gmapping_carry_record(g, &mine);
+    if (rc) return rc;
+    rc = slamhip_shard_allgather(g->ctx, &mine, ones.data(), (int)sizeof(mine), recs.data());
+    if (rc) return rc;
+    int changed = 0;
+    rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);
+    if (rc) return rc;
+    int any = 0;
+    std::vector<int> flags(world, 0);
+    rc = slamhip_shard_allgather(g->ctx, &changed, ones.data(), (int)sizeof(int), flags.data());
+    if (rc) return rc;
+    for (int f : flags) any |= f;
+    if (!any) break;
+  }
+  rc = slamhip_gmapping_carry_commit(g, recs.data(), world);
+  if (rc) return rc;
+  std::vector<double> raw(g->count), all(g->n_total);
+  rc = slamhip_gmapping_match_finish(g, raw.data());
+  if (rc) return rc;
+  // the one data-path collective of a step: all raw weights, in particle order
+  rc = slamhip_shard_allgather(g->ctx, raw.data(), g->shard_counts.data(), (int)sizeof(double), all.data());
+  if (rc) return rc;
+  std::vector<unsigned> idx(g->n_total);
+  int req = 0;
+  rc = slamhip_gmapping_plan_resample(g, all.data(), resample_seed, &req, idx.data());
+  if (rc) return rc;
+  if (req) {
+    std::vector<GmParticle> blobs(g->n_total);
+    rc = slamhip_shard_allgather(g->ctx, g->p.data(), g->shard_counts.data(), (int)sizeof(GmParticle), blobs.data());
+    if (rc) return rc;
+    rc = slamhip_gmapping_import(g, blobs.data(), idx.data());
     if (rc) return rc;
     if (idx_out) std::memcpy(idx_out, idx.data(), sizeof(unsigned) * g->n_total);
   }

@@ -626,6 +626,7 @@ public:
   double best_prob = 0.0;
   bool first = true, done = false;
   GmCarry carry;
+  GmCarry carry_in;  // what the job started from
   GmPoseInfo first_info{};  // side outputs of the initial pose (cross-particle carry check)
   double first_raw_score = 0.0;
   long long scorer_calls = 0, poses_evaluated = 0, launches = 0;
@@ -643,6 +644,7 @@ public:
     first = true;
     done = false;
     carry = carry_in;
+    this->carry_in = carry_in;
     scorer_calls = poses_evaluated = launches = 0;
     t_build_us = t_replay_us = 0;
     p_accept_ = p_accept0;

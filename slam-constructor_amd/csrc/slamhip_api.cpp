@@ -465,6 +465,7 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
     hipEventDestroy(ctx->ev_fork);
   }
   mu_release(ctx);
+  shard_release(ctx);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return SLAMHIP_OK;

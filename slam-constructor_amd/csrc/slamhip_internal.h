@@ -111,6 +111,7 @@ struct DeviceMap {
 
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip
 void mu_release(slamhip_ctx *ctx);                    // map_update.hip: frees the context's K6 scratch
+void shard_release(slamhip_ctx *ctx);                 // shard.cpp: leaves the RCCL group, frees its staging
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 
@@ -155,6 +156,7 @@ struct slamhip_ctx {
   unsigned *h_done_flag_b = nullptr;
   unsigned seq_b = 0;
   hipEvent_t ev_fork = nullptr;
+  void *shard = nullptr;  // RCCL group of the context (shard.cpp), or null
   bool low_latency = true;
   bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
   // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read

@@ -1,0 +1,204 @@
+"""GPU suite: the sharded GMapping step behind the C-ABI (csrc/shard.cpp, slamhip_gmapping_step_sharded).
+
+  * one rank: RCCL really runs (ncclCommInitRank / ncclAllGather with world = 1) and the sharded step equals
+    the unsharded one bit for bit;
+  * two shards on ONE GPU (RCCL refuses two ranks on one device, so the records travel through Python here):
+    the phases match_begin / carry_record / carry_fix / match_finish against the unsharded filter, also in a
+    scene built to make the shared OOPE cache of the reference (Q19/Q20) hit ACROSS the shard boundary;
+  * two ranks on two GPUs over RCCL (skipped on a 1-GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+from synth import make_scene
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GP = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]  # gate open: every particle matches
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return ge.load_package()
+
+
+def deltas(sc, n):
+    # large odometry steps open the travelled-distance gate of try_resample and spread the weights
+    d = [sc["true_pose"], [0.02, 0.01, 0.01], [0.4, 0.5, 0.3], [0.01, -0.02, 0.02], [0.5, -0.4, 0.25],
+         [0.02, 0.02, 0.0], [0.45, 0.5, -0.3], [0.0, 0.01, 0.01]]
+    return d[:n]
+
+
+def test_one_rank_over_rccl_equals_unsharded_step(pkg):
+    ctx = pkg.Context(0)
+    ctx.shard_init(0, 1, pkg.shard_unique_id())
+    assert ctx.shard_info() == (0, 1)
+    blk = np.arange(12, dtype=np.float64).reshape(4, 3)
+    np.testing.assert_array_equal(ctx.shard_allgather(blk, [4]), blk)
+    sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    n = 24
+    seeds = np.arange(1000, 1000 + n, dtype=np.uint32)
+    a = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=GP), n, seeds)
+    b = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=GP), n, seeds)
+    resampled = 0
+    for k, d in enumerate(deltas(sc, 8)):
+        ra, ia = a.step_sharded(1, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+        rb, ib = b.step(1, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+        assert ra == rb
+        if ra:
+            np.testing.assert_array_equal(ia, ib)
+            resampled += 1
+        for x, y in zip(a.state(), b.state()):
+            np.testing.assert_array_equal(x, y)
+    assert resampled >= 1
+    st = ctx.shard_stats()
+    assert st["collectives"] >= 8 * 3 and st["bytes"] > 0
+    ctx.shard_destroy()
+    ctx.close()
+
+
+def run_two_shards(pkg, ctx, sc, n, cut, steps, scan, gp=GP):
+    """Unsharded filter vs shards [0, cut) and [cut, n) on one GPU; the collectives are numpy concatenations."""
+    seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
+    prm = pkg.gmapping_params(gp8=gp)
+    whole = pkg.GmappingFilter(ctx, prm, n, seeds)
+    sh = [pkg.GmappingFilter(ctx, prm, n, seeds[:cut], first=0, count=cut),
+          pkg.GmappingFilter(ctx, prm, n, seeds[cut:], first=cut, count=n - cut)]
+    for s in sh:
+        s.set_shard_chain(True)
+    reruns_whole, reruns_sh, resampled = 0, 0, 0
+    for k, d in enumerate(steps):
+        rw, iw = whole.step(1, scan.range, scan.angle, None, d, 7 + k)
+        reruns_whole += whole.stats()["carry_reruns"]
+        for s in sh:
+            s.match_begin(1, scan.range, scan.angle, None, d)
+        for _ in range(3):
+            recs = [s.carry_record() for s in sh]
+            changed = [s.carry_fix(recs, r) for r, s in enumerate(sh)]
+            if not any(changed):
+                break
+        recs = [s.carry_record() for s in sh]
+        for s in sh:
+            s.carry_commit(recs)
+        raw = np.concatenate([s.match_finish() for s in sh])
+        reruns_sh += sum(s.stats()["carry_reruns"] for s in sh)
+        plans = [s.plan_resample(raw, 7 + k) for s in sh]
+        assert plans[0][0] == plans[1][0] == rw
+        if rw:
+            resampled += 1
+            np.testing.assert_array_equal(plans[0][1], iw)
+            np.testing.assert_array_equal(plans[1][1], iw)
+            blobs = np.concatenate([s.export() for s in sh])
+            for s in sh:
+                s.import_(blobs, iw)
+        pw, ww, mw = whole.state()
+        ps = np.concatenate([s.state()[0] for s in sh])
+        ws = np.concatenate([s.state()[1] for s in sh])
+        ms = np.concatenate([s.state()[2] for s in sh])
+        np.testing.assert_array_equal(ps, pw)
+        np.testing.assert_array_equal(ws, ww)
+        np.testing.assert_array_equal(ms, mw)
+    return reruns_whole, reruns_sh, resampled
+
+
+def test_two_shards_in_phases_equal_the_unsharded_filter(pkg):
+    ctx = pkg.Context(0)
+    sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    _, _, resampled = run_two_shards(pkg, ctx, sc, 21, 11, deltas(sc, 8), sc["scan"])
+    assert resampled >= 1
+    ctx.close()
+
+
+def test_cache_hit_across_the_shard_boundary(pkg):
+    """A scan of very few beams and particles that all start from one pose: the first beam of a particle's
+    first pose lands in the cell its predecessor's last beam ended in, with another cached value -- the
+    reference's shared OOPE cache then changes the score (Q19/Q20).  Inside a shard verify_chain re-matches
+    such a particle; across the boundary carry_fix has to."""
+    from synth import Scan
+    ctx = pkg.Context(0)
+    sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    full = sc["scan"]
+    hits_whole = hits_sh = 0
+    for pick in ([10], [200, 201], [100]):
+        scan = Scan(full.range[pick], full.angle[pick], np.full(len(pick), 1.0 / len(pick)))
+        gp = [0.0, 1e-9, 0.0, 1e-9, 0.0, 0.0, 0.0, 0.0]  # (almost) no pose noise: particles stay together
+        steps = [sc["true_pose"], [0.02, 0.01, 0.0], [0.0, 0.03, 0.01], [0.01, 0.0, 0.0]]
+        w, s, _ = run_two_shards(pkg, ctx, sc, 9, 4, steps, scan, gp=gp)
+        hits_whole += w
+        hits_sh += s
+    assert hits_whole > 0, "the scene does not exercise the shared cache at all"
+    assert hits_sh > 0
+    ctx.close()
+
+
+def _rank_main(rank, world, uid_path, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as g2
+    from synth import make_scene as mk
+    pkg = g2.load_package()
+    import time
+    if rank == 0:
+        uid = pkg.shard_unique_id()
+        np.save(uid_path + ".tmp.npy", uid)
+        os.replace(uid_path + ".tmp.npy", uid_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(uid_path):
+                break
+            time.sleep(0.05)
+        uid = np.load(uid_path)
+    ctx = pkg.Context(rank)
+    ctx.shard_init(rank, world, uid)
+    sc = mk(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    n = 21
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    first = sum(counts[:rank])
+    seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=GP), n, seeds[first:first + counts[rank]], first=first,
+                            count=counts[rank])
+    log = []
+    for k, d in enumerate(deltas(sc, 8)):
+        res, idx = pf.step_sharded(1, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+        p, w, m = pf.state()
+        log.append((res, idx.copy(), p, w, m))
+    np.save(out_path % rank, np.array(log, dtype=object), allow_pickle=True)
+    ctx.shard_destroy()
+    ctx.close()
+
+
+def test_two_ranks_over_rccl(pkg, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    uid_path, out_path = str(tmp_path / "uid.npy"), str(tmp_path / "rank%d.npy")
+    procs = [mpc.Process(target=_rank_main, args=(r, 2, uid_path, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    logs = [np.load(out_path % r, allow_pickle=True) for r in range(2)]
+    ctx = pkg.Context(0)
+    sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    n = 21
+    whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=GP), n, np.arange(2000, 2000 + n, dtype=np.uint32))
+    for k, d in enumerate(deltas(sc, 8)):
+        rw, iw = whole.step(1, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+        assert logs[0][k][0] == logs[1][k][0] == rw
+        if rw:
+            np.testing.assert_array_equal(logs[0][k][1], iw)
+        pw, ww, mw = whole.state()
+        np.testing.assert_array_equal(np.concatenate([logs[0][k][2], logs[1][k][2]]), pw)
+        np.testing.assert_array_equal(np.concatenate([logs[0][k][3], logs[1][k][3]]), ww)
+    ctx.close()
