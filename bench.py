@@ -319,9 +319,22 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(args.pf_steps + 2)]
     calls = 0
     resamplings = 0
+    # the data-path collective lives in the library (csrc/shard.cpp: RCCL group per context, all-gather of
+    # the raw weights inside slamhip_gmapping_step_sharded); torch.distributed only carries the 128-byte
+    # group id to the ranks and the benchmark's own barrier / max-over-ranks
+    in_library = world > 1 and args.backend == "nccl"
+    if in_library:
+        uid = torch.from_numpy(pkg.shard_unique_id() if rank == 0 else np.zeros(pkg.SHARD_ID_BYTES, np.uint8)).to(dev)
+        dist.broadcast(uid, 0)
+        ctx.shard_init(rank, world, uid.cpu().numpy())
 
     def one(k):
         nonlocal calls, resamplings
+        if in_library:
+            req, _idx = pf.step_sharded(1, scan.range, scan.angle, None, deltas[k], 7 + k)
+            calls += pf.stats()["scorer_calls"]
+            resamplings += 1 if req else 0
+            return
         raw = pf.predict_match(1, scan.range, scan.angle, None, deltas[k])
         calls += pf.stats()["scorer_calls"]
         allw = gather(raw, torch.float64)
@@ -423,8 +436,13 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
             "workload": "cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "
                         "GMapping cell, HC(6,0.1,0.1), likelihood step without map update"
                         % (n, world, scan.n, args.pf_size, args.pf_size, args.scale),
-            "collective": ("all_gather(raw weights) per step over %s" %
-                           ("RCCL" if args.backend == "nccl" else "gloo")) if world > 1 else "none (1 rank)",
+            "collective": ("slamhip_shard_allgather inside slamhip_gmapping_step_sharded: RCCL through the C-ABI, "
+                           "%d ranks in the group, %d collectives / %d bytes on this rank over the run"
+                           % (ctx.shard_info()[1], ctx.shard_stats()["collectives"], ctx.shard_stats()["bytes"]))
+                          if in_library else
+                          ("all_gather(raw weights) per step over gloo (torch.distributed; ranks share GPUs)"
+                           if world > 1 else "none (1 rank)"),
+            "ranks": world,
             "launches_last_step": st["launches"], "carry_reruns_last_step": st["carry_reruns"],
             "resamplings": resamplings}
 
@@ -481,16 +499,37 @@ def pf_cpu_baseline_reference(args, seconds):
                       "map update inside the step, %.1f s" % (steps, n, t_used)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run as a CHILD process -- nothing in this process has touched the GPU yet, and it never
+    will) and leave with the child's exit code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # counts devices without initialising the GPU
+    if have < args.gpus and args.backend == "nccl":
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus %d needs torch.distributed.run with that many ranks" % args.gpus,
-              file=sys.stderr)
+    if args.gpus != world:
+        print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)

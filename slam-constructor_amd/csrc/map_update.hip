@@ -77,14 +77,11 @@ struct MuScratch {
   const int *last_occ = nullptr;
   int last_n = -1;
 };
-// one scratch set per context, keyed by the context pointer (contexts are few and long-lived)
-std::vector<std::pair<slamhip_ctx *, MuScratch>> g_scratch;
-
+// one scratch set per context, owned by it (contexts are independent: one caller thread each, and a
+// process-wide registry would be shared state between those threads)
 MuScratch &scratch_of(slamhip_ctx *ctx) {
-  for (auto &p : g_scratch)
-    if (p.first == ctx) return p.second;
-  g_scratch.emplace_back(ctx, MuScratch{});
-  return g_scratch.back().second;
+  if (!ctx->mu_scratch) ctx->mu_scratch = new MuScratch;
+  return *static_cast<MuScratch *>(ctx->mu_scratch);
 }
 
 }  // namespace
@@ -250,6 +247,12 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
       const double wx = a.px + range[b] * c, wy = a.py + range[b] * s;
       const double ddx = wx - a.px, ddy = wy - a.py;
       if (a.max_range_sq < ddx * ddx + ddy * ddy) continue;
+      // a beam that is ray-traced needs a cell: the reference asserts here (regular_squares_grid.h:42), and
+      // int(floor(inf or NaN)) is not the same number on the host and on the device -- the record buffers
+      // are sized from THIS loop and filled by the device's
+      if (!(std::fabs(wx / a.scale) < 1073741824.0) || !(std::fabs(wy / a.scale) < 1073741824.0))
+        return fail("a scan point that is not range-gated has a non-finite or absurdly far end point "
+                    "(no-return beams need a finite range or slam/mapping/max_range)");
       const int ocx = (int)std::floor(wx / a.scale), ocy = (int)std::floor(wy / a.scale);
       total += (unsigned)(std::abs(ocx - rcx) + std::abs(ocy - rcy) + 1);
     }
@@ -277,6 +280,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     sc.cap_records = cap;
   }
   a.keys = sc.keys;
+  a.keys_cap = (unsigned long long)sc.cap_records;
   a.key_x0 = a.key_y0 = 0;
   a.key_w = m.pitch;
   hipLaunchKernelGGL(k_mu_emit<unsigned>, bgrid, dim3(256), 0, ctx->stream, a);
@@ -310,6 +314,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   }
   nu = (unsigned long long)total - nu;
   if (n_updates_out) *n_updates_out = (long long)nu;
+  if (err == 2) return fail("internal: the device counted more cell updates than the host sized the buffers for", SLAMHIP_ERR_STATE);
   if (err)
     return fail("a beam leaves the bound map window: grow the map (slamhip_map_bind) before updating; "
                 "cells inside the window were updated", SLAMHIP_ERR_STATE);
@@ -350,13 +355,9 @@ struct MuBatchScratch {
   void *temp = nullptr, *scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
 };
-std::vector<std::pair<slamhip_ctx *, MuBatchScratch>> g_bscratch;
-
 MuBatchScratch &bscratch_of(slamhip_ctx *ctx) {
-  for (auto &p : g_bscratch)
-    if (p.first == ctx) return p.second;
-  g_bscratch.emplace_back(ctx, MuBatchScratch{});
-  return g_bscratch.back().second;
+  if (!ctx->mu_bscratch) ctx->mu_bscratch = new MuBatchScratch;
+  return *static_cast<MuBatchScratch *>(ctx->mu_bscratch);
 }
 
 template <typename T>
@@ -446,7 +447,12 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   }
   {  // 32-bit record offsets: a beam of range r crosses at most |dx| + |dy| + 1 <= sqrt(2) r / scale + 3 cells
     double bound = 0;
-    for (int b = 0; b < n; ++b) bound += 1.4143 * std::min(std::fabs(range[b]), cfg->max_range) / scale + 3.0;
+    for (int b = 0; b < n; ++b) {
+      // same rule as the single-scan path: a beam that is not range-gated needs a finite end point
+      if (!(std::fabs(range[b]) < 1073741824.0 * scale) && !(cfg->max_range < std::fabs(range[b])))
+        return fail("a scan point that is not range-gated has a non-finite or absurdly large range");
+      bound += 1.4143 * std::min(std::fabs(range[b]), cfg->max_range) / scale + 3.0;
+    }
     if (bound * n_jobs >= 4.0e9) return fail("more than 2^32 cell updates in one batch: split the batch");
   }
   unsigned total = 0;
@@ -619,6 +625,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   if (cell_bits + job_bits > 62) return fail("batch too large");
   a.cell_bits = (int)cell_bits;
   a.keys = sc.keys;
+  a.keys_cap = (unsigned long long)sc.cap_records;
   a.rec_prob = sc.srt_prob;
   a.rec_beam = sc.order_sorted;
   // the invalid key (all ones) must still sort last: include one more bit than the valid keys use
@@ -637,6 +644,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   if (rc) return rc;
   nu = (unsigned long long)total - nu;
   if (n_updates_out) *n_updates_out = (long long)nu;
+  if (err == 2) return fail("internal: the device counted more cell updates than the buffers hold", SLAMHIP_ERR_STATE);
   if (err)
     return fail("a beam leaves the tile extent of the particle maps: create them with a larger extent; cells "
                 "inside it were updated", SLAMHIP_ERR_STATE);
@@ -645,29 +653,27 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
 
 // called by slamhip_ctx_destroy: the K6 scratch buffers of a context live as long as it does
 void mu_release(slamhip_ctx *ctx) {
-  for (size_t i = 0; i < g_scratch.size(); ++i) {
-    if (g_scratch[i].first != ctx) continue;
-    MuScratch &s = g_scratch[i].second;
+  if (ctx->mu_scratch) {
+    MuScratch &s = *static_cast<MuScratch *>(ctx->mu_scratch);
     for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.keys, (void *)s.keys_sorted, (void *)s.order,
                     (void *)s.order_sorted, (void *)s.beam_info, (void *)s.beam_end, (void *)s.scan,
                     (void *)s.srt_prob, (void *)s.srt_qual, (void *)s.occ, (void *)s.error_flag,
                     (void *)s.n_updates, s.temp})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
-    g_scratch.erase(g_scratch.begin() + i);
-    break;
+    delete &s;
+    ctx->mu_scratch = nullptr;
   }
-  for (size_t i = 0; i < g_bscratch.size(); ++i) {
-    if (g_bscratch[i].first != ctx) continue;
-    MuBatchScratch &s = g_bscratch[i].second;
+  if (ctx->mu_bscratch) {
+    MuBatchScratch &s = *static_cast<MuBatchScratch *>(ctx->mu_bscratch);
     for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.order, (void *)s.order_sorted, (void *)s.keys,
                     (void *)s.keys_sorted, (void *)s.beam_info, (void *)s.beam_end, (void *)s.scan,
                     (void *)s.srt_prob, (void *)s.occ, (void *)s.error_flag,
                     (void *)s.d_jobs, (void *)s.d_bbox, (void *)s.n_updates, (void *)s.d_total, s.temp, s.scan_temp})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
-    g_bscratch.erase(g_bscratch.begin() + i);
-    break;
+    delete &s;
+    ctx->mu_bscratch = nullptr;
   }
 }
 

@@ -26,6 +26,7 @@ struct MuArgs {
   int cell_bits, key_x0, key_y0, key_w;
   int key_shift;  // > 0: key_w = 1 << key_shift (a batch pads its window: the key decodes with shift and mask)
   void *keys;  // unsigned or unsigned long long per record (the kernels' Key parameter)
+  unsigned long long keys_cap;  // records the key buffer holds: k_mu_emit refuses to write beyond it
   int *job_bbox;  // per job (lo_x, lo_y, hi_x, hi_y) in external cells, reduced by k_mu_count
   // map
   double *payload;
@@ -204,6 +205,10 @@ __global__ void k_mu_emit(MuArgs a) {
   if (cap == 0) return;
   const MuJob jb = mu_job(a, b);
   const unsigned base = a.offsets[b];
+  if ((unsigned long long)base + cap > a.keys_cap) {  // the host sized the buffer for another count: no write
+    *a.error_flag = 2;
+    return;
+  }
   const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
   const double scale = a.scale;
   const double d_x = wx - jb.px, d_y = wy - jb.py;

@@ -749,7 +749,10 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   const hipEvent_t stop1 = ev_stop;
   hipError_t e = hipSuccess;
   if (oope == SLAMHIP_OOPE_GMAPPING) {
-    if (kb > 8) return hipErrorInvalidValue;
+    if (kb > 8) {
+      set_error("the GMapping kernel holds at most 2048 filtered beams per scan");
+      return hipErrorInvalidValue;
+    }
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
     // SLAMHIP_K3_WIDE=1 selects the 512-thread variant for one-pose launches (measured equal: kept
     // for experiments, off by default)

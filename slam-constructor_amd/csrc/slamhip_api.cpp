@@ -44,7 +44,9 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
   if (n <= ctx->pose_cap) return SLAMHIP_OK;
   int cap = 256;
   while (cap < n) cap *= 2;
+  // kernels of BOTH launch lanes read and write the staging buffers
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
   if (ctx->d_poses) {
     hipFree(ctx->d_poses);
     hipFree(ctx->d_scores);
@@ -55,7 +57,12 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
     hipHostFree(ctx->h_pose_sc);
     hipHostFree(ctx->h_gm_info);
     hipHostFree(ctx->h_pose_slot);
-    ctx->d_poses = nullptr;
+    // a failed allocation below must not leave pointers that ctx_destroy (or the next call) frees again
+    ctx->d_poses = ctx->d_scores = ctx->d_pose_sc = nullptr;
+    ctx->d_gm_info = nullptr;
+    ctx->h_poses = ctx->h_scores = ctx->h_pose_sc = nullptr;
+    ctx->h_gm_info = nullptr;
+    ctx->h_pose_slot = nullptr;
     ctx->pose_cap = 0;
   }
   SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_slot, sizeof(int) * cap, kPinned));
@@ -77,6 +84,13 @@ static int check_cfg(const DeviceMap &m, const slamhip_spe_cfg *cfg) {
     if (m.cell_model != SLAMHIP_CELL_GMAPPING)
       return invalid("GMAPPING OOPE needs a SLAMHIP_CELL_GMAPPING map");
     if (cfg->gm_window < 0 || cfg->gm_window > 4) return invalid("gm_window out of range");
+    if (cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL) {
+      // K3 sums in the canonical tree order and patches cross-pose cache hits afterwards: neither is the
+      // reference's beam-order sum, so a caller asking for the bit-exact order is told instead of served
+      // something else
+      g_last_error = "the GMapping OOPE has no beam-order (SLAMHIP_SUM_SEQUENTIAL) path: use SLAMHIP_SUM_TREE256";
+      return SLAMHIP_ERR_UNSUPPORTED;
+    }
     return SLAMHIP_OK;
   }
   if (cfg->oope < SLAMHIP_OOPE_OBSTACLE || cfg->oope > SLAMHIP_OOPE_GMAPPING)
@@ -137,6 +151,7 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
     const size_t need = (size_t)n_poses * ctx->scan_n;
     if (need > ctx->terms_cap) {
       SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
       if (ctx->d_terms) hipFree(ctx->d_terms);
       ctx->d_terms = nullptr;
       ctx->terms_cap = 0;
@@ -441,17 +456,15 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
     if (m.d_aux) hipFree(m.d_aux);
   }
   if (ctx->d_scan) hipFree(ctx->d_scan);
-  if (ctx->d_poses) {
-    hipFree(ctx->d_poses);
-    hipFree(ctx->d_scores);
-    hipFree(ctx->d_pose_sc);
-    hipFree(ctx->d_gm_info);
-    hipHostFree(ctx->h_poses);
-    hipHostFree(ctx->h_scores);
-    hipHostFree(ctx->h_pose_sc);
-    hipHostFree(ctx->h_gm_info);
-    hipHostFree(ctx->h_pose_slot);
-  }
+  if (ctx->d_poses) hipFree(ctx->d_poses);
+  if (ctx->d_scores) hipFree(ctx->d_scores);
+  if (ctx->d_pose_sc) hipFree(ctx->d_pose_sc);
+  if (ctx->d_gm_info) hipFree(ctx->d_gm_info);
+  if (ctx->h_poses) hipHostFree(ctx->h_poses);
+  if (ctx->h_scores) hipHostFree(ctx->h_scores);
+  if (ctx->h_pose_sc) hipHostFree(ctx->h_pose_sc);
+  if (ctx->h_gm_info) hipHostFree(ctx->h_gm_info);
+  if (ctx->h_pose_slot) hipHostFree(ctx->h_pose_slot);
   if (ctx->d_terms) hipFree(ctx->d_terms);
   if (ctx->d_dirty_xy) hipFree(ctx->d_dirty_xy);
   if (ctx->d_dirty_val) hipFree(ctx->d_dirty_val);

@@ -157,6 +157,7 @@ struct slamhip_ctx {
   unsigned seq_b = 0;
   hipEvent_t ev_fork = nullptr;
   void *shard = nullptr;  // RCCL group of the context (shard.cpp), or null
+  void *mu_scratch = nullptr, *mu_bscratch = nullptr;  // K6 work buffers (map_update.hip), owned by the context
   bool low_latency = true;
   bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
   // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read

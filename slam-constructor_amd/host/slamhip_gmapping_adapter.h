@@ -97,6 +97,12 @@ public:
     bool particle_maps = false;             // false: the reference's one shared map (Q20)
     int extent_tiles = 64, pool_tiles = 4096;  // per-particle maps only
     int map_id = 0;
+    // Sharded filter: when the context has joined an RCCL group (slamhip_shard_init) this object holds
+    // the particles [first, first + count) of n -- contiguous blocks in rank order, the first n % world
+    // ranks one more -- and every step is slamhip_gmapping_step_sharded: lock-step matching of the
+    // local block, ONE all-gather of the raw weights, identical resampling on every rank.  The map is
+    // replicated and not updated inside the step (the reference's particles write ONE shared map one
+    // after the other, Q20: that step cannot be split).
   };
   // seed_source: what std::random_device is to the reference (GmappingWorld ctor, gmapping_world.h:51;
   // UniformResamling::resample, particle_filter.h:51-52): n draws now, one per step
@@ -110,8 +116,24 @@ public:
                                     cfg.map.meters_per_cell, unknown), "map_bind");
     std::vector<uint32_t> seeds(n);
     for (auto &s : seeds) s = _seed();
-    slamhip_or_die(slamhip_gmapping_create(ctx, &cfg.filter, (int)n, 0, (int)n, seeds.data(), &_pf), "gmapping_create");
-    if (cfg.particle_maps)
+    slamhip_or_die(slamhip_shard_info(ctx, &_rank, &_world), "shard_info");
+    if (_world > 1) {
+      if (cfg.particle_maps) {
+        std::cerr << "[slamhip] a sharded HipGmappingParticleFilter keeps one replicated map" << std::endl;
+        std::exit(-1);
+      }
+      _counts.resize(_world);
+      for (int r = 0; r < _world; ++r) _counts[r] = (int)n / _world + (r < (int)n % _world ? 1 : 0);
+      _first = 0;
+      for (int r = 0; r < _rank; ++r) _first += _counts[r];
+      slamhip_or_die(slamhip_gmapping_create(ctx, &cfg.filter, (int)n, _first, _counts[_rank], seeds.data() + _first,
+                                             &_pf), "gmapping_create");
+    } else {
+      slamhip_or_die(slamhip_gmapping_create(ctx, &cfg.filter, (int)n, 0, (int)n, seeds.data(), &_pf), "gmapping_create");
+    }
+    if (_world > 1) {
+      // likelihood step only, see Config
+    } else if (cfg.particle_maps)
       slamhip_or_die(slamhip_gmapping_enable_particle_maps(_pf, cfg.map_id, &cfg.adder, cfg.extent_tiles,
                                                            cfg.pool_tiles), "enable_particle_maps");
     else
@@ -177,10 +199,26 @@ protected:
     }
     const double d[3] = {obs.pose_delta.x, obs.pose_delta.y, obs.pose_delta.theta};
     int res = 0;
-    slamhip_or_die(slamhip_gmapping_step(_pf, _cfg.map_id, (int)m, _range.data(), _angle.data(), _occ.data(), d,
-                                         _seed(), &res, nullptr), "gmapping_step");
+    if (_world > 1) {
+      // the resampling seed has to be the same everywhere: rank 0's draw
+      std::vector<unsigned> draws(_world);
+      const std::vector<int> ones(_world, 1);
+      const unsigned mine = _seed();
+      slamhip_or_die(slamhip_shard_allgather(_ctx, &mine, ones.data(), (int)sizeof(unsigned), draws.data()), "seed");
+      slamhip_or_die(slamhip_gmapping_step_sharded(_pf, _cfg.map_id, (int)m, _range.data(), _angle.data(), _occ.data(),
+                                                   d, draws[0], &res, nullptr), "gmapping_step_sharded");
+      std::vector<double> lp(3 * (size_t)_counts[_rank]), lw(_counts[_rank]);
+      slamhip_or_die(slamhip_gmapping_get(_pf, lp.data(), lw.data(), nullptr), "gmapping_get");
+      slamhip_or_die(slamhip_shard_allgather(_ctx, lp.data(), _counts.data(), 3 * (int)sizeof(double), _poses.data()),
+                     "poses");
+      slamhip_or_die(slamhip_shard_allgather(_ctx, lw.data(), _counts.data(), (int)sizeof(double), _weights.data()),
+                     "weights");
+    } else {
+      slamhip_or_die(slamhip_gmapping_step(_pf, _cfg.map_id, (int)m, _range.data(), _angle.data(), _occ.data(), d,
+                                           _seed(), &res, nullptr), "gmapping_step");
+      slamhip_or_die(slamhip_gmapping_get(_pf, _poses.data(), _weights.data(), nullptr), "gmapping_get");
+    }
     _resampled = res != 0;
-    slamhip_or_die(slamhip_gmapping_get(_pf, _poses.data(), _weights.data(), nullptr), "gmapping_get");
     // heaviest_particle: the LAST of equal maxima (particle_filter.h:114-121)
     _heaviest = 0;
     for (unsigned i = 0; i < _n; ++i)
@@ -199,6 +237,8 @@ private:
   std::vector<int> _occ;
   unsigned _heaviest = 0;
   bool _resampled = false;
+  int _rank = 0, _world = 1, _first = 0;
+  std::vector<int> _counts;
   RobotPose _pose{0, 0, 0};
   std::shared_ptr<HipDeviceGridMap> _view;
 };

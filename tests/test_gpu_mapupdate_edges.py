@@ -191,3 +191,30 @@ def test_crafted_scans_vs_oracle(pkg, ctx, name, estimator):
             if n_aux:
                 np.testing.assert_array_equal(ctx.map_download_aux(3, 0, 0, SIZE, SIZE, n_aux), aux[..., :n_aux])
     ctx.map_release(3)
+
+
+def test_non_finite_end_points_are_rejected_or_range_gated(pkg, ctx):
+    """no-return beams are commonly inf or NaN.  int(floor(inf / NaN)) differs between host and
+    device, and the record buffers are sized on the host: such a beam is refused with a message unless the
+    range gate (slam/mapping/max_range) drops it, exactly as the reference would assert in world_to_cell
+    (regular_squares_grid.h:42).  Afterwards the same context still updates maps."""
+    model, rule, stride, _aux = KINDS["mean"]
+    ctx.map_bind(3, model, SIZE, SIZE, (SIZE // 2, SIZE // 2), SCALE, [0.5])
+    pose = np.array([0.03, 0.02, 0.1])
+    ang = np.deg2rad(np.linspace(-100, 100, 64))
+    cos_a, sin_a = pkg.beam_trig(ang)
+    good = np.full(64, 5.0)
+    n_good = ctx.map_append_scan(3, rule, pose, good, cos_a, sin_a)
+    assert n_good > 64 * 40
+    for bad_value in (np.inf, -np.inf, np.nan, 1e300):
+        rng = good.copy()
+        rng[17] = bad_value
+        with pytest.raises(pkg.SlamHipError):
+            ctx.map_append_scan(3, rule, pose, rng, cos_a, sin_a)  # max_range = infinity: not gated
+    # with a finite max_range an infinite range is simply dropped (both sides skip the beam)
+    rng = good.copy()
+    rng[17] = np.inf
+    n_gated = ctx.map_append_scan(3, rule, pose, rng, cos_a, sin_a, max_range=20.0)
+    assert 0 < n_gated < n_good
+    assert ctx.map_append_scan(3, rule, pose, good, cos_a, sin_a) == n_good
+    ctx.map_release(3)
