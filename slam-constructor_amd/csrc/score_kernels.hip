@@ -176,8 +176,11 @@ __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int 
 // tile table in front), one after the other -- 9 x KB round trips per pose, ~30 of a launch's 37 us.
 // Here the nine cells are fetched whole (32 bytes) with independent loads, behind at most four
 // tile-table entries (the window's corners), and reduced with selects: two round trips per beam.
-__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const int *tiles, const GmParams &gp,
-                                                    int cx, int cy, double ox, double oy) {
+// `unk`: the prototype payload in LDS.  Taken from the kernel arguments it lived in scalar registers across
+// the whole kernel, and the compiler parked two of its doubles in SCRATCH (24 bytes per lane written at
+// entry and read back before the gathers: the kernel's only scratch, 1.7 MB of HBM writes per launch).
+__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
+                                                    const GmParams &gp, int cx, int cy, double ox, double oy) {
   const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
   int t00 = 0, t01 = 0, t10 = 0, t11 = 0, txl = 0, tyl = 0;
   if (tiles) {
@@ -192,7 +195,7 @@ __device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const int 
     t11 = tiles[tyh * m.pitch + txh];
   }
   const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
-  const double4 unknown = make_double4(m.unknown[0], m.unknown[1], m.unknown[2], 0.0);
+  const double4 unknown = make_double4(unk[0], unk[1], unk[2], 0.0);
   double4 v[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -225,14 +228,14 @@ __device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const int 
   return 0.0 < r ? r : 0.0;
 }
 
-__device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *tiles, const GmParams &gp,
-                                                 int cx, int cy, double ox, double oy) {
+__device__ __forceinline__ double gm_fresh_value(const MapView &m, const double *unk, const int *tiles,
+                                                 const GmParams &gp, int cx, int cy, double ox, double oy) {
   // The value is the maximum over the window's full cells of 1 - (1 - exp(-d^2 / 0.05)), d = distance
   // from the cell's obstacle mean to the beam's end point.  That function falls with d^2, so the
   // maximum belongs to the smallest d^2: the window only tracks that, and ONE exp is evaluated per beam.
   // (An exp per full cell -- up to nine per beam next to a wall, executed by the whole wave as soon as
   // one lane needs it -- was 4.5 of the 10 us of this phase in a lone launch.)
-  if (gp.window == 1) return gm_fresh_value_w1(m, tiles, gp, cx, cy, ox, oy);
+  if (gp.window == 1) return gm_fresh_value_w1(m, unk, tiles, gp, cx, cy, ox, oy);
   double best_d2 = __builtin_inf();
   bool any = false;
   const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
@@ -240,7 +243,7 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const int *ti
     for (int dy = -gp.window; dy <= gp.window; ++dy) {
       const int ix = cx + dx + m.origin_x, iy = cy + dy + m.origin_y;
       const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
-      double occ = m.unknown[0], obx = m.unknown[1], oby = m.unknown[2];
+      double occ = unk[0], obx = unk[1], oby = unk[2];
       if (inb) {
         size_t at;
         if (tiles) {
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   extern __shared__ double s_dyn[];  // val[n] | grp_last_cell (int2 as double) [G] | grp_last_start [G]
   __shared__ double s_pose[kMaxPosesPerBlock][4];
   __shared__ double s_part[kMaxPosesPerBlock][4];
+  __shared__ double s_unknown[4];
   __shared__ int s_run0_len;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -287,6 +291,11 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   double *s_val = s_dyn;
   int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kBlock);
   int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
+  if (t == 0) {  // before the first barrier below
+    s_unknown[0] = a.map.unknown[0];
+    s_unknown[1] = a.map.unknown[1];
+    s_unknown[2] = a.map.unknown[2];
+  }
   // Per-particle maps: workgroups go to the 8 XCDs round-robin by index, and consecutive poses read the
   // same particle's tiles.  Handing XCD x the x-th CONTIGUOUS eighth of the poses keeps a particle's
   // tiles in one L2 instead of all eight (the launch rounds the grid up to a multiple of 8).
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
         const double wy = y + br[k] * s;
         ccx[k] = to_cell(wx, scale, inv_scale);
         ccy[k] = to_cell(wy, scale, inv_scale);
-        s_val[b] = gm_fresh_value(a.map, tiles, a.gm, ccx[k], ccy[k], wx, wy);
+        s_val[b] = gm_fresh_value(a.map, s_unknown, tiles, a.gm, ccx[k], ccy[k], wx, wy);
         if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
       }
     }
@@ -425,20 +434,18 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
   }
 }
 
-// K3, one pose per workgroup of 512 threads.  The filter's launches hold a few hundred poses: with four
-// waves per pose the CUs run ~2.6 waves per SIMD and the waves wait on the 3x3 gathers 68 % of the
-// time (SQ_WAIT_ANY / SQ_WAVE_CYCLES, r01).  Here the expensive phase A (endpoint, nine gathers, exp)
-// is spread over EIGHT waves -- beam b goes to thread b % 512 -- while the run resolution and the sum
-// keep the canonical 256-thread layout (thread t < 256 owns beams t + 256k, read back from LDS), so
-// scores are bit-identical to k_score_gmapping's (the whole GPU suite passes with it).  Measured: no
-// faster (41.5 vs 41.1 us per filter launch) -- the waits are not hidden by more waves, the launch is
-// bound by the per-pose phase chain -- so it is opt-in (SLAMHIP_K3_WIDE=1), kept as the record of the
-// experiment.
+// K3, one pose per workgroup of 1024 threads, for launches of a few dozen poses (a lone matcher's batches
+// leave the GPU empty, so the per-pose chain of phases is the whole kernel time): the expensive phase A
+// (end point, nine gathers, exp) is spread over sixteen waves -- beam b goes to thread b % 1024 -- while the
+// run resolution and the sum keep the canonical 256-thread layout (thread t < 256 owns beams t + 256k, read
+// back from LDS), so scores are bit-identical to k_score_gmapping's.  (A 512-thread form for the filter's
+// launches of a few hundred poses measured equal -- 41.5 against 41.1 us -- and was removed.)
 template <int KB, int NT>
 __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
   extern __shared__ double s_dyn[];  // val[256 KB] | grp_cell int2 [4 KB] | grp_start int [4 KB] | cx, cy int [256 KB]
   __shared__ double s_pose1[4];
   __shared__ double s_part1[4];
+  __shared__ double s_unknown[4];
   __shared__ int s_run0_len;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -463,6 +470,11 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
   }
   const bool has0 = t < n;
   const double r0 = has0 ? a.scan.range[t] : 0.0, ca0 = has0 ? a.scan.cos_a[t] : 0.0, sa0 = has0 ? a.scan.sin_a[t] : 0.0;
+  if (t == 64) {
+    s_unknown[0] = a.map.unknown[0];
+    s_unknown[1] = a.map.unknown[1];
+    s_unknown[2] = a.map.unknown[2];
+  }
   if (t == 0) {
     if (!a.pose_sc) sincos(pose_th, &pose_sn, &pose_cs);
     s_pose1[0] = pose_x;
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
     const double wx = x + r * c;
     const double wy = y + r * s;
     const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
-    s_val[b] = gm_fresh_value(a.map, tiles, a.gm, cx, cy, wx, wy);
+    s_val[b] = gm_fresh_value(a.map, s_unknown, tiles, a.gm, cx, cy, wx, wy);
     s_cx[b] = cx;
     s_cy[b] = cy;
   }
@@ -754,16 +766,9 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
       return hipErrorInvalidValue;
     }
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
-    // SLAMHIP_K3_WIDE=1 selects the 512-thread variant for one-pose launches (measured equal: kept
-    // for experiments, off by default)
-    // SLAMHIP_K3_WIDE: 0 = never, 1 = 512 threads for every one-pose launch, unset = 1024 threads for
-    // launches of at most SLAMHIP_K3_WIDE_BELOW poses (a lone matcher's batches: a few dozen poses
-    // leave the GPU empty, so the per-pose chain is the whole kernel time)
-    static const char *wide_env = getenv("SLAMHIP_K3_WIDE");
+    // 1024 threads per pose for launches of at most SLAMHIP_K3_WIDE_BELOW poses (0: never)
     static const int wide_below = getenv("SLAMHIP_K3_WIDE_BELOW") ? atoi(getenv("SLAMHIP_K3_WIDE_BELOW")) : 160;
-    const int wide = (wide_env && wide_env[0] == '0') ? 0
-                     : (wide_env && wide_env[0] == '1') ? 512
-                     : (a.n_poses <= wide_below ? 1024 : 0);
+    const int wide = a.n_poses <= wide_below ? 1024 : 0;
     const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int);
     dim3 grid_gm = grid;  // k_score_gmapping only: the XCD-chunked block order (see the kernel)
     if (a.tables && !xcd_off && grid.x >= 16 && !(a.poses_per_block == 1 && wide)) {
@@ -774,8 +779,6 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   case K:                                                                                                     \
     if (a.poses_per_block == 1 && wide == 1024)                                                               \
       SLAMHIP_LAUNCH((k_score_gmapping_wide<K, 1024>), grid, dim3(1024), shm_wide, stream, ev_start, ev_stop, a); \
-    else if (a.poses_per_block == 1 && wide == 512)                                                           \
-      SLAMHIP_LAUNCH((k_score_gmapping_wide<K, 512>), grid, dim3(512), shm_wide, stream, ev_start, ev_stop, a); \
     else if (a.poses_per_block == 1)                                                                          \
       SLAMHIP_LAUNCH((k_score_gmapping<K, true>), grid_gm, dim3(kBlock), shm, stream, ev_start, ev_stop, a);  \
     else                                                                                                      \
