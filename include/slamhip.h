@@ -327,6 +327,13 @@ int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const
  * aux2 = (hits, tries) per cell; either may be NULL */
 int slamhip_gmapping_particle_map_download(slamhip_gmapping *g, int particle, int x0, int y0, int w, int h,
                                            double *payload3, double *aux2);
+/* The append half of GmappingWorld::handle_observation (gmapping_world.h:93-97) for a set of local
+ * particles at once: the raw scan is appended to the map of particle particles[k] from poses3[3k..3k+2] --
+ * ONE batched K6 over all (particle, beam) pairs, copy-on-write first.  The filter step does this itself for
+ * the particles that matched; this entry point is for callers that place scans from their own poses. */
+int slamhip_gmapping_particle_maps_append(slamhip_gmapping *g, int n_jobs, const int *particles,
+                                          const double *poses3, int n_raw, const double *range,
+                                          const double *angle, const int *is_occ, long long *n_updates);
 int slamhip_gmapping_particle_map_stats(slamhip_gmapping *g, long long *tiles_in_use, long long *tiles_shared,
                                         long long *bytes, long long *cow_copies, long long *cell_updates);
 /* Migration of a particle's map to another rank (the "moving a duplicated particle to another GPU"

@@ -638,6 +638,15 @@ class RefMapHandle(RefHandle):
     def stamp_text(self, text, off, w_zoom=1, h_zoom=1):
         self.ref.lib.ref_map_stamp_text(self.h, text.encode(), off[0], off[1], w_zoom, h_zoom)
 
+    def copy(self):
+        """`GridMap copy = original;` of a tiled map: tiles stay shared until one side writes."""
+        self.ref.lib.ref_map_copy.restype = C.c_void_p
+        self.ref.lib.ref_map_copy.argtypes = [C.c_void_p]
+        h = self.ref.lib.ref_map_copy(self.h)
+        if not h:
+            raise RuntimeError("this map class has no copy-on-write copies")
+        return RefMapHandle(self.ref, h, self.cell, self.map_type)
+
     def aux(self):
         """Update-only cell state: MEAN -> n [h, w, 1]; GMAPPING -> (hits, tries) [h, w, 2]."""
         g = self.geometry()

@@ -214,6 +214,24 @@ void *ref_map_create(int cell_model, int map_type, int w, int h, double scale,
 }
 void ref_map_destroy(void *h) { delete static_cast<RefMap *>(h); }
 
+// `GridMap copy = original;` of the tiled maps: the copy shares every tile with the original until one
+// of them writes (lazy_tiled_grid_map.h:40-71) -- what `*new_particle = *sampled` does to a particle's map
+// (particle_filter.h:92-96).  Null for map classes without those semantics.
+void *ref_map_copy(void *h) {
+  auto *src = static_cast<RefMap *>(h);
+  auto *m = new RefMap;
+  m->cell_model = src->cell_model;
+  if (auto u = std::dynamic_pointer_cast<UnboundedLazyTiledGridMap>(src->map))
+    m->map = std::make_shared<UnboundedLazyTiledGridMap>(*u);
+  else if (auto l = std::dynamic_pointer_cast<LazyTiledGridMap>(src->map))
+    m->map = std::make_shared<LazyTiledGridMap>(*l);
+  else {
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+
 // geometry: width, height, origin_x, origin_y, + scale
 void ref_map_geometry(void *h, int *out4, double *scale) {
   auto &m = *static_cast<RefMap *>(h)->map;

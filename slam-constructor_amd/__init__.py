@@ -8,9 +8,11 @@ There is NO CPU fallback in here: if the HIP library is missing or no GPU is usa
 / ``Context()`` raise.  The CPU oracle under oracle/ is test infrastructure and is never imported
 from this package.
 """
+import atexit
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -41,7 +43,7 @@ slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapp
 slamhip_gmapping_stats slamhip_gmapping_set_map_update slamhip_map_append_scan slamhip_map_download_aux
 slamhip_gmapping_enable_particle_maps slamhip_gmapping_particle_map_download
 slamhip_gmapping_particle_map_stats slamhip_gmapping_particle_map_export_size
-slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps
+slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps slamhip_gmapping_particle_maps_append
 slamhip_shard_unique_id slamhip_shard_init slamhip_shard_destroy slamhip_shard_info slamhip_shard_allgather
 slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begin slamhip_gmapping_carry_record
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
@@ -203,6 +205,7 @@ def load():
     L.slamhip_gmapping_particle_map_export_size.argtypes = [vp, i, C.POINTER(C.c_size_t)]
     L.slamhip_gmapping_particle_map_export.argtypes = [vp, i, vp, C.c_size_t]
     L.slamhip_gmapping_import_maps.argtypes = [vp, vp, up, i, _ip, C.POINTER(vp)]
+    L.slamhip_gmapping_particle_maps_append.argtypes = [vp, i, _ip, _dp, i, _dp, _dp, _ip, ll]
     L.slamhip_shard_unique_id.argtypes = [vp]
     L.slamhip_shard_init.argtypes = [vp, i, i, vp]
     L.slamhip_shard_destroy.argtypes = [vp]
@@ -225,6 +228,24 @@ def shard_unique_id():
     buf = np.zeros(SHARD_ID_BYTES, np.uint8)
     _check(load().slamhip_shard_unique_id(buf.ctypes.data_as(C.c_void_p)))
     return buf
+
+
+# Objects still alive when the interpreter shuts down (a failed test, a script without close()) must be
+# destroyed BEFORE the HIP runtime's own static destructors run: freeing device memory after that aborts the
+# process at exit.  Filters and matchers first (they point into their context), contexts last.
+_live = {"dep": weakref.WeakSet(), "ctx": weakref.WeakSet()}
+
+
+def _close_all():
+    for kind in ("dep", "ctx"):
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
+atexit.register(_close_all)
 
 
 def _check(rc):
@@ -318,9 +339,13 @@ class Context:
         _check(self.L.slamhip_ctx_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        self._deps = weakref.WeakSet()  # matchers / filters created on this context: closed before it
+        _live["ctx"].add(self)
 
     def close(self):
         if getattr(self, "h", None):
+            for d in list(self._deps):
+                d.close()
             self.L.slamhip_ctx_destroy(self.h)
             self.h = None
 
@@ -478,12 +503,17 @@ class Matcher:
             raise ValueError(kind)
         self.h = h
         self._obs = None
+        _live["dep"].add(self)
+        ctx._deps.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.slamhip_matcher_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:
-            if self.h:
-                self.L.slamhip_matcher_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
@@ -552,12 +582,18 @@ class GmappingFilter:
                                               n_total, first, self.count,
                                               sd.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(h)))
         self.h = h
+        _live["dep"].add(self)
+        if ctx is not None:
+            ctx._deps.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.slamhip_gmapping_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:
-            if self.h:
-                self.L.slamhip_gmapping_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
@@ -661,6 +697,20 @@ class GmappingFilter:
                            estimator, shift_amount)
         _check(self.L.slamhip_gmapping_enable_particle_maps(self.h, map_id, C.byref(cfg), extent_tiles,
                                                             pool_tiles))
+
+    def particle_maps_append(self, particles, poses, rng, ang, is_occ=None):
+        """Appends the raw scan to the maps of the listed local particles, each from its own pose (one batched
+        K6); returns the number of cell updates."""
+        pt = np.ascontiguousarray(particles, dtype=np.int32)
+        ps, rng, ang = _f64(poses), _f64(rng), _f64(ang)
+        assert ps.size == 3 * pt.size
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        nu = C.c_longlong(0)
+        _check(self.L.slamhip_gmapping_particle_maps_append(self.h, pt.size, pt.ctypes.data_as(_ip), _d(ps), rng.size,
+                                                            _d(rng), _d(ang),
+                                                            occ.ctypes.data_as(_ip) if occ is not None else None,
+                                                            C.byref(nu)))
+        return nu.value
 
     def particle_map(self, particle, x0, y0, w, h):
         """(payload[h, w, 3], counters[h, w, 2]) of the external window of one particle's map."""

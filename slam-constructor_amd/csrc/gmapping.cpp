@@ -766,6 +766,32 @@ int slamhip_gmapping_particle_map_download(slamhip_gmapping *g, int particle, in
   return tile_pool_download(g->tp, particle, x0, y0, w, h, payload3, aux2);
 }
 
+int slamhip_gmapping_particle_maps_append(slamhip_gmapping *g, int n_jobs, const int *particles,
+                                          const double *poses3, int n_raw, const double *range,
+                                          const double *angle, const int *is_occ, long long *n_updates) {
+  if (!g || !g->tp) return bad("per-particle maps are not enabled");
+  if (n_updates) *n_updates = 0;
+  if (n_jobs <= 0 || n_raw <= 0) return SLAMHIP_OK;
+  if (!particles || !poses3 || !range || !angle) return bad("null argument");
+  for (int k = 0; k < n_jobs; ++k) {
+    if (particles[k] < 0 || particles[k] >= g->count) return bad("particle index out of range");
+    for (int q = 0; q < k; ++q)
+      if (particles[q] == particles[k]) return bad("a particle's map takes one scan per batch");
+  }
+  SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
+  raw_trig(g, n_raw, angle);
+  slamhip_scan_adder_cfg cfg = g->upd;
+  cfg.rule = SLAMHIP_RULE_GMAPPING;
+  cfg.scan_quality = 1.0;
+  long long nu = 0;
+  int rc = mu_append_batch(g->ctx, g->tp, &cfg, n_jobs, poses3, particles, n_raw, range, g->trig_cos.data(),
+                           g->trig_sin.data(), is_occ, &nu);
+  if (rc) return rc;
+  g->cell_updates = nu;
+  if (n_updates) *n_updates = nu;
+  return SLAMHIP_OK;
+}
+
 int slamhip_gmapping_particle_map_stats(slamhip_gmapping *g, long long *tiles_in_use, long long *tiles_shared,
                                         long long *bytes, long long *cow_copies, long long *cell_updates) {
   if (!g || !g->tp) return bad("per-particle maps are not enabled");

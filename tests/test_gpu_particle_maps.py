@@ -240,3 +240,55 @@ def test_particle_maps_argument_checks(pkg):
     whole.enable_particle_maps(1, 4, 64)
     with pytest.raises(pkg.SlamHipError):  # shared-map mode and particle maps exclude each other
         whole.set_map_update(True)
+
+
+def test_particle_maps_vs_reference_copy_on_write_copies(pkg):
+    """VERDICT r1 items 6 + 8: the tile pool against REAL copies of the compiled reference's
+    UnboundedLazyTiledGridMap (tests/golden/make_golden_particle_maps.py): six copies of an ancestor map take
+    one scan each from their own pose -- one batched K6 here -- with the AreaOccupancyEstimator and blur 0.1 m
+    (BASELINE configs[4]); a copy of one of them moves on alone; originals must not see their copies' writes
+    (lazy_tiled_grid_map.h:40-71)."""
+    g = load("particle_maps_cow.npz")
+    w, h = [int(v) for v in g["size"]]
+    scale, blur, shift = float(g["scale"]), float(g["blur"]), float(g["shift_amount"])
+    ox, oy = [int(v) for v in g["origin"]]
+    base = tuple(g["base"])
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, w, h, g["origin"], scale, g["unknown"][:3])
+    c0, s0 = pkg.beam_trig(g["scan0_angle"])
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["pose0"], g["scan0_range"], c0, s0, is_occ=g["scan0_occ"], base=base,
+                        blur=blur, estimator=1, shift_amount=shift)
+    n = 8
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), n, np.arange(n, dtype=np.uint32))
+    pf.enable_particle_maps(4, extent_tiles=8, pool_tiles=16 + 24 * n, base=base, blur=blur, estimator=1,
+                            shift_amount=shift)
+
+    def check(particle, name):
+        got_p, got_a = pf.particle_map(particle, -ox, -oy, w, h)
+        np.testing.assert_array_equal(got_a, g[name + "_aux"], err_msg=name)            # hits / tries exact
+        np.testing.assert_allclose(got_p, g[name + "_payload"], rtol=1e-10, atol=1e-13, err_msg=name)
+
+    for i in range(n):
+        check(i, "A")  # every particle starts as the ancestor (one shared set of tiles)
+    st0 = pf.particle_map_stats()
+    nu = pf.particle_maps_append(np.arange(6), g["poses_b"], g["scan1_range"], g["scan1_angle"], g["scan1_occ"])
+    assert nu > 6 * 360 * 20
+    for i in range(6):
+        check(i, "B%d" % i)
+    check(6, "A")  # untouched particles still read the ancestor
+    check(7, "A")
+    st1 = pf.particle_map_stats()
+    assert st1["cow_copies"] > st0["cow_copies"] and st1["tiles_shared"] > 0
+    # `*new_particle = *sampled` (particle_filter.h:92-96): particle 6 becomes a copy of particle 2 -- a table
+    # copy, no tile moves -- and then writes alone
+    idx = np.array([0, 1, 2, 3, 4, 5, 2, 7], dtype=np.uint32)
+    pf.import_(pf.export(), idx)
+    st2 = pf.particle_map_stats()
+    assert st2["cow_copies"] == st1["cow_copies"]
+    check(6, "B2")
+    pf.particle_maps_append([6], g["pose_c"], g["scan2_range"], g["scan2_angle"], g["scan2_occ"])
+    check(6, "C")
+    check(2, "B2")  # the original did not see the copy's writes
+    check(7, "A")
+    assert pf.particle_map_stats()["cow_copies"] > st2["cow_copies"]
+    ctx.close()
