@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the scan-matching hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload hc|mc|sweep]
+    python bench.py --gpus N --steps K --warmup W [--workload hc|mc|sweep] [--legs ...]
 
 A "step" is one pass of the hot path over one batch of synthetic input: one
 GridScanMatcher::process_scan (the whole accept/reject chain of one scan match) on the
 BASELINE.json configuration the metric is quoted on.  Default workload (N=1): configs[1] --
 tinySLAM HC scan matcher, 1080-beam scan, 2000x2000 @ 0.05 m occupancy grid, 6-direction
 hill-climb with a 128-failed-rounds limit.  The map, the filtered scan and the matcher live in
-HBM / on the host before the timed region starts; candidate poses go up and scores come back
-inside it (they are part of the path).
+HBM / on the host before the timed region starts.
 
 value = (scorer calls the reference would make = on_scan_test events) x (filtered beams) / s,
 summed over all ranks; speculative evaluations that the replay discards are NOT counted.
 For N > 1 single-hypothesis matchers do not shard ("replicas only"): every rank runs
-its own independent match, there is no data-path collective, scaling is "weak".
+its own independent match, there is no data-path collective, scaling is "weak".  `--gpus N`
+without a launcher starts the N ranks itself (torch.distributed.run as a child process).
 
-One JSON line on rank 0 with the extra objects `roofline` (dominant kernel, algorithmic bytes /
-HIP-event kernel time against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU checker timed on
-this box's host cores on a bounded sample of the same workload, rank 0, N=1 only).
+One JSON line on rank 0 with the extra objects
+  roofline        dominant kernel of the headline: algorithmic bytes / HIP-event kernel time vs 8 TB/s
+  roofline_valu   what really binds it: VALU issue fraction and instructions per unit (PMC passes,
+                  profiles/<tag>_traffic.json) and the measured HBM utilisation
+  roofline_sweep  the same scoring arithmetic on flat 4096-pose batches (kernel ceiling)
+  cpu_baseline    the compiled reference (oracle/_ref) timed on this box's host cores on a bounded
+                  sample of the same workload (rank 0, N=1 only), with an all-cores line for context
+  particle_filter BASELINE configs[3] (GMapping, 100 particles sharded over the ranks, RCCL all-gather
+                  inside the library) and, on one GPU, the faithful shared-map step and per-particle maps
+  cfg5            BASELINE configs[4] on one GPU (500 particles, 8000^2 @ 0.025 m, area estimator + blur,
+                  K6 roofline)
+CPU baselines run BEFORE this process touches the GPU (they use worker processes).
 """
 import argparse
 import json
@@ -34,6 +43,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_UNIT = {"occ": 24, "tbm": 56, "gmapping": 232}  # SURVEY 8d algorithmic bytes / (pose, beam)
+K6_BYTES_PER_RECORD = 64  # per (beam, cell) 2 x 32 B read-modify-write
+ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5"]
 
 WORKLOADS = {
     # name: (cell model, weighting, matcher kind, params, bytes key, description)
@@ -50,23 +61,30 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hc", choices=["hc", "mc", "sweep"])
+    ap.add_argument("--legs", default=None,
+                    help="comma list of %s (default: all on one GPU, pf on several; 'none' = headline only)" % ALL_LEGS)
     ap.add_argument("--size", type=int, default=2000)
     ap.add_argument("--scale", type=float, default=0.05)
     ap.add_argument("--beams", type=int, default=1080)
     ap.add_argument("--sweep-poses", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-procs", type=int, default=16, help="worker processes of the all-cores CPU context lines")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--pf-size", type=int, default=4000)
     ap.add_argument("--pf-steps", type=int, default=10)
     ap.add_argument("--pf-tiles-per-particle", type=int, default=420,
                     help="tile-pool budget per particle of the per-particle-maps leg (768 KiB each)")
-    ap.add_argument("--no-pf", action="store_true", help="skip the GMapping particle-filter leg")
+    ap.add_argument("--no-pf", action="store_true", help="same as --legs none")
     ap.add_argument("--pf-sigma-xy", type=float, default=0.1, help="slam/particles/sample/xy/sigma (init_gmapping.h:17)")
     ap.add_argument("--pf-sigma-th", type=float, default=0.03, help="slam/particles/sample/theta/sigma (:19-20)")
     ap.add_argument("--pf-maps-sharded", action="store_true",
                     help="N > 1 only: also run the per-particle-maps filter sharded over the ranks (maps "
                          "migrate between ranks on resampling)")
+    ap.add_argument("--cfg5-particles", type=int, default=500)
+    ap.add_argument("--cfg5-size", type=int, default=8000)
+    ap.add_argument("--cfg5-scale", type=float, default=0.025)
+    ap.add_argument("--cfg5-steps", type=int, default=4)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU (path testing)")
     ap.add_argument("--strict", action="store_true",
@@ -75,23 +93,57 @@ def parse():
                     help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
     ap.add_argument("--chain", type=int, default=-1,
                     help="hill climbing on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.no_pf or args.workload == "sweep":
+        args.legs = "none"
+    if args.legs is None:
+        args.leg_set = set(ALL_LEGS) if args.gpus == 1 else {"pf"}
+    else:
+        args.leg_set = set(x for x in args.legs.split(",") if x and x != "none")
+        bad = args.leg_set - set(ALL_LEGS)
+        if bad:
+            ap.error("unknown leg(s): %s" % sorted(bad))
+    return args
 
 
-def load_traffic(workload):
-    """HBM bytes per scoring launch from the newest committed PMC summary
-    (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py from separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  PMC counters cannot be
-    collected from inside the benchmark, so this is the one roofline field not measured live."""
+def load_profile_json():
+    """The newest committed PMC summary (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py
+    from separate rocprofv3 --pmc passes of these same commands).  PMC counters cannot be collected from
+    inside the benchmark, so these are the roofline fields not measured live."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None, None
-    d = json.load(open(files[-1]))
-    w = d.get("workloads", {}).get(workload)
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+def load_traffic(workload):
+    d, path = load_profile_json()
+    w = (d or {}).get("workloads", {}).get(workload)
     if not w or "bytes_per_launch" not in w:
         return None, None
-    return w["bytes_per_launch"], "%s (%s)" % (os.path.relpath(files[-1], ROOT), w["correction"])
+    return w["bytes_per_launch"], "%s (%s)" % (path, w["correction"])
+
+
+def roofline_valu(workload, avg_launch_us):
+    """The bound that actually binds: the cell gathers are cache hits, so HBM idles and the
+    kernels are limited by VALU issue (FP64 and integer instructions alike take four cycles per wave64 on a
+    16-lane SIMD).  From the SQ counters of the committed PMC passes and the live kernel time."""
+    d, path = load_profile_json()
+    w = (d or {}).get("workloads", {}).get(workload)
+    if not w or "valu" not in w:
+        return None
+    v = dict(w["valu"])
+    out = {"bound": "valu", "source": path, "kernel": w.get("kernel"),
+           "valu_wave_insts_per_launch": v.get("SQ_INSTS_VALU"),
+           "valu_insts_per_unit": v.get("insts_per_unit"),
+           "valu_issue_frac": v.get("issue_frac"),
+           "peak": "1024 SIMDs x 1 VALU wave-instruction per 4 cycles",
+           "note": v.get("note")}
+    if "bytes_per_launch" in w and avg_launch_us:
+        out["hbm_gbs_measured"] = w["bytes_per_launch"] / (avg_launch_us * 1e-6) / 1e9
+        out["hbm_utilisation"] = out["hbm_gbs_measured"] / HBM_PEAK_GBS
+    return out
 
 
 def sweep_ceiling(pkg, ctx, cfg, sc, scan_n, n_poses, launches, bpu, torch):
@@ -119,11 +171,11 @@ def sweep_ceiling(pkg, ctx, cfg, sc, scan_n, n_poses, launches, bpu, torch):
            "poses_per_launch": n_poses, "beams": scan_n, "avg_launch_us": 1e3 * ms / max(n, 1)}
     alg = float(n_poses) * scan_n * bpu
     if traffic and traffic < 0.25 * alg:
-        # the candidate poses of a matcher sit within centimetres of each other: their cell gathers hit
-        # the same few hundred KB of the map, which stay in L2 -- the algorithmic bytes (one cell read
-        # per pose and beam) are then served by the caches, not by HBM, and may exceed its peak
         out["note"] = ("measured HBM traffic is %.0fx below the algorithmic bytes: the gathers of nearby poses are "
-                       "cache hits, the kernel is bound by FP64 issue and gather latency" % (alg / traffic))
+                       "cache hits, the kernel is bound by VALU issue and gather latency (valu)" % (alg / traffic))
+    rv = roofline_valu("sweep", out["avg_launch_us"])
+    if rv:
+        out["valu"] = rv
     return out
 
 
@@ -137,12 +189,24 @@ def cpu_model():
     return "unknown"
 
 
+# ------------------------------------------------------------------------------------------- CPU baselines
+def _ref_match_worker(job):
+    """One worker process: the compiled reference's process_scan on the scene, for `seconds`."""
+    sc_args, kind, params, seconds, weighting = job
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from synth import make_scene
+    sc = make_scene(**sc_args)
+    r = cpu_baseline_reference(sc, kind, params, seconds, weighting)
+    return (r["_units"], r["_seconds"]) if r else None
+
+
 def cpu_baseline_reference(sc, kind, params, seconds, weighting):
     """The compiled reference itself (oracle/_ref/libslamref.so = the unmodified reference headers
     built in place; travels to the GPU box prebuilt): the synthetic map is rebuilt as a reference
     UnboundedPlainGridMap (pointer-chasing cells, virtual calls) and the reference's own
     HillClimbingScanMatcher / MonteCarloScanMatcher::process_scan is timed on one thread."""
     import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     m = sc["map"]
     if m.cell_model != 0 or not po.ref_available():
@@ -175,11 +239,20 @@ def cpu_baseline_reference(sc, kind, params, seconds, weighting):
     return {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "reference",
             "sample": "%d x %s %s process_scan of the compiled reference (oracle/_ref, g++ -O3) on the same "
                       "scene rebuilt as UnboundedPlainGridMap<AffineQualityMergeCell>, %.1f s; host CPU: %s, "
-                      "%d logical cores visible" % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0)}
+                      "%d logical cores visible" % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0),
+            "_units": units, "_seconds": t_used}
 
 
-def cpu_baseline(sc, kind, params, seconds, weighting="even"):
-    """Single-thread CPU checker on the same scene: whole process_scan calls, bounded to ~seconds."""
+def run_workers(fn, jobs):
+    """`len(jobs)` worker processes (spawn: fresh interpreters; this process has not touched the GPU yet)."""
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        return pool.map(fn, jobs)
+
+
+def cpu_baseline(sc, sc_args, kind, params, seconds, weighting, procs):
+    """Single-thread CPU checker on the same scene: whole process_scan calls, bounded to ~seconds; plus, for
+    context, the same on `procs` host cores at once (independent matches, one per process)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     try:
@@ -192,9 +265,7 @@ def cpu_baseline(sc, kind, params, seconds, weighting="even"):
     cfg = po.make_cfg()
     units, t_used, reps = 0, 0.0, 0
     e = O.enumerator(okind, params)
-    if ref is not None:
-        seconds = min(seconds, 3.0)
-    t_end = time.perf_counter() + seconds
+    t_end = time.perf_counter() + (min(seconds, 3.0) if ref is not None else seconds)
     while True:
         t0 = time.perf_counter()
         r = O.process_scan(e, sc["map"], sc["scan"], cfg, sc["init_pose"], cap=8)
@@ -207,12 +278,87 @@ def cpu_baseline(sc, kind, params, seconds, weighting="even"):
             "sample": "%d x process_scan (%s %s) on the same scene, %.1f s, oracle/slam_oracle.c -O2, "
                       "flat-array map; host CPU: %s, %d logical cores visible"
                       % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0)}
-    if ref is not None:
-        ref["port_value"] = port["value"]  # the flat-array C restatement, for context
-        return ref
-    return port
+    if ref is None:
+        return port
+    ref.pop("_units", None)
+    ref.pop("_seconds", None)
+    ref["port_value"] = port["value"]  # the flat-array C restatement, for context
+    procs = max(1, min(procs, os.cpu_count() or 1))
+    if procs > 1:
+        try:
+            t0 = time.perf_counter()
+            per = min(seconds, 6.0)
+            res = [x for x in run_workers(_ref_match_worker, [(sc_args, kind, params, per, weighting)] * procs) if x]
+            if res:
+                ref["all_cores"] = {"value": sum(u / s for u, s in res), "unit": ref["unit"], "cores": len(res),
+                                    "sample": "%d worker processes, each the same reference match loop for %.0f s "
+                                              "(independent scans: the single-hypothesis matcher has no parallel form); "
+                                              "wall %.1f s incl. start-up" % (len(res), per, time.perf_counter() - t0)}
+        except Exception as ex:  # noqa: BLE001
+            ref["all_cores"] = {"error": str(ex)}
+    return ref
 
 
+def _ref_pf_worker(job):
+    sc_args, n, size, scale, seconds, seed0 = job
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from synth import make_scene
+    sc = make_scene(**sc_args)
+    return pf_reference_loop(sc, n, size, scale, seconds, seed0)
+
+
+def pf_reference_loop(sc, n, size, scale, seconds, seed0=1000):
+    """(particles x steps, seconds, steps) of the compiled reference's GmappingParticleFilter (shared map, map
+    update inside the step -- its default behaviour) on the scan sequence of the PF legs."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    if not po.ref_available():
+        return None
+    R = po.Ref()
+    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+    g = po.RefGmapping(R, n, size, size, scale, gp, np.arange(seed0, seed0 + n, dtype=np.uint32))
+    scan = R.scan_create(sc["scan"].range, sc["scan"].angle)
+    g.step(scan, sc["true_pose"], 7, np.arange(5000, 5000 + n, dtype=np.uint32))  # builds the map
+    rs = np.random.RandomState(5)
+    steps, t_used = 0, 0.0
+    while t_used < seconds and steps < 40:
+        d = rs.randn(3) * [0.05, 0.05, 0.02]
+        t0 = time.perf_counter()
+        g.step(scan, d, 8 + steps, np.arange(6000 + 100 * steps, 6000 + 100 * steps + n, dtype=np.uint32))
+        t_used += time.perf_counter() - t0
+        steps += 1
+    return n * steps, t_used, steps
+
+
+def pf_cpu_baselines(args, sc, sc_args, seconds):
+    """cfg4 on the host: the compiled reference's filter on the benchmarked map size, single thread (8
+    particles are enough: its cost is linear in the particle count, the particles run one after the other),
+    and -- for context -- one particle per worker process on `--cpu-procs` cores."""
+    try:
+        r = pf_reference_loop(sc, 8, args.pf_size, args.scale, seconds)
+        if not r:
+            return None
+        out = {"value": r[0] / r[1], "unit": "particles/s", "cores": 1, "kind": "reference",
+               "sample": "%d GmappingParticleFilter steps of 8 particles of the compiled reference (oracle/_ref) on "
+                         "the %dx%d map, map update inside the step, %.1f s; host CPU: %s"
+                         % (r[2], args.pf_size, args.pf_size, r[1], cpu_model())}
+        procs = max(1, min(args.cpu_procs, os.cpu_count() or 1, args.particles))
+        if procs > 1:
+            t0 = time.perf_counter()
+            res = [x for x in run_workers(_ref_pf_worker, [(sc_args, 1, args.pf_size, args.scale, min(seconds, 4.0),
+                                                            1000 + k) for k in range(procs)]) if x]
+            if res:
+                out["all_cores"] = {
+                    "value": sum(u / s for u, s, _ in res), "unit": "particles/s", "cores": len(res),
+                    "sample": "one particle per worker process (%d processes, each its own reference filter and map: "
+                              "the reference itself runs its particles sequentially on one shared map); wall %.1f s "
+                              "incl. start-up" % (len(res), time.perf_counter() - t0)}
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+
+
+# ------------------------------------------------------------------------------------------- particle filter
 def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count, rank, world, scan, deltas,
                               dist, torch, dev):
     """Per-particle copy-on-write maps with the particles sharded over the ranks (opt-in:
@@ -235,7 +381,6 @@ def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, firs
             return
         resamplings += 1
         blobs = gather(pfm.export(), torch.uint8)
-        # (source particle j, destination rank r) pairs, identical on every rank
         pairs = sorted({(int(idx[i]), owner(i)) for i in range(n) if owner(idx[i]) != owner(i)})
         mine = {j: pfm.export_particle_map(j - first) for j in sorted({j for j, _ in pairs if owner(j) == rank})}
         sizes = np.zeros(n, np.int64)
@@ -279,17 +424,30 @@ def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, firs
                     "on resampling" % world}
 
 
-def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
+def k6_roofline(ctx, note):
+    """roofline object of the map update from the HIP events recorded around every K6 pipeline since the last
+    reset (slamhip_profile_read_map_update)."""
+    ms, calls, records = ctx.profile_read_map_update(reset=True)
+    if not calls or ms <= 0:
+        return None
+    achieved = records * K6_BYTES_PER_RECORD / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "K6 pipeline (k_mu_count .. k_mu_apply, sort included)",
+            "bytes_per_unit": K6_BYTES_PER_RECORD, "unit_of_work": "(beam, cell) record", "launches": calls,
+            "units_launched": records, "avg_launch_us": 1e3 * ms / calls,
+            "timing": "HIP events recorded around each K6 pipeline on the context's stream, " + note}
+
+
+def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
     """BASELINE cfg 4: GMapping filter, `--particles` particles sharded over the ranks (contiguous
     blocks), 1080-beam scan, 4000x4000 @0.05 m GMapping-cell map replicated per GPU (the reference's
     particles share one map), HC(6, 0.1, 0.1), gate open so every particle matches on every scan.
-    One collective per step: all-gather of the raw weights over RCCL (plus the particle records
-    when a resampling happens).  Strong scaling: the particle count is fixed."""
-    from synth import make_scene
+    One collective per step: all-gather of the raw weights over RCCL, inside the library (plus the particle
+    records when a resampling happens).  Strong scaling: the particle count is fixed."""
     n = args.particles
     if n < world:
         return {"skipped": "fewer particles (%d) than ranks (%d)" % (n, world)}
-    sc = make_scene(cell_model=2, size=args.pf_size, scale=args.scale, n_beams=args.beams, seed=4)
+    legs = args.leg_set
     ctx.upload_map(1, sc["map"])
     # contiguous blocks; the first n % world ranks hold one particle more (100 particles on 8 GPUs: 13 x 4 + 12 x 4)
     counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
@@ -297,12 +455,11 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
     count, first = counts[rank], firsts[rank]
     seeds = np.arange(1000, 1000 + n, dtype=np.uint32)[first:first + count]
     gp = [0.0, args.pf_sigma_xy, 0.0, args.pf_sigma_th, 0.0, 0.0, 0.0, 0.0]
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
     scan = sc["scan"]
     dev = args.coll_device
 
     def gather(a, dtype):
-        """all-gather of per-particle rows (uneven shards are padded to the largest one)"""
+        """all-gather of per-particle rows over torch.distributed (gloo path; uneven shards are padded)"""
         if world == 1:
             return np.asarray(a)
         a = np.ascontiguousarray(a)
@@ -316,9 +473,8 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
         return np.concatenate([out[r, :counts[r] * per] for r in range(world)])
 
     rs = np.random.RandomState(5)
-    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(args.pf_steps + 2)]
-    calls = 0
-    resamplings = 0
+    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(args.pf_steps + 6)]
+    out = {"metric": "particles/sec at N=%d" % n, "unit": "particles/s", "scaling": "strong", "ranks": world}
     # the data-path collective lives in the library (csrc/shard.cpp: RCCL group per context, all-gather of
     # the raw weights inside slamhip_gmapping_step_sharded); torch.distributed only carries the 128-byte
     # group id to the ranks and the benchmark's own barrier / max-over-ranks
@@ -328,61 +484,85 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
         dist.broadcast(uid, 0)
         ctx.shard_init(rank, world, uid.cpu().numpy())
 
-    def one(k):
-        nonlocal calls, resamplings
-        if in_library:
-            req, _idx = pf.step_sharded(1, scan.range, scan.angle, None, deltas[k], 7 + k)
-            calls += pf.stats()["scorer_calls"]
-            resamplings += 1 if req else 0
-            return
-        raw = pf.predict_match(1, scan.range, scan.angle, None, deltas[k])
-        calls += pf.stats()["scorer_calls"]
-        allw = gather(raw, torch.float64)
-        req, idx = pf.plan_resample(allw, 7 + k)
-        if req:
-            resamplings += 1
-            pf.import_(gather(pf.export(), torch.uint8), idx)
+    if "pf" in legs:
+        pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
+        calls = 0
+        resamplings = 0
 
-    for k in range(2):
-        one(k)
-    calls = 0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(2, 2 + args.pf_steps):
-        one(k)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = pf.stats()
-    # second, instrumented pass (HIP events attached to every K3 dispatch; never in the timed pass)
-    ctx.profile_enable(True)
-    ctx.profile_read(reset=True)
-    for k in range(2 + args.pf_steps, 2 + args.pf_steps + 3):
-        one(k % len(deltas))
-    ctx.synchronize()
-    ctx.profile_enable(False)
-    g_ms, g_launches, g_units = ctx.profile_read(reset=True)
-    bpu = BYTES_PER_UNIT["gmapping"]
-    g_achieved = g_units * bpu / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-    pf_traffic, pf_traffic_src = load_traffic("pf")
-    pf_roofline = {"bound": "hbm", "achieved": g_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": g_achieved / HBM_PEAK_GBS, "traffic": pf_traffic, "traffic_source": pf_traffic_src,
-                   "kernel": "k_score_gmapping",
-                   "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,
-                   "avg_launch_us": 1e3 * g_ms / max(g_launches, 1),
-                   "timing": "HIP events attached to each dispatch, 3 extra steps after the timed pass"}
-    if world > 1:
-        tt = torch.tensor([dt, float(calls)], dtype=torch.float64, device=dev)
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tt.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt, calls = mx[0].item(), sm[1].item()
-    with_update = None
-    if world == 1:
+        def one(k):
+            nonlocal calls, resamplings
+            if in_library:
+                req, _idx = pf.step_sharded(1, scan.range, scan.angle, None, deltas[k], 7 + k)
+                calls += pf.stats()["scorer_calls"]
+                resamplings += 1 if req else 0
+                return
+            raw = pf.predict_match(1, scan.range, scan.angle, None, deltas[k])
+            calls += pf.stats()["scorer_calls"]
+            allw = gather(raw, torch.float64)
+            req, idx = pf.plan_resample(allw, 7 + k)
+            if req:
+                resamplings += 1
+                pf.import_(gather(pf.export(), torch.uint8), idx)
+
+        for k in range(2):
+            one(k)
+        calls = 0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(2, 2 + args.pf_steps):
+            one(k)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = pf.stats()
+        # second, instrumented pass (HIP events attached to every K3 dispatch; never in the timed pass)
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        t1 = time.perf_counter()
+        for k in range(2 + args.pf_steps, 2 + args.pf_steps + 3):
+            one(k)
+        ctx.synchronize()
+        dt_instr = time.perf_counter() - t1
+        ctx.profile_enable(False)
+        g_ms, g_launches, g_units = ctx.profile_read(reset=True)
+        bpu = BYTES_PER_UNIT["gmapping"]
+        g_achieved = g_units * bpu / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+        pf_traffic, pf_traffic_src = load_traffic("pf")
+        pf_roofline = {"bound": "hbm", "achieved": g_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": g_achieved / HBM_PEAK_GBS, "traffic": pf_traffic, "traffic_source": pf_traffic_src,
+                       "kernel": "k_score_gmapping",
+                       "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,
+                       "avg_launch_us": 1e3 * g_ms / max(g_launches, 1),
+                       "kernel_busy_frac": g_ms / (1e3 * dt_instr) if dt_instr > 0 else None,
+                       "timing": "HIP events attached to each dispatch, 3 extra steps after the timed pass"}
+        if world > 1:
+            tt = torch.tensor([dt, float(calls)], dtype=torch.float64, device=dev)
+            mx = tt.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = tt.clone()
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            dt, calls = mx[0].item(), sm[1].item()
+        collective = "none (1 rank)"
+        if in_library:
+            ss = ctx.shard_stats()
+            collective = ("slamhip_shard_allgather inside slamhip_gmapping_step_sharded: RCCL through the C-ABI, %d "
+                          "ranks in the group, %d collectives / %d bytes on this rank over the run"
+                          % (ctx.shard_info()[1], ss["collectives"], ss["bytes"]))
+        elif world > 1:
+            collective = "all_gather(raw weights) per step over gloo (torch.distributed; ranks share GPUs)"
+        out.update(value=n * args.pf_steps / dt, ms_per_step=1e3 * dt / args.pf_steps, steps=args.pf_steps,
+                   roofline=pf_roofline, roofline_valu=roofline_valu("pf", pf_roofline["avg_launch_us"]),
+                   pose_candidates_beams_per_s=calls * scan.n / dt,
+                   workload="cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "
+                            "GMapping cell, HC(6,0.1,0.1), likelihood step without map update"
+                            % (n, world, scan.n, args.pf_size, args.pf_size, args.scale),
+                   collective=collective, launches_last_step=st["launches"],
+                   carry_reruns_last_step=st["carry_reruns"], resamplings=resamplings)
+        pf.close()
+    if world == 1 and "pf_update" in legs:
         # the reference's full step: each particle appends its scan to the shared map before the
         # next one matches (sequential by construction) -- a few steps are enough
         pfu = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds)
@@ -395,11 +575,21 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
             pfu.step(1, scan.range, scan.angle, None, deltas[k], 7 + k)
         torch.cuda.synchronize()
         du = time.perf_counter() - tu
-        with_update = {"value": n * ksteps / du, "unit": "particles/s", "ms_per_step": 1e3 * du / ksteps,
-                       "steps": ksteps, "note": "sequential particles: GPU match then K6 map update on the "
-                                                "shared map, as the reference does"}
-    with_maps = None
-    if world == 1:
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        ctx.profile_read_map_update(reset=True)
+        pfu.step(1, scan.range, scan.angle, None, deltas[ksteps + 1], 7 + ksteps + 1)
+        ctx.synchronize()
+        ctx.profile_enable(False)
+        ctx.profile_read(reset=True)
+        out["with_map_update"] = {"value": n * ksteps / du, "unit": "particles/s", "ms_per_step": 1e3 * du / ksteps,
+                                  "steps": ksteps,
+                                  "note": "sequential particles: GPU match then K6 map update on the shared map, as "
+                                          "the reference does",
+                                  "roofline_map_update": k6_roofline(ctx, "one extra step after the timed pass (%d "
+                                                                          "single-scan updates)" % n)}
+        pfu.close()
+    if world == 1 and "pf_maps" in legs:
         # per-particle copy-on-write maps (tile pool): lock-step matching on every
         # particle's own map + ONE batched K6 for all appends of the step
         try:
@@ -416,89 +606,100 @@ def particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch):
             torch.cuda.synchronize()
             dm = time.perf_counter() - tm
             stt = pfm.particle_map_stats()
-            with_maps = {"value": n * msteps / dm, "unit": "particles/s", "ms_per_step": 1e3 * dm / msteps,
-                         "steps": msteps, "tiles_in_use": stt["tiles_in_use"], "pool_bytes": stt["bytes"],
-                         "cow_copies_first_step": first_stats["cow_copies"], "cow_copies_total": stt["cow_copies"],
-                         "cell_updates_last_step": stt["cell_updates"],
-                         "note": "every particle owns a copy-on-write map (128x128-cell tiles); matching in "
-                                 "lock-step, map updates of all particles in one batched K6"}
-            del pfm
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            ctx.profile_read_map_update(reset=True)
+            for k in range(2):
+                pfm.step(1, scan.range, scan.angle, None, deltas[(msteps + 1 + k) % len(deltas)], 7 + msteps + 1 + k)
+            ctx.synchronize()
+            ctx.profile_enable(False)
+            ctx.profile_read(reset=True)
+            out["with_particle_maps"] = {
+                "value": n * msteps / dm, "unit": "particles/s", "ms_per_step": 1e3 * dm / msteps,
+                "steps": msteps, "tiles_in_use": stt["tiles_in_use"], "pool_bytes": stt["bytes"],
+                "cow_copies_first_step": first_stats["cow_copies"], "cow_copies_total": stt["cow_copies"],
+                "cell_updates_last_step": stt["cell_updates"],
+                "note": "every particle owns a copy-on-write map (128x128-cell tiles); matching in "
+                        "lock-step, map updates of all particles in one batched K6",
+                "roofline_map_update": k6_roofline(ctx, "2 extra steps after the timed pass")}
+            pfm.close()
         except pkg.SlamHipError as e:  # e.g. the pool does not fit: report, do not hide
-            with_maps = {"error": str(e)}
+            out["with_particle_maps"] = {"error": str(e)}
     if world > 1 and args.pf_maps_sharded:
-        with_maps = sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count, rank, world,
-                                              scan, deltas, dist, torch, dev)
+        out["with_particle_maps"] = sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count,
+                                                              rank, world, scan, deltas, dist, torch, dev)
     ctx.map_release(1)
-    return {"metric": "particles/sec at N=%d" % n, "value": n * args.pf_steps / dt, "unit": "particles/s",
-            "with_map_update": with_update, "with_particle_maps": with_maps, "roofline": pf_roofline,
-            "ms_per_step": 1e3 * dt / args.pf_steps, "steps": args.pf_steps, "scaling": "strong",
-            "pose_candidates_beams_per_s": calls * scan.n / dt,
-            "workload": "cfg4: GMapping %d particles sharded over %d GPU(s), %d beams, %dx%d @%.2f m "
-                        "GMapping cell, HC(6,0.1,0.1), likelihood step without map update"
-                        % (n, world, scan.n, args.pf_size, args.pf_size, args.scale),
-            "collective": ("slamhip_shard_allgather inside slamhip_gmapping_step_sharded: RCCL through the C-ABI, "
-                           "%d ranks in the group, %d collectives / %d bytes on this rank over the run"
-                           % (ctx.shard_info()[1], ctx.shard_stats()["collectives"], ctx.shard_stats()["bytes"]))
-                          if in_library else
-                          ("all_gather(raw weights) per step over gloo (torch.distributed; ranks share GPUs)"
-                           if world > 1 else "none (1 rank)"),
-            "ranks": world,
-            "launches_last_step": st["launches"], "carry_reruns_last_step": st["carry_reruns"],
-            "resamplings": resamplings}
+    return out
 
 
-def pf_cpu_baseline(args, seconds):
-    """The oracle's sequential filter step on a small particle sample of the same scene."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle as po
+def cfg5_leg(args, pkg, ctx, torch):
+    """BASELINE configs[4] on ONE GPU: `--cfg5-particles` particles, 8000x8000 @ 0.025 m GMapping-cell map,
+    AreaOccupancyEstimator + blur 0.1 m ray-trace update, every particle its own copy-on-write map: lock-step
+    likelihood (K3 through tile tables) + one batched K6 per step.  The 8000^2 dense ancestor is bound in HBM
+    (2 GB + 1 GB of counters) and only the window the synthetic world covers is uploaded."""
     from synth import make_scene
-    sc = make_scene(cell_model=2, size=min(args.pf_size, 2000), scale=args.scale, n_beams=args.beams, seed=4)
-    O = po.Oracle()
-    n = 8
-    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
-    pf = O.gmapping_create(n, gp, np.arange(1000, 1000 + n, dtype=np.uint32))
-    scan = sc["scan"]
-    pf.step(sc["map"], scan.range, scan.angle, None, sc["true_pose"], 7)
-    rs = np.random.RandomState(5)
-    steps, t_used = 0, 0.0
-    while t_used < seconds and steps < 50:
-        t0 = time.perf_counter()
-        pf.step(sc["map"], scan.range, scan.angle, None, rs.randn(3) * [0.05, 0.05, 0.02], 8 + steps)
-        t_used += time.perf_counter() - t0
-        steps += 1
-    return {"value": n * steps / t_used, "unit": "particles/s", "cores": 1, "kind": "port",
-            "sample": "%d filter steps of %d particles (oracle, sequential, 2000^2 map window), %.1f s"
-                      % (steps, n, t_used)}
+    n, size, scale = args.cfg5_particles, args.cfg5_size, args.cfg5_scale
+    win = min(size, 3200)  # 80 m of world at 0.025 m: the rooms + corridors raster is at most ~56 m across
+    t0 = time.perf_counter()
+    sc = make_scene(cell_model=2, size=win, scale=scale, n_beams=args.beams, seed=6, blur_m=0.1)
+    t_scene = time.perf_counter() - t0
+    m, scan = sc["map"], sc["scan"]
+    off = (size - win) // 2
+    ctx.map_bind(2, 2, size, size, (m.origin[0] + off, m.origin[1] + off), scale, m.unknown)
+    ctx.map_upload_window(2, off, off, m.payload)
+    gp = [0.0, args.pf_sigma_xy / 2, 0.0, args.pf_sigma_th, 0.0, 0.0, 0.0, 0.0]
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, np.arange(3000, 3000 + n, dtype=np.uint32))
+    ext = (size + 127) // 128 + 1
+    reach = int(np.ceil(2.0 * (float(scan.range.max()) + 1.0) / scale / 128.0)) + 2
+    per_particle = reach * reach
+    try:
+        pf.enable_particle_maps(2, extent_tiles=ext, pool_tiles=ext * ext + n * per_particle, blur=0.1, estimator=1,
+                                shift_amount=0.01 * scale)
+    except pkg.SlamHipError as e:
+        pf.close()
+        ctx.map_release(2)
+        return {"error": "tile pool: %s" % e}
+    rs = np.random.RandomState(8)
+    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.03, 0.03, 0.01] for _ in range(args.cfg5_steps + 4)]
+    pf.step(2, scan.range, scan.angle, None, deltas[0], 7)  # clones every touched tile
+    first = pf.particle_map_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(1, 1 + args.cfg5_steps):
+        pf.step(2, scan.range, scan.angle, None, deltas[k], 7 + k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st, ms = pf.stats(), pf.particle_map_stats()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    ctx.profile_read_map_update(reset=True)
+    for k in range(2):
+        pf.step(2, scan.range, scan.angle, None, deltas[args.cfg5_steps + 1 + k], 7 + args.cfg5_steps + 1 + k)
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    g_ms, g_launches, g_units = ctx.profile_read(reset=True)
+    bpu = BYTES_PER_UNIT["gmapping"]
+    k3 = {"bound": "hbm", "achieved": g_units * bpu / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+          "unit": "GB/s", "kernel": "k_score_gmapping (tile tables)", "bytes_per_unit": bpu, "launches": g_launches,
+          "units_launched": g_units, "avg_launch_us": 1e3 * g_ms / max(g_launches, 1), "traffic": None}
+    k3["frac"] = k3["achieved"] / HBM_PEAK_GBS
+    out = {"metric": "particles/sec at N=%d" % n, "value": n * args.cfg5_steps / dt, "unit": "particles/s",
+           "ms_per_step": 1e3 * dt / args.cfg5_steps, "steps": args.cfg5_steps, "n_gpus": 1,
+           "workload": "cfg5: GMapping %d particles on 1 GPU, %d beams, %dx%d @%.3f m, per-particle copy-on-write maps, "
+                       "area occupancy estimator + blur 0.1 m map update in one batched K6 per step fused behind the "
+                       "lock-step likelihood" % (n, scan.n, size, size, scale),
+           "roofline": k6_roofline(ctx, "2 extra steps after the timed pass"), "roofline_likelihood": k3,
+           "cell_updates_last_step": ms["cell_updates"], "tiles_in_use": ms["tiles_in_use"], "pool_bytes": ms["bytes"],
+           "dense_ancestor_bytes": size * size * 48, "cow_copies_first_step": first["cow_copies"],
+           "launches_last_step": st["launches"], "scene_build_s": round(t_scene, 1),
+           "note": "BASELINE quotes this configuration on 8 GPUs; it fits one MI355X (288 GB), the sharded form is "
+                   "--gpus N --pf-maps-sharded"}
+    pf.close()
+    ctx.map_release(2)
+    return out
 
 
-def pf_cpu_baseline_reference(args, seconds):
-    """The compiled reference's own GmappingParticleFilter (oracle/_ref: shared map, map update inside
-    the step -- the reference's default behaviour) on the same scan sequence, a few particles."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle as po
-    from synth import make_scene
-    if not po.ref_available():
-        return None
-    sc = make_scene(cell_model=2, size=min(args.pf_size, 2000), scale=args.scale, n_beams=args.beams, seed=4)
-    R = po.Ref()
-    n = 8
-    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
-    g = po.RefGmapping(R, n, 1000, 1000, args.scale, gp, np.arange(1000, 1000 + n, dtype=np.uint32))
-    scan = R.scan_create(sc["scan"].range, sc["scan"].angle)
-    g.step(scan, sc["true_pose"], 7, np.arange(5000, 5000 + n, dtype=np.uint32))  # builds the map
-    rs = np.random.RandomState(5)
-    steps, t_used = 0, 0.0
-    while t_used < seconds and steps < 20:
-        d = rs.randn(3) * [0.05, 0.05, 0.02]
-        t0 = time.perf_counter()
-        g.step(scan, d, 8 + steps, np.arange(6000 + 100 * steps, 6000 + 100 * steps + n, dtype=np.uint32))
-        t_used += time.perf_counter() - t0
-        steps += 1
-    return {"value": n * steps / t_used, "unit": "particles/s", "cores": 1, "kind": "reference",
-            "sample": "%d GmappingParticleFilter steps of %d particles of the compiled reference (oracle/_ref), "
-                      "map update inside the step, %.1f s" % (steps, n, t_used)}
-
-
+# ------------------------------------------------------------------------------------------------- main
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
     torch.distributed.run as a CHILD process -- nothing in this process has touched the GPU yet, and it never
@@ -523,17 +724,37 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
+    import torch
+    if torch.cuda.device_count() < 1:
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    from synth import make_scene
+
+    wl = "hc" if args.workload == "sweep" else args.workload
+    cell, weighting, kind, params, bkey, desc = WORKLOADS[wl]
+    sc_args = dict(cell_model=cell, size=args.size, scale=args.scale, n_beams=args.beams, seed=100 + rank,
+                   weighting=weighting)
+    sc = make_scene(**sc_args)
+    scan = sc["scan"]
+    pf_needed = bool(args.leg_set & {"pf", "pf_update", "pf_maps"})
+    pf_sc_args = dict(cell_model=2, size=args.pf_size, scale=args.scale, n_beams=args.beams, seed=4)
+    pf_sc = make_scene(**pf_sc_args) if pf_needed else None
+
+    # ---- CPU baselines first: worker processes are started while this process is still GPU-free
+    cpu_out, pf_cpu_out = None, None
+    if world == 1 and rank == 0 and not args.no_cpu and args.workload != "sweep":
+        cpu_out = cpu_baseline(sc, sc_args, kind, params, args.cpu_seconds, weighting, args.cpu_procs)
+        if pf_needed:
+            pf_cpu_out = pf_cpu_baselines(args, pf_sc, pf_sc_args, min(args.cpu_seconds, 8.0))
+
+    # ---- from here on the GPU
+    import torch.distributed as dist
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()  # ranks may share a GPU under gloo
     torch.cuda.set_device(local_rank)
@@ -546,14 +767,7 @@ def main():
     args.coll_device = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     import __graft_entry__ as ge
-    from synth import make_scene
     pkg = ge.load_package()
-
-    wl = "hc" if args.workload == "sweep" else args.workload
-    cell, weighting, kind, params, bkey, desc = WORKLOADS[wl]
-    sc = make_scene(cell_model=cell, size=args.size, scale=args.scale, n_beams=args.beams,
-                    seed=100 + rank, weighting=weighting)
-    scan = sc["scan"]
     ctx = pkg.Context(local_rank)
     ctx.upload_map(0, sc["map"])
     cos_a, sin_a = pkg.beam_trig(scan.angle)
@@ -568,6 +782,8 @@ def main():
         ctx.synchronize()
 
     extra = {}
+    on_device = False
+    m = None
     if args.workload == "sweep":
         # kernel ceiling: flat batch of P device-resident poses, no host round trip
         P = args.sweep_poses
@@ -585,6 +801,7 @@ def main():
         m = pkg.Matcher(ctx, kind, cfg, params)
         if args.chain >= 0 and kind == "HC":
             m.set_device_chain(1 if args.chain else 0, args.chain if args.chain > 1 else 0)
+        on_device = kind == "HC" and args.chain != 0 and not args.strict
 
         def step():
             m.process_scan(0, sc["init_pose"])
@@ -592,9 +809,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # Pass 1 -- the timed region: exactly K steps, no instrumentation.  The per-dispatch HIP events
-    # cost ~12 us of queue processing per isolated launch (0.27 -> 0.45 ms/step on the HC workload),
-    # so they would distort `value` if they rode in this pass.
+    # Pass 1 -- the timed region: exactly K steps, no instrumentation.
     ctx.profile_enable(False)
     barrier()
     t0 = time.perf_counter()
@@ -615,10 +830,17 @@ def main():
     dt_instrumented = time.perf_counter() - t1
     ctx.profile_enable(False)
     k_ms, k_launches, k_units = ctx.profile_read(reset=True)
-    if args.workload != "sweep":
+    kernel_name = "k_score_point"
+    if m is not None:
         st = m.stats()
+        if on_device:
+            kernel_name = "k_hc_chain_step"
         extra.update(scorer_calls_per_step=st["scorer_calls"], poses_evaluated_per_step=st["poses_evaluated"],
                      launches_per_step=st["launches"],
+                     accept_chain=("on the device: one process_scan = a chain of kernels, each replaying the previous "
+                                   "one's speculation tree (csrc/hc_chain.hip)") if on_device else
+                                  "on the host: speculative batches, replay between launches",
+                     kernel_busy_frac=k_ms / (1e3 * dt_instrumented) if dt_instrumented > 0 else None,
                      host_us_last_step={k: round(st[k], 1) for k in ("build_us", "stage_us", "score_us", "replay_us")})
 
     units = float(calls) * scan.n
@@ -632,16 +854,25 @@ def main():
 
     ceiling = None
     if rank == 0 and args.workload != "sweep" and not args.strict:  # outside the timed region
-        ceiling = sweep_ceiling(pkg, ctx, cfg, sc, scan.n, args.sweep_poses, 50, BYTES_PER_UNIT[bkey], torch)
+        ceiling = sweep_ceiling(pkg, ctx, pkg.spe_cfg(), sc, scan.n, args.sweep_poses, 50, BYTES_PER_UNIT[bkey], torch)
+    if m is not None:
+        m.close()
 
     pf_out = None
-    if not args.no_pf and args.workload != "sweep":
-        pf_out = particle_filter_leg(args, pkg, ctx, rank, world, local_rank, dist, torch)
+    if pf_needed:
+        pf_out = particle_filter_leg(args, pkg, ctx, pf_sc, rank, world, dist, torch)
+    cfg5_out = None
+    if "cfg5" in args.leg_set and world == 1:
+        try:
+            cfg5_out = cfg5_leg(args, pkg, ctx, torch)
+        except pkg.SlamHipError as e:
+            cfg5_out = {"error": str(e)}
 
     if rank == 0:
         bpu = BYTES_PER_UNIT[bkey]
         achieved = (k_units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = load_traffic(args.workload)
+        avg_us = 1e3 * k_ms / max(k_launches, 1)
         out = {
             "metric": "pose-candidates*beams/sec (1080-beam scan, 2000^2 grid)",
             "value": units_all / t_max,
@@ -657,35 +888,35 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "beams_after_filter": scan.n,
                        "mode": "strict (sequential sum, host trig)" if args.strict else
-                               "default (canonical tree sum, device sincos)",
+                               ("beam-order sum, device sincos" if args.seq_sum else
+                                "default (canonical tree sum, device sincos)"),
                        "parallelism": "replicas x%d (no collective)" % world if world > 1 else "1 gpu",
                        "backend": args.backend if world > 1 else None,
                        **extra},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_score_point", "bytes_per_unit": bpu,
+                         "kernel": kernel_name, "bytes_per_unit": bpu,
                          "launches": k_launches, "units_launched": k_units,
-                         "avg_launch_us": 1e3 * k_ms / max(k_launches, 1),
-                         "timing": "HIP events attached to each k_score_point dispatch on the context's "
-                                   "stream, second pass of the same %d steps (%.4f ms/step with the events "
-                                   "attached; the timed pass carries none)"
-                                   % (args.steps, 1e3 * dt_instrumented / args.steps)},
+                         "avg_launch_us": avg_us,
+                         "timing": "HIP events attached to each %s dispatch on the context's stream, second pass of "
+                                   "the same %d steps (%.4f ms/step with the events attached; the timed pass carries "
+                                   "none)" % (kernel_name, args.steps, 1e3 * dt_instrumented / args.steps)},
         }
+        rv = roofline_valu(args.workload, avg_us)
+        if rv:
+            out["roofline_valu"] = rv
         if ceiling is not None:
             out["roofline_sweep"] = ceiling
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(sc, kind, params, args.cpu_seconds, weighting)
+        if cpu_out is not None:
+            out["cpu_baseline"] = cpu_out
         if pf_out is not None:
             out["particle_filter"] = pf_out
-            if world == 1 and not args.no_cpu and "value" in pf_out:
-                pf_out["cpu_baseline"] = pf_cpu_baseline(args, min(args.cpu_seconds, 8.0))
-                try:  # the full step (with map update) of the compiled reference, beside with_map_update
-                    refb = pf_cpu_baseline_reference(args, min(args.cpu_seconds, 6.0))
-                except Exception as e:  # noqa: BLE001
-                    refb = {"error": str(e)}
-                if refb is not None and pf_out.get("with_map_update"):
-                    pf_out["with_map_update"]["cpu_baseline"] = refb
+            if pf_cpu_out:
+                pf_out["cpu_baseline"] = pf_cpu_out
+        if cfg5_out is not None:
+            out["cfg5"] = cfg5_out
         print(json.dumps(out))
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

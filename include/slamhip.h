@@ -188,6 +188,11 @@ int slamhip_profile_enable(slamhip_ctx *ctx, int on);
 int slamhip_profile_read(slamhip_ctx *ctx, double *kernel_ms_total, long long *launches,
                          long long *units /* poses x beams launched */, int reset);
 
+/* the same for the map update (K6: count .. apply of one slamhip_map_append_scan or one batched append):
+ * recorded HIP events around the pipeline on the context's stream; records = (beam, cell) pairs applied */
+int slamhip_profile_read_map_update(slamhip_ctx *ctx, double *ms_total, long long *calls, long long *records,
+                                    int reset);
+
 /* ---------------------------------------------------------------- matchers
  * Replace GridScanMatcher::process_scan (src/core/scan_matchers/grid_scan_matcher.h:153-156) of
  *   MonteCarloScanMatcher   (monte_carlo_scan_matcher.h:84-100; enumerator :10-82)

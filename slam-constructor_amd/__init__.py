@@ -33,7 +33,7 @@ slamhip_ctx_synchronize slamhip_ctx_stream slamhip_map_bind slamhip_map_upload_w
 slamhip_map_apply_dirty slamhip_map_release slamhip_map_download_window slamhip_scan_upload
 slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_weights
 slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get
-slamhip_profile_enable slamhip_profile_read slamhip_matcher_create_mc slamhip_matcher_create_hc
+slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_process_scan
 slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
@@ -169,6 +169,7 @@ def load():
     L.slamhip_gm_cache_get.argtypes = [vp, _ip, _dp]
     L.slamhip_profile_enable.argtypes = [vp, i]
     L.slamhip_profile_read.argtypes = [vp, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i]
+    L.slamhip_profile_read_map_update.argtypes = [vp, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i]
     L.slamhip_matcher_create_mc.argtypes = [vp, C.POINTER(SpeCfg), u, d, d, u, u, C.POINTER(vp)]
     L.slamhip_matcher_create_hc.argtypes = [vp, C.POINTER(SpeCfg), u, d, d, C.POINTER(vp)]
     L.slamhip_matcher_create_bf.argtypes = [vp, C.POINTER(SpeCfg), _dp, C.POINTER(vp)]
@@ -481,6 +482,16 @@ class Context:
         ms, la, un = C.c_double(), C.c_longlong(), C.c_longlong()
         _check(self.L.slamhip_profile_read(self.h, C.byref(ms), C.byref(la), C.byref(un), int(reset)))
         return ms.value, la.value, un.value
+
+
+def _profile_read_map_update(self, reset=True):
+    """(ms of the K6 pipelines, calls, (beam, cell) records applied) since the last reset"""
+    ms, n, r = C.c_double(), C.c_longlong(), C.c_longlong()
+    _check(self.L.slamhip_profile_read_map_update(self.h, C.byref(ms), C.byref(n), C.byref(r), 1 if reset else 0))
+    return ms.value, n.value, r.value
+
+
+Context.profile_read_map_update = _profile_read_map_update
 
 
 class Matcher:

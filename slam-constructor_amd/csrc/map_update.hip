@@ -233,6 +233,12 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.n_padding = sc.n_updates;
 
   const dim3 bgrid((n + 255) / 256);
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;  // slamhip_profile_read_map_update: the whole pipeline
+  {
+    const int prc = profile_event_pair(ctx, &pe0, &pe1, 1);
+    if (prc) return prc;
+    if (pe0) SLAMHIP_CHECK(hipEventRecord(pe0, ctx->stream));
+  }
   if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, ctx->stream, sc.counts, sc.offsets, n);
@@ -306,6 +312,11 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.rec_beam = sc.order_sorted;
   mu_launch_apply<unsigned>(a, (const unsigned *)sc.keys_sorted, total, ctx->stream);
   SLAMHIP_CHECK(hipGetLastError());
+  if (pe1) {
+    SLAMHIP_CHECK(hipEventRecord(pe1, ctx->stream));
+    ctx->prof_k6_calls += 1;
+    ctx->prof_k6_records += total;
+  }
   int err = 0;
   unsigned long long nu = 0;  // padding records
   {
@@ -563,6 +574,12 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
 
   const dim3 bgrid((unsigned)((beams + 255) / 256));
   a.job_bbox = sc.d_bbox;
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;  // slamhip_profile_read_map_update: the whole pipeline
+  {
+    const int prc = profile_event_pair(ctx, &pe0, &pe1, 1);
+    if (prc) return prc;
+    if (pe0) SLAMHIP_CHECK(hipEventRecord(pe0, st));
+  }
   if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, st, a);
   {  // offsets: device-wide exclusive scan (the one-workgroup scan of the single-scan path takes 160 us
@@ -638,6 +655,11 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
     rc = mu_batch_tail<unsigned long long>(a, sc, total, beams, end_bit, st);
   if (rc) return rc;
   SLAMHIP_CHECK(hipGetLastError());
+  if (pe1) {
+    SLAMHIP_CHECK(hipEventRecord(pe1, st));
+    ctx->prof_k6_calls += 1;
+    ctx->prof_k6_records += total;
+  }
   int err = 0;
   unsigned long long nu = 0;  // padding records
   rc = mu_finish(ctx, sc.error_flag, sc.n_updates, sc.h_status, &err, &nu);

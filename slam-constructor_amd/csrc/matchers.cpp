@@ -206,7 +206,9 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   m->chain_launched = launched;
   m->chain_steps_avg = 0.75 * m->chain_steps_avg + 0.25 * (double)h->steps;
   if (ctx->profile) {
-    ctx->prof_launches += h->steps;
+    // every kernel launched carries an event pair, the run-ahead ones that found the chain finished too
+    // (rocprofv3 counts them as dispatches of the same kernel)
+    ctx->prof_launches += launched;
     ctx->prof_units += h->evaluated * (long long)a.scan.n;
   }
   out_delta[0] = h->pose[0] - init_pose[0];

@@ -175,6 +175,8 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
       ctx->ev_pool.resize(old_n + 512, nullptr);
       for (size_t i = old_n; i < ctx->ev_pool.size(); ++i) SLAMHIP_CHECK(hipEventCreate(&ctx->ev_pool[i]));
     }
+    ctx->ev_kind.resize(ctx->ev_used / 2 + 1, 0);
+    ctx->ev_kind[ctx->ev_used / 2] = 0;
     e0 = ctx->ev_pool[ctx->ev_used++];
     e1 = ctx->ev_pool[ctx->ev_used++];
   }
@@ -210,9 +212,11 @@ int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapVie
 }
 
 // an event pair of the profiling pool (resolved in slamhip_profile_read); null, null when profiling is off
-int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1) {
+int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kind) {
   *e0 = *e1 = nullptr;
   if (!ctx->profile) return SLAMHIP_OK;
+  ctx->ev_kind.resize(ctx->ev_used / 2 + 1, 0);
+  ctx->ev_kind[ctx->ev_used / 2] = (char)kind;
   if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
     const size_t old_n = ctx->ev_pool.size();
     ctx->ev_pool.resize(old_n + 512, nullptr);
@@ -230,8 +234,10 @@ static int profile_resolve(slamhip_ctx *ctx) {
   for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
     float ms = 0.f;
     SLAMHIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
-    ctx->prof_ms += ms;
+    if (i / 2 < ctx->ev_kind.size() && ctx->ev_kind[i / 2] == 1) ctx->prof_k6_ms += ms;
+    else ctx->prof_ms += ms;
   }
+  ctx->ev_kind.clear();
   ctx->ev_used = 0;
   return SLAMHIP_OK;
 }
@@ -858,6 +864,21 @@ int slamhip_profile_read(slamhip_ctx *ctx, double *kernel_ms_total, long long *l
     ctx->prof_ms = 0;
     ctx->prof_launches = 0;
     ctx->prof_units = 0;
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_profile_read_map_update(slamhip_ctx *ctx, double *ms_total, long long *calls, long long *records,
+                                    int reset) {
+  if (!ctx) return invalid("null ctx");
+  int rc = profile_resolve(ctx);
+  if (rc) return rc;
+  if (ms_total) *ms_total = ctx->prof_k6_ms;
+  if (calls) *calls = ctx->prof_k6_calls;
+  if (records) *records = ctx->prof_k6_records;
+  if (reset) {
+    ctx->prof_k6_ms = 0;
+    ctx->prof_k6_calls = ctx->prof_k6_records = 0;
   }
   return SLAMHIP_OK;
 }

@@ -164,8 +164,11 @@ struct slamhip_ctx {
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  std::vector<char> ev_kind;  // per event pair: 0 scoring dispatch, 1 one map update (K6 pipeline)
   double prof_ms = 0.0;
   long long prof_launches = 0, prof_units = 0;
+  double prof_k6_ms = 0.0;
+  long long prof_k6_calls = 0, prof_k6_records = 0;
 };
 
 namespace slamhip {
@@ -191,5 +194,5 @@ int score_wait(slamhip_ctx *ctx, unsigned seq, int lane = 0);
 int lane_fork(slamhip_ctx *ctx);
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
                 int *cell_model);
-int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);
+int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kind = 0);
 }  // namespace slamhip
