@@ -168,7 +168,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     while (cap < (size_t)n) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&sc.counts, sizeof(unsigned) * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.offsets, sizeof(unsigned) * (cap + 1)));
-    SLAMHIP_CHECK(hipMalloc(&sc.beam_end, sizeof(double) * 2 * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.beam_end, sizeof(double) * 4 * cap));  // end point + (1/dx, 1/dy)
     SLAMHIP_CHECK(hipMalloc(&sc.beam_info, sizeof(MuBeam) * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
@@ -228,6 +228,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.counts = sc.counts;
   a.offsets = sc.offsets;
   a.beam_end = sc.beam_end;
+  a.beam_inv = sc.beam_end + 2 * sc.cap_beams;
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
   a.n_padding = sc.n_updates;
@@ -483,7 +484,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
     while (cap < beams) cap *= 2;
     SLAMHIP_CHECK(regrow(sc.counts, cap));
     SLAMHIP_CHECK(regrow(sc.offsets, cap + 1));
-    SLAMHIP_CHECK(regrow(sc.beam_end, 2 * cap));
+    SLAMHIP_CHECK(regrow(sc.beam_end, 4 * cap));  // end point + (1/dx, 1/dy)
     SLAMHIP_CHECK(regrow(sc.beam_info, cap));
     sc.cap_beams = cap;
   }
@@ -568,6 +569,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   a.counts = sc.counts;
   a.offsets = sc.offsets;
   a.beam_end = sc.beam_end;
+  a.beam_inv = sc.beam_end + 2 * sc.cap_beams;
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
   a.n_padding = sc.n_updates;

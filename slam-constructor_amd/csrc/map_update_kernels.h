@@ -47,6 +47,7 @@ struct MuArgs {
   unsigned *counts, *offsets;  // per beam
   MuBeam *beam_info;  // per beam
   double *beam_end;   // 2 per beam (the obstacle point of its observations)
+  double *beam_inv;   // 2 per beam: 1 / (end - start) per axis (area estimator's fast test, mu_free_cell_valid)
   int *error_flag;    // set when a touched cell lies outside the window (k_mu_count clears both)
   unsigned long long *n_padding;  // records that are padding or outside the map: not cell updates
   // the SORTED records (k_mu_gather -> k_mu_apply*): observation, TBM only its quality, the beam
@@ -115,6 +116,10 @@ __global__ void k_mu_count(MuArgs a) {
     a.beam_end[2 * g] = wx;
     a.beam_end[2 * g + 1] = wy;
     const double ddx = wx - j.px, ddy = wy - j.py;
+    if (EST == 1) {
+      a.beam_inv[2 * g] = 1.0 / ddx;
+      a.beam_inv[2 * g + 1] = 1.0 / ddy;
+    }
     if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
       const int rcx = (int)floor(j.px / a.scale), rcy = (int)floor(j.py / a.scale);
       ocx = (int)floor(wx / a.scale);
@@ -322,6 +327,40 @@ __device__ __forceinline__ int mu_key_cell(const MuArgs &a, Key key, int *ix, in
   return a.jobs ? (int)(key >> a.cell_bits) : 0;
 }
 
+// Area estimator, a cell the beam passes over (is_occ = 0), cell kinds other than TBM: the estimate is always
+// (base_empty.prob, some quality) unless it is INVALID -- and those cell kinds read the quality only to see
+// whether it is NaN.  It is invalid in exactly one situation (area_occupancy_estimator.h:27-40,88-137): both
+// ends of the beam classified outside the cell AND Rectangle::find_intersections(Segment2D) returning fewer
+// than two points.  The test below proves "at least two points": the segment crosses the cell between an
+// entry and an exit point that (i) lie within the segment, (ii) sit on a cell edge at least `m` away from its
+// ends, so that the reference's exact interval test `e.beg <= i <= e.end` on its own (a few ulps different)
+// intersection cannot fail, and (iii) are farther apart than the fuzzy point comparison can merge.  Margins are
+// multiples of the tolerance of the reference's fuzzy comparisons at these coordinates (1e-7 * max(1, |x|),
+// math_utils.h:15-25), which is nine orders of magnitude above the rounding of the intersection itself.
+// Beams within 1000 tolerances of an axis direction, and everything the test does not prove, take the full
+// estimator.  195 M records of a cfg5 step: 16.1 ms of gather with the full estimator for every record.
+__device__ __forceinline__ bool mu_free_cell_valid(double x0, double y0, double x1, double y1, double inv_dx,
+                                                   double inv_dy, double left, double right, double bot, double top) {
+  const double dx = x1 - x0, dy = y1 - y0;
+  const double big = fmax(fmax(fabs(x0), fabs(y0)), fmax(fabs(x1), fabs(y1))) + (right - left);
+  const double tol = 1e-7 * fmax(1.0, big);
+  if (!(fabs(dx) > 1000.0 * tol) || !(fabs(dy) > 1000.0 * tol)) return false;
+  const double ta = (left - x0) * inv_dx, tb = (right - x0) * inv_dx;
+  const double tc = (bot - y0) * inv_dy, td = (top - y0) * inv_dy;
+  const double tx_in = fmin(ta, tb), tx_out = fmax(ta, tb), ty_in = fmin(tc, td), ty_out = fmax(tc, td);
+  const double t_in = fmax(tx_in, ty_in), t_out = fmin(tx_out, ty_out);
+  if (!(0.0 <= t_in && t_out <= 1.0 && t_in < t_out)) return false;
+  const double m = 64.0 * tol;
+  // the coordinate ALONG the edge it lies on, of the entry and of the exit point
+  const bool in_through_x = tx_in > ty_in, out_through_x = tx_out < ty_out;
+  const double e_along = in_through_x ? y0 + t_in * dy : x0 + t_in * dx;
+  const double x_along = out_through_x ? y0 + t_out * dy : x0 + t_out * dx;
+  const double e_lo = in_through_x ? bot : left, e_hi = in_through_x ? top : right;
+  const double x_lo = out_through_x ? bot : left, x_hi = out_through_x ? top : right;
+  if (!(e_lo + m <= e_along && e_along <= e_hi - m && x_lo + m <= x_along && x_along <= x_hi - m)) return false;
+  return (t_out - t_in) * fmax(fabs(dx), fabs(dy)) > 8.0 * tol;
+}
+
 // the observation a beam makes of one of its cells: (prob, qual)
 template <int EST>
 __device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int cy, const MuBeam *pbm) {
@@ -334,10 +373,15 @@ __device__ __forceinline__ double2 mu_value(const MuArgs &a, int b, int cx, int 
     const MuJob jb = mu_job(a, b);
     const double base4[4] = {a.base_occ_prob, a.base_occ_qual, a.base_empty_prob, a.base_empty_qual};
     const ae::ae_rect cb{a.scale * cy, a.scale * (cy + 1), a.scale * cx, a.scale * (cx + 1)};
-    const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{a.beam_end[2 * b], a.beam_end[2 * b + 1]},
-                                         cb, 0, base4, a.shift_amount);
-    prob = o.prob;
-    qual = o.qual;
+    const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
+    if (a.rule != 3 && mu_free_cell_valid(jb.px, jb.py, wx, wy, a.beam_inv[2 * b], a.beam_inv[2 * b + 1], cb.left,
+                                          cb.right, cb.bot, cb.top)) {
+      // valid, and only its probability is read: (base_empty.prob, any number)
+    } else {
+      const ae::ae_occ o = ae::ae_estimate(ae::ae_pt{jb.px, jb.py}, ae::ae_pt{wx, wy}, cb, 0, base4, a.shift_amount);
+      prob = o.prob;
+      qual = o.qual;
+    }
   }
   if (a.blur != 0.0) {  // (no blur: hole_dist_sq is 0 and the test below never holds)
     const double cdx = cx - ocx, cdy = cy - ocy;
