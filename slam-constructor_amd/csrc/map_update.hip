@@ -290,9 +290,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.keys_cap = (unsigned long long)sc.cap_records;
   a.key_x0 = a.key_y0 = 0;
   a.key_w = m.pitch;
-  hipLaunchKernelGGL(k_mu_emit<unsigned>, bgrid, dim3(256), 0, ctx->stream, a);
-  hipLaunchKernelGGL(k_mu_beam_ids, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, sc.counts, sc.offsets, (unsigned)n,
-                     sc.order);
+  hipLaunchKernelGGL(k_mu_emit<unsigned>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, sc.order);
   size_t tb = sc.temp_bytes;
   // sort only the bits a cell key can occupy; the invalid key (all ones) still sorts last because
   // every valid key is < 2^nbits - 1
@@ -401,9 +399,7 @@ template <typename Key>
 int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t beams, unsigned end_bit, hipStream_t st) {
   Key *keys = (Key *)sc.keys, *keys_sorted = (Key *)sc.keys_sorted;
   const dim3 bgrid((unsigned)((beams + 255) / 256)), rgrid((total + 255) / 256);
-  hipLaunchKernelGGL(k_mu_emit<Key>, bgrid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_mu_beam_ids, dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, st, sc.counts, sc.offsets,
-                     (unsigned)beams, sc.order);
+  hipLaunchKernelGGL(k_mu_emit<Key>, dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, st, a, sc.order);
   size_t tb = sc.temp_bytes;
   SLAMHIP_CHECK(rocprim::radix_sort_pairs<BatchSortConfig<Key>>(sc.temp, tb, keys, keys_sorted, sc.order,
                                                                 sc.order_sorted, total, 0,

@@ -186,34 +186,17 @@ __global__ __launch_bounds__(1024) void k_mu_offsets(const unsigned *counts, uns
   if (t == 1023) offsets[n] = s_part[1023];
 }
 
-// The value sorted along with a record's cell key is the beam that made it: one wave per beam fills its
-// (contiguous, beam-major) range of records.  The sort is stable and a beam visits a cell once, so the
-// records of a cell come out in beam order -- the reference's update order -- and still name their beam.
-__global__ __launch_bounds__(256) void k_mu_beam_ids(const unsigned *counts, const unsigned *offsets, unsigned beams,
-                                                      unsigned *beam_of) {
-  const unsigned b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= beams) return;
-  const unsigned cnt = counts[b], base = offsets[b];
-  for (unsigned k = threadIdx.x & 63; k < cnt; k += 64) beam_of[base + k] = b;
-}
-
-// The walk of one beam (RegularSquaresGrid::world_to_cells, regular_squares_grid.h:56-101, with the
-// Bresenham fail-over of DiscreteSegment2D): one thread per beam, inherently sequential (the error term
-// accumulates roundings), so its body is kept to the dependency chain -- the step is select-based, and
-// all it leaves behind per visited cell is the sort key.  The observation itself (occupancy estimate,
-// blur) is a pure function of (beam, cell) and is computed later, one thread per record, in k_mu_gather.
+// The walk of one beam as the reference runs it (RegularSquaresGrid::world_to_cells,
+// regular_squares_grid.h:56-101, with the Bresenham fail-over of DiscreteSegment2D): sequential (the error
+// term accumulates roundings), select-based steps, and all it leaves behind per visited cell is the sort key.
+// The observation itself (occupancy estimate, blur) is a pure function of (beam, cell) and is computed later,
+// one thread per record, in k_mu_gather.  Called by k_mu_emit for the beams its closed form does not settle.
 template <typename KeyT>
-__global__ void k_mu_emit(MuArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;  // global beam index: job * n + beam
-  if (b >= a.n * a.n_jobs) return;
+__device__ void mu_walk_beam(const MuArgs &a, int b) {  // b = global beam index: job * n + beam
   const unsigned cap = a.counts[b];
   if (cap == 0) return;
   const MuJob jb = mu_job(a, b);
   const unsigned base = a.offsets[b];
-  if ((unsigned long long)base + cap > a.keys_cap) {  // the host sized the buffer for another count: no write
-    *a.error_flag = 2;
-    return;
-  }
   const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
   const double scale = a.scale;
   const double d_x = wx - jb.px, d_y = wy - jb.py;
@@ -311,6 +294,90 @@ __global__ void k_mu_emit(MuArgs a) {
   }
   for (unsigned k = n; k < cap; ++k) out[k] = ~KeyT(0);
   if (bad) *a.error_flag = 1;
+}
+
+// The walk in parallel.  The reference's loop (regular_squares_grid.h:56-101) is a floating-point recurrence
+// per beam -- 76 of the 170 us of a single-scan update went to 17 waves stepping 600 cells one after the other.
+// But away from ties it is a plain digital line: with A = e_x_inc, B = e_y_inc (opposite signs), u = sign(A) e
+// and theta = (|B| - |A|) / 2 the rule "step in x iff |e + B| > |e + A|" reads "iff u < theta", u grows by |A|
+// on an x step and falls by |B| on a y step, so it stays in [theta - |B|, theta + |A|) and the number of y steps
+// among the first k is
+//     j_k = floor((u_0 + k |A| - theta + |B|) / (|A| + |B|)),      i_k = k - j_k .
+// One wave per beam, one lane per step: lane k evaluates the cell (i_k, j_k) directly, rebuilds the error term
+// e_k = e_0 + i_k A + j_k B and CHECKS the step the recurrence would take from it: the decision must be the one
+// the formula takes (i_(k+1) - i_k) and must be at least 2e-7 away from the tie test (|d| <= 1e-7; the
+// recurrence's accumulated rounding over a beam is below 1e-12), and the last lane must stand on the end cell.
+// If every lane agrees, induction over k gives the recurrence's cell sequence; otherwise -- ties along
+// diagonals, axis-parallel beams, walks that rounding sends astray -- lane 0 redoes the beam with the
+// sequential walk (mu_walk_beam: tie rule, Bresenham fail-over), so the result is the same either way.
+// The beam of every record (the value sorted along) is written here too (k_mu_beam_ids is gone).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.n * a.n_jobs) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned cap = a.counts[b];
+  if (cap == 0) return;
+  const unsigned base = a.offsets[b];
+  if ((unsigned long long)base + cap > a.keys_cap) {  // the host sized the buffer for another count: no write
+    if (lane == 0) *a.error_flag = 2;
+    return;
+  }
+  const MuJob jb = mu_job(a, b);
+  const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
+  const double scale = a.scale;
+  const double d_x = wx - jb.px, d_y = wy - jb.py;
+  const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
+  const int bx = (int)floor(jb.px / scale), by = (int)floor(jb.py / scale);
+  const int ex = a.beam_info[b].ex, ey = a.beam_info[b].ey;
+  const double mid_x = (bx + 0.5) * scale, mid_y = (by + 0.5) * scale;
+  const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
+  const double e0 = mid_cell_seg_y - mid_y * d_x;
+  const double A = inc_x * scale * d_y, B = -inc_y * scale * d_x;
+  const double absA = fabs(A), absB = fabs(B), W = absA + absB;
+  const double sgn = A < 0 ? -1.0 : 1.0;
+  const double theta = (absB - absA) * 0.5;
+  const double q0 = sgn * e0 - theta + absB;
+  const int steps_x = abs(ex - bx), steps_y = abs(ey - by);
+  const KeyT job_part = a.jobs ? (KeyT)(b / a.n) << a.cell_bits : KeyT(0);
+  const unsigned row = (unsigned)a.key_w;
+  const unsigned w = (unsigned)a.width, h = (unsigned)a.height;
+  KeyT *out = (KeyT *)a.keys + base;
+  bool ok = absA > 0.0 && absB > 0.0 && cap == (unsigned)(steps_x + steps_y + 1);
+  bool bad = false;
+  if (ok) {
+    for (unsigned k0 = 0; k0 < cap; k0 += 64) {
+      const unsigned k = k0 + lane;
+      if (k < cap) {
+        long long j = (long long)floor((q0 + (double)k * absA) / W);
+        long long jn = (long long)floor((q0 + (double)(k + 1) * absA) / W);
+        j = j < 0 ? 0 : (j > (long long)k ? (long long)k : j);
+        jn = jn < 0 ? 0 : (jn > (long long)k + 1 ? (long long)k + 1 : jn);
+        const long long i = (long long)k - j;
+        const double e = e0 + (double)i * A + (double)j * B;
+        const double d = fabs(e + B) - fabs(e + A);
+        if (k + 1 < cap) {
+          const bool x_formula = jn == j;  // the formula's next step is an x step
+          ok = ok && fabs(d) > 2e-7 && (0 < d) == x_formula && jn - j <= 1;
+        } else {
+          ok = ok && i == steps_x && j == steps_y;
+        }
+        const unsigned ix = (unsigned)(bx + inc_x * (int)i + a.origin_x), iy = (unsigned)(by + inc_y * (int)j + a.origin_y);
+        const bool oob = ix >= w || iy >= h;
+        bad |= oob;
+        out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
+        beam_of[base + k] = (unsigned)b;
+      }
+    }
+  }
+  ok = __all(ok);
+  if (ok) {
+    if (__any(bad) && lane == 0) *a.error_flag = 1;
+    return;
+  }
+  // the sequential walk decides (it rewrites every key of the beam and the padding)
+  for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
+  if (lane == 0) mu_walk_beam<KeyT>(a, b);
 }
 
 // the internal cell (and the job) a sort key names

@@ -1,0 +1,218 @@
+// tools/lds_probe.hip -- the north-star design put to the test: K1 with the beam table (range, cos, sin,
+// weight, factor) in LDS and the scan window -- the 3x3 cells around every beam's end point for the
+// workgroup's first pose -- staged in LDS, against the shipped K1 (beam constants in VGPRs, cells gathered
+// through L2), on the two launch shapes of the product:
+//   sweep    4096 poses spread +-0.2 m / +-0.1 rad, 8 poses per workgroup
+//   matcher  209 poses within +-0.1 m / +-0.05 rad (one speculation tree), 1 pose per workgroup
+// Same arithmetic (score_device.h), same canonical sum; scores must agree bit for bit.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include -I slam-constructor_amd/csrc \
+//        tools/lds_probe.hip -L slam-constructor_amd -lslamhip -Wl,-rpath,'$ORIGIN/../../slam-constructor_amd'
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "score_device.h"
+#include "slamhip.h"
+
+using namespace slamhip;
+
+#define CK(x)                                                                 \
+  do {                                                                        \
+    hipError_t e_ = (x);                                                      \
+    if (e_ != hipSuccess) {                                                   \
+      printf("%s: %s\n", #x, hipGetErrorString(e_));                          \
+      return 1;                                                               \
+    }                                                                         \
+  } while (0)
+
+// WINDOW: 0 = beam table in LDS only, 1 = + 3x3 cell window per beam in LDS
+template <int KB, int WINDOW>
+__global__ __launch_bounds__(256) void k_score_point_lds(ScoreArgs a) {
+  extern __shared__ double s_dyn[];  // beam table [5][KB*256] | window [KB*256][9]
+  __shared__ double s_pose[16][4];
+  __shared__ double s_part[16][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = a.scan.n;
+  constexpr int NB = KB * 256;
+  double *s_r = s_dyn, *s_c = s_dyn + NB, *s_s = s_dyn + 2 * NB, *s_w = s_dyn + 3 * NB, *s_f = s_dyn + 4 * NB;
+  double *s_win = s_dyn + 5 * NB;
+  const int p0 = blockIdx.x * a.poses_per_block;
+  const int npb = min(a.poses_per_block, a.n_poses - p0);
+  for (int b = t; b < NB; b += 256) {
+    const bool ok = b < n;
+    s_r[b] = ok ? a.scan.range[b] : 0.0;
+    s_c[b] = ok ? a.scan.cos_a[b] : 0.0;
+    s_s[b] = ok ? a.scan.sin_a[b] : 0.0;
+    s_w[b] = ok ? a.scan.weight[b] : 0.0;
+    s_f[b] = ok ? a.scan.factor[b] : 0.0;
+  }
+  if (t < npb) {
+    const int p = p0 + t;
+    double sn, cs;
+    sincos(a.poses[3 * p + 2], &sn, &cs);
+    s_pose[t][0] = a.poses[3 * p];
+    s_pose[t][1] = a.poses[3 * p + 1];
+    s_pose[t][2] = sn;
+    s_pose[t][3] = cs;
+  }
+  __syncthreads();
+  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
+  int c0x[KB], c0y[KB];
+  if (WINDOW) {
+    // the window of every own beam around its end cell for the workgroup's first pose
+    const double x = s_pose[0][0], y = s_pose[0][1], sn = s_pose[0][2], cs = s_pose[0][3];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int b = t + 256 * k;
+      const double c = cs * s_c[b] - sn * s_s[b], s = sn * s_c[b] + cs * s_s[b];
+      c0x[k] = to_cell(x + s_r[b] * c, scale, inv_scale);
+      c0y[k] = to_cell(y + s_r[b] * s, scale, inv_scale);
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        s_win[b * 9 + q] = load_cell<SLAMHIP_CELL_OCC>(a.map, c0x[k] + q % 3 - 1, c0y[k] + q / 3 - 1).x;
+    }
+  }
+  for (int j = 0; j < npb; ++j) {
+    const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int b = t + 256 * k;
+      if (b < n) {
+        const double c = cs * s_c[b] - sn * s_s[b], s = sn * s_c[b] + cs * s_s[b];
+        const int cx = to_cell(x + s_r[b] * c, scale, inv_scale), cy = to_cell(y + s_r[b] * s, scale, inv_scale);
+        double4 cell;
+        const int dx = cx - c0x[k], dy = cy - c0y[k];
+        if (WINDOW && (unsigned)(dx + 1) < 3u && (unsigned)(dy + 1) < 3u)
+          cell = make_double4(s_win[b * 9 + (dy + 1) * 3 + dx + 1], 0, 0, 0);
+        else
+          cell = load_cell<SLAMHIP_CELL_OCC>(a.map, cx, cy);
+        acc = acc + cell_probability<SLAMHIP_CELL_OCC>(a.oie, cell) * s_w[b] * s_f[b];
+      }
+    }
+    acc = wave_xor_sum(acc);
+    if (lane == 0) s_part[j][wave] = acc;
+  }
+  __syncthreads();
+  if (t < npb) {
+    const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
+    a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+  }
+}
+
+int main() {
+  const int size = 2000, n = 1080;
+  const double scale = 0.05;
+  std::mt19937 rng(5);
+  std::uniform_real_distribution<double> u(0.0, 1.0);
+  std::vector<double> pay((size_t)size * size);
+  for (auto &v : pay) v = u(rng) < 0.7 ? 0.01 + 0.02 * u(rng) : u(rng);
+  std::vector<double> range(n), angle(n), ca(n), sa(n), w(n, 1.0 / n), f(n, 1.0);
+  for (int i = 0; i < n; ++i) {
+    angle[i] = -2.356 + 4.712 * i / (n - 1);
+    range[i] = 6.0 + 4.0 * std::sin(3.0 * angle[i]) + 8.0 * u(rng) * (i % 7 == 0);
+    ca[i] = std::cos(angle[i]);
+    sa[i] = std::sin(angle[i]);
+  }
+  slamhip_ctx *ctx = nullptr;
+  if (slamhip_ctx_create(0, &ctx)) return printf("%s\n", slamhip_last_error()), 1;
+  const double unk[4] = {0.5, 0, 0, 0};
+  if (slamhip_map_bind(ctx, 0, SLAMHIP_CELL_OCC, size, size, size / 2, size / 2, scale, unk)) return 1;
+  if (slamhip_map_upload_window(ctx, 0, 0, 0, size, size, pay.data())) return 1;
+  if (slamhip_scan_upload(ctx, n, range.data(), ca.data(), sa.data(), w.data(), f.data())) return 1;
+  // the same data for the probe kernel
+  double *d_pay, *d_scan;
+  const int pitch = (size + 15) & ~15;
+  CK(hipMalloc(&d_pay, sizeof(double) * (size_t)pitch * size));
+  CK(hipMemcpy2D(d_pay, pitch * 8, pay.data(), size * 8, size * 8, size, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_scan, sizeof(double) * 5 * n));
+  const double *cols[5] = {range.data(), ca.data(), sa.data(), w.data(), f.data()};
+  for (int k = 0; k < 5; ++k) CK(hipMemcpy(d_scan + k * n, cols[k], sizeof(double) * n, hipMemcpyHostToDevice));
+  slamhip_spe_cfg cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  struct Shape {
+    const char *name;
+    int poses, ppb;
+    double sxy, sth;
+  } shapes[] = {{"sweep   4096 poses, 8 per workgroup", 4096, 8, 0.2, 0.1},
+                {"sweep   4096 poses, 4 per workgroup", 4096, 4, 0.2, 0.1},
+                {"sweep   4096 poses, 16 per workgroup", 4096, 16, 0.2, 0.1},
+                {"tight   4096 poses within 5 cm, 8 per workgroup", 4096, 8, 0.05, 0.01},
+                {"matcher 209 poses, 1 per workgroup", 209, 1, 0.1, 0.05}};
+  hipStream_t st = (hipStream_t)slamhip_ctx_stream(ctx);
+  for (const Shape &sh : shapes) {
+    std::vector<double> poses(3 * sh.poses);
+    std::normal_distribution<double> g(0.0, 1.0);
+    for (int p = 0; p < sh.poses; ++p) {
+      poses[3 * p] = 0.025 + sh.sxy * g(rng);
+      poses[3 * p + 1] = 0.025 + sh.sxy * g(rng);
+      poses[3 * p + 2] = 1.57 + sh.sth * g(rng);
+    }
+    double *d_poses, *d_ref, *d_out;
+    CK(hipMalloc(&d_poses, sizeof(double) * 3 * sh.poses));
+    CK(hipMalloc(&d_ref, sizeof(double) * sh.poses));
+    CK(hipMalloc(&d_out, sizeof(double) * sh.poses));
+    CK(hipMemcpy(d_poses, poses.data(), sizeof(double) * 3 * sh.poses, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto timed = [&](auto launch) -> float {
+      for (int r = 0; r < 5; ++r) launch();
+      hipStreamSynchronize(st);
+      hipEventRecord(e0, st);
+      for (int r = 0; r < 50; ++r) launch();
+      hipEventRecord(e1, st);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      return ms * 1e3f / 50;
+    };
+    const float t_k1 = timed([&] { slamhip_score_poses_device(ctx, 0, &cfg, sh.poses, d_poses, d_ref); });
+    ScoreArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.map.payload = d_pay;
+    a.map.width = size;
+    a.map.height = size;
+    a.map.pitch = pitch;
+    a.map.origin_x = a.map.origin_y = size / 2;
+    a.map.scale = scale;
+    a.map.inv_scale = 1.0 / scale;
+    a.map.unknown[0] = 0.5;
+    a.scan.range = d_scan;
+    a.scan.cos_a = d_scan + n;
+    a.scan.sin_a = d_scan + 2 * n;
+    a.scan.weight = d_scan + 3 * n;
+    a.scan.factor = d_scan + 4 * n;
+    a.scan.n = n;
+    double tw = 0;
+    for (double x : w) tw += x;
+    a.scan.tot_w = tw;
+    a.poses = d_poses;
+    a.scores = d_out;
+    a.n_poses = sh.poses;
+    a.poses_per_block = sh.ppb;
+    const dim3 grid((sh.poses + sh.ppb - 1) / sh.ppb);
+    const size_t shm0 = sizeof(double) * 5 * 5 * 256, shm1 = shm0 + sizeof(double) * 9 * 5 * 256;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_score_point_lds<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm1));
+    const float t_tab = timed([&] { hipLaunchKernelGGL((k_score_point_lds<5, 0>), grid, dim3(256), shm0, st, a); });
+    std::vector<double> ref(sh.poses), out(sh.poses);
+    CK(hipMemcpy(out.data(), d_out, sizeof(double) * sh.poses, hipMemcpyDeviceToHost));
+    const float t_win = timed([&] { hipLaunchKernelGGL((k_score_point_lds<5, 1>), grid, dim3(256), shm1, st, a); });
+    CK(hipMemcpy(ref.data(), d_ref, sizeof(double) * sh.poses, hipMemcpyDeviceToHost));
+    std::vector<double> out2(sh.poses);
+    CK(hipMemcpy(out2.data(), d_out, sizeof(double) * sh.poses, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int p = 0; p < sh.poses; ++p) bad += (std::memcmp(&ref[p], &out[p], 8) != 0) + (std::memcmp(&ref[p], &out2[p], 8) != 0);
+    printf("%-52s K1 (VGPR constants, L2 gathers; its own pose grouping) %7.2f us | beam table in LDS %7.2f us | + 3x3 "
+           "window in LDS %7.2f us | score mismatches %d\n", sh.name, t_k1, t_tab, t_win, bad);
+    hipFree(d_poses);
+    hipFree(d_ref);
+    hipFree(d_out);
+  }
+  slamhip_ctx_destroy(ctx);
+  return 0;
+}
