@@ -182,6 +182,7 @@ int slamhip_score_poses_device(slamhip_ctx *ctx, int map_id, const slamhip_spe_c
  * cfg->oope == SLAMHIP_OOPE_GMAPPING: poses are scored as ONE call sequence in the given order. */
 int slamhip_gm_cache_reset(slamhip_ctx *ctx);
 int slamhip_gm_cache_get(slamhip_ctx *ctx, int *cell_xy, double *prob);
+int slamhip_gm_cache_set(slamhip_ctx *ctx, const int *cell_xy, double prob);
 
 /* kernel timing of the scoring launches since the last reset (HIP events on the ctx stream) */
 int slamhip_profile_enable(slamhip_ctx *ctx, int on);

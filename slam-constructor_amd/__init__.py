@@ -32,7 +32,7 @@ EXPORTS = """slamhip_last_error slamhip_device_count slamhip_ctx_create slamhip_
 slamhip_ctx_synchronize slamhip_ctx_stream slamhip_map_bind slamhip_map_upload_window
 slamhip_map_apply_dirty slamhip_map_release slamhip_map_download_window slamhip_scan_upload
 slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_weights
-slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get
+slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get slamhip_gm_cache_set
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_process_scan
@@ -167,6 +167,7 @@ def load():
     L.slamhip_score_poses_device.argtypes = [vp, i, C.POINTER(SpeCfg), i, vp, vp]
     L.slamhip_gm_cache_reset.argtypes = [vp]
     L.slamhip_gm_cache_get.argtypes = [vp, _ip, _dp]
+    L.slamhip_gm_cache_set.argtypes = [vp, _ip, d]
     L.slamhip_profile_enable.argtypes = [vp, i]
     L.slamhip_profile_read.argtypes = [vp, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i]
     L.slamhip_profile_read_map_update.argtypes = [vp, _dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i]
@@ -474,6 +475,10 @@ class Context:
         p = C.c_double()
         _check(self.L.slamhip_gm_cache_get(self.h, xy.ctypes.data_as(_ip), C.byref(p)))
         return int(xy[0]), int(xy[1]), p.value
+
+    def gm_cache_set(self, cx, cy, prob):
+        xy = np.array([cx, cy], np.int32)
+        _check(self.L.slamhip_gm_cache_set(self.h, xy.ctypes.data_as(_ip), float(prob)))
 
     def profile_enable(self, on=True):
         _check(self.L.slamhip_profile_enable(self.h, int(on)))

@@ -1,0 +1,229 @@
+// gm_score_device.h -- the GMapping OOPE on the device, shared by K3 (score_kernels.hip) and the
+// hill-climbing chain (hc_chain.hip): one definition, so a pose scored by either gets the same bits.
+//   GmappingOccupancyObservationPE         src/slams/gmapping/gmapping_occupancy_observation_pe.h:17-38
+//   GmappingBaseCell::discrepancy          src/slams/gmapping/gmapping_grid_cell.h:35-38
+#pragma once
+
+#include "score_device.h"
+
+namespace slamhip {
+
+static constexpr int kGmBlock = 256;  // the canonical layout of run resolution and sum: thread t owns beams t + 256 k
+
+// ---- K3: GMapping OOPE -------------------------------------------------------------------------
+// value of one endpoint: max over the (2w+1)^2 window of cells with prob_occ >= th of
+// exp(-|cell.obst - endpoint|^2 / 0.05); the window order of the reference (dx outer, dy inner)
+// does not matter for a max of finite values.
+// `tiles`: null = dense window (m.pitch); else the tile table of the pose's own copy-on-write map
+// (tile_pool.h): m.payload is then the tile pool and m.width/height the virtual extent.
+// The 3 x 3 window (slam/scmtch/oope/window = 1, every shipped configuration).  A thread's time in K3 is
+// its chain of dependent loads: the generic loop below pays one round trip per window cell (two with a
+// tile table in front), one after the other -- 9 x KB round trips per pose, ~30 of a launch's 37 us.
+// Here the nine cells are fetched whole (32 bytes) with independent loads, behind at most four
+// tile-table entries (the window's corners), and reduced with selects: two round trips per beam.
+// `unk`: the prototype payload in LDS.  Taken from the kernel arguments it lived in scalar registers across
+// the whole kernel, and the compiler parked two of its doubles in SCRATCH (24 bytes per lane written at
+// entry and read back before the gathers: the kernel's only scratch, 1.7 MB of HBM writes per launch).
+__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
+                                                    const GmParams &gp, int cx, int cy, double ox, double oy) {
+  const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+  int t00 = 0, t01 = 0, t10 = 0, t11 = 0, txl = 0, tyl = 0;
+  if (tiles) {
+    const int tiles_y = m.height >> kTileShift;
+    txl = min(max(ix0 - 1, 0) >> kTileShift, m.pitch - 1);
+    tyl = min(max(iy0 - 1, 0) >> kTileShift, tiles_y - 1);
+    const int txh = min(max(ix0 + 1, 0) >> kTileShift, m.pitch - 1);
+    const int tyh = min(max(iy0 + 1, 0) >> kTileShift, tiles_y - 1);
+    t00 = tiles[tyl * m.pitch + txl];
+    t01 = tiles[tyl * m.pitch + txh];
+    t10 = tiles[tyh * m.pitch + txl];
+    t11 = tiles[tyh * m.pitch + txh];
+  }
+  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
+  const double4 unknown = make_double4(unk[0], unk[1], unk[2], 0.0);
+  double4 v[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
+    const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+    size_t at;
+    if (tiles) {
+      const bool lo_x = (ix >> kTileShift) == txl, lo_y = (iy >> kTileShift) == tyl;
+      const int tile = lo_y ? (lo_x ? t00 : t01) : (lo_x ? t10 : t11);
+      at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+    } else {
+      at = (size_t)iy * m.pitch + ix;
+    }
+    v[i] = unknown;
+    if (inb) v[i] = cells[at];
+  }
+  double best_d2 = __builtin_inf();
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double ddx = v[i].y - ox, ddy = v[i].z - oy;
+    const double d2 = ddx * ddx + ddy * ddy;
+    const bool better = !(v[i].x < gp.fullness_th) && d2 < best_d2;
+    best_d2 = better ? d2 : best_d2;
+    any |= better;
+  }
+  if (!any) return 0.0;
+  const double similarity = exp(-best_d2 / 0.05);
+  const double r = 1.0 - (1.0 - similarity);
+  return 0.0 < r ? r : 0.0;
+}
+
+__device__ __forceinline__ double gm_fresh_value(const MapView &m, const double *unk, const int *tiles,
+                                                 const GmParams &gp, int cx, int cy, double ox, double oy) {
+  // The value is the maximum over the window's full cells of 1 - (1 - exp(-d^2 / 0.05)), d = distance
+  // from the cell's obstacle mean to the beam's end point.  That function falls with d^2, so the
+  // maximum belongs to the smallest d^2: the window only tracks that, and ONE exp is evaluated per beam.
+  // (An exp per full cell -- up to nine per beam next to a wall, executed by the whole wave as soon as
+  // one lane needs it -- was 4.5 of the 10 us of this phase in a lone launch.)
+  if (gp.window == 1) return gm_fresh_value_w1(m, unk, tiles, gp, cx, cy, ox, oy);
+  double best_d2 = __builtin_inf();
+  bool any = false;
+  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
+  for (int dx = -gp.window; dx <= gp.window; ++dx) {
+    for (int dy = -gp.window; dy <= gp.window; ++dy) {
+      const int ix = cx + dx + m.origin_x, iy = cy + dy + m.origin_y;
+      const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+      double occ = unk[0], obx = unk[1], oby = unk[2];
+      if (inb) {
+        size_t at;
+        if (tiles) {
+          const int tile = tiles[(iy >> kTileShift) * m.pitch + (ix >> kTileShift)];  // pitch = tiles per row
+          at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+        } else {
+          at = (size_t)iy * m.pitch + ix;
+        }
+        const double4 v = cells[at];
+        occ = v.x; obx = v.y; oby = v.z;
+      }
+      if (occ < gp.fullness_th) continue;
+      const double ddx = obx - ox, ddy = oby - oy;
+      const double d2 = ddx * ddx + ddy * ddy;
+      if (d2 < best_d2) {  // (a NaN obstacle never wins, like `best < v` before)
+        best_d2 = d2;
+        any = true;
+      }
+    }
+  }
+  if (!any) return 0.0;
+  const double similarity = exp(-best_d2 / 0.05);
+  const double v = 1.0 - (1.0 - similarity);
+  return 0.0 < v ? v : 0.0;
+}
+
+// One pose scored by ONE workgroup of NT threads (NT >= 256): phase A (end point, nine gathers, exp) over all
+// threads -- beam b goes to thread b % NT --, run resolution (Q19: every maximal run of equal end cells takes
+// the value of its first beam) and the canonical sum by the first 256 threads.  s_dyn: val[256 KB] | grp_cell
+// int2 [4 KB] | grp_start int [4 KB] | cx, cy int [256 KB]; *s_run0 must hold n (set before a barrier).
+// Thread 0 leaves the score in *score_out (its own copy) and the side outputs of the cross-pose cache in *gi_out.
+// r0 / ca0 / sa0: the constants of beam `threadIdx.x`, loaded by the caller ahead of the pose.
+template <int KB, int NT>
+__device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const ScanView &scan, const GmParams &gm,
+                                                   const int *tiles, const double *s_unknown, double x, double y, double sn,
+                                                   double cs, double r0, double ca0, double sa0, double *s_dyn, int *s_run0,
+                                                   double *s_part1, GmPoseInfo *gi_out, double *score_out) {
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int n = scan.n;
+  const int G = (n + 63) >> 6;
+  double *s_val = s_dyn;
+  int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kGmBlock);
+  int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
+  int *s_cx = s_grp_start + 4 * KB;
+  int *s_cy = s_cx + KB * kGmBlock;
+  int &s_run0_len = *s_run0;
+  const double scale = map.scale, inv_scale = map.inv_scale;
+  // phase A over all threads
+  for (int b = t; b < n; b += NT) {
+    const double r = b == t ? r0 : scan.range[b], ca = b == t ? ca0 : scan.cos_a[b], sa = b == t ? sa0 : scan.sin_a[b];
+    const double c = cs * ca - sn * sa;
+    const double s = sn * ca + cs * sa;
+    const double wx = x + r * c;
+    const double wy = y + r * s;
+    const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
+    s_val[b] = gm_fresh_value(map, s_unknown, tiles, gm, cx, cy, wx, wy);
+    s_cx[b] = cx;
+    s_cy[b] = cy;
+  }
+  __syncthreads();
+  // canonical layout from here on; waves 4..7 only keep the barriers company
+  const bool act = t < kGmBlock;
+  int ccx[KB], ccy[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kGmBlock * k;
+    ccx[k] = 0;
+    ccy[k] = 0;
+    if (act && b < n) {
+      ccx[k] = s_cx[b];
+      ccy[k] = s_cy[b];
+      if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
+    }
+  }
+  __syncthreads();
+  unsigned long long mask[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kGmBlock * k;
+    const int g = 4 * k + wave;
+    int pcx = __shfl_up(ccx[k], 1, 64), pcy = __shfl_up(ccy[k], 1, 64);
+    if (act && lane == 0 && g > 0 && b < n) {
+      const int2 pc = s_grp_cell[g - 1];
+      pcx = pc.x;
+      pcy = pc.y;
+    }
+    const bool start = act && (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
+    mask[k] = __ballot(start);
+    if (act && lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
+    const unsigned long long later = g == 0 ? mask[k] & ~1ull : mask[k];  // see k_score_gmapping
+    if (lane == 0 && later) atomicMin(&s_run0_len, 64 * g + __ffsll((long long)later) - 1);
+  }
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int b = t + kGmBlock * k;
+    if (act && b < n) {
+      const int g = 4 * k + wave;
+      const unsigned long long upto = mask[k] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+      int head;
+      if (upto) {
+        head = 64 * g + 63 - __clzll(upto);
+      } else {
+        int gg = g - 1;
+        head = s_grp_start[gg];
+        while (head < 0) head = s_grp_start[--gg];  // beam 0 is always a start
+      }
+      const double v = s_val[head];
+      const double term = v * scan.weight[b] * scan.factor[b];
+      acc = acc + term;
+      if (b == n - 1 && gi_out) {
+        GmPoseInfo &gi = *gi_out;
+        gi.last_cx = ccx[k];
+        gi.last_cy = ccy[k];
+        gi.last_v = v;
+        gi.last_head = head;
+      }
+      if (b == 0 && gi_out) {
+        GmPoseInfo &gi = *gi_out;
+        gi.first_cx = ccx[k];
+        gi.first_cy = ccy[k];
+        gi.v0 = v;
+      }
+    }
+  }
+  acc = wave_xor_sum(acc);
+  if (act && lane == 0) s_part1[wave] = acc;
+  __syncthreads();
+  if (t == 0) {
+    if (gi_out) gi_out->run0_len = s_run0_len;
+    const double total = (s_part1[0] + s_part1[1]) + (s_part1[2] + s_part1[3]);
+    *score_out = (scan.tot_w == 0.0) ? __builtin_nan("") : total / scan.tot_w;
+  }
+}
+
+}  // namespace slamhip

@@ -107,6 +107,7 @@ struct slamhip_gmapping {
   std::vector<GmParticle> p;  // local shard
   double traversed[3] = {0, 0, 0};
   GmCarry carry;  // the shared OOPE cache as this shard sees it
+  slamhip_matcher *sm = nullptr;  // lone matches of the shared-map mode
   GmCarry step_carry;  // sharded steps: the cache entry the previous step ended with (on every shard)
   std::vector<MatchJob> jobs;
   std::vector<HillClimbingPoseEnumerator> pes;
@@ -300,6 +301,7 @@ int slamhip_gmapping_create(slamhip_ctx *ctx, const slamhip_gmapping_params *prm
 }
 
 int slamhip_gmapping_destroy(slamhip_gmapping *g) {
+  if (g && g->sm) slamhip_matcher_destroy(g->sm);
   if (g && g->tp) tile_pool_destroy(g->tp);
   delete g;
   return SLAMHIP_OK;
@@ -419,21 +421,29 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
         explicit ReuseGuard(slamhip_ctx *cc) : c(cc) { mu_allow_scan_reuse(c, true); }
         ~ReuseGuard() { mu_allow_scan_reuse(c, false); }
       } reuse_guard(ctx);
+      // one matcher object for the lone matches: with device pose trig its accept chain runs on the device
+      // (hc_chain.hip), otherwise through host-driven batches -- the same scorer calls either way
+      if (!g->sm) {
+        rc = slamhip_matcher_create_hc(ctx, &g->cfg, g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
+                                       g->prm.hc_rotation, &g->sm);
+        if (rc) return rc;
+      }
       for (int idx : act_idx) {
         GmParticle &p = g->p[idx];
-        MatchJob &job = g->jobs[idx];
-        g->pes[0] = HillClimbingPoseEnumerator(g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
-                                               g->prm.hc_rotation);
-        job.tree.min_reach = 0.02;
-        job.start(&g->pes[0], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr, g->carry, 0.25);
-        std::vector<MatchJob *> one{&job};
-        rc = run_jobs(g, map_id, one, 126);
+        // the filter's cache is the context's for the duration of the match
+        ctx->gm_cx = g->carry.cx;
+        ctx->gm_cy = g->carry.cy;
+        ctx->gm_prob = g->carry.prob;
+        double dl[3], best_prob = 0.0;
+        rc = slamhip_matcher_process_scan(g->sm, map_id, p.pose, dl, &best_prob);
         if (rc) return rc;
-        g->carry = job.carry;
-        double dl[3];
-        job.delta(dl);
+        g->carry = GmCarry{ctx->gm_cx, ctx->gm_cy, ctx->gm_prob};
+        long long calls = 0, evaluated = 0, launches = 0;
+        slamhip_matcher_stats(g->sm, &calls, &evaluated, &launches);
+        g->poses_evaluated += evaluated;
+        g->launches += launches;
         for (int c = 0; c < 3; ++c) p.pose[c] += dl[c];
-        if (0.0 < job.best_prob || p.scan_is_first) {
+        if (0.0 < best_prob || p.scan_is_first) {
           slamhip_scan_adder_cfg cfg = g->upd;
           cfg.rule = SLAMHIP_RULE_GMAPPING;
           cfg.scan_quality = 1.0;  // scan.quality handed to append_scan (gmapping_world.h:95)
@@ -444,9 +454,9 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
           g->cell_updates += nu;
           p.scan_is_first = 0;
         }
-        p.weight = job.best_prob * p.weight;
+        p.weight = best_prob * p.weight;
         reset_sm_delta(p);
-        g->scorer_calls += job.scorer_calls;
+        g->scorer_calls += calls;
       }
       act_idx.clear();  // everything is applied already: nothing left for match_finish
       return SLAMHIP_OK;

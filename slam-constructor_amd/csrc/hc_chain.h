@@ -67,7 +67,7 @@ HC_HD int hc_bucket_of(double p) { return hc_bucket_of_ratio(p, 1.0); }
 //            score, -1 = the root's
 //   w[9]     bytes: bp_cand, nfail (all-rejected rounds on the path root -> this instance), nfail_parent,
 //            depth (rounds on the path before this one), nseg (accepted moves on the path), is_root,
-//            tail_fail (all-rejected rounds after the last accepted move)
+//            tail_fail (all-rejected rounds after the last accepted move), parent (255 = none)
 //   w[10,11] seg_fail[k]: all-rejected rounds between the previous accepted move and move k (bytes)
 //   w[12,13] seg_out[k]: outcome 1..6 of move k (bytes)
 struct HcInst {
@@ -88,6 +88,7 @@ HC_HD int hc_depth(const HcInst &i) { return hc_byte9(i, 3); }
 HC_HD int hc_nseg(const HcInst &i) { return hc_byte9(i, 4); }
 HC_HD bool hc_is_root(const HcInst &i) { return hc_byte9(i, 5) != 0; }
 HC_HD unsigned hc_tail_fail(const HcInst &i) { return (unsigned)hc_byte9(i, 6); }
+HC_HD int hc_parent(const HcInst &i) { return hc_byte9(i, 7) == 255 ? -1 : hc_byte9(i, 7); }
 HC_HD unsigned hc_seg_fail(const HcInst &i, int k) {
   return (unsigned)(((k < 8 ? i.w[10] : i.w[11]) >> (8 * (k & 7))) & 0xffull);
 }
@@ -131,7 +132,11 @@ struct HcState {
   int first;               // the initial pose has not been scored yet (it rides in slot kHcSlots-1)
   int steps;
   int pad;
+  // GMapping OOPE only: the cache entry the last replayed pose left (gmapping_occupancy_observation_pe.h:43-44)
+  int carry_cx, carry_cy;
+  double carry_prob;
 };
+static_assert(sizeof(HcState) == 120, "HcState layout");
 
 // candidate c (0..5) of a round with base (x, y, theta) and steps dt, dr: +X -Y +Th -X +Y -Th
 // (action id % 3 = axis, id % 2 = sign; frame rotation always 0, Q5), in the reference's operation

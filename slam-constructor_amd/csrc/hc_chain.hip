@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include "gm_score_device.h"
 #include "hc_chain_device.h"
 #include "score_device.h"
 
@@ -43,9 +44,39 @@ __device__ __forceinline__ double bcast(double v, int lane) {
 // word of every lane's record in one bank
 static constexpr int kWalkStride = 17;
 
-template <int MODEL, int NT, bool SEQ>
+// GMapping OOPE in the chain: what the cross-pose cache (Q19) does to a replayed pose's score, and what the
+// pose leaves in it -- MatchJob's gm_apply_carry (matchers.h) for one pose
+struct HcCarry {
+  int cx, cy;
+  double prob;
+};
+__device__ __forceinline__ double hc_gm_fix(double score, HcCarry &cr, const GmPoseInfo &gi, const ScanView &scan) {
+  double last_v = gi.last_v;
+  if (cr.prob != -1.0 && gi.first_cx == cr.cx && gi.first_cy == cr.cy) {
+    const double c = cr.prob;
+    if (c != gi.v0) {
+      double delta = 0.0;
+      for (int b = 0; b < gi.run0_len; ++b)
+        delta += (c * scan.weight[b]) * scan.factor[b] - (gi.v0 * scan.weight[b]) * scan.factor[b];
+      if (scan.tot_w != 0.0) score += delta / scan.tot_w;
+    }
+    if (gi.last_head == 0) last_v = c;
+  }
+  cr.cx = gi.last_cx;
+  cr.cy = gi.last_cy;
+  cr.prob = last_v;
+  return score;
+}
+
+// MODEL: SLAMHIP_CELL_OCC / _TBM = the 1-cell OOPE (k_score_point's arithmetic), SLAMHIP_CELL_GMAPPING = the
+// GMapping OOPE (K3's one-pose body, KB = ceil(beams / 256))
+template <int MODEL, int NT, bool SEQ, int KB>
 __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
-  extern __shared__ double s_term[];            // one term per beam
+  constexpr bool GM = MODEL == SLAMHIP_CELL_GMAPPING;
+  extern __shared__ double s_term[];            // point OOPE: one term per beam; GMapping: K3's arrays
+  __shared__ GmPoseInfo s_info[GM ? kHcSlots : 1];  // side outputs of the previous tree's poses
+  __shared__ double s_unknown[4];
+  __shared__ int s_run0_len;
   __shared__ double s_sc[kHcSlots + 7];         // scores of the previous tree
   __shared__ unsigned long long s_walk[kHcMaxInst * kWalkStride];
   __shared__ HcState s_prev;                    // root state of the previous super-step
@@ -106,7 +137,18 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     for (int q = t; q < kHcMaxInst * 16; q += NT) s_walk[(q >> 4) * kWalkStride + (q & 15)] = wsrc[q];
     if (t < (int)(sizeof(HcState) / 8))
       reinterpret_cast<double *>(&s_prev)[t] = reinterpret_cast<const double *>(&ctl->state[pb])[t];
+    if (GM) {
+      const double *isrc = reinterpret_cast<const double *>(&ctl->infos[pb][0]);
+      double *idst = reinterpret_cast<double *>(&s_info[0]);
+      for (int q = t; q < (int)(kHcSlots * sizeof(GmPoseInfo) / 8); q += NT) idst[q] = isrc[q];
+    }
   }
+  if (GM && t == 64) {
+    s_unknown[0] = a.map.unknown[0];
+    s_unknown[1] = a.map.unknown[1];
+    s_unknown[2] = a.map.unknown[2];
+  }
+  if (GM && t == 65) s_run0_len = a.scan.n;
   if (done_epoch == a.epoch) return;  // launched past the end of the chain (uniform: before any barrier)
   __syncthreads();
   if (stamp) a.stamps[8 * k + 1] = wall_clock64();
@@ -122,6 +164,9 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       st.dr = a.dr0;
       st.shape = a.shape0;
       st.first = 1;
+      st.carry_cx = a.gm_cx;
+      st.carry_cy = a.gm_cy;
+      st.carry_prob = a.gm_prob;
       if (init_slot) {
         if (lane == 0) {
           ctl->state[0] = st;
@@ -137,15 +182,39 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       for (int q = 0; q < 16; ++q) me.w[q] = s_walk[lane * kWalkStride + q];
       if (stamp) a.stamps[8 * k + 6] = wall_clock64();
       const int n_inst = (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
-      const double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
+      double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
+      HcCarry root_carry{sp.carry_cx, sp.carry_cy, sp.carry_prob};
+      if (GM && sp.first) root_prob = hc_gm_fix(s_sc[kHcSlots - 1], root_carry, s_info[kHcSlots - 1], a.scan);
       const bool active = lane < n_inst;
       const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
       const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), a.max_failed);
-      const int bpi = hc_bp_inst(me);
-      const double enter = (!active || bpi < 0) ? root_prob : s_sc[6 * bpi + hc_bp_cand(me)];
       double s6[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) s6[c] = s_sc[6 * lane + c];
+      // GMapping: the cache as this round's candidates meet it, in order -- corrected scores go back to LDS,
+      // where descendants look up the score their path entered with
+      HcCarry carry_after0 = root_carry, carry_after5 = root_carry;
+      bool degenerate = false;
+      if (GM && active) {
+        HcCarry cr = root_carry;
+        const int par = hc_parent(me);
+        if (par >= 0) {
+          // the cache after the parent round's last candidate.  What a pose leaves behind depends on what it
+          // met only when its whole scan is one run (last_head == 0): such a parent is handed to the host
+          const GmPoseInfo &pg = s_info[6 * par + 5];
+          degenerate = pg.last_head == 0;
+          cr = HcCarry{pg.last_cx, pg.last_cy, pg.last_v};
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          s6[c] = hc_gm_fix(s6[c], cr, s_info[6 * lane + c], a.scan);
+          s_sc[6 * lane + c] = s6[c];
+          if (c == 0) carry_after0 = cr;
+        }
+        carry_after5 = cr;
+      }
+      const int bpi = hc_bp_inst(me);
+      const double enter = (!active || bpi < 0) ? root_prob : s_sc[6 * bpi + hc_bp_cand(me)];
       double run;
       int nacc;
       const int out = hc_round_outcome(enter, s6, trailing ? 1 : 6, &run, &nacc);
@@ -187,6 +256,14 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       next.done = bcast_i(next.done, tl);
       next.first = 0;
       next.steps = sp.steps + 1;
+      if (GM) {
+        // the cache after the walk's last scorer call: the terminal round's last candidate
+        const HcCarry fin = trailing ? carry_after0 : carry_after5;
+        next.carry_cx = bcast_i(fin.cx, tl);
+        next.carry_cy = bcast_i(fin.cy, tl);
+        next.carry_prob = bcast(fin.prob, tl);
+        if (__ballot(valid && degenerate) != 0ull && init_slot && lane == 0) a.host->error = 3;
+      }
       if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
         next.done = 1;
         if (init_slot && lane == 0) a.host->error = 1;
@@ -233,6 +310,9 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             h->calls = next.calls;
             h->evaluated = next.evaluated;
             h->steps = next.steps;
+            h->gm_cx = next.carry_cx;
+            h->gm_cy = next.carry_cy;
+            h->gm_prob = next.carry_prob;
             __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           }
         } else if (lane == 0) {
@@ -275,6 +355,19 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   if (!s_go) return;
   const double px = s_pose[0], py = s_pose[1], sn = s_pose[2], cs = s_pose[3];
 
+  if (GM) {
+    // ---- the GMapping OOPE: K3's one-pose body (gm_score_device.h); the side outputs of the cross-pose cache
+    // go next to the score, the replay of the next kernel applies the cache in the reference's call order
+    constexpr int KBG = KB > 0 ? KB : 1;
+    double score = 0.0;
+    gm_score_pose_wide<KBG, NT>(a.map, a.scan, a.gm, nullptr, s_unknown, px, py, sn, cs, br, bc, bs, s_term, &s_run0_len,
+                                s_part, &ctl->infos[k & 1][slot], &score);
+    if (t == 0) {
+      ctl->scores[k & 1][slot] = score;
+      if (stamp) a.stamps[8 * k + 5] = wall_clock64();
+    }
+    return;
+  }
   // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order,
   // wave butterfly, (g0+g1)+(g2+g3)) -- k_score_point's order
   // up to four beams per thread at a time: their cell gathers are issued together (a clamped index keeps the
@@ -351,19 +444,31 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
 #define HC_LAUNCH(NTV)                                                                                          \
   do {                                                                                                          \
     if (e0 || e1)                                                                                               \
-      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ>), dim3(kHcSlots), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
+      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(kHcSlots), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
     else                                                                                                        \
-      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ>), dim3(kHcSlots), dim3(NTV), shm, stream, a, k);      \
+      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(kHcSlots), dim3(NTV), shm, stream, a, k);  \
   } while (0)
 
 template <int MODEL, bool SEQ>
 static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int KB = 0;
   const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
   switch (nt) {
     case 256: HC_LAUNCH(256); break;
     case 1024: HC_LAUNCH(1024); break;
     default: HC_LAUNCH(512); break;
   }
+  return hipGetLastError();
+}
+
+// GMapping OOPE: 512 threads per pose (two workgroups per CU: all slots of a super-step resident at once)
+template <int KB>
+static hipError_t launch_gm(const HcChainArgs &a, int k, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int MODEL = SLAMHIP_CELL_GMAPPING;
+  constexpr bool SEQ = false;
+  const size_t shm = (size_t)KB * 256 * sizeof(double) + 4 * KB * sizeof(int2) + 4 * KB * sizeof(int) +
+                     2 * (size_t)KB * 256 * sizeof(int);
+  HC_LAUNCH(512);
   return hipGetLastError();
 }
 #undef HC_LAUNCH
@@ -376,6 +481,16 @@ hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int
   if (cell_model == SLAMHIP_CELL_TBM)
     return a.seq ? launch_nt<SLAMHIP_CELL_TBM, true>(a, k, nt, stream, e0, e1)
                  : launch_nt<SLAMHIP_CELL_TBM, false>(a, k, nt, stream, e0, e1);
+  if (cell_model == SLAMHIP_CELL_GMAPPING && !a.seq) {
+    switch ((a.scan.n + 255) / 256) {
+      case 1: return launch_gm<1>(a, k, stream, e0, e1);
+      case 2: return launch_gm<2>(a, k, stream, e0, e1);
+      case 3: return launch_gm<3>(a, k, stream, e0, e1);
+      case 4: return launch_gm<4>(a, k, stream, e0, e1);
+      case 5: return launch_gm<5>(a, k, stream, e0, e1);
+      default: break;
+    }
+  }
   return hipErrorInvalidValue;
 }
 

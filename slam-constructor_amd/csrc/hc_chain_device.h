@@ -18,7 +18,10 @@ struct HcHostOut {
   double best_prob;
   long long calls, evaluated;
   int steps;
-  int error;           // 1: replay found no terminal round (bug), 2: trace buffer too small
+  int gm_cx, gm_cy;    // GMapping OOPE: the cache entry after the last scorer call
+  double gm_prob;
+  int error;           // 1: replay found no terminal round (bug), 2: trace buffer too small, 3: a pose whose whole
+                       // scan is one run sat on the path (its cache hand-over needs the sequential replay)
   unsigned progress;   // super-steps started so far in this process_scan
   unsigned done_seq;   // = epoch of the process_scan whose result is above
 };
@@ -28,6 +31,7 @@ struct HcChainCtl {
   HcState state[2];               // root state of super-step k at [k & 1]
   HcInst walk[2][kHcMaxInst];     // the round instances of super-step k's tree, same parity
   double scores[2][kHcSlots + 7];
+  GmPoseInfo infos[2][kHcSlots + 7];  // GMapping OOPE: side outputs of every scored pose
   unsigned done_epoch;            // epoch of the last process_scan that ran to its end
 };
 
@@ -35,6 +39,9 @@ struct HcChainArgs {
   MapView map;
   ScanView scan;
   int oie;
+  GmParams gm;                 // GMapping OOPE (cell model GMAPPING): threshold and window
+  int gm_cx, gm_cy;            // ... and the cache entry the match starts from (-1 = empty)
+  double gm_prob;
   int seq;  // 1: the reference's beam-order sum instead of the canonical tree (SLAMHIP_SUM_SEQUENTIAL)
   HcChainCtl *ctl;
   const HcShape *shapes;  // kHcShapes of them

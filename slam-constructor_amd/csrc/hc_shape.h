@@ -39,6 +39,7 @@ inline void hc_build_shape(double p_accept, double repeat_boost, double min_reac
     std::memset(&in, 0, sizeof(in));
     for (int o = 0; o < 7; ++o) hc_set_child(in, o, -1);
     hc_set_bp_inst(in, -1);
+    hc_set_byte9(in, 7, cd.parent < 0 ? 255u : (unsigned)cd.parent);
     if (cd.parent < 0) {
       hc_set_byte9(in, 5, 1);  // is_root
     } else {

@@ -67,6 +67,8 @@ namespace slamhip {
 
 namespace {
 
+constexpr int kChainNeedsHost = 1;  // internal: positive, never leaves the library
+
 int chain_release(slamhip_matcher *m) {
   if (m->d_chain) hipFree(m->d_chain);
   if (m->d_shapes) hipFree(m->d_shapes);
@@ -86,7 +88,10 @@ int chain_release(slamhip_matcher *m) {
 // staged copies) keeps the host-driven path
 bool chain_eligible(slamhip_matcher *m) {
   if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
-  if (m->cfg.oope != SLAMHIP_OOPE_OBSTACLE || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
+  if ((m->cfg.oope != SLAMHIP_OOPE_OBSTACLE && !gm) || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  // the GMapping OOPE rides K3's one-pose body: 3x3 window, up to 1280 beams, canonical sum
+  if (gm && (m->cfg.gm_window != 1 || m->cfg.sum_order != SLAMHIP_SUM_TREE256 || m->ctx->scan_n > 1280)) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->max_batch < 6 * kHcMaxInst) return false;  // slamhip_matcher_set_batch asked for small batches
   if (m->chain_mode < 0) {
@@ -134,6 +139,11 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
                                 hipHostMallocMapped | hipHostMallocCoherent));
   }
   a.oie = m->cfg.oie;
+  a.gm.fullness_th = m->cfg.gm_fullness_th;
+  a.gm.window = m->cfg.gm_window;
+  a.gm_cx = ctx->gm_cx;
+  a.gm_cy = ctx->gm_cy;
+  a.gm_prob = ctx->gm_prob;
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
@@ -197,6 +207,12 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   if (h->error == 2) {
     set_error("hill-climbing chain: more scorer calls than the trace buffer holds");
     return SLAMHIP_ERR_UNSUPPORTED;
+  }
+  if (h->error == 3) return kChainNeedsHost;  // nothing has been reported or stored yet: the host path redoes the match
+  if (m->cfg.oope == SLAMHIP_OOPE_GMAPPING) {
+    ctx->gm_cx = h->gm_cx;
+    ctx->gm_cy = h->gm_cy;
+    ctx->gm_prob = h->gm_prob;
   }
   MatchJob &job = m->job;
   job.scorer_calls = h->calls;
@@ -344,7 +360,10 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   if (!m || !init_pose || !out_delta || !out_prob) return invalid_arg("null argument");
   slamhip_ctx *ctx = m->ctx;
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
-  if (chain_eligible(m)) return chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
+  if (chain_eligible(m)) {
+    const int crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
+    if (crc != kChainNeedsHost) return crc;
+  }
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   const int budget = m->max_batch > 0 ? m->max_batch : 256;
   int rc = ensure_pose_capacity(ctx, budget + 1);

@@ -39,6 +39,7 @@
 
 #include <algorithm>
 
+#include "gm_score_device.h"
 #include "score_device.h"
 
 namespace slamhip {
@@ -165,111 +166,7 @@ __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int 
   }
 }
 
-// ---- K3: GMapping OOPE -------------------------------------------------------------------------
-// value of one endpoint: max over the (2w+1)^2 window of cells with prob_occ >= th of
-// exp(-|cell.obst - endpoint|^2 / 0.05); the window order of the reference (dx outer, dy inner)
-// does not matter for a max of finite values.
-// `tiles`: null = dense window (m.pitch); else the tile table of the pose's own copy-on-write map
-// (tile_pool.h): m.payload is then the tile pool and m.width/height the virtual extent.
-// The 3 x 3 window (slam/scmtch/oope/window = 1, every shipped configuration).  A thread's time in K3 is
-// its chain of dependent loads: the generic loop below pays one round trip per window cell (two with a
-// tile table in front), one after the other -- 9 x KB round trips per pose, ~30 of a launch's 37 us.
-// Here the nine cells are fetched whole (32 bytes) with independent loads, behind at most four
-// tile-table entries (the window's corners), and reduced with selects: two round trips per beam.
-// `unk`: the prototype payload in LDS.  Taken from the kernel arguments it lived in scalar registers across
-// the whole kernel, and the compiler parked two of its doubles in SCRATCH (24 bytes per lane written at
-// entry and read back before the gathers: the kernel's only scratch, 1.7 MB of HBM writes per launch).
-__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
-                                                    const GmParams &gp, int cx, int cy, double ox, double oy) {
-  const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
-  int t00 = 0, t01 = 0, t10 = 0, t11 = 0, txl = 0, tyl = 0;
-  if (tiles) {
-    const int tiles_y = m.height >> kTileShift;
-    txl = min(max(ix0 - 1, 0) >> kTileShift, m.pitch - 1);
-    tyl = min(max(iy0 - 1, 0) >> kTileShift, tiles_y - 1);
-    const int txh = min(max(ix0 + 1, 0) >> kTileShift, m.pitch - 1);
-    const int tyh = min(max(iy0 + 1, 0) >> kTileShift, tiles_y - 1);
-    t00 = tiles[tyl * m.pitch + txl];
-    t01 = tiles[tyl * m.pitch + txh];
-    t10 = tiles[tyh * m.pitch + txl];
-    t11 = tiles[tyh * m.pitch + txh];
-  }
-  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
-  const double4 unknown = make_double4(unk[0], unk[1], unk[2], 0.0);
-  double4 v[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
-    const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
-    size_t at;
-    if (tiles) {
-      const bool lo_x = (ix >> kTileShift) == txl, lo_y = (iy >> kTileShift) == tyl;
-      const int tile = lo_y ? (lo_x ? t00 : t01) : (lo_x ? t10 : t11);
-      at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
-    } else {
-      at = (size_t)iy * m.pitch + ix;
-    }
-    v[i] = unknown;
-    if (inb) v[i] = cells[at];
-  }
-  double best_d2 = __builtin_inf();
-  bool any = false;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const double ddx = v[i].y - ox, ddy = v[i].z - oy;
-    const double d2 = ddx * ddx + ddy * ddy;
-    const bool better = !(v[i].x < gp.fullness_th) && d2 < best_d2;
-    best_d2 = better ? d2 : best_d2;
-    any |= better;
-  }
-  if (!any) return 0.0;
-  const double similarity = exp(-best_d2 / 0.05);
-  const double r = 1.0 - (1.0 - similarity);
-  return 0.0 < r ? r : 0.0;
-}
-
-__device__ __forceinline__ double gm_fresh_value(const MapView &m, const double *unk, const int *tiles,
-                                                 const GmParams &gp, int cx, int cy, double ox, double oy) {
-  // The value is the maximum over the window's full cells of 1 - (1 - exp(-d^2 / 0.05)), d = distance
-  // from the cell's obstacle mean to the beam's end point.  That function falls with d^2, so the
-  // maximum belongs to the smallest d^2: the window only tracks that, and ONE exp is evaluated per beam.
-  // (An exp per full cell -- up to nine per beam next to a wall, executed by the whole wave as soon as
-  // one lane needs it -- was 4.5 of the 10 us of this phase in a lone launch.)
-  if (gp.window == 1) return gm_fresh_value_w1(m, unk, tiles, gp, cx, cy, ox, oy);
-  double best_d2 = __builtin_inf();
-  bool any = false;
-  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
-  for (int dx = -gp.window; dx <= gp.window; ++dx) {
-    for (int dy = -gp.window; dy <= gp.window; ++dy) {
-      const int ix = cx + dx + m.origin_x, iy = cy + dy + m.origin_y;
-      const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
-      double occ = unk[0], obx = unk[1], oby = unk[2];
-      if (inb) {
-        size_t at;
-        if (tiles) {
-          const int tile = tiles[(iy >> kTileShift) * m.pitch + (ix >> kTileShift)];  // pitch = tiles per row
-          at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
-        } else {
-          at = (size_t)iy * m.pitch + ix;
-        }
-        const double4 v = cells[at];
-        occ = v.x; obx = v.y; oby = v.z;
-      }
-      if (occ < gp.fullness_th) continue;
-      const double ddx = obx - ox, ddy = oby - oy;
-      const double d2 = ddx * ddx + ddy * ddy;
-      if (d2 < best_d2) {  // (a NaN obstacle never wins, like `best < v` before)
-        best_d2 = d2;
-        any = true;
-      }
-    }
-  }
-  if (!any) return 0.0;
-  const double similarity = exp(-best_d2 / 0.05);
-  const double v = 1.0 - (1.0 - similarity);
-  return 0.0 < v ? v : 0.0;
-}
-
+// ---- K3: GMapping OOPE (gm_fresh_value and the one-pose body of the wide kernel: gm_score_device.h) ------
 // Run-cache quirk (Q19): in beam order every maximal run of equal endpoint cells takes the value
 // computed for the run's first beam.  Thread t owns beams t + 256k, so for a fixed k one wave
 // holds 64 CONSECUTIVE beams (group g = 4k + wave): run heads come from a ballot + clz inside
@@ -448,14 +345,7 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
   __shared__ double s_unknown[4];
   __shared__ int s_run0_len;
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
   const int n = a.scan.n;
-  const int G = (n + 63) >> 6;
-  double *s_val = s_dyn;
-  int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kBlock);
-  int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
-  int *s_cx = s_grp_start + 4 * KB;
-  int *s_cy = s_cx + KB * kBlock;
   const int p = blockIdx.x;
   // pose loads (PCIe) first, every thread's first beam right behind them: see k_score_point
   double pose_x = 0.0, pose_y = 0.0, pose_th = 0.0, pose_sn = 0.0, pose_cs = 0.0;
@@ -484,96 +374,11 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
     s_run0_len = n;
   }
   __syncthreads();
-  const double x = s_pose1[0], y = s_pose1[1], sn = s_pose1[2], cs = s_pose1[3];
-  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   const int *tiles = a.tables ? a.tables + (size_t)a.pose_slot[p] * a.table_stride : nullptr;
-  // phase A over all threads
-  for (int b = t; b < n; b += NT) {
-    const double r = b == t ? r0 : a.scan.range[b], ca = b == t ? ca0 : a.scan.cos_a[b], sa = b == t ? sa0 : a.scan.sin_a[b];
-    const double c = cs * ca - sn * sa;
-    const double s = sn * ca + cs * sa;
-    const double wx = x + r * c;
-    const double wy = y + r * s;
-    const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
-    s_val[b] = gm_fresh_value(a.map, s_unknown, tiles, a.gm, cx, cy, wx, wy);
-    s_cx[b] = cx;
-    s_cy[b] = cy;
-  }
-  __syncthreads();
-  // canonical layout from here on; waves 4..7 only keep the barriers company
-  const bool act = t < kBlock;
-  int ccx[KB], ccy[KB];
-#pragma unroll
-  for (int k = 0; k < KB; ++k) {
-    const int b = t + kBlock * k;
-    ccx[k] = 0;
-    ccy[k] = 0;
-    if (act && b < n) {
-      ccx[k] = s_cx[b];
-      ccy[k] = s_cy[b];
-      if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
-    }
-  }
-  __syncthreads();
-  unsigned long long mask[KB];
-#pragma unroll
-  for (int k = 0; k < KB; ++k) {
-    const int b = t + kBlock * k;
-    const int g = 4 * k + wave;
-    int pcx = __shfl_up(ccx[k], 1, 64), pcy = __shfl_up(ccy[k], 1, 64);
-    if (act && lane == 0 && g > 0 && b < n) {
-      const int2 pc = s_grp_cell[g - 1];
-      pcx = pc.x;
-      pcy = pc.y;
-    }
-    const bool start = act && (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
-    mask[k] = __ballot(start);
-    if (act && lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
-    const unsigned long long later = g == 0 ? mask[k] & ~1ull : mask[k];  // see k_score_gmapping
-    if (lane == 0 && later) atomicMin(&s_run0_len, 64 * g + __ffsll((long long)later) - 1);
-  }
-  __syncthreads();
-  double acc = 0.0;
-#pragma unroll
-  for (int k = 0; k < KB; ++k) {
-    const int b = t + kBlock * k;
-    if (act && b < n) {
-      const int g = 4 * k + wave;
-      const unsigned long long upto = mask[k] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-      int head;
-      if (upto) {
-        head = 64 * g + 63 - __clzll(upto);
-      } else {
-        int gg = g - 1;
-        head = s_grp_start[gg];
-        while (head < 0) head = s_grp_start[--gg];  // beam 0 is always a start
-      }
-      const double v = s_val[head];
-      const double term = v * a.scan.weight[b] * a.scan.factor[b];
-      acc = acc + term;
-      if (b == n - 1 && a.gm_info) {
-        GmPoseInfo &gi = a.gm_info[p];
-        gi.last_cx = ccx[k];
-        gi.last_cy = ccy[k];
-        gi.last_v = v;
-        gi.last_head = head;
-      }
-      if (b == 0 && a.gm_info) {
-        GmPoseInfo &gi = a.gm_info[p];
-        gi.first_cx = ccx[k];
-        gi.first_cy = ccy[k];
-        gi.v0 = v;
-      }
-    }
-  }
-  acc = wave_xor_sum(acc);
-  if (act && lane == 0) s_part1[wave] = acc;
-  __syncthreads();
-  if (t == 0) {
-    if (a.gm_info) a.gm_info[p].run0_len = s_run0_len;
-    const double total = (s_part1[0] + s_part1[1]) + (s_part1[2] + s_part1[3]);
-    a.scores[p] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
-  }
+  double score;
+  gm_score_pose_wide<KB, NT>(a.map, a.scan, a.gm, tiles, s_unknown, s_pose1[0], s_pose1[1], s_pose1[2], s_pose1[3], r0, ca0,
+                             sa0, s_dyn, &s_run0_len, s_part1, a.gm_info ? a.gm_info + p : nullptr, &score);
+  if (t == 0) a.scores[p] = score;
 }
 
 // ---- K2: window OOPEs (max / mean / overlap) ------------------------------------------------------

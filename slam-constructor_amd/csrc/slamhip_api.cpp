@@ -846,6 +846,14 @@ int slamhip_gm_cache_get(slamhip_ctx *ctx, int *cell_xy, double *prob) {
   return SLAMHIP_OK;
 }
 
+int slamhip_gm_cache_set(slamhip_ctx *ctx, const int *cell_xy, double prob) {
+  if (!ctx || !cell_xy) return invalid("bad arguments");
+  ctx->gm_cx = cell_xy[0];
+  ctx->gm_cy = cell_xy[1];
+  ctx->gm_prob = prob;
+  return SLAMHIP_OK;
+}
+
 int slamhip_profile_enable(slamhip_ctx *ctx, int on) {
   if (!ctx) return invalid("null ctx");
   ctx->profile = on != 0;

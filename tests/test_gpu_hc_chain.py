@@ -147,3 +147,38 @@ def test_fuzz_default_and_sequential_sum_modes_against_strict_mode(pkg, ctx):
     assert matches == 200 and calls > 200 * 40
     assert div_seq == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div_seq, matches)
     assert div_tree <= 10, "%d of %d default-mode matches diverged at tied comparisons" % (div_tree, matches)
+
+
+def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
+    """The GMapping OOPE on the device chain: K3's one-pose body scores the speculation tree, the replay applies
+    the reference's cross-pose cache (gmapping_occupancy_observation_pe.h:21-24,36-37,43-44) in call
+    order.  Trace, result and the cache left behind must equal the host-driven matcher's bit for bit -- over
+    consecutive matches (the cache is carried from one process_scan into the next)."""
+    from synth import CELL_GMAPPING
+    for n_beams, seed in ((360, 5), (1080, 6), (3, 7), (1, 8)):
+        sc = make_scene(cell_model=CELL_GMAPPING, size=600, scale=0.05, n_beams=max(n_beams, 16), seed=seed)
+        s = sc["scan"]
+        if n_beams < 16:  # very short scans: runs that span the whole scan (the degenerate cache hand-over)
+            keep = np.arange(n_beams) * 3
+            s.range, s.angle, s.weight, s.factor = s.range[keep], s.angle[keep], np.full(n_beams, 1.0 / n_beams), s.factor[keep]
+        upload(pkg, ctx, sc)
+        cfg = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING)
+        for prm in ([6, 0.1, 0.1], [40, 0.1, 0.1]):
+            dev = pkg.Matcher(ctx, "HC", cfg, prm)
+            dev.set_device_chain(1)
+            host = pkg.Matcher(ctx, "HC", cfg, prm)
+            host.set_device_chain(0)
+            init = sc["init_pose"]
+            cache_d = cache_h = None
+            for rep in range(4):
+                ctx.gm_cache_reset() if rep == 0 else ctx.gm_cache_set(*cache_d)
+                td = dev.process_scan(0, init, trace=True)
+                cache_d = ctx.gm_cache_get()
+                ctx.gm_cache_reset() if rep == 0 else ctx.gm_cache_set(*cache_h)
+                th = host.process_scan(0, init, trace=True)
+                cache_h = ctx.gm_cache_get()
+                assert_trace_equal(td, th)
+                assert cache_d == cache_h
+                init = init + np.array([0.011, -0.006, 0.003])
+            if n_beams >= 16:
+                assert dev.stats()["launches"] < host.stats()["launches"] or prm[0] == 6
