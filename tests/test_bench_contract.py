@@ -1,6 +1,8 @@
 """bench.py's output contract, checked on the lines committed under profiles/ (produced on the GPU box
 by tools/profile.sh): one JSON object with the driver's keys, BASELINE.json's metric, the `roofline`
-and `cpu_baseline` objects, null vs_baseline, no model keys."""
+and `cpu_baseline` objects, null vs_baseline, no model keys; and the rocprofv3 summary of the same
+command must agree with the kernel time the line was computed from."""
+import csv
 import glob
 import json
 import os
@@ -8,12 +10,14 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hc_bench_unprofiled.json")))
+# the driver's command (`python bench.py`: every leg, CPU baselines) and the headline alone (`--legs none`)
+DEFAULT = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_default_bench_unprofiled.json")))
+HEADLINE = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hc_bench_unprofiled.json")))
 
 
-@pytest.mark.skipif(not LINES, reason="no committed bench line yet")
-def test_headline_bench_line_contract():
-    d = json.load(open(LINES[-1]))
+@pytest.mark.skipif(not DEFAULT, reason="no committed bench line yet")
+def test_default_bench_line_contract():
+    d = json.load(open(DEFAULT[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -36,19 +40,30 @@ def test_headline_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == d["unit"]
+    assert c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"]
     pf = d["particle_filter"]
     assert pf["unit"] == "particles/s" and pf["scaling"] == "strong" and pf["roofline"]["kernel"] == "k_score_gmapping"
+    assert pf["cpu_baseline"]["kind"] == "reference" and "4000x4000" in pf["cpu_baseline"]["sample"]
+    for leg in ("with_map_update", "with_particle_maps"):
+        k6 = pf[leg]["roofline_map_update"]
+        assert k6["bytes_per_unit"] == 64 and abs(k6["frac"] - k6["achieved"] / 8000.0) < 1e-12
+    c5 = d["cfg5"]
+    assert "8000x8000" in c5["workload"] and "500 particles" in c5["workload"] and c5["unit"] == "particles/s"
+    assert c5["roofline"]["bytes_per_unit"] == 64 and c5["roofline"]["units_launched"] > 1e8
 
 
-@pytest.mark.skipif(not LINES, reason="no committed bench line yet")
+@pytest.mark.skipif(not HEADLINE, reason="no committed bench line yet")
 def test_rocprof_summary_agrees_with_the_live_kernel_time():
-    """The committed rocprofv3 --kernel-trace --stats average of k_score_point and the HIP-event average of
+    """The committed rocprofv3 --kernel-trace --stats average of the headline's kernel and the HIP-event average of
     the un-profiled run of the same command must agree (within 15 %)."""
-    import csv
-    tag = os.path.basename(LINES[-1]).split("_")[0]
-    d = json.load(open(LINES[-1]))
+    tag = os.path.basename(HEADLINE[-1]).split("_")[0]
+    d = json.load(open(HEADLINE[-1]))
+    kernel = d["roofline"]["kernel"]
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_hc_kernel_stats.csv" % tag))))
-    prof = [float(r["AverageNs"]) / 1e3 for r in rows if "k_score_point" in r["Name"]]
-    assert prof
+    prof = [float(r["AverageNs"]) / 1e3 for r in rows if kernel in r["Name"]]
+    assert prof, kernel
     live = d["roofline"]["avg_launch_us"]
     assert abs(live - prof[0]) <= 0.15 * prof[0], (live, prof)
+    # and the roofline_valu object is there, from the PMC passes of the same tag
+    v = d["roofline_valu"]
+    assert v["bound"] == "valu" and 0.0 < v["valu_issue_frac"] < 1.0 and v["hbm_utilisation"] < 0.5

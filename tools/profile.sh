@@ -1,21 +1,19 @@
 #!/bin/bash
-# tools/profile.sh <round-tag> -- run on the GPU box (gpurun): rocprofv3 kernel-trace + stats of the
-# default bench command (hc), of the sweep and of mc, then PMC passes for hc and sweep (FETCH_SIZE /
-# WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes; never mixed with trace domains
-# other than --kernel-trace).  Output: gpurun_out/<tag>/; tools/summarize_profiles.py <tag> then
-# copies the summaries into profiles/.
+# tools/profile.sh <round-tag> -- run on the GPU box (gpurun).  One rocprofv3 --kernel-trace --stats run PER LEG of
+# bench.py (so that every kernel's time can be re-derived from profiles/ alone), the same commands without the
+# profiler (HIP-event kernel times to compare with), and PMC passes -- FETCH_SIZE / WRITE_SIZE / SQ counters, each
+# in its own pass with --kernel-trace only, as MI355X_MICROARCH.md prescribes.  Output: gpurun_out/<tag>/;
+# tools/summarize_profiles.py <tag> then copies the summaries into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-run() { # name, extra bench args...
+run() { # name, bench args...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $ROOT/bench.py "$@" > $OUT/$name.bench.log 2>&1
   grep '^{"metric' $OUT/$name.bench.log | tail -1 > $OUT/$name.bench.json
-  # the same command without the profiler: under rocprofv3 the HIP events attached to a dispatch read
-  # ~8 us long (17 vs 9 us), so the live kernel time to compare with the trace is the un-profiled one
   python3 $ROOT/bench.py "$@" 2> /dev/null | grep '^{"metric' | tail -1 > $OUT/$name.plain.json
 }
 pmc() { # workload-name, pass-name, counters..., then "--", bench args
@@ -25,13 +23,28 @@ pmc() { # workload-name, pass-name, counters..., then "--", bench args
   shift
   rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $OUT/pmc_${wl}_$pass -o pmc -- python3 $ROOT/bench.py "$@" > $OUT/pmc_${wl}_$pass.log 2>&1
 }
-run hc --steps 50 --warmup 5 --cpu-seconds 6
-run sweep --workload sweep --steps 200 --warmup 10 --no-cpu
-run mc --workload mc --steps 20 --warmup 3 --no-cpu
+# 1. PMC passes first: their summary (HBM bytes and VALU instructions per launch) is what the bench lines of
+#    step 2 quote as roofline.traffic / roofline_valu, so it has to exist -- in THIS copy of the repo -- before them
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 for c in FETCH_SIZE WRITE_SIZE; do
+  pmc hc $c $c -- --legs none --steps 10 --warmup 2 --no-cpu
   pmc sweep $c $c -- --workload sweep --steps 20 --warmup 2 --no-cpu
-  pmc hc $c $c -- --steps 10 --warmup 2 --no-cpu --no-pf
-  pmc pf $c $c -- --steps 5 --warmup 1 --no-cpu --pf-steps 4   # k_score_gmapping of the particle-filter leg
+  pmc mc $c $c -- --workload mc --legs none --steps 5 --warmup 1 --no-cpu
+  pmc pf $c $c -- --legs pf --steps 3 --warmup 1 --no-cpu --pf-steps 4
 done
-pmc sweep sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -- --workload sweep --steps 20 --warmup 2 --no-cpu
-find $OUT -name "*.csv" | head -60
+pmc hc sq $SQ -- --legs none --steps 10 --warmup 2 --no-cpu
+pmc sweep sq $SQ -- --workload sweep --steps 20 --warmup 2 --no-cpu
+pmc mc sq $SQ -- --workload mc --legs none --steps 5 --warmup 1 --no-cpu
+pmc pf sq $SQ -- --legs pf --steps 3 --warmup 1 --no-cpu --pf-steps 4
+python3 $ROOT/tools/summarize_profiles.py $TAG > /dev/null 2>&1   # writes profiles/${TAG}_traffic.json here
+# 2. kernel traces and the un-profiled lines
+# the driver's command (all legs, CPU baselines): un-profiled only -- this is the line BENCH_rNN will hold
+python3 $ROOT/bench.py 2> $OUT/default.err | grep '^{"metric' | tail -1 > $OUT/default.plain.json
+run hc --legs none --steps 50 --warmup 5 --no-cpu
+run sweep --workload sweep --steps 200 --warmup 10 --no-cpu
+run mc --workload mc --legs none --steps 20 --warmup 3 --no-cpu
+run pf --legs pf --steps 3 --warmup 1 --no-cpu
+run pf_update --legs pf_update --steps 3 --warmup 1 --no-cpu
+run pf_maps --legs pf_maps --steps 3 --warmup 1 --no-cpu
+run cfg5 --legs cfg5 --steps 3 --warmup 1 --no-cpu
+ls $OUT | head -80
