@@ -229,8 +229,12 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
  * accept chain on the device: one process_scan = a chain of kernels with no host in between, each
  * replaying the previous one's speculation tree (csrc/hc_chain.h).  mode: 1 on (default), 0 = the
  * host-driven speculative batches every other configuration uses; threads: workgroup size 256 / 512 /
- * 1024, 0 = default.  Results are identical either way (same scores bit for bit, same observer
- * sequence). */
+ * 1024, 0 = default.  Scores are the same bit for bit either way.  On the device the default mode is CHECKED:
+ * a `best < candidate` between canonical tree sums that differ by less than the two orders of summation can
+ * (and whose beam terms are not identical) is decided again from the reference's beam-order sums, so the
+ * accept chain is the one the beam-order sum would give -- the host-driven default mode decides such ties
+ * from the tree sums as they are; mode 2 = the device chain without the check (the host-driven default mode's
+ * decisions exactly, for comparisons). */
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],
@@ -239,6 +243,11 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
  * (= on_scan_test events), poses actually evaluated on the GPU, launches */
 int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long *poses_evaluated,
                           long long *launches);
+
+/* device chain only (zeros otherwise), last process_scan: kernels launched (super-steps + run-ahead launches that
+ * found the chain finished) and super-steps the checked default mode scored a second time in beam order because
+ * a comparison on the path was too close for the canonical tree sum to settle */
+int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched, long long *steps_rescored);
 
 /* host-side time split of the last process_scan in microseconds: building the speculation DAG,
  * staging poses, launch + wait for scores, replay of the accept chain */

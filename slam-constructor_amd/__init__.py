@@ -36,7 +36,7 @@ slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_process_scan
-slamhip_matcher_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
+slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
@@ -182,6 +182,7 @@ def load():
     L.slamhip_matcher_process_scan.argtypes = [vp, i, _dp, _dp, _dp]
     L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
     L.slamhip_matcher_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
+    L.slamhip_matcher_chain_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.slamhip_pf_normalize.argtypes = [i, _dp]
     L.slamhip_pf_resampling_is_required.argtypes = [i, _dp, _ip]
     L.slamhip_pf_resample.argtypes = [i, _dp, C.c_uint32, C.POINTER(C.c_uint)]
@@ -540,7 +541,8 @@ class Matcher:
         _check(self.L.slamhip_matcher_set_batch(self.h, n))
 
     def set_device_chain(self, mode, threads=0):
-        """Hill climbing on the device (1) or through host-driven speculative batches (0)."""
+        """Hill climbing on the device with checked ties (1), on the device without the check (2), or through
+        host-driven speculative batches (0)."""
         _check(self.L.slamhip_matcher_set_device_chain(self.h, int(mode), int(threads)))
 
     def process_scan(self, map_id, init_pose, trace=False):
@@ -577,8 +579,10 @@ class Matcher:
         _check(self.L.slamhip_matcher_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         t = [C.c_double() for _ in range(4)]
         _check(self.L.slamhip_matcher_timing(self.h, *[C.byref(x) for x in t]))
+        kl, rs = C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_matcher_chain_stats(self.h, C.byref(kl), C.byref(rs)))
         return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value,
-                    build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
+                    kernels_launched=kl.value, steps_rescored=rs.value, build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
                     replay_us=t[3].value)
 
 

@@ -131,12 +131,15 @@ struct HcState {
   int done;                // the enumerator has no next candidate
   int first;               // the initial pose has not been scored yet (it rides in slot kHcSlots-1)
   int steps;
-  int pad;
+  int mode;                // 1: this super-step's tree is scored in beam order too and decided from those sums
+                           // (the previous replay met an ambiguous comparison); slot kHcSlots-1 then re-scores the base
   // GMapping OOPE only: the cache entry the last replayed pose left (gmapping_occupancy_observation_pe.h:43-44)
   int carry_cx, carry_cy;
   double carry_prob;
+  unsigned long long best_hash;  // term-vector hash of the best pose (checked default mode)
+  long long rescored;            // super-steps scored twice so far
 };
-static_assert(sizeof(HcState) == 120, "HcState layout");
+static_assert(sizeof(HcState) == 136, "HcState layout");
 
 // candidate c (0..5) of a round with base (x, y, theta) and steps dt, dr: +X -Y +Th -X +Y -Th
 // (action id % 3 = axis, id % 2 = sign; frame rotation always 0, Q5), in the reference's operation
@@ -210,6 +213,45 @@ HC_HD int hc_round_outcome(double enter, const double *s, int n, double *run, in
   return out;
 }
 
+// The same with the decision checked (default mode on the device): `dec` are the scores the comparisons use
+// (canonical tree sums, or -- in a re-scored super-step -- the reference's beam-order sums), `hash` identifies a
+// pose's vector of beam terms.  A comparison of two tree sums decides like the reference's beam-order sums
+// whenever they differ by more than the two orders of summation can (|tree - sequential| <= (n - 1) u sum|t|:
+// 2^-40 relative leaves a factor of three for n = 2048) or the term vectors are identical (equal sums in any
+// order: a tie, i.e. a rejection, in both).  Anything else is AMBIGUOUS: the super-step is scored again in
+// beam order and decided from that.
+struct HcDecision {
+  int out, nacc, last_acc;  // outcome, acceptances, candidate accepted last (-1: none)
+  unsigned accmask;         // bit c: candidate c was accepted
+  bool ambiguous;
+};
+// one comparison of the chain: candidate c with decision score s and term-vector hash h against the running best
+// (b, hb), which it replaces when accepted
+HC_HD void hc_decide_one(HcDecision &d, double &b, unsigned long long &hb, int c, double s, unsigned long long h,
+                         bool check) {
+  if (check && h != hb) {
+    const double diff = s > b ? s - b : b - s;
+    const double as = s < 0 ? -s : s, ab = b < 0 ? -b : b;
+    if (diff <= (as > ab ? as : ab) * 9.094947017729282e-13) d.ambiguous = true;  // 2^-40 (NaN: a rejection)
+  }
+  if (b < s) {  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
+    b = s;
+    hb = h;
+    d.out = c + 1;
+    d.last_acc = c;
+    d.accmask |= 1u << c;
+    ++d.nacc;
+  }
+}
+HC_HD HcDecision hc_round_decide(double enter, unsigned long long enter_hash, const double *dec,
+                                 const unsigned long long *hash, int n, bool check) {
+  HcDecision d{0, 0, -1, 0u, false};
+  double b = enter;
+  unsigned long long hb = enter_hash;
+  for (int c = 0; c < n; ++c) hc_decide_one(d, b, hb, c, dec[c], hash[c], check);
+  return d;
+}
+
 // the root state of the next super-step, from the instance the walk ended in (`in`, its round state `r`),
 // its outcome and best score.  done: the chain is over.
 HC_HD void hc_advance(const HcState &prev, const HcInst &in, const HcRound &r, int out, double run, unsigned max_failed,
@@ -232,6 +274,7 @@ HC_HD void hc_advance(const HcState &prev, const HcInst &in, const HcRound &r, i
   n.calls = prev.calls + (prev.first ? 1 : 0) + batch_calls;
   n.evaluated = prev.evaluated + evaluated;
   n.first = 0;
+  n.mode = 0;
   n.steps = prev.steps + 1;
   // acceptance-rate estimate for the next tree, exponentially forgetting (MatchJob::consume)
   n.recent_acc = 0.5 * prev.recent_acc + (double)batch_acc;

@@ -75,6 +75,8 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   constexpr bool GM = MODEL == SLAMHIP_CELL_GMAPPING;
   extern __shared__ double s_term[];            // point OOPE: one term per beam; GMapping: K3's arrays
   __shared__ GmPoseInfo s_info[GM ? kHcSlots : 1];  // side outputs of the previous tree's poses
+  __shared__ unsigned s_hash[GM ? 1 : kHcSlots + 7];  // term-vector fingerprints of the previous tree's poses
+  __shared__ unsigned long long s_hpart[4];
   __shared__ double s_unknown[4];
   __shared__ int s_run0_len;
   __shared__ double s_sc[kHcSlots + 7];         // scores of the previous tree
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   __shared__ HcState s_prev;                    // root state of the previous super-step
   __shared__ HcInst s_mine[kHcShapes];          // this workgroup's round instance in every shape
   __shared__ double s_pose[4];                  // x, y, sin, cos of the pose this workgroup scores
-  __shared__ int s_go;
+  __shared__ int s_go, s_mode;
   __shared__ double s_part[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int slot = blockIdx.x;
@@ -137,6 +139,9 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     for (int q = t; q < kHcMaxInst * 16; q += NT) s_walk[(q >> 4) * kWalkStride + (q & 15)] = wsrc[q];
     if (t < (int)(sizeof(HcState) / 8))
       reinterpret_cast<double *>(&s_prev)[t] = reinterpret_cast<const double *>(&ctl->state[pb])[t];
+    if (!GM && a.verify) {
+      for (int i = t; i < kHcSlots; i += NT) s_hash[i] = (unsigned)ctl->hashes[pb][i];
+    }
     if (GM) {
       const double *isrc = reinterpret_cast<const double *>(&ctl->infos[pb][0]);
       double *idst = reinterpret_cast<double *>(&s_info[0]);
@@ -214,10 +219,68 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         carry_after5 = cr;
       }
       const int bpi = hc_bp_inst(me);
-      const double enter = (!active || bpi < 0) ? root_prob : s_sc[6 * bpi + hc_bp_cand(me)];
-      double run;
-      int nacc;
-      const int out = hc_round_outcome(enter, s6, trailing ? 1 : 6, &run, &nacc);
+      const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
+      const double enter = bp_slot < 0 ? root_prob : s_sc[bp_slot];  // canonical (reported) score entering the round
+      double run = enter;
+      int nacc = 0, out = 0;
+      unsigned accmask = 0u;
+      bool ambiguous = false;
+      unsigned run_hash = 0u;
+      const bool rescored = !GM && a.verify && sp.mode == 1;  // decisions from the beam-order sums of this tree
+      if (!GM && a.verify) {
+        // slot kHcSlots-1 holds the base pose of a re-scored tree (or the initial pose): its sums head the path
+        const bool base_here = sp.first || sp.mode == 1;
+        const unsigned root_hash = base_here ? s_hash[kHcSlots - 1] : (unsigned)sp.best_hash;
+        unsigned hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
+        unsigned h6[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) h6[c] = s_hash[6 * lane + c];
+        if (!rescored) {
+          // decisions from the canonical sums; a comparison closer than the two summation orders can differ
+          // (2^-40, relative) between poses whose term vectors differ is one the tree sum cannot settle
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double s = s6[c];
+            const double diff = __builtin_fabs(s - run);
+            const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
+            const bool live = c == 0 || !trailing;
+            const bool close = diff <= (as > ab ? as : ab) * 9.094947017729282e-13;  // NaN: false, a rejection
+            ambiguous = ambiguous || (live && close && h6[c] != hb);
+            const bool acc = live && run < s;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
+            run = acc ? s : run;
+            hb = acc ? h6[c] : hb;
+            out = acc ? c + 1 : out;
+            nacc += acc ? 1 : 0;
+            accmask |= acc ? 1u << c : 0u;
+          }
+        } else {
+          // re-scored tree: the same comparisons on the beam-order sums (read where they lie: this is the rare step)
+          const double *seq = ctl->scores_seq[pb];
+          const double root_dec = seq[kHcSlots - 1];
+          double bdec = bp_slot < 0 ? root_dec : seq[bp_slot];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double sd = active ? seq[6 * lane + c] : 0.0;
+            const bool acc = (c == 0 || !trailing) && bdec < sd;
+            bdec = acc ? sd : bdec;
+            run = acc ? s6[c] : run;  // the canonical sum of the pose accepted last: stored and reported
+            hb = acc ? h6[c] : hb;
+            out = acc ? c + 1 : out;
+            nacc += acc ? 1 : 0;
+            accmask |= acc ? 1u << c : 0u;
+          }
+        }
+        run_hash = hb;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections
+            run = s6[c];
+            out = c + 1;
+            ++nacc;
+            accmask |= 1u << c;
+          }
+      }
       bool valid = reach;
 #pragma unroll
       for (int o = 0; o < 7; ++o) {
@@ -233,8 +296,11 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
 #pragma unroll
       for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
       if (stamp) a.stamps[8 * k + 7] = wall_clock64();
+      // checked default mode: a comparison on the walked path that the tree sum cannot settle -> the same tree is
+      // scored once more, in beam order as well, and decided from those sums
+      const bool dirty = !GM && a.verify && sp.mode == 0 && __ballot(valid && ambiguous) != 0ull;
       HcState next = sp;
-      if (terminal) {
+      if (terminal && !dirty) {
         const HcRound r = hc_round_of(sp, me);
         const long long batch_calls = 6ll * hc_depth(me) + (trailing ? 1 : 6);
         hc_advance(sp, me, r, out, run, a.max_failed, batch_calls, batch_acc,
@@ -256,6 +322,18 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       next.done = bcast_i(next.done, tl);
       next.first = 0;
       next.steps = sp.steps + 1;
+      if (!GM && a.verify) {
+        next.best_hash = (unsigned)bcast_i((int)run_hash, tl);
+        next.mode = 0;
+        next.rescored = sp.rescored;
+      }
+      if (dirty) {
+        next = sp;  // same root, same tree, same `first`
+        next.mode = 1;
+        next.steps = sp.steps + 1;
+        next.evaluated = sp.evaluated + 6ll * n_inst + 1;
+        next.rescored = sp.rescored + 1;
+      }
       if (GM) {
         // the cache after the walk's last scorer call: the terminal round's last candidate
         const HcCarry fin = trailing ? carry_after0 : carry_after5;
@@ -272,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       if (init_slot) {
         // ---- the last workgroup keeps the books (it scores nothing after the first super-step, so the
         // dependent loads and stores below are on no pose's critical path)
-        if (a.trace) {
+        if (a.trace && !dirty) {
           const long long base = sp.calls + (sp.first ? 1 : 0);
           if (sp.first && lane == 0 && a.trace_cap > 0) {
             HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};
@@ -280,15 +358,13 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
           }
           if (valid) {
             const HcRound r = hc_round_of(sp, me);
-            double b = enter;
             const int nc = trailing ? 1 : 6;
             for (int c = 0; c < nc; ++c) {
               HcTraceEntry e;
               hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, c, &e.x, &e.y, &e.theta);
               e.score = s_sc[6 * lane + c];
-              e.accepted = b < e.score ? 1 : 0;
+              e.accepted = (accmask >> c) & 1u;
               e.pad = 0;
-              if (e.accepted) b = e.score;
               const long long at = base + 6ll * hc_depth(me) + c;
               if (at < a.trace_cap) a.trace[at] = e;
               else a.host->error = 2;
@@ -310,6 +386,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             h->calls = next.calls;
             h->evaluated = next.evaluated;
             h->steps = next.steps;
+            h->rescored = next.rescored;
             h->gm_cx = next.carry_cx;
             h->gm_cy = next.carry_cy;
             h->gm_prob = next.carry_prob;
@@ -325,7 +402,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     bool go = !st.done;
     double px = st.x, py = st.y, pth = st.theta;
     if (init_slot) {
-      go = go && st.first;
+      go = go && (st.first || st.mode == 1);  // the initial pose / the base pose of a re-scored tree
     } else if (go) {
       HcInst in;
 #pragma unroll
@@ -348,7 +425,10 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         s_pose[3] = cs;
       }
     }
-    if (lane == 0) s_go = go ? 1 : 0;
+    if (lane == 0) {
+      s_go = go ? 1 : 0;
+      s_mode = st.mode;
+    }
   }
   __syncthreads();
   if (stamp) a.stamps[8 * k + 3] = wall_clock64();
@@ -425,17 +505,52 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     }
     return;
   }
+  const bool verify = !GM && a.verify;
   if (t < kSumLanes) {
     double acc = 0.0;
-    for (int b = t; b < n; b += kSumLanes) acc = acc + s_term[b];
-    acc = wave_xor_sum(acc);
-    if (lane == 0) s_part[wave] = acc;
+    // position-sensitive fingerprint of the term vector: a multilinear form of its 32-bit halves with odd
+    // per-beam multipliers, in integer arithmetic (any order of adding it up gives the same value)
+    unsigned long long h = 0ull;
+    unsigned k_lo = (2u * (unsigned)t + 1u) * 0x9E3779B1u, k_hi = (2u * (unsigned)t + 1u) * 0x85EBCA6Bu;
+    for (int b = t; b < n; b += kSumLanes) {
+      const double term = s_term[b];
+      acc = acc + term;
+      if (verify) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(term);
+        h += (unsigned long long)(unsigned)bits * k_lo + (unsigned long long)(unsigned)(bits >> 32) * k_hi;
+        k_lo += 2u * kSumLanes * 0x9E3779B1u;
+        k_hi += 2u * kSumLanes * 0x85EBCA6Bu;
+      }
+    }
+    // the fixed butterfly of wave_xor_sum, with the fingerprint's exchanges riding along (one LDS-crossbar latency
+    // per step for both)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(acc, off, 64);
+      const unsigned ol = (unsigned)__shfl_xor((int)(unsigned)h, off, 64), oh = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), off, 64);
+      acc = acc + o;
+      h += ((unsigned long long)oh << 32) | ol;
+    }
+    if (lane == 0) {
+      s_part[wave] = acc;
+      s_hpart[wave] = h;
+    }
   }
   __syncthreads();
   if (t == 0) {
     const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+    if (verify) {
+      const unsigned long long h = s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3];
+      ctl->hashes[k & 1][slot] = (h >> 32) ^ (h & 0xffffffffull);  // folded to 32 bits: what the replay compares
+    }
     if (stamp) a.stamps[8 * k + 5] = wall_clock64();
+  }
+  if (verify && s_mode && t == 64) {
+    // re-scored super-step: the reference's own order as well, one running sum over the beams
+    double acc = 0.0;
+    for (int b = 0; b < n; ++b) acc = acc + s_term[b];
+    ctl->scores_seq[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : acc / a.scan.tot_w;
   }
 }
 

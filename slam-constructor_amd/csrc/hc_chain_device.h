@@ -18,6 +18,7 @@ struct HcHostOut {
   double best_prob;
   long long calls, evaluated;
   int steps;
+  long long rescored;  // super-steps the checked default mode scored a second time, in beam order
   int gm_cx, gm_cy;    // GMapping OOPE: the cache entry after the last scorer call
   double gm_prob;
   int error;           // 1: replay found no terminal round (bug), 2: trace buffer too small, 3: a pose whose whole
@@ -31,6 +32,8 @@ struct HcChainCtl {
   HcState state[2];               // root state of super-step k at [k & 1]
   HcInst walk[2][kHcMaxInst];     // the round instances of super-step k's tree, same parity
   double scores[2][kHcSlots + 7];
+  double scores_seq[2][kHcSlots + 7];        // beam-order sums of a re-scored super-step
+  unsigned long long hashes[2][kHcSlots + 7];  // term-vector hashes (checked default mode)
   GmPoseInfo infos[2][kHcSlots + 7];  // GMapping OOPE: side outputs of every scored pose
   unsigned done_epoch;            // epoch of the last process_scan that ran to its end
 };
@@ -43,6 +46,8 @@ struct HcChainArgs {
   int gm_cx, gm_cy;            // ... and the cache entry the match starts from (-1 = empty)
   double gm_prob;
   int seq;  // 1: the reference's beam-order sum instead of the canonical tree (SLAMHIP_SUM_SEQUENTIAL)
+  int verify;  // 1 (default mode, point OOPE): comparisons too close for the tree sum to settle are re-decided from
+               // beam-order sums (hc_round_decide)
   HcChainCtl *ctl;
   const HcShape *shapes;  // kHcShapes of them
   unsigned long long n_inst;  // round instances of shape b in byte b (a dynamic index into an array of

@@ -32,6 +32,8 @@ struct slamhip_matcher {
   double chain_steps_avg = 12.0;
   int chain_mode = -1;  // -1 = decide from the environment at the first match, 0 off, 1 on
   int chain_nt = 512, chain_ahead = 3;
+  bool chain_verify = true;  // SLAMHIP_HC_CHAIN_VERIFY=0: plain tree-sum decisions
+  long long chain_rescored = 0;
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
 };
@@ -99,6 +101,7 @@ bool chain_eligible(slamhip_matcher *m) {
     m->chain_mode = (e && e[0] == '0') ? 0 : 1;
     if (const char *t = getenv("SLAMHIP_HC_CHAIN_THREADS")) m->chain_nt = atoi(t);
     if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
+    if (const char *v = getenv("SLAMHIP_HC_CHAIN_VERIFY")) m->chain_verify = v[0] != '0';
   }
   return m->chain_mode == 1;
 }
@@ -145,6 +148,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   a.gm_cy = ctx->gm_cy;
   a.gm_prob = ctx->gm_prob;
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
+  a.verify = (m->chain_verify && !a.seq && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE) ? 1 : 0;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
   a.n_inst = 0;
@@ -220,6 +224,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   job.launches = h->steps;
   job.t_build_us = job.t_replay_us = 0;
   m->chain_launched = launched;
+  m->chain_rescored = h->rescored;
   m->chain_steps_avg = 0.75 * m->chain_steps_avg + 0.25 * (double)h->steps;
   if (ctx->profile) {
     // every kernel launched carries an event pair, the run-ahead ones that found the chain finished too
@@ -313,10 +318,11 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch) {
 }
 
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads) {
-  if (!m || (mode != 0 && mode != 1) || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
+  if (!m || mode < 0 || mode > 2 || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
     return invalid_arg("bad device-chain setting");
   (void)chain_eligible(m);  // environment defaults first, then the explicit setting
-  m->chain_mode = mode;
+  m->chain_mode = mode ? 1 : 0;
+  if (mode) m->chain_verify = mode == 1;
   if (threads) m->chain_nt = threads;
   return SLAMHIP_OK;
 }
@@ -342,6 +348,13 @@ int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long
   if (scorer_calls) *scorer_calls = m->job.scorer_calls;
   if (poses_evaluated) *poses_evaluated = m->job.poses_evaluated;
   if (launches) *launches = m->job.launches;
+  return SLAMHIP_OK;
+}
+
+int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched, long long *steps_rescored) {
+  if (!m) return invalid_arg("null matcher");
+  if (kernels_launched) *kernels_launched = m->chain_launched;
+  if (steps_rescored) *steps_rescored = m->chain_rescored;
   return SLAMHIP_OK;
 }
 

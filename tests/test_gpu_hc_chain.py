@@ -43,7 +43,7 @@ def upload(pkg, ctx, sc):
 
 def matchers(pkg, ctx, prm, threads=0):
     dev = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
-    dev.set_device_chain(1, threads)
+    dev.set_device_chain(2, threads)  # unchecked: the host-driven default mode's decisions exactly
     host = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
     host.set_device_chain(0)
     return dev, host
@@ -86,6 +86,12 @@ def test_chain_workgroup_sizes_and_beam_counts(pkg, ctx, threads):
         dev, host = matchers(pkg, ctx, [20, 0.1, 0.1], threads)
         assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True),
                            host.process_scan(0, sc["init_pose"], trace=True))
+        # the checked default mode (what a matcher does unless told otherwise) walks the beam-order sum's accept path
+        chk = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), [20, 0.1, 0.1])
+        chk.set_device_chain(1, threads)
+        seq = pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), [20, 0.1, 0.1])
+        assert_trace_equal(chk.process_scan(0, sc["init_pose"], trace=True),
+                           seq.process_scan(0, sc["init_pose"], trace=True), exact_scores=False, rtol=1e-12)
 
 
 def test_chain_zero_weight_scan_and_far_pose(pkg, ctx):
@@ -102,16 +108,18 @@ def test_chain_zero_weight_scan_and_far_pose(pkg, ctx):
     assert_trace_equal(dev.process_scan(0, far, trace=True), host.process_scan(0, far, trace=True))
 
 
-def test_fuzz_default_and_sequential_sum_modes_against_strict_mode(pkg, ctx):
-    """how often does the default mode (canonical tree sum + device sincos; for hill
-    climbing the device chain) take another accept path than the bit-exact strict mode (beam-order sum +
-    host trig)?  200 matches over 40 random scenes.
-      * the device chain with the reference's beam-order sum (sum_order = SEQUENTIAL, device sincos): never --
+def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
+    """does a last-ulp difference of the default mode flip a strict `best < candidate` of the
+    bit-exact strict mode (beam-order sum + host trig)?  200 matches over 40 random scenes.
+      * default mode on the device chain (canonical tree sum, device sincos, decisions CHECKED -- comparisons the
+        tree sum cannot settle are decided again from beam-order sums): no divergence, and the check did fire;
+      * the device chain with the beam-order sum throughout (sum_order = SEQUENTIAL, device sincos): none either --
         the device sincos is not what flips a comparison;
-      * the default mode: only where the strict mode's `best < candidate` compares two sums that are equal or
-        one ulp apart (mathematically tied candidates: the same multiset of beam terms met in another beam
-        order), never anywhere else."""
-    div_seq, div_tree, matches, calls = 0, 0, 0, 0
+      * for the record, the host-driven default mode (tree sums as they are): the few divergences all sit at
+        comparisons whose strict-mode sums are equal or one ulp apart (mathematically tied candidates: the same
+        multiset of beam terms met in another beam order)."""
+    div = dict(dev=0, seq=0, host=0)
+    matches, calls, rescored = 0, 0, 0
     for seed in range(40):
         cell = CELL_TBM if seed % 3 == 0 else CELL_OCC
         sc = make_scene(cell_model=cell, size=500, scale=0.05, n_beams=360 + 90 * (seed % 5), seed=100 + seed,
@@ -119,34 +127,37 @@ def test_fuzz_default_and_sequential_sum_modes_against_strict_mode(pkg, ctx):
         upload(pkg, ctx, sc)
         rs = np.random.RandomState(seed)
         prm = [6 + 7 * (seed % 4), 0.1, 0.1]
-        dev = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
-        seq = pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm)  # runs on the device chain too
+        ms = dict(dev=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm), seq=pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm),
+                  host=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm))
+        ms["host"].set_device_chain(0)
         strict = pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), prm)
         for rep in range(5):
             init = sc["true_pose"] + rs.randn(3) * [0.08, 0.08, 0.04]
             b = strict.process_scan(0, init, trace=True)
             matches += 1
             calls += b["n_calls"]
-            for which, m in (("seq", seq), ("tree", dev)):
+            for which, m in ms.items():
                 a = m.process_scan(0, init, trace=True)
+                if which == "dev":
+                    rescored += m.stats()["steps_rescored"]
                 n = min(a["n_calls"], b["n_calls"])
                 bad = np.nonzero((a["accepted"][:n] != b["accepted"][:n]) | (a["poses"][:n] != b["poses"][:n]).any(1))[0]
                 if a["n_calls"] == b["n_calls"] and len(bad) == 0:
                     np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-12, atol=0)
                     continue
-                if which == "seq":
-                    div_seq += 1
-                    continue
-                div_tree += 1
-                i = int(bad[0]) if len(bad) else n
-                assert i < n and np.array_equal(a["poses"][i], b["poses"][i])  # same candidate, other decision
-                acc = np.nonzero(b["accepted"][:i])[0]
-                best = b["scores"][acc[-1]]
-                assert abs(b["scores"][i] - best) <= 2 * np.spacing(best), \
-                    "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
+                div[which] += 1
+                if which == "host":
+                    i = int(bad[0]) if len(bad) else n
+                    assert i < n and np.array_equal(a["poses"][i], b["poses"][i])  # same candidate, other decision
+                    acc = np.nonzero(b["accepted"][:i])[0]
+                    best = b["scores"][acc[-1]]
+                    assert abs(b["scores"][i] - best) <= 2 * np.spacing(best), \
+                        "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
     assert matches == 200 and calls > 200 * 40
-    assert div_seq == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div_seq, matches)
-    assert div_tree <= 10, "%d of %d default-mode matches diverged at tied comparisons" % (div_tree, matches)
+    assert div["dev"] == 0, "%d of %d checked default-mode matches diverged from the strict mode" % (div["dev"], matches)
+    assert div["seq"] == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div["seq"], matches)
+    assert rescored > 0, "the scenes never exercised the check"
+    assert div["host"] <= 10
 
 
 def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
