@@ -93,6 +93,8 @@ def parse():
                     help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
     ap.add_argument("--chain", type=int, default=-1,
                     help="hill climbing on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
+    ap.add_argument("--no-tie-check", action="store_true",
+                    help="default mode without the check of comparisons the tree sum cannot settle")
     args = ap.parse_args()
     if args.no_pf or args.workload == "sweep":
         args.legs = "none"
@@ -801,6 +803,8 @@ def main():
         m = pkg.Matcher(ctx, kind, cfg, params)
         if args.chain >= 0 and kind == "HC":
             m.set_device_chain(1 if args.chain else 0, args.chain if args.chain > 1 else 0)
+        if args.no_tie_check:
+            m.set_tie_check(0)
         on_device = kind == "HC" and args.chain != 0 and not args.strict
 
         def step():
@@ -889,7 +893,9 @@ def main():
             "config": {"workload": desc, "beams_after_filter": scan.n,
                        "mode": "strict (sequential sum, host trig)" if args.strict else
                                ("beam-order sum, device sincos" if args.seq_sum else
-                                "default (canonical tree sum, device sincos)"),
+                                ("default without the tie check (canonical tree sum, device sincos)" if args.no_tie_check else
+                                 "default (canonical tree sum, device sincos; comparisons the tree sum cannot "
+                                 "settle decided from beam-order sums)")),
                        "parallelism": "replicas x%d (no collective)" % world if world > 1 else "1 gpu",
                        "backend": args.backend if world > 1 else None,
                        **extra},

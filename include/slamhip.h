@@ -229,13 +229,18 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
  * accept chain on the device: one process_scan = a chain of kernels with no host in between, each
  * replaying the previous one's speculation tree (csrc/hc_chain.h).  mode: 1 on (default), 0 = the
  * host-driven speculative batches every other configuration uses; threads: workgroup size 256 / 512 /
- * 1024, 0 = default.  Scores are the same bit for bit either way.  On the device the default mode is CHECKED:
- * a `best < candidate` between canonical tree sums that differ by less than the two orders of summation can
- * (and whose beam terms are not identical) is decided again from the reference's beam-order sums, so the
- * accept chain is the one the beam-order sum would give -- the host-driven default mode decides such ties
- * from the tree sums as they are; mode 2 = the device chain without the check (the host-driven default mode's
- * decisions exactly, for comparisons). */
+ * 1024, 0 = default.  Scores and decisions are the same bit for bit either way. */
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
+/* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell OOPE is CHECKED (on = 1, the default; the environment
+ * variable SLAMHIP_TIE_CHECK=0 turns it off for a process): a `best < candidate`
+ * (pose_enumeration_scan_matcher.h:58) between canonical tree sums that lie within 2^-40 of each other -- more
+ * than the two orders of summation can differ by -- and whose beam terms are not identical (compared through a
+ * fingerprint of the term vector) is not decided from the tree sums: the poses in question are summed once more in
+ * the reference's beam order (weighted_mean_point_probability_spe.h:108-124) and those sums decide.  The accept
+ * chain is then the one SLAMHIP_SUM_SEQUENTIAL gives, at the default mode's speed; reported scores stay the
+ * canonical sums.  on = 0: decisions from the tree sums as they are (ties between mathematically equal
+ * candidates can then fall the other way: 4 of 200 fuzzed matches, tests/test_gpu_hc_chain.py). */
+int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],
                                  double out_delta[3], double *out_prob);

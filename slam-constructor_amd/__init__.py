@@ -35,7 +35,7 @@ slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_
 slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get slamhip_gm_cache_set
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
-slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_process_scan
+slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_set_tie_check slamhip_matcher_process_scan
 slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
@@ -179,6 +179,7 @@ def load():
     L.slamhip_matcher_set_observer.argtypes = [vp, C.POINTER(Observer)]
     L.slamhip_matcher_set_batch.argtypes = [vp, i]
     L.slamhip_matcher_set_device_chain.argtypes = [vp, i, i]
+    L.slamhip_matcher_set_tie_check.argtypes = [vp, i]
     L.slamhip_matcher_process_scan.argtypes = [vp, i, _dp, _dp, _dp]
     L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
     L.slamhip_matcher_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
@@ -541,9 +542,13 @@ class Matcher:
         _check(self.L.slamhip_matcher_set_batch(self.h, n))
 
     def set_device_chain(self, mode, threads=0):
-        """Hill climbing on the device with checked ties (1), on the device without the check (2), or through
-        host-driven speculative batches (0)."""
+        """Hill climbing on the device (1) or through host-driven speculative batches (0)."""
         _check(self.L.slamhip_matcher_set_device_chain(self.h, int(mode), int(threads)))
+
+    def set_tie_check(self, on):
+        """Checked default mode (on by default): comparisons the canonical tree sum cannot settle are decided from
+        beam-order sums."""
+        _check(self.L.slamhip_matcher_set_tie_check(self.h, int(bool(on))))
 
     def process_scan(self, map_id, init_pose, trace=False):
         """Returns dict(prob, delta[, poses, scores, accepted, n_calls]) -- the trace is what a

@@ -508,29 +508,19 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   const bool verify = !GM && a.verify;
   if (t < kSumLanes) {
     double acc = 0.0;
-    // position-sensitive fingerprint of the term vector: a multilinear form of its 32-bit halves with odd
-    // per-beam multipliers, in integer arithmetic (any order of adding it up gives the same value)
+    // fingerprint of the term vector (score_device.h)
     unsigned long long h = 0ull;
     unsigned k_lo = (2u * (unsigned)t + 1u) * 0x9E3779B1u, k_hi = (2u * (unsigned)t + 1u) * 0x85EBCA6Bu;
     for (int b = t; b < n; b += kSumLanes) {
       const double term = s_term[b];
       acc = acc + term;
       if (verify) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(term);
-        h += (unsigned long long)(unsigned)bits * k_lo + (unsigned long long)(unsigned)(bits >> 32) * k_hi;
+        h += term_fingerprint(term, k_lo, k_hi);
         k_lo += 2u * kSumLanes * 0x9E3779B1u;
         k_hi += 2u * kSumLanes * 0x85EBCA6Bu;
       }
     }
-    // the fixed butterfly of wave_xor_sum, with the fingerprint's exchanges riding along (one LDS-crossbar latency
-    // per step for both)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = __shfl_xor(acc, off, 64);
-      const unsigned ol = (unsigned)__shfl_xor((int)(unsigned)h, off, 64), oh = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), off, 64);
-      acc = acc + o;
-      h += ((unsigned long long)oh << 32) | ol;
-    }
+    wave_xor_sum_with(acc, h);
     if (lane == 0) {
       s_part[wave] = acc;
       s_hpart[wave] = h;
@@ -541,8 +531,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
     if (verify) {
-      const unsigned long long h = s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3];
-      ctl->hashes[k & 1][slot] = (h >> 32) ^ (h & 0xffffffffull);  // folded to 32 bits: what the replay compares
+      ctl->hashes[k & 1][slot] = fold_fingerprint(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]);
     }
     if (stamp) a.stamps[8 * k + 5] = wall_clock64();
   }

@@ -32,8 +32,11 @@ struct slamhip_matcher {
   double chain_steps_avg = 12.0;
   int chain_mode = -1;  // -1 = decide from the environment at the first match, 0 off, 1 on
   int chain_nt = 512, chain_ahead = 3;
-  bool chain_verify = true;  // SLAMHIP_HC_CHAIN_VERIFY=0: plain tree-sum decisions
-  long long chain_rescored = 0;
+  int tie_check = -1;  // checked default mode: -1 = from the environment (SLAMHIP_TIE_CHECK=0 turns it off), 0, 1
+  long long chain_rescored = 0;  // super-steps (device chain) / batches (host-driven) of the last match scored twice
+  long long rescored_poses = 0;
+  std::vector<double> keep_scores;
+  std::vector<unsigned> keep_fprints;
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
 };
@@ -88,6 +91,14 @@ int chain_release(slamhip_matcher *m) {
 // the chain covers what the shipped single-hypothesis configurations use: hill climbing over the 1-cell
 // OOPE in the default mode; everything else (strict order, host trigonometry, window OOPEs, GMapping,
 // staged copies) keeps the host-driven path
+bool tie_check_default(slamhip_matcher *m) {
+  if (m->tie_check < 0) {
+    const char *v = getenv("SLAMHIP_TIE_CHECK");
+    m->tie_check = (v && v[0] == '0') ? 0 : 1;
+  }
+  return m->tie_check == 1;
+}
+
 bool chain_eligible(slamhip_matcher *m) {
   if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
@@ -101,7 +112,6 @@ bool chain_eligible(slamhip_matcher *m) {
     m->chain_mode = (e && e[0] == '0') ? 0 : 1;
     if (const char *t = getenv("SLAMHIP_HC_CHAIN_THREADS")) m->chain_nt = atoi(t);
     if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
-    if (const char *v = getenv("SLAMHIP_HC_CHAIN_VERIFY")) m->chain_verify = v[0] != '0';
   }
   return m->chain_mode == 1;
 }
@@ -148,7 +158,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   a.gm_cy = ctx->gm_cy;
   a.gm_prob = ctx->gm_prob;
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
-  a.verify = (m->chain_verify && !a.seq && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE) ? 1 : 0;
+  a.verify = (tie_check_default(m) && !a.seq && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE) ? 1 : 0;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
   a.n_inst = 0;
@@ -318,12 +328,17 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch) {
 }
 
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads) {
-  if (!m || mode < 0 || mode > 2 || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
+  if (!m || (mode != 0 && mode != 1) || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
     return invalid_arg("bad device-chain setting");
   (void)chain_eligible(m);  // environment defaults first, then the explicit setting
-  m->chain_mode = mode ? 1 : 0;
-  if (mode) m->chain_verify = mode == 1;
+  m->chain_mode = mode;
   if (threads) m->chain_nt = threads;
+  return SLAMHIP_OK;
+}
+
+int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on) {
+  if (!m || (on != 0 && on != 1)) return invalid_arg("bad tie-check setting");
+  m->tie_check = on;
   return SLAMHIP_OK;
 }
 
@@ -379,9 +394,14 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   }
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   const int budget = m->max_batch > 0 ? m->max_batch : 256;
-  int rc = ensure_pose_capacity(ctx, budget + 1);
+  int rc = ensure_pose_capacity(ctx, budget + 2);  // + the initial pose, + the best pose of a batch scored twice
   if (rc) return rc;
   m->t_stage_us = m->t_score_us = 0;
+  // the checked default mode of the host-driven batches (the device chain has its own, csrc/hc_chain.hip)
+  (void)tie_check_default(m);
+  const bool checked = m->tie_check == 1 && !gm && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE &&
+                       m->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->low_latency && !ctx->stage_poses;
+  m->chain_rescored = 0;
   GmCarry carry;
   carry.cx = ctx->gm_cx;
   carry.cy = ctx->gm_cy;
@@ -396,13 +416,34 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
     if (n == 0) break;
     const double t0 = MatchJob::now_us();
     unsigned seq = 0;
+    ctx->want_fprints = checked;
     rc = score_staged(ctx, map_id, &m->cfg, n, nullptr, 0, &seq);
+    ctx->want_fprints = false;
     if (rc) return rc;
     m->pe->idle_work();  // outcome-independent host work while the batch is on the GPU (MC: polar pairs)
     rc = score_wait(ctx, seq);
     if (rc) return rc;
     m->t_score_us += MatchJob::now_us() - t0;
-    rc = job.consume(ctx->h_scores, ctx->h_gm_info, ctx);
+    if (checked && job.ambiguous(ctx->h_scores, ctx->h_fprints)) {
+      // a comparison the tree sums cannot settle: the same batch (and the pose that is the best so far) once more,
+      // summed in the reference's beam order; those sums decide, the canonical sums stay what is reported
+      m->keep_scores.assign(ctx->h_scores, ctx->h_scores + n);
+      m->keep_fprints.assign(ctx->h_fprints, ctx->h_fprints + n);
+      ctx->h_poses[3 * n] = job.best.x;
+      ctx->h_poses[3 * n + 1] = job.best.y;
+      ctx->h_poses[3 * n + 2] = job.best.theta;
+      slamhip_spe_cfg seq_cfg = m->cfg;
+      seq_cfg.sum_order = SLAMHIP_SUM_SEQUENTIAL;
+      rc = score_staged(ctx, map_id, &seq_cfg, n + 1, nullptr, 0, &seq);
+      if (rc) return rc;
+      rc = score_wait(ctx, seq);
+      if (rc) return rc;
+      ++m->chain_rescored;
+      m->rescored_poses += n + 1;
+      rc = job.consume(m->keep_scores.data(), ctx->h_gm_info, ctx, m->keep_fprints.data(), ctx->h_scores, ctx->h_scores[n]);
+    } else {
+      rc = job.consume(ctx->h_scores, ctx->h_gm_info, ctx, checked ? ctx->h_fprints : nullptr);
+    }
     if (rc) return rc;
   }
   if (gm) {

@@ -682,12 +682,43 @@ public:
     return n;
   }
 
-  // sc / gi point at this job's slice of the batch results
-  int consume(const double *sc, const GmPoseInfo *gi, const slamhip_ctx *ctx) {
+  // Checked default mode (fp = the batch's term-vector fingerprints): would the walk over this batch meet a
+  // `best < candidate` that the canonical tree sums cannot settle -- the two scores within 2^-40 (relative) of
+  // each other, more than the two orders of summation can differ by, and the term vectors not identical?
+  // Nothing is consumed; the caller then scores the batch once more in beam order and hands those sums to
+  // consume() as `dec`.  (csrc/hc_chain.h hc_decide_one: the same test on the device chain.)
+  bool ambiguous(const double *sc, const unsigned *fp) const {
+    double b = first ? sc[0] : best_prob;
+    unsigned hb = first ? fp[0] : best_fp;
+    int node = tree.root;
+    while (node >= 0) {
+      const SpecTree::Node &nd = tree.nodes[node];
+      const double s = sc[lead_ + nd.eval];
+      const unsigned h = fp[lead_ + nd.eval];
+      if (h != hb && std::fabs(s - b) <= std::max(std::fabs(s), std::fabs(b)) * 9.094947017729282e-13) return true;
+      const bool ok = b < s;
+      if (ok) {
+        b = s;
+        hb = h;
+      }
+      node = nd.child[ok ? 1 : 0];
+    }
+    return false;
+  }
+  int planned() const { return planned_; }
+  unsigned best_fp = 0;  // fingerprint of the best pose's term vector (checked default mode)
+
+  // sc / gi point at this job's slice of the batch results; fp (optional): the fingerprints, remembered for the
+  // best pose; dec (optional): the scores the comparisons are decided from -- the beam-order sums of a batch
+  // scored twice, dec_best the current best pose's -- while sc stays what is stored and reported
+  int consume(const double *sc, const GmPoseInfo *gi, const slamhip_ctx *ctx, const unsigned *fp = nullptr,
+              const double *dec = nullptr, double dec_best = 0.0) {
     const double t0 = timed ? now_us() : 0.0;
     launches += 1;
     poses_evaluated += planned_;
     if (first) {
+      if (fp) best_fp = fp[0];
+      if (dec) dec_best = dec[0];
       if (gm) {
         first_info = gi[0];
         first_raw_score = sc[0];
@@ -724,11 +755,13 @@ public:
       scorer_calls += 1;
       const double p3[3] = {c.x, c.y, c.theta};
       if (obs && obs->on_scan_test) obs->on_scan_test(obs->user, p3, prob);
-      const bool ok = best_prob < prob;  // strict: ties are rejections (Q1)
+      const bool ok = dec ? dec_best < dec[lead_ + nd.eval] : best_prob < prob;  // strict: ties are rejections (Q1)
       if (!lazy) pe->feedback(ok);
       ++batch_n;
       if (ok) {
         ++batch_acc;
+        if (dec) dec_best = dec[lead_ + nd.eval];
+        if (fp) best_fp = fp[lead_ + nd.eval];
         best_prob = prob;
         best = c;
         if (obs && obs->on_pose_update) obs->on_pose_update(obs->user, p3, best_prob);

@@ -21,6 +21,28 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
   return v;
 }
 
+// ---- term-vector fingerprints (the matchers' checked default mode) -------------------------------
+// h = sum over beams of lo32(term) * k_lo(b) + hi32(term) * k_hi(b) mod 2^64 with odd per-beam multipliers
+// k(b) = (2b + 1) * C mod 2^32: integer arithmetic, so every order of adding it up gives the same value; one
+// differing term changes it for certain, terms exchanged between beams change it unless the multipliers conspire.
+__device__ __forceinline__ unsigned long long term_fingerprint(double term, unsigned k_lo, unsigned k_hi) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(term);
+  return (unsigned long long)(unsigned)bits * k_lo + (unsigned long long)(unsigned)(bits >> 32) * k_hi;
+}
+__device__ __forceinline__ unsigned fold_fingerprint(unsigned long long h) { return (unsigned)(h >> 32) ^ (unsigned)h; }
+// wave_xor_sum's fixed butterfly with the fingerprint's exchanges riding along (one LDS-crossbar latency per step
+// for both)
+__device__ __forceinline__ void wave_xor_sum_with(double &v, unsigned long long &h) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    const unsigned ol = (unsigned)__shfl_xor((int)(unsigned)h, off, 64);
+    const unsigned oh = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), off, 64);
+    v = v + o;
+    h += ((unsigned long long)oh << 32) | ol;
+  }
+}
+
 // world_to_cell: int(floor(x / scale)) with a TRUE division (Q15: multiplying by 1/scale flips
 // cells at boundaries).  The division is the most expensive thing in the per-beam body, so it is
 // only executed when it can matter: with t = v/scale, RN(t) is within 2^-53 |t| of t and

@@ -65,10 +65,13 @@ hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream) {
 // ---- K1 ----------------------------------------------------------------------------------------
 // KB > 0: beams per thread known at compile time (n <= 256*KB), constants live in VGPRs.
 // KB == 0: generic (any n): constants re-read from L1/L2 in the pose loop.
-template <int MODEL, int KB, bool WRITE_TERMS>
+// FPRINT: a 32-bit fingerprint of every pose's term vector goes out next to its score (the matchers' checked
+// default mode: two poses with equal fingerprints add up the same terms, whatever the order of the sum)
+template <int MODEL, int KB, bool WRITE_TERMS, bool FPRINT>
 __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
   __shared__ double s_pose[kMaxPosesPerBlock][4];
   __shared__ double s_part[kMaxPosesPerBlock][4];
+  __shared__ unsigned long long s_hpart[FPRINT ? kMaxPosesPerBlock : 1][4];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int n = a.scan.n;
@@ -113,9 +116,12 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
   __syncthreads();
 
   const double scale = a.map.scale, inv_scale = a.map.inv_scale;
+  // position-sensitive multilinear form of the terms' 32-bit halves, odd per-beam multipliers (hc_chain.hip's)
+  const unsigned fk_lo = (2u * (unsigned)t + 1u) * 0x9E3779B1u, fk_hi = (2u * (unsigned)t + 1u) * 0x85EBCA6Bu;
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
     double acc = 0.0;
+    unsigned long long h = 0ull;
     if (KB > 0) {
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
@@ -129,6 +135,8 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
           const double term = pr * bw[k] * bf[k];
           if (WRITE_TERMS) a.terms[(size_t)(p0 + j) * n + b] = term;
           acc = acc + term;
+          if (FPRINT) h += term_fingerprint(term, fk_lo + (unsigned)k * (2u * kBlock * 0x9E3779B1u),
+                                            fk_hi + (unsigned)k * (2u * kBlock * 0x85EBCA6Bu));
         }
       }
     } else {
@@ -142,15 +150,25 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
         const double term = pr * a.scan.weight[b] * a.scan.factor[b];
         if (WRITE_TERMS) a.terms[(size_t)(p0 + j) * n + b] = term;
         acc = acc + term;
+        if (FPRINT) {
+          const unsigned kq = (unsigned)(b / kBlock);
+          h += term_fingerprint(term, fk_lo + kq * (2u * kBlock * 0x9E3779B1u), fk_hi + kq * (2u * kBlock * 0x85EBCA6Bu));
+        }
       }
     }
-    acc = wave_xor_sum(acc);
+    if (FPRINT) {
+      wave_xor_sum_with(acc, h);
+      if (lane == 0) s_hpart[j][wave] = h;
+    } else {
+      acc = wave_xor_sum(acc);
+    }
     if (lane == 0) s_part[j][wave] = acc;
   }
   __syncthreads();
   if (t < npb) {
     const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
     a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+    if (FPRINT) a.fprints[p0 + t] = fold_fingerprint(s_hpart[t][0] + s_hpart[t][1] + s_hpart[t][2] + s_hpart[t][3]);
   }
 }
 
@@ -522,16 +540,16 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
       hipLaunchKernelGGL(kernel, grid, block, shm, st, __VA_ARGS__);                       \
   } while (0)
 
-template <int MODEL, bool WT>
+template <int MODEL, bool WT, bool FP = false>
 static hipError_t launch_point_kb(const ScoreArgs &a, int kb, dim3 grid, hipStream_t st,
                                   hipEvent_t e0, hipEvent_t e1) {
   switch (kb) {
-    case 1: SLAMHIP_LAUNCH((k_score_point<MODEL, 1, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
-    case 2: SLAMHIP_LAUNCH((k_score_point<MODEL, 2, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
-    case 3: SLAMHIP_LAUNCH((k_score_point<MODEL, 3, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
-    case 4: SLAMHIP_LAUNCH((k_score_point<MODEL, 4, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
-    case 5: SLAMHIP_LAUNCH((k_score_point<MODEL, 5, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
-    default: SLAMHIP_LAUNCH((k_score_point<MODEL, 0, WT>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 1: SLAMHIP_LAUNCH((k_score_point<MODEL, 1, WT, FP>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 2: SLAMHIP_LAUNCH((k_score_point<MODEL, 2, WT, FP>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 3: SLAMHIP_LAUNCH((k_score_point<MODEL, 3, WT, FP>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 4: SLAMHIP_LAUNCH((k_score_point<MODEL, 4, WT, FP>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    case 5: SLAMHIP_LAUNCH((k_score_point<MODEL, 5, WT, FP>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
+    default: SLAMHIP_LAUNCH((k_score_point<MODEL, 0, WT, FP>), grid, dim3(kBlock), 0, st, e0, e1, a); break;
   }
   return hipGetLastError();
 }
@@ -606,10 +624,12 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
     e = hipGetLastError();
   } else if (cell_model == SLAMHIP_CELL_OCC) {
     e = wt ? launch_point_kb<SLAMHIP_CELL_OCC, true>(a, kb, grid, stream, ev_start, stop1)
-           : launch_point_kb<SLAMHIP_CELL_OCC, false>(a, kb, grid, stream, ev_start, stop1);
+           : (a.fprints ? launch_point_kb<SLAMHIP_CELL_OCC, false, true>(a, kb, grid, stream, ev_start, stop1)
+                        : launch_point_kb<SLAMHIP_CELL_OCC, false>(a, kb, grid, stream, ev_start, stop1));
   } else if (cell_model == SLAMHIP_CELL_TBM) {
     e = wt ? launch_point_kb<SLAMHIP_CELL_TBM, true>(a, kb, grid, stream, ev_start, stop1)
-           : launch_point_kb<SLAMHIP_CELL_TBM, false>(a, kb, grid, stream, ev_start, stop1);
+           : (a.fprints ? launch_point_kb<SLAMHIP_CELL_TBM, false, true>(a, kb, grid, stream, ev_start, stop1)
+                        : launch_point_kb<SLAMHIP_CELL_TBM, false>(a, kb, grid, stream, ev_start, stop1));
   } else {
     return hipErrorInvalidValue;
   }

@@ -57,6 +57,8 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
     hipHostFree(ctx->h_pose_sc);
     hipHostFree(ctx->h_gm_info);
     hipHostFree(ctx->h_pose_slot);
+    hipHostFree(ctx->h_fprints);
+    ctx->h_fprints = nullptr;
     // a failed allocation below must not leave pointers that ctx_destroy (or the next call) frees again
     ctx->d_poses = ctx->d_scores = ctx->d_pose_sc = nullptr;
     ctx->d_gm_info = nullptr;
@@ -66,6 +68,7 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
     ctx->pose_cap = 0;
   }
   SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_slot, sizeof(int) * cap, kPinned));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_fprints, sizeof(unsigned) * cap, kPinned));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_poses, sizeof(double) * 3 * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_scores, sizeof(double) * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_pose_sc, sizeof(double) * 2 * cap));
@@ -147,6 +150,7 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
   a->gm.window = cfg->gm_window;
   a->gm_info = nullptr;
   a->terms = nullptr;
+  a->fprints = nullptr;
   if (cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL && cfg->oope != SLAMHIP_OOPE_GMAPPING) {
     const size_t need = (size_t)n_poses * ctx->scan_n;
     if (need > ctx->terms_cap) {
@@ -363,6 +367,8 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
     rc = fill_args(ctx, *m, cfg, n_poses, poses_src, sc_src, ctx->h_scores + off, &a);
     if (rc) return rc;
     if (gm) a.gm_info = ctx->h_gm_info + off;
+    if (ctx->want_fprints && cfg->oope == SLAMHIP_OOPE_OBSTACLE && cfg->sum_order == SLAMHIP_SUM_TREE256)
+      a.fprints = ctx->h_fprints + off;
     if (tiled) {
       a.tables = tiled->tables;
       a.pose_slot = ctx->h_pose_slot + off;
@@ -470,6 +476,7 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   if (ctx->h_scores) hipHostFree(ctx->h_scores);
   if (ctx->h_pose_sc) hipHostFree(ctx->h_pose_sc);
   if (ctx->h_gm_info) hipHostFree(ctx->h_gm_info);
+  if (ctx->h_fprints) hipHostFree(ctx->h_fprints);
   if (ctx->h_pose_slot) hipHostFree(ctx->h_pose_slot);
   if (ctx->d_terms) hipFree(ctx->d_terms);
   if (ctx->d_dirty_xy) hipFree(ctx->d_dirty_xy);

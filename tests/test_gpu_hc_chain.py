@@ -43,9 +43,11 @@ def upload(pkg, ctx, sc):
 
 def matchers(pkg, ctx, prm, threads=0):
     dev = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
-    dev.set_device_chain(2, threads)  # unchecked: the host-driven default mode's decisions exactly
+    dev.set_device_chain(1, threads)
     host = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
     host.set_device_chain(0)
+    for m in (dev, host):
+        m.set_tie_check(0)  # both decide from the tree sums as they are: bit for bit the same walk
     return dev, host
 
 
@@ -110,16 +112,19 @@ def test_chain_zero_weight_scan_and_far_pose(pkg, ctx):
 
 def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
     """does a last-ulp difference of the default mode flip a strict `best < candidate` of the
-    bit-exact strict mode (beam-order sum + host trig)?  200 matches over 40 random scenes.
-      * default mode on the device chain (canonical tree sum, device sincos, decisions CHECKED -- comparisons the
-        tree sum cannot settle are decided again from beam-order sums): no divergence, and the check did fire;
-      * the device chain with the beam-order sum throughout (sum_order = SEQUENTIAL, device sincos): none either --
+    bit-exact strict mode (beam-order sum + host trig)?  200 HC and 200 MC matches over 40 random scenes.
+      * default mode, CHECKED (what a matcher does unless told otherwise: canonical tree sum, device sincos,
+        comparisons the tree sum cannot settle decided again from beam-order sums) -- HC on the device chain, HC
+        and MC through host-driven batches: no divergence, and the check did fire;
+      * the beam-order sum throughout on the device chain (sum_order = SEQUENTIAL, device sincos): none either --
         the device sincos is not what flips a comparison;
-      * for the record, the host-driven default mode (tree sums as they are): the few divergences all sit at
+      * for the record, the unchecked default mode (tree sums as they are): the few divergences all sit at
         comparisons whose strict-mode sums are equal or one ulp apart (mathematically tied candidates: the same
         multiset of beam terms met in another beam order)."""
-    div = dict(dev=0, seq=0, host=0)
-    matches, calls, rescored = 0, 0, 0
+    names = ("hc_dev", "hc_host", "hc_seq", "hc_raw", "mc", "mc_raw")
+    div = dict.fromkeys(names, 0)
+    rescored = dict.fromkeys(names, 0)
+    matches, calls = 0, 0
     for seed in range(40):
         cell = CELL_TBM if seed % 3 == 0 else CELL_OCC
         sc = make_scene(cell_model=cell, size=500, scale=0.05, n_beams=360 + 90 * (seed % 5), seed=100 + seed,
@@ -127,37 +132,48 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
         upload(pkg, ctx, sc)
         rs = np.random.RandomState(seed)
         prm = [6 + 7 * (seed % 4), 0.1, 0.1]
-        ms = dict(dev=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm), seq=pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm),
-                  host=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm))
-        ms["host"].set_device_chain(0)
-        strict = pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), prm)
+        ms = dict(hc_dev=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm), hc_host=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm),
+                  hc_seq=pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm), hc_raw=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm))
+        ms["hc_host"].set_device_chain(0)
+        ms["hc_raw"].set_device_chain(0)
+        ms["hc_raw"].set_tie_check(0)
+        strict = dict(hc=pkg.Matcher(ctx, "HC", pkg.spe_cfg(**STRICT), prm))
         for rep in range(5):
+            # Monte Carlo: fresh matchers per match, so that every one of them draws the same random stream
+            mc_prm = [1000 + 5 * seed + rep, 0.2, 0.1, 20 + 10 * (seed % 3), 300]
+            ms["mc"], ms["mc_raw"] = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), mc_prm), pkg.Matcher(ctx, "MC", pkg.spe_cfg(), mc_prm)
+            ms["mc_raw"].set_tie_check(0)
+            strict["mc"] = pkg.Matcher(ctx, "MC", pkg.spe_cfg(**STRICT), mc_prm)
             init = sc["true_pose"] + rs.randn(3) * [0.08, 0.08, 0.04]
-            b = strict.process_scan(0, init, trace=True)
+            ref = {k: m.process_scan(0, init, trace=True) for k, m in strict.items()}
             matches += 1
-            calls += b["n_calls"]
+            calls += ref["hc"]["n_calls"] + ref["mc"]["n_calls"]
             for which, m in ms.items():
+                b = ref[which[:2]]
                 a = m.process_scan(0, init, trace=True)
-                if which == "dev":
-                    rescored += m.stats()["steps_rescored"]
+                rescored[which] += m.stats()["steps_rescored"]
                 n = min(a["n_calls"], b["n_calls"])
                 bad = np.nonzero((a["accepted"][:n] != b["accepted"][:n]) | (a["poses"][:n] != b["poses"][:n]).any(1))[0]
                 if a["n_calls"] == b["n_calls"] and len(bad) == 0:
                     np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-12, atol=0)
                     continue
                 div[which] += 1
-                if which == "host":
+                if which.endswith("_raw"):
                     i = int(bad[0]) if len(bad) else n
                     assert i < n and np.array_equal(a["poses"][i], b["poses"][i])  # same candidate, other decision
                     acc = np.nonzero(b["accepted"][:i])[0]
                     best = b["scores"][acc[-1]]
                     assert abs(b["scores"][i] - best) <= 2 * np.spacing(best), \
                         "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
-    assert matches == 200 and calls > 200 * 40
-    assert div["dev"] == 0, "%d of %d checked default-mode matches diverged from the strict mode" % (div["dev"], matches)
-    assert div["seq"] == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div["seq"], matches)
-    assert rescored > 0, "the scenes never exercised the check"
-    assert div["host"] <= 10
+    print("fuzz: %d matches per matcher, divergences %r, re-scored steps / batches %r" % (matches, div, rescored))
+    assert matches == 200 and calls > 200 * 80
+    for which in ("hc_dev", "hc_host", "mc"):
+        assert div[which] == 0, "%d of %d checked default-mode %s matches diverged from the strict mode" % (div[which], matches, which)
+        # (Monte Carlo candidates are continuous random poses: sums that close with different terms are rare)
+        assert which == "mc" or rescored[which] > 0, "the scenes never exercised the check of %s" % which
+    assert div["hc_seq"] == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div["hc_seq"], matches)
+    assert rescored["hc_raw"] == rescored["mc_raw"] == 0
+    assert div["hc_raw"] <= 10 and div["mc_raw"] <= 10
 
 
 def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):

@@ -18,9 +18,10 @@ sc = make_scene(cell_model=0, size=2000, scale=0.05, n_beams=1080, seed=100)
 ctx.upload_map(0, sc["map"])
 c, s = pkg.beam_trig(sc["scan"].angle)
 ctx.scan_upload(sc["scan"].range, c, s, sc["scan"].weight, sc["scan"].factor)
-for threads, mode in ((256, 1), (512, 1), (512, 2), (1024, 1)):  # mode 2: without the tie check
+for threads, check in ((256, 1), (512, 1), (512, 0), (1024, 1)):  # check 0: without the tie check
     m = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), [128, 0.1, 0.1])
-    m.set_device_chain(mode, threads)
+    m.set_device_chain(1, threads)
+    m.set_tie_check(check)
     for _ in range(5):
         m.process_scan(0, sc["init_pose"])
     L = pkg.load()
@@ -32,7 +33,7 @@ for threads, mode in ((256, 1), (512, 1), (512, 2), (1024, 1)):  # mode 2: witho
     st = np.array(list(buf)).reshape(64, 8)
     steps = m.stats()["launches"]
     st = st[:steps]
-    print("threads %d, mode %d: %d super-steps, %d re-scored" % (threads, mode, steps, m.stats()["steps_rescored"]))
+    print("threads %d, tie check %d: %d super-steps, %d re-scored" % (threads, check, steps, m.stats()["steps_rescored"]))
     names = ["staged", "replayed", "pose", "terms", "stored"]
     d = np.diff(st[:, :6], axis=1) / 100.0
     ok = (st[:, 5] > 0)
