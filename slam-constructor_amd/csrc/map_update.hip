@@ -60,6 +60,7 @@ struct MuJob {
 using namespace slamhip;
 
 namespace {
+constexpr int kNearR = 16, kNearSide = 2 * kNearR + 1, kNearMaxWords = 64;
 struct MuScratch {
   size_t cap_records = 0, cap_beams = 0, temp_bytes = 0;
   unsigned *counts = nullptr, *offsets = nullptr, *keys = nullptr, *keys_sorted = nullptr;
@@ -71,6 +72,13 @@ struct MuScratch {
   unsigned long long *n_updates = nullptr;  // one word: padding records of the update
   unsigned long long *h_status = nullptr;   // pinned: (error flag, padding records) of the last update
   void *temp = nullptr;
+  // counting sort of a plain call's records (k_mu_rank): per-cell record counts of the key window (all zero between
+  // updates), chain starts, the records as scattered
+  size_t cap_bins = 0, scan_temp_bytes = 0;
+  unsigned *bins = nullptr, *offs = nullptr, *skeys = nullptr, *sbeam = nullptr;
+  unsigned *h_offsets = nullptr;  // pinned: first record slot of every beam, computed by the host
+  unsigned long long *near_bits = nullptr;  // [kNearSide^2][64] words: beams (up to 4096) visiting the cells next to the robot
+  void *scan_temp = nullptr;
   // scan re-use (see slamhip_map_append_scan)
   bool reuse_ok = false;
   const double *last_range = nullptr, *last_cos = nullptr, *last_sin = nullptr;
@@ -173,6 +181,10 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
     if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
+    if (sc.h_offsets) hipHostFree(sc.h_offsets);
+    SLAMHIP_CHECK(hipHostMalloc(&sc.h_offsets, sizeof(unsigned) * (cap + 1), hipHostMallocDefault));
+    if (!sc.near_bits)
+      SLAMHIP_CHECK(hipMalloc(&sc.near_bits, sizeof(unsigned long long) * kNearSide * kNearSide * kNearMaxWords));
     if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
     if (!sc.h_status) SLAMHIP_CHECK(hipHostMalloc(&sc.h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault));
     sc.cap_beams = cap;
@@ -240,15 +252,25 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     if (prc) return prc;
     if (pe0) SLAMHIP_CHECK(hipEventRecord(pe0, ctx->stream));
   }
+  a.host_offsets = sc.h_offsets;
+  const int near_words = (n + 63) / 64;
+  if (near_words <= kNearMaxWords) {
+    a.near_bits = sc.near_bits;
+    a.near_r = kNearR;
+    a.near_words = near_words;
+  }
   if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, ctx->stream, a);
-  hipLaunchKernelGGL(k_mu_offsets, dim3(1), dim3(1024), 0, ctx->stream, sc.counts, sc.offsets, n);
   // the record count is needed on the host to size the buffers: the same IEEE operations as
   // k_mu_count (no contraction on either side) give the same bounds without a device round trip
   unsigned total = 0;
+  int bb_lo_x, bb_lo_y, bb_hi_x, bb_hi_y;  // external cells the update can touch: robot cell .. end cells
   {
     const int rcx = (int)std::floor(a.px / a.scale), rcy = (int)std::floor(a.py / a.scale);
+    bb_lo_x = bb_hi_x = rcx;
+    bb_lo_y = bb_hi_y = rcy;
     for (int b = 0; b < n; ++b) {
+      sc.h_offsets[b] = total;
       const double c = a.cs * cos_a[b] - a.sn * sin_a[b];
       const double s = a.sn * cos_a[b] + a.cs * sin_a[b];
       const double wx = a.px + range[b] * c, wy = a.py + range[b] * s;
@@ -262,6 +284,10 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
                     "(no-return beams need a finite range or slam/mapping/max_range)");
       const int ocx = (int)std::floor(wx / a.scale), ocy = (int)std::floor(wy / a.scale);
       total += (unsigned)(std::abs(ocx - rcx) + std::abs(ocy - rcy) + 1);
+      bb_lo_x = std::min(bb_lo_x, ocx);
+      bb_hi_x = std::max(bb_hi_x, ocx);
+      bb_lo_y = std::min(bb_lo_y, ocy);
+      bb_hi_y = std::max(bb_hi_y, ocy);
     }
   }
   if (total == 0) {
@@ -269,9 +295,11 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     return SLAMHIP_OK;
   }
   if (total > sc.cap_records) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (void *p : {(void *)sc.keys, (void *)sc.keys_sorted, (void *)sc.order, (void *)sc.order_sorted,
-                    (void *)sc.srt_prob, (void *)sc.srt_qual, sc.temp})
+                    (void *)sc.srt_prob, (void *)sc.srt_qual, sc.temp, (void *)sc.skeys, (void *)sc.sbeam})
       if (p) hipFree(p);
+    sc.skeys = sc.sbeam = nullptr;
     size_t cap = 1 << 16;
     while (cap < total) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&sc.keys, sizeof(unsigned) * cap));
@@ -288,24 +316,85 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   }
   a.keys = sc.keys;
   a.keys_cap = (unsigned long long)sc.cap_records;
-  a.key_x0 = a.key_y0 = 0;
-  a.key_w = m.pitch;
+  // the key window: the cells between the robot's and the beams' end cells, clipped to the map (a walk is monotone
+  // between its two ends; cells outside the map become padding).  Small enough -- a few hundred thousand cells for
+  // a laser's reach -- the records are counting-sorted over it; otherwise keys are cells of the whole map and
+  // rocprim sorts them (SLAMHIP_K6_SORT=radix forces that path: the parity tests run both).
+  static const bool force_radix = getenv("SLAMHIP_K6_SORT") && std::strcmp(getenv("SLAMHIP_K6_SORT"), "radix") == 0;
+  const long long wx0 = std::max(0ll, (long long)bb_lo_x + m.origin_x), wy0 = std::max(0ll, (long long)bb_lo_y + m.origin_y);
+  const long long wx1 = std::min((long long)m.width - 1, (long long)bb_hi_x + m.origin_x);
+  const long long wy1 = std::min((long long)m.height - 1, (long long)bb_hi_y + m.origin_y);
+  const long long n_bins = (wx1 >= wx0 && wy1 >= wy0) ? (wx1 - wx0 + 1) * (wy1 - wy0 + 1) : 0;
+  const bool counting = !force_radix && n_bins > 0 && n_bins <= (1ll << 23) && near_words <= kNearMaxWords;
+  if (counting && ((size_t)n_bins + 1 > sc.cap_bins || !sc.skeys)) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (void *p : {(void *)sc.bins, (void *)sc.offs, sc.scan_temp})
+      if (p) hipFree(p);
+    sc.bins = sc.offs = nullptr;
+    sc.scan_temp = nullptr;
+    size_t cap = 1 << 18;
+    while (cap < (size_t)n_bins + 1) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&sc.bins, sizeof(unsigned) * cap));
+    SLAMHIP_CHECK(hipMemsetAsync(sc.bins, 0, sizeof(unsigned) * cap, ctx->stream));
+    SLAMHIP_CHECK(hipMalloc(&sc.offs, sizeof(unsigned) * cap));
+    sc.scan_temp_bytes = 0;
+    SLAMHIP_CHECK(rocprim::exclusive_scan(nullptr, sc.scan_temp_bytes, sc.bins, sc.offs, 0u, cap, rocprim::plus<unsigned>(),
+                                          ctx->stream));
+    SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, sc.scan_temp_bytes));
+    sc.cap_bins = cap;
+  }
+  if (counting && !sc.skeys) {
+    SLAMHIP_CHECK(hipMalloc(&sc.skeys, sizeof(unsigned) * sc.cap_records));
+    SLAMHIP_CHECK(hipMalloc(&sc.sbeam, sizeof(unsigned) * sc.cap_records));
+  }
+  if (counting) {
+    a.key_x0 = (int)wx0;
+    a.key_y0 = (int)wy0;
+    a.key_w = (int)(wx1 - wx0 + 1);
+    a.bins = sc.bins;
+    a.n_bins = (unsigned)n_bins;
+    a.near_bits = sc.near_bits;
+    a.near_r = kNearR;
+    a.near_words = near_words;
+    a.robot_ix = (int)std::floor(a.px / a.scale) + m.origin_x;
+    a.robot_iy = (int)std::floor(a.py / a.scale) + m.origin_y;
+  } else {
+    a.near_bits = nullptr;
+    a.key_x0 = a.key_y0 = 0;
+    a.key_w = m.pitch;
+  }
   hipLaunchKernelGGL(k_mu_emit<unsigned>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, sc.order);
-  size_t tb = sc.temp_bytes;
-  // sort only the bits a cell key can occupy; the invalid key (all ones) still sorts last because
-  // every valid key is < 2^nbits - 1
-  unsigned nbits = 1;
-  while (nbits < 32 && ((1ull << nbits) - 1) <= (unsigned long long)m.pitch * m.height) ++nbits;
-  SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted,
-                                          total, 0, nbits, ctx->stream));
-  if (a.est_kind == 1)
-    hipLaunchKernelGGL((k_mu_gather<unsigned, 1>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
-                       (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
-                       sc.srt_qual);
-  else
-    hipLaunchKernelGGL((k_mu_gather<unsigned, 0>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
-                       (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
-                       sc.srt_qual);
+  if (counting) {
+    hipLaunchKernelGGL(k_mu_near_bits, dim3(near_words, kNearSide), dim3(64), 0, ctx->stream, a);
+    size_t tb = sc.scan_temp_bytes;
+    SLAMHIP_CHECK(rocprim::exclusive_scan(sc.scan_temp, tb, sc.bins, sc.offs, 0u, (size_t)n_bins + 1, rocprim::plus<unsigned>(),
+                                          ctx->stream));
+    const dim3 rgrid((total + 255) / 256);
+    hipLaunchKernelGGL(k_mu_scatter, rgrid, dim3(256), 0, ctx->stream, a, (const unsigned *)sc.keys, (const unsigned *)sc.order,
+                       total, (const unsigned *)sc.offs, sc.skeys, sc.sbeam);
+    if (a.est_kind == 1)
+      hipLaunchKernelGGL(k_mu_rank<1>, rgrid, dim3(256), 0, ctx->stream, a, (const unsigned *)sc.skeys, (const unsigned *)sc.sbeam,
+                         (const unsigned *)sc.offs, total, sc.keys_sorted, sc.order_sorted, sc.srt_prob, sc.srt_qual);
+    else
+      hipLaunchKernelGGL(k_mu_rank<0>, rgrid, dim3(256), 0, ctx->stream, a, (const unsigned *)sc.skeys, (const unsigned *)sc.sbeam,
+                         (const unsigned *)sc.offs, total, sc.keys_sorted, sc.order_sorted, sc.srt_prob, sc.srt_qual);
+  } else {
+    size_t tb = sc.temp_bytes;
+    // sort only the bits a cell key can occupy; the invalid key (all ones) still sorts last because
+    // every valid key is < 2^nbits - 1
+    unsigned nbits = 1;
+    while (nbits < 32 && ((1ull << nbits) - 1) <= (unsigned long long)m.pitch * m.height) ++nbits;
+    SLAMHIP_CHECK(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys, sc.keys_sorted, sc.order, sc.order_sorted,
+                                            total, 0, nbits, ctx->stream));
+    if (a.est_kind == 1)
+      hipLaunchKernelGGL((k_mu_gather<unsigned, 1>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                         (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
+                         sc.srt_qual);
+    else
+      hipLaunchKernelGGL((k_mu_gather<unsigned, 0>), dim3((total + 255) / 256), dim3(256), 0, ctx->stream, a,
+                         (const unsigned *)sc.keys_sorted, (const unsigned *)sc.order_sorted, total, sc.srt_prob,
+                         sc.srt_qual);
+  }
   a.rec_prob = sc.srt_prob;
   a.rec_qual = sc.srt_qual;
   a.rec_beam = sc.order_sorted;
@@ -678,9 +767,11 @@ void mu_release(slamhip_ctx *ctx) {
     for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.keys, (void *)s.keys_sorted, (void *)s.order,
                     (void *)s.order_sorted, (void *)s.beam_info, (void *)s.beam_end, (void *)s.scan,
                     (void *)s.srt_prob, (void *)s.srt_qual, (void *)s.occ, (void *)s.error_flag,
-                    (void *)s.n_updates, s.temp})
+                    (void *)s.n_updates, s.temp, (void *)s.bins, (void *)s.offs, (void *)s.skeys,
+                    (void *)s.sbeam, s.scan_temp, (void *)s.near_bits})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
+    if (s.h_offsets) hipHostFree(s.h_offsets);
     delete &s;
     ctx->mu_scratch = nullptr;
   }

@@ -53,7 +53,28 @@ struct MuArgs {
   // the SORTED records (k_mu_gather -> k_mu_apply*): observation, TBM only its quality, the beam
   const double *rec_prob, *rec_qual;
   const unsigned *rec_beam;
+  // plain call: the host sizes the record buffers from its own evaluation of the per-beam counts, so it also
+  // knows every beam's first slot -- read from pinned memory by k_mu_emit (no scan kernel; a device-side cursor
+  // bumped by 1080 waves cost 16 us of same-address atomics) and left in `offsets` for the later kernels
+  const unsigned *host_offsets;
+  // plain call, counting sort (see k_mu_rank): k_mu_emit counts the records of every cell of the key window
+  unsigned *bins;
+  unsigned n_bins;
+  // the cells within near_r of the robot's cell take a record of nearly every beam: same-address atomics on their
+  // bins serialize (1080 of them on the robot's own cell: 16 us), so these cells get a BITMAP of the beams that
+  // visit them instead (k_mu_near_bits) -- which also is their chain in beam order
+  unsigned long long *near_bits;  // [(2 near_r + 1)^2][near_words]
+  int near_r, near_words, robot_ix, robot_iy;  // robot cell in internal coordinates
 };
+
+// index of a key's cell in the near grid, -1: a far cell
+__device__ __forceinline__ int mu_near_index(const MuArgs &a, unsigned key) {
+  const int ix = (int)(key % (unsigned)a.key_w) + a.key_x0, iy = (int)(key / (unsigned)a.key_w) + a.key_y0;
+  const int nx = ix - a.robot_ix + a.near_r, ny = iy - a.robot_iy + a.near_r;
+  const int side = 2 * a.near_r + 1;
+  if ((unsigned)nx >= (unsigned)side || (unsigned)ny >= (unsigned)side) return -1;
+  return ny * side + nx;
+}
 
 // thread g of the beam kernels handles beam g % n of job g / n (a plain call is one job)
 __device__ __forceinline__ MuJob mu_job(const MuArgs &a, int g) {
@@ -105,6 +126,10 @@ __global__ void k_mu_count(MuArgs a) {
   if (g == 0) {  // the status words of this update (later kernels of the stream set them)
     *a.error_flag = 0;
     *a.n_padding = 0;
+  }
+  if (a.near_bits) {
+    const int words = (2 * a.near_r + 1) * (2 * a.near_r + 1) * a.near_words;
+    for (int w = g; w < words; w += gridDim.x * blockDim.x) a.near_bits[w] = 0ull;
   }
   const bool in = g < a.n * a.n_jobs;
   unsigned cnt = 0;
@@ -318,11 +343,15 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
   const int lane = threadIdx.x & 63;
   const unsigned cap = a.counts[b];
   if (cap == 0) return;
-  const unsigned base = a.offsets[b];
+  const unsigned base = a.host_offsets ? a.host_offsets[b] : a.offsets[b];
   if ((unsigned long long)base + cap > a.keys_cap) {  // the host sized the buffer for another count: no write
-    if (lane == 0) *a.error_flag = 2;
+    if (lane == 0) {
+      *a.error_flag = 2;
+      if (a.host_offsets) a.counts[b] = 0u;  // (k_mu_near_bits: no records of this beam)
+    }
     return;
   }
+  if (a.host_offsets && lane == 0) a.offsets[b] = base;
   const MuJob jb = mu_job(a, b);
   const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
   const double scale = a.scale;
@@ -371,13 +400,24 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
     }
   }
   ok = __all(ok);
-  if (ok) {
-    if (__any(bad) && lane == 0) *a.error_flag = 1;
-    return;
+  if (!ok) {
+    // the sequential walk decides (it rewrites every key of the beam and the padding)
+    for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
+    if (lane == 0) mu_walk_beam<KeyT>(a, b);
+    __threadfence();  // lane 0's keys, read back by the whole wave below
+  } else if (__any(bad) && lane == 0) {
+    *a.error_flag = 1;
   }
-  // the sequential walk decides (it rewrites every key of the beam and the padding)
-  for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
-  if (lane == 0) mu_walk_beam<KeyT>(a, b);
+  if (a.bins) {
+    // the beam's keys are final: count them per cell of the key window (padding and cells outside it: no bin;
+    // cells near the robot: k_mu_near_bits)
+    for (unsigned k = lane; k < cap; k += 64) {
+      const KeyT key = out[k];
+      // (a cell within near_r of the robot in both axes is at most 2 near_r steps into a walk)
+      if (key < (KeyT)a.n_bins && (k > 2u * (unsigned)a.near_r || mu_near_index(a, (unsigned)key) < 0))
+        atomicAdd(&a.bins[(unsigned)key], 1u);
+    }
+  }
 }
 
 // the internal cell (and the job) a sort key names
@@ -489,6 +529,103 @@ __global__ void k_mu_gather(MuArgs a, const Key *keys_sorted, const unsigned *be
   srt_prob[i] = pq.x;
 }
 
+// ---- plain call: counting sort instead of a radix sort --------------------------------------------------------
+// One scan leaves ~170 k records over a key window of a few hundred thousand cells; what the update needs is every
+// cell's records side by side and in beam order.  rocprim's merge sort took 8 launches / 53 us for that (half of a
+// single-scan update).  Here: k_mu_emit counts the records per cell (`bins`), an exclusive scan turns the counts
+// into chain starts, k_mu_scatter drops every record into its cell's chain in whatever order the atomics hand out,
+// and k_mu_rank puts the chain in order -- a record's place is the number of records of its chain with a smaller
+// beam (a beam visits a cell at most once, so ranks are distinct) -- and computes the observation (k_mu_gather's
+// body) on the way.  Chains are a handful of records long except around the robot, whose own cell takes one of
+// every beam: those cells keep a bitmap of their beams instead (MuArgs::near_bits), which gives count and rank
+// without same-address atomics (first version: 16 us of serialized atomics in each of two kernels, and 57 us in
+// a rank loop over 1080-record chains).  Bins are back at zero when the update is through.
+// one wave per (word w of the bitmaps, step k of the walks): lane = beam 64 w + lane standing on its k-th cell; the
+// lanes that stand on the same near cell are found with ballots and recorded with one atomic OR per cell (a cell is
+// met at one step only, |dx| + |dy| = k, except by Bresenham fail-over walks), their number added to the cell's bin
+__global__ __launch_bounds__(64) void k_mu_near_bits(MuArgs a) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const unsigned k = blockIdx.y;  // 0 .. 2 near_r: a walk is monotone away from the robot's cell, later cells are far
+  const int b = 64 * w + lane;
+  const unsigned cap = b < a.n ? a.counts[b] : 0u;
+  const unsigned key = k < cap ? ((const unsigned *)a.keys)[a.offsets[b] + k] : ~0u;
+  const int idx = key < a.n_bins ? mu_near_index(a, key) : -1;
+  unsigned long long todo = __ballot(idx >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lidx = __shfl(idx, leader, 64);
+    const unsigned long long mask = __ballot(idx == lidx);
+    if (lane == leader) {
+      atomicOr(&a.near_bits[(size_t)lidx * a.near_words + w], mask);
+      atomicAdd(&a.bins[key], (unsigned)__popcll(mask));
+    }
+    todo &= ~mask;
+  }
+}
+
+__global__ void k_mu_scatter(MuArgs a, const unsigned *keys, const unsigned *beam_of, unsigned total, const unsigned *offs,
+                             unsigned *skeys, unsigned *sbeam) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned key = keys[i];
+  if (key >= a.n_bins) return;  // padding
+  const unsigned beam = beam_of[i];
+  const int nidx = mu_near_index(a, key);
+  unsigned pos = offs[key];
+  if (nidx < 0) {
+    // any free place of the chain (k_mu_rank orders it); the bin ends at 0.  Most far cells are met by one beam:
+    // no atomic then
+    if (offs[key + 1] - pos == 1u) a.bins[key] = 0u;
+    else pos += atomicSub(&a.bins[key], 1u) - 1u;
+  } else {
+    // a near cell: the place IS the rank, the number of visiting beams below this one
+    const unsigned long long *bw = a.near_bits + (size_t)nidx * a.near_words;
+    const unsigned wq = beam >> 6;
+    const unsigned long long below = (1ull << (beam & 63u)) - 1ull;
+    unsigned r = 0;
+#pragma unroll 4
+    for (unsigned q = 0; q < (unsigned)a.near_words; ++q) {  // (uniform trip count: the loads go out together)
+      const unsigned long long word = bw[q];
+      r += q < wq ? (unsigned)__popcll(word) : (q == wq ? (unsigned)__popcll(word & below) : 0u);
+    }
+    pos += r;
+  }
+  skeys[pos] = key;
+  sbeam[pos] = beam;
+}
+
+template <int EST>
+__global__ void k_mu_rank(MuArgs a, const unsigned *skeys, const unsigned *sbeam, const unsigned *offs, unsigned total,
+                          unsigned *keys_sorted, unsigned *beam_sorted, double *srt_prob, double *srt_qual) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const unsigned valid = offs[a.n_bins];
+  if (i == 0) *a.n_padding = (unsigned long long)(total - valid);
+  if (i >= valid) {  // the tail the later kernels skip (k_mu_apply: a padding key heads no chain)
+    keys_sorted[i] = ~0u;
+    beam_sorted[i] = 0u;
+    return;
+  }
+  const unsigned key = skeys[i], beam = sbeam[i];
+  unsigned at = i;
+  if (mu_near_index(a, key) < 0) {
+    const unsigned start = offs[key], end = offs[key + 1];
+    unsigned rank = 0;
+    for (unsigned j = start; j < end; ++j) rank += sbeam[j] < beam ? 1u : 0u;
+    at = start + rank;
+  } else {
+    a.bins[key] = 0u;  // (far bins were counted down by k_mu_scatter)
+  }
+  keys_sorted[at] = key;
+  beam_sorted[at] = beam;
+  int ix, iy;
+  mu_key_cell<unsigned>(a, key, &ix, &iy);
+  double2 pq = mu_value<EST>(a, (int)beam, ix - a.origin_x, iy - a.origin_y, a.beam_info + beam);
+  if (a.rule == 3) srt_qual[at] = pq.y;
+  else if (a.rule != 0 && isnan(pq.y)) pq.x = pq.y;
+  srt_prob[at] = pq.x;
+}
+
 __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs, double *out) {
   double tmp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -571,8 +708,12 @@ __device__ __forceinline__ void mu_step(const MuArgs &a, MuCell &c, double prob,
 // where a sorted key's cell lives: dense window, or (job, virtual cell) -> the job's slot -> tile
 template <typename Key>
 __device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
-  if (!a.tables) return (size_t)key;  // the window of a plain call is the bound map, pitch wide
+  if (!a.tables && !a.bins) return (size_t)key;  // the key window of a radix-sorted plain call is the bound map, pitch wide
   int ix, iy;
+  if (!a.tables) {  // counting-sorted plain call: keys are cells of the window around the scan
+    mu_key_cell<Key>(a, key, &ix, &iy);
+    return (size_t)iy * a.pitch + ix;
+  }
   const int job = mu_key_cell<Key>(a, key, &ix, &iy);
   const int tile = a.tables[(size_t)a.jobs[job].slot * a.table_stride + (iy >> kTileShift) * a.tiles_x + (ix >> kTileShift)];
   return ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);

@@ -18,8 +18,15 @@ sc = make_scene(cell_model=0, size=2000, scale=0.05, n_beams=1080, seed=100)
 ctx.upload_map(0, sc["map"])
 c, s = pkg.beam_trig(sc["scan"].angle)
 ctx.scan_upload(sc["scan"].range, c, s, sc["scan"].weight, sc["scan"].factor)
-for threads, check in ((256, 1), (512, 1), (512, 0), (1024, 1)):  # check 0: without the tie check
-    m = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), [128, 0.1, 0.1])
+cases = [(256, 1, False), (512, 1, False), (512, 0, False), (1024, 1, False), (512, 1, True)]
+for threads, check, gm in cases:  # check 0: without the tie check; gm: the GMapping OOPE on a GMapping map
+    if gm:
+        from synth import CELL_GMAPPING
+        sc = make_scene(cell_model=CELL_GMAPPING, size=2000, scale=0.05, n_beams=1080, seed=100)
+        ctx.upload_map(0, sc["map"])
+        c, s = pkg.beam_trig(sc["scan"].angle)
+        ctx.scan_upload(sc["scan"].range, c, s, sc["scan"].weight, sc["scan"].factor)
+    m = pkg.Matcher(ctx, "HC", pkg.spe_cfg(oope=pkg.OOPE_GMAPPING) if gm else pkg.spe_cfg(), [20 if gm else 128, 0.1, 0.1])
     m.set_device_chain(1, threads)
     m.set_tie_check(check)
     for _ in range(5):
@@ -33,7 +40,7 @@ for threads, check in ((256, 1), (512, 1), (512, 0), (1024, 1)):  # check 0: wit
     st = np.array(list(buf)).reshape(64, 8)
     steps = m.stats()["launches"]
     st = st[:steps]
-    print("threads %d, tie check %d: %d super-steps, %d re-scored" % (threads, check, steps, m.stats()["steps_rescored"]))
+    print("threads %d, tie check %d, gmapping %d: %d super-steps, %d re-scored" % (threads, check, gm, steps, m.stats()["steps_rescored"]))
     names = ["staged", "replayed", "pose", "terms", "stored"]
     d = np.diff(st[:, :6], axis=1) / 100.0
     ok = (st[:, 5] > 0)
