@@ -106,6 +106,17 @@ int slamhip_map_apply_dirty(slamhip_ctx *ctx, int map_id, int n, const int *coor
 /* Unbounded maps move their origin when they grow (plain_grid_map.h:133-173): re-bind keeps
  * the old cells at their shifted place. */
 int slamhip_map_release(slamhip_ctx *ctx, int map_id);
+/* An UNBOUNDED map in HBM (UnboundedPlainGridMap, src/core/maps/plain_grid_map.h:52-176): with on = 1 a
+ * slamhip_map_append_scan that reaches beyond the window grows it first -- a re-bind that keeps every cell at its
+ * external coordinates, the new area holding the unknown payload -- instead of failing.  The reference grows
+ * inside GridMap::update, cell by cell, by ensure_inside's Expansion_Rate rule (:133-173); the window here is a
+ * superset of that one with the same cells.  This is what lets a single-hypothesis world keep its map on the GPU
+ * (host/slamhip_resident_world.h). */
+int slamhip_map_set_auto_grow(slamhip_ctx *ctx, int map_id, int on);
+/* geometry of a bound window (RegularSquaresGrid::width/height/origin/scale, regular_squares_grid.h:26-38,141-143)
+ * and how often it has grown; any out pointer may be NULL */
+int slamhip_map_info(slamhip_ctx *ctx, int map_id, int *cell_model, int *width, int *height, int *origin_x,
+                     int *origin_y, double *scale, long long *times_grown);
 /* read back a window (tests / debugging) */
 int slamhip_map_download_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h,
                                 double *payload_out);
@@ -137,7 +148,8 @@ typedef struct {
 } slamhip_scan_adder_cfg;
 /* RAW scan points (range, cos/sin of their angle as for slamhip_scan_upload, is_occupied flag; may
  * be NULL = all occupied).  Every touched cell must lie inside the bound window (grow it with
- * slamhip_map_bind first), otherwise SLAMHIP_ERR_STATE.  n_updates = number of cell updates. */
+ * slamhip_map_bind first, or let it grow: slamhip_map_set_auto_grow), otherwise SLAMHIP_ERR_STATE.
+ * n_updates = number of cell updates. */
 int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
                             const double pose[3], int n, const double *range, const double *cos_a,
                             const double *sin_a, const int *is_occ, long long *n_updates);

@@ -10,6 +10,8 @@
 // Output: oracle/_ref/libslamref_world.so (links slam-constructor_amd/libslamhip.so).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <memory>
@@ -23,6 +25,7 @@
 #include "../test/core/mock_grid_cell.h"
 
 #include "slamhip_init_slam.h"
+#include "slamhip_resident_world.h"
 
 namespace {
 
@@ -74,8 +77,15 @@ void fill_props(MapPropertiesProvider &p, int preset, int matcher, unsigned seed
 
 struct Calls : public GridScanMatcherObserver {
   long tests = 0, updates = 0;
-  void on_scan_test(const RobotPose &, const LaserScan2D &, double) override { ++tests; }
-  void on_pose_update(const RobotPose &, const LaserScan2D &, double) override { ++updates; }
+  const char *tag = nullptr;  // REFWORLD_TRACE: print every event
+  void on_scan_test(const RobotPose &p, const LaserScan2D &s, double score) override {
+    ++tests;
+    if (tag) fprintf(stderr, "%s test %.17g %.17g %.17g -> %.17g (%zu pts)\n", tag, p.x, p.y, p.theta, score, s.points().size());
+  }
+  void on_pose_update(const RobotPose &p, const LaserScan2D &, double score) override {
+    ++updates;
+    if (tag) fprintf(stderr, "%s update %.17g %.17g %.17g -> %.17g\n", tag, p.x, p.y, p.theta, score);
+  }
 };
 
 }  // namespace
@@ -178,6 +188,136 @@ int refworld_compare(int preset, int matcher, int wrap, int n_scans, int n_beams
   out[14] = mr.height();
   hip.reset();
   hgsm.reset();
+  slamhip_ctx_destroy(ctx);
+  return 0;
+}
+
+// The same loop with the HIP world whose map is RESIDENT in HBM (host/slamhip_resident_world.h: match and map
+// update both on the GPU, the window grows by itself, no host map): poses after every scan and the final
+// map -- payload by payload: occupancy for tinySLAM's cells, the four belief masses for vinySLAM's -- against the
+// reference world.
+// out = {pose mismatches (bitwise), max |pose diff|, map cells compared, payload mismatches, max |payload diff|,
+//        ref scorer calls, hip scorer calls, ref accepted, hip accepted, times the HBM window grew,
+//        final reference width, height, final HBM window width, height, cell updates on the GPU}
+int refworld_compare_resident(int preset, int matcher, int n_scans, int n_beams, int strict, double size_m,
+                              double *poses_out, double *out) {
+  const double scale = 0.1;
+  auto gt = std::make_shared<UnboundedPlainGridMap>(std::make_shared<MockGridCell>(0.0),
+                                                    GridMapParams{300, 300, scale});
+  {
+    using C = CecumTextRasterMapPrimitive;
+    C c1{81, 60, C::BoundPosition::Top}, c2{31, 21, C::BoundPosition::Bot};
+    GridMapPatcher{}.apply_text_raster(*gt, c1.to_stream(), DiscretePoint2D{-40, 35}, 1, 1);
+    GridMapPatcher{}.apply_text_raster(*gt, c2.to_stream(), DiscretePoint2D{-15, -6}, 1, 1);
+  }
+  MapPropertiesProvider props;
+  fill_props(props, preset, matcher, 424242u, strict, size_m);
+  auto ref = init_1h_slam(props);
+  slamhip_ctx *ctx = nullptr;
+  if (slamhip_ctx_create(0, &ctx) != SLAMHIP_OK) {
+    std::cerr << "refworld: " << slamhip_last_error() << std::endl;
+    return -1;
+  }
+  auto hip = init_hip_resident_1h_slam(props, ctx, 0);
+  auto c_ref = std::make_shared<Calls>(), c_hip = std::make_shared<Calls>();
+  ref->add_sm_observer(c_ref);
+  hip->add_sm_observer(c_hip);
+  RobotPose truth{scale / 2, scale / 2 - 6 * scale, deg2rad(90)};
+  RobotPose prev_odom{0, 0, 0};
+  long pose_mis = 0;
+  double worst_pose = 0;
+  for (int k = 0; k < n_scans; ++k) {
+    TransformedLaserScan ts;
+    ts.scan = LaserScanGenerator{to_lsp(15, 270, n_beams)}.laser_scan_2D(*gt, truth, 1);
+    ts.quality = 1.0;
+    const double ex = 0.03 * std::sin(1.7 * k), ey = -0.025 * std::cos(0.9 * k), et = 0.02 * std::sin(0.6 * k + 1);
+    RobotPose odom{truth.x + ex, truth.y + ey, truth.theta + et};
+    ts.pose_delta = k == 0 ? RobotPoseDelta{truth.x, truth.y, truth.theta}
+                           : RobotPoseDelta{odom.x - prev_odom.x, odom.y - prev_odom.y, odom.theta - prev_odom.theta};
+    prev_odom = k == 0 ? truth : odom;
+    TransformedLaserScan ts_hip = ts;
+    if (std::getenv("REFWORLD_TRACE")) {
+      const bool on = k == std::atoi(std::getenv("REFWORLD_TRACE"));
+      c_ref->tag = on ? "ref" : nullptr;
+      c_hip->tag = on ? "hip" : nullptr;
+    }
+    ref->handle_sensor_data(ts);
+    hip->handle_sensor_data(ts_hip);
+    const RobotPose pr = ref->pose(), ph = hip->pose();
+    poses_out[6 * k + 0] = pr.x; poses_out[6 * k + 1] = pr.y; poses_out[6 * k + 2] = pr.theta;
+    poses_out[6 * k + 3] = ph.x; poses_out[6 * k + 4] = ph.y; poses_out[6 * k + 5] = ph.theta;
+    if (std::memcmp(&poses_out[6 * k], &poses_out[6 * k + 3], 3 * sizeof(double)) != 0) ++pose_mis;
+    worst_pose = std::max({worst_pose, std::fabs(pr.x - ph.x), std::fabs(pr.y - ph.y), std::fabs(pr.theta - ph.theta)});
+    if (std::getenv("REFWORLD_DEBUG"))
+      std::cerr << "scan " << k << ": tests " << c_ref->tests << " / " << c_hip->tests << ", updates " << c_ref->updates
+                << " / " << c_hip->updates << ", quality " << ts.quality << " / " << ts_hip.quality << std::endl;
+    truth = RobotPose{truth.x + 0.04 * std::cos(0.35 * k), truth.y + 0.09, truth.theta + 0.015 * std::sin(0.8 * k)};
+    if (std::fabs(truth.x / scale - std::round(truth.x / scale)) < 1e-3) truth.x += 0.013;
+    if (std::fabs(truth.y / scale - std::round(truth.y / scale)) < 1e-3) truth.y += 0.013;
+  }
+  // the final maps, payload by payload over the reference's extent (the HBM window is a superset or the cells
+  // outside it were never touched: they must hold the prototype's payload in the reference map)
+  const GridMap &mr = ref->map();
+  int model = 0, w = 0, h = 0, ox = 0, oy = 0;
+  long long grown = 0;
+  slamhip_map_info(ctx, 0, &model, &w, &h, &ox, &oy, nullptr, &grown);
+  const int st = model == SLAMHIP_CELL_TBM ? 4 : 1;
+  std::vector<double> dev((size_t)w * h * st);
+  if (slamhip_map_download_window(ctx, 0, 0, 0, w, h, dev.data()) != SLAMHIP_OK) {
+    std::cerr << "refworld: " << slamhip_last_error() << std::endl;
+    return -1;
+  }
+  auto payload = [&](const GridCell &c, double *p) {
+    if (st == 4) {
+      const auto &b = static_cast<const TbmBaseCell &>(c).belief();
+      p[0] = b.unknown(); p[1] = b.empty(); p[2] = b.occupied(); p[3] = b.conflict();
+    } else {
+      p[0] = c.occupancy().prob_occ;
+    }
+  };
+  double unk[4] = {0, 0, 0, 0};
+  payload(*mr.new_cell(), unk);
+  long cells = 0, cell_mis = 0;
+  double worst = 0;
+  const auto org = mr.origin();
+  for (int y = 0; y < mr.height(); ++y)
+    for (int x = 0; x < mr.width(); ++x) {
+      const GridMap::Coord c{x - org.x, y - org.y};
+      double a[4], b[4];
+      payload(mr[c], a);
+      const int ix = c.x + ox, iy = c.y + oy;
+      if (0 <= ix && ix < w && 0 <= iy && iy < h) std::memcpy(b, &dev[((size_t)iy * w + ix) * st], st * sizeof(double));
+      else std::memcpy(b, unk, st * sizeof(double));
+      ++cells;
+      if (std::memcmp(a, b, st * sizeof(double)) != 0) {
+        ++cell_mis;
+        for (int k = 0; k < st; ++k) worst = std::max(worst, std::fabs(a[k] - b[k]));
+      }
+    }
+  // and the view a map consumer gets: occupancy of a row of cells through GridMap::operator[]
+  long view_mis = 0;
+  for (int x = 0; x < mr.width(); ++x) {
+    const GridMap::Coord c{x - org.x, 0};
+    const Occupancy a = mr[c].occupancy(), b = hip->map()[c].occupancy();
+    if (std::memcmp(&a.prob_occ, &b.prob_occ, sizeof(double)) != 0) ++view_mis;
+  }
+  out[0] = double(pose_mis);
+  out[1] = worst_pose;
+  out[2] = double(cells);
+  out[3] = double(cell_mis);
+  out[4] = worst;
+  out[5] = double(c_ref->tests);
+  out[6] = double(c_hip->tests);
+  out[7] = double(c_ref->updates);
+  out[8] = double(c_hip->updates);
+  out[9] = double(grown);
+  out[10] = mr.width();
+  out[11] = mr.height();
+  out[12] = w;
+  out[13] = h;
+  out[14] = double(hip->cell_updates());
+  out[15] = double(view_mis);
+  hip.reset();
   slamhip_ctx_destroy(ctx);
   return 0;
 }

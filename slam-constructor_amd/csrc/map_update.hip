@@ -209,13 +209,16 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   MuArgs a;
   std::memset(&a, 0, sizeof(a));
   a.n_jobs = 1;
-  a.payload = m.d_payload;
-  a.aux = aux_stride ? m.d_aux : nullptr;
-  a.width = m.width;
-  a.height = m.height;
-  a.pitch = m.pitch;
-  a.origin_x = m.origin_x;
-  a.origin_y = m.origin_y;
+  auto fill_map = [&]() {
+    a.payload = m.d_payload;
+    a.aux = aux_stride ? m.d_aux : nullptr;
+    a.width = m.width;
+    a.height = m.height;
+    a.pitch = m.pitch;
+    a.origin_x = m.origin_x;
+    a.origin_y = m.origin_y;
+  };
+  fill_map();
   a.cell_dbl = cell_doubles(m.cell_model);
   a.aux_stride = aux_stride;
   a.scale = m.scale;
@@ -259,13 +262,11 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     a.near_r = kNearR;
     a.near_words = near_words;
   }
-  if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, ctx->stream, a);
   // the record count is needed on the host to size the buffers: the same IEEE operations as
   // k_mu_count (no contraction on either side) give the same bounds without a device round trip
   unsigned total = 0;
-  int bb_lo_x, bb_lo_y, bb_hi_x, bb_hi_y;  // external cells the update can touch: robot cell .. end cells
-  {
+  int bb_lo_x = 0, bb_lo_y = 0, bb_hi_x = 0, bb_hi_y = 0;  // external cells the update can touch: robot cell .. end cells
+  auto host_pass = [&]() -> int {
     const int rcx = (int)std::floor(a.px / a.scale), rcy = (int)std::floor(a.py / a.scale);
     bb_lo_x = bb_hi_x = rcx;
     bb_lo_y = bb_hi_y = rcy;
@@ -289,6 +290,43 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
       bb_lo_y = std::min(bb_lo_y, ocy);
       bb_hi_y = std::max(bb_hi_y, ocy);
     }
+    return SLAMHIP_OK;
+  };
+  auto launch_count = [&]() {
+    if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, ctx->stream, a);
+  };
+  if (!m.auto_grow) {
+    launch_count();  // runs while the host walks the beams
+    const int hrc = host_pass();
+    if (hrc) return hrc;
+  } else {
+    // an unbounded map (slamhip_map_set_auto_grow): the window first grows to hold every cell of the update, as
+    // UnboundedPlainGridMap::update does cell by cell (plain_grid_map.h:62-67,133-173).  Any superset of the
+    // reference's window holds the same cells; this one adds a fifth of the side (the reference's
+    // Expansion_Rate) or what the scan needs, whichever is more, on the sides that were left.
+    const int hrc = host_pass();
+    if (hrc) return hrc;
+    const long long lo_x = (long long)bb_lo_x + m.origin_x, hi_x = (long long)bb_hi_x + m.origin_x;
+    const long long lo_y = (long long)bb_lo_y + m.origin_y, hi_y = (long long)bb_hi_y + m.origin_y;
+    if (total > 0 && (lo_x < 0 || lo_y < 0 || hi_x >= m.width || hi_y >= m.height)) {
+      auto side = [](long long need, int dim) { return need > 0 ? std::max(need, (long long)dim / 5 + 1) : 0ll; };
+      const long long px = side(-lo_x, m.width), ax = side(hi_x - (m.width - 1), m.width);
+      const long long py = side(-lo_y, m.height), ay = side(hi_y - (m.height - 1), m.height);
+      const long long nw = px + m.width + ax, nh = py + m.height + ay;
+      if (nw * nh > (1ll << 31))
+        return fail("an unbounded map would grow beyond 2^31 cells: a scan point far outside the site?", SLAMHIP_ERR_STATE);
+      const long grown = m.grown + 1;
+      const int model = m.cell_model;
+      const double sc_ = m.scale;
+      double unk[4];
+      for (int k = 0; k < 4; ++k) unk[k] = m.unknown[k];
+      const int rc = slamhip_map_bind(ctx, map_id, model, (int)nw, (int)nh, m.origin_x + (int)px, m.origin_y + (int)py, sc_, unk);
+      if (rc) return rc;
+      ctx->maps[map_id].grown = grown;
+      fill_map();
+    }
+    launch_count();
   }
   if (total == 0) {
     if (n_updates_out) *n_updates_out = 0;

@@ -565,7 +565,32 @@ int slamhip_map_bind(slamhip_ctx *ctx, int map_id, int cell_model, int width, in
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (old.d_payload) hipFree(old.d_payload);
   if (old.d_aux) hipFree(old.d_aux);
+  if (old.bound && old.cell_model == cell_model) {
+    nm.auto_grow = old.auto_grow;
+    nm.grown = old.grown;
+  }
   ctx->maps[map_id] = nm;
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_set_auto_grow(slamhip_ctx *ctx, int map_id, int on) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  m->auto_grow = on != 0;
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_info(slamhip_ctx *ctx, int map_id, int *cell_model, int *width, int *height, int *origin_x,
+                     int *origin_y, double *scale, long long *times_grown) {
+  DeviceMap *m = get_map(ctx, map_id);
+  if (!m) return invalid("unknown map id");
+  if (cell_model) *cell_model = m->cell_model;
+  if (width) *width = m->width;
+  if (height) *height = m->height;
+  if (origin_x) *origin_x = m->origin_x;
+  if (origin_y) *origin_y = m->origin_y;
+  if (scale) *scale = m->scale;
+  if (times_grown) *times_grown = m->grown;
   return SLAMHIP_OK;
 }
 

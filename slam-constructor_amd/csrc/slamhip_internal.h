@@ -108,6 +108,10 @@ struct DeviceMap {
   // MeanProbabilityCell::_n (1 double) or GmappingBaseCell::_hits/_tries (2 doubles) per cell
   double *d_aux = nullptr;
   int aux_stride = 0;
+  // slamhip_map_set_auto_grow: an update that reaches beyond the window re-binds it first (the reference's
+  // unbounded maps grow inside update(), plain_grid_map.h:133-173)
+  bool auto_grow = false;
+  long grown = 0;  // number of such re-binds
 };
 
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip

@@ -149,7 +149,11 @@ public:
   long rebinds() const { return _n_rebind; }
   long cells_sent() const { return _n_cells; }
 
+  // the window IS the map (host/slamhip_resident_world.h: matched and updated in HBM): nothing to mirror
+  void set_resident(bool on) { _resident = on; }
+
   void sync(const GridMap &map, const HipMirroredGridMap *dirty_source = nullptr) {
+    if (_resident) return;
     if (!dirty_source) dirty_source = dynamic_cast<const HipMirroredGridMap *>(&map);
     const auto org = map.origin();
     const bool same = _w == map.width() && _h == map.height() && _ox == org.x && _oy == org.y &&
@@ -268,6 +272,7 @@ private:
   slamhip_ctx *_ctx;
   int _id, _model;
   bool _bounded;
+  bool _resident = false;
   int _w = -1, _h = -1, _ox = 0, _oy = 0;
   double _scale = 0;
   std::vector<double> _shadow;  // only kept for maps without a dirty log
@@ -319,6 +324,7 @@ public:
   // optional: a log kept somewhere else than in the map handed to process_scan (a map that IS a
   // HipMirroredGridMap is recognised by itself; any other map is compared cell by cell)
   void set_dirty_source(const HipMirroredGridMap *src) { _dirty_source = src; }
+  void set_resident_map(bool on) { _mirror->set_resident(on); }
   const HipMapMirror &mirror() const { return *_mirror; }
 
   double process_scan(const TransformedLaserScan &raw_scan, const RobotPose &init_pose,

@@ -1,0 +1,239 @@
+// slamhip_resident_world.h -- the single-hypothesis world (tinySLAM / vinySLAM) with its map RESIDENT in HBM.
+//
+// init_hip_1h_slam (slamhip_init_slam.h) keeps the reference's world, map and scan adder and mirrors the host
+// map into HBM before every match.  Here the map never exists on the host: one scan is
+//     match on the GPU (slamhip_matcher_process_scan)  ->  update of the same HBM window (slamhip_map_append_scan, K6)
+// which is SingleStateHypothesisLaserScanGridWorld::handle_observation
+// (src/core/states/single_state_hypothesis_laser_scan_grid_world.h:52-65) with GridMapScanAdder::append_scan
+// (src/core/maps/grid_map_scan_adders.h:54-75) replaced by the device's.  The window grows like the reference's
+// unbounded map (slamhip_map_set_auto_grow).  map() hands out a read-only view that fetches 64x64-cell chunks
+// from the GPU when a consumer (a map dumper, the ROS occupancy-grid publisher) looks at them.
+// Compiled only with the reference headers on the include path; contains no reference code.
+// oracle/ref_world_harness.cpp runs it next to init_1h_slam.
+#ifndef SLAMHIP_RESIDENT_WORLD_H
+#define SLAMHIP_RESIDENT_WORLD_H
+
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+#include "core/states/laser_scan_grid_world.h"
+#include "slamhip_init_scan_matching.h"
+
+// read-only GridMap over a device window: occupancy() of the cell kinds the path holds -- the payload double of
+// OCC cells; for TBM cells the conversion of the cell class the map was configured with (TbmOccConsistentCell /
+// TbmUnknownEvenOccCell::tbm2occ, src/core/maps/tbm_grid_cells.h:76-100; a cell that was never updated still
+// reports the prototype's Occupancy{0.5, 1}).  Belief masses: slamhip_map_download_window.
+class HipResidentMapView : public GridMap {
+public:
+  class Cell : public GridCell {
+  public:
+    explicit Cell(double prob = 0.5) : GridCell{Occupancy{prob, 1.0}} {}
+    std::unique_ptr<GridCell> clone() const override { return std::make_unique<Cell>(*this); }
+    void set(double prob, double qual = 1.0) { _occupancy = Occupancy{prob, qual}; }
+  };
+  // tbm_kind: 0 = tbm_consistent, 1 = tbm_unknown_even_occ (TBM windows only)
+  HipResidentMapView(slamhip_ctx *ctx, int map_id, const GridMapParams &p, double unknown_prob, int tbm_kind = 0)
+      : GridMap{std::make_shared<Cell>(unknown_prob), p}, _ctx{ctx}, _id{map_id}, _unknown{unknown_prob},
+        _tbm_kind{tbm_kind} {
+    refresh_geometry();
+  }
+  const GridCell &operator[](const Coord &c) const override {
+    const int cx = floor_div(c.x), cy = floor_div(c.y);
+    const long long key = ((long long)cy << 32) ^ (unsigned)cx;
+    auto it = _chunks.find(key);
+    if (it == _chunks.end()) {
+      std::vector<Cell> cells((size_t)kChunk * kChunk, Cell{_unknown});
+      // the part of the chunk that lies inside the window; the rest reads as the unknown cell
+      const int x0 = cx * kChunk + _ox, y0 = cy * kChunk + _oy;  // internal
+      const int ix0 = std::max(x0, 0), iy0 = std::max(y0, 0);
+      const int ix1 = std::min(x0 + kChunk, _w), iy1 = std::min(y0 + kChunk, _h);
+      if (ix0 < ix1 && iy0 < iy1) {
+        std::vector<double> tmp((size_t)(ix1 - ix0) * (iy1 - iy0) * _stride);
+        slamhip_or_die(slamhip_map_download_window(_ctx, _id, ix0, iy0, ix1 - ix0, iy1 - iy0, tmp.data()),
+                       "map_download_window");
+        for (int y = iy0; y < iy1; ++y)
+          for (int x = ix0; x < ix1; ++x)
+            set_cell(cells[(size_t)(y - y0) * kChunk + (x - x0)], &tmp[_stride * ((size_t)(y - iy0) * (ix1 - ix0) + (x - ix0))]);
+      }
+      it = _chunks.emplace(key, std::move(cells)).first;
+    }
+    return it->second[(size_t)(c.y - cy * kChunk) * kChunk + (c.x - cx * kChunk)];
+  }
+  void update(const Coord &, const AreaOccupancyObservation &) override {}  // a view: the world writes through K6
+  void reset(const Coord &, const GridCell &) override {}
+  DiscretePoint2D origin() const override { return DiscretePoint2D{_ox, _oy}; }
+  // an unbounded map has every cell (UnboundedPlainGridMap::has_cell, plain_grid_map.h:77) -- filter_scan drops
+  // the points whose cell the map does not have (weighted_mean_point_probability_spe.h:135-140)
+  bool has_cell(const Coord &) const override { return true; }
+  // after an update: cached chunks are stale, the window may have grown
+  void invalidate() {
+    _chunks.clear();
+    refresh_geometry();
+  }
+
+private:
+  void set_cell(Cell &c, const double *p) const {
+    if (_stride != 4) {
+      c.set(p[0]);
+    } else if (p[0] == 1.0 && p[1] == 0.0 && p[2] == 0.0) {
+      c.set(0.5);  // total ignorance: the cell was never updated
+    } else if (_tbm_kind == 1) {
+      c.set(p[2] + 0.5 * p[0]);
+    } else {
+      const double qual = p[2] + p[1];
+      c.set(p[2] / qual, qual);
+    }
+  }
+  void refresh_geometry() {
+    int model = 0;
+    slamhip_or_die(slamhip_map_info(_ctx, _id, &model, &_w, &_h, &_ox, &_oy, nullptr, nullptr), "map_info");
+    _stride = model == SLAMHIP_CELL_TBM ? 4 : (model == SLAMHIP_CELL_GMAPPING ? 3 : 1);
+    set_width(_w);
+    set_height(_h);
+  }
+  static constexpr int kChunk = 64;
+  static int floor_div(int v) { return v >= 0 ? v / kChunk : -((-v + kChunk - 1) / kChunk); }
+  slamhip_ctx *_ctx;
+  int _id;
+  double _unknown;
+  int _tbm_kind;
+  int _w = 0, _h = 0, _ox = 0, _oy = 0, _stride = 1;
+  mutable std::unordered_map<long long, std::vector<Cell>> _chunks;
+};
+
+class HipResidentWorld : public LaserScanGridWorld {
+public:
+  struct Config {
+    double localized_scan_quality = 1.0, raw_scan_quality = 1.0;  // SingleStateHypothesisLSGWProperties
+    std::size_t scan_margin = 0;
+    slamhip_scan_adder_cfg adder{};  // init_scan_adder + the cell kind of init_occupied_area_model
+    int cell_model = SLAMHIP_CELL_OCC;
+    GridMapParams map{100, 100, 0.1};
+    double unknown[4] = {0.5, 0, 0, 0};  // the cell prototype's payload
+    int map_id = 0;
+    int tbm_kind = 0;  // TBM cells: 0 tbm_consistent, 1 tbm_unknown_even_occ (what map() reports as occupancy)
+    HipScanTrig trig{};
+  };
+  HipResidentWorld(slamhip_ctx *ctx, std::shared_ptr<HipGridScanMatcher> gsm, const Config &cfg)
+      : _ctx{ctx}, _gsm{std::move(gsm)}, _cfg{cfg} {
+    // RegularSquaresGrid starts with the origin in the middle (regular_squares_grid.h:120-122)
+    const int w = cfg.map.width_cells, h = cfg.map.height_cells;
+    slamhip_or_die(slamhip_map_bind(ctx, cfg.map_id, cfg.cell_model, w, h, w / 2, h / 2, cfg.map.meters_per_cell,
+                                    cfg.unknown), "map_bind");
+    slamhip_or_die(slamhip_map_set_auto_grow(ctx, cfg.map_id, 1), "map_set_auto_grow");
+    _view = std::make_shared<HipResidentMapView>(ctx, cfg.map_id, cfg.map, 0.5, cfg.tbm_kind);
+  }
+
+  auto scan_matcher() { return std::static_pointer_cast<GridScanMatcher>(_gsm); }
+  void add_sm_observer(std::shared_ptr<GridScanMatcherObserver> obs) { _gsm->subscribe(obs); }
+  void remove_sm_observer(std::shared_ptr<GridScanMatcherObserver> obs) { _gsm->unsubscribe(obs); }
+  const GridMap &map() const override { return *_view; }
+  using LaserScanGridWorld::map;
+  long long cell_updates() const { return _cell_updates; }
+
+  void handle_observation(TransformedLaserScan &tr_scan) override {
+    _gsm->reset_state();
+    auto pose_delta = RobotPoseDelta{};
+    _gsm->process_scan(tr_scan, pose(), map(), pose_delta);  // the mirror is resident: nothing is uploaded
+    update_robot_pose(pose_delta);
+    tr_scan.quality = pose_delta ? _cfg.localized_scan_quality : _cfg.raw_scan_quality;
+
+    // GridMapScanAdder::append_scan (grid_map_scan_adders.h:54-75): the points [margin, n - margin - 1]
+    const auto &pts = tr_scan.scan.points();
+    if (pts.empty()) return;
+    const size_t first = _cfg.scan_margin, last = pts.size() - _cfg.scan_margin - 1;
+    std::vector<double> r, a;
+    std::vector<int> occ;
+    for (size_t i = first; i <= last && i < pts.size(); ++i) {
+      r.push_back(pts[i].range());
+      a.push_back(pts[i].angle());
+      occ.push_back(pts[i].is_occupied() ? 1 : 0);
+    }
+    const int n = (int)r.size();
+    std::vector<double> c(n), s(n);
+    if (_cfg.trig.mode == SLAMHIP_TRIG_CACHED)
+      slamhip_or_die(slamhip_beam_trig_cached(n, a.data(), _cfg.trig.a_min, _cfg.trig.a_max, _cfg.trig.a_inc, c.data(),
+                                              s.data()), "beam_trig_cached");
+    else
+      slamhip_or_die(slamhip_beam_trig_raw(n, a.data(), c.data(), s.data()), "beam_trig_raw");
+    slamhip_scan_adder_cfg adder = _cfg.adder;
+    adder.scan_quality = tr_scan.quality;
+    const RobotPose p = pose();
+    const double p3[3] = {p.x, p.y, p.theta};
+    long long nu = 0;
+    slamhip_or_die(slamhip_map_append_scan(_ctx, _cfg.map_id, &adder, p3, n, r.data(), c.data(), s.data(), occ.data(),
+                                           &nu), "map_append_scan");
+    _cell_updates += nu;
+    _view->invalidate();
+  }
+
+private:
+  slamhip_ctx *_ctx;
+  std::shared_ptr<HipGridScanMatcher> _gsm;
+  Config _cfg;
+  std::shared_ptr<HipResidentMapView> _view;
+  long long _cell_updates = 0;
+};
+
+// the factory next to init_1h_slam (src/utils/init_slam.h:12-25): same properties
+inline std::shared_ptr<HipResidentWorld> init_hip_resident_1h_slam(const PropertiesProvider &props,
+                                                                   slamhip_ctx *ctx = nullptr, int map_id = 0) {
+  if (!ctx) slamhip_or_die(slamhip_ctx_create(props.get_int("slam/scmtch/hip/device", 0), &ctx), "ctx_create");
+  HipResidentWorld::Config cfg;
+  std::tie(cfg.localized_scan_quality, cfg.raw_scan_quality) = init_pose_quality_estimators(props);
+  cfg.map = init_grid_map_params(props);
+  cfg.map_id = map_id;
+  const auto grid = props.get_str("slam/mapping/grid/type", "<undefined>");
+  if (grid != "unbounded_plain" && grid != "unbounded_lazy_tiled") {
+    std::cerr << "the resident world keeps an unbounded dense window; grid type " << grid << " is outside it" << std::endl;
+    std::exit(-1);
+  }
+  // init_occupied_area_model (init_occupancy_mapping.h:94-113): the cell kind is the update rule
+  const auto area = props.get_str("slam/mapping/grid/area/type", "<undefined>");
+  const bool occupancy_oie = props.get_str(Slam_SM_NS + "oie/type", "discrepancy") == "occupancy";
+  if (area.rfind("tbm", 0) == 0) {
+    if (occupancy_oie) {
+      std::cerr << "TBM cells scored through the occupancy OIE need the host map (init_hip_1h_slam)" << std::endl;
+      std::exit(-1);
+    }
+    cfg.cell_model = SLAMHIP_CELL_TBM;
+    cfg.tbm_kind = area == "tbm_unknown_even_occ" ? 1 : 0;
+    cfg.adder.rule = SLAMHIP_RULE_TBM;
+    const double vacuous[4] = {1.0, 0.0, 0.0, 0.0};  // TbmBaseCell: total ignorance (tbm_grid_cells.h:12-19)
+    std::memcpy(cfg.unknown, vacuous, sizeof(vacuous));
+  } else if (area == "mean_probability" || area == "affine_quality_merge") {
+    cfg.cell_model = SLAMHIP_CELL_OCC;
+    cfg.adder.rule = area == "mean_probability" ? SLAMHIP_RULE_MEAN : SLAMHIP_RULE_AFFINE;
+    cfg.unknown[0] = 0.5;  // Occupancy{0.5, 1} (naive_grid_cells.h:10,29)
+  } else {
+    std::cerr << "Unknown occupied area type: " << area << std::endl;
+    std::exit(-1);
+  }
+  // init_occ_estimator / init_scan_adder (init_occupancy_mapping.h:38-92)
+  cfg.adder.base_occupied_prob = props.get_dbl("slam/occupancy_estimator/base_occupied/prob", 0.95);
+  cfg.adder.base_occupied_qual = props.get_dbl("slam/occupancy_estimator/base_occupied/qual", 1.0);
+  cfg.adder.base_empty_prob = props.get_dbl("slam/occupancy_estimator/base_empty/prob", 0.01);
+  cfg.adder.base_empty_qual = props.get_dbl("slam/occupancy_estimator/base_empty/qual", 1.0);
+  const auto est = props.get_str("slam/occupancy_estimator/type", "const");
+  if (est != "const" && est != "area") {
+    std::cerr << "Unknown estimator type: " << est << std::endl;
+    std::exit(-1);
+  }
+  cfg.adder.occupancy_estimator = est == "area" ? 1 : 0;
+  if (props.get_str("slam/mapping/observation_quality_estimator/typetype", "idle") != "idle") {
+    std::cerr << "only the idle observation-quality estimator is on the HIP path" << std::endl;
+    std::exit(-1);
+  }
+  cfg.adder.blur = props.get_dbl("slam/mapping/blur", 0.0);
+  cfg.adder.max_range = props.get_dbl("slam/mapping/max_range", std::numeric_limits<double>::infinity());
+  cfg.adder.scan_quality = 1.0;
+  auto gsm = std::dynamic_pointer_cast<HipGridScanMatcher>(init_hip_scan_matcher(props, ctx, map_id));
+  gsm->set_resident_map(true);
+  return std::make_shared<HipResidentWorld>(ctx, gsm, cfg);
+}
+
+#endif  // SLAMHIP_RESIDENT_WORLD_H

@@ -218,3 +218,51 @@ def test_non_finite_end_points_are_rejected_or_range_gated(pkg, ctx):
     assert 0 < n_gated < n_good
     assert ctx.map_append_scan(3, rule, pose, good, cos_a, sin_a) == n_good
     ctx.map_release(3)
+
+
+@pytest.mark.parametrize("name", ["mean", "tbm", "gmapping"])
+def test_window_grows_by_itself_like_an_unbounded_map(pkg, ctx, name):
+    """slamhip_map_set_auto_grow: the same crafted scans appended to a 16x16-cell window that has to grow on every
+    side (UnboundedPlainGridMap::ensure_inside, plain_grid_map.h:133-173: old cells keep their external place, new
+    area holds the prototype) and to a fixed 400x400 window end in the same cells -- payload and update counters --
+    and a window without the switch refuses the scan."""
+    cell_model, rule, st, n_aux = KINDS[name]
+    unknown = {0: [0.5], 1: [1.0, 0.0, 0.0, 0.0], 2: [-1.0, 0.0, 0.0]}[cell_model]
+    ctx.map_bind(3, cell_model, SIZE, SIZE, (SIZE // 2, SIZE // 2), SCALE, unknown)
+    ctx.map_bind(4, cell_model, 16, 16, (8, 8), SCALE, unknown)
+    scans = crafted_scans()
+    pose, rng, ang, occ, blur, max_range = scans[0]
+    c, s = pkg.beam_trig(ang)
+    with pytest.raises(pkg.SlamHipError):
+        ctx.map_append_scan(4, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range)
+    ctx.map_release(4)  # (cells inside the window were updated: start over -- a re-bind alone would keep them)
+    ctx.map_bind(4, cell_model, 16, 16, (8, 8), SCALE, unknown)
+    ctx.map_set_auto_grow(4, True)
+    for pose, rng, ang, occ, blur, max_range in scans:
+        c, s = pkg.beam_trig(ang)
+        a = ctx.map_append_scan(3, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range)
+        b = ctx.map_append_scan(4, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range)
+        assert a == b
+    info = ctx.map_info(4)
+    assert info["times_grown"] >= 2 and info["width"] > 16 and info["height"] > 16 and info["cell_model"] == cell_model
+    ox, oy = info["origin"]
+    # the two windows in external cells: equal where they overlap, the prototype where only one of them reaches
+    # (the growth margin of the small one may stick out of the fixed one and vice versa)
+    W, H = info["width"], info["height"]
+    big = ctx.map_download_window(3, 0, 0, SIZE, SIZE, st)
+    small = ctx.map_download_window(4, 0, 0, W, H, st)
+    x0, y0 = SIZE // 2 - ox, SIZE // 2 - oy  # fixed-window coordinates of the grown window's cell (0, 0)
+    bx0, by0, bx1, by1 = max(x0, 0), max(y0, 0), min(x0 + W, SIZE), min(y0 + H, SIZE)
+    assert bx1 - bx0 > 150 and by1 - by0 > 150
+    np.testing.assert_array_equal(small[by0 - y0:by1 - y0, bx0 - x0:bx1 - x0], big[by0:by1, bx0:bx1])
+    outside = np.ones((SIZE, SIZE), bool)
+    outside[by0:by1, bx0:bx1] = False
+    assert (big[outside] == np.array(unknown)).all()
+    inside = np.zeros((H, W), bool)
+    inside[by0 - y0:by1 - y0, bx0 - x0:bx1 - x0] = True
+    assert (small[~inside] == np.array(unknown)).all()
+    if n_aux:
+        np.testing.assert_array_equal(ctx.map_download_aux(4, bx0 - x0, by0 - y0, bx1 - bx0, by1 - by0, n_aux),
+                                      ctx.map_download_aux(3, bx0, by0, bx1 - bx0, by1 - by0, n_aux))
+    ctx.map_release(3)
+    ctx.map_release(4)
