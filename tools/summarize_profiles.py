@@ -121,7 +121,11 @@ for wl in ("hc", "sweep", "mc", "pf"):
 for wl in list(traffic):
     pj = os.path.join(src, "%s.plain.json" % wl)
     try:
-        pd_ = json.load(open(pj))
+        if os.path.exists(pj) and os.path.getsize(pj) > 0:
+            pd_ = json.load(open(pj))
+        else:
+            # on the GPU box the PMC passes come first: the SQ pass's own bench line has the same launch shape
+            pd_ = [json.loads(ln) for ln in open(os.path.join(src, "pmc_%s_sq.log" % wl)) if ln.startswith('{"metric')][-1]
         r = pd_["particle_filter"]["roofline"] if wl == "pf" else pd_["roofline"]
         upl = r["units_launched"] / max(r["launches"], 1)
         if "valu" in traffic[wl]:
