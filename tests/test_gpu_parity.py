@@ -301,11 +301,13 @@ def test_gmapping_filter_vs_reference_golden(pkg, ctx, scenario):
     ctx.map_release(5)
 
 
-def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle):
-    """BASELINE cfg-4 shape (100 particles, 1080 beams, GMapping cell/OOPE, HC(6, 0.1, 0.1)) on a
-    2000x2000 @0.05 m map: the lock-step GPU filter against the sequential CPU oracle."""
+@pytest.mark.parametrize("size", [2000, 4000])
+def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle, size):
+    """BASELINE cfg 4 (100 particles, 1080 beams, GMapping cell/OOPE, HC(6, 0.1, 0.1)) on a 2000x2000 and on the
+    configuration's own 4000x4000 @0.05 m map (0.5 GB of cells in HBM): the lock-step GPU filter against the
+    sequential CPU oracle."""
     from synth import make_scene
-    sc = make_scene(cell_model=2, size=2000, scale=0.05, n_beams=1080, seed=11)
+    sc = make_scene(cell_model=2, size=size, scale=0.05, n_beams=1080, seed=11)
     m, scan = sc["map"], sc["scan"]
     ctx.upload_map(6, m)
     n = 100
