@@ -43,6 +43,7 @@
 namespace slamhip {
 
 constexpr int kHcMaxInst = 64;    // round instances per shape: one lane of a wave64 each
+constexpr int kHcDefaultInst = 42; // instances per shape by default: 6 x 42 + 1 = 253 workgroups, one per CU of an MI355X
 constexpr int kHcMaxSeg = 14;     // accepted moves on one path (deeper children are not speculated)
 constexpr int kHcShapes = 8;      // acceptance-rate buckets
 constexpr int kHcSlots = 6 * kHcMaxInst + 1;  // workgroups per super-step; the last one scores the initial pose

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   __shared__ int s_go, s_mode;
   __shared__ double s_part[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int slot = blockIdx.x;
+  // the grid holds 6 x (instances of the largest shape) scoring workgroups and, last, the bookkeeping one, which
+  // keeps slot kHcSlots - 1 whatever the grid size
+  const int slot = blockIdx.x + 1 == gridDim.x ? kHcSlots - 1 : (int)blockIdx.x;
   HcChainCtl *ctl = a.ctl;
   // ---- loads that depend on nothing: issued first, they overlap the replay below (the done test waits
   // for its word only after everything else is in flight)
@@ -548,14 +550,15 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
 #define HC_LAUNCH(NTV)                                                                                          \
   do {                                                                                                          \
     if (e0 || e1)                                                                                               \
-      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(kHcSlots), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
+      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
     else                                                                                                        \
-      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(kHcSlots), dim3(NTV), shm, stream, a, k);  \
+      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid), dim3(NTV), shm, stream, a, k);     \
   } while (0)
 
 template <int MODEL, bool SEQ>
 static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
   constexpr int KB = 0;
+  const int grid = 6 * a.max_inst + 1;
   const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
   switch (nt) {
     case 256: HC_LAUNCH(256); break;
@@ -565,14 +568,17 @@ static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t str
   return hipGetLastError();
 }
 
-// GMapping OOPE: 512 threads per pose (two workgroups per CU: all slots of a super-step resident at once)
+// GMapping OOPE: 512 threads per pose (two workgroups per CU: all slots of a 64-instance super-step resident at
+// once) or 1024 (one per CU: trees of at most 42 instances)
 template <int KB>
-static hipError_t launch_gm(const HcChainArgs &a, int k, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+static hipError_t launch_gm(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
   constexpr int MODEL = SLAMHIP_CELL_GMAPPING;
   constexpr bool SEQ = false;
+  const int grid = 6 * a.max_inst + 1;
   const size_t shm = (size_t)KB * 256 * sizeof(double) + 4 * KB * sizeof(int2) + 4 * KB * sizeof(int) +
                      2 * (size_t)KB * 256 * sizeof(int);
-  HC_LAUNCH(512);
+  if (nt == 1024) HC_LAUNCH(1024);
+  else HC_LAUNCH(512);
   return hipGetLastError();
 }
 #undef HC_LAUNCH
@@ -587,11 +593,11 @@ hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int
                  : launch_nt<SLAMHIP_CELL_TBM, false>(a, k, nt, stream, e0, e1);
   if (cell_model == SLAMHIP_CELL_GMAPPING && !a.seq) {
     switch ((a.scan.n + 255) / 256) {
-      case 1: return launch_gm<1>(a, k, stream, e0, e1);
-      case 2: return launch_gm<2>(a, k, stream, e0, e1);
-      case 3: return launch_gm<3>(a, k, stream, e0, e1);
-      case 4: return launch_gm<4>(a, k, stream, e0, e1);
-      case 5: return launch_gm<5>(a, k, stream, e0, e1);
+      case 1: return launch_gm<1>(a, k, nt, stream, e0, e1);
+      case 2: return launch_gm<2>(a, k, nt, stream, e0, e1);
+      case 3: return launch_gm<3>(a, k, nt, stream, e0, e1);
+      case 4: return launch_gm<4>(a, k, nt, stream, e0, e1);
+      case 5: return launch_gm<5>(a, k, nt, stream, e0, e1);
       default: break;
     }
   }

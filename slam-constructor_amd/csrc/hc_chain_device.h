@@ -50,6 +50,7 @@ struct HcChainArgs {
                // beam-order sums (hc_round_decide)
   HcChainCtl *ctl;
   const HcShape *shapes;  // kHcShapes of them
+  int max_inst;  // instances of the largest shape: the grid is 6 x max_inst + 1 workgroups
   unsigned long long n_inst;  // round instances of shape b in byte b (a dynamic index into an array of
                               // kernel arguments is a global load: 1 us on the replay's critical path)
   double init[3];

@@ -31,7 +31,8 @@ struct slamhip_matcher {
   unsigned chain_epoch = 0;
   double chain_steps_avg = 12.0;
   int chain_mode = -1;  // -1 = decide from the environment at the first match, 0 off, 1 on
-  int chain_nt = 512, chain_ahead = 3;
+  int chain_nt = 1024, chain_ahead = 3;
+  int chain_max_inst = slamhip::kHcMaxInst;  // instances of the largest shape (grid size of a super-step)
   int tie_check = -1;  // checked default mode: -1 = from the environment (SLAMHIP_TIE_CHECK=0 turns it off), 0, 1
   long long chain_rescored = 0;  // super-steps (device chain) / batches (host-driven) of the last match scored twice
   long long rescored_poses = 0;
@@ -124,10 +125,20 @@ int chain_prepare(slamhip_matcher *m) {
   std::vector<HcShape> shapes(kHcShapes);
   const double boost = getenv("SLAMHIP_HC_BOOST") ? atof(getenv("SLAMHIP_HC_BOOST")) : 1.0;
   const double reach = getenv("SLAMHIP_HC_CHAIN_REACH") ? atof(getenv("SLAMHIP_HC_CHAIN_REACH")) : 0.002;
-  const int max_inst = getenv("SLAMHIP_HC_CHAIN_INST") ? atoi(getenv("SLAMHIP_HC_CHAIN_INST")) : kHcMaxInst;
+  const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
+  // 42 instances = 253 workgroups of 1024 threads: ONE per CU, all resident at once.  Measured against 64
+  // instances x 512 threads (two workgroups per CU, a tree half as large again): cfg2 0.149 -> 0.138 ms per match
+  // (one more super-step, each 0.8 us shorter), the shared-map filter step 4.3 k -> 5.0 k particles/s (K3's one-pose
+  // body 10.7 -> 7 us); 32 or 52 instances, or 512 threads with 42, are slower again.
+  const char *ie = getenv(gm ? "SLAMHIP_GM_CHAIN_INST" : "SLAMHIP_HC_CHAIN_INST");
+  const int max_inst = std::min(kHcMaxInst, std::max(1, ie ? atoi(ie) : kHcDefaultInst));
+  if (gm)
+    if (const char *t = getenv("SLAMHIP_GM_CHAIN_THREADS")) m->chain_nt = atoi(t) == 1024 ? 1024 : 512;
+  m->chain_max_inst = 1;
   for (int b = 0; b < kHcShapes; ++b) {
     hc_build_shape(hc_bucket_rate(b), boost, reach, max_inst, &shapes[b]);
     m->shape_n_inst[b] = shapes[b].n_inst;
+    m->chain_max_inst = std::max(m->chain_max_inst, shapes[b].n_inst);
   }
   SLAMHIP_CHECK(hipMemcpy(m->d_shapes, shapes.data(), sizeof(HcShape) * kHcShapes, hipMemcpyHostToDevice));
   const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
@@ -152,6 +163,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
                                 hipHostMallocMapped | hipHostMallocCoherent));
   }
   a.oie = m->cfg.oie;
+  a.max_inst = m->chain_max_inst;
   a.gm.fullness_th = m->cfg.gm_fullness_th;
   a.gm.window = m->cfg.gm_window;
   a.gm_cx = ctx->gm_cx;

