@@ -75,7 +75,8 @@ struct MuScratch {
   // counting sort of a plain call's records (k_mu_rank): per-cell record counts of the key window (all zero between
   // updates), chain starts, the records as scattered
   size_t cap_bins = 0, scan_temp_bytes = 0;
-  unsigned *bins = nullptr, *offs = nullptr, *skeys = nullptr, *sbeam = nullptr;
+  unsigned *bins = nullptr, *offs = nullptr;
+  uint2 *srec = nullptr;  // (key, beam) of every record, as scattered into its cell's chain
   unsigned *h_offsets = nullptr;  // pinned: first record slot of every beam, computed by the host
   unsigned long long *near_bits = nullptr;  // [kNearSide^2][64] words: beams (up to 4096) visiting the cells next to the robot
   void *scan_temp = nullptr;
@@ -180,7 +181,10 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.beam_info, sizeof(MuBeam) * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
     SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
-    if (!sc.error_flag) SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
+    if (!sc.error_flag) {
+      SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), ctx->stream));
+    }
     if (sc.h_offsets) hipHostFree(sc.h_offsets);
     SLAMHIP_CHECK(hipHostMalloc(&sc.h_offsets, sizeof(unsigned) * (cap + 1), hipHostMallocDefault));
     if (!sc.near_bits)
@@ -297,7 +301,6 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, ctx->stream, a);
   };
   if (!m.auto_grow) {
-    launch_count();  // runs while the host walks the beams
     const int hrc = host_pass();
     if (hrc) return hrc;
   } else {
@@ -326,7 +329,6 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
       ctx->maps[map_id].grown = grown;
       fill_map();
     }
-    launch_count();
   }
   if (total == 0) {
     if (n_updates_out) *n_updates_out = 0;
@@ -335,9 +337,9 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   if (total > sc.cap_records) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (void *p : {(void *)sc.keys, (void *)sc.keys_sorted, (void *)sc.order, (void *)sc.order_sorted,
-                    (void *)sc.srt_prob, (void *)sc.srt_qual, sc.temp, (void *)sc.skeys, (void *)sc.sbeam})
+                    (void *)sc.srt_prob, (void *)sc.srt_qual, sc.temp, (void *)sc.srec})
       if (p) hipFree(p);
-    sc.skeys = sc.sbeam = nullptr;
+    sc.srec = nullptr;
     size_t cap = 1 << 16;
     while (cap < total) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&sc.keys, sizeof(unsigned) * cap));
@@ -364,7 +366,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   const long long wy1 = std::min((long long)m.height - 1, (long long)bb_hi_y + m.origin_y);
   const long long n_bins = (wx1 >= wx0 && wy1 >= wy0) ? (wx1 - wx0 + 1) * (wy1 - wy0 + 1) : 0;
   const bool counting = !force_radix && n_bins > 0 && n_bins <= (1ll << 23) && near_words <= kNearMaxWords;
-  if (counting && ((size_t)n_bins + 1 > sc.cap_bins || !sc.skeys)) {
+  if (counting && (size_t)n_bins + 1 > sc.cap_bins) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (void *p : {(void *)sc.bins, (void *)sc.offs, sc.scan_temp})
       if (p) hipFree(p);
@@ -381,10 +383,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, sc.scan_temp_bytes));
     sc.cap_bins = cap;
   }
-  if (counting && !sc.skeys) {
-    SLAMHIP_CHECK(hipMalloc(&sc.skeys, sizeof(unsigned) * sc.cap_records));
-    SLAMHIP_CHECK(hipMalloc(&sc.sbeam, sizeof(unsigned) * sc.cap_records));
-  }
+  if (counting && !sc.srec) SLAMHIP_CHECK(hipMalloc(&sc.srec, sizeof(uint2) * sc.cap_records));
   if (counting) {
     a.key_x0 = (int)wx0;
     a.key_y0 = (int)wy0;
@@ -401,7 +400,13 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     a.key_x0 = a.key_y0 = 0;
     a.key_w = m.pitch;
   }
-  hipLaunchKernelGGL(k_mu_emit<unsigned>, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, sc.order);
+  // counting-sorted updates on the zero-copy path need no k_mu_count: k_mu_emit does its work, k_mu_finish of the
+  // update before cleared the status word
+  const bool fused = counting && ctx->low_latency;
+  if (!fused) launch_count();
+  if (!fused) hipLaunchKernelGGL((k_mu_emit<unsigned, -1>), dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, sc.order);
+  else if (a.est_kind == 1) hipLaunchKernelGGL((k_mu_emit<unsigned, 1>), dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, sc.order);
+  else hipLaunchKernelGGL((k_mu_emit<unsigned, 0>), dim3((n + 3) / 4), dim3(256), 0, ctx->stream, a, sc.order);
   if (counting) {
     hipLaunchKernelGGL(k_mu_near_bits, dim3(near_words, kNearSide), dim3(64), 0, ctx->stream, a);
     size_t tb = sc.scan_temp_bytes;
@@ -409,12 +414,12 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
                                           ctx->stream));
     const dim3 rgrid((total + 255) / 256);
     hipLaunchKernelGGL(k_mu_scatter, rgrid, dim3(256), 0, ctx->stream, a, (const unsigned *)sc.keys, (const unsigned *)sc.order,
-                       total, (const unsigned *)sc.offs, sc.skeys, sc.sbeam);
+                       total, (const unsigned *)sc.offs, sc.srec);
     if (a.est_kind == 1)
-      hipLaunchKernelGGL(k_mu_rank<1>, rgrid, dim3(256), 0, ctx->stream, a, (const unsigned *)sc.skeys, (const unsigned *)sc.sbeam,
+      hipLaunchKernelGGL(k_mu_rank<1>, rgrid, dim3(256), 0, ctx->stream, a, (const uint2 *)sc.srec,
                          (const unsigned *)sc.offs, total, sc.keys_sorted, sc.order_sorted, sc.srt_prob, sc.srt_qual);
     else
-      hipLaunchKernelGGL(k_mu_rank<0>, rgrid, dim3(256), 0, ctx->stream, a, (const unsigned *)sc.skeys, (const unsigned *)sc.sbeam,
+      hipLaunchKernelGGL(k_mu_rank<0>, rgrid, dim3(256), 0, ctx->stream, a, (const uint2 *)sc.srec,
                          (const unsigned *)sc.offs, total, sc.keys_sorted, sc.order_sorted, sc.srt_prob, sc.srt_qual);
   } else {
     size_t tb = sc.temp_bytes;
@@ -526,7 +531,7 @@ template <typename Key>
 int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t beams, unsigned end_bit, hipStream_t st) {
   Key *keys = (Key *)sc.keys, *keys_sorted = (Key *)sc.keys_sorted;
   const dim3 bgrid((unsigned)((beams + 255) / 256)), rgrid((total + 255) / 256);
-  hipLaunchKernelGGL(k_mu_emit<Key>, dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, st, a, sc.order);
+  hipLaunchKernelGGL((k_mu_emit<Key, -1>), dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, st, a, sc.order);
   size_t tb = sc.temp_bytes;
   SLAMHIP_CHECK(rocprim::radix_sort_pairs<BatchSortConfig<Key>>(sc.temp, tb, keys, keys_sorted, sc.order,
                                                                 sc.order_sorted, total, 0,
@@ -805,8 +810,7 @@ void mu_release(slamhip_ctx *ctx) {
     for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.keys, (void *)s.keys_sorted, (void *)s.order,
                     (void *)s.order_sorted, (void *)s.beam_info, (void *)s.beam_end, (void *)s.scan,
                     (void *)s.srt_prob, (void *)s.srt_qual, (void *)s.occ, (void *)s.error_flag,
-                    (void *)s.n_updates, s.temp, (void *)s.bins, (void *)s.offs, (void *)s.skeys,
-                    (void *)s.sbeam, s.scan_temp, (void *)s.near_bits})
+                    (void *)s.n_updates, s.temp, (void *)s.bins, (void *)s.offs, (void *)s.srec, s.scan_temp, (void *)s.near_bits})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
     if (s.h_offsets) hipHostFree(s.h_offsets);

@@ -336,12 +336,47 @@ __device__ void mu_walk_beam(const MuArgs &a, int b) {  // b = global beam index
 // diagonals, axis-parallel beams, walks that rounding sends astray -- lane 0 redoes the beam with the
 // sequential walk (mu_walk_beam: tie rule, Bresenham fail-over), so the result is the same either way.
 // The beam of every record (the value sorted along) is written here too (k_mu_beam_ids is gone).
-template <typename KeyT>
+// FUSE >= 0 (plain call, counting sort): k_mu_count's work for occupancy estimator FUSE is done here, by every
+// lane of the beam's wave alike (one dispatch less per update; the status words are cleared by k_mu_finish of the
+// update before)
+template <typename KeyT, int FUSE>
 __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
+  if (FUSE >= 0 && a.near_bits) {
+    const int words = (2 * a.near_r + 1) * (2 * a.near_r + 1) * a.near_words;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < words; w += gridDim.x * blockDim.x) a.near_bits[w] = 0ull;
+  }
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.n * a.n_jobs) return;
   const int lane = threadIdx.x & 63;
-  const unsigned cap = a.counts[b];
+  unsigned cap;
+  double wx, wy;
+  int ex, ey;
+  if (FUSE >= 0) {
+    const MuJob j = mu_job(a, b);
+    mu_endpoint(a, j, b % a.n, &wx, &wy);
+    const double ddx = wx - j.px, ddy = wy - j.py;
+    cap = 0u;
+    ex = ey = 0;
+    if (!(a.max_range_sq < ddx * ddx + ddy * ddy)) {
+      const int rcx = (int)floor(j.px / a.scale), rcy = (int)floor(j.py / a.scale);
+      const MuBeam bm = mu_beam<(FUSE > 0 ? 1 : 0)>(a, j, b, wx, wy);
+      ex = bm.ex;
+      ey = bm.ey;
+      cap = (unsigned)(abs(ex - rcx) + abs(ey - rcy) + 1);
+      if (lane == 0) a.beam_info[b] = bm;
+    }
+    if (lane == 0) {
+      a.beam_end[2 * b] = wx;
+      a.beam_end[2 * b + 1] = wy;
+      if (FUSE > 0) {
+        a.beam_inv[2 * b] = 1.0 / ddx;
+        a.beam_inv[2 * b + 1] = 1.0 / ddy;
+      }
+      a.counts[b] = cap;
+    }
+  } else {
+    cap = a.counts[b];
+  }
   if (cap == 0) return;
   const unsigned base = a.host_offsets ? a.host_offsets[b] : a.offsets[b];
   if ((unsigned long long)base + cap > a.keys_cap) {  // the host sized the buffer for another count: no write
@@ -353,12 +388,16 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
   }
   if (a.host_offsets && lane == 0) a.offsets[b] = base;
   const MuJob jb = mu_job(a, b);
-  const double wx = a.beam_end[2 * b], wy = a.beam_end[2 * b + 1];
+  if (FUSE < 0) {
+    wx = a.beam_end[2 * b];
+    wy = a.beam_end[2 * b + 1];
+    ex = a.beam_info[b].ex;
+    ey = a.beam_info[b].ey;
+  }
   const double scale = a.scale;
   const double d_x = wx - jb.px, d_y = wy - jb.py;
   const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
   const int bx = (int)floor(jb.px / scale), by = (int)floor(jb.py / scale);
-  const int ex = a.beam_info[b].ex, ey = a.beam_info[b].ey;
   const double mid_x = (bx + 0.5) * scale, mid_y = (by + 0.5) * scale;
   const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
   const double e0 = mid_cell_seg_y - mid_y * d_x;
@@ -403,6 +442,7 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
   if (!ok) {
     // the sequential walk decides (it rewrites every key of the beam and the padding)
     for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
+    if (FUSE >= 0) __threadfence();  // lane 0's own stores above (counts, beam_end, beam_info), read back by the walk
     if (lane == 0) mu_walk_beam<KeyT>(a, b);
     __threadfence();  // lane 0's keys, read back by the whole wave below
   } else if (__any(bad) && lane == 0) {
@@ -564,7 +604,7 @@ __global__ __launch_bounds__(64) void k_mu_near_bits(MuArgs a) {
 }
 
 __global__ void k_mu_scatter(MuArgs a, const unsigned *keys, const unsigned *beam_of, unsigned total, const unsigned *offs,
-                             unsigned *skeys, unsigned *sbeam) {
+                             uint2 *srec) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const unsigned key = keys[i];
@@ -590,12 +630,11 @@ __global__ void k_mu_scatter(MuArgs a, const unsigned *keys, const unsigned *bea
     }
     pos += r;
   }
-  skeys[pos] = key;
-  sbeam[pos] = beam;
+  srec[pos] = make_uint2(key, beam);  // one 8-byte store per record
 }
 
 template <int EST>
-__global__ void k_mu_rank(MuArgs a, const unsigned *skeys, const unsigned *sbeam, const unsigned *offs, unsigned total,
+__global__ void k_mu_rank(MuArgs a, const uint2 *srec, const unsigned *offs, unsigned total,
                           unsigned *keys_sorted, unsigned *beam_sorted, double *srt_prob, double *srt_qual) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -606,12 +645,13 @@ __global__ void k_mu_rank(MuArgs a, const unsigned *skeys, const unsigned *sbeam
     beam_sorted[i] = 0u;
     return;
   }
-  const unsigned key = skeys[i], beam = sbeam[i];
+  const uint2 rec = srec[i];
+  const unsigned key = rec.x, beam = rec.y;
   unsigned at = i;
   if (mu_near_index(a, key) < 0) {
     const unsigned start = offs[key], end = offs[key + 1];
     unsigned rank = 0;
-    for (unsigned j = start; j < end; ++j) rank += sbeam[j] < beam ? 1u : 0u;
+    for (unsigned j = start; j < end; ++j) rank += srec[j].y < beam ? 1u : 0u;
     at = start + rank;
   } else {
     a.bins[key] = 0u;  // (far bins were counted down by k_mu_scatter)
@@ -902,6 +942,7 @@ __global__ void k_mu_finish(const int *error_flag, const unsigned long long *n_p
                             unsigned long long *h_status, unsigned *flag, unsigned seq) {
   h_status[0] = (unsigned long long)*error_flag;
   h_status[1] = *n_padding;
+  *const_cast<int *>(error_flag) = 0;  // the next update may start without k_mu_count (fused into k_mu_emit)
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

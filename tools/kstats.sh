@@ -2,7 +2,7 @@
 # tools/kstats.sh <bench args...> -- on the GPU box: rocprofv3 kernel stats of one bench.py command, top kernels printed
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/kstats
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -o ks -- python3 bench.py "$@" > gpurun_out/kstats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -o ks -- python3 bench.py "$@" > gpurun_out/kstats.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/kstats/**/*kernel_stats.csv", recursive=True)[0]
