@@ -135,19 +135,31 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   HC_PINF(a.scan.tot_w);
   const int pb = (k - 1) & 1;
   if (k > 0) {
+    // what the previous tree left behind: the slots of the largest shape's instances, and the bookkeeping slot
+    const int n_stage = 6 * a.max_inst;
     const double *sc_prev = ctl->scores[pb];
-    for (int i = t; i < kHcSlots; i += NT) s_sc[i] = sc_prev[i];
+    for (int i = t; i <= n_stage; i += NT) {
+      const int j = i < n_stage ? i : kHcSlots - 1;
+      s_sc[j] = sc_prev[j];
+    }
     const unsigned long long *wsrc = &ctl->walk[pb][0].w[0];
-    for (int q = t; q < kHcMaxInst * 16; q += NT) s_walk[(q >> 4) * kWalkStride + (q & 15)] = wsrc[q];
+    for (int q = t; q < a.max_inst * 16; q += NT) s_walk[(q >> 4) * kWalkStride + (q & 15)] = wsrc[q];
     if (t < (int)(sizeof(HcState) / 8))
       reinterpret_cast<double *>(&s_prev)[t] = reinterpret_cast<const double *>(&ctl->state[pb])[t];
     if (!GM && a.verify) {
-      for (int i = t; i < kHcSlots; i += NT) s_hash[i] = (unsigned)ctl->hashes[pb][i];
+      for (int i = t; i <= n_stage; i += NT) {
+        const int j = i < n_stage ? i : kHcSlots - 1;
+        s_hash[j] = (unsigned)ctl->hashes[pb][j];
+      }
     }
     if (GM) {
+      constexpr int kInfoWords = (int)(sizeof(GmPoseInfo) / 8);
       const double *isrc = reinterpret_cast<const double *>(&ctl->infos[pb][0]);
       double *idst = reinterpret_cast<double *>(&s_info[0]);
-      for (int q = t; q < (int)(kHcSlots * sizeof(GmPoseInfo) / 8); q += NT) idst[q] = isrc[q];
+      for (int q = t; q < (n_stage + 1) * kInfoWords; q += NT) {
+        const int j = q < n_stage * kInfoWords ? q : q - n_stage * kInfoWords + (kHcSlots - 1) * kInfoWords;
+        idst[j] = isrc[j];
+      }
     }
   }
   if (GM && t == 64) {
