@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--seq-sum", action="store_true",
                     help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
     ap.add_argument("--chain", type=int, default=-1,
-                    help="hill climbing on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
+                    help="the HC / MC accept chain on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
     ap.add_argument("--no-tie-check", action="store_true",
                     help="default mode without the check of comparisons the tree sum cannot settle")
     args = ap.parse_args()
@@ -801,11 +801,11 @@ def main():
         desc = "sweep: %d device-resident poses x %d beams per launch, %s" % (P, scan.n, desc)
     else:
         m = pkg.Matcher(ctx, kind, cfg, params)
-        if args.chain >= 0 and kind == "HC":
+        if args.chain >= 0 and kind in ("HC", "MC"):
             m.set_device_chain(1 if args.chain else 0, args.chain if args.chain > 1 else 0)
         if args.no_tie_check:
             m.set_tie_check(0)
-        on_device = kind == "HC" and args.chain != 0 and not args.strict
+        on_device = kind in ("HC", "MC") and args.chain != 0 and not args.strict
 
         def step():
             m.process_scan(0, sc["init_pose"])
@@ -838,11 +838,11 @@ def main():
     if m is not None:
         st = m.stats()
         if on_device:
-            kernel_name = "k_hc_chain_step"
+            kernel_name = "k_hc_chain_step" if kind == "HC" else "k_mc_chain_step"
         extra.update(scorer_calls_per_step=st["scorer_calls"], poses_evaluated_per_step=st["poses_evaluated"],
                      launches_per_step=st["launches"],
                      accept_chain=("on the device: one process_scan = a chain of kernels, each replaying the previous "
-                                   "one's speculation tree (csrc/hc_chain.hip)") if on_device else
+                                   "one's speculation tree (csrc/hc_chain.hip, csrc/mc_chain.hip)") if on_device else
                                   "on the host: speculative batches, replay between launches",
                      kernel_busy_frac=k_ms / (1e3 * dt_instrumented) if dt_instrumented > 0 else None,
                      host_us_last_step={k: round(st[k], 1) for k in ("build_us", "stage_us", "score_us", "replay_us")})

@@ -5,6 +5,7 @@
 
 #include "hc_chain_device.h"
 #include "hc_shape.h"
+#include "mc_chain_device.h"
 #include "matchers.h"
 
 struct slamhip_matcher {
@@ -40,6 +41,14 @@ struct slamhip_matcher {
   std::vector<unsigned> keep_fprints;
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
+  // Monte Carlo kept on the device (mc_chain.h)
+  bool is_mc = false;
+  slamhip::McChainCtl *d_mc = nullptr;
+  slamhip::McHostOut *h_mc = nullptr;
+  slamhip::McPair *d_tape = nullptr;
+  double *h_tape = nullptr;  // pinned staging of the tape window
+  size_t tape_cap = 0;
+  int mc_slots = 0;
 };
 
 using namespace slamhip;
@@ -81,6 +90,14 @@ int chain_release(slamhip_matcher *m) {
   if (m->h_chain) hipHostFree(m->h_chain);
   if (m->h_trace) hipHostFree(m->h_trace);
   if (m->d_stamps) hipFree(m->d_stamps);
+  if (m->d_mc) hipFree(m->d_mc);
+  if (m->d_tape) hipFree(m->d_tape);
+  if (m->h_mc) hipHostFree(m->h_mc);
+  if (m->h_tape) hipHostFree(m->h_tape);
+  m->d_mc = nullptr;
+  m->d_tape = nullptr;
+  m->h_mc = nullptr;
+  m->h_tape = nullptr;
   m->d_stamps = nullptr;
   m->d_chain = nullptr;
   m->d_shapes = nullptr;
@@ -273,6 +290,169 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   return SLAMHIP_OK;
 }
 
+// ---- Monte Carlo on the device (mc_chain.hip) -------------------------------------------------------
+// the 1-cell OOPE with device pose trigonometry on the zero-copy path, like the hill-climbing chain
+bool mc_chain_eligible(slamhip_matcher *m) {
+  if (!m->is_mc) return false;
+  if (m->cfg.oope != SLAMHIP_OOPE_OBSTACLE || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
+  if (m->max_batch < 64) return false;  // slamhip_matcher_set_batch asked for small batches
+  if (m->chain_mode < 0) {
+    const char *e = getenv("SLAMHIP_MC_CHAIN");
+    m->chain_mode = (e && e[0] == '0') ? 0 : 1;
+    if (const char *t = getenv("SLAMHIP_MC_CHAIN_THREADS")) m->chain_nt = atoi(t) == 512 ? 512 : 1024;
+    if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
+  }
+  return m->chain_mode == 1;
+}
+
+int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3], double out_delta[3],
+                          double *out_prob) {
+  slamhip_ctx *ctx = m->ctx;
+  auto *pe = static_cast<GaussianPoseEnumerator *>(m->pe.get());
+  const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
+  if (!m->d_mc) {
+    SLAMHIP_CHECK(hipMalloc(&m->d_mc, sizeof(McChainCtl)));
+    SLAMHIP_CHECK(hipMemset(m->d_mc, 0, sizeof(McChainCtl)));
+    SLAMHIP_CHECK(hipHostMalloc(&m->h_mc, sizeof(McHostOut), pinned));
+    std::memset(m->h_mc, 0, sizeof(McHostOut));
+    // 252 candidates + the bookkeeping workgroup = 253 workgroups of 1024 threads, one per CU (see chain_prepare)
+    const char *se = getenv("SLAMHIP_MC_CHAIN_SLOTS");
+    m->mc_slots = std::min(kMcSlots, std::max(1, se ? atoi(se) : 252));
+  }
+  McChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  int cell_model = 0;
+  int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
+  if (rc) return rc;
+  // the enumerator is reset when a match starts (pose_enumeration_scan_matcher.h:47): what carries over from
+  // match to match is the engine, i.e. the position on the pair tape.  A match draws three pairs per two
+  // candidates; every reset_shift (at most one per max_failed / 3 + 1 candidates) may drop a triple's second half.
+  pe->reset();
+  const size_t max_poses = pe->max_poses();
+  const size_t resets = max_poses / (pe->max_failed() / 3 + 1) + 2;
+  const size_t need = 3 * (max_poses / 2 + 2 + resets) + 8;
+  if (need > m->tape_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (m->d_tape) hipFree(m->d_tape);
+    if (m->h_tape) hipHostFree(m->h_tape);
+    m->d_tape = nullptr;
+    m->h_tape = nullptr;
+    size_t cap = 1024;
+    while (cap < need) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&m->d_tape, sizeof(McPair) * cap));
+    SLAMHIP_CHECK(hipHostMalloc(&m->h_tape, sizeof(McPair) * cap, hipHostMallocDefault));
+    m->tape_cap = cap;
+  }
+  const double t0 = MatchJob::now_us();
+  pe->copy_tape(need, m->h_tape);
+  SLAMHIP_CHECK(hipMemcpyAsync(m->d_tape, m->h_tape, sizeof(McPair) * need, hipMemcpyHostToDevice, ctx->stream));
+  m->t_stage_us = MatchJob::now_us() - t0;
+  const size_t trace_need = max_poses + 2;
+  if (m->has_obs && (!m->h_trace || (size_t)m->trace_cap < trace_need)) {
+    if (m->h_trace) hipHostFree(m->h_trace);
+    m->h_trace = nullptr;
+    m->trace_cap = (int)std::max<size_t>(1 << 16, trace_need);
+    SLAMHIP_CHECK(hipHostMalloc(&m->h_trace, sizeof(HcTraceEntry) * m->trace_cap, pinned));
+  }
+  static_assert(sizeof(McTraceEntry) == sizeof(HcTraceEntry), "one trace buffer serves both chains");
+  a.oie = m->cfg.oie;
+  a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
+  a.verify = (tie_check_default(m) && !a.seq) ? 1 : 0;
+  a.ctl = m->d_mc;
+  a.tape = m->d_tape;
+  a.n_slots = m->mc_slots;
+  for (int k = 0; k < 3; ++k) a.init[k] = init_pose[k];
+  a.td0 = pe->base_td();
+  a.rd0 = pe->base_rd();
+  a.max_failed = pe->max_failed();
+  a.max_poses = pe->max_poses();
+  unsigned epoch = ++m->chain_epoch;
+  if (epoch == 0) epoch = ++m->chain_epoch;
+  a.epoch = epoch;
+  a.host = m->h_mc;
+  a.trace = m->has_obs ? reinterpret_cast<McTraceEntry *>(m->h_trace) : nullptr;
+  a.trace_cap = m->has_obs ? m->trace_cap : 0;
+  volatile McHostOut *h = m->h_mc;
+  h->error = 0;
+  h->progress = 0;
+  int launched = 0;
+  auto launch_one = [&]() -> int {
+    hipEvent_t e0, e1;
+    int r = profile_event_pair(ctx, &e0, &e1);
+    if (r) return r;
+    SLAMHIP_CHECK(launch_mc_chain_step(a, cell_model, launched, m->chain_nt, ctx->stream, e0, e1));
+    ++launched;
+    return SLAMHIP_OK;
+  };
+  const int first = std::max(2, std::min(256, (int)(m->chain_steps_avg * 0.75)));
+  for (int i = 0; i < first; ++i) {
+    rc = launch_one();
+    if (rc) return rc;
+  }
+  unsigned long long spins = 0;
+  while (h->done_seq != epoch) {
+    const int started = (int)h->progress;
+    if (launched - started < m->chain_ahead) {
+      if (launched >= (1 << 20)) {
+        set_error("Monte-Carlo chain did not end");
+        return SLAMHIP_ERR_STATE;
+      }
+      rc = launch_one();
+      if (rc) return rc;
+      continue;
+    }
+    pe->prefetch_ahead(2 * need, 16);  // polar pairs of the next match while this one runs
+    if ((++spins & 0xfffffull) == 0) {
+      hipError_t qe = hipStreamQuery(ctx->stream);
+      if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "Monte-Carlo chain kernel");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (h->error == 2) {
+    set_error("Monte-Carlo chain: more scorer calls than the trace buffer holds");
+    return SLAMHIP_ERR_UNSUPPORTED;
+  }
+  if ((size_t)h->tape_pos + 3 > need) {
+    set_error("internal: the Monte-Carlo chain ran past the uploaded window of the pair tape");
+    return SLAMHIP_ERR_STATE;
+  }
+  {
+    const double saved[3] = {h->saved[0], h->saved[1], h->saved[2]};
+    pe->set_chain_result((size_t)h->tape_pos, h->failed, h->poses, h->td, h->rd, h->has_saved != 0, saved);
+    pe->trim();
+  }
+  MatchJob &job = m->job;
+  job.scorer_calls = h->calls;
+  job.poses_evaluated = h->evaluated;
+  job.launches = h->steps;
+  job.t_build_us = job.t_replay_us = 0;
+  m->chain_launched = launched;
+  m->chain_rescored = h->rescored;
+  m->chain_steps_avg = 0.75 * m->chain_steps_avg + 0.25 * (double)h->steps;
+  if (ctx->profile) {
+    ctx->prof_launches += launched;
+    ctx->prof_units += h->evaluated * (long long)a.scan.n;
+  }
+  out_delta[0] = h->pose[0] - init_pose[0];
+  out_delta[1] = h->pose[1] - init_pose[1];
+  out_delta[2] = h->pose[2] - init_pose[2];
+  *out_prob = h->best_prob;
+  m->t_score_us = MatchJob::now_us() - t0;
+  if (m->has_obs) {
+    const double t1 = MatchJob::now_us();
+    for (long long i = 0; i < h->calls; ++i) {
+      const HcTraceEntry &e = m->h_trace[i];
+      const double p3[3] = {e.x, e.y, e.theta};
+      if (m->obs.on_scan_test) m->obs.on_scan_test(m->obs.user, p3, e.score);
+      if (e.accepted && m->obs.on_pose_update) m->obs.on_pose_update(m->obs.user, p3, e.score);
+    }
+    job.t_replay_us = MatchJob::now_us() - t1;
+    if (m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, out_delta, *out_prob);
+  }
+  return SLAMHIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,9 +460,13 @@ extern "C" {
 int slamhip_matcher_create_mc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, unsigned seed,
                               double td, double rd, unsigned failed_limit, unsigned attempts_limit,
                               slamhip_matcher **out) {
-  return make_matcher(ctx, cfg,
-                      std::make_unique<GaussianPoseEnumerator>(seed, td, rd, failed_limit, attempts_limit),
-                      1024, out);
+  int rc = make_matcher(ctx, cfg,
+                        std::make_unique<GaussianPoseEnumerator>(seed, td, rd, failed_limit, attempts_limit),
+                        1024, out);
+  if (rc) return rc;
+  (*out)->is_mc = true;
+  (*out)->device = ctx->device;
+  return SLAMHIP_OK;
 }
 
 int slamhip_matcher_create_hc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, unsigned failed_rounds_limit,
@@ -404,6 +588,7 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
     const int crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
     if (crc != kChainNeedsHost) return crc;
   }
+  if (mc_chain_eligible(m)) return mc_chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   const int budget = m->max_batch > 0 ? m->max_batch : 256;
   int rc = ensure_pose_capacity(ctx, budget + 2);  // + the initial pose, + the best pose of a batch scored twice

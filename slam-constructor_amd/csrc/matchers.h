@@ -229,6 +229,40 @@ public:
   bool cheap_step() const override { return false; }
   void assign(const PoseEnumerator &o) override { *this = static_cast<const GaussianPoseEnumerator &>(o); }
 
+  // ---- the device chain (mc_chain.hip) runs the enumerator itself: what it starts from and what it hands back
+  unsigned max_failed() const { return max_failed_; }
+  unsigned max_poses() const { return max_poses_; }
+  double base_td() const { return base_td_; }
+  double base_rd() const { return base_rd_; }
+  size_t tape_pos() const { return pos_; }
+  // host idle time while a chain runs on the GPU: pairs for the NEXT match
+  void prefetch_ahead(size_t pairs_from_pos, int max_new) { tape_->prefetch(pos_ + pairs_from_pos, max_new); }
+  // pairs [tape_pos(), tape_pos() + n) of the tape (generated on demand)
+  void copy_tape(size_t n, double *ret_saved_pairs) {
+    for (size_t i = 0; i < n; ++i) {
+      const PairTape::Pair &p = tape_->at(pos_ + i);
+      ret_saved_pairs[2 * i] = p.ret;
+      ret_saved_pairs[2 * i + 1] = p.saved;
+    }
+  }
+  void set_chain_result(size_t pairs_consumed, unsigned failed, unsigned poses, double td, double rd, bool has_saved,
+                        const double saved[3]) {
+    pos_ += pairs_consumed;
+    failed_ = failed;
+    poses_ = poses;
+    td_ = td;
+    rd_ = rd;
+    rv_x_ = TapeNormal(0, td_);
+    rv_y_ = TapeNormal(0, td_);
+    rv_t_ = TapeNormal(0, rd_);
+    if (has_saved) {
+      rv_x_.has_saved = rv_y_.has_saved = rv_t_.has_saved = true;
+      rv_x_.saved = saved[0];
+      rv_y_.saved = saved[1];
+      rv_t_.saved = saved[2];
+    }
+  }
+
 private:
   void reset_shift(double td, double rd) {
     failed_ = 0;

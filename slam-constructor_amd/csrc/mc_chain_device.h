@@ -1,0 +1,66 @@
+// mc_chain_device.h -- what the Monte-Carlo chain kernel (mc_chain.hip) and its host driver (matchers.cpp) share.
+#pragma once
+
+#include "mc_chain.h"
+#include "slamhip_internal.h"
+
+namespace slamhip {
+
+constexpr int kMcSlots = 384;  // most candidates a super-step speculates on (6 per lane of the replaying wave)
+
+// one scorer call of the walked path, in the reference's order (what GridScanMatcherObserver sees)
+struct McTraceEntry {
+  double x, y, theta, score;
+  int accepted, pad;
+};
+
+// pinned, host-coherent: written by the bookkeeping workgroup, read by the spinning host
+struct McHostOut {
+  double pose[3];
+  double best_prob;
+  long long calls, evaluated;
+  int steps;
+  unsigned rescored;
+  // the enumerator's state after the match (GaussianPoseEnumerator: matchers.h)
+  long long tape_pos;  // pairs consumed, relative to the uploaded window
+  unsigned failed, poses;
+  double td, rd;
+  int has_saved;
+  double saved[3];
+  int error;          // 2: trace buffer too small
+  unsigned progress;  // super-steps started so far in this process_scan
+  unsigned done_seq;  // = epoch of the process_scan whose result is above
+};
+
+// device memory of one matcher
+struct McChainCtl {
+  McState state[2];  // state of super-step k at [k & 1]
+  double scores[2][kMcSlots + 8];
+  double scores_seq[2][kMcSlots + 8];
+  unsigned hashes[2][kMcSlots + 8];
+  unsigned done_epoch;
+};
+
+struct McChainArgs {
+  MapView map;
+  ScanView scan;
+  int oie;
+  int seq;     // 1: the reference's beam-order sum instead of the canonical tree (SLAMHIP_SUM_SEQUENTIAL)
+  int verify;  // 1: checked default mode
+  McChainCtl *ctl;
+  const McPair *tape;  // the window of the matcher's pair tape this match can consume, in HBM
+  int n_slots;         // candidates speculated on per super-step: the grid is n_slots + 1 workgroups
+  double init[3];
+  double td0, rd0;
+  unsigned max_failed, max_poses;
+  unsigned epoch;
+  McHostOut *host;
+  McTraceEntry *trace;  // pinned; null = no observer
+  int trace_cap;
+};
+
+// threads per workgroup: 512 or 1024
+hipError_t launch_mc_chain_step(const McChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
+}  // namespace slamhip

@@ -176,6 +176,34 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
     assert div["hc_raw"] <= 10 and div["mc_raw"] <= 10
 
 
+@pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
+@pytest.mark.parametrize("prm", [[666666, 0.2, 0.1, 20, 100], [7, 0.2, 0.1, 4096, 4096], [11, 0.3, 0.05, 30, 1000], [5, 0.2, 0.1, 3, 2]])
+def test_mc_chain_equals_host_driven_matcher(pkg, ctx, cell, weighting, prm):
+    """The Monte-Carlo matcher on the device chain (csrc/mc_chain.hip: candidates under "all rejected" per
+    super-step, first acceptance wins, the enumerator state advanced in closed form -- tape position, pending
+    second Marsaglia values, failure counter, halved dispersions) against the host-driven matcher: trace, result
+    and the random stream left behind (the next match continues on the same engine), bit for bit."""
+    sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=5, weighting=weighting)
+    upload(pkg, ctx, sc)
+    dev = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    host = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    host.set_device_chain(0)
+    for m in (dev, host):
+        m.set_tie_check(0)
+    init = sc["init_pose"]
+    for rep in range(4):  # consecutive matches: the engine is not reseeded
+        td = dev.process_scan(0, init, trace=True)
+        th = host.process_scan(0, init, trace=True)
+        assert_trace_equal(td, th)
+        sd, sh = dev.stats(), host.stats()
+        assert sd["scorer_calls"] == sh["scorer_calls"] == td["n_calls"]
+        q = dev.process_scan(0, init)  # without an observer; the host twin has to draw the same numbers
+        qh = host.process_scan(0, init)
+        assert q["prob"] == qh["prob"] and np.array_equal(q["delta"], qh["delta"])
+        init = init + np.array([0.013, -0.007, 0.004])
+    assert dev.stats()["kernels_launched"] > 0 and host.stats()["kernels_launched"] == 0
+
+
 def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
     """The GMapping OOPE on the device chain: K3's one-pose body scores the speculation tree, the replay applies
     the reference's cross-pose cache (gmapping_occupancy_observation_pe.h:21-24,36-37,43-44) in call
