@@ -47,7 +47,11 @@ struct slamhip_matcher {
   slamhip::McHostOut *h_mc = nullptr;
   slamhip::McPair *d_tape = nullptr;
   double *h_tape = nullptr;  // pinned staging of the tape window
-  size_t tape_cap = 0;
+  size_t tape_cap = 0;       // pairs d_tape / h_tape hold
+  size_t tape_base = 0;      // absolute tape position of d_tape[0]
+  size_t tape_filled = 0;    // pairs of the window already in HBM (or on their way, see tape_ready)
+  hipStream_t tape_stream = nullptr;  // uploads the next match's pairs while this match's chain runs
+  hipEvent_t tape_ready = nullptr;
   int mc_slots = 0;
 };
 
@@ -94,6 +98,10 @@ int chain_release(slamhip_matcher *m) {
   if (m->d_tape) hipFree(m->d_tape);
   if (m->h_mc) hipHostFree(m->h_mc);
   if (m->h_tape) hipHostFree(m->h_tape);
+  if (m->tape_stream) hipStreamDestroy(m->tape_stream);
+  if (m->tape_ready) hipEventDestroy(m->tape_ready);
+  m->tape_stream = nullptr;
+  m->tape_ready = nullptr;
   m->d_mc = nullptr;
   m->d_tape = nullptr;
   m->h_mc = nullptr;
@@ -300,7 +308,7 @@ bool mc_chain_eligible(slamhip_matcher *m) {
   if (m->chain_mode < 0) {
     const char *e = getenv("SLAMHIP_MC_CHAIN");
     m->chain_mode = (e && e[0] == '0') ? 0 : 1;
-    if (const char *t = getenv("SLAMHIP_MC_CHAIN_THREADS")) m->chain_nt = atoi(t) == 512 ? 512 : 1024;
+    if (const char *t = getenv("SLAMHIP_MC_CHAIN_THREADS")) m->chain_nt = atoi(t) == 1024 ? 1024 : 512;
     if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
   }
   return m->chain_mode == 1;
@@ -316,9 +324,10 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     SLAMHIP_CHECK(hipMemset(m->d_mc, 0, sizeof(McChainCtl)));
     SLAMHIP_CHECK(hipHostMalloc(&m->h_mc, sizeof(McHostOut), pinned));
     std::memset(m->h_mc, 0, sizeof(McHostOut));
-    // 252 candidates + the bookkeeping workgroup = 253 workgroups of 1024 threads, one per CU (see chain_prepare)
+    // 384 candidates per super-step in workgroups of 512 threads (two per CU): a Monte-Carlo chain is a long run of
+    // rejections, so the larger tree pays (cfg3: 16 super-steps of 7.2 us against 21 of 6.5 with 252 x 1024)
     const char *se = getenv("SLAMHIP_MC_CHAIN_SLOTS");
-    m->mc_slots = std::min(kMcSlots, std::max(1, se ? atoi(se) : 252));
+    m->mc_slots = std::min(kMcSlots, std::max(1, se ? atoi(se) : kMcSlots));
   }
   McChainArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -332,21 +341,47 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   const size_t max_poses = pe->max_poses();
   const size_t resets = max_poses / (pe->max_failed() / 3 + 1) + 2;
   const size_t need = 3 * (max_poses / 2 + 2 + resets) + 8;
-  if (need > m->tape_cap) {
-    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (m->d_tape) hipFree(m->d_tape);
-    if (m->h_tape) hipHostFree(m->h_tape);
-    m->d_tape = nullptr;
-    m->h_tape = nullptr;
-    size_t cap = 1024;
-    while (cap < need) cap *= 2;
-    SLAMHIP_CHECK(hipMalloc(&m->d_tape, sizeof(McPair) * cap));
-    SLAMHIP_CHECK(hipHostMalloc(&m->h_tape, sizeof(McPair) * cap, hipHostMallocDefault));
-    m->tape_cap = cap;
-  }
+  // The pairs live in HBM as a window [tape_base, tape_base + tape_filled) of the tape, filled AHEAD: while a
+  // chain runs, the host (spinning anyway) generates the pairs of the next match and a side stream uploads them,
+  // so a match in steady state starts without touching the tape.  The window is restarted when it runs out.
   const double t0 = MatchJob::now_us();
-  pe->copy_tape(need, m->h_tape);
-  SLAMHIP_CHECK(hipMemcpyAsync(m->d_tape, m->h_tape, sizeof(McPair) * need, hipMemcpyHostToDevice, ctx->stream));
+  const size_t pos = pe->tape_pos();
+  if (!m->tape_stream) {
+    SLAMHIP_CHECK(hipStreamCreateWithFlags(&m->tape_stream, hipStreamNonBlocking));
+    SLAMHIP_CHECK(hipEventCreateWithFlags(&m->tape_ready, hipEventDisableTiming));
+  }
+  auto upload_upto = [&](size_t abs_end) -> int {  // pairs [tape_base + tape_filled, abs_end) -> HBM, asynchronously
+    const size_t have = m->tape_base + m->tape_filled;
+    if (abs_end <= have) return SLAMHIP_OK;
+    const size_t cnt = abs_end - have;
+    double *dst = m->h_tape + 2 * m->tape_filled;
+    pe->copy_tape_abs(have, cnt, dst);
+    SLAMHIP_CHECK(hipMemcpyAsync(m->d_tape + m->tape_filled, dst, sizeof(McPair) * cnt, hipMemcpyHostToDevice,
+                                 m->tape_stream));
+    SLAMHIP_CHECK(hipEventRecord(m->tape_ready, m->tape_stream));
+    m->tape_filled += cnt;
+    return SLAMHIP_OK;
+  };
+  if (!m->d_tape || pos < m->tape_base || pos + need > m->tape_base + m->tape_cap) {
+    // (re)start the window at the current position
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SLAMHIP_CHECK(hipStreamSynchronize(m->tape_stream));
+    const size_t cap = std::max<size_t>(64 * need, 1 << 16);
+    if (cap > m->tape_cap) {
+      if (m->d_tape) hipFree(m->d_tape);
+      if (m->h_tape) hipHostFree(m->h_tape);
+      m->d_tape = nullptr;
+      m->h_tape = nullptr;
+      SLAMHIP_CHECK(hipMalloc(&m->d_tape, sizeof(McPair) * cap));
+      SLAMHIP_CHECK(hipHostMalloc(&m->h_tape, sizeof(McPair) * cap, hipHostMallocDefault));
+      m->tape_cap = cap;
+    }
+    m->tape_base = pos;
+    m->tape_filled = 0;
+  }
+  rc = upload_upto(pos + need);  // nothing to do when the last match filled ahead
+  if (rc) return rc;
+  SLAMHIP_CHECK(hipStreamWaitEvent(ctx->stream, m->tape_ready, 0));
   m->t_stage_us = MatchJob::now_us() - t0;
   const size_t trace_need = max_poses + 2;
   if (m->has_obs && (!m->h_trace || (size_t)m->trace_cap < trace_need)) {
@@ -360,7 +395,7 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
   a.verify = (tie_check_default(m) && !a.seq) ? 1 : 0;
   a.ctl = m->d_mc;
-  a.tape = m->d_tape;
+  a.tape = m->d_tape + (pos - m->tape_base);
   a.n_slots = m->mc_slots;
   for (int k = 0; k < 3; ++k) a.init[k] = init_pose[k];
   a.td0 = pe->base_td();
@@ -391,6 +426,7 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     if (rc) return rc;
   }
   unsigned long long spins = 0;
+  bool ahead_done = false;
   while (h->done_seq != epoch) {
     const int started = (int)h->progress;
     if (launched - started < m->chain_ahead) {
@@ -402,7 +438,19 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
       if (rc) return rc;
       continue;
     }
-    pe->prefetch_ahead(2 * need, 16);  // polar pairs of the next match while this one runs
+    // polar pairs of the next match while this one runs: generated a few at a time, uploaded once they are there
+    if (!ahead_done) {
+      pe->prefetch_ahead(2 * need, 32);
+      if (pe->tape_generated_upto() >= pos + 2 * need) {
+        if (pos + 2 * need <= m->tape_base + m->tape_cap) {
+          rc = upload_upto(pos + 2 * need);
+          if (rc) return rc;
+        }
+        ahead_done = true;
+      }
+    } else {
+      __builtin_ia32_pause();
+    }
     if ((++spins & 0xfffffull) == 0) {
       hipError_t qe = hipStreamQuery(ctx->stream);
       if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "Monte-Carlo chain kernel");
@@ -465,6 +513,7 @@ int slamhip_matcher_create_mc(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, unsi
                         1024, out);
   if (rc) return rc;
   (*out)->is_mc = true;
+  (*out)->chain_nt = 512;
   (*out)->device = ctx->device;
   return SLAMHIP_OK;
 }

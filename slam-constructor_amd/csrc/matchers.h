@@ -237,14 +237,15 @@ public:
   size_t tape_pos() const { return pos_; }
   // host idle time while a chain runs on the GPU: pairs for the NEXT match
   void prefetch_ahead(size_t pairs_from_pos, int max_new) { tape_->prefetch(pos_ + pairs_from_pos, max_new); }
-  // pairs [tape_pos(), tape_pos() + n) of the tape (generated on demand)
-  void copy_tape(size_t n, double *ret_saved_pairs) {
+  // pairs [from, from + n) of the tape by absolute position (generated on demand; from >= the trimmed base)
+  void copy_tape_abs(size_t from, size_t n, double *ret_saved_pairs) {
     for (size_t i = 0; i < n; ++i) {
-      const PairTape::Pair &p = tape_->at(pos_ + i);
+      const PairTape::Pair &p = tape_->at(from + i);
       ret_saved_pairs[2 * i] = p.ret;
       ret_saved_pairs[2 * i + 1] = p.saved;
     }
   }
+  size_t tape_generated_upto() const { return tape_->base + tape_->pairs.size(); }
   void set_chain_result(size_t pairs_consumed, unsigned failed, unsigned poses, double td, double rd, bool has_saved,
                         const double saved[3]) {
     pos_ += pairs_consumed;
