@@ -237,11 +237,13 @@ int slamhip_matcher_reset_state(slamhip_matcher *m);
 int slamhip_matcher_set_observer(slamhip_matcher *m, const slamhip_observer *obs);
 /* max speculative poses per launch (0 = default) */
 int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
-/* Hill climbing over the 1-cell OOPE in the default mode (TREE256 sum, device pose trig) runs its whole
- * accept chain on the device: one process_scan = a chain of kernels with no host in between, each
- * replaying the previous one's speculation tree (csrc/hc_chain.h).  mode: 1 on (default), 0 = the
- * host-driven speculative batches every other configuration uses; threads: workgroup size 256 / 512 /
- * 1024, 0 = default.  Scores and decisions are the same bit for bit either way. */
+/* Hill climbing (1-cell or GMapping OOPE) and Monte Carlo (1-cell OOPE) with device pose trigonometry run their
+ * whole accept chain on the device: one process_scan = a chain of kernels with no host in between, each replaying
+ * the previous one's speculative candidates in the reference's order (csrc/hc_chain.h, csrc/mc_chain.h;
+ * pose_enumeration_scan_matcher.h:31-77, hill_climbing_scan_matcher.h:10-170, monte_carlo_scan_matcher.h:10-100).
+ * mode: 1 on (default), 0 = the host-driven speculative batches every other configuration uses; threads:
+ * workgroup size 256 / 512 / 1024, 0 = default (1024 for hill climbing, 512 for Monte Carlo).  Scores, decisions,
+ * observer events and the Monte-Carlo engine's stream are the same bit for bit either way. */
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
 /* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell OOPE is CHECKED (on = 1, the default; the environment
  * variable SLAMHIP_TIE_CHECK=0 turns it off for a process): a `best < candidate`
