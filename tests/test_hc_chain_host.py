@@ -26,3 +26,22 @@ def test_chain_logic_equals_reference_loop(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok 240 matches")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no host compiler")
+def test_mc_chain_logic_equals_reference_loop(tmp_path):
+    """csrc/mc_chain.h (candidate j of a state in closed form, first acceptance, the enumerator state after the
+    consumed candidates) against the plain accept loop over GaussianPoseEnumerator: 168 matches, limits from 1/50 to
+    4096/4096, 1..384 candidates per super-step, quantised scores (ties), three matches per engine."""
+    exe = str(tmp_path / "mc_chain_test")
+    hip_inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(hip_inc, "hip", "hip_runtime.h")):
+        pytest.skip("HIP headers not found")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fno-omit-frame-pointer", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + hip_inc,
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "slam-constructor_amd", "csrc"),
+           os.path.join(ROOT, "tests", "native", "mc_chain_test.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok 168 matches")
