@@ -864,7 +864,12 @@ def main():
 
     pf_out = None
     if pf_needed:
-        pf_out = particle_filter_leg(args, pkg, ctx, pf_sc, rank, world, dist, torch)
+        try:
+            pf_out = particle_filter_leg(args, pkg, ctx, pf_sc, rank, world, dist, torch)
+        except Exception as e:  # noqa: BLE001  (the headline line must still go out; the failure is reported in it)
+            import traceback
+            traceback.print_exc()
+            pf_out = {"error": "%s: %s" % (type(e).__name__, e)}
     cfg5_out = None
     if "cfg5" in args.leg_set and world == 1:
         try:
