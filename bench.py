@@ -93,6 +93,8 @@ def parse():
                     help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
     ap.add_argument("--chain", type=int, default=-1,
                     help="the HC / MC accept chain on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
+    ap.add_argument("--leg-timeout", type=int, default=240,
+                    help="seconds the sharded particle-filter leg may take at N > 1 before the line goes out without it")
     ap.add_argument("--no-tie-check", action="store_true",
                     help="default mode without the check of comparisons the tree sum cannot settle")
     args = ap.parse_args()
@@ -862,22 +864,8 @@ def main():
     if m is not None:
         m.close()
 
-    pf_out = None
-    if pf_needed:
-        try:
-            pf_out = particle_filter_leg(args, pkg, ctx, pf_sc, rank, world, dist, torch)
-        except Exception as e:  # noqa: BLE001  (the headline line must still go out; the failure is reported in it)
-            import traceback
-            traceback.print_exc()
-            pf_out = {"error": "%s: %s" % (type(e).__name__, e)}
-    cfg5_out = None
-    if "cfg5" in args.leg_set and world == 1:
-        try:
-            cfg5_out = cfg5_leg(args, pkg, ctx, torch)
-        except pkg.SlamHipError as e:
-            cfg5_out = {"error": str(e)}
-
-    if rank == 0:
+    def emit_line(pf_out, cfg5_out):
+        """rank 0's ONE JSON line (the headline is complete before the secondary legs start)"""
         bpu = BYTES_PER_UNIT[bkey]
         achieved = (k_units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = load_traffic(args.workload)
@@ -927,6 +915,43 @@ def main():
         if cfg5_out is not None:
             out["cfg5"] = cfg5_out
         print(json.dumps(out))
+
+    # The secondary legs run AFTER the headline is complete.  With more than one rank the particle-filter leg joins
+    # an RCCL group inside the library: should that ever block (a fabric problem is not this benchmark's to sit
+    # out), a watchdog prints the headline with the failure noted and ends the process, so the driver still gets
+    # its line.
+    watchdog = None
+    if world > 1 and pf_needed:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                emit_line({"error": "the sharded particle-filter leg did not finish within %d s" % args.leg_timeout}, None)
+                sys.stdout.flush()
+            os._exit(0 if rank == 0 else 1)
+
+        watchdog = threading.Timer(args.leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    pf_out = None
+    if pf_needed:
+        try:
+            pf_out = particle_filter_leg(args, pkg, ctx, pf_sc, rank, world, dist, torch)
+        except Exception as e:  # noqa: BLE001  (the headline line must still go out; the failure is reported in it)
+            import traceback
+            traceback.print_exc()
+            pf_out = {"error": "%s: %s" % (type(e).__name__, e)}
+    cfg5_out = None
+    if "cfg5" in args.leg_set and world == 1:
+        try:
+            cfg5_out = cfg5_leg(args, pkg, ctx, torch)
+        except pkg.SlamHipError as e:
+            cfg5_out = {"error": str(e)}
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        emit_line(pf_out, cfg5_out)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
