@@ -14,10 +14,43 @@
 namespace slamhip {
 
 // ---- helpers ---------------------------------------------------------------------------------
+// value of lane (lane ^ OFF) without a trip through the LDS crossbar: DPP row operations inside a row of 16 lanes,
+// gfx950's permlane swaps between rows / halves (tools/scratch/dpp_probe.hip prints what each of them reads).
+// ds_bpermute (what __shfl_xor compiles to) costs an address computation and ~100 cycles per 32-bit half and step;
+// six dependent steps of it were a third of a microsecond at the end of every pose of the matcher chains.
+template <int OFF>
+__device__ __forceinline__ unsigned lane_xor_u32(unsigned v) {
+  static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "butterfly offsets only");
+  if (OFF == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  if (OFF == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  if (OFF == 4) {  // row_ror:12 into banks 0 and 2 (lanes with bit 2 clear), row_ror:4 into banks 1 and 3
+    const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x12C, 0xF, 0x5, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(a, (int)v, 0x124, 0xF, 0xA, false);
+  }
+  if (OFF == 8) return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  if (OFF == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // [0]: odd rows <- even rows, [1]: even <- odd
+    return (lane & 16) ? r[0] : r[1];
+  }
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // [0]: upper half <- lower, [1]: lower <- upper
+  return (lane & 32) ? r[0] : r[1];
+}
+template <int OFF>
+__device__ __forceinline__ double lane_xor_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = lane_xor_u32<OFF>((unsigned)b), hi = lane_xor_u32<OFF>((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double wave_xor_sum(double v) {
   // fixed butterfly: every lane ends with the same bits (a+b == b+a in IEEE)
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  v = v + lane_xor_f64<32>(v);
+  v = v + lane_xor_f64<16>(v);
+  v = v + lane_xor_f64<8>(v);
+  v = v + lane_xor_f64<4>(v);
+  v = v + lane_xor_f64<2>(v);
+  v = v + lane_xor_f64<1>(v);
   return v;
 }
 
@@ -30,17 +63,21 @@ __device__ __forceinline__ unsigned long long term_fingerprint(double term, unsi
   return (unsigned long long)(unsigned)bits * k_lo + (unsigned long long)(unsigned)(bits >> 32) * k_hi;
 }
 __device__ __forceinline__ unsigned fold_fingerprint(unsigned long long h) { return (unsigned)(h >> 32) ^ (unsigned)h; }
-// wave_xor_sum's fixed butterfly with the fingerprint's exchanges riding along (one LDS-crossbar latency per step
-// for both)
+// wave_xor_sum's fixed butterfly with the fingerprint's exchanges riding along
+template <int OFF>
+__device__ __forceinline__ void wave_xor_step_with(double &v, unsigned long long &h) {
+  const double o = lane_xor_f64<OFF>(v);
+  const unsigned ol = lane_xor_u32<OFF>((unsigned)h), oh = lane_xor_u32<OFF>((unsigned)(h >> 32));
+  v = v + o;
+  h += ((unsigned long long)oh << 32) | ol;
+}
 __device__ __forceinline__ void wave_xor_sum_with(double &v, unsigned long long &h) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(v, off, 64);
-    const unsigned ol = (unsigned)__shfl_xor((int)(unsigned)h, off, 64);
-    const unsigned oh = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), off, 64);
-    v = v + o;
-    h += ((unsigned long long)oh << 32) | ol;
-  }
+  wave_xor_step_with<32>(v, h);
+  wave_xor_step_with<16>(v, h);
+  wave_xor_step_with<8>(v, h);
+  wave_xor_step_with<4>(v, h);
+  wave_xor_step_with<2>(v, h);
+  wave_xor_step_with<1>(v, h);
 }
 
 // world_to_cell: int(floor(x / scale)) with a TRUE division (Q15: multiplying by 1/scale flips
