@@ -416,10 +416,19 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
       const std::vector<double> &rc_all = g->trig_cos, &rs_all = g->trig_sin;  // raw_trig() above
       g->pes.clear();
       g->pes.emplace_back(g->prm.hc_failed_rounds_limit, g->prm.hc_translation, g->prm.hc_rotation);
+      // ... and its completion is not awaited: the next particle's chain is queued behind the update on the same
+      // stream, the status words are collected when the loop is through
       struct ReuseGuard {
         slamhip_ctx *c;
-        explicit ReuseGuard(slamhip_ctx *cc) : c(cc) { mu_allow_scan_reuse(c, true); }
-        ~ReuseGuard() { mu_allow_scan_reuse(c, false); }
+        explicit ReuseGuard(slamhip_ctx *cc) : c(cc) {
+          mu_allow_scan_reuse(c, true);
+          mu_set_deferred(c, true);
+        }
+        ~ReuseGuard() {
+          mu_drain(c, nullptr, nullptr);  // (an early return: nothing may stay in flight)
+          mu_set_deferred(c, false);
+          mu_allow_scan_reuse(c, false);
+        }
       } reuse_guard(ctx);
       // one matcher object for the lone matches: with device pose trig its accept chain runs on the device
       // (hc_chain.hip), otherwise through host-driven batches -- the same scorer calls either way
@@ -451,12 +460,24 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
           rc = slamhip_map_append_scan(ctx, map_id, &cfg, p.pose, n_raw, range, rc_all.data(), rs_all.data(),
                                        is_occ, &nu);
           if (rc) return rc;
-          g->cell_updates += nu;
+          if (nu >= 0) g->cell_updates += nu;  // (deferred: counted by mu_drain below)
           p.scan_is_first = 0;
         }
         p.weight = best_prob * p.weight;
         reset_sm_delta(p);
         g->scorer_calls += calls;
+      }
+      {
+        long long nu = 0;
+        int uerr = 0;
+        rc = mu_drain(ctx, &nu, &uerr);
+        if (rc) return rc;
+        g->cell_updates += nu;
+        if (uerr) {
+          set_error(uerr == 2 ? "internal: the device counted more cell updates than the host sized the buffers for"
+                              : "a beam leaves the bound map window: bind a larger map before the filter runs");
+          return SLAMHIP_ERR_STATE;
+        }
       }
       act_idx.clear();  // everything is applied already: nothing left for match_finish
       return SLAMHIP_OK;

@@ -80,6 +80,13 @@ struct MuScratch {
   unsigned *h_offsets = nullptr;  // pinned: first record slot of every beam, computed by the host
   unsigned long long *near_bits = nullptr;  // [kNearSide^2][64] words: beams (up to 4096) visiting the cells next to the robot
   void *scan_temp = nullptr;
+  // deferred completion (mu_set_deferred): updates are queued without waiting for them; their status words land in
+  // a pinned ring and are summed up by mu_drain
+  bool deferred = false;
+  int pending = 0;
+  unsigned last_seq = 0;
+  unsigned long long *h_ring = nullptr;  // kRing x (error flag, padding records)
+  unsigned ring_total[64] = {0};
   // scan re-use (see slamhip_map_append_scan)
   bool reuse_ok = false;
   const double *last_range = nullptr, *last_cos = nullptr, *last_sin = nullptr;
@@ -96,6 +103,38 @@ MuScratch &scratch_of(slamhip_ctx *ctx) {
 }  // namespace
 
 namespace slamhip {
+constexpr int kRing = 64;
+// internal: while enabled, a plain slamhip_map_append_scan on the zero-copy path returns as soon as its kernels are
+// queued (n_updates_out = -1); the caller must not touch the scratch of this context from another stream and has
+// to call mu_drain before it reads the map on the host or leaves.  The GMapping filter's shared-map loop uses it:
+// the next particle's match is queued behind the update on the same stream, so nothing waits for the host.
+void mu_set_deferred(slamhip_ctx *ctx, bool on) { scratch_of(ctx).deferred = on; }
+
+// waits for the queued updates and adds up what they report
+int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err) {
+  MuScratch &sc = scratch_of(ctx);
+  if (n_updates) *n_updates = 0;
+  if (err) *err = 0;
+  if (!sc.pending) return SLAMHIP_OK;
+  const int rc = score_wait(ctx, sc.last_seq);
+  if (rc) {
+    sc.pending = 0;
+    return rc;
+  }
+  long long nu = 0;
+  int e = 0;
+  for (int k = 0; k < sc.pending; ++k) {
+    const unsigned long long fl = ((volatile unsigned long long *)sc.h_ring)[2 * k];
+    const unsigned long long pad = ((volatile unsigned long long *)sc.h_ring)[2 * k + 1];
+    if (fl) e = (int)fl;
+    nu += (long long)sc.ring_total[k] - (long long)pad;
+  }
+  sc.pending = 0;
+  if (n_updates) *n_updates = nu;
+  if (err) *err = e;
+  return SLAMHIP_OK;
+}
+
 // internal: while enabled, consecutive slamhip_map_append_scan calls that pass the very same host
 // arrays upload them once (the caller guarantees their contents do not change in between)
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on) {
@@ -191,6 +230,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
       SLAMHIP_CHECK(hipMalloc(&sc.near_bits, sizeof(unsigned long long) * kNearSide * kNearSide * kNearMaxWords));
     if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
     if (!sc.h_status) SLAMHIP_CHECK(hipHostMalloc(&sc.h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!sc.h_ring) SLAMHIP_CHECK(hipHostMalloc(&sc.h_ring, 2 * kRing * sizeof(unsigned long long), hipHostMallocDefault));
     sc.cap_beams = cap;
   }
   const size_t cb = sc.cap_beams;
@@ -447,6 +487,26 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipEventRecord(pe1, ctx->stream));
     ctx->prof_k6_calls += 1;
     ctx->prof_k6_records += total;
+  }
+  if (sc.deferred && ctx->low_latency) {
+    // queued, not awaited: the status words go to slot `pending` of the ring (mu_drain)
+    if (sc.pending == kRing) {
+      long long dn = 0;
+      int de = 0;
+      const int drc = mu_drain(ctx, &dn, &de);
+      if (drc) return drc;
+      if (de) return fail("a deferred map update reported an error (beam outside the window?)", SLAMHIP_ERR_STATE);
+    }
+    unsigned seq = ++ctx->seq;
+    if (seq == 0) seq = ++ctx->seq;
+    hipLaunchKernelGGL(k_mu_finish, dim3(1), dim3(1), 0, ctx->stream, (const int *)sc.error_flag,
+                       (const unsigned long long *)sc.n_updates, sc.h_ring + 2 * sc.pending, ctx->h_done_flag, seq);
+    SLAMHIP_CHECK(hipGetLastError());
+    sc.ring_total[sc.pending] = total;
+    sc.last_seq = seq;
+    ++sc.pending;
+    if (n_updates_out) *n_updates_out = -1;
+    return SLAMHIP_OK;
   }
   int err = 0;
   unsigned long long nu = 0;  // padding records
@@ -813,6 +873,7 @@ void mu_release(slamhip_ctx *ctx) {
                     (void *)s.n_updates, s.temp, (void *)s.bins, (void *)s.offs, (void *)s.srec, s.scan_temp, (void *)s.near_bits})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
+    if (s.h_ring) hipHostFree(s.h_ring);
     if (s.h_offsets) hipHostFree(s.h_offsets);
     delete &s;
     ctx->mu_scratch = nullptr;

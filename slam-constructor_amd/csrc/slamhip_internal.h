@@ -115,6 +115,8 @@ struct DeviceMap {
 };
 
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip
+void mu_set_deferred(slamhip_ctx *ctx, bool on);      // map_update.hip: queue plain updates without waiting
+int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err);
 void mu_release(slamhip_ctx *ctx);                    // map_update.hip: frees the context's K6 scratch
 void shard_release(slamhip_ctx *ctx);                 // shard.cpp: leaves the RCCL group, frees its staging
 void set_error(const std::string &msg);
