@@ -136,3 +136,52 @@ def test_gmapping_filter_with_map_update_vs_reference_golden(pkg, ctx):
         np.testing.assert_allclose(got[..., 1:], want[..., 1:], rtol=1e-12, atol=1e-14)  # obstacle means
         np.testing.assert_array_equal(ctx.map_download_aux(4, 0, 0, w, h, 2), g["step%d_aux" % k])
     ctx.map_release(4)
+
+
+def test_counting_sorted_and_radix_sorted_updates_agree(pkg, ctx):
+    """A plain update is counting-sorted over the window around the scan; scans of more than 4096 beams and windows
+    of more than 2^23 cells take the radix-sorted path (the fall-back every update took in round 1).  The same
+    beams, appended once as ONE scan of 5400 beams (radix) and once as five scans of 1080 (counting) in beam
+    order, must leave the same map for the order-insensitive part of the state -- GMapping hit / try counters
+    are sums -- and a long-range scan whose window exceeds 2^23 cells must equal the oracle."""
+    import pyoracle as po
+    from pyoracle_mapupdate import RULE_MEAN, append_scan
+    from synth import make_scene
+    sc = make_scene(cell_model=2, size=1200, scale=0.05, n_beams=1080, seed=31)
+    m, scan = sc["map"], sc["scan"]
+    pose = sc["true_pose"]
+    unknown = [-1.0, 0.0, 0.0]
+    rs = np.random.RandomState(5)
+    ranges = [np.clip(scan.range * (0.6 + 0.1 * k) + rs.rand(scan.n) * 0.2, 0.3, 25.0) for k in range(5)]
+    c, s = pkg.beam_trig(scan.angle)
+    for mid in (2, 3):
+        ctx.map_bind(mid, 2, m.width, m.height, m.origin, m.scale, unknown)
+    nu_small = sum(ctx.map_append_scan(2, pkg.RULE_GMAPPING, pose, r, c, s, None) for r in ranges)
+    nu_big = ctx.map_append_scan(3, pkg.RULE_GMAPPING, pose, np.concatenate(ranges), np.tile(c, 5), np.tile(s, 5), None)
+    assert nu_small == nu_big > 5 * 1080 * 20
+    np.testing.assert_array_equal(ctx.map_download_aux(2, 0, 0, m.width, m.height, 2),
+                                  ctx.map_download_aux(3, 0, 0, m.width, m.height, 2))  # hits, tries
+    a = ctx.map_download_window(2, 0, 0, m.width, m.height, 3)
+    b = ctx.map_download_window(3, 0, 0, m.width, m.height, 3)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)  # running means: same observations, same order per cell
+    ctx.map_release(2)
+    ctx.map_release(3)
+    # a window of more than 2^23 cells: 3100 x 3100 cells between the robot and the farthest end points
+    O = po.Oracle()
+    size = 3200
+    payload = np.full((size, size, 1), 0.5)
+    big = po.GridMapData(0, payload, (size // 2, size // 2), 0.05, [0.5])
+    aux = np.zeros((size, size, 1))
+    ctx.upload_map(2, big)
+    ang = np.deg2rad(np.linspace(-180, 180, 720, endpoint=False))
+    rng = np.full(ang.size, 77.0)  # 1540 cells along the axes: a window of 3081 x 3081 cells
+    rng[::7] = 55.5
+    c, s = pkg.beam_trig(ang)
+    tr = po.ScanData(rng, ang, None, None, po.TRIG_CACHED, 0.0, 1.0, s, c)
+    tr.angle = np.arange(ang.size, dtype=np.float64)
+    p0 = np.array([0.31, -0.17, 0.2])
+    nu_o = append_scan(O, big, aux, RULE_MEAN, p0, rng, tr.angle, None, quality=0.9, blur=0.0, trig=tr)
+    nu = ctx.map_append_scan(2, pkg.RULE_MEAN, p0, rng, c, s, None, quality=0.9, blur=0.0)
+    assert nu == nu_o
+    np.testing.assert_array_equal(ctx.map_download_window(2, 0, 0, size, size, 1), big.payload)
+    ctx.map_release(2)
