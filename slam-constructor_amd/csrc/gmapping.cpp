@@ -108,6 +108,9 @@ struct slamhip_gmapping {
   double traversed[3] = {0, 0, 0};
   GmCarry carry;  // the shared OOPE cache as this shard sees it
   slamhip_matcher *sm = nullptr;  // lone matches of the shared-map mode
+  GmMultiChain *mc = nullptr;     // likelihood-only steps on a dense map: one device chain per particle
+  std::vector<GmChainResult> chain_out;
+  std::vector<double> chain_inits;
   GmCarry step_carry;  // sharded steps: the cache entry the previous step ended with (on every shard)
   std::vector<MatchJob> jobs;
   std::vector<HillClimbingPoseEnumerator> pes;
@@ -302,6 +305,7 @@ int slamhip_gmapping_create(slamhip_ctx *ctx, const slamhip_gmapping_params *prm
 
 int slamhip_gmapping_destroy(slamhip_gmapping *g) {
   if (g && g->sm) slamhip_matcher_destroy(g->sm);
+  if (g && g->mc) gm_multi_chain_free(g->mc);
   if (g && g->tp) tile_pool_destroy(g->tp);
   delete g;
   return SLAMHIP_OK;
@@ -310,12 +314,14 @@ int slamhip_gmapping_destroy(slamhip_gmapping *g) {
 // the shared-cache chain in the reference's particle order, from job `from` on: a particle whose first
 // run would have hit its predecessor's final cache entry with another value is re-matched alone with
 // that carry
-static int verify_chain(slamhip_gmapping *g, int map_id, size_t from) {
+// (from == 0: job 0 started without a carry as well and is checked against `before`, the cache entry the step
+// starts from)
+static int verify_chain(slamhip_gmapping *g, int map_id, size_t from, const GmCarry *before = nullptr) {
   std::vector<MatchJob *> &act = g->act;
   const std::vector<int> &act_idx = g->act_idx;
   if (act.empty()) return SLAMHIP_OK;
   int rc;
-  GmCarry prev = act[from - 1]->carry;
+  GmCarry prev = from > 0 ? act[from - 1]->carry : (before ? *before : GmCarry{});
   for (size_t k = from; k < act.size(); ++k) {
     MatchJob &job = *act[k];
     const GmPoseInfo &fi = job.first_info;
@@ -492,6 +498,57 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
       job.start(&g->pes[k], Pose{p.pose[0], p.pose[1], p.pose[2]}, true, nullptr,
                 (k == 0 && !g->shard_chain) ? g->carry : GmCarry{}, 0.25);
       act.push_back(&job);
+    }
+    // Dense shared map, device pose trig, 3x3 window: every particle's accept chain runs on the device, all chains
+    // in shared launches (hc_chain.hip, grid.y = particle); no chain starts from a cache entry, the hand-overs --
+    // the step's own included -- are checked afterwards in particle order like the lock-step jobs'.
+    static const bool pf_chain_off = getenv("SLAMHIP_PF_CHAIN") && getenv("SLAMHIP_PF_CHAIN")[0] == '0';
+    const bool chains = !pf_chain_off && !g->tp && g->cfg.pose_trig == SLAMHIP_POSE_TRIG_DEVICE && g->cfg.gm_window == 1 &&
+                        g->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->scan_n <= 1280 && ctx->low_latency &&
+                        !ctx->stage_poses && g->prm.hc_failed_rounds_limit >= 1 && g->prm.hc_failed_rounds_limit <= 250;
+    if (chains) {
+      const int na = (int)act.size();
+      g->chain_inits.resize(3 * (size_t)na);
+      g->chain_out.resize(na);
+      for (int k = 0; k < na; ++k) {
+        const GmParticle &p = g->p[act_idx[k]];
+        for (int c = 0; c < 3; ++c) g->chain_inits[3 * k + c] = p.pose[c];
+      }
+      long long kernels = 0;
+      rc = gm_multi_chain_run(ctx, &g->mc, map_id, &g->cfg, g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
+                              g->prm.hc_rotation, na, g->chain_inits.data(), g->chain_out.data(), &kernels);
+      if (rc) return rc;
+      g->launches += kernels;
+      const GmCarry before = g->shard_chain ? GmCarry{} : g->carry;
+      for (int k = 0; k < na; ++k) {
+        MatchJob &job = *act[k];
+        const GmChainResult &r = g->chain_out[k];
+        if (r.error == 3) {
+          // a scan that is one run sat on this chain's path: its cache hand-over needs the sequential replay
+          std::vector<MatchJob *> one{&job};  // (started above, without a carry)
+          job.carry = GmCarry{};
+          job.carry_in = GmCarry{};
+          rc = run_jobs(g, map_id, one, 126, nullptr);
+          if (rc) return rc;
+          continue;
+        }
+        job.best = Pose{r.pose[0], r.pose[1], r.pose[2]};
+        job.best_prob = r.prob;
+        job.carry = GmCarry{r.cx, r.cy, r.cprob};
+        job.carry_in = GmCarry{};
+        job.first_info = r.first_info;
+        job.first_raw_score = r.first_raw;
+        job.scorer_calls = r.calls;
+        job.poses_evaluated = r.evaluated;
+        job.launches = r.steps;
+        job.first = false;
+        job.done = true;
+        g->poses_evaluated += r.evaluated;
+      }
+      g->chained = true;
+      rc = verify_chain(g, map_id, 0, &before);
+      if (rc) return rc;
+      return SLAMHIP_OK;
     }
     int per_job = std::max(6, std::min(126, 12288 / (int)act.size() / 6 * 6));
     double min_reach = 0.3;  // measured on MI355X, 100 particles: 1.9 ms/step at 0.3 vs 6.7 ms at 0.01

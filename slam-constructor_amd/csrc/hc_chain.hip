@@ -90,7 +90,8 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   // the grid holds 6 x (instances of the largest shape) scoring workgroups and, last, the bookkeeping one, which
   // keeps slot kHcSlots - 1 whatever the grid size
   const int slot = blockIdx.x + 1 == gridDim.x ? kHcSlots - 1 : (int)blockIdx.x;
-  HcChainCtl *ctl = a.ctl;
+  HcChainCtl *ctl = a.ctl + blockIdx.y;  // (one chain per grid row)
+  HcHostOut *host = a.host + blockIdx.y;
   // ---- loads that depend on nothing: issued first, they overlap the replay below (the done test waits
   // for its word only after everything else is in flight)
   const bool stamp = a.stamps && slot == 1 && t == 0 && k < 64;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   HC_PIN32(a.max_failed);
   HC_PIN64(a.n_inst);
   HC_PIN64(a.host);
+  HC_PIN64(a.inits);
   HC_PIN64(a.trace);
   HC_PIN32(a.trace_cap);
   HC_PIN64(a.stamps);
@@ -176,9 +178,9 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     HcState st;
     if (k == 0) {
       st = HcState{};
-      st.x = a.init[0];
-      st.y = a.init[1];
-      st.theta = a.init[2];
+      st.x = a.inits ? a.inits[3 * blockIdx.y] : a.init[0];
+      st.y = a.inits ? a.inits[3 * blockIdx.y + 1] : a.init[1];
+      st.theta = a.inits ? a.inits[3 * blockIdx.y + 2] : a.init[2];
       st.dt = a.dt0;
       st.dr = a.dr0;
       st.shape = a.shape0;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       if (init_slot) {
         if (lane == 0) {
           ctl->state[0] = st;
-          __hip_atomic_store(&a.host->progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&host->progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         ctl->walk[0][lane] = a.shapes[a.shape0].inst[lane];
       }
@@ -203,7 +205,13 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       const int n_inst = (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
       double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
       HcCarry root_carry{sp.carry_cx, sp.carry_cy, sp.carry_prob};
-      if (GM && sp.first) root_prob = hc_gm_fix(s_sc[kHcSlots - 1], root_carry, s_info[kHcSlots - 1], a.scan);
+      if (GM && sp.first) {
+        if (init_slot && lane == 0) {  // what the filter's cross-particle cache check looks at
+          ctl->first_info = s_info[kHcSlots - 1];
+          ctl->first_raw = s_sc[kHcSlots - 1];
+        }
+        root_prob = hc_gm_fix(s_sc[kHcSlots - 1], root_carry, s_info[kHcSlots - 1], a.scan);
+      }
       const bool active = lane < n_inst;
       const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
       const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), a.max_failed);
@@ -354,11 +362,11 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         next.carry_cx = bcast_i(fin.cx, tl);
         next.carry_cy = bcast_i(fin.cy, tl);
         next.carry_prob = bcast(fin.prob, tl);
-        if (__ballot(valid && degenerate) != 0ull && init_slot && lane == 0) a.host->error = 3;
+        if (__ballot(valid && degenerate) != 0ull && init_slot && lane == 0) host->error = 3;
       }
       if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
         next.done = 1;
-        if (init_slot && lane == 0) a.host->error = 1;
+        if (init_slot && lane == 0) host->error = 1;
       }
       st = next;
       if (init_slot) {
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
               e.pad = 0;
               const long long at = base + 6ll * hc_depth(me) + c;
               if (at < a.trace_cap) a.trace[at] = e;
-              else a.host->error = 2;
+              else host->error = 2;
             }
           }
         }
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
           __threadfence_system();
           if (lane == 0) {
             ctl->done_epoch = a.epoch;
-            HcHostOut *h = a.host;
+            HcHostOut *h = host;
             h->pose[0] = next.x;
             h->pose[1] = next.y;
             h->pose[2] = next.theta;
@@ -404,10 +412,15 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             h->gm_cx = next.carry_cx;
             h->gm_cy = next.carry_cy;
             h->gm_prob = next.carry_prob;
+            if (GM) {
+              h->first_info = ctl->first_info;
+              h->first_raw = ctl->first_raw;
+            }
+            if (a.n_done) atomicAdd(a.n_done, 1u);
             __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           }
         } else if (lane == 0) {
-          __hip_atomic_store(&a.host->progress, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&host->progress, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -562,13 +575,14 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
 #define HC_LAUNCH(NTV)                                                                                          \
   do {                                                                                                          \
     if (e0 || e1)                                                                                               \
-      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
+      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid, n_chains), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
     else                                                                                                        \
-      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid), dim3(NTV), shm, stream, a, k);     \
+      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid, n_chains), dim3(NTV), shm, stream, a, k);     \
   } while (0)
 
 template <int MODEL, bool SEQ>
-static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                            int n_chains) {
   constexpr int KB = 0;
   const int grid = 6 * a.max_inst + 1;
   const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
@@ -583,33 +597,46 @@ static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t str
 // GMapping OOPE: 512 threads per pose (two workgroups per CU: all slots of a 64-instance super-step resident at
 // once) or 1024 (one per CU: trees of at most 42 instances)
 template <int KB>
-static hipError_t launch_gm(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+static hipError_t launch_gm(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                            int n_chains) {
   constexpr int MODEL = SLAMHIP_CELL_GMAPPING;
   constexpr bool SEQ = false;
   const int grid = 6 * a.max_inst + 1;
   const size_t shm = (size_t)KB * 256 * sizeof(double) + 4 * KB * sizeof(int2) + 4 * KB * sizeof(int) +
                      2 * (size_t)KB * 256 * sizeof(int);
   if (nt == 1024) HC_LAUNCH(1024);
+  else if (nt == 256) HC_LAUNCH(256);
   else HC_LAUNCH(512);
   return hipGetLastError();
 }
 #undef HC_LAUNCH
 
+__global__ void k_chain_marker(const unsigned *n_done, unsigned *h_done_count, unsigned *flag, unsigned seq) {
+  *h_done_count = *n_done;
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_chain_marker(const unsigned *n_done, unsigned *h_done_count, unsigned *flag, unsigned seq,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(k_chain_marker, dim3(1), dim3(1), 0, stream, n_done, h_done_count, flag, seq);
+  return hipGetLastError();
+}
+
 hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
-                                hipEvent_t e0, hipEvent_t e1) {
+                                hipEvent_t e0, hipEvent_t e1, int n_chains) {
   if (cell_model == SLAMHIP_CELL_OCC)
-    return a.seq ? launch_nt<SLAMHIP_CELL_OCC, true>(a, k, nt, stream, e0, e1)
-                 : launch_nt<SLAMHIP_CELL_OCC, false>(a, k, nt, stream, e0, e1);
+    return a.seq ? launch_nt<SLAMHIP_CELL_OCC, true>(a, k, nt, stream, e0, e1, n_chains)
+                 : launch_nt<SLAMHIP_CELL_OCC, false>(a, k, nt, stream, e0, e1, n_chains);
   if (cell_model == SLAMHIP_CELL_TBM)
-    return a.seq ? launch_nt<SLAMHIP_CELL_TBM, true>(a, k, nt, stream, e0, e1)
-                 : launch_nt<SLAMHIP_CELL_TBM, false>(a, k, nt, stream, e0, e1);
+    return a.seq ? launch_nt<SLAMHIP_CELL_TBM, true>(a, k, nt, stream, e0, e1, n_chains)
+                 : launch_nt<SLAMHIP_CELL_TBM, false>(a, k, nt, stream, e0, e1, n_chains);
   if (cell_model == SLAMHIP_CELL_GMAPPING && !a.seq) {
     switch ((a.scan.n + 255) / 256) {
-      case 1: return launch_gm<1>(a, k, nt, stream, e0, e1);
-      case 2: return launch_gm<2>(a, k, nt, stream, e0, e1);
-      case 3: return launch_gm<3>(a, k, nt, stream, e0, e1);
-      case 4: return launch_gm<4>(a, k, nt, stream, e0, e1);
-      case 5: return launch_gm<5>(a, k, nt, stream, e0, e1);
+      case 1: return launch_gm<1>(a, k, nt, stream, e0, e1, n_chains);
+      case 2: return launch_gm<2>(a, k, nt, stream, e0, e1, n_chains);
+      case 3: return launch_gm<3>(a, k, nt, stream, e0, e1, n_chains);
+      case 4: return launch_gm<4>(a, k, nt, stream, e0, e1, n_chains);
+      case 5: return launch_gm<5>(a, k, nt, stream, e0, e1, n_chains);
       default: break;
     }
   }

@@ -25,6 +25,9 @@ struct HcHostOut {
                        // scan is one run sat on the path (its cache hand-over needs the sequential replay)
   unsigned progress;   // super-steps started so far in this process_scan
   unsigned done_seq;   // = epoch of the process_scan whose result is above
+  // GMapping OOPE: side outputs and raw score of the INITIAL pose (the filter's cross-particle cache check)
+  GmPoseInfo first_info;
+  double first_raw;
 };
 
 // device memory of one matcher
@@ -36,6 +39,8 @@ struct HcChainCtl {
   unsigned long long hashes[2][kHcSlots + 7];  // term-vector hashes (checked default mode)
   GmPoseInfo infos[2][kHcSlots + 7];  // GMapping OOPE: side outputs of every scored pose
   unsigned done_epoch;            // epoch of the last process_scan that ran to its end
+  GmPoseInfo first_info;          // (see HcHostOut)
+  double first_raw;
 };
 
 struct HcChainArgs {
@@ -48,7 +53,12 @@ struct HcChainArgs {
   int seq;  // 1: the reference's beam-order sum instead of the canonical tree (SLAMHIP_SUM_SEQUENTIAL)
   int verify;  // 1 (default mode, point OOPE): comparisons too close for the tree sum to settle are re-decided from
                // beam-order sums (hc_round_decide)
+  // Several chains in one launch (the GMapping filter: one chain per particle, same map, same scan): grid.y = chain,
+  // `ctl` and `host` are arrays, `inits` holds the chains' initial poses (null: one chain, `init` below) and every
+  // chain that ends bumps *n_done.
   HcChainCtl *ctl;
+  const double *inits;
+  unsigned *n_done;
   const HcShape *shapes;  // kHcShapes of them
   int max_inst;  // instances of the largest shape: the grid is 6 x max_inst + 1 workgroups
   unsigned long long n_inst;  // round instances of shape b in byte b (a dynamic index into an array of
@@ -64,8 +74,12 @@ struct HcChainArgs {
   long long *stamps;    // debugging: 8 wall-clock stamps (100 MHz) per super-step of workgroup 1, or null
 };
 
-// threads per workgroup: 256, 512 or 1024
+// threads per workgroup: 256, 512 or 1024; n_chains > 1: the multi-chain form (see HcChainArgs::inits)
 hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
-                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int n_chains = 1);
+// one thread: copies the number of finished chains to pinned memory and publishes a launch number (the host's
+// view of a burst of multi-chain super-steps)
+hipError_t launch_chain_marker(const unsigned *n_done, unsigned *h_done_count, unsigned *flag, unsigned seq,
+                               hipStream_t stream);
 
 }  // namespace slamhip

@@ -298,6 +298,205 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   return SLAMHIP_OK;
 }
 
+}  // namespace
+
+namespace slamhip {
+
+struct GmMultiChain {
+  int cap = 0, device = 0;
+  HcChainCtl *d_ctl = nullptr;
+  HcShape *d_shapes = nullptr;
+  HcHostOut *h_out = nullptr;    // pinned, one per chain
+  double *h_inits = nullptr;     // pinned staging of the initial poses
+  double *d_inits = nullptr;
+  unsigned *d_n_done = nullptr;
+  unsigned *h_done_count = nullptr;  // pinned
+  int shape_n_inst[kHcShapes] = {0};
+  int max_inst = 1, nt = 256, built_inst = 0;
+  unsigned epoch = 0;
+  double steps_avg = 14.0;
+};
+
+void gm_multi_chain_free(GmMultiChain *s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  hipDeviceSynchronize();
+  if (s->d_ctl) hipFree(s->d_ctl);
+  if (s->d_shapes) hipFree(s->d_shapes);
+  if (s->h_out) hipHostFree(s->h_out);
+  if (s->h_inits) hipHostFree(s->h_inits);
+  if (s->d_inits) hipFree(s->d_inits);
+  if (s->d_n_done) hipFree(s->d_n_done);
+  if (s->h_done_count) hipHostFree(s->h_done_count);
+  delete s;
+}
+
+// All chains advance one super-step per kernel (grid.y = chain); a chain that has ended leaves the launch at
+// once.  The host queues the kernels in bursts, each closed by a one-thread marker that reports how many chains
+// are through, and always has the next burst queued before it waits for a marker.
+int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, const slamhip_spe_cfg *cfg,
+                       unsigned max_failed, double dt, double dr, int n, const double *inits, GmChainResult *out,
+                       long long *kernels_launched) {
+  if (n <= 0) return SLAMHIP_OK;
+  const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
+  if (!*scratch) {
+    GmMultiChain *s = new GmMultiChain;
+    s->device = ctx->device;
+    *scratch = s;
+    SLAMHIP_CHECK(hipMalloc(&s->d_shapes, sizeof(HcShape) * kHcShapes));
+    SLAMHIP_CHECK(hipMalloc(&s->d_n_done, sizeof(unsigned)));
+    SLAMHIP_CHECK(hipHostMalloc(&s->h_done_count, sizeof(unsigned), pinned));
+  }
+  GmMultiChain *s = *scratch;
+  {
+    // The tree of a chain is as large as the launch can afford: about `wgs` scoring workgroups per super-step over
+    // all chains.  A hundred chains share them (one round instance each: a launch is throughput-bound, an instance
+    // has to be LIKELY on the path to be worth its six workgroups); a shard of a dozen particles gets deep trees and
+    // wide workgroups, like a lone matcher.  Measured (cfg4 scene, ms per step, chains / the lock-step jobs they
+    // replace): 100 particles 0.74 / 0.83 (1 instance; 2: 0.87, 4: 1.12), 25: 0.45 / 0.51, 13: 0.36 / 0.48; budgets
+    // of 200..300 workgroups are equal, 500 and more slower.
+    static const int wgs = getenv("SLAMHIP_PF_CHAIN_WGS") ? std::max(6, atoi(getenv("SLAMHIP_PF_CHAIN_WGS"))) : 280;
+    const char *ie = getenv("SLAMHIP_PF_CHAIN_INST");
+    const int want = std::min(kHcDefaultInst, std::max(1, ie ? atoi(ie) : wgs / (6 * n)));
+    if (want != s->built_inst) {
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      std::vector<HcShape> shapes(kHcShapes);
+      const double reach = getenv("SLAMHIP_PF_CHAIN_REACH") ? atof(getenv("SLAMHIP_PF_CHAIN_REACH")) : 0.01;
+      s->max_inst = 1;
+      for (int b = 0; b < kHcShapes; ++b) {
+        hc_build_shape(hc_bucket_rate(b), 1.0, reach, want, &shapes[b]);
+        s->shape_n_inst[b] = shapes[b].n_inst;
+        s->max_inst = std::max(s->max_inst, shapes[b].n_inst);
+      }
+      SLAMHIP_CHECK(hipMemcpy(s->d_shapes, shapes.data(), sizeof(HcShape) * kHcShapes, hipMemcpyHostToDevice));
+      s->built_inst = want;
+    }
+    const int total = n * (6 * s->max_inst + 1);
+    s->nt = total <= 256 ? 1024 : (total <= 512 ? 512 : 256);
+    if (const char *t = getenv("SLAMHIP_PF_CHAIN_THREADS")) s->nt = atoi(t) == 512 ? 512 : (atoi(t) == 1024 ? 1024 : 256);
+  }
+  if (n > s->cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (s->d_ctl) hipFree(s->d_ctl);
+    if (s->h_out) hipHostFree(s->h_out);
+    if (s->h_inits) hipHostFree(s->h_inits);
+    if (s->d_inits) hipFree(s->d_inits);
+    s->d_ctl = nullptr;
+    s->h_out = nullptr;
+    s->h_inits = nullptr;
+    s->d_inits = nullptr;
+    int cap = 16;
+    while (cap < n) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&s->d_ctl, sizeof(HcChainCtl) * cap));
+    SLAMHIP_CHECK(hipMemset(s->d_ctl, 0, sizeof(HcChainCtl) * cap));
+    SLAMHIP_CHECK(hipHostMalloc(&s->h_out, sizeof(HcHostOut) * cap, pinned));
+    std::memset(s->h_out, 0, sizeof(HcHostOut) * cap);
+    SLAMHIP_CHECK(hipHostMalloc(&s->h_inits, sizeof(double) * 3 * cap, hipHostMallocDefault));
+    SLAMHIP_CHECK(hipMalloc(&s->d_inits, sizeof(double) * 3 * cap));
+    s->cap = cap;
+  }
+  HcChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  int cell_model = 0;
+  int rc = score_views(ctx, map_id, cfg, &a.map, &a.scan, &cell_model);
+  if (rc) return rc;
+  a.oie = cfg->oie;
+  a.max_inst = s->max_inst;
+  a.gm.fullness_th = cfg->gm_fullness_th;
+  a.gm.window = cfg->gm_window;
+  a.gm_cx = a.gm_cy = -1;  // every chain starts without a carry-in (the filter checks the hand-overs afterwards)
+  a.gm_prob = -1.0;
+  a.ctl = s->d_ctl;
+  a.inits = s->d_inits;
+  a.n_done = s->d_n_done;
+  a.shapes = s->d_shapes;
+  for (int b = 0; b < kHcShapes; ++b) a.n_inst |= (unsigned long long)(s->shape_n_inst[b] & 0xff) << (8 * b);
+  a.dt0 = dt;
+  a.dr0 = dr;
+  a.max_failed = max_failed;
+  a.shape0 = hc_bucket_of(0.25);
+  unsigned epoch = ++s->epoch;
+  if (epoch == 0) epoch = ++s->epoch;
+  a.epoch = epoch;
+  a.host = s->h_out;
+  std::memcpy(s->h_inits, inits, sizeof(double) * 3 * n);
+  for (int c = 0; c < n; ++c) {
+    ((volatile HcHostOut *)s->h_out)[c].error = 0;
+    ((volatile HcHostOut *)s->h_out)[c].progress = 0;
+  }
+  SLAMHIP_CHECK(hipMemcpyAsync(s->d_inits, s->h_inits, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipMemsetAsync(s->d_n_done, 0, sizeof(unsigned), ctx->stream));
+  int launched = 0;
+  auto burst = [&](int count, unsigned *seq_out) -> int {
+    for (int i = 0; i < count; ++i) {
+      hipEvent_t e0, e1;
+      int r = profile_event_pair(ctx, &e0, &e1);
+      if (r) return r;
+      SLAMHIP_CHECK(launch_hc_chain_step(a, cell_model, launched, s->nt, ctx->stream, e0, e1, n));
+      ++launched;
+    }
+    unsigned seq = ++ctx->seq;
+    if (seq == 0) seq = ++ctx->seq;
+    SLAMHIP_CHECK(launch_chain_marker(s->d_n_done, s->h_done_count, ctx->h_done_flag, seq, ctx->stream));
+    *seq_out = seq;
+    return SLAMHIP_OK;
+  };
+  unsigned seq_prev = 0, seq_next = 0;
+  rc = burst(std::max(3, (int)(s->steps_avg * 0.8)), &seq_prev);
+  if (rc) return rc;
+  for (;;) {
+    rc = burst(3, &seq_next);  // queued before the wait: the GPU never runs dry
+    if (rc) return rc;
+    rc = score_wait(ctx, seq_prev);
+    if (rc) return rc;
+    if (*(volatile unsigned *)s->h_done_count >= (unsigned)n) break;
+    if (launched >= (1 << 16)) {
+      set_error("the filter's hill-climbing chains did not end");
+      return SLAMHIP_ERR_STATE;
+    }
+    seq_prev = seq_next;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  int max_steps = 0;
+  long long evaluated = 0;
+  for (int c = 0; c < n; ++c) {
+    const volatile HcHostOut *h = &s->h_out[c];
+    if (h->done_seq != epoch) {
+      set_error("internal: a chain was counted as finished without publishing its result");
+      return SLAMHIP_ERR_STATE;
+    }
+    GmChainResult &r = out[c];
+    r.error = h->error;
+    if (h->error == 1) {
+      set_error("internal: the device replay found no terminal round (hill-climbing chain bug)");
+      return SLAMHIP_ERR_STATE;
+    }
+    for (int k = 0; k < 3; ++k) r.pose[k] = h->pose[k];
+    r.prob = h->best_prob;
+    r.calls = h->calls;
+    r.evaluated = h->evaluated;
+    r.steps = h->steps;
+    r.cx = h->gm_cx;
+    r.cy = h->gm_cy;
+    r.cprob = h->gm_prob;
+    std::memcpy(&r.first_info, const_cast<const GmPoseInfo *>(&h->first_info), sizeof(GmPoseInfo));
+    r.first_raw = h->first_raw;
+    max_steps = std::max(max_steps, (int)h->steps);
+    evaluated += h->evaluated;
+  }
+  s->steps_avg = 0.75 * s->steps_avg + 0.25 * (double)max_steps;
+  if (kernels_launched) *kernels_launched = launched;
+  if (ctx->profile) {
+    ctx->prof_launches += launched;
+    ctx->prof_units += evaluated * (long long)a.scan.n;
+  }
+  return SLAMHIP_OK;
+}
+
+}  // namespace slamhip
+
+namespace {
+
 // ---- Monte Carlo on the device (mc_chain.hip) -------------------------------------------------------
 // the 1-cell OOPE with device pose trigonometry on the zero-copy path, like the hill-climbing chain
 bool mc_chain_eligible(slamhip_matcher *m) {

@@ -204,4 +204,23 @@ int lane_fork(slamhip_ctx *ctx);
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
                 int *cell_model);
 int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kind = 0);
+
+// ---- many hill-climbing chains over the GMapping OOPE in shared launches (matchers.cpp; the filter's lock-step
+// replacement: one chain per particle, same map, same scan, no carry-in -- DESIGN.md section 7)
+struct GmChainResult {
+  double pose[3];
+  double prob;
+  long long calls, evaluated;
+  int steps;
+  int cx, cy;    // the cache entry the chain ended with
+  double cprob;
+  GmPoseInfo first_info;  // side outputs and raw score of the initial pose
+  double first_raw;
+  int error;     // 3: a one-run scan sat on the path: the caller redoes this match on the host-driven path
+};
+struct GmMultiChain;
+int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, const slamhip_spe_cfg *cfg,
+                       unsigned max_failed, double dt, double dr, int n, const double *inits, GmChainResult *out,
+                       long long *kernels_launched);
+void gm_multi_chain_free(GmMultiChain *s);
 }  // namespace slamhip

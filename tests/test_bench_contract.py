@@ -42,7 +42,7 @@ def test_default_bench_line_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == d["unit"]
     assert c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"]
     pf = d["particle_filter"]
-    assert pf["unit"] == "particles/s" and pf["scaling"] == "strong" and pf["roofline"]["kernel"] == "k_score_gmapping"
+    assert pf["unit"] == "particles/s" and pf["scaling"] == "strong" and pf["roofline"]["kernel"] in ("k_hc_chain_step", "k_score_gmapping")
     assert pf["cpu_baseline"]["kind"] == "reference" and "4000x4000" in pf["cpu_baseline"]["sample"]
     for leg in ("with_map_update", "with_particle_maps"):
         k6 = pf[leg]["roofline_map_update"]

@@ -17,7 +17,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); SQ_BUSY_CYCLES / duration is printed beside it
 # dominant kernel of each leg (substring of the rocprof kernel name)
-LEG_KERNEL = {"hc": "k_hc_chain_step", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_score_gmapping",
+LEG_KERNEL = {"hc": "k_hc_chain_step", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_step",
               "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_"}
 lines = ["# rocprofv3 summaries, round tag `%s`\n" % tag,
          "Commands: `tools/profile.sh %s` -- one `rocprofv3 --kernel-trace --stats` run per leg of `bench.py` "
@@ -74,7 +74,7 @@ if os.path.exists(dj) and os.path.getsize(dj) > 2:
     lines.append("The driver's command (`python bench.py`, every leg, CPU baselines): `%s_default_bench_unprofiled.json`.\n" % tag)
 
 traffic = {}
-PMC_KERNEL = {"hc": "k_hc_chain_step", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_score_gmapping"}
+PMC_KERNEL = {"hc": "k_hc_chain_step<0", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_step<2"}
 for wl in ("hc", "sweep", "mc", "pf"):
     for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
         f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
