@@ -667,18 +667,23 @@ __global__ void k_mu_rank(MuArgs a, const uint2 *srec, const unsigned *offs, uns
 }
 
 __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs, double *out) {
-  double tmp[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tmp[i | j] += lhs[i] * rhs[j];
-  const double tot = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  // tmp[i | j] += lhs[i] * rhs[j] for i, j = 0..3 in that order (transferable_belief_model.h:102-143), written out
+  // per target so that nothing is indexed dynamically (the loop form left 24 bytes of scratch per lane)
+  const double l0 = lhs[0], l1 = lhs[1], l2 = lhs[2], l3 = lhs[3];
+  const double r0 = rhs[0], r1 = rhs[1], r2 = rhs[2], r3 = rhs[3];
+  const double t0 = 0.0 + l0 * r0;
+  const double t1 = ((0.0 + l0 * r1) + l1 * r0) + l1 * r1;
+  const double t2 = ((0.0 + l0 * r2) + l2 * r0) + l2 * r2;
+  const double t3 = ((((((((0.0 + l0 * r3) + l1 * r2) + l1 * r3) + l2 * r1) + l2 * r3) + l3 * r0) + l3 * r1) + l3 * r2) + l3 * r3;
+  const double tot = t0 + t1 + t2 + t3;
   if (tot == 0.0) {
     out[0] = 1.0;
     out[1] = out[2] = out[3] = 0.0;
   } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = tmp[i] / tot;
+    out[0] = t0 / tot;
+    out[1] = t1 / tot;
+    out[2] = t2 / tot;
+    out[3] = t3 / tot;
   }
 }
 
