@@ -12,19 +12,22 @@
 //
 // The cell update is order dependent (running means, TBM conjunction + normalisation) and the beams
 // of one scan overlap near the robot, so atomics cannot reproduce the sequential result.
-// Exact scheme:
-//   1. k_mu_count   one thread per beam: endpoint, range gate, upper bound |dx|+|dy|+1 of its cells, and
-//                   the per-beam constants of the observation (MuBeam)
-//   2. k_mu_offsets exclusive scan of the bounds (one workgroup; rocprim's device scan for a batch)
-//   3. k_mu_emit    one thread per beam: the 4-connected walk with the reference's fuzzy tie rule and
-//                   Bresenham fail-over.  The walk is a sequential recurrence, so it leaves only the sort
-//                   key of each visited cell, beam-major; k_mu_beam_ids fills in the beam of every record
-//   4. rocprim::radix_sort_pairs (stable) of (cell key, beam): every cell's records end up contiguous
-//      and still in beam order -- within a beam a cell is visited once, so beam order IS the
-//      reference's update order for that cell
-//   5. k_mu_gather  one thread per sorted record: the observation (occupancy estimate, blur) of its
-//                   (beam, cell) pair -- 8 bytes per record, TBM cells 16
-//   6. k_mu_apply   one thread per distinct cell applies its records sequentially; chains of >= 64
+// Exact scheme (has the long form and the measurements):
+//   1. per beam: endpoint, range gate, number of cells |dx|+|dy|+1, the per-beam constants of the observation
+//      (MuBeam) -- k_mu_count in a batch; in a plain call k_mu_emit does it itself and the host, which walks the
+//      beams anyway to size the buffers, leaves every beam's first record slot in pinned memory
+//   2. k_mu_emit    ONE WAVE per beam, one lane per step: the cells of the 4-connected walk in closed form, every
+//                   step verified against the recurrence's own decision; ties, axis-parallel beams and walks
+//                   that rounding sends astray fall back to the sequential walk (fuzzy tie rule, Bresenham
+//                   fail-over).  It leaves the sort key and the beam of every visited cell, beam-major
+//   3. grouping by cell, stable in beam order -- within a beam a cell is visited once, so beam order IS the
+//      reference's update order for that cell.  Plain call: a counting sort over the window around the scan
+//      (per-cell bins filled by k_mu_emit, exclusive scan, k_mu_scatter, k_mu_rank; the cells next to the robot
+//      keep a bitmap of their beams instead of a bin, k_mu_near_bits); batch, or a window too large for bins:
+//      rocprim::radix_sort_pairs (stable) of (cell key, beam)
+//   4. the observation (occupancy estimate, blur) of every (beam, cell) pair, 8 bytes per record, TBM cells 16:
+//      k_mu_rank in a plain call, k_mu_gather behind the radix sort
+//   5. k_mu_apply   one thread per distinct cell applies its records sequentially; chains of >= 64
 //                   records are then streamed through the whole wave that holds their head
 // HBM traffic: per (beam, cell) an 8-byte (key, beam) pair written, sorted and read, one 8-byte
 // observation written and read, plus one read-modify-write of the cell (8-48 bytes) per distinct cell.
