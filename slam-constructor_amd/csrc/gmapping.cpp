@@ -201,7 +201,7 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
   // result.  Measured at 100 particles: with the first K3 (40 us per full launch, two half launches
   // 2 x 33 us) the pipeline gained 5 % and stayed off; with the present K3 (25 us per full launch against
   // ~35 us of host work per round) it hides most of the host: 1.24 -> 0.98 ms per step.
-  static const int groups_env = getenv("SLAMHIP_PF_PIPELINE") ? atoi(getenv("SLAMHIP_PF_PIPELINE")) : 2;
+  constexpr int groups_env = 2;  // (1 = one launch per round, 3 and 4 measured slower: the launches get too small)
   constexpr int kMaxGroups = 4;
   const int n_groups = (ctx->low_latency && !ctx->stage_poses && n_jobs >= 16)
                            ? std::max(1, std::min(kMaxGroups, groups_env)) : 1;
@@ -212,7 +212,7 @@ int run_jobs(slamhip_gmapping *g, int map_id, std::vector<MatchJob *> &act, int 
   } grp[kMaxGroups];
   // odd groups launch on the context's second stream: their kernel starts while the even group's is
   // still draining and publishing (SLAMHIP_PF_LANES=1: everything on one stream)
-  static const bool two_lanes = !(getenv("SLAMHIP_PF_LANES") && getenv("SLAMHIP_PF_LANES")[0] == '1');
+  constexpr bool two_lanes = true;  // (both groups on one stream: 0.97 against 0.94 ms per step)
   if (n_groups > 1 && two_lanes) {
     rc = lane_fork(ctx);
     if (rc) return rc;
@@ -552,8 +552,6 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
     }
     int per_job = std::max(6, std::min(126, 12288 / (int)act.size() / 6 * 6));
     double min_reach = 0.3;  // measured on MI355X, 100 particles: 1.9 ms/step at 0.3 vs 6.7 ms at 0.01
-    if (const char *e = getenv("SLAMHIP_PF_BUDGET")) per_job = std::max(6, atoi(e));
-    if (const char *e = getenv("SLAMHIP_PF_MIN_REACH")) min_reach = atof(e);
     for (MatchJob *j : act) {
       j->tree.min_reach = min_reach;
       j->timed = false;

@@ -136,8 +136,6 @@ bool chain_eligible(slamhip_matcher *m) {
   if (m->chain_mode < 0) {
     const char *e = getenv("SLAMHIP_HC_CHAIN");
     m->chain_mode = (e && e[0] == '0') ? 0 : 1;
-    if (const char *t = getenv("SLAMHIP_HC_CHAIN_THREADS")) m->chain_nt = atoi(t);
-    if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
   }
   return m->chain_mode == 1;
 }
@@ -148,17 +146,14 @@ int chain_prepare(slamhip_matcher *m) {
   SLAMHIP_CHECK(hipMemset(m->d_chain, 0, sizeof(HcChainCtl)));
   SLAMHIP_CHECK(hipMalloc(&m->d_shapes, sizeof(HcShape) * kHcShapes));
   std::vector<HcShape> shapes(kHcShapes);
-  const double boost = getenv("SLAMHIP_HC_BOOST") ? atof(getenv("SLAMHIP_HC_BOOST")) : 1.0;
-  const double reach = getenv("SLAMHIP_HC_CHAIN_REACH") ? atof(getenv("SLAMHIP_HC_CHAIN_REACH")) : 0.002;
+  const double boost = 1.0, reach = 0.002;  // (shape building: weight of repeated outcomes, reach below which no instance is added)
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   // 42 instances = 253 workgroups of 1024 threads: ONE per CU, all resident at once.  Measured against 64
   // instances x 512 threads (two workgroups per CU, a tree half as large again): cfg2 0.149 -> 0.138 ms per match
   // (one more super-step, each 0.8 us shorter), the shared-map filter step 4.3 k -> 5.0 k particles/s (K3's one-pose
   // body 10.7 -> 7 us); 32 or 52 instances, or 512 threads with 42, are slower again.
-  const char *ie = getenv(gm ? "SLAMHIP_GM_CHAIN_INST" : "SLAMHIP_HC_CHAIN_INST");
-  const int max_inst = std::min(kHcMaxInst, std::max(1, ie ? atoi(ie) : kHcDefaultInst));
-  if (gm)
-    if (const char *t = getenv("SLAMHIP_GM_CHAIN_THREADS")) m->chain_nt = atoi(t) == 1024 ? 1024 : 512;
+  const int max_inst = kHcDefaultInst;
+  (void)gm;
   m->chain_max_inst = 1;
   for (int b = 0; b < kHcShapes; ++b) {
     hc_build_shape(hc_bucket_rate(b), boost, reach, max_inst, &shapes[b]);
@@ -355,13 +350,12 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     // wide workgroups, like a lone matcher.  Measured (cfg4 scene, ms per step, chains / the lock-step jobs they
     // replace): 100 particles 0.74 / 0.83 (1 instance; 2: 0.87, 4: 1.12), 25: 0.45 / 0.51, 13: 0.36 / 0.48; budgets
     // of 200..300 workgroups are equal, 500 and more slower.
-    static const int wgs = getenv("SLAMHIP_PF_CHAIN_WGS") ? std::max(6, atoi(getenv("SLAMHIP_PF_CHAIN_WGS"))) : 280;
-    const char *ie = getenv("SLAMHIP_PF_CHAIN_INST");
-    const int want = std::min(kHcDefaultInst, std::max(1, ie ? atoi(ie) : wgs / (6 * n)));
+    constexpr int wgs = 280;
+    const int want = std::min(kHcDefaultInst, std::max(1, wgs / (6 * n)));
     if (want != s->built_inst) {
       SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
       std::vector<HcShape> shapes(kHcShapes);
-      const double reach = getenv("SLAMHIP_PF_CHAIN_REACH") ? atof(getenv("SLAMHIP_PF_CHAIN_REACH")) : 0.01;
+      const double reach = 0.01;
       s->max_inst = 1;
       for (int b = 0; b < kHcShapes; ++b) {
         hc_build_shape(hc_bucket_rate(b), 1.0, reach, want, &shapes[b]);
@@ -373,7 +367,6 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     }
     const int total = n * (6 * s->max_inst + 1);
     s->nt = total <= 256 ? 1024 : (total <= 512 ? 512 : 256);
-    if (const char *t = getenv("SLAMHIP_PF_CHAIN_THREADS")) s->nt = atoi(t) == 512 ? 512 : (atoi(t) == 1024 ? 1024 : 256);
   }
   if (n > s->cap) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -507,8 +500,6 @@ bool mc_chain_eligible(slamhip_matcher *m) {
   if (m->chain_mode < 0) {
     const char *e = getenv("SLAMHIP_MC_CHAIN");
     m->chain_mode = (e && e[0] == '0') ? 0 : 1;
-    if (const char *t = getenv("SLAMHIP_MC_CHAIN_THREADS")) m->chain_nt = atoi(t) == 1024 ? 1024 : 512;
-    if (const char *a = getenv("SLAMHIP_HC_CHAIN_AHEAD")) m->chain_ahead = std::max(1, atoi(a));
   }
   return m->chain_mode == 1;
 }
@@ -525,8 +516,7 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     std::memset(m->h_mc, 0, sizeof(McHostOut));
     // 384 candidates per super-step in workgroups of 512 threads (two per CU): a Monte-Carlo chain is a long run of
     // rejections, so the larger tree pays (cfg3: 16 super-steps of 7.2 us against 21 of 6.5 with 252 x 1024)
-    const char *se = getenv("SLAMHIP_MC_CHAIN_SLOTS");
-    m->mc_slots = std::min(kMcSlots, std::max(1, se ? atoi(se) : kMcSlots));
+    m->mc_slots = kMcSlots;
   }
   McChainArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -852,8 +842,6 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   carry.cy = ctx->gm_cy;
   carry.prob = ctx->gm_prob;
   MatchJob &job = m->job;
-  if (const char *e = getenv("SLAMHIP_HC_BOOST")) job.tree.repeat_boost = atof(e);
-  if (const char *e = getenv("SLAMHIP_MIN_REACH")) job.tree.min_reach = atof(e);
   job.start(m->pe.get(), Pose{init_pose[0], init_pose[1], init_pose[2]}, gm, m->has_obs ? &m->obs : nullptr,
             carry, m->p_accept0);
   while (!job.done) {

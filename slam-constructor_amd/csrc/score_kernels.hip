@@ -571,14 +571,14 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
     a.poses_per_block = pick_poses_per_block(a.n_poses);
     // K3 up to a couple of thousand poses does not fill the chip's wave slots, and the poses of a
     // workgroup run one after the other: one pose per workgroup (100-particle filter step 1.69 -> 1.66 ms)
-    static const int gm_one_below = getenv("SLAMHIP_K3_ONE_BELOW") ? atoi(getenv("SLAMHIP_K3_ONE_BELOW")) : 2048;
+    constexpr int gm_one_below = 2048;
     if (oope == SLAMHIP_OOPE_GMAPPING && a.n_poses < gm_one_below) a.poses_per_block = 1;
   }
   if (a.poses_per_block > kMaxPosesPerBlock) a.poses_per_block = kMaxPosesPerBlock;
   const dim3 grid((a.n_poses + a.poses_per_block - 1) / a.poses_per_block);
   const int kb = (a.scan.n + kBlock - 1) / kBlock;
   const bool wt = sum_order == SLAMHIP_SUM_SEQUENTIAL;
-  static const bool xcd_off = getenv("SLAMHIP_K3_XCD") && getenv("SLAMHIP_K3_XCD")[0] == '0';
+  constexpr bool xcd_off = false;
   a.xcd_blocks = 0;
   if (wt && oope != SLAMHIP_OOPE_GMAPPING && (ev_start || ev_stop)) return hipErrorInvalidValue;
   const hipEvent_t stop1 = ev_stop;
@@ -589,8 +589,8 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
       return hipErrorInvalidValue;
     }
     const size_t shm = (size_t)kb * kBlock * sizeof(double) + 4 * kb * sizeof(int2) + 4 * kb * sizeof(int);
-    // 1024 threads per pose for launches of at most SLAMHIP_K3_WIDE_BELOW poses (0: never)
-    static const int wide_below = getenv("SLAMHIP_K3_WIDE_BELOW") ? atoi(getenv("SLAMHIP_K3_WIDE_BELOW")) : 160;
+    // 1024 threads per pose for launches of at most 160 poses
+    constexpr int wide_below = 160;
     const int wide = a.n_poses <= wide_below ? 1024 : 0;
     const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int);
     dim3 grid_gm = grid;  // k_score_gmapping only: the XCD-chunked block order (see the kernel)
