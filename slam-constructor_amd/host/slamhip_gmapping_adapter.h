@@ -77,6 +77,12 @@ public:
   DiscretePoint2D origin() const override { return _origin; }
   bool has_cell(const Coord &) const override { return true; }
   void invalidate() const { _chunks.clear(); }
+  // the device window grew (slamhip_map_set_auto_grow): RegularSquaresGrid::width / height / origin follow it
+  void set_geometry(DiscretePoint2D origin, int w, int h) {
+    _origin = origin;
+    set_width(w);
+    set_height(h);
+  }
 
 private:
   static constexpr int kChunk = 64;
@@ -114,6 +120,9 @@ public:
     const int w = cfg.map.width_cells, h = cfg.map.height_cells;
     slamhip_or_die(slamhip_map_bind(ctx, cfg.map_id, SLAMHIP_CELL_GMAPPING, w, h, w / 2, h / 2,
                                     cfg.map.meters_per_cell, unknown), "map_bind");
+    // the reference's map is unbounded (UnboundedLazyTiledGridMap, init_gmapping.h:27-33): a scan that reaches
+    // beyond the window makes the shared dense window grow instead of failing the step
+    slamhip_or_die(slamhip_map_set_auto_grow(ctx, cfg.map_id, 1), "map_set_auto_grow");
     std::vector<uint32_t> seeds(n);
     for (auto &s : seeds) s = _seed();
     slamhip_or_die(slamhip_shard_info(ctx, &_rank, &_world), "shard_info");
@@ -148,11 +157,12 @@ public:
                            "particle_map_download");
             return;
           }
-          // dense window: clip to what is bound, the rest reads as unknown
-          const int ox = _cfg.map.width_cells / 2, oy = _cfg.map.height_cells / 2;
+          // dense window (it grows with the scans, see below): clip to what is bound, the rest reads as unknown
+          int mw = 0, mh = 0, ox = 0, oy = 0;
+          slamhip_or_die(slamhip_map_info(_ctx, _cfg.map_id, nullptr, &mw, &mh, &ox, &oy, nullptr, nullptr), "map_info");
           for (size_t i = 0; i < (size_t)ww * hh; ++i) out[3 * i] = kUnknownProb, out[3 * i + 1] = out[3 * i + 2] = 0.0;
           const int ix0 = std::max(x0 + ox, 0), iy0 = std::max(y0 + oy, 0);
-          const int ix1 = std::min(x0 + ox + ww, _cfg.map.width_cells), iy1 = std::min(y0 + oy + hh, _cfg.map.height_cells);
+          const int ix1 = std::min(x0 + ox + ww, mw), iy1 = std::min(y0 + oy + hh, mh);
           if (ix0 >= ix1 || iy0 >= iy1) return;
           std::vector<double> tmp((size_t)(ix1 - ix0) * (iy1 - iy0) * 3);
           slamhip_or_die(slamhip_map_download_window(_ctx, _cfg.map_id, ix0, iy0, ix1 - ix0, iy1 - iy0, tmp.data()),
@@ -225,6 +235,11 @@ protected:
       if (!(_weights[i] < _weights[_heaviest])) _heaviest = i;
     _pose = RobotPose{_poses[3 * _heaviest], _poses[3 * _heaviest + 1], _poses[3 * _heaviest + 2]};
     _view->invalidate();
+    if (!_cfg.particle_maps) {
+      int mw = 0, mh = 0, ox = 0, oy = 0;
+      slamhip_or_die(slamhip_map_info(_ctx, _cfg.map_id, nullptr, &mw, &mh, &ox, &oy, nullptr, nullptr), "map_info");
+      _view->set_geometry(DiscretePoint2D{ox, oy}, mw, mh);
+    }
   }
 
 private:

@@ -23,88 +23,6 @@
 #include "core/states/laser_scan_grid_world.h"
 #include "slamhip_init_scan_matching.h"
 
-// read-only GridMap over a device window: occupancy() of the cell kinds the path holds -- the payload double of
-// OCC cells; for TBM cells the conversion of the cell class the map was configured with (TbmOccConsistentCell /
-// TbmUnknownEvenOccCell::tbm2occ, src/core/maps/tbm_grid_cells.h:76-100; a cell that was never updated still
-// reports the prototype's Occupancy{0.5, 1}).  Belief masses: slamhip_map_download_window.
-class HipResidentMapView : public GridMap {
-public:
-  class Cell : public GridCell {
-  public:
-    explicit Cell(double prob = 0.5) : GridCell{Occupancy{prob, 1.0}} {}
-    std::unique_ptr<GridCell> clone() const override { return std::make_unique<Cell>(*this); }
-    void set(double prob, double qual = 1.0) { _occupancy = Occupancy{prob, qual}; }
-  };
-  // tbm_kind: 0 = tbm_consistent, 1 = tbm_unknown_even_occ (TBM windows only)
-  HipResidentMapView(slamhip_ctx *ctx, int map_id, const GridMapParams &p, double unknown_prob, int tbm_kind = 0)
-      : GridMap{std::make_shared<Cell>(unknown_prob), p}, _ctx{ctx}, _id{map_id}, _unknown{unknown_prob},
-        _tbm_kind{tbm_kind} {
-    refresh_geometry();
-  }
-  const GridCell &operator[](const Coord &c) const override {
-    const int cx = floor_div(c.x), cy = floor_div(c.y);
-    const long long key = ((long long)cy << 32) ^ (unsigned)cx;
-    auto it = _chunks.find(key);
-    if (it == _chunks.end()) {
-      std::vector<Cell> cells((size_t)kChunk * kChunk, Cell{_unknown});
-      // the part of the chunk that lies inside the window; the rest reads as the unknown cell
-      const int x0 = cx * kChunk + _ox, y0 = cy * kChunk + _oy;  // internal
-      const int ix0 = std::max(x0, 0), iy0 = std::max(y0, 0);
-      const int ix1 = std::min(x0 + kChunk, _w), iy1 = std::min(y0 + kChunk, _h);
-      if (ix0 < ix1 && iy0 < iy1) {
-        std::vector<double> tmp((size_t)(ix1 - ix0) * (iy1 - iy0) * _stride);
-        slamhip_or_die(slamhip_map_download_window(_ctx, _id, ix0, iy0, ix1 - ix0, iy1 - iy0, tmp.data()),
-                       "map_download_window");
-        for (int y = iy0; y < iy1; ++y)
-          for (int x = ix0; x < ix1; ++x)
-            set_cell(cells[(size_t)(y - y0) * kChunk + (x - x0)], &tmp[_stride * ((size_t)(y - iy0) * (ix1 - ix0) + (x - ix0))]);
-      }
-      it = _chunks.emplace(key, std::move(cells)).first;
-    }
-    return it->second[(size_t)(c.y - cy * kChunk) * kChunk + (c.x - cx * kChunk)];
-  }
-  void update(const Coord &, const AreaOccupancyObservation &) override {}  // a view: the world writes through K6
-  void reset(const Coord &, const GridCell &) override {}
-  DiscretePoint2D origin() const override { return DiscretePoint2D{_ox, _oy}; }
-  // an unbounded map has every cell (UnboundedPlainGridMap::has_cell, plain_grid_map.h:77) -- filter_scan drops
-  // the points whose cell the map does not have (weighted_mean_point_probability_spe.h:135-140)
-  bool has_cell(const Coord &) const override { return true; }
-  // after an update: cached chunks are stale, the window may have grown
-  void invalidate() {
-    _chunks.clear();
-    refresh_geometry();
-  }
-
-private:
-  void set_cell(Cell &c, const double *p) const {
-    if (_stride != 4) {
-      c.set(p[0]);
-    } else if (p[0] == 1.0 && p[1] == 0.0 && p[2] == 0.0) {
-      c.set(0.5);  // total ignorance: the cell was never updated
-    } else if (_tbm_kind == 1) {
-      c.set(p[2] + 0.5 * p[0]);
-    } else {
-      const double qual = p[2] + p[1];
-      c.set(p[2] / qual, qual);
-    }
-  }
-  void refresh_geometry() {
-    int model = 0;
-    slamhip_or_die(slamhip_map_info(_ctx, _id, &model, &_w, &_h, &_ox, &_oy, nullptr, nullptr), "map_info");
-    _stride = model == SLAMHIP_CELL_TBM ? 4 : (model == SLAMHIP_CELL_GMAPPING ? 3 : 1);
-    set_width(_w);
-    set_height(_h);
-  }
-  static constexpr int kChunk = 64;
-  static int floor_div(int v) { return v >= 0 ? v / kChunk : -((-v + kChunk - 1) / kChunk); }
-  slamhip_ctx *_ctx;
-  int _id;
-  double _unknown;
-  int _tbm_kind;
-  int _w = 0, _h = 0, _ox = 0, _oy = 0, _stride = 1;
-  mutable std::unordered_map<long long, std::vector<Cell>> _chunks;
-};
-
 class HipResidentWorld : public LaserScanGridWorld {
 public:
   struct Config {

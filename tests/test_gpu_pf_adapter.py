@@ -74,6 +74,40 @@ def test_world_adapter_matches_reference_filter(lib):
         lib.refpf_destroy(pair)
 
 
+def test_world_adapter_map_grows_like_the_references(lib):
+    """The same five scans with both worlds started on a 48 x 48-cell map: the reference's UnboundedLazyTiledGridMap
+    grows inside the scan adder, the HIP world's dense HBM window by slamhip_map_set_auto_grow.  An unbounded map
+    has no edge, so the trajectory is the golden's (generated on the full-size map) and the occupancy over the
+    golden's whole window is equal cell by cell."""
+    g = load("gmapping_pf_update.npz")
+    n = len(g["seeds"])
+    w, h = [int(v) for v in g["size"]]
+    gp = np.ascontiguousarray(g["gp"], dtype=np.float64)
+    seeds = np.ascontiguousarray(g["seeds"], dtype=np.uint32)
+    pair = lib.refpf_create(n, 48, 48, float(g["scale"]), _d(gp), seeds.ctypes.data_as(_up), 3, 0, 1)
+    assert pair
+    try:
+        for k in range(int(g["n_steps"])):
+            r = np.ascontiguousarray(g["step%d_range" % k])
+            a = np.ascontiguousarray(g["step%d_angle" % k])
+            d = g["step%d_delta" % k]
+            extra = np.arange(9000 + 100 * k, 9000 + 100 * k + n, dtype=np.uint32)
+            rp, rw, hp, hw = np.zeros((n, 3)), np.zeros(n), np.zeros((n, 3)), np.zeros(n)
+            wp, fl = np.zeros(6), np.zeros(4, np.int32)
+            lib.refpf_step(pair, r.size, _d(r), _d(a), d[0], d[1], d[2], 7 + k, n, extra.ctypes.data_as(_up),
+                           _d(rp), _d(rw), _d(hp), _d(hw), _d(wp), fl.ctypes.data_as(_ip))
+            np.testing.assert_array_equal(rp, g["step%d_poses" % k])
+            np.testing.assert_allclose(hp, rp, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(hw, rw, rtol=1e-9, atol=0)
+            occ_ref, occ_hip = np.zeros((h, w)), np.zeros((h, w))
+            lib.refpf_map_occupancy(pair, 0, -w // 2, -h // 2, w, h, _d(occ_ref))
+            lib.refpf_map_occupancy(pair, 1, -w // 2, -h // 2, w, h, _d(occ_hip))
+            np.testing.assert_array_equal(occ_hip, occ_ref)
+            np.testing.assert_array_equal(occ_ref, g["step%d_payload" % k][..., 0])
+    finally:
+        lib.refpf_destroy(pair)
+
+
 def test_world_adapter_runs_with_particle_maps(lib):
     """The per-particle-maps mode behind the same world interface (no reference counterpart, Q20):
     finite weights, a pose per scan, and a map view that follows the heaviest particle."""
