@@ -132,6 +132,7 @@ bool chain_eligible(slamhip_matcher *m) {
   // the GMapping OOPE rides K3's one-pose body: 3x3 window, up to 1280 beams, canonical sum
   if (gm && (m->cfg.gm_window != 1 || m->cfg.sum_order != SLAMHIP_SUM_TREE256 || m->ctx->scan_n > 1280)) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
+  if (m->ctx->scan_n > 4096) return false;  // the terms of a pose sit in LDS (8 bytes per beam next to 15 KB of replay state)
   if (m->max_batch < 6 * kHcMaxInst) return false;  // slamhip_matcher_set_batch asked for small batches
   if (m->chain_mode < 0) {
     const char *e = getenv("SLAMHIP_HC_CHAIN");
@@ -496,6 +497,7 @@ bool mc_chain_eligible(slamhip_matcher *m) {
   if (!m->is_mc) return false;
   if (m->cfg.oope != SLAMHIP_OOPE_OBSTACLE || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
+  if (m->ctx->scan_n > 4096) return false;  // (see chain_eligible)
   if (m->max_batch < 64) return false;  // slamhip_matcher_set_batch asked for small batches
   if (m->chain_mode < 0) {
     const char *e = getenv("SLAMHIP_MC_CHAIN");

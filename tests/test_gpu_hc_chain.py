@@ -96,6 +96,20 @@ def test_chain_workgroup_sizes_and_beam_counts(pkg, ctx, threads):
                            seq.process_scan(0, sc["init_pose"], trace=True), exact_scores=False, rtol=1e-12)
 
 
+def test_scans_too_long_for_the_chain_take_the_host_driven_path(pkg, ctx, po, oracle):
+    """A pose's beam terms sit in LDS in the chain kernels: beyond 4096 beams a matcher goes through the host-driven
+    batches by itself -- same trace as the oracle's loop."""
+    sc = make_scene(cell_model=CELL_OCC, size=600, scale=0.05, n_beams=6000, seed=3)
+    upload(pkg, ctx, sc)
+    for kind, okind, prm in (("HC", po.SM_HC, [8, 0.1, 0.1]), ("MC", po.SM_MC, [17, 0.2, 0.1, 20, 100])):
+        m = pkg.Matcher(ctx, kind, pkg.spe_cfg(), prm)
+        t = m.process_scan(0, sc["init_pose"], trace=True)
+        assert m.stats()["kernels_launched"] == 0  # no chain kernel
+        e = oracle.enumerator(okind, prm)
+        r = oracle.process_scan(e, sc["map"], sc["scan"], po.make_cfg(), sc["init_pose"])
+        assert_trace_equal(t, r, exact_scores=False, rtol=1e-12)
+
+
 def test_chain_zero_weight_scan_and_far_pose(pkg, ctx):
     sc = make_scene(cell_model=CELL_OCC, size=400, scale=0.1, n_beams=360, seed=9)
     sc["scan"].weight[:] = 0.0  # total weight 0: every score is NaN, nothing is ever accepted
