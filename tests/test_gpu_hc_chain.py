@@ -6,6 +6,8 @@ loop (pose_enumeration_scan_matcher.h:31-77) itself, so
   * against the oracle's strict accept loop the trace must be identical with scores within 1e-12;
   * a fuzz over random scenes counts accept-trace divergences between the default mode (device chain) and
     the strict mode (SLAMHIP_SUM_SEQUENTIAL + host trig, bit-exact with the reference): none allowed."""
+import os
+
 import numpy as np
 import pytest
 from helpers import assert_trace_equal
@@ -139,7 +141,8 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
     div = dict.fromkeys(names, 0)
     rescored = dict.fromkeys(names, 0)
     matches, calls = 0, 0
-    for seed in range(40):
+    n_scenes = int(os.environ.get("SLAMHIP_FUZZ_SCENES", "40"))  # (a longer soak: 400 scenes, run by hand)
+    for seed in range(n_scenes):
         cell = CELL_TBM if seed % 3 == 0 else CELL_OCC
         sc = make_scene(cell_model=cell, size=500, scale=0.05, n_beams=360 + 90 * (seed % 5), seed=100 + seed,
                         weighting="viny" if cell == CELL_TBM else "even")
@@ -180,14 +183,14 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
                     assert abs(b["scores"][i] - best) <= 2 * np.spacing(best), \
                         "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
     print("fuzz: %d matches per matcher, divergences %r, re-scored steps / batches %r" % (matches, div, rescored))
-    assert matches == 200 and calls > 200 * 80
+    assert matches == 5 * n_scenes and calls > matches * 80
     for which in ("hc_dev", "hc_host", "mc"):
         assert div[which] == 0, "%d of %d checked default-mode %s matches diverged from the strict mode" % (div[which], matches, which)
         # (Monte Carlo candidates are continuous random poses: sums that close with different terms are rare)
         assert which == "mc" or rescored[which] > 0, "the scenes never exercised the check of %s" % which
     assert div["hc_seq"] == 0, "%d of %d matches diverged with the beam-order sum on the device" % (div["hc_seq"], matches)
     assert rescored["hc_raw"] == rescored["mc_raw"] == 0
-    assert div["hc_raw"] <= 10 and div["mc_raw"] <= 10
+    assert div["hc_raw"] <= matches // 20 and div["mc_raw"] <= matches // 20
 
 
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
