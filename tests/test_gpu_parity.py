@@ -195,7 +195,9 @@ def test_full_size_against_oracle_and_properties(pkg, ctx, po, oracle, cell, wei
     perm = rs.permutation(P)
     np.testing.assert_array_equal(ctx.score_poses(0, pkg.spe_cfg(), poses[perm]), dflt[perm])
     # matcher at full size: exact trace vs the oracle's accept loop
-    for kind, okind, prm in (("HC", po.SM_HC, [128, 0.1, 0.1]), ("MC", po.SM_MC, [666666, 0.2, 0.1, 64, 512])):
+    # (the last entry is BASELINE configs[2]'s own matcher: 4096 attempts, 4097 scorer calls)
+    for kind, okind, prm in (("HC", po.SM_HC, [128, 0.1, 0.1]), ("MC", po.SM_MC, [666666, 0.2, 0.1, 64, 512]),
+                             ("MC", po.SM_MC, [666666, 0.2, 0.1, 4096, 4096])):
         mt = pkg.Matcher(ctx, kind, pkg.spe_cfg(**STRICT), prm)
         t = mt.process_scan(0, sc["init_pose"], trace=True)
         e = oracle.enumerator(okind, prm)
