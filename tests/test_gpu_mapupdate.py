@@ -114,14 +114,18 @@ def test_append_scan_area_estimator_vs_reference_golden(pkg, ctx, name):
     ctx.map_release(2)
 
 
-def test_gmapping_filter_with_map_update_vs_reference_golden(pkg, ctx):
+@pytest.mark.parametrize("pose_trig", [1, 0])
+def test_gmapping_filter_with_map_update_vs_reference_golden(pkg, ctx, pose_trig):
     """The reference's FULL GMapping step through the C-ABI: every matching particle appends its scan
-    to the one shared map before the next particle matches (slamhip_gmapping_set_map_update)."""
+    to the one shared map before the next particle matches (slamhip_gmapping_set_map_update).
+    pose_trig 1 = host trigonometry (host-driven matches, bit-exact mode); 0 = the default: every match is a chain
+    of kernels on the device (GMapping OOPE, hc_chain.hip) and the map updates are queued behind them without
+    waiting -- same particles, same map."""
     g = load("gmapping_pf_update.npz")
     w, h = [int(v) for v in g["size"]]
     ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
     n = len(g["seeds"])
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n, g["seeds"])
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=pose_trig), n, g["seeds"])
     pf.set_map_update(True)
     for k in range(int(g["n_steps"])):
         res, _ = pf.step(4, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + k)
