@@ -278,16 +278,18 @@ def test_smoke_entry(pkg):
     ge.smoke()
 
 
+@pytest.mark.parametrize("pose_trig", [1, 0])
 @pytest.mark.parametrize("scenario", ["default", "nogate", "wide"])
-def test_gmapping_filter_vs_reference_golden(pkg, ctx, scenario):
+def test_gmapping_filter_vs_reference_golden(pkg, ctx, scenario, pose_trig):
     """G5 through the C-ABI: several GmappingParticleFilter::handle_sensor_data steps (gate, pose
-    noise, lock-step HC matching with the shared OOPE cache, weights, N_eff, resampling with
-    duplicated particles, master hand-over) against the compiled reference."""
+    noise, HC matching of every particle with the shared OOPE cache, weights, N_eff, resampling with
+    duplicated particles, master hand-over) against the compiled reference.  pose_trig 1: host trigonometry,
+    host-driven lock-step jobs; 0 (the default): one device chain per particle in shared launches."""
     g = load("gmapping_pf.npz")
     m = map_from(g, scenario + "_map_")
     ctx.upload_map(5, m)
     n = len(g[scenario + "_seeds"])
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g[scenario + "_gp"], skip_rate=3, pose_trig=1),
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g[scenario + "_gp"], skip_rate=3, pose_trig=pose_trig),
                             n, g[scenario + "_seeds"])
     resampled_any = False
     for k in range(int(g[scenario + "_n_steps"])):
