@@ -85,6 +85,8 @@ def test_matcher_traces_vs_reference_golden(pkg, ctx, scene, matcher):
     md = pkg.Matcher(ctx, kind, pkg.spe_cfg(), g[matcher + "_params"])
     td = md.process_scan(0, g["init_pose"], trace=True)
     assert_trace_equal(td, ref, exact_scores=False, rtol=1e-12)
+    if matcher == "mc":  # ... and the device chain leaves the engine where the reference's loop does
+        assert_trace_equal(md.process_scan(0, g["init_pose"], trace=True), trace(g, "mc_second_"), exact_scores=False, rtol=1e-12)
     # speculation depth must not change the result
     for batch in (1, 7, 64):
         mb = pkg.Matcher(ctx, kind, pkg.spe_cfg(**STRICT), g[matcher + "_params"])
