@@ -1,0 +1,45 @@
+"""GPU suite: bench.py itself, run the way the driver runs it (a child process, one JSON line on stdout) -- the
+headline alone and one particle-filter leg, short.  The committed lines under profiles/ are held to the contract by
+tests/test_bench_contract.py; this one makes sure the program that writes them still does."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_headline_line_from_a_live_run():
+    d = run_bench("--legs", "none", "--no-cpu", "--steps", "8", "--warmup", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    c, r = d["config"], d["roofline"]
+    assert "cfg2" in c["workload"] and c["beams_after_filter"] == 1080 and c["scorer_calls_per_step"] > 700
+    assert abs(d["value"] - c["scorer_calls_per_step"] * 1080 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert 0.05 < d["ms_per_step"] < 1.0  # a device chain, not seconds
+    assert r["kernel"] == "k_hc_chain_step" and r["launches"] > 0 and 0.0 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["units_launched"] * r["bytes_per_unit"] / (r["avg_launch_us"] * 1e-6 * r["launches"]) / 1e9) \
+        <= 1e-6 * r["achieved"]
+    assert "roofline_sweep" in d and d["roofline_sweep"]["kernel"] == "k_score_point"
+
+
+def test_particle_filter_leg_from_a_live_run():
+    d = run_bench("--legs", "pf", "--no-cpu", "--steps", "4", "--warmup", "1", "--pf-steps", "3")
+    pf = d["particle_filter"]
+    assert "error" not in pf, pf
+    assert pf["unit"] == "particles/s" and pf["ranks"] == 1 and pf["value"] > 1e4 and pf["roofline"]["bytes_per_unit"] == 232
+    assert "cfg4" in pf["workload"] and pf["carry_reruns_last_step"] >= 0
