@@ -402,7 +402,15 @@ int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, in
  *   per scan:    slamhip_gmapping_step_sharded(...)   = match_begin, the carry exchange, match_finish,
  *                                                        all-gather of the raw weights, plan_resample and,
  *                                                        when a resampling happens, all-gather of the
- *                                                        particle records + import */
+ *                                                        particle records + import
+ *
+ * slamhip_gmapping_step_sharded needs ONE collective per step in the common case: the carry records travel together
+ * with the raw weights the particles will have if no cache hand-over needs repair, and whether one does is read off
+ * the records by every rank alike (no flags exchanged).
+ *
+ * For tests on one GPU an id that starts with "SLAMHIP-LOOPBACK:" joins an IN-PROCESS group instead: its ranks are
+ * threads of one process (a context each), the all-gather goes through host memory.  RCCL admits one rank per
+ * device; this is how the sharded step is exercised with world > 1 there (tests/test_gpu_shard.py). */
 #define SLAMHIP_SHARD_ID_BYTES 128
 int slamhip_shard_unique_id(void *id_out);
 int slamhip_shard_init(slamhip_ctx *ctx, int rank, int world, const void *id);

@@ -908,6 +908,26 @@ int slamhip_gmapping_step(slamhip_gmapping *g, int map_id, int n_raw, const doub
   return SLAMHIP_OK;
 }
 
+// what match_finish will hand out as raw weights, without touching the particles (gmapping_world.h:99: weight *= the
+// match's probability for the particles that matched)
+static void provisional_weights(const slamhip_gmapping *g, double *out) {
+  for (int i = 0; i < g->count; ++i) out[i] = g->p[i].weight;
+  for (size_t k = 0; k < g->act_idx.size(); ++k) out[g->act_idx[k]] = g->act[k]->best_prob * g->p[g->act_idx[k]].weight;
+}
+
+// true when some shard's first job met the cache entry handed to it with another value than it ran with (none):
+// slamhip_gmapping_carry_fix's condition for a first round, evaluated for every shard from the records alone
+static bool carry_repair_needed(const GmCarry &step_carry, const slamhip_carry_record *all, int world) {
+  GmCarry pred = step_carry;
+  for (int r = 0; r < world; ++r) {
+    if (!all[r].has_active) continue;
+    if (pred.prob != -1.0 && all[r].first_cx == pred.cx && all[r].first_cy == pred.cy && pred.prob != all[r].first_v0)
+      return true;
+    pred = GmCarry{all[r].carry_cx, all[r].carry_cy, all[r].carry_prob};
+  }
+  return false;
+}
+
 int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
                                   const double *angle, const int *is_occ, const double odom_delta[3],
                                   uint32_t resample_seed, int *resampled, unsigned *idx_out) {
@@ -939,33 +959,77 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
     g->pending = false;
     return rc;
   }
-  // the shared OOPE cache across shards: exchange, re-check, until no shard changes its final entry
+  // ONE collective in the common case: every shard sends its carry record together with the raw weights its
+  // particles will have if no cache hand-over needs repair.  Whether one does is a pure function of the records --
+  // shard r re-matches its first job only when the final entry of the nearest matching shard before it (or of
+  // the previous step) hits that job's first run with another value -- so every rank reaches the same verdict
+  // without exchanging flags; only then the slow protocol (exchange, re-match, until no final entry changes)
+  // and a second all-gather of the weights run.
   std::vector<slamhip_carry_record> recs(world);
+  std::vector<double> raw(g->count), all(g->n_total);
   const std::vector<int> ones(world, 1);
-  for (int round = 0; round <= world; ++round) {
+  bool settled = false;
+  {
     slamhip_carry_record mine;
     rc = slamhip_gmapping_carry_record(g, &mine);
     if (rc) return rc;
-    rc = slamhip_shard_allgather(g->ctx, &mine, ones.data(), (int)sizeof(mine), recs.data());
+    constexpr int kRecDoubles = (int)((sizeof(slamhip_carry_record) + 7) / 8);
+    std::vector<int> cnt(world);
+    int total = 0;
+    for (int r = 0; r < world; ++r) {
+      cnt[r] = kRecDoubles + g->shard_counts[r];
+      total += cnt[r];
+    }
+    std::vector<double> blk(cnt[rank], 0.0), gathered(total, 0.0);
+    std::memcpy(blk.data(), &mine, sizeof(mine));
+    provisional_weights(g, blk.data() + kRecDoubles);
+    rc = slamhip_shard_allgather(g->ctx, blk.data(), cnt.data(), (int)sizeof(double), gathered.data());
     if (rc) return rc;
-    int changed = 0;
-    rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);
-    if (rc) return rc;
-    int any = 0;
-    std::vector<int> flags(world, 0);
-    rc = slamhip_shard_allgather(g->ctx, &changed, ones.data(), (int)sizeof(int), flags.data());
-    if (rc) return rc;
-    for (int f : flags) any |= f;
-    if (!any) break;
+    int at = 0, wat = 0;
+    for (int r = 0; r < world; ++r) {
+      std::memcpy(&recs[r], gathered.data() + at, sizeof(slamhip_carry_record));
+      std::memcpy(all.data() + wat, gathered.data() + at + kRecDoubles, sizeof(double) * g->shard_counts[r]);
+      at += cnt[r];
+      wat += g->shard_counts[r];
+    }
+    if (!carry_repair_needed(g->step_carry, recs.data(), world)) {
+      int changed = 0;
+      rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);  // (passes the cache through; no re-match)
+      if (rc) return rc;
+      if (changed) return bad("internal: a shard re-matched although no cache hand-over needed repair");
+      settled = true;
+    }
+  }
+  if (!settled) {
+    // the shared OOPE cache across shards: exchange, re-check, until no shard changes its final entry
+    for (int round = 0; round <= world; ++round) {
+      if (round > 0) {
+        slamhip_carry_record mine;
+        rc = slamhip_gmapping_carry_record(g, &mine);
+        if (rc) return rc;
+        rc = slamhip_shard_allgather(g->ctx, &mine, ones.data(), (int)sizeof(mine), recs.data());
+        if (rc) return rc;
+      }
+      int changed = 0;
+      rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);
+      if (rc) return rc;
+      int any = 0;
+      std::vector<int> flags(world, 0);
+      rc = slamhip_shard_allgather(g->ctx, &changed, ones.data(), (int)sizeof(int), flags.data());
+      if (rc) return rc;
+      for (int f : flags) any |= f;
+      if (!any) break;
+    }
   }
   rc = slamhip_gmapping_carry_commit(g, recs.data(), world);
   if (rc) return rc;
-  std::vector<double> raw(g->count), all(g->n_total);
   rc = slamhip_gmapping_match_finish(g, raw.data());
   if (rc) return rc;
-  // the one data-path collective of a step: all raw weights, in particle order
-  rc = slamhip_shard_allgather(g->ctx, raw.data(), g->shard_counts.data(), (int)sizeof(double), all.data());
-  if (rc) return rc;
+  if (!settled) {
+    // a re-match may have changed a shard's weights: all raw weights once more, in particle order
+    rc = slamhip_shard_allgather(g->ctx, raw.data(), g->shard_counts.data(), (int)sizeof(double), all.data());
+    if (rc) return rc;
+  }
   std::vector<unsigned> idx(g->n_total);
   int req = 0;
   rc = slamhip_gmapping_plan_resample(g, all.data(), resample_seed, &req, idx.data());

@@ -14,7 +14,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "slamhip_internal.h"
@@ -54,8 +59,24 @@ static Rccl *rccl() {
   return r.lib ? &r : nullptr;
 }
 
+// An in-process group: the "ranks" are threads of ONE process (each with its own context, all on whatever GPUs the
+// process sees), the all-gather goes through host memory behind a mutex.  It exists so that
+// slamhip_gmapping_step_sharded -- the protocol above the collective -- can be run with world > 1 where only one
+// GPU is available (tests/test_gpu_shard.py); RCCL itself admits one rank per device.
+struct LoopbackBoard {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, arrived = 0, left = 0;
+  long long generation = 0;
+  std::vector<std::vector<char>> blocks;
+};
+static std::mutex g_boards_mu;
+static std::map<std::string, std::shared_ptr<LoopbackBoard>> g_boards;
+static constexpr char kLoopbackTag[] = "SLAMHIP-LOOPBACK:";
+
 struct ShardState {
   ncclComm_t comm = nullptr;
+  std::shared_ptr<LoopbackBoard> board;  // non-null: an in-process group instead of an RCCL communicator
   int rank = 0, world = 1;
   char *d_send = nullptr, *d_recv = nullptr;  // device staging of the padded blocks
   char *h_send = nullptr, *h_recv = nullptr;  // pinned mirrors
@@ -95,6 +116,7 @@ void shard_release(slamhip_ctx *ctx) {
     Rccl *r = rccl();
     if (r) r->CommDestroy(s->comm);
   }
+  s->board.reset();
   free_buffers(s);
   delete s;
   ctx->shard = nullptr;
@@ -121,6 +143,28 @@ int slamhip_shard_unique_id(void *id_out) {
 int slamhip_shard_init(slamhip_ctx *ctx, int rank, int world, const void *id) {
   if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return invalid_arg("bad shard geometry");
   if (ctx->shard) return invalid_arg("the context already belongs to a shard group");
+  if (std::memcmp(id, kLoopbackTag, sizeof(kLoopbackTag) - 1) == 0) {
+    // in-process group: the rest of the id names it
+    const std::string name(static_cast<const char *>(id), strnlen(static_cast<const char *>(id), SLAMHIP_SHARD_ID_BYTES));
+    std::shared_ptr<LoopbackBoard> b;
+    {
+      std::lock_guard<std::mutex> lk(g_boards_mu);
+      auto &slot = g_boards[name];
+      if (!slot) {
+        slot = std::make_shared<LoopbackBoard>();
+        slot->world = world;
+        slot->blocks.resize(world);
+      }
+      b = slot;
+    }
+    if (b->world != world) return invalid_arg("the in-process group was created with another size");
+    auto *s = new ShardState;
+    s->rank = rank;
+    s->world = world;
+    s->board = b;
+    ctx->shard = s;
+    return SLAMHIP_OK;
+  }
   Rccl *r = rccl();
   if (!r) return no_rccl();
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
@@ -172,8 +216,6 @@ int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *coun
     set_error("slamhip_shard_init has not been called on this context");
     return SLAMHIP_ERR_STATE;
   }
-  Rccl *r = rccl();
-  if (!r) return no_rccl();
   int max_count = 0;
   for (int q = 0; q < s->world; ++q) {
     if (counts[q] < 0) return invalid_arg("negative block size");
@@ -182,6 +224,40 @@ int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *coun
   if (counts[s->rank] > 0 && !local) return invalid_arg("null local block");
   const size_t block = (size_t)max_count * elem_bytes;
   if (block == 0) return SLAMHIP_OK;
+  if (s->board) {
+    // every rank posts its block, waits for the others, copies all of them out, and the last one to leave
+    // opens the board for the next collective
+    LoopbackBoard &b = *s->board;
+    std::unique_lock<std::mutex> lk(b.mu);
+    b.cv.wait(lk, [&] { return b.left == 0; });  // the previous collective has been read by everybody
+    const long long gen = b.generation;
+    b.blocks[s->rank].assign(static_cast<const char *>(local), static_cast<const char *>(local) + (size_t)counts[s->rank] * elem_bytes);
+    if (++b.arrived == b.world) {
+      b.arrived = 0;
+      b.left = b.world;
+      ++b.generation;
+      b.cv.notify_all();
+    } else {
+      b.cv.wait(lk, [&] { return b.generation != gen; });
+    }
+    char *out = static_cast<char *>(all_out);
+    for (int q = 0; q < s->world; ++q) {
+      const size_t nb = (size_t)counts[q] * elem_bytes;
+      if (b.blocks[q].size() != nb) {
+        --b.left;
+        b.cv.notify_all();
+        return invalid_arg("the ranks of an in-process group disagree about the block sizes");
+      }
+      std::memcpy(out, b.blocks[q].data(), nb);
+      out += nb;
+    }
+    if (--b.left == 0) b.cv.notify_all();
+    s->collectives += 1;
+    s->bytes += (long long)(block * s->world);
+    return SLAMHIP_OK;
+  }
+  Rccl *r = rccl();
+  if (!r) return no_rccl();
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
   if (block > s->cap) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));

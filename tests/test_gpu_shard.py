@@ -56,7 +56,9 @@ def test_one_rank_over_rccl_equals_unsharded_step(pkg):
             np.testing.assert_array_equal(x, y)
     assert resampled >= 1
     st = ctx.shard_stats()
-    assert st["collectives"] >= 8 * 3 and st["bytes"] > 0
+    # the all-gather above and the block sizes once, then ONE collective per step (carry records + raw weights)
+    # and the particle records of every resampling
+    assert st["collectives"] == 2 + 8 + resampled and st["bytes"] > 0
     ctx.shard_destroy()
     ctx.close()
 
@@ -201,4 +203,113 @@ def test_two_ranks_over_rccl(pkg, tmp_path):
         pw, ww, mw = whole.state()
         np.testing.assert_array_equal(np.concatenate([logs[0][k][2], logs[1][k][2]]), pw)
         np.testing.assert_array_equal(np.concatenate([logs[0][k][3], logs[1][k][3]]), ww)
+    ctx.close()
+
+
+def loopback_id(name):
+    """128-byte group id of an in-process group (csrc/shard.cpp: the ranks are threads of this process)"""
+    raw = ("SLAMHIP-LOOPBACK:" + name).encode()
+    return np.frombuffer(raw + b"\0" * (128 - len(raw)), dtype=np.uint8).copy()
+
+
+def run_loopback_ranks(pkg, world, n, scene, steps, scan, gp, name):
+    """slamhip_gmapping_step_sharded on `world` ranks = threads, one context each on GPU 0; returns per-rank logs"""
+    import threading
+    uid = loopback_id(name)
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
+    logs, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            ctx = pkg.Context(0)
+            ctx.shard_init(rank, world, uid)
+            ctx.upload_map(1, scene["map"])
+            first = sum(counts[:rank])
+            pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds[first:first + counts[rank]], first=first,
+                                    count=counts[rank])
+            log = []
+            for k, d in enumerate(steps):
+                res, idx = pf.step_sharded(1, scan.range, scan.angle, None, d, 7 + k)
+                p, w, m = pf.state()
+                log.append((res, None if idx is None else np.array(idx).copy(), p, w, m, pf.stats()["carry_reruns"]))
+            logs[rank] = (log, ctx.shard_stats())
+            pf.close()
+            ctx.shard_destroy()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank is stuck in a collective"
+    return logs, counts
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_step_sharded_over_an_in_process_group(pkg, world):
+    """The library's own sharded step (slamhip_gmapping_step_sharded: match, ONE all-gather of carry records +
+    raw weights, identical resampling everywhere, records all-gathered when a resampling happens) with world > 1
+    on one GPU: the ranks are threads, the collective an in-process board (the RCCL communicator admits one rank
+    per device).  Every rank must hold exactly the particles of the unsharded filter after every step."""
+    ctx = pkg.Context(0)
+    sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    n = 21
+    steps = deltas(sc, 8)
+    whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=GP), n, np.arange(2000, 2000 + n, dtype=np.uint32))
+    logs, counts = run_loopback_ranks(pkg, world, n, sc, steps, sc["scan"], GP, "steps-%d" % world)
+    resampled = 0
+    for k, d in enumerate(steps):
+        rw, iw = whole.step(1, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+        pw, ww, mw = whole.state()
+        resampled += int(rw)
+        for r in range(world):
+            res, idx, p, w, m, _ = logs[r][0][k]
+            assert res == rw
+            if rw:
+                np.testing.assert_array_equal(idx, iw)
+        np.testing.assert_array_equal(np.concatenate([logs[r][0][k][2] for r in range(world)]), pw)
+        np.testing.assert_array_equal(np.concatenate([logs[r][0][k][3] for r in range(world)]), ww)
+        np.testing.assert_array_equal(np.concatenate([logs[r][0][k][4] for r in range(world)]), mw)
+    assert resampled >= 1
+    # one collective per step (+ the block sizes once, + the particle records of every resampling)
+    for r in range(world):
+        assert logs[r][1]["collectives"] == 1 + len(steps) + resampled, logs[r][1]
+    ctx.close()
+
+
+def test_step_sharded_repairs_the_cache_across_ranks(pkg):
+    """The scene of test_cache_hit_across_the_shard_boundary through slamhip_gmapping_step_sharded: when a shard's
+    first job meets its predecessor's final cache entry with another value, every rank reads that off the records,
+    the slow protocol runs (re-match, exchange until nothing changes, weights once more) and the result is still the
+    unsharded filter's."""
+    from synth import Scan
+    ctx = pkg.Context(0)
+    sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
+    ctx.upload_map(1, sc["map"])
+    full = sc["scan"]
+    reruns = extra_collectives = 0
+    for j, pick in enumerate(([10], [200, 201], [100])):
+        scan = Scan(full.range[pick], full.angle[pick], np.full(len(pick), 1.0 / len(pick)))
+        gp = [0.0, 1e-9, 0.0, 1e-9, 0.0, 0.0, 0.0, 0.0]
+        steps = [sc["true_pose"], [0.02, 0.01, 0.0], [0.0, 0.03, 0.01], [0.01, 0.0, 0.0]]
+        n, world = 9, 2
+        whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, np.arange(2000, 2000 + n, dtype=np.uint32))
+        logs, counts = run_loopback_ranks(pkg, world, n, sc, steps, scan, gp, "repair-%d" % j)
+        resampled = 0
+        for k, d in enumerate(steps):
+            rw, iw = whole.step(1, scan.range, scan.angle, None, d, 7 + k)
+            resampled += int(rw)
+            pw, ww, mw = whole.state()
+            np.testing.assert_array_equal(np.concatenate([logs[r][0][k][2] for r in range(world)]), pw)
+            np.testing.assert_array_equal(np.concatenate([logs[r][0][k][3] for r in range(world)]), ww)
+        reruns += sum(logs[r][0][k][5] for r in range(world) for k in range(len(steps)))
+        extra_collectives += logs[0][1]["collectives"] - (1 + len(steps) + resampled)
+    assert reruns > 0, "the scene did not exercise a hand-over across the ranks"
+    assert extra_collectives > 0  # the repair rounds did run
     ctx.close()
