@@ -16,6 +16,7 @@
 
 #include <condition_variable>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -116,7 +117,11 @@ void shard_release(slamhip_ctx *ctx) {
     Rccl *r = rccl();
     if (r) r->CommDestroy(s->comm);
   }
-  s->board.reset();
+  if (s->board) {
+    s->board.reset();
+    std::lock_guard<std::mutex> lk(g_boards_mu);  // a group nobody belongs to any more is forgotten
+    for (auto it = g_boards.begin(); it != g_boards.end();) it = it->second.use_count() == 1 ? g_boards.erase(it) : std::next(it);
+  }
   free_buffers(s);
   delete s;
   ctx->shard = nullptr;
