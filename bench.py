@@ -428,15 +428,23 @@ def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, firs
                     "on resampling" % world}
 
 
-def k6_roofline(ctx, note):
+def k6_roofline(ctx, note, leg=None):
     """roofline object of the map update from the HIP events recorded around every K6 pipeline since the last
-    reset (slamhip_profile_read_map_update)."""
+    reset (slamhip_profile_read_map_update); `traffic`: HBM bytes per pipeline from the committed PMC passes of
+    that leg (all of the pipeline's dispatches added up)."""
     ms, calls, records = ctx.profile_read_map_update(reset=True)
     if not calls or ms <= 0:
         return None
     achieved = records * K6_BYTES_PER_RECORD / (ms * 1e-3) / 1e9
+    traffic, traffic_src = load_traffic("k6_" + leg) if leg else (None, None)
+    measured = {}
+    if traffic:
+        # what the memory system really moved per pipeline (PMC passes of the same leg) over the live pipeline time
+        gbs = traffic / (ms * 1e-3 / calls) / 1e9
+        measured = {"hbm_gbs_measured": gbs, "hbm_utilisation": gbs / HBM_PEAK_GBS,
+                    "traffic_over_algorithmic": traffic / (records * K6_BYTES_PER_RECORD / calls)}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "K6 pipeline (k_mu_count .. k_mu_apply, sort included)",
+            "traffic": traffic, "traffic_source": traffic_src, **measured, "kernel": "K6 pipeline (k_mu_count .. k_mu_apply, sort included)",
             "bytes_per_unit": K6_BYTES_PER_RECORD, "unit_of_work": "(beam, cell) record", "launches": calls,
             "units_launched": records, "avg_launch_us": 1e3 * ms / calls,
             "timing": "HIP events recorded around each K6 pipeline on the context's stream, " + note}
@@ -594,7 +602,7 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
                                   "note": "sequential particles: GPU match then K6 map update on the shared map, as "
                                           "the reference does",
                                   "roofline_map_update": k6_roofline(ctx, "one extra step after the timed pass (%d "
-                                                                          "single-scan updates)" % n)}
+                                                                          "single-scan updates)" % n, "pf_update")}
         pfu.close()
     if world == 1 and "pf_maps" in legs:
         # per-particle copy-on-write maps (tile pool): lock-step matching on every
@@ -628,7 +636,7 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
                 "cell_updates_last_step": stt["cell_updates"],
                 "note": "every particle owns a copy-on-write map (128x128-cell tiles); matching in "
                         "lock-step, map updates of all particles in one batched K6",
-                "roofline_map_update": k6_roofline(ctx, "2 extra steps after the timed pass")}
+                "roofline_map_update": k6_roofline(ctx, "2 extra steps after the timed pass", "pf_maps")}
             pfm.close()
         except pkg.SlamHipError as e:  # e.g. the pool does not fit: report, do not hide
             out["with_particle_maps"] = {"error": str(e)}
@@ -695,7 +703,7 @@ def cfg5_leg(args, pkg, ctx, torch):
            "workload": "cfg5: GMapping %d particles on 1 GPU, %d beams, %dx%d @%.3f m, per-particle copy-on-write maps, "
                        "area occupancy estimator + blur 0.1 m map update in one batched K6 per step fused behind the "
                        "lock-step likelihood" % (n, scan.n, size, size, scale),
-           "roofline": k6_roofline(ctx, "2 extra steps after the timed pass"), "roofline_likelihood": k3,
+           "roofline": k6_roofline(ctx, "2 extra steps after the timed pass", "cfg5"), "roofline_likelihood": k3,
            "cell_updates_last_step": ms["cell_updates"], "tiles_in_use": ms["tiles_in_use"], "pool_bytes": ms["bytes"],
            "dense_ancestor_bytes": size * size * 48, "cow_copies_first_step": first["cow_copies"],
            "launches_last_step": st["launches"], "scene_build_s": round(t_scene, 1),

@@ -32,6 +32,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc mc $c $c -- --workload mc --legs none --steps 5 --warmup 1 --no-cpu
   pmc pf $c $c -- --legs pf --steps 3 --warmup 1 --no-cpu --pf-steps 4
 done
+# the map-update pipeline (K6) of the three legs that run it: HBM bytes per pipeline = all k_mu_* / rocprim dispatches
+for c in FETCH_SIZE WRITE_SIZE; do
+  pmc pf_update $c $c -- --legs pf_update --steps 3 --warmup 1 --no-cpu
+  pmc pf_maps $c $c -- --legs pf_maps --steps 3 --warmup 1 --no-cpu
+  pmc cfg5 $c $c -- --legs cfg5 --steps 3 --warmup 1 --no-cpu
+done
 pmc hc sq $SQ -- --legs none --steps 10 --warmup 2 --no-cpu
 pmc sweep sq $SQ -- --workload sweep --steps 20 --warmup 2 --no-cpu
 pmc mc sq $SQ -- --workload mc --legs none --steps 5 --warmup 1 --no-cpu

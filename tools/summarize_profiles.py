@@ -117,8 +117,33 @@ for wl in ("hc", "sweep", "mc", "pf"):
                              (v["issue_frac"], insts, mean_ns / 1e3))
             t["valu"] = v
         lines.append("")
+# K6: HBM bytes per map-update pipeline = the counters of ALL its dispatches (k_mu_*, rocprim scan / sort) added up,
+# divided by the number of pipelines (one k_mu_apply each)
+for wl in ("pf_update", "pf_maps", "cfg5"):
+    t = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        total, pipelines = 0.0, 0
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"]
+            if r["Counter_Name"] != c or not ("k_mu_" in name or "rocprim" in name):
+                continue
+            total += float(r["Counter_Value"])
+            pipelines += 1 if "k_mu_apply" in name else 0
+        if pipelines:
+            t[c + "_kb_raw"] = total / pipelines
+            t["pipelines"] = pipelines
+    if "FETCH_SIZE_kb_raw" in t and "WRITE_SIZE_kb_raw" in t:
+        t["kernel"] = "K6 pipeline (k_mu_* and rocprim dispatches of one map update)"
+        t["bytes_per_launch"] = 1024.0 * (2.0 * t["FETCH_SIZE_kb_raw"] + t["WRITE_SIZE_kb_raw"])
+        t["correction"] = "FETCH_SIZE KB x2 (gfx950), WRITE_SIZE KB as reported; separate --pmc passes; summed over the pipeline's dispatches"
+        traffic["k6_" + wl] = t
+        lines.append("## PMC, K6 pipeline of leg %s\n\n* HBM traffic per map-update pipeline = %.0f bytes over %d pipelines (%s)\n"
+                     % (wl, t["bytes_per_launch"], t["pipelines"], t["correction"]))
 # units per launch (for instructions per unit) from the un-profiled bench lines
-for wl in list(traffic):
+for wl in [w for w in traffic if not w.startswith("k6_")]:
     pj = os.path.join(src, "%s.plain.json" % wl)
     try:
         if os.path.exists(pj) and os.path.getsize(pj) > 0:
@@ -134,6 +159,8 @@ for wl in list(traffic):
     except Exception:  # noqa: BLE001
         pass
 for wl, t in traffic.items():
+    if wl.startswith("k6_"):
+        continue
     t["kernel"] = PMC_KERNEL[wl]
     if "FETCH_SIZE_kb_raw" in t and "WRITE_SIZE_kb_raw" in t:
         # MI355X_MICROARCH.md, HBM: rocprofv3 reports KB; on gfx950 FETCH_SIZE tallies 128-B
