@@ -785,10 +785,22 @@ __device__ __forceinline__ MuCell mu_cell_load(const MuArgs &a, size_t at) {
   return c;
 }
 
+// `was` is what mu_cell_load returned.  A GMapping cell in free space (mean 0) only counts tries: its 32-byte
+// payload keeps its bits and is not written back -- most cells of a scan are like that, and with one cell per
+// 32-byte sector that write is a third of the kernel's HBM bytes.
 template <int RULE>
-__device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const MuCell &c) {
-  if (RULE >= 3) reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
-  else a.payload[at] = c.c0;
+__device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const MuCell &c, const MuCell &was) {
+  if (RULE == 4) {
+    const bool same = __double_as_longlong(c.c0) == __double_as_longlong(was.c0) &&
+                      __double_as_longlong(c.c1) == __double_as_longlong(was.c1) &&
+                      __double_as_longlong(c.c2) == __double_as_longlong(was.c2) &&
+                      __double_as_longlong(c.c3) == __double_as_longlong(was.c3);
+    if (!same) reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
+  } else if (RULE == 3) {
+    reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
+  } else {
+    a.payload[at] = c.c0;
+  }
   if (RULE == 2) a.aux[at] = c.x0;
   if (RULE == 4) reinterpret_cast<double2 *>(a.aux)[at] = make_double2(c.x0, c.x1);
 }
@@ -820,6 +832,7 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
     const Key hkey = keys[hi];
     const size_t at = mu_cell_index<Key>(a, hkey);
     MuCell c = mu_cell_load<RULE>(a, at);
+    const MuCell was = c;
     for (unsigned j0 = hi;; j0 += 64) {
       const unsigned j = j0 + lane;
       const bool in = j < total;
@@ -860,7 +873,7 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
       }
       if (n_here < 64) break;
     }
-    if (lane == src) mu_cell_store<RULE>(a, at, c);
+    if (lane == src) mu_cell_store<RULE>(a, at, c, was);
   }
 }
 
@@ -897,6 +910,7 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
     at = mu_cell_index<Key>(a, key);
     c = mu_cell_load<RULE>(a, at);
   }
+  const MuCell was = c;
   for (int t = 0; __any(head && t < len_here); ++t) {
     const double pt = __shfl(p, lane + t, 64);
     const double qt = RULE == 3 ? __shfl(q, lane + t, 64) : 0.0;
@@ -936,7 +950,7 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
       }
     }
   }
-  if (head) mu_cell_store<RULE>(a, at, c);
+  if (head) mu_cell_store<RULE>(a, at, c, was);
   mu_apply_long_chains<Key, RULE>(a, keys, total, i, lane, is_long);
 }
 
