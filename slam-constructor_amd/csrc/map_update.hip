@@ -559,6 +559,10 @@ struct MuBatchScratch {
   unsigned long long *n_updates = nullptr, *d_total = nullptr, *h_status = nullptr;
   void *temp = nullptr, *scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
+  // free-space fast path (mu_batch_fast_tail)
+  unsigned *special = nullptr, *wave_cnt = nullptr, *wave_off = nullptr;
+  unsigned long long *wave_mask = nullptr;
+  size_t special_words = 0, cap_waves = 0;
 };
 MuBatchScratch &bscratch_of(slamhip_ctx *ctx) {
   if (!ctx->mu_bscratch) ctx->mu_bscratch = new MuBatchScratch;
@@ -606,6 +610,75 @@ int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t be
     hipLaunchKernelGGL((k_mu_gather<Key, 0>), rgrid, dim3(256), 0, st, a, (const Key *)keys_sorted,
                        (const unsigned *)sc.order_sorted, total, sc.srt_prob, (double *)nullptr);
   mu_launch_apply<Key>(a, (const Key *)keys_sorted, total, st);
+  return SLAMHIP_OK;
+}
+
+// The batch with the free-space fast path (map_update_kernels.h, k_mu_classify): walk, classify (the commuting
+// updates are applied there), compact what is left, and sort / evaluate / apply only that.  32-bit keys.
+int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t beams, unsigned end_bit, hipStream_t st,
+                       unsigned *n_slow_out) {
+  const size_t words = ((size_t)1 << (end_bit - 1)) / 32 + 1;  // one bit per valid key
+  if (words > sc.special_words) {
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+    SLAMHIP_CHECK(regrow(sc.special, words));
+    sc.special_words = words;
+  }
+  const size_t waves = ((size_t)total + 63) / 64;
+  if (waves > sc.cap_waves) {
+    SLAMHIP_CHECK(hipStreamSynchronize(st));
+    size_t cap = 4096;
+    while (cap < waves) cap *= 2;
+    SLAMHIP_CHECK(regrow(sc.wave_cnt, cap));
+    SLAMHIP_CHECK(regrow(sc.wave_off, cap));
+    SLAMHIP_CHECK(regrow(sc.wave_mask, cap));
+    sc.cap_waves = cap;
+  }
+  SLAMHIP_CHECK(hipMemsetAsync(sc.special, 0, sizeof(unsigned) * words, st));
+  a.special = sc.special;
+  unsigned *keys = (unsigned *)sc.keys, *keys_c = (unsigned *)sc.keys_sorted;
+  const dim3 rgrid((total + 255) / 256);
+  hipLaunchKernelGGL((k_mu_emit<unsigned, -1>), dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, st, a, sc.order);
+  if (a.est_kind == 1)
+    hipLaunchKernelGGL(k_mu_classify<1>, rgrid, dim3(256), 0, st, a, (const unsigned *)keys, (const unsigned *)sc.order,
+                       total, sc.wave_mask, sc.wave_cnt);
+  else
+    hipLaunchKernelGGL(k_mu_classify<0>, rgrid, dim3(256), 0, st, a, (const unsigned *)keys, (const unsigned *)sc.order,
+                       total, sc.wave_mask, sc.wave_cnt);
+  {
+    size_t need = 0;
+    SLAMHIP_CHECK(rocprim::exclusive_scan(nullptr, need, sc.wave_cnt, sc.wave_off, 0u, waves, rocprim::plus<unsigned>(), st));
+    if (need > sc.scan_temp_bytes) {
+      SLAMHIP_CHECK(hipStreamSynchronize(st));
+      if (sc.scan_temp) hipFree(sc.scan_temp);
+      sc.scan_temp = nullptr;
+      SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, need));
+      sc.scan_temp_bytes = need;
+    }
+    SLAMHIP_CHECK(rocprim::exclusive_scan(sc.scan_temp, need, sc.wave_cnt, sc.wave_off, 0u, waves, rocprim::plus<unsigned>(), st));
+  }
+  hipLaunchKernelGGL(k_mu_total, dim3(1), dim3(1), 0, st, (const unsigned *)sc.wave_cnt, (const unsigned *)sc.wave_off,
+                     waves, sc.d_total);
+  unsigned long long n_slow64 = 0;
+  SLAMHIP_CHECK(hipMemcpyAsync(&n_slow64, sc.d_total, sizeof(n_slow64), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_mu_compact, rgrid, dim3(256), 0, st, (const unsigned *)keys, (const unsigned *)sc.order, total,
+                     (const unsigned long long *)sc.wave_mask, (const unsigned *)sc.wave_off, keys_c, sc.order_sorted);
+  SLAMHIP_CHECK(hipStreamSynchronize(st));
+  const unsigned n_slow = (unsigned)n_slow64;
+  *n_slow_out = n_slow;
+  if (n_slow == 0) return SLAMHIP_OK;
+  // the compacted records go back into the buffers the walk filled (dead by now), sorted
+  size_t tb = sc.temp_bytes;
+  SLAMHIP_CHECK(rocprim::radix_sort_pairs<BatchSortConfig<unsigned>>(sc.temp, tb, keys_c, keys, sc.order_sorted, sc.order,
+                                                                     n_slow, 0, std::min(end_bit, 32u), st));
+  a.rec_beam = sc.order;
+  const dim3 sgrid((n_slow + 255) / 256);
+  if (a.est_kind == 1)
+    hipLaunchKernelGGL((k_mu_gather<unsigned, 1>), sgrid, dim3(256), 0, st, a, (const unsigned *)keys,
+                       (const unsigned *)sc.order, n_slow, sc.srt_prob, (double *)nullptr);
+  else
+    hipLaunchKernelGGL((k_mu_gather<unsigned, 0>), sgrid, dim3(256), 0, st, a, (const unsigned *)keys,
+                       (const unsigned *)sc.order, n_slow, sc.srt_prob, (double *)nullptr);
+  mu_launch_apply<unsigned>(a, (const unsigned *)keys, n_slow, st);
   return SLAMHIP_OK;
 }
 }  // namespace
@@ -842,7 +915,17 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   const unsigned end_bit = cell_bits + job_bits + 1;
   // (sorting by the cell bits alone -- one pass less, chains then ordered (cell, job) -- was measured: the
   // sort gains 100 us, k_mu_apply loses 190 us to the scattered tiles of consecutive chains)
-  if (end_bit <= 32 && !getenv("SLAMHIP_K6_KEY64"))
+  // free-space fast path: the const estimator's free observation must be valid and free, the bitmap of marked cells
+  // at most 256 MB (end_bit <= 32)
+  const bool fast_off = getenv("SLAMHIP_K6_FAST") && !strcmp(getenv("SLAMHIP_K6_FAST"), "0");
+  const bool fast = !fast_off && end_bit <= 32 && cfg->base_empty_prob <= 0.5 && !std::isnan(cfg->base_empty_qual) &&
+                    !getenv("SLAMHIP_K6_KEY64");
+  unsigned n_slow = 0;
+  if (fast) {
+    a.unknown_c0 = tp->unknown[0];
+    a.fresh_ok = tp->unknown[0] < 0.0 ? 1 : 0;
+    rc = mu_batch_fast_tail(a, sc, total, beams, end_bit, st, &n_slow);
+  } else if (end_bit <= 32 && !getenv("SLAMHIP_K6_KEY64"))
     rc = mu_batch_tail<unsigned>(a, sc, total, beams, end_bit, st);
   else
     rc = mu_batch_tail<unsigned long long>(a, sc, total, beams, end_bit, st);
@@ -886,7 +969,8 @@ void mu_release(slamhip_ctx *ctx) {
     for (void *p : {(void *)s.counts, (void *)s.offsets, (void *)s.order, (void *)s.order_sorted, (void *)s.keys,
                     (void *)s.keys_sorted, (void *)s.beam_info, (void *)s.beam_end, (void *)s.scan,
                     (void *)s.srt_prob, (void *)s.occ, (void *)s.error_flag,
-                    (void *)s.d_jobs, (void *)s.d_bbox, (void *)s.n_updates, (void *)s.d_total, s.temp, s.scan_temp})
+                    (void *)s.d_jobs, (void *)s.d_bbox, (void *)s.n_updates, (void *)s.d_total, s.temp, s.scan_temp,
+                    (void *)s.special, (void *)s.wave_cnt, (void *)s.wave_off, (void *)s.wave_mask})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
     delete &s;

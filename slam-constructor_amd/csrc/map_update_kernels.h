@@ -65,6 +65,11 @@ struct MuArgs {
   // visit them instead (k_mu_near_bits) -- which also is their chain in beam order
   unsigned long long *near_bits;  // [(2 near_r + 1)^2][near_words]
   int near_r, near_words, robot_ix, robot_iy;  // robot cell in internal coordinates
+  // batch, free-space fast path (k_mu_classify): one bit per sort key, set by k_mu_emit for every cell a beam may
+  // observe as occupied (its end cell and the cells inside the blur distance)
+  unsigned *special;
+  double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
+  int fresh_ok;
 };
 
 // index of a key's cell in the near grid, -1: a far cell
@@ -321,6 +326,9 @@ __device__ void mu_walk_beam(const MuArgs &a, int b) {  // b = global beam index
   if (bad) *a.error_flag = 1;
 }
 
+template <typename Key>
+__device__ __forceinline__ int mu_key_cell(const MuArgs &a, Key key, int *ix, int *iy);
+
 // The walk in parallel.  The reference's loop (regular_squares_grid.h:56-101) is a floating-point recurrence
 // per beam -- 76 of the 170 us of a single-scan update went to 17 waves stepping 600 cells one after the other.
 // But away from ties it is a plain digital line: with A = e_x_inc, B = e_y_inc (opposite signs), u = sign(A) e
@@ -447,6 +455,24 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
     __threadfence();  // lane 0's keys, read back by the whole wave below
   } else if (__any(bad) && lane == 0) {
     *a.error_flag = 1;
+  }
+  if (a.special) {
+    // a SUPERSET of the cells this beam can observe with a probability above 0.5 (mu_value): its end cell and the
+    // cells closer to it than the blur distance.  Along a monotone walk the L1 distance to the end cell is the
+    // number of steps left, so only the last sqrt(2) * blur steps can qualify; a walk the sequential fail-over
+    // rewrote is tested cell by cell.  (Lane k0 + lane reads the key it wrote itself.)
+    const double hole_sq = a.beam_info[b].hole_dist_sq;
+    const unsigned m = ok ? min(cap, (unsigned)ceil(1.4143 * sqrt(hole_sq)) + 2u) : cap;
+    for (unsigned k = ((cap - m) & ~63u) + lane; k < cap; k += 64) {
+      if (k + m < cap) continue;
+      const KeyT key = out[k];
+      if (key == ~KeyT(0)) continue;
+      int cix, ciy;
+      mu_key_cell<KeyT>(a, key, &cix, &ciy);
+      const double cdx = (cix - a.origin_x) - ex, cdy = (ciy - a.origin_y) - ey;
+      const double dist_sq = cdx * cdx + cdy * cdy;
+      if (dist_sq == 0.0 || dist_sq < hole_sq) atomicOr(&a.special[(size_t)(key >> 5)], 1u << (unsigned)(key & 31));
+    }
   }
   if (a.bins) {
     // the beam's keys are final: count them per cell of the key window (padding and cells outside it: no bin;
@@ -762,6 +788,83 @@ __device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
   const int job = mu_key_cell<Key>(a, key, &ix, &iy);
   const int tile = a.tables[(size_t)a.jobs[job].slot * a.table_stride + (iy >> kTileShift) * a.tiles_x + (ix >> kTileShift)];
   return ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+}
+
+// ---- batch: the free-space fast path -------------------------------------------------------------------------
+// GmappingBaseCell::operator+= (gmapping_grid_cell.h:20-33) for an observation that is valid and free
+// (occupancy <= 0.5) of a cell whose mean is 0:  ++_tries, mean = (0 * (_tries - 1) + 0) / _tries = +0.  No division
+// result depends on the order, and _tries is an integer far below 2^53: such updates COMMUTE, a floating-point atomic
+// add of 1.0 per observation gives the reference's cell bit for bit.  The same holds for a cell that was never
+// observed (mean = the prototype's -1, _tries 0): its first valid free observation leaves (+0, 1).  In a scan of a
+// mapped room 95+ % of the records are of that kind -- they do not need to be sorted into chains at all.
+//   k_mu_emit     marks the cells a beam may observe as occupied (MuArgs::special)
+//   k_mu_classify one thread per record, in emission order: unmarked cell with mean 0 (or never observed) ->
+//                 the observation's validity (area estimator) and the atomic; everything else -> flagged
+//   k_mu_compact  the flagged records, order kept, for the sort / gather / apply pipeline as before
+// A cell is in the same class for every record of the batch: the mark is set before, and the fast path moves a
+// mean only from -1 to +0, both "fast".  Cells that take the slow path are not touched here.
+template <int EST>
+__global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, const unsigned *keys, const unsigned *beam_of,
+                                                     unsigned total, unsigned long long *wave_mask,
+                                                     unsigned *wave_cnt) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool slow = false, pad = false;
+  if (i < total) {
+    const unsigned key = keys[i];
+    if (key == ~0u) {
+      pad = true;
+    } else if ((a.special[key >> 5] >> (key & 31u)) & 1u) {
+      slow = true;
+    } else {
+      const size_t at = mu_cell_index<unsigned>(a, key);
+      const double c0 = a.payload[4 * at];
+      const long long bits = __double_as_longlong(c0);
+      if (!(c0 == 0.0 || (a.fresh_ok && bits == __double_as_longlong(a.unknown_c0)))) {
+        slow = true;
+      } else {
+        // const estimator: (base_empty.prob, base_empty.qual), checked by the host.  Area estimator: the record is
+        // settled here only when mu_free_cell_valid PROVES the estimate valid (then it is base_empty.prob, free);
+        // the others -- the robot's own cell, corner grazes -- go with the flagged ones and get the full estimator
+        // in k_mu_gather: free updates commute, so a cell may take some of its records here and some there.
+        bool valid = true;
+        if (EST == 1) {
+          const int b = (int)beam_of[i];
+          int ix, iy;
+          mu_key_cell<unsigned>(a, key, &ix, &iy);
+          const int cx = ix - a.origin_x, cy = iy - a.origin_y;
+          const MuJob jb = mu_job(a, b);
+          valid = mu_free_cell_valid(jb.px, jb.py, a.beam_end[2 * b], a.beam_end[2 * b + 1], a.beam_inv[2 * b],
+                                     a.beam_inv[2 * b + 1], a.scale * cx, a.scale * (cx + 1), a.scale * cy,
+                                     a.scale * (cy + 1));
+          slow = !valid;
+        }
+        if (valid) {
+          unsafeAtomicAdd(&a.aux[2 * at + 1], 1.0);
+          if (bits != 0ll) a.payload[4 * at] = 0.0;
+        }
+      }
+    }
+  }
+  const unsigned long long mask = __ballot(slow), pads = __ballot(pad);
+  if (lane == 0 && i < total) {
+    wave_mask[i >> 6] = mask;
+    wave_cnt[i >> 6] = (unsigned)__popcll(mask);
+    if (pads) atomicAdd(a.n_padding, (unsigned long long)__popcll(pads));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mu_compact(const unsigned *keys, const unsigned *beam_of, unsigned total,
+                                                    const unsigned long long *wave_mask, const unsigned *wave_off,
+                                                    unsigned *keys_out, unsigned *beam_out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long mask = wave_mask[i >> 6];
+  if (!((mask >> lane) & 1ull)) return;
+  const unsigned pos = wave_off[i >> 6] + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+  keys_out[pos] = keys[i];
+  beam_out[pos] = beam_of[i];
 }
 
 template <int RULE>

@@ -26,7 +26,7 @@ def pkg():
     return ge.load_package()
 
 
-def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None):
+def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None):
     import pyoracle as po
     from pyoracle_mapupdate import (RULE_GMAPPING, append_scan_ex, gmapping_enable_particle_maps,
                                     gmapping_particle_map)
@@ -44,14 +44,15 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None):
     c0, s0 = pkg.beam_trig(a0)
     ctx.map_append_scan(4, pkg.RULE_GMAPPING, pose0, r0, c0, s0)
     pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, skip_rate=3, pose_trig=1), n, seeds)
-    pf.enable_particle_maps(4, extent_tiles=8, pool_tiles=16 + 24 * n)
+    adder = adder or {}
+    pf.enable_particle_maps(4, extent_tiles=8, pool_tiles=16 + 24 * n, **adder)
     # oracle side
     payload = np.tile(unknown, (h, w, 1)).astype(np.float64)
     m = po.GridMapData(po.CELL_GMAPPING, payload, g["origin"], scale, unknown)
     aux = np.zeros((h, w, 2))
     append_scan_ex(oracle, m, aux, RULE_GMAPPING, pose0, r0, a0)
     opf = oracle.gmapping_create(n, gp, seeds, skip_rate=3)
-    gmapping_enable_particle_maps(oracle, opf, m, aux)
+    gmapping_enable_particle_maps(oracle, opf, m, aux, **{{"estimator": "est_kind"}.get(k, k): v for k, v in adder.items()})
     got_p, got_a = pf.particle_map(n // 2, -ox, -oy, w, h)  # the ancestor went into the tiles intact
     np.testing.assert_array_equal(got_p[..., 0], m.payload[..., 0])
     np.testing.assert_array_equal(got_a, aux)
@@ -83,12 +84,16 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None):
     return pf, log, (ox, oy, w, h)
 
 
-@pytest.mark.parametrize("key64", [False, True])
-def test_particle_maps_filter_vs_oracle(pkg, oracle, key64, monkeypatch):
-    """key64: the batched map update with 8-byte (particle, cell) sort keys -- the fall-back for batches
-    whose particle and key-window bits exceed 32 -- forced through SLAMHIP_K6_KEY64."""
-    if key64:
+@pytest.mark.parametrize("mode", ["fast", "sorted", "key64"])
+def test_particle_maps_filter_vs_oracle(pkg, oracle, mode, monkeypatch):
+    """The batched map update three ways: `fast` (default) settles the free observations of zero-mean cells with
+    atomics and sorts only the rest (k_mu_classify); `sorted` (SLAMHIP_K6_FAST=0) sorts every record into cell
+    chains; `key64` is the sorted pipeline with 8-byte (particle, cell) keys -- the fall-back for batches whose
+    particle and key-window bits exceed 32 -- forced through SLAMHIP_K6_KEY64."""
+    if mode == "key64":
         monkeypatch.setenv("SLAMHIP_K6_KEY64", "1")
+    if mode == "sorted":
+        monkeypatch.setenv("SLAMHIP_K6_FAST", "0")
     n = 8
     pf, log, (ox, oy, w, h) = run_both(pkg, oracle, n=n)
     st = log[-1][1]
@@ -398,3 +403,57 @@ def test_cfg5_geometry_against_the_oracle(pkg, oracle):
     assert caveat_cells <= 64, "the caveat is rare: %d cells" % caveat_cells
     pf.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["fresh_map", "area_blur", "negative_blur", "free_points_and_range_gate",
+                                  "occupied_base_empty"])
+def test_fast_path_equals_the_sorted_chains(pkg, case, monkeypatch):
+    """The batched update's free-space fast path (k_mu_classify: atomics on the try counters of zero-mean and
+    never-observed cells) against the pipeline that sorts every record into its cell's chain, on the same pool
+    contents, bit for bit over every particle's whole map -- three scans in a row, so the second and third meet
+    cells the first one created.  Cases the oracle runs do not reach: a map nobody has written to, a blur that
+    scales with the beam length, points flagged free plus a range gate with non-finite ranges behind it, and a
+    base_empty probability above 0.5 (a "free" observation is then a hit: the fast path must stand aside)."""
+    from synth import make_scene
+    n, size, scale = 5, 512, 0.05
+    sc = make_scene(cell_model=2, size=size, scale=scale, n_beams=360, seed=11)
+    m, scan = sc["map"], sc["scan"]
+    rs = np.random.RandomState(3)
+    poses = sc["true_pose"] + rs.randn(n, 3) * [0.05, 0.05, 0.02]
+    adder = {}
+    occ = None
+    rng = scan.range.copy()
+    if case == "area_blur":
+        adder = {"blur": 0.25, "estimator": 1, "shift_amount": 0.01 * scale}
+    if case == "negative_blur":
+        adder = {"blur": -0.02}
+    if case == "free_points_and_range_gate":
+        adder = {"max_range": float(np.percentile(rng, 70)), "blur": 0.15}
+        occ = (rs.rand(scan.n) < 0.7).astype(np.int32)
+        rng[::17] = np.inf
+        rng[5::23] = 1e9
+    if case == "occupied_base_empty":
+        adder = {"base": (0.95, 1.0, 0.6, 1.0)}
+    maps = {}
+    for mode in ("fast", "sorted"):
+        monkeypatch.setenv("SLAMHIP_K6_FAST", "1" if mode == "fast" else "0")
+        ctx = pkg.Context(0)
+        ctx.map_bind(3, 2, size, size, m.origin, scale, m.unknown)
+        if case != "fresh_map":
+            ctx.map_upload_window(3, 0, 0, m.payload)
+        pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), n, np.arange(n, dtype=np.uint32))
+        pf.enable_particle_maps(3, extent_tiles=6, pool_tiles=8 + 20 * n, **adder)
+        total = 0
+        for k in range(3):
+            total += pf.particle_maps_append(np.arange(n), poses + 0.01 * k, rng, scan.angle, occ)
+        ox, oy = m.origin
+        maps[mode] = (total, [pf.particle_map(i, -ox, -oy, size, size) for i in range(n)])
+        pf.close()
+        ctx.close()
+    assert maps["fast"][0] == maps["sorted"][0] > 0
+    touched = 0
+    for (fp, fa), (sp, sa) in zip(maps["fast"][1], maps["sorted"][1]):
+        assert fp.tobytes() == sp.tobytes()
+        assert fa.tobytes() == sa.tobytes()
+        touched += int(np.count_nonzero(fa[..., 1]))
+    assert touched > n * 1000
