@@ -559,10 +559,9 @@ struct MuBatchScratch {
   unsigned long long *n_updates = nullptr, *d_total = nullptr, *h_status = nullptr;
   void *temp = nullptr, *scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
-  // free-space fast path (mu_batch_fast_tail)
-  unsigned *special = nullptr, *wave_cnt = nullptr, *wave_off = nullptr;
-  unsigned long long *wave_mask = nullptr;
-  size_t special_words = 0, cap_waves = 0;
+  // free-space fast path (mu_batch_fast_tail): the marked cells, per-beam count / place of the records left to sort
+  unsigned *special = nullptr, *slow_cnt = nullptr, *slow_off = nullptr;
+  size_t special_words = 0, cap_slow = 0;
 };
 MuBatchScratch &bscratch_of(slamhip_ctx *ctx) {
   if (!ctx->mu_bscratch) ctx->mu_bscratch = new MuBatchScratch;
@@ -623,30 +622,22 @@ int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t bea
     SLAMHIP_CHECK(regrow(sc.special, words));
     sc.special_words = words;
   }
-  const size_t waves = ((size_t)total + 63) / 64;
-  if (waves > sc.cap_waves) {
+  if (sc.cap_beams > sc.cap_slow) {
     SLAMHIP_CHECK(hipStreamSynchronize(st));
-    size_t cap = 4096;
-    while (cap < waves) cap *= 2;
-    SLAMHIP_CHECK(regrow(sc.wave_cnt, cap));
-    SLAMHIP_CHECK(regrow(sc.wave_off, cap));
-    SLAMHIP_CHECK(regrow(sc.wave_mask, cap));
-    sc.cap_waves = cap;
+    SLAMHIP_CHECK(regrow(sc.slow_cnt, sc.cap_beams));
+    SLAMHIP_CHECK(regrow(sc.slow_off, sc.cap_beams));
+    sc.cap_slow = sc.cap_beams;
   }
   SLAMHIP_CHECK(hipMemsetAsync(sc.special, 0, sizeof(unsigned) * words, st));
   a.special = sc.special;
   unsigned *keys = (unsigned *)sc.keys, *keys_c = (unsigned *)sc.keys_sorted;
-  const dim3 rgrid((total + 255) / 256);
-  hipLaunchKernelGGL((k_mu_emit<unsigned, -1>), dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, st, a, sc.order);
-  if (a.est_kind == 1)
-    hipLaunchKernelGGL(k_mu_classify<1>, rgrid, dim3(256), 0, st, a, (const unsigned *)keys, (const unsigned *)sc.order,
-                       total, sc.wave_mask, sc.wave_cnt);
-  else
-    hipLaunchKernelGGL(k_mu_classify<0>, rgrid, dim3(256), 0, st, a, (const unsigned *)keys, (const unsigned *)sc.order,
-                       total, sc.wave_mask, sc.wave_cnt);
+  const dim3 wgrid((unsigned)((beams + 3) / 4));  // a wave per beam
+  hipLaunchKernelGGL((k_mu_emit<unsigned, -1>), wgrid, dim3(256), 0, st, a, (unsigned *)nullptr);
+  if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_classify<1>, wgrid, dim3(256), 0, st, a, sc.slow_cnt);
+  else hipLaunchKernelGGL(k_mu_classify<0>, wgrid, dim3(256), 0, st, a, sc.slow_cnt);
   {
     size_t need = 0;
-    SLAMHIP_CHECK(rocprim::exclusive_scan(nullptr, need, sc.wave_cnt, sc.wave_off, 0u, waves, rocprim::plus<unsigned>(), st));
+    SLAMHIP_CHECK(rocprim::exclusive_scan(nullptr, need, sc.slow_cnt, sc.slow_off, 0u, beams, rocprim::plus<unsigned>(), st));
     if (need > sc.scan_temp_bytes) {
       SLAMHIP_CHECK(hipStreamSynchronize(st));
       if (sc.scan_temp) hipFree(sc.scan_temp);
@@ -654,14 +645,14 @@ int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t bea
       SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, need));
       sc.scan_temp_bytes = need;
     }
-    SLAMHIP_CHECK(rocprim::exclusive_scan(sc.scan_temp, need, sc.wave_cnt, sc.wave_off, 0u, waves, rocprim::plus<unsigned>(), st));
+    SLAMHIP_CHECK(rocprim::exclusive_scan(sc.scan_temp, need, sc.slow_cnt, sc.slow_off, 0u, beams, rocprim::plus<unsigned>(), st));
   }
-  hipLaunchKernelGGL(k_mu_total, dim3(1), dim3(1), 0, st, (const unsigned *)sc.wave_cnt, (const unsigned *)sc.wave_off,
-                     waves, sc.d_total);
+  hipLaunchKernelGGL(k_mu_total, dim3(1), dim3(1), 0, st, (const unsigned *)sc.slow_cnt, (const unsigned *)sc.slow_off,
+                     beams, sc.d_total);
   unsigned long long n_slow64 = 0;
   SLAMHIP_CHECK(hipMemcpyAsync(&n_slow64, sc.d_total, sizeof(n_slow64), hipMemcpyDeviceToHost, st));
-  hipLaunchKernelGGL(k_mu_compact, rgrid, dim3(256), 0, st, (const unsigned *)keys, (const unsigned *)sc.order, total,
-                     (const unsigned long long *)sc.wave_mask, (const unsigned *)sc.wave_off, keys_c, sc.order_sorted);
+  hipLaunchKernelGGL(k_mu_compact, wgrid, dim3(256), 0, st, a, (const unsigned *)sc.slow_cnt,
+                     (const unsigned *)sc.slow_off, keys_c, sc.order_sorted);
   SLAMHIP_CHECK(hipStreamSynchronize(st));
   const unsigned n_slow = (unsigned)n_slow64;
   *n_slow_out = n_slow;
@@ -970,7 +961,7 @@ void mu_release(slamhip_ctx *ctx) {
                     (void *)s.keys_sorted, (void *)s.beam_info, (void *)s.beam_end, (void *)s.scan,
                     (void *)s.srt_prob, (void *)s.occ, (void *)s.error_flag,
                     (void *)s.d_jobs, (void *)s.d_bbox, (void *)s.n_updates, (void *)s.d_total, s.temp, s.scan_temp,
-                    (void *)s.special, (void *)s.wave_cnt, (void *)s.wave_off, (void *)s.wave_mask})
+                    (void *)s.special, (void *)s.slow_cnt, (void *)s.slow_off})
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
     delete &s;

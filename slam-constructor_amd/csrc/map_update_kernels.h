@@ -442,14 +442,15 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
         const bool oob = ix >= w || iy >= h;
         bad |= oob;
         out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
-        beam_of[base + k] = (unsigned)b;
+        if (beam_of) beam_of[base + k] = (unsigned)b;
       }
     }
   }
   ok = __all(ok);
   if (!ok) {
     // the sequential walk decides (it rewrites every key of the beam and the padding)
-    for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
+    if (beam_of)
+      for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
     if (FUSE >= 0) __threadfence();  // lane 0's own stores above (counts, beam_end, beam_info), read back by the walk
     if (lane == 0) mu_walk_beam<KeyT>(a, b);
     __threadfence();  // lane 0's keys, read back by the whole wave below
@@ -798,73 +799,92 @@ __device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
 // observed (mean = the prototype's -1, _tries 0): its first valid free observation leaves (+0, 1).  In a scan of a
 // mapped room 95+ % of the records are of that kind -- they do not need to be sorted into chains at all.
 //   k_mu_emit     marks the cells a beam may observe as occupied (MuArgs::special)
-//   k_mu_classify one thread per record, in emission order: unmarked cell with mean 0 (or never observed) ->
-//                 the observation's validity (area estimator) and the atomic; everything else -> flagged
-//   k_mu_compact  the flagged records, order kept, for the sort / gather / apply pipeline as before
-// A cell is in the same class for every record of the batch: the mark is set before, and the fast path moves a
-// mean only from -1 to +0, both "fast".  Cells that take the slow path are not touched here.
+//   k_mu_classify one wave per beam, over the keys of its walk: unmarked cell with mean 0 (or never observed) ->
+//                 the observation's validity (area estimator) and the atomic; every other record moves to the
+//                 front of the beam's own stretch of the key buffer, order kept, and is counted per beam
+//   k_mu_compact  those stretches side by side (a scan of the per-beam counts gives the places), with the beam
+//                 of every record, for the sort / gather / apply pipeline as before
+// A cell that must go through a chain does so with ALL its records: the mark is set before, and the fast path moves
+// a mean only from -1 to +0, both "fast".  The other cells may split their records between the two paths.
 template <int EST>
-__global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, const unsigned *keys, const unsigned *beam_of,
-                                                     unsigned total, unsigned long long *wave_mask,
-                                                     unsigned *wave_cnt) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.n * a.n_jobs) return;
   const int lane = threadIdx.x & 63;
-  bool slow = false, pad = false;
-  if (i < total) {
-    const unsigned key = keys[i];
+  const unsigned cap = a.counts[b];
+  if (cap == 0) {
+    if (lane == 0) slow_cnt[b] = 0u;
+    return;
+  }
+  unsigned *out = (unsigned *)a.keys + a.offsets[b];
+  // per-beam constants of the validity proof (wave-uniform)
+  const MuJob jb = mu_job(a, b);
+  double wx = 0, wy = 0, inv_dx = 0, inv_dy = 0;
+  if (EST == 1) {
+    wx = a.beam_end[2 * b];
+    wy = a.beam_end[2 * b + 1];
+    inv_dx = a.beam_inv[2 * b];
+    inv_dy = a.beam_inv[2 * b + 1];
+  }
+  const long long unknown_bits = __double_as_longlong(a.unknown_c0);
+  unsigned n_slow = 0, n_pad = 0;
+  for (unsigned k0 = 0; k0 < cap; k0 += 64) {
+    const unsigned k = k0 + lane;
+    const unsigned key = k < cap ? out[k] : ~0u;
+    bool slow = false;
     if (key == ~0u) {
-      pad = true;
+      n_pad += k < cap ? 1u : 0u;
     } else if ((a.special[key >> 5] >> (key & 31u)) & 1u) {
       slow = true;
     } else {
       const size_t at = mu_cell_index<unsigned>(a, key);
       const double c0 = a.payload[4 * at];
       const long long bits = __double_as_longlong(c0);
-      if (!(c0 == 0.0 || (a.fresh_ok && bits == __double_as_longlong(a.unknown_c0)))) {
+      if (!(c0 == 0.0 || (a.fresh_ok && bits == unknown_bits))) {
         slow = true;
       } else {
         // const estimator: (base_empty.prob, base_empty.qual), checked by the host.  Area estimator: the record is
         // settled here only when mu_free_cell_valid PROVES the estimate valid (then it is base_empty.prob, free);
         // the others -- the robot's own cell, corner grazes -- go with the flagged ones and get the full estimator
         // in k_mu_gather: free updates commute, so a cell may take some of its records here and some there.
-        bool valid = true;
         if (EST == 1) {
-          const int b = (int)beam_of[i];
           int ix, iy;
           mu_key_cell<unsigned>(a, key, &ix, &iy);
           const int cx = ix - a.origin_x, cy = iy - a.origin_y;
-          const MuJob jb = mu_job(a, b);
-          valid = mu_free_cell_valid(jb.px, jb.py, a.beam_end[2 * b], a.beam_end[2 * b + 1], a.beam_inv[2 * b],
-                                     a.beam_inv[2 * b + 1], a.scale * cx, a.scale * (cx + 1), a.scale * cy,
-                                     a.scale * (cy + 1));
-          slow = !valid;
+          slow = !mu_free_cell_valid(jb.px, jb.py, wx, wy, inv_dx, inv_dy, a.scale * cx, a.scale * (cx + 1),
+                                     a.scale * cy, a.scale * (cy + 1));
         }
-        if (valid) {
+        if (!slow) {
           unsafeAtomicAdd(&a.aux[2 * at + 1], 1.0);
           if (bits != 0ll) a.payload[4 * at] = 0.0;
         }
       }
     }
+    // (every key of this round was read before the first store below, and a store lands at or before its own key)
+    const unsigned long long mask = __ballot(slow);
+    if (slow) out[n_slow + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = key;
+    n_slow += (unsigned)__popcll(mask);
   }
-  const unsigned long long mask = __ballot(slow), pads = __ballot(pad);
-  if (lane == 0 && i < total) {
-    wave_mask[i >> 6] = mask;
-    wave_cnt[i >> 6] = (unsigned)__popcll(mask);
-    if (pads) atomicAdd(a.n_padding, (unsigned long long)__popcll(pads));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) n_pad += __shfl_xor(n_pad, off, 64);
+  if (lane == 0) {
+    slow_cnt[b] = n_slow;
+    if (n_pad) atomicAdd(a.n_padding, (unsigned long long)n_pad);
   }
 }
 
-__global__ __launch_bounds__(256) void k_mu_compact(const unsigned *keys, const unsigned *beam_of, unsigned total,
-                                                    const unsigned long long *wave_mask, const unsigned *wave_off,
+__global__ __launch_bounds__(256) void k_mu_compact(MuArgs a, const unsigned *slow_cnt, const unsigned *slow_off,
                                                     unsigned *keys_out, unsigned *beam_out) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long mask = wave_mask[i >> 6];
-  if (!((mask >> lane) & 1ull)) return;
-  const unsigned pos = wave_off[i >> 6] + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-  keys_out[pos] = keys[i];
-  beam_out[pos] = beam_of[i];
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.n * a.n_jobs) return;
+  const unsigned n = slow_cnt[b];
+  if (n == 0) return;
+  const unsigned *in = (const unsigned *)a.keys + a.offsets[b];
+  const unsigned to = slow_off[b];
+  for (unsigned j = threadIdx.x & 63; j < n; j += 64) {
+    keys_out[to + j] = in[j];
+    beam_out[to + j] = (unsigned)b;
+  }
 }
 
 template <int RULE>
