@@ -29,8 +29,13 @@
 //      k_mu_rank in a plain call, k_mu_gather behind the radix sort
 //   5. k_mu_apply   one thread per distinct cell applies its records sequentially; chains of >= 64
 //                   records are then streamed through the whole wave that holds their head
+//   batch of GMapping-cell maps: 3-5 run only over the records that NEED an order.  A valid free observation of a
+//   cell whose mean is 0 (or that was never observed) only counts a try -- such updates commute -- so k_mu_classify
+//   settles them with one f64 atomic each and hands the rest (cells a beam may hit or blur, cells hit before:
+//   a few per cent) to the sort (mu_batch_fast_tail)
 // HBM traffic: per (beam, cell) an 8-byte (key, beam) pair written, sorted and read, one 8-byte
-// observation written and read, plus one read-modify-write of the cell (8-48 bytes) per distinct cell.
+// observation written and read, plus one read-modify-write of the cell (8-48 bytes) per distinct cell; on the
+// batch's fast path a 4-byte key written and read, the cell's mean read and its try counter updated in place.
 // The kernels live in map_update_kernels.h; this file holds the two host drivers (one scan into a bound
 // dense map; one scan from many poses into the copy-on-write maps of a particle filter).
 
@@ -616,7 +621,7 @@ int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t be
 // updates are applied there), compact what is left, and sort / evaluate / apply only that.  32-bit keys.
 int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t beams, unsigned end_bit, hipStream_t st,
                        unsigned *n_slow_out) {
-  const size_t words = ((size_t)1 << (end_bit - 1)) / 32 + 1;  // one bit per valid key
+  const size_t words = (((size_t)1 << (end_bit - 1)) / 32 + 4) & ~(size_t)3;  // one bit per valid key, whole uint4s
   if (words > sc.special_words) {
     SLAMHIP_CHECK(hipStreamSynchronize(st));
     SLAMHIP_CHECK(regrow(sc.special, words));
@@ -628,7 +633,8 @@ int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t bea
     SLAMHIP_CHECK(regrow(sc.slow_off, sc.cap_beams));
     sc.cap_slow = sc.cap_beams;
   }
-  SLAMHIP_CHECK(hipMemsetAsync(sc.special, 0, sizeof(unsigned) * words, st));
+  hipLaunchKernelGGL(k_mu_clear_marks, dim3((unsigned)std::min<size_t>((words / 4 + 255) / 256, 4096)), dim3(256), 0, st,
+                     (uint4 *)sc.special, words / 4);
   a.special = sc.special;
   unsigned *keys = (unsigned *)sc.keys, *keys_c = (unsigned *)sc.keys_sorted;
   const dim3 wgrid((unsigned)((beams + 3) / 4));  // a wave per beam

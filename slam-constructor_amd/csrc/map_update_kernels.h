@@ -806,6 +806,12 @@ __device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
 //                 of every record, for the sort / gather / apply pipeline as before
 // A cell that must go through a chain does so with ALL its records: the mark is set before, and the fast path moves
 // a mean only from -1 to +0, both "fast".  The other cells may split their records between the two paths.
+// (a kernel of this pipeline rather than a memset: it then shows in the pipeline's kernel trace and PMC sums)
+__global__ __launch_bounds__(256) void k_mu_clear_marks(uint4 *words16, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    words16[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 template <int EST>
 __global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
