@@ -457,3 +457,38 @@ def test_fast_path_equals_the_sorted_chains(pkg, case, monkeypatch):
         assert fa.tobytes() == sa.tobytes()
         touched += int(np.count_nonzero(fa[..., 1]))
     assert touched > n * 1000
+
+
+def test_fast_path_at_full_batch_size_counts_every_record_once(pkg, monkeypatch):
+    """The 100-particle batch of BASELINE configs[3] (1080 beams, 0.05 m cells) through both pipelines: the number of
+    cell updates, the sum of all try counters of a particle (every valid record is exactly one try, whichever path
+    settled it) and the whole map of sampled particles, byte for byte.  Two batches, so that the second meets the
+    hits of the first."""
+    from synth import make_scene
+    n, size, scale = 100, 2000, 0.05
+    sc = make_scene(cell_model=2, size=size, scale=scale, n_beams=1080, seed=21)
+    m, scan = sc["map"], sc["scan"]
+    rs = np.random.RandomState(5)
+    poses = sc["true_pose"] + rs.randn(n, 3) * [0.1, 0.1, 0.03]
+    sample = [0, 37, 99]
+    out = {}
+    for mode in ("fast", "sorted"):
+        monkeypatch.setenv("SLAMHIP_K6_FAST", "1" if mode == "fast" else "0")
+        ctx = pkg.Context(0)
+        ctx.map_bind(3, 2, size, size, m.origin, scale, m.unknown)
+        ctx.map_upload_window(3, 0, 0, m.payload)
+        pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), n, np.arange(n, dtype=np.uint32))
+        pf.enable_particle_maps(3, extent_tiles=(size + 127) // 128 + 1, pool_tiles=300 + 150 * n)
+        nu = [pf.particle_maps_append(np.arange(n), poses + 0.02 * k, scan.range, scan.angle) for k in range(2)]
+        ox, oy = m.origin
+        maps = [pf.particle_map(i, -ox, -oy, size, size) for i in sample]
+        out[mode] = (nu, maps)
+        pf.close()
+        ctx.close()
+    assert out["fast"][0] == out["sorted"][0]
+    assert min(out["fast"][0]) > n * 1080 * 50
+    for (fp, fa), (sp, sa) in zip(out["fast"][1], out["sorted"][1]):
+        assert fp.tobytes() == sp.tobytes() and fa.tobytes() == sa.tobytes()
+    # the ancestor carries no counters: a particle's tries are its records of the two batches
+    tries = [float(fa[..., 1].sum()) for fp, fa in out["fast"][1]]
+    assert abs(np.mean(tries) * n - sum(out["fast"][0])) < 0.05 * sum(out["fast"][0])
