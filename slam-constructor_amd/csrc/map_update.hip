@@ -639,8 +639,9 @@ int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t bea
   unsigned *keys = (unsigned *)sc.keys, *keys_c = (unsigned *)sc.keys_sorted;
   const dim3 wgrid((unsigned)((beams + 3) / 4));  // a wave per beam
   hipLaunchKernelGGL((k_mu_emit<unsigned, -1>), wgrid, dim3(256), 0, st, a, (unsigned *)nullptr);
-  if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_classify<1>, wgrid, dim3(256), 0, st, a, sc.slow_cnt);
-  else hipLaunchKernelGGL(k_mu_classify<0>, wgrid, dim3(256), 0, st, a, sc.slow_cnt);
+  const dim3 cgrid((unsigned)((beams + kClassifyBeams - 1) / kClassifyBeams)), cblock(64 * kClassifyBeams);
+  if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_classify<1>, cgrid, cblock, 0, st, a, sc.slow_cnt);
+  else hipLaunchKernelGGL(k_mu_classify<0>, cgrid, cblock, 0, st, a, sc.slow_cnt);
   {
     size_t need = 0;
     SLAMHIP_CHECK(rocprim::exclusive_scan(nullptr, need, sc.slow_cnt, sc.slow_off, 0u, beams, rocprim::plus<unsigned>(), st));

@@ -800,7 +800,8 @@ __device__ __forceinline__ size_t mu_cell_index(const MuArgs &a, Key key) {
 // mapped room 95+ % of the records are of that kind -- they do not need to be sorted into chains at all.
 //   k_mu_emit     marks the cells a beam may observe as occupied (MuArgs::special)
 //   k_mu_classify one wave per beam, over the keys of its walk: unmarked cell with mean 0 (or never observed) ->
-//                 the observation's validity (area estimator) and the atomic; every other record moves to the
+//                 the observation's validity (area estimator) and the atomic (near the robot one per run of
+//                 adjacent beams on the same cell); every other record moves to the
 //                 front of the beam's own stretch of the key buffer, order kept, and is counted per beam
 //   k_mu_compact  those stretches side by side (a scan of the per-beam counts gives the places), with the beam
 //                 of every record, for the sort / gather / apply pipeline as before
@@ -812,21 +813,31 @@ __global__ __launch_bounds__(256) void k_mu_clear_marks(uint4 *words16, size_t n
     words16[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Sixteen adjacent beams per workgroup.  Near the robot adjacent beams cross the SAME cells -- a cell at L1 distance
+// k from the robot's is met at step k of every walk that meets it, by a contiguous fan of beams (1 / (0.0058 k) of
+// them at 1080 beams per turn) -- and one atomic per observation is what the kernel spends most on (they resolve in
+// the fabric, 67 G/s).  For the first kNearRounds x 64 steps the sixteen waves therefore lay their settled keys side
+// by side in LDS, and the first beam of every run of equal keys adds the run's length with ONE atomic.
+static constexpr int kClassifyBeams = 16, kNearRounds = 3;
+
 template <int EST>
-__global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= a.n * a.n_jobs) return;
-  const int lane = threadIdx.x & 63;
-  const unsigned cap = a.counts[b];
-  if (cap == 0) {
-    if (lane == 0) slow_cnt[b] = 0u;
-    return;
-  }
-  unsigned *out = (unsigned *)a.keys + a.offsets[b];
+__global__ __launch_bounds__(64 * kClassifyBeams) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
+  __shared__ unsigned s_key[2][kClassifyBeams][64];
+  __shared__ unsigned s_max_cap;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * kClassifyBeams + w;
+  const bool live = b < a.n * a.n_jobs;
+  const unsigned cap = live ? a.counts[b] : 0u;
+  if (threadIdx.x == 0) s_max_cap = 0u;
+  __syncthreads();
+  if (lane == 0 && cap) atomicMax(&s_max_cap, cap);
+  __syncthreads();
+  const unsigned near_end = min((s_max_cap + 63u) & ~63u, 64u * kNearRounds);  // rounds every wave takes part in
+  unsigned *out = (unsigned *)a.keys + (cap ? a.offsets[b] : 0u);
   // per-beam constants of the validity proof (wave-uniform)
-  const MuJob jb = mu_job(a, b);
+  const MuJob jb = mu_job(a, live ? b : 0);
   double wx = 0, wy = 0, inv_dx = 0, inv_dy = 0;
-  if (EST == 1) {
+  if (EST == 1 && cap) {
     wx = a.beam_end[2 * b];
     wy = a.beam_end[2 * b + 1];
     inv_dx = a.beam_inv[2 * b];
@@ -834,18 +845,20 @@ __global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, unsigned *slow_cn
   }
   const long long unknown_bits = __double_as_longlong(a.unknown_c0);
   unsigned n_slow = 0, n_pad = 0;
-  for (unsigned k0 = 0; k0 < cap; k0 += 64) {
+  for (unsigned k0 = 0; k0 < max(cap, near_end); k0 += 64) {
     const unsigned k = k0 + lane;
     const unsigned key = k < cap ? out[k] : ~0u;
-    bool slow = false;
+    bool slow = false, settle = false;
+    size_t at = 0;
+    long long bits = 0;
     if (key == ~0u) {
       n_pad += k < cap ? 1u : 0u;
     } else if ((a.special[key >> 5] >> (key & 31u)) & 1u) {
       slow = true;
     } else {
-      const size_t at = mu_cell_index<unsigned>(a, key);
+      at = mu_cell_index<unsigned>(a, key);
       const double c0 = a.payload[4 * at];
-      const long long bits = __double_as_longlong(c0);
+      bits = __double_as_longlong(c0);
       if (!(c0 == 0.0 || (a.fresh_ok && bits == unknown_bits))) {
         slow = true;
       } else {
@@ -860,11 +873,28 @@ __global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, unsigned *slow_cn
           slow = !mu_free_cell_valid(jb.px, jb.py, wx, wy, inv_dx, inv_dy, a.scale * cx, a.scale * (cx + 1),
                                      a.scale * cy, a.scale * (cy + 1));
         }
-        if (!slow) {
-          unsafeAtomicAdd(&a.aux[2 * at + 1], 1.0);
-          if (bits != 0ll) a.payload[4 * at] = 0.0;
+        settle = !slow;
+      }
+    }
+    double add = 1.0;
+    if (k0 < near_end) {
+      // (uniform over the workgroup: every wave runs the near rounds, two buffers -> one barrier per round)
+      unsigned(*sk)[64] = s_key[(k0 >> 6) & 1];
+      sk[w][lane] = settle ? key : ~0u;
+      __syncthreads();
+      if (settle) {
+        if (w > 0 && sk[w - 1][lane] == key) {
+          settle = false;  // counted by the beam that heads the run
+        } else {
+          int len = 1;
+          for (int j = w + 1; j < kClassifyBeams && sk[j][lane] == key; ++j) ++len;
+          add = (double)len;
         }
       }
+    }
+    if (settle) {
+      unsafeAtomicAdd(&a.aux[2 * at + 1], add);
+      if (bits != 0ll) a.payload[4 * at] = 0.0;
     }
     // (every key of this round was read before the first store below, and a store lands at or before its own key)
     const unsigned long long mask = __ballot(slow);
@@ -873,7 +903,7 @@ __global__ __launch_bounds__(256) void k_mu_classify(MuArgs a, unsigned *slow_cn
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) n_pad += __shfl_xor(n_pad, off, 64);
-  if (lane == 0) {
+  if (lane == 0 && live) {
     slow_cnt[b] = n_slow;
     if (n_pad) atomicAdd(a.n_padding, (unsigned long long)n_pad);
   }
