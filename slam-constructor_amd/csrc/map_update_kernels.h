@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
   const double sgn = A < 0 ? -1.0 : 1.0;
   const double theta = (absB - absA) * 0.5;
   const double q0 = sgn * e0 - theta + absB;
+  const double inv_W = 1.0 / W;
   const int steps_x = abs(ex - bx), steps_y = abs(ey - by);
   const KeyT job_part = a.jobs ? (KeyT)(b / a.n) << a.cell_bits : KeyT(0);
   const unsigned row = (unsigned)a.key_w;
@@ -425,11 +426,13 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
     for (unsigned k0 = 0; k0 < cap; k0 += 64) {
       const unsigned k = k0 + lane;
       if (k < cap) {
-        long long j = (long long)floor((q0 + (double)k * absA) / W);
-        long long jn = (long long)floor((q0 + (double)(k + 1) * absA) / W);
-        j = j < 0 ? 0 : (j > (long long)k ? (long long)k : j);
-        jn = jn < 0 ? 0 : (jn > (long long)k + 1 ? (long long)k + 1 : jn);
-        const long long i = (long long)k - j;
+        // (times 1 / W rather than divided by W: the check below does not care how j was found, only that lane
+        // k's jn is lane k + 1's j -- the same expression -- and a quotient that lands on the other side of an
+        // integer sits next to a tie, where the walk goes to the sequential form anyway)
+        // (32-bit integers: a walk is far shorter than 2^31 steps, and 64-bit conversions are emulated)
+        const double fj = floor((q0 + (double)k * absA) * inv_W), fjn = floor((q0 + (double)(k + 1) * absA) * inv_W);
+        const int j = (int)fmin(fmax(fj, 0.0), (double)k), jn = (int)fmin(fmax(fjn, 0.0), (double)(k + 1));
+        const int i = (int)k - j;
         const double e = e0 + (double)i * A + (double)j * B;
         const double d = fabs(e + B) - fabs(e + A);
         if (k + 1 < cap) {
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
         } else {
           ok = ok && i == steps_x && j == steps_y;
         }
-        const unsigned ix = (unsigned)(bx + inc_x * (int)i + a.origin_x), iy = (unsigned)(by + inc_y * (int)j + a.origin_y);
+        const unsigned ix = (unsigned)(bx + inc_x * i + a.origin_x), iy = (unsigned)(by + inc_y * j + a.origin_y);
         const bool oob = ix >= w || iy >= h;
         bad |= oob;
         out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
