@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void k_mu_clear_marks(uint4 *words16, size_t n
 static constexpr int kClassifyBeams = 16, kNearRounds = 3;
 
 template <int EST>
-__global__ __launch_bounds__(64 * kClassifyBeams) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
+__global__ __launch_bounds__(64 * kClassifyBeams, 8) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
   __shared__ unsigned s_key[2][kClassifyBeams][64];
   __shared__ unsigned s_max_cap;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
