@@ -572,7 +572,9 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
     // K3 up to a couple of thousand poses does not fill the chip's wave slots, and the poses of a
     // workgroup run one after the other: one pose per workgroup (100-particle filter step 1.69 -> 1.66 ms)
     constexpr int gm_one_below = 2048;
-    if (oope == SLAMHIP_OOPE_GMAPPING && a.n_poses < gm_one_below) a.poses_per_block = 1;
+    // (through tile tables at any size: the multi-pose body's 163 VGPRs leave three waves per SIMD to hide the
+    // nine gathers per beam -- 3000 poses of a 500-particle round: 262 -> 136 us)
+    if (oope == SLAMHIP_OOPE_GMAPPING && (a.n_poses < gm_one_below || a.tables)) a.poses_per_block = 1;
   }
   if (a.poses_per_block > kMaxPosesPerBlock) a.poses_per_block = kMaxPosesPerBlock;
   const dim3 grid((a.n_poses + a.poses_per_block - 1) / a.poses_per_block);
