@@ -499,11 +499,13 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
                 (k == 0 && !g->shard_chain) ? g->carry : GmCarry{}, 0.25);
       act.push_back(&job);
     }
-    // Dense shared map, device pose trig, 3x3 window: every particle's accept chain runs on the device, all chains
+    // Device pose trig, 3x3 window: every particle's accept chain runs on the device, all chains
     // in shared launches (hc_chain.hip, grid.y = particle); no chain starts from a cache entry, the hand-overs --
     // the step's own included -- are checked afterwards in particle order like the lock-step jobs'.
     static const bool pf_chain_off = getenv("SLAMHIP_PF_CHAIN") && getenv("SLAMHIP_PF_CHAIN")[0] == '0';
-    const bool chains = !pf_chain_off && !g->tp && g->cfg.pose_trig == SLAMHIP_POSE_TRIG_DEVICE && g->cfg.gm_window == 1 &&
+    // (per-particle maps: every chain gathers through its particle's tile table; measured, ms per step, chains /
+    // lock-step: 13 particles 0.74 / 0.89, 100 particles 1.66 / 1.64 -- so for shards of up to 64 particles)
+    const bool chains = !pf_chain_off && (!g->tp || act.size() <= 64) && g->cfg.pose_trig == SLAMHIP_POSE_TRIG_DEVICE && g->cfg.gm_window == 1 &&
                         g->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->scan_n <= 1280 && ctx->low_latency &&
                         !ctx->stage_poses && g->prm.hc_failed_rounds_limit >= 1 && g->prm.hc_failed_rounds_limit <= 250;
     if (chains) {
@@ -515,8 +517,10 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
         for (int c = 0; c < 3; ++c) g->chain_inits[3 * k + c] = p.pose[c];
       }
       long long kernels = 0;
+      if (g->tp) bind_tiled_target(g);  // (slot = particle index)
       rc = gm_multi_chain_run(ctx, &g->mc, map_id, &g->cfg, g->prm.hc_failed_rounds_limit, g->prm.hc_translation,
-                              g->prm.hc_rotation, na, g->chain_inits.data(), g->chain_out.data(), &kernels);
+                              g->prm.hc_rotation, na, g->chain_inits.data(), g->chain_out.data(), &kernels,
+                              g->tp ? &g->tt : nullptr, g->tp ? act_idx.data() : nullptr);
       if (rc) return rc;
       g->launches += kernels;
       const GmCarry before = g->shard_chain ? GmCarry{} : g->carry;
@@ -528,7 +532,7 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
           std::vector<MatchJob *> one{&job};  // (started above, without a carry)
           job.carry = GmCarry{};
           job.carry_in = GmCarry{};
-          rc = run_jobs(g, map_id, one, 126, nullptr);
+          rc = run_jobs(g, map_id, one, 126, g->tp ? &act_idx[k] : nullptr);
           if (rc) return rc;
           continue;
         }

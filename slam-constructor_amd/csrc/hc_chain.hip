@@ -467,7 +467,8 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     // go next to the score, the replay of the next kernel applies the cache in the reference's call order
     constexpr int KBG = KB > 0 ? KB : 1;
     double score = 0.0;
-    gm_score_pose_wide<KBG, NT>(a.map, a.scan, a.gm, nullptr, s_unknown, px, py, sn, cs, br, bc, bs, s_term, &s_run0_len,
+    const int *tiles = a.tables ? a.tables + (size_t)a.slots[blockIdx.y] * a.table_stride : nullptr;
+    gm_score_pose_wide<KBG, NT>(a.map, a.scan, a.gm, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_term, &s_run0_len,
                                 s_part, &ctl->infos[k & 1][slot], &score);
     if (t == 0) {
       ctl->scores[k & 1][slot] = score;

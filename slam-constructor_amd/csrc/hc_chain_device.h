@@ -59,6 +59,11 @@ struct HcChainArgs {
   HcChainCtl *ctl;
   const double *inits;
   unsigned *n_done;
+  // ... each on its own copy-on-write map: `map` describes the tile pool, chain c gathers through the tile table of
+  // slot slots[c] (null: the one dense map)
+  const int *tables;
+  const int *slots;
+  int table_stride;
   const HcShape *shapes;  // kHcShapes of them
   int max_inst;  // instances of the largest shape: the grid is 6 x max_inst + 1 workgroups
   unsigned long long n_inst;  // round instances of shape b in byte b (a dynamic index into an array of

@@ -305,6 +305,7 @@ struct GmMultiChain {
   HcHostOut *h_out = nullptr;    // pinned, one per chain
   double *h_inits = nullptr;     // pinned staging of the initial poses
   double *d_inits = nullptr;
+  int *d_slots = nullptr;        // tile-pool slot of every chain (per-particle maps)
   unsigned *d_n_done = nullptr;
   unsigned *h_done_count = nullptr;  // pinned
   int shape_n_inst[kHcShapes] = {0};
@@ -322,6 +323,7 @@ void gm_multi_chain_free(GmMultiChain *s) {
   if (s->h_out) hipHostFree(s->h_out);
   if (s->h_inits) hipHostFree(s->h_inits);
   if (s->d_inits) hipFree(s->d_inits);
+  if (s->d_slots) hipFree(s->d_slots);
   if (s->d_n_done) hipFree(s->d_n_done);
   if (s->h_done_count) hipHostFree(s->h_done_count);
   delete s;
@@ -332,8 +334,9 @@ void gm_multi_chain_free(GmMultiChain *s) {
 // are through, and always has the next burst queued before it waits for a marker.
 int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, const slamhip_spe_cfg *cfg,
                        unsigned max_failed, double dt, double dr, int n, const double *inits, GmChainResult *out,
-                       long long *kernels_launched) {
+                       long long *kernels_launched, const TiledTarget *tiled, const int *slots) {
   if (n <= 0) return SLAMHIP_OK;
+  if (tiled && !slots) return SLAMHIP_ERR_INVALID;
   const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
   if (!*scratch) {
     GmMultiChain *s = new GmMultiChain;
@@ -375,6 +378,8 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     if (s->h_out) hipHostFree(s->h_out);
     if (s->h_inits) hipHostFree(s->h_inits);
     if (s->d_inits) hipFree(s->d_inits);
+    if (s->d_slots) hipFree(s->d_slots);
+    s->d_slots = nullptr;
     s->d_ctl = nullptr;
     s->h_out = nullptr;
     s->h_inits = nullptr;
@@ -387,13 +392,20 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     std::memset(s->h_out, 0, sizeof(HcHostOut) * cap);
     SLAMHIP_CHECK(hipHostMalloc(&s->h_inits, sizeof(double) * 3 * cap, hipHostMallocDefault));
     SLAMHIP_CHECK(hipMalloc(&s->d_inits, sizeof(double) * 3 * cap));
+    SLAMHIP_CHECK(hipMalloc(&s->d_slots, sizeof(int) * cap));
     s->cap = cap;
   }
   HcChainArgs a;
   std::memset(&a, 0, sizeof(a));
   int cell_model = 0;
-  int rc = score_views(ctx, map_id, cfg, &a.map, &a.scan, &cell_model);
+  int rc = score_views(ctx, map_id, cfg, &a.map, &a.scan, &cell_model, tiled);
   if (rc) return rc;
+  if (tiled) {
+    a.tables = tiled->tables;
+    a.table_stride = tiled->table_stride;
+    a.slots = s->d_slots;
+    SLAMHIP_CHECK(hipMemcpyAsync(s->d_slots, slots, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  }
   a.oie = cfg->oie;
   a.max_inst = s->max_inst;
   a.gm.fullness_th = cfg->gm_fullness_th;

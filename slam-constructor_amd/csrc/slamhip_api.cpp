@@ -200,9 +200,29 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
 
 // views of the bound map and the uploaded scan for kernels that are not launched through launch_score
 // (the hill-climbing chain); same checks as a scoring call
+// the kernels see a tile pool as "payload" and the tiles-per-row count as "pitch" (GMapping OOPE only)
+static void tiled_device_map(const TiledTarget *tiled, DeviceMap *v) {
+  v->bound = true;
+  v->cell_model = SLAMHIP_CELL_GMAPPING;
+  v->width = tiled->width;
+  v->height = tiled->height;
+  v->pitch = tiled->tiles_x;
+  v->origin_x = tiled->origin_x;
+  v->origin_y = tiled->origin_y;
+  v->scale = tiled->scale;
+  for (int k = 0; k < 4; ++k) v->unknown[k] = tiled->unknown[k];
+  v->d_payload = const_cast<double *>(tiled->pool);
+}
+
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
-                int *cell_model) {
+                int *cell_model, const TiledTarget *tiled) {
+  DeviceMap tiled_view;
   DeviceMap *m = get_map(ctx, map_id);
+  if (tiled) {
+    if (!cfg || cfg->oope != SLAMHIP_OOPE_GMAPPING) return invalid("per-particle maps are scored by the GMapping kernel only");
+    tiled_device_map(tiled, &tiled_view);
+    m = &tiled_view;
+  }
   if (!m) return invalid("unknown map id");
   int rc = check_cfg(*m, cfg);
   if (rc) return rc;
@@ -312,19 +332,9 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
   DeviceMap tiled_view;
   DeviceMap *m = nullptr;
   if (tiled) {
-    // the kernels see the tile pool as "payload" and the tiles-per-row count as "pitch" (K3 only)
     if (!cfg || cfg->oope != SLAMHIP_OOPE_GMAPPING || !ctx->low_latency)
       return invalid("per-particle maps are scored by the GMapping kernel on the zero-copy path only");
-    tiled_view.bound = true;
-    tiled_view.cell_model = SLAMHIP_CELL_GMAPPING;
-    tiled_view.width = tiled->width;
-    tiled_view.height = tiled->height;
-    tiled_view.pitch = tiled->tiles_x;
-    tiled_view.origin_x = tiled->origin_x;
-    tiled_view.origin_y = tiled->origin_y;
-    tiled_view.scale = tiled->scale;
-    for (int k = 0; k < 4; ++k) tiled_view.unknown[k] = tiled->unknown[k];
-    tiled_view.d_payload = const_cast<double *>(tiled->pool);
+    tiled_device_map(tiled, &tiled_view);
     m = &tiled_view;
   } else {
     m = get_map(ctx, map_id);

@@ -202,7 +202,7 @@ int score_wait(slamhip_ctx *ctx, unsigned seq, int lane = 0);
 // orders the second lane behind everything queued on the first so far (scan upload, map updates)
 int lane_fork(slamhip_ctx *ctx);
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
-                int *cell_model);
+                int *cell_model, const TiledTarget *tiled = nullptr);
 int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kind = 0);
 
 // ---- many hill-climbing chains over the GMapping OOPE in shared launches (matchers.cpp; the filter's lock-step
@@ -219,8 +219,9 @@ struct GmChainResult {
   int error;     // 3: a one-run scan sat on the path: the caller redoes this match on the host-driven path
 };
 struct GmMultiChain;
+// tiled + slots: chain c reads the copy-on-write map in slot slots[c] of the tile pool instead of the dense map
 int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, const slamhip_spe_cfg *cfg,
                        unsigned max_failed, double dt, double dr, int n, const double *inits, GmChainResult *out,
-                       long long *kernels_launched);
+                       long long *kernels_launched, const TiledTarget *tiled = nullptr, const int *slots = nullptr);
 void gm_multi_chain_free(GmMultiChain *s);
 }  // namespace slamhip
