@@ -619,8 +619,7 @@ int mu_batch_tail(const MuArgs &a, MuBatchScratch &sc, unsigned total, size_t be
 
 // The batch with the free-space fast path (map_update_kernels.h, k_mu_classify): walk, classify (the commuting
 // updates are applied there), compact what is left, and sort / evaluate / apply only that.  32-bit keys.
-int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t beams, unsigned end_bit, hipStream_t st,
-                       unsigned *n_slow_out) {
+int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, size_t beams, unsigned end_bit, hipStream_t st) {
   const size_t words = (((size_t)1 << (end_bit - 1)) / 32 + 4) & ~(size_t)3;  // one bit per valid key, whole uint4s
   if (words > sc.special_words) {
     SLAMHIP_CHECK(hipStreamSynchronize(st));
@@ -662,7 +661,6 @@ int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, unsigned total, size_t bea
                      (const unsigned *)sc.slow_off, keys_c, sc.order_sorted);
   SLAMHIP_CHECK(hipStreamSynchronize(st));
   const unsigned n_slow = (unsigned)n_slow64;
-  *n_slow_out = n_slow;
   if (n_slow == 0) return SLAMHIP_OK;
   // the compacted records go back into the buffers the walk filled (dead by now), sorted
   size_t tb = sc.temp_bytes;
@@ -918,11 +916,10 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   const bool fast_off = getenv("SLAMHIP_K6_FAST") && !strcmp(getenv("SLAMHIP_K6_FAST"), "0");
   const bool fast = !fast_off && end_bit <= 32 && cfg->base_empty_prob <= 0.5 && !std::isnan(cfg->base_empty_qual) &&
                     !getenv("SLAMHIP_K6_KEY64");
-  unsigned n_slow = 0;
   if (fast) {
     a.unknown_c0 = tp->unknown[0];
     a.fresh_ok = tp->unknown[0] < 0.0 ? 1 : 0;
-    rc = mu_batch_fast_tail(a, sc, total, beams, end_bit, st, &n_slow);
+    rc = mu_batch_fast_tail(a, sc, beams, end_bit, st);
   } else if (end_bit <= 32 && !getenv("SLAMHIP_K6_KEY64"))
     rc = mu_batch_tail<unsigned>(a, sc, total, beams, end_bit, st);
   else
