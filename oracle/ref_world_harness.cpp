@@ -9,6 +9,7 @@
 // final maps are compared.
 // Output: oracle/_ref/libslamref_world.so (links slam-constructor_amd/libslamhip.so).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -198,7 +199,8 @@ int refworld_compare(int preset, int matcher, int wrap, int n_scans, int n_beams
 // reference world.
 // out = {pose mismatches (bitwise), max |pose diff|, map cells compared, payload mismatches, max |payload diff|,
 //        ref scorer calls, hip scorer calls, ref accepted, hip accepted, times the HBM window grew,
-//        final reference width, height, final HBM window width, height, cell updates on the GPU}
+//        final reference width, height, final HBM window width, height, cell updates on the GPU, view mismatches,
+//        seconds inside the reference world's handle_sensor_data, seconds inside the resident world's}  (18 doubles)
 int refworld_compare_resident(int preset, int matcher, int n_scans, int n_beams, int strict, double size_m,
                               double *poses_out, double *out) {
   const double scale = 0.1;
@@ -225,7 +227,7 @@ int refworld_compare_resident(int preset, int matcher, int n_scans, int n_beams,
   RobotPose truth{scale / 2, scale / 2 - 6 * scale, deg2rad(90)};
   RobotPose prev_odom{0, 0, 0};
   long pose_mis = 0;
-  double worst_pose = 0;
+  double worst_pose = 0, ref_seconds = 0, hip_seconds = 0;
   for (int k = 0; k < n_scans; ++k) {
     TransformedLaserScan ts;
     ts.scan = LaserScanGenerator{to_lsp(15, 270, n_beams)}.laser_scan_2D(*gt, truth, 1);
@@ -241,8 +243,15 @@ int refworld_compare_resident(int preset, int matcher, int n_scans, int n_beams,
       c_ref->tag = on ? "ref" : nullptr;
       c_hip->tag = on ? "hip" : nullptr;
     }
+    const auto t0 = std::chrono::steady_clock::now();
     ref->handle_sensor_data(ts);
+    const auto t1 = std::chrono::steady_clock::now();
     hip->handle_sensor_data(ts_hip);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (k > 0) {  // (the first scan pays the allocations on both sides)
+      ref_seconds += std::chrono::duration<double>(t1 - t0).count();
+      hip_seconds += std::chrono::duration<double>(t2 - t1).count();
+    }
     const RobotPose pr = ref->pose(), ph = hip->pose();
     poses_out[6 * k + 0] = pr.x; poses_out[6 * k + 1] = pr.y; poses_out[6 * k + 2] = pr.theta;
     poses_out[6 * k + 3] = ph.x; poses_out[6 * k + 4] = ph.y; poses_out[6 * k + 5] = ph.theta;
@@ -317,6 +326,8 @@ int refworld_compare_resident(int preset, int matcher, int n_scans, int n_beams,
   out[13] = h;
   out[14] = double(hip->cell_updates());
   out[15] = double(view_mis);
+  out[16] = ref_seconds;  // wall time inside handle_sensor_data, scans 1 .. n-1: the reference's world ...
+  out[17] = hip_seconds;  // ... and the resident world (GPU match + GPU map update), same scans, same process
   hip.reset();
   slamhip_ctx_destroy(ctx);
   return 0;

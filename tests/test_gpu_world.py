@@ -63,10 +63,10 @@ def run_resident(lib, preset, matcher, strict, n_scans=12, n_beams=360, size_m=4
     lib.refworld_compare_resident.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                               C.POINTER(C.c_double), C.POINTER(C.c_double)]
     poses = (C.c_double * (6 * n_scans))()
-    out = (C.c_double * 16)()
+    out = (C.c_double * 18)()
     assert lib.refworld_compare_resident(preset, matcher, n_scans, n_beams, strict, size_m, poses, out) == 0
     keys = ["pose_mis", "worst_pose", "cells", "cell_mis", "worst_payload", "ref_calls", "hip_calls", "ref_acc", "hip_acc",
-            "grown", "ref_w", "ref_h", "w", "h", "cell_updates", "view_mis"]
+            "grown", "ref_w", "ref_h", "w", "h", "cell_updates", "view_mis", "ref_seconds", "hip_seconds"]
     return dict(zip(keys, list(out))), np.array(list(poses)).reshape(n_scans, 6)
 
 
