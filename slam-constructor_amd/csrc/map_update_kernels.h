@@ -967,17 +967,16 @@ __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const 
   if (RULE == 4) reinterpret_cast<double2 *>(a.aux)[at] = make_double2(c.x0, c.x1);
 }
 
-static constexpr unsigned kLongChain = 64;  // chains at least this long are streamed by a whole wave
-
 __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
 
-// Long chains (the robot's own cell takes one update per beam, its neighbours hundreds): one thread
-// walking such a chain pays a memory round trip per 8 records (330 us for 1080 updates).  Here the
-// WAVE that holds the chain's head streams it (at the end of k_mu_apply, after its short chains): 64 records per coalesced load, then every lane applies
+// Chains that run past the end of their wave (at most one per wave; the robot's own cell takes one update per
+// beam, its neighbours hundreds): one thread walking such a chain pays a memory round trip per 8 records (330 us
+// for 1080 updates).  Here the WAVE that holds the chain's head streams it (at the end of k_mu_apply, after the
+// chains that end inside the wave): 64 records per coalesced load, then every lane applies
 // them in order from broadcast values -- the same sequential arithmetic, executed redundantly by all
 // lanes, so the result is bit-identical to the one-thread walk.  GMapping cells: a run of free
 // observations of a cell whose mean is 0 only counts tries (see mu_step), so the run is skipped in one
@@ -1039,10 +1038,10 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
   }
 }
 
-// Chains shorter than kLongChain: one thread per distinct cell -- the one holding the chain's first record --
+// Chains that end inside their wave: one thread per distinct cell -- the one holding the chain's first record --
 // applies its records in order.  The records of a chain sit in the lanes behind their head: every lane
 // loads its own key and observation (coalesced), the heads pull them across with a lane shuffle per
-// step, and only a chain that runs past the end of its wave reads the rest from memory.
+// step; a chain that runs past the end of its wave goes to mu_apply_long_chains.
 template <typename Key, int RULE>
 __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, unsigned total) {
   constexpr Key kInvalid = ~Key(0);
@@ -1061,9 +1060,12 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
   const unsigned long long behind = lane == 63 ? 0ull : starts >> (lane + 1);
   const int len_here = behind ? __ffsll((long long)behind) : 64 - lane;
   const bool open_end = !behind;  // may continue in the next wave
+  // a chain that runs on into the next wave (at most one per wave: its last) is streamed by the whole wave below --
+  // one coalesced load per 64 records instead of the head thread's own dependent reads (8 records per round trip:
+  // 7 of a single-scan update's 19 us)
   bool is_long = false;
-  if (head && open_end && i + (kLongChain - 1) < total && keys[i + (kLongChain - 1)] == key) {
-    head = false;  // a long chain: streamed by the whole wave below
+  if (head && open_end && i + len_here < total && keys[i + len_here] == key) {
+    head = false;
     is_long = true;
   }
   size_t at = 0;
@@ -1082,35 +1084,6 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
         *x = a.beam_end[2 * b];
         *y = a.beam_end[2 * b + 1];
       });
-  }
-  // the rest of a chain that crosses into the next wave(s): most chains end with their wave, one key tells
-  if (head && open_end && i + len_here < total && keys[i + len_here] == key) {
-    constexpr int CH = 8;  // records fetched ahead
-    bool more = true;
-    for (unsigned j0 = i + len_here; more && j0 < total; j0 += CH) {
-      Key kk[CH];
-      double pp[CH], qq[CH];
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        const unsigned j = min(j0 + t, total - 1);
-        kk[t] = (j0 + t < total) ? keys[j] : kInvalid;
-        pp[t] = a.rec_prob[j];
-        qq[t] = RULE == 3 ? a.rec_qual[j] : 0.0;
-      }
-#pragma unroll
-      for (int t = 0; t < CH; ++t) {
-        if (!more) continue;
-        if (kk[t] != key) {
-          more = false;
-          continue;
-        }
-        mu_step<RULE>(a, c, pp[t], qq[t], [&](double *x, double *y) {
-          const unsigned b = a.rec_beam[j0 + t];
-          *x = a.beam_end[2 * b];
-          *y = a.beam_end[2 * b + 1];
-        });
-      }
-    }
   }
   if (head) mu_cell_store<RULE>(a, at, c, was);
   mu_apply_long_chains<Key, RULE>(a, keys, total, i, lane, is_long);
