@@ -92,9 +92,12 @@ struct MuScratch {
   // a pinned ring and are summed up by mu_drain
   bool deferred = false;
   int pending = 0;
-  unsigned last_seq = 0;
   unsigned long long *h_ring = nullptr;  // kRing x (error flag, padding records)
   unsigned ring_total[64] = {0};
+  // ... written by the update kernels into slot `pending` of these device arrays and handed over by ONE
+  // k_mu_finish_ring per drain (a finish kernel per update was 4.3 us of every particle's turn)
+  int *d_ring_err = nullptr;
+  unsigned long long *d_ring_pad = nullptr;
   // scan re-use (see slamhip_map_append_scan)
   bool reuse_ok = false;
   const double *last_range = nullptr, *last_cos = nullptr, *last_sin = nullptr;
@@ -124,7 +127,12 @@ int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err) {
   if (n_updates) *n_updates = 0;
   if (err) *err = 0;
   if (!sc.pending) return SLAMHIP_OK;
-  const int rc = score_wait(ctx, sc.last_seq);
+  unsigned seq = ++ctx->seq;
+  if (seq == 0) seq = ++ctx->seq;
+  hipLaunchKernelGGL(k_mu_finish_ring, dim3(1), dim3(64), 0, ctx->stream, sc.d_ring_err, sc.d_ring_pad, sc.pending,
+                     sc.h_ring, ctx->h_done_flag, seq);
+  SLAMHIP_CHECK(hipGetLastError());
+  const int rc = score_wait(ctx, seq);
   if (rc) {
     sc.pending = 0;
     return rc;
@@ -239,6 +247,12 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
     if (!sc.h_status) SLAMHIP_CHECK(hipHostMalloc(&sc.h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault));
     if (!sc.h_ring) SLAMHIP_CHECK(hipHostMalloc(&sc.h_ring, 2 * kRing * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!sc.d_ring_err) {
+      SLAMHIP_CHECK(hipMalloc(&sc.d_ring_err, kRing * sizeof(int)));
+      SLAMHIP_CHECK(hipMalloc(&sc.d_ring_pad, kRing * sizeof(unsigned long long)));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.d_ring_err, 0, kRing * sizeof(int), ctx->stream));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.d_ring_pad, 0, kRing * sizeof(unsigned long long), ctx->stream));
+    }
     sc.cap_beams = cap;
   }
   const size_t cb = sc.cap_beams;
@@ -299,6 +313,19 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
   a.n_padding = sc.n_updates;
+  const bool deferred = sc.deferred && ctx->low_latency;
+  if (deferred) {
+    // queued, not awaited: the status words go to slot `pending` of the ring (mu_drain)
+    if (sc.pending == kRing) {
+      long long dn = 0;
+      int de = 0;
+      const int drc = mu_drain(ctx, &dn, &de);
+      if (drc) return drc;
+      if (de) return fail("a deferred map update reported an error (beam outside the window?)", SLAMHIP_ERR_STATE);
+    }
+    a.error_flag = sc.d_ring_err + sc.pending;
+    a.n_padding = sc.d_ring_pad + sc.pending;
+  }
 
   const dim3 bgrid((n + 255) / 256);
   hipEvent_t pe0 = nullptr, pe1 = nullptr;  // slamhip_profile_read_map_update: the whole pipeline
@@ -496,22 +523,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     ctx->prof_k6_calls += 1;
     ctx->prof_k6_records += total;
   }
-  if (sc.deferred && ctx->low_latency) {
-    // queued, not awaited: the status words go to slot `pending` of the ring (mu_drain)
-    if (sc.pending == kRing) {
-      long long dn = 0;
-      int de = 0;
-      const int drc = mu_drain(ctx, &dn, &de);
-      if (drc) return drc;
-      if (de) return fail("a deferred map update reported an error (beam outside the window?)", SLAMHIP_ERR_STATE);
-    }
-    unsigned seq = ++ctx->seq;
-    if (seq == 0) seq = ++ctx->seq;
-    hipLaunchKernelGGL(k_mu_finish, dim3(1), dim3(1), 0, ctx->stream, (const int *)sc.error_flag,
-                       (const unsigned long long *)sc.n_updates, sc.h_ring + 2 * sc.pending, ctx->h_done_flag, seq);
-    SLAMHIP_CHECK(hipGetLastError());
+  if (deferred) {
     sc.ring_total[sc.pending] = total;
-    sc.last_seq = seq;
     ++sc.pending;
     if (n_updates_out) *n_updates_out = -1;
     return SLAMHIP_OK;
@@ -955,6 +968,8 @@ void mu_release(slamhip_ctx *ctx) {
       if (p) hipFree(p);
     if (s.h_status) hipHostFree(s.h_status);
     if (s.h_ring) hipHostFree(s.h_ring);
+    if (s.d_ring_err) hipFree(s.d_ring_err);
+    if (s.d_ring_pad) hipFree(s.d_ring_pad);
     if (s.h_offsets) hipHostFree(s.h_offsets);
     delete &s;
     ctx->mu_scratch = nullptr;

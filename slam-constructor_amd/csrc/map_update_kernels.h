@@ -1100,6 +1100,20 @@ __global__ void k_mu_finish(const int *error_flag, const unsigned long long *n_p
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// deferred updates (mu_set_deferred): the status words of all queued updates at once, slots back to zero
+__global__ void k_mu_finish_ring(int *err, unsigned long long *pad, int n, unsigned long long *h_ring, unsigned *flag,
+                                 unsigned seq) {
+  const int k = threadIdx.x;
+  if (k < n) {
+    h_ring[2 * k] = (unsigned long long)err[k];
+    h_ring[2 * k + 1] = pad[k];
+    err[k] = 0;
+    pad[k] = 0ull;
+  }
+  __syncthreads();
+  if (k == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the apply kernel for the cell kind of `a.rule`
 template <typename Key>
 void mu_launch_apply(const MuArgs &a, const Key *keys, unsigned total, hipStream_t stream) {
