@@ -33,6 +33,8 @@
 #include <string>
 #include <vector>
 
+#include "mt_block.h"
+
 #include "slamhip_internal.h"
 
 namespace slamhip {
@@ -120,11 +122,11 @@ struct NormalRV {
 // 2.5 KB engine copy per tree node would dominate the host time), and filled AHEAD by the matcher
 // while it waits for the GPU.
 struct PairTape {
-  explicit PairTape(unsigned seed) : engine(seed) {}
+  explicit PairTape(unsigned seed) : engine(seed) {}  // (the output sequence of std::mt19937(seed): mt_block.cpp)
   struct Pair {
     double ret, saved;  // unit normals in the order the distribution hands them out: y*mult, then x*mult
   };
-  std::mt19937 engine;
+  Mt19937Block engine;
   std::vector<Pair> pairs;
   size_t base = 0;  // absolute index of pairs[0]
   void generate() {

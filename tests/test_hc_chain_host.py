@@ -40,8 +40,24 @@ def test_mc_chain_logic_equals_reference_loop(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-fno-omit-frame-pointer", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + hip_inc,
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "slam-constructor_amd", "csrc"),
-           os.path.join(ROOT, "tests", "native", "mc_chain_test.cpp"), "-o", exe]
+           os.path.join(ROOT, "tests", "native", "mc_chain_test.cpp"),
+           os.path.join(ROOT, "slam-constructor_amd", "csrc", "mt_block.cpp"), "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok 168 matches")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no host compiler")
+def test_block_mt19937_is_std_mt19937(tmp_path):
+    """csrc/mt_block.cpp (the Monte-Carlo matcher's engine: 624 words per refill, vectorizable, an AVX2 clone picked at
+    run time) against std::mt19937: six seeds, two million words each."""
+    exe = str(tmp_path / "mt_block_test")
+    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I" + os.path.join(ROOT, "slam-constructor_amd", "csrc"),
+           os.path.join(ROOT, "tests", "native", "mt_block_test.cpp"),
+           os.path.join(ROOT, "slam-constructor_amd", "csrc", "mt_block.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok")
