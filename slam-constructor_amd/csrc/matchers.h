@@ -129,23 +129,31 @@ struct PairTape {
   Mt19937Block engine;
   std::vector<Pair> pairs;
   size_t base = 0;  // absolute index of pairs[0]
+  // One block of the engine = 624 words = 156 attempts of the polar method (four words each, accepted or not), so
+  // the tape grows a block at a time: the attempts' arithmetic is vectorized (mt_block.cpp), the accepted ones --
+  // 0 < r2 <= 1, pi / 4 of them -- take the logarithm in order.  Generating ahead of the consumer changes nothing:
+  // the tape is a function of the seed alone.
   void generate() {
-    double x, y, r2;
-    do {
-      x = 2.0 * canonical(engine) - 1.0;
-      y = 2.0 * canonical(engine) - 1.0;
-      r2 = x * x + y * y;
-    } while (r2 > 1.0 || r2 == 0.0);
-    const double mult = std::sqrt(-2 * std::log(r2) / r2);
-    pairs.push_back(Pair{y * mult, x * mult});
+    constexpr int kAttempts = 624 / 4;
+    double x[kAttempts], y[kAttempts], r2[kAttempts];
+    polar_attempts(engine.next_block(), kAttempts, x, y, r2);
+    for (int a = 0; a < kAttempts; ++a) {
+      if (r2[a] > 1.0 || r2[a] == 0.0) continue;
+      const double mult = std::sqrt(-2 * std::log(r2[a]) / r2[a]);
+      pairs.push_back(Pair{y[a] * mult, x[a] * mult});
+    }
   }
   const Pair &at(size_t i) {
     while (i - base >= pairs.size()) generate();
     return pairs[i - base];
   }
-  // make sure pairs up to absolute index `upto` exist, at most `max_new` new ones per call
+  // make sure pairs up to absolute index `upto` exist, about `max_new` new ones per call (whole blocks)
   void prefetch(size_t upto, int max_new) {
-    while (max_new-- > 0 && base + pairs.size() < upto) generate();
+    while (max_new > 0 && base + pairs.size() < upto) {
+      const size_t before = pairs.size();
+      generate();
+      max_new -= (int)(pairs.size() - before);
+    }
   }
   void trim(size_t consumed) {
     if (consumed - base < (1u << 15)) return;

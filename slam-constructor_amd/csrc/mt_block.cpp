@@ -41,6 +41,27 @@ static inline __attribute__((always_inline)) void refill_body(uint32_t *__restri
   }
 }
 
+static inline __attribute__((always_inline)) double canonical2(uint32_t lo, uint32_t hi) {
+  const double ret = ((double)lo + (double)hi * 4294967296.0) * 0x1p-64;  // (sum / 2^64: a power of two, exact)
+  return ret >= 1.0 ? 0x1.fffffffffffffp-1 : ret;                         // std::nextafter(1.0, 0.0)
+}
+
+static inline __attribute__((always_inline)) void attempts_body(const uint32_t *__restrict w, int n, double *__restrict x,
+                                                                double *__restrict y, double *__restrict r2) {
+  for (int a = 0; a < n; ++a) {
+    const double xx = 2.0 * canonical2(w[4 * a], w[4 * a + 1]) - 1.0;
+    const double yy = 2.0 * canonical2(w[4 * a + 2], w[4 * a + 3]) - 1.0;
+    x[a] = xx;
+    y[a] = yy;
+    r2[a] = xx * xx + yy * yy;
+  }
+}
+
+void attempts_generic(const uint32_t *w, int n, double *x, double *y, double *r2) { attempts_body(w, n, x, y, r2); }
+__attribute__((target("avx2"))) void attempts_avx2(const uint32_t *w, int n, double *x, double *y, double *r2) {
+  attempts_body(w, n, x, y, r2);
+}
+
 void refill_generic(uint32_t *s, uint32_t *out) { refill_body(s, out); }
 __attribute__((target("avx2"))) void refill_avx2(uint32_t *s, uint32_t *out) { refill_body(s, out); }
 
@@ -50,6 +71,12 @@ Mt19937Block::Mt19937Block(uint32_t seed) {
   s_[0] = seed;
   for (uint32_t i = 1; i < 624; ++i) s_[i] = 1812433253u * (s_[i - 1] ^ (s_[i - 1] >> 30)) + i;
   p_ = 624;
+}
+
+void polar_attempts(const uint32_t *words, int n, double *x, double *y, double *r2) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) attempts_avx2(words, n, x, y, r2);
+  else attempts_generic(words, n, x, y, r2);
 }
 
 void Mt19937Block::refill() {
