@@ -61,3 +61,23 @@ def test_block_mt19937_is_std_mt19937(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no host compiler")
+def test_pair_tape_is_std_normal_distribution(tmp_path):
+    """The Monte-Carlo matcher's tape of Marsaglia pairs (matchers.h PairTape: block engine + vectorized attempts)
+    against std::normal_distribution over std::mt19937 -- what the reference's GaussianRV1D draws from
+    (src/core/random_utils.h:17-34): 4 x 300 000 pairs and 200 000 candidates of three distributions on one engine."""
+    exe = str(tmp_path / "pair_tape_test")
+    hip_inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(hip_inc, "hip", "hip_runtime.h")):
+        pytest.skip("HIP headers not found")
+    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + hip_inc,
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "slam-constructor_amd", "csrc"),
+           os.path.join(ROOT, "tests", "native", "pair_tape_test.cpp"),
+           os.path.join(ROOT, "slam-constructor_amd", "csrc", "mt_block.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok")
