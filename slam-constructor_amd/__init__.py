@@ -534,6 +534,15 @@ class Matcher:
             raise ValueError(kind)
         self.h = h
         self._obs = None
+        self._obs_cleared = False  # the C side holds no observer of ours (set_observer(NULL) has been called)
+        # argument buffers of the per-scan calls, made once (a ctypes object per argument and call was a tenth of a
+        # headline match)
+        self._ip3, self._d3, self._prob = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+        self._st_ll = [C.c_longlong() for _ in range(5)]
+        self._st_d = [C.c_double() for _ in range(4)]
+        self._st_ll_ref = [C.byref(x) for x in self._st_ll]
+        self._st_d_ref = [C.byref(x) for x in self._st_d]
+        self._prob_ref = C.byref(self._prob)
         _live["dep"].add(self)
         ctx._deps.add(self)
 
@@ -566,8 +575,8 @@ class Matcher:
     def process_scan(self, map_id, init_pose, trace=False):
         """Returns dict(prob, delta[, poses, scores, accepted, n_calls]) -- the trace is what a
         GridScanMatcherObserver sees (on_scan_test / on_pose_update)."""
-        ip = _f64(init_pose)
-        delta, prob = np.zeros(3), C.c_double()
+        ip, d3 = self._ip3, self._d3
+        ip[0], ip[1], ip[2] = float(init_pose[0]), float(init_pose[1]), float(init_pose[2])
         rec = None
         if trace:
             rec = dict(poses=[], scores=[], accepted=[])
@@ -582,10 +591,14 @@ class Matcher:
 
             self._obs = Observer(None, OBS_FN(on_test), OBS_FN(on_update), OBS_FN(0))
             _check(self.L.slamhip_matcher_set_observer(self.h, C.byref(self._obs)))
-        else:
+            self._obs_cleared = False
+        elif not self._obs_cleared:
             _check(self.L.slamhip_matcher_set_observer(self.h, None))
-        _check(self.L.slamhip_matcher_process_scan(self.h, map_id, _d(ip), _d(delta), C.byref(prob)))
-        out = dict(prob=prob.value, delta=delta)
+            self._obs_cleared = True
+        rc = self.L.slamhip_matcher_process_scan(self.h, map_id, ip, d3, self._prob_ref)
+        if rc:
+            _check(rc)
+        out = dict(prob=self._prob.value, delta=np.array((d3[0], d3[1], d3[2])))
         if rec is not None:
             out.update(poses=np.array(rec["poses"]).reshape(-1, 3), scores=np.array(rec["scores"]),
                        accepted=np.array(rec["accepted"], dtype=np.int32),
@@ -593,12 +606,11 @@ class Matcher:
         return out
 
     def stats(self):
-        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
-        _check(self.L.slamhip_matcher_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        t = [C.c_double() for _ in range(4)]
-        _check(self.L.slamhip_matcher_timing(self.h, *[C.byref(x) for x in t]))
-        kl, rs = C.c_longlong(), C.c_longlong()
-        _check(self.L.slamhip_matcher_chain_stats(self.h, C.byref(kl), C.byref(rs)))
+        (a, b, c, kl, rs), t = self._st_ll, self._st_d
+        ra, rt = self._st_ll_ref, self._st_d_ref
+        _check(self.L.slamhip_matcher_stats(self.h, ra[0], ra[1], ra[2]))
+        _check(self.L.slamhip_matcher_timing(self.h, rt[0], rt[1], rt[2], rt[3]))
+        _check(self.L.slamhip_matcher_chain_stats(self.h, ra[3], ra[4]))
         return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value,
                     kernels_launched=kl.value, steps_rescored=rs.value, build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
                     replay_us=t[3].value)

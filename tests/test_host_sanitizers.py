@@ -22,7 +22,8 @@ def test_speculation_builders_under_asan(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I" + hip_inc, "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "slam-constructor_amd", "csrc"),
-           os.path.join(ROOT, "tests", "native", "spec_tree_asan.cpp"), "-o", exe]
+           os.path.join(ROOT, "tests", "native", "spec_tree_asan.cpp"),
+           os.path.join(ROOT, "slam-constructor_amd", "csrc", "mt_block.cpp"), "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
