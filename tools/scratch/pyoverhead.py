@@ -28,3 +28,4 @@ for _ in range(K):
     L.slamhip_matcher_process_scan(m.h, 0, a_ip, a_d, C.byref(prob))
 t2 = time.perf_counter()
 print("wrapper %.2f us/step, raw C-ABI call %.2f us/step" % (1e6 * (t1 - t0) / K, 1e6 * (t2 - t1) / K))
+print({k: round(v, 1) if isinstance(v, float) else v for k, v in m.stats().items()})
