@@ -681,22 +681,22 @@ class GmappingFilter:
 
     def step(self, map_id, rng, ang, is_occ, odom_delta, resample_seed):
         rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
-        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None  # (null: every point occupied)
         res = C.c_int(0)
         idx = np.zeros(self.n_total, np.uint32)
         _check(self.L.slamhip_gmapping_step(self.h, map_id, rng.size, _d(rng), _d(ang),
-                                            occ.ctypes.data_as(_ip), _d(d), resample_seed,
+                                            occ.ctypes.data_as(_ip) if occ is not None else None, _d(d), resample_seed,
                                             C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_uint))))
         return bool(res.value), idx
 
     def step_sharded(self, map_id, rng, ang, is_occ, odom_delta, resample_seed):
         """One scan on this shard, RCCL collectives included (Context.shard_init first)."""
         rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
-        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
         res = C.c_int(0)
         idx = np.zeros(self.n_total, np.uint32)
         _check(self.L.slamhip_gmapping_step_sharded(self.h, map_id, rng.size, _d(rng), _d(ang),
-                                                    occ.ctypes.data_as(_ip), _d(d), resample_seed,
+                                                    occ.ctypes.data_as(_ip) if occ is not None else None, _d(d), resample_seed,
                                                     C.byref(res), idx.ctypes.data_as(C.POINTER(C.c_uint))))
         return bool(res.value), idx
 
@@ -706,9 +706,9 @@ class GmappingFilter:
 
     def match_begin(self, map_id, rng, ang, is_occ, odom_delta):
         rng, ang, d = _f64(rng), _f64(ang), _f64(odom_delta)
-        occ = np.ascontiguousarray(is_occ if is_occ is not None else np.ones(rng.size), dtype=np.int32)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
         _check(self.L.slamhip_gmapping_match_begin(self.h, map_id, rng.size, _d(rng), _d(ang),
-                                                   occ.ctypes.data_as(_ip), _d(d)))
+                                                   occ.ctypes.data_as(_ip) if occ is not None else None, _d(d)))
 
     def carry_record(self):
         r = CarryRecord()
