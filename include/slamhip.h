@@ -153,6 +153,17 @@ typedef struct {
 int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
                             const double pose[3], int n, const double *range, const double *cos_a,
                             const double *sin_a, const int *is_occ, long long *n_updates);
+/* Map updates queued, not awaited (default off).  While on, slamhip_map_append_scan on the zero-copy path returns as
+ * soon as the update's kernels are queued on the context's stream -- the scan arrays are consumed before it returns,
+ * *n_updates is -1 -- and everything else the context does (matches, scores, downloads, further updates) is ordered
+ * behind them: the pose of a scan can be handed on while the GPU still writes that scan into the map
+ * (SingleStateHypothesisLaserScanGridWorld::handle_observation, single_state_hypothesis_laser_scan_grid_world.h:52-65,
+ * returns only after append_scan).  slamhip_map_drain waits for the queued updates and reports the sum of their cell
+ * updates; a failure on the device (a beam outside a window that may not grow) surfaces there as SLAMHIP_ERR_STATE.
+ * At most 64 updates stay queued (the 65th drains first); set_deferred(0) drains; a GMapping filter step on the
+ * same context drains what is queued into its own count. */
+int slamhip_map_set_deferred(slamhip_ctx *ctx, int on);
+int slamhip_map_drain(slamhip_ctx *ctx, long long *n_updates);
 /* update counters of a window (MEAN: n; GMAPPING: hits, tries) -- tests / debugging */
 int slamhip_map_download_aux(slamhip_ctx *ctx, int map_id, int x0, int y0, int w, int h, double *out);
 

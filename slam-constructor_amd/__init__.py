@@ -35,7 +35,7 @@ slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_
 slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get slamhip_gm_cache_set
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
-slamhip_map_set_auto_grow slamhip_map_info slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_set_tie_check slamhip_matcher_process_scan
+slamhip_map_set_auto_grow slamhip_map_info slamhip_map_set_deferred slamhip_map_drain slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_set_tie_check slamhip_matcher_process_scan
 slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
@@ -156,6 +156,8 @@ def load():
     L.slamhip_map_release.argtypes = [vp, i]
     L.slamhip_map_set_auto_grow.argtypes = [vp, i, i]
     L.slamhip_map_info.argtypes = [vp, i, _ip, _ip, _ip, _ip, _ip, _dp, C.POINTER(C.c_longlong)]
+    L.slamhip_map_set_deferred.argtypes = [vp, i]
+    L.slamhip_map_drain.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.slamhip_scan_upload.argtypes = [vp, i, _dp, _dp, _dp, _dp, _dp]
     L.slamhip_map_append_scan.argtypes = [vp, i, C.POINTER(ScanAdderCfg), _dp, i, _dp, _dp, _dp, _ip,
                                           C.POINTER(C.c_longlong)]
@@ -417,6 +419,15 @@ class Context:
     def map_set_auto_grow(self, map_id, on=True):
         """An unbounded map: map_append_scan grows the window instead of failing (UnboundedPlainGridMap)."""
         _check(self.L.slamhip_map_set_auto_grow(self.h, map_id, int(bool(on))))
+
+    def map_set_deferred(self, on=True):
+        """Map updates queued, not awaited: map_append_scan returns -1 updates, map_drain() reports them."""
+        _check(self.L.slamhip_map_set_deferred(self.h, 1 if on else 0))
+
+    def map_drain(self):
+        n = C.c_longlong(0)
+        _check(self.L.slamhip_map_drain(self.h, C.byref(n)))
+        return n.value
 
     def map_info(self, map_id):
         v = [C.c_int() for _ in range(5)]

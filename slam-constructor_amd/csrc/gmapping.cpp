@@ -426,13 +426,14 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
       // stream, the status words are collected when the loop is through
       struct ReuseGuard {
         slamhip_ctx *c;
+        bool was_deferred;  // (slamhip_map_set_deferred: the caller's own setting comes back afterwards)
         explicit ReuseGuard(slamhip_ctx *cc) : c(cc) {
           mu_allow_scan_reuse(c, true);
-          mu_set_deferred(c, true);
+          was_deferred = mu_set_deferred(c, true);
         }
         ~ReuseGuard() {
           mu_drain(c, nullptr, nullptr);  // (an early return: nothing may stay in flight)
-          mu_set_deferred(c, false);
+          mu_set_deferred(c, was_deferred);
           mu_allow_scan_reuse(c, false);
         }
       } reuse_guard(ctx);

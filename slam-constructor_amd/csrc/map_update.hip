@@ -85,7 +85,8 @@ struct MuScratch {
   size_t cap_bins = 0, scan_temp_bytes = 0;
   unsigned *bins = nullptr, *offs = nullptr;
   uint2 *srec = nullptr;  // (key, beam) of every record, as scattered into its cell's chain
-  unsigned *h_offsets = nullptr;  // pinned: first record slot of every beam, computed by the host
+  unsigned *h_offsets = nullptr;  // pinned: first record slot of every beam, computed by the host (x offset_slots)
+  int offset_slots = 1;
   unsigned long long *near_bits = nullptr;  // [kNearSide^2][64] words: beams (up to 4096) visiting the cells next to the robot
   void *scan_temp = nullptr;
   // deferred completion (mu_set_deferred): updates are queued without waiting for them; their status words land in
@@ -119,7 +120,12 @@ constexpr int kRing = 64;
 // queued (n_updates_out = -1); the caller must not touch the scratch of this context from another stream and has
 // to call mu_drain before it reads the map on the host or leaves.  The GMapping filter's shared-map loop uses it:
 // the next particle's match is queued behind the update on the same stream, so nothing waits for the host.
-void mu_set_deferred(slamhip_ctx *ctx, bool on) { scratch_of(ctx).deferred = on; }
+bool mu_set_deferred(slamhip_ctx *ctx, bool on) {  // returns the previous setting
+  MuScratch &sc = scratch_of(ctx);
+  const bool was = sc.deferred;
+  sc.deferred = on;
+  return was;
+}
 
 // waits for the queued updates and adds up what they report
 int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err) {
@@ -240,8 +246,11 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
       SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
       SLAMHIP_CHECK(hipMemsetAsync(sc.error_flag, 0, sizeof(int), ctx->stream));
     }
+    // (queued updates: one slot per update in flight -- the kernels of an update read their slot when they run,
+    // not when they are queued; scans too large for 64 slots are awaited)
     if (sc.h_offsets) hipHostFree(sc.h_offsets);
-    SLAMHIP_CHECK(hipHostMalloc(&sc.h_offsets, sizeof(unsigned) * (cap + 1), hipHostMallocDefault));
+    sc.offset_slots = cap <= 65536 ? kRing : 1;
+    SLAMHIP_CHECK(hipHostMalloc(&sc.h_offsets, sizeof(unsigned) * (cap + 1) * sc.offset_slots, hipHostMallocDefault));
     if (!sc.near_bits)
       SLAMHIP_CHECK(hipMalloc(&sc.near_bits, sizeof(unsigned long long) * kNearSide * kNearSide * kNearMaxWords));
     if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
@@ -313,7 +322,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
   a.n_padding = sc.n_updates;
-  const bool deferred = sc.deferred && ctx->low_latency;
+  const bool deferred = sc.deferred && ctx->low_latency && sc.offset_slots == kRing;
   if (deferred) {
     // queued, not awaited: the status words go to slot `pending` of the ring (mu_drain)
     if (sc.pending == kRing) {
@@ -334,7 +343,8 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     if (prc) return prc;
     if (pe0) SLAMHIP_CHECK(hipEventRecord(pe0, ctx->stream));
   }
-  a.host_offsets = sc.h_offsets;
+  unsigned *const h_off = sc.h_offsets + (deferred ? (size_t)sc.pending * (sc.cap_beams + 1) : 0);
+  a.host_offsets = h_off;
   const int near_words = (n + 63) / 64;
   if (near_words <= kNearMaxWords) {
     a.near_bits = sc.near_bits;
@@ -350,7 +360,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     bb_lo_x = bb_hi_x = rcx;
     bb_lo_y = bb_hi_y = rcy;
     for (int b = 0; b < n; ++b) {
-      sc.h_offsets[b] = total;
+      h_off[b] = total;
       const double c = a.cs * cos_a[b] - a.sn * sin_a[b];
       const double s = a.sn * cos_a[b] + a.cs * sin_a[b];
       const double wx = a.px + range[b] * c, wy = a.py + range[b] * s;

@@ -590,6 +590,34 @@ int slamhip_map_set_auto_grow(slamhip_ctx *ctx, int map_id, int on) {
   return SLAMHIP_OK;
 }
 
+int slamhip_map_set_deferred(slamhip_ctx *ctx, int on) {
+  if (!ctx) return invalid("null context");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  if (!on) {  // nothing stays queued behind the caller's back
+    long long nu = 0;
+    const int rc = slamhip_map_drain(ctx, &nu);
+    if (rc) return rc;
+  }
+  mu_set_deferred(ctx, on != 0);
+  return SLAMHIP_OK;
+}
+
+int slamhip_map_drain(slamhip_ctx *ctx, long long *n_updates) {
+  if (!ctx) return invalid("null context");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  long long nu = 0;
+  int err = 0;
+  const int rc = mu_drain(ctx, &nu, &err);
+  if (n_updates) *n_updates = nu;
+  if (rc) return rc;
+  if (err) {
+    set_error(err == 2 ? "internal: the device counted more cell updates than the host sized the buffers for"
+                       : "a queued map update met a beam that leaves the bound window (cells inside it were updated)");
+    return SLAMHIP_ERR_STATE;
+  }
+  return SLAMHIP_OK;
+}
+
 int slamhip_map_info(slamhip_ctx *ctx, int map_id, int *cell_model, int *width, int *height, int *origin_x,
                      int *origin_y, double *scale, long long *times_grown) {
   DeviceMap *m = get_map(ctx, map_id);

@@ -115,7 +115,7 @@ struct DeviceMap {
 };
 
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip
-void mu_set_deferred(slamhip_ctx *ctx, bool on);      // map_update.hip: queue plain updates without waiting
+bool mu_set_deferred(slamhip_ctx *ctx, bool on);      // map_update.hip: queue plain updates without waiting (returns the old setting)
 int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err);
 void mu_release(slamhip_ctx *ctx);                    // map_update.hip: frees the context's K6 scratch
 void shard_release(slamhip_ctx *ctx);                 // shard.cpp: leaves the RCCL group, frees its staging

@@ -43,6 +43,9 @@ public:
     slamhip_or_die(slamhip_map_bind(ctx, cfg.map_id, cfg.cell_model, w, h, w / 2, h / 2, cfg.map.meters_per_cell,
                                     cfg.unknown), "map_bind");
     slamhip_or_die(slamhip_map_set_auto_grow(ctx, cfg.map_id, 1), "map_set_auto_grow");
+    // the pose of a scan is handed on while the GPU still writes that scan into the map: the next match, and every
+    // read of the map, is ordered behind the update on the context's stream
+    slamhip_or_die(slamhip_map_set_deferred(ctx, 1), "map_set_deferred");
     _view = std::make_shared<HipResidentMapView>(ctx, cfg.map_id, cfg.map, 0.5, cfg.tbm_kind);
   }
 
@@ -51,7 +54,12 @@ public:
   void remove_sm_observer(std::shared_ptr<GridScanMatcherObserver> obs) { _gsm->unsubscribe(obs); }
   const GridMap &map() const override { return *_view; }
   using LaserScanGridWorld::map;
-  long long cell_updates() const { return _cell_updates; }
+  long long cell_updates() {  // (waits for the updates that are still queued)
+    long long nu = 0;
+    slamhip_or_die(slamhip_map_drain(_ctx, &nu), "map_drain");
+    _cell_updates += nu;
+    return _cell_updates;
+  }
 
   void handle_observation(TransformedLaserScan &tr_scan) override {
     _gsm->reset_state();
@@ -85,7 +93,7 @@ public:
     long long nu = 0;
     slamhip_or_die(slamhip_map_append_scan(_ctx, _cfg.map_id, &adder, p3, n, r.data(), c.data(), s.data(), occ.data(),
                                            &nu), "map_append_scan");
-    _cell_updates += nu;
+    if (nu > 0) _cell_updates += nu;  // (-1: queued, counted by cell_updates())
     _view->invalidate();
   }
 

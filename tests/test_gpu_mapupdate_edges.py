@@ -266,3 +266,56 @@ def test_window_grows_by_itself_like_an_unbounded_map(pkg, ctx, name):
                                       ctx.map_download_aux(3, bx0, by0, bx1 - bx0, by1 - by0, n_aux))
     ctx.map_release(3)
     ctx.map_release(4)
+
+
+@pytest.mark.parametrize("name", ["mean", "tbm", "gmapping"])
+def test_queued_updates_equal_awaited_updates(pkg, ctx, name):
+    """slamhip_map_set_deferred / slamhip_map_drain: the crafted scans, six rounds of them (so the ring of 64 queued
+    updates wraps), appended without waiting -- every call returns -1 -- into a window that grows by itself, against
+    the same scans awaited one by one: the drained update count is the sum, the windows are equal byte for byte, a
+    download in between is ordered behind what is queued, and a beam outside a window that may not grow surfaces at
+    the drain."""
+    cell_model, rule, st, n_aux = KINDS[name]
+    unknown = {0: [0.5], 1: [1.0, 0.0, 0.0, 0.0], 2: [-1.0, 0.0, 0.0]}[cell_model]
+    for mid in (3, 4):
+        ctx.map_bind(mid, cell_model, 48, 48, (24, 24), SCALE, unknown)
+        ctx.map_set_auto_grow(mid, True)
+    scans = crafted_scans() * 6
+    total = 0
+    for pose, rng, ang, occ, blur, max_range in scans:
+        c, s = pkg.beam_trig(ang)
+        total += ctx.map_append_scan(3, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range)
+    ctx.map_set_deferred(True)
+    mid_way = None
+    for k, (pose, rng, ang, occ, blur, max_range) in enumerate(scans):
+        c, s = pkg.beam_trig(ang)
+        assert ctx.map_append_scan(4, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range) == -1
+        if k == len(scans) // 2:
+            i4 = ctx.map_info(4)
+            mid_way = ctx.map_download_window(4, 0, 0, i4["width"], i4["height"], st)  # behind the queued updates
+    drained = ctx.map_drain()
+    assert ctx.map_drain() == 0
+    ctx.map_set_deferred(False)
+    assert len(scans) > 64 and mid_way is not None and np.isfinite(mid_way).all()
+    # (the ring drained itself once on the way: what map_drain reports is the rest)
+    assert 0 < drained <= total
+    i3, i4 = ctx.map_info(3), ctx.map_info(4)
+    assert (i3["width"], i3["height"], i3["origin"]) == (i4["width"], i4["height"], i4["origin"])
+    a = ctx.map_download_window(3, 0, 0, i3["width"], i3["height"], st)
+    b = ctx.map_download_window(4, 0, 0, i4["width"], i4["height"], st)
+    assert a.tobytes() == b.tobytes()
+    if n_aux:
+        assert ctx.map_download_aux(3, 0, 0, i3["width"], i3["height"], n_aux).tobytes() == \
+            ctx.map_download_aux(4, 0, 0, i4["width"], i4["height"], n_aux).tobytes()
+    # a window that may not grow: the failure of a queued update is reported by the drain
+    ctx.map_release(4)
+    ctx.map_bind(4, cell_model, 16, 16, (8, 8), SCALE, unknown)
+    ctx.map_set_deferred(True)
+    pose, rng, ang, occ, blur, max_range = scans[0]
+    c, s = pkg.beam_trig(ang)
+    assert ctx.map_append_scan(4, rule, pose, rng, c, s, occ, quality=0.8, blur=blur, max_range=max_range) == -1
+    with pytest.raises(pkg.SlamHipError):
+        ctx.map_drain()
+    ctx.map_set_deferred(False)
+    ctx.map_release(3)
+    ctx.map_release(4)
