@@ -87,6 +87,9 @@ struct MuScratch {
   uint2 *srec = nullptr;  // (key, beam) of every record, as scattered into its cell's chain
   unsigned *h_offsets = nullptr;  // pinned: first record slot of every beam, computed by the host (x offset_slots)
   int offset_slots = 1;
+  long long carried_updates = 0;   // cell updates of queued updates the ring collected by itself when it was full
+  double *h_scan_stage = nullptr;  // pinned, kRing x 3 cap_beams (scans of up to 8192 points)
+  int *h_occ_stage = nullptr;
   unsigned long long *near_bits = nullptr;  // [kNearSide^2][64] words: beams (up to 4096) visiting the cells next to the robot
   void *scan_temp = nullptr;
   // deferred completion (mu_set_deferred): updates are queued without waiting for them; their status words land in
@@ -130,9 +133,12 @@ bool mu_set_deferred(slamhip_ctx *ctx, bool on) {  // returns the previous setti
 // waits for the queued updates and adds up what they report
 int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err) {
   MuScratch &sc = scratch_of(ctx);
-  if (n_updates) *n_updates = 0;
+  if (n_updates) *n_updates = sc.carried_updates;
   if (err) *err = 0;
-  if (!sc.pending) return SLAMHIP_OK;
+  if (!sc.pending) {
+    sc.carried_updates = 0;
+    return SLAMHIP_OK;
+  }
   unsigned seq = ++ctx->seq;
   if (seq == 0) seq = ++ctx->seq;
   hipLaunchKernelGGL(k_mu_finish_ring, dim3(1), dim3(64), 0, ctx->stream, sc.d_ring_err, sc.d_ring_pad, sc.pending,
@@ -152,6 +158,8 @@ int mu_drain(slamhip_ctx *ctx, long long *n_updates, int *err) {
     nu += (long long)sc.ring_total[k] - (long long)pad;
   }
   sc.pending = 0;
+  nu += sc.carried_updates;
+  sc.carried_updates = 0;
   if (n_updates) *n_updates = nu;
   if (err) *err = e;
   return SLAMHIP_OK;
@@ -251,6 +259,16 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     if (sc.h_offsets) hipHostFree(sc.h_offsets);
     sc.offset_slots = cap <= 65536 ? kRing : 1;
     SLAMHIP_CHECK(hipHostMalloc(&sc.h_offsets, sizeof(unsigned) * (cap + 1) * sc.offset_slots, hipHostMallocDefault));
+    // ... and of the scan itself (lidar-sized scans): range | cos | sin packed in pinned memory and sent with one
+    // asynchronous copy instead of three staged ones, the point flags with a second
+    if (sc.h_scan_stage) hipHostFree(sc.h_scan_stage);
+    if (sc.h_occ_stage) hipHostFree(sc.h_occ_stage);
+    sc.h_scan_stage = nullptr;
+    sc.h_occ_stage = nullptr;
+    if (cap <= 8192) {
+      SLAMHIP_CHECK(hipHostMalloc(&sc.h_scan_stage, sizeof(double) * 3 * cap * kRing, hipHostMallocDefault));
+      SLAMHIP_CHECK(hipHostMalloc(&sc.h_occ_stage, sizeof(int) * cap * kRing, hipHostMallocDefault));
+    }
     if (!sc.near_bits)
       SLAMHIP_CHECK(hipMalloc(&sc.near_bits, sizeof(unsigned long long) * kNearSide * kNearSide * kNearMaxWords));
     if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
@@ -269,11 +287,35 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   // mu_allow_scan_reuse(), and identical host arrays are then uploaded only once
   const bool reuse = sc.reuse_ok && sc.last_range == range && sc.last_cos == cos_a && sc.last_sin == sin_a &&
                      sc.last_occ == is_occ && sc.last_n == n;
-  if (!reuse) {
+  const bool deferred = sc.deferred && ctx->low_latency && sc.offset_slots == kRing;
+  if (deferred && sc.pending == kRing) {  // every slot of the ring is taken: collect first
+    long long dn = 0;
+    int de = 0;
+    const int drc = mu_drain(ctx, &dn, &de);
+    if (drc) return drc;
+    sc.carried_updates += dn;
+    if (de) return fail("a deferred map update reported an error (beam outside the window?)", SLAMHIP_ERR_STATE);
+  }
+  if (!reuse && sc.h_scan_stage) {
+    // (slot `pending` while updates are queued -- its last user has been drained; slot 0 otherwise: awaited)
+    const size_t slot = deferred ? (size_t)sc.pending : 0;
+    double *st = sc.h_scan_stage + slot * 3 * cb;
+    std::memcpy(st, range, sizeof(double) * n);
+    std::memcpy(st + cb, cos_a, sizeof(double) * n);
+    std::memcpy(st + 2 * cb, sin_a, sizeof(double) * n);
+    SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, st, sizeof(double) * (2 * cb + n), hipMemcpyHostToDevice, ctx->stream));
+    if (is_occ) {
+      int *so = sc.h_occ_stage + slot * cb;
+      std::memcpy(so, is_occ, sizeof(int) * n);
+      SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, so, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+  } else if (!reuse) {
     SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cb, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cb, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!reuse) {
     sc.last_range = range;
     sc.last_cos = cos_a;
     sc.last_sin = sin_a;
@@ -322,16 +364,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.beam_info = sc.beam_info;
   a.error_flag = sc.error_flag;
   a.n_padding = sc.n_updates;
-  const bool deferred = sc.deferred && ctx->low_latency && sc.offset_slots == kRing;
-  if (deferred) {
-    // queued, not awaited: the status words go to slot `pending` of the ring (mu_drain)
-    if (sc.pending == kRing) {
-      long long dn = 0;
-      int de = 0;
-      const int drc = mu_drain(ctx, &dn, &de);
-      if (drc) return drc;
-      if (de) return fail("a deferred map update reported an error (beam outside the window?)", SLAMHIP_ERR_STATE);
-    }
+  if (deferred) {  // queued, not awaited: the status words go to slot `pending` of the ring (mu_drain)
     a.error_flag = sc.d_ring_err + sc.pending;
     a.n_padding = sc.d_ring_pad + sc.pending;
   }
@@ -981,6 +1014,8 @@ void mu_release(slamhip_ctx *ctx) {
     if (s.d_ring_err) hipFree(s.d_ring_err);
     if (s.d_ring_pad) hipFree(s.d_ring_pad);
     if (s.h_offsets) hipHostFree(s.h_offsets);
+    if (s.h_scan_stage) hipHostFree(s.h_scan_stage);
+    if (s.h_occ_stage) hipHostFree(s.h_occ_stage);
     delete &s;
     ctx->mu_scratch = nullptr;
   }

@@ -478,6 +478,10 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
     if (m.d_aux) hipFree(m.d_aux);
   }
   if (ctx->d_scan) hipFree(ctx->d_scan);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->h_scan_stage[k]) hipHostFree(ctx->h_scan_stage[k]);
+    if (ctx->scan_stage_done[k]) hipEventDestroy(ctx->scan_stage_done[k]);
+  }
   if (ctx->d_poses) hipFree(ctx->d_poses);
   if (ctx->d_scores) hipFree(ctx->d_scores);
   if (ctx->d_pose_sc) hipFree(ctx->d_pose_sc);
@@ -720,12 +724,19 @@ int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const doub
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
   if (n > ctx->scan_cap) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
     if (ctx->d_scan) hipFree(ctx->d_scan);
     ctx->d_scan = nullptr;
     ctx->scan_cap = 0;
     int cap = 2048;
     while (cap < n) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&ctx->d_scan, sizeof(double) * 5 * cap));
+    for (int k = 0; k < 2; ++k) {
+      if (ctx->h_scan_stage[k]) hipHostFree(ctx->h_scan_stage[k]);
+      ctx->h_scan_stage[k] = nullptr;
+      SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scan_stage[k], sizeof(double) * 5 * cap, hipHostMallocDefault));
+      if (!ctx->scan_stage_done[k]) SLAMHIP_CHECK(hipEventCreateWithFlags(&ctx->scan_stage_done[k], hipEventDisableTiming));
+    }
     ctx->scan_cap = cap;
   }
   ctx->h_weight.assign(weight, weight + n);
@@ -740,13 +751,19 @@ int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const doub
   ctx->scan_tot_w = tot_w;
   ctx->scan_n = n;
   const size_t c = ctx->scan_cap, bytes = sizeof(double) * n;
-  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan, range, bytes, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + c, cos_a, bytes, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + 2 * c, sin_a, bytes, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + 3 * c, weight, bytes, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan + 4 * c, ctx->h_factor.data(), bytes, hipMemcpyHostToDevice,
-                               ctx->stream));
-  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const int turn = ctx->scan_stage_turn;
+  ctx->scan_stage_turn ^= 1;
+  double *st = ctx->h_scan_stage[turn];
+  SLAMHIP_CHECK(hipEventSynchronize(ctx->scan_stage_done[turn]));  // the copy of two uploads ago (never recorded: returns at once)
+  std::memcpy(st, range, bytes);
+  std::memcpy(st + c, cos_a, bytes);
+  std::memcpy(st + 2 * c, sin_a, bytes);
+  std::memcpy(st + 3 * c, weight, bytes);
+  std::memcpy(st + 4 * c, ctx->h_factor.data(), bytes);
+  // (one copy over the five stretches, gaps included: 5 x scan_cap doubles are 80 KB at 2048 beams)
+  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan, st, sizeof(double) * (4 * c + n), hipMemcpyHostToDevice, ctx->stream));
+  SLAMHIP_CHECK(hipEventRecord(ctx->scan_stage_done[turn], ctx->stream));
+  if (ctx->stream_b) SLAMHIP_CHECK(hipStreamWaitEvent(ctx->stream_b, ctx->scan_stage_done[turn], 0));  // the second launch lane
   return SLAMHIP_OK;
 }
 
@@ -759,13 +776,27 @@ int slamhip_beam_trig_raw(int n, const double *angle, double *cos_out, double *s
 int slamhip_beam_trig_cached(int n, const double *angle, double a_min, double a_max, double a_inc,
                              double *cos_out, double *sin_out) {
   if (n < 0 || !angle || !cos_out || !sin_out || !(a_inc > 0)) return invalid("bad arguments");
-  std::vector<double> ts, tc;
-  for (double a = a_min; a < a_max; a += a_inc) {  // accumulating loop, as the provider builds it
-    double sv, cv;
-    ::sincos(a, &sv, &cv);  // fused pair, as in the reference build (see score_staged)
-    ts.push_back(sv);
-    tc.push_back(cv);
+  // the table of the last (a_min, a_max, a_inc) is kept: a world loop asks for the same one twice per scan, and
+  // building it is a libm sincos per entry
+  struct Table {
+    double a_min = 0, a_max = 0, a_inc = 0;
+    std::vector<double> ts, tc;
+  };
+  static thread_local Table tab;
+  if (tab.ts.empty() || tab.a_min != a_min || tab.a_max != a_max || tab.a_inc != a_inc) {
+    tab.ts.clear();
+    tab.tc.clear();
+    for (double a = a_min; a < a_max; a += a_inc) {  // accumulating loop, as the provider builds it
+      double sv, cv;
+      ::sincos(a, &sv, &cv);  // fused pair, as in the reference build (see score_staged)
+      tab.ts.push_back(sv);
+      tab.tc.push_back(cv);
+    }
+    tab.a_min = a_min;
+    tab.a_max = a_max;
+    tab.a_inc = a_inc;
   }
+  const std::vector<double> &ts = tab.ts, &tc = tab.tc;
   for (int i = 0; i < n; ++i) {
     const int idx = (int)std::round((angle[i] - a_min) / a_inc);
     if (idx < 0 || idx >= (int)ts.size()) return invalid("scan angle outside the trig table");

@@ -136,6 +136,11 @@ struct slamhip_ctx {
   std::vector<slamhip::DeviceMap> maps;
   // scan
   double *d_scan = nullptr;  // 5 arrays of scan_cap doubles
+  // slamhip_scan_upload: the five arrays packed in pinned memory (two buffers taking turns, an event each) and
+  // sent with ONE asynchronous copy -- no wait for the stream, which may still be busy with a queued map update
+  double *h_scan_stage[2] = {nullptr, nullptr};
+  hipEvent_t scan_stage_done[2] = {nullptr, nullptr};
+  int scan_stage_turn = 0;
   int scan_cap = 0, scan_n = 0;
   double scan_tot_w = 0.0;
   std::vector<double> h_weight, h_factor;  // host copies for GMapping carry-in fix-ups
