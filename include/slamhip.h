@@ -171,7 +171,9 @@ int slamhip_map_download_aux(slamhip_ctx *ctx, int map_id, int x0, int y0, int w
  * The FILTERED scan the scorer iterates (LaserScan2D after
  * WeightedMeanPointProbabilitySPE::filter_scan, weighted_mean_point_probability_spe.h:75-95),
  * flattened: per point range, cos/sin of its own angle as the scan's TrigonometryProvider
- * tabulates them, weight (ScanPointWeighting::weight, :21-60) and factor (sensor_data.h:74-75). */
+ * tabulates them, weight (ScanPointWeighting::weight, :21-60) and factor (sensor_data.h:74-75).
+ * The arrays are consumed before the call returns; the copy to HBM is queued on the context's stream (no wait for
+ * work that is still running there, e.g. a queued map update), ahead of every later score or match. */
 int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const double *cos_a,
                         const double *sin_a, const double *weight, const double *factor);
 /* host helpers building cos_a/sin_a: RawTrigonometryProvider (trigonometry_utils.h:17-35) ... */
