@@ -27,6 +27,8 @@ One JSON line on rank 0 with the extra objects
                   inside the library) and, on one GPU, the faithful shared-map step and per-particle maps
   cfg5            BASELINE configs[4] on one GPU (500 particles, 8000^2 @ 0.025 m, area estimator + blur,
                   K6 roofline)
+  world_loop      one hypothesis scan after scan on the headline's scene: scan upload + match + map update (queued
+                  behind the match) per scan, with the CPU restatement's same loop on one core beside it
 CPU baselines run BEFORE this process touches the GPU (they use worker processes).
 """
 import argparse
@@ -44,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_UNIT = {"occ": 24, "tbm": 56, "gmapping": 232}  # SURVEY 8d algorithmic bytes / (pose, beam)
 K6_BYTES_PER_RECORD = 64  # per (beam, cell) 2 x 32 B read-modify-write
-ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5"]
+ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5", "world"]
 
 WORKLOADS = {
     # name: (cell model, weighting, matcher kind, params, bytes key, description)
@@ -715,6 +717,65 @@ def cfg5_leg(args, pkg, ctx, torch):
 
 
 # ------------------------------------------------------------------------------------------------- main
+def world_cpu_baseline(sc, kind, params, scans=30):
+    """The single-hypothesis loop of world_leg on one host core with the CPU restatement (oracle/slam_oracle.c):
+    match, then GridMapScanAdder::append_scan from the matched pose, `scans` times."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    from pyoracle_mapupdate import RULE_MEAN, append_scan_ex
+    O = po.Oracle()
+    e = O.enumerator({"HC": po.SM_HC, "MC": po.SM_MC}[kind], params)
+    m0, scan = sc["map"], sc["scan"]
+    m = po.GridMapData(m0.cell_model, m0.payload.copy(), m0.origin, m0.scale, m0.unknown)
+    aux = np.zeros(m.payload.shape[:2] + (1,))
+    t0 = time.perf_counter()
+    for _ in range(scans):
+        r = O.process_scan(e, m, scan, po.make_cfg(), sc["init_pose"], cap=8)
+        append_scan_ex(O, m, aux, RULE_MEAN, np.asarray(sc["init_pose"]) + r["delta"], scan.range, scan.angle)
+    dt = time.perf_counter() - t0
+    return {"value": scans / dt, "unit": "scans/s", "cores": 1, "kind": "port",
+            "sample": "%d scans (match + map update) with oracle/slam_oracle.c on one core, %.2f s" % (scans, dt)}
+
+
+def world_leg(args, pkg, ctx, sc, cfg, kind, params):
+    """One hypothesis, scan after scan, everything through the C-ABI: upload the (filtered) scan, match from the
+    odometry pose, append the scan to the map from the matched pose -- SingleStateHypothesisLaserScanGridWorld::
+    handle_observation (single_state_hypothesis_laser_scan_grid_world.h:52-65) with the map resident in HBM and its
+    update queued behind the match (slamhip_map_set_deferred), as host/slamhip_resident_world.h runs it.  Parity of
+    this loop against the reference's world: tests/test_gpu_world.py."""
+    scan, m0 = sc["scan"], sc["map"]
+    cos_a, sin_a = pkg.beam_trig(scan.angle)
+    ctx.map_bind(5, m0.cell_model, m0.width, m0.height, m0.origin, m0.scale, m0.unknown)
+    ctx.map_upload_window(5, 0, 0, m0.payload)
+    ctx.map_set_auto_grow(5, True)
+    m = pkg.Matcher(ctx, kind, cfg, params)
+    ctx.map_set_deferred(True)
+    init = np.asarray(sc["init_pose"], dtype=np.float64)
+
+    def one_scan():
+        ctx.scan_upload(scan.range, cos_a, sin_a, scan.weight, scan.factor)
+        r = m.process_scan(5, init)
+        ctx.map_append_scan(5, pkg.RULE_MEAN, init + r["delta"], scan.range, cos_a, sin_a)
+
+    for _ in range(5):
+        one_scan()
+    updates = ctx.map_drain()
+    n = max(20, args.steps)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_scan()
+    updates = ctx.map_drain()
+    dt = time.perf_counter() - t0
+    ctx.map_set_deferred(False)
+    m.close()
+    ctx.map_release(5)
+    return {"metric": "scans/s, one hypothesis: scan upload + match + map update per scan", "value": n / dt,
+            "unit": "scans/s", "ms_per_scan": 1e3 * dt / n, "scans": n, "cell_updates_per_scan": updates / n,
+            "note": "map resident in HBM (MeanProbabilityCell), the update queued behind the match on the context's "
+                    "stream and drained at the end of the timed region; same scan and odometry error every time"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
     torch.distributed.run as a CHILD process -- nothing in this process has touched the GPU yet, and it never
@@ -767,6 +828,12 @@ def main():
         cpu_out = cpu_baseline(sc, sc_args, kind, params, args.cpu_seconds, weighting, args.cpu_procs)
         if pf_needed:
             pf_cpu_out = pf_cpu_baselines(args, pf_sc, pf_sc_args, min(args.cpu_seconds, 8.0))
+    world_cpu_out = None
+    if world == 1 and rank == 0 and not args.no_cpu and args.workload != "sweep" and "world" in args.leg_set:
+        try:
+            world_cpu_out = world_cpu_baseline(sc, kind, params)
+        except Exception as e:  # noqa: BLE001
+            world_cpu_out = {"error": str(e)}
 
     # ---- from here on the GPU
     import torch.distributed as dist
@@ -875,6 +942,8 @@ def main():
     if m is not None:
         m.close()
 
+    world_out = None  # (the world-loop leg, filled in below; emit_line reads it when the line goes out)
+
     def emit_line(pf_out, cfg5_out):
         """rank 0's ONE JSON line (the headline is complete before the secondary legs start)"""
         bpu = BYTES_PER_UNIT[bkey]
@@ -925,6 +994,8 @@ def main():
                 pf_out["cpu_baseline"] = pf_cpu_out
         if cfg5_out is not None:
             out["cfg5"] = cfg5_out
+        if world_out is not None:
+            out["world_loop"] = world_out
         print(json.dumps(out))
 
     # The secondary legs run AFTER the headline is complete.  With more than one rank the particle-filter leg joins
@@ -958,6 +1029,14 @@ def main():
             cfg5_out = cfg5_leg(args, pkg, ctx, torch)
         except pkg.SlamHipError as e:
             cfg5_out = {"error": str(e)}
+
+    if "world" in args.leg_set and world == 1 and args.workload != "sweep":
+        try:
+            world_out = world_leg(args, pkg, ctx, sc, cfg, kind, params)
+            if world_cpu_out:
+                world_out["cpu_baseline"] = world_cpu_out
+        except pkg.SlamHipError as e:
+            world_out = {"error": str(e)}
 
     if watchdog is not None:
         watchdog.cancel()
