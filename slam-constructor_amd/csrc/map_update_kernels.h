@@ -973,6 +973,30 @@ __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is 
   return __hiloint2double(hi, lo);
 }
 
+// x / y, correctly rounded, from a reciprocal of y refined AHEAD of x: the IEEE division sequence the compiler emits
+// for a / b (v_div_scale, v_rcp, two Newton steps, quotient, residual, v_div_fmas, v_div_fixup) splits into a part that
+// needs the denominator alone and a tail of three dependent operations on the numerator.  Inside 2^-500 .. 2^500 the
+// scaling steps leave both operands alone, so the refined reciprocal can be made a step early; outside (and for zeros,
+// infinities, NaNs) the plain division runs.  tools/scratch/div_probe.hip: 16.7 M divisions, all bit-equal.
+__device__ __forceinline__ double mu_refined_rcp(double y) {
+  const double r0 = __builtin_amdgcn_rcp(y);
+  const double f0 = __builtin_fma(-y, r0, 1.0);
+  const double r1 = __builtin_fma(r0, f0, r0);
+  const double f2 = __builtin_fma(-y, r1, 1.0);
+  return __builtin_fma(r1, f2, r1);
+}
+__device__ __forceinline__ bool mu_div_safe(double x) {
+  const double ax = fabs(x);
+  return ax > 0x1p-500 && ax < 0x1p500;
+}
+__device__ __forceinline__ double mu_div_with(double x, double y, double r) {
+  if (!(mu_div_safe(x) && mu_div_safe(y))) return x / y;
+  const double q = x * r;
+  const double e = __builtin_fma(-y, q, x);
+  const double q2 = __builtin_fma(e, r, q);
+  return __builtin_amdgcn_div_fixup(q2, y, x);
+}
+
 // Chains that run past the end of their wave (at most one per wave; the robot's own cell takes one update per
 // beam, its neighbours hundreds): one thread walking such a chain pays a memory round trip per 8 records (330 us
 // for 1080 updates).  Here the WAVE that holds the chain's head streams it (at the end of k_mu_apply, after the
@@ -1014,6 +1038,32 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
         busy = __ballot(hit);
       }
       int t = 0;
+      if (RULE == 2) {
+        // MeanProbabilityCell: c = (c n + p') / (n + 1), a division per observation that waits for the one before --
+        // 1080 of them on the robot's own cell, 100 ns each, were the whole kernel.  The denominator is known a
+        // step early: its refined reciprocal is made next to the step before (two independent chains in one
+        // loop body), which leaves three dependent operations of the division behind the numerator.
+        // The round takes this form only when every operand stays inside the range where the division's scaling
+        // steps do nothing (all p' in 2^-400 .. 2^400, none NaN, the mean non-negative and below 2^400: the mean is
+        // then a convex combination of such values all along); otherwise mu_step's plain divisions below.
+        const double tp = 0.5 + (p - 0.5) * a.quality;  // mu_step's that_p, per lane
+        const bool mine = lane < n_here;
+        const bool fine = !mine || (tp > 0x1p-400 && tp < 0x1p400);
+        if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52) {
+          double r = mu_refined_rcp(c.x0 + 1.0);
+          for (; t < n_here; ++t) {
+            const double n1 = c.x0 + 1;
+            const double x = c.c0 * c.x0 + mu_readlane(tp, t);
+            const double r_next = mu_refined_rcp(n1 + 1.0);  // (independent of x: scheduled beside the tail below)
+            const double q = x * r;
+            const double e = __builtin_fma(-n1, q, x);
+            const double q2 = __builtin_fma(e, r, q);
+            c.c0 = __builtin_amdgcn_div_fixup(q2, n1, x);
+            c.x0 = n1;
+            r = r_next;
+          }
+        }
+      }
       while (t < n_here) {
         // (every lane holds the same cell state; the first lane's test keeps `t` wave-uniform)
         if (RULE == 4 && __builtin_amdgcn_readfirstlane((int)(c.c0 == 0.0))) {  // skip the free run ahead
