@@ -225,8 +225,10 @@ int slamhip_profile_read_map_update(slamhip_ctx *ctx, double *ms_total, long lon
  *   HillClimbingScanMatcher (hill_climbing_scan_matcher.h:128-170; enumerators :10-126)
  *   BruteForceScanMatcher   (brute_force_scan_matcher.h:66-80; enumerator :10-64)
  * through PoseEnumerationScanMatcher::process_scan (pose_enumeration_scan_matcher.h:31-77).
- * The accept/reject chain is evaluated in speculative batches on the GPU and replayed on the
- * host in the reference's order, so observers see exactly the reference's event sequence. */
+ * The accept/reject chain is evaluated speculatively on the GPU and replayed in the reference's order -- by
+ * the next kernel of a device-resident chain (slamhip_matcher_set_device_chain, the default wherever it
+ * applies) or, for the configurations the chains do not cover, on the host between batches -- so observers
+ * see exactly the reference's event sequence either way. */
 typedef struct {
   void *user;
   /* GridScanMatcherObserver (grid_scan_matcher.h:16-32) */
@@ -301,7 +303,9 @@ int slamhip_pf_heaviest(int n, const double *weights, int *index);
  * / handle_observation, src/slams/gmapping/gmapping_world.h:57-101) for the likelihood part of
  * the step: odometry, matching gate, pose noise, HC(6, 0.1, 0.1) scan matching of all particles in
  * lock-step on the GPU, weight update, normalisation, N_eff test, multinomial resampling with
- * duplicated particles and master hand-over.  The map update inside the step is not built yet.
+ * duplicated particles and master hand-over.  The map update inside the step (gmapping_world.h:93-97) comes in
+ * two forms: slamhip_gmapping_set_map_update (the reference's ONE shared map, updated particle after particle)
+ * and slamhip_gmapping_enable_particle_maps (a copy-on-write map per particle, one batched update per step).
  *
  * A filter object holds the particles [first, first + count) of n_total (one object per GPU when
  * particles are sharded).  Sharded step:

@@ -93,3 +93,21 @@ def gmapping_particle_map(oracle, pf, particle):
     pay, aux = np.zeros((h, w, st)), np.zeros((h, w, 2))
     L.orc_gmapping_copy_particle_map(pf.h, particle, _d(pay), _d(aux))
     return pay, aux
+
+
+def gmapping_particle_map_append(oracle, pf, gmap, particle, pose, rng, ang, is_occ=None, trig=None):
+    """GridMapScanAdder::append_scan on ONE particle's own map (adder parameters of gmapping_enable_particle_maps),
+    from `pose`, with the scan's trig provider `trig` (None = raw).  Returns #cell updates."""
+    L = oracle.lib
+    L.orc_gmapping_particle_map_append.restype = C.c_longlong
+    L.orc_gmapping_particle_map_append.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int, _dp, _dp, _ip,
+                                                   C.c_void_p]
+    rng, ang, pose = f64(rng), f64(ang), f64(pose)
+    occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+    m = _map_struct(gmap)
+    ts = _scan_struct(trig or ScanData(rng, ang))
+    res = L.orc_gmapping_particle_map_append(pf.h, C.byref(m), particle, _d(pose), rng.size, _d(rng), _d(ang), _i(occ),
+                                             C.byref(ts))
+    if res < 0:
+        raise ValueError("particle map append failed (%d)" % res)
+    return int(res)

@@ -182,6 +182,10 @@ void orc_gmapping_set_update(orc_gmapping *g, const orc_adder *upd, double *payl
 /* every particle gets its own copy of (payload, aux); updates inside the step go to the copies */
 void orc_gmapping_set_particle_maps(orc_gmapping *g, const orc_adder *upd, const double *payload,
                                     size_t payload_doubles, const double *aux, size_t aux_doubles);
+/* GridMapScanAdder::append_scan on particle `particle`'s own map from `pose` (trig NULL = raw provider) */
+long long orc_gmapping_particle_map_append(orc_gmapping *g, const orc_map *map, int particle, const double *pose,
+                                           int n_raw, const double *range, const double *angle, const int *is_occ,
+                                           const orc_scan *trig);
 void orc_gmapping_copy_particle_map(const orc_gmapping *g, int particle, double *payload_out, double *aux_out);
 
 /* ---- map update (map_update_oracle.c) ---- */

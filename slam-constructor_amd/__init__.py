@@ -475,15 +475,19 @@ class Context:
         return r.value, w.value
 
     def shard_allgather(self, local, counts):
-        """All-gather of per-rank blocks of counts[r] rows (RCCL); returns the rows of all ranks in rank order."""
+        """All-gather of per-rank blocks of counts[r] rows (RCCL); returns the rows of all ranks in rank order.
+        The row shape is local.shape[1:] -- pass an array shaped (counts[rank], ...) even when counts[rank] is 0, so
+        that every rank puts the same element size on the wire."""
         a = np.ascontiguousarray(local)
         cn = np.ascontiguousarray(counts, dtype=np.int32)
         rank, world = self.shard_info()
         assert cn.size == world
-        row = a.size // max(int(cn[rank]), 1) if cn[rank] else 0
-        assert cn[rank] == 0 or a.size == row * cn[rank]
-        row = max(row, 1)
-        out = np.zeros((int(cn.sum()), row) if row > 1 else int(cn.sum()), dtype=a.dtype)
+        if a.ndim == 0 or a.shape[0] != int(cn[rank]):
+            raise ValueError("shard_allgather: local must have shape (counts[rank], ...), got %r for %d rows"
+                             % (a.shape, int(cn[rank])))
+        row_shape = a.shape[1:]
+        row = int(np.prod(row_shape)) if row_shape else 1
+        out = np.zeros((int(cn.sum()),) + tuple(row_shape), dtype=a.dtype)
         _check(self.L.slamhip_shard_allgather(self.h, a.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(_ip),
                                               a.dtype.itemsize * row, out.ctypes.data_as(C.c_void_p)))
         return out

@@ -878,7 +878,7 @@ int slamhip_gmapping_particle_maps_append(slamhip_gmapping *g, int n_jobs, const
   int rc = mu_append_batch(g->ctx, g->tp, &cfg, n_jobs, poses3, particles, n_raw, range, g->trig_cos.data(),
                            g->trig_sin.data(), is_occ, &nu);
   if (rc) return rc;
-  g->cell_updates = nu;
+  g->cell_updates += nu;
   if (n_updates) *n_updates = nu;
   return SLAMHIP_OK;
 }

@@ -370,11 +370,10 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   }
 
   const dim3 bgrid((n + 255) / 256);
-  hipEvent_t pe0 = nullptr, pe1 = nullptr;  // slamhip_profile_read_map_update: the whole pipeline
+  ProfilePairGuard prof;  // slamhip_profile_read_map_update: the whole pipeline (closed on every exit)
   {
-    const int prc = profile_event_pair(ctx, &pe0, &pe1, 1);
+    const int prc = prof.open(ctx, ctx->stream, 1);
     if (prc) return prc;
-    if (pe0) SLAMHIP_CHECK(hipEventRecord(pe0, ctx->stream));
   }
   unsigned *const h_off = sc.h_offsets + (deferred ? (size_t)sc.pending * (sc.cap_beams + 1) : 0);
   a.host_offsets = h_off;
@@ -561,8 +560,9 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.rec_beam = sc.order_sorted;
   mu_launch_apply<unsigned>(a, (const unsigned *)sc.keys_sorted, total, ctx->stream);
   SLAMHIP_CHECK(hipGetLastError());
-  if (pe1) {
-    SLAMHIP_CHECK(hipEventRecord(pe1, ctx->stream));
+  if (prof.on()) {
+    const int prc = prof.close();
+    if (prc) return prc;
     ctx->prof_k6_calls += 1;
     ctx->prof_k6_records += total;
   }
@@ -892,11 +892,10 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
 
   const dim3 bgrid((unsigned)((beams + 255) / 256));
   a.job_bbox = sc.d_bbox;
-  hipEvent_t pe0 = nullptr, pe1 = nullptr;  // slamhip_profile_read_map_update: the whole pipeline
+  ProfilePairGuard prof;  // slamhip_profile_read_map_update: the whole pipeline (closed on every exit)
   {
-    const int prc = profile_event_pair(ctx, &pe0, &pe1, 1);
+    const int prc = prof.open(ctx, st, 1);
     if (prc) return prc;
-    if (pe0) SLAMHIP_CHECK(hipEventRecord(pe0, st));
   }
   if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_count<1>, bgrid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_mu_count<0>, bgrid, dim3(256), 0, st, a);
@@ -982,8 +981,9 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
     rc = mu_batch_tail<unsigned long long>(a, sc, total, beams, end_bit, st);
   if (rc) return rc;
   SLAMHIP_CHECK(hipGetLastError());
-  if (pe1) {
-    SLAMHIP_CHECK(hipEventRecord(pe1, st));
+  if (prof.on()) {
+    const int prc = prof.close();
+    if (prc) return prc;
     ctx->prof_k6_calls += 1;
     ctx->prof_k6_records += total;
   }

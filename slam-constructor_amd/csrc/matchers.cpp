@@ -41,6 +41,7 @@ struct slamhip_matcher {
   std::vector<unsigned> keep_fprints;
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
+  int debug_trace_cap = 0;        // testing (slamhip_matcher_debug_trace_cap): pretend the trace buffer is this small
   // Monte Carlo kept on the device (mc_chain.h)
   bool is_mc = false;
   slamhip::McChainCtl *d_mc = nullptr;
@@ -207,6 +208,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   a.host = m->h_chain;
   a.trace = m->has_obs ? m->h_trace : nullptr;
   a.trace_cap = m->has_obs ? m->trace_cap : 0;
+  if (m->has_obs && m->debug_trace_cap > 0) a.trace_cap = std::min(a.trace_cap, m->debug_trace_cap);
   a.stamps = m->d_stamps;
   volatile HcHostOut *h = m->h_chain;
   h->error = 0;
@@ -247,15 +249,15 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  m->chain_launched = launched;
   if (h->error == 1) {
     set_error("internal: the device replay found no terminal round (hill-climbing chain bug)");
     return SLAMHIP_ERR_STATE;
   }
-  if (h->error == 2) {
-    set_error("hill-climbing chain: more scorer calls than the trace buffer holds");
-    return SLAMHIP_ERR_UNSUPPORTED;
-  }
-  if (h->error == 3) return kChainNeedsHost;  // nothing has been reported or stored yet: the host path redoes the match
+  // 2: the observer's trace outgrew its buffer (65536 scorer calls), 3: a one-run scan sat on the path.  Nothing has
+  // been reported to the observer or stored in the matcher yet, so the host-driven path -- which has neither limit --
+  // redoes the match.
+  if (h->error == 2 || h->error == 3) return kChainNeedsHost;
   if (m->cfg.oope == SLAMHIP_OOPE_GMAPPING) {
     ctx->gm_cx = h->gm_cx;
     ctx->gm_cy = h->gm_cy;
@@ -660,10 +662,9 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  if (h->error == 2) {
-    set_error("Monte-Carlo chain: more scorer calls than the trace buffer holds");
-    return SLAMHIP_ERR_UNSUPPORTED;
-  }
+  // the observer's trace outgrew its buffer: the enumerator has not been touched yet (set_chain_result below),
+  // the host-driven path redoes the match from the same engine position
+  if (h->error == 2) return kChainNeedsHost;
   if ((size_t)h->tape_pos + 3 > need) {
     set_error("internal: the Monte-Carlo chain ran past the uploaded window of the pair tape");
     return SLAMHIP_ERR_STATE;
@@ -805,6 +806,15 @@ int slamhip_matcher_debug_stamps(slamhip_matcher *m, long long *out512) {
   return SLAMHIP_OK;
 }
 
+// testing aid, not part of include/slamhip.h: the hill-climbing chain treats its observer trace buffer as `cap`
+// entries long (0 = its real size), so that the overflow path -- the match redone by the host-driven matcher --
+// can be exercised without a 65536-call match
+int slamhip_matcher_debug_trace_cap(slamhip_matcher *m, int cap) {
+  if (!m || cap < 0) return invalid_arg("bad trace cap");
+  m->debug_trace_cap = cap;
+  return SLAMHIP_OK;
+}
+
 int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long *poses_evaluated,
                           long long *launches) {
   if (!m) return invalid_arg("null matcher");
@@ -840,7 +850,10 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
     const int crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
     if (crc != kChainNeedsHost) return crc;
   }
-  if (mc_chain_eligible(m)) return mc_chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
+  if (mc_chain_eligible(m)) {
+    const int crc = mc_chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
+    if (crc != kChainNeedsHost) return crc;
+  }
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   const int budget = m->max_batch > 0 ? m->max_batch : 256;
   int rc = ensure_pose_capacity(ctx, budget + 2);  // + the initial pose, + the best pose of a batch scored twice

@@ -251,18 +251,42 @@ int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kin
   return SLAMHIP_OK;
 }
 
+int ProfilePairGuard::open(slamhip_ctx *ctx, hipStream_t st, int kind) {
+  stream = st;
+  const int rc = profile_event_pair(ctx, &e0, &e1, kind);
+  if (rc) return rc;
+  if (e0) {
+    SLAMHIP_CHECK(hipEventRecord(e0, st));
+    closed = false;
+  }
+  return SLAMHIP_OK;
+}
+int ProfilePairGuard::close() {
+  if (closed || !e1) return SLAMHIP_OK;
+  closed = true;
+  SLAMHIP_CHECK(hipEventRecord(e1, stream));
+  return SLAMHIP_OK;
+}
+
 static int profile_resolve(slamhip_ctx *ctx) {
   if (ctx->ev_used == 0) return SLAMHIP_OK;
+  // whatever happens below, the pool starts afresh: a failure here must not wedge every later read
+  const size_t used = ctx->ev_used;
+  ctx->ev_used = 0;
+  std::vector<char> kinds;
+  kinds.swap(ctx->ev_kind);
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
-  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+  for (size_t i = 0; i + 1 < used; i += 2) {
     float ms = 0.f;
-    SLAMHIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
-    if (i / 2 < ctx->ev_kind.size() && ctx->ev_kind[i / 2] == 1) ctx->prof_k6_ms += ms;
+    // a pair whose end was never recorded (a launch that failed between the two) is skipped, not fatal
+    if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    if (i / 2 < kinds.size() && kinds[i / 2] == 1) ctx->prof_k6_ms += ms;
     else ctx->prof_ms += ms;
   }
-  ctx->ev_kind.clear();
-  ctx->ev_used = 0;
   return SLAMHIP_OK;
 }
 

@@ -209,6 +209,21 @@ int lane_fork(slamhip_ctx *ctx);
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
                 int *cell_model, const TiledTarget *tiled = nullptr);
 int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kind = 0);
+// An event pair recorded AROUND a pipeline (the map update): every exit between the first record and the second --
+// an empty update, a failed grow, a HIP error -- would leave a pair whose end was never recorded (or holds a stale
+// time from the pool's last use), and slamhip_profile_read would fail on it.  The guard records the end on the
+// way out unless close() did.
+struct ProfilePairGuard {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t stream = nullptr;
+  bool closed = true;
+  int open(slamhip_ctx *ctx, hipStream_t st, int kind);
+  int close();  // records the end of the pair; SLAMHIP_OK when profiling is off
+  bool on() const { return e1 != nullptr; }
+  ~ProfilePairGuard() {
+    if (!closed && e1) (void)hipEventRecord(e1, stream);
+  }
+};
 
 // ---- many hill-climbing chains over the GMapping OOPE in shared launches (matchers.cpp; the filter's lock-step
 // replacement: one chain per particle, same map, same scan, no carry-in -- DESIGN.md section 7)

@@ -254,3 +254,26 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
                 init = init + np.array([0.011, -0.006, 0.003])
             if n_beams >= 16:
                 assert dev.stats()["launches"] <= host.stats()["launches"] or prm[0] == 6  # (super-steps vs round trips)
+
+
+def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx):
+    """with an observer attached the chain writes its trace into a fixed pinned buffer; a match with more
+    scorer calls than it holds (error 2) used to fail with SLAMHIP_ERR_UNSUPPORTED although the host-driven path
+    has no such limit.  Now the match is redone there -- nothing has been reported at that point -- and the
+    observer sees the one, complete trace.  The buffer is made artificially small through the testing hook."""
+    import ctypes as C
+    sc = make_scene(cell_model=CELL_OCC, size=600, scale=0.05, n_beams=720, seed=5)
+    upload(pkg, ctx, sc)
+    dev, host = matchers(pkg, ctx, [32, 0.1, 0.1])
+    L = pkg.load()
+    L.slamhip_matcher_debug_trace_cap.argtypes = [C.c_void_p, C.c_int]
+    L.slamhip_matcher_debug_trace_cap.restype = C.c_int
+    want = host.process_scan(0, sc["init_pose"], trace=True)
+    assert want["n_calls"] > 40
+    assert L.slamhip_matcher_debug_trace_cap(dev.h, 16) == 0
+    got = dev.process_scan(0, sc["init_pose"], trace=True)
+    assert_trace_equal(got, want)
+    assert dev.stats()["kernels_launched"] > 0  # the chain did run first
+    assert L.slamhip_matcher_debug_trace_cap(dev.h, 0) == 0
+    again = dev.process_scan(0, sc["init_pose"], trace=True)
+    assert_trace_equal(again, want)

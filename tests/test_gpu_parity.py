@@ -307,11 +307,15 @@ def test_gmapping_filter_vs_reference_golden(pkg, ctx, scenario, pose_trig):
     ctx.map_release(5)
 
 
+@pytest.mark.parametrize("pose_trig", [1, 0])
 @pytest.mark.parametrize("size", [2000, 4000])
-def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle, size):
+def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle, size, pose_trig):
     """BASELINE cfg 4 (100 particles, 1080 beams, GMapping cell/OOPE, HC(6, 0.1, 0.1)) on a 2000x2000 and on the
-    configuration's own 4000x4000 @0.05 m map (0.5 GB of cells in HBM): the lock-step GPU filter against the
-    sequential CPU oracle."""
+    configuration's own 4000x4000 @0.05 m map (0.5 GB of cells in HBM) against the sequential CPU oracle, both ways
+    the filter can run its likelihood step: pose_trig 1 = host pose trigonometry, host-driven lock-step jobs;
+    pose_trig 0 = the DEFAULT and what bench.py times (`pf` leg): device sincos, one accept chain per particle on the
+    device in shared launches (csrc/hc_chain.hip, grid.y = particle).  Same bars either way: resampling indices and
+    scorer calls exact, poses 1e-10, weights 1e-9 (gmapping_world.h:73-101)."""
     from synth import make_scene
     sc = make_scene(cell_model=2, size=size, scale=0.05, n_beams=1080, seed=11)
     m, scan = sc["map"], sc["scan"]
@@ -319,7 +323,7 @@ def test_gmapping_filter_100_particles_vs_oracle(pkg, ctx, po, oracle, size):
     n = 100
     seeds = np.arange(1000, 1000 + n, dtype=np.uint32)
     gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]  # gate open: every particle matches
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, pose_trig=1), n, seeds)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, pose_trig=pose_trig), n, seeds)
     opf = oracle.gmapping_create(n, gp, seeds)
     deltas = [sc["true_pose"], [0.02, 0.01, 0.01], [0.4, 0.5, 0.3], [0.01, -0.02, 0.02]]
     for k, d in enumerate(deltas):

@@ -301,8 +301,12 @@ def test_particle_maps_vs_reference_copy_on_write_copies(pkg):
     ctx.close()
 
 
-def test_cfg5_geometry_against_the_oracle(pkg, oracle):
-    """BASELINE configs[4] at its own geometry: an 8000 x 8000 map at 0.025 m per cell, 1080 beams that walk up to
+@pytest.mark.parametrize("pose_trig", [1, 0])
+def test_cfg5_geometry_against_the_oracle(pkg, oracle, pose_trig):
+    """pose_trig 1: host pose trigonometry, host-driven lock-step jobs; 0 (the default, what bench.py runs): device
+    sincos -- at six particles one accept chain per particle on the device, gathering through the particle's tile table
+    (the lock-step jobs of larger shards have test_cfg5_lock_step_through_tile_tables_70_particles below).
+    BASELINE configs[4] at its own geometry: an 8000 x 8000 map at 0.025 m per cell, 1080 beams that walk up to
     1200 cells, AreaOccupancyEstimator, blur 0.1 m (four cells), per-particle copy-on-write maps, the map update
     fused behind the likelihood.  Six particles instead of five hundred (the oracle keeps a dense map per particle),
     two steps: poses, weights and resampling decisions equal the oracle's, and EVERY particle's map over the whole
@@ -326,7 +330,7 @@ def test_cfg5_geometry_against_the_oracle(pkg, oracle):
     gp = [0.0, 0.05, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
     seeds = np.arange(3000, 3000 + n, dtype=np.uint32)
     shift = 0.01 * scale
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, pose_trig=1), n, seeds)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, pose_trig=pose_trig), n, seeds)
     ext = (size + 127) // 128 + 1
     reach = int(np.ceil(2.0 * (float(scan.range.max()) + 1.0) / scale / 128.0)) + 2
     pf.enable_particle_maps(2, extent_tiles=ext, pool_tiles=ext * ext + n * reach * reach, blur=0.1, estimator=1,
@@ -351,6 +355,7 @@ def test_cfg5_geometry_against_the_oracle(pkg, oracle):
         np.testing.assert_allclose(poses, oposes, rtol=0, atol=1e-10, err_msg="step %d" % k)
         np.testing.assert_allclose(wts, owts, rtol=1e-9, atol=0, err_msg="step %d" % k)
         poses_at.append(poses.copy())
+    assert pf.stats()["scorer_calls"] == opf.o.lib.orc_gmapping_scorer_calls(opf.h)
     assert pf.particle_map_stats()["cell_updates"] > n * 1080 * 300  # long beams: hundreds of cells each
     c_all, s_all = pkg.beam_trig(scan.angle)
     unexplained, caveat_cells = 0, 0
@@ -492,3 +497,132 @@ def test_fast_path_at_full_batch_size_counts_every_record_once(pkg, monkeypatch)
     # the ancestor carries no counters: a particle's tries are its records of the two batches
     tries = [float(fa[..., 1].sum()) for fp, fa in out["fast"][1]]
     assert abs(np.mean(tries) * n - sum(out["fast"][0])) < 0.05 * sum(out["fast"][0])
+
+
+def _device_trig_scan(pkg, po, rng, ang):
+    """The scan as the device sees it: per-beam libm cos / sin of the scan angle (slamhip_beam_trig_raw), combined
+    with the pose heading by angle addition -- for the oracle a cached-provider scan whose table slot i holds beam i."""
+    cos_a, sin_a = pkg.beam_trig(ang)
+    tr = po.ScanData(rng, ang, trig_mode=po.TRIG_CACHED, a_min=0.0, a_delta=1.0, tab_sin=sin_a, tab_cos=cos_a)
+    tr.angle = np.arange(len(ang), dtype=np.float64)
+    return tr
+
+
+def test_cfg5_lock_step_through_tile_tables_70_particles(pkg, oracle):
+    """What bench.py's cfg5 leg runs for its likelihood step, against the oracle: MORE than 64 particles with
+    per-particle maps and the default device pose trigonometry match through host-driven lock-step jobs whose K3
+    launches resolve every gather through the particle's tile table (csrc/gmapping.cpp: chains only up to 64).  Cell
+    size 0.025 m, area estimator, blur 0.1 m.  So that every particle reads a DIFFERENT map, each one first takes the
+    scan from its own jittered pose (one batched K6 here; the oracle appends with the device's trigonometry form, so
+    the raw-provider caveat of the cfg5 geometry test cannot arise) -- sampled maps are compared bit for bit on the
+    counters -- and then ONE filter step runs on both sides: poses 1e-10, weights 1e-9, scorer calls and resampling
+    decision exact (gmapping_world.h:73-101)."""
+    import pyoracle as po
+    from pyoracle_mapupdate import (gmapping_enable_particle_maps, gmapping_particle_map, gmapping_particle_map_append)
+    from synth import make_scene
+    win, scale, n = 1280, 0.025, 70
+    sc = make_scene(cell_model=2, size=win, scale=scale, n_beams=1080, seed=9, blur_m=0.1, max_dist=12.0)
+    m, scan = sc["map"], sc["scan"]
+    ctx = pkg.Context(0)
+    ctx.map_bind(2, 2, win, win, m.origin, scale, m.unknown)
+    ctx.map_upload_window(2, 0, 0, m.payload)
+    gp = [0.0, 0.05, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+    seeds = np.arange(4000, 4000 + n, dtype=np.uint32)
+    shift = 0.01 * scale
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp, pose_trig=0), n, seeds)
+    ext = (win + 127) // 128 + 1
+    pf.enable_particle_maps(2, extent_tiles=ext, pool_tiles=ext * ext + n * ext * ext, blur=0.1, estimator=1,
+                            shift_amount=shift)
+    aux = np.zeros((win, win, 2))
+    opf = oracle.gmapping_create(n, gp, seeds)
+    gmapping_enable_particle_maps(oracle, opf, m, aux, blur=0.1, est_kind=1, shift_amount=shift)
+    rs = np.random.RandomState(12)
+    poses0 = sc["true_pose"] + rs.randn(n, 3) * [0.04, 0.04, 0.01]
+    nu = pf.particle_maps_append(np.arange(n), poses0, scan.range, scan.angle)
+    tr = _device_trig_scan(pkg, po, scan.range, scan.angle)
+    onu = sum(gmapping_particle_map_append(oracle, opf, m, i, poses0[i], scan.range, tr.angle, None, trig=tr)
+              for i in range(n))
+    assert nu == onu > n * 1080 * 100
+    ox, oy = m.origin
+    for i in (0, 33, n - 1):
+        got_p, got_a = pf.particle_map(i, -ox, -oy, win, win)
+        want_p, want_a = gmapping_particle_map(oracle, opf, i)
+        np.testing.assert_array_equal(got_a, want_a, err_msg="particle %d" % i)
+        np.testing.assert_allclose(got_p, want_p, rtol=1e-10, atol=1e-13)
+    extra = np.arange(9000, 9000 + n, dtype=np.uint32)
+    res, idx = pf.step(2, scan.range, scan.angle, None, sc["true_pose"], 7)
+    ores, oidx = opf.step(m, scan.range, scan.angle, None, sc["true_pose"], 7, extra)
+    poses, wts, ms = pf.state()
+    oposes, owts, oms = opf.state()
+    assert res == ores
+    if res:
+        np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(ms, oms)
+    np.testing.assert_allclose(poses, oposes, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(wts, owts, rtol=1e-9, atol=0)
+    assert pf.stats()["scorer_calls"] == opf.o.lib.orc_gmapping_scorer_calls(opf.h)
+    assert len(np.unique(np.round(wts, 12))) > n // 2  # the particles really read different maps
+    pf.close()
+    ctx.close()
+
+
+def _cfg5_batch(pkg, sc, poses, particles_per_call, sample, fast, monkeypatch, size=8000):
+    """One particle_maps_append per group of `particles_per_call` particles at cfg5's geometry; returns the number of
+    cell updates and, per sampled particle, (sha256 of its payload window, sha256 of its counters, sum of tries)."""
+    import hashlib
+    m, scan = sc["map"], sc["scan"]
+    win, scale = m.width, m.scale
+    off = (size - win) // 2
+    monkeypatch.setenv("SLAMHIP_K6_FAST", "1" if fast else "0")
+    out, total = {}, 0
+    n = len(poses)
+    for g0 in range(0, n, particles_per_call):
+        grp = np.arange(g0, min(n, g0 + particles_per_call))
+        if particles_per_call < n and not any(int(i) in sample for i in grp):
+            continue  # a group no sampled particle belongs to says nothing in the small-group runs
+        ctx = pkg.Context(0)
+        ctx.map_bind(2, 2, size, size, (m.origin[0] + off, m.origin[1] + off), scale, m.unknown)
+        ctx.map_upload_window(2, off, off, m.payload)
+        k = len(grp)
+        pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), k, np.arange(k, dtype=np.uint32))
+        ext = (size + 127) // 128 + 1
+        reach = int(np.ceil(2.0 * (float(scan.range.max()) + 1.0) / scale / 128.0)) + 2
+        pf.enable_particle_maps(2, extent_tiles=ext, pool_tiles=ext * ext + k * reach * reach, blur=0.1, estimator=1,
+                                shift_amount=0.01 * scale)
+        total += pf.particle_maps_append(np.arange(k), poses[grp], scan.range, scan.angle)
+        ox, oy = m.origin
+        for j, i in enumerate(grp):
+            if int(i) in sample:
+                pay, aux = pf.particle_map(j, -ox, -oy, win, win)
+                out[int(i)] = (hashlib.sha256(pay.tobytes()).hexdigest(), hashlib.sha256(aux.tobytes()).hexdigest(),
+                               float(aux[..., 1].sum()))
+        pf.close()
+        ctx.close()
+    return total, out
+
+
+def test_cfg5_batch_of_500_particles_by_its_properties(pkg, monkeypatch):
+    """BASELINE configs[4] at FULL batch size -- 500 particles, 8000 x 8000 cells of 0.025 m, 1080 beams, area
+    estimator, blur 0.1 m, ONE batched K6 (190 M records) -- where the oracle cannot follow (a dense map per
+    particle).  Size-independent properties instead: (1) a particle's map does not depend on who else is in the batch:
+    sampled particles' maps equal, byte for byte, the maps the same particles get in batches of six (the size
+    test_cfg5_geometry_against_the_oracle pins to the oracle); (2) the free-space fast path (atomics + sorted rest) and
+    the pipeline that sorts every record agree byte for byte at the full batch size; (3) every valid record is
+    exactly one try: a particle's try counters add up to its records."""
+    from synth import make_scene
+    n, win, scale = 500, 3200, 0.025
+    sc = make_scene(cell_model=2, size=win, scale=scale, n_beams=1080, seed=6, blur_m=0.1)
+    rs = np.random.RandomState(17)
+    poses = sc["true_pose"] + rs.randn(n, 3) * [0.05, 0.05, 0.01]
+    sample = {0, 5, 131, 250, 377, 499}
+    total_fast, fast = _cfg5_batch(pkg, sc, poses, n, sample, True, monkeypatch)
+    total_sorted, srt = _cfg5_batch(pkg, sc, poses, n, sample, False, monkeypatch)
+    _, small = _cfg5_batch(pkg, sc, poses, 6, sample, True, monkeypatch)
+    assert total_fast == total_sorted > n * 1080 * 300
+    assert set(fast) == set(srt) == set(small) == sample
+    for i in sorted(sample):
+        assert fast[i][:2] == srt[i][:2], "particle %d: fast path != sorted chains at 500 particles" % i
+        assert fast[i][:2] == small[i][:2], "particle %d: its map depends on the batch it was in" % i
+    assert len({v[1] for v in fast.values()}) == len(sample)  # different poses, different maps
+    tries = np.array([v[2] for v in fast.values()])
+    assert abs(tries.mean() * n - total_fast) < 0.02 * total_fast
