@@ -46,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_UNIT = {"occ": 24, "tbm": 56, "gmapping": 232}  # SURVEY 8d algorithmic bytes / (pose, beam)
 K6_BYTES_PER_RECORD = 64  # per (beam, cell) 2 x 32 B read-modify-write
-ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5", "world"]
+ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5", "world", "replicas"]
 
 WORKLOADS = {
     # name: (cell model, weighting, matcher kind, params, bytes key, description)
@@ -70,7 +70,8 @@ def parse():
     ap.add_argument("--beams", type=int, default=1080)
     ap.add_argument("--sweep-poses", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-procs", type=int, default=16, help="worker processes of the all-cores CPU context lines")
+    ap.add_argument("--cpu-procs", type=int, default=0,
+                    help="worker processes of the all-cores CPU context lines (0 = one per physical core of the host)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--pf-size", type=int, default=4000)
@@ -185,6 +186,50 @@ def sweep_ceiling(pkg, ctx, cfg, sc, scan_n, n_poses, launches, bpu, torch):
     return out
 
 
+N_SCENES = 16
+
+
+def rotating_scenes(sc, n_beams, weighting, n=N_SCENES):
+    """What a robot sees instead of one match repeated: `n` (scan, odometry error) pairs on the scene's map -- robot
+    poses jittered around the mapped one, a fresh N(0, 0.01 m) range-noise seed per scan, initial-pose errors from
+    zero to three times the default (+0.07 m, -0.04 m, +0.03 rad), in a fixed shuffled order.  Deterministic (the
+    CPU baselines' worker processes rebuild the same set)."""
+    from synth import cast_scan, viny_weights
+    m = sc["map"]
+    rs = np.random.RandomState(2024)
+    mags = np.linspace(0.0, 3.0, n)
+    rs.shuffle(mags)
+    out = []
+    for j in range(n):
+        true = sc["true_pose"] + rs.randn(3) * [0.15, 0.15, 0.04]
+        rng, ang = cast_scan(sc["gt"], m.scale, true, n_beams, seed=1000 + j)
+        w = np.full(rng.size, 1.0 / rng.size) if weighting == "even" else viny_weights(rng, ang)
+        out.append(dict(range=rng, angle=ang, weight=w, init_pose=true + mags[j] * np.array([0.07, -0.04, 0.03]),
+                        error_x_default=float(mags[j])))
+    return out
+
+
+def physical_cores():
+    """(physical cores, logical cores) of this host from /proc/cpuinfo."""
+    logical = os.cpu_count() or 1
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen), logical
+    except OSError:
+        pass
+    return logical, logical
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -197,16 +242,34 @@ def cpu_model():
 
 # ------------------------------------------------------------------------------------------- CPU baselines
 def _ref_match_worker(job):
-    """One worker process: the compiled reference's process_scan on the scene, for `seconds`."""
-    sc_args, kind, params, seconds, weighting = job
+    """One worker process: the compiled reference's process_scan over the rotating scenes, for `seconds`.  Map and
+    scenes come from a file the parent wrote (rebuilding the synthetic scene would cost every worker half a minute)."""
+    path, kind, params, seconds, weighting, first = job
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from synth import make_scene
-    sc = make_scene(**sc_args)
-    r = cpu_baseline_reference(sc, kind, params, seconds, weighting)
+    from synth import MapData
+    z = np.load(path)
+    m = MapData(int(z["cell_model"]), z["payload"], z["origin"], float(z["scale"]), z["unknown"])
+    scenes = [dict(range=z["range%d" % k], angle=z["angle%d" % k], weight=z["weight%d" % k], init_pose=z["init%d" % k])
+              for k in range(int(z["n_scenes"]))]
+    r = cpu_baseline_reference({"map": m}, kind, params, seconds, weighting, scenes, first)
     return (r["_units"], r["_seconds"]) if r else None
 
 
-def cpu_baseline_reference(sc, kind, params, seconds, weighting):
+def _save_scene_for_workers(sc, scenes):
+    import tempfile
+    m = sc["map"]
+    d = dict(cell_model=np.array(m.cell_model), payload=m.payload, origin=np.array(m.origin), scale=np.array(m.scale),
+             unknown=m.unknown, n_scenes=np.array(len(scenes)))
+    for k, s_ in enumerate(scenes):
+        d["range%d" % k], d["angle%d" % k], d["weight%d" % k], d["init%d" % k] = (s_["range"], s_["angle"], s_["weight"],
+                                                                                 np.asarray(s_["init_pose"]))
+    f = tempfile.NamedTemporaryFile(prefix="slamhip_bench_scene_", suffix=".npz", delete=False)
+    f.close()
+    np.savez(f.name, **d)
+    return f.name
+
+
+def cpu_baseline_reference(sc, kind, params, seconds, weighting, scenes, first=0):
     """The compiled reference itself (oracle/_ref/libslamref.so = the unmodified reference headers
     built in place; travels to the GPU box prebuilt): the synthetic map is rebuilt as a reference
     UnboundedPlainGridMap (pointer-chasing cells, virtual calls) and the reference's own
@@ -229,23 +292,26 @@ def cpu_baseline_reference(sc, kind, params, seconds, weighting):
     vals = np.ascontiguousarray(pay[iy, ix])
     R.lib.ref_map_update_bulk(rm.h, len(vals), xy.ctypes.data_as(C.POINTER(C.c_int)),
                               vals.ctypes.data_as(C.POINTER(C.c_double)))
-    scan = R.scan_create(sc["scan"].range, sc["scan"].angle)
+    scans = [R.scan_create(s["range"], s["angle"]) for s in scenes]
     spe = R.spe_create(po.OOPE_OBSTACLE, po.OIE_DISCREPANCY, 1 if weighting == "viny" else 0)
     mt = R.matcher_create({"HC": po.SM_HC, "MC": po.SM_MC}[kind], spe, params)
     units, t_used, reps = 0, 0.0, 0
     t_end = time.perf_counter() + seconds
     while True:
+        k = (first + reps) % len(scenes)
         t0 = time.perf_counter()
-        r = R.process_scan(mt, scan, sc["init_pose"], rm, cap=4)
+        r = R.process_scan(mt, scans[k], scenes[k]["init_pose"], rm, cap=4)
         t_used += time.perf_counter() - t0
         units += r["n_calls"] * r["filtered_n"]
         reps += 1
         if time.perf_counter() > t_end or reps >= 2000:
             break
+    phys, logical = physical_cores()
     return {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "reference",
-            "sample": "%d x %s %s process_scan of the compiled reference (oracle/_ref, g++ -O3) on the same "
-                      "scene rebuilt as UnboundedPlainGridMap<AffineQualityMergeCell>, %.1f s; host CPU: %s, "
-                      "%d logical cores visible" % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0),
+            "sample": "%d x %s %s process_scan of the compiled reference (oracle/_ref, g++ -O3) over the same %d rotating "
+                      "(scan, odometry error) pairs on the same map rebuilt as UnboundedPlainGridMap<AffineQualityMergeCell>, "
+                      "%.1f s; host CPU: %s, %d physical / %d logical cores"
+                      % (reps, kind, params, len(scenes), t_used, cpu_model(), phys, logical),
             "_units": units, "_seconds": t_used}
 
 
@@ -256,13 +322,15 @@ def run_workers(fn, jobs):
         return pool.map(fn, jobs)
 
 
-def cpu_baseline(sc, sc_args, kind, params, seconds, weighting, procs):
-    """Single-thread CPU checker on the same scene: whole process_scan calls, bounded to ~seconds; plus, for
-    context, the same on `procs` host cores at once (independent matches, one per process)."""
+def cpu_baseline(sc, sc_args, kind, params, seconds, weighting, procs, scenes):
+    """Single-thread CPU checker on the same rotating scenes: whole process_scan calls, bounded to ~seconds; plus, for
+    context, the same on `procs` host cores at once (independent matches, one per process; 0 = one per PHYSICAL
+    core of this host)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    from synth import Scan
     try:
-        ref = cpu_baseline_reference(sc, kind, params, seconds, weighting)
+        ref = cpu_baseline_reference(sc, kind, params, seconds, weighting, scenes)
     except Exception as e:  # noqa: BLE001  (a missing/foreign prebuilt .so must not kill the bench)
         print("bench.py: reference baseline unavailable (%s); using the port" % e, file=sys.stderr)
         ref = None
@@ -272,16 +340,18 @@ def cpu_baseline(sc, sc_args, kind, params, seconds, weighting, procs):
     units, t_used, reps = 0, 0.0, 0
     e = O.enumerator(okind, params)
     t_end = time.perf_counter() + (min(seconds, 3.0) if ref is not None else seconds)
+    oscans = [Scan(s["range"], s["angle"], s["weight"]) for s in scenes]
     while True:
+        k = reps % len(scenes)
         t0 = time.perf_counter()
-        r = O.process_scan(e, sc["map"], sc["scan"], cfg, sc["init_pose"], cap=8)
+        r = O.process_scan(e, sc["map"], oscans[k], cfg, scenes[k]["init_pose"], cap=8)
         t_used += time.perf_counter() - t0
-        units += r["n_calls"] * sc["scan"].n
+        units += r["n_calls"] * oscans[k].n
         reps += 1
         if time.perf_counter() > t_end or reps >= 2000:
             break
     port = {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "port",
-            "sample": "%d x process_scan (%s %s) on the same scene, %.1f s, oracle/slam_oracle.c -O2, "
+            "sample": "%d x process_scan (%s %s) over the same rotating scenes, %.1f s, oracle/slam_oracle.c -O2, "
                       "flat-array map; host CPU: %s, %d logical cores visible"
                       % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0)}
     if ref is None:
@@ -289,17 +359,26 @@ def cpu_baseline(sc, sc_args, kind, params, seconds, weighting, procs):
     ref.pop("_units", None)
     ref.pop("_seconds", None)
     ref["port_value"] = port["value"]  # the flat-array C restatement, for context
-    procs = max(1, min(procs, os.cpu_count() or 1))
+    phys, logical = physical_cores()
+    procs = phys if procs <= 0 else max(1, min(procs, logical))
     if procs > 1:
         try:
             t0 = time.perf_counter()
             per = min(seconds, 6.0)
-            res = [x for x in run_workers(_ref_match_worker, [(sc_args, kind, params, per, weighting)] * procs) if x]
+            scene_file = _save_scene_for_workers(sc, scenes)
+            try:
+                res = [x for x in run_workers(_ref_match_worker,
+                                              [(scene_file, kind, params, per, weighting, 3 * w) for w in range(procs)]) if x]
+            finally:
+                os.unlink(scene_file)
             if res:
-                ref["all_cores"] = {"value": sum(u / s for u, s in res), "unit": ref["unit"], "cores": len(res),
-                                    "sample": "%d worker processes, each the same reference match loop for %.0f s "
-                                              "(independent scans: the single-hypothesis matcher has no parallel form); "
-                                              "wall %.1f s incl. start-up" % (len(res), per, time.perf_counter() - t0)}
+                ref["all_cores"] = {"value": sum(u / s for u, s in res), "unit": ref["unit"], "cores_used": len(res),
+                                    "physical_cores": phys, "logical_cores": logical,
+                                    "sample": "%d worker processes (one per physical core unless --cpu-procs says "
+                                              "otherwise), each the same reference match loop over the rotating scenes "
+                                              "for %.0f s (independent scans: the single-hypothesis matcher has no "
+                                              "parallel form); wall %.1f s incl. start-up"
+                                              % (len(res), per, time.perf_counter() - t0)}
         except Exception as ex:  # noqa: BLE001
             ref["all_cores"] = {"error": str(ex)}
     return ref
@@ -348,14 +427,17 @@ def pf_cpu_baselines(args, sc, sc_args, seconds):
                "sample": "%d GmappingParticleFilter steps of 8 particles of the compiled reference (oracle/_ref) on "
                          "the %dx%d map, map update inside the step, %.1f s; host CPU: %s"
                          % (r[2], args.pf_size, args.pf_size, r[1], cpu_model())}
-        procs = max(1, min(args.cpu_procs, os.cpu_count() or 1, args.particles))
+        phys, logical = physical_cores()
+        # (each worker builds its own 4000^2 reference map of heap-allocated cells, ~1.3 GB: at most 64 of them)
+        procs = min(phys, args.particles, 64) if args.cpu_procs <= 0 else max(1, min(args.cpu_procs, logical, args.particles))
         if procs > 1:
             t0 = time.perf_counter()
             res = [x for x in run_workers(_ref_pf_worker, [(sc_args, 1, args.pf_size, args.scale, min(seconds, 4.0),
                                                             1000 + k) for k in range(procs)]) if x]
             if res:
                 out["all_cores"] = {
-                    "value": sum(u / s for u, s, _ in res), "unit": "particles/s", "cores": len(res),
+                    "value": sum(u / s for u, s, _ in res), "unit": "particles/s", "cores_used": len(res),
+                    "physical_cores": phys, "logical_cores": logical,
                     "sample": "one particle per worker process (%d processes, each its own reference filter and map: "
                               "the reference itself runs its particles sequentially on one shared map); wall %.1f s "
                               "incl. start-up" % (len(res), time.perf_counter() - t0)}
@@ -717,63 +799,163 @@ def cfg5_leg(args, pkg, ctx, torch):
 
 
 # ------------------------------------------------------------------------------------------------- main
-def world_cpu_baseline(sc, kind, params, scans=30):
-    """The single-hypothesis loop of world_leg on one host core with the CPU restatement (oracle/slam_oracle.c):
-    match, then GridMapScanAdder::append_scan from the matched pose, `scans` times."""
+def world_cpu_baseline(sc, kind, params, scenes, weighting, scans=30):
+    """The single-hypothesis loop of world_leg on one host core with the COMPILED REFERENCE (oracle/_ref/libslamref.so):
+    per scan the reference matcher's process_scan on the reference map, then the reference scan adder's append_scan
+    from the matched pose -- the two calls SingleStateHypothesisLaserScanGridWorld::handle_observation makes
+    (single_state_hypothesis_laser_scan_grid_world.h:52-65) -- over the same rotating scans.  Falls back to the C
+    restatement (kind "port") where the prebuilt reference library is missing."""
+    import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    m0 = sc["map"]
+    if po.ref_available() and m0.cell_model == 0:
+        R = po.Ref()
+        R.lib.ref_map_update_bulk.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        rm = R.map_create(po.REF_CELL_MEAN, po.MAP_UNBOUNDED_PLAIN, m0.width, m0.height, m0.scale)
+        if rm.geometry()["origin"] == tuple(m0.origin):
+            pay = m0.payload[..., 0]
+            iy, ix = np.nonzero(pay != m0.unknown[0])
+            xy = np.ascontiguousarray(np.stack([ix - m0.origin[0], iy - m0.origin[1]], axis=1), dtype=np.int32)
+            vals = np.ascontiguousarray(pay[iy, ix])
+            R.lib.ref_map_update_bulk(rm.h, len(vals), xy.ctypes.data_as(C.POINTER(C.c_int)),
+                                      vals.ctypes.data_as(C.POINTER(C.c_double)))
+            rscans = [R.scan_create(s["range"], s["angle"]) for s in scenes]
+            spe = R.spe_create(po.OOPE_OBSTACLE, po.OIE_DISCREPANCY, 1 if weighting == "viny" else 0)
+            mt = R.matcher_create({"HC": po.SM_HC, "MC": po.SM_MC}[kind], spe, params)
+            t0 = time.perf_counter()
+            for i in range(scans):
+                k = i % len(scenes)
+                r = R.process_scan(mt, rscans[k], scenes[k]["init_pose"], rm, cap=4)
+                R.append_scan(rm, rscans[k], np.asarray(scenes[k]["init_pose"]) + r["delta"])
+            dt = time.perf_counter() - t0
+            return {"value": scans / dt, "unit": "scans/s", "cores": 1, "kind": "reference",
+                    "sample": "%d scans (reference process_scan + reference append_scan on an "
+                              "UnboundedPlainGridMap<MeanProbabilityCell>, oracle/_ref, g++ -O3) over the rotating scenes "
+                              "on one core, %.2f s" % (scans, dt)}
     from pyoracle_mapupdate import RULE_MEAN, append_scan_ex
+    from synth import Scan
     O = po.Oracle()
     e = O.enumerator({"HC": po.SM_HC, "MC": po.SM_MC}[kind], params)
-    m0, scan = sc["map"], sc["scan"]
     m = po.GridMapData(m0.cell_model, m0.payload.copy(), m0.origin, m0.scale, m0.unknown)
     aux = np.zeros(m.payload.shape[:2] + (1,))
+    oscans = [Scan(s["range"], s["angle"], s["weight"]) for s in scenes]
     t0 = time.perf_counter()
-    for _ in range(scans):
-        r = O.process_scan(e, m, scan, po.make_cfg(), sc["init_pose"], cap=8)
-        append_scan_ex(O, m, aux, RULE_MEAN, np.asarray(sc["init_pose"]) + r["delta"], scan.range, scan.angle)
+    for i in range(scans):
+        k = i % len(scenes)
+        r = O.process_scan(e, m, oscans[k], po.make_cfg(), scenes[k]["init_pose"], cap=8)
+        append_scan_ex(O, m, aux, RULE_MEAN, np.asarray(scenes[k]["init_pose"]) + r["delta"], oscans[k].range,
+                       oscans[k].angle)
     dt = time.perf_counter() - t0
     return {"value": scans / dt, "unit": "scans/s", "cores": 1, "kind": "port",
             "sample": "%d scans (match + map update) with oracle/slam_oracle.c on one core, %.2f s" % (scans, dt)}
 
 
-def world_leg(args, pkg, ctx, sc, cfg, kind, params):
+def world_leg(args, pkg, ctx, sc, cfg, kind, params, scenes):
     """One hypothesis, scan after scan, everything through the C-ABI: upload the (filtered) scan, match from the
     odometry pose, append the scan to the map from the matched pose -- SingleStateHypothesisLaserScanGridWorld::
     handle_observation (single_state_hypothesis_laser_scan_grid_world.h:52-65) with the map resident in HBM and its
-    update queued behind the match (slamhip_map_set_deferred), as host/slamhip_resident_world.h runs it.  Parity of
-    this loop against the reference's world: tests/test_gpu_world.py."""
-    scan, m0 = sc["scan"], sc["map"]
-    cos_a, sin_a = pkg.beam_trig(scan.angle)
+    update queued behind the match (slamhip_map_set_deferred), as host/slamhip_resident_world.h runs it -- over the
+    rotating scans (every scan arrives from the host, as a sensor's would).  Parity of this loop against the
+    reference's world: tests/test_gpu_world.py."""
+    m0 = sc["map"]
+    trig = [pkg.beam_trig(s["angle"]) for s in scenes]
     ctx.map_bind(5, m0.cell_model, m0.width, m0.height, m0.origin, m0.scale, m0.unknown)
     ctx.map_upload_window(5, 0, 0, m0.payload)
     ctx.map_set_auto_grow(5, True)
     m = pkg.Matcher(ctx, kind, cfg, params)
     ctx.map_set_deferred(True)
-    init = np.asarray(sc["init_pose"], dtype=np.float64)
+    it = [0]
 
     def one_scan():
-        ctx.scan_upload(scan.range, cos_a, sin_a, scan.weight, scan.factor)
-        r = m.process_scan(5, init)
-        ctx.map_append_scan(5, pkg.RULE_MEAN, init + r["delta"], scan.range, cos_a, sin_a)
+        k = it[0] % len(scenes)
+        it[0] += 1
+        s, (cos_a, sin_a) = scenes[k], trig[k]
+        ctx.scan_upload(s["range"], cos_a, sin_a, s["weight"], None)
+        r = m.process_scan(5, s["init_pose"])
+        ctx.map_append_scan(5, pkg.RULE_MEAN, s["init_pose"] + r["delta"], s["range"], cos_a, sin_a)
 
-    for _ in range(5):
+    for _ in range(len(scenes)):
         one_scan()
     updates = ctx.map_drain()
-    n = max(20, args.steps)
+    n = max(2 * len(scenes), args.steps)
     ctx.synchronize()
+    per = []
     t0 = time.perf_counter()
     for _ in range(n):
+        ts = time.perf_counter()
         one_scan()
+        per.append(1e3 * (time.perf_counter() - ts))
     updates = ctx.map_drain()
     dt = time.perf_counter() - t0
     ctx.map_set_deferred(False)
     m.close()
     ctx.map_release(5)
+    per = np.sort(np.asarray(per))
     return {"metric": "scans/s, one hypothesis: scan upload + match + map update per scan", "value": n / dt,
             "unit": "scans/s", "ms_per_scan": 1e3 * dt / n, "scans": n, "cell_updates_per_scan": updates / n,
+            "ms_per_scan_host_side": {"min": float(per[0]), "median": float(np.median(per)), "max": float(per[-1])},
             "note": "map resident in HBM (MeanProbabilityCell), the update queued behind the match on the context's "
-                    "stream and drained at the end of the timed region; same scan and odometry error every time"}
+                    "stream and drained at the end of the timed region; %d rotating (scan, odometry error) pairs, each "
+                    "scan uploaded from the host inside its step" % len(scenes)}
+
+
+def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16)):
+    """K independent matches per call (slamhip_matcher_process_scan_batch; SURVEY 8e: single-hypothesis matchers
+    replicate, they do not shard): the headline's matcher on K of the rotating scenes at once, all K accept chains
+    advancing in shared launches (grid.y = match).  Scans are resident in HBM (the slots the headline stored); K = 1
+    is the lone-match latency.  Per K: whole-call throughput in the headline's unit (reference-equivalent scorer
+    calls x beams / s), matches/s, ms per call, the chain kernel's roofline over the calls of a second, instrumented
+    pass (HIP events on every dispatch), and the speculation ratio."""
+    out = []
+    n_sc = len(scenes)
+    beams = [s["range"].size for s in scenes]
+    for K in ks:
+        m = pkg.Matcher(ctx, "HC", cfg, params)
+        groups = [[(g * K + j) % n_sc for j in range(K)] for g in range(max(1, n_sc // K) if K <= n_sc else 1)]
+        blocks = [m.make_batch([dict(map_id=0, scan_slot=k, init_pose=scenes[k]["init_pose"]) for k in grp])
+                  for grp in groups]
+        calls_per_block = []
+        for blk in blocks:  # warm-up: every block twice (tree shapes, run-ahead depth)
+            m.process_scan_batch(blk)
+            m.process_scan_batch(blk)
+            calls_per_block.append([m.batch_stats(j) for j in range(K)])
+        n_calls = max(len(blocks), int(np.ceil(max(args.steps, 32) / K)))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        units = evaluated = plain = 0
+        for it in range(n_calls):
+            g = it % len(blocks)
+            m.process_scan_batch(blocks[g])
+            for j, st in enumerate(calls_per_block[g]):
+                units += st["scorer_calls"] * beams[groups[g][j]]
+                plain += st["scorer_calls"]
+                evaluated += st["poses_evaluated"]
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        for it in range(n_calls):
+            m.process_scan_batch(blocks[it % len(blocks)])
+        ctx.synchronize()
+        ctx.profile_enable(False)
+        k_ms, k_launches, k_units = ctx.profile_read(reset=True)
+        achieved = k_units * bpu / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        st = m.stats()
+        on_chain = sum(1 for x in calls_per_block[0] if x["on_device_chain"])
+        out.append({"K": K, "value": units / dt, "unit": "pose-candidates*beams/s", "matches_per_s": n_calls * K / dt,
+                    "ms_per_call": 1e3 * dt / n_calls, "calls": n_calls,
+                    "speculation_ratio": evaluated / max(plain, 1), "kernels_per_call": st["kernels_launched"],
+                    "super_steps_longest_chain": st["launches"], "matches_on_shared_launches": on_chain,
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achieved / HBM_PEAK_GBS, "kernel": "k_hc_chain_step", "bytes_per_unit": bpu,
+                                 "launches": k_launches, "avg_launch_us": 1e3 * k_ms / max(k_launches, 1),
+                                 "kernel_busy_frac": None}})
+        m.close()
+    return {"metric": "pose-candidates*beams/sec, K independent matches per call (slamhip_matcher_process_scan_batch)",
+            "by_K": out,
+            "note": "the same matcher and rotating scenes as the headline; a match of a batch returns the trace of its "
+                    "lone run bit for bit (tests/test_gpu_batch.py)"}
 
 
 def self_launch(args):
@@ -818,6 +1000,7 @@ def main():
                    weighting=weighting)
     sc = make_scene(**sc_args)
     scan = sc["scan"]
+    scenes = rotating_scenes(sc, args.beams, weighting) if args.workload != "sweep" else None
     pf_needed = bool(args.leg_set & {"pf", "pf_update", "pf_maps"})
     pf_sc_args = dict(cell_model=2, size=args.pf_size, scale=args.scale, n_beams=args.beams, seed=4)
     pf_sc = make_scene(**pf_sc_args) if pf_needed else None
@@ -825,13 +1008,13 @@ def main():
     # ---- CPU baselines first: worker processes are started while this process is still GPU-free
     cpu_out, pf_cpu_out = None, None
     if world == 1 and rank == 0 and not args.no_cpu and args.workload != "sweep":
-        cpu_out = cpu_baseline(sc, sc_args, kind, params, args.cpu_seconds, weighting, args.cpu_procs)
+        cpu_out = cpu_baseline(sc, sc_args, kind, params, args.cpu_seconds, weighting, args.cpu_procs, scenes)
         if pf_needed:
             pf_cpu_out = pf_cpu_baselines(args, pf_sc, pf_sc_args, min(args.cpu_seconds, 8.0))
     world_cpu_out = None
     if world == 1 and rank == 0 and not args.no_cpu and args.workload != "sweep" and "world" in args.leg_set:
         try:
-            world_cpu_out = world_cpu_baseline(sc, kind, params)
+            world_cpu_out = world_cpu_baseline(sc, kind, params, scenes, weighting)
         except Exception as e:  # noqa: BLE001
             world_cpu_out = {"error": str(e)}
 
@@ -886,22 +1069,43 @@ def main():
         if args.no_tie_check:
             m.set_tie_check(0)
         on_device = kind in ("HC", "MC") and args.chain != 0 and not args.strict
+        # the rotating scenes live in HBM before the timed region starts (scan slots); a step selects one (a host
+        # pointer swap) and matches it from its own odometry pose
+        for j, s_ in enumerate(scenes):
+            c_, s__ = pkg.beam_trig(s_["angle"])
+            ctx.scan_store(j, s_["range"], c_, s__, s_["weight"])
+        beams_of = [s_["range"].size for s_ in scenes]
+        step_i = [0]
+        evaluated, plain_calls = [0], [0]
 
         def step():
-            m.process_scan(0, sc["init_pose"])
-            return m.stats()["scorer_calls"]
+            k = step_i[0] % len(scenes)
+            step_i[0] += 1
+            ctx.scan_select(k)
+            m.process_scan(0, scenes[k]["init_pose"])
+            st_ = m.stats()
+            evaluated[0] += st_["poses_evaluated"]
+            plain_calls[0] += st_["scorer_calls"]
+            return st_["scorer_calls"] * beams_of[k]
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(max(args.warmup, len(scenes) if scenes else 0)):
+        step()  # (at least one pass over every scene: the chain's run-ahead depth is a running average)
+    if m is not None:
+        step_i[0] = 0
+        evaluated[0] = plain_calls[0] = 0
     # Pass 1 -- the timed region: exactly K steps, no instrumentation.
     ctx.profile_enable(False)
     barrier()
     t0 = time.perf_counter()
     calls = 0
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         calls += step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     dt = time.perf_counter() - t0
+    timed_evaluated, timed_calls = (evaluated[0], plain_calls[0]) if m is not None else (0, 0)
     # Pass 2 -- the same K steps again with a HIP event pair attached to every scoring dispatch
     # (stream = the context's own stream): kernel begin..end per launch, for `roofline`.
     ctx.profile_enable(True)
@@ -919,7 +1123,14 @@ def main():
         st = m.stats()
         if on_device:
             kernel_name = "k_hc_chain_step" if kind == "HC" else "k_mc_chain_step"
-        extra.update(scorer_calls_per_step=st["scorer_calls"], poses_evaluated_per_step=st["poses_evaluated"],
+        sm = np.sort(np.asarray(step_ms))
+        extra.update(scenes="%d rotating (scan, odometry error) pairs resident in HBM: robot poses jittered by N(0, 0.15 m / "
+                            "0.04 rad), a fresh range-noise seed each, pose errors 0..3 x (+0.07 m, -0.04 m, +0.03 rad)"
+                            % len(scenes),
+                     ms_per_match={"min": float(sm[0]), "median": float(np.median(sm)), "max": float(sm[-1])},
+                     scorer_calls_per_step=timed_calls / args.steps,
+                     poses_evaluated_per_step=timed_evaluated / args.steps,
+                     speculation_ratio=timed_evaluated / max(timed_calls, 1),
                      launches_per_step=st["launches"],
                      accept_chain=("on the device: one process_scan = a chain of kernels, each replaying the previous "
                                    "one's speculation tree (csrc/hc_chain.hip, csrc/mc_chain.hip)") if on_device else
@@ -927,7 +1138,7 @@ def main():
                      kernel_busy_frac=k_ms / (1e3 * dt_instrumented) if dt_instrumented > 0 else None,
                      host_us_last_step={k: round(st[k], 1) for k in ("build_us", "stage_us", "score_us", "replay_us")})
 
-    units = float(calls) * scan.n
+    units = float(calls) * scan.n if m is None else float(calls)  # (matcher steps return calls x their scan's beams)
     t_max, units_all = dt, units
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=args.coll_device)
@@ -943,6 +1154,7 @@ def main():
         m.close()
 
     world_out = None  # (the world-loop leg, filled in below; emit_line reads it when the line goes out)
+    replicas_out = None
 
     def emit_line(pf_out, cfg5_out):
         """rank 0's ONE JSON line (the headline is complete before the secondary legs start)"""
@@ -963,7 +1175,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": desc, "beams_after_filter": scan.n,
+            "config": {"workload": desc,
+                       "beams_after_filter": scan.n if scenes is None else float(np.mean([x["range"].size for x in scenes])),
                        "mode": "strict (sequential sum, host trig)" if args.strict else
                                ("beam-order sum, device sincos" if args.seq_sum else
                                 ("default without the tie check (canonical tree sum, device sincos)" if args.no_tie_check else
@@ -996,6 +1209,8 @@ def main():
             out["cfg5"] = cfg5_out
         if world_out is not None:
             out["world_loop"] = world_out
+        if replicas_out is not None:
+            out["replicas"] = replicas_out
         print(json.dumps(out))
 
     # The secondary legs run AFTER the headline is complete.  With more than one rank the particle-filter leg joins
@@ -1032,11 +1247,17 @@ def main():
 
     if "world" in args.leg_set and world == 1 and args.workload != "sweep":
         try:
-            world_out = world_leg(args, pkg, ctx, sc, cfg, kind, params)
+            world_out = world_leg(args, pkg, ctx, sc, cfg, kind, params, scenes)
             if world_cpu_out:
                 world_out["cpu_baseline"] = world_cpu_out
         except pkg.SlamHipError as e:
             world_out = {"error": str(e)}
+
+    if "replicas" in args.leg_set and world == 1 and args.workload == "hc" and not args.strict and not args.seq_sum:
+        try:
+            replicas_out = replicas_leg(args, pkg, ctx, cfg, params, scenes, BYTES_PER_UNIT[bkey])
+        except pkg.SlamHipError as e:
+            replicas_out = {"error": str(e)}
 
     if watchdog is not None:
         watchdog.cancel()

@@ -176,6 +176,14 @@ int slamhip_map_download_aux(slamhip_ctx *ctx, int map_id, int x0, int y0, int w
  * work that is still running there, e.g. a queued map update), ahead of every later score or match. */
 int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const double *cos_a,
                         const double *sin_a, const double *weight, const double *factor);
+/* Scans kept RESIDENT in HBM: store copies a filtered scan (arrays as above) into slot `slot` (0..4095) of the
+ * context, select makes a stored scan the one the following scores and matches read -- a pointer swap on the
+ * host, nothing moves.  For callers that match the same scans repeatedly or several at once
+ * (slamhip_matcher_process_scan_batch takes slots as well); a later slamhip_scan_upload replaces the selection,
+ * not the stored scans. */
+int slamhip_scan_store(slamhip_ctx *ctx, int slot, int n, const double *range, const double *cos_a,
+                       const double *sin_a, const double *weight, const double *factor);
+int slamhip_scan_select(slamhip_ctx *ctx, int slot);
 /* host helpers building cos_a/sin_a: RawTrigonometryProvider (trigonometry_utils.h:17-35) ... */
 int slamhip_beam_trig_raw(int n, const double *angle, double *cos_out, double *sin_out);
 /* ... and CachedTrigonometryProvider::update + index lookup (trigonometry_utils.h:45-78) */
@@ -273,6 +281,33 @@ int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],
                                  double out_delta[3], double *out_prob);
+/* K independent matches in shared launches -- PoseEnumerationScanMatcher::process_scan
+ * (pose_enumeration_scan_matcher.h:31-77) once per robot / replica (the single-hypothesis matchers do not
+ * shard, they replicate): match k = (filtered scan k, initial pose k, map k).  Every match gets the result, the
+ * accept trace and the counters of a lone slamhip_matcher_process_scan on the same inputs, bit for bit; what changes
+ * is how the GPU is used: a lone hill-climbing match is a chain of ~16 dependent kernels of 253 one-pose workgroups
+ * (latency-bound, a quarter of the chip), K of them advance together, one super-step per kernel (grid.y = match,
+ * map and scan from a job table in HBM), with trees sized so that all matches' candidates fill the CUs.  Covers
+ * what the device chain covers (hill climbing, 1-cell OOPE, default mode, OCC or TBM maps of one cell model);
+ * anything else -- and a batch of one -- runs the matches one after another through slamhip_scan_upload +
+ * slamhip_matcher_process_scan (the context's uploaded scan is unspecified after the call).  The matcher's
+ * observer, if set, sees the matches' event sequences one after another, job 0 first, each closed by
+ * on_matching_end.  out_deltas: 3 doubles per job; out_probs: one. */
+typedef struct {
+  int map_id;
+  int scan_slot;                            /* >= 0: the scan stored in that slot (slamhip_scan_store), resident in
+                                             * HBM -- n and the arrays below are ignored; -1: the arrays below */
+  int n;                                    /* beams of the filtered scan, arrays as for slamhip_scan_upload */
+  const double *range, *cos_a, *sin_a, *weight;
+  const double *factor;                     /* may be NULL = all 1.0 */
+  double init_pose[3];
+} slamhip_match_job;
+int slamhip_matcher_process_scan_batch(slamhip_matcher *m, int n_jobs, const slamhip_match_job *jobs,
+                                       double *out_deltas, double *out_probs);
+/* counters of job `job` of the last batch (slamhip_matcher_stats gives the sums; its `launches` the longest
+ * chain's super-steps); on_device_chain: 1 when the match ran in the shared launches */
+int slamhip_matcher_batch_stats(slamhip_matcher *m, int job, long long *scorer_calls, long long *poses_evaluated,
+                                long long *super_steps, int *on_device_chain);
 /* counters of the last process_scan: scorer calls the reference would have made
  * (= on_scan_test events), poses actually evaluated on the GPU, launches */
 int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long *poses_evaluated,

@@ -47,7 +47,7 @@ slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps slamhip_gmappi
 slamhip_shard_unique_id slamhip_shard_init slamhip_shard_destroy slamhip_shard_info slamhip_shard_allgather
 slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begin slamhip_gmapping_carry_record
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
-slamhip_gmapping_step_sharded""".split()
+slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select""".split()
 
 SHARD_ID_BYTES = 128
 
@@ -57,6 +57,12 @@ _ip = C.POINTER(C.c_int)
 
 class SlamHipError(RuntimeError):
     pass
+
+
+class MatchJob(C.Structure):
+    """slamhip_match_job: one match of slamhip_matcher_process_scan_batch."""
+    _fields_ = [("map_id", C.c_int), ("scan_slot", C.c_int), ("n", C.c_int), ("range", _dp), ("cos_a", _dp), ("sin_a", _dp),
+                ("weight", _dp), ("factor", _dp), ("init_pose", C.c_double * 3)]
 
 
 class CarryRecord(C.Structure):
@@ -159,6 +165,8 @@ def load():
     L.slamhip_map_set_deferred.argtypes = [vp, i]
     L.slamhip_map_drain.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.slamhip_scan_upload.argtypes = [vp, i, _dp, _dp, _dp, _dp, _dp]
+    L.slamhip_scan_store.argtypes = [vp, i, i, _dp, _dp, _dp, _dp, _dp]
+    L.slamhip_scan_select.argtypes = [vp, i]
     L.slamhip_map_append_scan.argtypes = [vp, i, C.POINTER(ScanAdderCfg), _dp, i, _dp, _dp, _dp, _ip,
                                           C.POINTER(C.c_longlong)]
     L.slamhip_map_download_aux.argtypes = [vp, i, i, i, i, i, _dp]
@@ -214,6 +222,8 @@ def load():
     L.slamhip_gmapping_particle_map_export.argtypes = [vp, i, vp, C.c_size_t]
     L.slamhip_gmapping_import_maps.argtypes = [vp, vp, up, i, _ip, C.POINTER(vp)]
     L.slamhip_gmapping_particle_maps_append.argtypes = [vp, i, _ip, _dp, i, _dp, _dp, _ip, ll]
+    L.slamhip_matcher_process_scan_batch.argtypes = [vp, i, C.POINTER(MatchJob), _dp, _dp]
+    L.slamhip_matcher_batch_stats.argtypes = [vp, i, ll, ll, ll, _ip]
     L.slamhip_shard_unique_id.argtypes = [vp]
     L.slamhip_shard_init.argtypes = [vp, i, i, vp]
     L.slamhip_shard_destroy.argtypes = [vp]
@@ -448,6 +458,17 @@ class Context:
         _check(self.L.slamhip_scan_upload(self.h, rng.size, _d(rng), _d(cos_a), _d(sin_a),
                                           _d(weight), _d(fac)))
 
+    def scan_store(self, slot, rng, cos_a, sin_a, weight, factor=None):
+        """Keeps a filtered scan resident in HBM (slot 0..4095); scan_select / match jobs refer to it."""
+        rng, cos_a, sin_a, weight = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(weight)
+        fac = _f64(factor) if factor is not None else np.ones(rng.size)
+        _check(self.L.slamhip_scan_store(self.h, int(slot), rng.size, _d(rng), _d(cos_a), _d(sin_a), _d(weight), _d(fac)))
+
+    def scan_select(self, slot):
+        rc = self.L.slamhip_scan_select(self.h, int(slot))
+        if rc:
+            _check(rc)
+
     # scoring
     def score_poses(self, map_id, cfg, poses):
         poses = _f64(poses).reshape(-1, 3)
@@ -619,6 +640,71 @@ class Matcher:
                        accepted=np.array(rec["accepted"], dtype=np.int32),
                        n_calls=len(rec["scores"]))
         return out
+
+    def make_batch(self, jobs):
+        """Argument block of process_scan_batch, made once for a list of jobs = dicts(map_id, range, cos_a, sin_a,
+        weight[, factor], init_pose): the arrays are kept alive by the returned object."""
+        arr = (MatchJob * len(jobs))()
+        keep = []
+        for k, j in enumerate(jobs):
+            for q in range(3):
+                arr[k].init_pose[q] = float(j["init_pose"][q])
+            arr[k].map_id = int(j["map_id"])
+            if j.get("scan_slot") is not None:  # a scan stored in HBM (Context.scan_store)
+                arr[k].scan_slot = int(j["scan_slot"])
+                continue
+            arr[k].scan_slot = -1
+            r, c, s_, w = _f64(j["range"]), _f64(j["cos_a"]), _f64(j["sin_a"]), _f64(j["weight"])
+            f = _f64(j["factor"]) if j.get("factor") is not None else None
+            assert r.size == c.size == s_.size == w.size
+            keep += [r, c, s_, w, f]
+            arr[k].n = r.size
+            arr[k].range, arr[k].cos_a, arr[k].sin_a, arr[k].weight = _d(r), _d(c), _d(s_), _d(w)
+            arr[k].factor = _d(f) if f is not None else None
+        return dict(arr=arr, keep=keep, n=len(jobs), deltas=np.zeros((len(jobs), 3)), probs=np.zeros(len(jobs)))
+
+    def process_scan_batch(self, jobs, trace=False):
+        """K independent matches in shared launches (slamhip_matcher_process_scan_batch).  jobs: a list of dicts (see
+        make_batch) or a block make_batch returned.  Returns a list of dicts like process_scan's, one per job."""
+        blk = jobs if isinstance(jobs, dict) and "arr" in jobs else self.make_batch(jobs)
+        recs = None
+        if trace:
+            recs = [dict(poses=[], scores=[], accepted=[])]
+
+            def on_test(_u, p, s):
+                recs[-1]["poses"].append((p[0], p[1], p[2]))
+                recs[-1]["scores"].append(s)
+                recs[-1]["accepted"].append(0)
+
+            def on_update(_u, p, s):
+                recs[-1]["accepted"][-1] = 1
+
+            def on_end(_u, d, s):
+                recs.append(dict(poses=[], scores=[], accepted=[]))
+
+            self._obs = Observer(None, OBS_FN(on_test), OBS_FN(on_update), OBS_FN(on_end))
+            _check(self.L.slamhip_matcher_set_observer(self.h, C.byref(self._obs)))
+            self._obs_cleared = False
+        elif not self._obs_cleared:
+            _check(self.L.slamhip_matcher_set_observer(self.h, None))
+            self._obs_cleared = True
+        rc = self.L.slamhip_matcher_process_scan_batch(self.h, blk["n"], blk["arr"], _d(blk["deltas"]), _d(blk["probs"]))
+        if rc:
+            _check(rc)
+        out = []
+        for k in range(blk["n"]):
+            o = dict(prob=float(blk["probs"][k]), delta=blk["deltas"][k].copy())
+            if recs is not None:
+                r = recs[k]
+                o.update(poses=np.array(r["poses"]).reshape(-1, 3), scores=np.array(r["scores"]),
+                         accepted=np.array(r["accepted"], dtype=np.int32), n_calls=len(r["scores"]))
+            out.append(o)
+        return out
+
+    def batch_stats(self, job):
+        a, b, c, d = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_int()
+        _check(self.L.slamhip_matcher_batch_stats(self.h, job, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(scorer_calls=a.value, poses_evaluated=b.value, super_steps=c.value, on_device_chain=bool(d.value))
 
     def stats(self):
         (a, b, c, kl, rs), t = self._st_ll, self._st_d

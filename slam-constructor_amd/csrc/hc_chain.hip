@@ -70,9 +70,11 @@ __device__ __forceinline__ double hc_gm_fix(double score, HcCarry &cr, const GmP
 
 // MODEL: SLAMHIP_CELL_OCC / _TBM = the 1-cell OOPE (k_score_point's arithmetic), SLAMHIP_CELL_GMAPPING = the
 // GMapping OOPE (K3's one-pose body, KB = ceil(beams / 256))
-template <int MODEL, int NT, bool SEQ, int KB>
+// BATCH: grid.y independent matches, each with its own map and scan (HcChainArgs::jobs)
+template <int MODEL, int NT, bool SEQ, int KB, bool BATCH>
 __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   constexpr bool GM = MODEL == SLAMHIP_CELL_GMAPPING;
+  static_assert(!(BATCH && GM), "the filter's chains share one map view and one scan");
   extern __shared__ double s_term[];            // point OOPE: one term per beam; GMapping: K3's arrays
   __shared__ GmPoseInfo s_info[GM ? kHcSlots : 1];  // side outputs of the previous tree's poses
   __shared__ unsigned s_hash[GM ? 1 : kHcSlots + 7];  // term-vector fingerprints of the previous tree's poses
@@ -92,21 +94,33 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   const int slot = blockIdx.x + 1 == gridDim.x ? kHcSlots - 1 : (int)blockIdx.x;
   HcChainCtl *ctl = a.ctl + blockIdx.y;  // (one chain per grid row)
   HcHostOut *host = a.host + blockIdx.y;
+  // this chain's map and scan: kernel arguments, or -- a batch of matches -- its entry of the job table (a uniform
+  // address read before any store of the kernel: scalar loads, in flight with the staging loads below)
+  MapView map;
+  ScanView scan;
+  if (BATCH) {
+    const HcJobView *__restrict__ jv = a.jobs + blockIdx.y;
+    map = jv->map;
+    scan = jv->scan;
+  } else {
+    map = a.map;
+    scan = a.scan;
+  }
   // ---- loads that depend on nothing: issued first, they overlap the replay below (the done test waits
   // for its word only after everything else is in flight)
   const bool stamp = a.stamps && slot == 1 && t == 0 && k < 64;
   if (stamp) a.stamps[8 * k + 0] = wall_clock64();
   const unsigned done_epoch = __hip_atomic_load(&ctl->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int n = a.scan.n;
+  const int n = scan.n;
   const int inst_of_slot = slot / 6, cand = slot - 6 * inst_of_slot;
   const bool init_slot = slot == kHcSlots - 1;
   double br = 0.0, bc = 0.0, bs = 0.0, bw = 0.0, bf = 0.0;
   if (t < n) {
-    br = a.scan.range[t];
-    bc = a.scan.cos_a[t];
-    bs = a.scan.sin_a[t];
-    bw = a.scan.weight[t];
-    bf = a.scan.factor[t];
+    br = scan.range[t];
+    bc = scan.cos_a[t];
+    bs = scan.sin_a[t];
+    bw = scan.weight[t];
+    bf = scan.factor[t];
   }
   if (wave == 1 && lane < kHcShapes && !init_slot) {
     const uint4 *src = reinterpret_cast<const uint4 *>(&a.shapes[lane].inst[inst_of_slot]);
@@ -121,20 +135,20 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   HC_PIN64(a.trace);
   HC_PIN32(a.trace_cap);
   HC_PIN64(a.stamps);
-  HC_PIN64(a.map.payload);
-  HC_PIN32(a.map.width);
-  HC_PIN32(a.map.height);
-  HC_PIN32(a.map.pitch);
-  HC_PIN32(a.map.origin_x);
-  HC_PIN32(a.map.origin_y);
-  HC_PINF(a.map.scale);
-  HC_PINF(a.map.inv_scale);
-  HC_PINF(a.map.unknown[0]);
-  HC_PINF(a.map.unknown[1]);
-  HC_PINF(a.map.unknown[2]);
-  HC_PINF(a.map.unknown[3]);
+  HC_PIN64(map.payload);
+  HC_PIN32(map.width);
+  HC_PIN32(map.height);
+  HC_PIN32(map.pitch);
+  HC_PIN32(map.origin_x);
+  HC_PIN32(map.origin_y);
+  HC_PINF(map.scale);
+  HC_PINF(map.inv_scale);
+  HC_PINF(map.unknown[0]);
+  HC_PINF(map.unknown[1]);
+  HC_PINF(map.unknown[2]);
+  HC_PINF(map.unknown[3]);
   HC_PIN32(a.oie);
-  HC_PINF(a.scan.tot_w);
+  HC_PINF(scan.tot_w);
   const int pb = (k - 1) & 1;
   if (k > 0) {
     // what the previous tree left behind: the slots of the largest shape's instances, and the bookkeeping slot
@@ -165,11 +179,11 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     }
   }
   if (GM && t == 64) {
-    s_unknown[0] = a.map.unknown[0];
-    s_unknown[1] = a.map.unknown[1];
-    s_unknown[2] = a.map.unknown[2];
+    s_unknown[0] = map.unknown[0];
+    s_unknown[1] = map.unknown[1];
+    s_unknown[2] = map.unknown[2];
   }
-  if (GM && t == 65) s_run0_len = a.scan.n;
+  if (GM && t == 65) s_run0_len = scan.n;
   if (done_epoch == a.epoch) return;  // launched past the end of the chain (uniform: before any barrier)
   __syncthreads();
   if (stamp) a.stamps[8 * k + 1] = wall_clock64();
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
           ctl->first_info = s_info[kHcSlots - 1];
           ctl->first_raw = s_sc[kHcSlots - 1];
         }
-        root_prob = hc_gm_fix(s_sc[kHcSlots - 1], root_carry, s_info[kHcSlots - 1], a.scan);
+        root_prob = hc_gm_fix(s_sc[kHcSlots - 1], root_carry, s_info[kHcSlots - 1], scan);
       }
       const bool active = lane < n_inst;
       const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          s6[c] = hc_gm_fix(s6[c], cr, s_info[6 * lane + c], a.scan);
+          s6[c] = hc_gm_fix(s6[c], cr, s_info[6 * lane + c], scan);
           s_sc[6 * lane + c] = s6[c];
           if (c == 0) carry_after0 = cr;
         }
@@ -373,10 +387,11 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         // ---- the last workgroup keeps the books (it scores nothing after the first super-step, so the
         // dependent loads and stores below are on no pose's critical path)
         if (a.trace && !dirty) {
+          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_cap;
           const long long base = sp.calls + (sp.first ? 1 : 0);
           if (sp.first && lane == 0 && a.trace_cap > 0) {
             HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};
-            a.trace[0] = e;
+            trace[0] = e;
           }
           if (valid) {
             const HcRound r = hc_round_of(sp, me);
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
               e.accepted = (accmask >> c) & 1u;
               e.pad = 0;
               const long long at = base + 6ll * hc_depth(me) + c;
-              if (at < a.trace_cap) a.trace[at] = e;
+              if (at < a.trace_cap) trace[at] = e;
               else host->error = 2;
             }
           }
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     constexpr int KBG = KB > 0 ? KB : 1;
     double score = 0.0;
     const int *tiles = a.tables ? a.tables + (size_t)a.slots[blockIdx.y] * a.table_stride : nullptr;
-    gm_score_pose_wide<KBG, NT>(a.map, a.scan, a.gm, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_term, &s_run0_len,
+    gm_score_pose_wide<KBG, NT>(map, scan, a.gm, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_term, &s_run0_len,
                                 s_part, &ctl->infos[k & 1][slot], &score);
     if (t == 0) {
       ctl->scores[k & 1][slot] = score;
@@ -495,13 +510,13 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       w_[j] = bw;
       f_[j] = bf;
       if (j > 0 || base != t) {
-        r_ = a.scan.range[bc_];
-        ca = a.scan.cos_a[bc_];
-        sa = a.scan.sin_a[bc_];
-        w_[j] = a.scan.weight[bc_];
-        f_[j] = a.scan.factor[bc_];
+        r_ = scan.range[bc_];
+        ca = scan.cos_a[bc_];
+        sa = scan.sin_a[bc_];
+        w_[j] = scan.weight[bc_];
+        f_[j] = scan.factor[bc_];
       }
-      cell[j] = beam_cell<MODEL>(a.map, px, py, sn, cs, r_, ca, sa);
+      cell[j] = beam_cell<MODEL>(map, px, py, sn, cs, r_, ca, sa);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -529,7 +544,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         acc = acc + t7;
       }
       for (; b < n; ++b) acc = acc + s_term[b];
-      ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : acc / a.scan.tot_w;
+      ctl->scores[k & 1][slot] = (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w;
     }
     return;
   }
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   __syncthreads();
   if (t == 0) {
     const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+    ctl->scores[k & 1][slot] = (scan.tot_w == 0.0) ? __builtin_nan("") : total / scan.tot_w;
     if (verify) {
       ctl->hashes[k & 1][slot] = fold_fingerprint(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]);
     }
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     // re-scored super-step: the reference's own order as well, one running sum over the beams
     double acc = 0.0;
     for (int b = 0; b < n; ++b) acc = acc + s_term[b];
-    ctl->scores_seq[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : acc / a.scan.tot_w;
+    ctl->scores_seq[k & 1][slot] = (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w;
   }
 }
 
@@ -576,12 +591,12 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
 #define HC_LAUNCH(NTV)                                                                                          \
   do {                                                                                                          \
     if (e0 || e1)                                                                                               \
-      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid, n_chains), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
+      hipExtLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB, BATCH>), dim3(grid, n_chains), dim3(NTV), shm, stream, e0, e1, 0, a, k); \
     else                                                                                                        \
-      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB>), dim3(grid, n_chains), dim3(NTV), shm, stream, a, k);     \
+      hipLaunchKernelGGL((k_hc_chain_step<MODEL, NTV, SEQ, KB, BATCH>), dim3(grid, n_chains), dim3(NTV), shm, stream, a, k);     \
   } while (0)
 
-template <int MODEL, bool SEQ>
+template <int MODEL, bool SEQ, bool BATCH>
 static hipError_t launch_nt(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                             int n_chains) {
   constexpr int KB = 0;
@@ -601,7 +616,7 @@ template <int KB>
 static hipError_t launch_gm(const HcChainArgs &a, int k, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                             int n_chains) {
   constexpr int MODEL = SLAMHIP_CELL_GMAPPING;
-  constexpr bool SEQ = false;
+  constexpr bool SEQ = false, BATCH = false;
   const int grid = 6 * a.max_inst + 1;
   const size_t shm = (size_t)KB * 256 * sizeof(double) + 4 * KB * sizeof(int2) + 4 * KB * sizeof(int) +
                      2 * (size_t)KB * 256 * sizeof(int);
@@ -625,12 +640,18 @@ hipError_t launch_chain_marker(const unsigned *n_done, unsigned *h_done_count, u
 
 hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
                                 hipEvent_t e0, hipEvent_t e1, int n_chains) {
+  if (a.jobs) {  // a batch of independent matches: the default (canonical-sum) mode of the 1-cell OOPE
+    if (a.seq) return hipErrorInvalidValue;
+    if (cell_model == SLAMHIP_CELL_OCC) return launch_nt<SLAMHIP_CELL_OCC, false, true>(a, k, nt, stream, e0, e1, n_chains);
+    if (cell_model == SLAMHIP_CELL_TBM) return launch_nt<SLAMHIP_CELL_TBM, false, true>(a, k, nt, stream, e0, e1, n_chains);
+    return hipErrorInvalidValue;
+  }
   if (cell_model == SLAMHIP_CELL_OCC)
-    return a.seq ? launch_nt<SLAMHIP_CELL_OCC, true>(a, k, nt, stream, e0, e1, n_chains)
-                 : launch_nt<SLAMHIP_CELL_OCC, false>(a, k, nt, stream, e0, e1, n_chains);
+    return a.seq ? launch_nt<SLAMHIP_CELL_OCC, true, false>(a, k, nt, stream, e0, e1, n_chains)
+                 : launch_nt<SLAMHIP_CELL_OCC, false, false>(a, k, nt, stream, e0, e1, n_chains);
   if (cell_model == SLAMHIP_CELL_TBM)
-    return a.seq ? launch_nt<SLAMHIP_CELL_TBM, true>(a, k, nt, stream, e0, e1, n_chains)
-                 : launch_nt<SLAMHIP_CELL_TBM, false>(a, k, nt, stream, e0, e1, n_chains);
+    return a.seq ? launch_nt<SLAMHIP_CELL_TBM, true, false>(a, k, nt, stream, e0, e1, n_chains)
+                 : launch_nt<SLAMHIP_CELL_TBM, false, false>(a, k, nt, stream, e0, e1, n_chains);
   if (cell_model == SLAMHIP_CELL_GMAPPING && !a.seq) {
     switch ((a.scan.n + 255) / 256) {
       case 1: return launch_gm<1>(a, k, nt, stream, e0, e1, n_chains);

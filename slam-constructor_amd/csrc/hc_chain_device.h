@@ -43,9 +43,19 @@ struct HcChainCtl {
   double first_raw;
 };
 
+// one match of a BATCH of independent matches (slamhip_matcher_process_scan_batch): its own map and its own scan
+struct HcJobView {
+  MapView map;
+  ScanView scan;
+};
+
 struct HcChainArgs {
   MapView map;
   ScanView scan;
+  // Independent matches in shared launches (grid.y = match; PoseEnumerationScanMatcher::process_scan once per robot,
+  // pose_enumeration_scan_matcher.h:31-77): chain c reads map and scan from jobs[c] instead of the two views above
+  // (scan.n above is then the largest beam count of the batch: the launch's LDS size).  null: one map, one scan.
+  const HcJobView *jobs;
   int oie;
   GmParams gm;                 // GMapping OOPE (cell model GMAPPING): threshold and window
   int gm_cx, gm_cy;            // ... and the cache entry the match starts from (-1 = empty)
@@ -74,7 +84,7 @@ struct HcChainArgs {
   int shape0;
   unsigned epoch;
   HcHostOut *host;
-  HcTraceEntry *trace;  // pinned; null = no observer
+  HcTraceEntry *trace;  // pinned; null = no observer.  Chain c writes at trace + c * trace_cap.
   int trace_cap;
   long long *stamps;    // debugging: 8 wall-clock stamps (100 MHz) per super-step of workgroup 1, or null
 };

@@ -42,6 +42,7 @@ struct slamhip_matcher {
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
   int debug_trace_cap = 0;        // testing (slamhip_matcher_debug_trace_cap): pretend the trace buffer is this small
+  struct HcBatch *batch = nullptr;  // slamhip_matcher_process_scan_batch: blocks of the last batch (hc_batch_*)
   // Monte Carlo kept on the device (mc_chain.h)
   bool is_mc = false;
   slamhip::McChainCtl *d_mc = nullptr;
@@ -89,7 +90,9 @@ namespace {
 
 constexpr int kChainNeedsHost = 1;  // internal: positive, never leaves the library
 
+void hc_batch_free(slamhip_matcher *m);
 int chain_release(slamhip_matcher *m) {
+  hc_batch_free(m);
   if (m->d_chain) hipFree(m->d_chain);
   if (m->d_shapes) hipFree(m->d_shapes);
   if (m->h_chain) hipHostFree(m->h_chain);
@@ -292,6 +295,313 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
     }
     job.t_replay_us = MatchJob::now_us() - t1;
     if (m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, out_delta, *out_prob);
+  }
+  return SLAMHIP_OK;
+}
+
+
+// ---- K independent hill-climbing matches in shared launches ---------------------------------------
+// PoseEnumerationScanMatcher::process_scan once per robot (pose_enumeration_scan_matcher.h:31-77; SURVEY 8e
+// "replicas only"): match c = (scan c, initial pose c, map c).  The chain kernel takes the match from grid.y and
+// its map / scan from a job table in HBM; everything else -- control block, replay, trace -- is per chain already
+// (the filter's one-chain-per-particle launches, gm_multi_chain_run below, are the same mechanism with one map and
+// one scan).  A lone match is latency-bound: 253 one-pose workgroups, one per CU, 15-18 dependent kernels.  K of them
+// fill the chip: the tree of a chain shrinks with K (about kBatchWgs scoring workgroups per super-step over all
+// chains), workgroups get narrower, and several chains' poses are resident per CU.
+}  // namespace
+struct BatchJobResult {
+  double pose[3] = {0, 0, 0}, prob = 0;
+  long long calls = 0, evaluated = 0, rescored = 0;
+  int steps = 0, error = 0;
+  bool on_chain = false;
+};
+struct HcBatch {
+  int cap = 0;
+  slamhip::HcChainCtl *d_ctl = nullptr;
+  slamhip::HcHostOut *h_out = nullptr;     // pinned, one per chain
+  slamhip::HcJobView *h_jobs = nullptr, *d_jobs = nullptr;  // pinned staging / HBM
+  double *h_inits = nullptr, *d_inits = nullptr;
+  double *h_scan = nullptr, *d_scan = nullptr;  // the batch's scans: per match five arrays of its beam count
+  size_t scan_cap = 0;                     // doubles
+  slamhip::HcShape *d_shapes = nullptr;
+  int built_inst = 0, max_inst = 1, nt = 256;
+  int shape_n_inst[slamhip::kHcShapes] = {0};
+  unsigned *d_n_done = nullptr, *h_done_count = nullptr;
+  slamhip::HcTraceEntry *h_trace = nullptr;  // pinned: cap x trace_per entries (observer attached only)
+  int trace_per = 0, trace_chains = 0;
+  unsigned epoch = 0;
+  double steps_avg = 16.0;
+  long long kernels = 0;
+  std::vector<BatchJobResult> res;
+};
+namespace {
+
+void hc_batch_free(slamhip_matcher *m) {
+  HcBatch *b = m->batch;
+  if (!b) return;
+  if (b->d_ctl) hipFree(b->d_ctl);
+  if (b->h_out) hipHostFree(b->h_out);
+  if (b->h_jobs) hipHostFree(b->h_jobs);
+  if (b->d_jobs) hipFree(b->d_jobs);
+  if (b->h_inits) hipHostFree(b->h_inits);
+  if (b->d_inits) hipFree(b->d_inits);
+  if (b->h_scan) hipHostFree(b->h_scan);
+  if (b->d_scan) hipFree(b->d_scan);
+  if (b->d_shapes) hipFree(b->d_shapes);
+  if (b->d_n_done) hipFree(b->d_n_done);
+  if (b->h_done_count) hipHostFree(b->h_done_count);
+  if (b->h_trace) hipHostFree(b->h_trace);
+  delete b;
+  m->batch = nullptr;
+}
+
+// the matcher-level conditions of chain_eligible (the per-scan ones are tested job by job)
+bool batch_chain_eligible(slamhip_matcher *m) {
+  if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
+  if (m->cfg.oope != SLAMHIP_OOPE_OBSTACLE || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  if (m->cfg.sum_order != SLAMHIP_SUM_TREE256) return false;
+  if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
+  if (m->max_batch < 6 * kHcMaxInst) return false;
+  if (m->chain_mode < 0) {
+    const char *e = getenv("SLAMHIP_HC_CHAIN");
+    m->chain_mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  return m->chain_mode == 1;
+}
+
+// scoring workgroups per super-step over all chains of a batch.  Measured on MI355X (cfg2 scenes, G units/s at
+// K = 8): see DESIGN.md section 4a -- larger budgets buy fewer super-steps with more discarded poses.
+constexpr int kBatchWgs = 1024;
+constexpr int kBatchTracePer = 1 << 14;  // trace entries per chain (a longer match is redone by the single path)
+
+int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
+  slamhip_ctx *ctx = m->ctx;
+  const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
+  HcBatch *b = m->batch;
+  if (!b->d_shapes) {
+    SLAMHIP_CHECK(hipMalloc(&b->d_shapes, sizeof(HcShape) * kHcShapes));
+    SLAMHIP_CHECK(hipMalloc(&b->d_n_done, sizeof(unsigned)));
+    SLAMHIP_CHECK(hipHostMalloc(&b->h_done_count, sizeof(unsigned), pinned));
+  }
+  {
+    static const int wgs_env = getenv("SLAMHIP_BATCH_WGS") ? atoi(getenv("SLAMHIP_BATCH_WGS")) : 0;  // (experiments)
+    const int wgs = wgs_env > 0 ? wgs_env : kBatchWgs;
+    const int want = std::min(kHcDefaultInst, std::max(1, wgs / (6 * n)));
+    if (want != b->built_inst) {
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      std::vector<HcShape> shapes(kHcShapes);
+      b->max_inst = 1;
+      for (int s = 0; s < kHcShapes; ++s) {
+        hc_build_shape(hc_bucket_rate(s), 1.0, 0.002, want, &shapes[s]);
+        b->shape_n_inst[s] = shapes[s].n_inst;
+        b->max_inst = std::max(b->max_inst, shapes[s].n_inst);
+      }
+      SLAMHIP_CHECK(hipMemcpy(b->d_shapes, shapes.data(), sizeof(HcShape) * kHcShapes, hipMemcpyHostToDevice));
+      b->built_inst = want;
+    }
+    const int total = n * (6 * b->max_inst + 1);
+    b->nt = total <= 256 ? 1024 : (total <= 512 ? 512 : 256);
+    static const int nt_env = getenv("SLAMHIP_BATCH_NT") ? atoi(getenv("SLAMHIP_BATCH_NT")) : 0;  // (experiments)
+    if (nt_env == 256 || nt_env == 512 || nt_env == 1024) b->nt = nt_env;
+  }
+  if (n > b->cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (b->d_ctl) hipFree(b->d_ctl);
+    if (b->h_out) hipHostFree(b->h_out);
+    if (b->h_jobs) hipHostFree(b->h_jobs);
+    if (b->d_jobs) hipFree(b->d_jobs);
+    if (b->h_inits) hipHostFree(b->h_inits);
+    if (b->d_inits) hipFree(b->d_inits);
+    b->d_ctl = nullptr;
+    b->h_out = nullptr;
+    b->h_jobs = b->d_jobs = nullptr;
+    b->h_inits = b->d_inits = nullptr;
+    int cap = 8;
+    while (cap < n) cap *= 2;
+    SLAMHIP_CHECK(hipMalloc(&b->d_ctl, sizeof(HcChainCtl) * cap));
+    SLAMHIP_CHECK(hipMemset(b->d_ctl, 0, sizeof(HcChainCtl) * cap));
+    SLAMHIP_CHECK(hipHostMalloc(&b->h_out, sizeof(HcHostOut) * cap, pinned));
+    std::memset(b->h_out, 0, sizeof(HcHostOut) * cap);
+    SLAMHIP_CHECK(hipHostMalloc(&b->h_jobs, sizeof(HcJobView) * cap, hipHostMallocDefault));
+    SLAMHIP_CHECK(hipMalloc(&b->d_jobs, sizeof(HcJobView) * cap));
+    SLAMHIP_CHECK(hipHostMalloc(&b->h_inits, sizeof(double) * 3 * cap, hipHostMallocDefault));
+    SLAMHIP_CHECK(hipMalloc(&b->d_inits, sizeof(double) * 3 * cap));
+    b->cap = cap;
+  }
+  if (m->has_obs && b->trace_chains < b->cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (b->h_trace) hipHostFree(b->h_trace);
+    b->h_trace = nullptr;
+    b->trace_per = kBatchTracePer;
+    SLAMHIP_CHECK(hipHostMalloc(&b->h_trace, sizeof(HcTraceEntry) * (size_t)b->trace_per * b->cap, pinned));
+    b->trace_chains = b->cap;
+  }
+  // ---- the batch's scans: stored scans are read where they lie; scans handed over as host arrays go into one
+  // arena with one copy (the staging buffers are free: the previous batch returned after its chains had ended,
+  // i.e. long after its copies)
+  size_t doubles = 0;
+  int max_n = 0;
+  auto beams_of = [&](const slamhip_match_job &j) { return j.scan_slot >= 0 ? ctx->scan_slots[j.scan_slot].n : j.n; };
+  for (int c = 0; c < n; ++c) {
+    if (jobs[c].scan_slot < 0) doubles += 5 * (size_t)((jobs[c].n + 7) & ~7);
+    max_n = std::max(max_n, beams_of(jobs[c]));
+  }
+  if (doubles > b->scan_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (b->h_scan) hipHostFree(b->h_scan);
+    if (b->d_scan) hipFree(b->d_scan);
+    b->h_scan = b->d_scan = nullptr;
+    size_t cap = 1 << 14;
+    while (cap < doubles) cap *= 2;
+    SLAMHIP_CHECK(hipHostMalloc(&b->h_scan, sizeof(double) * cap, hipHostMallocDefault));
+    SLAMHIP_CHECK(hipMalloc(&b->d_scan, sizeof(double) * cap));
+    b->scan_cap = cap;
+  }
+  int cell_model = -1;
+  size_t at = 0;
+  for (int c = 0; c < n; ++c) {
+    const slamhip_match_job &j = jobs[c];
+    DeviceMap *dm = (j.map_id >= 0 && j.map_id < (int)ctx->maps.size() && ctx->maps[j.map_id].bound) ? &ctx->maps[j.map_id] : nullptr;
+    if (!dm) return invalid_arg("unknown map id in a match job");
+    if (dm->cell_model == SLAMHIP_CELL_GMAPPING) return invalid_arg("the batch form covers the 1-cell OOPE (OCC / TBM cells)");
+    if (cell_model >= 0 && dm->cell_model != cell_model) return invalid_arg("the maps of one batch must share a cell model");
+    cell_model = dm->cell_model;
+    HcJobView &v = b->h_jobs[c];
+    v.map.payload = dm->d_payload;
+    v.map.width = dm->width;
+    v.map.height = dm->height;
+    v.map.pitch = dm->pitch;
+    v.map.origin_x = dm->origin_x;
+    v.map.origin_y = dm->origin_y;
+    v.map.scale = dm->scale;
+    v.map.inv_scale = 1.0 / dm->scale;
+    for (int q = 0; q < 4; ++q) v.map.unknown[q] = dm->unknown[q];
+    const double *ds;
+    size_t stride;
+    if (j.scan_slot >= 0) {
+      const slamhip_ctx::ScanSlot &sl = ctx->scan_slots[j.scan_slot];
+      ds = sl.d;
+      stride = (size_t)sl.cap;
+      v.scan.n = sl.n;
+      v.scan.tot_w = sl.tot_w;
+    } else {
+      stride = (size_t)((j.n + 7) & ~7);
+      double *hs = b->h_scan + at;
+      const size_t bytes = sizeof(double) * (size_t)j.n;
+      std::memcpy(hs, j.range, bytes);
+      std::memcpy(hs + stride, j.cos_a, bytes);
+      std::memcpy(hs + 2 * stride, j.sin_a, bytes);
+      std::memcpy(hs + 3 * stride, j.weight, bytes);
+      if (j.factor) std::memcpy(hs + 4 * stride, j.factor, bytes);
+      else for (int i = 0; i < j.n; ++i) hs[4 * stride + i] = 1.0;
+      double tot_w = 0;  // in beam order, pose independent (weighted_mean_point_probability_spe.h:125)
+      for (int i = 0; i < j.n; ++i) tot_w += j.weight[i];
+      ds = b->d_scan + at;
+      v.scan.n = j.n;
+      v.scan.tot_w = tot_w;
+      at += 5 * stride;
+    }
+    v.scan.range = ds;
+    v.scan.cos_a = ds + stride;
+    v.scan.sin_a = ds + 2 * stride;
+    v.scan.weight = ds + 3 * stride;
+    v.scan.factor = ds + 4 * stride;
+    for (int q = 0; q < 3; ++q) b->h_inits[3 * c + q] = j.init_pose[q];
+  }
+  hipStream_t st = ctx->stream;
+  if (at) SLAMHIP_CHECK(hipMemcpyAsync(b->d_scan, b->h_scan, sizeof(double) * at, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(HcJobView) * n, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemcpyAsync(b->d_inits, b->h_inits, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+  SLAMHIP_CHECK(hipMemsetAsync(b->d_n_done, 0, sizeof(unsigned), st));
+  HcChainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.jobs = b->d_jobs;
+  a.scan.n = max_n;  // (the launch's LDS size)
+  a.oie = m->cfg.oie;
+  a.max_inst = b->max_inst;
+  a.gm_cx = a.gm_cy = -1;
+  a.gm_prob = -1.0;
+  a.verify = tie_check_default(m) ? 1 : 0;
+  a.ctl = b->d_ctl;
+  a.inits = b->d_inits;
+  a.n_done = b->d_n_done;
+  a.shapes = b->d_shapes;
+  for (int s = 0; s < kHcShapes; ++s) a.n_inst |= (unsigned long long)(b->shape_n_inst[s] & 0xff) << (8 * s);
+  a.dt0 = m->hc_dt;
+  a.dr0 = m->hc_dr;
+  a.max_failed = m->hc_max_failed;
+  a.shape0 = hc_bucket_of(m->p_accept0);
+  unsigned epoch = ++b->epoch;
+  if (epoch == 0) epoch = ++b->epoch;
+  a.epoch = epoch;
+  a.host = b->h_out;
+  a.trace = m->has_obs ? b->h_trace : nullptr;
+  a.trace_cap = m->has_obs ? b->trace_per : 0;
+  if (m->has_obs && m->debug_trace_cap > 0) a.trace_cap = std::min(a.trace_cap, m->debug_trace_cap);
+  for (int c = 0; c < n; ++c) {
+    ((volatile HcHostOut *)b->h_out)[c].error = 0;
+    ((volatile HcHostOut *)b->h_out)[c].progress = 0;
+  }
+  int launched = 0;
+  auto burst = [&](int count, unsigned *seq_out) -> int {
+    for (int i = 0; i < count; ++i) {
+      hipEvent_t e0, e1;
+      int r = profile_event_pair(ctx, &e0, &e1);
+      if (r) return r;
+      SLAMHIP_CHECK(launch_hc_chain_step(a, cell_model, launched, b->nt, st, e0, e1, n));
+      ++launched;
+    }
+    unsigned seq = ++ctx->seq;
+    if (seq == 0) seq = ++ctx->seq;
+    SLAMHIP_CHECK(launch_chain_marker(b->d_n_done, b->h_done_count, ctx->h_done_flag, seq, st));
+    *seq_out = seq;
+    return SLAMHIP_OK;
+  };
+  unsigned seq_prev = 0, seq_next = 0;
+  int rc = burst(std::max(3, (int)(b->steps_avg * 0.9)), &seq_prev);
+  if (rc) return rc;
+  for (;;) {
+    rc = burst(3, &seq_next);  // queued before the wait: the GPU never runs dry
+    if (rc) return rc;
+    rc = score_wait(ctx, seq_prev);
+    if (rc) return rc;
+    if (*(volatile unsigned *)b->h_done_count >= (unsigned)n) break;
+    if (launched >= (1 << 16)) {
+      set_error("the batch's hill-climbing chains did not end");
+      return SLAMHIP_ERR_STATE;
+    }
+    seq_prev = seq_next;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  int max_steps = 0;
+  long long units = 0;
+  for (int c = 0; c < n; ++c) {
+    const volatile HcHostOut *h = &b->h_out[c];
+    if (h->done_seq != epoch) {
+      set_error("internal: a chain was counted as finished without publishing its result");
+      return SLAMHIP_ERR_STATE;
+    }
+    if (h->error == 1) {
+      set_error("internal: the device replay found no terminal round (hill-climbing chain bug)");
+      return SLAMHIP_ERR_STATE;
+    }
+    BatchJobResult &r = b->res[c];
+    r.error = h->error;
+    r.on_chain = h->error == 0;
+    for (int q = 0; q < 3; ++q) r.pose[q] = h->pose[q];
+    r.prob = h->best_prob;
+    r.calls = h->calls;
+    r.evaluated = h->evaluated;
+    r.rescored = h->rescored;
+    r.steps = h->steps;
+    max_steps = std::max(max_steps, (int)h->steps);
+    units += h->evaluated * (long long)beams_of(jobs[c]);
+  }
+  b->steps_avg = 0.75 * b->steps_avg + 0.25 * (double)max_steps;
+  b->kernels = launched;
+  if (ctx->profile) {
+    ctx->prof_launches += launched;
+    ctx->prof_units += units;
   }
   return SLAMHIP_OK;
 }
@@ -745,7 +1055,7 @@ int slamhip_matcher_create_bf(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, cons
 
 int slamhip_matcher_destroy(slamhip_matcher *m) {
   if (m) {
-    if (m->d_chain) {
+    if (m->d_chain || m->batch) {
       // run-ahead kernels of the last chain may still read the blocks; the context may already be gone
       // (destroying it synchronised its stream), so wait on the device, not on the context's stream
       hipSetDevice(m->device);
@@ -803,6 +1113,90 @@ int slamhip_matcher_debug_stamps(slamhip_matcher *m, long long *out512) {
   }
   SLAMHIP_CHECK(hipDeviceSynchronize());
   if (out512) SLAMHIP_CHECK(hipMemcpy(out512, m->d_stamps, sizeof(long long) * 512, hipMemcpyDeviceToHost));
+  return SLAMHIP_OK;
+}
+
+int slamhip_matcher_process_scan_batch(slamhip_matcher *m, int n_jobs, const slamhip_match_job *jobs,
+                                       double *out_deltas, double *out_probs) {
+  if (!m || n_jobs < 0 || (n_jobs > 0 && (!jobs || !out_deltas || !out_probs))) return invalid_arg("null argument");
+  if (n_jobs == 0) return SLAMHIP_OK;
+  slamhip_ctx *ctx = m->ctx;
+  for (int c = 0; c < n_jobs; ++c) {
+    const slamhip_match_job &j = jobs[c];
+    if (j.scan_slot >= 0) {
+      if (j.scan_slot >= (int)ctx->scan_slots.size() || !ctx->scan_slots[j.scan_slot].d)
+        return invalid_arg("a match job names a scan slot nothing is stored in");
+    } else if (j.n <= 0 || !j.range || !j.cos_a || !j.sin_a || !j.weight) {
+      return invalid_arg("bad scan in a match job");
+    }
+  }
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  if (!m->batch) m->batch = new HcBatch;
+  HcBatch *b = m->batch;
+  b->res.assign(n_jobs, BatchJobResult{});
+  b->kernels = 0;
+  bool chains = n_jobs > 1 && batch_chain_eligible(m);
+  for (int c = 0; c < n_jobs && chains; ++c)
+    chains = (jobs[c].scan_slot >= 0 ? ctx->scan_slots[jobs[c].scan_slot].n : jobs[c].n) <= 4096;
+  if (chains) {
+    const int rc = hc_batch_run(m, n_jobs, jobs);
+    if (rc) return rc;
+  }
+  // results in job order; a match the chains did not settle (a configuration they do not cover, a trace longer
+  // than a chain's buffer) goes through the single-match path: upload its scan, process_scan
+  long long calls = 0, evaluated = 0, steps = 0;
+  for (int c = 0; c < n_jobs; ++c) {
+    BatchJobResult &r = b->res[c];
+    const slamhip_match_job &j = jobs[c];
+    double *dl = out_deltas + 3 * c;
+    if (r.on_chain) {
+      for (int q = 0; q < 3; ++q) dl[q] = r.pose[q] - j.init_pose[q];
+      out_probs[c] = r.prob;
+      if (m->has_obs) {
+        const HcTraceEntry *tr = b->h_trace + (size_t)c * b->trace_per;
+        for (long long i = 0; i < r.calls; ++i) {
+          const HcTraceEntry &e = tr[i];
+          const double p3[3] = {e.x, e.y, e.theta};
+          if (m->obs.on_scan_test) m->obs.on_scan_test(m->obs.user, p3, e.score);
+          if (e.accepted && m->obs.on_pose_update) m->obs.on_pose_update(m->obs.user, p3, e.score);
+        }
+        if (m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, dl, r.prob);
+      }
+    } else {
+      int rc = j.scan_slot >= 0 ? slamhip_scan_select(ctx, j.scan_slot)
+                                : slamhip_scan_upload(ctx, j.n, j.range, j.cos_a, j.sin_a, j.weight, j.factor);
+      if (rc) return rc;
+      rc = slamhip_matcher_process_scan(m, j.map_id, j.init_pose, dl, &out_probs[c]);
+      if (rc) return rc;
+      r.calls = m->job.scorer_calls;
+      r.evaluated = m->job.poses_evaluated;
+      r.steps = (int)m->job.launches;
+      r.rescored = m->chain_rescored;
+      for (int q = 0; q < 3; ++q) r.pose[q] = j.init_pose[q] + dl[q];
+      r.prob = out_probs[c];
+    }
+    calls += r.calls;
+    evaluated += r.evaluated;
+    steps = std::max<long long>(steps, r.steps);
+  }
+  m->job.scorer_calls = calls;
+  m->job.poses_evaluated = evaluated;
+  m->job.launches = steps;
+  m->chain_launched = b->kernels;
+  long long resc = 0;
+  for (const BatchJobResult &r : b->res) resc += r.rescored;
+  m->chain_rescored = resc;
+  return SLAMHIP_OK;
+}
+
+int slamhip_matcher_batch_stats(slamhip_matcher *m, int job, long long *scorer_calls, long long *poses_evaluated,
+                                long long *super_steps, int *on_device_chain) {
+  if (!m || !m->batch || job < 0 || job >= (int)m->batch->res.size()) return invalid_arg("no such job in the last batch");
+  const BatchJobResult &r = m->batch->res[job];
+  if (scorer_calls) *scorer_calls = r.calls;
+  if (poses_evaluated) *poses_evaluated = r.evaluated;
+  if (super_steps) *super_steps = r.steps;
+  if (on_device_chain) *on_device_chain = r.on_chain ? 1 : 0;
   return SLAMHIP_OK;
 }
 

@@ -131,12 +131,12 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
   a->map.scale = m.scale;
   a->map.inv_scale = 1.0 / m.scale;
   for (int k = 0; k < 4; ++k) a->map.unknown[k] = m.unknown[k];
-  const size_t c = ctx->scan_cap;
-  a->scan.range = ctx->d_scan;
-  a->scan.cos_a = ctx->d_scan + c;
-  a->scan.sin_a = ctx->d_scan + 2 * c;
-  a->scan.weight = ctx->d_scan + 3 * c;
-  a->scan.factor = ctx->d_scan + 4 * c;
+  const size_t c = ctx->scan_stride;
+  a->scan.range = ctx->scan_ptr;
+  a->scan.cos_a = ctx->scan_ptr + c;
+  a->scan.sin_a = ctx->scan_ptr + 2 * c;
+  a->scan.weight = ctx->scan_ptr + 3 * c;
+  a->scan.factor = ctx->scan_ptr + 4 * c;
   a->scan.n = ctx->scan_n;
   a->scan.tot_w = ctx->scan_tot_w;
   a->poses = d_poses;
@@ -502,6 +502,8 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
     if (m.d_aux) hipFree(m.d_aux);
   }
   if (ctx->d_scan) hipFree(ctx->d_scan);
+  for (auto &sl : ctx->scan_slots)
+    if (sl.d) hipFree(sl.d);
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_scan_stage[k]) hipHostFree(ctx->h_scan_stage[k]);
     if (ctx->scan_stage_done[k]) hipEventDestroy(ctx->scan_stage_done[k]);
@@ -774,6 +776,8 @@ int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const doub
   for (int i = 0; i < n; ++i) tot_w += weight[i];
   ctx->scan_tot_w = tot_w;
   ctx->scan_n = n;
+  ctx->scan_ptr = ctx->d_scan;
+  ctx->scan_stride = (size_t)ctx->scan_cap;
   const size_t c = ctx->scan_cap, bytes = sizeof(double) * n;
   const int turn = ctx->scan_stage_turn;
   ctx->scan_stage_turn ^= 1;
@@ -788,6 +792,64 @@ int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const doub
   SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan, st, sizeof(double) * (4 * c + n), hipMemcpyHostToDevice, ctx->stream));
   SLAMHIP_CHECK(hipEventRecord(ctx->scan_stage_done[turn], ctx->stream));
   if (ctx->stream_b) SLAMHIP_CHECK(hipStreamWaitEvent(ctx->stream_b, ctx->scan_stage_done[turn], 0));  // the second launch lane
+  return SLAMHIP_OK;
+}
+
+int slamhip_scan_store(slamhip_ctx *ctx, int slot, int n, const double *range, const double *cos_a,
+                       const double *sin_a, const double *weight, const double *factor) {
+  if (!ctx) return invalid("null ctx");
+  if (slot < 0 || slot >= 4096) return invalid("scan slot out of range (0..4095)");
+  if (n <= 0 || !range || !cos_a || !sin_a || !weight) return invalid("bad scan");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  if ((int)ctx->scan_slots.size() <= slot) ctx->scan_slots.resize(slot + 1);
+  slamhip_ctx::ScanSlot &sl = ctx->scan_slots[slot];
+  // work queued on the context may still read the slot (or the scan it is selected as)
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
+  if (n > sl.cap) {
+    const bool selected = ctx->scan_ptr == sl.d && sl.d;
+    if (sl.d) hipFree(sl.d);
+    sl.d = nullptr;
+    sl.cap = 0;
+    const int cap = (n + 7) & ~7;
+    SLAMHIP_CHECK(hipMalloc(&sl.d, sizeof(double) * 5 * cap));
+    sl.cap = cap;
+    if (selected) ctx->scan_ptr = sl.d;
+  }
+  sl.n = n;
+  sl.w.assign(weight, weight + n);
+  if (factor) sl.f.assign(factor, factor + n);
+  else sl.f.assign(n, 1.0);
+  double tot_w = 0;  // in beam order (weighted_mean_point_probability_spe.h:125)
+  for (int i = 0; i < n; ++i) tot_w += weight[i];
+  sl.tot_w = tot_w;
+  const size_t bytes = sizeof(double) * n, c = (size_t)sl.cap;
+  SLAMHIP_CHECK(hipMemcpy(sl.d, range, bytes, hipMemcpyHostToDevice));
+  SLAMHIP_CHECK(hipMemcpy(sl.d + c, cos_a, bytes, hipMemcpyHostToDevice));
+  SLAMHIP_CHECK(hipMemcpy(sl.d + 2 * c, sin_a, bytes, hipMemcpyHostToDevice));
+  SLAMHIP_CHECK(hipMemcpy(sl.d + 3 * c, weight, bytes, hipMemcpyHostToDevice));
+  SLAMHIP_CHECK(hipMemcpy(sl.d + 4 * c, sl.f.data(), bytes, hipMemcpyHostToDevice));
+  if (ctx->scan_ptr == sl.d) {  // the selected scan was rewritten in place
+    ctx->scan_n = n;
+    ctx->scan_tot_w = tot_w;
+    ctx->scan_stride = c;
+    ctx->h_weight = sl.w;
+    ctx->h_factor = sl.f;
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_scan_select(slamhip_ctx *ctx, int slot) {
+  if (!ctx) return invalid("null ctx");
+  if (slot < 0 || slot >= (int)ctx->scan_slots.size() || !ctx->scan_slots[slot].d || ctx->scan_slots[slot].n <= 0)
+    return invalid("no scan stored in that slot");
+  const slamhip_ctx::ScanSlot &sl = ctx->scan_slots[slot];
+  ctx->scan_ptr = sl.d;
+  ctx->scan_stride = (size_t)sl.cap;
+  ctx->scan_n = sl.n;
+  ctx->scan_tot_w = sl.tot_w;
+  ctx->h_weight.assign(sl.w.begin(), sl.w.end());
+  ctx->h_factor.assign(sl.f.begin(), sl.f.end());
   return SLAMHIP_OK;
 }
 

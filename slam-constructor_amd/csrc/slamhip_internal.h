@@ -143,6 +143,16 @@ struct slamhip_ctx {
   int scan_stage_turn = 0;
   int scan_cap = 0, scan_n = 0;
   double scan_tot_w = 0.0;
+  // the scan the kernels read: d_scan after slamhip_scan_upload, a stored scan after slamhip_scan_select
+  const double *scan_ptr = nullptr;
+  size_t scan_stride = 0;
+  struct ScanSlot {  // slamhip_scan_store: a filtered scan kept resident in HBM (five arrays of `cap` doubles)
+    double *d = nullptr;
+    int cap = 0, n = 0;
+    double tot_w = 0.0;
+    std::vector<double> w, f;
+  };
+  std::vector<ScanSlot> scan_slots;
   std::vector<double> h_weight, h_factor;  // host copies for GMapping carry-in fix-ups
   // pose / score staging
   double *d_poses = nullptr, *d_scores = nullptr, *d_pose_sc = nullptr;
