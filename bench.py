@@ -96,15 +96,21 @@ def parse():
                     help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
     ap.add_argument("--chain", type=int, default=-1,
                     help="the HC / MC accept chain on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
-    ap.add_argument("--leg-timeout", type=int, default=240,
+    ap.add_argument("--leg-timeout", type=int, default=480,
                     help="seconds the sharded particle-filter leg may take at N > 1 before the line goes out without it")
+    ap.add_argument("--dry-ranks", type=int, default=0,
+                    help="no GPU: start this many ranks the way --gpus N does (torch.distributed.run child, rendezvous "
+                         "on 127.0.0.1, gloo) and walk the multi-rank control flow of the benchmark on host-only filter "
+                         "shards -- block split, all-gathers, identical resampling, the map-migration plan with dummy "
+                         "maps point to point, barrier + max-over-ranks timing -- checking every rank against an "
+                         "unsharded filter.  So that the first multi-GPU run is not also the first multi-rank run.")
     ap.add_argument("--no-tie-check", action="store_true",
                     help="default mode without the check of comparisons the tree sum cannot settle")
     args = ap.parse_args()
     if args.no_pf or args.workload == "sweep":
         args.legs = "none"
     if args.legs is None:
-        args.leg_set = set(ALL_LEGS) if args.gpus == 1 else {"pf"}
+        args.leg_set = set(ALL_LEGS) if args.gpus == 1 else {"pf", "cfg5"}
     else:
         args.leg_set = set(x for x in args.legs.split(",") if x and x != "none")
         bad = args.leg_set - set(ALL_LEGS)
@@ -448,22 +454,32 @@ def pf_cpu_baselines(args, sc, sc_args, seconds):
 
 # ------------------------------------------------------------------------------------------- particle filter
 def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count, rank, world, scan, deltas,
-                              dist, torch, dev):
-    """Per-particle copy-on-write maps with the particles sharded over the ranks (opt-in:
-    --pf-maps-sharded).  Per step: local lock-step match + batched K6, all-gather of the raw weights,
-    identical resampling plan everywhere; on a resampling the particle records are all-gathered and the
-    maps of particles drawn from another rank travel point to point (sizes first, then the buffers)."""
+                              dist, torch, dev, map_id=1, size=None, tiles_per_particle=None, adder=None, steps=None):
+    """Per-particle copy-on-write maps with the particles sharded over the ranks.  With the context in the library's
+    RCCL group (--backend nccl) one call per scan does everything: slamhip_gmapping_step_sharded matches the shard,
+    all-gathers carry records + weights, plans the resampling identically everywhere and, when a resampling draws a
+    particle from another rank, moves its map itself (headers by all-gather, tile contents by ONE ncclSend/ncclRecv
+    group, device to device).  Under --backend gloo (ranks sharing GPUs: path testing) the same protocol runs over
+    torch.distributed: all-gather of the raw weights, records on resampling, maps point to point through host
+    buffers."""
+    size = size or args.pf_size
+    tiles_per_particle = tiles_per_particle or args.pf_tiles_per_particle
     pfm = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
-    ext = (args.pf_size + 127) // 128 + 1
-    pfm.enable_particle_maps(1, extent_tiles=ext, pool_tiles=ext * ext + 2 * count * args.pf_tiles_per_particle)
+    ext = (size + 127) // 128 + 1
+    pfm.enable_particle_maps(map_id, extent_tiles=ext, pool_tiles=ext * ext + 2 * count * tiles_per_particle, **(adder or {}))
     bounds = np.cumsum(counts)
     owner = lambda j: int(np.searchsorted(bounds, int(j), side="right"))  # noqa: E731  (contiguous blocks)
     moved_bytes = 0
     resamplings = 0
+    in_library = args.backend == "nccl"
 
     def one(k):
         nonlocal moved_bytes, resamplings
-        raw = pfm.predict_match(1, scan.range, scan.angle, None, deltas[k % len(deltas)])
+        if in_library:
+            req, _ = pfm.step_sharded(map_id, scan.range, scan.angle, None, deltas[k % len(deltas)], 7 + k)
+            resamplings += 1 if req else 0
+            return
+        raw = pfm.predict_match(map_id, scan.range, scan.angle, None, deltas[k % len(deltas)])
         req, idx = pfm.plan_resample(gather(raw, torch.float64), 7 + k)
         if not req:
             return
@@ -493,23 +509,76 @@ def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, firs
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    msteps = max(3, args.pf_steps)
+    msteps = steps or max(3, args.pf_steps)
     for k in range(1, 1 + msteps):
         one(k)
     dist.barrier()
     torch.cuda.synchronize()
     dm = time.perf_counter() - t0
+    if in_library:
+        moved_bytes = pfm.migration_stats()["tile_bytes_sent"]
     tt = torch.tensor([dm, float(moved_bytes)], dtype=torch.float64, device=dev)
     mx = tt.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = tt.clone()
     dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     st = pfm.particle_map_stats()
-    return {"value": n * msteps / mx[0].item(), "unit": "particles/s", "ms_per_step": 1e3 * mx[0].item() / msteps,
-            "steps": msteps, "resamplings": resamplings, "map_bytes_moved_between_ranks": sm[1].item(),
-            "tiles_in_use_rank0": st["tiles_in_use"],
-            "note": "particles and their copy-on-write maps sharded over %d ranks; maps migrate point to point "
-                    "on resampling" % world}
+    out = {"value": n * msteps / mx[0].item(), "unit": "particles/s", "ms_per_step": 1e3 * mx[0].item() / msteps,
+           "steps": msteps, "resamplings": resamplings, "map_bytes_moved_between_ranks": sm[1].item(),
+           "tiles_in_use_rank0": st["tiles_in_use"], "ranks": world, "scaling": "strong",
+           "migration": ("inside slamhip_gmapping_step_sharded: headers all-gathered, tile contents in one RCCL "
+                         "send/recv group, device to device" if in_library else
+                         "torch.distributed over gloo: batch_isend_irecv of exported host buffers"),
+           "note": "particles and their copy-on-write maps sharded over %d ranks; maps migrate point to point "
+                   "on resampling" % world}
+    pfm.close()
+    return out
+
+
+def cfg5_sharded_leg(args, pkg, ctx, rank, world, dist, torch):
+    """BASELINE configs[4] in the form BASELINE states it: `--cfg5-particles` particles WITH their own maps sharded over
+    the ranks of one node (8000x8000 @ 0.025 m, area occupancy estimator, blur 0.1 m, map update fused behind the
+    likelihood), every rank its own tile pool, maps migrating over xGMI on resampling -- through the library's one
+    entry point per scan."""
+    from synth import make_scene
+    n, size, scale = args.cfg5_particles, args.cfg5_size, args.cfg5_scale
+    if n < world:
+        return {"skipped": "fewer particles (%d) than ranks (%d)" % (n, world)}
+    win = min(size, 3200)
+    sc = make_scene(cell_model=2, size=win, scale=scale, n_beams=args.beams, seed=6, blur_m=0.1)
+    m, scan = sc["map"], sc["scan"]
+    off = (size - win) // 2
+    ctx.map_bind(2, 2, size, size, (m.origin[0] + off, m.origin[1] + off), scale, m.unknown)
+    ctx.map_upload_window(2, off, off, m.payload)
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    first, count = sum(counts[:rank]), counts[rank]
+    seeds = np.arange(3000, 3000 + n, dtype=np.uint32)[first:first + count]
+    gp = [0.0, args.pf_sigma_xy / 2, 0.0, args.pf_sigma_th, 0.0, 0.0, 0.0, 0.0]
+    rs = np.random.RandomState(8)
+    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.03, 0.03, 0.01] for _ in range(args.cfg5_steps + 4)]
+    reach = int(np.ceil(2.0 * (float(scan.range.max()) + 1.0) / scale / 128.0)) + 2
+    dev = args.coll_device
+
+    def gather(a, dtype):
+        a = np.ascontiguousarray(a)
+        per = a.size // count
+        padded = np.zeros(max(counts) * per, dtype=a.dtype)
+        padded[:a.size] = a.ravel()
+        t = torch.from_numpy(padded).to(dev)
+        out = torch.empty(world * t.numel(), dtype=dtype, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        out = out.cpu().numpy().reshape(world, -1)
+        return np.concatenate([out[r, :counts[r] * per] for r in range(world)])
+
+    out = sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, first, count, rank, world, scan, deltas,
+                                    dist, torch, dev, map_id=2, size=size, tiles_per_particle=reach * reach,
+                                    adder=dict(blur=0.1, estimator=1, shift_amount=0.01 * scale), steps=args.cfg5_steps)
+    out["metric"] = "particles/sec at N=%d" % n
+    out["workload"] = ("cfg5: GMapping %d particles sharded over %d GPUs, %d beams, %dx%d @%.3f m, per-particle "
+                       "copy-on-write maps (a tile pool per rank), area occupancy estimator + blur 0.1 m map update in one "
+                       "batched K6 per rank and step" % (n, world, scan.n, size, size, scale))
+    ctx.map_release(2)
+    return out
 
 
 def k6_roofline(ctx, note, leg=None):
@@ -532,6 +601,17 @@ def k6_roofline(ctx, note, leg=None):
             "bytes_per_unit": K6_BYTES_PER_RECORD, "unit_of_work": "(beam, cell) record", "launches": calls,
             "units_launched": records, "avg_launch_us": 1e3 * ms / calls,
             "timing": "HIP events recorded around each K6 pipeline on the context's stream, " + note}
+
+
+def join_shard_group(args, pkg, ctx, rank, world, dist, torch):
+    """The context joins the library's RCCL group (once): torch.distributed only carries the 128-byte id."""
+    if getattr(args, "_joined", False):
+        return
+    dev = args.coll_device
+    uid = torch.from_numpy(pkg.shard_unique_id() if rank == 0 else np.zeros(pkg.SHARD_ID_BYTES, np.uint8)).to(dev)
+    dist.broadcast(uid, 0)
+    ctx.shard_init(rank, world, uid.cpu().numpy())
+    args._joined = True
 
 
 def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
@@ -576,9 +656,7 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
     # group id to the ranks and the benchmark's own barrier / max-over-ranks
     in_library = world > 1 and args.backend == "nccl"
     if in_library:
-        uid = torch.from_numpy(pkg.shard_unique_id() if rank == 0 else np.zeros(pkg.SHARD_ID_BYTES, np.uint8)).to(dev)
-        dist.broadcast(uid, 0)
-        ctx.shard_init(rank, world, uid.cpu().numpy())
+        join_shard_group(args, pkg, ctx, rank, world, dist, torch)
 
     if "pf" in legs:
         pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
@@ -958,6 +1036,118 @@ def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16)):
                     "lone run bit for bit (tests/test_gpu_batch.py)"}
 
 
+def dry_ranks_main(args):
+    """One rank of `--dry-ranks N` (see the flag's help).  No GPU is touched: the filter shards are created without a
+    context (host-only bookkeeping of the C-ABI: plan_resample / export / import), the scan probabilities are injected,
+    and what the library's migrate_and_import does with tile buffers over RCCL is walked here with dummy per-particle
+    "maps" over gloo send / recv -- same plan rules (csrc/gmapping.cpp: need[r] = sources rank r draws from other
+    ranks, ascending; sends ordered by (destination, source))."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world != args.dry_ranks:
+        print("bench.py: --dry-ranks %d but the launcher started %d rank(s)" % (args.dry_ranks, world), file=sys.stderr)
+        sys.exit(2)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    n = args.particles
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    firsts = [sum(counts[:r]) for r in range(world)]
+    count, first = counts[rank], firsts[rank]
+    bounds = np.cumsum(counts)
+    owner = lambda j: int(np.searchsorted(bounds, int(j), side="right"))  # noqa: E731
+    gp = [0.0, args.pf_sigma_xy, 0.0, args.pf_sigma_th, 0.0, 0.0, 0.0, 0.0]
+    seeds = np.arange(1000, 1000 + n, dtype=np.uint32)
+
+    def gather(a):
+        a = np.ascontiguousarray(a)
+        per = a.size // max(count, 1)
+        padded = np.zeros(max(counts) * per, dtype=a.dtype)
+        padded[:a.size] = a.ravel()
+        t = torch.from_numpy(padded)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return np.concatenate([outs[r].numpy()[:counts[r] * per] for r in range(world)])
+
+    def run(first_, count_, gather_, maps):
+        """`steps` filter steps on the shard [first_, first_ + count_); maps: {global particle: dummy map bytes}"""
+        pf = pkg.GmappingFilter(None, pkg.gmapping_params(gp8=gp), n, seeds[first_:first_ + count_], first=first_, count=count_)
+        log, moved = [], 0
+        for step in range(args.pf_steps):
+            rs = np.random.RandomState(100 + step)
+            probs, poses = rs.rand(n) ** 3 + 1e-3, rs.randn(n, 3)
+            _, w, _ = pf.state()
+            pf.set(poses=poses[first_:first_ + count_], weights=w * probs[first_:first_ + count_])
+            _, raw, _ = pf.state()
+            all_raw = gather_(raw)
+            wn = all_raw / all_raw.sum()
+            need = bool(2.0 / np.sum(wn * wn) < n)
+            idx = None
+            if need:
+                idx = pkg.pf_resample(pkg.pf_normalize(all_raw), 7 + step)
+                pf.import_(gather_(pf.export()), idx)
+                if count_ == n:  # the unsharded checker: maps follow the indices
+                    maps = {i: maps[int(idx[i])] for i in range(n)}
+                else:
+                    needs = [sorted({int(idx[j]) for j in range(firsts[r], firsts[r] + counts[r]) if owner(idx[j]) != r})
+                             for r in range(world)]
+                    ops, recv = [], {}
+                    for r in range(world):  # my sends by (destination, source), my receives by source
+                        if r == rank:
+                            continue
+                        for src in needs[r]:
+                            if owner(src) == rank:
+                                t = torch.from_numpy(np.frombuffer(maps[src], dtype=np.uint8).copy())
+                                ops.append(dist.P2POp(dist.isend, t, r))
+                                moved += t.numel()
+                    for src in needs[rank]:
+                        recv[src] = torch.empty(64, dtype=torch.uint8)
+                        ops.append(dist.P2POp(dist.irecv, recv[src], owner(src)))
+                    if ops:
+                        for wk in dist.batch_isend_irecv(ops):
+                            wk.wait()
+                    new = {}
+                    for j in range(first_, first_ + count_):
+                        src = int(idx[j])
+                        new[j] = maps[src] if owner(src) == rank else recv[src].numpy().tobytes()
+                    maps = new
+            p_, w_, m_ = pf.state()
+            log.append((need, idx, p_, w_, m_, dict(maps)))
+        pf.close()
+        return log, moved
+
+    dummy = lambda j: (np.arange(64, dtype=np.uint8) * 3 + j).astype(np.uint8).tobytes()  # noqa: E731
+    dist.barrier()
+    t0 = time.perf_counter()
+    log, moved = run(first, count, gather, {j: dummy(j) for j in range(first, first + count)})
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = True
+    ref_log, _ = run(0, n, lambda a: np.asarray(a), {j: dummy(j) for j in range(n)})
+    resamplings = 0
+    for (need, idx, p_, w_, m_, maps), (rneed, ridx, rp, rw, rm, rmaps) in zip(log, ref_log):
+        resamplings += int(rneed)
+        ok &= need == rneed and (not need or np.array_equal(idx, ridx))
+        ok &= np.array_equal(p_, rp[first:first + count]) and np.array_equal(w_, rw[first:first + count])
+        ok &= np.array_equal(m_, rm[first:first + count])
+        ok &= all(maps[j] == rmaps[j] for j in range(first, first + count))
+    tt = torch.tensor([dt, float(moved), 0.0 if ok else 1.0], dtype=torch.float64)
+    mx = tt.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = tt.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "ranks": world, "particles": n, "shards": counts, "steps": args.pf_steps,
+                          "resamplings": resamplings, "dummy_map_bytes_moved": sm[1].item(),
+                          "ranks_that_disagree_with_the_unsharded_filter": int(sm[2].item()),
+                          "ok": bool(sm[2].item() == 0 and resamplings > 0), "seconds": mx[0].item(),
+                          "note": "host-only filter shards over gloo, launched like --gpus N; no GPU touched"}))
+    dist.destroy_process_group()
+    sys.exit(0 if sm[2].item() == 0 else 1)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU,
     torch.distributed.run as a CHILD process -- nothing in this process has touched the GPU yet, and it never
@@ -965,14 +1155,15 @@ def self_launch(args):
     import socket
     import subprocess
     import torch
+    nproc = args.dry_ranks if args.dry_ranks > 0 else args.gpus
     have = torch.cuda.device_count()  # counts devices without initialising the GPU
-    if have < args.gpus and args.backend == "nccl":
+    if not args.dry_ranks and have < args.gpus and args.backend == "nccl":
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
@@ -980,6 +1171,11 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.dry_ranks > 0:
+        if "WORLD_SIZE" not in os.environ:
+            sys.exit(self_launch(args))
+        dry_ranks_main(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -1088,8 +1284,12 @@ def main():
             plain_calls[0] += st_["scorer_calls"]
             return st_["scorer_calls"] * beams_of[k]
 
+    barrier()  # (the first torch.cuda.synchronize() initialises torch's own context: not inside the timed region)
     for _ in range(max(args.warmup, len(scenes) if scenes else 0)):
         step()  # (at least one pass over every scene: the chain's run-ahead depth is a running average)
+    barrier()
+    for _ in range(2):
+        step()
     if m is not None:
         step_i[0] = 0
         evaluated[0] = plain_calls[0] = 0
@@ -1105,6 +1305,8 @@ def main():
         step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("BENCH_DUMP_STEPS"):
+        print("step_ms:", " ".join("%.3f" % x for x in step_ms), file=sys.stderr)
     timed_evaluated, timed_calls = (evaluated[0], plain_calls[0]) if m is not None else (0, 0)
     # Pass 2 -- the same K steps again with a HIP event pair attached to every scoring dispatch
     # (stream = the context's own stream): kernel begin..end per launch, for `roofline`.
@@ -1218,7 +1420,7 @@ def main():
     # out), a watchdog prints the headline with the failure noted and ends the process, so the driver still gets
     # its line.
     watchdog = None
-    if world > 1 and pf_needed:
+    if world > 1 and (pf_needed or "cfg5" in args.leg_set):
         import threading
 
         def give_up():
@@ -1244,6 +1446,15 @@ def main():
             cfg5_out = cfg5_leg(args, pkg, ctx, torch)
         except pkg.SlamHipError as e:
             cfg5_out = {"error": str(e)}
+    elif "cfg5" in args.leg_set:
+        try:
+            if args.backend == "nccl":
+                join_shard_group(args, pkg, ctx, rank, world, dist, torch)
+            cfg5_out = cfg5_sharded_leg(args, pkg, ctx, rank, world, dist, torch)
+        except Exception as e:  # noqa: BLE001  (the line must still go out)
+            import traceback
+            traceback.print_exc()
+            cfg5_out = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if "world" in args.leg_set and world == 1 and args.workload != "sweep":
         try:

@@ -460,9 +460,12 @@ int slamhip_gmapping_get(slamhip_gmapping *g, double *poses, double *weights, in
  * with the raw weights the particles will have if no cache hand-over needs repair, and whether one does is read off
  * the records by every rank alike (no flags exchanged).
  *
- * For tests on one GPU an id that starts with "SLAMHIP-LOOPBACK:" joins an IN-PROCESS group instead: its ranks are
- * threads of one process (a context each), the all-gather goes through host memory.  RCCL admits one rank per
- * device; this is how the sharded step is exercised with world > 1 there (tests/test_gpu_shard.py). */
+ * A caller with its own means of moving bytes between the ranks (MPI, shared memory, a test harness that runs the
+ * ranks as threads of one process) joins a group with slamhip_shard_attach instead of slamhip_shard_init and hands in
+ * a slamhip_shard_transport; everything above the transport -- slamhip_shard_allgather's padding,
+ * slamhip_gmapping_step_sharded -- is the same code either way (tests/native/loopback_transport.cpp is such a
+ * transport: it is how the sharded step runs with world > 1 on the one GPU of a test box, RCCL admitting one rank
+ * per device). */
 #define SLAMHIP_SHARD_ID_BYTES 128
 int slamhip_shard_unique_id(void *id_out);
 int slamhip_shard_init(slamhip_ctx *ctx, int rank, int world, const void *id);
@@ -475,6 +478,31 @@ int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *coun
                             void *all_out);
 /* bytes moved through RCCL and collectives issued since slamhip_shard_init */
 int slamhip_shard_stats(slamhip_ctx *ctx, long long *collectives, long long *bytes);
+/* Point to point, all ranks together: this rank sends n_send blocks and receives n_recv.  Buffers are DEVICE memory of
+ * the context's GPU; messages between one pair of ranks are matched in the order they are listed on both sides.  Over
+ * RCCL this is one ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd on the context's stream (xGMI is point to
+ * point: a pair's bytes travel on the link between the two GPUs), awaited before the call returns.  It is what carries a
+ * resampled particle's map to the rank that drew it (particle_filter.h:88-103: `*new_particle = *sampled` copies
+ * the whole world; lazy_tiled_grid_map.h:40-71: tile by tile). */
+typedef struct {
+  int peer;
+  void *buf;
+  size_t bytes;
+} slamhip_shard_msg;
+int slamhip_shard_exchange(slamhip_ctx *ctx, int n_send, const slamhip_shard_msg *send, int n_recv,
+                           const slamhip_shard_msg *recv);
+int slamhip_shard_p2p_stats(slamhip_ctx *ctx, long long *exchanges, long long *bytes_sent);
+/* A transport of the caller's: allgather moves equal blocks of host memory (every rank's block_bytes from send_host
+ * into recv_host, world x block_bytes in rank order), exchange has the contract of slamhip_shard_exchange (device
+ * buffers; the context's stream is idle when it is called), destroy (may be NULL) runs when the context leaves the
+ * group.  Each returns 0 on success.  The table is copied. */
+typedef struct {
+  void *user;
+  int (*allgather)(void *user, const void *send_host, size_t block_bytes, void *recv_host);
+  int (*exchange)(void *user, int n_send, const slamhip_shard_msg *send, int n_recv, const slamhip_shard_msg *recv);
+  void (*destroy)(void *user);
+} slamhip_shard_transport;
+int slamhip_shard_attach(slamhip_ctx *ctx, int rank, int world, const slamhip_shard_transport *t);
 
 /* A step in phases, for callers that bring their own collective: match_begin = odometry, gate, pose noise
  * and the lock-step matching of the local shard; match_finish = poses, weights (and the batched map
@@ -499,12 +527,25 @@ int slamhip_gmapping_carry_fix(slamhip_gmapping *g, const slamhip_carry_record *
                                int *changed);
 int slamhip_gmapping_carry_commit(slamhip_gmapping *g, const slamhip_carry_record *all, int world);
 int slamhip_gmapping_match_finish(slamhip_gmapping *g, double *raw_weights_out);
-/* one scan on a shard, collectives included (needs slamhip_shard_init on the filter's context; a filter
- * with per-particle maps resamples through slamhip_gmapping_import_maps and is not covered here).
- * resampled / idx_out as in slamhip_gmapping_step; idx_out holds n_total indices. */
+/* One scan on a shard, collectives included (the filter's context has joined a group: slamhip_shard_init or
+ * slamhip_shard_attach).  resampled / idx_out as in slamhip_gmapping_step; idx_out holds n_total indices.
+ * Filters with per-particle maps (slamhip_gmapping_enable_particle_maps) are covered: when a resampling draws a
+ * particle that lives on another rank, its map travels inside this call -- every rank reads the same migration plan
+ * off the resampling indices; two small all-gathers carry the sizes and the maps' headers (tile positions, ancestor
+ * ordinals), ONE slamhip_shard_exchange carries the tile contents device to device (RCCL send / recv), then
+ * slamhip_gmapping_import_maps' work is done from the received buffers (particle_filter.h:88-103: the reference's
+ * resampling copies whole worlds; lazy_tiled_grid_map.h:40-71: maps copy tile by tile).
+ * Errors: a rank that fails inside a step says so in the status word of the step's next collective, and EVERY rank
+ * returns from that step with an error (the failing one with its own code, the others with SLAMHIP_ERR_STATE)
+ * instead of waiting for it; a failure behind a step's last collective is announced at the start of the next
+ * step.  A filter whose step was abandoned is usable again (slamhip_gmapping_match_abort does the same for callers
+ * that drive the phases themselves): the particles keep the odometry and pose noise the step had applied. */
 int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
                                   const double *angle, const int *is_occ, const double odom_delta[3],
                                   uint32_t resample_seed, int *resampled, unsigned *idx_out);
+int slamhip_gmapping_match_abort(slamhip_gmapping *g);
+/* maps this shard received from other ranks and tile bytes it sent, since the filter was created */
+int slamhip_gmapping_migration_stats(slamhip_gmapping *g, long long *maps_received, long long *tile_bytes_sent);
 int slamhip_gmapping_stats(slamhip_gmapping *g, long long *scorer_calls, long long *poses_evaluated,
                            long long *launches, long long *carry_reruns);
 

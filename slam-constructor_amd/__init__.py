@@ -47,7 +47,9 @@ slamhip_gmapping_particle_map_export slamhip_gmapping_import_maps slamhip_gmappi
 slamhip_shard_unique_id slamhip_shard_init slamhip_shard_destroy slamhip_shard_info slamhip_shard_allgather
 slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begin slamhip_gmapping_carry_record
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
-slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select""".split()
+slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select
+slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_gmapping_match_abort
+slamhip_gmapping_migration_stats""".split()
 
 SHARD_ID_BYTES = 128
 
@@ -57,6 +59,11 @@ _ip = C.POINTER(C.c_int)
 
 class SlamHipError(RuntimeError):
     pass
+
+
+class ShardMsg(C.Structure):
+    """slamhip_shard_msg"""
+    _fields_ = [("peer", C.c_int), ("buf", C.c_void_p), ("bytes", C.c_size_t)]
 
 
 class MatchJob(C.Structure):
@@ -229,6 +236,11 @@ def load():
     L.slamhip_shard_destroy.argtypes = [vp]
     L.slamhip_shard_info.argtypes = [vp, _ip, _ip]
     L.slamhip_shard_allgather.argtypes = [vp, vp, _ip, i, vp]
+    L.slamhip_shard_attach.argtypes = [vp, i, i, vp]
+    L.slamhip_shard_exchange.argtypes = [vp, i, vp, i, vp]
+    L.slamhip_shard_p2p_stats.argtypes = [vp, ll, ll]
+    L.slamhip_gmapping_match_abort.argtypes = [vp]
+    L.slamhip_gmapping_migration_stats.argtypes = [vp, ll, ll]
     L.slamhip_shard_stats.argtypes = [vp, ll, ll]
     L.slamhip_gmapping_set_shard_chain.argtypes = [vp, i]
     L.slamhip_gmapping_match_begin.argtypes = [vp, i, i, _dp, _dp, _ip, _dp]
@@ -486,6 +498,28 @@ class Context:
         uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
         assert uid.size == SHARD_ID_BYTES
         _check(self.L.slamhip_shard_init(self.h, rank, world, uid.ctypes.data_as(C.c_void_p)))
+
+    def shard_attach(self, transport, rank=None, world=None):
+        """Joins a group over the caller's own transport (a ctypes slamhip_shard_transport); rank / world default to
+        attributes of the same name on the object (tests/loopback.py sets them)."""
+        r = rank if rank is not None else getattr(transport, "_rank")
+        w = world if world is not None else getattr(transport, "_world")
+        _check(self.L.slamhip_shard_attach(self.h, r, w, C.byref(transport)))
+
+    def shard_exchange(self, sends, recvs):
+        """slamhip_shard_exchange: sends / recvs are lists of (peer, device pointer, bytes)."""
+        def arr(msgs):
+            a = (ShardMsg * max(len(msgs), 1))()
+            for k, (peer, ptr, nb) in enumerate(msgs):
+                a[k].peer, a[k].buf, a[k].bytes = int(peer), int(ptr), int(nb)
+            return a
+        sa, ra = arr(sends), arr(recvs)
+        _check(self.L.slamhip_shard_exchange(self.h, len(sends), sa, len(recvs), ra))
+
+    def shard_p2p_stats(self):
+        a, b = C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_shard_p2p_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(exchanges=a.value, bytes_sent=b.value)
 
     def shard_destroy(self):
         _check(self.L.slamhip_shard_destroy(self.h))
@@ -907,6 +941,14 @@ class GmappingFilter:
         poses, w, ms = np.zeros((self.count, 3)), np.zeros(self.count), np.zeros(self.count, np.int32)
         _check(self.L.slamhip_gmapping_get(self.h, _d(poses), _d(w), ms.ctypes.data_as(_ip)))
         return poses, w, ms
+
+    def match_abort(self):
+        _check(self.L.slamhip_gmapping_match_abort(self.h))
+
+    def migration_stats(self):
+        a, b = C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_gmapping_migration_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(maps_received=a.value, tile_bytes_sent=b.value)
 
     def stats(self):
         v = [C.c_longlong() for _ in range(4)]

@@ -31,7 +31,9 @@
 // the next one matches, so the step runs particle after particle (GPU match, then K6 on the same
 // HBM map); that mode cannot be sharded.
 
+#include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "matchers.h"
@@ -133,6 +135,13 @@ struct slamhip_gmapping {
   std::vector<int> act_idx;
   std::vector<MatchJob *> act;
   bool pending = false;      // begin ran, finish did not yet
+  // sharded steps: a failure behind the step's last collective travels in the status word of the next step's first
+  // one, so that every rank leaves that step together instead of waiting for a rank that has given up
+  int deferred_rc = 0;
+  // device staging of the tile contents of migrating maps (slamhip_gmapping_step_sharded with per-particle maps)
+  char *d_mig_send = nullptr, *d_mig_recv = nullptr;
+  size_t mig_send_cap = 0, mig_recv_cap = 0;
+  long long maps_migrated = 0, map_bytes_sent = 0;
   bool chained = false;      // the jobs of this step ran in lock-step (the carry chain can be re-checked)
   bool shard_chain = false;  // sharded step: the first job starts WITHOUT a carry and is checked afterwards
                              // against the predecessor shard's final cache entry (carry_fix)
@@ -307,6 +316,8 @@ int slamhip_gmapping_destroy(slamhip_gmapping *g) {
   if (g && g->sm) slamhip_matcher_destroy(g->sm);
   if (g && g->mc) gm_multi_chain_free(g->mc);
   if (g && g->tp) tile_pool_destroy(g->tp);
+  if (g && g->d_mig_send) hipFree(g->d_mig_send);
+  if (g && g->d_mig_recv) hipFree(g->d_mig_recv);
   delete g;
   return SLAMHIP_OK;
 }
@@ -797,11 +808,10 @@ int slamhip_gmapping_particle_map_export(slamhip_gmapping *g, int particle, void
   return tile_pool_export(g->tp, particle, host_buf, cap);
 }
 
-int slamhip_gmapping_import_maps(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx, int n_remote,
-                                 const int *remote_src, const void *const *remote_bufs) {
-  if (!g || !g->tp) return bad("per-particle maps are not enabled");
-  if (!all_blobs || !idx || n_remote < 0 || (n_remote > 0 && (!remote_src || !remote_bufs))) return bad("null argument");
-  SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
+// remote_bodies == null: remote_bufs[k] is header + body in one host buffer (the C-ABI form); otherwise the headers
+// (host) and the bodies (host or device memory) apart
+static int import_maps_impl(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx, int n_remote,
+                            const int *remote_src, const void *const *remote_bufs, const void *const *remote_bodies) {
   // where every new local particle's map comes from: an old local slot, or one of the exported maps
   std::vector<int> src(g->count);
   for (int l = 0; l < g->count; ++l) {
@@ -819,7 +829,16 @@ int slamhip_gmapping_import_maps(slamhip_gmapping *g, const void *all_blobs, con
   int rc = slamhip_gmapping_import(g, all_blobs, idx);
   g->maps_handled_by_caller = false;
   if (rc) return rc;
-  return tile_pool_assign_mixed(g->tp, src.data(), n_remote, remote_bufs);
+  return remote_bodies ? tile_pool_assign_mixed_split(g->tp, src.data(), n_remote, remote_bufs, remote_bodies)
+                       : tile_pool_assign_mixed(g->tp, src.data(), n_remote, remote_bufs);
+}
+
+int slamhip_gmapping_import_maps(slamhip_gmapping *g, const void *all_blobs, const unsigned *idx, int n_remote,
+                                 const int *remote_src, const void *const *remote_bufs) {
+  if (!g || !g->tp) return bad("per-particle maps are not enabled");
+  if (!all_blobs || !idx || n_remote < 0 || (n_remote > 0 && (!remote_src || !remote_bufs))) return bad("null argument");
+  SLAMHIP_CHECK(hipSetDevice(g->ctx->device));
+  return import_maps_impl(g, all_blobs, idx, n_remote, remote_src, remote_bufs, nullptr);
 }
 
 int slamhip_gmapping_enable_particle_maps(slamhip_gmapping *g, int map_id, const slamhip_scan_adder_cfg *cfg,
@@ -933,12 +952,163 @@ static bool carry_repair_needed(const GmCarry &step_carry, const slamhip_carry_r
   return false;
 }
 
+// leaves a step that cannot go on: the filter is usable again (the particles keep whatever the step had already
+// done to them -- odometry, pose noise -- but no match result is applied)
+static void match_abort(slamhip_gmapping *g) {
+  g->pending = false;
+  g->act.clear();
+  g->act_idx.clear();
+}
+
+int slamhip_gmapping_match_abort(slamhip_gmapping *g) {
+  if (!g) return bad("null filter");
+  match_abort(g);
+  return SLAMHIP_OK;
+}
+
+// Resampling of a sharded filter with per-particle maps, inside the library: `*new_particle = *sampled`
+// (particle_filter.h:92-96) for a particle that lives on another rank means its map travels -- tile by tile, like the
+// copy-on-write copy of lazy_tiled_grid_map.h:40-71, except that the tiles cross xGMI.  Every rank reads the same plan
+// off the resampling indices: which maps leave which rank for which.  Two small all-gathers (sizes, then the maps'
+// headers: tile positions and ancestor ordinals), ONE point-to-point exchange of the tile contents device to device
+// (slamhip_shard_exchange: RCCL send / recv in one group), then the import.
+static int migrate_and_import(slamhip_gmapping *g, int rank, int world, const std::vector<GmParticle> &blobs,
+                              const std::vector<unsigned> &idx) {
+  slamhip_ctx *ctx = g->ctx;
+  std::vector<int> start(world + 1, 0);
+  for (int r = 0; r < world; ++r) start[r + 1] = start[r] + g->shard_counts[r];
+  auto owner = [&](int j) {
+    int r = 0;
+    while (j >= start[r + 1]) ++r;
+    return r;
+  };
+  // need[r]: sources rank r draws from other ranks (ascending, each once); exports[q]: sources rank q sends
+  std::vector<std::vector<int>> need(world), exports(world);
+  for (int r = 0; r < world; ++r) {
+    std::vector<char> seen(g->n_total, 0);
+    for (int j = start[r]; j < start[r + 1]; ++j) {
+      const int src = (int)idx[j];
+      if (owner(src) != r) seen[src] = 1;
+    }
+    for (int j = 0; j < g->n_total; ++j)
+      if (seen[j]) need[r].push_back(j);
+  }
+  {
+    std::vector<char> seen(g->n_total, 0);
+    for (int r = 0; r < world; ++r)
+      for (int j : need[r]) seen[j] = 1;
+    for (int j = 0; j < g->n_total; ++j)
+      if (seen[j]) exports[owner(j)].push_back(j);
+  }
+  size_t n_exports_all = 0;
+  for (int q = 0; q < world; ++q) n_exports_all += exports[q].size();
+  if (n_exports_all == 0)  // every new particle's source is local everywhere
+    return import_maps_impl(g, blobs.data(), idx.data(), 0, nullptr, nullptr, nullptr);
+  // sizes of my exports, then everybody's
+  const std::vector<int> &mine = exports[rank];
+  std::vector<unsigned long long> my_sizes(2 * mine.size());
+  size_t my_header_bytes = 0, my_body_bytes = 0;
+  for (size_t k = 0; k < mine.size(); ++k) {
+    size_t hb = 0, bb = 0;
+    tile_pool_export_sizes(g->tp, mine[k] - g->first, &hb, &bb);
+    my_sizes[2 * k] = hb;
+    my_sizes[2 * k + 1] = bb;
+    my_header_bytes += hb;
+    my_body_bytes += bb;
+  }
+  std::vector<int> cnt(world);
+  for (int q = 0; q < world; ++q) cnt[q] = 2 * (int)exports[q].size();
+  std::vector<unsigned long long> all_sizes(2 * n_exports_all);
+  int rc = slamhip_shard_allgather(ctx, my_sizes.data(), cnt.data(), (int)sizeof(unsigned long long), all_sizes.data());
+  if (rc) return rc;
+  // (rank, export ordinal) -> sizes and the offset of its header in the gathered header blob
+  std::vector<std::vector<size_t>> hb_of(world), bb_of(world), hoff_of(world);
+  size_t hoff = 0, at = 0;
+  std::vector<int> hcnt(world, 0);
+  for (int q = 0; q < world; ++q) {
+    for (size_t k = 0; k < exports[q].size(); ++k, ++at) {
+      hb_of[q].push_back((size_t)all_sizes[2 * at]);
+      bb_of[q].push_back((size_t)all_sizes[2 * at + 1]);
+      hoff_of[q].push_back(hoff);
+      hoff += hb_of[q].back();
+      hcnt[q] += (int)hb_of[q].back();
+    }
+  }
+  // my maps: headers to host memory, tile contents into the device send buffer (queued on the stream)
+  if (my_body_bytes > g->mig_send_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (g->d_mig_send) hipFree(g->d_mig_send);
+    g->d_mig_send = nullptr;
+    g->mig_send_cap = 0;
+    SLAMHIP_CHECK(hipMalloc(&g->d_mig_send, my_body_bytes));
+    g->mig_send_cap = my_body_bytes;
+  }
+  std::vector<char> my_headers(my_header_bytes ? my_header_bytes : 1);
+  std::vector<size_t> send_off(mine.size());
+  {
+    size_t ho = 0, bo = 0;
+    for (size_t k = 0; k < mine.size(); ++k) {
+      send_off[k] = bo;
+      rc = tile_pool_export_split(g->tp, mine[k] - g->first, my_headers.data() + ho, g->d_mig_send + bo, false);
+      if (rc) return rc;
+      ho += (size_t)my_sizes[2 * k];
+      bo += (size_t)my_sizes[2 * k + 1];
+    }
+  }
+  std::vector<char> all_headers(hoff ? hoff : 1);
+  rc = slamhip_shard_allgather(ctx, my_headers.data(), hcnt.data(), 1, all_headers.data());
+  if (rc) return rc;
+  // the exchange: my sends by (destination, source) ascending, my receives by source ascending -- one order per pair
+  auto ordinal = [&](int q, int src) {
+    const std::vector<int> &e = exports[q];
+    return (size_t)(std::lower_bound(e.begin(), e.end(), src) - e.begin());
+  };
+  size_t recv_bytes = 0;
+  std::vector<size_t> recv_off(need[rank].size());
+  for (size_t k = 0; k < need[rank].size(); ++k) {
+    const int src = need[rank][k], q = owner(src);
+    recv_off[k] = recv_bytes;
+    recv_bytes += bb_of[q][ordinal(q, src)];
+  }
+  if (recv_bytes > g->mig_recv_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (g->d_mig_recv) hipFree(g->d_mig_recv);
+    g->d_mig_recv = nullptr;
+    g->mig_recv_cap = 0;
+    SLAMHIP_CHECK(hipMalloc(&g->d_mig_recv, recv_bytes));
+    g->mig_recv_cap = recv_bytes;
+  }
+  std::vector<slamhip_shard_msg> sends, recvs;
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) continue;
+    for (int src : need[r]) {
+      if (owner(src) != rank) continue;
+      const size_t k = ordinal(rank, src);
+      sends.push_back(slamhip_shard_msg{r, g->d_mig_send + send_off[k], (size_t)my_sizes[2 * k + 1]});
+      g->map_bytes_sent += (long long)my_sizes[2 * k + 1];
+    }
+  }
+  for (size_t k = 0; k < need[rank].size(); ++k) {
+    const int src = need[rank][k], q = owner(src);
+    recvs.push_back(slamhip_shard_msg{q, g->d_mig_recv + recv_off[k], bb_of[q][ordinal(q, src)]});
+  }
+  rc = slamhip_shard_exchange(ctx, (int)sends.size(), sends.data(), (int)recvs.size(), recvs.data());
+  if (rc) return rc;
+  g->maps_migrated += (long long)need[rank].size();
+  std::vector<const void *> hdr(need[rank].size()), body(need[rank].size());
+  for (size_t k = 0; k < need[rank].size(); ++k) {
+    const int src = need[rank][k], q = owner(src);
+    hdr[k] = all_headers.data() + hoff_of[q][ordinal(q, src)];
+    body[k] = g->d_mig_recv + recv_off[k];
+  }
+  return import_maps_impl(g, blobs.data(), idx.data(), (int)need[rank].size(), need[rank].data(), hdr.data(), body.data());
+}
+
 int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, const double *range,
                                   const double *angle, const int *is_occ, const double odom_delta[3],
                                   uint32_t resample_seed, int *resampled, unsigned *idx_out) {
   if (!g) return bad("null filter");
   if (!g->ctx) return bad("a sharded step needs a GPU context");
-  if (g->tp) return bad("per-particle maps resample through slamhip_gmapping_import_maps: drive the phases yourself");
   if (g->update) return bad("the shared-map update is sequential over all particles and cannot be sharded");
   int rank = 0, world = 1;
   int rc = slamhip_shard_info(g->ctx, &rank, &world);
@@ -959,11 +1129,13 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
     rc = slamhip_gmapping_set_shard_chain(g, 1);
     if (rc) return rc;
   }
-  rc = slamhip_gmapping_match_begin(g, map_id, n_raw, range, angle, is_occ, odom_delta);
-  if (rc) {
-    g->pending = false;
-    return rc;
-  }
+  // A failure of this rank must not leave the others waiting in a collective: whatever happens locally up to the
+  // step's first all-gather -- and whatever happened behind the last collective of the step before -- travels in a
+  // status word next to the carry record, and EVERY rank abandons the step when any word is set.
+  int local_rc = g->deferred_rc;
+  g->deferred_rc = 0;
+  if (!local_rc) local_rc = slamhip_gmapping_match_begin(g, map_id, n_raw, range, angle, is_occ, odom_delta);
+  const std::string local_msg = local_rc ? std::string(slamhip_last_error()) : std::string();
   // ONE collective in the common case: every shard sends its carry record together with the raw weights its
   // particles will have if no cache hand-over needs repair.  Whether one does is a pure function of the records --
   // shard r re-matches its first job only when the final entry of the nearest matching shard before it (or of
@@ -976,9 +1148,12 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
   bool settled = false;
   {
     slamhip_carry_record mine;
-    rc = slamhip_gmapping_carry_record(g, &mine);
-    if (rc) return rc;
-    constexpr int kRecDoubles = (int)((sizeof(slamhip_carry_record) + 7) / 8);
+    std::memset(&mine, 0, sizeof(mine));
+    if (!local_rc) {
+      local_rc = slamhip_gmapping_carry_record(g, &mine);
+      if (local_rc) std::memset(&mine, 0, sizeof(mine));
+    }
+    constexpr int kRecDoubles = 1 + (int)((sizeof(slamhip_carry_record) + 7) / 8);  // status word first
     std::vector<int> cnt(world);
     int total = 0;
     for (int r = 0; r < world; ++r) {
@@ -986,68 +1161,158 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
       total += cnt[r];
     }
     std::vector<double> blk(cnt[rank], 0.0), gathered(total, 0.0);
-    std::memcpy(blk.data(), &mine, sizeof(mine));
-    provisional_weights(g, blk.data() + kRecDoubles);
+    blk[0] = (double)local_rc;
+    std::memcpy(blk.data() + 1, &mine, sizeof(mine));
+    if (!local_rc) provisional_weights(g, blk.data() + kRecDoubles);
     rc = slamhip_shard_allgather(g->ctx, blk.data(), cnt.data(), (int)sizeof(double), gathered.data());
-    if (rc) return rc;
-    int at = 0, wat = 0;
+    if (rc) {
+      match_abort(g);
+      return rc;
+    }
+    int at = 0, wat = 0, failed_rank = -1;
     for (int r = 0; r < world; ++r) {
-      std::memcpy(&recs[r], gathered.data() + at, sizeof(slamhip_carry_record));
+      if (gathered[at] != 0.0 && failed_rank < 0) failed_rank = r;
+      std::memcpy(&recs[r], gathered.data() + at + 1, sizeof(slamhip_carry_record));
       std::memcpy(all.data() + wat, gathered.data() + at + kRecDoubles, sizeof(double) * g->shard_counts[r]);
       at += cnt[r];
       wat += g->shard_counts[r];
     }
+    if (failed_rank >= 0) {
+      match_abort(g);
+      if (local_rc) {
+        set_error(local_msg);
+        return local_rc;
+      }
+      set_error("rank " + std::to_string(failed_rank) + " of the shard group failed: the step was abandoned on every rank");
+      return SLAMHIP_ERR_STATE;
+    }
     if (!carry_repair_needed(g->step_carry, recs.data(), world)) {
       int changed = 0;
       rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);  // (passes the cache through; no re-match)
-      if (rc) return rc;
-      if (changed) return bad("internal: a shard re-matched although no cache hand-over needed repair");
+      if (!rc && changed) rc = bad("internal: a shard re-matched although no cache hand-over needed repair");
+      if (rc) {  // (no collective follows in this step: the others learn of it at the next one's)
+        match_abort(g);
+        g->deferred_rc = rc;
+        return rc;
+      }
       settled = true;
     }
   }
   if (!settled) {
-    // the shared OOPE cache across shards: exchange, re-check, until no shard changes its final entry
+    // the shared OOPE cache across shards: exchange, re-check, until no shard changes its final entry.  The flag a
+    // rank contributes is 1 when its entry changed, -1 when it failed: then every rank stops.
     for (int round = 0; round <= world; ++round) {
+      int flag = 0;
       if (round > 0) {
         slamhip_carry_record mine;
+        std::memset(&mine, 0, sizeof(mine));
         rc = slamhip_gmapping_carry_record(g, &mine);
-        if (rc) return rc;
+        if (rc) flag = -1;
         rc = slamhip_shard_allgather(g->ctx, &mine, ones.data(), (int)sizeof(mine), recs.data());
-        if (rc) return rc;
+        if (rc) {
+          match_abort(g);
+          return rc;
+        }
       }
       int changed = 0;
-      rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);
-      if (rc) return rc;
-      int any = 0;
+      if (flag == 0) {
+        local_rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);
+        flag = local_rc ? -1 : changed;
+      }
+      const std::string msg = flag < 0 ? std::string(slamhip_last_error()) : std::string();
+      int any = 0, failed_rank = -1;
       std::vector<int> flags(world, 0);
-      rc = slamhip_shard_allgather(g->ctx, &changed, ones.data(), (int)sizeof(int), flags.data());
-      if (rc) return rc;
-      for (int f : flags) any |= f;
+      rc = slamhip_shard_allgather(g->ctx, &flag, ones.data(), (int)sizeof(int), flags.data());
+      if (rc) {
+        match_abort(g);
+        return rc;
+      }
+      for (int r = 0; r < world; ++r) {
+        if (flags[r] < 0 && failed_rank < 0) failed_rank = r;
+        any |= flags[r];
+      }
+      if (failed_rank >= 0) {
+        match_abort(g);
+        if (flag < 0) {
+          set_error(msg);
+          return local_rc ? local_rc : SLAMHIP_ERR_STATE;
+        }
+        set_error("rank " + std::to_string(failed_rank) + " of the shard group failed while repairing the cache hand-over");
+        return SLAMHIP_ERR_STATE;
+      }
       if (!any) break;
     }
   }
   rc = slamhip_gmapping_carry_commit(g, recs.data(), world);
-  if (rc) return rc;
-  rc = slamhip_gmapping_match_finish(g, raw.data());
-  if (rc) return rc;
+  if (!rc) rc = slamhip_gmapping_match_finish(g, raw.data());
+  if (rc && settled) {  // behind the step's only collective: reported to the others at the next step's
+    match_abort(g);
+    g->deferred_rc = rc;
+    return rc;
+  }
   if (!settled) {
-    // a re-match may have changed a shard's weights: all raw weights once more, in particle order
-    rc = slamhip_shard_allgather(g->ctx, raw.data(), g->shard_counts.data(), (int)sizeof(double), all.data());
-    if (rc) return rc;
+    // a re-match may have changed a shard's weights: all raw weights once more, in particle order (with a status
+    // word in front: match_finish may have failed on some rank)
+    std::vector<int> cnt(world);
+    int total = 0;
+    for (int r = 0; r < world; ++r) {
+      cnt[r] = 1 + g->shard_counts[r];
+      total += cnt[r];
+    }
+    std::vector<double> blk(cnt[rank], 0.0), gathered(total, 0.0);
+    blk[0] = (double)rc;
+    const std::string msg = rc ? std::string(slamhip_last_error()) : std::string();
+    std::memcpy(blk.data() + 1, raw.data(), sizeof(double) * g->count);
+    int rc2 = slamhip_shard_allgather(g->ctx, blk.data(), cnt.data(), (int)sizeof(double), gathered.data());
+    if (rc2) {
+      match_abort(g);
+      return rc2;
+    }
+    int at = 0, wat = 0, failed_rank = -1;
+    for (int r = 0; r < world; ++r) {
+      if (gathered[at] != 0.0 && failed_rank < 0) failed_rank = r;
+      std::memcpy(all.data() + wat, gathered.data() + at + 1, sizeof(double) * g->shard_counts[r]);
+      at += cnt[r];
+      wat += g->shard_counts[r];
+    }
+    if (failed_rank >= 0) {
+      match_abort(g);
+      if (rc) {
+        set_error(msg);
+        return rc;
+      }
+      set_error("rank " + std::to_string(failed_rank) + " of the shard group failed in its map update");
+      return SLAMHIP_ERR_STATE;
+    }
   }
   std::vector<unsigned> idx(g->n_total);
   int req = 0;
-  rc = slamhip_gmapping_plan_resample(g, all.data(), resample_seed, &req, idx.data());
-  if (rc) return rc;
+  rc = slamhip_gmapping_plan_resample(g, all.data(), resample_seed, &req, idx.data());  // (same inputs, same verdict everywhere)
+  if (rc) {
+    g->deferred_rc = rc;
+    return rc;
+  }
   if (req) {
     std::vector<GmParticle> blobs(g->n_total);
     rc = slamhip_shard_allgather(g->ctx, g->p.data(), g->shard_counts.data(), (int)sizeof(GmParticle), blobs.data());
     if (rc) return rc;
-    rc = slamhip_gmapping_import(g, blobs.data(), idx.data());
-    if (rc) return rc;
+    // own maps: the maps of particles drawn from other ranks travel first (two all-gathers and one exchange that
+    // every rank enters, whatever it needs itself)
+    rc = g->tp ? migrate_and_import(g, rank, world, blobs, idx) : slamhip_gmapping_import(g, blobs.data(), idx.data());
+    if (rc) {
+      g->deferred_rc = rc;
+      return rc;
+    }
     if (idx_out) std::memcpy(idx_out, idx.data(), sizeof(unsigned) * g->n_total);
   }
   if (resampled) *resampled = req;
+  return SLAMHIP_OK;
+}
+
+int slamhip_gmapping_migration_stats(slamhip_gmapping *g, long long *maps_received, long long *tile_bytes_sent) {
+  if (!g) return bad("null filter");
+  if (maps_received) *maps_received = g->maps_migrated;
+  if (tile_bytes_sent) *tile_bytes_sent = g->map_bytes_sent;
   return SLAMHIP_OK;
 }
 

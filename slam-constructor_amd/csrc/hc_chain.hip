@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         // ---- the last workgroup keeps the books (it scores nothing after the first super-step, so the
         // dependent loads and stores below are on no pose's critical path)
         if (a.trace && !dirty) {
-          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_cap;
+          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_stride;
           const long long base = sp.calls + (sp.first ? 1 : 0);
           if (sp.first && lane == 0 && a.trace_cap > 0) {
             HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};

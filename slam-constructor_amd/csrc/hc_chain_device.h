@@ -84,8 +84,9 @@ struct HcChainArgs {
   int shape0;
   unsigned epoch;
   HcHostOut *host;
-  HcTraceEntry *trace;  // pinned; null = no observer.  Chain c writes at trace + c * trace_cap.
-  int trace_cap;
+  HcTraceEntry *trace;  // pinned; null = no observer.  Chain c writes at trace + c * trace_stride, at most
+  int trace_cap;        // trace_cap entries
+  int trace_stride;
   long long *stamps;    // debugging: 8 wall-clock stamps (100 MHz) per super-step of workgroup 1, or null
 };
 

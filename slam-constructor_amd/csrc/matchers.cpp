@@ -537,6 +537,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   a.host = b->h_out;
   a.trace = m->has_obs ? b->h_trace : nullptr;
   a.trace_cap = m->has_obs ? b->trace_per : 0;
+  a.trace_stride = b->trace_per;
   if (m->has_obs && m->debug_trace_cap > 0) a.trace_cap = std::min(a.trace_cap, m->debug_trace_cap);
   for (int c = 0; c < n; ++c) {
     ((volatile HcHostOut *)b->h_out)[c].error = 0;

@@ -14,12 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <condition_variable>
 #include <cstring>
-#include <iterator>
-#include <map>
-#include <memory>
-#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +28,10 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -50,8 +49,13 @@ static Rccl *rccl() {
       r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
       r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
       r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+      r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
+      r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
+      r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+      r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString || !r.Send ||
+          !r.Recv || !r.GroupStart || !r.GroupEnd) {
         dlclose(r.lib);
         r.lib = nullptr;
       }
@@ -60,29 +64,16 @@ static Rccl *rccl() {
   return r.lib ? &r : nullptr;
 }
 
-// An in-process group: the "ranks" are threads of ONE process (each with its own context, all on whatever GPUs the
-// process sees), the all-gather goes through host memory behind a mutex.  It exists so that
-// slamhip_gmapping_step_sharded -- the protocol above the collective -- can be run with world > 1 where only one
-// GPU is available (tests/test_gpu_shard.py); RCCL itself admits one rank per device.
-struct LoopbackBoard {
-  std::mutex mu;
-  std::condition_variable cv;
-  int world = 0, arrived = 0, left = 0;
-  long long generation = 0;
-  std::vector<std::vector<char>> blocks;
-};
-static std::mutex g_boards_mu;
-static std::map<std::string, std::shared_ptr<LoopbackBoard>> g_boards;
-static constexpr char kLoopbackTag[] = "SLAMHIP-LOOPBACK:";
-
 struct ShardState {
-  ncclComm_t comm = nullptr;
-  std::shared_ptr<LoopbackBoard> board;  // non-null: an in-process group instead of an RCCL communicator
+  ncclComm_t comm = nullptr;             // the built-in transport: an RCCL communicator ...
+  slamhip_shard_transport ext{};         // ... or the caller's own (slamhip_shard_attach)
+  bool attached = false;
   int rank = 0, world = 1;
   char *d_send = nullptr, *d_recv = nullptr;  // device staging of the padded blocks
   char *h_send = nullptr, *h_recv = nullptr;  // pinned mirrors
   size_t cap = 0;                             // bytes per rank the buffers hold
   long long collectives = 0, bytes = 0;
+  long long exchanges = 0, p2p_bytes = 0;
 };
 
 static int rccl_fail(ncclResult_t e, const char *what) {
@@ -117,11 +108,7 @@ void shard_release(slamhip_ctx *ctx) {
     Rccl *r = rccl();
     if (r) r->CommDestroy(s->comm);
   }
-  if (s->board) {
-    s->board.reset();
-    std::lock_guard<std::mutex> lk(g_boards_mu);  // a group nobody belongs to any more is forgotten
-    for (auto it = g_boards.begin(); it != g_boards.end();) it = it->second.use_count() == 1 ? g_boards.erase(it) : std::next(it);
-  }
+  if (s->attached && s->ext.destroy) s->ext.destroy(s->ext.user);
   free_buffers(s);
   delete s;
   ctx->shard = nullptr;
@@ -148,28 +135,6 @@ int slamhip_shard_unique_id(void *id_out) {
 int slamhip_shard_init(slamhip_ctx *ctx, int rank, int world, const void *id) {
   if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return invalid_arg("bad shard geometry");
   if (ctx->shard) return invalid_arg("the context already belongs to a shard group");
-  if (std::memcmp(id, kLoopbackTag, sizeof(kLoopbackTag) - 1) == 0) {
-    // in-process group: the rest of the id names it
-    const std::string name(static_cast<const char *>(id), strnlen(static_cast<const char *>(id), SLAMHIP_SHARD_ID_BYTES));
-    std::shared_ptr<LoopbackBoard> b;
-    {
-      std::lock_guard<std::mutex> lk(g_boards_mu);
-      auto &slot = g_boards[name];
-      if (!slot) {
-        slot = std::make_shared<LoopbackBoard>();
-        slot->world = world;
-        slot->blocks.resize(world);
-      }
-      b = slot;
-    }
-    if (b->world != world) return invalid_arg("the in-process group was created with another size");
-    auto *s = new ShardState;
-    s->rank = rank;
-    s->world = world;
-    s->board = b;
-    ctx->shard = s;
-    return SLAMHIP_OK;
-  }
   Rccl *r = rccl();
   if (!r) return no_rccl();
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
@@ -184,6 +149,71 @@ int slamhip_shard_init(slamhip_ctx *ctx, int rank, int world, const void *id) {
     return rccl_fail(e, "ncclCommInitRank");
   }
   ctx->shard = s;
+  return SLAMHIP_OK;
+}
+
+int slamhip_shard_attach(slamhip_ctx *ctx, int rank, int world, const slamhip_shard_transport *t) {
+  if (!ctx || !t || world < 1 || rank < 0 || rank >= world) return invalid_arg("bad shard geometry");
+  if (!t->allgather || !t->exchange) return invalid_arg("a shard transport needs allgather and exchange");
+  if (ctx->shard) return invalid_arg("the context already belongs to a shard group");
+  auto *s = new ShardState;
+  s->rank = rank;
+  s->world = world;
+  s->ext = *t;
+  s->attached = true;
+  ctx->shard = s;
+  return SLAMHIP_OK;
+}
+
+int slamhip_shard_exchange(slamhip_ctx *ctx, int n_send, const slamhip_shard_msg *send, int n_recv,
+                           const slamhip_shard_msg *recv) {
+  if (!ctx || n_send < 0 || n_recv < 0 || (n_send > 0 && !send) || (n_recv > 0 && !recv))
+    return invalid_arg("bad exchange arguments");
+  auto *s = static_cast<ShardState *>(ctx->shard);
+  if (!s) {
+    set_error("slamhip_shard_init has not been called on this context");
+    return SLAMHIP_ERR_STATE;
+  }
+  for (int k = 0; k < n_send; ++k)
+    if (send[k].peer < 0 || send[k].peer >= s->world || (send[k].bytes && !send[k].buf)) return invalid_arg("bad send message");
+  for (int k = 0; k < n_recv; ++k)
+    if (recv[k].peer < 0 || recv[k].peer >= s->world || (recv[k].bytes && !recv[k].buf)) return invalid_arg("bad receive message");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  long long moved = 0;
+  for (int k = 0; k < n_send; ++k) moved += (long long)send[k].bytes;
+  if (s->attached) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));  // what filled the send buffers has run
+    const int trc = s->ext.exchange(s->ext.user, n_send, send, n_recv, recv);
+    if (trc) {
+      set_error("the attached shard transport failed in its exchange");
+      return trc < 0 ? trc : SLAMHIP_ERR_STATE;
+    }
+  } else {
+    Rccl *r = rccl();
+    if (!r) return no_rccl();
+    // one group: every send and receive of this rank is posted before any of them blocks (point-to-point xGMI
+    // links: a pair's messages travel on the link between the two GPUs)
+    ncclResult_t e = r->GroupStart();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclGroupStart");
+    for (int k = 0; k < n_send && e == ncclSuccess; ++k)
+      if (send[k].bytes) e = r->Send(send[k].buf, send[k].bytes, ncclUint8, send[k].peer, s->comm, ctx->stream);
+    for (int k = 0; k < n_recv && e == ncclSuccess; ++k)
+      if (recv[k].bytes) e = r->Recv(recv[k].buf, recv[k].bytes, ncclUint8, recv[k].peer, s->comm, ctx->stream);
+    const ncclResult_t e2 = r->GroupEnd();
+    if (e != ncclSuccess) return rccl_fail(e, "ncclSend / ncclRecv");
+    if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  s->exchanges += 1;
+  s->p2p_bytes += moved;
+  return SLAMHIP_OK;
+}
+
+int slamhip_shard_p2p_stats(slamhip_ctx *ctx, long long *exchanges, long long *bytes_sent) {
+  if (!ctx) return invalid_arg("null ctx");
+  auto *s = static_cast<ShardState *>(ctx->shard);
+  if (exchanges) *exchanges = s ? s->exchanges : 0;
+  if (bytes_sent) *bytes_sent = s ? s->p2p_bytes : 0;
   return SLAMHIP_OK;
 }
 
@@ -229,34 +259,21 @@ int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *coun
   if (counts[s->rank] > 0 && !local) return invalid_arg("null local block");
   const size_t block = (size_t)max_count * elem_bytes;
   if (block == 0) return SLAMHIP_OK;
-  if (s->board) {
-    // every rank posts its block, waits for the others, copies all of them out, and the last one to leave
-    // opens the board for the next collective
-    LoopbackBoard &b = *s->board;
-    std::unique_lock<std::mutex> lk(b.mu);
-    b.cv.wait(lk, [&] { return b.left == 0; });  // the previous collective has been read by everybody
-    const long long gen = b.generation;
-    b.blocks[s->rank].assign(static_cast<const char *>(local), static_cast<const char *>(local) + (size_t)counts[s->rank] * elem_bytes);
-    if (++b.arrived == b.world) {
-      b.arrived = 0;
-      b.left = b.world;
-      ++b.generation;
-      b.cv.notify_all();
-    } else {
-      b.cv.wait(lk, [&] { return b.generation != gen; });
+  if (s->attached) {
+    // the caller's transport moves equal host blocks; padding and unpadding happen here
+    std::vector<char> snd(block, 0), rcv(block * (size_t)s->world);
+    if (counts[s->rank] > 0) std::memcpy(snd.data(), local, (size_t)counts[s->rank] * elem_bytes);
+    const int trc = s->ext.allgather(s->ext.user, snd.data(), block, rcv.data());
+    if (trc) {
+      set_error("the attached shard transport failed in its all-gather");
+      return trc < 0 ? trc : SLAMHIP_ERR_STATE;
     }
     char *out = static_cast<char *>(all_out);
     for (int q = 0; q < s->world; ++q) {
       const size_t nb = (size_t)counts[q] * elem_bytes;
-      if (b.blocks[q].size() != nb) {
-        --b.left;
-        b.cv.notify_all();
-        return invalid_arg("the ranks of an in-process group disagree about the block sizes");
-      }
-      std::memcpy(out, b.blocks[q].data(), nb);
+      std::memcpy(out, rcv.data() + (size_t)q * block, nb);
       out += nb;
     }
-    if (--b.left == 0) b.cv.notify_all();
     s->collectives += 1;
     s->bytes += (long long)(block * s->world);
     return SLAMHIP_OK;

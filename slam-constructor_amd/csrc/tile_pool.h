@@ -72,10 +72,19 @@ int tile_pool_assign(TilePool *tp, const int *src_of_new);
 // its own ancestor tiles).
 size_t tile_pool_export_size(const TilePool *tp, int slot);
 int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap);
+// the same in two parts: the header (tile positions, ancestor ordinals: host memory, header_bytes) and the body (tile
+// contents: host OR device memory, body_bytes) -- the sharded filter step all-gathers the small headers and sends
+// the bodies device to device (RCCL send / recv over xGMI).  wait = false leaves the copies queued on the stream.
+void tile_pool_export_sizes(const TilePool *tp, int slot, size_t *header_bytes, size_t *body_bytes);
+int tile_pool_export_split(TilePool *tp, int slot, void *header_host, void *body, bool wait);
 // new generation with remote sources: new slot s becomes a copy of old local slot src[s] when
 // src[s] >= 0, or of the exported map remote_bufs[-src[s] - 1] otherwise (imported once, shared by
 // every new slot that names it -- the tiles are then shared like after a local copy)
 int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs);
+// ... with the bodies apart from the headers (remote_bufs[k] = header in host memory, remote_bodies[k] = tile contents
+// in host or device memory)
+int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs,
+                                 const void *const *remote_bodies);
 // external window [x0, x0+w) x [y0, y0+h) of a slot: payload (3 doubles per cell: prob, obst.x, obst.y)
 // and counters (2 per cell: hits, tries); either may be null
 int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, double *payload3, double *aux2);

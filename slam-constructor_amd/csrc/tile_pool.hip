@@ -370,8 +370,9 @@ constexpr size_t kTileAuxBytes = (size_t)kTileCells * 2 * sizeof(double);
 size_t export_header_bytes(long long n_entries) { return 8 + (size_t)n_entries * 16; }
 }  // namespace
 
-size_t tile_pool_export_size(const TilePool *tp, int slot) {
-  if (slot < 0 || slot >= tp->n_slots) return 0;
+void tile_pool_export_sizes(const TilePool *tp, int slot, size_t *header_bytes, size_t *body_bytes) {
+  *header_bytes = *body_bytes = 0;
+  if (slot < 0 || slot >= tp->n_slots) return;
   const int *row = tp->h_tables.data() + (size_t)slot * tp->table_stride();
   long long n = 0, with_content = 0;
   for (int i = 0; i < tp->table_stride(); ++i) {
@@ -379,43 +380,74 @@ size_t tile_pool_export_size(const TilePool *tp, int slot) {
     ++n;
     with_content += tp->ancestor_of[row[i]] < 0;
   }
-  return export_header_bytes(n) + (size_t)with_content * (kTilePayloadBytes + kTileAuxBytes);
+  *header_bytes = export_header_bytes(n);
+  *body_bytes = (size_t)with_content * (kTilePayloadBytes + kTileAuxBytes);
 }
 
-int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap) {
-  if (slot < 0 || slot >= tp->n_slots || !host_buf) return tp_fail("bad export arguments");
-  const size_t need = tile_pool_export_size(tp, slot);
-  if (cap < need) return tp_fail("export buffer too small");
+size_t tile_pool_export_size(const TilePool *tp, int slot) {
+  size_t h = 0, b = 0;
+  tile_pool_export_sizes(tp, slot, &h, &b);
+  return (slot < 0 || slot >= tp->n_slots) ? 0 : h + b;
+}
+
+int tile_pool_export_split(TilePool *tp, int slot, void *header_host, void *body, bool wait) {
+  if (slot < 0 || slot >= tp->n_slots || !header_host) return tp_fail("bad export arguments");
   const int *row = tp->h_tables.data() + (size_t)slot * tp->table_stride();
   std::vector<int> idx;
   for (int i = 0; i < tp->table_stride(); ++i)
     if (row[i] != 0) idx.push_back(i);
-  char *out = static_cast<char *>(host_buf);
+  char *out = static_cast<char *>(header_host);
   const long long n = (long long)idx.size();
   std::memcpy(out, &n, 8);
   int *ent = reinterpret_cast<int *>(out + 8);
+  bool any = false;
   for (size_t k = 0; k < idx.size(); ++k) {
     ent[4 * k] = (idx[k] % tp->tiles_x) * kTileSide - tp->origin_x;
     ent[4 * k + 1] = (idx[k] / tp->tiles_x) * kTileSide - tp->origin_y;
     ent[4 * k + 2] = tp->ancestor_of[row[idx[k]]];  // an untouched ancestor tile travels as its ordinal
     ent[4 * k + 3] = 0;
+    any |= ent[4 * k + 2] < 0;
   }
-  char *p = out + export_header_bytes(n);
+  if (any && !body) return tp_fail("null export body");
+  char *p = static_cast<char *>(body);
   for (int i : idx) {
     const size_t tile = (size_t)row[i];
     if (tp->ancestor_of[tile] >= 0) continue;
-    SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_pool + tile * kTileCells * 4, kTilePayloadBytes, hipMemcpyDeviceToHost,
-                                 tp->ctx->stream));
+    // (hipMemcpyDefault: the body may be host memory -- a buffer for the caller's own transport -- or device memory,
+    // from where RCCL sends it over xGMI)
+    SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_pool + tile * kTileCells * 4, kTilePayloadBytes, hipMemcpyDefault, tp->ctx->stream));
     p += kTilePayloadBytes;
-    SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_aux + tile * kTileCells * 2, kTileAuxBytes, hipMemcpyDeviceToHost,
-                                 tp->ctx->stream));
+    SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_aux + tile * kTileCells * 2, kTileAuxBytes, hipMemcpyDefault, tp->ctx->stream));
     p += kTileAuxBytes;
   }
-  SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  if (wait) SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
   return SLAMHIP_OK;
 }
 
+int tile_pool_export(TilePool *tp, int slot, void *host_buf, size_t cap) {
+  if (slot < 0 || slot >= tp->n_slots || !host_buf) return tp_fail("bad export arguments");
+  size_t hb = 0, bb = 0;
+  tile_pool_export_sizes(tp, slot, &hb, &bb);
+  if (cap < hb + bb) return tp_fail("export buffer too small");
+  return tile_pool_export_split(tp, slot, host_buf, static_cast<char *>(host_buf) + hb, true);
+}
+
 int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs) {
+  // one buffer per map: the header, then the body
+  std::vector<const void *> bodies(n_remote > 0 ? n_remote : 0, nullptr);
+  for (int r = 0; r < n_remote; ++r) {
+    const char *in = static_cast<const char *>(remote_bufs[r]);
+    if (!in) continue;
+    long long n = 0;
+    std::memcpy(&n, in, 8);
+    if (n < 0 || n > (1 << 20)) return tp_fail("corrupt exported map");
+    bodies[r] = in + export_header_bytes(n);
+  }
+  return tile_pool_assign_mixed_split(tp, src, n_remote, remote_bufs, bodies.data());
+}
+
+int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, const void *const *remote_bufs,
+                                 const void *const *remote_bodies) {
   // a map that arrives from a pool grown further than this one: grow first (tables are re-laid out)
   for (int r = 0; r < n_remote; ++r) {
     bool used = false;
@@ -463,7 +495,7 @@ int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const voi
     std::memcpy(&n, in, 8);
     if (n < 0 || n > stride) return tp_fail("corrupt exported map");
     const int *ent = reinterpret_cast<const int *>(in + 8);
-    const char *p = in + export_header_bytes(n);
+    const char *p = static_cast<const char *>(remote_bodies[r]);  // host or device memory
     imported[r].assign(stride, 0);
     for (long long k = 0; k < n; ++k) {
       const int tx = (ent[4 * k] + tp->origin_x) >> kTileShift, ty = (ent[4 * k + 1] + tp->origin_y) >> kTileShift;
@@ -479,10 +511,11 @@ int tile_pool_assign_mixed(TilePool *tp, const int *src, int n_remote, const voi
       int rcode = alloc_tile(tp, &fresh);
       if (rcode) return rcode;
       tp->refcnt[fresh] = 0;  // counted below, once per new slot that takes this map
+      if (!p) return tp_fail("missing body of an exported map");
       SLAMHIP_CHECK(hipMemcpyAsync(tp->d_pool + (size_t)fresh * kTileCells * 4, p, kTilePayloadBytes,
-                                   hipMemcpyHostToDevice, st));
+                                   hipMemcpyDefault, st));
       p += kTilePayloadBytes;
-      SLAMHIP_CHECK(hipMemcpyAsync(tp->d_aux + (size_t)fresh * kTileCells * 2, p, kTileAuxBytes, hipMemcpyHostToDevice, st));
+      SLAMHIP_CHECK(hipMemcpyAsync(tp->d_aux + (size_t)fresh * kTileCells * 2, p, kTileAuxBytes, hipMemcpyDefault, st));
       p += kTileAuxBytes;
       imported[r][ti] = fresh;
     }

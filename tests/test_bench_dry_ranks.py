@@ -1,0 +1,27 @@
+"""CPU suite: `python bench.py --dry-ranks N` -- the benchmark's multi-rank control flow without a GPU (the same
+self-launch as --gpus N: torch.distributed.run child, rendezvous on 127.0.0.1; gloo; host-only filter shards; block
+split, all-gathers, identical resampling on every rank, the map-migration plan with dummy maps point to point,
+barrier + max-over-ranks timing), every rank checked against an unsharded filter.  N = 8 is the node the driver's
+scaling run uses: 100 particles in blocks of 13 x 4 + 12 x 4."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("ranks,particles", [(2, 24), (8, 100)])
+def test_dry_ranks(ranks, particles):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-ranks", str(ranks), "--particles",
+                        str(particles), "--pf-steps", "5"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] and d["ok"] and d["ranks"] == ranks and sum(d["shards"]) == particles
+    assert d["ranks_that_disagree_with_the_unsharded_filter"] == 0
+    assert d["resamplings"] >= 1 and d["dummy_map_bytes_moved"] > 0
+    if ranks == 8:
+        assert d["shards"] == [13] * 4 + [12] * 4

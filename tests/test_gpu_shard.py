@@ -206,16 +206,11 @@ def test_two_ranks_over_rccl(pkg, tmp_path):
     ctx.close()
 
 
-def loopback_id(name):
-    """128-byte group id of an in-process group (csrc/shard.cpp: the ranks are threads of this process)"""
-    raw = ("SLAMHIP-LOOPBACK:" + name).encode()
-    return np.frombuffer(raw + b"\0" * (128 - len(raw)), dtype=np.uint8).copy()
-
-
 def run_loopback_ranks(pkg, world, n, scene, steps, scan, gp, name):
     """slamhip_gmapping_step_sharded on `world` ranks = threads, one context each on GPU 0; returns per-rank logs"""
     import threading
-    uid = loopback_id(name)
+    import loopback
+    loopback.lib()  # (built once, before the threads start)
     counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
     seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
     logs, errors = [None] * world, []
@@ -223,7 +218,7 @@ def run_loopback_ranks(pkg, world, n, scene, steps, scan, gp, name):
     def rank_main(rank):
         try:
             ctx = pkg.Context(0)
-            ctx.shard_init(rank, world, uid)
+            loopback.attach(pkg, ctx, name, rank, world)
             ctx.upload_map(1, scene["map"])
             first = sum(counts[:rank])
             pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds[first:first + counts[rank]], first=first,
@@ -254,8 +249,8 @@ def run_loopback_ranks(pkg, world, n, scene, steps, scan, gp, name):
 def test_step_sharded_over_an_in_process_group(pkg, world):
     """The library's own sharded step (slamhip_gmapping_step_sharded: match, ONE all-gather of carry records +
     raw weights, identical resampling everywhere, records all-gathered when a resampling happens) with world > 1
-    on one GPU: the ranks are threads, the collective an in-process board (the RCCL communicator admits one rank
-    per device).  Every rank must hold exactly the particles of the unsharded filter after every step."""
+    on one GPU: the ranks are threads, the transport an in-process board handed in through slamhip_shard_attach
+    (tests/native/loopback_transport.cpp; the RCCL communicator admits one rank per device).  Every rank must hold exactly the particles of the unsharded filter after every step."""
     ctx = pkg.Context(0)
     sc = make_scene(cell_model=2, size=800, scale=0.05, n_beams=360, seed=4)
     ctx.upload_map(1, sc["map"])
@@ -313,3 +308,141 @@ def test_step_sharded_repairs_the_cache_across_ranks(pkg):
     assert reruns > 0, "the scene did not exercise a hand-over across the ranks"
     assert extra_collectives > 0  # the repair rounds did run
     ctx.close()
+
+
+def test_exchange_over_rccl_with_one_rank(pkg):
+    """slamhip_shard_exchange on a 1-rank RCCL communicator: ncclSend / ncclRecv to oneself inside one group -- the
+    call the map migration makes, on the real transport (with more ranks it needs as many GPUs)."""
+    import torch
+    ctx = pkg.Context(0)
+    ctx.shard_init(0, 1, pkg.shard_unique_id())
+    a = torch.arange(4096, dtype=torch.float64, device="cuda") * 1.5
+    b = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    c = torch.zeros(100, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.shard_exchange([(0, a.data_ptr(), 4096 * 8), (0, a.data_ptr() + 800, 800)],
+                       [(0, b.data_ptr(), 4096 * 8), (0, c.data_ptr(), 800)])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(c, a[100:200])
+    assert ctx.shard_p2p_stats() == dict(exchanges=1, bytes_sent=4096 * 8 + 800)
+    ctx.shard_exchange([], [])
+    ctx.shard_destroy()
+    ctx.close()
+
+
+def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None):
+    """slamhip_gmapping_step_sharded with per-particle maps on `world` in-process ranks; returns per-rank logs:
+    (resampled, idx, poses, weights, masters) per step, the final maps of the rank's particles, migration stats"""
+    import threading
+    import loopback
+    from helpers import load
+    loopback.lib()
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    ox, oy = [int(v) for v in g["origin"]]
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
+    logs, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            ctx = pkg.Context(0)
+            loopback.attach(pkg, ctx, name, rank, world)
+            ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+            c0, s0 = pkg.beam_trig(g["step0_angle"])
+            ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["step0_delta"], g["step0_range"], c0, s0)
+            first = sum(counts[:rank])
+            pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n,
+                                    seeds[first:first + counts[rank]], first=first, count=counts[rank])
+            pf.enable_particle_maps(4, 8, 16 + 24 * n)
+            log = []
+            for it, k in enumerate(steps_spec):
+                map_id = 4 if not (fail_rank == rank and it == 1) else 77  # an unknown map id: this rank fails in its match
+                try:
+                    res, idx = pf.step_sharded(map_id, g["step%d_range" % k], g["step%d_angle" % k], None,
+                                               g["step%d_delta" % k], 7 + it)
+                except pkg.SlamHipError as e:
+                    log.append(("error", str(e)))
+                    continue
+                p, wts, m = pf.state()
+                log.append((res, np.array(idx).copy(), p, wts, m))
+            maps = [pf.particle_map(i, -ox, -oy, w, h) for i in range(counts[rank])]
+            logs[rank] = (log, maps, pf.migration_stats(), ctx.shard_p2p_stats())
+            pf.close()
+            ctx.shard_destroy()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert all(not t.is_alive() for t in threads), "a rank is stuck in a collective"
+    assert not errors, errors
+    return logs, counts, (ox, oy, w, h), g
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_step_sharded_with_particle_maps_migrates_inside_the_library(pkg, world):
+    """BASELINE configs[4]'s form -- particles WITH their own copy-on-write maps sharded over the ranks -- through the
+    library's one entry point: slamhip_gmapping_step_sharded all-gathers weights and records as before and, when a
+    resampling draws a particle from another rank, moves that particle's map itself (headers by all-gather, tile
+    contents by ONE slamhip_shard_exchange, device to device).  2 and 3 in-process ranks with a tile pool each on
+    one GPU against the unsharded filter: poses, weights, masters, resampling indices and EVERY particle's map bit
+    for bit through at least two resamplings with migrations (particle_filter.h:83-106,
+    lazy_tiled_grid_map.h:40-71)."""
+    from helpers import load
+    n = 10
+    n_base = int(load("gmapping_pf_update.npz")["n_steps"])
+    steps_spec = list(range(n_base)) + [1 + (k % (n_base - 1)) for k in range(20)]
+    logs, counts, (ox, oy, w, h), g = run_map_ranks(pkg, world, n, steps_spec, "maps-%d" % world)
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+    c0, s0 = pkg.beam_trig(g["step0_angle"])
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["step0_delta"], g["step0_range"], c0, s0)
+    whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n,
+                               np.arange(2000, 2000 + n, dtype=np.uint32))
+    whole.enable_particle_maps(4, 8, 16 + 24 * n)
+    resamplings = 0
+    for it, k in enumerate(steps_spec):
+        res, idx = whole.step(4, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + it)
+        pw, ww, mw = whole.state()
+        resamplings += int(res)
+        for r in range(world):
+            assert logs[r][0][it][0] == res, (it, r)
+            if res:
+                np.testing.assert_array_equal(logs[r][0][it][1], idx)
+        np.testing.assert_array_equal(np.concatenate([logs[r][0][it][2] for r in range(world)]), pw, err_msg="step %d" % it)
+        np.testing.assert_array_equal(np.concatenate([logs[r][0][it][3] for r in range(world)]), ww)
+        np.testing.assert_array_equal(np.concatenate([logs[r][0][it][4] for r in range(world)]), mw)
+    first = 0
+    for r in range(world):
+        for l in range(counts[r]):
+            a_p, a_a = whole.particle_map(first + l, -ox, -oy, w, h)
+            b_p, b_a = logs[r][1][l]
+            np.testing.assert_array_equal(b_p, a_p, err_msg="particle %d" % (first + l))
+            np.testing.assert_array_equal(b_a, a_a)
+        first += counts[r]
+    received = sum(logs[r][2]["maps_received"] for r in range(world))
+    sent = sum(logs[r][2]["tile_bytes_sent"] for r in range(world))
+    assert resamplings >= 2 and received >= 1, (resamplings, received)
+    assert sent == sum(logs[r][3]["bytes_sent"] for r in range(world))
+    ctx.close()
+
+
+def test_a_failing_rank_takes_every_rank_out_of_the_step(pkg):
+    """a rank-local error after match_begin used to leave g->pending set (every later step failed with
+    'the previous step was not finished') and the other ranks blocked in the all-gather.  Now the failure travels in
+    the status word of the step's collective: all ranks return from THAT step with an error, nobody hangs, and the
+    filters take the next step."""
+    logs, counts, _, _ = run_map_ranks(pkg, 2, 8, [0, 1, 2], "fail-1", fail_rank=1)
+    for r in range(2):
+        log = logs[r][0]
+        assert log[0][0] != "error"
+        assert log[1][0] == "error", log[1]
+        assert log[2][0] != "error", log[2]
+    assert "unknown map id" in logs[1][0][1][1] or "map" in logs[1][0][1][1]
+    assert "rank 1" in logs[0][0][1][1]
