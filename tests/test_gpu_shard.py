@@ -357,9 +357,12 @@ def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None):
             pf.enable_particle_maps(4, 8, 16 + 24 * n)
             log = []
             for it, k in enumerate(steps_spec):
-                map_id = 4 if not (fail_rank == rank and it == 1) else 77  # an unknown map id: this rank fails in its match
+                if fail_rank == rank and it == 1:
+                    # a step left half done by the caller (match_begin without match_finish): this rank's
+                    # step_sharded fails in its own match_begin
+                    pf.match_begin(4, g["step%d_range" % k], g["step%d_angle" % k], None, [0.0, 0.0, 0.0])
                 try:
-                    res, idx = pf.step_sharded(map_id, g["step%d_range" % k], g["step%d_angle" % k], None,
+                    res, idx = pf.step_sharded(4, g["step%d_range" % k], g["step%d_angle" % k], None,
                                                g["step%d_delta" % k], 7 + it)
                 except pkg.SlamHipError as e:
                     log.append(("error", str(e)))
@@ -395,7 +398,7 @@ def test_step_sharded_with_particle_maps_migrates_inside_the_library(pkg, world)
     for bit through at least two resamplings with migrations (particle_filter.h:83-106,
     lazy_tiled_grid_map.h:40-71)."""
     from helpers import load
-    n = 10
+    n = 8
     n_base = int(load("gmapping_pf_update.npz")["n_steps"])
     steps_spec = list(range(n_base)) + [1 + (k % (n_base - 1)) for k in range(20)]
     logs, counts, (ox, oy, w, h), g = run_map_ranks(pkg, world, n, steps_spec, "maps-%d" % world)
@@ -444,5 +447,94 @@ def test_a_failing_rank_takes_every_rank_out_of_the_step(pkg):
         assert log[0][0] != "error"
         assert log[1][0] == "error", log[1]
         assert log[2][0] != "error", log[2]
-    assert "unknown map id" in logs[1][0][1][1] or "map" in logs[1][0][1][1]
-    assert "rank 1" in logs[0][0][1][1]
+    assert "not finished" in logs[1][0][1][1], logs[1][0][1][1]
+    assert "rank 1" in logs[0][0][1][1], logs[0][0][1][1]
+
+
+def _rank_main_maps(rank, world, uid_path, out_path):
+    """one process = one GPU = one rank of an RCCL group: the sharded step with per-particle maps"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import __graft_entry__ as g2
+    from helpers import load
+    pkg = g2.load_package()
+    if rank == 0:
+        np.save(uid_path + ".tmp.npy", pkg.shard_unique_id())
+        os.replace(uid_path + ".tmp.npy", uid_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(uid_path):
+                break
+            time.sleep(0.05)
+    uid = np.load(uid_path)
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    ox, oy = [int(v) for v in g["origin"]]
+    n = 8
+    counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
+    first = sum(counts[:rank])
+    ctx = pkg.Context(rank)
+    ctx.shard_init(rank, world, uid)
+    ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+    c0, s0 = pkg.beam_trig(g["step0_angle"])
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["step0_delta"], g["step0_range"], c0, s0)
+    seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n,
+                            seeds[first:first + counts[rank]], first=first, count=counts[rank])
+    pf.enable_particle_maps(4, 8, 16 + 24 * n)
+    n_base = int(g["n_steps"])
+    log = []
+    for it, k in enumerate(list(range(n_base)) + [1 + (j % (n_base - 1)) for j in range(20)]):
+        res, idx = pf.step_sharded(4, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + it)
+        p, wts, m = pf.state()
+        log.append((res, np.array(idx).copy(), p, wts, m))
+    maps = [pf.particle_map(i, -ox, -oy, w, h) for i in range(counts[rank])]
+    np.save(out_path % rank, np.array([log, maps, pf.migration_stats()], dtype=object), allow_pickle=True)
+    pf.close()
+    ctx.shard_destroy()
+    ctx.close()
+
+
+def test_two_ranks_over_rccl_with_particle_maps(pkg, tmp_path):
+    """The map migration on its real transport: two processes, two GPUs, ncclSend / ncclRecv of the tile contents
+    between them -- against the unsharded filter on one GPU, every particle's map bit for bit.  Needs two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import multiprocessing as mp
+    from helpers import load
+    mpc = mp.get_context("spawn")
+    uid_path, out_path = str(tmp_path / "uid.npy"), str(tmp_path / "rank%d.npy")
+    procs = [mpc.Process(target=_rank_main_maps, args=(r, 2, uid_path, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = [np.load(out_path % r, allow_pickle=True) for r in range(2)]
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    ox, oy = [int(v) for v in g["origin"]]
+    n = 8
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+    c0, s0 = pkg.beam_trig(g["step0_angle"])
+    ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["step0_delta"], g["step0_range"], c0, s0)
+    whole = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n,
+                               np.arange(2000, 2000 + n, dtype=np.uint32))
+    whole.enable_particle_maps(4, 8, 16 + 24 * n)
+    n_base = int(g["n_steps"])
+    for it, k in enumerate(list(range(n_base)) + [1 + (j % (n_base - 1)) for j in range(20)]):
+        res, idx = whole.step(4, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + it)
+        pw, ww, mw = whole.state()
+        assert got[0][0][it][0] == got[1][0][it][0] == res
+        np.testing.assert_array_equal(np.concatenate([got[r][0][it][2] for r in range(2)]), pw)
+        np.testing.assert_array_equal(np.concatenate([got[r][0][it][3] for r in range(2)]), ww)
+    for i in range(n):
+        a_p, a_a = whole.particle_map(i, -ox, -oy, w, h)
+        b_p, b_a = got[i // 4][1][i % 4]
+        np.testing.assert_array_equal(b_p, a_p)
+        np.testing.assert_array_equal(b_a, a_a)
+    assert got[0][2]["maps_received"] + got[1][2]["maps_received"] >= 1
+    ctx.close()
