@@ -153,6 +153,18 @@ typedef struct {
 int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
                             const double pose[3], int n, const double *range, const double *cos_a,
                             const double *sin_a, const int *is_occ, long long *n_updates);
+/* The same with a PER-POINT observation quality: the update quality of a cell a beam touches is scan_quality x
+ * quality[i] -- GridMapScanAdder::append_scan multiplies by ObservationMappingQualityEstimator::quality(points, pt_i)
+ * (grid_map_scan_adders.h:17-43,66-71).  quality = NULL is IdleOMQE (1.0); slamhip_omqe_quality gives the values of
+ * the estimators init_omqe builds (init_occupancy_mapping.h:64-80: "idle", "ahr").  The AffineQualityMergeCell,
+ * MeanProbabilityCell and TbmBaseCell rules read it; GridCell and GmappingBaseCell ignore an observation's quality. */
+int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
+                              const double pose[3], int n, const double *range, const double *cos_a,
+                              const double *sin_a, const int *is_occ, const double *quality, long long *n_updates);
+/* host helper: ObservationMappingQualityEstimator::quality of every point of a scan (n values): kind 0 IdleOMQE,
+ * 1 AngleHistogramResiprocalOMQE = 1 / AngleHistogram::value (grid_map_scan_adders.h:24-43,
+ * src/core/features/angle_histogram.h:17-96), over the scan append_scan is given (all its points) */
+int slamhip_omqe_quality(int kind, int n, const double *range, const double *angle, double *out);
 /* Map updates queued, not awaited (default off).  While on, slamhip_map_append_scan on the zero-copy path returns as
  * soon as the update's kernels are queued on the context's stream -- the scan arrays are consumed before it returns,
  * *n_updates is -1 -- and everything else the context does (matches, scores, downloads, further updates) is ordered

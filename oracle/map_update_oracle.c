@@ -113,6 +113,49 @@ long long orc_append_scan_ex(const orc_map *map, double *payload, double *aux, i
                              int n, const double *range, const double *angle, const int *is_occ,
                              const orc_scan *trig, double scan_quality, const double *base4, double blur,
                              double max_range, int est_kind, double shift_amount) {
+  return orc_append_scan_q(map, payload, aux, rule, pose, n, range, angle, is_occ, trig, scan_quality, base4, blur,
+                           max_range, est_kind, shift_amount, NULL);
+}
+
+/* ObservationMappingQualityEstimator::quality per point (grid_map_scan_adders.h:17-43): kind 0 IdleOMQE (1.0),
+ * kind 1 AngleHistogramResiprocalOMQE = 1 / AngleHistogram::value (src/core/features/angle_histogram.h:17-43,
+ * 71-96): twenty bins over [0, pi) of the direction of the segment from point i-1 to point i (points in the
+ * sensor frame), a point's value = the count of its segment's bin, point 0 = the number of points */
+void orc_omqe_quality(int kind, int n, const double *range, const double *angle, double *out) {
+  if (kind == 0) {
+    for (int i = 0; i < n; ++i) out[i] = 1.0;
+    return;
+  }
+  unsigned hist[20];
+  memset(hist, 0, sizeof(hist));
+  double *dirs = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+  const double step = (180 * M_PI / 180) / 20;
+  for (int i = 1; i < n; ++i) {
+    double s1, c1, s0, c0;
+    sincos(angle[i], &s1, &c1);
+    sincos(angle[i - 1], &s0, &c0);
+    const double d_x = range[i] * c1 - range[i - 1] * c0;
+    const double d_y = range[i] * s1 - range[i - 1] * s0;
+    double a = 0;
+    if (d_y != 0) {
+      a = acos(d_x / sqrt(d_x * d_x + d_y * d_y));
+      if (d_y < 0 && d_x != 0) a = M_PI - a;
+    }
+    hist[(size_t)floor(a / step)]++;
+    dirs[i] = a;
+  }
+  for (int i = 0; i < n; ++i) {
+    const unsigned v = i == 0 ? (unsigned)n : hist[(size_t)floor(dirs[i] / step)];
+    out[i] = 1.0 / v;
+  }
+  free(dirs);
+}
+
+/* beam_quality (n values, or NULL = IdleOMQE): what _omqe->quality(points, pt_i) returns for every point */
+long long orc_append_scan_q(const orc_map *map, double *payload, double *aux, int rule, const double *pose,
+                            int n, const double *range, const double *angle, const int *is_occ,
+                            const orc_scan *trig, double scan_quality, const double *base4, double blur,
+                            double max_range, int est_kind, double shift_amount, const double *beam_quality) {
   if (n <= 0) return 0;
   orc_scan s = *trig;
   s.range = range;
@@ -130,7 +173,7 @@ long long orc_append_scan_ex(const orc_map *map, double *payload, double *aux, i
     double wx, wy;
     orc_endpoint(&s, i, pose, sin_b, cos_b, &wx, &wy);
     const int occ = is_occ ? is_occ[i] : 1;
-    const double quality = scan_quality * 1.0; /* IdleOMQE */
+    const double quality = scan_quality * (beam_quality ? beam_quality[i] : 1.0); /* x _omqe->quality(points, i) */
     const double ddx = wx - pose[0], ddy = wy - pose[1];
     if (max_range_sq < ddx * ddx + ddy * ddy) continue; /* Segment2D::length_sq */
     const int rcx = (int)floor(pose[0] / scale), rcy = (int)floor(pose[1] / scale);

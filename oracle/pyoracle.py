@@ -535,10 +535,26 @@ class Ref:
         return out[:n].copy()
 
     def append_scan(self, m, scan, pose, quality=1.0, occ_est=0, base=(0.95, 1.0, 0.01, 1.0),
-                    blur=0.0, max_range=float("inf")):
+                    blur=0.0, max_range=float("inf"), omqe=0):
+        """omqe 0: IdleOMQE, 1: AngleHistogramResiprocalOMQE (per-point observation quality)"""
         b = f64(base)
+        if omqe:
+            self.lib.ref_append_scan_omqe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                                      C.c_double, C.c_int, _dp, C.c_double, C.c_double, C.c_int]
+            self.lib.ref_append_scan_omqe.restype = None
+            self.lib.ref_append_scan_omqe(m.h, scan.h, pose[0], pose[1], pose[2], quality, occ_est, _d(b), blur,
+                                          max_range, omqe)
+            return
         self.lib.ref_append_scan(m.h, scan.h, pose[0], pose[1], pose[2], quality, occ_est, _d(b),
                                  blur, max_range)
+
+    def omqe_quality(self, scan):
+        """AngleHistogramResiprocalOMQE::quality of every point of `scan`"""
+        self.lib.ref_omqe_quality.argtypes = [C.c_void_p, _dp]
+        self.lib.ref_omqe_quality.restype = None
+        out = np.zeros(scan.size())
+        self.lib.ref_omqe_quality(scan.h, _d(out))
+        return out
 
     def world_to_cells(self, m, x0, y0, x1, y1, cap=1 << 16):
         out = np.zeros((cap, 2), np.int32)

@@ -28,6 +28,37 @@ def append_scan(oracle, gmap, aux, rule, pose, rng, ang, is_occ=None, quality=1.
     return int(res)
 
 
+def omqe_quality(oracle, kind, rng, ang):
+    """ObservationMappingQualityEstimator::quality of every point: kind 0 idle, 1 angle-histogram reciprocal."""
+    L = oracle.lib
+    L.orc_omqe_quality.restype = None
+    L.orc_omqe_quality.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    rng, ang = f64(rng), f64(ang)
+    out = np.zeros(rng.size)
+    L.orc_omqe_quality(kind, rng.size, _d(rng), _d(ang), _d(out))
+    return out
+
+
+def append_scan_q(oracle, gmap, aux, rule, pose, rng, ang, beam_quality, is_occ=None, quality=1.0,
+                  base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), trig=None, est_kind=0,
+                  shift_amount=0.0):
+    """append_scan with a per-point observation quality (the OMQE's values)."""
+    L = oracle.lib
+    L.orc_append_scan_q.restype = C.c_longlong
+    L.orc_append_scan_q.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _ip, C.c_void_p, C.c_double,
+                                    _dp, C.c_double, C.c_double, C.c_int, C.c_double, _dp]
+    rng, ang, pose, b, bq = f64(rng), f64(ang), f64(pose), f64(base), f64(beam_quality)
+    occ = i32(is_occ) if is_occ is not None else np.ones(rng.size, np.int32)
+    m = _map_struct(gmap)
+    ts = _scan_struct(trig or ScanData(rng, ang))
+    res = L.orc_append_scan_q(C.byref(m), _d(gmap.payload), _d(aux) if aux is not None else None, rule, _d(pose),
+                              rng.size, _d(rng), _d(ang), _i(occ), C.byref(ts), quality, _d(b), blur, max_range,
+                              est_kind, shift_amount, _d(bq))
+    if res < 0:
+        raise ValueError("a touched cell lies outside the map window")
+    return int(res)
+
+
 def append_scan_ex(oracle, gmap, aux, rule, pose, rng, ang, is_occ=None, quality=1.0,
                    base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), trig=None,
                    est_kind=0, shift_amount=0.0):

@@ -555,6 +555,40 @@ void ref_append_scan(void *map_h, void *scan_h, double x, double y, double th, d
   adder->append_scan(m, RobotPose{x, y, th}, scan, quality, 0);
 }
 
+// the same with the observation-mapping-quality estimator chosen: omqe 0 = IdleOMQE, 1 = AngleHistogramResiprocalOMQE
+// (grid_map_scan_adders.h:24-43; what init_omqe builds for slam/mapping/observation_quality_estimator/typetype =
+// idle / ahr, init_occupancy_mapping.h:64-80)
+void ref_append_scan_omqe(void *map_h, void *scan_h, double x, double y, double th, double quality,
+                          int occ_est, const double *base4, double blur, double max_range, int omqe) {
+  auto &m = *static_cast<RefMap *>(map_h)->map;
+  auto &scan = static_cast<RefScan *>(scan_h)->scan;
+  std::shared_ptr<CellOccupancyEstimator> est;
+  Occupancy bo{base4[0], base4[1]}, be{base4[2], base4[3]};
+  if (occ_est == 1)
+    est = std::make_shared<AreaOccupancyEstimator>(bo, be);
+  else
+    est = std::make_shared<ConstOccupancyEstimator>(bo, be);
+  std::shared_ptr<ObservationMappingQualityEstimator> q;
+  if (omqe == 1) q = std::make_shared<AngleHistogramResiprocalOMQE>();
+  else q = std::make_shared<IdleOMQE>();
+  auto adder = WallDistanceBlurringScanAdder::builder()
+                   .set_occupancy_estimator(est)
+                   .set_observation_quality_estimator(q)
+                   .set_blur_distance(blur)
+                   .set_max_usable_range(max_range)
+                   .build();
+  adder->append_scan(m, RobotPose{x, y, th}, scan, quality, 0);
+}
+
+// AngleHistogramResiprocalOMQE::quality of every point of the scan (after reset(scan))
+void ref_omqe_quality(void *scan_h, double *out) {
+  auto &scan = static_cast<RefScan *>(scan_h)->scan;
+  AngleHistogramResiprocalOMQE q;
+  q.reset(scan);
+  const auto &pts = scan.points();
+  for (size_t i = 0; i < pts.size(); ++i) out[i] = q.quality(pts, i);
+}
+
 // world_to_cells of a segment (regular_squares_grid.h:56-101); returns count
 int ref_world_to_cells(void *map_h, double x0, double y0, double x1, double y1, int cap,
                        int *out_xy) {

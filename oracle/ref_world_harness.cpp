@@ -32,8 +32,14 @@ namespace {
 
 // preset 0: config/slams/tiny_slam_base.properties (+ tiny_mean_cell, monte_carlo_scan_matching)
 // preset 1: config/slams/viny_slam_base.properties
+// presets 2, 3: the same two with the `ahr` observation quality estimator (AngleHistogramResiprocalOMQE,
+// init_occupancy_mapping.h:64-80 -- the key really is ".../typetype")
 void fill_props(MapPropertiesProvider &p, int preset, int matcher, unsigned seed, int strict, double size_m) {
   auto S = [&](const char *k, const std::string &v) { p.set_property(k, v); };
+  if (preset >= 2) {
+    S("slam/mapping/observation_quality_estimator/typetype", "ahr");
+    preset -= 2;
+  }
   if (preset == 0) {
     S("slam/mapping/blur", "0.5");
     S("slam/occupancy_estimator/type", "const");

@@ -205,6 +205,13 @@ long long orc_append_scan_ex(const orc_map *map, double *payload, double *aux, i
                              int n, const double *range, const double *angle, const int *is_occ,
                              const orc_scan *trig, double scan_quality, const double *base4, double blur,
                              double max_range, int est_kind, double shift_amount);
+/* per-point observation quality (grid_map_scan_adders.h:24-43): kind 0 idle, 1 angle-histogram reciprocal */
+void orc_omqe_quality(int kind, int n, const double *range, const double *angle, double *out);
+/* append_scan with a per-point quality factor (NULL = IdleOMQE) */
+long long orc_append_scan_q(const orc_map *map, double *payload, double *aux, int rule, const double *pose,
+                            int n, const double *range, const double *angle, const int *is_occ,
+                            const orc_scan *trig, double scan_quality, const double *base4, double blur,
+                            double max_range, int est_kind, double shift_amount, const double *beam_quality);
 /* pieces exposed for the known answers of the reference's own unit tests
  * (tests/golden/make_golden_ref_tests.py -> reference_test_vectors.json) */
 int orc_discrete_segment(int bx, int by, int ex, int ey, int cap, int *out_xy);

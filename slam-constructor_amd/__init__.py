@@ -49,7 +49,7 @@ slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begi
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
 slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select
 slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_gmapping_match_abort
-slamhip_gmapping_migration_stats""".split()
+slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality""".split()
 
 SHARD_ID_BYTES = 128
 
@@ -236,6 +236,8 @@ def load():
     L.slamhip_shard_destroy.argtypes = [vp]
     L.slamhip_shard_info.argtypes = [vp, _ip, _ip]
     L.slamhip_shard_allgather.argtypes = [vp, vp, _ip, i, vp]
+    L.slamhip_map_append_scan_q.argtypes = [vp, i, C.POINTER(ScanAdderCfg), _dp, i, _dp, _dp, _dp, _ip, _dp, ll]
+    L.slamhip_omqe_quality.argtypes = [i, i, _dp, _dp, _dp]
     L.slamhip_shard_attach.argtypes = [vp, i, i, vp]
     L.slamhip_shard_exchange.argtypes = [vp, i, vp, i, vp]
     L.slamhip_shard_p2p_stats.argtypes = [vp, ll, ll]
@@ -251,6 +253,14 @@ def load():
     L.slamhip_gmapping_step_sharded.argtypes = [vp, i, i, _dp, _dp, _ip, _dp, C.c_uint32, _ip, up]
     _lib = L
     return L
+
+
+def omqe_quality(kind, rng, ang):
+    """ObservationMappingQualityEstimator::quality per point: kind 0 idle, 1 angle-histogram reciprocal ("ahr")."""
+    rng, ang = _f64(rng), _f64(ang)
+    out = np.zeros(rng.size)
+    _check(load().slamhip_omqe_quality(int(kind), rng.size, _d(rng), _d(ang), _d(out)))
+    return out
 
 
 def shard_unique_id():
@@ -416,18 +426,20 @@ class Context:
 
     def map_append_scan(self, map_id, rule, pose, rng, cos_a, sin_a, is_occ=None, quality=1.0,
                         base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), estimator=0,
-                        shift_amount=0.0):
+                        shift_amount=0.0, beam_quality=None):
         """GridMapScanAdder::append_scan on the HBM mirror (estimator 0 const, 1 area); returns the
-        number of cell updates."""
+        number of cell updates.  beam_quality: the observation quality estimator's value per point (omqe_quality)."""
         cfg = ScanAdderCfg(rule, quality, base[0], base[1], base[2], base[3], blur, max_range,
                            estimator, shift_amount)
         rng, cos_a, sin_a, pose = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(pose)
         occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        bq = _f64(beam_quality) if beam_quality is not None else None
+        assert bq is None or bq.size == rng.size
         nu = C.c_longlong(0)
-        _check(self.L.slamhip_map_append_scan(self.h, map_id, C.byref(cfg), _d(pose), rng.size, _d(rng),
-                                              _d(cos_a), _d(sin_a),
-                                              occ.ctypes.data_as(_ip) if occ is not None else None,
-                                              C.byref(nu)))
+        _check(self.L.slamhip_map_append_scan_q(self.h, map_id, C.byref(cfg), _d(pose), rng.size, _d(rng),
+                                                _d(cos_a), _d(sin_a),
+                                                occ.ctypes.data_as(_ip) if occ is not None else None,
+                                                _d(bq) if bq is not None else None, C.byref(nu)))
         return nu.value
 
     def map_download_aux(self, map_id, x0, y0, w, h, stride):

@@ -106,6 +106,7 @@ struct MuScratch {
   bool reuse_ok = false;
   const double *last_range = nullptr, *last_cos = nullptr, *last_sin = nullptr;
   const int *last_occ = nullptr;
+  const double *last_quality = nullptr;
   int last_n = -1;
 };
 // one scratch set per context, owned by it (contexts are independent: one caller thread each, and a
@@ -211,6 +212,13 @@ extern "C" {
 int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
                             const double pose[3], int n, const double *range, const double *cos_a,
                             const double *sin_a, const int *is_occ, long long *n_updates_out) {
+  return slamhip_map_append_scan_q(ctx, map_id, cfg, pose, n, range, cos_a, sin_a, is_occ, nullptr, n_updates_out);
+}
+
+int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
+                              const double pose[3], int n, const double *range, const double *cos_a,
+                              const double *sin_a, const int *is_occ, const double *quality,
+                              long long *n_updates_out) {
   if (!ctx || !cfg || !pose || !range || !cos_a || !sin_a) return fail("null argument");
   if (map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound) return fail("unknown map id");
   if (n <= 0) {
@@ -248,7 +256,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMalloc(&sc.offsets, sizeof(unsigned) * (cap + 1)));
     SLAMHIP_CHECK(hipMalloc(&sc.beam_end, sizeof(double) * 4 * cap));  // end point + (1/dx, 1/dy)
     SLAMHIP_CHECK(hipMalloc(&sc.beam_info, sizeof(MuBeam) * cap));
-    SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 3 * cap));
+    SLAMHIP_CHECK(hipMalloc(&sc.scan, sizeof(double) * 4 * cap));  // range | cos | sin | per-point quality
     SLAMHIP_CHECK(hipMalloc(&sc.occ, sizeof(int) * cap));
     if (!sc.error_flag) {
       SLAMHIP_CHECK(hipMalloc(&sc.error_flag, sizeof(int)));
@@ -266,7 +274,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     sc.h_scan_stage = nullptr;
     sc.h_occ_stage = nullptr;
     if (cap <= 8192) {
-      SLAMHIP_CHECK(hipHostMalloc(&sc.h_scan_stage, sizeof(double) * 3 * cap * kRing, hipHostMallocDefault));
+      SLAMHIP_CHECK(hipHostMalloc(&sc.h_scan_stage, sizeof(double) * 4 * cap * kRing, hipHostMallocDefault));
       SLAMHIP_CHECK(hipHostMalloc(&sc.h_occ_stage, sizeof(int) * cap * kRing, hipHostMallocDefault));
     }
     if (!sc.near_bits)
@@ -286,7 +294,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   // the GMapping filter appends the SAME raw scan once per particle: it brackets its loop with
   // mu_allow_scan_reuse(), and identical host arrays are then uploaded only once
   const bool reuse = sc.reuse_ok && sc.last_range == range && sc.last_cos == cos_a && sc.last_sin == sin_a &&
-                     sc.last_occ == is_occ && sc.last_n == n;
+                     sc.last_occ == is_occ && sc.last_n == n && !quality && !sc.last_quality;
   const bool deferred = sc.deferred && ctx->low_latency && sc.offset_slots == kRing;
   if (deferred && sc.pending == kRing) {  // every slot of the ring is taken: collect first
     long long dn = 0;
@@ -299,11 +307,12 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   if (!reuse && sc.h_scan_stage) {
     // (slot `pending` while updates are queued -- its last user has been drained; slot 0 otherwise: awaited)
     const size_t slot = deferred ? (size_t)sc.pending : 0;
-    double *st = sc.h_scan_stage + slot * 3 * cb;
+    double *st = sc.h_scan_stage + slot * 4 * cb;
     std::memcpy(st, range, sizeof(double) * n);
     std::memcpy(st + cb, cos_a, sizeof(double) * n);
     std::memcpy(st + 2 * cb, sin_a, sizeof(double) * n);
-    SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, st, sizeof(double) * (2 * cb + n), hipMemcpyHostToDevice, ctx->stream));
+    if (quality) std::memcpy(st + 3 * cb, quality, sizeof(double) * n);
+    SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, st, sizeof(double) * ((quality ? 3 : 2) * cb + n), hipMemcpyHostToDevice, ctx->stream));
     if (is_occ) {
       int *so = sc.h_occ_stage + slot * cb;
       std::memcpy(so, is_occ, sizeof(int) * n);
@@ -313,6 +322,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     SLAMHIP_CHECK(hipMemcpyAsync(sc.scan, range, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + cb, cos_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 2 * cb, sin_a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (quality) SLAMHIP_CHECK(hipMemcpyAsync(sc.scan + 3 * cb, quality, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (is_occ) SLAMHIP_CHECK(hipMemcpyAsync(sc.occ, is_occ, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
   }
   if (!reuse) {
@@ -321,6 +331,7 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
     sc.last_sin = sin_a;
     sc.last_occ = is_occ;
     sc.last_n = n;
+    sc.last_quality = quality;
   }
 
   MuArgs a;
@@ -343,6 +354,9 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
   a.cos_a = sc.scan + cb;
   a.sin_a = sc.scan + 2 * cb;
   a.is_occ = is_occ ? sc.occ : nullptr;
+  // per-point observation quality (ObservationMappingQualityEstimator::quality, grid_map_scan_adders.h:17-43):
+  // a cell update's quality is scan_quality x the value of ITS beam; null = IdleOMQE
+  a.beam_quality = quality ? sc.scan + 3 * cb : nullptr;
   a.n = n;
   a.px = pose[0];
   a.py = pose[1];

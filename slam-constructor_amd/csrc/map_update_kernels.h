@@ -36,6 +36,7 @@ struct MuArgs {
   // scan
   const double *range, *cos_a, *sin_a;
   const int *is_occ;
+  const double *beam_quality;  // per beam: the OMQE's value (plain calls only); null = 1.0 for every beam
   int n;
   double px, py, sn, cs;  // pose, sin/cos of its heading (host sincos)
   // adder
@@ -728,22 +729,23 @@ struct MuCell {
 // (GridCell grid_cell.h:27-30, AffineQualityMergeCell / MeanProbabilityCell naive_grid_cells.h:14-20,33-40,
 // TbmBaseCell tbm_grid_cells.h:57-66, GmappingBaseCell gmapping_grid_cell.h:20-33).  `qual` is read for
 // TBM cells only; `obst(&x, &y)` fetches the observation's obstacle point, GMapping hits only.
+// `quality` = scan quality x the observation-quality estimator's value for the record's beam (rules 1..3 read it)
 template <int RULE, typename Obst>
-__device__ __forceinline__ void mu_step(const MuArgs &a, MuCell &c, double prob, double qual, Obst obst) {
+__device__ __forceinline__ void mu_step(double quality, MuCell &c, double prob, double qual, Obst obst) {
   if (RULE == 0) {  // GridCell / MockGridCell: last write wins
     c.c0 = prob;
   } else if (RULE == 1) {  // AffineQualityMergeCell
     if (isnan(prob)) return;
-    c.c0 = (1.0 - a.quality) * c.c0 + a.quality * prob;
+    c.c0 = (1.0 - quality) * c.c0 + quality * prob;
   } else if (RULE == 2) {  // MeanProbabilityCell: x0 = _n
     if (isnan(prob)) return;
     const double n1 = c.x0 + 1;
-    const double that_p = 0.5 + (prob - 0.5) * a.quality;
+    const double that_p = 0.5 + (prob - 0.5) * quality;
     c.c0 = (c.c0 * c.x0 + that_p) / n1;
     c.x0 = n1;
   } else if (RULE == 3) {  // TbmBaseCell
     if (isnan(prob) || isnan(qual)) return;
-    const double eq = qual * a.quality;
+    const double eq = qual * quality;
     const double occupied = prob * eq, empty = (1 - prob) * eq;
     const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
     const double cur[4] = {c.c0, c.c1, c.c2, c.c3};
@@ -1024,6 +1026,10 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
       const Key k = in ? keys[j] : kInvalid;
       const double p = in ? a.rec_prob[j] : 0.0;
       const double q = (RULE == 3 && in) ? a.rec_qual[j] : 0.0;
+      // this record's update quality: scan quality x its beam's (uniform branch: a kernel argument)
+      constexpr bool kReadsQuality = RULE >= 1 && RULE <= 3;
+      double ql = a.quality;
+      if (kReadsQuality && a.beam_quality && in) ql = a.quality * a.beam_quality[a.rec_beam[j]];
       const unsigned long long m = __ballot(in && k == hkey);
       const int n_here = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
       double ox = 0.0, oy = 0.0;
@@ -1046,7 +1052,7 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
         // The round takes this form only when every operand stays inside the range where the division's scaling
         // steps do nothing (all p' in 2^-400 .. 2^400, none NaN, the mean non-negative and below 2^400: the mean is
         // then a convex combination of such values all along); otherwise mu_step's plain divisions below.
-        const double tp = 0.5 + (p - 0.5) * a.quality;  // mu_step's that_p, per lane
+        const double tp = 0.5 + (p - 0.5) * ql;  // mu_step's that_p, per lane
         const bool mine = lane < n_here;
         const bool fine = !mine || (tp > 0x1p-400 && tp < 0x1p400);
         if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52) {
@@ -1076,7 +1082,8 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
             continue;
           }
         }
-        mu_step<RULE>(a, c, mu_readlane(p, t), RULE == 3 ? mu_readlane(q, t) : 0.0, [&](double *x, double *y) {
+        const double qt = (kReadsQuality && a.beam_quality) ? mu_readlane(ql, t) : a.quality;
+        mu_step<RULE>(qt, c, mu_readlane(p, t), RULE == 3 ? mu_readlane(q, t) : 0.0, [&](double *x, double *y) {
           *x = mu_readlane(ox, t);
           *y = mu_readlane(oy, t);
         });
@@ -1101,6 +1108,9 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
   const Key key = in ? keys[i] : kInvalid;
   const double p = in ? a.rec_prob[i] : 0.0;
   const double q = (RULE == 3 && in) ? a.rec_qual[i] : 0.0;
+  constexpr bool kReadsQuality = RULE >= 1 && RULE <= 3;
+  double ql = a.quality;  // this record's update quality: scan quality x its beam's
+  if (kReadsQuality && a.beam_quality && in) ql = a.quality * a.beam_quality[a.rec_beam[i]];
   Key prev = __shfl_up(key, 1, 64);
   if (lane == 0) prev = (in && i > 0) ? keys[i - 1] : kInvalid;
   const bool start = !in || i == 0 || prev != key;  // first record of a run of equal keys
@@ -1128,8 +1138,9 @@ __global__ __launch_bounds__(256) void k_mu_apply(MuArgs a, const Key *keys, uns
   for (int t = 0; __any(head && t < len_here); ++t) {
     const double pt = __shfl(p, lane + t, 64);
     const double qt = RULE == 3 ? __shfl(q, lane + t, 64) : 0.0;
+    const double qlt = (kReadsQuality && a.beam_quality) ? __shfl(ql, lane + t, 64) : a.quality;
     if (head && t < len_here)
-      mu_step<RULE>(a, c, pt, qt, [&](double *x, double *y) {
+      mu_step<RULE>(qlt, c, pt, qt, [&](double *x, double *y) {
         const unsigned b = a.rec_beam[i + t];
         *x = a.beam_end[2 * b];
         *y = a.beam_end[2 * b + 1];

@@ -979,6 +979,19 @@ int slamhip_scan_weights(int kind, int n, const double *range, const double *ang
   return invalid("unknown weighting kind");
 }
 
+// ObservationMappingQualityEstimator::quality (grid_map_scan_adders.h:17-43): IdleOMQE, or
+// AngleHistogramResiprocalOMQE = 1 / AngleHistogram::value -- the arithmetic of the `ahr` scan-point weighting above
+// (weighted_mean_point_probability_spe.h:34-45 is the same reciprocal of the same histogram)
+int slamhip_omqe_quality(int kind, int n, const double *range, const double *angle, double *out) {
+  if (n < 0 || !range || !angle || !out) return invalid("bad arguments");
+  if (kind == 0) {
+    for (int i = 0; i < n; ++i) out[i] = 1.0;
+    return SLAMHIP_OK;
+  }
+  if (kind == 1) return slamhip_scan_weights(2, n, range, angle, out);
+  return invalid("unknown observation quality estimator");
+}
+
 // ---------------------------------------------------------------------------------- scoring
 int slamhip_score_poses(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
                         const double *poses_xyt, double *scores_out) {

@@ -34,6 +34,7 @@ public:
     double unknown[4] = {0.5, 0, 0, 0};  // the cell prototype's payload
     int map_id = 0;
     int tbm_kind = 0;  // TBM cells: 0 tbm_consistent, 1 tbm_unknown_even_occ (what map() reports as occupancy)
+    int omqe = 0;      // observation quality estimator (init_omqe): 0 idle, 1 ahr (AngleHistogramResiprocalOMQE)
     HipScanTrig trig{};
   };
   HipResidentWorld(slamhip_ctx *ctx, std::shared_ptr<HipGridScanMatcher> gsm, const Config &cfg)
@@ -68,19 +69,38 @@ public:
     update_robot_pose(pose_delta);
     tr_scan.quality = pose_delta ? _cfg.localized_scan_quality : _cfg.raw_scan_quality;
 
-    // GridMapScanAdder::append_scan (grid_map_scan_adders.h:54-75): the points [margin, n - margin - 1]
+    // GridMapScanAdder::append_scan (grid_map_scan_adders.h:54-75): the points [margin, n - margin - 1]; the
+    // observation quality estimator is reset on the WHOLE scan and asked per point index (:63-71)
     const auto &pts = tr_scan.scan.points();
     if (pts.empty()) return;
     const size_t first = _cfg.scan_margin, last = pts.size() - _cfg.scan_margin - 1;
-    std::vector<double> r, a;
-    std::vector<int> occ;
+    std::vector<double> &r = _r, &a = _a, &q = _q;
+    std::vector<int> &occ = _occ;
+    r.clear();
+    a.clear();
+    occ.clear();
+    q.clear();
+    if (_cfg.omqe) {
+      _all_r.resize(pts.size());
+      _all_a.resize(pts.size());
+      _all_q.resize(pts.size());
+      for (size_t i = 0; i < pts.size(); ++i) {
+        _all_r[i] = pts[i].range();
+        _all_a[i] = pts[i].angle();
+      }
+      slamhip_or_die(slamhip_omqe_quality(_cfg.omqe, (int)pts.size(), _all_r.data(), _all_a.data(), _all_q.data()),
+                     "omqe_quality");
+    }
     for (size_t i = first; i <= last && i < pts.size(); ++i) {
       r.push_back(pts[i].range());
       a.push_back(pts[i].angle());
       occ.push_back(pts[i].is_occupied() ? 1 : 0);
+      if (_cfg.omqe) q.push_back(_all_q[i]);
     }
     const int n = (int)r.size();
-    std::vector<double> c(n), s(n);
+    std::vector<double> &c = _c, &s = _s;
+    c.resize(n);
+    s.resize(n);
     if (_cfg.trig.mode == SLAMHIP_TRIG_CACHED)
       slamhip_or_die(slamhip_beam_trig_cached(n, a.data(), _cfg.trig.a_min, _cfg.trig.a_max, _cfg.trig.a_inc, c.data(),
                                               s.data()), "beam_trig_cached");
@@ -91,8 +111,8 @@ public:
     const RobotPose p = pose();
     const double p3[3] = {p.x, p.y, p.theta};
     long long nu = 0;
-    slamhip_or_die(slamhip_map_append_scan(_ctx, _cfg.map_id, &adder, p3, n, r.data(), c.data(), s.data(), occ.data(),
-                                           &nu), "map_append_scan");
+    slamhip_or_die(slamhip_map_append_scan_q(_ctx, _cfg.map_id, &adder, p3, n, r.data(), c.data(), s.data(), occ.data(),
+                                             _cfg.omqe ? q.data() : nullptr, &nu), "map_append_scan");
     if (nu > 0) _cell_updates += nu;  // (-1: queued, counted by cell_updates())
     _view->invalidate();
   }
@@ -103,6 +123,8 @@ private:
   Config _cfg;
   std::shared_ptr<HipResidentMapView> _view;
   long long _cell_updates = 0;
+  std::vector<double> _r, _a, _q, _c, _s, _all_r, _all_a, _all_q;  // per-scan buffers, kept between scans
+  std::vector<int> _occ;
 };
 
 // the factory next to init_1h_slam (src/utils/init_slam.h:12-25): same properties
@@ -150,10 +172,13 @@ inline std::shared_ptr<HipResidentWorld> init_hip_resident_1h_slam(const Propert
     std::exit(-1);
   }
   cfg.adder.occupancy_estimator = est == "area" ? 1 : 0;
-  if (props.get_str("slam/mapping/observation_quality_estimator/typetype", "idle") != "idle") {
-    std::cerr << "only the idle observation-quality estimator is on the HIP path" << std::endl;
+  // init_omqe (init_occupancy_mapping.h:64-80; the key really ends in "typetype")
+  const auto omqe = props.get_str("slam/mapping/observation_quality_estimator/typetype", "idle");
+  if (omqe != "idle" && omqe != "ahr") {
+    std::cerr << "[ERROR] Unknown OMQE type: " << omqe << std::endl;
     std::exit(-1);
   }
+  cfg.omqe = omqe == "ahr" ? 1 : 0;
   cfg.adder.blur = props.get_dbl("slam/mapping/blur", 0.0);
   cfg.adder.max_range = props.get_dbl("slam/mapping/max_range", std::numeric_limits<double>::infinity());
   cfg.adder.scan_quality = 1.0;

@@ -189,3 +189,41 @@ def test_counting_sorted_and_radix_sorted_updates_agree(pkg, ctx):
     assert nu == nu_o
     np.testing.assert_array_equal(ctx.map_download_window(2, 0, 0, size, size, 1), big.payload)
     ctx.map_release(2)
+
+
+@pytest.mark.parametrize("sort", ["counting", "radix"])
+@pytest.mark.parametrize("name", ["mean", "affine", "tbm", "gmapping"])
+def test_append_scan_with_per_point_quality_vs_reference_golden(pkg, name, sort, monkeypatch):
+    """The `ahr` observation quality estimator (AngleHistogramResiprocalOMQE, grid_map_scan_adders.h:32-43; selected by
+    slam/mapping/observation_quality_estimator/typetype, init_occupancy_mapping.h:64-80): K6 with a per-point quality
+    (slamhip_map_append_scan_q + slamhip_omqe_quality) against maps exported from the compiled reference running that
+    estimator (tests/golden/make_golden_omqe.py), both sorting paths, bit for bit (GMapping obstacle means to the
+    raw-provider ulp of the idle golden)."""
+    if sort == "radix":
+        monkeypatch.setenv("SLAMHIP_K6_SORT", "radix")
+    g = load("map_update_ahr.npz")
+    cell_model, rule = MODELS[name]
+    w, h = [int(v) for v in g[name + "_size"]]
+    st = STRIDE[cell_model]
+    unk = g[name + "_unknown"]
+    ctx = pkg.Context(0)
+    ctx.map_bind(2, cell_model, w, h, g[name + "_origin"], float(g["scale"]), unk[:st])
+    lo, hi = [int(v) for v in g["crop"]]
+    for k in range(int(g["n_steps"])):
+        q, blur, max_range = g["step%d_params" % k]
+        c, s = pkg.beam_trig(g["step%d_angle" % k])
+        bq = pkg.omqe_quality(1, g["step%d_range" % k], g["step%d_angle" % k])
+        np.testing.assert_array_equal(bq, g["step%d_quality" % k])
+        ctx.map_append_scan(2, rule, g["step%d_pose" % k], g["step%d_range" % k], c, s, g["step%d_occ" % k], quality=q,
+                            base=g[name + "_base"], blur=blur, max_range=max_range, beam_quality=bq)
+        got = ctx.map_download_window(2, lo, lo, hi - lo, hi - lo, st)
+        want = g["%s_step%d_payload" % (name, k)]
+        if name == "gmapping":
+            np.testing.assert_array_equal(got[..., 0], want[..., 0])
+            np.testing.assert_allclose(got[..., 1:], want[..., 1:], rtol=1e-13, atol=1e-15)
+        else:
+            np.testing.assert_array_equal(got, want, err_msg="%s step %d" % (name, k))
+        if rule in AUX:
+            np.testing.assert_array_equal(ctx.map_download_aux(2, lo, lo, hi - lo, hi - lo, AUX[rule]),
+                                          g["%s_step%d_aux" % (name, k)])
+    ctx.close()

@@ -81,3 +81,26 @@ def test_gmapping_filter_with_map_update_vs_reference(oracle):
         np.testing.assert_array_equal(wts, g["step%d_weights" % k])
         np.testing.assert_array_equal(m.payload, g["step%d_payload" % k])
         np.testing.assert_array_equal(aux, g["step%d_aux" % k])
+
+
+@pytest.mark.parametrize("name", ["mean", "affine", "tbm", "gmapping"])
+def test_append_scan_with_per_point_quality_vs_reference(oracle, name):
+    """AngleHistogramResiprocalOMQE (grid_map_scan_adders.h:32-43, init_occupancy_mapping.h:64-80: the `ahr` observation
+    quality estimator): the per-point qualities and the maps after each scan against the compiled reference
+    (tests/golden/make_golden_omqe.py), bit for bit."""
+    from pyoracle_mapupdate import append_scan_q, omqe_quality
+    g = load("map_update_ahr.npz")
+    m, aux, rule = fresh_map(g, name)
+    lo, hi = g["crop"]
+    for k in range(int(g["n_steps"])):
+        q, blur, max_range = g["step%d_params" % k]
+        bq = omqe_quality(oracle, 1, g["step%d_range" % k], g["step%d_angle" % k])
+        np.testing.assert_array_equal(bq, g["step%d_quality" % k])
+        assert bq.min() < 0.5 * bq.max()  # the estimator really distinguishes points
+        append_scan_q(oracle, m, aux, rule, g["step%d_pose" % k], g["step%d_range" % k], g["step%d_angle" % k], bq,
+                      g["step%d_occ" % k], quality=q, base=g[name + "_base"], blur=blur, max_range=max_range)
+        np.testing.assert_array_equal(m.payload[lo:hi, lo:hi], g["%s_step%d_payload" % (name, k)], err_msg="step %d" % k)
+        if aux is not None:
+            np.testing.assert_array_equal(aux[lo:hi, lo:hi], g["%s_step%d_aux" % (name, k)])
+    # (idle estimator: all ones)
+    assert np.array_equal(omqe_quality(oracle, 0, g["step0_range"], g["step0_angle"]), np.ones(g["step0_range"].size))
