@@ -64,6 +64,7 @@ struct MuJob {
 }  // namespace slamhip
 
 #include "map_update_kernels.h"
+#include "map_update_gather.h"
 
 using namespace slamhip;
 
@@ -92,6 +93,17 @@ struct MuScratch {
   int *h_occ_stage = nullptr;
   unsigned long long *near_bits = nullptr;  // [kNearSide^2][64] words: beams (up to 4096) visiting the cells next to the robot
   void *scan_temp = nullptr;
+  // the gather form of a plain call (map_update_gather.h): per-beam closed forms, the irregular-cell bitmap of the key
+  // window (all zero between updates), the workgroup counter of k_mu_cells, and what is known about the scanner's
+  // beam directions -- analysed when they change (a scanner's angles do not change from scan to scan)
+  int force_path = -1;  // -1: SLAMHIP_K6_SORT decides (unset: the fastest that applies); 0 auto, 1 counting, 2 radix
+  MuLine *lines = nullptr;
+  size_t cap_lines = 0, cap_irr_words = 0;
+  unsigned *irr_bits = nullptr, *done_count = nullptr, *d_lut = nullptr;
+  std::vector<double> geo_cos, geo_sin;
+  bool geo_ok = false;
+  double geo_a0 = 0.0;
+  int geo_near_r = 8;
   // deferred completion (mu_set_deferred): updates are queued without waiting for them; their status words land in
   // a pinned ring and are summed up by mu_drain
   bool deferred = false;
@@ -207,6 +219,56 @@ int mu_finish(slamhip_ctx *ctx, const int *d_error_flag, const unsigned long lon
 }
 }  // namespace
 
+// The gather form needs the scan's beam directions in ascending order over less than a full turn (a laser scan's
+// are), and a table from direction to beam index.  Both depend on the scanner only: analysed when cos_a / sin_a differ
+// from the last call's (a 17 KB compare per update), not per scan.
+int mu_scan_geometry(slamhip_ctx *ctx, MuScratch &sc, int n, const double *cos_a, const double *sin_a, bool *ok) {
+  if ((int)sc.geo_cos.size() == n && std::memcmp(sc.geo_cos.data(), cos_a, sizeof(double) * n) == 0 &&
+      std::memcmp(sc.geo_sin.data(), sin_a, sizeof(double) * n) == 0) {
+    *ok = sc.geo_ok;
+    return SLAMHIP_OK;
+  }
+  sc.geo_cos.assign(cos_a, cos_a + n);
+  sc.geo_sin.assign(sin_a, sin_a + n);
+  sc.geo_ok = false;
+  *ok = false;
+  std::vector<double> rel(n);
+  double prev = 0.0, a0 = 0.0;
+  for (int b = 0; b < n; ++b) {
+    double ang = std::atan2(sin_a[b], cos_a[b]);
+    if (!std::isfinite(ang)) return SLAMHIP_OK;
+    if (b == 0) {
+      a0 = ang;
+      rel[0] = 0.0;
+      prev = ang;
+      continue;
+    }
+    while (ang < prev - 1e-12) ang += kTwoPi;  // unwrap: ascending
+    if (!(ang >= prev) || ang - a0 >= kTwoPi - 0.05) return SLAMHIP_OK;  // not ascending within one turn
+    rel[b] = ang - a0;
+    prev = ang;
+  }
+  std::vector<unsigned> lut(kGatherLut + 1);
+  int b = 0;
+  for (int m = 0; m <= kGatherLut; ++m) {
+    const double edge = (double)m * (kTwoPi / kGatherLut);
+    while (b < n && rel[b] < edge) ++b;
+    lut[m] = (unsigned)b;
+  }
+  if (!sc.d_lut) SLAMHIP_CHECK(hipMalloc(&sc.d_lut, sizeof(unsigned) * (kGatherLut + 1)));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));  // (queued updates may still read the old table)
+  SLAMHIP_CHECK(hipMemcpy(sc.d_lut, lut.data(), sizeof(unsigned) * (kGatherLut + 1), hipMemcpyHostToDevice));
+  sc.geo_a0 = a0;
+  // cells closer to the robot than this take one wave each: beyond it a cell asks at most ~50 beams
+  const double span = n > 1 ? rel[n - 1] : 1.0;
+  const double density = n > 1 && span > 0 ? (double)(n - 1) / span : 1.0;  // beams per radian
+  const double half_window = std::min(1.5, 24.0 / density);
+  sc.geo_near_r = std::max(2, std::min(kNearR, (int)std::ceil(0.75 / std::sin(half_window))));
+  sc.geo_ok = true;
+  *ok = true;
+  return SLAMHIP_OK;
+}
+
 extern "C" {
 
 int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
@@ -279,7 +341,10 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
     }
     if (!sc.near_bits)
       SLAMHIP_CHECK(hipMalloc(&sc.near_bits, sizeof(unsigned long long) * kNearSide * kNearSide * kNearMaxWords));
-    if (!sc.n_updates) SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+    if (!sc.n_updates) {
+      SLAMHIP_CHECK(hipMalloc(&sc.n_updates, sizeof(unsigned long long)));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.n_updates, 0, sizeof(unsigned long long), ctx->stream));
+    }
     if (!sc.h_status) SLAMHIP_CHECK(hipHostMalloc(&sc.h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault));
     if (!sc.h_ring) SLAMHIP_CHECK(hipHostMalloc(&sc.h_ring, 2 * kRing * sizeof(unsigned long long), hipHostMallocDefault));
     if (!sc.d_ring_err) {
@@ -491,7 +556,11 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
   // between its two ends; cells outside the map become padding).  Small enough -- a few hundred thousand cells for
   // a laser's reach -- the records are counting-sorted over it; otherwise keys are cells of the whole map and
   // rocprim sorts them (SLAMHIP_K6_SORT=radix forces that path: the parity tests run both).
-  static const bool force_radix = getenv("SLAMHIP_K6_SORT") && std::strcmp(getenv("SLAMHIP_K6_SORT"), "radix") == 0;
+  if (sc.force_path < 0) {
+    const char *e = getenv("SLAMHIP_K6_SORT");
+    sc.force_path = (e && std::strcmp(e, "radix") == 0) ? 2 : ((e && std::strcmp(e, "counting") == 0) ? 1 : 0);
+  }
+  const bool force_radix = sc.force_path == 2;
   const long long wx0 = std::max(0ll, (long long)bb_lo_x + m.origin_x), wy0 = std::max(0ll, (long long)bb_lo_y + m.origin_y);
   const long long wx1 = std::min((long long)m.width - 1, (long long)bb_hi_x + m.origin_x);
   const long long wy1 = std::min((long long)m.height - 1, (long long)bb_hi_y + m.origin_y);
@@ -513,6 +582,106 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
                                           ctx->stream));
     SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, sc.scan_temp_bytes));
     sc.cap_bins = cap;
+  }
+  // The GATHER form (map_update_gather.h, the default wherever it applies): two kernels, no records.  SLAMHIP_K6_SORT =
+  // counting / radix keep the record pipelines (the parity tests run all three).
+  const bool force_counting = sc.force_path == 1;
+  bool gather = counting && !force_counting && ctx->low_latency && n <= 4096;
+  if (gather) {
+    const int grc = mu_scan_geometry(ctx, sc, n, cos_a, sin_a, &gather);
+    if (grc) return grc;
+  }
+  if (gather) {
+    if ((size_t)n > sc.cap_lines) {
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (sc.lines) hipFree(sc.lines);
+      sc.lines = nullptr;
+      SLAMHIP_CHECK(hipMalloc(&sc.lines, sizeof(MuLine) * sc.cap_beams));
+      sc.cap_lines = sc.cap_beams;
+    }
+    const size_t words = ((size_t)n_bins + 31) / 32 + 1;
+    if (words > sc.cap_irr_words) {
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (sc.irr_bits) hipFree(sc.irr_bits);
+      sc.irr_bits = nullptr;
+      size_t cap = 1 << 14;
+      while (cap < words) cap *= 2;
+      SLAMHIP_CHECK(hipMalloc(&sc.irr_bits, sizeof(unsigned) * cap));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.irr_bits, 0, sizeof(unsigned) * cap, ctx->stream));
+      sc.cap_irr_words = cap;
+    }
+    if (!sc.done_count) {
+      SLAMHIP_CHECK(hipMalloc(&sc.done_count, sizeof(unsigned)));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.done_count, 0, sizeof(unsigned), ctx->stream));
+    }
+    a.key_x0 = (int)wx0;
+    a.key_y0 = (int)wy0;
+    a.key_w = (int)(wx1 - wx0 + 1);
+    a.key_h = (int)(wy1 - wy0 + 1);
+    a.n_bins = (unsigned)n_bins;
+    a.bins = nullptr;
+    a.near_bits = nullptr;
+    a.near_r = sc.geo_near_r;
+    a.robot_ix = (int)std::floor(a.px / a.scale) + m.origin_x;
+    a.robot_iy = (int)std::floor(a.py / a.scale) + m.origin_y;
+    a.lines = sc.lines;
+    a.lut = sc.d_lut;
+    a.lut_bins = kGatherLut;
+    a.theta = pose[2];
+    a.rel_a0 = sc.geo_a0;
+    a.irr_bits = sc.irr_bits;
+    a.done_count = sc.done_count;
+    if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_lines<1>, dim3(n), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_mu_lines<0>, dim3(n), dim3(256), 0, ctx->stream, a);
+    const unsigned far_blocks = (unsigned)(((a.key_w + 63) / 64) * ((a.key_h + 3) / 4));
+    const unsigned side = 2u * (unsigned)a.near_r + 1u, near_blocks = (side * side + 3u) / 4u;
+    unsigned seq = 0;
+    unsigned long long *h_status = nullptr;
+    if (!deferred) {
+      seq = ++ctx->seq;
+      if (seq == 0) seq = ++ctx->seq;
+      h_status = sc.h_status;
+    }
+    const dim3 cgrid(far_blocks + near_blocks), cblock(256);
+#define SLAMHIP_MU_CELLS(R)                                                                                          \
+  case R:                                                                                                            \
+    if (a.est_kind == 1)                                                                                             \
+      hipLaunchKernelGGL((k_mu_cells<R, 1>), cgrid, cblock, 0, ctx->stream, a, far_blocks, h_status, ctx->h_done_flag, seq); \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_mu_cells<R, 0>), cgrid, cblock, 0, ctx->stream, a, far_blocks, h_status, ctx->h_done_flag, seq); \
+    break;
+    switch (a.rule) {
+      SLAMHIP_MU_CELLS(0)
+      SLAMHIP_MU_CELLS(1)
+      SLAMHIP_MU_CELLS(2)
+      SLAMHIP_MU_CELLS(3)
+      default:
+        SLAMHIP_MU_CELLS(4)
+    }
+#undef SLAMHIP_MU_CELLS
+    SLAMHIP_CHECK(hipGetLastError());
+    if (prof.on()) {
+      const int prc = prof.close();
+      if (prc) return prc;
+      ctx->prof_k6_calls += 1;
+      ctx->prof_k6_records += total;
+    }
+    if (deferred) {
+      sc.ring_total[sc.pending] = total;
+      ++sc.pending;
+      if (n_updates_out) *n_updates_out = -1;
+      return SLAMHIP_OK;
+    }
+    const int wrc = score_wait(ctx, seq);
+    if (wrc) return wrc;
+    const int gerr = (int)((volatile unsigned long long *)sc.h_status)[0];
+    const unsigned long long gpad = ((volatile unsigned long long *)sc.h_status)[1];
+    if (n_updates_out) *n_updates_out = (long long)((unsigned long long)total - gpad);
+    if (gerr == 2) return fail("internal: the device counted more cell updates than the host sized the buffers for", SLAMHIP_ERR_STATE);
+    if (gerr)
+      return fail("a beam leaves the bound map window: grow the map (slamhip_map_bind) before updating; "
+                  "cells inside the window were updated", SLAMHIP_ERR_STATE);
+    return SLAMHIP_OK;
   }
   if (counting && !sc.srec) SLAMHIP_CHECK(hipMalloc(&sc.srec, sizeof(uint2) * sc.cap_records));
   if (counting) {
@@ -598,6 +767,15 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
   if (err)
     return fail("a beam leaves the bound map window: grow the map (slamhip_map_bind) before updating; "
                 "cells inside the window were updated", SLAMHIP_ERR_STATE);
+  return SLAMHIP_OK;
+}
+
+// testing aid, not part of include/slamhip.h: which pipeline plain map updates of this context take -- 0 the default
+// (gather where it applies, else counting sort, else radix sort), 1 counting sort, 2 radix sort.  The environment
+// variable SLAMHIP_K6_SORT = counting / radix sets the same for a whole process.
+int slamhip_map_debug_k6_path(slamhip_ctx *ctx, int path) {
+  if (!ctx || path < 0 || path > 2) return fail("bad K6 path");
+  scratch_of(ctx).force_path = path;
   return SLAMHIP_OK;
 }
 

@@ -71,6 +71,23 @@ struct MuArgs {
   unsigned *special;
   double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
   int fresh_ok;
+  // plain call, GATHER form (map_update_gather.h): one thread per cell of the key window asks the beams around its
+  // direction whether their walk visits it -- no keys, no sort
+  struct MuLine *lines;        // per beam: the closed form of its walk
+  const unsigned *lut;         // lut[m] = beams whose angle relative to beam 0 is below m * 2 pi / lut_bins
+  int lut_bins, key_h;
+  double theta, rel_a0;        // pose heading; angle of beam 0 in the sensor frame
+  unsigned *irr_bits;          // one bit per window cell: an IRREGULAR beam (sequential walk) has a record there
+  unsigned *done_count;        // workgroups of k_mu_cells that are through (the last one hands the status over)
+};
+
+// the walk of one beam in closed form (see k_mu_emit): step k stands on the cell i_k = k - j_k steps in x and
+// j_k = clamp(floor((q0 + k absA) invW), 0, k) steps in y from the robot's cell.  ok: the form was checked against
+// the recurrence step by step; otherwise the beam's cells are the keys its sequential walk left in MuArgs::keys.
+struct MuLine {
+  double q0, absA, invW;
+  unsigned cap;    // cells of the walk (0: the beam is range-gated)
+  unsigned flags;  // 1: ok, 2: x grows, 4: y grows
 };
 
 // index of a key's cell in the near grid, -1: a far cell
@@ -999,6 +1016,66 @@ __device__ __forceinline__ double mu_div_with(double x, double y, double r) {
   return __builtin_amdgcn_div_fixup(q2, y, x);
 }
 
+// Up to 64 observations of ONE cell applied in order by a whole wave: lane t < n_here holds record t (probability p,
+// TBM quality q, update quality ql, obstacle point ox / oy for GMapping hits); every lane ends with the same cell
+// state -- the sequential arithmetic executed redundantly from lane broadcasts, bit-identical to one thread walking
+// the chain.  GMapping cells: a run of free observations of a cell whose mean is 0 only counts tries (see mu_step)
+// and is skipped in one step from the ballot of the hits.  MeanProbabilityCell: the division's reciprocal is made a
+// step ahead (see below).
+template <int RULE>
+__device__ __forceinline__ void mu_wave_apply(const MuArgs &a, MuCell &c, int lane, int n_here, bool in, double p,
+                                              double q, double ql, double ox, double oy) {
+  constexpr bool kReadsQuality = RULE >= 1 && RULE <= 3;
+  unsigned long long busy = ~0ull;  // records that need arithmetic
+  if (RULE == 4) busy = __ballot(in && !(p <= 0.5));  // hits and NaNs
+  int t = 0;
+  if (RULE == 2) {
+    // MeanProbabilityCell: c = (c n + p') / (n + 1), a division per observation that waits for the one before --
+    // 1080 of them on the robot's own cell, 100 ns each, were the whole kernel.  The denominator is known a
+    // step early: its refined reciprocal is made next to the step before (two independent chains in one
+    // loop body), which leaves three dependent operations of the division behind the numerator.
+    // The round takes this form only when every operand stays inside the range where the division's scaling
+    // steps do nothing (all p' in 2^-400 .. 2^400, none NaN, the mean non-negative and below 2^400: the mean is
+    // then a convex combination of such values all along); otherwise mu_step's plain divisions below.
+    const double tp = 0.5 + (p - 0.5) * ql;  // mu_step's that_p, per lane
+    const bool mine = lane < n_here;
+    const bool fine = !mine || (tp > 0x1p-400 && tp < 0x1p400);
+    if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52) {
+      double r = mu_refined_rcp(c.x0 + 1.0);
+      for (; t < n_here; ++t) {
+        const double n1 = c.x0 + 1;
+        const double x = c.c0 * c.x0 + mu_readlane(tp, t);
+        const double r_next = mu_refined_rcp(n1 + 1.0);  // (independent of x: scheduled beside the tail below)
+        const double qq = x * r;
+        const double e = __builtin_fma(-n1, qq, x);
+        const double q2 = __builtin_fma(e, r, qq);
+        c.c0 = __builtin_amdgcn_div_fixup(q2, n1, x);
+        c.x0 = n1;
+        r = r_next;
+      }
+    }
+  }
+  while (t < n_here) {
+    // (every lane holds the same cell state; the first lane's test keeps `t` wave-uniform)
+    if (RULE == 4 && __builtin_amdgcn_readfirstlane((int)(c.c0 == 0.0))) {  // skip the free run ahead
+      const unsigned long long ahead = busy >> t;
+      const int stop = ahead ? min(n_here, t + __ffsll((long long)ahead) - 1) : n_here;
+      if (stop > t) {
+        c.x1 += (double)(stop - t);
+        c.c0 = 0.0;
+        t = stop;
+        continue;
+      }
+    }
+    const double qt = (kReadsQuality && a.beam_quality) ? mu_readlane(ql, t) : a.quality;
+    mu_step<RULE>(qt, c, mu_readlane(p, t), RULE == 3 ? mu_readlane(q, t) : 0.0, [&](double *x, double *y) {
+      *x = mu_readlane(ox, t);
+      *y = mu_readlane(oy, t);
+    });
+    ++t;
+  }
+}
+
 // Chains that run past the end of their wave (at most one per wave; the robot's own cell takes one update per
 // beam, its neighbours hundreds): one thread walking such a chain pays a memory round trip per 8 records (330 us
 // for 1080 updates).  Here the WAVE that holds the chain's head streams it (at the end of k_mu_apply, after the
@@ -1033,62 +1110,12 @@ __device__ __forceinline__ void mu_apply_long_chains(const MuArgs &a, const Key 
       const unsigned long long m = __ballot(in && k == hkey);
       const int n_here = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
       double ox = 0.0, oy = 0.0;
-      unsigned long long busy = ~0ull;  // records that need arithmetic
-      if (RULE == 4) {
-        const bool hit = in && !(p <= 0.5);  // hits and NaNs
-        if (hit && !isnan(p)) {
-          const unsigned b = a.rec_beam[j];
-          ox = a.beam_end[2 * b];
-          oy = a.beam_end[2 * b + 1];
-        }
-        busy = __ballot(hit);
+      if (RULE == 4 && in && !(p <= 0.5) && !isnan(p)) {  // hits: the obstacle point of the record's beam
+        const unsigned b = a.rec_beam[j];
+        ox = a.beam_end[2 * b];
+        oy = a.beam_end[2 * b + 1];
       }
-      int t = 0;
-      if (RULE == 2) {
-        // MeanProbabilityCell: c = (c n + p') / (n + 1), a division per observation that waits for the one before --
-        // 1080 of them on the robot's own cell, 100 ns each, were the whole kernel.  The denominator is known a
-        // step early: its refined reciprocal is made next to the step before (two independent chains in one
-        // loop body), which leaves three dependent operations of the division behind the numerator.
-        // The round takes this form only when every operand stays inside the range where the division's scaling
-        // steps do nothing (all p' in 2^-400 .. 2^400, none NaN, the mean non-negative and below 2^400: the mean is
-        // then a convex combination of such values all along); otherwise mu_step's plain divisions below.
-        const double tp = 0.5 + (p - 0.5) * ql;  // mu_step's that_p, per lane
-        const bool mine = lane < n_here;
-        const bool fine = !mine || (tp > 0x1p-400 && tp < 0x1p400);
-        if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52) {
-          double r = mu_refined_rcp(c.x0 + 1.0);
-          for (; t < n_here; ++t) {
-            const double n1 = c.x0 + 1;
-            const double x = c.c0 * c.x0 + mu_readlane(tp, t);
-            const double r_next = mu_refined_rcp(n1 + 1.0);  // (independent of x: scheduled beside the tail below)
-            const double q = x * r;
-            const double e = __builtin_fma(-n1, q, x);
-            const double q2 = __builtin_fma(e, r, q);
-            c.c0 = __builtin_amdgcn_div_fixup(q2, n1, x);
-            c.x0 = n1;
-            r = r_next;
-          }
-        }
-      }
-      while (t < n_here) {
-        // (every lane holds the same cell state; the first lane's test keeps `t` wave-uniform)
-        if (RULE == 4 && __builtin_amdgcn_readfirstlane((int)(c.c0 == 0.0))) {  // skip the free run ahead
-          const unsigned long long ahead = busy >> t;
-          const int stop = ahead ? min(n_here, t + __ffsll((long long)ahead) - 1) : n_here;
-          if (stop > t) {
-            c.x1 += (double)(stop - t);
-            c.c0 = 0.0;
-            t = stop;
-            continue;
-          }
-        }
-        const double qt = (kReadsQuality && a.beam_quality) ? mu_readlane(ql, t) : a.quality;
-        mu_step<RULE>(qt, c, mu_readlane(p, t), RULE == 3 ? mu_readlane(q, t) : 0.0, [&](double *x, double *y) {
-          *x = mu_readlane(ox, t);
-          *y = mu_readlane(oy, t);
-        });
-        ++t;
-      }
+      mu_wave_apply<RULE>(a, c, lane, n_here, in, p, q, ql, ox, oy);
       if (n_here < 64) break;
     }
     if (lane == src) mu_cell_store<RULE>(a, at, c, was);
@@ -1158,6 +1185,7 @@ __global__ void k_mu_finish(const int *error_flag, const unsigned long long *n_p
   h_status[0] = (unsigned long long)*error_flag;
   h_status[1] = *n_padding;
   *const_cast<int *>(error_flag) = 0;  // the next update may start without k_mu_count (fused into k_mu_emit)
+  *const_cast<unsigned long long *>(n_padding) = 0ull;  // (the gather form only adds to it)
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -26,8 +26,28 @@ def ctx(pkg):
     c.close()
 
 
+K6_PATHS = {"gather": 0, "counting": 1, "radix": 2}
+
+
+@pytest.fixture(autouse=True)
+def _default_k6_path(pkg, ctx):
+    set_k6_path(pkg, ctx, "gather")
+    yield
+
+
+def set_k6_path(pkg, ctx, name):
+    """testing hook of the library: which pipeline plain updates of this context take (the default is `gather`:
+    map_update_gather.h; `counting` and `radix` are the record pipelines it falls back to)"""
+    import ctypes as C
+    L = pkg.load()
+    L.slamhip_map_debug_k6_path.argtypes = [C.c_void_p, C.c_int]
+    assert L.slamhip_map_debug_k6_path(ctx.h, K6_PATHS[name]) == 0
+
+
+@pytest.mark.parametrize("path", list(K6_PATHS))
 @pytest.mark.parametrize("name", list(MODELS))
-def test_append_scan_vs_reference_golden(pkg, ctx, name):
+def test_append_scan_vs_reference_golden(pkg, ctx, name, path):
+    set_k6_path(pkg, ctx, path)
     g = load("map_update.npz")
     cell_model, rule = MODELS[name]
     w, h = [int(v) for v in g[name + "_size"]]
@@ -88,8 +108,14 @@ def test_append_scan_full_size_vs_oracle_and_rescoring(pkg, ctx):
     ctx.map_release(2)
 
 
+@pytest.mark.parametrize("path", list(K6_PATHS))
 @pytest.mark.parametrize("name", ["mean", "tbm", "gmapping"])
-def test_append_scan_area_estimator_vs_reference_golden(pkg, ctx, name):
+def test_append_scan_area_estimator_vs_reference_golden(pkg, ctx, name, path):
+    set_k6_path(pkg, ctx, path)
+    _area_estimator_vs_reference_golden(pkg, ctx, name)
+
+
+def _area_estimator_vs_reference_golden(pkg, ctx, name):
     """AreaOccupancyEstimator on the GPU (slam/occupancy_estimator/type = area, BASELINE cfg 5)."""
     g = load("map_update_area.npz")
     cell_model, rule = MODELS[name]
@@ -191,22 +217,21 @@ def test_counting_sorted_and_radix_sorted_updates_agree(pkg, ctx):
     ctx.map_release(2)
 
 
-@pytest.mark.parametrize("sort", ["counting", "radix"])
+@pytest.mark.parametrize("sort", list(K6_PATHS))
 @pytest.mark.parametrize("name", ["mean", "affine", "tbm", "gmapping"])
-def test_append_scan_with_per_point_quality_vs_reference_golden(pkg, name, sort, monkeypatch):
+def test_append_scan_with_per_point_quality_vs_reference_golden(pkg, name, sort):
     """The `ahr` observation quality estimator (AngleHistogramResiprocalOMQE, grid_map_scan_adders.h:32-43; selected by
     slam/mapping/observation_quality_estimator/typetype, init_occupancy_mapping.h:64-80): K6 with a per-point quality
     (slamhip_map_append_scan_q + slamhip_omqe_quality) against maps exported from the compiled reference running that
     estimator (tests/golden/make_golden_omqe.py), both sorting paths, bit for bit (GMapping obstacle means to the
     raw-provider ulp of the idle golden)."""
-    if sort == "radix":
-        monkeypatch.setenv("SLAMHIP_K6_SORT", "radix")
     g = load("map_update_ahr.npz")
     cell_model, rule = MODELS[name]
     w, h = [int(v) for v in g[name + "_size"]]
     st = STRIDE[cell_model]
     unk = g[name + "_unknown"]
     ctx = pkg.Context(0)
+    set_k6_path(pkg, ctx, sort)
     ctx.map_bind(2, cell_model, w, h, g[name + "_origin"], float(g["scale"]), unk[:st])
     lo, hi = [int(v) for v in g["crop"]]
     for k in range(int(g["n_steps"])):

@@ -35,6 +35,23 @@ def ctx(pkg):
     c.close()
 
 
+K6_PATHS = {"gather": 0, "counting": 1, "radix": 2}
+
+
+def set_k6_path(pkg, ctx, name):
+    """testing hook: the pipeline plain updates of this context take (default `gather`, map_update_gather.h)"""
+    import ctypes as C
+    L = pkg.load()
+    L.slamhip_map_debug_k6_path.argtypes = [C.c_void_p, C.c_int]
+    assert L.slamhip_map_debug_k6_path(ctx.h, K6_PATHS[name]) == 0
+
+
+@pytest.fixture(autouse=True)
+def _default_k6_path(pkg, ctx):
+    set_k6_path(pkg, ctx, "gather")
+    yield
+
+
 def crafted_scans():
     """(pose, range, angle, is_occ, blur, max_range) tuples."""
     out = []
@@ -128,9 +145,11 @@ def astray_scans(n_scans=4, beams=64):
     return out
 
 
+@pytest.mark.parametrize("path", list(K6_PATHS))
 @pytest.mark.parametrize("name", ["mean", "gmapping"])
-def test_astray_walks_vs_oracle(pkg, ctx, name):
+def test_astray_walks_vs_oracle(pkg, ctx, name, path):
     import pyoracle as po
+    set_k6_path(pkg, ctx, path)
     from pyoracle_mapupdate import append_scan_ex
     O = po.Oracle()
     cell_model, rule, st, n_aux = KINDS[name]
@@ -156,10 +175,14 @@ def test_astray_walks_vs_oracle(pkg, ctx, name):
     ctx.map_release(3)
 
 
+@pytest.mark.parametrize("path", list(K6_PATHS))
 @pytest.mark.parametrize("name", list(KINDS))
 @pytest.mark.parametrize("estimator", [0, 1])
-def test_crafted_scans_vs_oracle(pkg, ctx, name, estimator):
+def test_crafted_scans_vs_oracle(pkg, ctx, name, estimator, path):
+    """Ties along diagonals, axis-parallel beams, poses on cell corners and centres, bundles of identical beams: in the
+    gather form these are the IRREGULAR beams (sequential walk + bitmap) next to regular ones in the same scan."""
     import pyoracle as po
+    set_k6_path(pkg, ctx, path)
     from pyoracle_mapupdate import append_scan_ex
     O = po.Oracle()
     cell_model, rule, st, n_aux = KINDS[name]
