@@ -99,7 +99,8 @@ struct MuScratch {
   int force_path = -1;  // -1: SLAMHIP_K6_SORT decides (unset: the fastest that applies); 0 auto, 1 counting, 2 radix
   MuLine *lines = nullptr;
   size_t cap_lines = 0, cap_irr_words = 0;
-  unsigned *irr_bits = nullptr, *done_count = nullptr, *d_lut = nullptr;
+  unsigned *irr_bits = nullptr, *d_lut = nullptr;
+  unsigned char *bad = nullptr;
   std::vector<double> geo_cos, geo_sin;
   bool geo_ok = false;
   double geo_a0 = 0.0;
@@ -248,11 +249,19 @@ int mu_scan_geometry(slamhip_ctx *ctx, MuScratch &sc, int n, const double *cos_a
     rel[b] = ang - a0;
     prev = ang;
   }
+  // the table over the PSEUDO-angle of a beam relative to beam 0 (mu_pseudo_angle: monotone in the angle)
+  auto pseudo = [](double ang) {
+    const double x = std::cos(ang), y = std::sin(ang);
+    const double t = std::fabs(y) / (std::fabs(x) + std::fabs(y));
+    return y >= 0.0 ? (x >= 0.0 ? t : 2.0 - t) : (x < 0.0 ? 2.0 + t : 4.0 - t);
+  };
   std::vector<unsigned> lut(kGatherLut + 1);
   int b = 0;
   for (int m = 0; m <= kGatherLut; ++m) {
-    const double edge = (double)m * (kTwoPi / kGatherLut);
-    while (b < n && rel[b] < edge) ++b;
+    const double edge = (double)m * (4.0 / kGatherLut);
+    // (rel ascends within one turn, so its pseudo-angle ascends too -- except that angles a hair below a full turn
+    // fold to ~4; they stay in front of `edge` only while rel itself is below the turn)
+    while (b < n && (rel[b] < 1e-12 ? 0.0 : pseudo(rel[b])) < edge) ++b;
     lut[m] = (unsigned)b;
   }
   if (!sc.d_lut) SLAMHIP_CHECK(hipMalloc(&sc.d_lut, sizeof(unsigned) * (kGatherLut + 1)));
@@ -262,8 +271,10 @@ int mu_scan_geometry(slamhip_ctx *ctx, MuScratch &sc, int n, const double *cos_a
   // cells closer to the robot than this take one wave each: beyond it a cell asks at most ~50 beams
   const double span = n > 1 ? rel[n - 1] : 1.0;
   const double density = n > 1 && span > 0 ? (double)(n - 1) / span : 1.0;  // beams per radian
-  const double half_window = std::min(1.5, 24.0 / density);
-  sc.geo_near_r = std::max(2, std::min(kNearR, (int)std::ceil(0.75 / std::sin(half_window))));
+  // (measured, 1080 beams over 270 degrees, k_mu_cells in us by radius: 8 cells 49, 12 cells 35, 18 cells 19, 26 and
+  // 36 cells 19-20: a far cell's thread asks its candidates one after the other, a near cell's wave 64 at a time)
+  const double half_window = std::min(1.5, 10.0 / density);
+  sc.geo_near_r = std::max(2, std::min(40, (int)std::ceil(0.75 / std::sin(half_window))));
   sc.geo_ok = true;
   *ok = true;
   return SLAMHIP_OK;
@@ -586,7 +597,7 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
   // The GATHER form (map_update_gather.h, the default wherever it applies): two kernels, no records.  SLAMHIP_K6_SORT =
   // counting / radix keep the record pipelines (the parity tests run all three).
   const bool force_counting = sc.force_path == 1;
-  bool gather = counting && !force_counting && ctx->low_latency && n <= 4096;
+  bool gather = counting && !force_counting && ctx->low_latency && n <= 4096 && n_bins <= (1ll << 22);
   if (gather) {
     const int grc = mu_scan_geometry(ctx, sc, n, cos_a, sin_a, &gather);
     if (grc) return grc;
@@ -597,9 +608,13 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
       if (sc.lines) hipFree(sc.lines);
       sc.lines = nullptr;
       SLAMHIP_CHECK(hipMalloc(&sc.lines, sizeof(MuLine) * sc.cap_beams));
+      if (sc.bad) hipFree(sc.bad);
+      sc.bad = nullptr;
+      SLAMHIP_CHECK(hipMalloc(&sc.bad, sc.cap_beams + 8));
+      SLAMHIP_CHECK(hipMemsetAsync(sc.bad, 0, sc.cap_beams + 8, ctx->stream));
       sc.cap_lines = sc.cap_beams;
     }
-    const size_t words = ((size_t)n_bins + 31) / 32 + 1;
+    const size_t words = (size_t)n_bins + 1;  // (a marker word per window cell)
     if (words > sc.cap_irr_words) {
       SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
       if (sc.irr_bits) hipFree(sc.irr_bits);
@@ -609,10 +624,6 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
       SLAMHIP_CHECK(hipMalloc(&sc.irr_bits, sizeof(unsigned) * cap));
       SLAMHIP_CHECK(hipMemsetAsync(sc.irr_bits, 0, sizeof(unsigned) * cap, ctx->stream));
       sc.cap_irr_words = cap;
-    }
-    if (!sc.done_count) {
-      SLAMHIP_CHECK(hipMalloc(&sc.done_count, sizeof(unsigned)));
-      SLAMHIP_CHECK(hipMemsetAsync(sc.done_count, 0, sizeof(unsigned), ctx->stream));
     }
     a.key_x0 = (int)wx0;
     a.key_y0 = (int)wy0;
@@ -627,28 +638,20 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
     a.lines = sc.lines;
     a.lut = sc.d_lut;
     a.lut_bins = kGatherLut;
-    a.theta = pose[2];
-    a.rel_a0 = sc.geo_a0;
+    ::sincos(pose[2] + sc.geo_a0, &a.rot_s, &a.rot_c);
     a.irr_bits = sc.irr_bits;
-    a.done_count = sc.done_count;
+    a.bad = sc.bad;
     if (a.est_kind == 1) hipLaunchKernelGGL(k_mu_lines<1>, dim3(n), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_mu_lines<0>, dim3(n), dim3(256), 0, ctx->stream, a);
-    const unsigned far_blocks = (unsigned)(((a.key_w + 63) / 64) * ((a.key_h + 3) / 4));
+    const unsigned far_blocks = (unsigned)(((a.key_w + 15) / 16) * ((a.key_h + 15) / 16));
     const unsigned side = 2u * (unsigned)a.near_r + 1u, near_blocks = (side * side + 3u) / 4u;
-    unsigned seq = 0;
-    unsigned long long *h_status = nullptr;
-    if (!deferred) {
-      seq = ++ctx->seq;
-      if (seq == 0) seq = ++ctx->seq;
-      h_status = sc.h_status;
-    }
     const dim3 cgrid(far_blocks + near_blocks), cblock(256);
 #define SLAMHIP_MU_CELLS(R)                                                                                          \
   case R:                                                                                                            \
     if (a.est_kind == 1)                                                                                             \
-      hipLaunchKernelGGL((k_mu_cells<R, 1>), cgrid, cblock, 0, ctx->stream, a, far_blocks, h_status, ctx->h_done_flag, seq); \
+      hipLaunchKernelGGL((k_mu_cells<R, 1>), cgrid, cblock, 0, ctx->stream, a, far_blocks);                           \
     else                                                                                                             \
-      hipLaunchKernelGGL((k_mu_cells<R, 0>), cgrid, cblock, 0, ctx->stream, a, far_blocks, h_status, ctx->h_done_flag, seq); \
+      hipLaunchKernelGGL((k_mu_cells<R, 0>), cgrid, cblock, 0, ctx->stream, a, far_blocks);                           \
     break;
     switch (a.rule) {
       SLAMHIP_MU_CELLS(0)
@@ -672,10 +675,12 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
       if (n_updates_out) *n_updates_out = -1;
       return SLAMHIP_OK;
     }
-    const int wrc = score_wait(ctx, seq);
+    // (a same-address counter that let the last workgroup hand the status over cost 42 us with 700 workgroups:
+    // the one-thread kernel behind the update is 4)
+    int gerr = 0;
+    unsigned long long gpad = 0;
+    const int wrc = mu_finish(ctx, sc.error_flag, sc.n_updates, sc.h_status, &gerr, &gpad);
     if (wrc) return wrc;
-    const int gerr = (int)((volatile unsigned long long *)sc.h_status)[0];
-    const unsigned long long gpad = ((volatile unsigned long long *)sc.h_status)[1];
     if (n_updates_out) *n_updates_out = (long long)((unsigned long long)total - gpad);
     if (gerr == 2) return fail("internal: the device counted more cell updates than the host sized the buffers for", SLAMHIP_ERR_STATE);
     if (gerr)

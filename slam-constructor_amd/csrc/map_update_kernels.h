@@ -74,21 +74,27 @@ struct MuArgs {
   // plain call, GATHER form (map_update_gather.h): one thread per cell of the key window asks the beams around its
   // direction whether their walk visits it -- no keys, no sort
   struct MuLine *lines;        // per beam: the closed form of its walk
-  const unsigned *lut;         // lut[m] = beams whose angle relative to beam 0 is below m * 2 pi / lut_bins
+  const unsigned *lut;         // lut[m] = beams whose pseudo-angle relative to beam 0 is below m * 4 / lut_bins
   int lut_bins, key_h;
-  double theta, rel_a0;        // pose heading; angle of beam 0 in the sensor frame
-  unsigned *irr_bits;          // one bit per window cell: an IRREGULAR beam (sequential walk) has a record there
-  unsigned *done_count;        // workgroups of k_mu_cells that are through (the last one hands the status over)
+  double rot_c, rot_s;         // cos / sin of (pose heading + angle of beam 0): world direction -> relative to beam 0
+  unsigned *irr_bits;          // one word per window cell: 0, or beam + 1 of the IRREGULAR beam (sequential walk) that
+                               // visits it; top bit: several do.  All zero between updates.
+  unsigned char *bad;          // per beam: 1 = irregular (padded to a multiple of 8 bytes with zeros)
 };
 
 // the walk of one beam in closed form (see k_mu_emit): step k stands on the cell i_k = k - j_k steps in x and
 // j_k = clamp(floor((q0 + k absA) invW), 0, k) steps in y from the robot's cell.  ok: the form was checked against
 // the recurrence step by step; otherwise the beam's cells are the keys its sequential walk left in MuArgs::keys.
+// The second half is what an observation of the beam needs (MuBeam without obst_dist_sq, which is the squared cell
+// distance robot -> end cell and is made again from ex, ey): 64 bytes per beam, staged in LDS by k_mu_cells.
 struct MuLine {
   double q0, absA, invW;
   unsigned cap;    // cells of the walk (0: the beam is range-gated)
   unsigned flags;  // 1: ok, 2: x grows, 4: y grows
+  int ex, ey;
+  double base_prob, base_qual, hole_dist_sq;
 };
+static_assert(sizeof(MuLine) == 64, "MuLine layout");
 
 // index of a key's cell in the near grid, -1: a far cell
 __device__ __forceinline__ int mu_near_index(const MuArgs &a, unsigned key) {
