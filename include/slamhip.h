@@ -209,6 +209,19 @@ int slamhip_filter_scan(int n, const double *range, const double *angle, const i
                         const double *tab_sin, const double *tab_cos, const double pose[3],
                         unsigned skip_rate, double max_range, int bounded, int width, int height,
                         int origin_x, int origin_y, double scale, int *kept_idx, int *kept_n);
+/* filter_scan + weights + beam trig + slamhip_scan_upload in one call, from the RAW scan (range, angle, is_occ or
+ * NULL = all occupied, factor or NULL = all 1.0): what a GridScanMatcher does with a scan before the first candidate
+ * is scored (weighted_mean_point_probability_spe.h:75-95; ScanPointWeighting :21-60; trig providers
+ * trigonometry_utils.h:17-84).  `bounded`: the map map_id is a PlainGridMap / LazyTiledGridMap whose has_cell()
+ * tests the window; 0 for the Unbounded* maps, for which no end point is computed at all (map_id is then not
+ * looked at).  Quantities that depend on the beam ANGLES only are kept inside the context until the angle array
+ * changes.  weighting: 0 even, 1 viny, 2 ahr; kept_n (may be NULL) = points kept, kept_idx (may be NULL, room for n)
+ * their raw indices.  With no point kept nothing is uploaded and scoring fails with SLAMHIP_ERR_STATE (the
+ * reference scores such a scan NaN). */
+int slamhip_scan_filter_upload(slamhip_ctx *ctx, int map_id, int n, const double *range, const double *angle,
+                               const int *is_occ, const double *factor, int trig_mode, double a_min, double a_max,
+                               double a_inc, const double pose[3], unsigned skip_rate, double max_range, int bounded,
+                               int weighting, int *kept_n, int *kept_idx);
 /* ScanPointWeighting::weight for a filtered scan: kind 0 even, 1 viny, 2 ahr */
 int slamhip_scan_weights(int kind, int n, const double *range, const double *angle, double *out);
 

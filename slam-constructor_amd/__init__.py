@@ -49,7 +49,7 @@ slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begi
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
 slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select
 slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_gmapping_match_abort
-slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality""".split()
+slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality slamhip_scan_filter_upload""".split()
 
 SHARD_ID_BYTES = 128
 

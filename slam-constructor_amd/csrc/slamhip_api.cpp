@@ -979,6 +979,110 @@ int slamhip_scan_weights(int kind, int n, const double *range, const double *ang
   return invalid("unknown weighting kind");
 }
 
+// The per-scan host half of a match in one call, from the RAW scan: WeightedMeanPointProbabilitySPE::filter_scan
+// (weighted_mean_point_probability_spe.h:75-95,136-141) at the initial pose, the scan-point weights of the filtered
+// scan (:21-60), the beams' cos / sin as the scan's trig provider tabulates them, and the upload.  Through the adapter
+// classes this half was the larger one of a resident world's scan (70 of 140 us): the reference's filter_scan calls
+// libm twice per point for an end point whose only use is has_cell() -- always true on an unbounded map -- and the
+// beams' sincos were made again for every scan although a scanner's angles never change.  Here nothing is computed
+// that the decision does not need: no end point unless the map is bounded, angle-only quantities cached until the
+// angle array changes (compared by content).
+int slamhip_scan_filter_upload(slamhip_ctx *ctx, int map_id, int n, const double *range, const double *angle,
+                               const int *is_occ, const double *factor, int trig_mode, double a_min, double a_max,
+                               double a_inc, const double pose[3], unsigned skip_rate, double max_range, int bounded,
+                               int weighting, int *kept_n, int *kept_idx) {
+  if (!ctx || n <= 0 || !range || !angle || !pose) return invalid("bad arguments");
+  if (weighting < 0 || weighting > 2) return invalid("unknown weighting kind");
+  DeviceMap *m = get_map(ctx, map_id);
+  if (bounded && !m) return invalid("unknown map id");
+  slamhip_ctx::ScanPrep &sp = ctx->scan_prep;
+  const bool same = (int)sp.angle.size() == n && sp.trig_mode == trig_mode && sp.a_min == a_min && sp.a_max == a_max &&
+                    sp.a_inc == a_inc && std::memcmp(sp.angle.data(), angle, sizeof(double) * n) == 0;
+  if (!same) {
+    sp.angle.assign(angle, angle + n);
+    sp.trig_mode = trig_mode;
+    sp.a_min = a_min;
+    sp.a_max = a_max;
+    sp.a_inc = a_inc;
+    sp.cos_a.resize(n);
+    sp.sin_a.resize(n);
+    int rc = trig_mode == SLAMHIP_TRIG_CACHED
+                 ? slamhip_beam_trig_cached(n, angle, a_min, a_max, a_inc, sp.cos_a.data(), sp.sin_a.data())
+                 : slamhip_beam_trig_raw(n, angle, sp.cos_a.data(), sp.sin_a.data());
+    if (rc) {
+      sp.angle.clear();
+      return rc;
+    }
+    // VinySlamSPW's angular factor (weighted_mean_point_probability_spe.h:47-60): the weight is this times sqrt(range)
+    sp.viny_f.resize(n);
+    for (int i = 0; i < n; ++i) {
+      double sv, cv;
+      ::sincos(angle[i], &sv, &cv);
+      const double ac = std::abs(cv);
+      double w = std::abs(sv) + ac;
+      if (0.9 < ac) w = 3;
+      else if (0.8 < ac) w = 2;
+      sp.viny_f[i] = w;
+    }
+  }
+  // ---- filter_scan: keeps point i iff (skip_rate == 0 or i % skip_rate == 0), occupied, its end point's cell in the
+  // map, and not beyond the usable range (Q8 - Q10)
+  constexpr double eps = std::numeric_limits<double>::epsilon();
+  sp.kept.clear();
+  double sb = 0, cb = 1;
+  if (bounded) ::sincos(pose[2], &sb, &cb);
+  for (int i = 0; i < n; ++i) {
+    if (skip_rate && (unsigned(i) % skip_rate)) continue;
+    if (is_occ && !is_occ[i]) continue;
+    const bool too_far = (0.0 < max_range + eps) && (max_range < range[i] + eps);
+    if (too_far) continue;
+    if (bounded) {
+      double c, s;
+      if (trig_mode == SLAMHIP_TRIG_CACHED) {
+        c = cb * sp.cos_a[i] - sb * sp.sin_a[i];
+        s = sb * sp.cos_a[i] + cb * sp.sin_a[i];
+      } else {
+        ::sincos(pose[2] + angle[i], &s, &c);
+      }
+      const double wx = pose[0] + range[i] * c, wy = pose[1] + range[i] * s;
+      const int ix = (int)std::floor(wx / m->scale) + m->origin_x, iy = (int)std::floor(wy / m->scale) + m->origin_y;
+      if (!(0 <= ix && ix < m->width && 0 <= iy && iy < m->height)) continue;
+    }
+    sp.kept.push_back(i);
+  }
+  const int k = (int)sp.kept.size();
+  if (kept_n) *kept_n = k;
+  if (kept_idx) std::memcpy(kept_idx, sp.kept.data(), sizeof(int) * k);
+  if (k == 0) {
+    ctx->scan_n = 0;  // (scoring without a scan fails; the reference scores NaN: the adapter handles an empty scan itself)
+    return SLAMHIP_OK;
+  }
+  sp.r.resize(k);
+  sp.c.resize(k);
+  sp.s.resize(k);
+  sp.w.resize(k);
+  sp.f.resize(k);
+  for (int q = 0; q < k; ++q) {
+    const int i = sp.kept[q];
+    sp.r[q] = range[i];
+    sp.c[q] = sp.cos_a[i];
+    sp.s[q] = sp.sin_a[i];
+    sp.f[q] = factor ? factor[i] : 1.0;
+  }
+  if (weighting == 0) {
+    const double w = 1.0 / k;  // EvenSPW (:21-32)
+    for (int q = 0; q < k; ++q) sp.w[q] = w;
+  } else if (weighting == 1) {
+    for (int q = 0; q < k; ++q) sp.w[q] = sp.viny_f[sp.kept[q]] * std::sqrt(sp.r[q]);
+  } else {
+    sp.a.resize(k);
+    for (int q = 0; q < k; ++q) sp.a[q] = angle[sp.kept[q]];
+    const int rc = slamhip_scan_weights(2, k, sp.r.data(), sp.a.data(), sp.w.data());
+    if (rc) return rc;
+  }
+  return slamhip_scan_upload(ctx, k, sp.r.data(), sp.c.data(), sp.s.data(), sp.w.data(), sp.f.data());
+}
+
 // ObservationMappingQualityEstimator::quality (grid_map_scan_adders.h:17-43): IdleOMQE, or
 // AngleHistogramResiprocalOMQE = 1 / AngleHistogram::value -- the arithmetic of the `ahr` scan-point weighting above
 // (weighted_mean_point_probability_spe.h:34-45 is the same reciprocal of the same histogram)

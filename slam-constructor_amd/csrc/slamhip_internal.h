@@ -153,6 +153,16 @@ struct slamhip_ctx {
     std::vector<double> w, f;
   };
   std::vector<ScanSlot> scan_slots;
+  // slamhip_scan_filter_upload: what depends on the scanner's beam ANGLES only (cos / sin per raw beam as the scan's
+  // trig provider tabulates them, the viny weighting's angular factor) is kept between scans -- a scanner's angles do
+  // not change -- next to the buffers the filtered scan is assembled in
+  struct ScanPrep {
+    std::vector<double> angle, cos_a, sin_a, viny_f;
+    int trig_mode = -1;
+    double a_min = 0, a_max = 0, a_inc = 0;
+    std::vector<double> r, a, c, s, w, f;
+    std::vector<int> kept;
+  } scan_prep;
   std::vector<double> h_weight, h_factor;  // host copies for GMapping carry-in fix-ups
   // pose / score staging
   double *d_poses = nullptr, *d_scores = nullptr, *d_pose_sc = nullptr;

@@ -66,7 +66,11 @@ inline std::shared_ptr<GridScanMatcher> init_hip_scan_matcher(const PropertiesPr
   const auto gm = props.get_str("slam/mapping/grid/type", "<undefined>");
   const bool bounded = gm == "plain" || gm == "lazy_tiled";
   auto mirror = std::make_shared<HipMapMirror>(ctx, map_id, model, bounded);
-  return std::make_shared<HipGridScanMatcher>(spe, ctx, m, mirror, weighting);
+  auto gsm = std::make_shared<HipGridScanMatcher>(spe, ctx, m, mirror, weighting);
+  if (props.get_str(Slam_SM_NS + "spe/type", "<undefined>") == "wmpp")  // (init_spe's own parameters, :99-100)
+    gsm->set_filter_params(props.get_uint(Slam_SM_NS + "spe/wmpp/sp_skip_rate", 0),
+                           props.get_dbl(Slam_SM_NS + "spe/wmpp/sp_max_usable_range", -1), bounded);
+  return gsm;
 }
 
 #endif  // SLAMHIP_INIT_SCAN_MATCHING_H

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <limits>
 #include <memory>
 #include <utility>
 #include <unordered_map>
@@ -327,9 +328,21 @@ public:
   void set_dirty_source(const HipMirroredGridMap *src) { _dirty_source = src; }
   void set_resident_map(bool on) { _mirror->set_resident(on); }
   const HipMapMirror &mirror() const { return *_mirror; }
+  // what init_spe hands WeightedMeanPointProbabilitySPE (slam/scmtch/spe/wmpp/sp_skip_rate, sp_max_usable_range) and
+  // whether the map's has_cell() tests a window (PlainGridMap / LazyTiledGridMap): with these the matcher filters the
+  // raw scan through slamhip_scan_filter_upload itself whenever no observer wants the filtered LaserScan2D
+  void set_filter_params(unsigned skip_rate, double max_range, bool bounded) {
+    _skip_rate = skip_rate;
+    _max_range = max_range;
+    _bounded = bounded;
+    _own_filter = true;
+  }
 
   double process_scan(const TransformedLaserScan &raw_scan, const RobotPose &init_pose,
                       const GridMap &map, RobotPoseDelta &pose_delta) override {
+    int n_obs = 0;
+    do_for_each_observer([&](ObsPtr) { ++n_obs; });
+    if (_own_filter && n_obs == 0) return process_raw_scan(raw_scan, init_pose, map, pose_delta);
     do_for_each_observer([&](ObsPtr obs) { obs->on_matching_start(init_pose, raw_scan, map); });
     _scan = filter_scan(raw_scan.scan, init_pose, map);
     _mirror->sync(map, _dirty_source);
@@ -345,6 +358,41 @@ public:
   }
 
 private:
+  // Nobody listens: no filtered LaserScan2D has to exist.  The raw points go to the library as three arrays (kept
+  // between scans), which filters, weighs and uploads them (slamhip_scan_filter_upload): no libm call per point on an
+  // unbounded map, no sincos per beam per scan.
+  double process_raw_scan(const TransformedLaserScan &raw_scan, const RobotPose &init_pose, const GridMap &map,
+                          RobotPoseDelta &pose_delta) {
+    const auto &pts = raw_scan.scan.points();
+    const int n = (int)pts.size();
+    _mirror->sync(map, _dirty_source);
+    _r.resize(n);
+    _a.resize(n);
+    _f.resize(n);
+    _occ.resize(n);
+    for (int i = 0; i < n; ++i) {
+      _r[i] = pts[i].range();
+      _a[i] = pts[i].angle();
+      _f[i] = pts[i].factor();
+      _occ[i] = pts[i].is_occupied() ? 1 : 0;
+    }
+    const double p0[3] = {init_pose.x, init_pose.y, init_pose.theta};
+    int kept = 0;
+    if (n > 0)
+      slamhip_or_die(slamhip_scan_filter_upload(_ctx, _mirror->id(), n, _r.data(), _a.data(), _occ.data(), _f.data(),
+                                                _trig.mode, _trig.a_min, _trig.a_max, _trig.a_inc, p0, _skip_rate,
+                                                _max_range, _bounded ? 1 : 0, _weighting, &kept, nullptr),
+                     "scan_filter_upload");
+    if (kept == 0) {  // no usable point: the reference's estimate is NaN for every pose, nothing is ever accepted
+      pose_delta = RobotPoseDelta{0, 0, 0};
+      return std::numeric_limits<double>::quiet_NaN();
+    }
+    slamhip_or_die(slamhip_matcher_set_observer(_m, nullptr), "set_observer");
+    double d[3], prob = 0;
+    slamhip_or_die(slamhip_matcher_process_scan(_m, _mirror->id(), p0, d, &prob), "process_scan");
+    pose_delta = RobotPoseDelta{d[0], d[1], d[2]};
+    return prob;
+  }
   static void on_test(void *self, const double p[3], double score) {
     auto *t = static_cast<HipGridScanMatcher *>(self);
     t->do_for_each_observer([&](ObsPtr obs) { obs->on_scan_test(RobotPose{p[0], p[1], p[2]}, t->_scan, score); });
@@ -360,6 +408,11 @@ private:
   HipScanTrig _trig;
   const HipMirroredGridMap *_dirty_source = nullptr;
   LaserScan2D _scan;
+  bool _own_filter = false, _bounded = false;
+  unsigned _skip_rate = 0;
+  double _max_range = -1;
+  std::vector<double> _r, _a, _f;
+  std::vector<int> _occ;
 };
 
 // ------------------------------------------------------------------------------------------------

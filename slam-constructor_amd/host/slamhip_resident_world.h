@@ -99,13 +99,16 @@ public:
     }
     const int n = (int)r.size();
     std::vector<double> &c = _c, &s = _s;
-    c.resize(n);
-    s.resize(n);
-    if (_cfg.trig.mode == SLAMHIP_TRIG_CACHED)
-      slamhip_or_die(slamhip_beam_trig_cached(n, a.data(), _cfg.trig.a_min, _cfg.trig.a_max, _cfg.trig.a_inc, c.data(),
-                                              s.data()), "beam_trig_cached");
-    else
-      slamhip_or_die(slamhip_beam_trig_raw(n, a.data(), c.data(), s.data()), "beam_trig_raw");
+    if (a != _trig_a) {  // (a scanner's angles do not change from scan to scan: their cos / sin are made once)
+      c.resize(n);
+      s.resize(n);
+      if (_cfg.trig.mode == SLAMHIP_TRIG_CACHED)
+        slamhip_or_die(slamhip_beam_trig_cached(n, a.data(), _cfg.trig.a_min, _cfg.trig.a_max, _cfg.trig.a_inc, c.data(),
+                                                s.data()), "beam_trig_cached");
+      else
+        slamhip_or_die(slamhip_beam_trig_raw(n, a.data(), c.data(), s.data()), "beam_trig_raw");
+      _trig_a = a;
+    }
     slamhip_scan_adder_cfg adder = _cfg.adder;
     adder.scan_quality = tr_scan.quality;
     const RobotPose p = pose();
@@ -123,7 +126,7 @@ private:
   Config _cfg;
   std::shared_ptr<HipResidentMapView> _view;
   long long _cell_updates = 0;
-  std::vector<double> _r, _a, _q, _c, _s, _all_r, _all_a, _all_q;  // per-scan buffers, kept between scans
+  std::vector<double> _r, _a, _q, _c, _s, _all_r, _all_a, _all_q, _trig_a;  // per-scan buffers, kept between scans
   std::vector<int> _occ;
 };
 

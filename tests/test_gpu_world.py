@@ -88,6 +88,21 @@ def test_resident_world_matches_reference_world(lib, preset, matcher, strict):
     assert r["view_mis"] == 0
 
 
+@pytest.mark.parametrize("preset,matcher", [(0, 1), (1, 0), (1, 1), (3, 1)])
+def test_resident_world_without_observers_filters_the_raw_scan_itself(lib, preset, matcher, monkeypatch):
+    """The production shape: nobody subscribed to the HIP world's matcher.  The adapter then hands the RAW scan to
+    slamhip_scan_filter_upload (filter_scan without an end point on the unbounded map, weights and beam trig from what
+    is cached per scanner geometry) instead of calling the reference's filter_scan and rebuilding the filtered scan --
+    the host half of a scan, 70 of 140 us through the adapter classes.  Same trajectory and final map as the
+    reference's world, bit for bit (weighted_mean_point_probability_spe.h:75-95,136-141; :21-60)."""
+    monkeypatch.setenv("REFWORLD_NO_OBSERVER", "1")
+    for strict in (1, 0):
+        r, poses = run_resident(lib, preset, matcher, strict)
+        assert r["pose_mis"] == 0, "trajectories differ by up to %g" % r["worst_pose"]
+        assert r["cell_mis"] == 0 and r["view_mis"] == 0 and r["cells"] == r["ref_w"] * r["ref_h"]
+        assert r["ref_calls"] > 12 * 20 and np.ptp(poses[:, 1]) > 0.5
+
+
 def test_resident_world_longer_run(lib):
     r, _ = run_resident(lib, 1, 1, 0, n_scans=30, n_beams=720)
     assert r["pose_mis"] == 0 and r["cell_mis"] == 0 and r["ref_calls"] == r["hip_calls"] and r["view_mis"] == 0
