@@ -159,6 +159,28 @@ def roofline_valu(workload, avg_launch_us):
     return out
 
 
+# the dependent chain of ONE super-step of the device-resident hill-climbing chain (1024-thread workgroups,
+# point OOPE), priced from the guide's primitive latencies at ~2.1 GHz (global_load: L2 hit 200 cycles, memory 900; a
+# dependent FP64 / integer VALU op 8 cycles; LDS read ~64 cycles; kernel boundary 1.45 us), beside the wall_clock64
+# stamps of tools/hc_chain_stamps.py (profiles/r03_chain_stamps.txt).
+HC_LATENCY_MODEL_US = {"boundary": 1.45, "staged": 0.90, "replayed": 0.52, "pose": 0.50, "terms": 0.25, "stored": 0.20}
+HC_LATENCY_STAMPS_US = {"boundary": 1.85, "staged": 1.61, "replayed": 1.88, "pose": 0.69, "terms": 0.93, "stored": 0.89}
+
+
+def latency_model(ms_per_match, super_steps):
+    """achieved / model for the headline's real bound, the serial accept chain: a match is `super_steps` kernels in a
+    row, each a chain of dependent memory round trips, barriers and FP64 sequences that no amount of width shortens."""
+    if not super_steps or not ms_per_match:
+        return None
+    model = sum(HC_LATENCY_MODEL_US.values())
+    achieved = 1e3 * ms_per_match / super_steps
+    return {"bound": "latency", "unit": "us per super-step", "model": model, "achieved": achieved,
+            "frac": model / achieved, "super_steps_per_match": super_steps,
+            "model_stages_us": HC_LATENCY_MODEL_US, "stamped_stages_us": HC_LATENCY_STAMPS_US,
+            "note": "achieved = median ms per match / mean super-steps per match (includes the host's enqueue and the "
+                    "result read-back); stamped = in-kernel wall_clock64 timeline of one scoring workgroup"}
+
+
 def sweep_ceiling(pkg, ctx, cfg, sc, scan_n, n_poses, launches, bpu, torch):
     """Kernel ceiling beside the matcher-mode number: the same scoring kernel on flat batches of
     device-resident poses (no host round trip, launches back to back)."""
@@ -1399,6 +1421,10 @@ def main():
         rv = roofline_valu(args.workload, avg_us)
         if rv:
             out["roofline_valu"] = rv
+        if on_device and kind == "HC" and "ms_per_match" in extra:
+            lm = latency_model(extra["ms_per_match"]["median"], k_launches / max(args.steps, 1))
+            if lm:
+                out["latency_model"] = lm
         if ceiling is not None:
             out["roofline_sweep"] = ceiling
         if cpu_out is not None:

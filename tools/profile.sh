@@ -5,7 +5,7 @@
 # in its own pass with --kernel-trace only, as MI355X_MICROARCH.md prescribes.  Output: gpurun_out/<tag>/;
 # tools/summarize_profiles.py <tag> then copies the summaries into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -37,6 +37,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc pf_update $c $c -- --legs pf_update --steps 3 --warmup 1 --no-cpu
   pmc pf_maps $c $c -- --legs pf_maps --steps 3 --warmup 1 --no-cpu
   pmc cfg5 $c $c -- --legs cfg5 --steps 3 --warmup 1 --no-cpu
+  pmc world $c $c -- --legs world --steps 3 --warmup 1 --no-cpu
 done
 pmc hc sq $SQ -- --legs none --steps 10 --warmup 2 --no-cpu
 pmc sweep sq $SQ -- --workload sweep --steps 20 --warmup 2 --no-cpu
@@ -53,4 +54,7 @@ run pf --legs pf --steps 3 --warmup 1 --no-cpu
 run pf_update --legs pf_update --steps 3 --warmup 1 --no-cpu
 run pf_maps --legs pf_maps --steps 3 --warmup 1 --no-cpu
 run cfg5 --legs cfg5 --steps 3 --warmup 1 --no-cpu
+run world --legs world --steps 3 --warmup 1 --no-cpu
+run replicas --legs replicas --steps 3 --warmup 1 --no-cpu
+python3 $ROOT/tools/hc_chain_stamps.py > $OUT/chain_stamps.txt 2>&1
 ls $OUT | head -80

@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
@@ -18,7 +18,8 @@ os.makedirs(dst, exist_ok=True)
 CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); SQ_BUSY_CYCLES / duration is printed beside it
 # dominant kernel of each leg (substring of the rocprof kernel name)
 LEG_KERNEL = {"hc": "k_hc_chain_step", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_step",
-              "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_"}
+              "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_", "world": "k_hc_chain_step",
+              "replicas": "k_hc_chain_step"}
 lines = ["# rocprofv3 summaries, round tag `%s`\n" % tag,
          "Commands: `tools/profile.sh %s` -- one `rocprofv3 --kernel-trace --stats` run per leg of `bench.py` "
          "(`--legs none` = the headline alone, `--workload sweep`, `--workload mc`, `--legs pf`, `pf_update`, `pf_maps`, "
@@ -29,7 +30,7 @@ def short(name):
     return name.replace("void ", "").replace("slamhip::", "").replace("(anonymous namespace)::", "")[:72]
 
 
-for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5"):
+for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world", "replicas"):
     st = os.path.join(src, name, "%s_kernel_stats.csv" % name)
     if not os.path.exists(st):
         continue
@@ -58,10 +59,19 @@ for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5"):
                                 pr["launches"], pr["achieved"], pr["frac"], pd_["ms_per_step"], pd_["value"], pd_["unit"],
                                 d["ms_per_step"]))
             else:
-                leg = {"pf": None, "pf_update": "with_map_update", "pf_maps": "with_particle_maps"}.get(name, "cfg5")
-                obj = pd_.get("cfg5") if name == "cfg5" else pd_.get("particle_filter", {})
-                if leg and name != "cfg5":
-                    obj = obj.get(leg, {})
+                leg = {"pf": None, "pf_update": "with_map_update", "pf_maps": "with_particle_maps"}.get(name, name)
+                if name in ("cfg5", "world", "replicas"):
+                    obj = pd_.get({"world": "world_loop"}.get(name, name), {})
+                    if name == "replicas":
+                        lines.append("\nun-profiled replicas leg (`%s_%s_bench_unprofiled.json`): " % (tag, name) + "; ".join(
+                            "K=%d %.3f ms/call = %.3g units/s (kernel frac %.3f)" %
+                            (r_["K"], r_["ms_per_call"], r_["value"], r_["roofline"]["frac"])
+                            for r_ in obj.get("by_K", [])) + "\n")
+                        obj = {}
+                else:
+                    obj = pd_.get("particle_filter", {})
+                    if leg:
+                        obj = obj.get(leg, {})
                 if obj:
                     lines.append("\nun-profiled line of this leg (`%s_%s_bench_unprofiled.json`): %.3f ms/step = %.0f %s\n"
                                  % (tag, name, obj.get("ms_per_step", float("nan")), obj.get("value", float("nan")),
@@ -72,6 +82,11 @@ dj = os.path.join(src, "default.plain.json")
 if os.path.exists(dj) and os.path.getsize(dj) > 2:
     shutil.copy(dj, os.path.join(dst, "%s_default_bench_unprofiled.json" % tag))
     lines.append("The driver's command (`python bench.py`, every leg, CPU baselines): `%s_default_bench_unprofiled.json`.\n" % tag)
+
+cs = os.path.join(src, "chain_stamps.txt")
+if os.path.exists(cs):
+    shutil.copy(cs, os.path.join(dst, "%s_chain_stamps.txt" % tag))
+    lines.append("In-kernel timeline of the hill-climbing chain's super-step (`tools/hc_chain_stamps.py`): `%s_chain_stamps.txt`.\n" % tag)
 
 traffic = {}
 PMC_KERNEL = {"hc": "k_hc_chain_step<0", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_step<2"}
@@ -119,7 +134,7 @@ for wl in ("hc", "sweep", "mc", "pf"):
         lines.append("")
 # K6: HBM bytes per map-update pipeline = the counters of ALL its dispatches (k_mu_*, rocprim scan / sort) added up,
 # divided by the number of pipelines (one k_mu_apply each)
-for wl in ("pf_update", "pf_maps", "cfg5"):
+for wl in ("pf_update", "pf_maps", "cfg5", "world"):
     t = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
@@ -131,7 +146,7 @@ for wl in ("pf_update", "pf_maps", "cfg5"):
             if r["Counter_Name"] != c or not ("k_mu_" in name or "rocprim" in name):
                 continue
             total += float(r["Counter_Value"])
-            pipelines += 1 if "k_mu_apply" in name else 0
+            pipelines += 1 if ("k_mu_apply" in name or "k_mu_cells" in name) else 0
         if pipelines:
             t[c + "_kb_raw"] = total / pipelines
             t["pipelines"] = pipelines
