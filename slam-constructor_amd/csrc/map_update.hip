@@ -888,6 +888,8 @@ int mu_batch_fast_tail(MuArgs &a, MuBatchScratch &sc, size_t beams, unsigned end
   hipLaunchKernelGGL(k_mu_clear_marks, dim3((unsigned)std::min<size_t>((words / 4 + 255) / 256, 4096)), dim3(256), 0, st,
                      (uint4 *)sc.special, words / 4);
   a.special = sc.special;
+  a.lazy_keys = 1;
+  a.walk_flag = sc.slow_cnt;  // (read by k_mu_classify before it leaves the beam's count of sorted records there)
   unsigned *keys = (unsigned *)sc.keys, *keys_c = (unsigned *)sc.keys_sorted;
   const dim3 wgrid((unsigned)((beams + 3) / 4));  // a wave per beam
   hipLaunchKernelGGL((k_mu_emit<unsigned, -1>), wgrid, dim3(256), 0, st, a, (unsigned *)nullptr);

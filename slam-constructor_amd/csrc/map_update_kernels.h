@@ -71,6 +71,11 @@ struct MuArgs {
   unsigned *special;
   double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
   int fresh_ok;
+  // ... with LAZY keys: a beam whose closed form holds writes no keys at all (k_mu_classify evaluates the form again,
+  // step by step, instead of reading 4 bytes per record back); walk_flag[b] = 1 names the beams whose keys the
+  // sequential walk wrote
+  int lazy_keys;
+  unsigned *walk_flag;
   // plain call, GATHER form (map_update_gather.h): one thread per cell of the key window asks the beams around its
   // direction whether their walk visits it -- no keys, no sort
   struct MuLine *lines;        // per beam: the closed form of its walk
@@ -353,6 +358,48 @@ __device__ void mu_walk_beam(const MuArgs &a, int b) {  // b = global beam index
 template <typename Key>
 __device__ __forceinline__ int mu_key_cell(const MuArgs &a, Key key, int *ix, int *iy);
 
+// the closed form of one beam's walk (derived in k_mu_emit's comment below), shared by the kernels that evaluate it
+struct MuWalkLine {
+  double q0, absA, inv_W, e0, A, B;
+  int bx, by, inc_x, inc_y;
+};
+__device__ __forceinline__ MuWalkLine mu_walk_line(const MuArgs &a, const MuJob &jb, double wx, double wy) {
+  MuWalkLine L;
+  const double scale = a.scale;
+  const double d_x = wx - jb.px, d_y = wy - jb.py;
+  L.inc_x = 0 < d_x ? 1 : -1;
+  L.inc_y = 0 < d_y ? 1 : -1;
+  L.bx = (int)floor(jb.px / scale);
+  L.by = (int)floor(jb.py / scale);
+  const double mid_x = (L.bx + 0.5) * scale, mid_y = (L.by + 0.5) * scale;
+  const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
+  L.e0 = mid_cell_seg_y - mid_y * d_x;
+  L.A = L.inc_x * scale * d_y;
+  L.B = -L.inc_y * scale * d_x;
+  L.absA = fabs(L.A);
+  const double absB = fabs(L.B), W = L.absA + absB;
+  const double sgn = L.A < 0 ? -1.0 : 1.0;
+  const double theta = (absB - L.absA) * 0.5;
+  L.q0 = sgn * L.e0 - theta + absB;
+  L.inv_W = 1.0 / W;
+  return L;
+}
+// y steps among the first k steps of the walk (x steps: k - j)
+// (times 1 / W rather than divided by W: k_mu_emit's check does not care how j was found, only that lane k's jn is
+// lane k + 1's j -- the same expression -- and a quotient that lands on the other side of an integer sits next to a
+// tie, where the walk goes to the sequential form anyway)
+// (32-bit integers: a walk is far shorter than 2^31 steps, and 64-bit conversions are emulated)
+__device__ __forceinline__ int mu_walk_j(double q0, double absA, double inv_W, unsigned k) {
+  const double fj = floor((q0 + (double)k * absA) * inv_W);
+  return (int)fmin(fmax(fj, 0.0), (double)k);
+}
+__device__ __forceinline__ int mu_walk_j(const MuWalkLine &L, unsigned k) { return mu_walk_j(L.q0, L.absA, L.inv_W, k); }
+// a double that is the same in every lane of the wave, moved to scalar registers
+__device__ __forceinline__ double mu_uniform(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // The walk in parallel.  The reference's loop (regular_squares_grid.h:56-101) is a floating-point recurrence
 // per beam -- 76 of the 170 us of a single-scan update went to 17 waves stepping 600 cells one after the other.
 // But away from ties it is a plain digital line: with A = e_x_inc, B = e_y_inc (opposite signs), u = sign(A) e
@@ -426,19 +473,9 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
     ex = a.beam_info[b].ex;
     ey = a.beam_info[b].ey;
   }
-  const double scale = a.scale;
-  const double d_x = wx - jb.px, d_y = wy - jb.py;
-  const int inc_x = 0 < d_x ? 1 : -1, inc_y = 0 < d_y ? 1 : -1;
-  const int bx = (int)floor(jb.px / scale), by = (int)floor(jb.py / scale);
-  const double mid_x = (bx + 0.5) * scale, mid_y = (by + 0.5) * scale;
-  const double mid_cell_seg_y = d_x * jb.py + (mid_x - jb.px) * d_y;
-  const double e0 = mid_cell_seg_y - mid_y * d_x;
-  const double A = inc_x * scale * d_y, B = -inc_y * scale * d_x;
-  const double absA = fabs(A), absB = fabs(B), W = absA + absB;
-  const double sgn = A < 0 ? -1.0 : 1.0;
-  const double theta = (absB - absA) * 0.5;
-  const double q0 = sgn * e0 - theta + absB;
-  const double inv_W = 1.0 / W;
+  const MuWalkLine L = mu_walk_line(a, jb, wx, wy);
+  const double e0 = L.e0, A = L.A, B = L.B, absA = L.absA, absB = fabs(L.B);
+  const int bx = L.bx, by = L.by, inc_x = L.inc_x, inc_y = L.inc_y;
   const int steps_x = abs(ex - bx), steps_y = abs(ey - by);
   const KeyT job_part = a.jobs ? (KeyT)(b / a.n) << a.cell_bits : KeyT(0);
   const unsigned row = (unsigned)a.key_w;
@@ -450,12 +487,7 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
     for (unsigned k0 = 0; k0 < cap; k0 += 64) {
       const unsigned k = k0 + lane;
       if (k < cap) {
-        // (times 1 / W rather than divided by W: the check below does not care how j was found, only that lane
-        // k's jn is lane k + 1's j -- the same expression -- and a quotient that lands on the other side of an
-        // integer sits next to a tie, where the walk goes to the sequential form anyway)
-        // (32-bit integers: a walk is far shorter than 2^31 steps, and 64-bit conversions are emulated)
-        const double fj = floor((q0 + (double)k * absA) * inv_W), fjn = floor((q0 + (double)(k + 1) * absA) * inv_W);
-        const int j = (int)fmin(fmax(fj, 0.0), (double)k), jn = (int)fmin(fmax(fjn, 0.0), (double)(k + 1));
+        const int j = mu_walk_j(L, k), jn = mu_walk_j(L, k + 1);
         const int i = (int)k - j;
         const double e = e0 + (double)i * A + (double)j * B;
         const double d = fabs(e + B) - fabs(e + A);
@@ -468,7 +500,8 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
         const unsigned ix = (unsigned)(bx + inc_x * i + a.origin_x), iy = (unsigned)(by + inc_y * j + a.origin_y);
         const bool oob = ix >= w || iy >= h;
         bad |= oob;
-        out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
+        if (!a.lazy_keys)
+          out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
         if (beam_of) beam_of[base + k] = (unsigned)b;
       }
     }
@@ -484,16 +517,25 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
   } else if (__any(bad) && lane == 0) {
     *a.error_flag = 1;
   }
+  if (a.lazy_keys && lane == 0) a.walk_flag[b] = ok ? 0u : 1u;
   if (a.special) {
     // a SUPERSET of the cells this beam can observe with a probability above 0.5 (mu_value): its end cell and the
     // cells closer to it than the blur distance.  Along a monotone walk the L1 distance to the end cell is the
     // number of steps left, so only the last sqrt(2) * blur steps can qualify; a walk the sequential fail-over
-    // rewrote is tested cell by cell.  (Lane k0 + lane reads the key it wrote itself.)
+    // rewrote is tested cell by cell.  (Lane k0 + lane reads the key it wrote itself, or evaluates the form again.)
     const double hole_sq = a.beam_info[b].hole_dist_sq;
     const unsigned m = ok ? min(cap, (unsigned)ceil(1.4143 * sqrt(hole_sq)) + 2u) : cap;
     for (unsigned k = ((cap - m) & ~63u) + lane; k < cap; k += 64) {
       if (k + m < cap) continue;
-      const KeyT key = out[k];
+      KeyT key;
+      if (a.lazy_keys && ok) {  // the closed form's cell of step k (written nowhere)
+        const int j = mu_walk_j(L, k), i = (int)k - j;
+        const unsigned ix = (unsigned)(bx + inc_x * i + a.origin_x), iy = (unsigned)(by + inc_y * j + a.origin_y);
+        key = (ix >= w || iy >= h) ? ~KeyT(0)
+                                   : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
+      } else {
+        key = out[k];
+      }
       if (key == ~KeyT(0)) continue;
       int cix, ciy;
       mu_key_cell<KeyT>(a, key, &cix, &ciy);
@@ -852,30 +894,61 @@ template <int EST>
 __global__ __launch_bounds__(64 * kClassifyBeams, 8) void k_mu_classify(MuArgs a, unsigned *slow_cnt) {
   __shared__ unsigned s_key[2][kClassifyBeams][64];
   __shared__ unsigned s_max_cap;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int b = blockIdx.x * kClassifyBeams + w;
   const bool live = b < a.n * a.n_jobs;
-  const unsigned cap = live ? a.counts[b] : 0u;
+  const unsigned cap = live ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.counts[b]) : 0u;
   if (threadIdx.x == 0) s_max_cap = 0u;
   __syncthreads();
   if (lane == 0 && cap) atomicMax(&s_max_cap, cap);
   __syncthreads();
   const unsigned near_end = min((s_max_cap + 63u) & ~63u, 64u * kNearRounds);  // rounds every wave takes part in
-  unsigned *out = (unsigned *)a.keys + (cap ? a.offsets[b] : 0u);
+  unsigned *out = (unsigned *)a.keys + (cap ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.offsets[b]) : 0u);
   // per-beam constants of the validity proof (wave-uniform)
-  const MuJob jb = mu_job(a, live ? b : 0);
+  MuJob jb = mu_job(a, live ? b : 0);
+  jb.px = mu_uniform(jb.px);
+  jb.py = mu_uniform(jb.py);
   double wx = 0, wy = 0, inv_dx = 0, inv_dy = 0;
   if (EST == 1 && cap) {
-    wx = a.beam_end[2 * b];
-    wy = a.beam_end[2 * b + 1];
-    inv_dx = a.beam_inv[2 * b];
-    inv_dy = a.beam_inv[2 * b + 1];
+    wx = mu_uniform(a.beam_end[2 * b]);
+    wy = mu_uniform(a.beam_end[2 * b + 1]);
+    inv_dx = mu_uniform(a.beam_inv[2 * b]);
+    inv_dy = mu_uniform(a.beam_inv[2 * b + 1]);
   }
   const long long unknown_bits = __double_as_longlong(a.unknown_c0);
+  // lazy keys: the walk's cells come from the closed form k_mu_emit checked (the same expressions); only a beam the
+  // sequential walk rewrote has its keys in memory
+  // (what follows is the same for every lane of the beam's wave: into scalar registers, out of the way of the
+  // sixty-four vector registers eight waves per SIMD leave each lane)
+  const bool formula = a.lazy_keys && cap && __builtin_amdgcn_readfirstlane((int)a.walk_flag[b]) == 0;
+  double q0 = 0, absA = 0, inv_W = 0;
+  int bx = 0, by = 0, inc_x = 1, inc_y = 1;
+  if (formula) {
+    const double ewx = EST == 1 ? wx : a.beam_end[2 * b], ewy = EST == 1 ? wy : a.beam_end[2 * b + 1];
+    const MuWalkLine L = mu_walk_line(a, jb, ewx, ewy);
+    q0 = mu_uniform(L.q0);
+    absA = mu_uniform(L.absA);
+    inv_W = mu_uniform(L.inv_W);
+    bx = __builtin_amdgcn_readfirstlane(L.bx);
+    by = __builtin_amdgcn_readfirstlane(L.by);
+    inc_x = __builtin_amdgcn_readfirstlane(L.inc_x);
+    inc_y = __builtin_amdgcn_readfirstlane(L.inc_y);
+  }
+  const unsigned job_part = a.jobs ? (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(b / a.n) << a.cell_bits)) : 0u;
   unsigned n_slow = 0, n_pad = 0;
   for (unsigned k0 = 0; k0 < max(cap, near_end); k0 += 64) {
     const unsigned k = k0 + lane;
-    const unsigned key = k < cap ? out[k] : ~0u;
+    unsigned key = ~0u;
+    if (k < cap) {
+      if (formula) {
+        const int j = mu_walk_j(q0, absA, inv_W, k), i = (int)k - j;
+        const unsigned ix = (unsigned)(bx + inc_x * i + a.origin_x), iy = (unsigned)(by + inc_y * j + a.origin_y);
+        if (ix < (unsigned)a.width && iy < (unsigned)a.height)
+          key = job_part + (iy - (unsigned)a.key_y0) * (unsigned)a.key_w + (ix - (unsigned)a.key_x0);
+      } else {
+        key = out[k];
+      }
+    }
     bool slow = false, settle = false;
     size_t at = 0;
     long long bits = 0;

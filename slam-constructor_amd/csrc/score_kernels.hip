@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void k_sum_sequential(const double *terms, int 
 // filter launches): without the pose loop the beam constants die after phase A / C instead of
 // staying live for a next iteration -- 163 -> fewer VGPRs, more waves to hide the 9-cell gathers.
 template <int KB, bool ONE>
-__global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
+__global__ __launch_bounds__(kBlock, (ONE && KB <= 5) ? 5 : 1) void k_score_gmapping(ScoreArgs a) {
   extern __shared__ double s_dyn[];  // val[n] | grp_last_cell (int2 as double) [G] | grp_last_start [G]
   __shared__ double s_pose[kMaxPosesPerBlock][4];
   __shared__ double s_part[kMaxPosesPerBlock][4];
@@ -234,14 +234,17 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
       pose_cs = a.pose_sc[2 * p + 1];
     }
   }
-  double br[KB], bc[KB], bs[KB], bw[KB], bf[KB];
+  constexpr int KR = ONE ? 1 : KB;  // (one pose: the beam constants are read where phase A uses them)
+  double br[KR], bc[KR], bs[KR], bw[KB], bf[KB];
 #pragma unroll
   for (int k = 0; k < KB; ++k) {
     const int b = t + kBlock * k;
     const bool ok = b < n;
-    br[k] = ok ? a.scan.range[b] : 0.0;
-    bc[k] = ok ? a.scan.cos_a[b] : 0.0;
-    bs[k] = ok ? a.scan.sin_a[b] : 0.0;
+    if (!ONE) {
+      br[k] = ok ? a.scan.range[b] : 0.0;
+      bc[k] = ok ? a.scan.cos_a[b] : 0.0;
+      bs[k] = ok ? a.scan.sin_a[b] : 0.0;
+    }
     // one pose: weight and factor are read where they are used (phase C) instead of occupying
     // 4 KB of VGPRs across the gathers
     bw[k] = (ok && !ONE) ? a.scan.weight[b] : 0.0;
@@ -269,10 +272,12 @@ __global__ __launch_bounds__(kBlock) void k_score_gmapping(ScoreArgs a) {
       ccx[k] = 0;
       ccy[k] = 0;
       if (b < n) {
-        const double c = cs * bc[k] - sn * bs[k];
-        const double s = sn * bc[k] + cs * bs[k];
-        const double wx = x + br[k] * c;
-        const double wy = y + br[k] * s;
+        const double rk = ONE ? a.scan.range[b] : br[ONE ? 0 : k];
+        const double ck = ONE ? a.scan.cos_a[b] : bc[ONE ? 0 : k], sk = ONE ? a.scan.sin_a[b] : bs[ONE ? 0 : k];
+        const double c = cs * ck - sn * sk;
+        const double s = sn * ck + cs * sk;
+        const double wx = x + rk * c;
+        const double wy = y + rk * s;
         ccx[k] = to_cell(wx, scale, inv_scale);
         ccy[k] = to_cell(wy, scale, inv_scale);
         s_val[b] = gm_fresh_value(a.map, s_unknown, tiles, a.gm, ccx[k], ccy[k], wx, wy);
