@@ -48,3 +48,15 @@ def assert_trace_equal(t, ref, exact_scores=True, rtol=1e-12):
         np.testing.assert_allclose(t["scores"], ref["scores"], rtol=rtol, atol=0)
         np.testing.assert_allclose(t["prob"], ref["prob"], rtol=rtol, atol=0)
     np.testing.assert_array_equal(t["delta"], ref["delta"])
+
+
+def dense_snapshot(g, name):
+    """(payload[h, w, 3], counters[h, w, 2]) of a sparsely stored GMapping map snapshot (tests/golden/cfg5_cached.npz:
+    the cells that differ from the never-observed prototype, as flat index deltas + rows)."""
+    w, h = [int(v) for v in g["size"]]
+    pay = np.tile(np.asarray(g["unknown"], dtype=np.float64)[:3], (h, w, 1))
+    aux = np.zeros((h, w, 2))
+    flat = np.cumsum(g[name + "_idx_delta"].astype(np.int64))
+    pay.reshape(-1, 3)[flat] = g[name + "_payload"]
+    aux.reshape(-1, 2)[flat] = g[name + "_counters"]
+    return pay, aux

@@ -301,6 +301,50 @@ def test_particle_maps_vs_reference_copy_on_write_copies(pkg):
     ctx.close()
 
 
+def test_cfg5_geometry_cached_provider_golden(pkg):
+    """cfg5's geometry against the compiled reference with no caveat (tests/golden/make_golden_cfg5_cached.py): 0.025 m
+    cells, 1080-beam scans whose walks are up to 676 cells long, AreaOccupancyEstimator, blur 0.1 m, three scans per
+    history -- with the reference's CACHED trigonometry provider, whose angle-addition form is the device's own
+    arithmetic.  Every cell of every snapshot: hit / try counters exact, occupancy bit-exact, obstacle means to 1e-12
+    (running means of end points).  Twice: the batched update of two particles' copy-on-write maps (histories P and Q
+    in the same launches), and the single-scan update of a dense map (history P)."""
+    from helpers import dense_snapshot
+    g = load("cfg5_cached.npz")
+    w, h = [int(v) for v in g["size"]]
+    scale, blur, shift = float(g["scale"]), float(g["blur"]), float(g["shift_amount"])
+    ox, oy = [int(v) for v in g["origin"]]
+    base = tuple(g["base"])
+    cos_t, sin_t = pkg.beam_trig(g["angle"])  # libm at the table's angles = the provider's table (asserted by the generator)
+
+    def check(got_p, got_a, name):
+        want_p, want_a = dense_snapshot(g, name)
+        np.testing.assert_array_equal(got_a, want_a, err_msg=name)
+        np.testing.assert_array_equal(got_p[..., 0], want_p[..., 0], err_msg=name)
+        np.testing.assert_allclose(got_p[..., 1:], want_p[..., 1:], rtol=1e-12, atol=1e-14, err_msg=name)
+
+    ctx = pkg.Context(0)
+    ctx.map_bind(4, 2, w, h, g["origin"], scale, g["unknown"][:3])  # never observed: the particles' common ancestor
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), 2, np.arange(2, dtype=np.uint32))
+    tiles = (max(w, h) + 127) // 128 + 1
+    pf.enable_particle_maps(4, extent_tiles=tiles, pool_tiles=3 * tiles * tiles, base=base, blur=blur, estimator=1,
+                            shift_amount=shift)
+    ctx.map_bind(5, 2, w, h, g["origin"], scale, g["unknown"][:3])
+    for k in range(3):
+        rng, beam = g["scan%d_range" % k], g["scan%d_beam" % k]
+        nu = pf.particle_maps_append([0, 1], np.stack([g["poses_p"][k], g["poses_q"][k]]), rng, g["angle"][beam])
+        assert nu > 2 * rng.size * 100
+        ctx.map_append_scan(5, pkg.RULE_GMAPPING, g["poses_p"][k], rng, cos_t[beam], sin_t[beam], base=base, blur=blur,
+                            estimator=1, shift_amount=shift)
+        if k == 0:
+            check(*pf.particle_map(0, -ox, -oy, w, h), "P0")
+            check(ctx.map_download_window(5, 0, 0, w, h, 3), ctx.map_download_aux(5, 0, 0, w, h, 2), "P0")
+    check(*pf.particle_map(0, -ox, -oy, w, h), "P2")
+    check(*pf.particle_map(1, -ox, -oy, w, h), "Q2")
+    check(ctx.map_download_window(5, 0, 0, w, h, 3), ctx.map_download_aux(5, 0, 0, w, h, 2), "P2")
+    pf.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("pose_trig", [1, 0])
 def test_cfg5_geometry_against_the_oracle(pkg, oracle, pose_trig):
     """pose_trig 1: host pose trigonometry, host-driven lock-step jobs; 0 (the default, what bench.py runs): device

@@ -104,3 +104,29 @@ def test_append_scan_with_per_point_quality_vs_reference(oracle, name):
             np.testing.assert_array_equal(aux[lo:hi, lo:hi], g["%s_step%d_aux" % (name, k)])
     # (idle estimator: all ones)
     assert np.array_equal(omqe_quality(oracle, 0, g["step0_range"], g["step0_angle"]), np.ones(g["step0_range"].size))
+
+
+def test_cfg5_geometry_cached_provider_vs_reference(oracle):
+    """cfg5's geometry (0.025 m cells, 1080 beams, walks of up to 676 cells, area estimator, blur 0.1 m) with the
+    CACHED trigonometry provider (tests/golden/make_golden_cfg5_cached.py): the reference evaluates the device's own
+    angle-addition form, so there is no raw-provider caveat -- every cell of every snapshot, counters and payload,
+    bit for bit."""
+    from helpers import dense_snapshot
+    from pyoracle import TRIG_CACHED, Oracle, ScanData
+    from pyoracle_mapupdate import append_scan_ex
+    g = load("cfg5_cached.npz")
+    w, h = [int(v) for v in g["size"]]
+    tab_sin, tab_cos = Oracle().trig_table(float(g["a_min"]), float(g["a_max"]), float(g["a_inc"]))
+    for hist, poses, checks in (("P", g["poses_p"], {0: "P0", 2: "P2"}), ("Q", g["poses_q"], {2: "Q2"})):
+        pay = np.tile(g["unknown"][:3], (h, w, 1)).astype(np.float64)
+        m = GridMapData(CELL_GMAPPING, pay, g["origin"], float(g["scale"]), g["unknown"][:3])
+        aux = np.zeros((h, w, 2))
+        for k in range(3):
+            rng, ang = g["scan%d_range" % k], g["angle"][g["scan%d_beam" % k]]
+            tr = ScanData(rng, ang, None, None, TRIG_CACHED, float(g["a_min"]), float(g["a_inc"]), tab_sin, tab_cos)
+            append_scan_ex(oracle, m, aux, RULE_GMAPPING, poses[k], rng, ang, None, base=g["base"], blur=float(g["blur"]),
+                           est_kind=1, shift_amount=float(g["shift_amount"]), trig=tr)
+            if k in checks:
+                want_p, want_a = dense_snapshot(g, checks[k])
+                np.testing.assert_array_equal(aux, want_a, err_msg=checks[k])
+                np.testing.assert_array_equal(m.payload, want_p, err_msg=checks[k])
