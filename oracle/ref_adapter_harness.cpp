@@ -19,6 +19,7 @@
 #include "core/maps/plain_grid_map.h"
 #include "core/maps/naive_grid_cells.h"
 #include "core/maps/tbm_grid_cells.h"
+#include "slams/gmapping/gmapping_grid_cell.h"
 #include "core/maps/grid_map_scan_adders.h"
 #include "core/maps/const_occupancy_estimator.h"
 #include "core/scan_matchers/observation_impact_estimators.h"
@@ -165,6 +166,53 @@ int refad_compare(int cell, int kind, const double *p, int n_beams, int strict, 
   out[8] = double(ts.scan.points().size());
   out[9] = obs_ok;
   hip.reset();
+  slamhip_ctx_destroy(ctx);
+  return 0;
+}
+
+// The map mirror on a GMapping map of the UNPATCHED reference: GmappingBaseCell keeps its mean obstacle point private
+// and offers no accessor; slamhip_reference_adapter.h reads it through a member pointer (SLAMHIP_GMAPPING_OBSTACLE).
+// This harness has no access either (no `#define private public` here), so the mirrored means are checked through the
+// cell's public discrepancy(): 1 - exp(-|obst - q|^2 / 0.05) evaluated from the downloaded (x, y) must equal the
+// cell's own value bit for bit, for two probe points per cell.  out = {cells checked, mismatches}
+int refad_gmapping_mirror(double *out) {
+  const int w = 40, h = 30;
+  const double scale = 0.1;
+  UnboundedPlainGridMap map{std::make_shared<GmappingBaseCell>(), GridMapParams{w, h, scale}};
+  std::mt19937 gen(5);
+  std::uniform_real_distribution<double> u(-0.04, 0.04);
+  std::vector<GridMap::Coord> touched;
+  const auto org = map.origin();
+  for (int k = 0; k < 200; ++k) {
+    const GridMap::Coord c{int(gen() % (w - 2)) + 1 - org.x, int(gen() % (h - 2)) + 1 - org.y};
+    const int hits = 1 + int(gen() % 3);
+    for (int j = 0; j < hits; ++j)  // running means of slightly different obstacle points
+      map.update(c, AreaOccupancyObservation{true, {0.6 + 0.1 * j, 1.0},
+                                             {(c.x + 0.5) * scale + u(gen), (c.y + 0.5) * scale + u(gen)}, 1.0});
+    if (gen() % 4 == 0) map.update(c, AreaOccupancyObservation{false, {0.01, 1.0}, {0, 0}, 1.0});
+    touched.push_back(c);
+  }
+  if (map.width() != w || map.height() != h) return -2;
+  slamhip_ctx *ctx = nullptr;
+  if (slamhip_ctx_create(0, &ctx) != SLAMHIP_OK) return -1;
+  HipMapMirror mirror{ctx, 3, SLAMHIP_CELL_GMAPPING, false};
+  mirror.sync(map);
+  std::vector<double> win(size_t(w) * h * 3);
+  if (slamhip_map_download_window(ctx, 3, 0, 0, w, h, win.data()) != SLAMHIP_OK) return -3;
+  long bad = 0;
+  for (const auto &c : touched) {
+    const double *p = &win[(size_t(c.y + map.origin().y) * w + (c.x + map.origin().x)) * 3];
+    const GridCell &cell = map[c];
+    if (p[0] != cell.occupancy().prob_occ) ++bad;
+    for (int q = 0; q < 2; ++q) {
+      const Point2D probe{(c.x + 0.3 + 0.4 * q) * scale, (c.y + 0.8 - 0.5 * q) * scale};
+      const double want = cell.discrepancy(AreaOccupancyObservation{true, {1, 1}, probe, 1});
+      const double got = 1.0 - std::exp(-Point2D{p[1], p[2]}.dist_sq(probe) / 0.05);
+      if (std::memcmp(&want, &got, sizeof(double)) != 0) ++bad;
+    }
+  }
+  out[0] = double(touched.size());
+  out[1] = double(bad);
   slamhip_ctx_destroy(ctx);
   return 0;
 }

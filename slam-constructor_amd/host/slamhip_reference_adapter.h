@@ -40,10 +40,32 @@
 #include "slamhip.h"
 
 #ifndef SLAMHIP_GMAPPING_OBSTACLE
-// GmappingBaseCell keeps its mean obstacle point private (gmapping_grid_cell.h:40-42); the
-// integration adds `const Point2D &obstacle() const { return obst; }` there and defines this
-// macro as `(cell).obstacle()`.
-#define SLAMHIP_GMAPPING_OBSTACLE(cell) Point2D{0, 0}
+// GmappingBaseCell keeps its mean obstacle point private and has no accessor (gmapping_grid_cell.h:40-42).  The
+// reference stays unpatched: the arguments of an explicit template instantiation may name a private member (access
+// checks do not apply to them, [temp.spec]), and the instantiation hands the member pointer to a friend function.
+// (A build that would rather add `const Point2D &obstacle() const { return obst; }` to the cell defines this macro
+// as `static_cast<const GmappingBaseCell &>(cell).obstacle()` before including this header.)
+#if __has_include("slams/gmapping/gmapping_grid_cell.h")
+#include "slams/gmapping/gmapping_grid_cell.h"
+namespace {  // (one instantiation per translation unit)
+template <typename Tag, typename Tag::type Member>
+struct SlamhipPrivateMember {
+  friend typename Tag::type slamhip_private_member(Tag) { return Member; }
+};
+struct SlamhipGmappingObst {
+  using type = Point2D GmappingBaseCell::*;
+  friend type slamhip_private_member(SlamhipGmappingObst);
+};
+template struct SlamhipPrivateMember<SlamhipGmappingObst, &GmappingBaseCell::obst>;
+inline const Point2D &slamhip_gmapping_obstacle(const GridCell &cell) {
+  return static_cast<const GmappingBaseCell &>(cell).*slamhip_private_member(SlamhipGmappingObst{});
+}
+}  // namespace
+#define SLAMHIP_GMAPPING_OBSTACLE(cell) slamhip_gmapping_obstacle(cell)
+#else
+#define SLAMHIP_GMAPPING_OBSTACLE(cell) \
+  (slamhip_or_die(SLAMHIP_ERR_UNSUPPORTED, "GMapping cells: slams/gmapping/gmapping_grid_cell.h is not on the include path"), Point2D{0, 0})
+#endif
 #endif
 
 inline void slamhip_or_die(int rc, const char *what) {

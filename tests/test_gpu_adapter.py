@@ -41,3 +41,12 @@ def test_adapter_matches_reference_matcher(lib, cell, kind, params, strict):
         assert rel == 0.0 and ref_prob == hip_prob and ddelta == 0.0
     else:
         assert rel <= 1e-12 and ddelta == 0.0 and abs(ref_prob - hip_prob) <= 1e-12 * abs(ref_prob)
+
+
+def test_mirror_reads_gmapping_obstacle_means_of_the_unpatched_reference(lib):
+    """GmappingBaseCell::obst is private and has no accessor (gmapping_grid_cell.h:40-42); the mirror reads it through
+    a member pointer, so the reference needs no patch.  200 cells with running means of obstacle points: occupancy
+    and the cell's own discrepancy() from the mirrored window, bit for bit (oracle/ref_adapter_harness.cpp)."""
+    out = (C.c_double * 2)()
+    assert lib.refad_gmapping_mirror(out) == 0
+    assert out[0] == 200 and out[1] == 0
