@@ -729,8 +729,7 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
         pf_traffic, pf_traffic_src = load_traffic("pf")
         pf_roofline = {"bound": "hbm", "achieved": g_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": g_achieved / HBM_PEAK_GBS, "traffic": pf_traffic, "traffic_source": pf_traffic_src,
-                       "kernel": ("k_score_gmapping" if os.environ.get("SLAMHIP_PF_CHAIN", "1")[:1] == "0"
-                                  else "k_hc_chain_step"),
+                       "kernel": "k_hc_chain_step",
                        "kernel_note": "one hill-climbing chain per particle on the device, all chains in shared "
                                       "launches (GMapping OOPE: K3's one-pose body inside csrc/hc_chain.hip)",
                        "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,

@@ -87,6 +87,24 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx);
 int slamhip_ctx_synchronize(slamhip_ctx *ctx);
 /* hipStream_t of the context, for callers that enqueue their own work around ours */
 void *slamhip_ctx_stream(slamhip_ctx *ctx);
+/* Options of a context.  Every option switches between execution paths that give the SAME results (the parity tests
+ * and the measurements in DESIGN.md run both sides); the library reads no environment variables.  Set them before the
+ * objects they concern are created or used. */
+enum {
+  SLAMHIP_OPT_LOW_LATENCY = 0,   /* 1 (default): results come back through pinned completion words the host polls,
+                                  * poses are read over PCIe by the kernels; 0: stream synchronisation */
+  SLAMHIP_OPT_STAGE_POSES = 1,   /* 1: pose batches are copied to HBM before a scoring kernel reads them; 0 (default) */
+  SLAMHIP_OPT_FILTER_CHAINS = 2, /* 1 (default): a filter step runs one accept chain per particle on the device;
+                                  * 0: the host-driven lock-step jobs */
+  SLAMHIP_OPT_K6_PATH = 3,       /* single-scan map update: 0 (default) the fastest pipeline that applies (gather,
+                                  * else counting sort, else radix sort), 1 counting sort, 2 radix sort */
+  SLAMHIP_OPT_K6_BATCH_FAST = 4, /* batched map update: 1 (default) free observations of zero-mean cells are settled
+                                  * with atomics and only the rest is sorted; 0: every record is sorted into its chain */
+  SLAMHIP_OPT_K6_BATCH_KEY64 = 5 /* batched map update: 1 forces the 8-byte (particle, cell) keys of very large
+                                  * batches; 0 (default): by size */
+};
+int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value);
+int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value);
 
 /* ---------------------------------------------------------------- map mirror
  * Replaces GridMap::operator[] on the scoring path (src/core/maps/grid_map.h:62,

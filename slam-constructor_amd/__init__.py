@@ -25,11 +25,12 @@ OOPE_OBSTACLE, OOPE_MAX, OOPE_MEAN, OOPE_OVERLAP, OOPE_GMAPPING = range(5)
 OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
 SUM_TREE256, SUM_SEQUENTIAL = 0, 1
 POSE_TRIG_DEVICE, POSE_TRIG_HOST = 0, 1
+(OPT_LOW_LATENCY, OPT_STAGE_POSES, OPT_FILTER_CHAINS, OPT_K6_PATH, OPT_K6_BATCH_FAST, OPT_K6_BATCH_KEY64) = range(6)
 TRIG_RAW, TRIG_CACHED = 0, 1
 STRIDE = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}
 
 EXPORTS = """slamhip_last_error slamhip_device_count slamhip_ctx_create slamhip_ctx_destroy
-slamhip_ctx_synchronize slamhip_ctx_stream slamhip_map_bind slamhip_map_upload_window
+slamhip_ctx_synchronize slamhip_ctx_stream slamhip_ctx_set_option slamhip_ctx_get_option slamhip_map_bind slamhip_map_upload_window
 slamhip_map_apply_dirty slamhip_map_release slamhip_map_download_window slamhip_scan_upload
 slamhip_beam_trig_raw slamhip_beam_trig_cached slamhip_filter_scan slamhip_scan_weights
 slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm_cache_get slamhip_gm_cache_set
@@ -400,6 +401,17 @@ class Context:
 
     def stream(self):
         return self.L.slamhip_ctx_stream(self.h)
+
+    def set_option(self, option, value):
+        """slamhip_ctx_set_option: OPT_* switches between execution paths with the same results."""
+        self.L.slamhip_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _check(self.L.slamhip_ctx_set_option(self.h, int(option), int(value)))
+
+    def get_option(self, option):
+        self.L.slamhip_ctx_get_option.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        v = C.c_int(0)
+        _check(self.L.slamhip_ctx_get_option(self.h, int(option), C.byref(v)))
+        return v.value
 
     # map mirror
     def map_bind(self, map_id, cell_model, width, height, origin, scale, unknown):

@@ -514,7 +514,7 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
     // Device pose trig, 3x3 window: every particle's accept chain runs on the device, all chains
     // in shared launches (hc_chain.hip, grid.y = particle); no chain starts from a cache entry, the hand-overs --
     // the step's own included -- are checked afterwards in particle order like the lock-step jobs'.
-    static const bool pf_chain_off = getenv("SLAMHIP_PF_CHAIN") && getenv("SLAMHIP_PF_CHAIN")[0] == '0';
+    const bool pf_chain_off = !ctx->filter_chains;  // (SLAMHIP_OPT_FILTER_CHAINS)
     // (per-particle maps: every chain gathers through its particle's tile table; measured, ms per step, chains /
     // lock-step: 13 particles 0.74 / 0.89, 100 particles 1.66 / 1.64 -- so for shards of up to 64 particles)
     const bool chains = !pf_chain_off && (!g->tp || act.size() <= 64) && g->cfg.pose_trig == SLAMHIP_POSE_TRIG_DEVICE && g->cfg.gm_window == 1 &&

@@ -96,7 +96,7 @@ struct MuScratch {
   // the gather form of a plain call (map_update_gather.h): per-beam closed forms, the irregular-cell bitmap of the key
   // window (all zero between updates), the workgroup counter of k_mu_cells, and what is known about the scanner's
   // beam directions -- analysed when they change (a scanner's angles do not change from scan to scan)
-  int force_path = -1;  // -1: SLAMHIP_K6_SORT decides (unset: the fastest that applies); 0 auto, 1 counting, 2 radix
+  int force_path = 0;  // SLAMHIP_OPT_K6_PATH of the context: 0 the fastest that applies, 1 counting sort, 2 radix sort
   MuLine *lines = nullptr;
   size_t cap_lines = 0, cap_irr_words = 0;
   unsigned *irr_bits = nullptr, *d_lut = nullptr;
@@ -566,11 +566,8 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
   // the key window: the cells between the robot's and the beams' end cells, clipped to the map (a walk is monotone
   // between its two ends; cells outside the map become padding).  Small enough -- a few hundred thousand cells for
   // a laser's reach -- the records are counting-sorted over it; otherwise keys are cells of the whole map and
-  // rocprim sorts them (SLAMHIP_K6_SORT=radix forces that path: the parity tests run both).
-  if (sc.force_path < 0) {
-    const char *e = getenv("SLAMHIP_K6_SORT");
-    sc.force_path = (e && std::strcmp(e, "radix") == 0) ? 2 : ((e && std::strcmp(e, "counting") == 0) ? 1 : 0);
-  }
+  // rocprim sorts them (SLAMHIP_OPT_K6_PATH forces either path: the parity tests run all three).
+  sc.force_path = ctx->k6_path;
   const bool force_radix = sc.force_path == 2;
   const long long wx0 = std::max(0ll, (long long)bb_lo_x + m.origin_x), wy0 = std::max(0ll, (long long)bb_lo_y + m.origin_y);
   const long long wx1 = std::min((long long)m.width - 1, (long long)bb_hi_x + m.origin_x);
@@ -772,15 +769,6 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
   if (err)
     return fail("a beam leaves the bound map window: grow the map (slamhip_map_bind) before updating; "
                 "cells inside the window were updated", SLAMHIP_ERR_STATE);
-  return SLAMHIP_OK;
-}
-
-// testing aid, not part of include/slamhip.h: which pipeline plain map updates of this context take -- 0 the default
-// (gather where it applies, else counting sort, else radix sort), 1 counting sort, 2 radix sort.  The environment
-// variable SLAMHIP_K6_SORT = counting / radix sets the same for a whole process.
-int slamhip_map_debug_k6_path(slamhip_ctx *ctx, int path) {
-  if (!ctx || path < 0 || path > 2) return fail("bad K6 path");
-  scratch_of(ctx).force_path = path;
   return SLAMHIP_OK;
 }
 
@@ -1167,14 +1155,13 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   // sort gains 100 us, k_mu_apply loses 190 us to the scattered tiles of consecutive chains)
   // free-space fast path: the const estimator's free observation must be valid and free, the bitmap of marked cells
   // at most 256 MB (end_bit <= 32)
-  const bool fast_off = getenv("SLAMHIP_K6_FAST") && !strcmp(getenv("SLAMHIP_K6_FAST"), "0");
-  const bool fast = !fast_off && end_bit <= 32 && cfg->base_empty_prob <= 0.5 && !std::isnan(cfg->base_empty_qual) &&
-                    !getenv("SLAMHIP_K6_KEY64");
+  const bool fast = ctx->k6_batch_fast && end_bit <= 32 && cfg->base_empty_prob <= 0.5 &&
+                    !std::isnan(cfg->base_empty_qual) && !ctx->k6_batch_key64;
   if (fast) {
     a.unknown_c0 = tp->unknown[0];
     a.fresh_ok = tp->unknown[0] < 0.0 ? 1 : 0;
     rc = mu_batch_fast_tail(a, sc, beams, end_bit, st);
-  } else if (end_bit <= 32 && !getenv("SLAMHIP_K6_KEY64"))
+  } else if (end_bit <= 32 && !ctx->k6_batch_key64)
     rc = mu_batch_tail<unsigned>(a, sc, total, beams, end_bit, st);
   else
     rc = mu_batch_tail<unsigned long long>(a, sc, total, beams, end_bit, st);

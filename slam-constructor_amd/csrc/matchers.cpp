@@ -122,10 +122,7 @@ int chain_release(slamhip_matcher *m) {
 // OOPE in the default mode; everything else (strict order, host trigonometry, window OOPEs, GMapping,
 // staged copies) keeps the host-driven path
 bool tie_check_default(slamhip_matcher *m) {
-  if (m->tie_check < 0) {
-    const char *v = getenv("SLAMHIP_TIE_CHECK");
-    m->tie_check = (v && v[0] == '0') ? 0 : 1;
-  }
+  if (m->tie_check < 0) m->tie_check = 1;  // (slamhip_matcher_set_tie_check switches it off)
   return m->tie_check == 1;
 }
 
@@ -138,10 +135,7 @@ bool chain_eligible(slamhip_matcher *m) {
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->ctx->scan_n > 4096) return false;  // the terms of a pose sit in LDS (8 bytes per beam next to 15 KB of replay state)
   if (m->max_batch < 6 * kHcMaxInst) return false;  // slamhip_matcher_set_batch asked for small batches
-  if (m->chain_mode < 0) {
-    const char *e = getenv("SLAMHIP_HC_CHAIN");
-    m->chain_mode = (e && e[0] == '0') ? 0 : 1;
-  }
+  if (m->chain_mode < 0) m->chain_mode = 1;  // (slamhip_matcher_set_device_chain switches it off)
   return m->chain_mode == 1;
 }
 
@@ -362,10 +356,7 @@ bool batch_chain_eligible(slamhip_matcher *m) {
   if (m->cfg.sum_order != SLAMHIP_SUM_TREE256) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->max_batch < 6 * kHcMaxInst) return false;
-  if (m->chain_mode < 0) {
-    const char *e = getenv("SLAMHIP_HC_CHAIN");
-    m->chain_mode = (e && e[0] == '0') ? 0 : 1;
-  }
+  if (m->chain_mode < 0) m->chain_mode = 1;  // (slamhip_matcher_set_device_chain switches it off)
   return m->chain_mode == 1;
 }
 
@@ -384,9 +375,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     SLAMHIP_CHECK(hipHostMalloc(&b->h_done_count, sizeof(unsigned), pinned));
   }
   {
-    static const int wgs_env = getenv("SLAMHIP_BATCH_WGS") ? atoi(getenv("SLAMHIP_BATCH_WGS")) : 0;  // (experiments)
-    const int wgs = wgs_env > 0 ? wgs_env : kBatchWgs;
-    const int want = std::min(kHcDefaultInst, std::max(1, wgs / (6 * n)));
+    const int want = std::min(kHcDefaultInst, std::max(1, kBatchWgs / (6 * n)));
     if (want != b->built_inst) {
       SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
       std::vector<HcShape> shapes(kHcShapes);
@@ -401,8 +390,6 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     }
     const int total = n * (6 * b->max_inst + 1);
     b->nt = total <= 256 ? 1024 : (total <= 512 ? 512 : 256);
-    static const int nt_env = getenv("SLAMHIP_BATCH_NT") ? atoi(getenv("SLAMHIP_BATCH_NT")) : 0;  // (experiments)
-    if (nt_env == 256 || nt_env == 512 || nt_env == 1024) b->nt = nt_env;
   }
   if (n > b->cap) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -824,10 +811,7 @@ bool mc_chain_eligible(slamhip_matcher *m) {
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->ctx->scan_n > 4096) return false;  // (see chain_eligible)
   if (m->max_batch < 64) return false;  // slamhip_matcher_set_batch asked for small batches
-  if (m->chain_mode < 0) {
-    const char *e = getenv("SLAMHIP_MC_CHAIN");
-    m->chain_mode = (e && e[0] == '0') ? 0 : 1;
-  }
+  if (m->chain_mode < 0) m->chain_mode = 1;  // (slamhip_matcher_set_device_chain switches it off)
   return m->chain_mode == 1;
 }
 

@@ -485,11 +485,38 @@ int slamhip_ctx_create(int device, slamhip_ctx **out) {
     return hip_fail(e, "completion flag allocation");
   }
   *ctx->h_done_flag = 0;
-  const char *ll = getenv("SLAMHIP_LOW_LATENCY");
-  ctx->low_latency = !(ll && ll[0] == '0');
-  const char *sp = getenv("SLAMHIP_STAGE_POSES");
-  ctx->stage_poses = sp && sp[0] == '1';
   *out = ctx;
+  return SLAMHIP_OK;
+}
+
+int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value) {
+  if (!ctx) return invalid("null argument");
+  switch (option) {
+    case SLAMHIP_OPT_LOW_LATENCY: ctx->low_latency = value != 0; break;
+    case SLAMHIP_OPT_STAGE_POSES: ctx->stage_poses = value != 0; break;
+    case SLAMHIP_OPT_FILTER_CHAINS: ctx->filter_chains = value != 0; break;
+    case SLAMHIP_OPT_K6_PATH:
+      if (value < 0 || value > 2) return invalid("SLAMHIP_OPT_K6_PATH: 0 (default), 1 (counting sort) or 2 (radix sort)");
+      ctx->k6_path = value;
+      break;
+    case SLAMHIP_OPT_K6_BATCH_FAST: ctx->k6_batch_fast = value != 0; break;
+    case SLAMHIP_OPT_K6_BATCH_KEY64: ctx->k6_batch_key64 = value != 0; break;
+    default: return invalid("unknown option");
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value) {
+  if (!ctx || !value) return invalid("null argument");
+  switch (option) {
+    case SLAMHIP_OPT_LOW_LATENCY: *value = ctx->low_latency; break;
+    case SLAMHIP_OPT_STAGE_POSES: *value = ctx->stage_poses; break;
+    case SLAMHIP_OPT_FILTER_CHAINS: *value = ctx->filter_chains; break;
+    case SLAMHIP_OPT_K6_PATH: *value = ctx->k6_path; break;
+    case SLAMHIP_OPT_K6_BATCH_FAST: *value = ctx->k6_batch_fast; break;
+    case SLAMHIP_OPT_K6_BATCH_KEY64: *value = ctx->k6_batch_key64; break;
+    default: return invalid("unknown option");
+  }
   return SLAMHIP_OK;
 }
 

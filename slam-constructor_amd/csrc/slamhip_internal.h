@@ -194,6 +194,9 @@ struct slamhip_ctx {
   void *mu_scratch = nullptr, *mu_bscratch = nullptr;  // K6 work buffers (map_update.hip), owned by the context
   bool low_latency = true;
   bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
+  // slamhip_ctx_set_option: equivalent execution paths (defaults = what is measured)
+  bool filter_chains = true, k6_batch_fast = true, k6_batch_key64 = false;
+  int k6_path = 0;
   // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;

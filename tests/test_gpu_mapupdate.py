@@ -36,12 +36,7 @@ def _default_k6_path(pkg, ctx):
 
 
 def set_k6_path(pkg, ctx, name):
-    """testing hook of the library: which pipeline plain updates of this context take (the default is `gather`:
-    map_update_gather.h; `counting` and `radix` are the record pipelines it falls back to)"""
-    import ctypes as C
-    L = pkg.load()
-    L.slamhip_map_debug_k6_path.argtypes = [C.c_void_p, C.c_int]
-    assert L.slamhip_map_debug_k6_path(ctx.h, K6_PATHS[name]) == 0
+    ctx.set_option(pkg.OPT_K6_PATH, K6_PATHS[name])
 
 
 @pytest.mark.parametrize("path", list(K6_PATHS))

@@ -39,11 +39,7 @@ K6_PATHS = {"gather": 0, "counting": 1, "radix": 2}
 
 
 def set_k6_path(pkg, ctx, name):
-    """testing hook: the pipeline plain updates of this context take (default `gather`, map_update_gather.h)"""
-    import ctypes as C
-    L = pkg.load()
-    L.slamhip_map_debug_k6_path.argtypes = [C.c_void_p, C.c_int]
-    assert L.slamhip_map_debug_k6_path(ctx.h, K6_PATHS[name]) == 0
+    ctx.set_option(pkg.OPT_K6_PATH, K6_PATHS[name])
 
 
 @pytest.fixture(autouse=True)

@@ -414,102 +414,69 @@ def test_cell_index_on_boundaries_matches_true_division(pkg, ctx, po, oracle, sc
     np.testing.assert_array_equal(got, want)
 
 
-_PF_TWIN = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-import __graft_entry__ as ge
-from synth import make_scene
-pkg = ge.load_package()
-ctx = pkg.Context(0)
-sc = make_scene(cell_model=2, size=1500, scale=0.05, n_beams=1080, seed=13)
-ctx.upload_map(0, sc["map"])
-out = {}
-for n in (100, 13, 1):
-    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, np.arange(500, 500 + n, dtype=np.uint32))
-    for k, d in enumerate([sc["true_pose"], [0.02, 0.01, 0.01], [0.3, 0.2, 0.2], [0.01, -0.02, 0.02], [0.0, 0.05, -0.01]]):
-        res, idx = pf.step(0, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
-        poses, w, ms = pf.state()
-        out["n%d_s%d_poses" % (n, k)], out["n%d_s%d_w" % (n, k)] = poses, w
-        out["n%d_s%d_calls" % (n, k)] = np.array([pf.stats()["scorer_calls"], int(res)])
-    pf.close()
-np.savez(sys.argv[2], **out)
-"""
+def _pf_twin(pkg, chains):
+    from synth import make_scene
+    ctx = pkg.Context(0)
+    ctx.set_option(pkg.OPT_FILTER_CHAINS, 1 if chains else 0)
+    sc = make_scene(cell_model=2, size=1500, scale=0.05, n_beams=1080, seed=13)
+    ctx.upload_map(0, sc["map"])
+    out = {}
+    for n in (100, 13, 1):
+        gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+        pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, np.arange(500, 500 + n, dtype=np.uint32))
+        for k, d in enumerate([sc["true_pose"], [0.02, 0.01, 0.01], [0.3, 0.2, 0.2], [0.01, -0.02, 0.02], [0.0, 0.05, -0.01]]):
+            res, idx = pf.step(0, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+            poses, w, ms = pf.state()
+            out["n%d_s%d_poses" % (n, k)], out["n%d_s%d_w" % (n, k)] = poses, w
+            out["n%d_s%d_calls" % (n, k)] = np.array([pf.stats()["scorer_calls"], int(res)])
+        pf.close()
+    ctx.close()
+    return out
 
 
-def test_filter_chains_on_the_device_equal_the_lock_step_jobs(tmp_path):
+def test_filter_chains_on_the_device_equal_the_lock_step_jobs(pkg):
     """The likelihood-only filter step runs one hill-climbing chain per particle on the device, all chains in shared
-    launches; SLAMHIP_PF_CHAIN=0 keeps the host-driven lock-step jobs.  The switch is read once
-    per process, so the two run in two processes: 100 / 13 / 1 particles, five steps each with resamplings --
-    poses, weights, scorer calls and resampling decisions bit for bit."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / "twin.py"
-    script.write_text(_PF_TWIN)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for val in ("1", "0"):
-        f = str(tmp_path / ("pf_%s.npz" % val))
-        env = dict(os.environ, SLAMHIP_PF_CHAIN=val)
-        r = subprocess.run([sys.executable, str(script), root, f], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout + r.stderr
-        outs.append(np.load(f))
-    a, b = outs
-    assert set(a.files) == set(b.files) and len(a.files) == 3 * 5 * 3
-    for k in a.files:
+    launches; SLAMHIP_OPT_FILTER_CHAINS = 0 keeps the host-driven lock-step jobs.  100 / 13 / 1
+    particles, five steps each with resamplings -- poses, weights, scorer calls and resampling decisions bit for bit."""
+    a, b = _pf_twin(pkg, True), _pf_twin(pkg, False)
+    assert set(a) == set(b) and len(a) == 3 * 5 * 3
+    for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
-_PF_MAPS_TWIN = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-import __graft_entry__ as ge
-from synth import make_scene
-pkg = ge.load_package()
-ctx = pkg.Context(0)
-size = 1500
-sc = make_scene(cell_model=2, size=size, scale=0.05, n_beams=1080, seed=13)
-m = sc["map"]
-ctx.upload_map(0, m)
-out = {}
-for n in (40, 5):
-    gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
-    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, np.arange(500, 500 + n, dtype=np.uint32))
-    pf.enable_particle_maps(0, extent_tiles=(size + 127) // 128 + 1, pool_tiles=200 + 120 * n)
-    for k, d in enumerate([sc["true_pose"], [0.02, 0.01, 0.01], [0.3, 0.2, 0.2], [0.01, -0.02, 0.02]]):
-        res, idx = pf.step(0, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
-        poses, w, ms = pf.state()
-        out["n%d_s%d_poses" % (n, k)], out["n%d_s%d_w" % (n, k)] = poses, w
-        out["n%d_s%d_calls" % (n, k)] = np.array([pf.stats()["scorer_calls"], int(res)])
-    ox, oy = m.origin
-    for i in (0, n - 1):
-        pay, aux = pf.particle_map(i, -ox, -oy, size, size)
-        out["n%d_map%d" % (n, i)], out["n%d_aux%d" % (n, i)] = pay, aux
-    pf.close()
-np.savez(sys.argv[2], **out)
-"""
+def _pf_maps_twin(pkg, chains):
+    from synth import make_scene
+    ctx = pkg.Context(0)
+    ctx.set_option(pkg.OPT_FILTER_CHAINS, 1 if chains else 0)
+    size = 1500
+    sc = make_scene(cell_model=2, size=size, scale=0.05, n_beams=1080, seed=13)
+    m = sc["map"]
+    ctx.upload_map(0, m)
+    out = {}
+    for n in (40, 5):
+        gp = [0.0, 0.1, 0.0, 0.03, 0.0, 0.0, 0.0, 0.0]
+        pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, np.arange(500, 500 + n, dtype=np.uint32))
+        pf.enable_particle_maps(0, extent_tiles=(size + 127) // 128 + 1, pool_tiles=200 + 120 * n)
+        for k, d in enumerate([sc["true_pose"], [0.02, 0.01, 0.01], [0.3, 0.2, 0.2], [0.01, -0.02, 0.02]]):
+            res, idx = pf.step(0, sc["scan"].range, sc["scan"].angle, None, d, 7 + k)
+            poses, w, ms = pf.state()
+            out["n%d_s%d_poses" % (n, k)], out["n%d_s%d_w" % (n, k)] = poses, w
+            out["n%d_s%d_calls" % (n, k)] = np.array([pf.stats()["scorer_calls"], int(res)])
+        ox, oy = m.origin
+        for i in (0, n - 1):
+            pay, aux = pf.particle_map(i, -ox, -oy, size, size)
+            out["n%d_map%d" % (n, i)], out["n%d_aux%d" % (n, i)] = pay, aux
+        pf.close()
+    ctx.close()
+    return out
 
 
-def test_filter_chains_through_tile_tables_equal_the_lock_step_jobs(tmp_path):
+def test_filter_chains_through_tile_tables_equal_the_lock_step_jobs(pkg):
     """The same twin run with per-particle copy-on-write maps: every chain gathers through the tile table of its own
     particle (HcChainArgs::tables / slots), and the step ends with the batched map update.  40 and 5 particles, four
     steps with resamplings: poses, weights, scorer calls, resampling decisions and the maps of the first and last
     particle bit for bit."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / "twin_maps.py"
-    script.write_text(_PF_MAPS_TWIN)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for val in ("1", "0"):
-        f = str(tmp_path / ("pfm_%s.npz" % val))
-        env = dict(os.environ, SLAMHIP_PF_CHAIN=val)
-        r = subprocess.run([sys.executable, str(script), root, f], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout + r.stderr
-        outs.append(np.load(f))
-    a, b = outs
-    assert set(a.files) == set(b.files) and len(a.files) == 2 * (4 * 3 + 4)
-    for k in a.files:
+    a, b = _pf_maps_twin(pkg, True), _pf_maps_twin(pkg, False)
+    assert set(a) == set(b) and len(a) == 2 * (4 * 3 + 4)
+    for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)

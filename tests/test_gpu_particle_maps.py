@@ -26,7 +26,7 @@ def pkg():
     return ge.load_package()
 
 
-def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None):
+def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None, options=()):
     import pyoracle as po
     from pyoracle_mapupdate import (RULE_GMAPPING, append_scan_ex, gmapping_enable_particle_maps,
                                     gmapping_particle_map)
@@ -40,6 +40,8 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None)
     r0, a0, pose0 = g["step0_range"], g["step0_angle"], g["step0_delta"]
     # HIP side: dense ancestor (K6, pinned to the reference elsewhere) -> tile pool
     ctx = pkg.Context(0)
+    for opt, val in options:
+        ctx.set_option(opt, val)
     ctx.map_bind(4, 2, w, h, g["origin"], scale, unknown)
     c0, s0 = pkg.beam_trig(a0)
     ctx.map_append_scan(4, pkg.RULE_GMAPPING, pose0, r0, c0, s0)
@@ -85,17 +87,14 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None)
 
 
 @pytest.mark.parametrize("mode", ["fast", "sorted", "key64"])
-def test_particle_maps_filter_vs_oracle(pkg, oracle, mode, monkeypatch):
+def test_particle_maps_filter_vs_oracle(pkg, oracle, mode):
     """The batched map update three ways: `fast` (default) settles the free observations of zero-mean cells with
-    atomics and sorts only the rest (k_mu_classify); `sorted` (SLAMHIP_K6_FAST=0) sorts every record into cell
+    atomics and sorts only the rest (k_mu_classify); `sorted` (SLAMHIP_OPT_K6_BATCH_FAST = 0) sorts every record into cell
     chains; `key64` is the sorted pipeline with 8-byte (particle, cell) keys -- the fall-back for batches whose
-    particle and key-window bits exceed 32 -- forced through SLAMHIP_K6_KEY64."""
-    if mode == "key64":
-        monkeypatch.setenv("SLAMHIP_K6_KEY64", "1")
-    if mode == "sorted":
-        monkeypatch.setenv("SLAMHIP_K6_FAST", "0")
+    particle and key-window bits exceed 32 -- forced through SLAMHIP_OPT_K6_BATCH_KEY64."""
+    options = {"fast": (), "key64": ((pkg.OPT_K6_BATCH_KEY64, 1),), "sorted": ((pkg.OPT_K6_BATCH_FAST, 0),)}[mode]
     n = 8
-    pf, log, (ox, oy, w, h) = run_both(pkg, oracle, n=n)
+    pf, log, (ox, oy, w, h) = run_both(pkg, oracle, n=n, options=options)
     st = log[-1][1]
     assert st["cell_updates"] > 0 and st["tiles_in_use"] > 16
     # the maps of different particles really differ (pose noise -> different cells updated)
@@ -456,7 +455,7 @@ def test_cfg5_geometry_against_the_oracle(pkg, oracle, pose_trig):
 
 @pytest.mark.parametrize("case", ["fresh_map", "area_blur", "negative_blur", "free_points_and_range_gate",
                                   "occupied_base_empty"])
-def test_fast_path_equals_the_sorted_chains(pkg, case, monkeypatch):
+def test_fast_path_equals_the_sorted_chains(pkg, case):
     """The batched update's free-space fast path (k_mu_classify: atomics on the try counters of zero-mean and
     never-observed cells) against the pipeline that sorts every record into its cell's chain, on the same pool
     contents, bit for bit over every particle's whole map -- three scans in a row, so the second and third meet
@@ -485,8 +484,8 @@ def test_fast_path_equals_the_sorted_chains(pkg, case, monkeypatch):
         adder = {"base": (0.95, 1.0, 0.6, 1.0)}
     maps = {}
     for mode in ("fast", "sorted"):
-        monkeypatch.setenv("SLAMHIP_K6_FAST", "1" if mode == "fast" else "0")
         ctx = pkg.Context(0)
+        ctx.set_option(pkg.OPT_K6_BATCH_FAST, 1 if mode == "fast" else 0)
         ctx.map_bind(3, 2, size, size, m.origin, scale, m.unknown)
         if case != "fresh_map":
             ctx.map_upload_window(3, 0, 0, m.payload)
@@ -508,7 +507,7 @@ def test_fast_path_equals_the_sorted_chains(pkg, case, monkeypatch):
     assert touched > n * 1000
 
 
-def test_fast_path_at_full_batch_size_counts_every_record_once(pkg, monkeypatch):
+def test_fast_path_at_full_batch_size_counts_every_record_once(pkg):
     """The 100-particle batch of BASELINE configs[3] (1080 beams, 0.05 m cells) through both pipelines: the number of
     cell updates, the sum of all try counters of a particle (every valid record is exactly one try, whichever path
     settled it) and the whole map of sampled particles, byte for byte.  Two batches, so that the second meets the
@@ -522,8 +521,8 @@ def test_fast_path_at_full_batch_size_counts_every_record_once(pkg, monkeypatch)
     sample = [0, 37, 99]
     out = {}
     for mode in ("fast", "sorted"):
-        monkeypatch.setenv("SLAMHIP_K6_FAST", "1" if mode == "fast" else "0")
         ctx = pkg.Context(0)
+        ctx.set_option(pkg.OPT_K6_BATCH_FAST, 1 if mode == "fast" else 0)
         ctx.map_bind(3, 2, size, size, m.origin, scale, m.unknown)
         ctx.map_upload_window(3, 0, 0, m.payload)
         pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), n, np.arange(n, dtype=np.uint32))
@@ -610,14 +609,13 @@ def test_cfg5_lock_step_through_tile_tables_70_particles(pkg, oracle):
     ctx.close()
 
 
-def _cfg5_batch(pkg, sc, poses, particles_per_call, sample, fast, monkeypatch, size=8000):
+def _cfg5_batch(pkg, sc, poses, particles_per_call, sample, fast, size=8000):
     """One particle_maps_append per group of `particles_per_call` particles at cfg5's geometry; returns the number of
     cell updates and, per sampled particle, (sha256 of its payload window, sha256 of its counters, sum of tries)."""
     import hashlib
     m, scan = sc["map"], sc["scan"]
     win, scale = m.width, m.scale
     off = (size - win) // 2
-    monkeypatch.setenv("SLAMHIP_K6_FAST", "1" if fast else "0")
     out, total = {}, 0
     n = len(poses)
     for g0 in range(0, n, particles_per_call):
@@ -625,6 +623,7 @@ def _cfg5_batch(pkg, sc, poses, particles_per_call, sample, fast, monkeypatch, s
         if particles_per_call < n and not any(int(i) in sample for i in grp):
             continue  # a group no sampled particle belongs to says nothing in the small-group runs
         ctx = pkg.Context(0)
+        ctx.set_option(pkg.OPT_K6_BATCH_FAST, 1 if fast else 0)
         ctx.map_bind(2, 2, size, size, (m.origin[0] + off, m.origin[1] + off), scale, m.unknown)
         ctx.map_upload_window(2, off, off, m.payload)
         k = len(grp)
@@ -645,7 +644,7 @@ def _cfg5_batch(pkg, sc, poses, particles_per_call, sample, fast, monkeypatch, s
     return total, out
 
 
-def test_cfg5_batch_of_500_particles_by_its_properties(pkg, monkeypatch):
+def test_cfg5_batch_of_500_particles_by_its_properties(pkg):
     """BASELINE configs[4] at FULL batch size -- 500 particles, 8000 x 8000 cells of 0.025 m, 1080 beams, area
     estimator, blur 0.1 m, ONE batched K6 (190 M records) -- where the oracle cannot follow (a dense map per
     particle).  Size-independent properties instead: (1) a particle's map does not depend on who else is in the batch:
@@ -659,9 +658,9 @@ def test_cfg5_batch_of_500_particles_by_its_properties(pkg, monkeypatch):
     rs = np.random.RandomState(17)
     poses = sc["true_pose"] + rs.randn(n, 3) * [0.05, 0.05, 0.01]
     sample = {0, 5, 131, 250, 377, 499}
-    total_fast, fast = _cfg5_batch(pkg, sc, poses, n, sample, True, monkeypatch)
-    total_sorted, srt = _cfg5_batch(pkg, sc, poses, n, sample, False, monkeypatch)
-    _, small = _cfg5_batch(pkg, sc, poses, 6, sample, True, monkeypatch)
+    total_fast, fast = _cfg5_batch(pkg, sc, poses, n, sample, True)
+    total_sorted, srt = _cfg5_batch(pkg, sc, poses, n, sample, False)
+    _, small = _cfg5_batch(pkg, sc, poses, 6, sample, True)
     assert total_fast == total_sorted > n * 1080 * 300
     assert set(fast) == set(srt) == set(small) == sample
     for i in sorted(sample):

@@ -23,8 +23,8 @@ for seed in range(rounds):
     occ = None if seed % 3 else (rs.rand(scan.n) < 0.8).astype(np.int32)
     out = {}
     for mode in ("1", "0"):
-        os.environ["SLAMHIP_K6_FAST"] = mode
         ctx = pkg.Context(0)
+        ctx.set_option(pkg.OPT_K6_BATCH_FAST, int(mode))
         ctx.map_bind(3, 2, size, size, m.origin, scale, m.unknown)
         if seed % 4:
             ctx.map_upload_window(3, 0, 0, m.payload)
