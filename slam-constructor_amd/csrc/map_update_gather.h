@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_mu_lines(MuArgs a) {
   // every step's decision checked against the recurrence (as in k_mu_emit); whether the walk ENDS on the end cell is
   // kept apart: a walk whose steps all check out but which stands on another cell after its cap cells is the
   // reference's everyday fail-over to Bresenham -- two or three beams of a scan
-  bool ok = absA > 0.0 && absB > 0.0, end_ok = true;
+  bool ok = absA + absB > 0.0, end_ok = true;  // (axis-parallel beams included: the check decides)
   for (unsigned k = (unsigned)t; k < cap && ok; k += 256u) {
     const double fj = floor((q0 + (double)k * absA) * inv_W), fjn = floor((q0 + (double)(k + 1) * absA) * inv_W);
     const int jj = (int)fmin(fmax(fj, 0.0), (double)k), jn = (int)fmin(fmax(fjn, 0.0), (double)(k + 1));
@@ -203,17 +203,24 @@ __global__ __launch_bounds__(256) void k_mu_lines(MuArgs a) {
     if (oob_cnt) atomicAdd(a.n_padding, oob_cnt);
     return;
   }
-  if (t != 0) return;
-  // ties along diagonals, axis-parallel beams: the sequential walk decides (rare)
-  __threadfence();  // counts / offsets / beam_end / beam_info above, read back by the walk
-  mu_walk_beam<unsigned>(a, b);
-  unsigned long long pad = 0ull;
-  for (unsigned k = 0; k < cap; ++k) {
-    const unsigned key = keys[k];
+  // ties: one scan in five has such a beam (a ray within 1e-7 of a grid vertex).  Wave 0 walks it piece by piece
+  // (mu_walk_beam_wave; thread 0 step by step where that gives up); the marks (an atomic with a returned value each)
+  // are everybody's: one thread walking and then marking 600 cells one round trip after the other was 80-200 us, the
+  // kernel's whole tail.
+  __threadfence();  // counts / offsets / beam_end / beam_info above (thread 0's stores), read back by the walk
+  __syncthreads();
+  if (wave == 0) {
+    if (!mu_walk_beam_wave<unsigned>(a, b, lane) && lane == 0) mu_walk_beam<unsigned>(a, b);
+    __threadfence();  // its keys, read back by the workgroup
+  }
+  __syncthreads();
+  unsigned pad = 0u;
+  for (unsigned k = (unsigned)t; k < cap; k += 256u) {
+    const unsigned key = __builtin_nontemporal_load(&keys[k]);
     if (key >= a.n_bins) ++pad;
     else mark(key);
   }
-  if (pad) atomicAdd(a.n_padding, pad);
+  if (pad) atomicAdd(a.n_padding, (unsigned long long)pad);
 }
 
 // ---- k_mu_cells -------------------------------------------------------------------------------------------------

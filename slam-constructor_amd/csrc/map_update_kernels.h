@@ -400,6 +400,87 @@ __device__ __forceinline__ double mu_uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// The walk of a beam the one-piece closed form does not settle, by a whole wave and exactly as mu_walk_beam would leave
+// it.  What breaks the closed form is a TIE (|d| <= 1e-7: the ray passes a grid vertex): the reference then steps
+// diagonally -- or along the one open axis in the end row / column -- and RESETS the error term to 0
+// (regular_squares_grid.h:85-91), i.e. the rest of the walk is a new digital line from the next cell.  So the walk is
+// a few closed-form pieces: the wave checks 64 steps of the current piece at a time (cell, rebuilt error term, the
+// recurrence's decision against the formula's, as k_mu_emit does), emits the cells up to the first tie, starts the next
+// piece behind it, and stops on the end cell; the rest of the beam's stretch is padding.  A step is classified only
+// when it is clear of the tolerance by 1e-9 (the recurrence's accumulated rounding is below 1e-12); anything else --
+// an unclassifiable step, a decision the formula does not reproduce, a zero-length beam, more than eight ties (a
+// ray along a diagonal ties at every step), a walk that does not arrive within its cap cells (the reference's
+// Bresenham fail-over) -- returns false with nothing decided, and lane 0 walks the beam step by step.
+// (One scan in five has such a beam; lane 0 alone needed 25-40 us for its 600 cells.)
+template <typename KeyT>
+__device__ bool mu_walk_beam_wave(const MuArgs &a, int b, int lane) {
+  const unsigned cap = a.counts[b];
+  if (cap == 0) return true;
+  const MuJob jb = mu_job(a, b);
+  const MuWalkLine L = mu_walk_line(a, jb, a.beam_end[2 * b], a.beam_end[2 * b + 1]);
+  const double absB = fabs(L.B);
+  if (!(L.absA + absB > 0.0)) return false;  // (a beam that ends where it starts)
+  const int ex = a.beam_info[b].ex, ey = a.beam_info[b].ey;
+  const int steps_x = abs(ex - L.bx), steps_y = abs(ey - L.by);
+  const KeyT job_part = a.jobs ? (KeyT)(b / a.n) << a.cell_bits : KeyT(0);
+  const unsigned row = (unsigned)a.key_w, w = (unsigned)a.width, h = (unsigned)a.height;
+  KeyT *out = (KeyT *)a.keys + a.offsets[b];
+  // the current piece: first walk index, cell (in steps from the robot's) and error term there, the formula's offset
+  unsigned k_base = 0u;
+  int ci = 0, cj = 0;
+  double e_base = L.e0, q0s = L.q0;
+  bool bad = false;
+  unsigned n = 0u;  // cells of the walk
+  int ties = 0;
+  for (unsigned k0 = 0u;;) {
+    const unsigned k = k0 + (unsigned)lane, m = k - k_base;
+    const int jm = mu_walk_j(q0s, L.absA, L.inv_W, m), jn = mu_walk_j(q0s, L.absA, L.inv_W, m + 1u);
+    const int im = (int)m - jm;
+    const int i = ci + im, j = cj + jm;
+    const double e = e_base + (double)im * L.A + (double)jm * L.B;
+    const double d = fabs(e + L.B) - fabs(e + L.A), ad = fabs(d);
+    // 0 a plain step the formula reproduces, 1 the end cell, 2 a tie, 3 not classifiable, 4 beyond the cap
+    int cls;
+    if (k >= cap) cls = 4;
+    else if (i == steps_x && j == steps_y) cls = 1;
+    else if (i > steps_x || j > steps_y) cls = 3;
+    else if (ad < 1e-7 - 1e-9) cls = 2;
+    else if (ad > 1e-7 + 1e-9 && (0 < d) == (jn == jm) && jn - jm <= 1) cls = 0;
+    else cls = 3;
+    const unsigned long long ev = __ballot(cls != 0);
+    const int first = ev ? __ffsll((long long)ev) - 1 : 64;
+    const int fcls = first < 64 ? __builtin_amdgcn_readlane(cls, first) : 0;
+    if (fcls == 3 || fcls == 4) return false;
+    if (lane <= first) {  // (lane `first` stands on the end cell or on the cell the tie is decided from: a cell of the walk)
+      const unsigned ix = (unsigned)(L.bx + L.inc_x * i + a.origin_x), iy = (unsigned)(L.by + L.inc_y * j + a.origin_y);
+      const bool oob = ix >= w || iy >= h;
+      bad |= oob;
+      out[k] = oob ? ~KeyT(0) : job_part + (KeyT)(iy - (unsigned)a.key_y0) * row + (KeyT)(ix - (unsigned)a.key_x0);
+    }
+    if (first == 64) {
+      k0 += 64u;
+      continue;
+    }
+    if (fcls == 1) {
+      n = k0 + (unsigned)first + 1u;
+      break;
+    }
+    // a tie at walk index k0 + first
+    if (++ties > 8) return false;
+    const int ti = __builtin_amdgcn_readlane(i, first), tj = __builtin_amdgcn_readlane(j, first);
+    const bool at_x = ti == steps_x, at_y = tj == steps_y;
+    ci = ti + (at_x ? 0 : 1);
+    cj = tj + ((at_x || !at_y) ? 1 : 0);
+    k_base = k0 + (unsigned)first + 1u;
+    e_base = 0.0;
+    q0s = (0.0 - (absB - L.absA) * 0.5) + absB;
+    k0 = k_base;
+  }
+  for (unsigned k = n + (unsigned)lane; k < cap; k += 64u) out[k] = ~KeyT(0);
+  if (__any(bad) && lane == 0) *a.error_flag = 1;
+  return true;
+}
+
 // The walk in parallel.  The reference's loop (regular_squares_grid.h:56-101) is a floating-point recurrence
 // per beam -- 76 of the 170 us of a single-scan update went to 17 waves stepping 600 cells one after the other.
 // But away from ties it is a plain digital line: with A = e_x_inc, B = e_y_inc (opposite signs), u = sign(A) e
@@ -481,7 +562,8 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
   const unsigned row = (unsigned)a.key_w;
   const unsigned w = (unsigned)a.width, h = (unsigned)a.height;
   KeyT *out = (KeyT *)a.keys + base;
-  bool ok = absA > 0.0 && absB > 0.0 && cap == (unsigned)(steps_x + steps_y + 1);
+  // (an axis-parallel beam -- |A| or |B| zero -- is a digital line like any other: the per-step check below decides)
+  bool ok = absA + absB > 0.0 && cap == (unsigned)(steps_x + steps_y + 1);
   bool bad = false;
   if (ok) {
     for (unsigned k0 = 0; k0 < cap; k0 += 64) {
@@ -512,8 +594,8 @@ __global__ __launch_bounds__(256) void k_mu_emit(MuArgs a, unsigned *beam_of) {
     if (beam_of)
       for (unsigned k = lane; k < cap; k += 64) beam_of[base + k] = (unsigned)b;
     if (FUSE >= 0) __threadfence();  // lane 0's own stores above (counts, beam_end, beam_info), read back by the walk
-    if (lane == 0) mu_walk_beam<KeyT>(a, b);
-    __threadfence();  // lane 0's keys, read back by the whole wave below
+    if (!mu_walk_beam_wave<KeyT>(a, b, lane) && lane == 0) mu_walk_beam<KeyT>(a, b);
+    __threadfence();  // the keys, read back by the whole wave below
   } else if (__any(bad) && lane == 0) {
     *a.error_flag = 1;
   }

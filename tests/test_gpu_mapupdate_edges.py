@@ -81,6 +81,20 @@ def crafted_scans():
     rng = np.array([0.0, 0.0, 5.0, 25.0, 1e-9, 7.5, 19.99, 20.01])
     ang = np.deg2rad(np.array([0.0, 90.0, 10.0, 20.0, 30.0, 40.0, 50.0, 60.0]))
     out.append((np.array([0.2, 0.2, 0.0]), rng, ang, np.ones(8, np.int32), -0.004, 20.0))
+    # 5. rays from a cell centre along (p, q) with p, q odd pass a grid VERTEX every (p, q) cells: 1, 2, 6 and 13 ties
+    #    per beam with plain digital-line stretches between them -- the reference steps diagonally and resets its error
+    #    term there (regular_squares_grid.h:85-91); the wave walks such a beam piece by piece (mu_walk_beam_wave), the
+    #    13-tie ones go to the step-by-step walk
+    ang, rng = [], []
+    for p_, q_ in [(3, 1), (1, 3), (5, 3), (3, 5), (7, 1), (-3, 1), (3, -1), (-5, -3), (-7, 5), (9, 7), (-1, -9)]:
+        for t_end in (0.75, 2.2, 6.3, 12.7):
+            if t_end * max(abs(p_), abs(q_)) > 100:
+                continue
+            ang.append(np.arctan2(q_, p_))
+            rng.append(t_end * np.hypot(p_, q_) * SCALE)
+    out.append((np.array([SCALE / 2, SCALE / 2, 0.0]), np.array(rng), np.array(ang), np.ones(len(rng), np.int32), 0.0, np.inf))
+    out.append((np.array([-3.5 * SCALE, 6.5 * SCALE, 0.0]), np.array(rng), np.array(ang),
+                (np.arange(len(rng)) % 4 != 0).astype(np.int32), 0.2, np.inf))
     return out
 
 
