@@ -890,8 +890,9 @@ def cfg5_leg(args, pkg, ctx, torch):
            "cell_updates_last_step": ms["cell_updates"], "tiles_in_use": ms["tiles_in_use"], "pool_bytes": ms["bytes"],
            "dense_ancestor_bytes": size * size * 48, "cow_copies_first_step": first["cow_copies"],
            "launches_last_step": st["launches"], "scene_build_s": round(t_scene, 1),
-           "note": "BASELINE quotes this configuration on 8 GPUs; it fits one MI355X (288 GB), the sharded form is "
-                   "--gpus N --pf-maps-sharded"}
+           "note": "BASELINE quotes this configuration on 8 GPUs; it fits one MI355X (288 GB); with --gpus N > 1 this "
+                   "object is the sharded form (slamhip_gmapping_step_sharded: particles and their maps over the "
+                   "ranks, maps migrating over RCCL send / recv on resampling)"}
     pf.close()
     ctx.map_release(2)
     return out

@@ -361,7 +361,7 @@ bool batch_chain_eligible(slamhip_matcher *m) {
 }
 
 // scoring workgroups per super-step over all chains of a batch.  Measured on MI355X (cfg2 scenes, G units/s at
-// K = 8): see DESIGN.md section 4a -- larger budgets buy fewer super-steps with more discarded poses.
+// K = 8): see DESIGN.md section 4d -- larger budgets buy fewer super-steps with more discarded poses.
 constexpr int kBatchWgs = 1024;
 constexpr int kBatchTracePer = 1 << 14;  // trace entries per chain (a longer match is redone by the single path)
 
