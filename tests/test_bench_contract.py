@@ -40,7 +40,15 @@ def test_default_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["unit"] == d["unit"]
-    assert c["all_cores"]["cores"] > 1 and c["all_cores"]["value"] > c["value"]
+    ac = c["all_cores"]  # one process per PHYSICAL core of the host (`cores_used`)
+    assert ac["cores_used"] > 1 and ac["cores_used"] <= ac["logical_cores"] and ac["value"] > c["value"]
+    assert ac["cores_used"] == ac["physical_cores"]
+    assert d["config"]["speculation_ratio"] >= 1.0 and set(d["config"]["ms_per_match"]) == {"min", "median", "max"}
+    lm = d["latency_model"]
+    assert lm["bound"] == "latency" and abs(lm["frac"] - lm["model"] / lm["achieved"]) < 1e-12 and 0.0 < lm["frac"] <= 1.0
+    rep = d["replicas"]["by_K"]
+    assert [r_["K"] for r_ in rep] == [1, 2, 4, 8, 16] and all(r_["matches_on_shared_launches"] == r_["K"] for r_ in rep[1:])  # (a batch of one is the lone chain)
+    assert d["world_loop"]["cpu_baseline"]["kind"] == "reference"
     pf = d["particle_filter"]
     assert pf["unit"] == "particles/s" and pf["scaling"] == "strong" and pf["roofline"]["kernel"] in ("k_hc_chain_step", "k_score_gmapping")
     assert pf["cpu_baseline"]["kind"] == "reference" and "4000x4000" in pf["cpu_baseline"]["sample"]
