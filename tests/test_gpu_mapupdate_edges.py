@@ -185,6 +185,68 @@ def test_astray_walks_vs_oracle(pkg, ctx, name, path):
     ctx.map_release(3)
 
 
+def vertex_grazing_scans(n_scans=6, beams=192):
+    """Rays aimed at grid vertices with a perpendicular miss between 1e-10 and 1e-5 m, log-uniform, on either side:
+    the tie test of world_to_cells (|d| <= 1e-7) lands on both sides of its tolerance, at one vertex or at several (a
+    ray through one vertex from a rational offset passes others close by).  Ranges reach 2 ... 40 cells beyond the
+    vertex."""
+    rs = np.random.RandomState(77)
+    out = []
+    for k in range(n_scans):
+        pose = np.array([rs.uniform(-2, 2), rs.uniform(-2, 2), rs.uniform(-np.pi, np.pi)])
+        if k % 2 == 0:  # robot on a cell centre: rational directions meet many vertices
+            pose[:2] = (np.floor(pose[:2] / SCALE) + 0.5) * SCALE
+        ang, rng = [], []
+        for _ in range(beams):
+            v = (np.floor(pose[:2] / SCALE) + rs.randint(-60, 61, 2)) * SCALE  # a grid vertex
+            d = v - pose[:2]
+            dist = np.hypot(*d)
+            if dist < 2 * SCALE:
+                continue
+            miss = rs.choice([-1.0, 1.0]) * 10.0 ** rs.uniform(-10, -5)
+            a = np.arctan2(d[1], d[0]) + miss / dist
+            ang.append(a - pose[2])
+            rng.append(dist + rs.uniform(2, 40) * SCALE)
+        out.append((pose, np.array(rng), np.array(ang), (rs.rand(len(rng)) < 0.8).astype(np.int32),
+                    [0.0, 0.15][k % 2], np.inf))
+    return out
+
+
+@pytest.mark.parametrize("path", ["gather", "counting"])
+@pytest.mark.parametrize("name", ["mean", "gmapping"])
+def test_vertex_grazing_rays_vs_oracle(pkg, ctx, name, path):
+    """The walks of beams that pass grid vertices within the tie tolerance or just outside it (mu_walk_beam_wave: pieces
+    of the closed form between ties, classification clear of the tolerance by 1e-9, everything else step by step):
+    cell updates, payload and counters against the oracle's sequential walk."""
+    import pyoracle as po
+    from pyoracle_mapupdate import append_scan_ex
+    set_k6_path(pkg, ctx, path)
+    O = po.Oracle()
+    cell_model, rule, st, n_aux = KINDS[name]
+    unknown = {0: [0.5], 1: [1.0, 0.0, 0.0, 0.0], 2: [-1.0, 0.0, 0.0]}[cell_model]
+    payload = np.empty((SIZE, SIZE, st))
+    payload[:] = unknown
+    m = po.GridMapData(cell_model, payload, (SIZE // 2, SIZE // 2), SCALE, unknown)
+    aux = np.zeros((SIZE, SIZE, max(n_aux, 1)))
+    ctx.upload_map(3, m)
+    for k, (pose, rng, ang, occ, blur, max_range) in enumerate(vertex_grazing_scans()):
+        c, s = pkg.beam_trig(ang)
+        tr = po.ScanData(rng, ang, None, None, po.TRIG_CACHED, 0.0, 1.0, s, c)
+        tr.angle = np.arange(rng.size, dtype=np.float64)
+        nu_o = append_scan_ex(O, m, aux if n_aux else None, rule, pose, rng, tr.angle, occ, quality=0.9, blur=blur,
+                              max_range=max_range, trig=tr)
+        nu = ctx.map_append_scan(3, rule, pose, rng, c, s, occ, quality=0.9, blur=blur, max_range=max_range)
+        assert nu == nu_o, "scan %d" % k
+        got = ctx.map_download_window(3, 0, 0, SIZE, SIZE, st)
+        if name == "gmapping":
+            np.testing.assert_array_equal(got[..., 0], m.payload[..., 0], err_msg="scan %d" % k)
+            np.testing.assert_allclose(got, m.payload, rtol=1e-11, atol=1e-13, err_msg="scan %d" % k)
+        else:
+            np.testing.assert_array_equal(got, m.payload, err_msg="scan %d" % k)
+        np.testing.assert_array_equal(ctx.map_download_aux(3, 0, 0, SIZE, SIZE, n_aux), aux[..., :n_aux])
+    ctx.map_release(3)
+
+
 @pytest.mark.parametrize("path", list(K6_PATHS))
 @pytest.mark.parametrize("name", list(KINDS))
 @pytest.mark.parametrize("estimator", [0, 1])
