@@ -19,8 +19,9 @@ static constexpr int kGmBlock = 256;  // the canonical layout of run resolution 
 // The 3 x 3 window (slam/scmtch/oope/window = 1, every shipped configuration).  A thread's time in K3 is
 // its chain of dependent loads: the generic loop below pays one round trip per window cell (two with a
 // tile table in front), one after the other -- 9 x KB round trips per pose, ~30 of a launch's 37 us.
-// Here the nine cells are fetched whole (32 bytes) with independent loads, behind at most four
-// tile-table entries (the window's corners), and reduced with selects: two round trips per beam.
+// Here the nine cells are fetched with independent loads, behind at most four tile-table entries (the window's
+// corners), and reduced with selects: a round trip for the tiles, one for the occupancies, one for the obstacle
+// means of the full cells.
 // `unk`: the prototype payload in LDS.  Taken from the kernel arguments it lived in scalar registers across
 // the whole kernel, and the compiler parked two of its doubles in SCRATCH (24 bytes per lane written at
 // entry and read back before the gathers: the kernel's only scratch, 1.7 MB of HBM writes per launch).
@@ -39,9 +40,13 @@ __device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const doub
     t10 = tiles[tyh * m.pitch + txl];
     t11 = tiles[tyh * m.pitch + txh];
   }
-  const double4 *cells = reinterpret_cast<const double4 *>(m.payload);
-  const double4 unknown = make_double4(unk[0], unk[1], unk[2], 0.0);
-  double4 v[9];
+  // Two steps of independent loads (r03): the OCCUPANCY of the nine cells, 8 bytes each, then the obstacle mean
+  // (16 bytes) of the full ones only -- one to three next to a wall, none in free space.  Fetching the nine cells
+  // whole was 288 bytes per beam through the CU's L1, and with one pose per CU that cache's throughput, not HBM and
+  // not instruction issue, is what phase A waited for.
+  const double *pay = m.payload;
+  unsigned at9[9];
+  double occ9[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
@@ -54,16 +59,27 @@ __device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const doub
     } else {
       at = (size_t)iy * m.pitch + ix;
     }
-    v[i] = unknown;
-    if (inb) v[i] = cells[at];
+    at9[i] = inb ? (unsigned)at : ~0u;  // (cell indices fit 32 bits: 2^32 cells are 128 GB of payload)
+    occ9[i] = unk[0];
+    if (inb) occ9[i] = pay[4 * at];
   }
   double best_d2 = __builtin_inf();
   bool any = false;
+  double obx9[9], oby9[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    const double ddx = v[i].y - ox, ddy = v[i].z - oy;
+    obx9[i] = unk[1];
+    oby9[i] = unk[2];
+    if (!(occ9[i] < gp.fullness_th) && at9[i] != ~0u) {
+      obx9[i] = pay[4 * (size_t)at9[i] + 1];
+      oby9[i] = pay[4 * (size_t)at9[i] + 2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double ddx = obx9[i] - ox, ddy = oby9[i] - oy;
     const double d2 = ddx * ddx + ddy * ddy;
-    const bool better = !(v[i].x < gp.fullness_th) && d2 < best_d2;
+    const bool better = !(occ9[i] < gp.fullness_th) && d2 < best_d2;
     best_d2 = better ? d2 : best_d2;
     any |= better;
   }
@@ -125,7 +141,8 @@ template <int KB, int NT>
 __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const ScanView &scan, const GmParams &gm,
                                                    const int *tiles, const double *s_unknown, double x, double y, double sn,
                                                    double cs, double r0, double ca0, double sa0, double *s_dyn, int *s_run0,
-                                                   double *s_part1, GmPoseInfo *gi_out, double *score_out) {
+                                                   double *s_part1, GmPoseInfo *gi_out, double *score_out,
+                                                   long long *stamp_a = nullptr) {
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int n = scan.n;
@@ -150,6 +167,7 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
     s_cy[b] = cy;
   }
   __syncthreads();
+  if (stamp_a) *stamp_a = wall_clock64();  // (tools/hc_chain_stamps.py: the end of phase A)
   // canonical layout from here on; waves 4..7 only keep the barriers company
   const bool act = t < kGmBlock;
   int ccx[KB], ccy[KB];

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     double score = 0.0;
     const int *tiles = a.tables ? a.tables + (size_t)a.slots[blockIdx.y] * a.table_stride : nullptr;
     gm_score_pose_wide<KBG, NT>(map, scan, a.gm, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_term, &s_run0_len,
-                                s_part, &ctl->infos[k & 1][slot], &score);
+                                s_part, &ctl->infos[k & 1][slot], &score, stamp ? &a.stamps[8 * k + 4] : nullptr);
     if (t == 0) {
       ctl->scores[k & 1][slot] = score;
       if (stamp) a.stamps[8 * k + 5] = wall_clock64();

@@ -18,7 +18,7 @@ sc = make_scene(cell_model=0, size=2000, scale=0.05, n_beams=1080, seed=100)
 ctx.upload_map(0, sc["map"])
 c, s = pkg.beam_trig(sc["scan"].angle)
 ctx.scan_upload(sc["scan"].range, c, s, sc["scan"].weight, sc["scan"].factor)
-cases = [(256, 1, False), (512, 1, False), (512, 0, False), (1024, 1, False), (512, 1, True)]
+cases = [(256, 1, False), (512, 1, False), (512, 0, False), (1024, 1, False), (1024, 1, True)]
 for threads, check, gm in cases:  # check 0: without the tie check; gm: the GMapping OOPE on a GMapping map
     if gm:
         from synth import CELL_GMAPPING
@@ -41,7 +41,7 @@ for threads, check, gm in cases:  # check 0: without the tie check; gm: the GMap
     steps = m.stats()["launches"]
     st = st[:steps]
     print("threads %d, tie check %d, gmapping %d: %d super-steps, %d re-scored" % (threads, check, gm, steps, m.stats()["steps_rescored"]))
-    names = ["staged", "replayed", "pose", "terms", "stored"]
+    names = ["staged", "replayed", "pose", "terms (GMapping: phase A)", "stored (GMapping: run cache + sum)"]
     d = np.diff(st[:, :6], axis=1) / 100.0
     ok = (st[:, 5] > 0)
     print("  us per phase (mean over the super-steps that scored): " +
