@@ -9,6 +9,9 @@
 namespace slamhip {
 
 static constexpr int kGmBlock = 256;  // the canonical layout of run resolution and sum: thread t owns beams t + 256 k
+// dynamic LDS of gm_score_pose_wide behind its int arrays: one double per thread for the helper lanes' distances
+template <int NT>
+constexpr size_t kGmHelperDoubles = NT >= 512 ? (size_t)NT : 0;
 
 // ---- K3: GMapping OOPE -------------------------------------------------------------------------
 // value of one endpoint: max over the (2w+1)^2 window of cells with prob_occ >= th of
@@ -25,68 +28,124 @@ static constexpr int kGmBlock = 256;  // the canonical layout of run resolution 
 // `unk`: the prototype payload in LDS.  Taken from the kernel arguments it lived in scalar registers across
 // the whole kernel, and the compiler parked two of its doubles in SCRATCH (24 bytes per lane written at
 // entry and read back before the gathers: the kernel's only scratch, 1.7 MB of HBM writes per launch).
-__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
-                                                    const GmParams &gp, int cx, int cy, double ox, double oy) {
-  const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
-  int t00 = 0, t01 = 0, t10 = 0, t11 = 0, txl = 0, tyl = 0;
-  if (tiles) {
-    const int tiles_y = m.height >> kTileShift;
-    txl = min(max(ix0 - 1, 0) >> kTileShift, m.pitch - 1);
-    tyl = min(max(iy0 - 1, 0) >> kTileShift, tiles_y - 1);
-    const int txh = min(max(ix0 + 1, 0) >> kTileShift, m.pitch - 1);
-    const int tyh = min(max(iy0 + 1, 0) >> kTileShift, tiles_y - 1);
-    t00 = tiles[tyl * m.pitch + txl];
-    t01 = tiles[tyl * m.pitch + txh];
-    t10 = tiles[tyh * m.pitch + txl];
-    t11 = tiles[tyh * m.pitch + txh];
-  }
-  // Two steps of independent loads (r03): the OCCUPANCY of the nine cells, 8 bytes each, then the obstacle mean
-  // (16 bytes) of the full ones only -- one to three next to a wall, none in free space.  Fetching the nine cells
-  // whole was 288 bytes per beam through the CU's L1, and with one pose per CU that cache's throughput, not HBM and
-  // not instruction issue, is what phase A waited for.
-  const double *pay = m.payload;
-  unsigned at9[9];
-  double occ9[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
-    const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
-    size_t at;
-    if (tiles) {
-      const bool lo_x = (ix >> kTileShift) == txl, lo_y = (iy >> kTileShift) == tyl;
-      const int tile = lo_y ? (lo_x ? t00 : t01) : (lo_x ? t10 : t11);
-      at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
-    } else {
-      at = (size_t)iy * m.pitch + ix;
-    }
-    at9[i] = inb ? (unsigned)at : ~0u;  // (cell indices fit 32 bits: 2^32 cells are 128 GB of payload)
-    occ9[i] = unk[0];
-    if (inb) occ9[i] = pay[4 * at];
-  }
-  double best_d2 = __builtin_inf();
-  bool any = false;
-  double obx9[9], oby9[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    obx9[i] = unk[1];
-    oby9[i] = unk[2];
-    if (!(occ9[i] < gp.fullness_th) && at9[i] != ~0u) {
-      obx9[i] = pay[4 * (size_t)at9[i] + 1];
-      oby9[i] = pay[4 * (size_t)at9[i] + 2];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const double ddx = obx9[i] - ox, ddy = oby9[i] - oy;
-    const double d2 = ddx * ddx + ddy * ddy;
-    const bool better = !(occ9[i] < gp.fullness_th) && d2 < best_d2;
-    best_d2 = better ? d2 : best_d2;
-    any |= better;
-  }
+// value of a window whose smallest squared distance to a full cell's obstacle mean is best_d2 (any: there is one)
+__device__ __forceinline__ double gm_value_of(double best_d2, bool any) {
   if (!any) return 0.0;
   const double similarity = exp(-best_d2 / 0.05);
   const double r = 1.0 - (1.0 - similarity);
   return 0.0 < r ? r : 0.0;
+}
+
+// The 3 x 3 window of one end point in stages of independent loads, so that a caller can interleave the stages of
+// two windows: tile-table entries (the window's corners) -> issue_occ: the OCCUPANCY of the nine cells, 8 bytes
+// each -> issue_obst: the obstacle mean (16 bytes) of the full ones only -- one to three next to a wall, none in
+// free space -> finish.  (r03: fetching the nine cells whole was 288 bytes per beam through the CU's L1.)
+struct GmWindow1 {
+  unsigned at9[9];  // cell index, ~0: outside the map (cell indices fit 32 bits: 2^32 cells are 128 GB of payload)
+  double occ9[9], obx9[9], oby9[9];
+  __device__ __forceinline__ void issue_occ(const MapView &m, const double *unk, const int *tiles, int cx, int cy) {
+    const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+    int t00 = 0, t01 = 0, t10 = 0, t11 = 0, txl = 0, tyl = 0;
+    if (tiles) {
+      const int tiles_y = m.height >> kTileShift;
+      txl = min(max(ix0 - 1, 0) >> kTileShift, m.pitch - 1);
+      tyl = min(max(iy0 - 1, 0) >> kTileShift, tiles_y - 1);
+      const int txh = min(max(ix0 + 1, 0) >> kTileShift, m.pitch - 1);
+      const int tyh = min(max(iy0 + 1, 0) >> kTileShift, tiles_y - 1);
+      t00 = tiles[tyl * m.pitch + txl];
+      t01 = tiles[tyl * m.pitch + txh];
+      t10 = tiles[tyh * m.pitch + txl];
+      t11 = tiles[tyh * m.pitch + txh];
+    }
+    const double *pay = m.payload;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
+      const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+      size_t at;
+      if (tiles) {
+        const bool lo_x = (ix >> kTileShift) == txl, lo_y = (iy >> kTileShift) == tyl;
+        const int tile = lo_y ? (lo_x ? t00 : t01) : (lo_x ? t10 : t11);
+        at = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+      } else {
+        at = (size_t)iy * m.pitch + ix;
+      }
+      at9[i] = inb ? (unsigned)at : ~0u;
+      occ9[i] = unk[0];
+      if (inb) occ9[i] = pay[4 * at];
+    }
+  }
+  __device__ __forceinline__ void issue_obst(const MapView &m, const double *unk, const GmParams &gp) {
+    const double *pay = m.payload;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      obx9[i] = unk[1];
+      oby9[i] = unk[2];
+      if (!(occ9[i] < gp.fullness_th) && at9[i] != ~0u) {
+        obx9[i] = pay[4 * (size_t)at9[i] + 1];
+        oby9[i] = pay[4 * (size_t)at9[i] + 2];
+      }
+    }
+  }
+  __device__ __forceinline__ double finish(const GmParams &gp, double ox, double oy) const {
+    double best_d2 = __builtin_inf();
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double ddx = obx9[i] - ox, ddy = oby9[i] - oy;
+      const double d2 = ddx * ddx + ddy * ddy;
+      const bool better = !(occ9[i] < gp.fullness_th) && d2 < best_d2;
+      best_d2 = better ? d2 : best_d2;
+      any |= better;
+    }
+    return gm_value_of(best_d2, any);
+  }
+};
+
+// ... and ONE cell of such a window (cell i of the nine, the reference's order): what a helper lane fetches for a
+// beam that has no thread of its own (gm_score_pose_wide).  d2(): the squared distance if the cell is full, else +inf.
+struct GmWindowCell {
+  unsigned at;
+  double occ, obx, oby;
+  __device__ __forceinline__ void issue_occ(const MapView &m, const double *unk, const int *tiles, int cx, int cy, int i) {
+    const int ix = cx + m.origin_x + i / 3 - 1, iy = cy + m.origin_y + i % 3 - 1;
+    const bool inb = (unsigned)ix < (unsigned)m.width && (unsigned)iy < (unsigned)m.height;
+    at = ~0u;
+    occ = unk[0];
+    if (inb) {
+      size_t a;
+      if (tiles) {
+        const int tile = tiles[(iy >> kTileShift) * m.pitch + (ix >> kTileShift)];  // pitch = tiles per row
+        a = ((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask);
+      } else {
+        a = (size_t)iy * m.pitch + ix;
+      }
+      at = (unsigned)a;
+      occ = m.payload[4 * a];
+    }
+  }
+  __device__ __forceinline__ void issue_obst(const MapView &m, const double *unk, const GmParams &gp) {
+    obx = unk[1];
+    oby = unk[2];
+    if (!(occ < gp.fullness_th) && at != ~0u) {
+      obx = m.payload[4 * (size_t)at + 1];
+      oby = m.payload[4 * (size_t)at + 2];
+    }
+  }
+  __device__ __forceinline__ double d2(const GmParams &gp, double ox, double oy) const {
+    const double ddx = obx - ox, ddy = oby - oy;
+    const double v = ddx * ddx + ddy * ddy;
+    // (a NaN distance never wins in GmWindow1::finish: `d2 < best` is false; +inf here says the same)
+    return (!(occ < gp.fullness_th) && v < __builtin_inf()) ? v : __builtin_inf();
+  }
+};
+
+__device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
+                                                    const GmParams &gp, int cx, int cy, double ox, double oy) {
+  GmWindow1 w;
+  w.issue_occ(m, unk, tiles, cx, cy);
+  w.issue_obst(m, unk, gp);
+  return w.finish(gp, ox, oy);
 }
 
 __device__ __forceinline__ double gm_fresh_value(const MapView &m, const double *unk, const int *tiles,
@@ -152,22 +211,75 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
   int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
   int *s_cx = s_grp_start + 4 * KB;
   int *s_cy = s_cx + KB * kGmBlock;
+  double *s_sur = reinterpret_cast<double *>(s_cy + KB * kGmBlock);  // NT doubles (kGmHelperDoubles<NT>)
   int &s_run0_len = *s_run0;
   const double scale = map.scale, inv_scale = map.inv_scale;
-  // phase A over all threads
-  for (int b = t; b < n; b += NT) {
-    const double r = b == t ? r0 : scan.range[b], ca = b == t ? ca0 : scan.cos_a[b], sa = b == t ? sa0 : scan.sin_a[b];
-    const double c = cs * ca - sn * sa;
-    const double s = sn * ca + cs * sa;
-    const double wx = x + r * c;
-    const double wy = y + r * s;
+  // phase A over all threads.  A scan a little longer than the workgroup -- 1080 beams on 1024 threads -- would send
+  // the first wave through the phase TWICE for its 56 surplus beams (2.4 of the phase's 6.6 us: another end point,
+  // another two round trips of gathers).  Instead nine HELPER lanes per surplus beam fetch one cell of its window each,
+  // next to their own beam's nine and in the same two round trips; the beam's value is made from their nine
+  // distances behind the barrier (the same selection: the smallest distance to a full cell).
+  const int surplus = n - NT;
+  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT;
+  if (helpers) {
+    const double c = cs * ca0 - sn * sa0;
+    const double s = sn * ca0 + cs * sa0;
+    const double wx = x + r0 * c;
+    const double wy = y + r0 * s;
     const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
-    s_val[b] = gm_fresh_value(map, s_unknown, tiles, gm, cx, cy, wx, wy);
-    s_cx[b] = cx;
-    s_cy[b] = cy;
+    const bool hlp = t < 9 * surplus;
+    const int hb = NT + t / 9, hi = t - 9 * (t / 9);
+    double hwx = 0.0, hwy = 0.0;
+    int hcx = 0, hcy = 0;
+    if (hlp) {
+      const double hr = scan.range[hb], hca = scan.cos_a[hb], hsa = scan.sin_a[hb];
+      const double hc_ = cs * hca - sn * hsa;
+      const double hs_ = sn * hca + cs * hsa;
+      hwx = x + hr * hc_;
+      hwy = y + hr * hs_;
+      hcx = to_cell(hwx, scale, inv_scale);
+      hcy = to_cell(hwy, scale, inv_scale);
+    }
+    GmWindow1 own;
+    GmWindowCell cell;
+    own.issue_occ(map, s_unknown, tiles, cx, cy);
+    if (hlp) cell.issue_occ(map, s_unknown, tiles, hcx, hcy, hi);
+    own.issue_obst(map, s_unknown, gm);
+    if (hlp) cell.issue_obst(map, s_unknown, gm);
+    s_val[t] = own.finish(gm, wx, wy);
+    s_cx[t] = cx;
+    s_cy[t] = cy;
+    if (hlp) {
+      s_sur[t] = cell.d2(gm, hwx, hwy);
+      if (hi == 0) {
+        s_cx[hb] = hcx;
+        s_cy[hb] = hcy;
+      }
+    }
+  } else {
+    for (int b = t; b < n; b += NT) {
+      const double r = b == t ? r0 : scan.range[b], ca = b == t ? ca0 : scan.cos_a[b], sa = b == t ? sa0 : scan.sin_a[b];
+      const double c = cs * ca - sn * sa;
+      const double s = sn * ca + cs * sa;
+      const double wx = x + r * c;
+      const double wy = y + r * s;
+      const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
+      s_val[b] = gm_fresh_value(map, s_unknown, tiles, gm, cx, cy, wx, wy);
+      s_cx[b] = cx;
+      s_cy[b] = cy;
+    }
   }
   __syncthreads();
   if (stamp_a) *stamp_a = wall_clock64();  // (tools/hc_chain_stamps.py: the end of phase A)
+  if (helpers && t < surplus) {  // (read two barriers further down, in phase C)
+    double best_d2 = __builtin_inf();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double d2 = s_sur[9 * t + i];
+      best_d2 = d2 < best_d2 ? d2 : best_d2;
+    }
+    s_val[NT + t] = gm_value_of(best_d2, best_d2 < __builtin_inf());
+  }
   // canonical layout from here on; waves 4..7 only keep the barriers company
   const bool act = t < kGmBlock;
   int ccx[KB], ccy[KB];

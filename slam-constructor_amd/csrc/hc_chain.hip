@@ -618,8 +618,9 @@ static hipError_t launch_gm(const HcChainArgs &a, int k, int nt, hipStream_t str
   constexpr int MODEL = SLAMHIP_CELL_GMAPPING;
   constexpr bool SEQ = false, BATCH = false;
   const int grid = 6 * a.max_inst + 1;
+  // (+ one double per thread for the helper lanes of gm_score_pose_wide: its 512- and 1024-thread forms)
   const size_t shm = (size_t)KB * 256 * sizeof(double) + 4 * KB * sizeof(int2) + 4 * KB * sizeof(int) +
-                     2 * (size_t)KB * 256 * sizeof(int);
+                     2 * (size_t)KB * 256 * sizeof(int) + (nt >= 512 ? (size_t)nt * sizeof(double) : 0);
   if (nt == 1024) HC_LAUNCH(1024);
   else if (nt == 256) HC_LAUNCH(256);
   else HC_LAUNCH(512);

@@ -599,7 +599,7 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
     // 1024 threads per pose for launches of at most 160 poses
     constexpr int wide_below = 160;
     const int wide = a.n_poses <= wide_below ? 1024 : 0;
-    const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int);
+    const size_t shm_wide = shm + 2 * (size_t)kb * kBlock * sizeof(int) + kGmHelperDoubles<1024> * sizeof(double);
     dim3 grid_gm = grid;  // k_score_gmapping only: the XCD-chunked block order (see the kernel)
     if (a.tables && !xcd_off && grid.x >= 16 && !(a.poses_per_block == 1 && wide)) {
       a.xcd_blocks = (int)grid.x;
