@@ -494,6 +494,25 @@ class Context:
         _check(self.L.slamhip_scan_upload(self.h, rng.size, _d(rng), _d(cos_a), _d(sin_a),
                                           _d(weight), _d(fac)))
 
+    def scan_filter_upload(self, map_id, rng, ang, pose, is_occ=None, factor=None, trig_mode=TRIG_RAW, a_min=0.0,
+                           a_max=0.0, a_inc=1.0, skip_rate=0, max_range=-1.0, bounded=False, weighting="even"):
+        """slamhip_scan_filter_upload: the RAW scan in -- filter_scan, weighting, beam trig and the upload in one call.
+        Returns the raw indices of the points kept."""
+        rng, ang, pose = _f64(rng), _f64(ang), _f64(pose)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        fac = _f64(factor) if factor is not None else None
+        kept = np.zeros(max(rng.size, 1), np.int32)
+        n = C.c_int(0)
+        self.L.slamhip_scan_filter_upload.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _dp, C.c_int, C.c_double,
+                                                      C.c_double, C.c_double, _dp, C.c_uint, C.c_double, C.c_int, C.c_int,
+                                                      C.POINTER(C.c_int), _ip]
+        _check(self.L.slamhip_scan_filter_upload(
+            self.h, int(map_id), rng.size, _d(rng), _d(ang), occ.ctypes.data_as(_ip) if occ is not None else None,
+            _d(fac) if fac is not None else None, int(trig_mode), a_min, a_max, a_inc, _d(pose), int(skip_rate),
+            float(max_range), int(bool(bounded)), {"even": 0, "viny": 1, "ahr": 2}[weighting], C.byref(n),
+            kept.ctypes.data_as(_ip)))
+        return kept[:n.value].copy()
+
     def scan_store(self, slot, rng, cos_a, sin_a, weight, factor=None):
         """Keeps a filtered scan resident in HBM (slot 0..4095); scan_select / match jobs refer to it."""
         rng, cos_a, sin_a, weight = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(weight)
