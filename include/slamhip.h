@@ -311,8 +311,7 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
  * workgroup size 256 / 512 / 1024, 0 = default (1024 for hill climbing, 512 for Monte Carlo).  Scores, decisions,
  * observer events and the Monte-Carlo engine's stream are the same bit for bit either way. */
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
-/* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell OOPE is CHECKED (on = 1, the default; the environment
- * variable SLAMHIP_TIE_CHECK=0 turns it off for a process): a `best < candidate`
+/* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell OOPE is CHECKED (on = 1, the default): a `best < candidate`
  * (pose_enumeration_scan_matcher.h:58) between canonical tree sums that lie within 2^-40 of each other -- more
  * than the two orders of summation can differ by -- and whose beam terms are not identical (compared through a
  * fingerprint of the term vector) is not decided from the tree sums: the poses in question are summed once more in

@@ -591,8 +591,8 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
     SLAMHIP_CHECK(hipMalloc(&sc.scan_temp, sc.scan_temp_bytes));
     sc.cap_bins = cap;
   }
-  // The GATHER form (map_update_gather.h, the default wherever it applies): two kernels, no records.  SLAMHIP_K6_SORT =
-  // counting / radix keep the record pipelines (the parity tests run all three).
+  // The GATHER form (map_update_gather.h, the default wherever it applies): two kernels, no records.
+  // SLAMHIP_OPT_K6_PATH = 1 / 2 keep the record pipelines (the parity tests run all three).
   const bool force_counting = sc.force_path == 1;
   bool gather = counting && !force_counting && ctx->low_latency && n <= 4096 && n_bins <= (1ll << 22);
   if (gather) {

@@ -34,7 +34,7 @@ struct slamhip_matcher {
   int chain_mode = -1;  // -1 = decide from the environment at the first match, 0 off, 1 on
   int chain_nt = 1024, chain_ahead = 3;
   int chain_max_inst = slamhip::kHcMaxInst;  // instances of the largest shape (grid size of a super-step)
-  int tie_check = -1;  // checked default mode: -1 = from the environment (SLAMHIP_TIE_CHECK=0 turns it off), 0, 1
+  int tie_check = -1;  // checked default mode: -1 = not set yet (on), 0, 1 (slamhip_matcher_set_tie_check)
   long long chain_rescored = 0;  // super-steps (device chain) / batches (host-driven) of the last match scored twice
   long long rescored_poses = 0;
   std::vector<double> keep_scores;
