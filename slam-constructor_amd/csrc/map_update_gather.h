@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void k_mu_cells(MuArgs a, unsigned far_blocks)
           const double oxc = in ? s_buf[wave][3][lane] : 0.0, oyc = in ? s_buf[wave][4][lane] : 0.0;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and those loads before the next round's stores
           __builtin_amdgcn_wave_barrier();
-          mu_wave_apply<RULE>(a, c, lane, n_here, in, pc, qc, qlc, oxc, oyc);
+          // (the wave's stretch of s_buf is free again: every lane holds its record)
+          mu_wave_apply<RULE>(a, c, lane, n_here, in, pc, qc, qlc, oxc, oyc, &s_buf[wave][0][0]);
         }
       }
     }

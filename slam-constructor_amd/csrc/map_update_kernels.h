@@ -1157,7 +1157,7 @@ __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is 
 // for a / b (v_div_scale, v_rcp, two Newton steps, quotient, residual, v_div_fmas, v_div_fixup) splits into a part that
 // needs the denominator alone and a tail of three dependent operations on the numerator.  Inside 2^-500 .. 2^500 the
 // scaling steps leave both operands alone, so the refined reciprocal can be made a step early; outside (and for zeros,
-// infinities, NaNs) the plain division runs.  tools/scratch/div_probe.hip: 16.7 M divisions, all bit-equal.
+// infinities, NaNs) the plain division runs.  tools/probes/div_probe.hip: 16.7 M divisions, all bit-equal.
 __device__ __forceinline__ double mu_refined_rcp(double y) {
   const double r0 = __builtin_amdgcn_rcp(y);
   const double f0 = __builtin_fma(-y, r0, 1.0);
@@ -1185,7 +1185,7 @@ __device__ __forceinline__ double mu_div_with(double x, double y, double r) {
 // step ahead (see below).
 template <int RULE>
 __device__ __forceinline__ void mu_wave_apply(const MuArgs &a, MuCell &c, int lane, int n_here, bool in, double p,
-                                              double q, double ql, double ox, double oy) {
+                                              double q, double ql, double ox, double oy, double *s_wave = nullptr) {
   constexpr bool kReadsQuality = RULE >= 1 && RULE <= 3;
   unsigned long long busy = ~0ull;  // records that need arithmetic
   if (RULE == 4) busy = __ballot(in && !(p <= 0.5));  // hits and NaNs
@@ -1201,7 +1201,35 @@ __device__ __forceinline__ void mu_wave_apply(const MuArgs &a, MuCell &c, int la
     const double tp = 0.5 + (p - 0.5) * ql;  // mu_step's that_p, per lane
     const bool mine = lane < n_here;
     const bool fine = !mine || (tp > 0x1p-400 && tp < 0x1p400);
-    if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52) {
+    if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52 && s_wave) {
+      // With 192 doubles of LDS of the wave's own (k_mu_cells): everything a step needs besides the running mean --
+      // its denominator n + 1 + t (exact: integers below 2^53), that denominator's refined reciprocal, the
+      // observation -- is made by lane t for step t, all 64 at once, and the loop reads it back with uniform LDS
+      // loads that depend on nothing in the chain.  What is left per observation is the chain itself: multiply, add,
+      // multiply, two fused multiply-adds.  (From lane broadcasts and with the reciprocal made inside the loop a
+      // step took 65 ns: fourteen vector instructions, a quarter-rate v_rcp among them, for five that depend.)
+      const double nj = c.x0 + 1.0 + (double)lane;
+      s_wave[lane] = mu_refined_rcp(nj);
+      s_wave[64 + lane] = nj;
+      s_wave[128 + lane] = tp;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double c0 = c.c0, x0 = c.x0;
+#pragma unroll 4
+      for (; t < n_here; ++t) {
+        const double r = s_wave[t], n1 = s_wave[64 + t], tpt = s_wave[128 + t];
+        const double x = c0 * x0 + tpt;
+        const double qq = x * r;
+        const double e = __builtin_fma(-n1, qq, x);
+        c0 = __builtin_fma(e, r, qq);
+        x0 = n1;
+      }
+      c.c0 = c0;
+      c.x0 = x0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // these loads before the caller's next stores
+      __builtin_amdgcn_wave_barrier();
+    } else if (__all(fine) && c.c0 >= 0.0 && c.c0 < 0x1p400 && c.x0 >= 0.0 && c.x0 < 0x1p52) {
       double r = mu_refined_rcp(c.x0 + 1.0);
       for (; t < n_here; ++t) {
         const double n1 = c.x0 + 1;
@@ -1209,8 +1237,9 @@ __device__ __forceinline__ void mu_wave_apply(const MuArgs &a, MuCell &c, int la
         const double r_next = mu_refined_rcp(n1 + 1.0);  // (independent of x: scheduled beside the tail below)
         const double qq = x * r;
         const double e = __builtin_fma(-n1, qq, x);
-        const double q2 = __builtin_fma(e, r, qq);
-        c.c0 = __builtin_amdgcn_div_fixup(q2, n1, x);
+        // (no v_div_fixup: with both operands inside 2^-500 .. 2^500 -- the test above -- it has nothing to fix, and
+        // it was one of six dependent operations per observation; tools/probes/div_probe.hip: 0 of 13.6 M different)
+        c.c0 = __builtin_fma(e, r, qq);
         c.x0 = n1;
         r = r_next;
       }

@@ -1,7 +1,7 @@
 // scratch: a / b from a reciprocal refined AHEAD (the part of the IEEE division sequence that depends on the
 // denominator alone) against the compiler's own division, bit for bit -- for the dependent chains of
 // MeanProbabilityCell updates, where the denominator (n + 1) is known a step early.
-// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/scratch/div_probe.hip -o tools/_build/div_probe
+// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/div_probe.hip -o tools/_build/div_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -27,6 +27,13 @@ __device__ __forceinline__ double div_with(double x, double y, double r) {
   const double q2 = __builtin_fma(e, r, q);
   return __builtin_amdgcn_div_fixup(q2, y, x);
 }
+// ... and without v_div_fixup, which inside the safe range has nothing to fix (no zero, infinity, NaN, no scaled
+// operand): one dependent operation less in the chain
+__device__ __forceinline__ double div_nofix(double x, double y, double r) {
+  const double q = x * r;
+  const double e = __builtin_fma(-y, q, x);
+  return __builtin_fma(e, r, q);
+}
 __global__ void k(const double *x, const double *y, int n, unsigned long long *bad, double *ex) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -34,6 +41,13 @@ __global__ void k(const double *x, const double *y, int n, unsigned long long *b
   const double b = div_with(x[i], y[i], refined_rcp(y[i]));
   if (__double_as_longlong(a) != __double_as_longlong(b)) {
     if (atomicAdd(bad, 1ull) == 0) { ex[0] = x[i]; ex[1] = y[i]; ex[2] = a; ex[3] = b; }
+  }
+  if (safe(x[i]) && safe(y[i])) {
+    atomicAdd(bad + 2, 1ull);
+    const double c = div_nofix(x[i], y[i], refined_rcp(y[i]));
+    if (__double_as_longlong(a) != __double_as_longlong(c)) {
+      if (atomicAdd(bad + 1, 1ull) == 0) { ex[4] = x[i]; ex[5] = y[i]; ex[6] = a; ex[7] = c; }
+    }
   }
 }
 int main() {
@@ -56,14 +70,17 @@ int main() {
     }
   }
   double *dx, *dy, *dex; unsigned long long *dbad;
-  hipMalloc(&dx, 8 * n); hipMalloc(&dy, 8 * n); hipMalloc(&dex, 32); hipMalloc(&dbad, 8);
+  hipMalloc(&dx, 8 * n); hipMalloc(&dy, 8 * n); hipMalloc(&dex, 64); hipMalloc(&dbad, 24);
   hipMemcpy(dx, x.data(), 8 * n, hipMemcpyHostToDevice); hipMemcpy(dy, y.data(), 8 * n, hipMemcpyHostToDevice);
-  hipMemset(dbad, 0, 8);
+  hipMemset(dbad, 0, 24);
   hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, dy, n, dbad, dex);
-  unsigned long long bad = 0; double ex[4];
-  hipMemcpy(&bad, dbad, 8, hipMemcpyDeviceToHost); hipMemcpy(ex, dex, 32, hipMemcpyDeviceToHost);
+  unsigned long long bad3[3] = {0, 0, 0}; double ex[8];
+  hipMemcpy(bad3, dbad, 24, hipMemcpyDeviceToHost); hipMemcpy(ex, dex, 64, hipMemcpyDeviceToHost);
+  const unsigned long long bad = bad3[0];
   std::printf("%d divisions, %llu different", n, bad);
   if (bad) std::printf(" (first: %a / %a = %a, got %a)", ex[0], ex[1], ex[2], ex[3]);
+  std::printf("; without v_div_fixup inside the safe range: %llu of %llu different", bad3[1], bad3[2]);
+  if (bad3[1]) std::printf(" (first: %a / %a = %a, got %a)", ex[4], ex[5], ex[6], ex[7]);
   std::printf("\n");
-  return bad ? 1 : 0;
+  return (bad || bad3[1]) ? 1 : 0;
 }

@@ -2,7 +2,9 @@
 """The reference's single-hypothesis world loop (tinySLAM / vinySLAM) with and without the drop-in, in ONE process on
 the GPU box: oracle/_ref/libslamref_world.so (built here from the reference's headers, oracle/Makefile) runs
 init_1h_slam's world and the HBM-resident world (host/slamhip_resident_world.h) over the same synthetic scans, compares
-them (trajectory and final map bit for bit) and reports the wall time each spent inside handle_sensor_data.
+them (trajectory and final map bit for bit) and reports the wall time per scan of each -- the two worlds run one AFTER
+the other over the same scans (interleaved, the resident world's queued map update would finish unseen while the
+reference computes its next scan), the resident world's time includes its last queued update.
 A measurement for DESIGN.md section 6 -- not part of bench.py: the library under oracle/ is test infrastructure.
 
     python tools/world_loop_timing.py [n_scans] [n_beams]
