@@ -488,7 +488,12 @@ def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, firs
     tiles_per_particle = tiles_per_particle or args.pf_tiles_per_particle
     pfm = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n, seeds, first=first, count=count)
     ext = (size + 127) // 128 + 1
-    pfm.enable_particle_maps(map_id, extent_tiles=ext, pool_tiles=ext * ext + 2 * count * tiles_per_particle, **(adder or {}))
+    # room for the shard's own maps and as much again for maps that migrate in; never more than 70 % of what the GPU
+    # has free (ranks that share a GPU -- path testing under gloo -- would otherwise take each other's memory)
+    pool_tiles = ext * ext + 2 * count * tiles_per_particle
+    free_bytes, _total = torch.cuda.mem_get_info()
+    pool_tiles = max(ext * ext + count, min(pool_tiles, int(0.7 * free_bytes / (128 * 128 * 48))))
+    pfm.enable_particle_maps(map_id, extent_tiles=ext, pool_tiles=pool_tiles, **(adder or {}))
     bounds = np.cumsum(counts)
     owner = lambda j: int(np.searchsorted(bounds, int(j), side="right"))  # noqa: E731  (contiguous blocks)
     moved_bytes = 0
