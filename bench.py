@@ -96,6 +96,9 @@ def parse():
                     help="the reference's beam-order sum (SLAMHIP_SUM_SEQUENTIAL) with device pose trig")
     ap.add_argument("--chain", type=int, default=-1,
                     help="the HC / MC accept chain on the device: 0 off, 1 on, 256/512/1024 = on with that workgroup size")
+    ap.add_argument("--chain-mode", type=int, default=-1, choices=[-1, 1, 2],
+                    help="device chain of the hill-climbing headline: 1 = a kernel per super-step (csrc/hc_chain.hip), "
+                         "2 = one co-resident launch per match (csrc/hc_resident.hip); -1 = the library's default (2)")
     ap.add_argument("--leg-timeout", type=int, default=480,
                     help="seconds the sharded particle-filter leg may take at N > 1 before the line goes out without it")
     ap.add_argument("--dry-ranks", type=int, default=0,
@@ -1288,7 +1291,10 @@ def main():
     else:
         m = pkg.Matcher(ctx, kind, cfg, params)
         if args.chain >= 0 and kind in ("HC", "MC"):
-            m.set_device_chain(1 if args.chain else 0, args.chain if args.chain > 1 else 0)
+            m.set_device_chain((args.chain_mode if args.chain_mode > 0 else 2) if args.chain else 0,
+                               args.chain if args.chain > 1 else 0)
+        elif args.chain_mode > 0 and kind == "HC":
+            m.set_device_chain(args.chain_mode)
         if args.no_tie_check:
             m.set_tie_check(0)
         on_device = kind in ("HC", "MC") and args.chain != 0 and not args.strict
@@ -1351,7 +1357,10 @@ def main():
     if m is not None:
         st = m.stats()
         if on_device:
-            kernel_name = "k_hc_chain_step" if kind == "HC" else "k_mc_chain_step"
+            resident = kind == "HC" and m.resident_stats()["matches"] > 0
+            kernel_name = ("k_hc_chain_resident" if resident else "k_hc_chain_step") if kind == "HC" else "k_mc_chain_step"
+            if resident:
+                extra.update(resident=m.resident_stats())
         sm = np.sort(np.asarray(step_ms))
         extra.update(scenes="%d rotating (scan, odometry error) pairs resident in HBM: robot poses jittered by N(0, 0.15 m / "
                             "0.04 rad), a fresh range-noise seed each, pose errors 0..3 x (+0.07 m, -0.04 m, +0.03 rad)"
@@ -1361,8 +1370,11 @@ def main():
                      poses_evaluated_per_step=timed_evaluated / args.steps,
                      speculation_ratio=timed_evaluated / max(timed_calls, 1),
                      launches_per_step=st["launches"],
-                     accept_chain=("on the device: one process_scan = a chain of kernels, each replaying the previous "
-                                   "one's speculation tree (csrc/hc_chain.hip, csrc/mc_chain.hip)") if on_device else
+                     accept_chain=(("on the device: one process_scan = ONE launch of co-resident workgroups that exchange "
+                                    "their scores inside it and replay every super-step's speculation tree "
+                                    "(csrc/hc_resident.hip)") if kernel_name == "k_hc_chain_resident" else
+                                   ("on the device: one process_scan = a chain of kernels, each replaying the previous "
+                                    "one's speculation tree (csrc/hc_chain.hip, csrc/mc_chain.hip)")) if on_device else
                                   "on the host: speculative batches, replay between launches",
                      kernel_busy_frac=k_ms / (1e3 * dt_instrumented) if dt_instrumented > 0 else None,
                      host_us_last_step={k: round(st[k], 1) for k in ("build_us", "stage_us", "score_us", "replay_us")})

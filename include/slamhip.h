@@ -307,10 +307,17 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
  * whole accept chain on the device: one process_scan = a chain of kernels with no host in between, each replaying
  * the previous one's speculative candidates in the reference's order (csrc/hc_chain.h, csrc/mc_chain.h;
  * pose_enumeration_scan_matcher.h:31-77, hill_climbing_scan_matcher.h:10-170, monte_carlo_scan_matcher.h:10-100).
- * mode: 1 on (default), 0 = the host-driven speculative batches every other configuration uses; threads:
- * workgroup size 256 / 512 / 1024, 0 = default (1024 for hill climbing, 512 for Monte Carlo).  Scores, decisions,
- * observer events and the Monte-Carlo engine's stream are the same bit for bit either way. */
+ * mode: 0 = the host-driven speculative batches every other configuration uses; 1 = a chain of kernels, one per
+ * super-step; 2 (default) = hill climbing over the 1-cell OOPE as ONE launch whose workgroups stay on the chip and
+ * exchange their scores inside it (csrc/hc_resident.hip) -- every wait in it is bounded, and a match whose
+ * workgroups were not all resident (the device was shared) is redone by mode 1, as is everything mode 2 does not
+ * cover (GMapping OOPE, Monte Carlo); threads: workgroup size 256 / 512 / 1024, 0 = default (1024 for hill
+ * climbing, 512 for Monte Carlo).  Scores, decisions, observer events and the Monte-Carlo engine's stream are the
+ * same bit for bit in every mode. */
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
+/* mode 2's bookkeeping: matches launched in the co-resident form, and how many of them gave up (bounded wait ran
+ * out) and were redone by the chain of kernels */
+int slamhip_matcher_resident_stats(slamhip_matcher *m, long long *matches, long long *gave_up);
 /* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell OOPE is CHECKED (on = 1, the default): a `best < candidate`
  * (pose_enumeration_scan_matcher.h:58) between canonical tree sums that lie within 2^-40 of each other -- more
  * than the two orders of summation can differ by -- and whose beam terms are not identical (compared through a

@@ -37,7 +37,7 @@ slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_map_set_auto_grow slamhip_map_info slamhip_map_set_deferred slamhip_map_drain slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_set_tie_check slamhip_matcher_process_scan
-slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
+slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_resident_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
@@ -204,6 +204,7 @@ def load():
     L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
     L.slamhip_matcher_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.slamhip_matcher_chain_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.slamhip_matcher_resident_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.slamhip_pf_normalize.argtypes = [i, _dp]
     L.slamhip_pf_resampling_is_required.argtypes = [i, _dp, _ip]
     L.slamhip_pf_resample.argtypes = [i, _dp, C.c_uint32, C.POINTER(C.c_uint)]
@@ -677,7 +678,8 @@ class Matcher:
         _check(self.L.slamhip_matcher_set_batch(self.h, n))
 
     def set_device_chain(self, mode, threads=0):
-        """Hill climbing on the device (1) or through host-driven speculative batches (0)."""
+        """Device chains: 2 = hill climbing over the 1-cell OOPE as one co-resident launch (default), 1 = a kernel
+        per super-step, 0 = host-driven speculative batches."""
         _check(self.L.slamhip_matcher_set_device_chain(self.h, int(mode), int(threads)))
 
     def set_tie_check(self, on):
@@ -792,6 +794,12 @@ class Matcher:
         return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value,
                     kernels_launched=kl.value, steps_rescored=rs.value, build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
                     replay_us=t[3].value)
+
+    def resident_stats(self):
+        """Matches launched in the co-resident form, and how many of them gave up and were redone by the kernel chain."""
+        a, b = C.c_longlong(), C.c_longlong()
+        _check(self.L.slamhip_matcher_resident_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(matches=a.value, gave_up=b.value)
 
 
 class GmappingFilter:

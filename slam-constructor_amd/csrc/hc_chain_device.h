@@ -43,6 +43,20 @@ struct HcChainCtl {
   double first_raw;
 };
 
+// ---- the co-resident form of the chain (hc_resident.hip): one launch per match, scores exchanged inside it
+// {score, term-vector fingerprint, tag}: ONE naturally aligned 16-byte write-through store, its own flag (the tag is
+// the last dword)
+struct alignas(16) HcGranule {
+  double score;
+  unsigned hash, tag;
+};
+struct HcResidentCtl {
+  HcGranule gran[2][kHcSlots + 7];  // super-step k's scores at [k & 1]
+  HcGranule seq[2][kHcSlots + 7];   // beam-order sums of a re-scored super-step
+  unsigned fail_epoch;              // = epoch of a match whose workgroups gave up (a bounded spin ran out)
+  unsigned pad[3];
+};
+
 // one match of a BATCH of independent matches (slamhip_matcher_process_scan_batch): its own map and its own scan
 struct HcJobView {
   MapView map;
@@ -88,11 +102,21 @@ struct HcChainArgs {
   int trace_cap;        // trace_cap entries
   int trace_stride;
   long long *stamps;    // debugging: 8 wall-clock stamps (100 MHz) per super-step of workgroup 1, or null
+  // co-resident form only (hc_resident.hip)
+  HcResidentCtl *rctl;   // one per chain
+  unsigned *h_all_done;  // pinned; a batch's last chain to end stores the epoch here (null: a lone chain)
+  int debug_mute;        // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
 };
 
 // threads per workgroup: 256, 512 or 1024; n_chains > 1: the multi-chain form (see HcChainArgs::inits)
 hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,
                                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int n_chains = 1);
+// the whole match in ONE launch of co-resident workgroups (1-cell OOPE); the caller has checked the grid against
+// hc_resident_capacity.  HcHostOut::error 4: a workgroup was not resident (bounded spin ran out), 5: more super-steps
+// than a tag counts -- either way nothing was reported, the kernel chain redoes the match
+hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream,
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int n_chains = 1);
+hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, size_t lds_bytes, int *out_wgs);
 // one thread: copies the number of finished chains to pinned memory and publishes a launch number (the host's
 // view of a burst of multi-chain super-steps)
 hipError_t launch_chain_marker(const unsigned *n_done, unsigned *h_done_count, unsigned *flag, unsigned seq,

@@ -1,0 +1,664 @@
+// hc_resident.hip -- one hill-climbing process_scan as ONE launch of co-resident workgroups.
+//
+//   PoseEnumerationScanMatcher::process_scan      src/core/scan_matchers/pose_enumeration_scan_matcher.h:31-77
+//   Distorsion1DPoseEnumerator +
+//   FailedRoundsLimitedPoseEnumerator (HC)        src/core/scan_matchers/hill_climbing_scan_matcher.h:10-126
+//
+// hc_chain.hip runs a match as a chain of kernels: a super-step scores one speculation tree, the next kernel's
+// prologue stages the 253 scores from memory and replays the accept chain over them.  Its fixed costs per
+// super-step -- kernel boundary 1.8 us, staging 1.6 us -- are what this file removes: the same 6 x instances + 1
+// one-pose workgroups are launched ONCE and loop over the super-steps.  A workgroup
+//   scores its pose (k_score_point's arithmetic and canonical sum: same bits as every other path),
+//   publishes {score, fingerprint, tag} as ONE 16-byte write-through (sc0 sc1) store -- a granule, the data is
+//     its own flag --,
+//   and wave 0 re-reads the granules of the whole tree (sc1 loads, they bypass the CU's L1) until every tag is
+//     this super-step's, replays the accept chain (hc_chain.h: lane = round instance, seven ballots) and derives
+//     the pose it scores next.
+// Nobody waits for a barrier or a flag, only for data; every workgroup replays (nothing is broadcast).
+// Measured before it was built (tools/probes/coresident_probe.hip, profiles/r04_coresident_probe.txt): granule
+// all-gather 2.0 us from publish to "all 253 here" against 1.7 (boundary) + 0.9 (staging) in the probe's model of
+// the kernel chain; an arrival counter is 5.0 us, three 8-byte granules per score 3.5 us, replaying once and
+// broadcasting the root no better than everybody replaying.
+//
+// Residency.  The loop only terminates if every workgroup of the grid is on the chip at the same time.  The grid is
+// sized by the host from the occupancy query (hc_resident_capacity) -- hipLaunchCooperativeKernel would add the same
+// check at +15-19 us per launch (MI355X_MICROARCH.md, coop-launch) -- and EVERY spin is bounded: a sweep that does
+// not complete within kHcSpinLimit polls stores the match's epoch in HcResidentCtl::fail_epoch, reports error 4 to the
+// host and leaves; the other workgroups see the word and leave; workgroups that start later leave at once.  The
+// host then runs the match on the kernel chain.  A hang is impossible by construction.
+//
+// Visibility (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", form R2): a
+// granule is one naturally aligned 16-byte sc1 store by one lane and is read by 16-byte sc1 loads; it was never
+// observed torn (the probe checks a hash of the score in every granule it reads: 0 of 3 x 10^8), and the tag word
+// is the LAST dword of the granule.  Everything else a workgroup reads during the loop is read-only for the match
+// (map, scan, shapes) or its own LDS.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "hc_chain_device.h"
+#include "score_device.h"
+
+namespace slamhip {
+
+namespace {
+
+constexpr int kSumLanes = 256;          // the canonical sum's partials (= k_score_point's block)
+constexpr unsigned kHcSpinLimit = 1u << 17;  // polls of one sweep (~0.4 us each) before the chain gives up
+constexpr int kHcResidentMaxSteps = 4000;    // super-steps a tag can count (12 bits, 0 excluded)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ long long bcast_ll(long long v, int lane) {
+  const int lo = bcast_i((int)(unsigned)(unsigned long long)v, lane);
+  const int hi = bcast_i((int)(unsigned)((unsigned long long)v >> 32), lane);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double bcast(double v, int lane) {
+  return __longlong_as_double(bcast_ll(__double_as_longlong(v), lane));
+}
+
+// tag of super-step k of the match with this epoch: never 0 (a zeroed block matches nothing); the host clears the
+// block whenever the 20 epoch bits wrap
+__device__ __forceinline__ unsigned hc_tag(unsigned epoch, int k) { return ((epoch & 0xfffffu) << 12) | (unsigned)(k + 1); }
+
+__device__ __forceinline__ void gran_store(HcGranule *p, double score, unsigned hash, unsigned tag) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(score);
+  u32x4 g;
+  g.x = (unsigned)u;
+  g.y = (unsigned)(u >> 32);
+  g.z = hash;
+  g.w = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(g) : "memory");
+}
+// issue only: gran_wait ties the loaded values to the one wait
+__device__ __forceinline__ u32x4 gran_load(const HcGranule *p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// (one operand per granule: the values cannot be used before the wait)
+__device__ __forceinline__ void gran_wait(u32x4 (&g)[7]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6])::"memory");
+}
+__device__ __forceinline__ void gran_wait(u32x4 (&g)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])::"memory");
+}
+__device__ __forceinline__ void gran_wait(u32x4 (&g)[2]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1])::"memory");
+}
+__device__ __forceinline__ double gran_score(const u32x4 &g) {
+  return __longlong_as_double((long long)(((unsigned long long)g.y << 32) | (unsigned long long)g.x));
+}
+
+}  // namespace
+
+// MODEL: SLAMHIP_CELL_OCC / _TBM (the 1-cell OOPE); SEQ: the reference's beam-order sum; BATCH: grid.y independent
+// matches, each with its own map and scan (HcChainArgs::jobs); G: granules per lane of the sweeping wave, i.e. the
+// grid has at most 64 G workgroups (2, 4 or 7)
+template <int MODEL, int NT, bool SEQ, bool BATCH, int G>
+__global__ __launch_bounds__(NT) void k_hc_chain_resident(HcChainArgs a) {
+  extern __shared__ double s_term[];  // one term per beam
+  __shared__ unsigned s_hash[kHcSlots + 7];
+  __shared__ double s_sc[kHcSlots + 7];
+  __shared__ HcInst s_mine[kHcShapes];  // this workgroup's round instance in every shape
+  __shared__ double s_pose[2][4];       // x, y, sin, cos of the pose this workgroup scores, by step parity
+  __shared__ int s_go[2], s_mode[2];
+  __shared__ int s_stop;
+  __shared__ HcState s_st;              // root state of the super-step about to be scored (wave 0's, between phases)
+  __shared__ double s_part[4];
+  __shared__ unsigned long long s_hpart[4];
+  const int t = threadIdx.x, wave = t >> 6;
+  const int slot = blockIdx.x + 1 == gridDim.x ? kHcSlots - 1 : (int)blockIdx.x;
+  const int inst_of_slot = slot / 6, cand = slot - 6 * inst_of_slot;
+  const bool init_slot = slot == kHcSlots - 1;
+  HcResidentCtl *const rc = a.rctl + blockIdx.y;
+  HcHostOut *const host = a.host + blockIdx.y;
+  // a workgroup that starts after the others have given up (it was not resident with them) leaves at once
+  if (__hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) return;
+  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing: the others must give up, not hang)
+  MapView map;
+  ScanView scan;
+  if (BATCH) {
+    const HcJobView *__restrict__ jv = a.jobs + blockIdx.y;
+    map = jv->map;
+    scan = jv->scan;
+  } else {
+    map = a.map;
+    scan = a.scan;
+  }
+  const int n = scan.n;
+  // this thread's first beam: its constants stay in registers for the whole match
+  double br = 0.0, bc = 0.0, bs = 0.0, bw = 0.0, bf = 0.0;
+  if (t < n) {
+    br = scan.range[t];
+    bc = scan.cos_a[t];
+    bs = scan.sin_a[t];
+    bw = scan.weight[t];
+    bf = scan.factor[t];
+  }
+  if (wave == 1 && (t & 63) < kHcShapes && !init_slot) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(&a.shapes[t & 63].inst[inst_of_slot]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_mine[t & 63]);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
+  }
+  if (t == 0) s_stop = 0;
+  const bool verify = a.verify != 0;
+  const bool stamp = a.stamps && slot == 1 && t == 0;
+  HcGranule *const gran = &rc->gran[0][0];
+  HcGranule *const gseq = &rc->seq[0][0];
+  constexpr int kGranRow = kHcSlots + 7;
+
+  if (t == 0) {
+    HcState st{};
+    st.x = a.inits ? a.inits[3 * blockIdx.y] : a.init[0];
+    st.y = a.inits ? a.inits[3 * blockIdx.y + 1] : a.init[1];
+    st.theta = a.inits ? a.inits[3 * blockIdx.y + 2] : a.init[2];
+    st.dt = a.dt0;
+    st.dr = a.dr0;
+    st.shape = a.shape0;
+    st.first = 1;
+    st.carry_cx = st.carry_cy = -1;
+    st.carry_prob = -1.0;
+    s_st = st;
+  }
+  __syncthreads();  // s_mine, s_stop, s_st
+
+  const int t_entry = t;
+  for (int k = 0;; ++k) {
+    const int pk = k & 1;
+    // the thread index as a value the compiler cannot see through: everything derived from it (beam addresses,
+    // fingerprint multipliers, LDS offsets) is recomputed per super-step instead of being hoisted out of the loop and
+    // held in registers across it -- hoisted, the kernel needs 237 VGPRs and a 1024-thread workgroup spills 85
+    int t = t_entry;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63;
+    // ---- wave 0: this workgroup's pose of super-step k
+    if (wave == 0) {
+      if (stamp && k < 64) a.stamps[8 * k + 0] = wall_clock64();
+      const HcState &st = s_st;
+      bool go = !st.done;
+      double px = st.x, py = st.y, pth = st.theta;
+      if (init_slot) {
+        go = go && (st.first || st.mode == 1);  // the initial pose / the base pose of a re-scored tree
+      } else if (go) {
+        HcInst in;
+#pragma unroll
+        for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
+        go = inst_of_slot < (int)((a.n_inst >> (8 * st.shape)) & 0xffull) &&
+             (hc_is_root(in) || st.failed + hc_nfail_parent(in) < a.max_failed);  // else: behind the end of the chain
+        if (go) {
+          const HcRound r = hc_round_of(st, in);
+          go = !(hc_trailing(r.failed, a.max_failed) && cand > 0);  // a trailing round has one candidate
+          hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, cand, &px, &py, &pth);
+        }
+      }
+      if (go) {
+        double sn, cs;
+        sincos(pth, &sn, &cs);
+        if (lane == 0) {
+          s_pose[pk][0] = px;
+          s_pose[pk][1] = py;
+          s_pose[pk][2] = sn;
+          s_pose[pk][3] = cs;
+        }
+      }
+      if (lane == 0) {
+        s_go[pk] = go ? 1 : 0;
+        s_mode[pk] = st.mode;
+        if (st.done) s_stop = 1;
+      }
+      if (stamp && k < 64) a.stamps[8 * k + 3] = wall_clock64();
+    }
+    __syncthreads();  // (A)
+    if (s_stop) break;
+    const int go = s_go[pk], mode = s_mode[pk];
+    const unsigned tag = hc_tag(a.epoch, k);
+    if (go) {
+      const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
+      // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order, wave
+      // butterfly, (g0+g1)+(g2+g3)) -- k_score_point's order; up to four beams per thread at a time, their cell
+      // gathers issued together (hc_chain.hip)
+      for (int base = t; base < n; base += 4 * NT) {
+        double4 cell[4];
+        double w_[4], f_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int b = base + j * NT;
+          w_[j] = 0.0;
+          f_[j] = 0.0;
+          cell[j] = make_double4(0.0, 0.0, 0.0, 0.0);
+          if ((base - lane) + j * NT >= n) continue;  // no lane of this wave has a beam in this slot
+          const int bc_ = b < n ? b : n - 1;
+          double r_ = br, ca = bc, sa = bs;
+          w_[j] = bw;
+          f_[j] = bf;
+          if (j > 0 || base != t) {
+            r_ = scan.range[bc_];
+            ca = scan.cos_a[bc_];
+            sa = scan.sin_a[bc_];
+            w_[j] = scan.weight[bc_];
+            f_[j] = scan.factor[bc_];
+          }
+          cell[j] = beam_cell<MODEL>(map, px, py, sn, cs, r_, ca, sa);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int b = base + j * NT;
+          if (b < n) s_term[b] = cell_probability<MODEL>(a.oie, cell[j]) * w_[j] * f_[j];
+        }
+      }
+      __syncthreads();  // (B)
+      if (stamp && k < 64) a.stamps[8 * k + 4] = wall_clock64();
+      if (SEQ) {
+        // the reference's own order: one running sum over the beams (weighted_mean_point_probability_spe.h:108-124)
+        if (t == 0) {
+          double acc = 0.0;
+          int b = 0;
+          for (; b + 8 <= n; b += 8) {
+            const double t0 = s_term[b], t1 = s_term[b + 1], t2 = s_term[b + 2], t3 = s_term[b + 3];
+            const double t4 = s_term[b + 4], t5 = s_term[b + 5], t6 = s_term[b + 6], t7 = s_term[b + 7];
+            acc = acc + t0;
+            acc = acc + t1;
+            acc = acc + t2;
+            acc = acc + t3;
+            acc = acc + t4;
+            acc = acc + t5;
+            acc = acc + t6;
+            acc = acc + t7;
+          }
+          for (; b < n; ++b) acc = acc + s_term[b];
+          gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0u, tag);
+        }
+        __syncthreads();  // (C) (s_term is rewritten by the next super-step)
+      } else {
+        if (t < kSumLanes) {
+          double acc = 0.0;
+          unsigned long long h = 0ull;  // fingerprint of the term vector (score_device.h)
+          unsigned k_lo = (2u * (unsigned)t + 1u) * 0x9E3779B1u, k_hi = (2u * (unsigned)t + 1u) * 0x85EBCA6Bu;
+          for (int b = t; b < n; b += kSumLanes) {
+            const double term = s_term[b];
+            acc = acc + term;
+            if (verify) {
+              h += term_fingerprint(term, k_lo, k_hi);
+              k_lo += 2u * kSumLanes * 0x9E3779B1u;
+              k_hi += 2u * kSumLanes * 0x85EBCA6Bu;
+            }
+          }
+          wave_xor_sum_with(acc, h);
+          if (lane == 0) {
+            s_part[wave] = acc;
+            s_hpart[wave] = h;
+          }
+        }
+        __syncthreads();  // (C)
+        if (t == 0) {
+          const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+          const unsigned fp = verify ? fold_fingerprint(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]) : 0u;
+          gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : total / scan.tot_w, fp, tag);
+        }
+        if (verify && mode && t == 64) {
+          // re-scored super-step: the reference's own order as well, one running sum over the beams
+          double acc = 0.0;
+          for (int b = 0; b < n; ++b) acc = acc + s_term[b];
+          gran_store(&gseq[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0u, tag);
+        }
+      }
+      if (stamp && k < 64) a.stamps[8 * k + 5] = wall_clock64();
+    } else if (!init_slot && t == 0) {
+      // nothing to score (behind the end of the chain, or the surplus candidates of a trailing round): the sweepers
+      // wait for every slot of the shape, so the tag goes out all the same
+      gran_store(&gran[pk * kGranRow + slot], 0.0, 0u, tag);
+      if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0u, tag);
+    }
+
+    // ---- wave 0: all scores of super-step k, then its replay
+    if (wave == 0) {
+      const HcState &sp = s_st;  // (fields are read where they are used: a register copy of the struct is 34 VGPRs)
+      const int n_inst = (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
+      // the round instances of this tree's shape, lane = instance: loads in flight while the scores arrive
+      HcInst me;
+      {
+        const unsigned long long *src = &a.shapes[sp.shape].inst[lane].w[0];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) me.w[q] = src[q];
+      }
+      const bool active = lane < n_inst;
+      const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
+      const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), a.max_failed);
+      const int bpi = hc_bp_inst(me);
+      const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
+      // where every instance's round starts: closed form of the root and the path, no score involved -- computed
+      // here, while the granules are on their way, instead of on the terminal lane after the ballots
+      HcRound rr{sp.x, sp.y, sp.theta, sp.dt, sp.dr, sp.failed};
+      if (reach) rr = hc_round_of(sp, me);
+      // ---- sweep: slots 0 .. 6 n_inst - 1, and the bookkeeping slot when it scored (initial pose / re-scored base)
+      const int n6 = 6 * n_inst;
+      const bool base_here = sp.first || sp.mode == 1;
+      const int n_wait = n6 + (base_here ? 1 : 0);
+      const bool rescored = !SEQ && verify && sp.mode == 1;
+      bool failed = false;
+      {
+        const HcGranule *g0 = gran + pk * kGranRow;
+        unsigned spins = 0;
+        for (;;) {
+          u32x4 g[G];
+          bool ok = true;
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            g[q] = u32x4{0u, 0u, 0u, 0u};
+            if (64 * q < n_wait) {  // (uniform)
+              const int i = lane + 64 * q;
+              const int j = i < n6 ? i : kHcSlots - 1;
+              g[q] = gran_load(g0 + j);
+            }
+          }
+          gran_wait(g);
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            if (64 * q < n_wait) {
+              const int i = lane + 64 * q;
+              if (i < n_wait) {
+                const int j = i < n6 ? i : kHcSlots - 1;
+                const bool here = g[q].w == tag;
+                ok = ok && here;
+                if (here) {
+                  s_sc[j] = gran_score(g[q]);
+                  s_hash[j] = g[q].z;
+                }
+              }
+            }
+          }
+          if (__all(ok)) break;
+          ++spins;
+          if ((spins & 31u) == 0u) {
+            const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+            if (gone || spins > kHcSpinLimit) {
+              failed = true;
+              break;
+            }
+          }
+        }
+      }
+      if (stamp && k < 64) a.stamps[8 * k + 1] = wall_clock64();
+      if (failed || k + 1 >= kHcResidentMaxSteps) {
+        // a workgroup of the grid is not on the chip (or the chain is longer than a tag can count): everybody
+        // leaves, the host runs the match on the kernel chain
+        if (lane == 0) {
+          __hip_atomic_store(&rc->fail_epoch, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&host->error, failed ? 4 : 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __threadfence_system();
+          __hip_atomic_store(&host->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          s_stop = 1;
+        }
+        continue;  // to (A), where the workgroup leaves
+      }
+      // ---- replay of super-step k's tree, lane = round instance (hc_chain.h)
+      double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
+      double s6[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s6[c] = s_sc[6 * lane + c];
+      const double enter = bp_slot < 0 ? root_prob : s_sc[bp_slot];  // canonical (reported) score entering the round
+      double run = enter;
+      int nacc = 0, out = 0;
+      unsigned accmask = 0u;
+      bool ambiguous = false;
+      unsigned run_hash = 0u;
+      if (!SEQ && verify) {
+        // slot kHcSlots-1 holds the base pose of a re-scored tree (or the initial pose): its sums head the path
+        const unsigned root_hash = base_here ? s_hash[kHcSlots - 1] : (unsigned)sp.best_hash;
+        unsigned hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
+        unsigned h6[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) h6[c] = s_hash[6 * lane + c];
+        if (!rescored) {
+          // decisions from the canonical sums; a comparison closer than the two summation orders can differ
+          // (2^-40, relative) between poses whose term vectors differ is one the tree sum cannot settle
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const double s = s6[c];
+            const double diff = __builtin_fabs(s - run);
+            const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
+            const bool live = c == 0 || !trailing;
+            const bool close = diff <= (as > ab ? as : ab) * 9.094947017729282e-13;  // NaN: false, a rejection
+            ambiguous = ambiguous || (live && close && h6[c] != hb);
+            const bool acc = live && run < s;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
+            run = acc ? s : run;
+            hb = acc ? h6[c] : hb;
+            out = acc ? c + 1 : out;
+            nacc += acc ? 1 : 0;
+            accmask |= acc ? 1u << c : 0u;
+          }
+        } else {
+          // re-scored tree: the same comparisons on the beam-order sums.  Their granules were stored next to the
+          // canonical ones by other lanes: wait for their tags as well, one granule at a time (the rare step: a
+          // rolled loop that costs no registers)
+          const HcGranule *q0 = gseq + pk * kGranRow;
+          double bdec = 0.0;
+#pragma unroll 1
+          for (int c = -1; c < 6; ++c) {
+            const int j = c < 0 ? (bp_slot < 0 ? kHcSlots - 1 : bp_slot) : (active ? 6 * lane + c : kHcSlots - 1);
+            double sd = 0.0;
+            for (unsigned spins = 0;; ++spins) {
+              u32x4 g = gran_load(q0 + j);
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
+              sd = gran_score(g);
+              if (__all(g.w == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+            }                                                         // the same workgroups are here already)
+            if (c < 0) {
+              bdec = sd;
+              continue;
+            }
+            const bool acc = active && (c == 0 || !trailing) && bdec < sd;
+            bdec = acc ? sd : bdec;
+            run = acc ? s_sc[6 * lane + c] : run;  // the canonical sum of the pose accepted last: stored and reported
+            hb = acc ? s_hash[6 * lane + c] : hb;
+            out = acc ? c + 1 : out;
+            nacc += acc ? 1 : 0;
+            accmask |= acc ? 1u << c : 0u;
+          }
+        }
+        run_hash = hb;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections
+            run = s6[c];
+            out = c + 1;
+            ++nacc;
+            accmask |= 1u << c;
+          }
+      }
+      bool valid = reach;
+#pragma unroll
+      for (int o = 0; o < 7; ++o) {
+        const unsigned long long has = __ballot(reach && out == o);
+        valid = valid && (me.w[o] & ~has) == 0ull;
+      }
+      const bool terminal = valid && (trailing || hc_child(me, out) < 0);
+      const unsigned long long tmask = __ballot(terminal);
+      // exactly one lane is terminal: the walk's last round
+      const int tl = tmask ? __ffsll((long long)tmask) - 1 : 0;
+      // acceptances on the walked path: a round has at most six, so six ballots and popcounts add them up
+      long long batch_acc = 0;
+#pragma unroll
+      for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
+      if (stamp && k < 64) a.stamps[8 * k + 7] = wall_clock64();
+      // checked default mode: a comparison on the walked path that the tree sum cannot settle -> the same tree is
+      // scored once more, in beam order as well, and decided from those sums
+      const bool dirty = !SEQ && verify && sp.mode == 0 && __ballot(valid && ambiguous) != 0ull;
+      // the terminal lane's round, outcome and best score in every lane, then the advance computed by all of them
+      HcRound rt;
+      rt.x = bcast(rr.x, tl);
+      rt.y = bcast(rr.y, tl);
+      rt.theta = bcast(rr.theta, tl);
+      rt.dt = bcast(rr.dt, tl);
+      rt.dr = bcast(rr.dr, tl);
+      rt.failed = (unsigned)bcast_i((int)rr.failed, tl);
+      const int out_t = bcast_i(out, tl);
+      const double run_t = bcast(run, tl);
+      const int depth_t = bcast_i(hc_depth(me), tl);
+      const bool trailing_t = bcast_i(trailing ? 1 : 0, tl) != 0;
+      HcState next = sp;
+      if (!dirty) {
+        const long long batch_calls = 6ll * depth_t + (trailing_t ? 1 : 6);
+        hc_advance(sp, me, rt, out_t, run_t, a.max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0),
+                   &next);
+        if (!SEQ && verify) {
+          next.best_hash = (unsigned)bcast_i((int)run_hash, tl);
+          next.mode = 0;
+          next.rescored = sp.rescored;
+        }
+      } else {
+        // same root, same tree, same `first`
+        next.mode = 1;
+        next.steps = sp.steps + 1;
+        next.evaluated = sp.evaluated + 6ll * n_inst + 1;
+        next.rescored = sp.rescored + 1;
+      }
+      if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
+        next.done = 1;
+        if (init_slot && lane == 0) host->error = 1;
+      }
+      if (stamp && k < 64) a.stamps[8 * k + 2] = wall_clock64();
+      if (init_slot) {
+        // ---- the last workgroup keeps the books (it scores nothing after the first super-step)
+        if (a.trace && !dirty) {
+          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_stride;
+          const long long base = sp.calls + (sp.first ? 1 : 0);
+          if (sp.first && lane == 0 && a.trace_cap > 0) {
+            HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};
+            trace[0] = e;
+          }
+          if (valid) {
+            const int nc = trailing ? 1 : 6;
+            for (int c = 0; c < nc; ++c) {
+              HcTraceEntry e;
+              hc_candidate(rr.x, rr.y, rr.theta, rr.dt, rr.dr, c, &e.x, &e.y, &e.theta);
+              e.score = s_sc[6 * lane + c];
+              e.accepted = (accmask >> c) & 1u;
+              e.pad = 0;
+              const long long at = base + 6ll * hc_depth(me) + c;
+              if (at < a.trace_cap) trace[at] = e;
+              else host->error = 2;
+            }
+          }
+        }
+        if (next.done) {
+          // every lane's trace stores first, then the result, then the flag the host spins on
+          __threadfence_system();
+          if (lane == 0) {
+            HcHostOut *h = host;
+            h->pose[0] = next.x;
+            h->pose[1] = next.y;
+            h->pose[2] = next.theta;
+            h->best_prob = next.best_prob;
+            h->calls = next.calls;
+            h->evaluated = next.evaluated;
+            h->steps = next.steps;
+            h->rescored = next.rescored;
+            h->gm_cx = -1;
+            h->gm_cy = -1;
+            h->gm_prob = -1.0;
+            if (a.n_done) {
+              // (a batch: the last chain to end tells the host)
+              const unsigned before = atomicAdd(a.n_done, 1u);
+              __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+              if (before + 1u == gridDim.y && a.h_all_done) {
+                __threadfence_system();
+                __hip_atomic_store(a.h_all_done, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+              }
+            } else {
+              __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
+        }
+      }
+      if (lane == 0) s_st = next;  // (`sp` above is this very object: the books are kept from the old state first)
+    }
+  }
+}
+
+#define HCR_LAUNCH(NTV, GV)                                                                                     \
+  do {                                                                                                          \
+    if (e0 || e1)                                                                                               \
+      hipExtLaunchKernelGGL((k_hc_chain_resident<MODEL, NTV, SEQ, BATCH, GV>), dim3(grid, n_chains), dim3(NTV), shm, stream, e0, e1, 0, a); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_hc_chain_resident<MODEL, NTV, SEQ, BATCH, GV>), dim3(grid, n_chains), dim3(NTV), shm, stream, a);     \
+  } while (0)
+
+// granules per sweeping lane for a grid of `grid` workgroups
+static int gran_per_lane(int grid) { return grid <= 128 ? 2 : (grid <= 256 ? 4 : 7); }
+
+template <int MODEL, bool SEQ, bool BATCH>
+static hipError_t launch_res(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                             int n_chains) {
+  const int grid = 6 * a.max_inst + 1;
+  const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
+  const int g = gran_per_lane(grid);
+  // (workgroup sizes and sweep widths that go together: a lone chain is 253 x 1024 threads, a batch's chains are
+  // narrower trees of narrower workgroups)
+  if (nt == 1024) {
+    if (g == 2) HCR_LAUNCH(1024, 2);
+    else if (g == 4) HCR_LAUNCH(1024, 4);
+    else return hipErrorInvalidValue;  // 385 workgroups of 1024 threads are not resident together
+  } else if (nt == 256) {
+    if (g == 2) HCR_LAUNCH(256, 2);
+    else if (g == 4) HCR_LAUNCH(256, 4);
+    else HCR_LAUNCH(256, 7);
+  } else {
+    if (g == 2) HCR_LAUNCH(512, 2);
+    else if (g == 4) HCR_LAUNCH(512, 4);
+    else HCR_LAUNCH(512, 7);
+  }
+  return hipGetLastError();
+}
+#undef HCR_LAUNCH
+
+hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream, hipEvent_t e0,
+                                    hipEvent_t e1, int n_chains) {
+  if (!a.rctl) return hipErrorInvalidValue;
+  if (a.jobs) {
+    if (a.seq) return hipErrorInvalidValue;
+    if (cell_model == SLAMHIP_CELL_OCC) return launch_res<SLAMHIP_CELL_OCC, false, true>(a, nt, stream, e0, e1, n_chains);
+    if (cell_model == SLAMHIP_CELL_TBM) return launch_res<SLAMHIP_CELL_TBM, false, true>(a, nt, stream, e0, e1, n_chains);
+    return hipErrorInvalidValue;
+  }
+  if (cell_model == SLAMHIP_CELL_OCC)
+    return a.seq ? launch_res<SLAMHIP_CELL_OCC, true, false>(a, nt, stream, e0, e1, n_chains)
+                 : launch_res<SLAMHIP_CELL_OCC, false, false>(a, nt, stream, e0, e1, n_chains);
+  if (cell_model == SLAMHIP_CELL_TBM)
+    return a.seq ? launch_res<SLAMHIP_CELL_TBM, true, false>(a, nt, stream, e0, e1, n_chains)
+                 : launch_res<SLAMHIP_CELL_TBM, false, false>(a, nt, stream, e0, e1, n_chains);
+  return hipErrorInvalidValue;
+}
+
+// workgroups of `nt` threads (with `lds_bytes` of dynamic LDS) the device keeps resident at once, by the occupancy
+// query with the register-file rule of MI355X_MICROARCH.md ("Residency and cooperative launch": the API can be one
+// block per CU high above 80 SGPRs; this kernel's waves also need <= 128 VGPRs at 1024 threads) and one CU of margin
+hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, size_t lds_bytes, int *out_wgs) {
+  int dev = 0, cus = 0, per_cu = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return e;
+  const void *fn = nullptr;
+#define HCR_FN(M, B)                                                                                  \
+  (nt == 1024 ? (const void *)k_hc_chain_resident<M, 1024, false, B, 4>                               \
+              : (nt == 256 ? (const void *)k_hc_chain_resident<M, 256, false, B, 7>                   \
+                           : (const void *)k_hc_chain_resident<M, 512, false, B, 7>))
+  if (cell_model == SLAMHIP_CELL_TBM) fn = batch ? HCR_FN(SLAMHIP_CELL_TBM, true) : HCR_FN(SLAMHIP_CELL_TBM, false);
+  else fn = batch ? HCR_FN(SLAMHIP_CELL_OCC, true) : HCR_FN(SLAMHIP_CELL_OCC, false);
+#undef HCR_FN
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, lds_bytes);
+  if (e != hipSuccess) return e;
+  const int by_waves = 2048 / nt;  // 128-VGPR waves: four per SIMD
+  per_cu = per_cu < by_waves ? per_cu : by_waves;
+  if (per_cu > 6) per_cu = 6;      // floor(800 / (ceil(sgpr / 16) * 16 + 16)) at ~106 SGPRs
+  *out_wgs = per_cu * cus;
+  return hipSuccess;
+}
+
+}  // namespace slamhip

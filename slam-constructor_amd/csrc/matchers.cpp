@@ -31,8 +31,15 @@ struct slamhip_matcher {
   int shape_n_inst[slamhip::kHcShapes] = {0};
   unsigned chain_epoch = 0;
   double chain_steps_avg = 12.0;
-  int chain_mode = -1;  // -1 = decide from the environment at the first match, 0 off, 1 on
+  int chain_mode = -1;  // -1 = decide at the first match, 0 off, 1 the chain of kernels, 2 one co-resident launch
   int chain_nt = 1024, chain_ahead = 3;
+  // the co-resident form (hc_resident.hip): exchange block, workgroups the device keeps resident (by workgroup
+  // size; 0 = not asked yet), matches that gave up in a row / in total (bounded spin ran out: kernel chain instead)
+  slamhip::HcResidentCtl *d_rctl = nullptr;
+  int resident_cap[3] = {0, 0, 0};
+  int resident_gave_up_row = 0;
+  int debug_resident_mute = 0;  // testing (slamhip_matcher_debug_resident_mute)
+  long long resident_gave_up = 0, resident_matches = 0;
   int chain_max_inst = slamhip::kHcMaxInst;  // instances of the largest shape (grid size of a super-step)
   int tie_check = -1;  // checked default mode: -1 = not set yet (on), 0, 1 (slamhip_matcher_set_tie_check)
   long long chain_rescored = 0;  // super-steps (device chain) / batches (host-driven) of the last match scored twice
@@ -89,11 +96,15 @@ namespace slamhip {
 namespace {
 
 constexpr int kChainNeedsHost = 1;  // internal: positive, never leaves the library
+constexpr int kResidentGaveUp = 2;  // internal: the co-resident launch left without a result, the kernel chain redoes the match
+constexpr int kChainDefaultMode = 2;  // device chains: 1 = a kernel per super-step, 2 = one co-resident launch where it applies
 
 void hc_batch_free(slamhip_matcher *m);
 int chain_release(slamhip_matcher *m) {
   hc_batch_free(m);
   if (m->d_chain) hipFree(m->d_chain);
+  if (m->d_rctl) hipFree(m->d_rctl);
+  m->d_rctl = nullptr;
   if (m->d_shapes) hipFree(m->d_shapes);
   if (m->h_chain) hipHostFree(m->h_chain);
   if (m->h_trace) hipHostFree(m->h_trace);
@@ -135,8 +146,24 @@ bool chain_eligible(slamhip_matcher *m) {
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->ctx->scan_n > 4096) return false;  // the terms of a pose sit in LDS (8 bytes per beam next to 15 KB of replay state)
   if (m->max_batch < 6 * kHcMaxInst) return false;  // slamhip_matcher_set_batch asked for small batches
-  if (m->chain_mode < 0) m->chain_mode = 1;  // (slamhip_matcher_set_device_chain switches it off)
-  return m->chain_mode == 1;
+  if (m->chain_mode < 0) m->chain_mode = kChainDefaultMode;  // (slamhip_matcher_set_device_chain changes it)
+  return m->chain_mode >= 1;
+}
+
+// Can this match run as ONE launch of co-resident workgroups?  The 1-cell OOPE only (the GMapping OOPE's super-steps
+// hand side outputs of every pose to the replay: kernel chain), and the grid must fit the device at once.
+bool resident_wanted(slamhip_matcher *m) {
+  return m->chain_mode == 2 && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE && m->resident_gave_up_row < 3;
+}
+int resident_capacity(slamhip_matcher *m, int cell_model, int nt, bool batch, size_t lds, int *wgs) {
+  const int idx = nt == 1024 ? 2 : (nt == 512 ? 1 : 0);
+  if (m->resident_cap[idx] == 0) {
+    int cap = 0;
+    SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, batch, lds, &cap));
+    m->resident_cap[idx] = cap > 0 ? cap : -1;
+  }
+  *wgs = m->resident_cap[idx] > 0 ? m->resident_cap[idx] : 0;
+  return SLAMHIP_OK;
 }
 
 int chain_prepare(slamhip_matcher *m) {
@@ -167,7 +194,7 @@ int chain_prepare(slamhip_matcher *m) {
 }
 
 int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3], double out_delta[3],
-                       double *out_prob) {
+                       double *out_prob, bool resident) {
   slamhip_ctx *ctx = m->ctx;
   int rc = chain_prepare(m);
   if (rc) return rc;
@@ -212,6 +239,51 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   h->progress = 0;
   const double t0 = MatchJob::now_us();
   int launched = 0;
+  if (resident) {
+    // ---- ONE launch (hc_resident.hip): every workgroup of the tree stays on the chip for the whole match
+    int cap = 0;
+    rc = resident_capacity(m, cell_model, m->chain_nt, false, sizeof(double) * (size_t)std::max(a.scan.n, 1), &cap);
+    if (rc) return rc;
+    if (6 * a.max_inst + 1 > cap) return kResidentGaveUp;  // (not counted: this matcher's grid never fits)
+    if (!m->d_rctl) {
+      SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
+      SLAMHIP_CHECK(hipMemset(m->d_rctl, 0, sizeof(HcResidentCtl)));
+    }
+    // a tag carries 20 bits of the epoch: clear the block when they wrap (queued in front of the launch)
+    if ((epoch & 0xfffffu) == 0u) SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));
+    a.rctl = m->d_rctl;
+    a.debug_mute = m->debug_resident_mute;
+    hipEvent_t e0, e1;
+    rc = profile_event_pair(ctx, &e0, &e1);
+    if (rc) return rc;
+    SLAMHIP_CHECK(launch_hc_chain_resident(a, cell_model, m->chain_nt, ctx->stream, e0, e1));
+    launched = 1;
+    ++m->resident_matches;
+    unsigned long long spins = 0;
+    while (h->done_seq != epoch) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffffull) == 0) {
+        hipError_t qe = hipStreamQuery(ctx->stream);
+        if (qe == hipSuccess && h->done_seq != epoch) {
+          set_error("internal: the co-resident chain ended without publishing a result");
+          return SLAMHIP_ERR_STATE;
+        }
+        if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "co-resident hill-climbing chain");
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (h->error == 4 || h->error == 5) {
+      // a workgroup was not resident with the others (the bounded sweep ran out), or the chain is longer than a
+      // tag counts: nothing has been reported; wait for the stragglers to leave, then the kernel chain runs the match
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (h->error == 4) {
+        ++m->resident_gave_up_row;
+        ++m->resident_gave_up;
+      }
+      return kResidentGaveUp;
+    }
+    m->resident_gave_up_row = 0;
+  }
   auto launch_one = [&]() -> int {
     hipEvent_t e0, e1;
     int r = profile_event_pair(ctx, &e0, &e1);
@@ -222,7 +294,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   };
   // the expected number of super-steps goes out at once; afterwards the host stays a few launches ahead of
   // the step the GPU reports (a launch costs the host ~3.5 us, a super-step the GPU ~5 us)
-  const int first = std::max(2, std::min(256, (int)(m->chain_steps_avg * 0.75)));
+  const int first = resident ? 0 : std::max(2, std::min(256, (int)(m->chain_steps_avg * 0.75)));
   for (int i = 0; i < first; ++i) {
     rc = launch_one();
     if (rc) return rc;
@@ -356,8 +428,8 @@ bool batch_chain_eligible(slamhip_matcher *m) {
   if (m->cfg.sum_order != SLAMHIP_SUM_TREE256) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->max_batch < 6 * kHcMaxInst) return false;
-  if (m->chain_mode < 0) m->chain_mode = 1;  // (slamhip_matcher_set_device_chain switches it off)
-  return m->chain_mode == 1;
+  if (m->chain_mode < 0) m->chain_mode = kChainDefaultMode;  // (slamhip_matcher_set_device_chain changes it)
+  return m->chain_mode >= 1;
 }
 
 // scoring workgroups per super-step over all chains of a batch.  Measured on MI355X (cfg2 scenes, G units/s at
@@ -811,8 +883,8 @@ bool mc_chain_eligible(slamhip_matcher *m) {
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
   if (m->ctx->scan_n > 4096) return false;  // (see chain_eligible)
   if (m->max_batch < 64) return false;  // slamhip_matcher_set_batch asked for small batches
-  if (m->chain_mode < 0) m->chain_mode = 1;  // (slamhip_matcher_set_device_chain switches it off)
-  return m->chain_mode == 1;
+  if (m->chain_mode < 0) m->chain_mode = kChainDefaultMode;  // (slamhip_matcher_set_device_chain changes it)
+  return m->chain_mode >= 1;
 }
 
 int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3], double out_delta[3],
@@ -1072,10 +1144,11 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch) {
 }
 
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads) {
-  if (!m || (mode != 0 && mode != 1) || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
+  if (!m || mode < 0 || mode > 2 || (threads != 0 && threads != 256 && threads != 512 && threads != 1024))
     return invalid_arg("bad device-chain setting");
-  (void)chain_eligible(m);  // environment defaults first, then the explicit setting
+  (void)chain_eligible(m);  // defaults first, then the explicit setting
   m->chain_mode = mode;
+  m->resident_gave_up_row = 0;
   if (threads) m->chain_nt = threads;
   return SLAMHIP_OK;
 }
@@ -1210,6 +1283,21 @@ int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched,
   return SLAMHIP_OK;
 }
 
+// testing aid, not part of include/slamhip.h: workgroup `slot_plus_1 - 1` of the following co-resident launches leaves
+// at once (0 = none) -- what a workgroup that never became resident looks like to the others
+int slamhip_matcher_debug_resident_mute(slamhip_matcher *m, int slot_plus_1) {
+  if (!m) return invalid_arg("null matcher");
+  m->debug_resident_mute = slot_plus_1;
+  return SLAMHIP_OK;
+}
+
+int slamhip_matcher_resident_stats(slamhip_matcher *m, long long *matches, long long *gave_up) {
+  if (!m) return invalid_arg("null matcher");
+  if (matches) *matches = m->resident_matches;
+  if (gave_up) *gave_up = m->resident_gave_up;
+  return SLAMHIP_OK;
+}
+
 int slamhip_matcher_timing(slamhip_matcher *m, double *build_us, double *stage_us, double *score_us,
                            double *replay_us) {
   if (!m) return invalid_arg("null matcher");
@@ -1226,7 +1314,9 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   slamhip_ctx *ctx = m->ctx;
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
   if (chain_eligible(m)) {
-    const int crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
+    int crc = kResidentGaveUp;
+    if (resident_wanted(m)) crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob, true);
+    if (crc == kResidentGaveUp) crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob, false);
     if (crc != kChainNeedsHost) return crc;
   }
   if (mc_chain_eligible(m)) {

@@ -43,9 +43,12 @@ def upload(pkg, ctx, sc):
     ctx.scan_upload(sc["scan"].range, cos_a, sin_a, sc["scan"].weight, sc["scan"].factor)
 
 
-def matchers(pkg, ctx, prm, threads=0):
+CHAIN_MODES = [1, 2]  # a kernel per super-step (hc_chain.hip) / one co-resident launch (hc_resident.hip)
+
+
+def matchers(pkg, ctx, prm, threads=0, mode=1):
     dev = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
-    dev.set_device_chain(1, threads)
+    dev.set_device_chain(mode, threads)
     host = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
     host.set_device_chain(0)
     for m in (dev, host):
@@ -53,12 +56,13 @@ def matchers(pkg, ctx, prm, threads=0):
     return dev, host
 
 
+@pytest.mark.parametrize("mode", CHAIN_MODES)
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
 @pytest.mark.parametrize("prm", [[1, 0.1, 0.1], [6, 0.1, 0.1], [128, 0.1, 0.1], [250, 0.3, 0.05]])
-def test_chain_equals_host_driven_matcher(pkg, ctx, po, oracle, cell, weighting, prm):
+def test_chain_equals_host_driven_matcher(pkg, ctx, po, oracle, cell, weighting, prm, mode):
     sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=5, weighting=weighting)
     upload(pkg, ctx, sc)
-    dev, host = matchers(pkg, ctx, prm)
+    dev, host = matchers(pkg, ctx, prm, mode=mode)
     init = sc["init_pose"]
     for rep in range(3):  # repeated matches on one matcher: run-ahead kernels of the last chain, new epoch
         td = dev.process_scan(0, init, trace=True)
@@ -71,6 +75,8 @@ def test_chain_equals_host_driven_matcher(pkg, ctx, po, oracle, cell, weighting,
         q = dev.process_scan(0, init)
         assert q["prob"] == td["prob"] and np.array_equal(q["delta"], td["delta"])
         init = init + np.array([0.013, -0.007, 0.004])
+    if mode == 2:  # every match ran as ONE launch, none gave up
+        assert dev.resident_stats() == dict(matches=6, gave_up=0) and dev.stats()["kernels_launched"] == 1
     # the oracle's strict loop: identical trace, scores to 1e-12
     e = oracle.enumerator(po.SM_HC, prm)
     r = oracle.process_scan(e, sc["map"], sc["scan"], po.make_cfg(), sc["init_pose"])
@@ -78,8 +84,9 @@ def test_chain_equals_host_driven_matcher(pkg, ctx, po, oracle, cell, weighting,
     assert_trace_equal(t, r, exact_scores=False, rtol=1e-12)
 
 
+@pytest.mark.parametrize("mode", CHAIN_MODES)
 @pytest.mark.parametrize("threads", [256, 512, 1024])
-def test_chain_workgroup_sizes_and_beam_counts(pkg, ctx, threads):
+def test_chain_workgroup_sizes_and_beam_counts(pkg, ctx, threads, mode):
     rs = np.random.RandomState(3)
     for n_beams in (1, 63, 257, 1080, 1500, 2300):
         sc = make_scene(cell_model=CELL_OCC, size=400, scale=0.1, n_beams=max(n_beams, 8), seed=7)
@@ -87,12 +94,12 @@ def test_chain_workgroup_sizes_and_beam_counts(pkg, ctx, threads):
         keep = np.sort(rs.choice(s.n, min(n_beams, s.n), replace=False))
         s.range, s.angle, s.weight, s.factor = s.range[keep], s.angle[keep], s.weight[keep], s.factor[keep]
         upload(pkg, ctx, sc)
-        dev, host = matchers(pkg, ctx, [20, 0.1, 0.1], threads)
+        dev, host = matchers(pkg, ctx, [20, 0.1, 0.1], threads, mode)
         assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True),
                            host.process_scan(0, sc["init_pose"], trace=True))
         # the checked default mode (what a matcher does unless told otherwise) walks the beam-order sum's accept path
         chk = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), [20, 0.1, 0.1])
-        chk.set_device_chain(1, threads)
+        chk.set_device_chain(mode, threads)
         seq = pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), [20, 0.1, 0.1])
         assert_trace_equal(chk.process_scan(0, sc["init_pose"], trace=True),
                            seq.process_scan(0, sc["init_pose"], trace=True), exact_scores=False, rtol=1e-12)
@@ -112,11 +119,12 @@ def test_scans_too_long_for_the_chain_take_the_host_driven_path(pkg, ctx, po, or
         assert_trace_equal(t, r, exact_scores=False, rtol=1e-12)
 
 
-def test_chain_zero_weight_scan_and_far_pose(pkg, ctx):
+@pytest.mark.parametrize("mode", CHAIN_MODES)
+def test_chain_zero_weight_scan_and_far_pose(pkg, ctx, mode):
     sc = make_scene(cell_model=CELL_OCC, size=400, scale=0.1, n_beams=360, seed=9)
     sc["scan"].weight[:] = 0.0  # total weight 0: every score is NaN, nothing is ever accepted
     upload(pkg, ctx, sc)
-    dev, host = matchers(pkg, ctx, [6, 0.1, 0.1])
+    dev, host = matchers(pkg, ctx, [6, 0.1, 0.1], mode=mode)
     td, th = dev.process_scan(0, sc["init_pose"], trace=True), host.process_scan(0, sc["init_pose"], trace=True)
     assert td["n_calls"] == th["n_calls"] == 1 + 6 * 6 + 1 and not td["accepted"][1:].any()
     assert np.isnan(td["scores"]).all() and np.array_equal(td["poses"], th["poses"])
@@ -137,7 +145,7 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
       * for the record, the unchecked default mode (tree sums as they are): the few divergences all sit at
         comparisons whose strict-mode sums are equal or one ulp apart (mathematically tied candidates: the same
         multiset of beam terms met in another beam order)."""
-    names = ("hc_dev", "hc_host", "hc_seq", "hc_raw", "mc", "mc_raw")
+    names = ("hc_dev", "hc_k1", "hc_host", "hc_seq", "hc_raw", "mc", "mc_raw")
     div = dict.fromkeys(names, 0)
     rescored = dict.fromkeys(names, 0)
     matches, calls = 0, 0
@@ -150,7 +158,9 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
         rs = np.random.RandomState(seed)
         prm = [6 + 7 * (seed % 4), 0.1, 0.1]
         ms = dict(hc_dev=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm), hc_host=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm),
-                  hc_seq=pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm), hc_raw=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm))
+                  hc_seq=pkg.Matcher(ctx, "HC", pkg.spe_cfg(sum_order=1), prm), hc_raw=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm),
+                  hc_k1=pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm))
+        ms["hc_k1"].set_device_chain(1)  # (hc_dev: the default, one co-resident launch per match)
         ms["hc_host"].set_device_chain(0)
         ms["hc_raw"].set_device_chain(0)
         ms["hc_raw"].set_tie_check(0)
@@ -184,7 +194,7 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
                         "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
     print("fuzz: %d matches per matcher, divergences %r, re-scored steps / batches %r" % (matches, div, rescored))
     assert matches == 5 * n_scenes and calls > matches * 80
-    for which in ("hc_dev", "hc_host", "mc"):
+    for which in ("hc_dev", "hc_k1", "hc_host", "mc"):
         assert div[which] == 0, "%d of %d checked default-mode %s matches diverged from the strict mode" % (div[which], matches, which)
         # (Monte Carlo candidates are continuous random poses: sums that close with different terms are rare)
         assert which == "mc" or rescored[which] > 0, "the scenes never exercised the check of %s" % which
@@ -256,7 +266,8 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
                 assert dev.stats()["launches"] <= host.stats()["launches"] or prm[0] == 6  # (super-steps vs round trips)
 
 
-def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx):
+@pytest.mark.parametrize("mode", CHAIN_MODES)
+def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx, mode):
     """with an observer attached the chain writes its trace into a fixed pinned buffer; a match with more
     scorer calls than it holds (error 2) used to fail with SLAMHIP_ERR_UNSUPPORTED although the host-driven path
     has no such limit.  Now the match is redone there -- nothing has been reported at that point -- and the
@@ -264,7 +275,7 @@ def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx):
     import ctypes as C
     sc = make_scene(cell_model=CELL_OCC, size=600, scale=0.05, n_beams=720, seed=5)
     upload(pkg, ctx, sc)
-    dev, host = matchers(pkg, ctx, [32, 0.1, 0.1])
+    dev, host = matchers(pkg, ctx, [32, 0.1, 0.1], mode=mode)
     L = pkg.load()
     L.slamhip_matcher_debug_trace_cap.argtypes = [C.c_void_p, C.c_int]
     L.slamhip_matcher_debug_trace_cap.restype = C.c_int
@@ -277,3 +288,36 @@ def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx):
     assert L.slamhip_matcher_debug_trace_cap(dev.h, 0) == 0
     again = dev.process_scan(0, sc["init_pose"], trace=True)
     assert_trace_equal(again, want)
+
+
+def test_resident_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx):
+    """the co-resident launch only terminates when every workgroup of the tree is on the chip, so
+    every wait in it is bounded.  The testing hook makes one workgroup leave at once -- what a workgroup that never
+    became resident looks like: the others must give up within the bound (error 4, nothing reported), the kernel
+    chain redoes the match with the same trace, and after three such matches in a row the matcher stops trying."""
+    import ctypes as C
+    import time
+    sc = make_scene(cell_model=CELL_OCC, size=600, scale=0.05, n_beams=720, seed=5)
+    upload(pkg, ctx, sc)
+    dev, host = matchers(pkg, ctx, [16, 0.1, 0.1], mode=2)
+    L = pkg.load()
+    L.slamhip_matcher_debug_resident_mute.argtypes = [C.c_void_p, C.c_int]
+    L.slamhip_matcher_debug_resident_mute.restype = C.c_int
+    want = host.process_scan(0, sc["init_pose"], trace=True)
+    assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), want)
+    assert dev.resident_stats() == dict(matches=1, gave_up=0)
+    for muted, slot in enumerate((3, 1, 200), start=1):  # a scoring workgroup each time
+        assert L.slamhip_matcher_debug_resident_mute(dev.h, slot + 1) == 0
+        t0 = time.time()
+        got = dev.process_scan(0, sc["init_pose"], trace=True)
+        assert time.time() - t0 < 5.0  # bounded: ~0.1 s of polling, not a hang
+        assert_trace_equal(got, want)
+        assert dev.resident_stats() == dict(matches=1 + muted, gave_up=muted)
+        assert dev.stats()["kernels_launched"] > 1  # the kernel chain ran
+    # three in a row: the matcher keeps to the kernel chain until told otherwise
+    assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), want)
+    assert dev.resident_stats() == dict(matches=4, gave_up=3)
+    assert L.slamhip_matcher_debug_resident_mute(dev.h, 0) == 0
+    dev.set_device_chain(2)
+    assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), want)
+    assert dev.resident_stats() == dict(matches=5, gave_up=3) and dev.stats()["kernels_launched"] == 1
