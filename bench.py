@@ -1020,6 +1020,8 @@ def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16)):
     beams = [s["range"].size for s in scenes]
     for K in ks:
         m = pkg.Matcher(ctx, "HC", cfg, params)
+        if args.chain_mode > 0:
+            m.set_device_chain(args.chain_mode)
         groups = [[(g * K + j) % n_sc for j in range(K)] for g in range(max(1, n_sc // K) if K <= n_sc else 1)]
         blocks = [m.make_batch([dict(map_id=0, scan_slot=k, init_pose=scenes[k]["init_pose"]) for k in grp])
                   for grp in groups]
@@ -1051,12 +1053,15 @@ def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16)):
         achieved = k_units * bpu / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         st = m.stats()
         on_chain = sum(1 for x in calls_per_block[0] if x["on_device_chain"])
-        out.append({"K": K, "value": units / dt, "unit": "pose-candidates*beams/s", "matches_per_s": n_calls * K / dt,
+        res = m.resident_stats()
+        out.append({"K": K, "co_resident_launches": res["matches"], "co_resident_gave_up": res["gave_up"], "value": units / dt, "unit": "pose-candidates*beams/s", "matches_per_s": n_calls * K / dt,
                     "ms_per_call": 1e3 * dt / n_calls, "calls": n_calls,
                     "speculation_ratio": evaluated / max(plain, 1), "kernels_per_call": st["kernels_launched"],
                     "super_steps_longest_chain": st["launches"], "matches_on_shared_launches": on_chain,
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": achieved / HBM_PEAK_GBS, "kernel": "k_hc_chain_step", "bytes_per_unit": bpu,
+                                 "frac": achieved / HBM_PEAK_GBS,
+                                 "kernel": "k_hc_chain_resident" if res["matches"] > res["gave_up"] else "k_hc_chain_step",
+                                 "bytes_per_unit": bpu,
                                  "launches": k_launches, "avg_launch_us": 1e3 * k_ms / max(k_launches, 1),
                                  "kernel_busy_frac": None}})
         m.close()

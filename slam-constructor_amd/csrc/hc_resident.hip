@@ -97,8 +97,9 @@ __device__ __forceinline__ double gran_score(const u32x4 &g) {
 // MODEL: SLAMHIP_CELL_OCC / _TBM (the 1-cell OOPE); SEQ: the reference's beam-order sum; BATCH: grid.y independent
 // matches, each with its own map and scan (HcChainArgs::jobs); G: granules per lane of the sweeping wave, i.e. the
 // grid has at most 64 G workgroups (2, 4 or 7)
+// (four waves per SIMD whatever the workgroup size: 128 VGPRs, so that 4 x 256, 2 x 512 or 1 x 1024 threads share a CU)
 template <int MODEL, int NT, bool SEQ, bool BATCH, int G>
-__global__ __launch_bounds__(NT) void k_hc_chain_resident(HcChainArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   extern __shared__ double s_term[];  // one term per beam
   __shared__ unsigned s_hash[kHcSlots + 7];
   __shared__ double s_sc[kHcSlots + 7];
@@ -562,16 +563,14 @@ __global__ __launch_bounds__(NT) void k_hc_chain_resident(HcChainArgs a) {
             h->gm_cx = -1;
             h->gm_cy = -1;
             h->gm_prob = -1.0;
+            __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             if (a.n_done) {
-              // (a batch: the last chain to end tells the host)
+              // a batch: the last chain to end tells the host.  This chain's result is on its way to the host BEFORE
+              // it counts itself, so whoever sees the full count may announce everybody's
+              __threadfence_system();
               const unsigned before = atomicAdd(a.n_done, 1u);
-              __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-              if (before + 1u == gridDim.y && a.h_all_done) {
-                __threadfence_system();
+              if (before + 1u == gridDim.y && a.h_all_done)
                 __hip_atomic_store(a.h_all_done, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-              }
-            } else {
-              __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
           }
         }

@@ -393,6 +393,9 @@ struct HcBatch {
   int built_inst = 0, max_inst = 1, nt = 256;
   int shape_n_inst[slamhip::kHcShapes] = {0};
   unsigned *d_n_done = nullptr, *h_done_count = nullptr;
+  slamhip::HcResidentCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain (cap of them)
+  unsigned *h_all_done = nullptr;            // pinned: the last chain to end stores the epoch here
+  bool ran_resident = false;
   slamhip::HcTraceEntry *h_trace = nullptr;  // pinned: cap x trace_per entries (observer attached only)
   int trace_per = 0, trace_chains = 0;
   unsigned epoch = 0;
@@ -416,6 +419,8 @@ void hc_batch_free(slamhip_matcher *m) {
   if (b->d_shapes) hipFree(b->d_shapes);
   if (b->d_n_done) hipFree(b->d_n_done);
   if (b->h_done_count) hipHostFree(b->h_done_count);
+  if (b->d_rctl) hipFree(b->d_rctl);
+  if (b->h_all_done) hipHostFree(b->h_all_done);
   if (b->h_trace) hipHostFree(b->h_trace);
   delete b;
   m->batch = nullptr;
@@ -471,6 +476,8 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     if (b->d_jobs) hipFree(b->d_jobs);
     if (b->h_inits) hipHostFree(b->h_inits);
     if (b->d_inits) hipFree(b->d_inits);
+    if (b->d_rctl) hipFree(b->d_rctl);
+    b->d_rctl = nullptr;
     b->d_ctl = nullptr;
     b->h_out = nullptr;
     b->h_jobs = b->d_jobs = nullptr;
@@ -603,6 +610,73 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     ((volatile HcHostOut *)b->h_out)[c].progress = 0;
   }
   int launched = 0;
+  // ---- ONE launch for the whole batch (hc_resident.hip) when all chains' workgroups fit the device at once: the
+  // chains then advance independently -- no chain waits at a kernel boundary for the slowest one of its super-step
+  b->ran_resident = false;
+  if (resident_wanted(m) && !a.seq) {
+    int cap_wgs = 0;
+    int rc0 = resident_capacity(m, cell_model, b->nt, true, sizeof(double) * (size_t)std::max(max_n, 1), &cap_wgs);
+    if (rc0) return rc0;
+    if (n * (6 * b->max_inst + 1) <= cap_wgs) {
+      if (!b->d_rctl) {
+        SLAMHIP_CHECK(hipMalloc(&b->d_rctl, sizeof(HcResidentCtl) * b->cap));
+        SLAMHIP_CHECK(hipMemset(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap));
+      }
+      if (!b->h_all_done) {
+        SLAMHIP_CHECK(hipHostMalloc(&b->h_all_done, sizeof(unsigned), pinned));
+        *b->h_all_done = 0;
+      }
+      if ((epoch & 0xfffffu) == 0u) SLAMHIP_CHECK(hipMemsetAsync(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap, st));
+      a.rctl = b->d_rctl;
+      a.h_all_done = b->h_all_done;
+      a.debug_mute = m->debug_resident_mute;
+      hipEvent_t e0, e1;
+      rc0 = profile_event_pair(ctx, &e0, &e1);
+      if (rc0) return rc0;
+      SLAMHIP_CHECK(launch_hc_chain_resident(a, cell_model, b->nt, st, e0, e1, n));
+      launched = 1;
+      ++m->resident_matches;
+      volatile unsigned *all_done = b->h_all_done;
+      unsigned long long spins = 0;
+      bool gave_up = false;
+      for (;;) {
+        if (*all_done == epoch) break;
+        __builtin_ia32_pause();
+        if ((++spins & 0xffffull) == 0) {
+          // a chain that gave up publishes its own done_seq with error 4 / 5 and never counts as ended
+          for (int c = 0; c < n && !gave_up; ++c) {
+            const volatile HcHostOut *hc = &b->h_out[c];
+            gave_up = hc->done_seq == epoch && (hc->error == 4 || hc->error == 5);
+          }
+          if (gave_up) break;
+          hipError_t qe = hipStreamQuery(st);
+          if (qe == hipSuccess && *all_done != epoch) {
+            gave_up = true;  // (every workgroup has left and the batch is not through: treated like a give-up)
+            break;
+          }
+          if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "co-resident hill-climbing chains");
+        }
+      }
+      if (gave_up) {
+        // nothing of this batch has been reported: wait for the stragglers, then the kernel chains redo it
+        SLAMHIP_CHECK(hipStreamSynchronize(st));
+        ++m->resident_gave_up_row;
+        ++m->resident_gave_up;
+        SLAMHIP_CHECK(hipMemsetAsync(b->d_n_done, 0, sizeof(unsigned), st));
+        for (int c = 0; c < n; ++c) ((volatile HcHostOut *)b->h_out)[c].error = 0;
+        a.rctl = nullptr;
+        a.h_all_done = nullptr;
+        a.debug_mute = 0;
+        launched = 0;
+        epoch = ++b->epoch;
+        if (epoch == 0) epoch = ++b->epoch;
+        a.epoch = epoch;
+      } else {
+        m->resident_gave_up_row = 0;
+        b->ran_resident = true;
+      }
+    }
+  }
   auto burst = [&](int count, unsigned *seq_out) -> int {
     for (int i = 0; i < count; ++i) {
       hipEvent_t e0, e1;
@@ -618,9 +692,10 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     return SLAMHIP_OK;
   };
   unsigned seq_prev = 0, seq_next = 0;
-  int rc = burst(std::max(3, (int)(b->steps_avg * 0.9)), &seq_prev);
+  int rc = SLAMHIP_OK;
+  if (!b->ran_resident) rc = burst(std::max(3, (int)(b->steps_avg * 0.9)), &seq_prev);
   if (rc) return rc;
-  for (;;) {
+  while (!b->ran_resident) {
     rc = burst(3, &seq_next);  // queued before the wait: the GPU never runs dry
     if (rc) return rc;
     rc = score_wait(ctx, seq_prev);

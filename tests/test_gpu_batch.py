@@ -56,13 +56,16 @@ def lone(pkg, ctx, m, job, trace=True):
     return m.process_scan(job["map_id"], job["init_pose"], trace=trace)
 
 
+@pytest.mark.parametrize("mode", [1, 2])  # kernel chains (hc_chain.hip) / one co-resident launch (hc_resident.hip)
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
 @pytest.mark.parametrize("k", [2, 3, 8, 20])
-def test_batch_equals_lone_matches(pkg, ctx, cell, weighting, k):
+def test_batch_equals_lone_matches(pkg, ctx, cell, weighting, k, mode):
     jobs = scenes(pkg, ctx, cell, weighting, k, beams=(720, 360, 1080))
     prm = [24, 0.1, 0.1]
     mb = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    mb.set_device_chain(mode)
     ml = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    ml.set_device_chain(1)
     got = mb.process_scan_batch(jobs, trace=True)
     assert len(got) == k
     total_calls = 0
@@ -73,7 +76,11 @@ def test_batch_equals_lone_matches(pkg, ctx, cell, weighting, k):
         assert st["on_device_chain"] and st["scorer_calls"] == want["n_calls"] == ml.stats()["scorer_calls"]
         total_calls += st["scorer_calls"]
     s = mb.stats()
-    assert s["scorer_calls"] == total_calls and s["kernels_launched"] >= 3
+    assert s["scorer_calls"] == total_calls
+    if mode == 2:  # all chains' workgroups fit the device at once: ONE launch, nobody gave up
+        assert s["kernels_launched"] == 1 and mb.resident_stats() == dict(matches=1, gave_up=0)
+    else:
+        assert s["kernels_launched"] >= 3
     # without an observer: same results, no trace buffers involved; the argument block reused
     blk = mb.make_batch(jobs)
     for _ in range(2):
@@ -164,3 +171,30 @@ def test_stored_scans_equal_uploaded_scans(pkg, ctx):
         ctx.scan_select(999)
     with pytest.raises(pkg.SlamHipError):
         mb.process_scan_batch([dict(map_id=0, scan_slot=998, init_pose=[0, 0, 0])])
+
+
+def test_resident_batch_gives_up_when_a_workgroup_is_missing(pkg, ctx):
+    """The co-resident batch launch (csrc/hc_resident.hip) with one workgroup of every chain leaving at once (testing
+    hook): the chains must give up within the bound, and the kernel chains redo the whole batch with the lone
+    matches' traces."""
+    import time
+    jobs = scenes(pkg, ctx, CELL_OCC, "even", 4)
+    prm = [16, 0.1, 0.1]
+    mb = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    mb.set_device_chain(2)
+    ml = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    L = pkg.load()
+    L.slamhip_matcher_debug_resident_mute.argtypes = [C.c_void_p, C.c_int]
+    L.slamhip_matcher_debug_resident_mute.restype = C.c_int
+    assert L.slamhip_matcher_debug_resident_mute(mb.h, 3) == 0
+    t0 = time.time()
+    got = mb.process_scan_batch(jobs, trace=True)
+    assert time.time() - t0 < 5.0
+    assert mb.resident_stats() == dict(matches=1, gave_up=1) and mb.stats()["kernels_launched"] >= 3
+    for g, job in zip(got, jobs):
+        assert_trace_equal(g, lone(pkg, ctx, ml, job))
+    assert L.slamhip_matcher_debug_resident_mute(mb.h, 0) == 0
+    again = mb.process_scan_batch(jobs, trace=True)
+    for g, a in zip(got, again):
+        assert_trace_equal(g, a)
+    assert mb.resident_stats() == dict(matches=2, gave_up=1) and mb.stats()["kernels_launched"] == 1
