@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--chain-mode", type=int, default=-1, choices=[-1, 1, 2],
                     help="device chain of the hill-climbing headline: 1 = a kernel per super-step (csrc/hc_chain.hip), "
                          "2 = one co-resident launch per match (csrc/hc_resident.hip); -1 = the library's default (2)")
+    ap.add_argument("--resident-scan", action="store_true",
+                    help="headline step = scan_select + process_scan on filtered scans already in HBM (the r01-r03 "
+                         "form) instead of the raw scan in (filter + weights + trig + upload inside the step)")
     ap.add_argument("--leg-timeout", type=int, default=480,
                     help="seconds the sharded particle-filter leg may take at N > 1 before the line goes out without it")
     ap.add_argument("--dry-ranks", type=int, default=0,
@@ -233,10 +236,14 @@ def rotating_scenes(sc, n_beams, weighting, n=N_SCENES):
     out = []
     for j in range(n):
         true = sc["true_pose"] + rs.randn(3) * [0.15, 0.15, 0.04]
-        rng, ang = cast_scan(sc["gt"], m.scale, true, n_beams, seed=1000 + j)
+        # the scan as the scanner hands it over: every beam, with a flag on the ones that hit something (what
+        # TransformedLaserScan holds, sensor_data.h:203-208) -- and the hits alone, i.e. what filter_scan keeps
+        raw_rng, raw_ang, occ = cast_scan(sc["gt"], m.scale, true, n_beams, seed=1000 + j, raw=True)
+        keep = occ != 0
+        rng, ang = raw_rng[keep], raw_ang[keep]
         w = np.full(rng.size, 1.0 / rng.size) if weighting == "even" else viny_weights(rng, ang)
         out.append(dict(range=rng, angle=ang, weight=w, init_pose=true + mags[j] * np.array([0.07, -0.04, 0.03]),
-                        error_x_default=float(mags[j])))
+                        raw_range=raw_rng, raw_angle=raw_ang, is_occ=occ, error_x_default=float(mags[j])))
     return out
 
 
@@ -280,7 +287,8 @@ def _ref_match_worker(job):
     from synth import MapData
     z = np.load(path)
     m = MapData(int(z["cell_model"]), z["payload"], z["origin"], float(z["scale"]), z["unknown"])
-    scenes = [dict(range=z["range%d" % k], angle=z["angle%d" % k], weight=z["weight%d" % k], init_pose=z["init%d" % k])
+    scenes = [dict(range=z["range%d" % k], angle=z["angle%d" % k], weight=z["weight%d" % k], init_pose=z["init%d" % k],
+                   raw_range=z["rrange%d" % k], raw_angle=z["rangle%d" % k], is_occ=z["occ%d" % k])
               for k in range(int(z["n_scenes"]))]
     r = cpu_baseline_reference({"map": m}, kind, params, seconds, weighting, scenes, first)
     return (r["_units"], r["_seconds"]) if r else None
@@ -294,6 +302,7 @@ def _save_scene_for_workers(sc, scenes):
     for k, s_ in enumerate(scenes):
         d["range%d" % k], d["angle%d" % k], d["weight%d" % k], d["init%d" % k] = (s_["range"], s_["angle"], s_["weight"],
                                                                                  np.asarray(s_["init_pose"]))
+        d["rrange%d" % k], d["rangle%d" % k], d["occ%d" % k] = s_["raw_range"], s_["raw_angle"], s_["is_occ"]
     f = tempfile.NamedTemporaryFile(prefix="slamhip_bench_scene_", suffix=".npz", delete=False)
     f.close()
     np.savez(f.name, **d)
@@ -323,10 +332,13 @@ def cpu_baseline_reference(sc, kind, params, seconds, weighting, scenes, first=0
     vals = np.ascontiguousarray(pay[iy, ix])
     R.lib.ref_map_update_bulk(rm.h, len(vals), xy.ctypes.data_as(C.POINTER(C.c_int)),
                               vals.ctypes.data_as(C.POINTER(C.c_double)))
-    scans = [R.scan_create(s["range"], s["angle"]) for s in scenes]
+    # the RAW scans (every beam + its is_occupied flag): the reference filters inside process_scan
+    # (pose_enumeration_scan_matcher.h:38), and that is inside the timed calls on both sides
+    scans = [R.scan_create(s["raw_range"], s["raw_angle"], s["is_occ"]) for s in scenes]
     spe = R.spe_create(po.OOPE_OBSTACLE, po.OIE_DISCREPANCY, 1 if weighting == "viny" else 0)
     mt = R.matcher_create({"HC": po.SM_HC, "MC": po.SM_MC}[kind], spe, params)
     units, t_used, reps = 0, 0.0, 0
+    per_scene = {}
     t_end = time.perf_counter() + seconds
     while True:
         k = (first + reps) % len(scenes)
@@ -334,8 +346,11 @@ def cpu_baseline_reference(sc, kind, params, seconds, weighting, scenes, first=0
         r = R.process_scan(mt, scans[k], scenes[k]["init_pose"], rm, cap=4)
         t_used += time.perf_counter() - t0
         units += r["n_calls"] * r["filtered_n"]
+        if k not in per_scene and kind == "HC":  # (a Monte-Carlo matcher's engine runs on from match to match)
+            per_scene[k] = dict(prob=float(r["prob"]), delta=[float(x) for x in r["delta"]], n_calls=int(r["n_calls"]),
+                                filtered_n=int(r["filtered_n"]))
         reps += 1
-        if time.perf_counter() > t_end or reps >= 2000:
+        if (time.perf_counter() > t_end and (kind != "HC" or len(per_scene) == len(scenes))) or reps >= 2000:
             break
     phys, logical = physical_cores()
     return {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "reference",
@@ -343,7 +358,7 @@ def cpu_baseline_reference(sc, kind, params, seconds, weighting, scenes, first=0
                       "(scan, odometry error) pairs on the same map rebuilt as UnboundedPlainGridMap<AffineQualityMergeCell>, "
                       "%.1f s; host CPU: %s, %d physical / %d logical cores"
                       % (reps, kind, params, len(scenes), t_used, cpu_model(), phys, logical),
-            "_units": units, "_seconds": t_used}
+            "_units": units, "_seconds": t_used, "_per_scene": per_scene}
 
 
 def run_workers(fn, jobs):
@@ -372,24 +387,31 @@ def cpu_baseline(sc, sc_args, kind, params, seconds, weighting, procs, scenes):
     e = O.enumerator(okind, params)
     t_end = time.perf_counter() + (min(seconds, 3.0) if ref is not None else seconds)
     oscans = [Scan(s["range"], s["angle"], s["weight"]) for s in scenes]
+    port_scene = {}
     while True:
         k = reps % len(scenes)
         t0 = time.perf_counter()
         r = O.process_scan(e, sc["map"], oscans[k], cfg, scenes[k]["init_pose"], cap=8)
         t_used += time.perf_counter() - t0
         units += r["n_calls"] * oscans[k].n
+        if k not in port_scene and kind == "HC":
+            port_scene[k] = dict(prob=float(r["prob"]), delta=[float(x) for x in r["delta"]], n_calls=int(r["n_calls"]),
+                                 filtered_n=int(oscans[k].n))
         reps += 1
-        if time.perf_counter() > t_end or reps >= 2000:
+        if (time.perf_counter() > t_end and (ref is not None or kind != "HC" or len(port_scene) == len(scenes))) or reps >= 2000:
             break
     port = {"value": units / t_used, "unit": "pose-candidates*beams/s", "cores": 1, "kind": "port",
             "sample": "%d x process_scan (%s %s) over the same rotating scenes, %.1f s, oracle/slam_oracle.c -O2, "
                       "flat-array map; host CPU: %s, %d logical cores visible"
                       % (reps, kind, params, t_used, cpu_model(), os.cpu_count() or 0)}
     if ref is None:
+        port["_per_scene"] = port_scene
         return port
     ref.pop("_units", None)
     ref.pop("_seconds", None)
     ref["port_value"] = port["value"]  # the flat-array C restatement, for context
+    # (ref["_per_scene"]: what the reference returned for every benchmarked scene -- main() checks the HIP results of the
+    # same scenes against it after the timed region and takes the key out of the line)
     phys, logical = physical_cores()
     procs = phys if procs <= 0 else max(1, min(procs, logical))
     if procs > 1:
@@ -1311,8 +1333,15 @@ def main():
         beams_of = [s_["range"].size for s_ in scenes]
         step_i = [0]
         evaluated, plain_calls = [0], [0]
+        # The timed step is the reference's process_scan (pose_enumeration_scan_matcher.h:31-77): the RAW scan comes in
+        # from host memory, filter_scan (:38), the scan-point weights, the beam trigonometry and the copy to HBM are
+        # INSIDE the step (slamhip_scan_filter_upload), then the match.  (`--resident-scan`: the r01-r03 form, the
+        # filtered scans already in HBM and a step = scan_select + process_scan; reported either way as
+        # config.ms_per_step_resident.)
+        raw_upload = [ctx.make_raw_scan(0, s_["raw_range"], s_["raw_angle"], is_occ=s_["is_occ"], weighting=weighting)
+                      for s_ in scenes]
 
-        def step():
+        def step_resident():
             k = step_i[0] % len(scenes)
             step_i[0] += 1
             ctx.scan_select(k)
@@ -1321,6 +1350,18 @@ def main():
             evaluated[0] += st_["poses_evaluated"]
             plain_calls[0] += st_["scorer_calls"]
             return st_["scorer_calls"] * beams_of[k]
+
+        def step_raw():
+            k = step_i[0] % len(scenes)
+            step_i[0] += 1
+            kept = raw_upload[k](scenes[k]["init_pose"])
+            m.process_scan(0, scenes[k]["init_pose"])
+            st_ = m.stats()
+            evaluated[0] += st_["poses_evaluated"]
+            plain_calls[0] += st_["scorer_calls"]
+            return st_["scorer_calls"] * kept
+
+        step = step_resident if args.resident_scan else step_raw
 
     barrier()  # (the first torch.cuda.synchronize() initialises torch's own context: not inside the timed region)
     for _ in range(max(args.warmup, len(scenes) if scenes else 0)):
@@ -1359,7 +1400,43 @@ def main():
     ctx.profile_enable(False)
     k_ms, k_launches, k_units = ctx.profile_read(reset=True)
     kernel_name = "k_score_point"
+    parity = None
     if m is not None:
+        # the other form of the step, same K steps, for the record
+        other = step_raw if args.resident_scan else step_resident
+        for _ in range(len(scenes)):
+            other()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            other()
+        barrier()
+        ms_other = 1e3 * (time.perf_counter() - t2) / args.steps
+        extra.update(includes_filter_and_upload=not args.resident_scan,
+                     **{"ms_per_step_raw_scan_in" if args.resident_scan else "ms_per_step_resident": ms_other})
+        # ---- parity gate on the benchmarked inputs (outside every timed region): the result of every rotating scene
+        # through the timed path against what the CPU baseline's reference run returned for the same scene
+        want = (cpu_out or {}).pop("_per_scene", None) if rank == 0 else None
+        if want and kind == "HC":
+            bad, max_rel, kept_bad = [], 0.0, []
+            for k_ in sorted(want):
+                kept = raw_upload[k_](scenes[k_]["init_pose"])
+                r_ = m.process_scan(0, scenes[k_]["init_pose"])
+                w_ = want[k_]
+                calls_ = m.stats()["scorer_calls"]
+                same = calls_ == w_["n_calls"] and [float(x) for x in r_["delta"]] == w_["delta"]
+                rel = abs(r_["prob"] / w_["prob"] - 1.0) if w_["prob"] != 0 else abs(r_["prob"])
+                max_rel = max(max_rel, rel)
+                if kept != w_["filtered_n"]:
+                    kept_bad.append(k_)
+                if not same or not rel <= 1e-9:
+                    bad.append(k_)
+            parity = {"scenes": len(want), "traces_equal": len(want) - len(bad), "max_rel_score": max_rel,
+                      "filtered_counts_equal": len(want) - len(kept_bad),
+                      "against": "the compiled reference's process_scan on the same raw scans (oracle/_ref)"
+                                 if cpu_out.get("kind") == "reference" else "the C restatement (oracle/slam_oracle.c)",
+                      "what": "scorer calls and pose delta bit for bit, best score within 1e-9 relative (measured above)",
+                      "scenes_differing": bad + kept_bad}
         st = m.stats()
         if on_device:
             resident = kind == "HC" and m.resident_stats()["matches"] > 0
@@ -1450,7 +1527,12 @@ def main():
         if ceiling is not None:
             out["roofline_sweep"] = ceiling
         if cpu_out is not None:
+            cpu_out.pop("_per_scene", None)
             out["cpu_baseline"] = cpu_out
+        out["parity"] = parity if parity is not None else {
+            "scenes": 0, "note": "not checked in this run: " + ("--no-cpu" if args.no_cpu else (
+                "the gate runs on rank 0 of a 1-GPU hill-climbing run, where the CPU baseline has the reference's "
+                "results of the benchmarked scenes"))}
         if pf_out is not None:
             out["particle_filter"] = pf_out
             if pf_cpu_out:
@@ -1475,7 +1557,7 @@ def main():
             if rank == 0:
                 emit_line({"error": "the sharded particle-filter leg did not finish within %d s" % args.leg_timeout}, None)
                 sys.stdout.flush()
-            os._exit(0 if rank == 0 else 1)
+            os._exit(5)  # the line is out, the run still failed: a hung leg is not a success
 
         watchdog = threading.Timer(args.leg_timeout, give_up)
         watchdog.daemon = True
@@ -1525,6 +1607,10 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if parity is not None and (parity["traces_equal"] != parity["scenes"] or parity["filtered_counts_equal"] != parity["scenes"]):
+        print("bench.py: PARITY FAILURE on the benchmarked scenes %r (the line above carries the details)"
+              % parity["scenes_differing"], file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

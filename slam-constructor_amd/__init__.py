@@ -514,6 +514,32 @@ class Context:
             kept.ctypes.data_as(_ip)))
         return kept[:n.value].copy()
 
+    def make_raw_scan(self, map_id, rng, ang, is_occ=None, factor=None, trig_mode=TRIG_RAW, a_min=0.0, a_max=0.0,
+                      a_inc=1.0, skip_rate=0, max_range=-1.0, bounded=False, weighting="even"):
+        """Argument block of slamhip_scan_filter_upload made once for a raw scan (a caller that holds its scans in
+        C arrays pays no conversions per call): returns upload(pose) -> number of points kept."""
+        rng, ang = _f64(rng), _f64(ang)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        fac = _f64(factor) if factor is not None else None
+        n_kept = C.c_int(0)
+        pose3 = (C.c_double * 3)()
+        fn = self.L.slamhip_scan_filter_upload
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
+                       _dp, C.c_uint, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), _ip]
+        args = (self.h, int(map_id), rng.size, _d(rng), _d(ang), occ.ctypes.data_as(_ip) if occ is not None else None,
+                _d(fac) if fac is not None else None, int(trig_mode), a_min, a_max, a_inc,
+                C.cast(pose3, _dp), int(skip_rate), float(max_range), int(bool(bounded)),
+                {"even": 0, "viny": 1, "ahr": 2}[weighting], C.pointer(n_kept), None)
+        keep = (rng, ang, occ, fac)
+
+        def upload(pose, _keep=keep):
+            pose3[0], pose3[1], pose3[2] = float(pose[0]), float(pose[1]), float(pose[2])
+            rc = fn(*args)
+            if rc:
+                _check(rc)
+            return n_kept.value
+        return upload
+
     def scan_store(self, slot, rng, cos_a, sin_a, weight, factor=None):
         """Keeps a filtered scan resident in HBM (slot 0..4095); scan_select / match jobs refer to it."""
         rng, cos_a, sin_a, weight = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(weight)

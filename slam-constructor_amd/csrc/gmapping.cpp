@@ -138,6 +138,9 @@ struct slamhip_gmapping {
   // sharded steps: a failure behind the step's last collective travels in the status word of the next step's first
   // one, so that every rank leaves that step together instead of waiting for a rank that has given up
   int deferred_rc = 0;
+  // testing (slamhip_gmapping_debug_fail): make the n-th call from now of one place fail as a rank-local error --
+  // 1 match_finish, 2 the export of migrating maps (between the migration's collectives), 3 the final map import
+  int debug_fail_where = 0, debug_fail_countdown = 0;
   // device staging of the tile contents of migrating maps (slamhip_gmapping_step_sharded with per-particle maps)
   char *d_mig_send = nullptr, *d_mig_recv = nullptr;
   size_t mig_send_cap = 0, mig_recv_cap = 0;
@@ -157,6 +160,15 @@ namespace {
 int bad(const char *msg) {
   set_error(msg);
   return SLAMHIP_ERR_INVALID;
+}
+
+// the testing hook's trigger: true when place `where` is to fail now
+bool debug_fail_now(slamhip_gmapping *g, int where) {
+  if (g->debug_fail_where != where) return false;
+  if (--g->debug_fail_countdown > 0) return false;
+  g->debug_fail_where = 0;
+  set_error("injected failure (slamhip_gmapping_debug_fail)");
+  return true;
 }
 
 int heaviest(const std::vector<double> &w) {
@@ -587,6 +599,7 @@ int slamhip_gmapping_match_finish(slamhip_gmapping *g, double *raw_weights_out) 
   slamhip_ctx *ctx = g->ctx;
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
   g->pending = false;
+  if (debug_fail_now(g, 1)) return SLAMHIP_ERR_STATE;
   const std::vector<int> &act_idx = g->act_idx;
   std::vector<MatchJob *> &act = g->act;
   const int n_raw = (int)g->scan_range.size();
@@ -972,8 +985,11 @@ int slamhip_gmapping_match_abort(slamhip_gmapping *g) {
 // off the resampling indices: which maps leave which rank for which.  Two small all-gathers (sizes, then the maps'
 // headers: tile positions and ancestor ordinals), ONE point-to-point exchange of the tile contents device to device
 // (slamhip_shard_exchange: RCCL send / recv in one group), then the import.
+// *everyone_left: the migration failed on some rank and EVERY rank returned an error from the same collective
+// (nothing to defer); otherwise an error is this rank's alone.
 static int migrate_and_import(slamhip_gmapping *g, int rank, int world, const std::vector<GmParticle> &blobs,
-                              const std::vector<unsigned> &idx) {
+                              const std::vector<unsigned> &idx, bool *everyone_left) {
+  *everyone_left = false;
   slamhip_ctx *ctx = g->ctx;
   std::vector<int> start(world + 1, 0);
   for (int r = 0; r < world; ++r) start[r + 1] = start[r] + g->shard_counts[r];
@@ -1004,65 +1020,97 @@ static int migrate_and_import(slamhip_gmapping *g, int rank, int world, const st
   for (int q = 0; q < world; ++q) n_exports_all += exports[q].size();
   if (n_exports_all == 0)  // every new particle's source is local everywhere
     return import_maps_impl(g, blobs.data(), idx.data(), 0, nullptr, nullptr, nullptr);
+  // A rank-local failure between the migration's collectives must not leave the others waiting in the next one:
+  // it travels as a STATUS WORD in front of this rank's block of the next all-gather, and every rank leaves the
+  // migration behind that collective, before anybody enters the exchange.
   // sizes of my exports, then everybody's
   const std::vector<int> &mine = exports[rank];
-  std::vector<unsigned long long> my_sizes(2 * mine.size());
+  std::vector<unsigned long long> my_sizes(1 + 2 * mine.size(), 0ull);  // [0]: status
   size_t my_header_bytes = 0, my_body_bytes = 0;
   for (size_t k = 0; k < mine.size(); ++k) {
     size_t hb = 0, bb = 0;
     tile_pool_export_sizes(g->tp, mine[k] - g->first, &hb, &bb);
-    my_sizes[2 * k] = hb;
-    my_sizes[2 * k + 1] = bb;
+    my_sizes[1 + 2 * k] = hb;
+    my_sizes[2 + 2 * k] = bb;
     my_header_bytes += hb;
     my_body_bytes += bb;
   }
+  int local_rc = SLAMHIP_OK;
+  std::string local_msg;
+  auto fail_locally = [&](int rc_) {
+    if (!local_rc && rc_) {
+      local_rc = rc_;
+      local_msg = slamhip_last_error();
+    }
+  };
+  // the send buffer grows BEFORE the first collective
+  if (my_body_bytes > g->mig_send_cap) {
+    hipError_t he = hipStreamSynchronize(ctx->stream);
+    if (he == hipSuccess) {
+      if (g->d_mig_send) hipFree(g->d_mig_send);
+      g->d_mig_send = nullptr;
+      g->mig_send_cap = 0;
+      he = hipMalloc(&g->d_mig_send, my_body_bytes);
+    }
+    if (he != hipSuccess) fail_locally(hip_fail(he, "staging of the migrating maps (send)"));
+    else g->mig_send_cap = my_body_bytes;
+  }
+  my_sizes[0] = (unsigned long long)(unsigned)local_rc;
   std::vector<int> cnt(world);
-  for (int q = 0; q < world; ++q) cnt[q] = 2 * (int)exports[q].size();
-  std::vector<unsigned long long> all_sizes(2 * n_exports_all);
+  for (int q = 0; q < world; ++q) cnt[q] = 1 + 2 * (int)exports[q].size();
+  std::vector<unsigned long long> all_sizes((size_t)world + 2 * n_exports_all);
   int rc = slamhip_shard_allgather(ctx, my_sizes.data(), cnt.data(), (int)sizeof(unsigned long long), all_sizes.data());
   if (rc) return rc;
+  auto leave_together = [&](int failed_rank, const char *where) {
+    *everyone_left = true;
+    if (local_rc) {
+      set_error(local_msg);
+      return local_rc;
+    }
+    set_error("rank " + std::to_string(failed_rank) + " of the shard group failed " + where +
+              ": the resampling was abandoned on every rank");
+    return (int)SLAMHIP_ERR_STATE;
+  };
   // (rank, export ordinal) -> sizes and the offset of its header in the gathered header blob
   std::vector<std::vector<size_t>> hb_of(world), bb_of(world), hoff_of(world);
   size_t hoff = 0, at = 0;
   std::vector<int> hcnt(world, 0);
+  std::vector<size_t> hbase(world, 0);
+  int failed_rank = -1;
   for (int q = 0; q < world; ++q) {
-    for (size_t k = 0; k < exports[q].size(); ++k, ++at) {
-      hb_of[q].push_back((size_t)all_sizes[2 * at]);
-      bb_of[q].push_back((size_t)all_sizes[2 * at + 1]);
+    if (all_sizes[at] != 0ull && failed_rank < 0) failed_rank = q;
+    ++at;
+    hbase[q] = hoff;
+    hoff += 8;  // the status word in front of rank q's headers
+    hcnt[q] = 8;
+    for (size_t k = 0; k < exports[q].size(); ++k, at += 2) {
+      hb_of[q].push_back((size_t)all_sizes[at]);
+      bb_of[q].push_back((size_t)all_sizes[at + 1]);
       hoff_of[q].push_back(hoff);
       hoff += hb_of[q].back();
       hcnt[q] += (int)hb_of[q].back();
     }
   }
+  if (failed_rank >= 0) return leave_together(failed_rank, "while staging its migrating maps");
   // my maps: headers to host memory, tile contents into the device send buffer (queued on the stream)
-  if (my_body_bytes > g->mig_send_cap) {
-    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (g->d_mig_send) hipFree(g->d_mig_send);
-    g->d_mig_send = nullptr;
-    g->mig_send_cap = 0;
-    SLAMHIP_CHECK(hipMalloc(&g->d_mig_send, my_body_bytes));
-    g->mig_send_cap = my_body_bytes;
-  }
-  std::vector<char> my_headers(my_header_bytes ? my_header_bytes : 1);
+  std::vector<char> my_headers(8 + my_header_bytes, 0);
   std::vector<size_t> send_off(mine.size());
   {
-    size_t ho = 0, bo = 0;
-    for (size_t k = 0; k < mine.size(); ++k) {
+    size_t ho = 8, bo = 0;
+    for (size_t k = 0; k < mine.size() && !local_rc; ++k) {
       send_off[k] = bo;
-      rc = tile_pool_export_split(g->tp, mine[k] - g->first, my_headers.data() + ho, g->d_mig_send + bo, false);
-      if (rc) return rc;
-      ho += (size_t)my_sizes[2 * k];
-      bo += (size_t)my_sizes[2 * k + 1];
+      if (debug_fail_now(g, 2)) fail_locally(SLAMHIP_ERR_STATE);
+      else fail_locally(tile_pool_export_split(g->tp, mine[k] - g->first, my_headers.data() + ho, g->d_mig_send + bo, false));
+      ho += (size_t)my_sizes[1 + 2 * k];
+      bo += (size_t)my_sizes[2 + 2 * k];
     }
   }
-  std::vector<char> all_headers(hoff ? hoff : 1);
-  rc = slamhip_shard_allgather(ctx, my_headers.data(), hcnt.data(), 1, all_headers.data());
-  if (rc) return rc;
   // the exchange: my sends by (destination, source) ascending, my receives by source ascending -- one order per pair
   auto ordinal = [&](int q, int src) {
     const std::vector<int> &e = exports[q];
     return (size_t)(std::lower_bound(e.begin(), e.end(), src) - e.begin());
   };
+  // ... and the receive buffer grows before the second collective
   size_t recv_bytes = 0;
   std::vector<size_t> recv_off(need[rank].size());
   for (size_t k = 0; k < need[rank].size(); ++k) {
@@ -1071,21 +1119,37 @@ static int migrate_and_import(slamhip_gmapping *g, int rank, int world, const st
     recv_bytes += bb_of[q][ordinal(q, src)];
   }
   if (recv_bytes > g->mig_recv_cap) {
-    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (g->d_mig_recv) hipFree(g->d_mig_recv);
-    g->d_mig_recv = nullptr;
-    g->mig_recv_cap = 0;
-    SLAMHIP_CHECK(hipMalloc(&g->d_mig_recv, recv_bytes));
-    g->mig_recv_cap = recv_bytes;
+    hipError_t he = hipStreamSynchronize(ctx->stream);
+    if (he == hipSuccess) {
+      if (g->d_mig_recv) hipFree(g->d_mig_recv);
+      g->d_mig_recv = nullptr;
+      g->mig_recv_cap = 0;
+      he = hipMalloc(&g->d_mig_recv, recv_bytes);
+    }
+    if (he != hipSuccess) fail_locally(hip_fail(he, "staging of the migrating maps (receive)"));
+    else g->mig_recv_cap = recv_bytes;
   }
+  {
+    const unsigned long long status = (unsigned long long)(unsigned)local_rc;
+    std::memcpy(my_headers.data(), &status, 8);
+  }
+  std::vector<char> all_headers(hoff ? hoff : 1);
+  rc = slamhip_shard_allgather(ctx, my_headers.data(), hcnt.data(), 1, all_headers.data());
+  if (rc) return rc;
+  for (int q = 0; q < world; ++q) {
+    unsigned long long status = 0;
+    std::memcpy(&status, all_headers.data() + hbase[q], 8);
+    if (status != 0ull && failed_rank < 0) failed_rank = q;
+  }
+  if (failed_rank >= 0) return leave_together(failed_rank, "while exporting its migrating maps");
   std::vector<slamhip_shard_msg> sends, recvs;
   for (int r = 0; r < world; ++r) {
     if (r == rank) continue;
     for (int src : need[r]) {
       if (owner(src) != rank) continue;
       const size_t k = ordinal(rank, src);
-      sends.push_back(slamhip_shard_msg{r, g->d_mig_send + send_off[k], (size_t)my_sizes[2 * k + 1]});
-      g->map_bytes_sent += (long long)my_sizes[2 * k + 1];
+      sends.push_back(slamhip_shard_msg{r, g->d_mig_send + send_off[k], (size_t)my_sizes[2 + 2 * k]});
+      g->map_bytes_sent += (long long)my_sizes[2 + 2 * k];
     }
   }
   for (size_t k = 0; k < need[rank].size(); ++k) {
@@ -1101,6 +1165,9 @@ static int migrate_and_import(slamhip_gmapping *g, int rank, int world, const st
     hdr[k] = all_headers.data() + hoff_of[q][ordinal(q, src)];
     body[k] = g->d_mig_recv + recv_off[k];
   }
+  // (behind the migration's last collective: a failure here is this rank's alone -- the caller defers it to the next
+  // step's status word)
+  if (debug_fail_now(g, 3)) return SLAMHIP_ERR_STATE;
   return import_maps_impl(g, blobs.data(), idx.data(), (int)need[rank].size(), need[rank].data(), hdr.data(), body.data());
 }
 
@@ -1146,6 +1213,8 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
   std::vector<double> raw(g->count), all(g->n_total);
   const std::vector<int> ones(world, 1);
   bool settled = false;
+  int late_rc = 0;  // settled path: this rank failed behind the step's first collective
+  std::string late_msg;
   {
     slamhip_carry_record mine;
     std::memset(&mine, 0, sizeof(mine));
@@ -1190,10 +1259,11 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
       int changed = 0;
       rc = slamhip_gmapping_carry_fix(g, recs.data(), world, rank, &changed);  // (passes the cache through; no re-match)
       if (!rc && changed) rc = bad("internal: a shard re-matched although no cache hand-over needed repair");
-      if (rc) {  // (no collective follows in this step: the others learn of it at the next one's)
-        match_abort(g);
-        g->deferred_rc = rc;
-        return rc;
+      // a failure from here on is behind the step's first collective.  The others cannot see it yet, and they WILL
+      // enter the resampling's collectives when the weights say so: this rank goes there with them (late_rc)
+      if (rc) {
+        late_rc = rc;
+        late_msg = slamhip_last_error();
       }
       settled = true;
     }
@@ -1243,13 +1313,14 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
       if (!any) break;
     }
   }
-  rc = slamhip_gmapping_carry_commit(g, recs.data(), world);
+  rc = late_rc;
+  if (!rc) rc = slamhip_gmapping_carry_commit(g, recs.data(), world);
   if (!rc) rc = slamhip_gmapping_match_finish(g, raw.data());
-  if (rc && settled) {  // behind the step's only collective: reported to the others at the next step's
-    match_abort(g);
-    g->deferred_rc = rc;
-    return rc;
+  if (rc && settled && !late_rc) {
+    late_rc = rc;
+    late_msg = slamhip_last_error();
   }
+  if (late_rc) match_abort(g);
   if (!settled) {
     // a re-match may have changed a shard's weights: all raw weights once more, in particle order (with a status
     // word in front: match_finish may have failed on some rank)
@@ -1287,25 +1358,76 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
   }
   std::vector<unsigned> idx(g->n_total);
   int req = 0;
-  rc = slamhip_gmapping_plan_resample(g, all.data(), resample_seed, &req, idx.data());  // (same inputs, same verdict everywhere)
+  // (same inputs, same verdict everywhere -- also on a rank that failed late: the plan needs the gathered weights only)
+  rc = slamhip_gmapping_plan_resample(g, all.data(), resample_seed, &req, idx.data());
   if (rc) {
     g->deferred_rc = rc;
     return rc;
   }
-  if (req) {
+  if (!req) {
+    if (late_rc) {  // no collective follows in this step: the others learn of it at the next one's
+      g->deferred_rc = late_rc;
+      set_error(late_msg);
+      return late_rc;
+    }
+    if (resampled) *resampled = 0;
+    return SLAMHIP_OK;
+  }
+  {
+    // the particle records of all ranks, each rank's block headed by a status word: a rank that failed late (its map
+    // update, say) is in this collective with the others, and EVERY rank abandons the resampling together
     std::vector<GmParticle> blobs(g->n_total);
-    rc = slamhip_shard_allgather(g->ctx, g->p.data(), g->shard_counts.data(), (int)sizeof(GmParticle), blobs.data());
+    std::vector<int> bcnt(world);
+    size_t total = 0;
+    for (int r = 0; r < world; ++r) {
+      bcnt[r] = 8 + (int)sizeof(GmParticle) * g->shard_counts[r];
+      total += (size_t)bcnt[r];
+    }
+    std::vector<char> blk((size_t)bcnt[rank], 0), gathered(total, 0);
+    const unsigned long long status = (unsigned long long)(unsigned)late_rc;
+    std::memcpy(blk.data(), &status, 8);
+    std::memcpy(blk.data() + 8, g->p.data(), sizeof(GmParticle) * g->count);
+    rc = slamhip_shard_allgather(g->ctx, blk.data(), bcnt.data(), 1, gathered.data());
     if (rc) return rc;
+    size_t at = 0;
+    int pat = 0, failed_rank = -1;
+    for (int r = 0; r < world; ++r) {
+      unsigned long long st_r = 0;
+      std::memcpy(&st_r, gathered.data() + at, 8);
+      if (st_r != 0ull && failed_rank < 0) failed_rank = r;
+      std::memcpy(blobs.data() + pat, gathered.data() + at + 8, sizeof(GmParticle) * g->shard_counts[r]);
+      at += (size_t)bcnt[r];
+      pat += g->shard_counts[r];
+    }
+    if (failed_rank >= 0) {
+      if (late_rc) {
+        set_error(late_msg);
+        return late_rc;
+      }
+      set_error("rank " + std::to_string(failed_rank) + " of the shard group failed behind the step's first collective: "
+                "the resampling was abandoned on every rank");
+      return SLAMHIP_ERR_STATE;
+    }
     // own maps: the maps of particles drawn from other ranks travel first (two all-gathers and one exchange that
-    // every rank enters, whatever it needs itself)
-    rc = g->tp ? migrate_and_import(g, rank, world, blobs, idx) : slamhip_gmapping_import(g, blobs.data(), idx.data());
+    // every rank enters, whatever it needs itself; collective-complete on failure, see migrate_and_import)
+    bool everyone_left = false;
+    rc = g->tp ? migrate_and_import(g, rank, world, blobs, idx, &everyone_left)
+               : slamhip_gmapping_import(g, blobs.data(), idx.data());
     if (rc) {
-      g->deferred_rc = rc;
+      if (!everyone_left) g->deferred_rc = rc;  // (this rank's alone: the others learn of it at the next step's collective)
       return rc;
     }
     if (idx_out) std::memcpy(idx_out, idx.data(), sizeof(unsigned) * g->n_total);
   }
   if (resampled) *resampled = req;
+  return SLAMHIP_OK;
+}
+
+// testing aid, not part of include/slamhip.h (see slamhip_gmapping::debug_fail_where)
+int slamhip_gmapping_debug_fail(slamhip_gmapping *g, int where, int nth_call) {
+  if (!g) return bad("null filter");
+  g->debug_fail_where = where;
+  g->debug_fail_countdown = nth_call;
   return SLAMHIP_OK;
 }
 

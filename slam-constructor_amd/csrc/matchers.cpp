@@ -247,7 +247,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
     if (6 * a.max_inst + 1 > cap) return kResidentGaveUp;  // (not counted: this matcher's grid never fits)
     if (!m->d_rctl) {
       SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
-      SLAMHIP_CHECK(hipMemset(m->d_rctl, 0, sizeof(HcResidentCtl)));
+      SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));  // (ordered with the launch)
     }
     // a tag carries 20 bits of the epoch: clear the block when they wrap (queued in front of the launch)
     if ((epoch & 0xfffffu) == 0u) SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));
@@ -620,7 +620,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     if (n * (6 * b->max_inst + 1) <= cap_wgs) {
       if (!b->d_rctl) {
         SLAMHIP_CHECK(hipMalloc(&b->d_rctl, sizeof(HcResidentCtl) * b->cap));
-        SLAMHIP_CHECK(hipMemset(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap));
+        SLAMHIP_CHECK(hipMemsetAsync(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap, st));  // (ordered with the launch)
       }
       if (!b->h_all_done) {
         SLAMHIP_CHECK(hipHostMalloc(&b->h_all_done, sizeof(unsigned), pinned));

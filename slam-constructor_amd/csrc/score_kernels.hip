@@ -62,6 +62,33 @@ hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// The scan's way to HBM: a kernel PULLS the packed scan out of pinned host memory (16 bytes per thread over PCIe)
+// instead of an SDMA copy queued in front of the match -- hipMemcpyAsync costs the host ~6 us and the stream ~10 us
+// before the next kernel starts, this launch ~2.5 and ~4.  The last workgroup through tells the host that the staging
+// buffer may be refilled (it has been READ, which is all the host needs to know).
+__global__ __launch_bounds__(256) void k_scan_pull(const double2 *__restrict__ src, double2 *__restrict__ dst, int n2,
+                                                   unsigned *counter, unsigned *h_flag, unsigned seq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n2) dst[i] = src[i];
+  __syncthreads();  // (every load of the workgroup has returned: its values went into stores)
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == gridDim.x) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(h_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles, unsigned *counter, unsigned *h_flag,
+                            unsigned seq, hipStream_t stream) {
+  const int n2 = (int)((n_doubles + 1) / 2);
+  hipLaunchKernelGGL(k_scan_pull, dim3((n2 + 255) / 256), dim3(256), 0, stream,
+                     reinterpret_cast<const double2 *>(h_src), reinterpret_cast<double2 *>(d_dst), n2, counter, h_flag,
+                     seq);
+  return hipGetLastError();
+}
+
 // ---- K1 ----------------------------------------------------------------------------------------
 // KB > 0: beams per thread known at compile time (n <= 256*KB), constants live in VGPRs.
 // KB == 0: generic (any n): constants re-read from L1/L2 in the pose loop.

@@ -534,6 +534,8 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   for (int k = 0; k < 2; ++k) {
     if (ctx->h_scan_stage[k]) hipHostFree(ctx->h_scan_stage[k]);
     if (ctx->scan_stage_done[k]) hipEventDestroy(ctx->scan_stage_done[k]);
+    if (k == 0 && ctx->h_scan_pulled) hipHostFree(ctx->h_scan_pulled);
+    if (k == 0 && ctx->d_scan_pull_count) hipFree(ctx->d_scan_pull_count);
   }
   if (ctx->d_poses) hipFree(ctx->d_poses);
   if (ctx->d_scores) hipFree(ctx->d_scores);
@@ -770,33 +772,66 @@ int slamhip_map_apply_dirty(slamhip_ctx *ctx, int map_id, int n, const int *coor
 }
 
 // ---------------------------------------------------------------------------------- scan
-int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const double *cos_a,
-                        const double *sin_a, const double *weight, const double *factor) {
-  if (!ctx) return invalid("null ctx");
-  if (n <= 0 || !range || !cos_a || !sin_a || !weight) return invalid("bad scan");
+// The scan's staging: two pinned buffers taking turns, packed {range, cos, sin, weight, factor} x `stride` doubles.
+// acquire: room for n_max points, waits until the pull of two uploads ago has read the buffer (a word in pinned
+// memory the pull kernel writes: no event calls), returns the buffer and its stride.
+// commit: n <= n_max points are in the buffer -- host copies of weights / factors, the total weight, and the pull
+// kernel queued on the context's stream.
+static int scan_stage_acquire(slamhip_ctx *ctx, int n_max, double **st, size_t *stride) {
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
-  if (n > ctx->scan_cap) {
+  if (n_max > ctx->scan_cap) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->stream_b) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream_b));
     if (ctx->d_scan) hipFree(ctx->d_scan);
     ctx->d_scan = nullptr;
     ctx->scan_cap = 0;
     int cap = 2048;
-    while (cap < n) cap *= 2;
+    while (cap < n_max) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&ctx->d_scan, sizeof(double) * 5 * cap));
     for (int k = 0; k < 2; ++k) {
       if (ctx->h_scan_stage[k]) hipHostFree(ctx->h_scan_stage[k]);
       ctx->h_scan_stage[k] = nullptr;
-      SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scan_stage[k], sizeof(double) * 5 * cap, hipHostMallocDefault));
+      SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scan_stage[k], sizeof(double) * 5 * cap, hipHostMallocMapped));
       if (!ctx->scan_stage_done[k]) SLAMHIP_CHECK(hipEventCreateWithFlags(&ctx->scan_stage_done[k], hipEventDisableTiming));
+      ctx->scan_pull_seq[k] = 0;
+    }
+    if (!ctx->h_scan_pulled) {
+      SLAMHIP_CHECK(hipHostMalloc(&ctx->h_scan_pulled, sizeof(unsigned) * 2, hipHostMallocMapped | hipHostMallocCoherent));
+      ctx->h_scan_pulled[0] = ctx->h_scan_pulled[1] = 0;
+      SLAMHIP_CHECK(hipMalloc(&ctx->d_scan_pull_count, sizeof(unsigned)));
+      // (on the context's stream: hipMemset on the null stream is not ordered with it -- the first pull's workgroups
+      // were seen counting into a word that was cleared under them)
+      SLAMHIP_CHECK(hipMemsetAsync(ctx->d_scan_pull_count, 0, sizeof(unsigned), ctx->stream));
     }
     ctx->scan_cap = cap;
   }
+  const int turn = ctx->scan_stage_turn;
+  if (ctx->scan_pull_seq[turn] != 0) {
+    volatile unsigned *pulled = ctx->h_scan_pulled + turn;
+    unsigned long long spins = 0;
+    while (*pulled != ctx->scan_pull_seq[turn]) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffffull) == 0) {
+        hipError_t qe = hipStreamQuery(ctx->stream);
+        if (qe != hipSuccess && qe != hipErrorNotReady) return slamhip::hip_fail(qe, "scan pull kernel");
+        if (qe == hipSuccess && *pulled != ctx->scan_pull_seq[turn]) {
+          char msg[200];
+          std::snprintf(msg, sizeof msg, "internal: a scan pull never reported back (buffer %d: pull %u queued, %u / %u reported, %u pulls so far)",
+                        turn, ctx->scan_pull_seq[turn], ctx->h_scan_pulled[0], ctx->h_scan_pulled[1], ctx->scan_pull_next);
+          return invalid(msg);
+        }
+      }
+    }
+  }
+  *st = ctx->h_scan_stage[turn];
+  *stride = (size_t)((n_max + 7) & ~7);
+  return SLAMHIP_OK;
+}
+
+static int scan_stage_commit(slamhip_ctx *ctx, int n, double *st, size_t stride) {
+  const double *weight = st + 3 * stride, *factor = st + 4 * stride;
   ctx->h_weight.assign(weight, weight + n);
-  if (factor)
-    ctx->h_factor.assign(factor, factor + n);
-  else
-    ctx->h_factor.assign(n, 1.0);
+  ctx->h_factor.assign(factor, factor + n);
   // total_weight accumulates in beam order and does not depend on the pose
   // (weighted_mean_point_probability_spe.h:125)
   double tot_w = 0;
@@ -804,22 +839,38 @@ int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const doub
   ctx->scan_tot_w = tot_w;
   ctx->scan_n = n;
   ctx->scan_ptr = ctx->d_scan;
-  ctx->scan_stride = (size_t)ctx->scan_cap;
-  const size_t c = ctx->scan_cap, bytes = sizeof(double) * n;
+  ctx->scan_stride = stride;
   const int turn = ctx->scan_stage_turn;
   ctx->scan_stage_turn ^= 1;
-  double *st = ctx->h_scan_stage[turn];
-  SLAMHIP_CHECK(hipEventSynchronize(ctx->scan_stage_done[turn]));  // the copy of two uploads ago (never recorded: returns at once)
+  unsigned seq = ++ctx->scan_pull_next;
+  if (seq == 0) seq = ++ctx->scan_pull_next;
+  ctx->scan_pull_seq[turn] = seq;
+  // (one pull over the five stretches, gaps included: 5 x stride doubles are 43 KB at 1080 beams)
+  SLAMHIP_CHECK(launch_scan_pull(st, ctx->d_scan, 4 * stride + (size_t)n, ctx->d_scan_pull_count,
+                                 ctx->h_scan_pulled + turn, seq, ctx->stream));
+  if (ctx->stream_b) {  // the second launch lane waits for the scan
+    SLAMHIP_CHECK(hipEventRecord(ctx->scan_stage_done[turn], ctx->stream));
+    SLAMHIP_CHECK(hipStreamWaitEvent(ctx->stream_b, ctx->scan_stage_done[turn], 0));
+  }
+  return SLAMHIP_OK;
+}
+
+int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const double *cos_a,
+                        const double *sin_a, const double *weight, const double *factor) {
+  if (!ctx) return invalid("null ctx");
+  if (n <= 0 || !range || !cos_a || !sin_a || !weight) return invalid("bad scan");
+  double *st = nullptr;
+  size_t c = 0;
+  int rc = scan_stage_acquire(ctx, n, &st, &c);
+  if (rc) return rc;
+  const size_t bytes = sizeof(double) * n;
   std::memcpy(st, range, bytes);
   std::memcpy(st + c, cos_a, bytes);
   std::memcpy(st + 2 * c, sin_a, bytes);
   std::memcpy(st + 3 * c, weight, bytes);
-  std::memcpy(st + 4 * c, ctx->h_factor.data(), bytes);
-  // (one copy over the five stretches, gaps included: 5 x scan_cap doubles are 80 KB at 2048 beams)
-  SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_scan, st, sizeof(double) * (4 * c + n), hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipEventRecord(ctx->scan_stage_done[turn], ctx->stream));
-  if (ctx->stream_b) SLAMHIP_CHECK(hipStreamWaitEvent(ctx->stream_b, ctx->scan_stage_done[turn], 0));  // the second launch lane
-  return SLAMHIP_OK;
+  if (factor) std::memcpy(st + 4 * c, factor, bytes);
+  else for (int i = 0; i < n; ++i) st[4 * c + i] = 1.0;
+  return scan_stage_commit(ctx, n, st, c);
 }
 
 int slamhip_scan_store(slamhip_ctx *ctx, int slot, int n, const double *range, const double *cos_a,
@@ -1084,30 +1135,34 @@ int slamhip_scan_filter_upload(slamhip_ctx *ctx, int map_id, int n, const double
     ctx->scan_n = 0;  // (scoring without a scan fails; the reference scores NaN: the adapter handles an empty scan itself)
     return SLAMHIP_OK;
   }
-  sp.r.resize(k);
-  sp.c.resize(k);
-  sp.s.resize(k);
-  sp.w.resize(k);
-  sp.f.resize(k);
+  // straight into the pinned staging buffer the pull kernel reads (no intermediate arrays)
+  double *st = nullptr;
+  size_t c = 0;
+  int rc = scan_stage_acquire(ctx, k, &st, &c);
+  if (rc) return rc;
+  double *r_ = st, *c_ = st + c, *s_ = st + 2 * c, *w_ = st + 3 * c, *f_ = st + 4 * c;
   for (int q = 0; q < k; ++q) {
     const int i = sp.kept[q];
-    sp.r[q] = range[i];
-    sp.c[q] = sp.cos_a[i];
-    sp.s[q] = sp.sin_a[i];
-    sp.f[q] = factor ? factor[i] : 1.0;
+    r_[q] = range[i];
+    c_[q] = sp.cos_a[i];
+    s_[q] = sp.sin_a[i];
+    f_[q] = factor ? factor[i] : 1.0;
   }
   if (weighting == 0) {
     const double w = 1.0 / k;  // EvenSPW (:21-32)
-    for (int q = 0; q < k; ++q) sp.w[q] = w;
+    for (int q = 0; q < k; ++q) w_[q] = w;
   } else if (weighting == 1) {
-    for (int q = 0; q < k; ++q) sp.w[q] = sp.viny_f[sp.kept[q]] * std::sqrt(sp.r[q]);
+    for (int q = 0; q < k; ++q) w_[q] = sp.viny_f[sp.kept[q]] * std::sqrt(r_[q]);
   } else {
     sp.a.resize(k);
+    sp.r.assign(r_, r_ + k);
+    sp.w.resize(k);
     for (int q = 0; q < k; ++q) sp.a[q] = angle[sp.kept[q]];
-    const int rc = slamhip_scan_weights(2, k, sp.r.data(), sp.a.data(), sp.w.data());
+    rc = slamhip_scan_weights(2, k, sp.r.data(), sp.a.data(), sp.w.data());
     if (rc) return rc;
+    std::memcpy(w_, sp.w.data(), sizeof(double) * k);
   }
-  return slamhip_scan_upload(ctx, k, sp.r.data(), sp.c.data(), sp.s.data(), sp.w.data(), sp.f.data());
+  return scan_stage_commit(ctx, k, st, c);
 }
 
 // ObservationMappingQualityEstimator::quality (grid_map_scan_adders.h:17-43): IdleOMQE, or

@@ -87,6 +87,9 @@ hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_or
                         hipStream_t stream, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream);
+// n_doubles (rounded up to two) from pinned host memory to HBM by a kernel; *h_flag = seq once the source has been read
+hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles, unsigned *counter, unsigned *h_flag,
+                            unsigned seq, hipStream_t stream);
 hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
                                 const int *d_coords, const double *d_vals, hipStream_t stream);
 hipError_t launch_repack_window(double *dst, int dst_pitch, int cell_dbl, const double *src,
@@ -139,8 +142,13 @@ struct slamhip_ctx {
   // slamhip_scan_upload: the five arrays packed in pinned memory (two buffers taking turns, an event each) and
   // sent with ONE asynchronous copy -- no wait for the stream, which may still be busy with a queued map update
   double *h_scan_stage[2] = {nullptr, nullptr};
-  hipEvent_t scan_stage_done[2] = {nullptr, nullptr};
+  hipEvent_t scan_stage_done[2] = {nullptr, nullptr};  // (recorded for the second launch lane only)
   int scan_stage_turn = 0;
+  // ... pulled into HBM by a kernel (k_scan_pull): the sequence number of the pull that last read each buffer, what
+  // the kernel reported back (pinned), its arrival counter
+  unsigned scan_pull_seq[2] = {0, 0}, scan_pull_next = 0;
+  unsigned *h_scan_pulled = nullptr;
+  unsigned *d_scan_pull_count = nullptr;
   int scan_cap = 0, scan_n = 0;
   double scan_tot_w = 0.0;
   // the scan the kernels read: d_scan after slamhip_scan_upload, a stored scan after slamhip_scan_select

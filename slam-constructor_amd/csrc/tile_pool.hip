@@ -478,11 +478,45 @@ int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, con
     std::memcpy(nt.data() + (size_t)s * stride, from, sizeof(int) * stride);
     for (int i = 0; i < stride; ++i) rc[from[i]] += 1;
   }
+  // Everything that can fail is checked BEFORE the pool's bookkeeping is touched (an import that failed
+  // half way -- pool exhausted, corrupt header -- used to leave tables pointing at tiles already on the free list):
+  // the headers of every map that will be imported, and that the fresh tiles they need exist
+  {
+    long long fresh_needed = 0;
+    for (int r = 0; r < n_remote; ++r) {
+      bool used = false;
+      for (int s = 0; s < tp->n_slots; ++s) used |= (src[s] == -r - 1);
+      if (!used) continue;
+      const char *in = static_cast<const char *>(remote_bufs[r]);
+      long long n = 0;
+      std::memcpy(&n, in, 8);
+      if (n < 0 || n > stride) return tp_fail("corrupt exported map");
+      const int *ent = reinterpret_cast<const int *>(in + 8);
+      bool body_needed = false;
+      for (long long k = 0; k < n; ++k) {
+        const int tx = (ent[4 * k] + tp->origin_x) >> kTileShift, ty = (ent[4 * k + 1] + tp->origin_y) >> kTileShift;
+        const int ord = ent[4 * k + 2];
+        if (tx < 0 || tx >= tp->tiles_x || ty < 0 || ty >= tp->tiles_y) return tp_fail("corrupt exported map (tile position)");
+        if (ord >= 0) {
+          if (ord >= (int)tp->ancestor.size()) return tp_fail("exported map names an ancestor tile this pool lacks");
+        } else {
+          ++fresh_needed;
+          body_needed = true;
+        }
+      }
+      if (body_needed && !remote_bodies[r]) return tp_fail("missing body of an exported map");
+    }
+    long long available = (long long)tp->free_list.size() + (long long)(tp->capacity - tp->next_unused);
+    for (int t = 1; t < tp->next_unused; ++t)
+      if (tp->refcnt[t] > 0 && rc[t] == 0 && tp->ancestor_of[t] < 0) ++available;  // released by this generation change
+    if (fresh_needed > available)
+      return tp_fail("tile pool exhausted: create the particle maps with a larger capacity", SLAMHIP_ERR_STATE);
+  }
   for (int t = 1; t < tp->next_unused; ++t)
     if (tp->refcnt[t] > 0 && rc[t] == 0 && tp->ancestor_of[t] < 0) tp->free_list.push_back(t);
   rc[0] = 1 << 30;
   tp->refcnt.swap(rc);
-  // import every remote map once
+  // import every remote map once (none of the checks below can fire any more: they are the ones made above)
   std::vector<std::vector<int>> imported(n_remote);  // table row of the imported map
   hipStream_t st = tp->ctx->stream;
   for (int r = 0; r < n_remote; ++r) {

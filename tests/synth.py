@@ -78,8 +78,10 @@ def make_world(size, scale, seed=0):
     return gt
 
 
-def cast_scan(gt, scale, pose, n_beams, fov_deg=270.0, max_dist=30.0, noise=0.01, seed=42):
-    """Ray-cast a scan from `pose` on the raster (origin at the raster centre)."""
+def cast_scan(gt, scale, pose, n_beams, fov_deg=270.0, max_dist=30.0, noise=0.01, seed=42, raw=False):
+    """Ray-cast a scan from `pose` on the raster (origin at the raster centre).  raw: the scan as the scanner hands
+    it over -- every beam, (ranges, angles, is_occupied) with max_dist on the beams that hit nothing -- instead of
+    the hits alone; ranges[is_occupied] are the same numbers either way."""
     size = gt.shape[0]
     org = size // 2
     ang = np.deg2rad(-fov_deg / 2 + fov_deg / n_beams * np.arange(n_beams))
@@ -104,6 +106,8 @@ def cast_scan(gt, scale, pose, n_beams, fov_deg=270.0, max_dist=30.0, noise=0.01
     ok = np.isfinite(ranges)
     rs = np.random.RandomState(seed)
     ranges = ranges + rs.randn(n_beams) * noise
+    if raw:
+        return np.where(ok, ranges, max_dist), ang, ok.astype(np.int32)
     return ranges[ok], ang[ok]
 
 

@@ -31,7 +31,12 @@ def test_headline_line_from_a_live_run():
     assert "cfg2" in c["workload"] and c["beams_after_filter"] == 1080 and c["scorer_calls_per_step"] > 700
     assert abs(d["value"] - c["scorer_calls_per_step"] * 1080 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert 0.05 < d["ms_per_step"] < 1.0  # a device chain, not seconds
-    assert r["kernel"] == "k_hc_chain_step" and r["launches"] > 0 and 0.0 < r["frac"] < 1.0
+    # one co-resident launch per match (csrc/hc_resident.hip), none gave up; the step takes the RAW scan (filter +
+    # weights + beam trig + upload inside), the resident-scan figure rides along
+    assert r["kernel"] == "k_hc_chain_resident" and r["launches"] > 0 and 0.0 < r["frac"] < 1.0
+    assert c["resident"]["matches"] > 0 and c["resident"]["gave_up"] == 0
+    assert c["includes_filter_and_upload"] is True and 0.05 < c["ms_per_step_resident"] <= d["ms_per_step"] * 1.05
+    assert d["parity"]["scenes"] == 0 and "--no-cpu" in d["parity"]["note"]
     assert abs(r["achieved"] - r["units_launched"] * r["bytes_per_unit"] / (r["avg_launch_us"] * 1e-6 * r["launches"]) / 1e9) \
         <= 1e-6 * r["achieved"]
     assert "roofline_sweep" in d and d["roofline_sweep"]["kernel"] == "k_score_point"
