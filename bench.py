@@ -790,6 +790,57 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
                    collective=collective, launches_last_step=st["launches"],
                    carry_reruns_last_step=st["carry_reruns"], resamplings=resamplings)
         pf.close()
+        if world == 1:
+            # What the 1/2/4/8-GPU strong-scaling curve should look like, stated before it is measured (the driver
+            # runs it): the step time of the LARGEST shard of a G-rank run -- ceil(n / G)
+            # particles of the n, measured on this GPU -- plus the step's one collective (measured on a 1-rank RCCL
+            # group here: host -> device -> ncclAllGather -> device -> host; more ranks add link latency to it).
+            try:
+                model = []
+                coll_us = None
+                try:
+                    ctx.shard_init(0, 1, pkg.shard_unique_id())
+                    blk = np.zeros((n, 1))
+                    for _ in range(5):
+                        ctx.shard_allgather(blk, [n])
+                    tc = time.perf_counter()
+                    for _ in range(50):
+                        ctx.shard_allgather(blk, [n])
+                    coll_us = 1e6 * (time.perf_counter() - tc) / 50
+                    ctx.shard_destroy()
+                except Exception as e:  # noqa: BLE001
+                    coll_us = None
+                    model.append({"collective_error": str(e)})
+                for G in (1, 2, 4, 8):
+                    if n < G:
+                        continue
+                    cG = -(-n // G)
+                    f = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=gp), n,
+                                           np.arange(1000, 1000 + n, dtype=np.uint32)[:cG], first=0, count=cG)
+                    for k in range(2):
+                        f.predict_match(1, scan.range, scan.angle, None, deltas[k])
+                    ctx.synchronize()
+                    tg = time.perf_counter()
+                    for k in range(2, 2 + args.pf_steps):
+                        f.predict_match(1, scan.range, scan.angle, None, deltas[k])
+                    ctx.synchronize()
+                    shard_ms = 1e3 * (time.perf_counter() - tg) / args.pf_steps
+                    f.close()
+                    pred = shard_ms + (coll_us or 0.0) * 1e-3 * (1 if G > 1 else 0)
+                    model.append({"ranks": G, "particles_on_largest_shard": cG, "shard_ms_per_step": shard_ms,
+                                  "predicted_ms_per_step": pred, "predicted_particles_per_s": n / (pred * 1e-3),
+                                  "predicted_speedup": None})
+                base = next((m_["predicted_ms_per_step"] for m_ in model if m_.get("ranks") == 1), None)
+                for m_ in model:
+                    if base and "ranks" in m_:
+                        m_["predicted_speedup"] = base / m_["predicted_ms_per_step"]
+                out["scaling_model"] = {
+                    "by_ranks": model, "collective_us_one_rank_group": coll_us,
+                    "note": "strong scaling of a latency chain: a shard's step costs about as many super-steps as the "
+                            "whole filter's (every particle's accept chain is as long), only narrower launches -- so "
+                            "the curve flattens early; measured per-shard times on one GPU + the step's one all-gather"}
+            except pkg.SlamHipError as e:
+                out["scaling_model"] = {"error": str(e)}
     if world == 1 and "pf_update" in legs:
         # the reference's full step: each particle appends its scan to the shared map before the
         # next one matches (sequential by construction) -- a few steps are enough
@@ -1479,6 +1530,16 @@ def main():
     world_out = None  # (the world-loop leg, filled in below; emit_line reads it when the line goes out)
     replicas_out = None
 
+    # devices the ranks really run on (under `--backend gloo` several ranks may share one: that is not N GPUs)
+    n_devices = world
+    if world > 1:
+        ids = [None] * world
+        try:
+            dist.all_gather_object(ids, (os.uname().nodename, local_rank))
+            n_devices = len(set(ids))
+        except Exception:  # noqa: BLE001
+            n_devices = min(world, torch.cuda.device_count())
+
     def emit_line(pf_out, cfg5_out):
         """rank 0's ONE JSON line (the headline is complete before the secondary legs start)"""
         bpu = BYTES_PER_UNIT[bkey]
@@ -1489,7 +1550,7 @@ def main():
             "metric": "pose-candidates*beams/sec (1080-beam scan, 2000^2 grid)",
             "value": units_all / t_max,
             "unit": "pose-candidates*beams/s",
-            "n_gpus": world,
+            "n_gpus": n_devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps,
@@ -1506,6 +1567,7 @@ def main():
                                  "default (canonical tree sum, device sincos; comparisons the tree sum cannot "
                                  "settle decided from beam-order sums)")),
                        "parallelism": "replicas x%d (no collective)" % world if world > 1 else "1 gpu",
+                       "ranks": world,
                        "backend": args.backend if world > 1 else None,
                        **extra},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -36,7 +36,8 @@ typedef enum {
   SLAMHIP_ERR_HIP = -2,       /* HIP runtime error (text in slamhip_last_error) */
   SLAMHIP_ERR_NO_DEVICE = -3, /* no usable GPU: the product path never falls back to the CPU */
   SLAMHIP_ERR_STATE = -4,     /* call order (e.g. scoring before a scan/map was uploaded) */
-  SLAMHIP_ERR_UNSUPPORTED = -5
+  SLAMHIP_ERR_UNSUPPORTED = -5,
+  SLAMHIP_ERR_TIMEOUT = -6    /* a collective of the shard group did not complete within the group's deadline */
 } slamhip_status;
 
 /* Cell payload models mirrored in HBM:
@@ -541,6 +542,14 @@ typedef struct {
 int slamhip_shard_exchange(slamhip_ctx *ctx, int n_send, const slamhip_shard_msg *send, int n_recv,
                            const slamhip_shard_msg *recv);
 int slamhip_shard_p2p_stats(slamhip_ctx *ctx, long long *exchanges, long long *bytes_sent);
+/* Every wait on a collective of the built-in (RCCL) transport is bounded: slamhip_shard_allgather / _exchange poll the
+ * stream until the deadline (default 30 s; ms <= 0 restores it) and then return SLAMHIP_ERR_TIMEOUT -- a peer that
+ * died INSIDE a collective, which no status word can report.  The communicator is aborted (ncclCommAbort) and the
+ * group is broken from then on: every later collective of this context fails at once with SLAMHIP_ERR_STATE, so a
+ * sharded step in flight is abandoned on every survivor within the deadline; slamhip_shard_destroy + a fresh
+ * slamhip_shard_init among the survivors start over.  (An attached transport bounds its own waits and reports
+ * through its return code.) */
+int slamhip_shard_set_timeout(slamhip_ctx *ctx, int ms);
 /* A transport of the caller's: allgather moves equal blocks of host memory (every rank's block_bytes from send_host
  * into recv_host, world x block_bytes in rank order), exchange has the contract of slamhip_shard_exchange (device
  * buffers; the context's stream is idle when it is called), destroy (may be NULL) runs when the context leaves the

@@ -49,7 +49,7 @@ slamhip_shard_unique_id slamhip_shard_init slamhip_shard_destroy slamhip_shard_i
 slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begin slamhip_gmapping_carry_record
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
 slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select
-slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_gmapping_match_abort
+slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_shard_set_timeout slamhip_gmapping_match_abort
 slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality slamhip_scan_filter_upload""".split()
 
 SHARD_ID_BYTES = 128
@@ -568,6 +568,11 @@ class Context:
         uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
         assert uid.size == SHARD_ID_BYTES
         _check(self.L.slamhip_shard_init(self.h, rank, world, uid.ctypes.data_as(C.c_void_p)))
+
+    def shard_set_timeout(self, ms):
+        """Deadline of every wait on a collective of the RCCL transport (slamhip_shard_set_timeout)."""
+        self.L.slamhip_shard_set_timeout.argtypes = [C.c_void_p, C.c_int]
+        _check(self.L.slamhip_shard_set_timeout(self.h, int(ms)))
 
     def shard_attach(self, transport, rank=None, world=None):
         """Joins a group over the caller's own transport (a ctypes slamhip_shard_transport); rank / world default to

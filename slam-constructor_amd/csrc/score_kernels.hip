@@ -57,6 +57,17 @@ __global__ void k_publish(unsigned *flag, unsigned seq) {
   __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// testing: keeps the stream busy for `ticks` of the 100 MHz wall clock (what a collective whose peer has died looks
+// like to a waiting host -- bounded, so that it ends by itself)
+__global__ void k_stall(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+hipError_t launch_stall(int ms, hipStream_t stream) {
+  hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, stream, (long long)ms * 100000ll);
+  return hipGetLastError();
+}
+
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, stream, flag, seq);
   return hipGetLastError();

@@ -14,8 +14,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "slamhip_internal.h"
@@ -27,6 +29,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // (optional)
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -48,6 +51,7 @@ static Rccl *rccl() {
       r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
       r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
       r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+      r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
       r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
       r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
       r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
@@ -74,6 +78,11 @@ struct ShardState {
   size_t cap = 0;                             // bytes per rank the buffers hold
   long long collectives = 0, bytes = 0;
   long long exchanges = 0, p2p_bytes = 0;
+  int timeout_ms = 30000;  // deadline of every wait on a collective (slamhip_shard_set_timeout)
+  bool broken = false;     // a collective timed out: the communicator is being aborted
+  std::thread aborter;     // ncclCommAbort waits for the communicator's work on the stream: off the caller's thread
+  // the attached transport's staging (padded blocks), kept between calls
+  std::vector<char> ext_snd, ext_rcv;
 };
 
 static int rccl_fail(ncclResult_t e, const char *what) {
@@ -92,6 +101,45 @@ static int invalid_arg(const char *msg) {
   return SLAMHIP_ERR_INVALID;
 }
 
+static int broken_group() {
+  set_error("the shard group is broken (a collective timed out earlier): slamhip_shard_destroy, then join a new group");
+  return SLAMHIP_ERR_STATE;
+}
+
+// Waits for what has been queued on the stream -- the collective and the copies around it -- but not for ever: a
+// peer that dies inside a collective never completes it.  On the deadline the communicator is aborted (so that the
+// kernel RCCL left on the stream ends) and the group is marked broken.
+static int bounded_wait(slamhip_ctx *ctx, ShardState *s, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) return SLAMHIP_OK;
+    if (q != hipErrorNotReady) return hip_fail(q, what);
+    if ((++spins & 63u) == 0u) {
+      const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > s->timeout_ms) break;
+      if (ms > 2) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (a healthy collective is through long before)
+    }
+  }
+  s->broken = true;
+  Rccl *r = rccl();
+  if (s->comm && r && r->CommAbort) {
+    // (ncclCommAbort itself waits for what the communicator has on the stream: the caller gets its answer NOW, the
+    // abort runs beside it and is joined by slamhip_shard_destroy)
+    ncclComm_t comm = s->comm;
+    s->comm = nullptr;
+    const int device = ctx->device;
+    s->aborter = std::thread([r, comm, device] {
+      (void)hipSetDevice(device);
+      r->CommAbort(comm);
+    });
+  }
+  set_error(std::string(what) + ": not complete after " + std::to_string(s->timeout_ms) +
+            " ms -- a peer of the shard group stopped responding; the communicator was aborted");
+  return SLAMHIP_ERR_TIMEOUT;
+}
+
 static void free_buffers(ShardState *s) {
   if (s->d_send) hipFree(s->d_send);
   if (s->d_recv) hipFree(s->d_recv);
@@ -108,6 +156,7 @@ void shard_release(slamhip_ctx *ctx) {
     Rccl *r = rccl();
     if (r) r->CommDestroy(s->comm);
   }
+  if (s->aborter.joinable()) s->aborter.join();  // (a broken group's communicator goes with ncclCommAbort)
   if (s->attached && s->ext.destroy) s->ext.destroy(s->ext.user);
   free_buffers(s);
   delete s;
@@ -178,6 +227,7 @@ int slamhip_shard_exchange(slamhip_ctx *ctx, int n_send, const slamhip_shard_msg
     if (send[k].peer < 0 || send[k].peer >= s->world || (send[k].bytes && !send[k].buf)) return invalid_arg("bad send message");
   for (int k = 0; k < n_recv; ++k)
     if (recv[k].peer < 0 || recv[k].peer >= s->world || (recv[k].bytes && !recv[k].buf)) return invalid_arg("bad receive message");
+  if (s->broken) return broken_group();
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
   long long moved = 0;
   for (int k = 0; k < n_send; ++k) moved += (long long)send[k].bytes;
@@ -202,10 +252,30 @@ int slamhip_shard_exchange(slamhip_ctx *ctx, int n_send, const slamhip_shard_msg
     const ncclResult_t e2 = r->GroupEnd();
     if (e != ncclSuccess) return rccl_fail(e, "ncclSend / ncclRecv");
     if (e2 != ncclSuccess) return rccl_fail(e2, "ncclGroupEnd");
-    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int wrc = bounded_wait(ctx, s, "slamhip_shard_exchange");
+    if (wrc) return wrc;
   }
   s->exchanges += 1;
   s->p2p_bytes += moved;
+  return SLAMHIP_OK;
+}
+
+// testing aid, not part of include/slamhip.h: a kernel that keeps the context's stream busy for `ms` (at most 5 s)
+int slamhip_debug_stall(slamhip_ctx *ctx, int ms) {
+  if (!ctx || ms < 0 || ms > 5000) return invalid_arg("bad stall");
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  SLAMHIP_CHECK(launch_stall(ms, ctx->stream));
+  return SLAMHIP_OK;
+}
+
+int slamhip_shard_set_timeout(slamhip_ctx *ctx, int ms) {
+  if (!ctx) return invalid_arg("null ctx");
+  auto *s = static_cast<ShardState *>(ctx->shard);
+  if (!s) {
+    set_error("slamhip_shard_init has not been called on this context");
+    return SLAMHIP_ERR_STATE;
+  }
+  s->timeout_ms = ms > 0 ? ms : 30000;
   return SLAMHIP_OK;
 }
 
@@ -257,12 +327,17 @@ int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *coun
     max_count = std::max(max_count, counts[q]);
   }
   if (counts[s->rank] > 0 && !local) return invalid_arg("null local block");
+  if (s->broken) return broken_group();
   const size_t block = (size_t)max_count * elem_bytes;
   if (block == 0) return SLAMHIP_OK;
   if (s->attached) {
-    // the caller's transport moves equal host blocks; padding and unpadding happen here
-    std::vector<char> snd(block, 0), rcv(block * (size_t)s->world);
-    if (counts[s->rank] > 0) std::memcpy(snd.data(), local, (size_t)counts[s->rank] * elem_bytes);
+    // the caller's transport moves equal host blocks; padding and unpadding happen here (staging kept between calls)
+    std::vector<char> &snd = s->ext_snd, &rcv = s->ext_rcv;
+    if (snd.size() < block) snd.resize(block);
+    if (rcv.size() < block * (size_t)s->world) rcv.resize(block * (size_t)s->world);
+    const size_t mine_b = (size_t)counts[s->rank] * elem_bytes;
+    if (mine_b > 0) std::memcpy(snd.data(), local, mine_b);
+    std::memset(snd.data() + mine_b, 0, block - mine_b);
     const int trc = s->ext.allgather(s->ext.user, snd.data(), block, rcv.data());
     if (trc) {
       set_error("the attached shard transport failed in its all-gather");
@@ -293,13 +368,16 @@ int slamhip_shard_allgather(slamhip_ctx *ctx, const void *local, const int *coun
     s->cap = cap;
   }
   const size_t mine = (size_t)counts[s->rank] * elem_bytes;
-  std::memcpy(s->h_send, local, mine);
+  if (mine > 0) std::memcpy(s->h_send, local, mine);  // (local may be null when this rank contributes nothing)
   std::memset(s->h_send + mine, 0, block - mine);
   SLAMHIP_CHECK(hipMemcpyAsync(s->d_send, s->h_send, block, hipMemcpyHostToDevice, ctx->stream));
   ncclResult_t e = r->AllGather(s->d_send, s->d_recv, block, ncclUint8, s->comm, ctx->stream);
   if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
   SLAMHIP_CHECK(hipMemcpyAsync(s->h_recv, s->d_recv, block * s->world, hipMemcpyDeviceToHost, ctx->stream));
-  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  {
+    const int wrc = bounded_wait(ctx, s, "slamhip_shard_allgather");
+    if (wrc) return wrc;
+  }
   char *out = static_cast<char *>(all_out);
   for (int q = 0; q < s->world; ++q) {
     const size_t nb = (size_t)counts[q] * elem_bytes;

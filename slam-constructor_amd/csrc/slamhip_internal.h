@@ -87,6 +87,7 @@ hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_or
                         hipStream_t stream, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream);
+hipError_t launch_stall(int ms, hipStream_t stream);  // testing
 // n_doubles (rounded up to two) from pinned host memory to HBM by a kernel; *h_flag = seq once the source has been read
 hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles, unsigned *counter, unsigned *h_flag,
                             unsigned seq, hipStream_t stream);

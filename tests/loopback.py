@@ -29,7 +29,15 @@ def lib():
         _lib = C.CDLL(out)
         _lib.loopback_transport_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(ShardTransport)]
         _lib.loopback_transport_create.restype = C.c_int
+        _lib.loopback_transport_set_timeout.argtypes = [C.c_char_p, C.c_int]
+        _lib.loopback_transport_set_timeout.restype = C.c_int
     return _lib
+
+
+def set_timeout(name, ms):
+    """every wait of group `name` gives up after `ms` (the group is dead from then on)"""
+    if lib().loopback_transport_set_timeout(name.encode(), int(ms)):
+        raise RuntimeError("loopback_transport_set_timeout failed")
 
 
 def attach(pkg, ctx, name, rank, world):

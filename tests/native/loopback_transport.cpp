@@ -11,6 +11,7 @@
 //                                     -I<repo>/include loopback_transport.cpp -L/opt/rocm/lib -lamdhip64
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -39,15 +40,26 @@ struct Board {
   std::vector<std::vector<char>> blocks;  // all-gather
   std::vector<Posted> posted;             // exchange
   int failed = 0;
-  void barrier(std::unique_lock<std::mutex> &lk) {
+  // every wait of this transport is bounded (include/slamhip.h: "an attached transport bounds its own waits"): a rank
+  // that does not arrive within the deadline kills the group -- everybody waiting, and everybody who comes later,
+  // gets SLAMHIP_ERR_TIMEOUT
+  int timeout_ms = 600000;
+  bool dead = false;
+  bool barrier(std::unique_lock<std::mutex> &lk) {
+    if (dead) return false;
     const long long gen = generation;
     if (++waiting == world) {
       waiting = 0;
       ++generation;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != gen; });
+      return true;
     }
+    if (!cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return generation != gen || dead; }) || dead) {
+      dead = true;
+      cv.notify_all();
+      return false;
+    }
+    return true;
   }
 };
 
@@ -64,14 +76,14 @@ int lb_allgather(void *user, const void *send, size_t block, void *recv) {
   Board &b = *r->board;
   std::unique_lock<std::mutex> lk(b.mu);
   b.blocks[r->rank].assign(static_cast<const char *>(send), static_cast<const char *>(send) + block);
-  b.barrier(lk);  // every block is posted
+  if (!b.barrier(lk)) return SLAMHIP_ERR_TIMEOUT;  // every block is posted
   int rc = 0;
   char *out = static_cast<char *>(recv);
   for (int q = 0; q < b.world; ++q) {
     if (b.blocks[q].size() != block) rc = -1;  // the ranks disagree about the block size
     else std::memcpy(out + (size_t)q * block, b.blocks[q].data(), block);
   }
-  b.barrier(lk);  // every block is read: the board may be rewritten
+  if (!b.barrier(lk)) return SLAMHIP_ERR_TIMEOUT;  // every block is read: the board may be rewritten
   return rc;
 }
 
@@ -80,7 +92,7 @@ int lb_exchange(void *user, int n_send, const slamhip_shard_msg *send, int n_rec
   Board &b = *r->board;
   std::unique_lock<std::mutex> lk(b.mu);
   for (int k = 0; k < n_send; ++k) b.posted.push_back(Posted{r->rank, send[k].peer, send[k].buf, send[k].bytes});
-  b.barrier(lk);  // everything that will be sent is on the board (in each sender's order)
+  if (!b.barrier(lk)) return SLAMHIP_ERR_TIMEOUT;  // everything that will be sent is on the board (in each sender's order)
   int rc = 0;
   std::vector<size_t> taken(b.world, 0);  // per sender: how many of its messages to me I have matched
   for (int k = 0; k < n_recv; ++k) {
@@ -107,10 +119,10 @@ int lb_exchange(void *user, int n_send, const slamhip_shard_msg *send, int n_rec
     }
   }
   if (rc) b.failed = 1;
-  b.barrier(lk);  // every receive has copied: the senders' buffers are free again
+  if (!b.barrier(lk)) return SLAMHIP_ERR_TIMEOUT;  // every receive has copied: the senders' buffers are free again
   if (r->rank == 0) b.posted.clear();
   const int failed = b.failed;
-  b.barrier(lk);
+  if (!b.barrier(lk)) return SLAMHIP_ERR_TIMEOUT;
   if (r->rank == 0) b.failed = 0;
   return rc ? rc : (failed ? -3 : 0);
 }
@@ -146,5 +158,15 @@ extern "C" int loopback_transport_create(const char *name, int rank, int world, 
   out->allgather = lb_allgather;
   out->exchange = lb_exchange;
   out->destroy = lb_destroy;
+  return 0;
+}
+
+// deadline of every wait of group `name` (default: ten minutes)
+extern "C" int loopback_transport_set_timeout(const char *name, int ms) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_boards.find(name ? name : "");
+  if (it == g_boards.end() || ms <= 0) return -1;
+  std::lock_guard<std::mutex> lk2(it->second->mu);
+  it->second->timeout_ms = ms;
   return 0;
 }

@@ -9,6 +9,8 @@
 import os
 import sys
 
+import ctypes as C
+
 import numpy as np
 import pytest
 from synth import make_scene
@@ -330,7 +332,7 @@ def test_exchange_over_rccl_with_one_rank(pkg):
     ctx.close()
 
 
-def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None):
+def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None, inject=None):
     """slamhip_gmapping_step_sharded with per-particle maps on `world` in-process ranks; returns per-rank logs:
     (resampled, idx, poses, weights, masters) per step, the final maps of the rank's particles, migration stats"""
     import threading
@@ -356,7 +358,15 @@ def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None):
                                     seeds[first:first + counts[rank]], first=first, count=counts[rank])
             pf.enable_particle_maps(4, 8, 16 + 24 * n)
             log = []
+            dbg = pkg.load().slamhip_gmapping_debug_fail
+            dbg.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            dbg.restype = C.c_int
             for it, k in enumerate(steps_spec):
+                # inject = (rank, where, step): the library's testing hook makes one place fail on one rank as a
+                # rank-local error (1 match_finish, 2 the export between the migration's collectives, 3 the final
+                # import), armed right before step `step`
+                if inject and inject[0] == rank and it == inject[2]:
+                    assert dbg(pf.h, inject[1], 1) == 0
                 if fail_rank == rank and it == 1:
                     # a step left half done by the caller (match_begin without match_finish): this rank's
                     # step_sharded fails in its own match_begin
@@ -449,6 +459,146 @@ def test_a_failing_rank_takes_every_rank_out_of_the_step(pkg):
         assert log[2][0] != "error", log[2]
     assert "not finished" in logs[1][0][1][1], logs[1][0][1][1]
     assert "rank 1" in logs[0][0][1][1], logs[0][0][1][1]
+
+
+def _errors_by_step(logs, world):
+    return [[logs[r][0][it][0] == "error" for r in range(world)] for it in range(len(logs[0][0]))]
+
+
+def test_late_failures_leave_every_collective_together(pkg):
+    """ADVICE r3 (medium, twice): a rank that fails BEHIND the step's first collective -- its map update in
+    match_finish, the export of a migrating map between the migration's collectives -- used to return while the other
+    ranks went on into the resampling's all-gathers and waited there for good.  Now such a rank stays in the step's
+    collectives with a status word, and every rank leaves from the same one.  Three ranks in-process (a hang would
+    show as a stuck thread), failures injected through the library's testing hook:
+      * match_finish in a step that resamples: EVERY rank returns an error from that step, the next step runs;
+      * match_finish in a step that does not resample: no collective follows, the rank fails alone and the others
+        learn of it from the status word of the NEXT step's first all-gather (everybody fails there, then goes on);
+      * the export between the migration's all-gathers: every rank leaves the resampling together;
+      * the import behind the migration's last collective: alone, then everybody at the next step."""
+    from helpers import load
+    world, n = 3, 8
+    n_base = int(load("gmapping_pf_update.npz")["n_steps"])
+    steps_spec = list(range(n_base)) + [1 + (k % (n_base - 1)) for k in range(20)]
+    clean, _, _, _ = run_map_ranks(pkg, world, n, steps_spec, "late-clean")
+    res = [bool(clean[0][0][it][0]) for it in range(len(steps_spec))]
+    assert any(res[1:]) and not all(res[1:])
+    it_res = 1 + res[1:].index(True)
+    it_plain = 1 + res[1:-1].index(False)
+    # match_finish, resampling step: together, at once
+    logs, _, _, _ = run_map_ranks(pkg, world, n, steps_spec, "late-a", inject=(1, 1, it_res))
+    err = _errors_by_step(logs, world)
+    assert err[it_res] == [True] * world and not any(any(e) for i, e in enumerate(err) if i != it_res), err
+    assert "injected" in logs[1][0][it_res][1] and "rank 1" in logs[0][0][it_res][1] and "rank 1" in logs[2][0][it_res][1]
+    # match_finish, no resampling: alone, then everybody at the next step's first collective
+    logs, _, _, _ = run_map_ranks(pkg, world, n, steps_spec, "late-b", inject=(2, 1, it_plain))
+    err = _errors_by_step(logs, world)
+    assert err[it_plain] == [False, False, True] and err[it_plain + 1] == [True] * world, err
+    assert not any(any(e) for i, e in enumerate(err) if i not in (it_plain, it_plain + 1)), err
+    # the migration: export between its collectives (together), import behind them (alone, then everybody)
+    logs, _, _, _ = run_map_ranks(pkg, world, n, steps_spec, "late-c", inject=(0, 2, 0))
+    err = _errors_by_step(logs, world)
+    hit = [i for i, e in enumerate(err) if any(e)]
+    assert len(hit) == 1 and err[hit[0]] == [True] * world and res[hit[0]], (hit, err)
+    assert "abandoned on every rank" in logs[1][0][hit[0]][1]
+    logs, _, _, _ = run_map_ranks(pkg, world, n, steps_spec, "late-d", inject=(1, 3, 0))
+    err = _errors_by_step(logs, world)
+    hit = [i for i, e in enumerate(err) if any(e)]
+    assert len(hit) == 2 and hit[1] == hit[0] + 1 and err[hit[0]] == [False, True, False] and err[hit[1]] == [True] * world, (hit, err)
+
+
+def test_a_rank_that_stops_responding_takes_the_step_down_within_the_deadline(pkg):
+    """the status words cover errors raised BEFORE a collective; a peer that dies INSIDE one used to
+    hang the group for good.  Two in-process ranks over the loopback transport (deadline 400 ms): rank 1 takes two
+    steps and then never calls again; rank 0's third step must come back with SLAMHIP_ERR_TIMEOUT within the deadline
+    -- the library hands the transport's verdict through and abandons the step (the filter is not left `pending`)."""
+    import threading
+    import time
+    import loopback
+    from helpers import load
+    loopback.lib()
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    n, world, name = 8, 2, "dies"
+    counts = [4, 4]
+    seeds = np.arange(2000, 2000 + n, dtype=np.uint32)
+    out, errors = {}, []
+    attached = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            ctx = pkg.Context(0)
+            loopback.attach(pkg, ctx, name, rank, world)
+            attached.wait()
+            if rank == 0:
+                loopback.set_timeout(name, 400)
+            ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+            c0, s0 = pkg.beam_trig(g["step0_angle"])
+            ctx.map_append_scan(4, pkg.RULE_GMAPPING, g["step0_delta"], g["step0_range"], c0, s0)
+            first = sum(counts[:rank])
+            pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=1), n,
+                                    seeds[first:first + counts[rank]], first=first, count=counts[rank])
+            for it in range(2 if rank == 1 else 3):
+                t0 = time.time()
+                try:
+                    pf.step_sharded(4, g["step%d_range" % it], g["step%d_angle" % it], None, g["step%d_delta" % it], 7 + it)
+                    out[(rank, it)] = ("ok", time.time() - t0)
+                except pkg.SlamHipError as e:
+                    out[(rank, it)] = (str(e), time.time() - t0)
+            if rank == 0:
+                # the step was abandoned, not left half done: a host-side call that needs no group still works
+                pf.match_abort()
+                out["state"] = pf.state()[0].shape
+            pf.close()
+            ctx.shard_destroy()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in threads), "a rank is stuck in a collective"
+    assert not errors, errors
+    assert out[(0, 0)][0] == out[(0, 1)][0] == out[(1, 0)][0] == out[(1, 1)][0] == "ok"
+    msg, took = out[(0, 2)]
+    assert msg != "ok" and took < 3.0, out[(0, 2)]
+    assert out["state"] == (4, 3)
+
+
+def test_rccl_collective_wait_is_bounded(pkg):
+    """The same on the built-in transport: slamhip_shard_allgather / _exchange poll the stream until the group's
+    deadline instead of hipStreamSynchronize.  One GPU admits one RCCL rank, so the dead peer is played by a kernel
+    that keeps the stream busy for a second (testing hook) in front of the collective of a 1-rank group with a 150 ms
+    deadline: SLAMHIP_ERR_TIMEOUT within the deadline, the communicator aborted, every later collective refused at
+    once -- and after slamhip_shard_destroy a fresh group works."""
+    import time
+    ctx = pkg.Context(0)
+    L = pkg.load()
+    L.slamhip_debug_stall.argtypes = [C.c_void_p, C.c_int]
+    L.slamhip_debug_stall.restype = C.c_int
+    ctx.shard_init(0, 1, pkg.shard_unique_id())
+    a = np.arange(12, dtype=np.float64).reshape(4, 3)
+    np.testing.assert_array_equal(ctx.shard_allgather(a, [4]), a)
+    ctx.shard_set_timeout(150)
+    assert L.slamhip_debug_stall(ctx.h, 1000) == 0
+    t0 = time.time()
+    with pytest.raises(pkg.SlamHipError, match="stopped responding"):
+        ctx.shard_allgather(a, [4])
+    assert time.time() - t0 < 0.8
+    with pytest.raises(pkg.SlamHipError, match="broken"):
+        ctx.shard_allgather(a, [4])
+    with pytest.raises(pkg.SlamHipError, match="broken"):
+        ctx.shard_exchange([], [])
+    ctx.shard_destroy()
+    ctx.synchronize()
+    ctx.shard_init(0, 1, pkg.shard_unique_id())
+    np.testing.assert_array_equal(ctx.shard_allgather(a, [4]), a)
+    ctx.shard_destroy()
+    ctx.close()
 
 
 def _rank_main_maps(rank, world, uid_path, out_path):
