@@ -230,7 +230,13 @@ struct HcDecision {
 // (b, hb), which it replaces when accepted
 HC_HD void hc_decide_one(HcDecision &d, double &b, unsigned long long &hb, int c, double s, unsigned long long h,
                          bool check) {
-  if (check && h != hb) {
+  // (equal fingerprints with DIFFERENT sums cannot be identical term vectors -- those add up to the same bits: a
+  // fingerprint collision, as unsettled as differing fingerprints)
+  union {
+    double d;
+    unsigned long long u;
+  } sb{s}, bb{b};
+  if (check && (h != hb || sb.u != bb.u)) {
     const double diff = s > b ? s - b : b - s;
     const double as = s < 0 ? -s : s, ab = b < 0 ? -b : b;
     if (diff <= (as > ab ? as : ab) * 9.094947017729282e-13) d.ambiguous = true;  // 2^-40 (NaN: a rejection)

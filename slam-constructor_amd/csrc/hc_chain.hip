@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   static_assert(!(BATCH && GM), "the filter's chains share one map view and one scan");
   extern __shared__ double s_term[];            // point OOPE: one term per beam; GMapping: K3's arrays
   __shared__ GmPoseInfo s_info[GM ? kHcSlots : 1];  // side outputs of the previous tree's poses
-  __shared__ unsigned s_hash[GM ? 1 : kHcSlots + 7];  // term-vector fingerprints of the previous tree's poses
+  __shared__ unsigned long long s_hash[GM ? 1 : kHcSlots + 7];  // term-vector fingerprints of the previous tree's poses
   __shared__ unsigned long long s_hpart[4];
   __shared__ double s_unknown[4];
   __shared__ int s_run0_len;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     if (!GM && a.verify) {
       for (int i = t; i <= n_stage; i += NT) {
         const int j = i < n_stage ? i : kHcSlots - 1;
-        s_hash[j] = (unsigned)ctl->hashes[pb][j];
+        s_hash[j] = ctl->hashes[pb][j];
       }
     }
     if (GM) {
@@ -261,14 +261,14 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       int nacc = 0, out = 0;
       unsigned accmask = 0u;
       bool ambiguous = false;
-      unsigned run_hash = 0u;
+      unsigned long long run_hash = 0ull;
       const bool rescored = !GM && a.verify && sp.mode == 1;  // decisions from the beam-order sums of this tree
       if (!GM && a.verify) {
         // slot kHcSlots-1 holds the base pose of a re-scored tree (or the initial pose): its sums head the path
         const bool base_here = sp.first || sp.mode == 1;
-        const unsigned root_hash = base_here ? s_hash[kHcSlots - 1] : (unsigned)sp.best_hash;
-        unsigned hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
-        unsigned h6[6];
+        const unsigned long long root_hash = base_here ? s_hash[kHcSlots - 1] : sp.best_hash;
+        unsigned long long hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
+        unsigned long long h6[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) h6[c] = s_hash[6 * lane + c];
         if (!rescored) {
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
             const bool live = c == 0 || !trailing;
             const bool close = diff <= (as > ab ? as : ab) * 9.094947017729282e-13;  // NaN: false, a rejection
-            ambiguous = ambiguous || (live && close && h6[c] != hb);
+            // (equal fingerprints with different sums: not identical vectors -- a collision, equally unsettled)
+            ambiguous = ambiguous || (live && close && (h6[c] != hb || __double_as_longlong(s) != __double_as_longlong(run)));
             const bool acc = live && run < s;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
             run = acc ? s : run;
             hb = acc ? h6[c] : hb;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       next.first = 0;
       next.steps = sp.steps + 1;
       if (!GM && a.verify) {
-        next.best_hash = (unsigned)bcast_i((int)run_hash, tl);
+        next.best_hash = (unsigned long long)bcast_ll((long long)run_hash, tl);
         next.mode = 0;
         next.rescored = sp.rescored;
       }
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
     const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     ctl->scores[k & 1][slot] = (scan.tot_w == 0.0) ? __builtin_nan("") : total / scan.tot_w;
     if (verify) {
-      ctl->hashes[k & 1][slot] = fold_fingerprint(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]);
+      ctl->hashes[k & 1][slot] = s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3];
     }
     if (stamp) a.stamps[8 * k + 5] = wall_clock64();
   }

@@ -58,18 +58,25 @@ __device__ __forceinline__ double bcast(double v, int lane) {
   return __longlong_as_double(bcast_ll(__double_as_longlong(v), lane));
 }
 
-// tag of super-step k of the match with this epoch: never 0 (a zeroed block matches nothing); the host clears the
-// block whenever the 20 epoch bits wrap
-__device__ __forceinline__ unsigned hc_tag(unsigned epoch, int k) { return ((epoch & 0xfffffu) << 12) | (unsigned)(k + 1); }
+// 16-bit tag of super-step k of the match with this epoch, never 0: twelve bits of step, four of epoch.  Four are
+// enough because every workgroup clears its own two granules when a match starts: what can still lie in a slot is
+// the previous match's, whose epoch bits differ (the host clears the block when a launch uses more slots than
+// the one before, hc_resident_capacity's callers).  The granule's last dword = 16 fingerprint bits | tag.
+__device__ __forceinline__ unsigned hc_tag(unsigned epoch, int k) { return ((epoch & 0xfu) << 12) | (unsigned)(k + 1); }
 
-__device__ __forceinline__ void gran_store(HcGranule *p, double score, unsigned hash, unsigned tag) {
+// hash: the low 48 bits count (fold_fingerprint48)
+__device__ __forceinline__ void gran_store(HcGranule *p, double score, unsigned long long hash, unsigned tag) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(score);
   u32x4 g;
   g.x = (unsigned)u;
   g.y = (unsigned)(u >> 32);
-  g.z = hash;
-  g.w = tag;
+  g.z = (unsigned)hash;
+  g.w = ((unsigned)(hash >> 32) << 16) | (tag & 0xffffu);
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(g) : "memory");
+}
+__device__ __forceinline__ unsigned gran_tag(const u32x4 &g) { return g.w & 0xffffu; }
+__device__ __forceinline__ unsigned long long gran_hash(const u32x4 &g) {
+  return ((unsigned long long)(g.w >> 16) << 32) | (unsigned long long)g.z;
 }
 // issue only: gran_wait ties the loaded values to the one wait
 __device__ __forceinline__ u32x4 gran_load(const HcGranule *p) {
@@ -101,7 +108,7 @@ __device__ __forceinline__ double gran_score(const u32x4 &g) {
 template <int MODEL, int NT, bool SEQ, bool BATCH, int G>
 __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   extern __shared__ double s_term[];  // one term per beam
-  __shared__ unsigned s_hash[kHcSlots + 7];
+  __shared__ unsigned long long s_hash[kHcSlots + 7];  // (48 bits each)
   __shared__ double s_sc[kHcSlots + 7];
   __shared__ HcInst s_mine[kHcShapes];  // this workgroup's round instance in every shape
   __shared__ double s_pose[2][4];       // x, y, sin, cos of the pose this workgroup scores, by step parity
@@ -146,6 +153,10 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
   }
   if (t == 0) s_stop = 0;
+  if (t < 4) {  // this slot's granules of both parities start the match empty (see hc_tag)
+    HcGranule *g0 = (t & 2) ? &rc->seq[t & 1][slot] : &rc->gran[t & 1][slot];
+    gran_store(g0, 0.0, 0ull, 0u);
+  }
   const bool verify = a.verify != 0;
   const bool stamp = a.stamps && slot == 1 && t == 0;
   HcGranule *const gran = &rc->gran[0][0];
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             acc = acc + t7;
           }
           for (; b < n; ++b) acc = acc + s_term[b];
-          gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0u, tag);
+          gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0ull, tag);
         }
         __syncthreads();  // (C) (s_term is rewritten by the next super-step)
       } else {
@@ -297,22 +308,22 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         __syncthreads();  // (C)
         if (t == 0) {
           const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-          const unsigned fp = verify ? fold_fingerprint(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]) : 0u;
+          const unsigned long long fp = verify ? fold_fingerprint48(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]) : 0ull;
           gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : total / scan.tot_w, fp, tag);
         }
         if (verify && mode && t == 64) {
           // re-scored super-step: the reference's own order as well, one running sum over the beams
           double acc = 0.0;
           for (int b = 0; b < n; ++b) acc = acc + s_term[b];
-          gran_store(&gseq[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0u, tag);
+          gran_store(&gseq[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0ull, tag);
         }
       }
       if (stamp && k < 64) a.stamps[8 * k + 5] = wall_clock64();
     } else if (!init_slot && t == 0) {
       // nothing to score (behind the end of the chain, or the surplus candidates of a trailing round): the sweepers
       // wait for every slot of the shape, so the tag goes out all the same
-      gran_store(&gran[pk * kGranRow + slot], 0.0, 0u, tag);
-      if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0u, tag);
+      gran_store(&gran[pk * kGranRow + slot], 0.0, 0ull, tag);
+      if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0ull, tag);
     }
 
     // ---- wave 0: all scores of super-step k, then its replay
@@ -363,11 +374,11 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
               const int i = lane + 64 * q;
               if (i < n_wait) {
                 const int j = i < n6 ? i : kHcSlots - 1;
-                const bool here = g[q].w == tag;
+                const bool here = gran_tag(g[q]) == tag;
                 ok = ok && here;
                 if (here) {
                   s_sc[j] = gran_score(g[q]);
-                  s_hash[j] = g[q].z;
+                  s_hash[j] = gran_hash(g[q]);
                 }
               }
             }
@@ -406,12 +417,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       int nacc = 0, out = 0;
       unsigned accmask = 0u;
       bool ambiguous = false;
-      unsigned run_hash = 0u;
+      unsigned long long run_hash = 0ull;
       if (!SEQ && verify) {
         // slot kHcSlots-1 holds the base pose of a re-scored tree (or the initial pose): its sums head the path
-        const unsigned root_hash = base_here ? s_hash[kHcSlots - 1] : (unsigned)sp.best_hash;
-        unsigned hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
-        unsigned h6[6];
+        const unsigned long long root_hash = base_here ? s_hash[kHcSlots - 1] : sp.best_hash;
+        unsigned long long hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
+        unsigned long long h6[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) h6[c] = s_hash[6 * lane + c];
         if (!rescored) {
@@ -424,7 +435,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
             const bool live = c == 0 || !trailing;
             const bool close = diff <= (as > ab ? as : ab) * 9.094947017729282e-13;  // NaN: false, a rejection
-            ambiguous = ambiguous || (live && close && h6[c] != hb);
+            // (equal fingerprints with different sums: not identical vectors -- a collision, equally unsettled)
+            ambiguous = ambiguous || (live && close && (h6[c] != hb || __double_as_longlong(s) != __double_as_longlong(run)));
             const bool acc = live && run < s;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
             run = acc ? s : run;
             hb = acc ? h6[c] : hb;
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
               u32x4 g = gran_load(q0 + j);
               asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
               sd = gran_score(g);
-              if (__all(g.w == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+              if (__all(gran_tag(g) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
             }                                                         // the same workgroups are here already)
             if (c < 0) {
               bdec = sd;
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         hc_advance(sp, me, rt, out_t, run_t, a.max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0),
                    &next);
         if (!SEQ && verify) {
-          next.best_hash = (unsigned)bcast_i((int)run_hash, tl);
+          next.best_hash = (unsigned long long)bcast_ll((long long)run_hash, tl);
           next.mode = 0;
           next.rescored = sp.rescored;
         }

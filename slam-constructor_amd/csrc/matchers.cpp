@@ -45,7 +45,7 @@ struct slamhip_matcher {
   long long chain_rescored = 0;  // super-steps (device chain) / batches (host-driven) of the last match scored twice
   long long rescored_poses = 0;
   std::vector<double> keep_scores;
-  std::vector<unsigned> keep_fprints;
+  std::vector<unsigned long long> keep_fprints;
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
   int debug_trace_cap = 0;        // testing (slamhip_matcher_debug_trace_cap): pretend the trace buffer is this small
@@ -249,8 +249,8 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
       SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
       SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));  // (ordered with the launch)
     }
-    // a tag carries 20 bits of the epoch: clear the block when they wrap (queued in front of the launch)
-    if ((epoch & 0xfffffu) == 0u) SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));
+    // (every workgroup clears its own granules when a match starts, and this matcher's grid never changes: nothing
+    // stale can carry a current tag -- hc_tag in hc_resident.hip)
     a.rctl = m->d_rctl;
     a.debug_mute = m->debug_resident_mute;
     hipEvent_t e0, e1;
@@ -395,6 +395,7 @@ struct HcBatch {
   unsigned *d_n_done = nullptr, *h_done_count = nullptr;
   slamhip::HcResidentCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain (cap of them)
   unsigned *h_all_done = nullptr;            // pinned: the last chain to end stores the epoch here
+  int rctl_grid = 0, rctl_chains = 0;        // slots per chain / chains of the last co-resident launch
   bool ran_resident = false;
   slamhip::HcTraceEntry *h_trace = nullptr;  // pinned: cap x trace_per entries (observer attached only)
   int trace_per = 0, trace_chains = 0;
@@ -478,6 +479,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     if (b->d_inits) hipFree(b->d_inits);
     if (b->d_rctl) hipFree(b->d_rctl);
     b->d_rctl = nullptr;
+    b->rctl_grid = b->rctl_chains = 0;
     b->d_ctl = nullptr;
     b->h_out = nullptr;
     b->h_jobs = b->d_jobs = nullptr;
@@ -626,7 +628,12 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
         SLAMHIP_CHECK(hipHostMalloc(&b->h_all_done, sizeof(unsigned), pinned));
         *b->h_all_done = 0;
       }
-      if ((epoch & 0xfffffu) == 0u) SLAMHIP_CHECK(hipMemsetAsync(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap, st));
+      // a launch with more slots per chain than the one before meets granules no workgroup has cleared since an
+      // older launch of that size: clear the block (queued in front of the launch)
+      if (6 * b->max_inst + 1 > b->rctl_grid || n > b->rctl_chains)
+        SLAMHIP_CHECK(hipMemsetAsync(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap, st));
+      b->rctl_grid = 6 * b->max_inst + 1;
+      b->rctl_chains = n;
       a.rctl = b->d_rctl;
       a.h_all_done = b->h_all_done;
       a.debug_mute = m->debug_resident_mute;

@@ -732,15 +732,19 @@ public:
   // each other, more than the two orders of summation can differ by, and the term vectors not identical?
   // Nothing is consumed; the caller then scores the batch once more in beam order and hands those sums to
   // consume() as `dec`.  (csrc/hc_chain.h hc_decide_one: the same test on the device chain.)
-  bool ambiguous(const double *sc, const unsigned *fp) const {
+  bool ambiguous(const double *sc, const unsigned long long *fp) const {
     double b = first ? sc[0] : best_prob;
-    unsigned hb = first ? fp[0] : best_fp;
+    unsigned long long hb = first ? fp[0] : best_fp;
     int node = tree.root;
     while (node >= 0) {
       const SpecTree::Node &nd = tree.nodes[node];
       const double s = sc[lead_ + nd.eval];
-      const unsigned h = fp[lead_ + nd.eval];
-      if (h != hb && std::fabs(s - b) <= std::max(std::fabs(s), std::fabs(b)) * 9.094947017729282e-13) return true;
+      const unsigned long long h = fp[lead_ + nd.eval];
+      // (equal fingerprints with DIFFERENT sums cannot be identical term vectors -- those add up to the same bits --
+      // so that is a fingerprint collision and as unsettled as differing fingerprints)
+      if ((h != hb || std::memcmp(&s, &b, sizeof(double)) != 0) &&
+          std::fabs(s - b) <= std::max(std::fabs(s), std::fabs(b)) * 9.094947017729282e-13)
+        return true;
       const bool ok = b < s;
       if (ok) {
         b = s;
@@ -751,12 +755,12 @@ public:
     return false;
   }
   int planned() const { return planned_; }
-  unsigned best_fp = 0;  // fingerprint of the best pose's term vector (checked default mode)
+  unsigned long long best_fp = 0;  // fingerprint of the best pose's term vector (checked default mode)
 
   // sc / gi point at this job's slice of the batch results; fp (optional): the fingerprints, remembered for the
   // best pose; dec (optional): the scores the comparisons are decided from -- the beam-order sums of a batch
   // scored twice, dec_best the current best pose's -- while sc stays what is stored and reported
-  int consume(const double *sc, const GmPoseInfo *gi, const slamhip_ctx *ctx, const unsigned *fp = nullptr,
+  int consume(const double *sc, const GmPoseInfo *gi, const slamhip_ctx *ctx, const unsigned long long *fp = nullptr,
               const double *dec = nullptr, double dec_best = 0.0) {
     const double t0 = timed ? now_us() : 0.0;
     launches += 1;

@@ -37,7 +37,7 @@ struct McState {
   unsigned failed, poses;
   int has_saved;
   int done, first, mode, steps;
-  unsigned best_hash;  // fingerprint of the best pose's term vector (checked default mode)
+  unsigned long long best_hash;  // fingerprint of the best pose's term vector (checked default mode)
   unsigned rescored;
 };
 
@@ -103,7 +103,7 @@ MC_HD void mc_consume(McState &s, const McPair *tape, int n) {
 // distributions when more than max_failed / 3 failures preceded it (monte_carlo_scan_matcher.h:44-55,58-70: the
 // failure counter is NOT reset by an acceptance below that mark)
 MC_HD void mc_advance(McState &s, const McPair *tape, int n, int j_acc, double acc_x, double acc_y, double acc_theta,
-                      double acc_prob, unsigned acc_hash, unsigned max_failed, unsigned max_poses) {
+                      double acc_prob, unsigned long long acc_hash, unsigned max_failed, unsigned max_poses) {
   const int used = j_acc >= 0 ? j_acc + 1 : n;
   mc_consume(s, tape, used);
   s.calls += used;

@@ -27,7 +27,7 @@ template <int MODEL, int NT, bool SEQ>
 __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
   extern __shared__ double s_term[];
   __shared__ double s_sc[kMcSlots + 8];
-  __shared__ unsigned s_hash[kMcSlots + 8];
+  __shared__ unsigned long long s_hash[kMcSlots + 8];
   __shared__ McState s_prev;
   __shared__ double s_pose[4];
   __shared__ int s_go, s_mode;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
       const bool rescored = verify && sp.mode == 1;  // decisions from the beam-order sums of this super-step
       const double root = sp.first ? s_sc[kMcSlots] : sp.best_prob;
       const bool base_here = sp.first || sp.mode == 1;
-      const unsigned root_hash = verify ? (base_here ? s_hash[kMcSlots] : sp.best_hash) : 0u;
+      const unsigned long long root_hash = verify ? (base_here ? s_hash[kMcSlots] : sp.best_hash) : 0ull;
       const double *seq = ctl->scores_seq[pb];
       const double root_dec = rescored ? seq[kMcSlots] : root;
       const int avail = (int)mc_available(sp, a.max_failed, a.max_poses);
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
         if (verify && !rescored && live) {
           const double diff = __builtin_fabs(s - root);
           const double as = __builtin_fabs(s), ab = __builtin_fabs(root);
-          if (diff <= (as > ab ? as : ab) * 9.094947017729282e-13 && s_hash[j] != root_hash) amb_mask |= 1u << c;
+          // (equal fingerprints with different sums: not identical vectors -- a collision, equally unsettled)
+          if (diff <= (as > ab ? as : ab) * 9.094947017729282e-13 &&
+              (s_hash[j] != root_hash || __double_as_longlong(s) != __double_as_longlong(root)))
+            amb_mask |= 1u << c;
         }
       }
       const unsigned long long acc_lanes = __ballot(first_c < 6);
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
       if (!dirty) {
         if (j_acc >= 0) mc_candidate(sp, a.tape, j_acc, &ax, &ay, &ath);
         const double aprob = j_acc >= 0 ? s_sc[j_acc] : 0.0;
-        const unsigned ahash = (verify && j_acc >= 0) ? s_hash[j_acc] : 0u;
+        const unsigned long long ahash = (verify && j_acc >= 0) ? s_hash[j_acc] : 0ull;
         if (sp.first) {  // the initial pose was scored in the same super-step: call number one
           next.best_prob = root;
           next.best_hash = root_hash;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
   if (t == 0) {
     const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
     ctl->scores[k & 1][slot] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
-    if (verify) ctl->hashes[k & 1][slot] = fold_fingerprint(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]);
+    if (verify) ctl->hashes[k & 1][slot] = s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3];
   }
   if (verify && s_mode && t == 64) {
     double acc = 0.0;

@@ -37,7 +37,7 @@ struct McChainCtl {
   McState state[2];  // state of super-step k at [k & 1]
   double scores[2][kMcSlots + 8];
   double scores_seq[2][kMcSlots + 8];
-  unsigned hashes[2][kMcSlots + 8];
+  unsigned long long hashes[2][kMcSlots + 8];
   unsigned done_epoch;
 };
 

@@ -62,7 +62,11 @@ __device__ __forceinline__ unsigned long long term_fingerprint(double term, unsi
   const unsigned long long bits = (unsigned long long)__double_as_longlong(term);
   return (unsigned long long)(unsigned)bits * k_lo + (unsigned long long)(unsigned)(bits >> 32) * k_hi;
 }
-__device__ __forceinline__ unsigned fold_fingerprint(unsigned long long h) { return (unsigned)(h >> 32) ^ (unsigned)h; }
+// (r01-r03 folded h to 32 bits; the chains and K1 now carry all 64 -- VERDICT r3 item 7 -- and the co-resident chain,
+// whose granule has room for 48 next to the score and the tag, folds the top 16 into them)
+__device__ __forceinline__ unsigned long long fold_fingerprint48(unsigned long long h) {
+  return (h ^ (h >> 48)) & 0xffffffffffffull;
+}
 // wave_xor_sum's fixed butterfly with the fingerprint's exchanges riding along
 template <int OFF>
 __device__ __forceinline__ void wave_xor_step_with(double &v, unsigned long long &h) {

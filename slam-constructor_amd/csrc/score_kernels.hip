@@ -103,7 +103,7 @@ hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles
 // ---- K1 ----------------------------------------------------------------------------------------
 // KB > 0: beams per thread known at compile time (n <= 256*KB), constants live in VGPRs.
 // KB == 0: generic (any n): constants re-read from L1/L2 in the pose loop.
-// FPRINT: a 32-bit fingerprint of every pose's term vector goes out next to its score (the matchers' checked
+// FPRINT: a 64-bit fingerprint of every pose's term vector goes out next to its score (the matchers' checked
 // default mode: two poses with equal fingerprints add up the same terms, whatever the order of the sum)
 template <int MODEL, int KB, bool WRITE_TERMS, bool FPRINT>
 __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_score_point(ScoreArgs a) {
   if (t < npb) {
     const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
     a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
-    if (FPRINT) a.fprints[p0 + t] = fold_fingerprint(s_hpart[t][0] + s_hpart[t][1] + s_hpart[t][2] + s_hpart[t][3]);
+    if (FPRINT) a.fprints[p0 + t] = s_hpart[t][0] + s_hpart[t][1] + s_hpart[t][2] + s_hpart[t][3];
   }
 }
 

@@ -68,7 +68,7 @@ int ensure_pose_capacity(slamhip_ctx *ctx, int n) {
     ctx->pose_cap = 0;
   }
   SLAMHIP_CHECK(hipHostMalloc(&ctx->h_pose_slot, sizeof(int) * cap, kPinned));
-  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_fprints, sizeof(unsigned) * cap, kPinned));
+  SLAMHIP_CHECK(hipHostMalloc(&ctx->h_fprints, sizeof(unsigned long long) * cap, kPinned));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_poses, sizeof(double) * 3 * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_scores, sizeof(double) * cap));
   SLAMHIP_CHECK(hipMalloc(&ctx->d_pose_sc, sizeof(double) * 2 * cap));

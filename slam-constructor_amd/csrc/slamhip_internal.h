@@ -59,7 +59,7 @@ struct ScoreArgs {
   GmParams gm;
   GmPoseInfo *gm_info;  // GMAPPING only
   double *terms;        // SEQUENTIAL order only: n_poses x scan.n scratch
-  unsigned *fprints;    // K1, canonical sum only: per-pose term-vector fingerprints (null = none)
+  unsigned long long *fprints;  // K1, canonical sum only: per-pose term-vector fingerprints, 64 bits (null = none)
   // per-particle copy-on-write maps (K3 only, tile_pool.h): tile tables of all slots, the slot of
   // every pose; then map.payload = tile pool, map.pitch = tiles per table row, map.width/height =
   // the virtual extent in cells.  null = one dense window for all poses.
@@ -177,7 +177,7 @@ struct slamhip_ctx {
   double *d_poses = nullptr, *d_scores = nullptr, *d_pose_sc = nullptr;
   double *h_poses = nullptr, *h_scores = nullptr, *h_pose_sc = nullptr;  // pinned
   slamhip::GmPoseInfo *d_gm_info = nullptr, *h_gm_info = nullptr;
-  unsigned *h_fprints = nullptr;  // pinned, next to h_scores
+  unsigned long long *h_fprints = nullptr;  // pinned, next to h_scores
   bool want_fprints = false;      // the next score_staged() asks K1 for fingerprints (matchers' checked mode)
   int *h_pose_slot = nullptr;  // pinned: map slot of every staged pose (per-particle maps only)
   int pose_cap = 0;
