@@ -46,7 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_UNIT = {"occ": 24, "tbm": 56, "gmapping": 232}  # SURVEY 8d algorithmic bytes / (pose, beam)
 K6_BYTES_PER_RECORD = 64  # per (beam, cell) 2 x 32 B read-modify-write
-ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5", "world", "replicas"]
+ALL_LEGS = ["pf", "pf_update", "pf_maps", "cfg5", "world", "replicas", "bf"]
 
 WORKLOADS = {
     # name: (cell model, weighting, matcher kind, params, bytes key, description)
@@ -1144,6 +1144,44 @@ def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16)):
                     "lone run bit for bit (tests/test_gpu_batch.py)"}
 
 
+def bf_leg(args, pkg, ctx, sc, scenes, bpu, ceiling):
+    """The brute-force matcher on the search-space evaluator's sweep -- 201 x 201 poses around the odometry pose
+    (src/utils/pose2D_search_space_evaluator.cpp:154-184) -- as ONE flat K1 launch + a device arg-max
+    (csrc/bf_device.hip) on the headline's map and rotating scenes (filtered scans resident in HBM): whole
+    process_scan calls per second in the headline's unit, beside the flat sweep's kernel rate (roofline_sweep)."""
+    rng9 = [-0.5, 0.5 - 1e-9, 0.005, -0.5, 0.5 - 1e-9, 0.005, 0.0, 0.0, 1.0]  # 201 x 201 x 1
+    m = pkg.Matcher(ctx, "BF", pkg.spe_cfg(), rng9)
+    beams = [s["range"].size for s in scenes]
+    for k in range(3):
+        ctx.scan_select(k)
+        m.process_scan(0, scenes[k]["init_pose"])
+    n_calls = 24
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    units = calls = 0
+    for it in range(n_calls):
+        k = it % len(scenes)
+        ctx.scan_select(k)
+        m.process_scan(0, scenes[k]["init_pose"])
+        st = m.stats()
+        units += st["scorer_calls"] * beams[k]
+        calls += st["scorer_calls"]
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    m.close()
+    out = {"metric": "pose-candidates*beams/sec, brute-force matcher, 201 x 201 search space per process_scan",
+           "value": units / dt, "unit": "pose-candidates*beams/s", "ms_per_match": 1e3 * dt / n_calls,
+           "poses_per_match": calls / n_calls, "kernels_per_match": st["kernels_launched"],
+           "on_device": st["kernels_launched"] == 4,
+           "roofline": {"bound": "hbm", "achieved": units / dt * bpu / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": units / dt * bpu / 1e9 / HBM_PEAK_GBS, "kernel": "k_score_point", "bytes_per_unit": bpu,
+                        "timing": "whole process_scan calls (pose list + sweep + arg-max + result over PCIe), host clock"}}
+    if ceiling and ceiling.get("achieved"):
+        out["fraction_of_flat_sweep_rate"] = out["roofline"]["achieved"] / ceiling["achieved"]
+    return out
+
+
 def dry_ranks_main(args):
     """One rank of `--dry-ranks N` (see the flag's help).  No GPU is touched: the filter shards are created without a
     context (host-only bookkeeping of the C-ABI: plan_resample / export / import), the scan probabilities are injected,
@@ -1529,6 +1567,7 @@ def main():
 
     world_out = None  # (the world-loop leg, filled in below; emit_line reads it when the line goes out)
     replicas_out = None
+    extra_legs = {}
 
     # devices the ranks really run on (under `--backend gloo` several ranks may share one: that is not N GPUs)
     n_devices = world
@@ -1605,6 +1644,9 @@ def main():
             out["world_loop"] = world_out
         if replicas_out is not None:
             out["replicas"] = replicas_out
+        for k_, v_ in extra_legs.items():
+            if v_ is not None:
+                out[k_] = v_
         print(json.dumps(out))
 
     # The secondary legs run AFTER the headline is complete.  With more than one rank the particle-filter leg joins
@@ -1655,6 +1697,14 @@ def main():
                 world_out["cpu_baseline"] = world_cpu_out
         except pkg.SlamHipError as e:
             world_out = {"error": str(e)}
+
+    bf_out = None
+    if "bf" in args.leg_set and world == 1 and args.workload == "hc" and not args.strict and not args.seq_sum:
+        try:
+            bf_out = bf_leg(args, pkg, ctx, sc, scenes, BYTES_PER_UNIT[bkey], ceiling)
+        except pkg.SlamHipError as e:
+            bf_out = {"error": str(e)}
+    extra_legs["brute_force"] = bf_out
 
     if "replicas" in args.leg_set and world == 1 and args.workload == "hc" and not args.strict and not args.seq_sum:
         try:

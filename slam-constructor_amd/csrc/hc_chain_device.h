@@ -106,6 +106,8 @@ struct HcChainArgs {
   HcResidentCtl *rctl;   // one per chain
   unsigned *h_all_done;  // pinned; a batch's last chain to end stores the epoch here (null: a lone chain)
   int debug_mute;        // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
+  int oope;              // SLAMHIP_OOPE_OBSTACLE (0), or a window OOPE (max / mean / overlap) with its analysis area
+  double area[4];
 };
 
 // threads per workgroup: 256, 512 or 1024; n_chains > 1: the multi-chain form (see HcChainArgs::inits)

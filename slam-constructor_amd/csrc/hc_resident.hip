@@ -103,9 +103,10 @@ __device__ __forceinline__ double gran_score(const u32x4 &g) {
 
 // MODEL: SLAMHIP_CELL_OCC / _TBM (the 1-cell OOPE); SEQ: the reference's beam-order sum; BATCH: grid.y independent
 // matches, each with its own map and scan (HcChainArgs::jobs); G: granules per lane of the sweeping wave, i.e. the
-// grid has at most 64 G workgroups (2, 4 or 7)
+// grid has at most 64 G workgroups (2, 4 or 7); WIN: the window OOPEs (max / mean / overlap, K2's per-beam value) in
+// place of the 1-cell one
 // (four waves per SIMD whatever the workgroup size: 128 VGPRs, so that 4 x 256, 2 x 512 or 1 x 1024 threads share a CU)
-template <int MODEL, int NT, bool SEQ, bool BATCH, int G>
+template <int MODEL, int NT, bool SEQ, bool BATCH, int G, bool WIN = false>
 __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   extern __shared__ double s_term[];  // one term per beam
   __shared__ unsigned long long s_hash[kHcSlots + 7];  // (48 bits each)
@@ -233,33 +234,53 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order, wave
       // butterfly, (g0+g1)+(g2+g3)) -- k_score_point's order; up to four beams per thread at a time, their cell
       // gathers issued together (hc_chain.hip)
-      for (int base = t; base < n; base += 4 * NT) {
-        double4 cell[4];
-        double w_[4], f_[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int b = base + j * NT;
-          w_[j] = 0.0;
-          f_[j] = 0.0;
-          cell[j] = make_double4(0.0, 0.0, 0.0, 0.0);
-          if ((base - lane) + j * NT >= n) continue;  // no lane of this wave has a beam in this slot
-          const int bc_ = b < n ? b : n - 1;
-          double r_ = br, ca = bc, sa = bs;
-          w_[j] = bw;
-          f_[j] = bf;
-          if (j > 0 || base != t) {
-            r_ = scan.range[bc_];
-            ca = scan.cos_a[bc_];
-            sa = scan.sin_a[bc_];
-            w_[j] = scan.weight[bc_];
-            f_[j] = scan.factor[bc_];
+      if (WIN) {
+        // window OOPEs: k_score_window's per-beam value (occupancy_observation_probability.h:29-99), one beam at a
+        // time -- a beam reads a window of cells, not one
+        const double half_v = (a.area[1] - a.area[0]) / 2, half_h = (a.area[3] - a.area[2]) / 2;
+        for (int b = t; b < n; b += NT) {
+          double r_ = br, ca = bc, sa = bs, w = bw, f = bf;
+          if (b != t) {
+            r_ = scan.range[b];
+            ca = scan.cos_a[b];
+            sa = scan.sin_a[b];
+            w = scan.weight[b];
+            f = scan.factor[b];
           }
-          cell[j] = beam_cell<MODEL>(map, px, py, sn, cs, r_, ca, sa);
+          const double c = cs * ca - sn * sa;
+          const double s = sn * ca + cs * sa;
+          const double ox = px + r_ * c, oy = py + r_ * s;
+          s_term[b] = window_probability<MODEL>(map, a.oie, a.oope, half_v, half_h, ox, oy) * w * f;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int b = base + j * NT;
-          if (b < n) s_term[b] = cell_probability<MODEL>(a.oie, cell[j]) * w_[j] * f_[j];
+      } else {
+        for (int base = t; base < n; base += 4 * NT) {
+          double4 cell[4];
+          double w_[4], f_[4];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int b = base + j * NT;
+            w_[j] = 0.0;
+            f_[j] = 0.0;
+            cell[j] = make_double4(0.0, 0.0, 0.0, 0.0);
+            if ((base - lane) + j * NT >= n) continue;  // no lane of this wave has a beam in this slot
+            const int bc_ = b < n ? b : n - 1;
+            double r_ = br, ca = bc, sa = bs;
+            w_[j] = bw;
+            f_[j] = bf;
+            if (j > 0 || base != t) {
+              r_ = scan.range[bc_];
+              ca = scan.cos_a[bc_];
+              sa = scan.sin_a[bc_];
+              w_[j] = scan.weight[bc_];
+              f_[j] = scan.factor[bc_];
+            }
+            cell[j] = beam_cell<MODEL>(map, px, py, sn, cs, r_, ca, sa);
+          }
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int b = base + j * NT;
+            if (b < n) s_term[b] = cell_probability<MODEL>(a.oie, cell[j]) * w_[j] * f_[j];
+          }
         }
       }
       __syncthreads();  // (B)
@@ -603,6 +624,28 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
 // granules per sweeping lane for a grid of `grid` workgroups
 static int gran_per_lane(int grid) { return grid <= 128 ? 2 : (grid <= 256 ? 4 : 7); }
 
+#define HCR_LAUNCH_WIN(NTV)                                                                                      \
+  do {                                                                                                          \
+    if (e0 || e1)                                                                                               \
+      hipExtLaunchKernelGGL((k_hc_chain_resident<MODEL, NTV, false, false, 4, true>), dim3(grid, n_chains), dim3(NTV), shm, stream, e0, e1, 0, a); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_hc_chain_resident<MODEL, NTV, false, false, 4, true>), dim3(grid, n_chains), dim3(NTV), shm, stream, a);     \
+  } while (0)
+
+// the window OOPEs: lone chains of at most 256 workgroups, default sum order
+template <int MODEL>
+static hipError_t launch_res_win(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                                 int n_chains) {
+  const int grid = 6 * a.max_inst + 1;
+  if (grid > 256) return hipErrorInvalidValue;
+  const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
+  if (nt == 1024) HCR_LAUNCH_WIN(1024);
+  else if (nt == 256) HCR_LAUNCH_WIN(256);
+  else HCR_LAUNCH_WIN(512);
+  return hipGetLastError();
+}
+#undef HCR_LAUNCH_WIN
+
 template <int MODEL, bool SEQ, bool BATCH>
 static hipError_t launch_res(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                              int n_chains) {
@@ -631,6 +674,12 @@ static hipError_t launch_res(const HcChainArgs &a, int nt, hipStream_t stream, h
 hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream, hipEvent_t e0,
                                     hipEvent_t e1, int n_chains) {
   if (!a.rctl) return hipErrorInvalidValue;
+  if (a.oope != SLAMHIP_OOPE_OBSTACLE) {
+    if (a.jobs || a.seq) return hipErrorInvalidValue;
+    if (cell_model == SLAMHIP_CELL_OCC) return launch_res_win<SLAMHIP_CELL_OCC>(a, nt, stream, e0, e1, n_chains);
+    if (cell_model == SLAMHIP_CELL_TBM) return launch_res_win<SLAMHIP_CELL_TBM>(a, nt, stream, e0, e1, n_chains);
+    return hipErrorInvalidValue;
+  }
   if (a.jobs) {
     if (a.seq) return hipErrorInvalidValue;
     if (cell_model == SLAMHIP_CELL_OCC) return launch_res<SLAMHIP_CELL_OCC, false, true>(a, nt, stream, e0, e1, n_chains);

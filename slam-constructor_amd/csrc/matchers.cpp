@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 
+#include "bf_device.h"
 #include "hc_chain_device.h"
 #include "hc_shape.h"
 #include "mc_chain_device.h"
@@ -50,6 +51,20 @@ struct slamhip_matcher {
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
   int debug_trace_cap = 0;        // testing (slamhip_matcher_debug_trace_cap): pretend the trace buffer is this small
   struct HcBatch *batch = nullptr;  // slamhip_matcher_process_scan_batch: blocks of the last batch (hc_batch_*)
+  // brute force as one flat sweep + a device arg-max (bf_device.hip)
+  bool is_bf = false;
+  double bf_r[9] = {0};
+  std::vector<double> bf_off;  // x offsets, y offsets, theta offsets as the enumerator accumulates them
+  int bf_nx = 0, bf_ny = 0, bf_nt = 0;
+  double *d_bf_off = nullptr, *d_bf_poses = nullptr, *d_bf_scores = nullptr;
+  unsigned long long *d_bf_fp = nullptr;
+  long long *d_bf_pidx = nullptr, *d_bf_agg_i = nullptr;
+  double *d_bf_agg_s = nullptr;
+  unsigned *d_bf_counters = nullptr;
+  slamhip::BfHostOut *h_bf = nullptr;
+  long long bf_cap = 0;
+  unsigned bf_seq = 0;
+  std::vector<double> bf_scores_host;
   // Monte Carlo kept on the device (mc_chain.h)
   bool is_mc = false;
   slamhip::McChainCtl *d_mc = nullptr;
@@ -109,6 +124,22 @@ int chain_release(slamhip_matcher *m) {
   if (m->h_chain) hipHostFree(m->h_chain);
   if (m->h_trace) hipHostFree(m->h_trace);
   if (m->d_stamps) hipFree(m->d_stamps);
+  if (m->d_bf_off) hipFree(m->d_bf_off);
+  if (m->d_bf_poses) hipFree(m->d_bf_poses);
+  if (m->d_bf_scores) hipFree(m->d_bf_scores);
+  if (m->d_bf_fp) hipFree(m->d_bf_fp);
+  if (m->d_bf_pidx) hipFree(m->d_bf_pidx);
+  if (m->d_bf_agg_i) hipFree(m->d_bf_agg_i);
+  if (m->d_bf_agg_s) hipFree(m->d_bf_agg_s);
+  if (m->d_bf_counters) hipFree(m->d_bf_counters);
+  m->d_bf_pidx = m->d_bf_agg_i = nullptr;
+  m->d_bf_agg_s = nullptr;
+  m->d_bf_counters = nullptr;
+  if (m->h_bf) hipHostFree(m->h_bf);
+  m->d_bf_off = m->d_bf_poses = m->d_bf_scores = nullptr;
+  m->d_bf_fp = nullptr;
+  m->h_bf = nullptr;
+  m->bf_cap = 0;
   if (m->d_mc) hipFree(m->d_mc);
   if (m->d_tape) hipFree(m->d_tape);
   if (m->h_mc) hipHostFree(m->h_mc);
@@ -132,6 +163,10 @@ int chain_release(slamhip_matcher *m) {
 // the chain covers what the shipped single-hypothesis configurations use: hill climbing over the 1-cell
 // OOPE in the default mode; everything else (strict order, host trigonometry, window OOPEs, GMapping,
 // staged copies) keeps the host-driven path
+bool is_window_oope(int oope) {
+  return oope == SLAMHIP_OOPE_MAX || oope == SLAMHIP_OOPE_MEAN || oope == SLAMHIP_OOPE_OVERLAP;
+}
+
 bool tie_check_default(slamhip_matcher *m) {
   if (m->tie_check < 0) m->tie_check = 1;  // (slamhip_matcher_set_tie_check switches it off)
   return m->tie_check == 1;
@@ -140,7 +175,10 @@ bool tie_check_default(slamhip_matcher *m) {
 bool chain_eligible(slamhip_matcher *m) {
   if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
-  if ((m->cfg.oope != SLAMHIP_OOPE_OBSTACLE && !gm) || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  // (the window OOPEs ride the co-resident form only: hc_resident.hip's WIN instantiations, default sum order)
+  const bool win = is_window_oope(m->cfg.oope);
+  if (win && (m->cfg.sum_order != SLAMHIP_SUM_TREE256 || m->chain_mode == 1)) return false;
+  if ((m->cfg.oope != SLAMHIP_OOPE_OBSTACLE && !gm && !win) || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
   // the GMapping OOPE rides K3's one-pose body: 3x3 window, up to 1280 beams, canonical sum
   if (gm && (m->cfg.gm_window != 1 || m->cfg.sum_order != SLAMHIP_SUM_TREE256 || m->ctx->scan_n > 1280)) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;
@@ -153,7 +191,8 @@ bool chain_eligible(slamhip_matcher *m) {
 // Can this match run as ONE launch of co-resident workgroups?  The 1-cell OOPE only (the GMapping OOPE's super-steps
 // hand side outputs of every pose to the replay: kernel chain), and the grid must fit the device at once.
 bool resident_wanted(slamhip_matcher *m) {
-  return m->chain_mode == 2 && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE && m->resident_gave_up_row < 3;
+  return m->chain_mode == 2 && (m->cfg.oope == SLAMHIP_OOPE_OBSTACLE || is_window_oope(m->cfg.oope)) &&
+         m->resident_gave_up_row < 3;
 }
 int resident_capacity(slamhip_matcher *m, int cell_model, int nt, bool batch, size_t lds, int *wgs) {
   const int idx = nt == 1024 ? 2 : (nt == 512 ? 1 : 0);
@@ -209,6 +248,9 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
                                 hipHostMallocMapped | hipHostMallocCoherent));
   }
   a.oie = m->cfg.oie;
+  a.oope = is_window_oope(m->cfg.oope) ? m->cfg.oope : SLAMHIP_OOPE_OBSTACLE;
+  for (int k = 0; k < 4; ++k) a.area[k] = m->cfg.area[k];
+  if (is_window_oope(m->cfg.oope) && !resident) return kChainNeedsHost;  // (no kernel-chain form: host-driven batches)
   a.max_inst = m->chain_max_inst;
   a.gm.fullness_th = m->cfg.gm_fullness_th;
   a.gm.window = m->cfg.gm_window;
@@ -957,6 +999,199 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
 
 namespace {
 
+// ---- brute force on the device (bf_device.hip) -----------------------------------------------------
+// One flat sweep over the enumerator's whole pose list + a device arg-max with the reference's first-wins rule
+// (brute_force_scan_matcher.h:10-81, pose_enumeration_scan_matcher.h:48-69).  Covers the point and window OOPEs in
+// the default sum order with device pose trigonometry; everything else, and a sweep whose walk meets a comparison
+// the tree sums cannot settle, takes the host-driven batches.
+bool bf_device_eligible(slamhip_matcher *m) {
+  if (!m->is_bf || m->cfg.oope == SLAMHIP_OOPE_GMAPPING || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
+  if (m->cfg.sum_order != SLAMHIP_SUM_TREE256 || !m->ctx->low_latency || m->ctx->stage_poses) return false;
+  if (m->chain_mode < 0) m->chain_mode = kChainDefaultMode;
+  return m->chain_mode >= 1;  // (slamhip_matcher_set_device_chain(0) keeps the host-driven batches)
+}
+
+int bf_device_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3], double out_delta[3],
+                           double *out_prob) {
+  slamhip_ctx *ctx = m->ctx;
+  if (m->bf_off.empty()) {
+    // the enumerator's offsets, made by ITS additions (feedback(): x fastest, then y, then theta; each axis
+    // accumulates `+= step` from `from` while the value is still below `to`; theta while t <= to)
+    const double *r = m->bf_r;
+    std::vector<double> xs, ys, ts;
+    for (double x = r[0];; x += r[2]) {
+      xs.push_back(x);
+      if (!(x < r[1]) || xs.size() > (1u << 22)) break;
+    }
+    for (double y = r[3];; y += r[5]) {
+      ys.push_back(y);
+      if (!(y < r[4]) || ys.size() > (1u << 22)) break;
+    }
+    for (double t = r[6]; t <= r[7] && ts.size() <= (1u << 22); t += r[8]) ts.push_back(t);
+    if (xs.size() > (1u << 22) || ys.size() > (1u << 22) || ts.size() > (1u << 22)) return kChainNeedsHost;
+    m->bf_nx = (int)xs.size();
+    m->bf_ny = (int)ys.size();
+    m->bf_nt = (int)ts.size();
+    m->bf_off = xs;
+    m->bf_off.insert(m->bf_off.end(), ys.begin(), ys.end());
+    m->bf_off.insert(m->bf_off.end(), ts.begin(), ts.end());
+    if (m->bf_off.empty()) m->bf_off.push_back(0.0);
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_off, sizeof(double) * m->bf_off.size()));
+    SLAMHIP_CHECK(hipMemcpyAsync(m->d_bf_off, m->bf_off.data(), sizeof(double) * m->bf_off.size(), hipMemcpyHostToDevice,
+                                 ctx->stream));
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SLAMHIP_CHECK(hipHostMalloc(&m->h_bf, sizeof(BfHostOut), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(m->h_bf, 0, sizeof(BfHostOut));
+  }
+  const long long n = 1 + (long long)m->bf_nx * m->bf_ny * m->bf_nt;
+  if (n > (1ll << 26)) return kChainNeedsHost;
+  if (n > m->bf_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (m->d_bf_poses) hipFree(m->d_bf_poses);
+    if (m->d_bf_scores) hipFree(m->d_bf_scores);
+    if (m->d_bf_fp) hipFree(m->d_bf_fp);
+    if (m->d_bf_pidx) hipFree(m->d_bf_pidx);
+    if (m->d_bf_agg_i) hipFree(m->d_bf_agg_i);
+    if (m->d_bf_agg_s) hipFree(m->d_bf_agg_s);
+    m->d_bf_poses = m->d_bf_scores = m->d_bf_agg_s = nullptr;
+    m->d_bf_fp = nullptr;
+    m->d_bf_pidx = m->d_bf_agg_i = nullptr;
+    m->bf_cap = 0;
+    const long long blocks = (n + 1023) / 1024;
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_poses, sizeof(double) * 3 * n));
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_scores, sizeof(double) * n));
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_fp, sizeof(unsigned long long) * n));
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_pidx, sizeof(long long) * n));
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_agg_s, sizeof(double) * blocks));
+    SLAMHIP_CHECK(hipMalloc(&m->d_bf_agg_i, sizeof(long long) * blocks));
+    if (!m->d_bf_counters) {
+      SLAMHIP_CHECK(hipMalloc(&m->d_bf_counters, sizeof(unsigned) * 4));
+      SLAMHIP_CHECK(hipMemsetAsync(m->d_bf_counters, 0, sizeof(unsigned) * 4, ctx->stream));
+    }
+    m->bf_cap = n;
+  }
+  ScoreArgs a;
+  std::memset(&a, 0, sizeof(a));
+  int cell_model = 0;
+  int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
+  if (rc) return rc;
+  (void)tie_check_default(m);
+  const bool verify = m->tie_check == 1 && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE;
+  const double t0 = MatchJob::now_us();
+  // (the enumerator object stays the one source of the latched base pose: a match that falls back to the host-driven
+  // batches enumerates around the same pose)
+  const Pose base = static_cast<BruteForcePoseEnumerator *>(m->pe.get())->latch_base(Pose{init_pose[0], init_pose[1], init_pose[2]});
+  const double base3[3] = {base.x, base.y, base.theta};
+  BfPoseArgs pa;
+  for (int k = 0; k < 3; ++k) {
+    pa.init[k] = init_pose[k];
+    pa.base[k] = base3[k];
+  }
+  pa.off = m->d_bf_off;
+  pa.nx = m->bf_nx;
+  pa.ny = m->bf_ny;
+  pa.nt = m->bf_nt;
+  pa.n = n;
+  pa.poses = m->d_bf_poses;
+  SLAMHIP_CHECK(launch_bf_poses(pa, ctx->stream));
+  a.poses = m->d_bf_poses;
+  a.scores = m->d_bf_scores;
+  a.n_poses = (int)n;
+  a.oie = m->cfg.oie;
+  for (int k = 0; k < 4; ++k) a.area[k] = m->cfg.area[k];
+  a.gm.fullness_th = m->cfg.gm_fullness_th;
+  a.gm.window = m->cfg.gm_window;
+  a.fprints = verify ? m->d_bf_fp : nullptr;
+  hipEvent_t e0, e1;
+  rc = profile_event_pair(ctx, &e0, &e1);
+  if (rc) return rc;
+  SLAMHIP_CHECK(launch_score(a, cell_model, m->cfg.oope, m->cfg.sum_order, ctx->stream, e0, e1));
+  unsigned seq = ++m->bf_seq;
+  if (seq == 0) seq = ++m->bf_seq;
+  BfArgmaxArgs ga;
+  ga.scores = m->d_bf_scores;
+  ga.fprints = verify ? m->d_bf_fp : nullptr;
+  ga.n = n;
+  ga.verify = verify ? 1 : 0;
+  ga.out = m->h_bf;
+  ga.seq = seq;
+  ga.pidx = m->d_bf_pidx;
+  ga.agg_s = m->d_bf_agg_s;
+  ga.agg_i = m->d_bf_agg_i;
+  ga.counters = m->d_bf_counters;
+  if (n < 2) return kChainNeedsHost;  // (no candidate at all: nothing for the sweep to do)
+  SLAMHIP_CHECK(launch_bf_argmax(ga, ctx->stream));
+  if (m->has_obs) {
+    m->bf_scores_host.resize((size_t)n);
+    SLAMHIP_CHECK(hipMemcpyAsync(m->bf_scores_host.data(), m->d_bf_scores, sizeof(double) * n, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+  }
+  volatile BfHostOut *h = m->h_bf;
+  unsigned long long spins = 0;
+  while (h->seq != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffffull) == 0) {
+      hipError_t qe = hipStreamQuery(ctx->stream);
+      if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "brute-force sweep");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (m->has_obs) SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    ctx->prof_launches += 1;
+    ctx->prof_units += n * (long long)a.scan.n;
+  }
+  if (h->ambiguous) return kChainNeedsHost;  // nothing reported yet: the host-driven batches settle it
+  auto pose_of = [&](long long i, double p3[3]) {
+    p3[0] = init_pose[0];
+    p3[1] = init_pose[1];
+    p3[2] = init_pose[2];
+    if (i > 0) {
+      const long long j = i - 1;
+      const int ix = (int)(j % m->bf_nx);
+      const long long r = j / m->bf_nx;
+      const int iy = (int)(r % m->bf_ny), it = (int)(r / m->bf_ny);
+      p3[0] = base3[0] + m->bf_off[ix];
+      p3[1] = base3[1] + m->bf_off[m->bf_nx + iy];
+      p3[2] = base3[2] + m->bf_off[m->bf_nx + m->bf_ny + it];
+    }
+  };
+  double best[3];
+  pose_of(h->best_index, best);
+  for (int k = 0; k < 3; ++k) out_delta[k] = best[k] - init_pose[k];
+  *out_prob = h->best_score;
+  MatchJob &job = m->job;
+  job.scorer_calls = n;
+  job.poses_evaluated = n;
+  job.launches = 1;
+  job.t_build_us = job.t_replay_us = 0;
+  m->chain_launched = 4;  // poses, sweep, scan, decide
+  m->chain_rescored = 0;
+  m->t_stage_us = 0;
+  m->t_score_us = MatchJob::now_us() - t0;
+  if (m->has_obs) {
+    // the observer's events in the reference's order, from the score array (:43-46, :53-60)
+    const double t1 = MatchJob::now_us();
+    const double *sc = m->bf_scores_host.data();
+    double b = sc[0];
+    double p3[3];
+    pose_of(0, p3);
+    if (m->obs.on_scan_test) m->obs.on_scan_test(m->obs.user, p3, sc[0]);
+    if (m->obs.on_pose_update) m->obs.on_pose_update(m->obs.user, p3, sc[0]);
+    for (long long i = 1; i < n; ++i) {
+      pose_of(i, p3);
+      if (m->obs.on_scan_test) m->obs.on_scan_test(m->obs.user, p3, sc[i]);
+      if (b < sc[i]) {
+        b = sc[i];
+        if (m->obs.on_pose_update) m->obs.on_pose_update(m->obs.user, p3, sc[i]);
+      }
+    }
+    job.t_replay_us = MatchJob::now_us() - t1;
+    if (m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, out_delta, *out_prob);
+  }
+  return SLAMHIP_OK;
+}
+
 // ---- Monte Carlo on the device (mc_chain.hip) -------------------------------------------------------
 // the 1-cell OOPE with device pose trigonometry on the zero-copy path, like the hill-climbing chain
 bool mc_chain_eligible(slamhip_matcher *m) {
@@ -1189,12 +1424,16 @@ int slamhip_matcher_create_bf(slamhip_ctx *ctx, const slamhip_spe_cfg *cfg, cons
   if (!(range9[0] <= range9[1] && range9[3] <= range9[4] && range9[6] <= range9[7]) ||
       !(range9[2] > 0 && range9[5] > 0 && range9[8] > 0))
     return invalid_arg("brute-force ranges need from <= to and positive steps");
-  return make_matcher(ctx, cfg, std::make_unique<BruteForcePoseEnumerator>(range9), 8192, out);
+  const int rc = make_matcher(ctx, cfg, std::make_unique<BruteForcePoseEnumerator>(range9), 8192, out);
+  if (rc) return rc;
+  (*out)->is_bf = true;
+  std::memcpy((*out)->bf_r, range9, sizeof((*out)->bf_r));
+  return SLAMHIP_OK;
 }
 
 int slamhip_matcher_destroy(slamhip_matcher *m) {
   if (m) {
-    if (m->d_chain || m->batch) {
+    if (m->d_chain || m->batch || m->d_bf_poses) {
       // run-ahead kernels of the last chain may still read the blocks; the context may already be gone
       // (destroying it synchronised its stream), so wait on the device, not on the context's stream
       hipSetDevice(m->device);
@@ -1403,6 +1642,10 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   }
   if (mc_chain_eligible(m)) {
     const int crc = mc_chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
+    if (crc != kChainNeedsHost) return crc;
+  }
+  if (bf_device_eligible(m)) {
+    const int crc = bf_device_process_scan(m, map_id, init_pose, out_delta, out_prob);
     if (crc != kChainNeedsHost) return crc;
   }
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;

@@ -417,6 +417,15 @@ public:
   }
   bool accept_changes_future() const override { return false; }
   void assign(const PoseEnumerator &o) override { *this = static_cast<const BruteForcePoseEnumerator &>(o); }
+  // the base pose, latched by the first next() of the enumerator's life and never cleared (the reference's reset()
+  // leaves _base_pose_is_set alone, brute_force_scan_matcher.h:27-40): later matches enumerate around it
+  const Pose &latch_base(const Pose &first_prev) {
+    if (!base_set_) {
+      base_ = first_prev;
+      base_set_ = true;
+    }
+    return base_;
+  }
 
 private:
   double r_[9];

@@ -156,6 +156,92 @@ __device__ __forceinline__ double4 beam_cell(const MapView &m, double x, double 
   const double wy = y + r * s;
   return load_cell<MODEL>(m, to_cell(wx, m.scale, m.inv_scale), to_cell(wy, m.scale, m.inv_scale));
 }
+// ---- K2: window OOPEs (max / mean / overlap) ------------------------------------------------------
+// MaxOccupancyObservationPE / MeanOccupancyObservationPE / OverlapWeightedOccupancyObservationPE
+// (src/core/scan_matchers/occupancy_observation_probability.h:29-99) over GridRasterizedRectangle
+// (src/core/maps/grid_rasterization.h:26-64: x outer, y inner) and LightWeightRectangle::overlap /
+// intersect_internal (src/core/geometry_primitives.h:205-310) with the reference's fuzzy
+// comparisons (src/core/math_utils.h:15-25,37-51).  Sums run in the reference's cell order, so
+// per-beam values are bit-identical to the CPU path.
+struct Lwr {
+  double bot, top, left, right;
+};
+__device__ __forceinline__ bool fz_equal(double a, double b) {
+  const double m = fmax(fabs(a), fabs(b));
+  return fabs(a - b) <= 1e-7 * fmax(1.0, m);
+}
+__device__ __forceinline__ bool fz_less(double a, double b) { return a < b + 2.220446049250313e-16; }
+__device__ __forceinline__ bool fz_le(double a, double b) { return fz_equal(a, b) || fz_less(a, b); }
+__device__ __forceinline__ bool fz_ordered(double a, double b, double c) { return fz_le(a, b) && fz_le(b, c); }
+__device__ __forceinline__ double lwr_area(const Lwr &r) { return (r.top - r.bot) * (r.right - r.left); }
+__device__ __forceinline__ bool lwr_contains(const Lwr &r, double x, double y) {
+  return fz_ordered(r.left, x, r.right) && fz_ordered(r.bot, y, r.top);
+}
+__device__ inline Lwr lwr_intersect(const Lwr &self, const Lwr &that, bool reversed) {
+  unsigned nm = 0;
+  double cl = self.left, cr = self.right, ct = self.top, cb = self.bot;
+  if (lwr_contains(self, that.left, that.bot)) { ++nm; cl = that.left; cb = that.bot; }
+  if (lwr_contains(self, that.right, that.bot)) { ++nm; cr = that.right; cb = that.bot; }
+  if (lwr_contains(self, that.left, that.top)) { ++nm; cl = that.left; ct = that.top; }
+  if (lwr_contains(self, that.right, that.top)) { ++nm; cr = that.right; ct = that.top; }
+  if (nm == 0) {
+    if (reversed) return Lwr{0, 0, 0, 0};
+    return lwr_intersect(that, self, true);
+  }
+  return Lwr{cb, ct, cl, cr};
+}
+__device__ inline double lwr_overlap(const Lwr &self, const Lwr &that) {
+  if (lwr_area(self) != 0) return lwr_area(lwr_intersect(self, that, false)) / lwr_area(self);
+  if (lwr_area(that) != 0) return lwr_contains(that, self.left, self.bot) ? 1.0 : 0.0;
+  return (fz_equal(self.top, that.top) && fz_equal(self.bot, that.bot) && fz_equal(self.left, that.left) &&
+          fz_equal(self.right, that.right)) ? 1.0 : 0.0;
+}
+
+// per-beam value of the window OOPEs at the beam's end point (ox, oy); half_v / half_h: half the analysis area's
+// extent (sp_analysis_area, grid_scan_matcher.h:87-91)
+template <int MODEL>
+__device__ __forceinline__ double window_probability(const MapView &map, int oie, int oope, double half_v, double half_h,
+                                                     double ox, double oy) {
+  const double scale = map.scale, inv_scale = map.inv_scale;
+  const Lwr area{oy - half_v, oy + half_v, ox - half_h, ox + half_h};
+  const double ar = lwr_area(area);
+  int lbx, lby, rtx, rty;
+  if (ar != 0 && ar != __builtin_inf()) {
+    lbx = to_cell(area.left, scale, inv_scale);
+    lby = to_cell(area.bot, scale, inv_scale);
+    rtx = to_cell(area.right, scale, inv_scale);
+    rty = to_cell(area.top, scale, inv_scale);
+  } else if (ar == 0) {
+    lbx = rtx = to_cell(area.left, scale, inv_scale);
+    lby = rty = to_cell(area.bot, scale, inv_scale);
+  } else {
+    lbx = -map.origin_x;
+    lby = -map.origin_y;
+    rtx = map.width - 1 - map.origin_x;
+    rty = map.height - 1 - map.origin_y;
+  }
+  double tot_p = 0, tot_w = 0, mx = 0;
+  unsigned cnt = 0;
+  for (int cx = lbx; cx <= rtx; ++cx)
+    for (int cy = lby; cy <= rty; ++cy) {
+      const double impact = point_probability<MODEL>(map, oie, cx, cy);
+      if (oope == SLAMHIP_OOPE_MAX) {
+        mx = impact < mx ? mx : impact;
+      } else if (oope == SLAMHIP_OOPE_MEAN) {
+        tot_p += impact;
+        cnt += 1;
+      } else {
+        const Lwr cb{scale * cy, scale * (cy + 1), scale * cx, scale * (cx + 1)};
+        const double w = lwr_overlap(area, cb);
+        tot_p += impact * w;
+        tot_w += w;
+      }
+    }
+  if (oope == SLAMHIP_OOPE_MAX) return mx;
+  if (oope == SLAMHIP_OOPE_MEAN) return cnt ? tot_p / cnt : 0.5;
+  return tot_w != 0 ? tot_p / tot_w : 0.5;
+}
+
 template <int MODEL>
 __device__ __forceinline__ double beam_term(const MapView &m, int oie, double x, double y, double sn, double cs,
                                             double r, double ca, double sa, double w, double f) {

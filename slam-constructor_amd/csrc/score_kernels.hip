@@ -442,47 +442,7 @@ __global__ __launch_bounds__(NT) void k_score_gmapping_wide(ScoreArgs a) {
   if (t == 0) a.scores[p] = score;
 }
 
-// ---- K2: window OOPEs (max / mean / overlap) ------------------------------------------------------
-// MaxOccupancyObservationPE / MeanOccupancyObservationPE / OverlapWeightedOccupancyObservationPE
-// (src/core/scan_matchers/occupancy_observation_probability.h:29-99) over GridRasterizedRectangle
-// (src/core/maps/grid_rasterization.h:26-64: x outer, y inner) and LightWeightRectangle::overlap /
-// intersect_internal (src/core/geometry_primitives.h:205-310) with the reference's fuzzy
-// comparisons (src/core/math_utils.h:15-25,37-51).  Sums run in the reference's cell order, so
-// per-beam values are bit-identical to the CPU path.
-struct Lwr {
-  double bot, top, left, right;
-};
-__device__ __forceinline__ bool fz_equal(double a, double b) {
-  const double m = fmax(fabs(a), fabs(b));
-  return fabs(a - b) <= 1e-7 * fmax(1.0, m);
-}
-__device__ __forceinline__ bool fz_less(double a, double b) { return a < b + 2.220446049250313e-16; }
-__device__ __forceinline__ bool fz_le(double a, double b) { return fz_equal(a, b) || fz_less(a, b); }
-__device__ __forceinline__ bool fz_ordered(double a, double b, double c) { return fz_le(a, b) && fz_le(b, c); }
-__device__ __forceinline__ double lwr_area(const Lwr &r) { return (r.top - r.bot) * (r.right - r.left); }
-__device__ __forceinline__ bool lwr_contains(const Lwr &r, double x, double y) {
-  return fz_ordered(r.left, x, r.right) && fz_ordered(r.bot, y, r.top);
-}
-__device__ Lwr lwr_intersect(const Lwr &self, const Lwr &that, bool reversed) {
-  unsigned nm = 0;
-  double cl = self.left, cr = self.right, ct = self.top, cb = self.bot;
-  if (lwr_contains(self, that.left, that.bot)) { ++nm; cl = that.left; cb = that.bot; }
-  if (lwr_contains(self, that.right, that.bot)) { ++nm; cr = that.right; cb = that.bot; }
-  if (lwr_contains(self, that.left, that.top)) { ++nm; cl = that.left; ct = that.top; }
-  if (lwr_contains(self, that.right, that.top)) { ++nm; cr = that.right; ct = that.top; }
-  if (nm == 0) {
-    if (reversed) return Lwr{0, 0, 0, 0};
-    return lwr_intersect(that, self, true);
-  }
-  return Lwr{cb, ct, cl, cr};
-}
-__device__ double lwr_overlap(const Lwr &self, const Lwr &that) {
-  if (lwr_area(self) != 0) return lwr_area(lwr_intersect(self, that, false)) / lwr_area(self);
-  if (lwr_area(that) != 0) return lwr_contains(that, self.left, self.bot) ? 1.0 : 0.0;
-  return (fz_equal(self.top, that.top) && fz_equal(self.bot, that.bot) && fz_equal(self.left, that.left) &&
-          fz_equal(self.right, that.right)) ? 1.0 : 0.0;
-}
-
+// (the window OOPEs' per-beam value: window_probability, score_device.h -- shared with the co-resident chain)
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) {
   __shared__ double s_pose[kMaxPosesPerBlock][4];
@@ -507,7 +467,6 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
     s_pose[t][3] = cs;
   }
   __syncthreads();
-  const double scale = a.map.scale, inv_scale = a.map.inv_scale;
   const double half_v = (a.area[1] - a.area[0]) / 2, half_h = (a.area[3] - a.area[2]) / 2;
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
@@ -517,44 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
       const double c = cs * ca - sn * sa;
       const double s = sn * ca + cs * sa;
       const double ox = x + r * c, oy = y + r * s;
-      const Lwr area{oy - half_v, oy + half_v, ox - half_h, ox + half_h};
-      const double ar = lwr_area(area);
-      int lbx, lby, rtx, rty;
-      if (ar != 0 && ar != __builtin_inf()) {
-        lbx = to_cell(area.left, scale, inv_scale);
-        lby = to_cell(area.bot, scale, inv_scale);
-        rtx = to_cell(area.right, scale, inv_scale);
-        rty = to_cell(area.top, scale, inv_scale);
-      } else if (ar == 0) {
-        lbx = rtx = to_cell(area.left, scale, inv_scale);
-        lby = rty = to_cell(area.bot, scale, inv_scale);
-      } else {
-        lbx = -a.map.origin_x;
-        lby = -a.map.origin_y;
-        rtx = a.map.width - 1 - a.map.origin_x;
-        rty = a.map.height - 1 - a.map.origin_y;
-      }
-      double tot_p = 0, tot_w = 0, mx = 0;
-      unsigned cnt = 0;
-      for (int cx = lbx; cx <= rtx; ++cx)
-        for (int cy = lby; cy <= rty; ++cy) {
-          const double impact = point_probability<MODEL>(a.map, a.oie, cx, cy);
-          if (oope == SLAMHIP_OOPE_MAX) {
-            mx = impact < mx ? mx : impact;
-          } else if (oope == SLAMHIP_OOPE_MEAN) {
-            tot_p += impact;
-            cnt += 1;
-          } else {
-            const Lwr cb{scale * cy, scale * (cy + 1), scale * cx, scale * (cx + 1)};
-            const double w = lwr_overlap(area, cb);
-            tot_p += impact * w;
-            tot_w += w;
-          }
-        }
-      double pr;
-      if (oope == SLAMHIP_OOPE_MAX) pr = mx;
-      else if (oope == SLAMHIP_OOPE_MEAN) pr = cnt ? tot_p / cnt : 0.5;
-      else pr = tot_w != 0 ? tot_p / tot_w : 0.5;
+      const double pr = window_probability<MODEL>(a.map, a.oie, oope, half_v, half_h, ox, oy);
       const double term = pr * a.scan.weight[b] * a.scan.factor[b];
       if (a.terms) a.terms[(size_t)(p0 + j) * n + b] = term;
       acc = acc + term;

@@ -321,3 +321,29 @@ def test_resident_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx):
     dev.set_device_chain(2)
     assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), want)
     assert dev.resident_stats() == dict(matches=5, gave_up=3) and dev.stats()["kernels_launched"] == 1
+
+
+@pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
+@pytest.mark.parametrize("oope", ["max", "mean", "overlap"])
+def test_window_oopes_on_the_resident_chain_equal_the_host_driven_matcher(pkg, ctx, cell, weighting, oope):
+    """VERDICT r3 item 6 (second half): the window OOPEs -- Max / Mean / OverlapWeighted
+    (occupancy_observation_probability.h:29-99) -- used to take the host-driven batches with a PCIe round trip each;
+    now hill climbing over them runs as the co-resident launch too (K2's per-beam value inside hc_resident.hip).
+    Trace, result and scorer calls equal the host-driven matcher's bit for bit, over consecutive matches."""
+    sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=5, weighting=weighting)
+    upload(pkg, ctx, sc)
+    kinds = dict(max=pkg.OOPE_MAX, mean=pkg.OOPE_MEAN, overlap=pkg.OOPE_OVERLAP)
+    cfg = pkg.spe_cfg(oope=kinds[oope], area=(-0.06, 0.06, -0.04, 0.04))
+    for prm in ([6, 0.1, 0.1], [40, 0.1, 0.1]):
+        dev = pkg.Matcher(ctx, "HC", cfg, prm)
+        host = pkg.Matcher(ctx, "HC", cfg, prm)
+        host.set_device_chain(0)
+        init = sc["init_pose"]
+        for rep in range(3):
+            td = dev.process_scan(0, init, trace=True)
+            th = host.process_scan(0, init, trace=True)
+            assert_trace_equal(td, th)
+            assert dev.stats()["scorer_calls"] == host.stats()["scorer_calls"] == td["n_calls"]
+            init = init + np.array([0.013, -0.007, 0.004])
+        assert dev.resident_stats() == dict(matches=3, gave_up=0) and dev.stats()["kernels_launched"] == 1
+        assert host.stats()["kernels_launched"] == 0

@@ -669,3 +669,54 @@ def test_cfg5_batch_of_500_particles_by_its_properties(pkg):
     assert len({v[1] for v in fast.values()}) == len(sample)  # different poses, different maps
     tries = np.array([v[2] for v in fast.values()])
     assert abs(tries.mean() * n - total_fast) < 0.02 * total_fast
+
+
+def test_cfg5_batch_of_500_direct_oracle_replay_of_sampled_particles(pkg, oracle):
+    """the 500-particle check above is transitive (500-batch = 6-batch = oracle).  With per-particle
+    maps a particle's map depends on its OWN pose history only (gmapping_world.h:93-97), so the oracle can replay a
+    sample of the 500 directly: three batched K6 appends of all 500 particles at cfg5's geometry (8000 x 8000 cells of
+    0.025 m through tile tables, area estimator, blur 0.1 m) while the oracle appends the same three scans to eight
+    sampled particles' dense maps from the same poses -- counters bit for bit, running means to 1e-10, update counts
+    equal (area_occupancy_estimator.h:27-240, grid_map_scan_adders.h:54-75,138-172, gmapping_grid_cell.h:20-33)."""
+    import pyoracle as po
+    from pyoracle_mapupdate import (gmapping_enable_particle_maps, gmapping_particle_map, gmapping_particle_map_append)
+    from synth import make_scene
+    n, win, scale, size = 500, 1280, 0.025, 8000
+    sc = make_scene(cell_model=2, size=win, scale=scale, n_beams=1080, seed=9, blur_m=0.1, max_dist=12.0)
+    m, scan = sc["map"], sc["scan"]
+    off = (size - win) // 2
+    shift = 0.01 * scale
+    sample = [0, 7, 131, 250, 251, 377, 498, 499]
+    rs = np.random.RandomState(23)
+    hist = [sc["true_pose"] + rs.randn(n, 3) * [0.05, 0.05, 0.01]]
+    for _ in range(2):
+        hist.append(hist[-1] + rs.randn(n, 3) * [0.03, 0.03, 0.008])
+    ctx = pkg.Context(0)
+    ctx.map_bind(2, 2, size, size, (m.origin[0] + off, m.origin[1] + off), scale, m.unknown)
+    ctx.map_upload_window(2, off, off, m.payload)
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(), n, np.arange(n, dtype=np.uint32))
+    ext = (size + 127) // 128 + 1
+    reach = int(np.ceil(2.0 * (float(scan.range.max()) + 1.0) / scale / 128.0)) + 2
+    pf.enable_particle_maps(2, extent_tiles=ext, pool_tiles=ext * ext + n * reach * reach, blur=0.1, estimator=1,
+                            shift_amount=shift)
+    # the oracle's filter holds only the sampled particles, each on its own dense copy of the window
+    k = len(sample)
+    opf = oracle.gmapping_create(k, [0.0] * 8, np.arange(k, dtype=np.uint32))
+    gmapping_enable_particle_maps(oracle, opf, m, np.zeros((win, win, 2)), blur=0.1, est_kind=1, shift_amount=shift)
+    tr = _device_trig_scan(pkg, po, scan.range, scan.angle)
+    for step, poses in enumerate(hist):
+        total = pf.particle_maps_append(np.arange(n), poses, scan.range, scan.angle)
+        assert total > n * 1080 * 100
+        want_updates = sum(gmapping_particle_map_append(oracle, opf, m, j, poses[i], scan.range, tr.angle, None, trig=tr)
+                           for j, i in enumerate(sample))
+        # (the batch reports one number for all 500; the sample's share is checked through the try counters below)
+        assert want_updates > k * 1080 * 100
+    ox, oy = m.origin
+    for j, i in enumerate(sample):
+        got_p, got_a = pf.particle_map(i, -ox, -oy, win, win)
+        want_p, want_a = gmapping_particle_map(oracle, opf, j)
+        np.testing.assert_array_equal(got_a, want_a, err_msg="particle %d: hit / try counters after three scans" % i)
+        np.testing.assert_allclose(got_p, want_p, rtol=1e-10, atol=1e-13, err_msg="particle %d" % i)
+        assert got_a[..., 1].sum() > 3 * 1080 * 100
+    pf.close()
+    ctx.close()

@@ -177,3 +177,38 @@ def test_hip_search_space_map(pkg, scene, strict):
     assert mine[:hdr].tobytes() == ref[:hdr].tobytes()
     diff = np.abs(mine[hdr:].astype(np.int32) - ref[hdr:].astype(np.int32))
     assert diff.max() <= 1 and np.count_nonzero(diff) <= 20, (diff.max(), np.count_nonzero(diff))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell,oope", [(0, "obstacle"), (1, "obstacle"), (0, "max"), (0, "mean")])
+def test_bf_device_sweep_equals_the_host_driven_batches(pkg, cell, oope):
+    """the brute-force matcher as ONE flat sweep + a device arg-max (csrc/bf_device.hip) against
+    the host-driven speculative batches (slamhip_matcher_set_device_chain(0)): observer trace -- every pose, every
+    score, every acceptance in the reference's first-wins order (brute_force_scan_matcher.h:10-81,
+    pose_enumeration_scan_matcher.h:48-69) --, result and scorer-call count bit for bit, with and without an
+    observer; four kernels per match (poses, sweep, the arg-max's scan and decide)."""
+    from helpers import assert_trace_equal
+    from synth import make_scene
+    sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=11, weighting="viny" if cell else "even")
+    ctx = pkg.Context(0)
+    ctx.upload_map(0, sc["map"])
+    c, s = pkg.beam_trig(sc["scan"].angle)
+    ctx.scan_upload(sc["scan"].range, c, s, sc["scan"].weight, sc["scan"].factor)
+    kinds = dict(obstacle=pkg.OOPE_OBSTACLE, max=pkg.OOPE_MAX, mean=pkg.OOPE_MEAN)
+    cfg = pkg.spe_cfg(oope=kinds[oope], area=(-0.05, 0.05, -0.05, 0.05)) if oope != "obstacle" else pkg.spe_cfg()
+    rng9 = [-0.3, 0.3, 0.04, -0.2, 0.2, 0.05, -0.1, 0.1, 0.03]  # 16 x 9 x 7 poses + the initial one
+    dev = pkg.Matcher(ctx, "BF", cfg, rng9)
+    host = pkg.Matcher(ctx, "BF", cfg, rng9)
+    host.set_device_chain(0)
+    init = sc["init_pose"]
+    for rep in range(2):
+        td = dev.process_scan(0, init, trace=True)
+        th = host.process_scan(0, init, trace=True)
+        assert_trace_equal(td, th)
+        assert td["n_calls"] == 16 * 9 * 7 + 1 and td["accepted"].sum() >= 2
+        sd = dev.stats()
+        assert sd["scorer_calls"] == td["n_calls"] and sd["kernels_launched"] == 4 and sd["launches"] == 1
+        q = dev.process_scan(0, init)
+        assert q["prob"] == td["prob"] and np.array_equal(q["delta"], td["delta"])
+        init = init + np.array([0.011, -0.006, 0.004])
+    ctx.close()
