@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--chain-mode", type=int, default=-1, choices=[-1, 1, 2],
                     help="device chain of the hill-climbing headline: 1 = a kernel per super-step (csrc/hc_chain.hip), "
                          "2 = one co-resident launch per match (csrc/hc_resident.hip); -1 = the library's default (2)")
+    ap.add_argument("--resident-chains", type=int, default=-1, choices=[-1, 0, 1],
+                    help="the filter legs' per-particle chains: 1 = one co-resident launch per step where it fits "
+                         "(csrc/hc_resident_gm.hip), 0 = a kernel per super-step (csrc/hc_chain.hip); -1 = the library's default (1)")
     ap.add_argument("--resident-scan", action="store_true",
                     help="headline step = scan_select + process_scan on filtered scans already in HBM (the r01-r03 "
                          "form) instead of the raw scan in (filter + weights + trig + upload inside the step)")
@@ -1376,6 +1379,8 @@ def main():
     import __graft_entry__ as ge
     pkg = ge.load_package()
     ctx = pkg.Context(local_rank)
+    if args.resident_chains >= 0:
+        ctx.set_option(pkg.OPT_RESIDENT_CHAINS, args.resident_chains)
     ctx.upload_map(0, sc["map"])
     cos_a, sin_a = pkg.beam_trig(scan.angle)
     ctx.scan_upload(scan.range, cos_a, sin_a, scan.weight, scan.factor)

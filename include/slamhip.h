@@ -101,6 +101,9 @@ enum {
                                   * else counting sort, else radix sort), 1 counting sort, 2 radix sort */
   SLAMHIP_OPT_K6_BATCH_FAST = 4, /* batched map update: 1 (default) free observations of zero-mean cells are settled
                                   * with atomics and only the rest is sorted; 0: every record is sorted into its chain */
+  SLAMHIP_OPT_RESIDENT_CHAINS = 6, /* 1 (default): the filter's per-particle accept chains run as ONE launch of
+                                    * co-resident workgroups when they all fit the device (csrc/hc_resident_gm.hip);
+                                    * 0: a kernel per super-step (csrc/hc_chain.hip).  Same results either way. */
   SLAMHIP_OPT_K6_BATCH_KEY64 = 5 /* batched map update: 1 forces the 8-byte (particle, cell) keys of very large
                                   * batches; 0 (default): by size */
 };

@@ -25,7 +25,8 @@ OOPE_OBSTACLE, OOPE_MAX, OOPE_MEAN, OOPE_OVERLAP, OOPE_GMAPPING = range(5)
 OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
 SUM_TREE256, SUM_SEQUENTIAL = 0, 1
 POSE_TRIG_DEVICE, POSE_TRIG_HOST = 0, 1
-(OPT_LOW_LATENCY, OPT_STAGE_POSES, OPT_FILTER_CHAINS, OPT_K6_PATH, OPT_K6_BATCH_FAST, OPT_K6_BATCH_KEY64) = range(6)
+(OPT_LOW_LATENCY, OPT_STAGE_POSES, OPT_FILTER_CHAINS, OPT_K6_PATH, OPT_K6_BATCH_FAST, OPT_K6_BATCH_KEY64,
+ OPT_RESIDENT_CHAINS) = range(7)
 TRIG_RAW, TRIG_CACHED = 0, 1
 STRIDE = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}
 

@@ -201,8 +201,10 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
                                                    const int *tiles, const double *s_unknown, double x, double y, double sn,
                                                    double cs, double r0, double ca0, double sa0, double *s_dyn, int *s_run0,
                                                    double *s_part1, GmPoseInfo *gi_out, double *score_out,
-                                                   long long *stamp_a = nullptr) {
-  const int t = threadIdx.x;
+                                                   long long *stamp_a = nullptr, int tid = -1) {
+  // (tid: the caller's own copy of threadIdx.x -- a persistent kernel hands in one the compiler cannot see through,
+  // so that nothing derived from it is hoisted out of its loop and held in registers, hc_resident_gm.hip)
+  const int t = tid < 0 ? (int)threadIdx.x : tid;
   const int lane = t & 63, wave = t >> 6;
   const int n = scan.n;
   const int G = (n + 63) >> 6;

@@ -467,6 +467,8 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
                                        g->prm.hc_rotation, &g->sm);
         if (rc) return rc;
       }
+      // (a lone GMapping chain stays a chain of kernels: the co-resident form is no faster for ONE chain, see
+      // resident_wanted in matchers.cpp)
       for (int idx : act_idx) {
         GmParticle &p = g->p[idx];
         // the filter's cache is the context's for the duration of the match

@@ -57,6 +57,14 @@ struct HcResidentCtl {
   unsigned pad[3];
 };
 
+// ... and over the GMapping OOPE (hc_resident_gm.hip): a pose hands the replay its score AND its cache side outputs
+// (GmPoseInfo), four granules of {12 bytes, tag} per slot
+struct HcResidentGmCtl {
+  HcGranule gran[2][kHcSlots + 7][4];
+  unsigned fail_epoch;
+  unsigned pad[3];
+};
+
 // one match of a BATCH of independent matches (slamhip_matcher_process_scan_batch): its own map and its own scan
 struct HcJobView {
   MapView map;
@@ -104,6 +112,7 @@ struct HcChainArgs {
   long long *stamps;    // debugging: 8 wall-clock stamps (100 MHz) per super-step of workgroup 1, or null
   // co-resident form only (hc_resident.hip)
   HcResidentCtl *rctl;   // one per chain
+  HcResidentGmCtl *rctl_gm;  // ... of the GMapping form
   unsigned *h_all_done;  // pinned; a batch's last chain to end stores the epoch here (null: a lone chain)
   int debug_mute;        // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
   int oope;              // SLAMHIP_OOPE_OBSTACLE (0), or a window OOPE (max / mean / overlap) with its analysis area
@@ -119,6 +128,11 @@ hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int
 hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream,
                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int n_chains = 1);
 hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, size_t lds_bytes, int *out_wgs);
+// the GMapping OOPE's co-resident form (hc_resident_gm.hip): one chain, or n_chains of a filter step (grid.y = chain:
+// HcChainArgs::inits / n_done / h_all_done / tables / slots as in launch_hc_chain_step)
+hipError_t launch_hc_chain_resident_gm(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                                       hipEvent_t ev_stop = nullptr, int n_chains = 1);
+hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs);
 // one thread: copies the number of finished chains to pinned memory and publishes a launch number (the host's
 // view of a burst of multi-chain super-steps)
 hipError_t launch_chain_marker(const unsigned *n_done, unsigned *h_done_count, unsigned *flag, unsigned seq,

@@ -36,69 +36,13 @@
 #include <hip/hip_ext.h>
 
 #include "hc_chain_device.h"
+#include "hc_resident_device.h"
 #include "score_device.h"
 
 namespace slamhip {
 
 namespace {
-
 constexpr int kSumLanes = 256;          // the canonical sum's partials (= k_score_point's block)
-constexpr unsigned kHcSpinLimit = 1u << 17;  // polls of one sweep (~0.4 us each) before the chain gives up
-constexpr int kHcResidentMaxSteps = 4000;    // super-steps a tag can count (12 bits, 0 excluded)
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ long long bcast_ll(long long v, int lane) {
-  const int lo = bcast_i((int)(unsigned)(unsigned long long)v, lane);
-  const int hi = bcast_i((int)(unsigned)((unsigned long long)v >> 32), lane);
-  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-__device__ __forceinline__ double bcast(double v, int lane) {
-  return __longlong_as_double(bcast_ll(__double_as_longlong(v), lane));
-}
-
-// 16-bit tag of super-step k of the match with this epoch, never 0: twelve bits of step, four of epoch.  Four are
-// enough because every workgroup clears its own two granules when a match starts: what can still lie in a slot is
-// the previous match's, whose epoch bits differ (the host clears the block when a launch uses more slots than
-// the one before, hc_resident_capacity's callers).  The granule's last dword = 16 fingerprint bits | tag.
-__device__ __forceinline__ unsigned hc_tag(unsigned epoch, int k) { return ((epoch & 0xfu) << 12) | (unsigned)(k + 1); }
-
-// hash: the low 48 bits count (fold_fingerprint48)
-__device__ __forceinline__ void gran_store(HcGranule *p, double score, unsigned long long hash, unsigned tag) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(score);
-  u32x4 g;
-  g.x = (unsigned)u;
-  g.y = (unsigned)(u >> 32);
-  g.z = (unsigned)hash;
-  g.w = ((unsigned)(hash >> 32) << 16) | (tag & 0xffffu);
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(g) : "memory");
-}
-__device__ __forceinline__ unsigned gran_tag(const u32x4 &g) { return g.w & 0xffffu; }
-__device__ __forceinline__ unsigned long long gran_hash(const u32x4 &g) {
-  return ((unsigned long long)(g.w >> 16) << 32) | (unsigned long long)g.z;
-}
-// issue only: gran_wait ties the loaded values to the one wait
-__device__ __forceinline__ u32x4 gran_load(const HcGranule *p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-// (one operand per granule: the values cannot be used before the wait)
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[7]) {
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6])::"memory");
-}
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[4]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])::"memory");
-}
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[2]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1])::"memory");
-}
-__device__ __forceinline__ double gran_score(const u32x4 &g) {
-  return __longlong_as_double((long long)(((unsigned long long)g.y << 32) | (unsigned long long)g.x));
-}
-
 }  // namespace
 
 // MODEL: SLAMHIP_CELL_OCC / _TBM (the 1-cell OOPE); SEQ: the reference's beam-order sum; BATCH: grid.y independent

@@ -33,10 +33,12 @@ struct slamhip_matcher {
   unsigned chain_epoch = 0;
   double chain_steps_avg = 12.0;
   int chain_mode = -1;  // -1 = decide at the first match, 0 off, 1 the chain of kernels, 2 one co-resident launch
+  bool chain_mode_explicit = false;  // set through slamhip_matcher_set_device_chain (not the default)
   int chain_nt = 1024, chain_ahead = 3;
   // the co-resident form (hc_resident.hip): exchange block, workgroups the device keeps resident (by workgroup
   // size; 0 = not asked yet), matches that gave up in a row / in total (bounded spin ran out: kernel chain instead)
   slamhip::HcResidentCtl *d_rctl = nullptr;
+  slamhip::HcResidentGmCtl *d_rctl_gm = nullptr;
   int resident_cap[3] = {0, 0, 0};
   int resident_gave_up_row = 0;
   int debug_resident_mute = 0;  // testing (slamhip_matcher_debug_resident_mute)
@@ -120,6 +122,8 @@ int chain_release(slamhip_matcher *m) {
   if (m->d_chain) hipFree(m->d_chain);
   if (m->d_rctl) hipFree(m->d_rctl);
   m->d_rctl = nullptr;
+  if (m->d_rctl_gm) hipFree(m->d_rctl_gm);
+  m->d_rctl_gm = nullptr;
   if (m->d_shapes) hipFree(m->d_shapes);
   if (m->h_chain) hipHostFree(m->h_chain);
   if (m->h_trace) hipHostFree(m->h_trace);
@@ -191,7 +195,12 @@ bool chain_eligible(slamhip_matcher *m) {
 // Can this match run as ONE launch of co-resident workgroups?  The 1-cell OOPE only (the GMapping OOPE's super-steps
 // hand side outputs of every pose to the replay: kernel chain), and the grid must fit the device at once.
 bool resident_wanted(slamhip_matcher *m) {
-  return m->chain_mode == 2 && (m->cfg.oope == SLAMHIP_OOPE_OBSTACLE || is_window_oope(m->cfg.oope)) &&
+  // A LONE chain over the GMapping OOPE is co-resident only when asked for (mode 2 set explicitly): measured on
+  // MI355X it is no faster than the chain of kernels -- four granules per pose instead of one, a second workgroup
+  // barrier per super-step, K3's one-pose body at the 128-VGPR limit (profiles/r04_resident_stamps.txt) -- while a
+  // filter step's MANY chains in one launch are (gm_multi_chain_run: 0.71 -> 0.59 ms per 100 particles).
+  const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING && m->chain_mode_explicit;
+  return m->chain_mode == 2 && (m->cfg.oope == SLAMHIP_OOPE_OBSTACLE || is_window_oope(m->cfg.oope) || gm) &&
          m->resident_gave_up_row < 3;
 }
 int resident_capacity(slamhip_matcher *m, int cell_model, int nt, bool batch, size_t lds, int *wgs) {
@@ -283,22 +292,30 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   int launched = 0;
   if (resident) {
     // ---- ONE launch (hc_resident.hip): every workgroup of the tree stays on the chip for the whole match
+    const bool gm_res = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
     int cap = 0;
-    rc = resident_capacity(m, cell_model, m->chain_nt, false, sizeof(double) * (size_t)std::max(a.scan.n, 1), &cap);
+    if (gm_res) SLAMHIP_CHECK(hc_resident_gm_capacity(m->chain_nt, a.scan.n, &cap));
+    else rc = resident_capacity(m, cell_model, m->chain_nt, false, sizeof(double) * (size_t)std::max(a.scan.n, 1), &cap);
     if (rc) return rc;
     if (6 * a.max_inst + 1 > cap) return kResidentGaveUp;  // (not counted: this matcher's grid never fits)
-    if (!m->d_rctl) {
+    if (gm_res && !m->d_rctl_gm) {
+      SLAMHIP_CHECK(hipMalloc(&m->d_rctl_gm, sizeof(HcResidentGmCtl)));
+      SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl_gm, 0, sizeof(HcResidentGmCtl), ctx->stream));
+    }
+    if (!gm_res && !m->d_rctl) {
       SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
       SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));  // (ordered with the launch)
     }
     // (every workgroup clears its own granules when a match starts, and this matcher's grid never changes: nothing
     // stale can carry a current tag -- hc_tag in hc_resident.hip)
     a.rctl = m->d_rctl;
+    a.rctl_gm = m->d_rctl_gm;
     a.debug_mute = m->debug_resident_mute;
     hipEvent_t e0, e1;
     rc = profile_event_pair(ctx, &e0, &e1);
     if (rc) return rc;
-    SLAMHIP_CHECK(launch_hc_chain_resident(a, cell_model, m->chain_nt, ctx->stream, e0, e1));
+    if (gm_res) SLAMHIP_CHECK(launch_hc_chain_resident_gm(a, m->chain_nt, ctx->stream, e0, e1));
+    else SLAMHIP_CHECK(launch_hc_chain_resident(a, cell_model, m->chain_nt, ctx->stream, e0, e1));
     launched = 1;
     ++m->resident_matches;
     unsigned long long spins = 0;
@@ -802,6 +819,9 @@ struct GmMultiChain {
   double *h_inits = nullptr;     // pinned staging of the initial poses
   double *d_inits = nullptr;
   int *d_slots = nullptr;        // tile-pool slot of every chain (per-particle maps)
+  HcResidentGmCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain
+  unsigned *h_all_done = nullptr;     // pinned: the last chain to end stores the epoch here
+  int rctl_grid = 0, rctl_chains = 0, gave_up_row = 0;
   unsigned *d_n_done = nullptr;
   unsigned *h_done_count = nullptr;  // pinned
   int shape_n_inst[kHcShapes] = {0};
@@ -814,6 +834,8 @@ void gm_multi_chain_free(GmMultiChain *s) {
   if (!s) return;
   hipSetDevice(s->device);
   hipDeviceSynchronize();
+  if (s->d_rctl) hipFree(s->d_rctl);
+  if (s->h_all_done) hipHostFree(s->h_all_done);
   if (s->d_ctl) hipFree(s->d_ctl);
   if (s->d_shapes) hipFree(s->d_shapes);
   if (s->h_out) hipHostFree(s->h_out);
@@ -875,6 +897,9 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     if (s->h_inits) hipHostFree(s->h_inits);
     if (s->d_inits) hipFree(s->d_inits);
     if (s->d_slots) hipFree(s->d_slots);
+    if (s->d_rctl) hipFree(s->d_rctl);
+    s->d_rctl = nullptr;
+    s->rctl_grid = s->rctl_chains = 0;
     s->d_slots = nullptr;
     s->d_ctl = nullptr;
     s->h_out = nullptr;
@@ -929,6 +954,69 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
   SLAMHIP_CHECK(hipMemcpyAsync(s->d_inits, s->h_inits, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
   SLAMHIP_CHECK(hipMemsetAsync(s->d_n_done, 0, sizeof(unsigned), ctx->stream));
   int launched = 0;
+  // ---- ONE launch for all chains (hc_resident_gm.hip) when their workgroups fit the device at once: every
+  // particle's chain then advances at its own pace instead of in lock-step launches
+  bool ran_resident = false;
+  if (ctx->resident_chains && s->gave_up_row < 3 && a.scan.n <= 1280) {
+    int cap_wgs = 0;
+    SLAMHIP_CHECK(hc_resident_gm_capacity(s->nt, a.scan.n, &cap_wgs));
+    if (n * (6 * s->max_inst + 1) <= cap_wgs) {
+      if (!s->d_rctl) {
+        SLAMHIP_CHECK(hipMalloc(&s->d_rctl, sizeof(HcResidentGmCtl) * s->cap));
+        SLAMHIP_CHECK(hipMemsetAsync(s->d_rctl, 0, sizeof(HcResidentGmCtl) * s->cap, ctx->stream));
+      }
+      if (!s->h_all_done) {
+        SLAMHIP_CHECK(hipHostMalloc(&s->h_all_done, sizeof(unsigned), pinned));
+        *s->h_all_done = 0;
+      }
+      if (6 * s->max_inst + 1 > s->rctl_grid || n > s->rctl_chains)
+        SLAMHIP_CHECK(hipMemsetAsync(s->d_rctl, 0, sizeof(HcResidentGmCtl) * s->cap, ctx->stream));
+      s->rctl_grid = 6 * s->max_inst + 1;
+      s->rctl_chains = n;
+      a.rctl_gm = s->d_rctl;
+      a.h_all_done = s->h_all_done;
+      hipEvent_t e0, e1;
+      rc = profile_event_pair(ctx, &e0, &e1);
+      if (rc) return rc;
+      SLAMHIP_CHECK(launch_hc_chain_resident_gm(a, s->nt, ctx->stream, e0, e1, n));
+      launched = 1;
+      volatile unsigned *all_done = s->h_all_done;
+      unsigned long long spins = 0;
+      bool gave_up = false;
+      for (;;) {
+        if (*all_done == epoch) break;
+        __builtin_ia32_pause();
+        if ((++spins & 0xffffull) == 0) {
+          for (int c = 0; c < n && !gave_up; ++c) {
+            const volatile HcHostOut *hc = &s->h_out[c];
+            gave_up = hc->done_seq == epoch && (hc->error == 4 || hc->error == 5);
+          }
+          if (gave_up) break;
+          hipError_t qe = hipStreamQuery(ctx->stream);
+          if (qe == hipSuccess && *all_done != epoch) {
+            gave_up = true;
+            break;
+          }
+          if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "co-resident GMapping chains");
+        }
+      }
+      if (gave_up) {
+        SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ++s->gave_up_row;
+        SLAMHIP_CHECK(hipMemsetAsync(s->d_n_done, 0, sizeof(unsigned), ctx->stream));
+        for (int c = 0; c < n; ++c) ((volatile HcHostOut *)s->h_out)[c].error = 0;
+        a.rctl_gm = nullptr;
+        a.h_all_done = nullptr;
+        launched = 0;
+        epoch = ++s->epoch;
+        if (epoch == 0) epoch = ++s->epoch;
+        a.epoch = epoch;
+      } else {
+        s->gave_up_row = 0;
+        ran_resident = true;
+      }
+    }
+  }
   auto burst = [&](int count, unsigned *seq_out) -> int {
     for (int i = 0; i < count; ++i) {
       hipEvent_t e0, e1;
@@ -944,9 +1032,9 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     return SLAMHIP_OK;
   };
   unsigned seq_prev = 0, seq_next = 0;
-  rc = burst(std::max(3, (int)(s->steps_avg * 0.8)), &seq_prev);
+  if (!ran_resident) rc = burst(std::max(3, (int)(s->steps_avg * 0.8)), &seq_prev);
   if (rc) return rc;
-  for (;;) {
+  while (!ran_resident) {
     rc = burst(3, &seq_next);  // queued before the wait: the GPU never runs dry
     if (rc) return rc;
     rc = score_wait(ctx, seq_prev);
@@ -1469,6 +1557,7 @@ int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads) 
     return invalid_arg("bad device-chain setting");
   (void)chain_eligible(m);  // defaults first, then the explicit setting
   m->chain_mode = mode;
+  m->chain_mode_explicit = true;
   m->resident_gave_up_row = 0;
   if (threads) m->chain_nt = threads;
   return SLAMHIP_OK;
@@ -1524,6 +1613,16 @@ int slamhip_matcher_process_scan_batch(slamhip_matcher *m, int n_jobs, const sla
   // results in job order; a match the chains did not settle (a configuration they do not cover, a trace longer
   // than a chain's buffer) goes through the single-match path: upload its scan, process_scan
   long long calls = 0, evaluated = 0, steps = 0;
+  // The single-match path works on the context's CURRENT scan: a fallback selects or uploads the job's scan.  The
+  // caller's own selection is put back afterwards -- or, when a fallback upload has overwritten the very buffer it
+  // pointed at, invalidated, so that a later process_scan fails loudly instead of scoring another robot's scan
+  // 
+  const double *saved_ptr = ctx->scan_ptr;
+  const size_t saved_stride = ctx->scan_stride;
+  const int saved_n = ctx->scan_n;
+  const double saved_tot_w = ctx->scan_tot_w;
+  std::vector<double> saved_w, saved_f;
+  bool fell_back = false, uploaded = false;
   for (int c = 0; c < n_jobs; ++c) {
     BatchJobResult &r = b->res[c];
     const slamhip_match_job &j = jobs[c];
@@ -1542,6 +1641,12 @@ int slamhip_matcher_process_scan_batch(slamhip_matcher *m, int n_jobs, const sla
         if (m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, dl, r.prob);
       }
     } else {
+      if (!fell_back) {
+        saved_w = ctx->h_weight;
+        saved_f = ctx->h_factor;
+        fell_back = true;
+      }
+      uploaded = uploaded || j.scan_slot < 0;
       int rc = j.scan_slot >= 0 ? slamhip_scan_select(ctx, j.scan_slot)
                                 : slamhip_scan_upload(ctx, j.n, j.range, j.cos_a, j.sin_a, j.weight, j.factor);
       if (rc) return rc;
@@ -1557,6 +1662,18 @@ int slamhip_matcher_process_scan_batch(slamhip_matcher *m, int n_jobs, const sla
     calls += r.calls;
     evaluated += r.evaluated;
     steps = std::max<long long>(steps, r.steps);
+  }
+  if (fell_back) {
+    if (uploaded && saved_ptr == ctx->d_scan) {
+      ctx->scan_n = 0;  // (its contents are gone: "no scan uploaded" from here on)
+    } else {
+      ctx->scan_ptr = saved_ptr;
+      ctx->scan_stride = saved_stride;
+      ctx->scan_n = saved_n;
+      ctx->scan_tot_w = saved_tot_w;
+      ctx->h_weight.swap(saved_w);
+      ctx->h_factor.swap(saved_f);
+    }
   }
   m->job.scorer_calls = calls;
   m->job.poses_evaluated = evaluated;

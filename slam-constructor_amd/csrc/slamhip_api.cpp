@@ -501,6 +501,7 @@ int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value) {
       break;
     case SLAMHIP_OPT_K6_BATCH_FAST: ctx->k6_batch_fast = value != 0; break;
     case SLAMHIP_OPT_K6_BATCH_KEY64: ctx->k6_batch_key64 = value != 0; break;
+    case SLAMHIP_OPT_RESIDENT_CHAINS: ctx->resident_chains = value != 0; break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;
@@ -515,6 +516,7 @@ int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value) {
     case SLAMHIP_OPT_K6_PATH: *value = ctx->k6_path; break;
     case SLAMHIP_OPT_K6_BATCH_FAST: *value = ctx->k6_batch_fast; break;
     case SLAMHIP_OPT_K6_BATCH_KEY64: *value = ctx->k6_batch_key64; break;
+    case SLAMHIP_OPT_RESIDENT_CHAINS: *value = ctx->resident_chains; break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;

@@ -29,6 +29,7 @@
 #include <iostream>
 #include <limits>
 #include <memory>
+#include <typeinfo>
 #include <utility>
 #include <unordered_map>
 #include <vector>
@@ -364,7 +365,12 @@ public:
                       const GridMap &map, RobotPoseDelta &pose_delta) override {
     int n_obs = 0;
     do_for_each_observer([&](ObsPtr) { ++n_obs; });
-    if (_own_filter && n_obs == 0) return process_raw_scan(raw_scan, init_pose, map, pose_delta);
+    // (the fast path restates WeightedMeanPointProbabilitySPE's filter_scan / should_skip_point inside the library: it is
+    // only taken when the estimator IS that class -- a subclass may override either -- and it leaves no stale _scan)
+    if (_own_filter && n_obs == 0 && spe_is_plain_wmpp()) {
+      _scan = LaserScan2D{};
+      return process_raw_scan(raw_scan, init_pose, map, pose_delta);
+    }
     do_for_each_observer([&](ObsPtr obs) { obs->on_matching_start(init_pose, raw_scan, map); });
     _scan = filter_scan(raw_scan.scan, init_pose, map);
     _mirror->sync(map, _dirty_source);
@@ -380,6 +386,11 @@ public:
   }
 
 private:
+  bool spe_is_plain_wmpp() const {
+    const auto spe = scan_probability_estimator();
+    return spe && typeid(*spe) == typeid(WeightedMeanPointProbabilitySPE);
+  }
+
   // Nobody listens: no filtered LaserScan2D has to exist.  The raw points go to the library as three arrays (kept
   // between scans), which filters, weighs and uploads them (slamhip_scan_filter_upload): no libm call per point on an
   // unbounded map, no sincos per beam per scan.

@@ -231,7 +231,8 @@ def test_mc_chain_equals_host_driven_matcher(pkg, ctx, cell, weighting, prm):
     assert dev.stats()["kernels_launched"] > 0 and host.stats()["kernels_launched"] == 0
 
 
-def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
+@pytest.mark.parametrize("mode", CHAIN_MODES)
+def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx, mode):
     """The GMapping OOPE on the device chain: K3's one-pose body scores the speculation tree, the replay applies
     the reference's cross-pose cache (gmapping_occupancy_observation_pe.h:21-24,36-37,43-44) in call
     order.  Trace, result and the cache left behind must equal the host-driven matcher's bit for bit -- over
@@ -247,7 +248,7 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
         cfg = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING)
         for prm in ([6, 0.1, 0.1], [40, 0.1, 0.1]):
             dev = pkg.Matcher(ctx, "HC", cfg, prm)
-            dev.set_device_chain(1)
+            dev.set_device_chain(mode)  # 2: one co-resident launch (csrc/hc_resident_gm.hip)
             host = pkg.Matcher(ctx, "HC", cfg, prm)
             host.set_device_chain(0)
             init = sc["init_pose"]
@@ -264,6 +265,8 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx):
                 init = init + np.array([0.011, -0.006, 0.003])
             if n_beams >= 16:
                 assert dev.stats()["launches"] <= host.stats()["launches"] or prm[0] == 6  # (super-steps vs round trips)
+            if mode == 2 and n_beams >= 16:
+                assert dev.resident_stats()["matches"] == 4 and dev.resident_stats()["gave_up"] == 0
 
 
 @pytest.mark.parametrize("mode", CHAIN_MODES)
