@@ -167,6 +167,21 @@ int chain_release(slamhip_matcher *m) {
 // the chain covers what the shipped single-hypothesis configurations use: hill climbing over the 1-cell
 // OOPE in the default mode; everything else (strict order, host trigonometry, window OOPEs, GMapping,
 // staged copies) keeps the host-driven path
+// Failed-round limits the device chains cover.  A chain halves both steps once per failed round -- as ONE exact
+// multiplication by 2^-f per walked segment (hc_chain.h) where the reference halves f times: the two agree as long as
+// no intermediate is subnormal, i.e. as long as step * 2^-(limit + 1) is a normal double (limit <= 1000 keeps 2^-f
+// itself representable).  r01-r03 stopped at 250 for no better reason than the size of a byte.
+bool hc_limit_on_device(const slamhip_matcher *m) {
+  if (m->hc_max_failed == 0 || m->hc_max_failed > 1000) return false;
+  for (double step : {m->hc_dt, m->hc_dr}) {
+    if (step == 0.0) continue;  // (a zero step stays zero either way)
+    int e = 0;
+    (void)std::frexp(std::fabs(step), &e);
+    if (!std::isfinite(step) || e - 1 - (int)m->hc_max_failed - 1 < -1021) return false;
+  }
+  return true;
+}
+
 bool is_window_oope(int oope) {
   return oope == SLAMHIP_OOPE_MAX || oope == SLAMHIP_OOPE_MEAN || oope == SLAMHIP_OOPE_OVERLAP;
 }
@@ -177,7 +192,7 @@ bool tie_check_default(slamhip_matcher *m) {
 }
 
 bool chain_eligible(slamhip_matcher *m) {
-  if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
+  if (!m->is_hc || !hc_limit_on_device(m)) return false;
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
   // (the window OOPEs ride the co-resident form only: hc_resident.hip's WIN instantiations, default sum order)
   const bool win = is_window_oope(m->cfg.oope);
@@ -488,7 +503,7 @@ void hc_batch_free(slamhip_matcher *m) {
 
 // the matcher-level conditions of chain_eligible (the per-scan ones are tested job by job)
 bool batch_chain_eligible(slamhip_matcher *m) {
-  if (!m->is_hc || m->hc_max_failed == 0 || m->hc_max_failed > 250) return false;
+  if (!m->is_hc || !hc_limit_on_device(m)) return false;
   if (m->cfg.oope != SLAMHIP_OOPE_OBSTACLE || m->cfg.pose_trig != SLAMHIP_POSE_TRIG_DEVICE) return false;
   if (m->cfg.sum_order != SLAMHIP_SUM_TREE256) return false;
   if (!m->ctx->low_latency || m->ctx->stage_poses) return false;

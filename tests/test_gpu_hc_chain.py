@@ -58,7 +58,8 @@ def matchers(pkg, ctx, prm, threads=0, mode=1):
 
 @pytest.mark.parametrize("mode", CHAIN_MODES)
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
-@pytest.mark.parametrize("prm", [[1, 0.1, 0.1], [6, 0.1, 0.1], [128, 0.1, 0.1], [250, 0.3, 0.05]])
+@pytest.mark.parametrize("prm", [[1, 0.1, 0.1], [6, 0.1, 0.1], [128, 0.1, 0.1], [250, 0.3, 0.05], [700, 0.1, 0.1],
+                                 [1000, 0.2, 0.1]])
 def test_chain_equals_host_driven_matcher(pkg, ctx, po, oracle, cell, weighting, prm, mode):
     sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=5, weighting=weighting)
     upload(pkg, ctx, sc)
