@@ -1435,25 +1435,33 @@ def main():
         raw_upload = [ctx.make_raw_scan(0, s_["raw_range"], s_["raw_angle"], is_occ=s_["is_occ"], weighting=weighting)
                       for s_ in scenes]
 
+        # scorer calls / poses scored of a scene's match: a pure function of the scene (deterministic chains), read
+        # from the matcher once per scene before the timed region -- three C calls of bookkeeping per step are not part
+        # of process_scan -- and re-checked against the matcher's own counters after it
+        per_scene_stats = {}
+
+        def account(k, kept):
+            if k not in per_scene_stats or kind != "HC":  # (a Monte-Carlo matcher's engine runs on: no table)
+                st_ = m.stats()
+                per_scene_stats[k] = (st_["scorer_calls"], st_["poses_evaluated"])
+            c_, e_ = per_scene_stats[k]
+            evaluated[0] += e_
+            plain_calls[0] += c_
+            return c_ * kept
+
         def step_resident():
             k = step_i[0] % len(scenes)
             step_i[0] += 1
             ctx.scan_select(k)
             m.process_scan(0, scenes[k]["init_pose"])
-            st_ = m.stats()
-            evaluated[0] += st_["poses_evaluated"]
-            plain_calls[0] += st_["scorer_calls"]
-            return st_["scorer_calls"] * beams_of[k]
+            return account(k, beams_of[k])
 
         def step_raw():
             k = step_i[0] % len(scenes)
             step_i[0] += 1
             kept = raw_upload[k](scenes[k]["init_pose"])
             m.process_scan(0, scenes[k]["init_pose"])
-            st_ = m.stats()
-            evaluated[0] += st_["poses_evaluated"]
-            plain_calls[0] += st_["scorer_calls"]
-            return st_["scorer_calls"] * kept
+            return account(k, kept)
 
         step = step_resident if args.resident_scan else step_raw
 
@@ -1481,6 +1489,12 @@ def main():
     if os.environ.get("BENCH_DUMP_STEPS"):
         print("step_ms:", " ".join("%.3f" % x for x in step_ms), file=sys.stderr)
     timed_evaluated, timed_calls = (evaluated[0], plain_calls[0]) if m is not None else (0, 0)
+    if m is not None:
+        k_last = (step_i[0] - 1) % len(scenes)
+        st_chk = m.stats()
+        if (st_chk["scorer_calls"], st_chk["poses_evaluated"]) != per_scene_stats[k_last]:
+            print("bench.py: the matcher's counters of the last timed match differ from the scene's table", file=sys.stderr)
+            sys.exit(6)
     # Pass 2 -- the same K steps again with a HIP event pair attached to every scoring dispatch
     # (stream = the context's own stream): kernel begin..end per launch, for `roofline`.
     ctx.profile_enable(True)

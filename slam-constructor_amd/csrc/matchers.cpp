@@ -887,6 +887,9 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     // wide workgroups, like a lone matcher.  Measured (cfg4 scene, ms per step, chains / the lock-step jobs they
     // replace): 100 particles 0.74 / 0.83 (1 instance; 2: 0.87, 4: 1.12), 25: 0.45 / 0.51, 13: 0.36 / 0.48; budgets
     // of 200..300 workgroups are equal, 500 and more slower.
+    // (r04, the co-resident launch: 280 / 500 / 700 / 950 workgroups give 0.304 / 0.322 / 0.369 / 0.383 ms per step
+    // for a 13-particle shard and 0.443 / 0.445 / 0.477 / 0.510 for 50 -- deeper trees cost more per pose than the
+    // super-steps they save here too)
     constexpr int wgs = 280;
     const int want = std::min(kHcDefaultInst, std::max(1, wgs / (6 * n)));
     if (want != s->built_inst) {
