@@ -71,16 +71,23 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   // a workgroup that starts after the others have given up (it was not resident with them) leaves at once
   if (__hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) return;
   if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing: the others must give up, not hang)
-  MapView map;
-  ScanView scan;
-  if (BATCH) {
-    const HcJobView *__restrict__ jv = a.jobs + blockIdx.y;
-    map = jv->map;
-    scan = jv->scan;
-  } else {
-    map = a.map;
-    scan = a.scan;
+  // this chain's map and scan: kernel arguments, or -- a batch of matches -- its entry of the job table
+  MapViewCP map_p;
+  ScanViewCP scan_p;
+  {
+    const __attribute__((address_space(4))) HcChainArgs *ap0 =
+        (const __attribute__((address_space(4))) HcChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (BATCH) {
+      const __attribute__((address_space(4))) HcJobView *jv =
+          (const __attribute__((address_space(4))) HcJobView *)(unsigned long long)(a.jobs + blockIdx.y);
+      map_p = &jv->map;
+      scan_p = &jv->scan;
+    } else {
+      map_p = &ap0->map;
+      scan_p = &ap0->scan;
+    }
   }
+  const ScanView scan = load_view(scan_p);
   const int n = scan.n;
   // this thread's first beam: its constants stay in registers for the whole match
   double br = 0.0, bc = 0.0, bs = 0.0, bw = 0.0, bf = 0.0;
@@ -132,9 +139,19 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     int t = t_entry;
     asm volatile("" : "+v"(t));
     const int lane = t & 63;
+    // the kernel's arguments through a pointer the compiler cannot see through either: what the loop needs of them
+    // is re-read from the kernarg segment (scalar loads, cached) where it is used instead of living in -- and being
+    // spilled from -- scalar registers across the whole loop
+    const __attribute__((address_space(4))) HcChainArgs *ap =
+        (const __attribute__((address_space(4))) HcChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    // (the map view too: ~20 scalar registers that would otherwise live across the loop)
+    MapViewCP mp = map_p;
+    asm volatile("" : "+s"(mp));
+    const MapView map = load_view(mp);
     // ---- wave 0: this workgroup's pose of super-step k
     if (wave == 0) {
-      if (stamp && k < 64) a.stamps[8 * k + 0] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 0] = wall_clock64();
       const HcState &st = s_st;
       bool go = !st.done;
       double px = st.x, py = st.y, pth = st.theta;
@@ -144,11 +161,11 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         HcInst in;
 #pragma unroll
         for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
-        go = inst_of_slot < (int)((a.n_inst >> (8 * st.shape)) & 0xffull) &&
-             (hc_is_root(in) || st.failed + hc_nfail_parent(in) < a.max_failed);  // else: behind the end of the chain
+        go = inst_of_slot < (int)((ap->n_inst >> (8 * st.shape)) & 0xffull) &&
+             (hc_is_root(in) || st.failed + hc_nfail_parent(in) < ap->max_failed);  // else: behind the end of the chain
         if (go) {
           const HcRound r = hc_round_of(st, in);
-          go = !(hc_trailing(r.failed, a.max_failed) && cand > 0);  // a trailing round has one candidate
+          go = !(hc_trailing(r.failed, ap->max_failed) && cand > 0);  // a trailing round has one candidate
           hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, cand, &px, &py, &pth);
         }
       }
@@ -167,12 +184,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         s_mode[pk] = st.mode;
         if (st.done) s_stop = 1;
       }
-      if (stamp && k < 64) a.stamps[8 * k + 3] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 3] = wall_clock64();
     }
     __syncthreads();  // (A)
     if (s_stop) break;
     const int go = s_go[pk], mode = s_mode[pk];
-    const unsigned tag = hc_tag(a.epoch, k);
+    const unsigned tag = hc_tag(ap->epoch, k);
     if (go) {
       const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
       // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order, wave
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       if (WIN) {
         // window OOPEs: k_score_window's per-beam value (occupancy_observation_probability.h:29-99), one beam at a
         // time -- a beam reads a window of cells, not one
-        const double half_v = (a.area[1] - a.area[0]) / 2, half_h = (a.area[3] - a.area[2]) / 2;
+        const double half_v = (ap->area[1] - ap->area[0]) / 2, half_h = (ap->area[3] - ap->area[2]) / 2;
         for (int b = t; b < n; b += NT) {
           double r_ = br, ca = bc, sa = bs, w = bw, f = bf;
           if (b != t) {
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           const double c = cs * ca - sn * sa;
           const double s = sn * ca + cs * sa;
           const double ox = px + r_ * c, oy = py + r_ * s;
-          s_term[b] = window_probability<MODEL>(map, a.oie, a.oope, half_v, half_h, ox, oy) * w * f;
+          s_term[b] = window_probability<MODEL>(map, ap->oie, ap->oope, half_v, half_h, ox, oy) * w * f;
         }
       } else {
         for (int base = t; base < n; base += 4 * NT) {
@@ -223,12 +240,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int b = base + j * NT;
-            if (b < n) s_term[b] = cell_probability<MODEL>(a.oie, cell[j]) * w_[j] * f_[j];
+            if (b < n) s_term[b] = cell_probability<MODEL>(ap->oie, cell[j]) * w_[j] * f_[j];
           }
         }
       }
       __syncthreads();  // (B)
-      if (stamp && k < 64) a.stamps[8 * k + 4] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 4] = wall_clock64();
       if (SEQ) {
         // the reference's own order: one running sum over the beams (weighted_mean_point_probability_spe.h:108-124)
         if (t == 0) {
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           gran_store(&gseq[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0ull, tag);
         }
       }
-      if (stamp && k < 64) a.stamps[8 * k + 5] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 5] = wall_clock64();
     } else if (!init_slot && t == 0) {
       // nothing to score (behind the end of the chain, or the surplus candidates of a trailing round): the sweepers
       // wait for every slot of the shape, so the tag goes out all the same
@@ -294,17 +311,17 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     // ---- wave 0: all scores of super-step k, then its replay
     if (wave == 0) {
       const HcState &sp = s_st;  // (fields are read where they are used: a register copy of the struct is 34 VGPRs)
-      const int n_inst = (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
+      const int n_inst = (int)((ap->n_inst >> (8 * sp.shape)) & 0xffull);
       // the round instances of this tree's shape, lane = instance: loads in flight while the scores arrive
       HcInst me;
       {
-        const unsigned long long *src = &a.shapes[sp.shape].inst[lane].w[0];
+        const unsigned long long *src = &ap->shapes[sp.shape].inst[lane].w[0];
 #pragma unroll
         for (int q = 0; q < 14; ++q) me.w[q] = src[q];
       }
       const bool active = lane < n_inst;
-      const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
-      const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), a.max_failed);
+      const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < ap->max_failed);
+      const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), ap->max_failed);
       const int bpi = hc_bp_inst(me);
       const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
       // where every instance's round starts: closed form of the root and the path, no score involved -- computed
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           if (__all(ok)) break;
           ++spins;
           if ((spins & 31u) == 0u) {
-            const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+            const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ap->epoch;
             if (gone || spins > kHcSpinLimit) {
               failed = true;
               break;
@@ -359,15 +376,15 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           }
         }
       }
-      if (stamp && k < 64) a.stamps[8 * k + 1] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 1] = wall_clock64();
       if (failed || k + 1 >= kHcResidentMaxSteps) {
         // a workgroup of the grid is not on the chip (or the chain is longer than a tag can count): everybody
         // leaves, the host runs the match on the kernel chain
         if (lane == 0) {
-          __hip_atomic_store(&rc->fail_epoch, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&rc->fail_epoch, ap->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&host->error, failed ? 4 : 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __threadfence_system();
-          __hip_atomic_store(&host->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&host->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           s_stop = 1;
         }
         continue;  // to (A), where the workgroup leaves
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       long long batch_acc = 0;
 #pragma unroll
       for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
-      if (stamp && k < 64) a.stamps[8 * k + 7] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 7] = wall_clock64();
       // checked default mode: a comparison on the walked path that the tree sum cannot settle -> the same tree is
       // scored once more, in beam order as well, and decided from those sums
       const bool dirty = !SEQ && verify && sp.mode == 0 && __ballot(valid && ambiguous) != 0ull;
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       HcState next = sp;
       if (!dirty) {
         const long long batch_calls = 6ll * depth_t + (trailing_t ? 1 : 6);
-        hc_advance(sp, me, rt, out_t, run_t, a.max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0),
+        hc_advance(sp, me, rt, out_t, run_t, ap->max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0),
                    &next);
         if (!SEQ && verify) {
           next.best_hash = (unsigned long long)bcast_ll((long long)run_hash, tl);
@@ -500,13 +517,13 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         next.done = 1;
         if (init_slot && lane == 0) host->error = 1;
       }
-      if (stamp && k < 64) a.stamps[8 * k + 2] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 2] = wall_clock64();
       if (init_slot) {
         // ---- the last workgroup keeps the books (it scores nothing after the first super-step)
-        if (a.trace && !dirty) {
-          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_stride;
+        if (ap->trace && !dirty) {
+          HcTraceEntry *const trace = ap->trace + (size_t)blockIdx.y * (size_t)ap->trace_stride;
           const long long base = sp.calls + (sp.first ? 1 : 0);
-          if (sp.first && lane == 0 && a.trace_cap > 0) {
+          if (sp.first && lane == 0 && ap->trace_cap > 0) {
             HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};
             trace[0] = e;
           }
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
               e.accepted = (accmask >> c) & 1u;
               e.pad = 0;
               const long long at = base + 6ll * hc_depth(me) + c;
-              if (at < a.trace_cap) trace[at] = e;
+              if (at < ap->trace_cap) trace[at] = e;
               else host->error = 2;
             }
           }
@@ -540,14 +557,14 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             h->gm_cx = -1;
             h->gm_cy = -1;
             h->gm_prob = -1.0;
-            __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.n_done) {
+            __hip_atomic_store(&h->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (ap->n_done) {
               // a batch: the last chain to end tells the host.  This chain's result is on its way to the host BEFORE
               // it counts itself, so whoever sees the full count may announce everybody's
               __threadfence_system();
-              const unsigned before = atomicAdd(a.n_done, 1u);
-              if (before + 1u == gridDim.y && a.h_all_done)
-                __hip_atomic_store(a.h_all_done, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+              const unsigned before = atomicAdd(ap->n_done, 1u);
+              if (before + 1u == gridDim.y && ap->h_all_done)
+                __hip_atomic_store(ap->h_all_done, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
           }
         }

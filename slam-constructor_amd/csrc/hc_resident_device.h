@@ -24,6 +24,35 @@ __device__ __forceinline__ double bcast(double v, int lane) {
   return __longlong_as_double(bcast_ll(__double_as_longlong(v), lane));
 }
 
+// The views read through a constant-address-space pointer (the kernarg segment, or a job table in HBM): scalar
+// loads where they are needed instead of scalar registers held -- and spilled -- across a persistent loop
+typedef const __attribute__((address_space(4))) MapView *MapViewCP;
+typedef const __attribute__((address_space(4))) ScanView *ScanViewCP;
+__device__ __forceinline__ MapView load_view(MapViewCP p) {
+  MapView m;
+  m.payload = p->payload;
+  m.width = p->width;
+  m.height = p->height;
+  m.pitch = p->pitch;
+  m.origin_x = p->origin_x;
+  m.origin_y = p->origin_y;
+  m.scale = p->scale;
+  m.inv_scale = p->inv_scale;
+  for (int k = 0; k < 4; ++k) m.unknown[k] = p->unknown[k];
+  return m;
+}
+__device__ __forceinline__ ScanView load_view(ScanViewCP p) {
+  ScanView s;
+  s.range = p->range;
+  s.cos_a = p->cos_a;
+  s.sin_a = p->sin_a;
+  s.weight = p->weight;
+  s.factor = p->factor;
+  s.n = p->n;
+  s.tot_w = p->tot_w;
+  return s;
+}
+
 // 16-bit tag of super-step k of the match with this epoch, never 0: twelve bits of step, four of epoch.  Four are
 // enough because every workgroup clears its own two granules when a match starts: what can still lie in a slot is
 // the previous match's, whose epoch bits differ (the host clears the block when a launch uses more slots than

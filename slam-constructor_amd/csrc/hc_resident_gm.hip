@@ -79,8 +79,10 @@ __device__ __forceinline__ void gm_gran_store(HcGranule *p, int q, double score,
 // NT threads per pose (256 / 512 / 1024), KB = ceil(beams / 256), G = granules of one kind a sweeping lane looks
 // after (the grid has at most 64 G workgroups: 1 for the filter's many small trees, 4 for a lone chain's 253);
 // gran4: [2][kHcSlots + 7][4] granules per chain
+// (256-thread workgroups -- the filter's hundred small trees -- get three waves per SIMD, 168 VGPRs: K3's one-pose body
+// spills 27 registers at four, and 3 x 256 workgroups per CU still hold the 700 of a 100-particle step)
 template <int NT, int KB, int G>
-__global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
+__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_gm(HcChainArgs a) {
   constexpr int kRow = kHcSlots + 7;
   extern __shared__ double s_dyn[];  // K3's arrays (gm_score_pose_wide)
   __shared__ GmPoseInfo s_info[kRow];
@@ -105,8 +107,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
   HcHostOut *const host = a.host + blockIdx.y;
   if (__hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) return;
   if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing)
-  const MapView map = a.map;
-  const ScanView scan = a.scan;
+  const __attribute__((address_space(4))) HcChainArgs *const ap0 =
+      (const __attribute__((address_space(4))) HcChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+  const ScanView scan = load_view(&ap0->scan);
   const int n = scan.n;
   double br = 0.0, bc = 0.0, bs = 0.0;
   if (t < n) {
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
     for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
   }
   if (t == 64) {
-    s_unknown[0] = map.unknown[0];
-    s_unknown[1] = map.unknown[1];
-    s_unknown[2] = map.unknown[2];
+    s_unknown[0] = a.map.unknown[0];
+    s_unknown[1] = a.map.unknown[1];
+    s_unknown[2] = a.map.unknown[2];
   }
   HcGranule *const gran = &rc->gran[0][0][0];
   if (t < 8) gm_gran_store(gran + ((size_t)(t >> 2) * kRow + slot) * 4 + (t & 3), 0, 0.0, GmPoseInfo{}, 0u);
@@ -153,8 +156,15 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
     int tt = t_entry;
     asm volatile("" : "+v"(tt));  // (see hc_resident.hip: nothing derived from the thread index is hoisted)
     const int lane = tt & 63;
+    // (... and the kernel's arguments and the map view are re-read from the kernarg segment where they are used)
+    const __attribute__((address_space(4))) HcChainArgs *ap = ap0;
+    asm volatile("" : "+s"(ap));
+    const MapView map = load_view(&ap->map);
+    GmParams gmp;
+    gmp.fullness_th = ap->gm.fullness_th;
+    gmp.window = ap->gm.window;
     if (wave == 0) {
-      if (stamp && k < 64) a.stamps[8 * k + 0] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 0] = wall_clock64();
       const HcState &st = s_st;
       bool go = !st.done;
       double px = st.x, py = st.y, pth = st.theta;
@@ -164,11 +174,11 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
         HcInst in;
 #pragma unroll
         for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
-        go = inst_of_slot < (int)((a.n_inst >> (8 * st.shape)) & 0xffull) &&
-             (hc_is_root(in) || st.failed + hc_nfail_parent(in) < a.max_failed);
+        go = inst_of_slot < (int)((ap->n_inst >> (8 * st.shape)) & 0xffull) &&
+             (hc_is_root(in) || st.failed + hc_nfail_parent(in) < ap->max_failed);
         if (go) {
           const HcRound r = hc_round_of(st, in);
-          go = !(hc_trailing(r.failed, a.max_failed) && cand > 0);
+          go = !(hc_trailing(r.failed, ap->max_failed) && cand > 0);
           hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, cand, &px, &py, &pth);
         }
       }
@@ -187,30 +197,30 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
         s_run0_len = n;
         if (st.done) s_stop = 1;
       }
-      if (stamp && k < 64) a.stamps[8 * k + 3] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 3] = wall_clock64();
     }
     __syncthreads();  // (A)
     if (s_stop) break;
     const int go = s_go[pk];
-    const unsigned tag = hc_tag(a.epoch, k);
+    const unsigned tag = hc_tag(ap->epoch, k);
     HcGranule *const mine4 = gran + ((size_t)pk * kRow + slot) * 4;
     if (go) {
       const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
       double score = 0.0;
-      gm_score_pose_wide<KB, NT>(map, scan, a.gm, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_dyn, &s_run0_len, s_part,
-                                 &s_gi, &score, (stamp && k < 64) ? &a.stamps[8 * k + 4] : nullptr, tt);
+      gm_score_pose_wide<KB, NT>(map, scan, gmp, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_dyn, &s_run0_len, s_part,
+                                 &s_gi, &score, (stamp && k < 64) ? &ap->stamps[8 * k + 4] : nullptr, tt);
       if (tt == 0) s_score = score;
       // (thread 0 wrote the score and run0_len, other threads the rest of s_gi before the body's last barrier: the four
       // publishing lanes are thread 0's wave, behind it in program order)
       if (tt < 4) gm_gran_store(mine4 + tt, tt, s_score, s_gi, tag);
-      if (stamp && k < 64) a.stamps[8 * k + 5] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 5] = wall_clock64();
     } else if (!init_slot && tt < 4) {
       gm_gran_store(mine4 + tt, tt, 0.0, GmPoseInfo{}, tag);
     }
     // ---- waves 0..3: one granule kind each, all slots of the tree, into LDS
     if (wave < 4) {
       const HcState &sp = s_st;
-      const int n6 = 6 * (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
+      const int n6 = 6 * (int)((ap->n_inst >> (8 * sp.shape)) & 0xffull);
       const int n_wait = n6 + (sp.first ? 1 : 0);
       const HcGranule *g0 = gran + (size_t)pk * kRow * 4 + wave;
       unsigned spins = 0;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
         if (__all(ok)) break;
         ++spins;
         if ((spins & 31u) == 0u) {
-          const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+          const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ap->epoch;
           if (gone || spins > kHcSpinLimit) {
             failed = true;
             break;
@@ -271,29 +281,29 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
       if (failed && lane == 0) s_sweep_failed = 1;
     }
     __syncthreads();  // (D) the four kinds of every slot are in LDS
-    if (stamp && k < 64) a.stamps[8 * k + 1] = wall_clock64();
+    if (stamp && k < 64) ap->stamps[8 * k + 1] = wall_clock64();
     if (s_sweep_failed || k + 1 >= kHcResidentMaxSteps) {
       if (tt == 0) {
-        __hip_atomic_store(&rc->fail_epoch, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rc->fail_epoch, ap->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&host->error, s_sweep_failed ? 4 : 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
-        __hip_atomic_store(&host->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       break;  // (uniform: every thread read the same words behind the barrier)
     }
     if (wave == 0) {
       // ---- replay of super-step k's tree, lane = round instance (hc_chain.hip's GMapping replay)
       const HcState &sp = s_st;
-      const int n_inst = (int)((a.n_inst >> (8 * sp.shape)) & 0xffull);
+      const int n_inst = (int)((ap->n_inst >> (8 * sp.shape)) & 0xffull);
       HcInst me;
       {
-        const unsigned long long *src = &a.shapes[sp.shape].inst[lane].w[0];
+        const unsigned long long *src = &ap->shapes[sp.shape].inst[lane].w[0];
 #pragma unroll
         for (int q = 0; q < 14; ++q) me.w[q] = src[q];
       }
       const bool active = lane < n_inst;
-      const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < a.max_failed);
-      const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), a.max_failed);
+      const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < ap->max_failed);
+      const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), ap->max_failed);
       HcRound rr{sp.x, sp.y, sp.theta, sp.dt, sp.dr, sp.failed};
       if (reach) rr = hc_round_of(sp, me);
       double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
       long long batch_acc = 0;
 #pragma unroll
       for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
-      if (stamp && k < 64) a.stamps[8 * k + 7] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 7] = wall_clock64();
       HcRound rt;
       rt.x = bcast(rr.x, tl);
       rt.y = bcast(rr.y, tl);
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
       HcState next = sp;
       {
         const long long batch_calls = 6ll * depth_t + (trailing_t ? 1 : 6);
-        hc_advance(sp, me, rt, out_t, run_t, a.max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0), &next);
+        hc_advance(sp, me, rt, out_t, run_t, ap->max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0), &next);
       }
       {
         // the cache after the walk's last scorer call: the terminal round's last candidate
@@ -383,16 +393,16 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
         next.done = 1;
         if (init_slot && lane == 0) host->error = 1;
       }
-      if (stamp && k < 64) a.stamps[8 * k + 2] = wall_clock64();
+      if (stamp && k < 64) ap->stamps[8 * k + 2] = wall_clock64();
       if (init_slot) {
         if (sp.first && lane == 0) {  // what the filter's cross-particle cache check looks at
           s_first_info = s_info[kHcSlots - 1];
           s_first_raw = first_raw;
         }
-        if (a.trace) {
-          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_stride;
+        if (ap->trace) {
+          HcTraceEntry *const trace = ap->trace + (size_t)blockIdx.y * (size_t)ap->trace_stride;
           const long long base = sp.calls + (sp.first ? 1 : 0);
-          if (sp.first && lane == 0 && a.trace_cap > 0) {
+          if (sp.first && lane == 0 && ap->trace_cap > 0) {
             HcTraceEntry e{sp.x, sp.y, sp.theta, root_prob, 1, 0};
             trace[0] = e;
           }
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
               e.accepted = (accmask >> c) & 1u;
               e.pad = 0;
               const long long at = base + 6ll * hc_depth(me) + c;
-              if (at < a.trace_cap) trace[at] = e;
+              if (at < ap->trace_cap) trace[at] = e;
               else host->error = 2;
             }
           }
@@ -427,12 +437,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident_gm(HcChainArgs a) {
             h->gm_prob = next.carry_prob;
             h->first_info = s_first_info;
             h->first_raw = s_first_raw;
-            __hip_atomic_store(&h->done_seq, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (a.n_done) {
+            __hip_atomic_store(&h->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (ap->n_done) {
               __threadfence_system();
-              const unsigned before = atomicAdd(a.n_done, 1u);
-              if (before + 1u == gridDim.y && a.h_all_done)
-                __hip_atomic_store(a.h_all_done, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+              const unsigned before = atomicAdd(ap->n_done, 1u);
+              if (before + 1u == gridDim.y && ap->h_all_done)
+                __hip_atomic_store(ap->h_all_done, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
           }
         }
@@ -501,8 +511,9 @@ hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs) {
                                            : (const void *)k_hc_chain_resident_gm<512, 5, 4>);
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, shm);
   if (e != hipSuccess) return e;
-  const int by_waves = 2048 / nt;
+  const int by_waves = nt == 256 ? 6 : 2048 / nt;  // (three 168-VGPR waves per SIMD at 256 threads, four 128-VGPR ones else)
   per_cu = per_cu < by_waves ? per_cu : by_waves;
+  if (nt == 256 && per_cu > 3) per_cu = 3;
   if (per_cu > 6) per_cu = 6;
   *out_wgs = per_cu * cus;
   return hipSuccess;

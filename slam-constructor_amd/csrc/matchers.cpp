@@ -1595,6 +1595,7 @@ int slamhip_matcher_debug_stamps(slamhip_matcher *m, long long *out512) {
   if (!m->d_stamps) {
     SLAMHIP_CHECK(hipMalloc(&m->d_stamps, sizeof(long long) * 512));
     SLAMHIP_CHECK(hipMemset(m->d_stamps, 0, sizeof(long long) * 512));
+    SLAMHIP_CHECK(hipDeviceSynchronize());  // (hipMemset of device memory does not wait: the next match would race it)
     return SLAMHIP_OK;
   }
   SLAMHIP_CHECK(hipDeviceSynchronize());
