@@ -174,18 +174,26 @@ def roofline_valu(workload, avg_launch_us):
 # stamps of tools/hc_chain_stamps.py (profiles/r03_chain_stamps.txt).
 HC_LATENCY_MODEL_US = {"boundary": 1.45, "staged": 0.90, "replayed": 0.52, "pose": 0.50, "terms": 0.25, "stored": 0.20}
 HC_LATENCY_STAMPS_US = {"boundary": 1.85, "staged": 1.61, "replayed": 1.88, "pose": 0.69, "terms": 0.93, "stored": 0.89}
+# r04, the co-resident chain (csrc/hc_resident.hip): no kernel boundary and no staging -- the scores cross the chip as
+# granules: one write-through store, one hop (MI355X_MICROARCH.md handoff-1to1, idle: 0.8 us) and half a poll period;
+# stamps: tools/hc_resident_stamps.py (profiles/r04_resident_stamps.txt)
+HC_RESIDENT_MODEL_US = {"gather": 1.05, "replayed": 0.52, "pose": 0.50, "terms": 0.25, "sum_publish": 0.30}
+HC_RESIDENT_STAMPS_US = {"gather": 1.51, "replayed": 1.69, "pose": 0.67, "terms": 1.07, "sum_publish": 0.91, "loop": 0.32}
 
 
-def latency_model(ms_per_match, super_steps):
-    """achieved / model for the headline's real bound, the serial accept chain: a match is `super_steps` kernels in a
-    row, each a chain of dependent memory round trips, barriers and FP64 sequences that no amount of width shortens."""
+def latency_model(ms_per_match, super_steps, resident=False):
+    """achieved / model for the headline's real bound, the serial accept chain: a match is `super_steps` super-steps
+    in a row, each a chain of dependent memory round trips, barriers and FP64 sequences that no amount of width
+    shortens."""
     if not super_steps or not ms_per_match:
         return None
-    model = sum(HC_LATENCY_MODEL_US.values())
+    stages, stamps = (HC_RESIDENT_MODEL_US, HC_RESIDENT_STAMPS_US) if resident else (HC_LATENCY_MODEL_US, HC_LATENCY_STAMPS_US)
+    model = sum(stages.values())
     achieved = 1e3 * ms_per_match / super_steps
     return {"bound": "latency", "unit": "us per super-step", "model": model, "achieved": achieved,
             "frac": model / achieved, "super_steps_per_match": super_steps,
-            "model_stages_us": HC_LATENCY_MODEL_US, "stamped_stages_us": HC_LATENCY_STAMPS_US,
+            "form": "one co-resident launch per match" if resident else "a kernel per super-step",
+            "model_stages_us": stages, "stamped_stages_us": stamps,
             "note": "achieved = median ms per match / mean super-steps per match (includes the host's enqueue and the "
                     "result read-back); stamped = in-kernel wall_clock64 timeline of one scoring workgroup"}
 
@@ -762,9 +770,10 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
         pf_traffic, pf_traffic_src = load_traffic("pf")
         pf_roofline = {"bound": "hbm", "achieved": g_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": g_achieved / HBM_PEAK_GBS, "traffic": pf_traffic, "traffic_source": pf_traffic_src,
-                       "kernel": "k_hc_chain_step",
-                       "kernel_note": "one hill-climbing chain per particle on the device, all chains in shared "
-                                      "launches (GMapping OOPE: K3's one-pose body inside csrc/hc_chain.hip)",
+                       "kernel": "k_hc_chain_resident_gm" if g_launches <= 3 * 2 else "k_hc_chain_step",
+                       "kernel_note": "one hill-climbing chain per particle on the device (GMapping OOPE: K3's one-pose "
+                                      "body): ONE co-resident launch per step when all chains' workgroups fit the device "
+                                      "(csrc/hc_resident_gm.hip), else shared launches per super-step (csrc/hc_chain.hip)",
                        "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,
                        "avg_launch_us": 1e3 * g_ms / max(g_launches, 1),
                        "kernel_busy_frac": g_ms / (1e3 * dt_instr) if dt_instr > 0 else None,
@@ -1426,7 +1435,7 @@ def main():
             ctx.scan_store(j, s_["range"], c_, s__, s_["weight"])
         beams_of = [s_["range"].size for s_ in scenes]
         step_i = [0]
-        evaluated, plain_calls = [0], [0]
+        evaluated, plain_calls, super_steps = [0], [0], [0]
         # The timed step is the reference's process_scan (pose_enumeration_scan_matcher.h:31-77): the RAW scan comes in
         # from host memory, filter_scan (:38), the scan-point weights, the beam trigonometry and the copy to HBM are
         # INSIDE the step (slamhip_scan_filter_upload), then the match.  (`--resident-scan`: the r01-r03 form, the
@@ -1443,10 +1452,11 @@ def main():
         def account(k, kept):
             if k not in per_scene_stats or kind != "HC":  # (a Monte-Carlo matcher's engine runs on: no table)
                 st_ = m.stats()
-                per_scene_stats[k] = (st_["scorer_calls"], st_["poses_evaluated"])
-            c_, e_ = per_scene_stats[k]
+                per_scene_stats[k] = (st_["scorer_calls"], st_["poses_evaluated"], st_["launches"])
+            c_, e_, l_ = per_scene_stats[k]
             evaluated[0] += e_
             plain_calls[0] += c_
+            super_steps[0] += l_
             return c_ * kept
 
         def step_resident():
@@ -1473,7 +1483,7 @@ def main():
         step()
     if m is not None:
         step_i[0] = 0
-        evaluated[0] = plain_calls[0] = 0
+        evaluated[0] = plain_calls[0] = super_steps[0] = 0
     # Pass 1 -- the timed region: exactly K steps, no instrumentation.
     ctx.profile_enable(False)
     barrier()
@@ -1489,10 +1499,11 @@ def main():
     if os.environ.get("BENCH_DUMP_STEPS"):
         print("step_ms:", " ".join("%.3f" % x for x in step_ms), file=sys.stderr)
     timed_evaluated, timed_calls = (evaluated[0], plain_calls[0]) if m is not None else (0, 0)
+    timed_super_steps = super_steps[0] if m is not None else 0
     if m is not None:
         k_last = (step_i[0] - 1) % len(scenes)
         st_chk = m.stats()
-        if (st_chk["scorer_calls"], st_chk["poses_evaluated"]) != per_scene_stats[k_last]:
+        if (st_chk["scorer_calls"], st_chk["poses_evaluated"]) != per_scene_stats[k_last][:2]:
             print("bench.py: the matcher's counters of the last timed match differ from the scene's table", file=sys.stderr)
             sys.exit(6)
     # Pass 2 -- the same K steps again with a HIP event pair attached to every scoring dispatch
@@ -1560,6 +1571,7 @@ def main():
                      poses_evaluated_per_step=timed_evaluated / args.steps,
                      speculation_ratio=timed_evaluated / max(timed_calls, 1),
                      launches_per_step=st["launches"],
+                     super_steps_per_match=timed_super_steps / max(args.steps, 1),
                      accept_chain=(("on the device: one process_scan = ONE launch of co-resident workgroups that exchange "
                                     "their scores inside it and replay every super-step's speculation tree "
                                     "(csrc/hc_resident.hip)") if kernel_name == "k_hc_chain_resident" else
@@ -1641,7 +1653,8 @@ def main():
         if rv:
             out["roofline_valu"] = rv
         if on_device and kind == "HC" and "ms_per_match" in extra:
-            lm = latency_model(extra["ms_per_match"]["median"], k_launches / max(args.steps, 1))
+            lm = latency_model(extra["ms_per_match"]["median"], extra.get("super_steps_per_match"),
+                               resident=kernel_name == "k_hc_chain_resident")
             if lm:
                 out["latency_model"] = lm
         if ceiling is not None:

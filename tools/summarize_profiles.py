@@ -17,9 +17,9 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); SQ_BUSY_CYCLES / duration is printed beside it
 # dominant kernel of each leg (substring of the rocprof kernel name)
-LEG_KERNEL = {"hc": "k_hc_chain_step", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_step",
-              "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_", "world": "k_hc_chain_step",
-              "replicas": "k_hc_chain_step"}
+LEG_KERNEL = {"hc": "k_hc_chain_resident", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_resident_gm",
+              "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_", "world": "k_hc_chain_resident",
+              "replicas": "k_hc_chain_resident", "bf": "k_score_point"}
 lines = ["# rocprofv3 summaries, round tag `%s`\n" % tag,
          "Commands: `tools/profile.sh %s` -- one `rocprofv3 --kernel-trace --stats` run per leg of `bench.py` "
          "(`--legs none` = the headline alone, `--workload sweep`, `--workload mc`, `--legs pf`, `pf_update`, `pf_maps`, "
@@ -30,7 +30,7 @@ def short(name):
     return name.replace("void ", "").replace("slamhip::", "").replace("(anonymous namespace)::", "")[:72]
 
 
-for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world", "replicas"):
+for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world", "replicas", "bf"):
     st = os.path.join(src, name, "%s_kernel_stats.csv" % name)
     if not os.path.exists(st):
         continue
@@ -60,8 +60,8 @@ for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world",
                                 d["ms_per_step"]))
             else:
                 leg = {"pf": None, "pf_update": "with_map_update", "pf_maps": "with_particle_maps"}.get(name, name)
-                if name in ("cfg5", "world", "replicas"):
-                    obj = pd_.get({"world": "world_loop"}.get(name, name), {})
+                if name in ("cfg5", "world", "replicas", "bf"):
+                    obj = pd_.get({"world": "world_loop", "bf": "brute_force"}.get(name, name), {})
                     if name == "replicas":
                         lines.append("\nun-profiled replicas leg (`%s_%s_bench_unprofiled.json`): " % (tag, name) + "; ".join(
                             "K=%d %.3f ms/call = %.3g units/s (kernel frac %.3f)" %
@@ -74,8 +74,8 @@ for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world",
                         obj = obj.get(leg, {})
                 if obj:
                     lines.append("\nun-profiled line of this leg (`%s_%s_bench_unprofiled.json`): %.3f ms/step = %.0f %s\n"
-                                 % (tag, name, obj.get("ms_per_step", float("nan")), obj.get("value", float("nan")),
-                                    obj.get("unit", "")))
+                                 % (tag, name, obj.get("ms_per_step", obj.get("ms_per_match", obj.get("ms_per_scan", float("nan")))),
+                                    obj.get("value", float("nan")), obj.get("unit", "")))
     except Exception as e:  # noqa: BLE001
         lines.append("\n(bench line not captured: %s)\n" % e)
 dj = os.path.join(src, "default.plain.json")
@@ -83,13 +83,17 @@ if os.path.exists(dj) and os.path.getsize(dj) > 2:
     shutil.copy(dj, os.path.join(dst, "%s_default_bench_unprofiled.json" % tag))
     lines.append("The driver's command (`python bench.py`, every leg, CPU baselines): `%s_default_bench_unprofiled.json`.\n" % tag)
 
+rs_ = os.path.join(src, "resident_stamps.txt")
+if os.path.exists(rs_):
+    shutil.copy(rs_, os.path.join(dst, "%s_resident_stamps.txt" % tag))
+    lines.append("In-kernel timeline of the co-resident chain's super-step (`tools/hc_resident_stamps.py`): `%s_resident_stamps.txt`.\n" % tag)
 cs = os.path.join(src, "chain_stamps.txt")
 if os.path.exists(cs):
     shutil.copy(cs, os.path.join(dst, "%s_chain_stamps.txt" % tag))
     lines.append("In-kernel timeline of the hill-climbing chain's super-step (`tools/hc_chain_stamps.py`): `%s_chain_stamps.txt`.\n" % tag)
 
 traffic = {}
-PMC_KERNEL = {"hc": "k_hc_chain_step<0", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_step<2"}
+PMC_KERNEL = {"hc": "k_hc_chain_resident<0", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_resident_gm"}
 for wl in ("hc", "sweep", "mc", "pf"):
     for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
         f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
