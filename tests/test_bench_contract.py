@@ -50,7 +50,18 @@ def test_default_bench_line_contract():
     assert [r_["K"] for r_ in rep] == [1, 2, 4, 8, 16] and all(r_["matches_on_shared_launches"] == r_["K"] for r_ in rep[1:])  # (a batch of one is the lone chain)
     assert d["world_loop"]["cpu_baseline"]["kind"] == "reference"
     pf = d["particle_filter"]
-    assert pf["unit"] == "particles/s" and pf["scaling"] == "strong" and pf["roofline"]["kernel"] in ("k_hc_chain_step", "k_score_gmapping")
+    assert pf["unit"] == "particles/s" and pf["scaling"] == "strong"
+    assert pf["roofline"]["kernel"] in ("k_hc_chain_resident_gm", "k_hc_chain_step", "k_score_gmapping")
+    # r04: what the 1/2/4/8-rank curve is expected to look like, stated before the driver measures it
+    sm = [m_ for m_ in pf["scaling_model"]["by_ranks"] if "ranks" in m_]
+    assert [m_["ranks"] for m_ in sm] == [1, 2, 4, 8] and all(m_["predicted_ms_per_step"] > 0 for m_ in sm)
+    # r04: the timed step takes the raw scan, and the benchmarked scenes are checked against the reference's results
+    assert d["config"]["includes_filter_and_upload"] is True and d["config"]["ms_per_step_resident"] > 0
+    par = d["parity"]
+    assert par["scenes"] == 16 and par["traces_equal"] == 16 and par["filtered_counts_equal"] == 16 and par["max_rel_score"] <= 1e-9
+    assert d["roofline"]["kernel"] == "k_hc_chain_resident" and d["config"]["resident"]["gave_up"] == 0
+    bf = d["brute_force"]
+    assert bf["on_device"] and bf["poses_per_match"] == 201 * 201 + 1 and bf["fraction_of_flat_sweep_rate"] > 0.8
     assert pf["cpu_baseline"]["kind"] == "reference" and "4000x4000" in pf["cpu_baseline"]["sample"]
     for leg in ("with_map_update", "with_particle_maps"):
         k6 = pf[leg]["roofline_map_update"]
