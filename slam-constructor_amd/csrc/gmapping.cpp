@@ -530,8 +530,10 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
     // the step's own included -- are checked afterwards in particle order like the lock-step jobs'.
     const bool pf_chain_off = !ctx->filter_chains;  // (SLAMHIP_OPT_FILTER_CHAINS)
     // (per-particle maps: every chain gathers through its particle's tile table; measured, ms per step, chains /
-    // lock-step: 13 particles 0.74 / 0.89, 100 particles 1.66 / 1.64 -- so for shards of up to 64 particles)
-    const bool chains = !pf_chain_off && (!g->tp || act.size() <= 64) && g->cfg.pose_trig == SLAMHIP_POSE_TRIG_DEVICE && g->cfg.gm_window == 1 &&
+    // lock-step: 13 particles 0.74 / 0.89, 100 particles as a chain of kernels 1.66 / 1.64 -- so for shards of up to
+    // 64 particles, and -- r04 -- for as many as fit ONE co-resident launch: 100 particles 1.53 / 1.68; cfg5's 500
+    // do not fit, and in groups of 100 or 64 per launch they are slower than lock-step, 10.8 and 11.6 / 9.1 ms)
+    const bool chains = !pf_chain_off && (!g->tp || act.size() <= 64 || gm_multi_chain_fits_resident(ctx, (int)act.size())) && g->cfg.pose_trig == SLAMHIP_POSE_TRIG_DEVICE && g->cfg.gm_window == 1 &&
                         g->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->scan_n <= 1280 && ctx->low_latency &&
                         !ctx->stage_poses && g->prm.hc_failed_rounds_limit >= 1 && g->prm.hc_failed_rounds_limit <= 250;
     if (chains) {

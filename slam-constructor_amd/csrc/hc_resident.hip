@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     gran_store(g0, 0.0, 0ull, 0u);
   }
   const bool verify = a.verify != 0;
-  const bool stamp = a.stamps && slot == 1 && t == 0;
+  const bool stamp = a.stamps && slot == 1 && t == 0 && blockIdx.y == 0;
   HcGranule *const gran = &rc->gran[0][0];
   HcGranule *const gseq = &rc->seq[0][0];
   constexpr int kGranRow = kHcSlots + 7;

@@ -99,6 +99,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
   __shared__ double s_score;
   __shared__ GmPoseInfo s_first_info;  // (bookkeeping workgroup) side outputs and raw score of the initial pose
   __shared__ double s_first_raw;
+  // this thread's first beam (range, cos, sin), read once per match: kept in LDS, not in registers -- K3's one-pose
+  // body is at the register limit, and loop-carried registers were spilled to scratch and reloaded (a trip through
+  // memory) in front of every pose
+  __shared__ double s_beam[3 * NT];
   const int t = threadIdx.x, wave = t >> 6;
   const int slot = blockIdx.x + 1 == gridDim.x ? kHcSlots - 1 : (int)blockIdx.x;
   const int inst_of_slot = slot / 6, cand = slot - 6 * inst_of_slot;
@@ -111,11 +115,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       (const __attribute__((address_space(4))) HcChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   const ScanView scan = load_view(&ap0->scan);
   const int n = scan.n;
-  double br = 0.0, bc = 0.0, bs = 0.0;
-  if (t < n) {
-    br = scan.range[t];
-    bc = scan.cos_a[t];
-    bs = scan.sin_a[t];
+  {
+    double br0 = 0.0, bc0 = 0.0, bs0 = 0.0;
+    if (t < n) {
+      br0 = scan.range[t];
+      bc0 = scan.cos_a[t];
+      bs0 = scan.sin_a[t];
+    }
+    s_beam[t] = br0;
+    s_beam[NT + t] = bc0;
+    s_beam[2 * NT + t] = bs0;
   }
   if (wave == 1 && (t & 63) < kHcShapes && !init_slot) {
     const uint4 *src = reinterpret_cast<const uint4 *>(&a.shapes[t & 63].inst[inst_of_slot]);
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
     if (go) {
       const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
       double score = 0.0;
+      const double br = s_beam[tt], bc = s_beam[NT + tt], bs = s_beam[2 * NT + tt];
       gm_score_pose_wide<KB, NT>(map, scan, gmp, tiles, s_unknown, px, py, sn, cs, br, bc, bs, s_dyn, &s_run0_len, s_part,
                                  &s_gi, &score, (stamp && k < 64) ? &ap->stamps[8 * k + 4] : nullptr, tt);
       if (tt == 0) s_score = score;
@@ -304,8 +314,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       const bool active = lane < n_inst;
       const bool reach = active && (hc_is_root(me) || sp.failed + hc_nfail_parent(me) < ap->max_failed);
       const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), ap->max_failed);
-      HcRound rr{sp.x, sp.y, sp.theta, sp.dt, sp.dr, sp.failed};
-      if (reach) rr = hc_round_of(sp, me);
       double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
       HcCarry root_carry{sp.carry_cx, sp.carry_cy, sp.carry_prob};
       double first_raw = 0.0;
@@ -363,6 +371,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
 #pragma unroll
       for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
       if (stamp && k < 64) ap->stamps[8 * k + 7] = wall_clock64();
+      // (the round states are made AFTER the decisions here, unlike hc_resident.hip: the cache fix-ups above are at
+      // the register limit of a 1024-thread workgroup, and eleven live registers less is the difference to spilling)
+      HcRound rr{sp.x, sp.y, sp.theta, sp.dt, sp.dr, sp.failed};
+      if (valid) rr = hc_round_of(sp, me);
       HcRound rt;
       rt.x = bcast(rr.x, tl);
       rt.y = bcast(rr.y, tl);

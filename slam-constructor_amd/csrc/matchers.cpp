@@ -667,6 +667,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   a.ctl = b->d_ctl;
   a.inits = b->d_inits;
   a.n_done = b->d_n_done;
+  a.stamps = m->d_stamps;  // (debugging: chain 0's workgroup 1)
   a.shapes = b->d_shapes;
   for (int s = 0; s < kHcShapes; ++s) a.n_inst |= (unsigned long long)(b->shape_n_inst[s] & 0xff) << (8 * s);
   a.dt0 = m->hc_dt;
@@ -865,6 +866,17 @@ void gm_multi_chain_free(GmMultiChain *s) {
 // All chains advance one super-step per kernel (grid.y = chain); a chain that has ended leaves the launch at
 // once.  The host queues the kernels in bursts, each closed by a one-thread marker that reports how many chains
 // are through, and always has the next burst queued before it waits for a marker.
+// (the same sizing as gm_multi_chain_run's: one round instance per chain from 47 chains on, 256-thread workgroups)
+bool gm_multi_chain_fits_resident(slamhip_ctx *ctx, int n) {
+  if (!ctx->resident_chains || n <= 0 || ctx->scan_n > 1280) return false;
+  const int inst = std::min(kHcDefaultInst, std::max(1, 280 / (6 * n)));
+  const int total = n * (6 * inst + 1);
+  const int nt = total <= 256 ? 1024 : (total <= 512 ? 512 : 256);
+  int cap_wgs = 0;
+  if (hc_resident_gm_capacity(nt, ctx->scan_n, &cap_wgs) != hipSuccess) return false;
+  return total <= cap_wgs;
+}
+
 int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, const slamhip_spe_cfg *cfg,
                        unsigned max_failed, double dt, double dr, int n, const double *inits, GmChainResult *out,
                        long long *kernels_launched, const TiledTarget *tiled, const int *slots) {

@@ -276,4 +276,6 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
                        unsigned max_failed, double dt, double dr, int n, const double *inits, GmChainResult *out,
                        long long *kernels_launched, const TiledTarget *tiled = nullptr, const int *slots = nullptr);
 void gm_multi_chain_free(GmMultiChain *s);
+// whether gm_multi_chain_run would take n chains as ONE co-resident launch (hc_resident_gm.hip) on this context
+bool gm_multi_chain_fits_resident(slamhip_ctx *ctx, int n);
 }  // namespace slamhip

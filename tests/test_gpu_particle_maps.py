@@ -348,7 +348,7 @@ def test_cfg5_geometry_cached_provider_golden(pkg):
 def test_cfg5_geometry_against_the_oracle(pkg, oracle, pose_trig):
     """pose_trig 1: host pose trigonometry, host-driven lock-step jobs; 0 (the default, what bench.py runs): device
     sincos -- at six particles one accept chain per particle on the device, gathering through the particle's tile table
-    (the lock-step jobs of larger shards have test_cfg5_lock_step_through_tile_tables_70_particles below).
+    (the lock-step jobs of larger shards have test_cfg5_matching_through_tile_tables_beyond_64_particles below).
     BASELINE configs[4] at its own geometry: an 8000 x 8000 map at 0.025 m per cell, 1080 beams that walk up to
     1200 cells, AreaOccupancyEstimator, blur 0.1 m (four cells), per-particle copy-on-write maps, the map update
     fused behind the likelihood.  Six particles instead of five hundred (the oracle keeps a dense map per particle),
@@ -551,10 +551,13 @@ def _device_trig_scan(pkg, po, rng, ang):
     return tr
 
 
-def test_cfg5_lock_step_through_tile_tables_70_particles(pkg, oracle):
-    """What bench.py's cfg5 leg runs for its likelihood step, against the oracle: MORE than 64 particles with
-    per-particle maps and the default device pose trigonometry match through host-driven lock-step jobs whose K3
-    launches resolve every gather through the particle's tile table (csrc/gmapping.cpp: chains only up to 64).  Cell
+@pytest.mark.parametrize("n", [70, 120])
+def test_cfg5_matching_through_tile_tables_beyond_64_particles(pkg, oracle, n):
+    """What bench.py's cfg5 and pf_maps legs run for their likelihood step, against the oracle: MORE than 64 particles
+    with per-particle maps and the default device pose trigonometry.  120 particles match through host-driven
+    lock-step jobs whose K3 launches resolve every gather through the particle's tile table (cfg5's path); 70 fit ONE
+    co-resident launch of per-particle chains (csrc/gmapping.cpp: gm_multi_chain_fits_resident, r04 -- before, chains
+    only up to 64), which gather through the same tables.  Cell
     size 0.025 m, area estimator, blur 0.1 m.  So that every particle reads a DIFFERENT map, each one first takes the
     scan from its own jittered pose (one batched K6 here; the oracle appends with the device's trigonometry form, so
     the raw-provider caveat of the cfg5 geometry test cannot arise) -- sampled maps are compared bit for bit on the
@@ -563,7 +566,7 @@ def test_cfg5_lock_step_through_tile_tables_70_particles(pkg, oracle):
     import pyoracle as po
     from pyoracle_mapupdate import (gmapping_enable_particle_maps, gmapping_particle_map, gmapping_particle_map_append)
     from synth import make_scene
-    win, scale, n = 1280, 0.025, 70
+    win, scale = 1280, 0.025
     sc = make_scene(cell_model=2, size=win, scale=scale, n_beams=1080, seed=9, blur_m=0.1, max_dist=12.0)
     m, scan = sc["map"], sc["scan"]
     ctx = pkg.Context(0)
