@@ -68,8 +68,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   const bool init_slot = slot == kHcSlots - 1;
   HcResidentCtl *const rc = a.rctl + blockIdx.y;
   HcHostOut *const host = a.host + blockIdx.y;
-  // a workgroup that starts after the others have given up (it was not resident with them) leaves at once
-  if (__hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) return;
+  // a workgroup that starts after the others have given up (it was not resident with them) leaves at once -- the word
+  // is a trip to memory (agent scope), so it is only looked at below, once this thread's beam is on its way too
+  const unsigned fail_epoch_at_entry = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing: the others must give up, not hang)
   // this chain's map and scan: kernel arguments, or -- a batch of matches -- its entry of the job table
   MapViewCP map_p;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
   }
+  if (fail_epoch_at_entry == a.epoch) return;
   if (t == 0) s_stop = 0;
   if (t < 4) {  // this slot's granules of both parities start the match empty (see hc_tag)
     HcGranule *g0 = (t & 2) ? &rc->seq[t & 1][slot] : &rc->gran[t & 1][slot];
@@ -410,22 +412,25 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         if (!rescored) {
           // decisions from the canonical sums; a comparison closer than the two summation orders can differ
           // (2^-40, relative) between poses whose term vectors differ is one the tree sum cannot settle
+          int amb = 0;
 #pragma unroll
           for (int c = 0; c < 6; ++c) {
             const double s = s6[c];
             const double diff = __builtin_fabs(s - run);
             const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
-            const bool live = c == 0 || !trailing;
-            const bool close = diff <= (as > ab ? as : ab) * 9.094947017729282e-13;  // NaN: false, a rejection
+            const int live = (c == 0) | (int)!trailing;
+            const int close = (int)(diff <= (as > ab ? as : ab) * 9.094947017729282e-13);  // NaN: false, a rejection
             // (equal fingerprints with different sums: not identical vectors -- a collision, equally unsettled)
-            ambiguous = ambiguous || (live && close && (h6[c] != hb || __double_as_longlong(s) != __double_as_longlong(run)));
-            const bool acc = live && run < s;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
+            // (bitwise, not short-circuit: one straight line of compares instead of six nested exec-mask branches)
+            amb |= live & close & ((int)(h6[c] != hb) | (int)(__double_as_longlong(s) != __double_as_longlong(run)));
+            const bool acc = (live & (int)(run < s)) != 0;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
             run = acc ? s : run;
             hb = acc ? h6[c] : hb;
             out = acc ? c + 1 : out;
             nacc += acc ? 1 : 0;
             accmask |= acc ? 1u << c : 0u;
           }
+          ambiguous = amb != 0;
         } else {
           // re-scored tree: the same comparisons on the beam-order sums.  Their granules were stored next to the
           // canonical ones by other lanes: wait for their tags as well, one granule at a time (the rare step: a
@@ -569,7 +574,30 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           }
         }
       }
-      if (lane == 0) s_st = next;  // (`sp` above is this very object: the books are kept from the old state first)
+      if (lane == 0) {
+        // (`sp` above is this very object: the books are kept from the old state first.  Field by field, and only what
+        // a super-step changes: the whole struct assigned went through scratch -- a store and a load through memory
+        // between two super-steps -- for the GMapping carry fields this kernel never touches)
+        HcState &w = s_st;
+        w.x = next.x;
+        w.y = next.y;
+        w.theta = next.theta;
+        w.best_prob = next.best_prob;
+        w.dt = next.dt;
+        w.dr = next.dr;
+        w.recent_acc = next.recent_acc;
+        w.recent_n = next.recent_n;
+        w.calls = next.calls;
+        w.evaluated = next.evaluated;
+        w.failed = next.failed;
+        w.shape = next.shape;
+        w.done = next.done;
+        w.first = next.first;
+        w.steps = next.steps;
+        w.mode = next.mode;
+        w.best_hash = next.best_hash;
+        w.rescored = next.rescored;
+      }
     }
   }
 }

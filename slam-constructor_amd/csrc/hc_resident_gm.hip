@@ -459,7 +459,30 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
           }
         }
       }
-      if (lane == 0) s_st = next;
+      if (lane == 0) {
+        // (field by field, only what a super-step changes: the struct assigned as a whole went through scratch -- see
+        // hc_resident.hip)
+        HcState &w = s_st;
+        w.x = next.x;
+        w.y = next.y;
+        w.theta = next.theta;
+        w.best_prob = next.best_prob;
+        w.dt = next.dt;
+        w.dr = next.dr;
+        w.recent_acc = next.recent_acc;
+        w.recent_n = next.recent_n;
+        w.calls = next.calls;
+        w.evaluated = next.evaluated;
+        w.failed = next.failed;
+        w.shape = next.shape;
+        w.done = next.done;
+        w.first = next.first;
+        w.steps = next.steps;
+        w.mode = next.mode;
+        w.carry_cx = next.carry_cx;
+        w.carry_cy = next.carry_cy;
+        w.carry_prob = next.carry_prob;
+      }
     }
   }
 }
