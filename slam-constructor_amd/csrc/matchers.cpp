@@ -459,6 +459,10 @@ struct HcBatch {
   int cap = 0;
   slamhip::HcChainCtl *d_ctl = nullptr;
   slamhip::HcHostOut *h_out = nullptr;     // pinned, one per chain
+  // one block per side -- {chains-done counter (0), initial poses, job table} -- that ONE pull kernel moves in front of a
+  // launch (launch_block_pull); the pointers below point into it
+  char *h_stage = nullptr, *d_stage = nullptr;
+  size_t stage_jobs_at = 0;
   slamhip::HcJobView *h_jobs = nullptr, *d_jobs = nullptr;  // pinned staging / HBM
   double *h_inits = nullptr, *d_inits = nullptr;
   double *h_scan = nullptr, *d_scan = nullptr;  // the batch's scans: per match five arrays of its beam count
@@ -485,14 +489,11 @@ void hc_batch_free(slamhip_matcher *m) {
   if (!b) return;
   if (b->d_ctl) hipFree(b->d_ctl);
   if (b->h_out) hipHostFree(b->h_out);
-  if (b->h_jobs) hipHostFree(b->h_jobs);
-  if (b->d_jobs) hipFree(b->d_jobs);
-  if (b->h_inits) hipHostFree(b->h_inits);
-  if (b->d_inits) hipFree(b->d_inits);
+  if (b->h_stage) hipHostFree(b->h_stage);
+  if (b->d_stage) hipFree(b->d_stage);
   if (b->h_scan) hipHostFree(b->h_scan);
   if (b->d_scan) hipFree(b->d_scan);
   if (b->d_shapes) hipFree(b->d_shapes);
-  if (b->d_n_done) hipFree(b->d_n_done);
   if (b->h_done_count) hipHostFree(b->h_done_count);
   if (b->d_rctl) hipFree(b->d_rctl);
   if (b->h_all_done) hipHostFree(b->h_all_done);
@@ -523,7 +524,6 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   HcBatch *b = m->batch;
   if (!b->d_shapes) {
     SLAMHIP_CHECK(hipMalloc(&b->d_shapes, sizeof(HcShape) * kHcShapes));
-    SLAMHIP_CHECK(hipMalloc(&b->d_n_done, sizeof(unsigned)));
     SLAMHIP_CHECK(hipHostMalloc(&b->h_done_count, sizeof(unsigned), pinned));
   }
   {
@@ -547,27 +547,38 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (b->d_ctl) hipFree(b->d_ctl);
     if (b->h_out) hipHostFree(b->h_out);
-    if (b->h_jobs) hipHostFree(b->h_jobs);
-    if (b->d_jobs) hipFree(b->d_jobs);
-    if (b->h_inits) hipHostFree(b->h_inits);
-    if (b->d_inits) hipFree(b->d_inits);
+    if (b->h_stage) hipHostFree(b->h_stage);
+    if (b->d_stage) hipFree(b->d_stage);
     if (b->d_rctl) hipFree(b->d_rctl);
     b->d_rctl = nullptr;
     b->rctl_grid = b->rctl_chains = 0;
     b->d_ctl = nullptr;
     b->h_out = nullptr;
+    b->h_stage = b->d_stage = nullptr;
     b->h_jobs = b->d_jobs = nullptr;
     b->h_inits = b->d_inits = nullptr;
+    b->d_n_done = nullptr;
     int cap = 8;
     while (cap < n) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&b->d_ctl, sizeof(HcChainCtl) * cap));
     SLAMHIP_CHECK(hipMemset(b->d_ctl, 0, sizeof(HcChainCtl) * cap));
     SLAMHIP_CHECK(hipHostMalloc(&b->h_out, sizeof(HcHostOut) * cap, pinned));
     std::memset(b->h_out, 0, sizeof(HcHostOut) * cap);
-    SLAMHIP_CHECK(hipHostMalloc(&b->h_jobs, sizeof(HcJobView) * cap, hipHostMallocDefault));
-    SLAMHIP_CHECK(hipMalloc(&b->d_jobs, sizeof(HcJobView) * cap));
-    SLAMHIP_CHECK(hipHostMalloc(&b->h_inits, sizeof(double) * 3 * cap, hipHostMallocDefault));
-    SLAMHIP_CHECK(hipMalloc(&b->d_inits, sizeof(double) * 3 * cap));
+    {
+      // [0, 16): the chains-done counter; then the initial poses; then the job table (a pull copies the front of the
+      // block up to the last job in use)
+      b->stage_jobs_at = 16 + ((sizeof(double) * 3 * (size_t)cap + 15) & ~(size_t)15);
+      const size_t bytes = b->stage_jobs_at + ((sizeof(HcJobView) * (size_t)cap + 15) & ~(size_t)15);
+      SLAMHIP_CHECK(hipHostMalloc(&b->h_stage, bytes, hipHostMallocMapped));
+      std::memset(b->h_stage, 0, bytes);
+      SLAMHIP_CHECK(hipMalloc(&b->d_stage, bytes));
+      SLAMHIP_CHECK(hipMemset(b->d_stage, 0, bytes));
+      b->d_n_done = reinterpret_cast<unsigned *>(b->d_stage);
+      b->h_inits = reinterpret_cast<double *>(b->h_stage + 16);
+      b->d_inits = reinterpret_cast<double *>(b->d_stage + 16);
+      b->h_jobs = reinterpret_cast<HcJobView *>(b->h_stage + b->stage_jobs_at);
+      b->d_jobs = reinterpret_cast<HcJobView *>(b->d_stage + b->stage_jobs_at);
+    }
     b->cap = cap;
   }
   if (m->has_obs && b->trace_chains < b->cap) {
@@ -652,9 +663,8 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   }
   hipStream_t st = ctx->stream;
   if (at) SLAMHIP_CHECK(hipMemcpyAsync(b->d_scan, b->h_scan, sizeof(double) * at, hipMemcpyHostToDevice, st));
-  SLAMHIP_CHECK(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(HcJobView) * n, hipMemcpyHostToDevice, st));
-  SLAMHIP_CHECK(hipMemcpyAsync(b->d_inits, b->h_inits, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-  SLAMHIP_CHECK(hipMemsetAsync(b->d_n_done, 0, sizeof(unsigned), st));
+  // (counter = 0, initial poses, job table: one pull of the pinned block)
+  SLAMHIP_CHECK(launch_block_pull(b->h_stage, b->d_stage, b->stage_jobs_at + sizeof(HcJobView) * (size_t)n, st));
   HcChainArgs a;
   std::memset(&a, 0, sizeof(a));
   a.jobs = b->d_jobs;
@@ -835,6 +845,10 @@ struct GmMultiChain {
   double *h_inits = nullptr;     // pinned staging of the initial poses
   double *d_inits = nullptr;
   int *d_slots = nullptr;        // tile-pool slot of every chain (per-particle maps)
+  // {chains-done counter (0), initial poses, slots}: one pinned block, one pull kernel in front of a launch
+  char *h_stage = nullptr, *d_stage = nullptr;
+  size_t stage_slots_at = 0;
+  int *h_slots = nullptr;
   HcResidentGmCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain
   unsigned *h_all_done = nullptr;     // pinned: the last chain to end stores the epoch here
   int rctl_grid = 0, rctl_chains = 0, gave_up_row = 0;
@@ -855,10 +869,8 @@ void gm_multi_chain_free(GmMultiChain *s) {
   if (s->d_ctl) hipFree(s->d_ctl);
   if (s->d_shapes) hipFree(s->d_shapes);
   if (s->h_out) hipHostFree(s->h_out);
-  if (s->h_inits) hipHostFree(s->h_inits);
-  if (s->d_inits) hipFree(s->d_inits);
-  if (s->d_slots) hipFree(s->d_slots);
-  if (s->d_n_done) hipFree(s->d_n_done);
+  if (s->h_stage) hipHostFree(s->h_stage);
+  if (s->d_stage) hipFree(s->d_stage);
   if (s->h_done_count) hipHostFree(s->h_done_count);
   delete s;
 }
@@ -888,7 +900,6 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     s->device = ctx->device;
     *scratch = s;
     SLAMHIP_CHECK(hipMalloc(&s->d_shapes, sizeof(HcShape) * kHcShapes));
-    SLAMHIP_CHECK(hipMalloc(&s->d_n_done, sizeof(unsigned)));
     SLAMHIP_CHECK(hipHostMalloc(&s->h_done_count, sizeof(unsigned), pinned));
   }
   GmMultiChain *s = *scratch;
@@ -924,13 +935,14 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (s->d_ctl) hipFree(s->d_ctl);
     if (s->h_out) hipHostFree(s->h_out);
-    if (s->h_inits) hipHostFree(s->h_inits);
-    if (s->d_inits) hipFree(s->d_inits);
-    if (s->d_slots) hipFree(s->d_slots);
+    if (s->h_stage) hipHostFree(s->h_stage);
+    if (s->d_stage) hipFree(s->d_stage);
     if (s->d_rctl) hipFree(s->d_rctl);
     s->d_rctl = nullptr;
     s->rctl_grid = s->rctl_chains = 0;
-    s->d_slots = nullptr;
+    s->h_stage = s->d_stage = nullptr;
+    s->d_slots = s->h_slots = nullptr;
+    s->d_n_done = nullptr;
     s->d_ctl = nullptr;
     s->h_out = nullptr;
     s->h_inits = nullptr;
@@ -941,9 +953,19 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     SLAMHIP_CHECK(hipMemset(s->d_ctl, 0, sizeof(HcChainCtl) * cap));
     SLAMHIP_CHECK(hipHostMalloc(&s->h_out, sizeof(HcHostOut) * cap, pinned));
     std::memset(s->h_out, 0, sizeof(HcHostOut) * cap);
-    SLAMHIP_CHECK(hipHostMalloc(&s->h_inits, sizeof(double) * 3 * cap, hipHostMallocDefault));
-    SLAMHIP_CHECK(hipMalloc(&s->d_inits, sizeof(double) * 3 * cap));
-    SLAMHIP_CHECK(hipMalloc(&s->d_slots, sizeof(int) * cap));
+    {
+      s->stage_slots_at = 16 + ((sizeof(double) * 3 * (size_t)cap + 15) & ~(size_t)15);
+      const size_t bytes = s->stage_slots_at + ((sizeof(int) * (size_t)cap + 15) & ~(size_t)15);
+      SLAMHIP_CHECK(hipHostMalloc(&s->h_stage, bytes, hipHostMallocMapped));
+      std::memset(s->h_stage, 0, bytes);
+      SLAMHIP_CHECK(hipMalloc(&s->d_stage, bytes));
+      SLAMHIP_CHECK(hipMemset(s->d_stage, 0, bytes));
+      s->d_n_done = reinterpret_cast<unsigned *>(s->d_stage);
+      s->h_inits = reinterpret_cast<double *>(s->h_stage + 16);
+      s->d_inits = reinterpret_cast<double *>(s->d_stage + 16);
+      s->h_slots = reinterpret_cast<int *>(s->h_stage + s->stage_slots_at);
+      s->d_slots = reinterpret_cast<int *>(s->d_stage + s->stage_slots_at);
+    }
     s->cap = cap;
   }
   HcChainArgs a;
@@ -955,7 +977,7 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     a.tables = tiled->tables;
     a.table_stride = tiled->table_stride;
     a.slots = s->d_slots;
-    SLAMHIP_CHECK(hipMemcpyAsync(s->d_slots, slots, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    std::memcpy(s->h_slots, slots, sizeof(int) * n);
   }
   a.oie = cfg->oie;
   a.max_inst = s->max_inst;
@@ -981,8 +1003,10 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     ((volatile HcHostOut *)s->h_out)[c].error = 0;
     ((volatile HcHostOut *)s->h_out)[c].progress = 0;
   }
-  SLAMHIP_CHECK(hipMemcpyAsync(s->d_inits, s->h_inits, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
-  SLAMHIP_CHECK(hipMemsetAsync(s->d_n_done, 0, sizeof(unsigned), ctx->stream));
+  // (counter = 0, initial poses, tile-pool slots: one pull of the pinned block)
+  SLAMHIP_CHECK(launch_block_pull(s->h_stage, s->d_stage,
+                                  tiled ? s->stage_slots_at + sizeof(int) * (size_t)n : 16 + sizeof(double) * 3 * (size_t)n,
+                                  ctx->stream));
   int launched = 0;
   // ---- ONE launch for all chains (hc_resident_gm.hip) when their workgroups fit the device at once: every
   // particle's chain then advances at its own pace instead of in lock-step launches

@@ -100,6 +100,23 @@ hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles
   return hipGetLastError();
 }
 
+// The same for a launch's small argument blocks (job tables, initial poses, a zeroed counter): ONE pull of the pinned
+// block in front of the launch instead of several hipMemcpyAsync / hipMemsetAsync calls (each ~6 us of host time and
+// ~10 us of stream time, see above).  The host rewrites the block only after the launch that follows has reported its
+// results, so nobody needs to be told that it has been read.
+__global__ __launch_bounds__(256) void k_block_pull(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+
+hipError_t launch_block_pull(const void *h_src, void *d_dst, size_t bytes, hipStream_t stream) {
+  const int n16 = (int)((bytes + 15) / 16);
+  if (n16 <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_block_pull, dim3((n16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(h_src),
+                     reinterpret_cast<uint4 *>(d_dst), n16);
+  return hipGetLastError();
+}
+
 // ---- K1 ----------------------------------------------------------------------------------------
 // KB > 0: beams per thread known at compile time (n <= 256*KB), constants live in VGPRs.
 // KB == 0: generic (any n): constants re-read from L1/L2 in the pose loop.

@@ -89,6 +89,8 @@ hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_or
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream);
 hipError_t launch_stall(int ms, hipStream_t stream);  // testing
 // n_doubles (rounded up to two) from pinned host memory to HBM by a kernel; *h_flag = seq once the source has been read
+// bytes rounded up to 16: both blocks must be that long
+hipError_t launch_block_pull(const void *h_src, void *d_dst, size_t bytes, hipStream_t stream);
 hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles, unsigned *counter, unsigned *h_flag,
                             unsigned seq, hipStream_t stream);
 hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
