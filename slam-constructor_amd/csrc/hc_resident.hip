@@ -52,7 +52,8 @@ constexpr int kSumLanes = 256;          // the canonical sum's partials (= k_sco
 // (four waves per SIMD whatever the workgroup size: 128 VGPRs, so that 4 x 256, 2 x 512 or 1 x 1024 threads share a CU)
 template <int MODEL, int NT, bool SEQ, bool BATCH, int G, bool WIN = false>
 __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
-  extern __shared__ double s_term[];  // one term per beam
+  extern __shared__ double s_term[];  // one term per beam; behind them, for workgroups narrower than the scan: range,
+                                      // cosine, sine of every beam (hc_resident_lds_bytes)
   __shared__ unsigned long long s_hash[kHcSlots + 7];  // (48 bits each)
   __shared__ double s_sc[kHcSlots + 7];
   __shared__ HcInst s_mine[kHcShapes];  // this workgroup's round instance in every shape
@@ -104,6 +105,21 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     uint4 *dst = reinterpret_cast<uint4 *>(&s_mine[t & 63]);
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
+  }
+  // A thread scores up to five beams, and 1080 beams on 1024 threads give the first 56 threads a second one.  What
+  // the cell ADDRESS of those further beams depends on -- range, cosine, sine -- is kept in LDS for the whole match
+  // (the host asks for it when the workgroups still fit the device with that much LDS, HcChainArgs::lds_consts): read
+  // from memory, as weight and factor still are, it was a round trip in front of the gathers' own in every
+  // super-step (r04, super-step of a lone chain, us: 256 threads 7.3 -> 6.6, 512 6.3 -> 6.1).
+  const bool ldsc = !WIN && a.lds_consts != 0;
+  const int n_more = n > NT ? n - NT : 0;
+  double *const s_r = s_term + n - NT, *const s_ca = s_r + n_more, *const s_sa = s_ca + n_more;  // (indexed by beam >= NT)
+  if (ldsc) {
+    for (int b = NT + t; b < n; b += NT) {
+      s_r[b] = scan.range[b];
+      s_ca[b] = scan.cos_a[b];
+      s_sa[b] = scan.sin_a[b];
+    }
   }
   if (fail_epoch_at_entry == a.epoch) return;
   if (t == 0) s_stop = 0;
@@ -216,11 +232,14 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           s_term[b] = window_probability<MODEL>(map, ap->oie, ap->oope, half_v, half_h, ox, oy) * w * f;
         }
       } else {
-        for (int base = t; base < n; base += 4 * NT) {
-          double4 cell[4];
-          double w_[4], f_[4];
+        // (five beams of a 256-thread workgroup at a time: 1080 beams are then ONE round of gathers for every wave -- with
+        // four, wave 0 went round twice for its 56 surplus beams while fifteen waves waited at the barrier)
+        constexpr int UNR = NT == 256 ? 5 : 4;
+        for (int base = t; base < n; base += UNR * NT) {
+          double4 cell[UNR];
+          double w_[UNR], f_[UNR];
   #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < UNR; ++j) {
             const int b = base + j * NT;
             w_[j] = 0.0;
             f_[j] = 0.0;
@@ -231,16 +250,16 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             w_[j] = bw;
             f_[j] = bf;
             if (j > 0 || base != t) {
-              r_ = scan.range[bc_];
-              ca = scan.cos_a[bc_];
-              sa = scan.sin_a[bc_];
+              r_ = ldsc ? s_r[bc_] : scan.range[bc_];
+              ca = ldsc ? s_ca[bc_] : scan.cos_a[bc_];
+              sa = ldsc ? s_sa[bc_] : scan.sin_a[bc_];
               w_[j] = scan.weight[bc_];
               f_[j] = scan.factor[bc_];
             }
             cell[j] = beam_cell<MODEL>(map, px, py, sn, cs, r_, ca, sa);
           }
   #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < UNR; ++j) {
             const int b = base + j * NT;
             if (b < n) s_term[b] = cell_probability<MODEL>(ap->oie, cell[j]) * w_[j] * f_[j];
           }
@@ -602,6 +621,14 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   }
 }
 
+// dynamic LDS of a workgroup: the beams' terms and, with lds_consts, range, cosine and sine of the beams behind every
+// thread's first one
+size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts) {
+  const size_t n = (size_t)(n_beams > 0 ? n_beams : 1);
+  const size_t more = lds_consts && n > (size_t)nt ? n - (size_t)nt : 0;
+  return sizeof(double) * (n + 3 * more);
+}
+
 #define HCR_LAUNCH(NTV, GV)                                                                                     \
   do {                                                                                                          \
     if (e0 || e1)                                                                                               \
@@ -627,7 +654,7 @@ static hipError_t launch_res_win(const HcChainArgs &a, int nt, hipStream_t strea
                                  int n_chains) {
   const int grid = 6 * a.max_inst + 1;
   if (grid > 256) return hipErrorInvalidValue;
-  const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
+  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, false);  // (the window form keeps no beam constants in LDS)
   if (nt == 1024) HCR_LAUNCH_WIN(1024);
   else if (nt == 256) HCR_LAUNCH_WIN(256);
   else HCR_LAUNCH_WIN(512);
@@ -639,7 +666,7 @@ template <int MODEL, bool SEQ, bool BATCH>
 static hipError_t launch_res(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                              int n_chains) {
   const int grid = 6 * a.max_inst + 1;
-  const size_t shm = sizeof(double) * (size_t)(a.scan.n > 0 ? a.scan.n : 1);
+  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, a.lds_consts != 0);
   const int g = gran_per_lane(grid);
   // (workgroup sizes and sweep widths that go together: a lone chain is 253 x 1024 threads, a batch's chains are
   // narrower trees of narrower workgroups)
@@ -684,10 +711,11 @@ hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt
   return hipErrorInvalidValue;
 }
 
-// workgroups of `nt` threads (with `lds_bytes` of dynamic LDS) the device keeps resident at once, by the occupancy
+// workgroups of `nt` threads (scoring `n_beams`: hc_resident_lds_bytes of dynamic LDS) the device keeps resident at once, by the occupancy
 // query with the register-file rule of MI355X_MICROARCH.md ("Residency and cooperative launch": the API can be one
 // block per CU high above 80 SGPRs; this kernel's waves also need <= 128 VGPRs at 1024 threads) and one CU of margin
-hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, size_t lds_bytes, int *out_wgs) {
+hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, int n_beams, bool lds_consts, int *out_wgs) {
+  const size_t lds_bytes = hc_resident_lds_bytes(nt, n_beams, lds_consts);
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;

@@ -39,7 +39,8 @@ struct slamhip_matcher {
   // size; 0 = not asked yet), matches that gave up in a row / in total (bounded spin ran out: kernel chain instead)
   slamhip::HcResidentCtl *d_rctl = nullptr;
   slamhip::HcResidentGmCtl *d_rctl_gm = nullptr;
-  int resident_cap[3] = {0, 0, 0};
+  int resident_cap[6] = {0, 0, 0, 0, 0, 0};        // by workgroup size, without / with the beam constants in LDS
+  int resident_cap_beams[6] = {0, 0, 0, 0, 0, 0};  // the scan length the capacity was asked for
   int resident_gave_up_row = 0;
   int debug_resident_mute = 0;  // testing (slamhip_matcher_debug_resident_mute)
   long long resident_gave_up = 0, resident_matches = 0;
@@ -218,15 +219,31 @@ bool resident_wanted(slamhip_matcher *m) {
   return m->chain_mode == 2 && (m->cfg.oope == SLAMHIP_OOPE_OBSTACLE || is_window_oope(m->cfg.oope) || gm) &&
          m->resident_gave_up_row < 3;
 }
-int resident_capacity(slamhip_matcher *m, int cell_model, int nt, bool batch, size_t lds, int *wgs) {
-  const int idx = nt == 1024 ? 2 : (nt == 512 ? 1 : 0);
-  if (m->resident_cap[idx] == 0) {
+int resident_capacity(slamhip_matcher *m, int cell_model, int nt, bool batch, int n_beams, bool lds_consts, int *wgs) {
+  const int idx = (nt == 1024 ? 2 : (nt == 512 ? 1 : 0)) + (lds_consts ? 3 : 0);
+  if (m->resident_cap[idx] == 0 || n_beams > m->resident_cap_beams[idx]) {  // (a longer scan: more LDS per workgroup)
     int cap = 0;
-    SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, batch, lds, &cap));
+    SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, batch, n_beams, lds_consts, &cap));
     m->resident_cap[idx] = cap > 0 ? cap : -1;
+    m->resident_cap_beams[idx] = n_beams;
   }
   *wgs = m->resident_cap[idx] > 0 ? m->resident_cap[idx] : 0;
   return SLAMHIP_OK;
+}
+// the 1-cell form keeps the further beams' constants in LDS (HcChainArgs::lds_consts) when `wgs_needed` workgroups
+// are resident together with that much LDS each
+int resident_capacity_pick(slamhip_matcher *m, int cell_model, int nt, bool batch, int n_beams, int wgs_needed,
+                           bool may_lds_consts, int *lds_consts, int *wgs) {
+  *lds_consts = 0;
+  if (may_lds_consts) {
+    int rc = resident_capacity(m, cell_model, nt, batch, n_beams, true, wgs);
+    if (rc) return rc;
+    if (wgs_needed <= *wgs) {
+      *lds_consts = 1;
+      return SLAMHIP_OK;
+    }
+  }
+  return resident_capacity(m, cell_model, nt, batch, n_beams, false, wgs);
 }
 
 int chain_prepare(slamhip_matcher *m) {
@@ -310,7 +327,8 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
     const bool gm_res = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
     int cap = 0;
     if (gm_res) SLAMHIP_CHECK(hc_resident_gm_capacity(m->chain_nt, a.scan.n, &cap));
-    else rc = resident_capacity(m, cell_model, m->chain_nt, false, sizeof(double) * (size_t)std::max(a.scan.n, 1), &cap);
+    else rc = resident_capacity_pick(m, cell_model, m->chain_nt, false, a.scan.n, 6 * a.max_inst + 1,
+                                     !is_window_oope(m->cfg.oope), &a.lds_consts, &cap);
     if (rc) return rc;
     if (6 * a.max_inst + 1 > cap) return kResidentGaveUp;  // (not counted: this matcher's grid never fits)
     if (gm_res && !m->d_rctl_gm) {
@@ -702,7 +720,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   b->ran_resident = false;
   if (resident_wanted(m) && !a.seq) {
     int cap_wgs = 0;
-    int rc0 = resident_capacity(m, cell_model, b->nt, true, sizeof(double) * (size_t)std::max(max_n, 1), &cap_wgs);
+    int rc0 = resident_capacity_pick(m, cell_model, b->nt, true, max_n, n * (6 * b->max_inst + 1), true, &a.lds_consts, &cap_wgs);
     if (rc0) return rc0;
     if (n * (6 * b->max_inst + 1) <= cap_wgs) {
       if (!b->d_rctl) {
