@@ -1423,7 +1423,7 @@ def main():
         if args.chain >= 0 and kind in ("HC", "MC"):
             m.set_device_chain((args.chain_mode if args.chain_mode > 0 else 2) if args.chain else 0,
                                args.chain if args.chain > 1 else 0)
-        elif args.chain_mode > 0 and kind == "HC":
+        elif args.chain_mode > 0 and kind in ("HC", "MC"):
             m.set_device_chain(args.chain_mode)
         if args.no_tie_check:
             m.set_tie_check(0)
@@ -1558,8 +1558,9 @@ def main():
                       "scenes_differing": bad + kept_bad}
         st = m.stats()
         if on_device:
-            resident = kind == "HC" and m.resident_stats()["matches"] > 0
-            kernel_name = ("k_hc_chain_resident" if resident else "k_hc_chain_step") if kind == "HC" else "k_mc_chain_step"
+            resident = m.resident_stats()["matches"] > 0
+            kernel_name = (("k_hc_chain_resident" if resident else "k_hc_chain_step") if kind == "HC" else
+                           ("k_mc_chain_resident" if resident else "k_mc_chain_step"))
             if resident:
                 extra.update(resident=m.resident_stats())
         sm = np.sort(np.asarray(step_ms))
@@ -1574,7 +1575,7 @@ def main():
                      super_steps_per_match=timed_super_steps / max(args.steps, 1),
                      accept_chain=(("on the device: one process_scan = ONE launch of co-resident workgroups that exchange "
                                     "their scores inside it and replay every super-step's speculation tree "
-                                    "(csrc/hc_resident.hip)") if kernel_name == "k_hc_chain_resident" else
+                                    "(csrc/hc_resident.hip, csrc/mc_resident.hip)") if resident else
                                    ("on the device: one process_scan = a chain of kernels, each replaying the previous "
                                     "one's speculation tree (csrc/hc_chain.hip, csrc/mc_chain.hip)")) if on_device else
                                   "on the host: speculative batches, replay between launches",

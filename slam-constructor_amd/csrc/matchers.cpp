@@ -1461,6 +1461,84 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   h->error = 0;
   h->progress = 0;
   int launched = 0;
+  bool ahead_done = false;
+  // polar pairs of the next match while this one runs: generated a few at a time, uploaded once they are there
+  auto fill_ahead = [&]() -> int {
+    if (ahead_done) {
+      __builtin_ia32_pause();
+      return SLAMHIP_OK;
+    }
+    pe->prefetch_ahead(2 * need, 32);
+    if (pe->tape_generated_upto() >= pos + 2 * need) {
+      if (pos + 2 * need <= m->tape_base + m->tape_cap) {
+        int r = upload_upto(pos + 2 * need);
+        if (r) return r;
+      }
+      ahead_done = true;
+    }
+    return SLAMHIP_OK;
+  };
+  // ---- ONE launch (mc_resident.hip): every workgroup of the super-step stays on the chip for the whole match
+  bool ran_resident = false;
+  if (m->chain_mode == 2 && m->resident_gave_up_row < 3) {
+    int cap = 0;
+    // (1024-thread workgroups are resident one per CU: 252 candidates per super-step then, like the hill-climbing tree)
+    if (m->chain_nt == 1024) a.n_slots = std::min(a.n_slots, 252);
+    a.lds_consts = 1;
+    SLAMHIP_CHECK(mc_resident_capacity(cell_model, m->chain_nt, a.scan.n, true, &cap));
+    if (a.n_slots + 1 > cap) {
+      a.lds_consts = 0;
+      SLAMHIP_CHECK(mc_resident_capacity(cell_model, m->chain_nt, a.scan.n, false, &cap));
+    }
+    if (a.n_slots + 1 <= cap) {
+      if (!m->d_rctl) {
+        SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
+        SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));  // (ordered with the launch)
+      }
+      a.rctl = m->d_rctl;
+      a.debug_mute = m->debug_resident_mute;
+      a.stamps = m->d_stamps;
+      hipEvent_t e0, e1;
+      rc = profile_event_pair(ctx, &e0, &e1);
+      if (rc) return rc;
+      SLAMHIP_CHECK(launch_mc_chain_resident(a, cell_model, m->chain_nt, ctx->stream, e0, e1));
+      launched = 1;
+      ++m->resident_matches;
+      unsigned long long rspins = 0;
+      while (h->done_seq != epoch) {
+        rc = fill_ahead();
+        if (rc) return rc;
+        if ((++rspins & 0xfffffull) == 0) {
+          hipError_t qe = hipStreamQuery(ctx->stream);
+          if (qe == hipSuccess && h->done_seq != epoch) {
+            set_error("internal: the co-resident Monte-Carlo chain ended without publishing a result");
+            return SLAMHIP_ERR_STATE;
+          }
+          if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "co-resident Monte-Carlo chain");
+        }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      if (h->error == 4 || h->error == 5) {
+        // a workgroup was not resident with the others (the bounded sweep ran out), or the chain is longer than a tag
+        // counts: nothing has been reported and the enumerator has not been touched; wait for the stragglers to
+        // leave, then the chain of kernels runs the match under a new epoch
+        SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (h->error == 4) {
+          ++m->resident_gave_up_row;
+          ++m->resident_gave_up;
+        }
+        epoch = ++m->chain_epoch;
+        if (epoch == 0) epoch = ++m->chain_epoch;
+        a.epoch = epoch;
+        a.n_slots = m->mc_slots;
+        h->error = 0;
+        launched = 0;
+      } else {
+        m->resident_gave_up_row = 0;
+        ran_resident = true;
+      }
+    }
+  }
   auto launch_one = [&]() -> int {
     hipEvent_t e0, e1;
     int r = profile_event_pair(ctx, &e0, &e1);
@@ -1469,13 +1547,12 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     ++launched;
     return SLAMHIP_OK;
   };
-  const int first = std::max(2, std::min(256, (int)(m->chain_steps_avg * 0.75)));
+  const int first = ran_resident ? 0 : std::max(2, std::min(256, (int)(m->chain_steps_avg * 0.75)));
   for (int i = 0; i < first; ++i) {
     rc = launch_one();
     if (rc) return rc;
   }
   unsigned long long spins = 0;
-  bool ahead_done = false;
   while (h->done_seq != epoch) {
     const int started = (int)h->progress;
     if (launched - started < m->chain_ahead) {
@@ -1487,19 +1564,8 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
       if (rc) return rc;
       continue;
     }
-    // polar pairs of the next match while this one runs: generated a few at a time, uploaded once they are there
-    if (!ahead_done) {
-      pe->prefetch_ahead(2 * need, 32);
-      if (pe->tape_generated_upto() >= pos + 2 * need) {
-        if (pos + 2 * need <= m->tape_base + m->tape_cap) {
-          rc = upload_upto(pos + 2 * need);
-          if (rc) return rc;
-        }
-        ahead_done = true;
-      }
-    } else {
-      __builtin_ia32_pause();
-    }
+    rc = fill_ahead();
+    if (rc) return rc;
     if ((++spins & 0xfffffull) == 0) {
       hipError_t qe = hipStreamQuery(ctx->stream);
       if (qe != hipSuccess && qe != hipErrorNotReady) return hip_fail(qe, "Monte-Carlo chain kernel");

@@ -5,6 +5,10 @@
 #include "slamhip_internal.h"
 
 namespace slamhip {
+struct HcResidentCtl;  // hc_chain_device.h: the granule block of a co-resident chain (mc_resident.hip uses the same)
+}
+
+namespace slamhip {
 
 constexpr int kMcSlots = 384;  // most candidates a super-step speculates on (6 per lane of the replaying wave)
 
@@ -57,7 +61,19 @@ struct McChainArgs {
   McHostOut *host;
   McTraceEntry *trace;  // pinned; null = no observer
   int trace_cap;
+  // the co-resident form (mc_resident.hip): ONE launch per match, scores exchanged through granules
+  HcResidentCtl *rctl;
+  int lds_consts;  // range, cosine, sine of the beams behind a thread's first one are kept in LDS
+  int debug_mute;  // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
+  long long *stamps;  // debugging (slamhip_matcher_debug_stamps): wall-clock stamps of workgroup 1, eight per super-step
 };
+
+// mc_resident.hip: the whole match as one launch of a.n_slots + 1 co-resident workgroups; the grid must not exceed
+// mc_resident_capacity.  McHostOut::error 4: a workgroup was not resident (bounded spin ran out), 5: more super-steps
+// than a tag counts -- nothing has been reported then, the caller runs the chain of kernels
+hipError_t launch_mc_chain_resident(const McChainArgs &a, int cell_model, int nt, hipStream_t stream,
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_consts, int *out_wgs);
 
 // threads per workgroup: 512 or 1024
 hipError_t launch_mc_chain_step(const McChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,

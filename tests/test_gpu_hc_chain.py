@@ -206,15 +206,18 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
 
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
 @pytest.mark.parametrize("prm", [[666666, 0.2, 0.1, 20, 100], [7, 0.2, 0.1, 4096, 4096], [11, 0.3, 0.05, 30, 1000], [5, 0.2, 0.1, 3, 2]])
-def test_mc_chain_equals_host_driven_matcher(pkg, ctx, cell, weighting, prm):
+@pytest.mark.parametrize("mode", CHAIN_MODES)
+def test_mc_chain_equals_host_driven_matcher(pkg, ctx, cell, weighting, prm, mode):
     """The Monte-Carlo matcher on the device chain (csrc/mc_chain.hip: candidates under "all rejected" per
     super-step, first acceptance wins, the enumerator state advanced in closed form -- tape position, pending
-    second Marsaglia values, failure counter, halved dispersions) against the host-driven matcher: trace, result
-    and the random stream left behind (the next match continues on the same engine), bit for bit."""
+    second Marsaglia values, failure counter, halved dispersions; mode 2: the same as ONE co-resident launch,
+    csrc/mc_resident.hip) against the host-driven matcher: trace, result and the random stream left behind (the
+    next match continues on the same engine), bit for bit."""
     sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=5, weighting=weighting)
     upload(pkg, ctx, sc)
     dev = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
     host = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    dev.set_device_chain(mode)
     host.set_device_chain(0)
     for m in (dev, host):
         m.set_tie_check(0)
@@ -230,6 +233,44 @@ def test_mc_chain_equals_host_driven_matcher(pkg, ctx, cell, weighting, prm):
         assert q["prob"] == qh["prob"] and np.array_equal(q["delta"], qh["delta"])
         init = init + np.array([0.013, -0.007, 0.004])
     assert dev.stats()["kernels_launched"] > 0 and host.stats()["kernels_launched"] == 0
+    if mode == 2:
+        assert dev.resident_stats() == dict(matches=8, gave_up=0) and dev.stats()["kernels_launched"] == 1
+    else:
+        assert dev.resident_stats() == dict(matches=0, gave_up=0)
+
+
+@pytest.mark.parametrize("tie_check", [0, 1])
+def test_resident_mc_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx, tie_check):
+    """The Monte-Carlo counterpart of the test below (csrc/mc_resident.hip): with one workgroup gone the others give up
+    within the bound, nothing has been reported and the enumerator has not been touched -- the chain of kernels redoes
+    the match on the same random stream; the matches after it continue on that stream as if nothing had happened."""
+    import ctypes as C
+    import time
+    sc = make_scene(cell_model=CELL_TBM, size=600, scale=0.05, n_beams=720, seed=5, weighting="viny")
+    upload(pkg, ctx, sc)
+    prm = [666666, 0.2, 0.1, 40, 300]
+    dev = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    host = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    dev.set_device_chain(2)
+    host.set_device_chain(0)
+    for m in (dev, host):
+        m.set_tie_check(tie_check)
+    L = pkg.load()
+    L.slamhip_matcher_debug_resident_mute.argtypes = [C.c_void_p, C.c_int]
+    L.slamhip_matcher_debug_resident_mute.restype = C.c_int
+    assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), host.process_scan(0, sc["init_pose"], trace=True))
+    assert dev.resident_stats() == dict(matches=1, gave_up=0)
+    for muted, slot in enumerate((0, 5), start=1):  # candidates every super-step scores
+        assert L.slamhip_matcher_debug_resident_mute(dev.h, slot + 1) == 0
+        t0 = time.time()
+        got = dev.process_scan(0, sc["init_pose"], trace=True)
+        assert time.time() - t0 < 5.0  # bounded, not a hang
+        assert_trace_equal(got, host.process_scan(0, sc["init_pose"], trace=True))
+        assert dev.resident_stats() == dict(matches=1 + muted, gave_up=muted)
+        assert dev.stats()["kernels_launched"] > 1  # the chain of kernels ran
+    assert L.slamhip_matcher_debug_resident_mute(dev.h, 0) == 0
+    assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), host.process_scan(0, sc["init_pose"], trace=True))
+    assert dev.resident_stats() == dict(matches=4, gave_up=2) and dev.stats()["kernels_launched"] == 1
 
 
 @pytest.mark.parametrize("mode", CHAIN_MODES)

@@ -17,7 +17,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); SQ_BUSY_CYCLES / duration is printed beside it
 # dominant kernel of each leg (substring of the rocprof kernel name)
-LEG_KERNEL = {"hc": "k_hc_chain_resident", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_resident_gm",
+LEG_KERNEL = {"hc": "k_hc_chain_resident", "sweep": "k_score_point", "mc": "k_mc_chain_resident", "pf": "k_hc_chain_resident_gm",
               "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_", "world": "k_hc_chain_resident",
               "replicas": "k_hc_chain_resident", "bf": "k_score_point"}
 lines = ["# rocprofv3 summaries, round tag `%s`\n" % tag,
@@ -93,7 +93,7 @@ if os.path.exists(cs):
     lines.append("In-kernel timeline of the hill-climbing chain's super-step (`tools/hc_chain_stamps.py`): `%s_chain_stamps.txt`.\n" % tag)
 
 traffic = {}
-PMC_KERNEL = {"hc": "k_hc_chain_resident<0", "sweep": "k_score_point", "mc": "k_mc_chain_step", "pf": "k_hc_chain_resident_gm"}
+PMC_KERNEL = {"hc": "k_hc_chain_resident<0", "sweep": "k_score_point", "mc": "k_mc_chain_resident", "pf": "k_hc_chain_resident_gm"}
 for wl in ("hc", "sweep", "mc", "pf"):
     for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
         f = os.path.join(src, "pmc_%s_%s" % (wl, c), "pmc_counter_collection.csv")
