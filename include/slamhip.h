@@ -312,12 +312,14 @@ int slamhip_matcher_set_batch(slamhip_matcher *m, int max_batch);
  * the previous one's speculative candidates in the reference's order (csrc/hc_chain.h, csrc/mc_chain.h;
  * pose_enumeration_scan_matcher.h:31-77, hill_climbing_scan_matcher.h:10-170, monte_carlo_scan_matcher.h:10-100).
  * mode: 0 = the host-driven speculative batches every other configuration uses; 1 = a chain of kernels, one per
- * super-step; 2 (default) = hill climbing over the 1-cell OOPE as ONE launch whose workgroups stay on the chip and
- * exchange their scores inside it (csrc/hc_resident.hip) -- every wait in it is bounded, and a match whose
- * workgroups were not all resident (the device was shared) is redone by mode 1, as is everything mode 2 does not
- * cover (GMapping OOPE, Monte Carlo); threads: workgroup size 256 / 512 / 1024, 0 = default (1024 for hill
- * climbing, 512 for Monte Carlo).  Scores, decisions, observer events and the Monte-Carlo engine's stream are the
- * same bit for bit in every mode. */
+ * super-step; 2 (default) = the match as ONE launch whose workgroups stay on the chip and exchange their scores
+ * inside it -- hill climbing over the 1-cell and window OOPEs (csrc/hc_resident.hip), Monte Carlo
+ * (csrc/mc_resident.hip), and, when asked for explicitly, hill climbing over the GMapping OOPE
+ * (csrc/hc_resident_gm.hip; by default a lone GMapping chain stays on mode 1, which is as fast).  Every wait in
+ * that launch is bounded, and a match whose workgroups were not all resident (the device was shared) is redone by
+ * mode 1, as is everything mode 2 does not cover; threads: workgroup size 256 / 512 / 1024, 0 = default (1024 for
+ * hill climbing, 512 for Monte Carlo).  Scores, decisions, observer events and the Monte-Carlo engine's stream are
+ * the same bit for bit in every mode. */
 int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
 /* mode 2's bookkeeping: matches launched in the co-resident form, and how many of them gave up (bounded wait ran
  * out) and were redone by the chain of kernels */
