@@ -1484,11 +1484,25 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     int cap = 0;
     // (1024-thread workgroups are resident one per CU: 252 candidates per super-step then, like the hill-climbing tree)
     if (m->chain_nt == 1024) a.n_slots = std::min(a.n_slots, 252);
+    // (the occupancy query once per workgroup size and scan length, like resident_capacity)
+    auto mc_cap = [&](bool ldsc, int *out) -> int {
+      const int idx = (m->chain_nt == 1024 ? 2 : 1) + (ldsc ? 3 : 0);
+      if (m->resident_cap[idx] == 0 || a.scan.n > m->resident_cap_beams[idx]) {
+        int c = 0;
+        SLAMHIP_CHECK(mc_resident_capacity(cell_model, m->chain_nt, a.scan.n, ldsc, &c));
+        m->resident_cap[idx] = c > 0 ? c : -1;
+        m->resident_cap_beams[idx] = a.scan.n;
+      }
+      *out = m->resident_cap[idx] > 0 ? m->resident_cap[idx] : 0;
+      return SLAMHIP_OK;
+    };
     a.lds_consts = 1;
-    SLAMHIP_CHECK(mc_resident_capacity(cell_model, m->chain_nt, a.scan.n, true, &cap));
+    rc = mc_cap(true, &cap);
+    if (rc) return rc;
     if (a.n_slots + 1 > cap) {
       a.lds_consts = 0;
-      SLAMHIP_CHECK(mc_resident_capacity(cell_model, m->chain_nt, a.scan.n, false, &cap));
+      rc = mc_cap(false, &cap);
+      if (rc) return rc;
     }
     if (a.n_slots + 1 <= cap) {
       if (!m->d_rctl) {

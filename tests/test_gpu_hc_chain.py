@@ -239,6 +239,25 @@ def test_mc_chain_equals_host_driven_matcher(pkg, ctx, cell, weighting, prm, mod
         assert dev.resident_stats() == dict(matches=0, gave_up=0)
 
 
+def test_mc_resident_chain_with_1024_thread_workgroups(pkg, ctx):
+    """1024-thread workgroups are resident one per CU, so the co-resident Monte-Carlo launch speculates on 252
+    candidates per super-step instead of 384 (csrc/matchers.cpp): the trace, the result and the random stream left
+    behind do not depend on how many candidates a super-step scores.  1080 beams: the 56 beams behind a thread's first
+    one have their constants in LDS."""
+    sc = make_scene(cell_model=CELL_TBM, size=600, scale=0.05, n_beams=1080, seed=8, weighting="viny")
+    upload(pkg, ctx, sc)
+    prm = [31, 0.2, 0.1, 600, 2000]
+    dev = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    host = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), prm)
+    dev.set_device_chain(2, 1024)
+    host.set_device_chain(0)
+    init = sc["init_pose"]
+    for rep in range(3):
+        assert_trace_equal(dev.process_scan(0, init, trace=True), host.process_scan(0, init, trace=True))
+        init = init + np.array([0.011, 0.006, -0.003])
+    assert dev.resident_stats() == dict(matches=3, gave_up=0) and dev.stats()["kernels_launched"] == 1
+
+
 @pytest.mark.parametrize("tie_check", [0, 1])
 def test_resident_mc_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx, tie_check):
     """The Monte-Carlo counterpart of the test below (csrc/mc_resident.hip): with one workgroup gone the others give up
