@@ -39,6 +39,7 @@ struct slamhip_matcher {
   // size; 0 = not asked yet), matches that gave up in a row / in total (bounded spin ran out: kernel chain instead)
   slamhip::HcResidentCtl *d_rctl = nullptr;
   slamhip::HcResidentGmCtl *d_rctl_gm = nullptr;
+  int mc_rctl_grid = 0;  // workgroups of the last co-resident Monte-Carlo launch
   int resident_cap[6] = {0, 0, 0, 0, 0, 0};        // by workgroup size, without / with the beam constants in LDS
   int resident_cap_beams[6] = {0, 0, 0, 0, 0, 0};  // the scan length the capacity was asked for
   int resident_gave_up_row = 0;
@@ -1509,6 +1510,12 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
         SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
         SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));  // (ordered with the launch)
       }
+      // (every workgroup clears its own granules when a match starts; a launch with MORE slots than the one before --
+      // the workgroup size was changed -- could meet what a slot held sixteen epochs ago before its owner has started:
+      // the block is cleared then, hc_tag in hc_resident_device.h)
+      if (a.n_slots + 1 > m->mc_rctl_grid && m->mc_rctl_grid > 0)
+        SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));
+      m->mc_rctl_grid = a.n_slots + 1;
       a.rctl = m->d_rctl;
       a.debug_mute = m->debug_resident_mute;
       a.stamps = m->d_stamps;
