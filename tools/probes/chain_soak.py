@@ -19,7 +19,7 @@ n_hc = int(os.environ.get("SOAK_HC", "20000"))
 for k in range(n_hc):
     r = m.process_scan(0, sc["init_pose"])
     assert r["prob"] == first["prob"] and np.array_equal(r["delta"], first["delta"]), k
-print("HC chain: %d matches identical, %.1f s" % (n_hc, time.time() - t0))
+print("HC chain: %d matches identical, %.1f s; co-resident launches %r" % (n_hc, time.time() - t0, m.resident_stats()))
 dev = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), [99, 0.2, 0.1, 200, 600])
 host = pkg.Matcher(ctx, "MC", pkg.spe_cfg(), [99, 0.2, 0.1, 200, 600])
 host.set_device_chain(0)
@@ -30,4 +30,4 @@ for k in range(n_mc):
     a, b = dev.process_scan(0, init), host.process_scan(0, init)
     assert a["prob"] == b["prob"] and np.array_equal(a["delta"], b["delta"]), k
     init = sc["init_pose"] + 0.02 * np.array([np.sin(k), np.cos(1.3 * k), 0.3 * np.sin(0.7 * k)])
-print("MC chain: %d matches equal to the host-driven twin, %.1f s" % (n_mc, time.time() - t0))
+print("MC chain: %d matches equal to the host-driven twin, %.1f s; co-resident launches %r" % (n_mc, time.time() - t0, dev.resident_stats()))
