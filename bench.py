@@ -528,7 +528,8 @@ def sharded_particle_maps_leg(args, pkg, ctx, gather, counts, gp, seeds, n, firs
     # has free (ranks that share a GPU -- path testing under gloo -- would otherwise take each other's memory)
     pool_tiles = ext * ext + 2 * count * tiles_per_particle
     free_bytes, _total = torch.cuda.mem_get_info()
-    pool_tiles = max(ext * ext + count, min(pool_tiles, int(0.7 * free_bytes / (128 * 128 * 48))))
+    sharing = max(1, -(-world // max(1, torch.cuda.device_count())))  # ranks on this GPU (they size their pools at once)
+    pool_tiles = max(ext * ext + count, min(pool_tiles, int(0.7 * free_bytes / sharing / (128 * 128 * 48))))
     pfm.enable_particle_maps(map_id, extent_tiles=ext, pool_tiles=pool_tiles, **(adder or {}))
     bounds = np.cumsum(counts)
     owner = lambda j: int(np.searchsorted(bounds, int(j), side="right"))  # noqa: E731  (contiguous blocks)
