@@ -113,6 +113,8 @@ def parse():
                          "shards -- block split, all-gathers, identical resampling, the map-migration plan with dummy "
                          "maps point to point, barrier + max-over-ranks timing -- checking every rank against an "
                          "unsharded filter.  So that the first multi-GPU run is not also the first multi-rank run.")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="slamhip_matcher_set_batch on the headline's matcher (Monte Carlo: candidates per super-step, A/B runs)")
     ap.add_argument("--no-tie-check", action="store_true",
                     help="default mode without the check of comparisons the tree sum cannot settle")
     args = ap.parse_args()
@@ -1428,6 +1430,8 @@ def main():
             m.set_device_chain(args.chain_mode)
         if args.no_tie_check:
             m.set_tie_check(0)
+        if args.batch > 0:
+            m.set_batch(args.batch)
         on_device = kind in ("HC", "MC") and args.chain != 0 and not args.strict
         # the rotating scenes live in HBM before the timed region starts (scan slots); a step selects one (a host
         # pointer swap) and matches it from its own odometry pose

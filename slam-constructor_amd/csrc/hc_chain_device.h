@@ -113,6 +113,8 @@ struct HcChainArgs {
   // co-resident form only (hc_resident.hip)
   HcResidentCtl *rctl;   // one per chain
   HcResidentGmCtl *rctl_gm;  // ... of the GMapping form
+  unsigned tag_epoch;    // co-resident launches on these blocks so far: the epoch bits of a granule's tag (hc_tag) -- NOT
+                         // `epoch`, which the other forms of the chain bump too
   unsigned *h_all_done;  // pinned; a batch's last chain to end stores the epoch here (null: a lone chain)
   int debug_mute;        // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
   int lds_consts;  // co-resident 1-cell form: range, cosine, sine of the beams behind a thread's first one are kept in LDS

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       s_sa[b] = scan.sin_a[b];
     }
   }
-  if (fail_epoch_at_entry == a.epoch) return;
-  if (t == 0) s_stop = 0;
+  // (ONE thread's reading decides for the workgroup, behind the barrier below: every thread for itself could let some
+  // waves of a workgroup leave and others stay -- ADVICE r4)
+  if (t == 0) s_stop = fail_epoch_at_entry == a.epoch ? 1 : 0;
   if (t < 4) {  // this slot's granules of both parities start the match empty (see hc_tag)
     HcGranule *g0 = (t & 2) ? &rc->seq[t & 1][slot] : &rc->gran[t & 1][slot];
     gran_store(g0, 0.0, 0ull, 0u);
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     s_st = st;
   }
   __syncthreads();  // s_mine, s_stop, s_st
+  if (s_stop) return;  // started after the others gave up (uniform)
 
   const int t_entry = t;
   for (int k = 0;; ++k) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     __syncthreads();  // (A)
     if (s_stop) break;
     const int go = s_go[pk], mode = s_mode[pk];
-    const unsigned tag = hc_tag(ap->epoch, k);
+    const unsigned tag = hc_tag(ap->tag_epoch, k);
     if (go) {
       const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
       // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order, wave
@@ -322,9 +324,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         }
       }
       if (stamp && k < 64) ap->stamps[8 * k + 5] = wall_clock64();
-    } else if (!init_slot && t == 0) {
-      // nothing to score (behind the end of the chain, or the surplus candidates of a trailing round): the sweepers
-      // wait for every slot of the shape, so the tag goes out all the same
+    } else if (t == 0) {
+      // nothing to score (behind the end of the chain, the surplus candidates of a trailing round, a smaller shape, the
+      // bookkeeping workgroup behind the first super-step): the tag goes out all the same.  The sweepers wait for EVERY
+      // workgroup of the grid in every super-step, so nobody -- the bookkeeping workgroup streaming an observer's
+      // trace over PCIe least of all -- is ever more than one super-step behind the others, whose next-but-one
+      // granules would overwrite what it still has to read
       gran_store(&gran[pk * kGranRow + slot], 0.0, 0ull, tag);
       if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0ull, tag);
     }
@@ -349,10 +354,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       // here, while the granules are on their way, instead of on the terminal lane after the ballots
       HcRound rr{sp.x, sp.y, sp.theta, sp.dt, sp.dr, sp.failed};
       if (reach) rr = hc_round_of(sp, me);
-      // ---- sweep: slots 0 .. 6 n_inst - 1, and the bookkeeping slot when it scored (initial pose / re-scored base)
-      const int n6 = 6 * n_inst;
+      // ---- sweep: every workgroup of the grid (the bookkeeping one scored the initial pose / a re-scored base)
       const bool base_here = sp.first || sp.mode == 1;
-      const int n_wait = n6 + (base_here ? 1 : 0);
+      const int n_grid = (int)gridDim.x - 1;  // (+ the bookkeeping workgroup)
       const bool rescored = !SEQ && verify && sp.mode == 1;
       bool failed = false;
       {
@@ -360,30 +364,23 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         unsigned spins = 0;
         for (;;) {
           u32x4 g[G];
+          const HcGranule *gp[G];
           bool ok = true;
 #pragma unroll
           for (int q = 0; q < G; ++q) {
-            g[q] = u32x4{0u, 0u, 0u, 0u};
-            if (64 * q < n_wait) {  // (uniform)
-              const int i = lane + 64 * q;
-              const int j = i < n6 ? i : kHcSlots - 1;
-              g[q] = gran_load(g0 + j);
-            }
+            const int i = lane + 64 * q;
+            gp[q] = g0 + (i < n_grid ? i : kHcSlots - 1);  // (behind the grid: the bookkeeping workgroup's, once more)
           }
-          gran_wait(g);
+          gran_fetch(g, gp);  // (the loads and their wait in one statement: hc_resident_device.h)
 #pragma unroll
           for (int q = 0; q < G; ++q) {
-            if (64 * q < n_wait) {
-              const int i = lane + 64 * q;
-              if (i < n_wait) {
-                const int j = i < n6 ? i : kHcSlots - 1;
-                const bool here = gran_tag(g[q]) == tag;
-                ok = ok && here;
-                if (here) {
-                  s_sc[j] = gran_score(g[q]);
-                  s_hash[j] = gran_hash(g[q]);
-                }
-              }
+            const int i = lane + 64 * q;
+            const int j = i < n_grid ? i : kHcSlots - 1;
+            const bool here = gran_tag(g[q]) == tag;
+            ok = ok && here;
+            if (here) {
+              s_sc[j] = gran_score(g[q]);
+              s_hash[j] = gran_hash(g[q]);
             }
           }
           if (__all(ok)) break;
@@ -461,10 +458,11 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             const int j = c < 0 ? (bp_slot < 0 ? kHcSlots - 1 : bp_slot) : (active ? 6 * lane + c : kHcSlots - 1);
             double sd = 0.0;
             for (unsigned spins = 0;; ++spins) {
-              u32x4 g = gran_load(q0 + j);
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
-              sd = gran_score(g);
-              if (__all(gran_tag(g) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+              u32x4 g[1];
+              const HcGranule *gp[1] = {q0 + j};
+              gran_fetch(g, gp);
+              sd = gran_score(g[0]);
+              if (__all(gran_tag(g[0]) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
             }                                                         // the same workgroups are here already)
             if (c < 0) {
               bdec = sd;

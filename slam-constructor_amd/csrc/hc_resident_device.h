@@ -53,11 +53,13 @@ __device__ __forceinline__ ScanView load_view(ScanViewCP p) {
   return s;
 }
 
-// 16-bit tag of super-step k of the match with this epoch, never 0: twelve bits of step, four of epoch.  Four are
-// enough because every workgroup clears its own two granules when a match starts: what can still lie in a slot is
-// the previous match's, whose epoch bits differ (the host clears the block when a launch uses more slots than
-// the one before, hc_resident_capacity's callers).  The granule's last dword = 16 fingerprint bits | tag.
-__device__ __forceinline__ unsigned hc_tag(unsigned epoch, int k) { return ((epoch & 0xfu) << 12) | (unsigned)(k + 1); }
+// 16-bit tag of super-step k of a co-resident launch, never 0: twelve bits of step, four of `tag_epoch` = the number of
+// co-resident launches on this exchange block so far.  Four are enough because every workgroup clears its own
+// granules when a launch starts: what can still lie in a slot is the previous LAUNCH's, whose bits differ by one (the
+// match epoch would not do: matches run in other forms in between bump it too, and sixteen of those would bring the
+// same bits back -- ADVICE r4; the host clears the block when a launch uses more slots than the one before).  The
+// granule's last dword = 16 fingerprint bits | tag.
+__device__ __forceinline__ unsigned hc_tag(unsigned tag_epoch, int k) { return ((tag_epoch & 0xfu) << 12) | (unsigned)(k + 1); }
 
 // hash: the low 48 bits count (fold_fingerprint48)
 __device__ __forceinline__ void gran_store(HcGranule *p, double score, unsigned long long hash, unsigned tag) {
@@ -73,25 +75,66 @@ __device__ __forceinline__ unsigned gran_tag(const u32x4 &g) { return g.w & 0xff
 __device__ __forceinline__ unsigned long long gran_hash(const u32x4 &g) {
   return ((unsigned long long)(g.w >> 16) << 32) | (unsigned long long)g.z;
 }
-// issue only: gran_wait ties the loaded values to the one wait
-__device__ __forceinline__ u32x4 gran_load(const HcGranule *p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// G granules at once: the loads AND their one wait in ONE asm statement with early-clobber outputs, so that the
+// compiler can neither copy, spill nor rename a destination register between a load and the wait it cannot see
+// (SIInsertWaitcnts does not look inside inline asm: ADVICE r4).  Every address is read: callers clamp the slots
+// a sweep does not need to one it does.
+__device__ __forceinline__ void gran_fetch(u32x4 (&g)[1], const HcGranule *const (&p)[1]) {
+  asm volatile(
+               "global_load_dwordx4 %0, %1, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(g[0])
+               : "v"(p[0])
+               : "memory");
 }
-// (one operand per granule: the values cannot be used before the wait)
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[7]) {
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6])::"memory");
+__device__ __forceinline__ void gran_fetch(u32x4 (&g)[2], const HcGranule *const (&p)[2]) {
+  asm volatile(
+               "global_load_dwordx4 %0, %2, off sc1\n\t"
+               "global_load_dwordx4 %1, %3, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(g[0]), "=&v"(g[1])
+               : "v"(p[0]), "v"(p[1])
+               : "memory");
 }
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[4]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3])::"memory");
+__device__ __forceinline__ void gran_fetch(u32x4 (&g)[4], const HcGranule *const (&p)[4]) {
+  asm volatile(
+               "global_load_dwordx4 %0, %4, off sc1\n\t"
+               "global_load_dwordx4 %1, %5, off sc1\n\t"
+               "global_load_dwordx4 %2, %6, off sc1\n\t"
+               "global_load_dwordx4 %3, %7, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+               : "memory");
 }
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[1]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0])::"memory");
+__device__ __forceinline__ void gran_fetch(u32x4 (&g)[7], const HcGranule *const (&p)[7]) {
+  asm volatile(
+               "global_load_dwordx4 %0, %7, off sc1\n\t"
+               "global_load_dwordx4 %1, %8, off sc1\n\t"
+               "global_load_dwordx4 %2, %9, off sc1\n\t"
+               "global_load_dwordx4 %3, %10, off sc1\n\t"
+               "global_load_dwordx4 %4, %11, off sc1\n\t"
+               "global_load_dwordx4 %5, %12, off sc1\n\t"
+               "global_load_dwordx4 %6, %13, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6])
+               : "memory");
 }
-__device__ __forceinline__ void gran_wait(u32x4 (&g)[2]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1])::"memory");
+__device__ __forceinline__ void gran_fetch(u32x4 (&g)[8], const HcGranule *const (&p)[8]) {
+  asm volatile(
+               "global_load_dwordx4 %0, %8, off sc1\n\t"
+               "global_load_dwordx4 %1, %9, off sc1\n\t"
+               "global_load_dwordx4 %2, %10, off sc1\n\t"
+               "global_load_dwordx4 %3, %11, off sc1\n\t"
+               "global_load_dwordx4 %4, %12, off sc1\n\t"
+               "global_load_dwordx4 %5, %13, off sc1\n\t"
+               "global_load_dwordx4 %6, %14, off sc1\n\t"
+               "global_load_dwordx4 %7, %15, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+               : "memory");
 }
 __device__ __forceinline__ double gran_score(const u32x4 &g) {
   return __longlong_as_double((long long)(((unsigned long long)g.y << 32) | (unsigned long long)g.x));

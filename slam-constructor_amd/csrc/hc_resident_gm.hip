@@ -109,7 +109,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
   const bool init_slot = slot == kHcSlots - 1;
   HcResidentGmCtl *const rc = a.rctl_gm + blockIdx.y;
   HcHostOut *const host = a.host + blockIdx.y;
-  if (__hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) return;
+  // (a workgroup that starts after the others gave up leaves at once -- ONE thread's reading, behind the barrier below)
+  const unsigned fail_epoch_at_entry = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing)
   const __attribute__((address_space(4))) HcChainArgs *const ap0 =
       (const __attribute__((address_space(4))) HcChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
   HcGranule *const gran = &rc->gran[0][0][0];
   if (t < 8) gm_gran_store(gran + ((size_t)(t >> 2) * kRow + slot) * 4 + (t & 3), 0, 0.0, GmPoseInfo{}, 0u);
   if (t == 0) {
-    s_stop = 0;
+    s_stop = fail_epoch_at_entry == a.epoch ? 1 : 0;
     s_sweep_failed = 0;
     HcState st{};
     st.x = a.inits ? a.inits[3 * blockIdx.y] : a.init[0];
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
   const int *tiles = a.tables ? a.tables + (size_t)a.slots[blockIdx.y] * a.table_stride : nullptr;
   const bool stamp = a.stamps && slot == 1 && t == 0;
   __syncthreads();
+  if (s_stop) return;  // (uniform)
 
   const int t_entry = t;
   for (int k = 0;; ++k) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
     __syncthreads();  // (A)
     if (s_stop) break;
     const int go = s_go[pk];
-    const unsigned tag = hc_tag(ap->epoch, k);
+    const unsigned tag = hc_tag(ap->tag_epoch, k);
     HcGranule *const mine4 = gran + ((size_t)pk * kRow + slot) * 4;
     if (go) {
       const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
@@ -224,57 +226,50 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       // publishing lanes are thread 0's wave, behind it in program order)
       if (tt < 4) gm_gran_store(mine4 + tt, tt, s_score, s_gi, tag);
       if (stamp && k < 64) ap->stamps[8 * k + 5] = wall_clock64();
-    } else if (!init_slot && tt < 4) {
+    } else if (tt < 4) {
+      // (nothing to score: the tags go out all the same -- the sweepers wait for EVERY workgroup of the grid in every
+      // super-step, so nobody is ever more than one super-step behind: hc_resident.hip)
       gm_gran_store(mine4 + tt, tt, 0.0, GmPoseInfo{}, tag);
     }
     // ---- waves 0..3: one granule kind each, all slots of the tree, into LDS
     if (wave < 4) {
-      const HcState &sp = s_st;
-      const int n6 = 6 * (int)((ap->n_inst >> (8 * sp.shape)) & 0xffull);
-      const int n_wait = n6 + (sp.first ? 1 : 0);
+      const int n_grid = (int)gridDim.x - 1;  // (+ the bookkeeping workgroup)
       const HcGranule *g0 = gran + (size_t)pk * kRow * 4 + wave;
       unsigned spins = 0;
       bool failed = false;
       for (;;) {
         u32x4 g[G];
+        const HcGranule *gp[G];
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < G; ++q) {
-          g[q] = u32x4{0u, 0u, 0u, 0u};
-          if (64 * q < n_wait) {
-            const int i = lane + 64 * q;
-            const int j = i < n6 ? i : kHcSlots - 1;
-            g[q] = gran_load(g0 + 4 * (size_t)j);
-          }
+          const int i = lane + 64 * q;
+          gp[q] = g0 + 4 * (size_t)(i < n_grid ? i : kHcSlots - 1);
         }
-        gran_wait(g);
+        gran_fetch(g, gp);
 #pragma unroll
         for (int q = 0; q < G; ++q) {
-          if (64 * q < n_wait) {
-            const int i = lane + 64 * q;
-            if (i < n_wait) {
-              const int j = i < n6 ? i : kHcSlots - 1;
-              const bool here = gran_tag(g[q]) == (tag & 0xffffu);
-              ok = ok && here;
-              if (here) {
-                const double d = gran_score(g[q]);
-                GmPoseInfo &gi = s_info[j];
-                if (wave == 0) {
-                  s_sc[j] = d;
-                  gi.run0_len = (int)g[q].z;
-                } else if (wave == 1) {
-                  gi.v0 = d;
-                  gi.last_head = (int)g[q].z;
-                } else if (wave == 2) {
-                  gi.last_v = d;
-                  gi.first_cx = (int)g[q].z;
-                } else {
-                  const unsigned long long w = (unsigned long long)__double_as_longlong(d);
-                  gi.first_cy = (int)(unsigned)w;
-                  gi.last_cx = (int)(unsigned)(w >> 32);
-                  gi.last_cy = (int)g[q].z;
-                }
-              }
+          const int i = lane + 64 * q;
+          const int j = i < n_grid ? i : kHcSlots - 1;
+          const bool here = gran_tag(g[q]) == (tag & 0xffffu);
+          ok = ok && here;
+          if (here) {
+            const double d = gran_score(g[q]);
+            GmPoseInfo &gi = s_info[j];
+            if (wave == 0) {
+              s_sc[j] = d;
+              gi.run0_len = (int)g[q].z;
+            } else if (wave == 1) {
+              gi.v0 = d;
+              gi.last_head = (int)g[q].z;
+            } else if (wave == 2) {
+              gi.last_v = d;
+              gi.first_cx = (int)g[q].z;
+            } else {
+              const unsigned long long w = (unsigned long long)__double_as_longlong(d);
+              gi.first_cy = (int)(unsigned)w;
+              gi.last_cx = (int)(unsigned)(w >> 32);
+              gi.last_cy = (int)g[q].z;
             }
           }
         }

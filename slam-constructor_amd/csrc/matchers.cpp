@@ -39,7 +39,9 @@ struct slamhip_matcher {
   // size; 0 = not asked yet), matches that gave up in a row / in total (bounded spin ran out: kernel chain instead)
   slamhip::HcResidentCtl *d_rctl = nullptr;
   slamhip::HcResidentGmCtl *d_rctl_gm = nullptr;
+  slamhip::McResidentCtl *d_mc_rctl = nullptr;
   int mc_rctl_grid = 0;  // workgroups of the last co-resident Monte-Carlo launch
+  unsigned rctl_launches = 0;  // co-resident launches on this matcher's exchange block: the epoch bits of the tags (hc_tag)
   int resident_cap[6] = {0, 0, 0, 0, 0, 0};        // by workgroup size, without / with the beam constants in LDS
   int resident_cap_beams[6] = {0, 0, 0, 0, 0, 0};  // the scan length the capacity was asked for
   int resident_gave_up_row = 0;
@@ -126,6 +128,8 @@ int chain_release(slamhip_matcher *m) {
   m->d_rctl = nullptr;
   if (m->d_rctl_gm) hipFree(m->d_rctl_gm);
   m->d_rctl_gm = nullptr;
+  if (m->d_mc_rctl) hipFree(m->d_mc_rctl);
+  m->d_mc_rctl = nullptr;
   if (m->d_shapes) hipFree(m->d_shapes);
   if (m->h_chain) hipHostFree(m->h_chain);
   if (m->h_trace) hipHostFree(m->h_trace);
@@ -344,6 +348,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
     // stale can carry a current tag -- hc_tag in hc_resident.hip)
     a.rctl = m->d_rctl;
     a.rctl_gm = m->d_rctl_gm;
+    a.tag_epoch = ++m->rctl_launches;
     a.debug_mute = m->debug_resident_mute;
     hipEvent_t e0, e1;
     rc = profile_event_pair(ctx, &e0, &e1);
@@ -493,6 +498,7 @@ struct HcBatch {
   slamhip::HcResidentCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain (cap of them)
   unsigned *h_all_done = nullptr;            // pinned: the last chain to end stores the epoch here
   int rctl_grid = 0, rctl_chains = 0;        // slots per chain / chains of the last co-resident launch
+  unsigned rctl_launches = 0;                // co-resident launches on d_rctl (hc_tag)
   bool ran_resident = false;
   slamhip::HcTraceEntry *h_trace = nullptr;  // pinned: cap x trace_per entries (observer attached only)
   int trace_per = 0, trace_chains = 0;
@@ -739,6 +745,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
       b->rctl_grid = 6 * b->max_inst + 1;
       b->rctl_chains = n;
       a.rctl = b->d_rctl;
+      a.tag_epoch = ++b->rctl_launches;
       a.h_all_done = b->h_all_done;
       a.debug_mute = m->debug_resident_mute;
       hipEvent_t e0, e1;
@@ -871,6 +878,7 @@ struct GmMultiChain {
   HcResidentGmCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain
   unsigned *h_all_done = nullptr;     // pinned: the last chain to end stores the epoch here
   int rctl_grid = 0, rctl_chains = 0, gave_up_row = 0;
+  unsigned rctl_launches = 0;  // co-resident launches on d_rctl (hc_tag)
   unsigned *d_n_done = nullptr;
   unsigned *h_done_count = nullptr;  // pinned
   int shape_n_inst[kHcShapes] = {0};
@@ -1047,6 +1055,7 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
       s->rctl_grid = 6 * s->max_inst + 1;
       s->rctl_chains = n;
       a.rctl_gm = s->d_rctl;
+      a.tag_epoch = ++s->rctl_launches;
       a.h_all_done = s->h_all_done;
       hipEvent_t e0, e1;
       rc = profile_event_pair(ctx, &e0, &e1);
@@ -1375,10 +1384,12 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     SLAMHIP_CHECK(hipMemset(m->d_mc, 0, sizeof(McChainCtl)));
     SLAMHIP_CHECK(hipHostMalloc(&m->h_mc, sizeof(McHostOut), pinned));
     std::memset(m->h_mc, 0, sizeof(McHostOut));
-    // 384 candidates per super-step in workgroups of 512 threads (two per CU): a Monte-Carlo chain is a long run of
-    // rejections, so the larger tree pays (cfg3: 16 super-steps of 7.2 us against 21 of 6.5 with 252 x 1024)
-    m->mc_slots = kMcSlots;
   }
+  // 511 candidates per super-step in workgroups of 512 threads (with the bookkeeping workgroup two on EVERY CU): a
+  // Monte-Carlo chain is a long run of rejections, so the larger tree pays (r03: 384 x 512 threads against 252 x 1024,
+  // 16 super-steps of 7.2 us against 21 of 6.5; r05: 511 against 384, mc_chain_device.h).  slamhip_matcher_set_batch
+  // caps it (at least 64: mc_chain_eligible).
+  m->mc_slots = std::min(kMcSlots, m->max_batch);
   McChainArgs a;
   std::memset(&a, 0, sizeof(a));
   int cell_model = 0;
@@ -1506,17 +1517,18 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
       if (rc) return rc;
     }
     if (a.n_slots + 1 <= cap) {
-      if (!m->d_rctl) {
-        SLAMHIP_CHECK(hipMalloc(&m->d_rctl, sizeof(HcResidentCtl)));
-        SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));  // (ordered with the launch)
+      if (!m->d_mc_rctl) {
+        SLAMHIP_CHECK(hipMalloc(&m->d_mc_rctl, sizeof(McResidentCtl)));
+        SLAMHIP_CHECK(hipMemsetAsync(m->d_mc_rctl, 0, sizeof(McResidentCtl), ctx->stream));  // (ordered with the launch)
       }
       // (every workgroup clears its own granules when a match starts; a launch with MORE slots than the one before --
-      // the workgroup size was changed -- could meet what a slot held sixteen epochs ago before its owner has started:
-      // the block is cleared then, hc_tag in hc_resident_device.h)
+      // the workgroup size or the batch limit was changed -- could meet what a slot held sixteen launches ago before
+      // its owner has started: the block is cleared then, hc_tag in hc_resident_device.h)
       if (a.n_slots + 1 > m->mc_rctl_grid && m->mc_rctl_grid > 0)
-        SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl, 0, sizeof(HcResidentCtl), ctx->stream));
+        SLAMHIP_CHECK(hipMemsetAsync(m->d_mc_rctl, 0, sizeof(McResidentCtl), ctx->stream));
       m->mc_rctl_grid = a.n_slots + 1;
-      a.rctl = m->d_rctl;
+      a.rctl = m->d_mc_rctl;
+      a.tag_epoch = ++m->rctl_launches;
       a.debug_mute = m->debug_resident_mute;
       a.stamps = m->d_stamps;
       hipEvent_t e0, e1;

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
         __hip_atomic_store(&a.host->progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     } else {
-      // ---- replay of the previous super-step: lane l looks at candidates 6 l .. 6 l + 5
+      // ---- replay of the previous super-step: lane l looks at candidates 8 l .. 8 l + 7 (kMcPerLane)
       const McState sp = s_prev;
       const bool verify = a.verify != 0;
       const bool rescored = verify && sp.mode == 1;  // decisions from the beam-order sums of this super-step
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
       const double root_dec = rescored ? seq[kMcSlots] : root;
       const int avail = (int)mc_available(sp, a.max_failed, a.max_poses);
       const int n_cand = avail < a.n_slots ? avail : a.n_slots;
-      int first_c = 6;         // this lane's first accepted candidate
+      int first_c = kMcPerLane;         // this lane's first accepted candidate
       unsigned amb_mask = 0u;  // candidates of this lane whose comparison the tree sum cannot settle
 #pragma unroll
-      for (int c = 5; c >= 0; --c) {
-        const int j = 6 * lane + c;
+      for (int c = kMcPerLane - 1; c >= 0; --c) {
+        const int j = kMcPerLane * lane + c;
         const bool live = j < n_cand;
         const double s = s_sc[j < kMcSlots ? j : 0];
         const double d = rescored ? (live ? seq[j] : 0.0) : s;
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
             amb_mask |= 1u << c;
         }
       }
-      const unsigned long long acc_lanes = __ballot(first_c < 6);
+      const unsigned long long acc_lanes = __ballot(first_c < kMcPerLane);
       const int acc_lane = acc_lanes ? __ffsll((long long)acc_lanes) - 1 : -1;
-      const int j_acc = acc_lane < 0 ? -1 : 6 * acc_lane + __builtin_amdgcn_readlane(first_c, acc_lane < 0 ? 0 : acc_lane);
+      const int j_acc = acc_lane < 0 ? -1 : kMcPerLane * acc_lane + __builtin_amdgcn_readlane(first_c, acc_lane < 0 ? 0 : acc_lane);
       const int used = j_acc >= 0 ? j_acc + 1 : n_cand;  // scorer calls of this super-step, in order
       // an unsettled comparison among the calls that count?
       unsigned mine = amb_mask;
-      if (6 * lane + 5 >= used) {
-        const int keep = used - 6 * lane;  // candidates of this lane below `used`
+      if (kMcPerLane * lane + kMcPerLane - 1 >= used) {
+        const int keep = used - kMcPerLane * lane;  // candidates of this lane below `used`
         mine = keep <= 0 ? 0u : (amb_mask & ((1u << keep) - 1u));
       }
       const bool dirty = verify && !rescored && __ballot(mine != 0u) != 0ull;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(NT) void k_mc_chain_step(McChainArgs a, int k) {
             McTraceEntry e{sp.x, sp.y, sp.theta, root, 1, 0};
             a.trace[0] = e;
           }
-          for (int c = 0; c < 6; ++c) {
-            const int j = 6 * lane + c;
+          for (int c = 0; c < kMcPerLane; ++c) {
+            const int j = kMcPerLane * lane + c;
             if (j < used) {
               McTraceEntry e;
               mc_candidate(sp, a.tape, j, &e.x, &e.y, &e.theta);

@@ -1,16 +1,18 @@
 // mc_chain_device.h -- what the Monte-Carlo chain kernel (mc_chain.hip) and its host driver (matchers.cpp) share.
 #pragma once
 
+#include "hc_chain_device.h"
 #include "mc_chain.h"
 #include "slamhip_internal.h"
 
 namespace slamhip {
-struct HcResidentCtl;  // hc_chain_device.h: the granule block of a co-resident chain (mc_resident.hip uses the same)
-}
 
-namespace slamhip {
-
-constexpr int kMcSlots = 384;  // most candidates a super-step speculates on (6 per lane of the replaying wave)
+// Most candidates a super-step speculates on: kMcPerLane per lane of the replaying wave, one short of 64 x 8 so that
+// candidates + the bookkeeping workgroup are 512 workgroups of 512 threads -- two on EVERY CU of an MI355X (r04 ran
+// 384 + 1: half the CUs scored two poses per super-step and set the pace, the other half one; the extra 127
+// candidates cost no time per super-step and a Monte-Carlo chain is mostly long runs of rejections).
+constexpr int kMcPerLane = 8;
+constexpr int kMcSlots = 64 * kMcPerLane - 1;
 
 // one scorer call of the walked path, in the reference's order (what GridScanMatcherObserver sees)
 struct McTraceEntry {
@@ -62,10 +64,19 @@ struct McChainArgs {
   McTraceEntry *trace;  // pinned; null = no observer
   int trace_cap;
   // the co-resident form (mc_resident.hip): ONE launch per match, scores exchanged through granules
-  HcResidentCtl *rctl;
+  struct McResidentCtl *rctl;
+  unsigned tag_epoch;  // co-resident launches on `rctl` so far (hc_tag: NOT the match epoch, which other forms bump too)
   int lds_consts;  // range, cosine, sine of the beams behind a thread's first one are kept in LDS
   int debug_mute;  // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
   long long *stamps;  // debugging (slamhip_matcher_debug_stamps): wall-clock stamps of workgroup 1, eight per super-step
+};
+
+// the granule block of a co-resident Monte-Carlo chain (HcResidentCtl's layout with this chain's row length)
+struct McResidentCtl {
+  HcGranule gran[2][kMcSlots + 1];  // super-step k's scores at [k & 1]; the bookkeeping workgroup's at [kMcSlots]
+  HcGranule seq[2][kMcSlots + 1];   // beam-order sums of a re-scored super-step
+  unsigned fail_epoch;              // = epoch of a match whose workgroups gave up (a bounded spin ran out)
+  unsigned pad[3];
 };
 
 // mc_resident.hip: the whole match as one launch of a.n_slots + 1 co-resident workgroups; the grid must not exceed

@@ -5,11 +5,11 @@
 //   PoseEnumerationScanMatcher::process_scan      src/core/scan_matchers/pose_enumeration_scan_matcher.h:31-77
 //   MonteCarloScanMatcher + GaussianPoseEnumerator src/core/scan_matchers/monte_carlo_scan_matcher.h:10-100
 //
-// The n_slots + 1 one-pose workgroups (384 candidates + the bookkeeping workgroup, 512 threads each: two per CU) are
-// launched ONCE and loop over the super-steps.  A workgroup scores its candidate of the current state (mc_chain.h's
+// The n_slots + 1 one-pose workgroups (511 candidates + the bookkeeping workgroup, 512 threads each: two on every CU)
+// are launched ONCE and loop over the super-steps.  A workgroup scores its candidate of the current state (mc_chain.h's
 // closed forms: every candidate hangs off the same best pose under "all rejected so far"), publishes {score,
 // fingerprint, tag} as one 16-byte write-through granule, and its wave 0 gathers the granules of the candidates the
-// state still hands out, finds the first accepted one (lane l looks at candidates 6 l .. 6 l + 5: mc_chain.hip's
+// state still hands out, finds the first accepted one (lane l looks at candidates 8 l .. 8 l + 7: mc_chain.hip's
 // replay, the same decisions bit for bit) and advances the state.  Every spin is bounded: a sweep that does not
 // complete stores the match's epoch in HcResidentCtl::fail_epoch, reports error 4 and leaves; the host then runs the
 // match as the chain of kernels.
@@ -24,7 +24,7 @@ namespace slamhip {
 
 namespace {
 constexpr int kSumLanes = 256;
-constexpr int kMcGran = 7;  // granules per lane of the sweeping wave: 385 slots
+constexpr int kMcGran = kMcPerLane;  // granules per lane of the sweeping wave: 512 slots
 }  // namespace
 
 template <int MODEL, int NT, bool SEQ>
@@ -41,8 +41,11 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
   const int t0 = threadIdx.x, wave = t0 >> 6;
   const bool init_slot = blockIdx.x + 1 == gridDim.x;  // the bookkeeping workgroup: slot kMcSlots
   const int slot = init_slot ? kMcSlots : (int)blockIdx.x;
-  HcResidentCtl *const rc = a.rctl;
+  McResidentCtl *const rc = a.rctl;
   McHostOut *const host = a.host;
+  // (a workgroup that starts after the others gave up leaves at once; ONE thread looks and the workgroup decides
+  // behind a barrier -- every thread for itself could let some waves of a workgroup leave and others stay: ADVICE r4)
+  // (the word is a trip to memory: asked for here, looked at below once this thread's beam is on its way too)
   const unsigned fail_epoch_at_entry = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing: the others must give up, not hang)
   const __attribute__((address_space(4))) McChainArgs *ap0 =
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
       s_sa[b] = scan.sin_a[b];
     }
   }
-  if (fail_epoch_at_entry == a.epoch) return;  // started after the others gave up
-  if (t0 == 0) s_stop = 0;
+  if (t0 == 0) s_stop = fail_epoch_at_entry == a.epoch ? 1 : 0;
+  __syncthreads();
+  if (s_stop) return;  // started after the others gave up (uniform: thread 0's reading)
   if (t0 < 4) {  // this slot's granules of both parities start the match empty (hc_tag)
     HcGranule *g0 = (t0 & 2) ? &rc->seq[t0 & 1][slot] : &rc->gran[t0 & 1][slot];
     gran_store(g0, 0.0, 0ull, 0u);
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
   const bool stamp = a.stamps && slot == 1 && t0 == 0;
   HcGranule *const gran = &rc->gran[0][0];
   HcGranule *const gseq = &rc->seq[0][0];
-  constexpr int kGranRow = kHcSlots + 7;
+  constexpr int kGranRow = kMcSlots + 1;
   if (t0 == 0) {
     McState st{};
     st.x = a.init[0];
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
     __syncthreads();  // (A)
     if (s_stop) break;
     const int go = s_go[pk], mode = s_mode[pk];
-    const unsigned tag = hc_tag(ap->epoch, k);
+    const unsigned tag = hc_tag(ap->tag_epoch, k);
     if (go) {
       const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
       // ---- score it: mc_chain.hip's body (terms by beam, the gathers of a round in flight together, canonical sum)
@@ -212,15 +216,21 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
         }
       }
       if (stamp && k < 64) ap->stamps[8 * k + 5] = wall_clock64();
+    } else if (t == 0) {
+      // nothing to score: the tag goes out all the same.  The sweepers wait for EVERY workgroup of the grid in every
+      // super-step, so nobody -- the bookkeeping workgroup streaming an observer's trace over PCIe least of all -- is
+      // ever more than one super-step behind the others, whose next-but-one granules would overwrite what it still
+      // has to read
+      gran_store(&gran[pk * kGranRow + slot], 0.0, 0ull, tag);
     }
 
-    // ---- wave 0: the scores of the candidates the state still hands out, then mc_chain.hip's replay
+    // ---- wave 0: the granules of the whole grid, then mc_chain.hip's replay over the candidates the state hands out
     if (wave == 0) {
       const McState &sp = s_st;
       const int avail = (int)mc_available(sp, ap->max_failed, ap->max_poses);
       const int n_cand = avail < ap->n_slots ? avail : ap->n_slots;
       const bool base_here = sp.first || sp.mode == 1;
-      const int n_wait = n_cand + (base_here ? 1 : 0);
+      const int n_grid = ap->n_slots;  // (+ the bookkeeping workgroup)
       const bool rescored = !SEQ && verify && sp.mode == 1;  // decisions from the beam-order sums of this super-step
       bool failed = false;
       {
@@ -228,29 +238,23 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
         unsigned spins = 0;
         for (;;) {
           u32x4 g[kMcGran];
+          const HcGranule *gp[kMcGran];
           bool ok = true;
 #pragma unroll
           for (int q = 0; q < kMcGran; ++q) {
-            g[q] = u32x4{0u, 0u, 0u, 0u};
-            if (64 * q < n_wait) {  // (uniform)
-              const int i = lane + 64 * q;
-              g[q] = gran_load(g0 + (i < n_cand ? i : kMcSlots));
-            }
+            const int i = lane + 64 * q;
+            gp[q] = g0 + (i < n_grid ? i : kMcSlots);  // (behind the grid: the bookkeeping workgroup's, once more)
           }
-          gran_wait(g);
+          gran_fetch(g, gp);
 #pragma unroll
           for (int q = 0; q < kMcGran; ++q) {
-            if (64 * q < n_wait) {
-              const int i = lane + 64 * q;
-              if (i < n_wait) {
-                const int j = i < n_cand ? i : kMcSlots;
-                const bool here = gran_tag(g[q]) == tag;
-                ok = ok && here;
-                if (here) {
-                  s_sc[j] = gran_score(g[q]);
-                  s_hash[j] = gran_hash(g[q]);
-                }
-              }
+            const int i = lane + 64 * q;
+            const int j = i < n_grid ? i : kMcSlots;
+            const bool here = gran_tag(g[q]) == tag;
+            ok = ok && here;
+            if (here) {
+              s_sc[j] = gran_score(g[q]);
+              s_hash[j] = gran_hash(g[q]);
             }
           }
           if (__all(ok)) break;
@@ -277,14 +281,14 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
         }
         continue;  // to (A), where the workgroup leaves
       }
-      // ---- replay: lane l looks at candidates 6 l .. 6 l + 5 (mc_chain.hip)
+      // ---- replay: lane l looks at candidates 8 l .. 8 l + 7 (mc_chain.hip)
       const double root = sp.first ? s_sc[kMcSlots] : sp.best_prob;
       const unsigned long long root_hash = verify ? (base_here ? s_hash[kMcSlots] : sp.best_hash) : 0ull;
       double root_dec = root;
-      double dec6[6];
+      double dec6[kMcPerLane];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const int j = 6 * lane + c;
+      for (int c = 0; c < kMcPerLane; ++c) {
+        const int j = kMcPerLane * lane + c;
         dec6[c] = s_sc[j < kMcSlots ? j : 0];
       }
       if (rescored) {
@@ -292,25 +296,26 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
         // granule at a time (the rare super-step: a rolled loop that costs no registers)
         const HcGranule *q0 = gseq + pk * kGranRow;
 #pragma unroll 1
-        for (int c = -1; c < 6; ++c) {
-          const int j = c < 0 ? kMcSlots : 6 * lane + c;
+        for (int c = -1; c < kMcPerLane; ++c) {
+          const int j = c < 0 ? kMcSlots : kMcPerLane * lane + c;
           const bool live = c < 0 || j < n_cand;
           double sd = 0.0;
           for (unsigned spins = 0;; ++spins) {
-            u32x4 g = gran_load(q0 + (live ? j : kMcSlots));
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g)::"memory");
-            sd = gran_score(g);
-            if (__all(gran_tag(g) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+            u32x4 g[1];
+            const HcGranule *gp[1] = {q0 + (live ? j : kMcSlots)};
+            gran_fetch(g, gp);
+            sd = gran_score(g[0]);
+            if (__all(gran_tag(g[0]) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
           }                                                               // the same workgroups are here already)
           if (c < 0) root_dec = sd;
           else dec6[c] = live ? sd : 0.0;
         }
       }
-      int first_c = 6;         // this lane's first accepted candidate
+      int first_c = kMcPerLane;  // this lane's first accepted candidate
       unsigned amb_mask = 0u;  // candidates of this lane whose comparison the tree sum cannot settle
 #pragma unroll
-      for (int c = 5; c >= 0; --c) {
-        const int j = 6 * lane + c;
+      for (int c = kMcPerLane - 1; c >= 0; --c) {
+        const int j = kMcPerLane * lane + c;
         const bool live = j < n_cand;
         const double s = s_sc[j < kMcSlots ? j : 0];
         const double d = dec6[c];
@@ -324,13 +329,13 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
           amb_mask |= (unsigned)(close & differ) << c;
         }
       }
-      const unsigned long long acc_lanes = __ballot(first_c < 6);
+      const unsigned long long acc_lanes = __ballot(first_c < kMcPerLane);
       const int acc_lane = acc_lanes ? __ffsll((long long)acc_lanes) - 1 : -1;
-      const int j_acc = acc_lane < 0 ? -1 : 6 * acc_lane + __builtin_amdgcn_readlane(first_c, acc_lane < 0 ? 0 : acc_lane);
+      const int j_acc = acc_lane < 0 ? -1 : kMcPerLane * acc_lane + __builtin_amdgcn_readlane(first_c, acc_lane < 0 ? 0 : acc_lane);
       const int used = j_acc >= 0 ? j_acc + 1 : n_cand;  // scorer calls of this super-step, in order
       unsigned mine = amb_mask;  // an unsettled comparison among the calls that count?
-      if (6 * lane + 5 >= used) {
-        const int keep = used - 6 * lane;  // candidates of this lane below `used`
+      if (kMcPerLane * lane + kMcPerLane - 1 >= used) {
+        const int keep = used - kMcPerLane * lane;  // candidates of this lane below `used`
         mine = keep <= 0 ? 0u : (amb_mask & ((1u << keep) - 1u));
       }
       const bool dirty = !SEQ && verify && !rescored && __ballot(mine != 0u) != 0ull;
@@ -366,8 +371,8 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
             McTraceEntry e{sp.x, sp.y, sp.theta, root, 1, 0};
             trace[0] = e;
           }
-          for (int c = 0; c < 6; ++c) {
-            const int j = 6 * lane + c;
+          for (int c = 0; c < kMcPerLane; ++c) {
+            const int j = kMcPerLane * lane + c;
             if (j < used) {
               McTraceEntry e;
               mc_candidate(sp, ap->tape, j, &e.x, &e.y, &e.theta);
