@@ -259,11 +259,34 @@ HC_HD HcDecision hc_round_decide(double enter, unsigned long long enter_hash, co
   return d;
 }
 
-// the root state of the next super-step, from the instance the walk ended in (`in`, its round state `r`),
-// its outcome and best score.  done: the chain is over.
-HC_HD void hc_advance(const HcState &prev, const HcInst &in, const HcRound &r, int out, double run, unsigned max_failed,
-                      long long batch_calls, long long batch_acc, long long evaluated, HcState *next) {
-  HcState n = prev;
+// state at the start of round instance `in` of the tree whose root is (x, y, theta, dt, dr, failed)
+HC_HD HcRound hc_round_from(double x, double y, double theta, double dt, double dr, unsigned failed, const HcInst &in) {
+  HcState s{};
+  s.x = x;
+  s.y = y;
+  s.theta = theta;
+  s.dt = dt;
+  s.dr = dr;
+  s.failed = failed;
+  return hc_round_of(s, in);
+}
+
+// What the next super-step's tree hangs off, as a function of the root state, the instance the walk ended in (`in`,
+// its round state `r`) and that round's outcome ALONE -- no score enters: the workgroups of a co-resident chain
+// tabulate it for every (terminal instance, outcome) pair while the scores are still on their way (hc_resident.hip).
+// The acceptance-rate estimate that picks the next tree's shape counts the ACCEPTED ROUNDS on the walked path (the
+// path's moves + this round's, if it accepted anything) over its scorer calls, exponentially forgetting
+// (MatchJob::consume counts acceptances; r01-r04 did here too, which made the shape a function of the scores: a round
+// whose running maximum moved twice counted twice).  The shape only decides what is speculated on, never a result.
+struct HcNextCore {
+  double x, y, theta, dt, dr;    // best pose = base of the round about to start, and its steps
+  double recent_acc, recent_n;
+  unsigned failed;
+  int shape, done;
+  long long batch_calls;         // scorer calls of the walked path
+};
+HC_HD HcNextCore hc_next_core(const HcState &prev, const HcInst &in, const HcRound &r, int out, unsigned max_failed) {
+  HcNextCore n;
   n.x = r.x;
   n.y = r.y;
   n.theta = r.theta;
@@ -271,23 +294,43 @@ HC_HD void hc_advance(const HcState &prev, const HcInst &in, const HcRound &r, i
   n.dr = r.dr;
   n.failed = r.failed;
   if (out > 0) hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, out - 1, &n.x, &n.y, &n.theta);
-  n.best_prob = run;
-  n.done = hc_trailing(r.failed, max_failed) ? 1 : 0;
+  const bool trailing = hc_trailing(r.failed, max_failed);
+  n.done = trailing ? 1 : 0;
   if (!n.done && out == 0) {
     n.dt = r.dt * 0.5;
     n.dr = r.dr * 0.5;
     n.failed = r.failed + 1;
   }
-  n.calls = prev.calls + (prev.first ? 1 : 0) + batch_calls;
+  n.batch_calls = 6ll * hc_depth(in) + (trailing ? 1 : 6);
+  const long long rounds_acc = (long long)hc_nseg(in) + (out > 0 ? 1 : 0);
+  n.recent_acc = 0.5 * prev.recent_acc + (double)rounds_acc;
+  n.recent_n = 0.5 * prev.recent_n + (double)n.batch_calls;
+  n.shape = hc_bucket_of_ratio(n.recent_acc + 0.5, n.recent_n + 4.0);
+  return n;
+}
+
+// the root state of the next super-step, from the instance the walk ended in (`in`, its round state `r`),
+// its outcome and best score.  done: the chain is over.
+HC_HD void hc_advance(const HcState &prev, const HcInst &in, const HcRound &r, int out, double run, unsigned max_failed,
+                      long long evaluated, HcState *next) {
+  const HcNextCore c = hc_next_core(prev, in, r, out, max_failed);
+  HcState n = prev;
+  n.x = c.x;
+  n.y = c.y;
+  n.theta = c.theta;
+  n.dt = c.dt;
+  n.dr = c.dr;
+  n.failed = c.failed;
+  n.best_prob = run;
+  n.done = c.done;
+  n.calls = prev.calls + (prev.first ? 1 : 0) + c.batch_calls;
   n.evaluated = prev.evaluated + evaluated;
   n.first = 0;
   n.mode = 0;
   n.steps = prev.steps + 1;
-  // acceptance-rate estimate for the next tree, exponentially forgetting (MatchJob::consume)
-  n.recent_acc = 0.5 * prev.recent_acc + (double)batch_acc;
-  n.recent_n = 0.5 * prev.recent_n + (double)batch_calls;
-  n.shape = hc_bucket_of_ratio(n.recent_acc + 0.5, n.recent_n + 4.0);
-  (void)in;
+  n.recent_acc = c.recent_acc;
+  n.recent_n = c.recent_n;
+  n.shape = c.shape;
   *next = n;
 }
 

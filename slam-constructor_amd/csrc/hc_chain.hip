@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
       const double enter = bp_slot < 0 ? root_prob : s_sc[bp_slot];  // canonical (reported) score entering the round
       double run = enter;
-      int nacc = 0, out = 0;
+      int out = 0;
       unsigned accmask = 0u;
       bool ambiguous = false;
       unsigned long long run_hash = 0ull;
@@ -287,7 +287,6 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             run = acc ? s : run;
             hb = acc ? h6[c] : hb;
             out = acc ? c + 1 : out;
-            nacc += acc ? 1 : 0;
             accmask |= acc ? 1u << c : 0u;
           }
         } else {
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             run = acc ? s6[c] : run;  // the canonical sum of the pose accepted last: stored and reported
             hb = acc ? h6[c] : hb;
             out = acc ? c + 1 : out;
-            nacc += acc ? 1 : 0;
             accmask |= acc ? 1u << c : 0u;
           }
         }
@@ -314,8 +312,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
           if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections
             run = s6[c];
             out = c + 1;
-            ++nacc;
-            accmask |= 1u << c;
+              accmask |= 1u << c;
           }
       }
       bool valid = reach;
@@ -328,10 +325,6 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       const unsigned long long tmask = __ballot(terminal);
       // exactly one lane is terminal: the walk's last round
       const int tl = tmask ? __ffsll((long long)tmask) - 1 : 0;
-      // acceptances on the walked path: a round has at most six, so six ballots and popcounts add them up
-      long long batch_acc = 0;
-#pragma unroll
-      for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
       if (stamp) a.stamps[8 * k + 7] = wall_clock64();
       // checked default mode: a comparison on the walked path that the tree sum cannot settle -> the same tree is
       // scored once more, in beam order as well, and decided from those sums
@@ -339,9 +332,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
       HcState next = sp;
       if (terminal && !dirty) {
         const HcRound r = hc_round_of(sp, me);
-        const long long batch_calls = 6ll * hc_depth(me) + (trailing ? 1 : 6);
-        hc_advance(sp, me, r, out, run, a.max_failed, batch_calls, batch_acc,
-                   6ll * n_inst + (sp.first ? 1 : 0), &next);
+        hc_advance(sp, me, r, out, run, a.max_failed, 6ll * n_inst + (sp.first ? 1 : 0), &next);
       }
       // hand the new root state to every lane
       next.x = bcast(next.x, tl);

@@ -45,6 +45,29 @@ namespace {
 constexpr int kSumLanes = 256;          // the canonical sum's partials (= k_score_point's block)
 }  // namespace
 
+// What a workgroup tabulates, while the scores of super-step k are on their way, for every (terminal round instance,
+// outcome) pair the tree of super-step k allows: the root of the next tree (hc_next_core: no score enters it) and the
+// pose THIS workgroup scores in it, sine and cosine included.  The replay then only picks an entry -- the serial
+// "advance" and "pose" phases of r04's super-step (0.54 + 0.69 us of 6.0, one wave at work and fifteen watching) are
+// done by the waves that used to watch.
+struct HcNextEntry {
+  double x, y, theta;     // base of the next tree's root round (HcNextCore)
+  double px, py, sn, cs;  // this workgroup's pose in the next tree
+  unsigned counts;        // failed rounds (16 bits) | scorer calls of the walked path (12) | its accepted rounds (4)
+  unsigned flags;         // shape of the next tree (3 bits) | done (bit 3) | this workgroup scores a pose in it (bit 4)
+  // (the steps follow from the failed rounds -- one exact halving each: hc_round_of --, the acceptance-rate estimate
+  // from the two counts: hc_entry_commit)
+};
+static_assert(sizeof(HcNextEntry) == 64, "HcNextEntry layout");
+__device__ __forceinline__ unsigned hc_entry_counts(const HcNextCore &c, int rounds_acc) {
+  return (c.failed & 0xffffu) | (((unsigned)c.batch_calls & 0xfffu) << 16) | (((unsigned)rounds_acc & 0xfu) << 28);
+}
+
+// s_sel: what the pose of the next super-step is read from
+constexpr int kSelRescore = -1;  // the same tree once more (an unsettled comparison): the poses just scored
+constexpr int kSelFirst = -2;    // the first super-step: the prologue's pose
+constexpr int kSelStop = -3;     // leave: the replay found no terminal round (a bug, reported) or the chain gave up
+
 // MODEL: SLAMHIP_CELL_OCC / _TBM (the 1-cell OOPE); SEQ: the reference's beam-order sum; BATCH: grid.y independent
 // matches, each with its own map and scan (HcChainArgs::jobs); G: granules per lane of the sweeping wave, i.e. the
 // grid has at most 64 G workgroups (2, 4 or 7); WIN: the window OOPEs (max / mean / overlap, K2's per-beam value) in
@@ -53,14 +76,16 @@ constexpr int kSumLanes = 256;          // the canonical sum's partials (= k_sco
 template <int MODEL, int NT, bool SEQ, bool BATCH, int G, bool WIN = false>
 __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   extern __shared__ double s_term[];  // one term per beam; behind them, for workgroups narrower than the scan: range,
-                                      // cosine, sine of every beam (hc_resident_lds_bytes)
+                                      // cosine, sine of every further beam; then the table of next poses
+                                      // (hc_resident_lds_bytes)
   __shared__ unsigned long long s_hash[kHcSlots + 7];  // (48 bits each)
   __shared__ double s_sc[kHcSlots + 7];
   __shared__ HcInst s_mine[kHcShapes];  // this workgroup's round instance in every shape
-  __shared__ double s_pose[2][4];       // x, y, sin, cos of the pose this workgroup scores, by step parity
-  __shared__ int s_go[2], s_mode[2];
+  __shared__ double s_cur[4];           // x, y, sin, cos of the pose being scored (a re-scored super-step reads it again)
+  __shared__ int s_cur_go;
+  __shared__ int s_sel;                 // where the next super-step's pose comes from: a table entry, or kSel*
   __shared__ int s_stop;
-  __shared__ HcState s_st;              // root state of the super-step about to be scored (wave 0's, between phases)
+  __shared__ HcState s_st;              // root state of the super-step being scored
   __shared__ double s_part[4];
   __shared__ unsigned long long s_hpart[4];
   const int t = threadIdx.x, wave = t >> 6;
@@ -121,6 +146,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       s_sa[b] = scan.sin_a[b];
     }
   }
+  // (behind the terms and the beam constants of the LONGEST scan of the launch: hc_resident_lds_bytes)
+  HcNextEntry *const s_tab = reinterpret_cast<HcNextEntry *>(s_term + a.tab_offset);
   // (ONE thread's reading decides for the workgroup, behind the barrier below: every thread for itself could let some
   // waves of a workgroup leave and others stay -- ADVICE r4)
   if (t == 0) s_stop = fail_epoch_at_entry == a.epoch ? 1 : 0;
@@ -146,9 +173,39 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     st.carry_cx = st.carry_cy = -1;
     st.carry_prob = -1.0;
     s_st = st;
+    s_sel = kSelFirst;
   }
   __syncthreads();  // s_mine, s_stop, s_st
   if (s_stop) return;  // started after the others gave up (uniform)
+  // ---- the first super-step's pose: the initial pose (bookkeeping workgroup), or this workgroup's candidate of the
+  // first tree -- the one pose of a match that is derived serially
+  if (wave == 0) {
+    const HcState &st = s_st;
+    bool go = true;
+    double px = st.x, py = st.y, pth = st.theta;
+    if (!init_slot) {
+      HcInst in;
+#pragma unroll
+      for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
+      go = inst_of_slot < (int)((a.n_inst >> (8 * st.shape)) & 0xffull) &&
+           (hc_is_root(in) || st.failed + hc_nfail_parent(in) < a.max_failed);  // else: behind the end of the chain
+      if (go) {
+        const HcRound r = hc_round_of(st, in);
+        go = !(hc_trailing(r.failed, a.max_failed) && cand > 0);  // a trailing round has one candidate
+        hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, cand, &px, &py, &pth);
+      }
+    }
+    double sn, cs;
+    sincos(pth, &sn, &cs);
+    if (t == 0) {
+      s_cur[0] = px;
+      s_cur[1] = py;
+      s_cur[2] = sn;
+      s_cur[3] = cs;
+      s_cur_go = go ? 1 : 0;
+    }
+  }
+  __syncthreads();
 
   const int t_entry = t;
   for (int k = 0;; ++k) {
@@ -169,49 +226,102 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     MapViewCP mp = map_p;
     asm volatile("" : "+s"(mp));
     const MapView map = load_view(mp);
-    // ---- wave 0: this workgroup's pose of super-step k
-    if (wave == 0) {
-      if (stamp && k < 64) ap->stamps[8 * k + 0] = wall_clock64();
-      const HcState &st = s_st;
-      bool go = !st.done;
-      double px = st.x, py = st.y, pth = st.theta;
-      if (init_slot) {
-        go = go && (st.first || st.mode == 1);  // the initial pose / the base pose of a re-scored tree
-      } else if (go) {
-        HcInst in;
-#pragma unroll
-        for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
-        go = inst_of_slot < (int)((ap->n_inst >> (8 * st.shape)) & 0xffull) &&
-             (hc_is_root(in) || st.failed + hc_nfail_parent(in) < ap->max_failed);  // else: behind the end of the chain
-        if (go) {
-          const HcRound r = hc_round_of(st, in);
-          go = !(hc_trailing(r.failed, ap->max_failed) && cand > 0);  // a trailing round has one candidate
-          hc_candidate(r.x, r.y, r.theta, r.dt, r.dr, cand, &px, &py, &pth);
-        }
-      }
-      if (go) {
-        double sn, cs;
-        sincos(pth, &sn, &cs);
+    if (stamp && k < 64) ap->stamps[8 * k + 0] = wall_clock64();
+    // ---- the pose of super-step k: the entry the previous replay picked from the table made beside it
+    const int sel = s_sel;
+    if (sel == kSelStop) break;  // (uniform)
+    int go, mode = 0;
+    double px, py, sn, cs;
+    if (sel >= 0) {
+      const HcNextEntry &e = s_tab[sel];
+      const unsigned flags = e.flags;
+      const int done = (int)((flags >> 3) & 1u);
+      go = (int)((flags >> 4) & 1u);
+      px = e.px;
+      py = e.py;
+      sn = e.sn;
+      cs = e.cs;
+      if (wave == NT / 64 - 1 && lane < 2) {
+        // the new root (its bookkeeping half was written by the replay) and the pose, should the tree be re-scored:
+        // two lanes of the LAST wave -- wave 0 has the scan's surplus beams and the replay, it is the one the
+        // others wait for
         if (lane == 0) {
-          s_pose[pk][0] = px;
-          s_pose[pk][1] = py;
-          s_pose[pk][2] = sn;
-          s_pose[pk][3] = cs;
+          HcState &w = s_st;
+          const unsigned counts = e.counts;
+          const unsigned failed = counts & 0xffffu;
+          const double half = hc_pow_half(failed - w.failed);  // one exact halving per failed round (hc_round_of)
+          w.x = e.x;
+          w.y = e.y;
+          w.theta = e.theta;
+          w.dt = w.dt * half;
+          w.dr = w.dr * half;
+          w.recent_acc = 0.5 * w.recent_acc + (double)(counts >> 28);
+          w.recent_n = 0.5 * w.recent_n + (double)((counts >> 16) & 0xfffu);
+          w.failed = failed;
+          w.shape = (int)(flags & 7u);
+          w.done = done;
+        } else {
+          s_cur[0] = px;
+          s_cur[1] = py;
+          s_cur[2] = sn;
+          s_cur[3] = cs;
+          s_cur_go = go;
         }
       }
-      if (lane == 0) {
-        s_go[pk] = go ? 1 : 0;
-        s_mode[pk] = st.mode;
-        if (st.done) s_stop = 1;
+      if (done && init_slot && t == 0) {
+        // ---- the chain is over: the last workgroup reports (every lane's trace stores first, then the result, then
+        // the flag the host spins on)
+        const HcState &w = s_st;  // (the bookkeeping half: this thread's own stores of the replay)
+        __threadfence_system();
+        HcHostOut *h = host;
+        h->pose[0] = e.x;
+        h->pose[1] = e.y;
+        h->pose[2] = e.theta;
+        h->best_prob = w.best_prob;
+        h->calls = w.calls;
+        h->evaluated = w.evaluated;
+        h->steps = w.steps;
+        h->rescored = w.rescored;
+        h->gm_cx = -1;
+        h->gm_cy = -1;
+        h->gm_prob = -1.0;
+        __hip_atomic_store(&h->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (ap->n_done) {
+          // a batch: the last chain to end tells the host.  This chain's result is on its way to the host BEFORE
+          // it counts itself, so whoever sees the full count may announce everybody's
+          __threadfence_system();
+          const unsigned before = atomicAdd(ap->n_done, 1u);
+          if (before + 1u == gridDim.y && ap->h_all_done)
+            __hip_atomic_store(ap->h_all_done, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
-      if (stamp && k < 64) ap->stamps[8 * k + 3] = wall_clock64();
+      if (done) break;  // (uniform: every thread read the same entry)
+    } else {
+      if (sel == kSelRescore && init_slot) {
+        // a re-scored tree: the bookkeeping workgroup scores its base pose once more (the rare super-step)
+        if (wave == 0) {
+          double sn_, cs_;
+          sincos(s_st.theta, &sn_, &cs_);
+          if (t == 0) {
+            s_cur[0] = s_st.x;
+            s_cur[1] = s_st.y;
+            s_cur[2] = sn_;
+            s_cur[3] = cs_;
+            s_cur_go = 1;
+          }
+        }
+        __syncthreads();  // (uniform: the whole workgroup is the bookkeeping one)
+      }
+      go = s_cur_go;
+      px = s_cur[0];
+      py = s_cur[1];
+      sn = s_cur[2];
+      cs = s_cur[3];
+      mode = sel == kSelRescore ? 1 : 0;
     }
-    __syncthreads();  // (A)
-    if (s_stop) break;
-    const int go = s_go[pk], mode = s_mode[pk];
+    if (stamp && k < 64) ap->stamps[8 * k + 3] = wall_clock64();
     const unsigned tag = hc_tag(ap->tag_epoch, k);
     if (go) {
-      const double px = s_pose[pk][0], py = s_pose[pk][1], sn = s_pose[pk][2], cs = s_pose[pk][3];
       // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order, wave
       // butterfly, (g0+g1)+(g2+g3)) -- k_score_point's order; up to four beams per thread at a time, their cell
       // gathers issued together (hc_chain.hip)
@@ -333,9 +443,63 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       gran_store(&gran[pk * kGranRow + slot], 0.0, 0ull, tag);
       if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0ull, tag);
     }
+    // (a workgroup that scored nothing passed no barrier since it read its pose: the table is rewritten below)
+    if (!go) __syncthreads();
 
-    // ---- wave 0: all scores of super-step k, then its replay
-    if (wave == 0) {
+    if (wave != 0) {
+      // ---- every other wave, while wave 0 waits for the scores: the table of next poses.  Lane = one (terminal
+      // instance, outcome) pair of this super-step's tree (at most 7 x 42 = 294 of the 960 idle lanes of a lone chain)
+      {
+        const HcState &sp = s_st;
+        const int shape = sp.shape;
+        const int n_inst = (int)((ap->n_inst >> (8 * shape)) & 0xffull);
+        const unsigned max_failed = ap->max_failed;
+        for (int e = t - 64; e < 7 * n_inst; e += NT - 64) {
+          const int tl = e / 7, out = e - 7 * tl;
+          HcInst in;
+          {
+            const unsigned long long *src = &ap->shapes[shape].inst[tl].w[0];
+#pragma unroll
+            for (int q = 0; q < 14; ++q) in.w[q] = src[q];
+          }
+          if (!(hc_is_root(in) || sp.failed + hc_nfail_parent(in) < max_failed)) continue;  // not reachable
+          const bool trailing = hc_trailing(sp.failed + hc_nfail(in), max_failed);
+          // only where a walk can END: a trailing round (one candidate: outcomes 0 and 1), or an outcome the shape
+          // speculates no further on
+          if (trailing ? out > 1 : hc_child(in, out) >= 0) continue;
+          const HcRound r = hc_round_of(sp, in);
+          const HcNextCore c = hc_next_core(sp, in, r, out, max_failed);
+          HcNextEntry &w = s_tab[e];
+          w.x = c.x;
+          w.y = c.y;
+          w.theta = c.theta;
+          w.counts = hc_entry_counts(c, hc_nseg(in) + (out > 0 ? 1 : 0));
+          // this workgroup's pose in the tree hanging off that root (the bookkeeping workgroup scores nothing there)
+          bool go = !c.done && !init_slot;
+          double px_ = c.x, py_ = c.y, pth_ = c.theta;
+          if (go) {
+            HcInst mine;
+#pragma unroll
+            for (int q = 0; q < 14; ++q) mine.w[q] = s_mine[c.shape].w[q];
+            go = inst_of_slot < (int)((ap->n_inst >> (8 * c.shape)) & 0xffull) &&
+                 (hc_is_root(mine) || c.failed + hc_nfail_parent(mine) < max_failed);  // else: behind the end of the chain
+            if (go) {
+              const HcRound r2 = hc_round_from(c.x, c.y, c.theta, c.dt, c.dr, c.failed, mine);
+              go = !(hc_trailing(r2.failed, max_failed) && cand > 0);  // a trailing round has one candidate
+              hc_candidate(r2.x, r2.y, r2.theta, r2.dt, r2.dr, cand, &px_, &py_, &pth_);
+            }
+          }
+          double sn_ = 0.0, cs_ = 1.0;
+          if (go) sincos(pth_, &sn_, &cs_);
+          w.px = px_;
+          w.py = py_;
+          w.sn = sn_;
+          w.cs = cs_;
+          w.flags = (unsigned)c.shape | (c.done ? 8u : 0u) | (go ? 16u : 0u);
+        }
+      }
+    } else {
+      // ---- wave 0: all scores of super-step k, then its replay
       const HcState &sp = s_st;  // (fields are read where they are used: a register copy of the struct is 34 VGPRs)
       const int n_inst = (int)((ap->n_inst >> (8 * sp.shape)) & 0xffull);
       // the round instances of this tree's shape, lane = instance: loads in flight while the scores arrive
@@ -350,10 +514,6 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       const bool trailing = reach && hc_trailing(sp.failed + hc_nfail(me), ap->max_failed);
       const int bpi = hc_bp_inst(me);
       const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
-      // where every instance's round starts: closed form of the root and the path, no score involved -- computed
-      // here, while the granules are on their way, instead of on the terminal lane after the ballots
-      HcRound rr{sp.x, sp.y, sp.theta, sp.dt, sp.dr, sp.failed};
-      if (reach) rr = hc_round_of(sp, me);
       // ---- sweep: every workgroup of the grid (the bookkeeping one scored the initial pose / a re-scored base)
       const bool base_here = sp.first || sp.mode == 1;
       const int n_grid = (int)gridDim.x - 1;  // (+ the bookkeeping workgroup)
@@ -403,146 +563,109 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           __hip_atomic_store(&host->error, failed ? 4 : 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __threadfence_system();
           __hip_atomic_store(&host->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          s_stop = 1;
+          s_sel = kSelStop;
         }
-        continue;  // to (A), where the workgroup leaves
-      }
-      // ---- replay of super-step k's tree, lane = round instance (hc_chain.h)
-      double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
-      double s6[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) s6[c] = s_sc[6 * lane + c];
-      const double enter = bp_slot < 0 ? root_prob : s_sc[bp_slot];  // canonical (reported) score entering the round
-      double run = enter;
-      int nacc = 0, out = 0;
-      unsigned accmask = 0u;
-      bool ambiguous = false;
-      unsigned long long run_hash = 0ull;
-      if (!SEQ && verify) {
-        // slot kHcSlots-1 holds the base pose of a re-scored tree (or the initial pose): its sums head the path
-        const unsigned long long root_hash = base_here ? s_hash[kHcSlots - 1] : sp.best_hash;
-        unsigned long long hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
-        unsigned long long h6[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) h6[c] = s_hash[6 * lane + c];
-        if (!rescored) {
-          // decisions from the canonical sums; a comparison closer than the two summation orders can differ
-          // (2^-40, relative) between poses whose term vectors differ is one the tree sum cannot settle
-          int amb = 0;
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const double s = s6[c];
-            const double diff = __builtin_fabs(s - run);
-            const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
-            const int live = (c == 0) | (int)!trailing;
-            const int close = (int)(diff <= (as > ab ? as : ab) * 9.094947017729282e-13);  // NaN: false, a rejection
-            // (equal fingerprints with different sums: not identical vectors -- a collision, equally unsettled)
-            // (bitwise, not short-circuit: one straight line of compares instead of six nested exec-mask branches)
-            amb |= live & close & ((int)(h6[c] != hb) | (int)(__double_as_longlong(s) != __double_as_longlong(run)));
-            const bool acc = (live & (int)(run < s)) != 0;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
-            run = acc ? s : run;
-            hb = acc ? h6[c] : hb;
-            out = acc ? c + 1 : out;
-            nacc += acc ? 1 : 0;
-            accmask |= acc ? 1u << c : 0u;
-          }
-          ambiguous = amb != 0;
-        } else {
-          // re-scored tree: the same comparisons on the beam-order sums.  Their granules were stored next to the
-          // canonical ones by other lanes: wait for their tags as well, one granule at a time (the rare step: a
-          // rolled loop that costs no registers)
-          const HcGranule *q0 = gseq + pk * kGranRow;
-          double bdec = 0.0;
-#pragma unroll 1
-          for (int c = -1; c < 6; ++c) {
-            const int j = c < 0 ? (bp_slot < 0 ? kHcSlots - 1 : bp_slot) : (active ? 6 * lane + c : kHcSlots - 1);
-            double sd = 0.0;
-            for (unsigned spins = 0;; ++spins) {
-              u32x4 g[1];
-              const HcGranule *gp[1] = {q0 + j};
-              gran_fetch(g, gp);
-              sd = gran_score(g[0]);
-              if (__all(gran_tag(g[0]) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
-            }                                                         // the same workgroups are here already)
-            if (c < 0) {
-              bdec = sd;
-              continue;
-            }
-            const bool acc = active && (c == 0 || !trailing) && bdec < sd;
-            bdec = acc ? sd : bdec;
-            run = acc ? s_sc[6 * lane + c] : run;  // the canonical sum of the pose accepted last: stored and reported
-            hb = acc ? s_hash[6 * lane + c] : hb;
-            out = acc ? c + 1 : out;
-            nacc += acc ? 1 : 0;
-            accmask |= acc ? 1u << c : 0u;
-          }
-        }
-        run_hash = hb;
       } else {
+        // ---- replay of super-step k's tree, lane = round instance (hc_chain.h)
+        double root_prob = sp.first ? s_sc[kHcSlots - 1] : sp.best_prob;
+        double s6[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-          if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections
-            run = s6[c];
-            out = c + 1;
-            ++nacc;
-            accmask |= 1u << c;
-          }
-      }
-      bool valid = reach;
-#pragma unroll
-      for (int o = 0; o < 7; ++o) {
-        const unsigned long long has = __ballot(reach && out == o);
-        valid = valid && (me.w[o] & ~has) == 0ull;
-      }
-      const bool terminal = valid && (trailing || hc_child(me, out) < 0);
-      const unsigned long long tmask = __ballot(terminal);
-      // exactly one lane is terminal: the walk's last round
-      const int tl = tmask ? __ffsll((long long)tmask) - 1 : 0;
-      // acceptances on the walked path: a round has at most six, so six ballots and popcounts add them up
-      long long batch_acc = 0;
-#pragma unroll
-      for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
-      if (stamp && k < 64) ap->stamps[8 * k + 7] = wall_clock64();
-      // checked default mode: a comparison on the walked path that the tree sum cannot settle -> the same tree is
-      // scored once more, in beam order as well, and decided from those sums
-      const bool dirty = !SEQ && verify && sp.mode == 0 && __ballot(valid && ambiguous) != 0ull;
-      // the terminal lane's round, outcome and best score in every lane, then the advance computed by all of them
-      HcRound rt;
-      rt.x = bcast(rr.x, tl);
-      rt.y = bcast(rr.y, tl);
-      rt.theta = bcast(rr.theta, tl);
-      rt.dt = bcast(rr.dt, tl);
-      rt.dr = bcast(rr.dr, tl);
-      rt.failed = (unsigned)bcast_i((int)rr.failed, tl);
-      const int out_t = bcast_i(out, tl);
-      const double run_t = bcast(run, tl);
-      const int depth_t = bcast_i(hc_depth(me), tl);
-      const bool trailing_t = bcast_i(trailing ? 1 : 0, tl) != 0;
-      HcState next = sp;
-      if (!dirty) {
-        const long long batch_calls = 6ll * depth_t + (trailing_t ? 1 : 6);
-        hc_advance(sp, me, rt, out_t, run_t, ap->max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0),
-                   &next);
+        for (int c = 0; c < 6; ++c) s6[c] = s_sc[6 * lane + c];
+        const double enter = bp_slot < 0 ? root_prob : s_sc[bp_slot];  // canonical (reported) score entering the round
+        double run = enter;
+        int out = 0;
+        unsigned accmask = 0u;
+        bool ambiguous = false;
+        unsigned long long run_hash = 0ull;
         if (!SEQ && verify) {
-          next.best_hash = (unsigned long long)bcast_ll((long long)run_hash, tl);
-          next.mode = 0;
-          next.rescored = sp.rescored;
+          // slot kHcSlots-1 holds the base pose of a re-scored tree (or the initial pose): its sums head the path
+          const unsigned long long root_hash = base_here ? s_hash[kHcSlots - 1] : sp.best_hash;
+          unsigned long long hb = bp_slot < 0 ? root_hash : s_hash[bp_slot];
+          unsigned long long h6[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) h6[c] = s_hash[6 * lane + c];
+          if (!rescored) {
+            // decisions from the canonical sums; a comparison closer than the two summation orders can differ
+            // (2^-40, relative) between poses whose term vectors differ is one the tree sum cannot settle
+            int amb = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              const double s = s6[c];
+              const double diff = __builtin_fabs(s - run);
+              const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
+              const int live = (c == 0) | (int)!trailing;
+              const int close = (int)(diff <= (as > ab ? as : ab) * 9.094947017729282e-13);  // NaN: false, a rejection
+              // (equal fingerprints with different sums: not identical vectors -- a collision, equally unsettled)
+              // (bitwise, not short-circuit: one straight line of compares instead of six nested exec-mask branches)
+              amb |= live & close & ((int)(h6[c] != hb) | (int)(__double_as_longlong(s) != __double_as_longlong(run)));
+              const bool acc = (live & (int)(run < s)) != 0;  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
+              run = acc ? s : run;
+              hb = acc ? h6[c] : hb;
+              out = acc ? c + 1 : out;
+              accmask |= acc ? 1u << c : 0u;
+            }
+            ambiguous = amb != 0;
+          } else {
+            // re-scored tree: the same comparisons on the beam-order sums.  Their granules were stored next to the
+            // canonical ones by other lanes: wait for their tags as well, one granule at a time (the rare step: a
+            // rolled loop that costs no registers)
+            const HcGranule *q0 = gseq + pk * kGranRow;
+            double bdec = 0.0;
+#pragma unroll 1
+            for (int c = -1; c < 6; ++c) {
+              const int j = c < 0 ? (bp_slot < 0 ? kHcSlots - 1 : bp_slot) : (active ? 6 * lane + c : kHcSlots - 1);
+              double sd = 0.0;
+              for (unsigned spins = 0;; ++spins) {
+                u32x4 g[1];
+                const HcGranule *gp[1] = {q0 + j};
+                gran_fetch(g, gp);
+                sd = gran_score(g[0]);
+                if (__all(gran_tag(g[0]) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+              }                                                                 // the same workgroups are here already)
+              if (c < 0) {
+                bdec = sd;
+                continue;
+              }
+              const bool acc = active && (c == 0 || !trailing) && bdec < sd;
+              bdec = acc ? sd : bdec;
+              run = acc ? s_sc[6 * lane + c] : run;  // the canonical sum of the pose accepted last: stored and reported
+              hb = acc ? s_hash[6 * lane + c] : hb;
+              out = acc ? c + 1 : out;
+              accmask |= acc ? 1u << c : 0u;
+            }
+          }
+          run_hash = hb;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections
+              run = s6[c];
+              out = c + 1;
+              accmask |= 1u << c;
+            }
         }
-      } else {
-        // same root, same tree, same `first`
-        next.mode = 1;
-        next.steps = sp.steps + 1;
-        next.evaluated = sp.evaluated + 6ll * n_inst + 1;
-        next.rescored = sp.rescored + 1;
-      }
-      if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
-        next.done = 1;
-        if (init_slot && lane == 0) host->error = 1;
-      }
-      if (stamp && k < 64) ap->stamps[8 * k + 2] = wall_clock64();
-      if (init_slot) {
-        // ---- the last workgroup keeps the books (it scores nothing after the first super-step)
-        if (ap->trace && !dirty) {
+        bool valid = reach;
+#pragma unroll
+        for (int o = 0; o < 7; ++o) {
+          const unsigned long long has = __ballot(reach && out == o);
+          valid = valid && (me.w[o] & ~has) == 0ull;
+        }
+        const bool terminal = valid && (trailing || hc_child(me, out) < 0);
+        const unsigned long long tmask = __ballot(terminal);
+        // exactly one lane is terminal: the walk's last round
+        const int tl = tmask ? __ffsll((long long)tmask) - 1 : 0;
+        if (stamp && k < 64) ap->stamps[8 * k + 7] = wall_clock64();
+        // checked default mode: a comparison on the walked path that the tree sum cannot settle -> the same tree is
+        // scored once more, in beam order as well, and decided from those sums
+        const bool dirty = !SEQ && verify && sp.mode == 0 && __ballot(valid && ambiguous) != 0ull;
+        // the terminal lane's outcome and best score in every lane; where the next tree hangs is in the table
+        const int out_t = bcast_i(out, tl);
+        const double run_t = bcast(run, tl);
+        const int depth_t = bcast_i(hc_depth(me), tl);
+        const bool trailing_t = bcast_i(trailing ? 1 : 0, tl) != 0;
+        const unsigned long long run_hash_t = (unsigned long long)bcast_ll((long long)run_hash, tl);
+        if (init_slot && ap->trace && !dirty) {
+          // ---- the last workgroup keeps the books (it scores nothing after the first super-step)
           HcTraceEntry *const trace = ap->trace + (size_t)blockIdx.y * (size_t)ap->trace_stride;
           const long long base = sp.calls + (sp.first ? 1 : 0);
           if (sp.first && lane == 0 && ap->trace_cap > 0) {
@@ -550,6 +673,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             trace[0] = e;
           }
           if (valid) {
+            const HcRound rr = hc_round_of(sp, me);
             const int nc = trailing ? 1 : 6;
             for (int c = 0; c < nc; ++c) {
               HcTraceEntry e;
@@ -563,68 +687,51 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             }
           }
         }
-        if (next.done) {
-          // every lane's trace stores first, then the result, then the flag the host spins on
-          __threadfence_system();
-          if (lane == 0) {
-            HcHostOut *h = host;
-            h->pose[0] = next.x;
-            h->pose[1] = next.y;
-            h->pose[2] = next.theta;
-            h->best_prob = next.best_prob;
-            h->calls = next.calls;
-            h->evaluated = next.evaluated;
-            h->steps = next.steps;
-            h->rescored = next.rescored;
-            h->gm_cx = -1;
-            h->gm_cy = -1;
-            h->gm_prob = -1.0;
-            __hip_atomic_store(&h->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (ap->n_done) {
-              // a batch: the last chain to end tells the host.  This chain's result is on its way to the host BEFORE
-              // it counts itself, so whoever sees the full count may announce everybody's
+        if (stamp && k < 64) ap->stamps[8 * k + 2] = wall_clock64();
+        if (lane == 0) {
+          // the bookkeeping half of the next root state (`sp` above is this very object: the trace was written from
+          // the old state first); the other half -- pose, steps, shape -- is copied from the table behind the barrier
+          HcState &w = s_st;
+          if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
+            if (init_slot) {
+              __hip_atomic_store(&host->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               __threadfence_system();
-              const unsigned before = atomicAdd(ap->n_done, 1u);
-              if (before + 1u == gridDim.y && ap->h_all_done)
-                __hip_atomic_store(ap->h_all_done, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(&host->done_seq, ap->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            s_sel = kSelStop;
+          } else if (!dirty) {
+            w.best_prob = run_t;
+            w.calls = sp.calls + (sp.first ? 1 : 0) + 6ll * depth_t + (trailing_t ? 1 : 6);
+            w.evaluated = sp.evaluated + 6ll * n_inst + (sp.first ? 1 : 0);
+            w.first = 0;
+            w.mode = 0;
+            w.steps = sp.steps + 1;
+            if (!SEQ && verify) w.best_hash = run_hash_t;
+            s_sel = 7 * tl + out_t;
+          } else {
+            // same root, same tree, same `first`
+            w.mode = 1;
+            w.steps = sp.steps + 1;
+            w.evaluated = sp.evaluated + 6ll * n_inst + 1;
+            w.rescored = sp.rescored + 1;
+            s_sel = kSelRescore;
           }
         }
       }
-      if (lane == 0) {
-        // (`sp` above is this very object: the books are kept from the old state first.  Field by field, and only what
-        // a super-step changes: the whole struct assigned went through scratch -- a store and a load through memory
-        // between two super-steps -- for the GMapping carry fields this kernel never touches)
-        HcState &w = s_st;
-        w.x = next.x;
-        w.y = next.y;
-        w.theta = next.theta;
-        w.best_prob = next.best_prob;
-        w.dt = next.dt;
-        w.dr = next.dr;
-        w.recent_acc = next.recent_acc;
-        w.recent_n = next.recent_n;
-        w.calls = next.calls;
-        w.evaluated = next.evaluated;
-        w.failed = next.failed;
-        w.shape = next.shape;
-        w.done = next.done;
-        w.first = next.first;
-        w.steps = next.steps;
-        w.mode = next.mode;
-        w.best_hash = next.best_hash;
-        w.rescored = next.rescored;
-      }
     }
+    __syncthreads();  // (A) the table is complete and the replay has picked its entry
   }
 }
 
-// dynamic LDS of a workgroup: the beams' terms and, with lds_consts, range, cosine and sine of the beams behind every
-// thread's first one
-size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts) {
+// dynamic LDS of a workgroup: the beams' terms, with lds_consts range, cosine and sine of the beams behind every
+// thread's first one, and the table of next poses (7 entries per round instance of the largest shape)
+size_t hc_resident_tab_offset(int nt, int n_beams, bool lds_consts) {  // (in doubles)
   const size_t n = (size_t)(n_beams > 0 ? n_beams : 1);
   const size_t more = lds_consts && n > (size_t)nt ? n - (size_t)nt : 0;
-  return sizeof(double) * (n + 3 * more);
+  return n + 3 * more;
+}
+size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst) {
+  return sizeof(double) * hc_resident_tab_offset(nt, n_beams, lds_consts) + sizeof(HcNextEntry) * 7 * (size_t)max_inst;
 }
 
 #define HCR_LAUNCH(NTV, GV)                                                                                     \
@@ -648,11 +755,13 @@ static int gran_per_lane(int grid) { return grid <= 128 ? 2 : (grid <= 256 ? 4 :
 
 // the window OOPEs: lone chains of at most 256 workgroups, default sum order
 template <int MODEL>
-static hipError_t launch_res_win(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+static hipError_t launch_res_win(const HcChainArgs &a_in, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                                  int n_chains) {
+  HcChainArgs a = a_in;
   const int grid = 6 * a.max_inst + 1;
   if (grid > 256) return hipErrorInvalidValue;
-  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, false);  // (the window form keeps no beam constants in LDS)
+  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, false, a.max_inst);  // (the window form keeps no beam constants in LDS)
+  a.tab_offset = (int)hc_resident_tab_offset(nt, a.scan.n, false);
   if (nt == 1024) HCR_LAUNCH_WIN(1024);
   else if (nt == 256) HCR_LAUNCH_WIN(256);
   else HCR_LAUNCH_WIN(512);
@@ -661,10 +770,12 @@ static hipError_t launch_res_win(const HcChainArgs &a, int nt, hipStream_t strea
 #undef HCR_LAUNCH_WIN
 
 template <int MODEL, bool SEQ, bool BATCH>
-static hipError_t launch_res(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+static hipError_t launch_res(const HcChainArgs &a_in, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                              int n_chains) {
+  HcChainArgs a = a_in;
   const int grid = 6 * a.max_inst + 1;
-  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, a.lds_consts != 0);
+  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, a.lds_consts != 0, a.max_inst);
+  a.tab_offset = (int)hc_resident_tab_offset(nt, a.scan.n, a.lds_consts != 0);
   const int g = gran_per_lane(grid);
   // (workgroup sizes and sweep widths that go together: a lone chain is 253 x 1024 threads, a batch's chains are
   // narrower trees of narrower workgroups)
@@ -709,30 +820,52 @@ hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt
   return hipErrorInvalidValue;
 }
 
-// workgroups of `nt` threads (scoring `n_beams`: hc_resident_lds_bytes of dynamic LDS) the device keeps resident at once, by the occupancy
-// query with the register-file rule of MI355X_MICROARCH.md ("Residency and cooperative launch": the API can be one
-// block per CU high above 80 SGPRs; this kernel's waves also need <= 128 VGPRs at 1024 threads) and one CU of margin
-hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, int n_beams, bool lds_consts, int *out_wgs) {
-  const size_t lds_bytes = hc_resident_lds_bytes(nt, n_beams, lds_consts);
+// the instantiation launch_res / launch_res_win pick for a workgroup size and a sweep width
+template <int M, bool B>
+static const void *res_fn(int nt, int g) {
+  if (nt == 1024)
+    return g == 2 ? (const void *)k_hc_chain_resident<M, 1024, false, B, 2>
+                  : (g == 4 ? (const void *)k_hc_chain_resident<M, 1024, false, B, 4> : nullptr);
+  if (nt == 256)
+    return g == 2 ? (const void *)k_hc_chain_resident<M, 256, false, B, 2>
+                  : (g == 4 ? (const void *)k_hc_chain_resident<M, 256, false, B, 4>
+                            : (const void *)k_hc_chain_resident<M, 256, false, B, 7>);
+  return g == 2 ? (const void *)k_hc_chain_resident<M, 512, false, B, 2>
+                : (g == 4 ? (const void *)k_hc_chain_resident<M, 512, false, B, 4>
+                          : (const void *)k_hc_chain_resident<M, 512, false, B, 7>);
+}
+template <int M>
+static const void *res_fn_win(int nt) {
+  return nt == 1024 ? (const void *)k_hc_chain_resident<M, 1024, false, false, 4, true>
+                    : (nt == 256 ? (const void *)k_hc_chain_resident<M, 256, false, false, 4, true>
+                                 : (const void *)k_hc_chain_resident<M, 512, false, false, 4, true>);
+}
+
+// Workgroups of `nt` threads (scoring `n_beams`, trees of `max_inst` round instances: hc_resident_lds_bytes of dynamic
+// LDS) the device keeps resident at once: the occupancy query of the instantiation that will be LAUNCHED, the
+// register-file rule of MI355X_MICROARCH.md ("Residency and cooperative launch": the API can be one block per CU high
+// above 80 SGPRs; this kernel's waves also need <= 128 VGPRs at 1024 threads), minus ONE CU's worth of workgroups of
+// margin -- a grid that needs every slot of the chip waits for any other kernel's last workgroup to leave.
+hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window, int n_beams, bool lds_consts, int max_inst,
+                                int *out_wgs) {
+  const size_t lds_bytes = hc_resident_lds_bytes(nt, n_beams, lds_consts, max_inst);
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e != hipSuccess) return e;
   const void *fn = nullptr;
-#define HCR_FN(M, B)                                                                                  \
-  (nt == 1024 ? (const void *)k_hc_chain_resident<M, 1024, false, B, 4>                               \
-              : (nt == 256 ? (const void *)k_hc_chain_resident<M, 256, false, B, 7>                   \
-                           : (const void *)k_hc_chain_resident<M, 512, false, B, 7>))
-  if (cell_model == SLAMHIP_CELL_TBM) fn = batch ? HCR_FN(SLAMHIP_CELL_TBM, true) : HCR_FN(SLAMHIP_CELL_TBM, false);
-  else fn = batch ? HCR_FN(SLAMHIP_CELL_OCC, true) : HCR_FN(SLAMHIP_CELL_OCC, false);
-#undef HCR_FN
+  const int g = window ? 4 : gran_per_lane(6 * max_inst + 1);
+  if (window) fn = cell_model == SLAMHIP_CELL_TBM ? res_fn_win<SLAMHIP_CELL_TBM>(nt) : res_fn_win<SLAMHIP_CELL_OCC>(nt);
+  else if (batch) fn = cell_model == SLAMHIP_CELL_TBM ? res_fn<SLAMHIP_CELL_TBM, true>(nt, g) : res_fn<SLAMHIP_CELL_OCC, true>(nt, g);
+  else fn = cell_model == SLAMHIP_CELL_TBM ? res_fn<SLAMHIP_CELL_TBM, false>(nt, g) : res_fn<SLAMHIP_CELL_OCC, false>(nt, g);
+  if (!fn) return hipErrorInvalidValue;
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, lds_bytes);
   if (e != hipSuccess) return e;
   const int by_waves = 2048 / nt;  // 128-VGPR waves: four per SIMD
   per_cu = per_cu < by_waves ? per_cu : by_waves;
   if (per_cu > 6) per_cu = 6;      // floor(800 / (ceil(sgpr / 16) * 16 + 16)) at ~106 SGPRs
-  *out_wgs = per_cu * cus;
+  *out_wgs = per_cu * (cus - 1);
   return hipSuccess;
 }
 

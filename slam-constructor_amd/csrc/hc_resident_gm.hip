@@ -343,14 +343,13 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
       const double enter = bp_slot < 0 ? root_prob : s_sc[bp_slot];
       double run = enter;
-      int nacc = 0, out = 0;
+      int out = 0;
       unsigned accmask = 0u;
 #pragma unroll
       for (int c = 0; c < 6; ++c)
         if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
           run = s6[c];
           out = c + 1;
-          ++nacc;
           accmask |= 1u << c;
         }
       bool valid = reach;
@@ -362,9 +361,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       const bool terminal = valid && (trailing || hc_child(me, out) < 0);
       const unsigned long long tmask = __ballot(terminal);
       const int tl = tmask ? __ffsll((long long)tmask) - 1 : 0;
-      long long batch_acc = 0;
-#pragma unroll
-      for (int v = 1; v <= 6; ++v) batch_acc += (long long)v * __popcll(__ballot(valid && nacc == v));
       if (stamp && k < 64) ap->stamps[8 * k + 7] = wall_clock64();
       // (the round states are made AFTER the decisions here, unlike hc_resident.hip: the cache fix-ups above are at
       // the register limit of a 1024-thread workgroup, and eleven live registers less is the difference to spilling)
@@ -379,12 +375,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       rt.failed = (unsigned)bcast_i((int)rr.failed, tl);
       const int out_t = bcast_i(out, tl);
       const double run_t = bcast(run, tl);
-      const int depth_t = bcast_i(hc_depth(me), tl);
-      const bool trailing_t = bcast_i(trailing ? 1 : 0, tl) != 0;
       HcState next = sp;
       {
-        const long long batch_calls = 6ll * depth_t + (trailing_t ? 1 : 6);
-        hc_advance(sp, me, rt, out_t, run_t, ap->max_failed, batch_calls, batch_acc, 6ll * n_inst + (sp.first ? 1 : 0), &next);
+        // (the terminal lane's instance record in every lane: hc_next_core reads its depth and its path's moves)
+        HcInst mt;
+        mt.w[9] = (unsigned long long)bcast_ll((long long)me.w[9], tl);
+        hc_advance(sp, mt, rt, out_t, run_t, ap->max_failed, 6ll * n_inst + (sp.first ? 1 : 0), &next);
       }
       {
         // the cache after the walk's last scorer call: the terminal round's last candidate
@@ -545,7 +541,7 @@ hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs) {
   per_cu = per_cu < by_waves ? per_cu : by_waves;
   if (nt == 256 && per_cu > 3) per_cu = 3;
   if (per_cu > 6) per_cu = 6;
-  *out_wgs = per_cu * cus;
+  *out_wgs = per_cu * (cus - 1);  // (one CU's worth of margin: hc_resident_capacity)
   return hipSuccess;
 }
 

@@ -42,8 +42,12 @@ struct slamhip_matcher {
   slamhip::McResidentCtl *d_mc_rctl = nullptr;
   int mc_rctl_grid = 0;  // workgroups of the last co-resident Monte-Carlo launch
   unsigned rctl_launches = 0;  // co-resident launches on this matcher's exchange block: the epoch bits of the tags (hc_tag)
-  int resident_cap[6] = {0, 0, 0, 0, 0, 0};        // by workgroup size, without / with the beam constants in LDS
-  int resident_cap_beams[6] = {0, 0, 0, 0, 0, 0};  // the scan length the capacity was asked for
+  // answers of the occupancy query so far, keyed by everything the answer depends on (kernel instantiation: cell model,
+  // workgroup size, lone / batch / window form, sweep width via max_inst; dynamic LDS: scan length, beam constants)
+  struct ResidentCap {
+    int cell_model, nt, form, n_beams, lds_consts, max_inst, cap;
+  };
+  std::vector<ResidentCap> resident_caps;
   int resident_gave_up_row = 0;
   int debug_resident_mute = 0;  // testing (slamhip_matcher_debug_resident_mute)
   long long resident_gave_up = 0, resident_matches = 0;
@@ -224,31 +228,38 @@ bool resident_wanted(slamhip_matcher *m) {
   return m->chain_mode == 2 && (m->cfg.oope == SLAMHIP_OOPE_OBSTACLE || is_window_oope(m->cfg.oope) || gm) &&
          m->resident_gave_up_row < 3;
 }
-int resident_capacity(slamhip_matcher *m, int cell_model, int nt, bool batch, int n_beams, bool lds_consts, int *wgs) {
-  const int idx = (nt == 1024 ? 2 : (nt == 512 ? 1 : 0)) + (lds_consts ? 3 : 0);
-  if (m->resident_cap[idx] == 0 || n_beams > m->resident_cap_beams[idx]) {  // (a longer scan: more LDS per workgroup)
-    int cap = 0;
-    SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, batch, n_beams, lds_consts, &cap));
-    m->resident_cap[idx] = cap > 0 ? cap : -1;
-    m->resident_cap_beams[idx] = n_beams;
-  }
-  *wgs = m->resident_cap[idx] > 0 ? m->resident_cap[idx] : 0;
+// form: 0 a lone chain, 1 a batch (job table), 2 a window OOPE, 3 Monte Carlo
+int resident_capacity(slamhip_matcher *m, int cell_model, int nt, int form, int n_beams, bool lds_consts, int max_inst,
+                      int *wgs) {
+  for (const auto &c : m->resident_caps)
+    if (c.cell_model == cell_model && c.nt == nt && c.form == form && c.n_beams == n_beams &&
+        c.lds_consts == (lds_consts ? 1 : 0) && c.max_inst == max_inst) {
+      *wgs = c.cap;
+      return SLAMHIP_OK;
+    }
+  int cap = 0;
+  if (form == 3) SLAMHIP_CHECK(mc_resident_capacity(cell_model, nt, n_beams, lds_consts, &cap));
+  else SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, form == 1, form == 2, n_beams, lds_consts, max_inst, &cap));
+  if (cap < 0) cap = 0;
+  if (m->resident_caps.size() >= 64) m->resident_caps.clear();  // (scans of ever-changing lengths: start over)
+  m->resident_caps.push_back({cell_model, nt, form, n_beams, lds_consts ? 1 : 0, max_inst, cap});
+  *wgs = cap;
   return SLAMHIP_OK;
 }
 // the 1-cell form keeps the further beams' constants in LDS (HcChainArgs::lds_consts) when `wgs_needed` workgroups
 // are resident together with that much LDS each
-int resident_capacity_pick(slamhip_matcher *m, int cell_model, int nt, bool batch, int n_beams, int wgs_needed,
+int resident_capacity_pick(slamhip_matcher *m, int cell_model, int nt, int form, int n_beams, int max_inst, int wgs_needed,
                            bool may_lds_consts, int *lds_consts, int *wgs) {
   *lds_consts = 0;
   if (may_lds_consts) {
-    int rc = resident_capacity(m, cell_model, nt, batch, n_beams, true, wgs);
+    int rc = resident_capacity(m, cell_model, nt, form, n_beams, true, max_inst, wgs);
     if (rc) return rc;
     if (wgs_needed <= *wgs) {
       *lds_consts = 1;
       return SLAMHIP_OK;
     }
   }
-  return resident_capacity(m, cell_model, nt, batch, n_beams, false, wgs);
+  return resident_capacity(m, cell_model, nt, form, n_beams, false, max_inst, wgs);
 }
 
 int chain_prepare(slamhip_matcher *m) {
@@ -332,8 +343,8 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
     const bool gm_res = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
     int cap = 0;
     if (gm_res) SLAMHIP_CHECK(hc_resident_gm_capacity(m->chain_nt, a.scan.n, &cap));
-    else rc = resident_capacity_pick(m, cell_model, m->chain_nt, false, a.scan.n, 6 * a.max_inst + 1,
-                                     !is_window_oope(m->cfg.oope), &a.lds_consts, &cap);
+    else rc = resident_capacity_pick(m, cell_model, m->chain_nt, is_window_oope(m->cfg.oope) ? 2 : 0, a.scan.n, a.max_inst,
+                                     6 * a.max_inst + 1, !is_window_oope(m->cfg.oope), &a.lds_consts, &cap);
     if (rc) return rc;
     if (6 * a.max_inst + 1 > cap) return kResidentGaveUp;  // (not counted: this matcher's grid never fits)
     if (gm_res && !m->d_rctl_gm) {
@@ -727,7 +738,8 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   b->ran_resident = false;
   if (resident_wanted(m) && !a.seq) {
     int cap_wgs = 0;
-    int rc0 = resident_capacity_pick(m, cell_model, b->nt, true, max_n, n * (6 * b->max_inst + 1), true, &a.lds_consts, &cap_wgs);
+    int rc0 = resident_capacity_pick(m, cell_model, b->nt, 1, max_n, b->max_inst, n * (6 * b->max_inst + 1), true,
+                                     &a.lds_consts, &cap_wgs);
     if (rc0) return rc0;
     if (n * (6 * b->max_inst + 1) <= cap_wgs) {
       if (!b->d_rctl) {
@@ -1496,27 +1508,21 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     int cap = 0;
     // (1024-thread workgroups are resident one per CU: 252 candidates per super-step then, like the hill-climbing tree)
     if (m->chain_nt == 1024) a.n_slots = std::min(a.n_slots, 252);
-    // (the occupancy query once per workgroup size and scan length, like resident_capacity)
-    auto mc_cap = [&](bool ldsc, int *out) -> int {
-      const int idx = (m->chain_nt == 1024 ? 2 : 1) + (ldsc ? 3 : 0);
-      if (m->resident_cap[idx] == 0 || a.scan.n > m->resident_cap_beams[idx]) {
-        int c = 0;
-        SLAMHIP_CHECK(mc_resident_capacity(cell_model, m->chain_nt, a.scan.n, ldsc, &c));
-        m->resident_cap[idx] = c > 0 ? c : -1;
-        m->resident_cap_beams[idx] = a.scan.n;
-      }
-      *out = m->resident_cap[idx] > 0 ? m->resident_cap[idx] : 0;
-      return SLAMHIP_OK;
-    };
     a.lds_consts = 1;
-    rc = mc_cap(true, &cap);
+    rc = resident_capacity(m, cell_model, m->chain_nt, 3, a.scan.n, true, 0, &cap);
     if (rc) return rc;
-    if (a.n_slots + 1 > cap) {
-      a.lds_consts = 0;
-      rc = mc_cap(false, &cap);
+    if (a.n_slots + 1 > cap) {  // (fewer workgroups fit with the beam constants in LDS than without?)
+      int cap_plain = 0;
+      rc = resident_capacity(m, cell_model, m->chain_nt, 3, a.scan.n, false, 0, &cap_plain);
       if (rc) return rc;
+      if (cap_plain > cap) {
+        a.lds_consts = 0;
+        cap = cap_plain;
+      }
     }
-    if (a.n_slots + 1 <= cap) {
+    // (the capacity leaves one CU's worth of workgroups free: 509 candidates + the bookkeeping workgroup on an MI355X)
+    a.n_slots = std::min(a.n_slots, cap - 1);
+    if (a.n_slots >= 64) {
       if (!m->d_mc_rctl) {
         SLAMHIP_CHECK(hipMalloc(&m->d_mc_rctl, sizeof(McResidentCtl)));
         SLAMHIP_CHECK(hipMemsetAsync(m->d_mc_rctl, 0, sizeof(McResidentCtl), ctx->stream));  // (ordered with the launch)

@@ -495,7 +495,7 @@ hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_co
   if (e != hipSuccess) return e;
   const int by_waves = 2048 / nt;  // 128-VGPR waves: four per SIMD
   per_cu = per_cu < by_waves ? per_cu : by_waves;
-  *out_wgs = per_cu * cus;
+  *out_wgs = per_cu * (cus - 1);  // (one CU's worth of margin: hc_resident_capacity)
   return hipSuccess;
 }
 

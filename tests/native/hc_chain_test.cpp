@@ -106,12 +106,10 @@ std::vector<Entry> chain_loop(const std::vector<HcShape> &shapes, unsigned max_f
     for (int i = 0; i < kHcMaxInst; ++i)
       if (reach[i]) has[out[i]] |= 1ull << i;
     int terminal = -1, n_term = 0;
-    long long batch_acc = 0;
     for (int i = 0; i < kHcMaxInst; ++i) {
       const HcInst &me = sh.inst[i];
       valid[i] = reach[i];
       for (int o = 0; o < 7; ++o) valid[i] = valid[i] && (me.w[o] & ~has[o]) == 0ull;
-      if (valid[i]) batch_acc += nacc[i];
       if (valid[i] && (trailing[i] || hc_child(me, out[i]) < 0)) {
         terminal = i;
         ++n_term;
@@ -142,8 +140,7 @@ std::vector<Entry> chain_loop(const std::vector<HcShape> &shapes, unsigned max_f
     }
     HcState next;
     const HcRound r = hc_round_of(st, tm);
-    hc_advance(st, tm, r, out[terminal], run[terminal], max_failed, 6ll * hc_depth(tm) + (trailing[terminal] ? 1 : 6),
-               batch_acc, 6ll * sh.n_inst + (st.first ? 1 : 0), &next);
+    hc_advance(st, tm, r, out[terminal], run[terminal], max_failed, 6ll * sh.n_inst + (st.first ? 1 : 0), &next);
     st = next;
   }
   *best_out = Pose{st.x, st.y, st.theta};
