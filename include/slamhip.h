@@ -324,14 +324,22 @@ int slamhip_matcher_set_device_chain(slamhip_matcher *m, int mode, int threads);
 /* mode 2's bookkeeping: matches launched in the co-resident form, and how many of them gave up (bounded wait ran
  * out) and were redone by the chain of kernels */
 int slamhip_matcher_resident_stats(slamhip_matcher *m, long long *matches, long long *gave_up);
-/* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell OOPE is CHECKED (on = 1, the default): a `best < candidate`
- * (pose_enumeration_scan_matcher.h:58) between canonical tree sums that lie within 2^-40 of each other -- more
- * than the two orders of summation can differ by -- and whose beam terms are not identical (compared through a
- * fingerprint of the term vector) is not decided from the tree sums: the poses in question are summed once more in
- * the reference's beam order (weighted_mean_point_probability_spe.h:108-124) and those sums decide.  The accept
- * chain is then the one SLAMHIP_SUM_SEQUENTIAL gives, at the default mode's speed; reported scores stay the
- * canonical sums.  on = 0: decisions from the tree sums as they are (ties between mathematically equal
- * candidates can then fall the other way: 4 of 200 fuzzed matches, tests/test_gpu_hc_chain.py). */
+/* The default mode (SLAMHIP_SUM_TREE256) over the 1-cell AND the window OOPEs (max / mean / overlap: r05) is CHECKED
+ * (on = 1, the default) in every form -- co-resident launch, chain of kernels, host-driven batches, brute-force
+ * sweep: a `best < candidate` (pose_enumeration_scan_matcher.h:58) between canonical tree sums that lie within 2^-40
+ * of each other -- more than the two orders of summation can differ by -- and whose beam terms are not identical
+ * (compared through a fingerprint of the term vector) is not decided from the tree sums: the poses in question are
+ * summed once more in the reference's beam order (weighted_mean_point_probability_spe.h:108-124) and those sums
+ * decide.  The accept chain is then the one SLAMHIP_SUM_SEQUENTIAL gives, at the default mode's speed; reported
+ * scores stay the canonical sums.  on = 0: decisions from the tree sums as they are (ties between mathematically
+ * equal candidates can then fall the other way: 4 of 200 fuzzed matches over the 1-cell OOPE, 2 of 200 over `max`,
+ * tests/test_gpu_hc_chain.py).
+ * NOT checked: the GMapping OOPE.  Its per-beam value is exp() of a distance and the device's exp is not glibc's, so
+ * there is no bit-exact sum to fall back on; its chains decide from the canonical sums.  Measured against the
+ * oracle's strict loop (reference order, libm): 0 of 200 fuzzed matches part from it at failed-round limits 6 (what
+ * GMapping hard-wires, init_gmapping.h:58-60), 10 and 14; at limit 27 -- steps of 7e-10 m around an optimum, where
+ * the candidates' scores differ by less than the last bits of ANY double-precision evaluation -- 17 of 20 do, each
+ * at a comparison whose two strict-mode scores lie within 16 ulps (the same test file). */
 int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],

@@ -315,7 +315,9 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   a.gm_cy = ctx->gm_cy;
   a.gm_prob = ctx->gm_prob;
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
-  a.verify = (tie_check_default(m) && !a.seq && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE) ? 1 : 0;
+  // (the 1-cell AND the window OOPEs: `max` is as discrete as the 1-cell value, so mathematically tied candidates
+  // are as likely -- VERDICT r4 item 2; the GMapping OOPE's chains decide from the tree sums: include/slamhip.h)
+  a.verify = (tie_check_default(m) && !a.seq && m->cfg.oope != SLAMHIP_OOPE_GMAPPING) ? 1 : 0;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
   a.n_inst = 0;
@@ -1258,7 +1260,7 @@ int bf_device_process_scan(slamhip_matcher *m, int map_id, const double init_pos
   int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
   if (rc) return rc;
   (void)tie_check_default(m);
-  const bool verify = m->tie_check == 1 && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE;
+  const bool verify = m->tie_check == 1;  // (the GMapping OOPE never gets here: bf_device_eligible)
   const double t0 = MatchJob::now_us();
   // (the enumerator object stays the one source of the latched base pose: a match that falls back to the host-driven
   // batches enumerates around the same pose)
@@ -1950,8 +1952,8 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   m->t_stage_us = m->t_score_us = 0;
   // the checked default mode of the host-driven batches (the device chain has its own, csrc/hc_chain.hip)
   (void)tie_check_default(m);
-  const bool checked = m->tie_check == 1 && !gm && m->cfg.oope == SLAMHIP_OOPE_OBSTACLE &&
-                       m->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->low_latency && !ctx->stage_poses;
+  const bool checked = m->tie_check == 1 && !gm && m->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->low_latency &&
+                       !ctx->stage_poses;
   m->chain_rescored = 0;
   GmCarry carry;
   carry.cx = ctx->gm_cx;

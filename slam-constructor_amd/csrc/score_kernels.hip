@@ -464,11 +464,15 @@ template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) {
   __shared__ double s_pose[kMaxPosesPerBlock][4];
   __shared__ double s_part[kMaxPosesPerBlock][4];
+  __shared__ unsigned long long s_hpart[kMaxPosesPerBlock][4];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int n = a.scan.n;
   const int p0 = blockIdx.x * a.poses_per_block;
   const int npb = min(a.poses_per_block, a.n_poses - p0);
+  // (the checked default mode over the window OOPEs, r05: K1's term-vector fingerprint, same multipliers)
+  const bool fprint = a.fprints != nullptr;
+  const unsigned fk_lo = (2u * (unsigned)t + 1u) * 0x9E3779B1u, fk_hi = (2u * (unsigned)t + 1u) * 0x85EBCA6Bu;
   if (t < npb) {
     const int p = p0 + t;
     double sn, cs;
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
   for (int j = 0; j < npb; ++j) {
     const double x = s_pose[j][0], y = s_pose[j][1], sn = s_pose[j][2], cs = s_pose[j][3];
     double acc = 0.0;
+    unsigned long long h = 0ull;
     for (int b = t; b < n; b += kBlock) {
       const double ca = a.scan.cos_a[b], sa = a.scan.sin_a[b], r = a.scan.range[b];
       const double c = cs * ca - sn * sa;
@@ -497,14 +502,22 @@ __global__ __launch_bounds__(kBlock) void k_score_window(ScoreArgs a, int oope) 
       const double term = pr * a.scan.weight[b] * a.scan.factor[b];
       if (a.terms) a.terms[(size_t)(p0 + j) * n + b] = term;
       acc = acc + term;
+      if (fprint) {
+        const unsigned kq = (unsigned)(b / kBlock);
+        h += term_fingerprint(term, fk_lo + kq * (2u * kBlock * 0x9E3779B1u), fk_hi + kq * (2u * kBlock * 0x85EBCA6Bu));
+      }
     }
-    acc = wave_xor_sum(acc);
-    if (lane == 0) s_part[j][wave] = acc;
+    wave_xor_sum_with(acc, h);  // (the butterfly of wave_xor_sum with the fingerprint riding along: same sum bits)
+    if (lane == 0) {
+      s_part[j][wave] = acc;
+      s_hpart[j][wave] = h;
+    }
   }
   __syncthreads();
   if (t < npb) {
     const double total = (s_part[t][0] + s_part[t][1]) + (s_part[t][2] + s_part[t][3]);
     a.scores[p0 + t] = (a.scan.tot_w == 0.0) ? __builtin_nan("") : total / a.scan.tot_w;
+    if (fprint) a.fprints[p0 + t] = s_hpart[t][0] + s_hpart[t][1] + s_hpart[t][2] + s_hpart[t][3];
   }
 }
 
@@ -599,6 +612,7 @@ hipError_t launch_score(const ScoreArgs &args, int cell_model, int oope, int sum
   }
   if (oope == SLAMHIP_OOPE_MAX || oope == SLAMHIP_OOPE_MEAN || oope == SLAMHIP_OOPE_OVERLAP) {
     if (!wt) a.terms = nullptr;
+    if (wt) a.fprints = nullptr;
     if (cell_model == SLAMHIP_CELL_OCC)
       SLAMHIP_LAUNCH((k_score_window<SLAMHIP_CELL_OCC>), grid, dim3(kBlock), 0, stream, ev_start, stop1, a, oope);
     else if (cell_model == SLAMHIP_CELL_TBM)

@@ -401,7 +401,7 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
     rc = fill_args(ctx, *m, cfg, n_poses, poses_src, sc_src, ctx->h_scores + off, &a);
     if (rc) return rc;
     if (gm) a.gm_info = ctx->h_gm_info + off;
-    if (ctx->want_fprints && cfg->oope == SLAMHIP_OOPE_OBSTACLE && cfg->sum_order == SLAMHIP_SUM_TREE256)
+    if (ctx->want_fprints && cfg->oope != SLAMHIP_OOPE_GMAPPING && cfg->sum_order == SLAMHIP_SUM_TREE256)
       a.fprints = ctx->h_fprints + off;
     if (tiled) {
       a.tables = tiled->tables;

@@ -204,6 +204,124 @@ def test_fuzz_default_mode_takes_the_strict_modes_accept_path(pkg, ctx):
     assert div["hc_raw"] <= matches // 20 and div["mc_raw"] <= matches // 20
 
 
+@pytest.mark.parametrize("oope", ["max", "mean", "overlap"])
+def test_fuzz_default_mode_over_the_window_oopes(pkg, ctx, oope):
+    """the reference's strict `best < candidate` (pose_enumeration_scan_matcher.h:56) over the
+    window OOPEs (occupancy_observation_probability.h:29-99).  `max` is as discrete as the 1-cell value, so
+    mathematically tied candidates -- the same multiset of beam terms met in another beam order -- are as likely.
+    200 hill-climbing matches per OOPE over 40 random scenes: the default mode (canonical tree sum, device sincos,
+    CHECKED since r05: term-vector fingerprints from K2 and from the WIN instantiation of the co-resident chain) on
+    the co-resident launch and through host-driven batches against the strict mode (beam-order sum + host trig =
+    the reference's arithmetic): no divergence allowed; the unchecked default mode is counted for the record, and
+    whatever it flips must be a tie of the strict sums."""
+    kinds = dict(max=pkg.OOPE_MAX, mean=pkg.OOPE_MEAN, overlap=pkg.OOPE_OVERLAP)
+    area = (-0.06, 0.06, -0.04, 0.04)
+    names = ("dev", "host", "raw")
+    div, rescored = dict.fromkeys(names, 0), dict.fromkeys(names, 0)
+    matches = calls = 0
+    n_scenes = int(os.environ.get("SLAMHIP_FUZZ_SCENES", "40"))
+    for seed in range(n_scenes):
+        cell = CELL_TBM if seed % 3 == 0 else CELL_OCC
+        sc = make_scene(cell_model=cell, size=500, scale=0.05, n_beams=360 + 90 * (seed % 5), seed=300 + seed,
+                        weighting="viny" if cell == CELL_TBM else "even")
+        upload(pkg, ctx, sc)
+        rs = np.random.RandomState(1000 + seed)
+        prm = [6 + 7 * (seed % 4), 0.1, 0.1]
+        cfg = pkg.spe_cfg(oope=kinds[oope], area=area)
+        ms = dict(dev=pkg.Matcher(ctx, "HC", cfg, prm), host=pkg.Matcher(ctx, "HC", cfg, prm), raw=pkg.Matcher(ctx, "HC", cfg, prm))
+        ms["host"].set_device_chain(0)
+        ms["raw"].set_tie_check(0)
+        strict = pkg.Matcher(ctx, "HC", pkg.spe_cfg(oope=kinds[oope], area=area, **STRICT), prm)
+        for rep in range(5):
+            init = sc["true_pose"] + rs.randn(3) * [0.08, 0.08, 0.04]
+            b = strict.process_scan(0, init, trace=True)
+            matches += 1
+            calls += b["n_calls"]
+            for which, m in ms.items():
+                a = m.process_scan(0, init, trace=True)
+                rescored[which] += m.stats()["steps_rescored"]
+                n = min(a["n_calls"], b["n_calls"])
+                bad = np.nonzero((a["accepted"][:n] != b["accepted"][:n]) | (a["poses"][:n] != b["poses"][:n]).any(1))[0]
+                if a["n_calls"] == b["n_calls"] and len(bad) == 0:
+                    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-12, atol=0)
+                    continue
+                div[which] += 1
+                if which == "raw":
+                    i = int(bad[0]) if len(bad) else n
+                    assert i < n and np.array_equal(a["poses"][i], b["poses"][i])  # same candidate, other decision
+                    acc = np.nonzero(b["accepted"][:i])[0]
+                    best = b["scores"][acc[-1]]
+                    assert abs(b["scores"][i] - best) <= 2 * np.spacing(best), \
+                        "default mode flipped a comparison that is not a tie: %r vs %r" % (b["scores"][i], best)
+        assert ms["dev"].resident_stats()["gave_up"] == 0 and ms["dev"].resident_stats()["matches"] == 5
+    print("fuzz over the %s OOPE: %d matches per matcher, divergences %r, re-scored steps / batches %r"
+          % (oope, matches, div, rescored))
+    assert matches == 5 * n_scenes and calls > matches * 60
+    assert div["dev"] == 0 and div["host"] == 0, "checked default-mode matches diverged from the strict mode: %r" % div
+    assert rescored["raw"] == 0 and div["raw"] <= matches // 10
+
+
+def test_fuzz_default_mode_over_the_gmapping_oope(pkg, ctx, po):
+    """... and over the GMapping OOPE (gmapping_occupancy_observation_pe.h:17-38), whose chains decide from the canonical
+    tree sums as they are: there is no bit-exact form of K3 to fall back on -- a per-beam value is exp() of a distance,
+    and the device's exp is not glibc's.  The strict reference here is the ORACLE: the reference's loop with the
+    reference's beam-order sum and libm exp.
+      * 200 matches over 40 random scenes with failed-round limits 6 (what GMapping hard-wires, init_gmapping.h:58-60),
+        10 and 14 -- device chains of both forms and the host-driven batches: the accept trace must be the oracle's in
+        every one of them (measured r05: 0 of 200);
+      * for the record, limit 27: steps shrink to 0.1 * 2^-27 = 7e-10 m around an optimum, where the candidates' scores
+        differ by LESS than the last bits any double-precision evaluation of the sum can resolve (second-order small:
+        (step / scale)^2 ~ 1e-16 relative) -- the reference's own decisions there follow the rounding of ITS exp and
+        ITS order of additions, and 49 of 50 device matches part from the oracle's trace.  Asserted: every such parting
+        happens at the SAME candidate, at a comparison whose two strict-mode scores lie within 16 ulps."""
+    from synth import CELL_GMAPPING
+    names = ("k1", "res", "host")
+    div, div27 = dict.fromkeys(names, 0), dict.fromkeys(names, 0)
+    matches = matches27 = calls = 0
+    O = po.Oracle()
+    n_scenes = int(os.environ.get("SLAMHIP_FUZZ_SCENES", "40"))
+    for seed in range(n_scenes + max(2, n_scenes // 10)):
+        deep = seed >= n_scenes
+        sc = make_scene(cell_model=CELL_GMAPPING, size=500, scale=0.05, n_beams=360 + 90 * (seed % 5), seed=500 + seed)
+        upload(pkg, ctx, sc)
+        rs = np.random.RandomState(2000 + seed)
+        prm = [27 if deep else (6, 6, 10, 14)[seed % 4], 0.1, 0.1]
+        cfg = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING)
+        ms = dict(k1=pkg.Matcher(ctx, "HC", cfg, prm), res=pkg.Matcher(ctx, "HC", cfg, prm), host=pkg.Matcher(ctx, "HC", cfg, prm))
+        ms["k1"].set_device_chain(1)
+        ms["res"].set_device_chain(2)
+        ms["host"].set_device_chain(0)
+        for rep in range(5):
+            init = sc["true_pose"] + rs.randn(3) * [0.08, 0.08, 0.04]
+            b = O.process_scan(O.enumerator(po.SM_HC, prm), sc["map"], sc["scan"], po.make_cfg(oope=po.OOPE_GMAPPING), init,
+                               cache=po.Oracle.new_gm_cache())
+            if deep:
+                matches27 += 1
+            else:
+                matches += 1
+                calls += b["n_calls"]
+            for which, m in ms.items():
+                ctx.gm_cache_reset()
+                a = m.process_scan(0, init, trace=True)
+                n = min(a["n_calls"], b["n_calls"])
+                bad = np.nonzero((a["accepted"][:n] != b["accepted"][:n]))[0]
+                if a["n_calls"] == b["n_calls"] and len(bad) == 0:
+                    np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-10, atol=1e-300)
+                    np.testing.assert_allclose(a["poses"], b["poses"], rtol=0, atol=1e-12)
+                    continue
+                (div27 if deep else div)[which] += 1
+                if deep:
+                    i = int(bad[0]) if len(bad) else n
+                    assert i < n and np.allclose(a["poses"][i], b["poses"][i], rtol=0, atol=1e-12)  # same candidate
+                    best = b["scores"][np.nonzero(b["accepted"][:i])[0][-1]]
+                    assert abs(b["scores"][i] - best) <= 16 * np.spacing(best), \
+                        "a GMapping chain parted from the oracle at a comparison that is not noise: %r vs %r" % (b["scores"][i], best)
+    print("fuzz over the GMapping OOPE: %d matches per matcher at limits 6 / 10 / 14, divergences from the oracle's strict "
+          "loop %r; %d matches at limit 27: %r" % (matches, div, matches27, div27))
+    assert matches == 5 * n_scenes and calls > matches * 40
+    assert div == dict.fromkeys(names, 0), "GMapping-OOPE matches left the oracle's accept path: %r" % div
+
+
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
 @pytest.mark.parametrize("prm", [[666666, 0.2, 0.1, 20, 100], [7, 0.2, 0.1, 4096, 4096], [11, 0.3, 0.05, 30, 1000], [5, 0.2, 0.1, 3, 2]])
 @pytest.mark.parametrize("mode", CHAIN_MODES)
