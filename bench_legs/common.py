@@ -1,0 +1,217 @@
+"""bench_legs.common -- what the legs of bench.py share: the roofline constants, the committed PMC
+summaries, the rotating benchmark scenes, host facts, the K6 and flat-sweep roofline objects."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_UNIT = {"occ": 24, "tbm": 56, "gmapping": 232}  # SURVEY 8d algorithmic bytes / (pose, beam)
+K6_BYTES_PER_RECORD = 64  # per (beam, cell) 2 x 32 B read-modify-write
+
+WORKLOADS = {
+    # name: (cell model, weighting, matcher kind, params, bytes key, description)
+    "hc": (0, "even", "HC", [128, 0.1, 0.1], "occ",
+           "cfg2: tinySLAM HC(dt 0.1, dr 0.1, failed-rounds 128), 1080 beams, 2000x2000 @0.05 m, occupancy cell"),
+    "mc": (1, "viny", "MC", [666666, 0.2, 0.1, 4096, 4096], "tbm",
+           "cfg3: vinySLAM MC(seed 666666, 4096 attempts), 1080 beams, TBM cell, viny weights, 2000x2000 @0.05 m"),
+}
+
+
+def load_profile_json():
+    """The newest committed PMC summary (profiles/<tag>_traffic.json, written by tools/summarize_profiles.py
+    from separate rocprofv3 --pmc passes of these same commands).  PMC counters cannot be collected from
+    inside the benchmark, so these are the roofline fields not measured live."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+def load_traffic(workload):
+    d, path = load_profile_json()
+    w = (d or {}).get("workloads", {}).get(workload)
+    if not w or "bytes_per_launch" not in w:
+        return None, None
+    return w["bytes_per_launch"], "%s (%s)" % (path, w["correction"])
+
+
+def roofline_valu(workload, avg_launch_us):
+    """The bound that actually binds: the cell gathers are cache hits, so HBM idles and the
+    kernels are limited by VALU issue (FP64 and integer instructions alike take four cycles per wave64 on a
+    16-lane SIMD).  From the SQ counters of the committed PMC passes and the live kernel time."""
+    d, path = load_profile_json()
+    w = (d or {}).get("workloads", {}).get(workload)
+    if not w or "valu" not in w:
+        return None
+    v = dict(w["valu"])
+    out = {"bound": "valu", "source": path, "kernel": w.get("kernel"),
+           "valu_wave_insts_per_launch": v.get("SQ_INSTS_VALU"),
+           "valu_insts_per_unit": v.get("insts_per_unit"),
+           "valu_issue_frac": v.get("issue_frac"),
+           "peak": "1024 SIMDs x 1 VALU wave-instruction per 4 cycles",
+           "note": v.get("note")}
+    if "bytes_per_launch" in w and avg_launch_us:
+        out["hbm_gbs_measured"] = w["bytes_per_launch"] / (avg_launch_us * 1e-6) / 1e9
+        out["hbm_utilisation"] = out["hbm_gbs_measured"] / HBM_PEAK_GBS
+    return out
+
+
+# the dependent chain of ONE super-step of the device-resident hill-climbing chain (1024-thread workgroups,
+# point OOPE), priced from the guide's primitive latencies at ~2.1 GHz (global_load: L2 hit 200 cycles, memory 900; a
+# dependent FP64 / integer VALU op 8 cycles; LDS read ~64 cycles; kernel boundary 1.45 us), beside the wall_clock64
+# stamps of tools/hc_chain_stamps.py (profiles/r03_chain_stamps.txt).
+HC_LATENCY_MODEL_US = {"boundary": 1.45, "staged": 0.90, "replayed": 0.52, "pose": 0.50, "terms": 0.25, "stored": 0.20}
+HC_LATENCY_STAMPS_US = {"boundary": 1.85, "staged": 1.61, "replayed": 1.88, "pose": 0.69, "terms": 0.93, "stored": 0.89}
+# r04, the co-resident chain (csrc/hc_resident.hip): no kernel boundary and no staging -- the scores cross the chip as
+# granules: one write-through store, one hop (MI355X_MICROARCH.md handoff-1to1, idle: 0.8 us) and half a poll period;
+# stamps: tools/hc_resident_stamps.py (profiles/r04_resident_stamps.txt)
+HC_RESIDENT_MODEL_US = {"gather": 1.05, "replayed": 0.52, "pose": 0.50, "terms": 0.25, "sum_publish": 0.30}
+HC_RESIDENT_STAMPS_US = {"gather": 1.51, "replayed": 1.69, "pose": 0.67, "terms": 1.07, "sum_publish": 0.91, "loop": 0.32}
+
+
+def latency_model(ms_per_match, super_steps, resident=False):
+    """achieved / model for the headline's real bound, the serial accept chain: a match is `super_steps` super-steps
+    in a row, each a chain of dependent memory round trips, barriers and FP64 sequences that no amount of width
+    shortens."""
+    if not super_steps or not ms_per_match:
+        return None
+    stages, stamps = (HC_RESIDENT_MODEL_US, HC_RESIDENT_STAMPS_US) if resident else (HC_LATENCY_MODEL_US, HC_LATENCY_STAMPS_US)
+    model = sum(stages.values())
+    achieved = 1e3 * ms_per_match / super_steps
+    return {"bound": "latency", "unit": "us per super-step", "model": model, "achieved": achieved,
+            "frac": model / achieved, "super_steps_per_match": super_steps,
+            "form": "one co-resident launch per match" if resident else "a kernel per super-step",
+            "model_stages_us": stages, "stamped_stages_us": stamps,
+            "note": "achieved = median ms per match / mean super-steps per match (includes the host's enqueue and the "
+                    "result read-back); stamped = in-kernel wall_clock64 timeline of one scoring workgroup"}
+
+
+def sweep_ceiling(pkg, ctx, cfg, sc, scan_n, n_poses, launches, bpu, torch):
+    """Kernel ceiling beside the matcher-mode number: the same scoring kernel on flat batches of
+    device-resident poses (no host round trip, launches back to back)."""
+    rs = np.random.RandomState(11)
+    poses = torch.from_numpy(sc["init_pose"] + rs.randn(n_poses, 3) * [0.2, 0.2, 0.1]).cuda()
+    scores = torch.empty(n_poses, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(5):
+        ctx.score_poses_device(0, cfg, n_poses, poses.data_ptr(), scores.data_ptr())
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    for _ in range(launches):
+        ctx.score_poses_device(0, cfg, n_poses, poses.data_ptr(), scores.data_ptr())
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    ms, n, units = ctx.profile_read(reset=True)
+    achieved = units * bpu / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, src = load_traffic("sweep")
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+           "kernel": "k_score_point", "bytes_per_unit": bpu, "launches": n,
+           "poses_per_launch": n_poses, "beams": scan_n, "avg_launch_us": 1e3 * ms / max(n, 1)}
+    alg = float(n_poses) * scan_n * bpu
+    if traffic and traffic < 0.25 * alg:
+        out["note"] = ("measured HBM traffic is %.0fx below the algorithmic bytes: the gathers of nearby poses are "
+                       "cache hits, the kernel is bound by VALU issue and gather latency (valu)" % (alg / traffic))
+    rv = roofline_valu("sweep", out["avg_launch_us"])
+    if rv:
+        out["valu"] = rv
+    return out
+
+
+N_SCENES = 16
+
+
+def rotating_scenes(sc, n_beams, weighting, n=N_SCENES):
+    """What a robot sees instead of one match repeated: `n` (scan, odometry error) pairs on the scene's map -- robot
+    poses jittered around the mapped one, a fresh N(0, 0.01 m) range-noise seed per scan, initial-pose errors from
+    zero to three times the default (+0.07 m, -0.04 m, +0.03 rad), in a fixed shuffled order.  Deterministic (the
+    CPU baselines' worker processes rebuild the same set)."""
+    from synth import cast_scan, viny_weights
+    m = sc["map"]
+    rs = np.random.RandomState(2024)
+    mags = np.linspace(0.0, 3.0, n)
+    rs.shuffle(mags)
+    out = []
+    for j in range(n):
+        true = sc["true_pose"] + rs.randn(3) * [0.15, 0.15, 0.04]
+        # the scan as the scanner hands it over: every beam, with a flag on the ones that hit something (what
+        # TransformedLaserScan holds, sensor_data.h:203-208) -- and the hits alone, i.e. what filter_scan keeps
+        raw_rng, raw_ang, occ = cast_scan(sc["gt"], m.scale, true, n_beams, seed=1000 + j, raw=True)
+        keep = occ != 0
+        rng, ang = raw_rng[keep], raw_ang[keep]
+        w = np.full(rng.size, 1.0 / rng.size) if weighting == "even" else viny_weights(rng, ang)
+        out.append(dict(range=rng, angle=ang, weight=w, init_pose=true + mags[j] * np.array([0.07, -0.04, 0.03]), true_pose=true,
+                        raw_range=raw_rng, raw_angle=raw_ang, is_occ=occ, error_x_default=float(mags[j])))
+    return out
+
+
+def physical_cores():
+    """(physical cores, logical cores) of this host from /proc/cpuinfo."""
+    logical = os.cpu_count() or 1
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen), logical
+    except OSError:
+        pass
+    return logical, logical
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def run_workers(fn, jobs):
+    """`len(jobs)` worker processes (spawn: fresh interpreters; this process has not touched the GPU yet)."""
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        return pool.map(fn, jobs)
+
+
+def k6_roofline(ctx, note, leg=None):
+    """roofline object of the map update from the HIP events recorded around every K6 pipeline since the last
+    reset (slamhip_profile_read_map_update); `traffic`: HBM bytes per pipeline from the committed PMC passes of
+    that leg (all of the pipeline's dispatches added up)."""
+    ms, calls, records = ctx.profile_read_map_update(reset=True)
+    if not calls or ms <= 0:
+        return None
+    achieved = records * K6_BYTES_PER_RECORD / (ms * 1e-3) / 1e9
+    traffic, traffic_src = load_traffic("k6_" + leg) if leg else (None, None)
+    measured = {}
+    if traffic:
+        # what the memory system really moved per pipeline (PMC passes of the same leg) over the live pipeline time
+        gbs = traffic / (ms * 1e-3 / calls) / 1e9
+        measured = {"hbm_gbs_measured": gbs, "hbm_utilisation": gbs / HBM_PEAK_GBS,
+                    "traffic_over_algorithmic": traffic / (records * K6_BYTES_PER_RECORD / calls)}
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src, **measured, "kernel": "K6 pipeline (k_mu_count .. k_mu_apply, sort included)",
+            "bytes_per_unit": K6_BYTES_PER_RECORD, "unit_of_work": "(beam, cell) record", "launches": calls,
+            "units_launched": records, "avg_launch_us": 1e3 * ms / calls,
+            "timing": "HIP events recorded around each K6 pipeline on the context's stream, " + note}
+
+

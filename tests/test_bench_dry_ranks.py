@@ -23,5 +23,8 @@ def test_dry_ranks(ranks, particles):
     assert d["dry_run"] and d["ok"] and d["ranks"] == ranks and sum(d["shards"]) == particles
     assert d["ranks_that_disagree_with_the_unsharded_filter"] == 0
     assert d["resamplings"] >= 1 and d["dummy_map_bytes_moved"] > 0
+    # (r05: what the sharded per-particle-maps leg -- the default at --gpus N > 1 -- reports from the library's counters)
+    assert d["maps_migrated"] >= 1 and d["p2p_exchanges_max_over_ranks"] >= 1
+    assert d["dummy_map_bytes_moved"] == 64 * d["maps_migrated"]
     if ranks == 8:
         assert d["shards"] == [13] * 4 + [12] * 4
