@@ -113,6 +113,7 @@ struct HcChainArgs {
   // co-resident form only (hc_resident.hip)
   HcResidentCtl *rctl;   // one per chain
   HcResidentGmCtl *rctl_gm;  // ... of the GMapping form
+  unsigned spin_limit;   // polls of one sweep before the chain gives up (the host sizes it from the matches it has seen)
   unsigned tag_epoch;    // co-resident launches on these blocks so far: the epoch bits of a granule's tag (hc_tag) -- NOT
                          // `epoch`, which the other forms of the chain bump too
   unsigned *h_all_done;  // pinned; a batch's last chain to end stores the epoch here (null: a lone chain)
@@ -133,13 +134,13 @@ hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int
 hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream,
                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int n_chains = 1);
 hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window, int n_beams, bool lds_consts, int max_inst,
-                                int *out_wgs);
+                                int *out_wgs, int *out_per_cu = nullptr);
 size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst);
 // the GMapping OOPE's co-resident form (hc_resident_gm.hip): one chain, or n_chains of a filter step (grid.y = chain:
 // HcChainArgs::inits / n_done / h_all_done / tables / slots as in launch_hc_chain_step)
 hipError_t launch_hc_chain_resident_gm(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t ev_start = nullptr,
                                        hipEvent_t ev_stop = nullptr, int n_chains = 1);
-hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs);
+hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs, int *out_per_cu = nullptr);
 // one thread: copies the number of finished chains to pinned memory and publishes a launch number (the host's
 // view of a burst of multi-chain super-steps)
 hipError_t launch_chain_marker(const unsigned *n_done, unsigned *h_done_count, unsigned *flag, unsigned seq,

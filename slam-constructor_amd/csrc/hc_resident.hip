@@ -547,7 +547,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           ++spins;
           if ((spins & 31u) == 0u) {
             const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ap->epoch;
-            if (gone || spins > kHcSpinLimit) {
+            if (gone || spins > ap->spin_limit) {
               failed = true;
               break;
             }
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
                 const HcGranule *gp[1] = {q0 + j};
                 gran_fetch(g, gp);
                 sd = gran_score(g[0]);
-                if (__all(gran_tag(g[0]) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+                if (__all(gran_tag(g[0]) == tag) || spins > ap->spin_limit) break;  // (cannot run out: the canonical granules of
               }                                                                 // the same workgroups are here already)
               if (c < 0) {
                 bdec = sd;
@@ -847,7 +847,7 @@ static const void *res_fn_win(int nt) {
 // above 80 SGPRs; this kernel's waves also need <= 128 VGPRs at 1024 threads), minus ONE CU's worth of workgroups of
 // margin -- a grid that needs every slot of the chip waits for any other kernel's last workgroup to leave.
 hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window, int n_beams, bool lds_consts, int max_inst,
-                                int *out_wgs) {
+                                int *out_wgs, int *out_per_cu) {
   const size_t lds_bytes = hc_resident_lds_bytes(nt, n_beams, lds_consts, max_inst);
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -866,6 +866,7 @@ hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window,
   per_cu = per_cu < by_waves ? per_cu : by_waves;
   if (per_cu > 6) per_cu = 6;      // floor(800 / (ceil(sgpr / 16) * 16 + 16)) at ~106 SGPRs
   *out_wgs = per_cu * (cus - 1);
+  if (out_per_cu) *out_per_cu = per_cu;
   return hipSuccess;
 }
 

@@ -9,7 +9,8 @@
 namespace slamhip {
 namespace {
 
-constexpr unsigned kHcSpinLimit = 1u << 17;  // polls of one sweep (~0.4 us each) before the chain gives up
+constexpr unsigned kHcSpinLimit = 1u << 17;  // most polls of one sweep (~0.4 us each) before a chain gives up; the host
+                                             // passes a tighter bound once it has seen matches (HcChainArgs::spin_limit)
 constexpr int kHcResidentMaxSteps = 4000;    // super-steps a tag can count (12 bits, 0 excluded)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

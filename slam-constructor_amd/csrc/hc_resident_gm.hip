@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
         ++spins;
         if ((spins & 31u) == 0u) {
           const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ap->epoch;
-          if (gone || spins > kHcSpinLimit) {
+          if (gone || spins > ap->spin_limit) {
             failed = true;
             break;
           }
@@ -523,7 +523,7 @@ hipError_t launch_hc_chain_resident_gm(const HcChainArgs &a, int nt, hipStream_t
 }
 
 // workgroups of `nt` threads the device keeps resident at once (see hc_resident_capacity)
-hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs) {
+hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs, int *out_per_cu) {
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -542,6 +542,7 @@ hipError_t hc_resident_gm_capacity(int nt, int n_beams, int *out_wgs) {
   if (nt == 256 && per_cu > 3) per_cu = 3;
   if (per_cu > 6) per_cu = 6;
   *out_wgs = per_cu * (cus - 1);  // (one CU's worth of margin: hc_resident_capacity)
+  if (out_per_cu) *out_per_cu = per_cu;
   return hipSuccess;
 }
 

@@ -2,6 +2,7 @@
 // speculative drivers of matchers.h.
 
 #include <cstdlib>
+#include <mutex>
 
 #include "bf_device.h"
 #include "hc_chain_device.h"
@@ -45,9 +46,11 @@ struct slamhip_matcher {
   // answers of the occupancy query so far, keyed by everything the answer depends on (kernel instantiation: cell model,
   // workgroup size, lone / batch / window form, sweep width via max_inst; dynamic LDS: scan length, beam constants)
   struct ResidentCap {
-    int cell_model, nt, form, n_beams, lds_consts, max_inst, cap;
+    int cell_model, nt, form, n_beams, lds_consts, max_inst, cap, per_cu;
   };
   std::vector<ResidentCap> resident_caps;
+  double resident_us_max = 0;      // the longest co-resident match / batch seen (decaying): sizes the kernels' spin bound
+  int chain_matches_since_off = 0;  // kernel-chain matches since the co-resident form switched itself off (re-arm)
   int resident_gave_up_row = 0;
   int debug_resident_mute = 0;  // testing (slamhip_matcher_debug_resident_mute)
   long long resident_gave_up = 0, resident_matches = 0;
@@ -123,6 +126,10 @@ namespace {
 constexpr int kChainNeedsHost = 1;  // internal: positive, never leaves the library
 constexpr int kResidentGaveUp = 2;  // internal: the co-resident launch left without a result, the kernel chain redoes the match
 constexpr int kChainDefaultMode = 2;  // device chains: 1 = a kernel per super-step, 2 = one co-resident launch where it applies
+// after three give-ups in a row a matcher stops asking for the co-resident form; 64 matches later it asks again (the
+// other tenant of the device may be gone)
+constexpr int kResidentRearmAfter = 64;
+
 
 void hc_batch_free(slamhip_matcher *m);
 int chain_release(slamhip_matcher *m) {
@@ -225,41 +232,92 @@ bool resident_wanted(slamhip_matcher *m) {
   // barrier per super-step, K3's one-pose body at the 128-VGPR limit (profiles/r04_resident_stamps.txt) -- while a
   // filter step's MANY chains in one launch are (gm_multi_chain_run: 0.71 -> 0.59 ms per 100 particles).
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING && m->chain_mode_explicit;
+  if (m->resident_gave_up_row >= 3 && ++m->chain_matches_since_off >= kResidentRearmAfter) {
+    m->resident_gave_up_row = 0;  // (re-armed: the device may be ours again)
+    m->chain_matches_since_off = 0;
+  }
   return m->chain_mode == 2 && (m->cfg.oope == SLAMHIP_OOPE_OBSTACLE || is_window_oope(m->cfg.oope) || gm) &&
          m->resident_gave_up_row < 3;
 }
+// ---- co-resident launches of ONE process on one device (two contexts -- two robots -- on a GPU).
+// A co-resident grid only runs when ALL its workgroups are on the chip; two such grids launched at once can each get
+// half and wait for the other's slots until their spin bounds run out.  Within a process the library knows who is
+// resident: a launch takes its CUs' worth of slots from this per-device ledger for as long as its host call lasts
+// (process_scan is synchronous) and, when they are not there, runs as the chain of kernels AT ONCE -- nobody stalls.
+// (Across processes only the bounded spins help: sized from the matches seen, spin_limit_for below.)
+std::mutex g_resident_mu;
+int g_resident_cus[64] = {0};
+int g_device_cus[64] = {0};
+struct ResidentLease {
+  int device = -1, cus = 0;
+  bool take(int dev, int wgs, int per_cu) {
+    if (dev < 0 || dev >= 64 || per_cu <= 0) return false;
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    if (g_device_cus[dev] == 0) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 1) return false;
+      g_device_cus[dev] = n;
+    }
+    const int need = (wgs + per_cu - 1) / per_cu;
+    if (g_resident_cus[dev] + need > g_device_cus[dev] - 1) return false;  // (the capacity's one CU of margin stays free)
+    g_resident_cus[dev] += need;
+    device = dev;
+    cus = need;
+    return true;
+  }
+  void release() {
+    if (device < 0) return;
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    g_resident_cus[device] -= cus;
+    device = -1;
+  }
+  ~ResidentLease() { release(); }
+};
+
+// polls a sweep may take before a chain gives up: ten times the longest match seen (a poll is ~0.4 us), never less
+// than 2^12 (1.6 ms) nor more than 2^17 (~55 ms: the bound of a matcher's first launches)
+unsigned spin_limit_for(double us_max) {
+  constexpr unsigned kMax = 1u << 17, kMin = 1u << 12;
+  if (!(us_max > 0)) return kMax;
+  const double polls = 25.0 * us_max;
+  return polls >= (double)kMax ? kMax : (polls <= (double)kMin ? kMin : (unsigned)polls);
+}
+void note_resident_time(double *us_max, double us) { *us_max = std::max(0.98 * *us_max, us); }
+
 // form: 0 a lone chain, 1 a batch (job table), 2 a window OOPE, 3 Monte Carlo
 int resident_capacity(slamhip_matcher *m, int cell_model, int nt, int form, int n_beams, bool lds_consts, int max_inst,
-                      int *wgs) {
+                      int *wgs, int *per_cu = nullptr) {
   for (const auto &c : m->resident_caps)
     if (c.cell_model == cell_model && c.nt == nt && c.form == form && c.n_beams == n_beams &&
         c.lds_consts == (lds_consts ? 1 : 0) && c.max_inst == max_inst) {
       *wgs = c.cap;
+      if (per_cu) *per_cu = c.per_cu;
       return SLAMHIP_OK;
     }
-  int cap = 0;
-  if (form == 3) SLAMHIP_CHECK(mc_resident_capacity(cell_model, nt, n_beams, lds_consts, &cap));
-  else SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, form == 1, form == 2, n_beams, lds_consts, max_inst, &cap));
+  int cap = 0, pc = 0;
+  if (form == 3) SLAMHIP_CHECK(mc_resident_capacity(cell_model, nt, n_beams, lds_consts, &cap, &pc));
+  else SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, form == 1, form == 2, n_beams, lds_consts, max_inst, &cap, &pc));
   if (cap < 0) cap = 0;
   if (m->resident_caps.size() >= 64) m->resident_caps.clear();  // (scans of ever-changing lengths: start over)
-  m->resident_caps.push_back({cell_model, nt, form, n_beams, lds_consts ? 1 : 0, max_inst, cap});
+  m->resident_caps.push_back({cell_model, nt, form, n_beams, lds_consts ? 1 : 0, max_inst, cap, pc});
   *wgs = cap;
+  if (per_cu) *per_cu = pc;
   return SLAMHIP_OK;
 }
 // the 1-cell form keeps the further beams' constants in LDS (HcChainArgs::lds_consts) when `wgs_needed` workgroups
 // are resident together with that much LDS each
 int resident_capacity_pick(slamhip_matcher *m, int cell_model, int nt, int form, int n_beams, int max_inst, int wgs_needed,
-                           bool may_lds_consts, int *lds_consts, int *wgs) {
+                           bool may_lds_consts, int *lds_consts, int *wgs, int *per_cu = nullptr) {
   *lds_consts = 0;
   if (may_lds_consts) {
-    int rc = resident_capacity(m, cell_model, nt, form, n_beams, true, max_inst, wgs);
+    int rc = resident_capacity(m, cell_model, nt, form, n_beams, true, max_inst, wgs, per_cu);
     if (rc) return rc;
     if (wgs_needed <= *wgs) {
       *lds_consts = 1;
       return SLAMHIP_OK;
     }
   }
-  return resident_capacity(m, cell_model, nt, form, n_beams, false, max_inst, wgs);
+  return resident_capacity(m, cell_model, nt, form, n_beams, false, max_inst, wgs, per_cu);
 }
 
 int chain_prepare(slamhip_matcher *m) {
@@ -343,12 +401,16 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   if (resident) {
     // ---- ONE launch (hc_resident.hip): every workgroup of the tree stays on the chip for the whole match
     const bool gm_res = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
-    int cap = 0;
-    if (gm_res) SLAMHIP_CHECK(hc_resident_gm_capacity(m->chain_nt, a.scan.n, &cap));
+    int cap = 0, per_cu = 0;
+    if (gm_res) SLAMHIP_CHECK(hc_resident_gm_capacity(m->chain_nt, a.scan.n, &cap, &per_cu));
     else rc = resident_capacity_pick(m, cell_model, m->chain_nt, is_window_oope(m->cfg.oope) ? 2 : 0, a.scan.n, a.max_inst,
-                                     6 * a.max_inst + 1, !is_window_oope(m->cfg.oope), &a.lds_consts, &cap);
+                                     6 * a.max_inst + 1, !is_window_oope(m->cfg.oope), &a.lds_consts, &cap, &per_cu);
     if (rc) return rc;
     if (6 * a.max_inst + 1 > cap) return kResidentGaveUp;  // (not counted: this matcher's grid never fits)
+    // (another context of this process holds the device's resident slots: the chain of kernels at once, no stall)
+    ResidentLease lease;
+    if (!lease.take(m->device, 6 * a.max_inst + 1, per_cu)) return kResidentGaveUp;
+    a.spin_limit = spin_limit_for(m->resident_us_max);
     if (gm_res && !m->d_rctl_gm) {
       SLAMHIP_CHECK(hipMalloc(&m->d_rctl_gm, sizeof(HcResidentGmCtl)));
       SLAMHIP_CHECK(hipMemsetAsync(m->d_rctl_gm, 0, sizeof(HcResidentGmCtl), ctx->stream));
@@ -394,6 +456,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
       return kResidentGaveUp;
     }
     m->resident_gave_up_row = 0;
+    note_resident_time(&m->resident_us_max, MatchJob::now_us() - t0);
   }
   auto launch_one = [&]() -> int {
     hipEvent_t e0, e1;
@@ -739,11 +802,14 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   // chains then advance independently -- no chain waits at a kernel boundary for the slowest one of its super-step
   b->ran_resident = false;
   if (resident_wanted(m) && !a.seq) {
-    int cap_wgs = 0;
+    int cap_wgs = 0, per_cu = 0;
     int rc0 = resident_capacity_pick(m, cell_model, b->nt, 1, max_n, b->max_inst, n * (6 * b->max_inst + 1), true,
-                                     &a.lds_consts, &cap_wgs);
+                                     &a.lds_consts, &cap_wgs, &per_cu);
     if (rc0) return rc0;
-    if (n * (6 * b->max_inst + 1) <= cap_wgs) {
+    ResidentLease lease;  // (the device's resident slots may be another context's: the kernel chains at once then)
+    if (n * (6 * b->max_inst + 1) <= cap_wgs && lease.take(m->device, n * (6 * b->max_inst + 1), per_cu)) {
+      const double t_res0 = MatchJob::now_us();
+      a.spin_limit = spin_limit_for(m->resident_us_max);
       if (!b->d_rctl) {
         SLAMHIP_CHECK(hipMalloc(&b->d_rctl, sizeof(HcResidentCtl) * b->cap));
         SLAMHIP_CHECK(hipMemsetAsync(b->d_rctl, 0, sizeof(HcResidentCtl) * b->cap, st));  // (ordered with the launch)
@@ -806,6 +872,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
       } else {
         m->resident_gave_up_row = 0;
         b->ran_resident = true;
+        note_resident_time(&m->resident_us_max, MatchJob::now_us() - t_res0);
       }
     }
   }
@@ -893,6 +960,8 @@ struct GmMultiChain {
   unsigned *h_all_done = nullptr;     // pinned: the last chain to end stores the epoch here
   int rctl_grid = 0, rctl_chains = 0, gave_up_row = 0;
   unsigned rctl_launches = 0;  // co-resident launches on d_rctl (hc_tag)
+  double resident_us_max = 0;  // the longest co-resident step seen (decaying): sizes the spin bound
+  int steps_since_off = 0;     // steps since the co-resident form switched itself off (re-arm)
   unsigned *d_n_done = nullptr;
   unsigned *h_done_count = nullptr;  // pinned
   int shape_n_inst[kHcShapes] = {0};
@@ -1052,10 +1121,17 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
   // ---- ONE launch for all chains (hc_resident_gm.hip) when their workgroups fit the device at once: every
   // particle's chain then advances at its own pace instead of in lock-step launches
   bool ran_resident = false;
+  if (s->gave_up_row >= 3 && ++s->steps_since_off >= kResidentRearmAfter) {
+    s->gave_up_row = 0;  // (re-armed)
+    s->steps_since_off = 0;
+  }
   if (ctx->resident_chains && s->gave_up_row < 3 && a.scan.n <= 1280) {
-    int cap_wgs = 0;
-    SLAMHIP_CHECK(hc_resident_gm_capacity(s->nt, a.scan.n, &cap_wgs));
-    if (n * (6 * s->max_inst + 1) <= cap_wgs) {
+    int cap_wgs = 0, per_cu = 0;
+    SLAMHIP_CHECK(hc_resident_gm_capacity(s->nt, a.scan.n, &cap_wgs, &per_cu));
+    ResidentLease lease;
+    if (n * (6 * s->max_inst + 1) <= cap_wgs && lease.take(s->device, n * (6 * s->max_inst + 1), per_cu)) {
+      const double t_res0 = MatchJob::now_us();
+      a.spin_limit = spin_limit_for(s->resident_us_max);
       if (!s->d_rctl) {
         SLAMHIP_CHECK(hipMalloc(&s->d_rctl, sizeof(HcResidentGmCtl) * s->cap));
         SLAMHIP_CHECK(hipMemsetAsync(s->d_rctl, 0, sizeof(HcResidentGmCtl) * s->cap, ctx->stream));
@@ -1110,6 +1186,7 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
       } else {
         s->gave_up_row = 0;
         ran_resident = true;
+        note_resident_time(&s->resident_us_max, MatchJob::now_us() - t_res0);
       }
     }
   }
@@ -1506,25 +1583,32 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   };
   // ---- ONE launch (mc_resident.hip): every workgroup of the super-step stays on the chip for the whole match
   bool ran_resident = false;
+  if (m->resident_gave_up_row >= 3 && ++m->chain_matches_since_off >= kResidentRearmAfter) {
+    m->resident_gave_up_row = 0;  // (re-armed)
+    m->chain_matches_since_off = 0;
+  }
   if (m->chain_mode == 2 && m->resident_gave_up_row < 3) {
-    int cap = 0;
+    int cap = 0, per_cu = 0;
     // (1024-thread workgroups are resident one per CU: 252 candidates per super-step then, like the hill-climbing tree)
     if (m->chain_nt == 1024) a.n_slots = std::min(a.n_slots, 252);
     a.lds_consts = 1;
-    rc = resident_capacity(m, cell_model, m->chain_nt, 3, a.scan.n, true, 0, &cap);
+    rc = resident_capacity(m, cell_model, m->chain_nt, 3, a.scan.n, true, 0, &cap, &per_cu);
     if (rc) return rc;
     if (a.n_slots + 1 > cap) {  // (fewer workgroups fit with the beam constants in LDS than without?)
-      int cap_plain = 0;
-      rc = resident_capacity(m, cell_model, m->chain_nt, 3, a.scan.n, false, 0, &cap_plain);
+      int cap_plain = 0, pc_plain = 0;
+      rc = resident_capacity(m, cell_model, m->chain_nt, 3, a.scan.n, false, 0, &cap_plain, &pc_plain);
       if (rc) return rc;
       if (cap_plain > cap) {
         a.lds_consts = 0;
         cap = cap_plain;
+        per_cu = pc_plain;
       }
     }
     // (the capacity leaves one CU's worth of workgroups free: 509 candidates + the bookkeeping workgroup on an MI355X)
     a.n_slots = std::min(a.n_slots, cap - 1);
-    if (a.n_slots >= 64) {
+    ResidentLease lease;
+    if (a.n_slots >= 64 && lease.take(m->device, a.n_slots + 1, per_cu)) {
+      a.spin_limit = spin_limit_for(m->resident_us_max);
       if (!m->d_mc_rctl) {
         SLAMHIP_CHECK(hipMalloc(&m->d_mc_rctl, sizeof(McResidentCtl)));
         SLAMHIP_CHECK(hipMemsetAsync(m->d_mc_rctl, 0, sizeof(McResidentCtl), ctx->stream));  // (ordered with the launch)
@@ -1577,8 +1661,10 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
       } else {
         m->resident_gave_up_row = 0;
         ran_resident = true;
+        note_resident_time(&m->resident_us_max, MatchJob::now_us() - t0);
       }
     }
+    if (!ran_resident) a.n_slots = m->mc_slots;  // (the chain of kernels: the matcher's own candidate count)
   }
   auto launch_one = [&]() -> int {
     hipEvent_t e0, e1;

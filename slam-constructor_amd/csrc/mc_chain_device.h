@@ -65,6 +65,7 @@ struct McChainArgs {
   int trace_cap;
   // the co-resident form (mc_resident.hip): ONE launch per match, scores exchanged through granules
   struct McResidentCtl *rctl;
+  unsigned spin_limit;  // polls of one sweep before the chain gives up
   unsigned tag_epoch;  // co-resident launches on `rctl` so far (hc_tag: NOT the match epoch, which other forms bump too)
   int lds_consts;  // range, cosine, sine of the beams behind a thread's first one are kept in LDS
   int debug_mute;  // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
@@ -84,7 +85,7 @@ struct McResidentCtl {
 // than a tag counts -- nothing has been reported then, the caller runs the chain of kernels
 hipError_t launch_mc_chain_resident(const McChainArgs &a, int cell_model, int nt, hipStream_t stream,
                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_consts, int *out_wgs);
+hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_consts, int *out_wgs, int *out_per_cu = nullptr);
 
 // threads per workgroup: 512 or 1024
 hipError_t launch_mc_chain_step(const McChainArgs &a, int cell_model, int k, int nt, hipStream_t stream,

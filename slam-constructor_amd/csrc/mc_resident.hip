@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
           ++spins;
           if ((spins & 31u) == 0u) {
             const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ap->epoch;
-            if (gone || spins > kHcSpinLimit) {
+            if (gone || spins > ap->spin_limit) {
               failed = true;
               break;
             }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
             const HcGranule *gp[1] = {q0 + (live ? j : kMcSlots)};
             gran_fetch(g, gp);
             sd = gran_score(g[0]);
-            if (__all(gran_tag(g[0]) == tag) || spins > kHcSpinLimit) break;  // (cannot run out: the canonical granules of
+            if (__all(gran_tag(g[0]) == tag) || spins > ap->spin_limit) break;  // (cannot run out: the canonical granules of
           }                                                               // the same workgroups are here already)
           if (c < 0) root_dec = sd;
           else dec6[c] = live ? sd : 0.0;
@@ -478,7 +478,7 @@ hipError_t launch_mc_chain_resident(const McChainArgs &a, int cell_model, int nt
 }
 
 // workgroups of `nt` threads the device keeps resident at once (hc_resident_capacity's rule)
-hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_consts, int *out_wgs) {
+hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_consts, int *out_wgs, int *out_per_cu) {
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -496,6 +496,7 @@ hipError_t mc_resident_capacity(int cell_model, int nt, int n_beams, bool lds_co
   const int by_waves = 2048 / nt;  // 128-VGPR waves: four per SIMD
   per_cu = per_cu < by_waves ? per_cu : by_waves;
   *out_wgs = per_cu * (cus - 1);  // (one CU's worth of margin: hc_resident_capacity)
+  if (out_per_cu) *out_per_cu = per_cu;
   return hipSuccess;
 }
 
