@@ -18,6 +18,8 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libslamhip.so")
+# the same library built with -DSLAMHIP_TESTING: the debugging / fault-injection hooks the shipped one does not export
+TESTING_LIB_PATH = os.path.join(PKG_DIR, "libslamhip_testing.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
 
 CELL_OCC, CELL_TBM, CELL_GMAPPING = 0, 1, 2
@@ -144,19 +146,21 @@ def build(verbose=False):
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load():
+def load(testing=False):
     """dlopen libslamhip.so and declare the prototypes.  Raises if it is missing: the product
-    path has no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise SlamHipError("libslamhip.so is not built (run __graft_entry__.build()); "
-                           "there is no CPU fallback")
-    L = C.CDLL(LIB_PATH)
+    path has no fallback.  testing=True: libslamhip_testing.so -- the same sources with the test hooks compiled in
+    (slamhip_*debug*), for the tests that need one; objects of the two libraries do not mix (pass testing=True to
+    Context and take matchers / filters from that context)."""
+    if testing in _libs:
+        return _libs[testing]
+    path = TESTING_LIB_PATH if testing else LIB_PATH
+    if not os.path.exists(path):
+        raise SlamHipError("%s is not built (run __graft_entry__.build()); "
+                           "there is no CPU fallback" % os.path.basename(path))
+    L = C.CDLL(path)
     vp, d, i, u = C.c_void_p, C.c_double, C.c_int, C.c_uint
     L.slamhip_last_error.restype = C.c_char_p
     L.slamhip_ctx_create.argtypes = [i, C.POINTER(vp)]
@@ -254,7 +258,7 @@ def load():
     L.slamhip_gmapping_carry_commit.argtypes = [vp, C.POINTER(CarryRecord), i]
     L.slamhip_gmapping_match_finish.argtypes = [vp, _dp]
     L.slamhip_gmapping_step_sharded.argtypes = [vp, i, i, _dp, _dp, _ip, _dp, C.c_uint32, _ip, up]
-    _lib = L
+    _libs[testing] = L
     return L
 
 
@@ -293,7 +297,9 @@ atexit.register(_close_all)
 
 def _check(rc):
     if rc != 0:
-        raise SlamHipError("slamhip error %d: %s" % (rc, load().slamhip_last_error().decode()))
+        # (the message is thread-local state of whichever of the two libraries the failing call went into)
+        msgs = [L_.slamhip_last_error().decode() for L_ in _libs.values()]
+        raise SlamHipError("slamhip error %d: %s" % (rc, "; ".join(m for m in msgs if m) or "(no message)"))
 
 
 def _f64(a):
@@ -376,8 +382,8 @@ def pf_heaviest(w):
 class Context:
     """One GPU + one HIP stream (slamhip_ctx)."""
 
-    def __init__(self, device=0):
-        self.L = load()
+    def __init__(self, device=0, testing=False):
+        self.L = load(testing)
         h = C.c_void_p()
         _check(self.L.slamhip_ctx_create(device, C.byref(h)))
         self.h = h
@@ -839,7 +845,7 @@ class GmappingFilter:
     n_total.  ctx may be None for host-only bookkeeping (weights / resampling of a shard)."""
 
     def __init__(self, ctx, params, n_total, seeds, first=0, count=None):
-        self.L = load()
+        self.L = ctx.L if ctx is not None else load()
         self.ctx = ctx
         self.n_total, self.first = n_total, first
         self.count = n_total - first if count is None else count

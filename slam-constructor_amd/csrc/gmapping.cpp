@@ -164,6 +164,11 @@ int bad(const char *msg) {
 
 // the testing hook's trigger: true when place `where` is to fail now
 bool debug_fail_now(slamhip_gmapping *g, int where) {
+#ifndef SLAMHIP_TESTING
+  (void)g;
+  (void)where;
+  return false;  // (no injected failures in the shipped library)
+#endif
   if (g->debug_fail_where != where) return false;
   if (--g->debug_fail_countdown > 0) return false;
   g->debug_fail_where = 0;
@@ -1427,6 +1432,7 @@ int slamhip_gmapping_step_sharded(slamhip_gmapping *g, int map_id, int n_raw, co
   return SLAMHIP_OK;
 }
 
+#ifdef SLAMHIP_TESTING
 // testing aid, not part of include/slamhip.h (see slamhip_gmapping::debug_fail_where)
 int slamhip_gmapping_debug_fail(slamhip_gmapping *g, int where, int nth_call) {
   if (!g) return bad("null filter");
@@ -1434,6 +1440,7 @@ int slamhip_gmapping_debug_fail(slamhip_gmapping *g, int where, int nth_call) {
   g->debug_fail_countdown = nth_call;
   return SLAMHIP_OK;
 }
+#endif  // SLAMHIP_TESTING
 
 int slamhip_gmapping_migration_stats(slamhip_gmapping *g, long long *maps_received, long long *tile_bytes_sent) {
   if (!g) return bad("null filter");

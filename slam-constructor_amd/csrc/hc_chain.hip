@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
   }
   // ---- loads that depend on nothing: issued first, they overlap the replay below (the done test waits
   // for its word only after everything else is in flight)
-  const bool stamp = a.stamps && slot == 1 && t == 0 && k < 64;
+  const bool stamp = SLAMHIP_STAMPS_ON(a.stamps && slot == 1 && t == 0 && k < 64);
   if (stamp) a.stamps[8 * k + 0] = wall_clock64();
   const unsigned done_epoch = __hip_atomic_load(&ctl->done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int n = scan.n;

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   // a workgroup that starts after the others have given up (it was not resident with them) leaves at once -- the word
   // is a trip to memory (agent scope), so it is only looked at below, once this thread's beam is on its way too
   const unsigned fail_epoch_at_entry = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing: the others must give up, not hang)
+#ifdef SLAMHIP_TESTING
+  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (the others must give up, not hang)
+#endif
   // this chain's map and scan: kernel arguments, or -- a batch of matches -- its entry of the job table
   MapViewCP map_p;
   ScanViewCP scan_p;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     gran_store(g0, 0.0, 0ull, 0u);
   }
   const bool verify = a.verify != 0;
-  const bool stamp = a.stamps && slot == 1 && t == 0 && blockIdx.y == 0;
+  const bool stamp = SLAMHIP_STAMPS_ON(a.stamps && slot == 1 && t == 0 && blockIdx.y == 0);
   HcGranule *const gran = &rc->gran[0][0];
   HcGranule *const gseq = &rc->seq[0][0];
   constexpr int kGranRow = kHcSlots + 7;

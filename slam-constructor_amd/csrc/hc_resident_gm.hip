@@ -111,7 +111,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
   HcHostOut *const host = a.host + blockIdx.y;
   // (a workgroup that starts after the others gave up leaves at once -- ONE thread's reading, behind the barrier below)
   const unsigned fail_epoch_at_entry = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing)
+#ifdef SLAMHIP_TESTING
+  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (the others must give up, not hang)
+#endif
   const __attribute__((address_space(4))) HcChainArgs *const ap0 =
       (const __attribute__((address_space(4))) HcChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   const ScanView scan = load_view(&ap0->scan);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
     s_st = st;
   }
   const int *tiles = a.tables ? a.tables + (size_t)a.slots[blockIdx.y] * a.table_stride : nullptr;
-  const bool stamp = a.stamps && slot == 1 && t == 0;
+  const bool stamp = SLAMHIP_STAMPS_ON(a.stamps && slot == 1 && t == 0);
   __syncthreads();
   if (s_stop) return;  // (uniform)
 

@@ -1834,6 +1834,7 @@ int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on) {
   return SLAMHIP_OK;
 }
 
+#ifdef SLAMHIP_TESTING
 // debugging aid, not part of include/slamhip.h: wall-clock stamps (100 MHz) of workgroup 1 inside the
 // first 64 super-steps of the following process_scan calls: kernel entry, staged, replayed, pose ready,
 // terms ready, score stored, two spare
@@ -1849,6 +1850,7 @@ int slamhip_matcher_debug_stamps(slamhip_matcher *m, long long *out512) {
   if (out512) SLAMHIP_CHECK(hipMemcpy(out512, m->d_stamps, sizeof(long long) * 512, hipMemcpyDeviceToHost));
   return SLAMHIP_OK;
 }
+#endif  // SLAMHIP_TESTING
 
 int slamhip_matcher_process_scan_batch(slamhip_matcher *m, int n_jobs, const slamhip_match_job *jobs,
                                        double *out_deltas, double *out_probs) {
@@ -1962,6 +1964,7 @@ int slamhip_matcher_batch_stats(slamhip_matcher *m, int job, long long *scorer_c
   return SLAMHIP_OK;
 }
 
+#ifdef SLAMHIP_TESTING
 // testing aid, not part of include/slamhip.h: the hill-climbing chain treats its observer trace buffer as `cap`
 // entries long (0 = its real size), so that the overflow path -- the match redone by the host-driven matcher --
 // can be exercised without a 65536-call match
@@ -1970,6 +1973,7 @@ int slamhip_matcher_debug_trace_cap(slamhip_matcher *m, int cap) {
   m->debug_trace_cap = cap;
   return SLAMHIP_OK;
 }
+#endif  // SLAMHIP_TESTING
 
 int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long *poses_evaluated,
                           long long *launches) {
@@ -1987,6 +1991,7 @@ int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched,
   return SLAMHIP_OK;
 }
 
+#ifdef SLAMHIP_TESTING
 // testing aid, not part of include/slamhip.h: workgroup `slot_plus_1 - 1` of the following co-resident launches leaves
 // at once (0 = none) -- what a workgroup that never became resident looks like to the others
 int slamhip_matcher_debug_resident_mute(slamhip_matcher *m, int slot_plus_1) {
@@ -1994,6 +1999,7 @@ int slamhip_matcher_debug_resident_mute(slamhip_matcher *m, int slot_plus_1) {
   m->debug_resident_mute = slot_plus_1;
   return SLAMHIP_OK;
 }
+#endif  // SLAMHIP_TESTING
 
 int slamhip_matcher_resident_stats(slamhip_matcher *m, long long *matches, long long *gave_up) {
   if (!m) return invalid_arg("null matcher");

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
   // behind a barrier -- every thread for itself could let some waves of a workgroup leave and others stay: ADVICE r4)
   // (the word is a trip to memory: asked for here, looked at below once this thread's beam is on its way too)
   const unsigned fail_epoch_at_entry = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (testing: the others must give up, not hang)
+#ifdef SLAMHIP_TESTING
+  if (a.debug_mute && (int)blockIdx.x + 1 == a.debug_mute) return;  // (the others must give up, not hang)
+#endif
   const __attribute__((address_space(4))) McChainArgs *ap0 =
       (const __attribute__((address_space(4))) McChainArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   const ScanView scan = load_view(&ap0->scan);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(NT, 4) void k_mc_chain_resident(McChainArgs a) {
     gran_store(g0, 0.0, 0ull, 0u);
   }
   const bool verify = a.verify != 0;
-  const bool stamp = a.stamps && slot == 1 && t0 == 0;
+  const bool stamp = SLAMHIP_STAMPS_ON(a.stamps && slot == 1 && t0 == 0);
   HcGranule *const gran = &rc->gran[0][0];
   HcGranule *const gseq = &rc->seq[0][0];
   constexpr int kGranRow = kMcSlots + 1;

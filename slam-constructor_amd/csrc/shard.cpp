@@ -260,6 +260,7 @@ int slamhip_shard_exchange(slamhip_ctx *ctx, int n_send, const slamhip_shard_msg
   return SLAMHIP_OK;
 }
 
+#ifdef SLAMHIP_TESTING
 // testing aid, not part of include/slamhip.h: a kernel that keeps the context's stream busy for `ms` (at most 5 s)
 int slamhip_debug_stall(slamhip_ctx *ctx, int ms) {
   if (!ctx || ms < 0 || ms > 5000) return invalid_arg("bad stall");
@@ -267,6 +268,7 @@ int slamhip_debug_stall(slamhip_ctx *ctx, int ms) {
   SLAMHIP_CHECK(launch_stall(ms, ctx->stream));
   return SLAMHIP_OK;
 }
+#endif  // SLAMHIP_TESTING
 
 int slamhip_shard_set_timeout(slamhip_ctx *ctx, int ms) {
   if (!ctx) return invalid_arg("null ctx");

@@ -2,6 +2,17 @@
 // of the C-ABI (slamhip_api.cpp, matchers.cpp).  Not installed; the public ABI is include/slamhip.h.
 #pragma once
 
+// Testing and debugging hooks (in-kernel wall-clock stamps, a workgroup that leaves at once, injected failures, a stalled
+// stream, a pretend-small trace buffer) exist only in libslamhip_testing.so, which csrc/Makefile builds from the same
+// sources with -DSLAMHIP_TESTING and which the tests that need a hook load; the shipped libslamhip.so exports none of
+// them and its kernels carry no branch for them.
+#ifdef SLAMHIP_TESTING
+#define SLAMHIP_STAMPS_ON(expr) (expr)
+#else
+#define SLAMHIP_STAMPS_ON(expr) false
+#endif
+
+
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -28,6 +28,14 @@ def ctx(pkg):
     c.close()
 
 
+@pytest.fixture(scope="module")
+def tctx(pkg):
+    """a context of libslamhip_testing.so -- the build with the test hooks (slamhip_matcher_debug_*) compiled in"""
+    c = pkg.Context(0, testing=True)
+    yield c
+    c.close()
+
+
 def scenes(pkg, ctx, cell, weighting, k, beams=(720,), sizes=(600, 500)):
     """k jobs over len(sizes) maps: scans cast from jittered robot poses with their own noise seeds, initial poses
     with errors from zero to three times the default."""
@@ -105,10 +113,11 @@ def test_batch_against_the_oracle(pkg, ctx, oracle):
         assert_trace_equal(g, r, exact_scores=False, rtol=1e-12)
 
 
-def test_batch_falls_back_job_by_job(pkg, ctx):
+def test_batch_falls_back_job_by_job(pkg, tctx):
     """What the shared launches do not cover runs through the single-match path inside the same call: a strict-mode
     matcher (beam-order sum, host trigonometry) keeps every job off the chains; a trace buffer made too small
     (testing hook) sends the jobs whose trace outgrew it there and leaves the others on the chains."""
+    ctx = tctx
     jobs = scenes(pkg, ctx, CELL_OCC, "even", 4)
     prm = [12, 0.1, 0.1]
     strict = dict(sum_order=1, pose_trig=1)
@@ -122,7 +131,7 @@ def test_batch_falls_back_job_by_job(pkg, ctx):
     ml = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
     want = [lone(pkg, ctx, ml, job) for job in jobs]
     cap = sorted(w["n_calls"] for w in want)[1] + 1  # the two shortest traces fit
-    L = pkg.load()
+    L = pkg.load(testing=True)
     L.slamhip_matcher_debug_trace_cap.argtypes = [C.c_void_p, C.c_int]
     assert L.slamhip_matcher_debug_trace_cap(md.h, cap) == 0
     got = md.process_scan_batch(jobs, trace=True)
@@ -173,17 +182,18 @@ def test_stored_scans_equal_uploaded_scans(pkg, ctx):
         mb.process_scan_batch([dict(map_id=0, scan_slot=998, init_pose=[0, 0, 0])])
 
 
-def test_resident_batch_gives_up_when_a_workgroup_is_missing(pkg, ctx):
+def test_resident_batch_gives_up_when_a_workgroup_is_missing(pkg, tctx):
     """The co-resident batch launch (csrc/hc_resident.hip) with one workgroup of every chain leaving at once (testing
     hook): the chains must give up within the bound, and the kernel chains redo the whole batch with the lone
     matches' traces."""
+    ctx = tctx
     import time
     jobs = scenes(pkg, ctx, CELL_OCC, "even", 4)
     prm = [16, 0.1, 0.1]
     mb = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
     mb.set_device_chain(2)
     ml = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
-    L = pkg.load()
+    L = pkg.load(testing=True)
     L.slamhip_matcher_debug_resident_mute.argtypes = [C.c_void_p, C.c_int]
     L.slamhip_matcher_debug_resident_mute.restype = C.c_int
     assert L.slamhip_matcher_debug_resident_mute(mb.h, 3) == 0

@@ -32,6 +32,14 @@ def ctx(pkg):
 
 
 @pytest.fixture(scope="module")
+def tctx(pkg):
+    """a context of libslamhip_testing.so -- the build with the test hooks (slamhip_matcher_debug_*) compiled in"""
+    c = pkg.Context(0, testing=True)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
 def po():
     import pyoracle
     return pyoracle
@@ -377,10 +385,11 @@ def test_mc_resident_chain_with_1024_thread_workgroups(pkg, ctx):
 
 
 @pytest.mark.parametrize("tie_check", [0, 1])
-def test_resident_mc_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx, tie_check):
+def test_resident_mc_chain_gives_up_when_a_workgroup_is_missing(pkg, tctx, tie_check):
     """The Monte-Carlo counterpart of the test below (csrc/mc_resident.hip): with one workgroup gone the others give up
     within the bound, nothing has been reported and the enumerator has not been touched -- the chain of kernels redoes
     the match on the same random stream; the matches after it continue on that stream as if nothing had happened."""
+    ctx = tctx
     import ctypes as C
     import time
     sc = make_scene(cell_model=CELL_TBM, size=600, scale=0.05, n_beams=720, seed=5, weighting="viny")
@@ -392,7 +401,7 @@ def test_resident_mc_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx, tie_ch
     host.set_device_chain(0)
     for m in (dev, host):
         m.set_tie_check(tie_check)
-    L = pkg.load()
+    L = pkg.load(testing=True)
     L.slamhip_matcher_debug_resident_mute.argtypes = [C.c_void_p, C.c_int]
     L.slamhip_matcher_debug_resident_mute.restype = C.c_int
     assert_trace_equal(dev.process_scan(0, sc["init_pose"], trace=True), host.process_scan(0, sc["init_pose"], trace=True))
@@ -449,16 +458,17 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx, mode):
 
 
 @pytest.mark.parametrize("mode", CHAIN_MODES)
-def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx, mode):
+def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, tctx, mode):
     """with an observer attached the chain writes its trace into a fixed pinned buffer; a match with more
     scorer calls than it holds (error 2) used to fail with SLAMHIP_ERR_UNSUPPORTED although the host-driven path
     has no such limit.  Now the match is redone there -- nothing has been reported at that point -- and the
     observer sees the one, complete trace.  The buffer is made artificially small through the testing hook."""
+    ctx = tctx
     import ctypes as C
     sc = make_scene(cell_model=CELL_OCC, size=600, scale=0.05, n_beams=720, seed=5)
     upload(pkg, ctx, sc)
     dev, host = matchers(pkg, ctx, [32, 0.1, 0.1], mode=mode)
-    L = pkg.load()
+    L = pkg.load(testing=True)
     L.slamhip_matcher_debug_trace_cap.argtypes = [C.c_void_p, C.c_int]
     L.slamhip_matcher_debug_trace_cap.restype = C.c_int
     want = host.process_scan(0, sc["init_pose"], trace=True)
@@ -472,17 +482,18 @@ def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, ctx, m
     assert_trace_equal(again, want)
 
 
-def test_resident_chain_gives_up_when_a_workgroup_is_missing(pkg, ctx):
+def test_resident_chain_gives_up_when_a_workgroup_is_missing(pkg, tctx):
     """the co-resident launch only terminates when every workgroup of the tree is on the chip, so
     every wait in it is bounded.  The testing hook makes one workgroup leave at once -- what a workgroup that never
     became resident looks like: the others must give up within the bound (error 4, nothing reported), the kernel
     chain redoes the match with the same trace, and after three such matches in a row the matcher stops trying."""
+    ctx = tctx
     import ctypes as C
     import time
     sc = make_scene(cell_model=CELL_OCC, size=600, scale=0.05, n_beams=720, seed=5)
     upload(pkg, ctx, sc)
     dev, host = matchers(pkg, ctx, [16, 0.1, 0.1], mode=2)
-    L = pkg.load()
+    L = pkg.load(testing=True)
     L.slamhip_matcher_debug_resident_mute.argtypes = [C.c_void_p, C.c_int]
     L.slamhip_matcher_debug_resident_mute.restype = C.c_int
     want = host.process_scan(0, sc["init_pose"], trace=True)

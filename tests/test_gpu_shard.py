@@ -348,7 +348,7 @@ def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None, inject=None):
 
     def rank_main(rank):
         try:
-            ctx = pkg.Context(0)
+            ctx = pkg.Context(0, testing=inject is not None)  # (failures are injected through libslamhip_testing.so)
             loopback.attach(pkg, ctx, name, rank, world)
             ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
             c0, s0 = pkg.beam_trig(g["step0_angle"])
@@ -358,9 +358,11 @@ def run_map_ranks(pkg, world, n, steps_spec, name, fail_rank=None, inject=None):
                                     seeds[first:first + counts[rank]], first=first, count=counts[rank])
             pf.enable_particle_maps(4, 8, 16 + 24 * n)
             log = []
-            dbg = pkg.load().slamhip_gmapping_debug_fail
-            dbg.argtypes = [C.c_void_p, C.c_int, C.c_int]
-            dbg.restype = C.c_int
+            dbg = None
+            if inject is not None:
+                dbg = pkg.load(testing=True).slamhip_gmapping_debug_fail
+                dbg.argtypes = [C.c_void_p, C.c_int, C.c_int]
+                dbg.restype = C.c_int
             for it, k in enumerate(steps_spec):
                 # inject = (rank, where, step): the library's testing hook makes one place fail on one rank as a
                 # rank-local error (1 match_finish, 2 the export between the migration's collectives, 3 the final
@@ -576,8 +578,8 @@ def test_rccl_collective_wait_is_bounded(pkg):
     deadline: SLAMHIP_ERR_TIMEOUT within the deadline, the communicator aborted, every later collective refused at
     once -- and after slamhip_shard_destroy a fresh group works."""
     import time
-    ctx = pkg.Context(0)
-    L = pkg.load()
+    ctx = pkg.Context(0, testing=True)
+    L = pkg.load(testing=True)
     L.slamhip_debug_stall.argtypes = [C.c_void_p, C.c_int]
     L.slamhip_debug_stall.restype = C.c_int
     ctx.shard_init(0, 1, pkg.shard_unique_id())

@@ -95,3 +95,24 @@ def test_particle_filter_bookkeeping_vs_golden(pkg):
     w = np.array([0.1, 0.4, 0.4, 0.1])
     assert pkg.pf_heaviest(w) == 2  # last of equal maxima wins (particle_filter.h:114-121)
     assert abs(pkg.pf_normalize(np.array([1.0, 3.0])).sum() - 1.0) < 1e-15
+
+
+def test_shipped_library_exports_no_test_hooks():
+    """the debugging / fault-injection entry points (slamhip_*debug*) live in libslamhip_testing.so --
+    the same sources with -DSLAMHIP_TESTING -- and NOT in the shipped libslamhip.so."""
+    import subprocess
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    def debug_syms(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(ln.split()[-1] for ln in out.splitlines() if "debug" in ln.lower())
+
+    assert debug_syms(pkg.LIB_PATH) == []
+    assert debug_syms(pkg.TESTING_LIB_PATH) == ["slamhip_debug_stall", "slamhip_gmapping_debug_fail",
+                                                "slamhip_matcher_debug_resident_mute", "slamhip_matcher_debug_stamps",
+                                                "slamhip_matcher_debug_trace_cap"]
+    # ... and everything include/slamhip.h declares is in both
+    for testing in (False, True):
+        lib = pkg.load(testing)
+        assert not [s for s in pkg.EXPORTS if not hasattr(lib, s)]

@@ -13,7 +13,7 @@ import __graft_entry__ as ge  # noqa: E402
 from synth import make_scene  # noqa: E402
 
 pkg = ge.load_package()
-ctx = pkg.Context(0)
+ctx = pkg.Context(0, testing=True)  # (the stamps are a hook of libslamhip_testing.so)
 sc = make_scene(cell_model=0, size=2000, scale=0.05, n_beams=1080, seed=100)
 ctx.upload_map(0, sc["map"])
 c, s = pkg.beam_trig(sc["scan"].angle)
@@ -31,7 +31,7 @@ for threads, check, gm in cases:  # check 0: without the tie check; gm: the GMap
     m.set_tie_check(check)
     for _ in range(5):
         m.process_scan(0, sc["init_pose"])
-    L = pkg.load()
+    L = pkg.load(testing=True)
     L.slamhip_matcher_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.slamhip_matcher_debug_stamps(m.h, None)
     m.process_scan(0, sc["init_pose"])

@@ -13,12 +13,12 @@ import __graft_entry__ as ge  # noqa: E402
 from synth import make_scene  # noqa: E402
 
 pkg = ge.load_package()
-ctx = pkg.Context(0)
+ctx = pkg.Context(0, testing=True)  # (the stamps are a hook of libslamhip_testing.so)
 sc = make_scene(cell_model=0, size=2000, scale=0.05, n_beams=1080, seed=100)
 ctx.upload_map(0, sc["map"])
 c, s = pkg.beam_trig(sc["scan"].angle)
 ctx.scan_upload(sc["scan"].range, c, s, sc["scan"].weight, sc["scan"].factor)
-L = pkg.load()
+L = pkg.load(testing=True)
 L.slamhip_matcher_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 for threads, check in [(1024, 1), (1024, 0), (512, 1), (256, 1), (1024, -1), (512, 2)]:
     mc = check == 2  # the Monte-Carlo matcher (csrc/mc_resident.hip), BASELINE configs[2]'s parameters on a TBM map
