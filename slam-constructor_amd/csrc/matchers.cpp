@@ -323,7 +323,11 @@ int resident_capacity_pick(slamhip_matcher *m, int cell_model, int nt, int form,
 int chain_prepare(slamhip_matcher *m) {
   if (m->d_chain) return SLAMHIP_OK;
   SLAMHIP_CHECK(hipMalloc(&m->d_chain, sizeof(HcChainCtl)));
-  SLAMHIP_CHECK(hipMemset(m->d_chain, 0, sizeof(HcChainCtl)));
+  // (every clearing of a fresh device block goes on the context's own stream: that stream is non-blocking, a hipMemset
+  // on the null stream is asynchronous for device memory and NOT ordered with it -- the block's first user could run
+  // ahead of the memset and have its staged data zeroed under it: r05, a sharded step that started from pose 0 once
+  // in fifteen runs with three contexts on one device)
+  SLAMHIP_CHECK(hipMemsetAsync(m->d_chain, 0, sizeof(HcChainCtl), m->ctx->stream));
   SLAMHIP_CHECK(hipMalloc(&m->d_shapes, sizeof(HcShape) * kHcShapes));
   std::vector<HcShape> shapes(kHcShapes);
   const double boost = 1.0, reach = 0.002;  // (shape building: weight of repeated outcomes, reach below which no instance is added)
@@ -662,7 +666,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     int cap = 8;
     while (cap < n) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&b->d_ctl, sizeof(HcChainCtl) * cap));
-    SLAMHIP_CHECK(hipMemset(b->d_ctl, 0, sizeof(HcChainCtl) * cap));
+    SLAMHIP_CHECK(hipMemsetAsync(b->d_ctl, 0, sizeof(HcChainCtl) * cap, ctx->stream));
     SLAMHIP_CHECK(hipHostMalloc(&b->h_out, sizeof(HcHostOut) * cap, pinned));
     std::memset(b->h_out, 0, sizeof(HcHostOut) * cap);
     {
@@ -673,7 +677,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
       SLAMHIP_CHECK(hipHostMalloc(&b->h_stage, bytes, hipHostMallocMapped));
       std::memset(b->h_stage, 0, bytes);
       SLAMHIP_CHECK(hipMalloc(&b->d_stage, bytes));
-      SLAMHIP_CHECK(hipMemset(b->d_stage, 0, bytes));
+      SLAMHIP_CHECK(hipMemsetAsync(b->d_stage, 0, bytes, ctx->stream));
       b->d_n_done = reinterpret_cast<unsigned *>(b->d_stage);
       b->h_inits = reinterpret_cast<double *>(b->h_stage + 16);
       b->d_inits = reinterpret_cast<double *>(b->d_stage + 16);
@@ -1060,7 +1064,7 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
     int cap = 16;
     while (cap < n) cap *= 2;
     SLAMHIP_CHECK(hipMalloc(&s->d_ctl, sizeof(HcChainCtl) * cap));
-    SLAMHIP_CHECK(hipMemset(s->d_ctl, 0, sizeof(HcChainCtl) * cap));
+    SLAMHIP_CHECK(hipMemsetAsync(s->d_ctl, 0, sizeof(HcChainCtl) * cap, ctx->stream));
     SLAMHIP_CHECK(hipHostMalloc(&s->h_out, sizeof(HcHostOut) * cap, pinned));
     std::memset(s->h_out, 0, sizeof(HcHostOut) * cap);
     {
@@ -1069,7 +1073,7 @@ int gm_multi_chain_run(slamhip_ctx *ctx, GmMultiChain **scratch, int map_id, con
       SLAMHIP_CHECK(hipHostMalloc(&s->h_stage, bytes, hipHostMallocMapped));
       std::memset(s->h_stage, 0, bytes);
       SLAMHIP_CHECK(hipMalloc(&s->d_stage, bytes));
-      SLAMHIP_CHECK(hipMemset(s->d_stage, 0, bytes));
+      SLAMHIP_CHECK(hipMemsetAsync(s->d_stage, 0, bytes, ctx->stream));
       s->d_n_done = reinterpret_cast<unsigned *>(s->d_stage);
       s->h_inits = reinterpret_cast<double *>(s->h_stage + 16);
       s->d_inits = reinterpret_cast<double *>(s->d_stage + 16);
@@ -1472,7 +1476,7 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   const unsigned pinned = hipHostMallocMapped | hipHostMallocCoherent;
   if (!m->d_mc) {
     SLAMHIP_CHECK(hipMalloc(&m->d_mc, sizeof(McChainCtl)));
-    SLAMHIP_CHECK(hipMemset(m->d_mc, 0, sizeof(McChainCtl)));
+    SLAMHIP_CHECK(hipMemsetAsync(m->d_mc, 0, sizeof(McChainCtl), ctx->stream));
     SLAMHIP_CHECK(hipHostMalloc(&m->h_mc, sizeof(McHostOut), pinned));
     std::memset(m->h_mc, 0, sizeof(McHostOut));
   }
