@@ -547,6 +547,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           }
           if (__all(ok)) break;
           ++spins;
+          // (batches: the CUs are short of issue slots, not of polls -- a pause of ~0.2 us between two polls of a sweep: K = 8
+          // 0.199 -> 0.193 ms per call, K = 16 0.283 -> 0.276; s_sleep 20: 0.198; a lone chain polls at once)
+          if (BATCH) __builtin_amdgcn_s_sleep(8);
           if ((spins & 31u) == 0u) {
             const bool gone = __hip_atomic_load(&rc->fail_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ap->epoch;
             if (gone || spins > ap->spin_limit) {
