@@ -119,6 +119,7 @@ struct HcChainArgs {
   unsigned *h_all_done;  // pinned; a batch's last chain to end stores the epoch here (null: a lone chain)
   int debug_mute;        // testing: workgroup debug_mute - 1 leaves at once, as if it had never become resident
   int lds_consts;  // co-resident 1-cell form: range, cosine, sine of the beams behind a thread's first one are kept in LDS
+  int pair;              // co-resident batch form: a workgroup (512 threads) scores two poses per super-step
   int tab_offset;        // co-resident 1-cell / window form: where the table of next poses starts in dynamic LDS, in doubles
                          // (set by the launcher: hc_resident_tab_offset)
   int oope;              // SLAMHIP_OOPE_OBSTACLE (0), or a window OOPE (max / mean / overlap) with its analysis area
@@ -134,8 +135,8 @@ hipError_t launch_hc_chain_step(const HcChainArgs &a, int cell_model, int k, int
 hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream,
                                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int n_chains = 1);
 hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window, int n_beams, bool lds_consts, int max_inst,
-                                int *out_wgs, int *out_per_cu = nullptr);
-size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst);
+                                int *out_wgs, int *out_per_cu = nullptr, bool pair = false);
+size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst, bool pair = false);
 // the GMapping OOPE's co-resident form (hc_resident_gm.hip): one chain, or n_chains of a filter step (grid.y = chain:
 // HcChainArgs::inits / n_done / h_all_done / tables / slots as in launch_hc_chain_step)
 hipError_t launch_hc_chain_resident_gm(const HcChainArgs &a, int nt, hipStream_t stream, hipEvent_t ev_start = nullptr,

@@ -50,15 +50,16 @@ constexpr int kSumLanes = 256;          // the canonical sum's partials (= k_sco
 // pose THIS workgroup scores in it, sine and cosine included.  The replay then only picks an entry -- the serial
 // "advance" and "pose" phases of r04's super-step (0.54 + 0.69 us of 6.0, one wave at work and fifteen watching) are
 // done by the waves that used to watch.
-struct HcNextEntry {
-  double x, y, theta;     // base of the next tree's root round (HcNextCore)
-  double px, py, sn, cs;  // this workgroup's pose in the next tree
-  unsigned counts;        // failed rounds (16 bits) | scorer calls of the walked path (12) | its accepted rounds (4)
-  unsigned flags;         // shape of the next tree (3 bits) | done (bit 3) | this workgroup scores a pose in it (bit 4)
+template <int H>  // poses per workgroup: 1, or 2 (the PAIR form of the batch chains)
+struct HcNextEntryT {
+  double x, y, theta;  // base of the next tree's root round (HcNextCore)
+  double p[H][4];      // x, y, sin, cos of the pose(s) this workgroup scores in the next tree
+  unsigned counts;     // failed rounds (16 bits) | scorer calls of the walked path (12) | its accepted rounds (4)
+  unsigned flags;      // shape of the next tree (3 bits) | done (bit 3) | pose h is scored (bit 4 + h)
   // (the steps follow from the failed rounds -- one exact halving each: hc_round_of --, the acceptance-rate estimate
-  // from the two counts: hc_entry_commit)
+  // from the two counts)
 };
-static_assert(sizeof(HcNextEntry) == 64, "HcNextEntry layout");
+static_assert(sizeof(HcNextEntryT<1>) == 64 && sizeof(HcNextEntryT<2>) == 96, "HcNextEntry layout");
 __device__ __forceinline__ unsigned hc_entry_counts(const HcNextCore &c, int rounds_acc) {
   return (c.failed & 0xffffu) | (((unsigned)c.batch_calls & 0xfffu) << 16) | (((unsigned)rounds_acc & 0xfu) << 28);
 }
@@ -73,25 +74,37 @@ constexpr int kSelStop = -3;     // leave: the replay found no terminal round (a
 // grid has at most 64 G workgroups (2, 4 or 7); WIN: the window OOPEs (max / mean / overlap, K2's per-beam value) in
 // place of the 1-cell one
 // (four waves per SIMD whatever the workgroup size: 128 VGPRs, so that 4 x 256, 2 x 512 or 1 x 1024 threads share a CU)
-template <int MODEL, int NT, bool SEQ, bool BATCH, int G, bool WIN = false>
+// PAIR (batches): a workgroup of 512 threads scores TWO poses per super-step, 256 threads each, side by side -- and
+// sweeps, replays and tabulates ONCE for the two.  At saturation the CUs are short of issue slots (LOG r05), and what
+// every workgroup does for itself besides its terms -- polling the granules, the replay, the table of next poses -- is
+// ~45 % on top of them; the pair halves that share, and its two poses share the beam constants in LDS, which then fit
+// again beside the table (K = 8).
+template <int MODEL, int NT, bool SEQ, bool BATCH, int G, bool WIN = false, bool PAIR = false>
 __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
+  constexpr int H = PAIR ? 2 : 1;    // poses per workgroup
+  constexpr int NTH = NT / H;        // threads per pose
+  typedef HcNextEntryT<H> HcNextEntry;
   extern __shared__ double s_term[];  // one term per beam; behind them, for workgroups narrower than the scan: range,
                                       // cosine, sine of every further beam; then the table of next poses
                                       // (hc_resident_lds_bytes)
   __shared__ unsigned long long s_hash[kHcSlots + 7];  // (48 bits each)
   __shared__ double s_sc[kHcSlots + 7];
-  __shared__ HcInst s_mine[kHcShapes];  // this workgroup's round instance in every shape
-  __shared__ double s_cur[4];           // x, y, sin, cos of the pose being scored (a re-scored super-step reads it again)
-  __shared__ int s_cur_go;
+  __shared__ HcInst s_mine[H][kHcShapes];  // this workgroup's round instance(s) in every shape
+  __shared__ double s_cur[H][4];           // x, y, sin, cos of the pose being scored (a re-scored super-step reads it again)
+  __shared__ int s_cur_go[H];
   __shared__ int s_sel;                 // where the next super-step's pose comes from: a table entry, or kSel*
   __shared__ int s_stop;
   __shared__ HcState s_st;              // root state of the super-step being scored
-  __shared__ double s_part[4];
-  __shared__ unsigned long long s_hpart[4];
+  __shared__ double s_part[H][4];
+  __shared__ unsigned long long s_hpart[H][4];
   const int t = threadIdx.x, wave = t >> 6;
-  const int slot = blockIdx.x + 1 == gridDim.x ? kHcSlots - 1 : (int)blockIdx.x;
+  const int half = PAIR ? (t >= NTH ? 1 : 0) : 0;  // which of the workgroup's poses this thread works on
+  const int tl = t - half * NTH, lwave = tl >> 6;  // ... and its place among that pose's threads
+  // the last workgroup keeps the books (and scores the initial pose / a re-scored base: its first half)
+  const bool init_slot = blockIdx.x + 1 == gridDim.x;
+  const int slot = init_slot ? kHcSlots - 1 : (PAIR ? 2 * (int)blockIdx.x + half : (int)blockIdx.x);
   const int inst_of_slot = slot / 6, cand = slot - 6 * inst_of_slot;
-  const bool init_slot = slot == kHcSlots - 1;
+  const bool exists = init_slot ? half == 0 : slot < 6 * a.max_inst;  // (the bookkeeping workgroup's second half: no slot)
   HcResidentCtl *const rc = a.rctl + blockIdx.y;
   HcHostOut *const host = a.host + blockIdx.y;
   // a workgroup that starts after the others have given up (it was not resident with them) leaves at once -- the word
@@ -120,16 +133,16 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   const int n = scan.n;
   // this thread's first beam: its constants stay in registers for the whole match
   double br = 0.0, bc = 0.0, bs = 0.0, bw = 0.0, bf = 0.0;
-  if (t < n) {
-    br = scan.range[t];
-    bc = scan.cos_a[t];
-    bs = scan.sin_a[t];
-    bw = scan.weight[t];
-    bf = scan.factor[t];
+  if (tl < n) {
+    br = scan.range[tl];
+    bc = scan.cos_a[tl];
+    bs = scan.sin_a[tl];
+    bw = scan.weight[tl];
+    bf = scan.factor[tl];
   }
-  if (wave == 1 && (t & 63) < kHcShapes && !init_slot) {
+  if (lwave == 1 && (t & 63) < kHcShapes && !init_slot && exists) {
     const uint4 *src = reinterpret_cast<const uint4 *>(&a.shapes[t & 63].inst[inst_of_slot]);
-    uint4 *dst = reinterpret_cast<uint4 *>(&s_mine[t & 63]);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_mine[half][t & 63]);
 #pragma unroll
     for (int q = 0; q < (int)(sizeof(HcInst) / 16); ++q) dst[q] = src[q];
   }
@@ -139,10 +152,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   // from memory, as weight and factor still are, it was a round trip in front of the gathers' own in every
   // super-step (r04, super-step of a lone chain, us: 256 threads 7.3 -> 6.6, 512 6.3 -> 6.1).
   const bool ldsc = !WIN && a.lds_consts != 0;
-  const int n_more = n > NT ? n - NT : 0;
-  double *const s_r = s_term + n - NT, *const s_ca = s_r + n_more, *const s_sa = s_ca + n_more;  // (indexed by beam >= NT)
+  const int n_more = n > NTH ? n - NTH : 0;
+  // (a pair: two term vectors, a.scan.n -- the launch's longest scan -- apart; the constants behind them are shared)
+  double *const my_term = s_term + (PAIR ? half * a.scan.n : 0);
+  double *const s_r = s_term + (PAIR ? 2 * a.scan.n : n) - NTH, *const s_ca = s_r + n_more, *const s_sa = s_ca + n_more;  // (indexed by beam >= NTH)
   if (ldsc) {
-    for (int b = NT + t; b < n; b += NT) {
+    for (int b = NTH + t; b < n; b += NT) {
       s_r[b] = scan.range[b];
       s_ca[b] = scan.cos_a[b];
       s_sa[b] = scan.sin_a[b];
@@ -153,12 +168,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   // (ONE thread's reading decides for the workgroup, behind the barrier below: every thread for itself could let some
   // waves of a workgroup leave and others stay -- ADVICE r4)
   if (t == 0) s_stop = fail_epoch_at_entry == a.epoch ? 1 : 0;
-  if (t < 4) {  // this slot's granules of both parities start the match empty (see hc_tag)
-    HcGranule *g0 = (t & 2) ? &rc->seq[t & 1][slot] : &rc->gran[t & 1][slot];
+  if (tl < 4 && exists) {  // this slot's granules of both parities start the match empty (see hc_tag)
+    HcGranule *g0 = (tl & 2) ? &rc->seq[tl & 1][slot] : &rc->gran[tl & 1][slot];
     gran_store(g0, 0.0, 0ull, 0u);
   }
   const bool verify = a.verify != 0;
-  const bool stamp = SLAMHIP_STAMPS_ON(a.stamps && slot == 1 && t == 0 && blockIdx.y == 0);
+  const bool stamp = SLAMHIP_STAMPS_ON(a.stamps && slot == 1 && tl == 0 && blockIdx.y == 0);
   HcGranule *const gran = &rc->gran[0][0];
   HcGranule *const gseq = &rc->seq[0][0];
   constexpr int kGranRow = kHcSlots + 7;
@@ -181,14 +196,14 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   if (s_stop) return;  // started after the others gave up (uniform)
   // ---- the first super-step's pose: the initial pose (bookkeeping workgroup), or this workgroup's candidate of the
   // first tree -- the one pose of a match that is derived serially
-  if (wave == 0) {
+  if (lwave == 0) {
     const HcState &st = s_st;
-    bool go = true;
+    bool go = exists;
     double px = st.x, py = st.y, pth = st.theta;
-    if (!init_slot) {
+    if (!init_slot && exists) {
       HcInst in;
 #pragma unroll
-      for (int q = 0; q < 14; ++q) in.w[q] = s_mine[st.shape].w[q];
+      for (int q = 0; q < 14; ++q) in.w[q] = s_mine[half][st.shape].w[q];
       go = inst_of_slot < (int)((a.n_inst >> (8 * st.shape)) & 0xffull) &&
            (hc_is_root(in) || st.failed + hc_nfail_parent(in) < a.max_failed);  // else: behind the end of the chain
       if (go) {
@@ -199,12 +214,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     }
     double sn, cs;
     sincos(pth, &sn, &cs);
-    if (t == 0) {
-      s_cur[0] = px;
-      s_cur[1] = py;
-      s_cur[2] = sn;
-      s_cur[3] = cs;
-      s_cur_go = go ? 1 : 0;
+    if (tl == 0) {
+      s_cur[half][0] = px;
+      s_cur[half][1] = py;
+      s_cur[half][2] = sn;
+      s_cur[half][3] = cs;
+      s_cur_go[half] = go ? 1 : 0;
     }
   }
   __syncthreads();
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     int t = t_entry;
     asm volatile("" : "+v"(t));
     const int lane = t & 63;
+    const int tl = PAIR ? t - half * NTH : t;  // (this thread's place among its pose's threads, from the laundered index)
     // the kernel's arguments through a pointer the compiler cannot see through either: what the loop needs of them
     // is re-read from the kernarg segment (scalar loads, cached) where it is used instead of living in -- and being
     // spilled from -- scalar registers across the whole loop
@@ -238,12 +254,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       const HcNextEntry &e = s_tab[sel];
       const unsigned flags = e.flags;
       const int done = (int)((flags >> 3) & 1u);
-      go = (int)((flags >> 4) & 1u);
-      px = e.px;
-      py = e.py;
-      sn = e.sn;
-      cs = e.cs;
-      if (wave == NT / 64 - 1 && lane < 2) {
+      go = (int)((flags >> (4 + half)) & 1u);
+      px = e.p[half][0];
+      py = e.p[half][1];
+      sn = e.p[half][2];
+      cs = e.p[half][3];
+      if (wave == NT / 64 - 1 && lane < 1 + H) {
         // the new root (its bookkeeping half was written by the replay) and the pose, should the tree be re-scored:
         // two lanes of the LAST wave -- wave 0 has the scan's surplus beams and the replay, it is the one the
         // others wait for
@@ -263,11 +279,12 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           w.shape = (int)(flags & 7u);
           w.done = done;
         } else {
-          s_cur[0] = px;
-          s_cur[1] = py;
-          s_cur[2] = sn;
-          s_cur[3] = cs;
-          s_cur_go = go;
+          const int hh = lane - 1;  // (the pose of half hh, should the tree be re-scored)
+          s_cur[hh][0] = e.p[hh][0];
+          s_cur[hh][1] = e.p[hh][1];
+          s_cur[hh][2] = e.p[hh][2];
+          s_cur[hh][3] = e.p[hh][3];
+          s_cur_go[hh] = (int)((flags >> (4 + hh)) & 1u);
         }
       }
       if (done && init_slot && t == 0) {
@@ -305,24 +322,26 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           double sn_, cs_;
           sincos(s_st.theta, &sn_, &cs_);
           if (t == 0) {
-            s_cur[0] = s_st.x;
-            s_cur[1] = s_st.y;
-            s_cur[2] = sn_;
-            s_cur[3] = cs_;
-            s_cur_go = 1;
+            s_cur[0][0] = s_st.x;
+            s_cur[0][1] = s_st.y;
+            s_cur[0][2] = sn_;
+            s_cur[0][3] = cs_;
+            s_cur_go[0] = 1;
           }
         }
         __syncthreads();  // (uniform: the whole workgroup is the bookkeeping one)
       }
-      go = s_cur_go;
-      px = s_cur[0];
-      py = s_cur[1];
-      sn = s_cur[2];
-      cs = s_cur[3];
+      go = s_cur_go[half];
+      px = s_cur[half][0];
+      py = s_cur[half][1];
+      sn = s_cur[half][2];
+      cs = s_cur[half][3];
       mode = sel == kSelRescore ? 1 : 0;
     }
     if (stamp && k < 64) ap->stamps[8 * k + 3] = wall_clock64();
     const unsigned tag = hc_tag(ap->tag_epoch, k);
+    // (both barriers below are passed by every thread of the workgroup whether its pose is scored or not: the two
+    // halves of a pair decide that independently)
     if (go) {
       // ---- score it: terms by beam, then the canonical sum (256 strided partials in ascending beam order, wave
       // butterfly, (g0+g1)+(g2+g3)) -- k_score_point's order; up to four beams per thread at a time, their cell
@@ -331,9 +350,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         // window OOPEs: k_score_window's per-beam value (occupancy_observation_probability.h:29-99), one beam at a
         // time -- a beam reads a window of cells, not one
         const double half_v = (ap->area[1] - ap->area[0]) / 2, half_h = (ap->area[3] - ap->area[2]) / 2;
-        for (int b = t; b < n; b += NT) {
+        for (int b = tl; b < n; b += NTH) {
           double r_ = br, ca = bc, sa = bs, w = bw, f = bf;
-          if (b != t) {
+          if (b != tl) {
             r_ = scan.range[b];
             ca = scan.cos_a[b];
             sa = scan.sin_a[b];
@@ -343,27 +362,27 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           const double c = cs * ca - sn * sa;
           const double s = sn * ca + cs * sa;
           const double ox = px + r_ * c, oy = py + r_ * s;
-          s_term[b] = window_probability<MODEL>(map, ap->oie, ap->oope, half_v, half_h, ox, oy) * w * f;
+          my_term[b] = window_probability<MODEL>(map, ap->oie, ap->oope, half_v, half_h, ox, oy) * w * f;
         }
       } else {
-        // (five beams of a 256-thread workgroup at a time: 1080 beams are then ONE round of gathers for every wave -- with
+        // (five beams of 256 threads at a time: 1080 beams are then ONE round of gathers for every wave -- with
         // four, wave 0 went round twice for its 56 surplus beams while fifteen waves waited at the barrier)
-        constexpr int UNR = NT == 256 ? 5 : 4;
-        for (int base = t; base < n; base += UNR * NT) {
+        constexpr int UNR = NTH == 256 ? 5 : 4;
+        for (int base = tl; base < n; base += UNR * NTH) {
           double4 cell[UNR];
           double w_[UNR], f_[UNR];
   #pragma unroll
           for (int j = 0; j < UNR; ++j) {
-            const int b = base + j * NT;
+            const int b = base + j * NTH;
             w_[j] = 0.0;
             f_[j] = 0.0;
             cell[j] = make_double4(0.0, 0.0, 0.0, 0.0);
-            if ((base - lane) + j * NT >= n) continue;  // no lane of this wave has a beam in this slot
+            if ((base - lane) + j * NTH >= n) continue;  // no lane of this wave has a beam in this slot
             const int bc_ = b < n ? b : n - 1;
             double r_ = br, ca = bc, sa = bs;
             w_[j] = bw;
             f_[j] = bf;
-            if (j > 0 || base != t) {
+            if (j > 0 || base != tl) {
               r_ = ldsc ? s_r[bc_] : scan.range[bc_];
               ca = ldsc ? s_ca[bc_] : scan.cos_a[bc_];
               sa = ldsc ? s_sa[bc_] : scan.sin_a[bc_];
@@ -374,21 +393,23 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           }
   #pragma unroll
           for (int j = 0; j < UNR; ++j) {
-            const int b = base + j * NT;
-            if (b < n) s_term[b] = cell_probability<MODEL>(ap->oie, cell[j]) * w_[j] * f_[j];
+            const int b = base + j * NTH;
+            if (b < n) my_term[b] = cell_probability<MODEL>(ap->oie, cell[j]) * w_[j] * f_[j];
           }
         }
       }
-      __syncthreads();  // (B)
-      if (stamp && k < 64) ap->stamps[8 * k + 4] = wall_clock64();
+    }
+    __syncthreads();  // (B)
+    if (stamp && k < 64) ap->stamps[8 * k + 4] = wall_clock64();
+    if (go) {
       if (SEQ) {
         // the reference's own order: one running sum over the beams (weighted_mean_point_probability_spe.h:108-124)
-        if (t == 0) {
+        if (tl == 0) {
           double acc = 0.0;
           int b = 0;
           for (; b + 8 <= n; b += 8) {
-            const double t0 = s_term[b], t1 = s_term[b + 1], t2 = s_term[b + 2], t3 = s_term[b + 3];
-            const double t4 = s_term[b + 4], t5 = s_term[b + 5], t6 = s_term[b + 6], t7 = s_term[b + 7];
+            const double t0 = my_term[b], t1 = my_term[b + 1], t2 = my_term[b + 2], t3 = my_term[b + 3];
+            const double t4 = my_term[b + 4], t5 = my_term[b + 5], t6 = my_term[b + 6], t7 = my_term[b + 7];
             acc = acc + t0;
             acc = acc + t1;
             acc = acc + t2;
@@ -398,45 +419,48 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             acc = acc + t6;
             acc = acc + t7;
           }
-          for (; b < n; ++b) acc = acc + s_term[b];
+          for (; b < n; ++b) acc = acc + my_term[b];
           gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0ull, tag);
         }
-        __syncthreads();  // (C) (s_term is rewritten by the next super-step)
-      } else {
-        if (t < kSumLanes) {
-          double acc = 0.0;
-          unsigned long long h = 0ull;  // fingerprint of the term vector (score_device.h)
-          unsigned k_lo = (2u * (unsigned)t + 1u) * 0x9E3779B1u, k_hi = (2u * (unsigned)t + 1u) * 0x85EBCA6Bu;
-          for (int b = t; b < n; b += kSumLanes) {
-            const double term = s_term[b];
-            acc = acc + term;
-            if (verify) {
-              h += term_fingerprint(term, k_lo, k_hi);
-              k_lo += 2u * kSumLanes * 0x9E3779B1u;
-              k_hi += 2u * kSumLanes * 0x85EBCA6Bu;
-            }
-          }
-          wave_xor_sum_with(acc, h);
-          if (lane == 0) {
-            s_part[wave] = acc;
-            s_hpart[wave] = h;
+      } else if (tl < kSumLanes) {
+        double acc = 0.0;
+        unsigned long long h = 0ull;  // fingerprint of the term vector (score_device.h)
+        unsigned k_lo = (2u * (unsigned)tl + 1u) * 0x9E3779B1u, k_hi = (2u * (unsigned)tl + 1u) * 0x85EBCA6Bu;
+        for (int b = tl; b < n; b += kSumLanes) {
+          const double term = my_term[b];
+          acc = acc + term;
+          if (verify) {
+            h += term_fingerprint(term, k_lo, k_hi);
+            k_lo += 2u * kSumLanes * 0x9E3779B1u;
+            k_hi += 2u * kSumLanes * 0x85EBCA6Bu;
           }
         }
-        __syncthreads();  // (C)
-        if (t == 0) {
-          const double total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-          const unsigned long long fp = verify ? fold_fingerprint48(s_hpart[0] + s_hpart[1] + s_hpart[2] + s_hpart[3]) : 0ull;
+        wave_xor_sum_with(acc, h);
+        if (lane == 0) {
+          s_part[half][lwave] = acc;
+          s_hpart[half][lwave] = h;
+        }
+      }
+    }
+    __syncthreads();  // (C) (the terms are rewritten by the next super-step)
+    if (go) {
+      if (!SEQ) {
+        if (tl == 0) {
+          const double total = (s_part[half][0] + s_part[half][1]) + (s_part[half][2] + s_part[half][3]);
+          const unsigned long long fp =
+              verify ? fold_fingerprint48(s_hpart[half][0] + s_hpart[half][1] + s_hpart[half][2] + s_hpart[half][3]) : 0ull;
           gran_store(&gran[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : total / scan.tot_w, fp, tag);
         }
-        if (verify && mode && t == 64) {
+        if (verify && mode && tl == 64) {
           // re-scored super-step: the reference's own order as well, one running sum over the beams
+          // (read behind barrier (C): nobody writes the terms before the barrier that ends this super-step)
           double acc = 0.0;
-          for (int b = 0; b < n; ++b) acc = acc + s_term[b];
+          for (int b = 0; b < n; ++b) acc = acc + my_term[b];
           gran_store(&gseq[pk * kGranRow + slot], (scan.tot_w == 0.0) ? __builtin_nan("") : acc / scan.tot_w, 0ull, tag);
         }
       }
       if (stamp && k < 64) ap->stamps[8 * k + 5] = wall_clock64();
-    } else if (t == 0) {
+    } else if (tl == 0 && exists) {
       // nothing to score (behind the end of the chain, the surplus candidates of a trailing round, a smaller shape, the
       // bookkeeping workgroup behind the first super-step): the tag goes out all the same.  The sweepers wait for EVERY
       // workgroup of the grid in every super-step, so nobody -- the bookkeeping workgroup streaming an observer's
@@ -445,8 +469,6 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       gran_store(&gran[pk * kGranRow + slot], 0.0, 0ull, tag);
       if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0ull, tag);
     }
-    // (a workgroup that scored nothing passed no barrier since it read its pose: the table is rewritten below)
-    if (!go) __syncthreads();
 
     if (wave != 0) {
       // ---- every other wave, while wave 0 waits for the scores: the table of next poses.  Lane = one (terminal
@@ -457,10 +479,10 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         const int n_inst = (int)((ap->n_inst >> (8 * shape)) & 0xffull);
         const unsigned max_failed = ap->max_failed;
         for (int e = t - 64; e < 7 * n_inst; e += NT - 64) {
-          const int tl = e / 7, out = e - 7 * tl;
+          const int ti = e / 7, out = e - 7 * ti;  // terminal round instance, its outcome
           HcInst in;
           {
-            const unsigned long long *src = &ap->shapes[shape].inst[tl].w[0];
+            const unsigned long long *src = &ap->shapes[shape].inst[ti].w[0];
 #pragma unroll
             for (int q = 0; q < 14; ++q) in.w[q] = src[q];
           }
@@ -476,28 +498,35 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           w.y = c.y;
           w.theta = c.theta;
           w.counts = hc_entry_counts(c, hc_nseg(in) + (out > 0 ? 1 : 0));
-          // this workgroup's pose in the tree hanging off that root (the bookkeeping workgroup scores nothing there)
-          bool go = !c.done && !init_slot;
-          double px_ = c.x, py_ = c.y, pth_ = c.theta;
-          if (go) {
-            HcInst mine;
+          // this workgroup's pose(s) in the tree hanging off that root (the bookkeeping workgroup scores nothing there)
+          unsigned flags = (unsigned)c.shape | (c.done ? 8u : 0u);
 #pragma unroll
-            for (int q = 0; q < 14; ++q) mine.w[q] = s_mine[c.shape].w[q];
-            go = inst_of_slot < (int)((ap->n_inst >> (8 * c.shape)) & 0xffull) &&
-                 (hc_is_root(mine) || c.failed + hc_nfail_parent(mine) < max_failed);  // else: behind the end of the chain
+          for (int hh = 0; hh < H; ++hh) {
+            const int slot_h = PAIR ? 2 * (int)blockIdx.x + hh : slot;
+            const int inst_h = slot_h / 6, cand_h = slot_h - 6 * inst_h;
+            bool go = !c.done && !init_slot && slot_h < 6 * ap->max_inst;
+            double px_ = c.x, py_ = c.y, pth_ = c.theta;
             if (go) {
-              const HcRound r2 = hc_round_from(c.x, c.y, c.theta, c.dt, c.dr, c.failed, mine);
-              go = !(hc_trailing(r2.failed, max_failed) && cand > 0);  // a trailing round has one candidate
-              hc_candidate(r2.x, r2.y, r2.theta, r2.dt, r2.dr, cand, &px_, &py_, &pth_);
+              HcInst mine;
+#pragma unroll
+              for (int q = 0; q < 14; ++q) mine.w[q] = s_mine[hh][c.shape].w[q];
+              go = inst_h < (int)((ap->n_inst >> (8 * c.shape)) & 0xffull) &&
+                   (hc_is_root(mine) || c.failed + hc_nfail_parent(mine) < max_failed);  // else: behind the end of the chain
+              if (go) {
+                const HcRound r2 = hc_round_from(c.x, c.y, c.theta, c.dt, c.dr, c.failed, mine);
+                go = !(hc_trailing(r2.failed, max_failed) && cand_h > 0);  // a trailing round has one candidate
+                hc_candidate(r2.x, r2.y, r2.theta, r2.dt, r2.dr, cand_h, &px_, &py_, &pth_);
+              }
             }
+            double sn_ = 0.0, cs_ = 1.0;
+            if (go) sincos(pth_, &sn_, &cs_);
+            w.p[hh][0] = px_;
+            w.p[hh][1] = py_;
+            w.p[hh][2] = sn_;
+            w.p[hh][3] = cs_;
+            flags |= go ? (16u << hh) : 0u;
           }
-          double sn_ = 0.0, cs_ = 1.0;
-          if (go) sincos(pth_, &sn_, &cs_);
-          w.px = px_;
-          w.py = py_;
-          w.sn = sn_;
-          w.cs = cs_;
-          w.flags = (unsigned)c.shape | (c.done ? 8u : 0u) | (go ? 16u : 0u);
+          w.flags = flags;
         }
       }
     } else {
@@ -518,7 +547,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       const int bp_slot = (!active || bpi < 0) ? -1 : 6 * bpi + hc_bp_cand(me);
       // ---- sweep: every workgroup of the grid (the bookkeeping one scored the initial pose / a re-scored base)
       const bool base_here = sp.first || sp.mode == 1;
-      const int n_grid = (int)gridDim.x - 1;  // (+ the bookkeeping workgroup)
+      const int n_grid = 6 * ap->max_inst;  // scoring slots (+ the bookkeeping workgroup's)
       const bool rescored = !SEQ && verify && sp.mode == 1;
       bool failed = false;
       {
@@ -730,13 +759,15 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
 
 // dynamic LDS of a workgroup: the beams' terms, with lds_consts range, cosine and sine of the beams behind every
 // thread's first one, and the table of next poses (7 entries per round instance of the largest shape)
-size_t hc_resident_tab_offset(int nt, int n_beams, bool lds_consts) {  // (in doubles)
+size_t hc_resident_tab_offset(int nt, int n_beams, bool lds_consts, bool pair) {  // (in doubles)
   const size_t n = (size_t)(n_beams > 0 ? n_beams : 1);
-  const size_t more = lds_consts && n > (size_t)nt ? n - (size_t)nt : 0;
-  return n + 3 * more;
+  const size_t nth = (size_t)(pair ? nt / 2 : nt);  // threads per pose
+  const size_t more = lds_consts && n > nth ? n - nth : 0;
+  return (pair ? 2 : 1) * n + 3 * more;
 }
-size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst) {
-  return sizeof(double) * hc_resident_tab_offset(nt, n_beams, lds_consts) + sizeof(HcNextEntry) * 7 * (size_t)max_inst;
+size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst, bool pair) {
+  return sizeof(double) * hc_resident_tab_offset(nt, n_beams, lds_consts, pair) +
+         (pair ? sizeof(HcNextEntryT<2>) : sizeof(HcNextEntryT<1>)) * 7 * (size_t)max_inst;
 }
 
 #define HCR_LAUNCH(NTV, GV)                                                                                     \
@@ -745,6 +776,14 @@ size_t hc_resident_lds_bytes(int nt, int n_beams, bool lds_consts, int max_inst)
       hipExtLaunchKernelGGL((k_hc_chain_resident<MODEL, NTV, SEQ, BATCH, GV>), dim3(grid, n_chains), dim3(NTV), shm, stream, e0, e1, 0, a); \
     else                                                                                                        \
       hipLaunchKernelGGL((k_hc_chain_resident<MODEL, NTV, SEQ, BATCH, GV>), dim3(grid, n_chains), dim3(NTV), shm, stream, a);     \
+  } while (0)
+
+#define HCR_LAUNCH_PAIR(GV)                                                                                     \
+  do {                                                                                                          \
+    if (e0 || e1)                                                                                               \
+      hipExtLaunchKernelGGL((k_hc_chain_resident<MODEL, 512, false, BATCH, GV, false, BATCH>), dim3(grid, n_chains), dim3(512), shm, stream, e0, e1, 0, a); \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_hc_chain_resident<MODEL, 512, false, BATCH, GV, false, BATCH>), dim3(grid, n_chains), dim3(512), shm, stream, a);     \
   } while (0)
 
 // granules per sweeping lane for a grid of `grid` workgroups
@@ -765,8 +804,8 @@ static hipError_t launch_res_win(const HcChainArgs &a_in, int nt, hipStream_t st
   HcChainArgs a = a_in;
   const int grid = 6 * a.max_inst + 1;
   if (grid > 256) return hipErrorInvalidValue;
-  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, false, a.max_inst);  // (the window form keeps no beam constants in LDS)
-  a.tab_offset = (int)hc_resident_tab_offset(nt, a.scan.n, false);
+  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, false, a.max_inst, false);  // (the window form keeps no beam constants in LDS)
+  a.tab_offset = (int)hc_resident_tab_offset(nt, a.scan.n, false, false);
   if (nt == 1024) HCR_LAUNCH_WIN(1024);
   else if (nt == 256) HCR_LAUNCH_WIN(256);
   else HCR_LAUNCH_WIN(512);
@@ -778,10 +817,19 @@ template <int MODEL, bool SEQ, bool BATCH>
 static hipError_t launch_res(const HcChainArgs &a_in, int nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
                              int n_chains) {
   HcChainArgs a = a_in;
-  const int grid = 6 * a.max_inst + 1;
-  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, a.lds_consts != 0, a.max_inst);
-  a.tab_offset = (int)hc_resident_tab_offset(nt, a.scan.n, a.lds_consts != 0);
-  const int g = gran_per_lane(grid);
+  const bool pair = BATCH && a.pair != 0;
+  const int slots = 6 * a.max_inst + 1;
+  const int grid = pair ? 3 * a.max_inst + 1 : slots;  // (a pair: two scoring slots per workgroup + the bookkeeping one)
+  const size_t shm = hc_resident_lds_bytes(nt, a.scan.n, a.lds_consts != 0, a.max_inst, pair);
+  a.tab_offset = (int)hc_resident_tab_offset(nt, a.scan.n, a.lds_consts != 0, pair);
+  const int g = gran_per_lane(slots);
+  if (pair) {
+    if (nt != 512) return hipErrorInvalidValue;
+    if (g == 2) HCR_LAUNCH_PAIR(2);
+    else if (g == 4) HCR_LAUNCH_PAIR(4);
+    else HCR_LAUNCH_PAIR(7);
+    return hipGetLastError();
+  }
   // (workgroup sizes and sweep widths that go together: a lone chain is 253 x 1024 threads, a batch's chains are
   // narrower trees of narrower workgroups)
   if (nt == 1024) {
@@ -800,6 +848,7 @@ static hipError_t launch_res(const HcChainArgs &a_in, int nt, hipStream_t stream
   return hipGetLastError();
 }
 #undef HCR_LAUNCH
+#undef HCR_LAUNCH_PAIR
 
 hipError_t launch_hc_chain_resident(const HcChainArgs &a, int cell_model, int nt, hipStream_t stream, hipEvent_t e0,
                                     hipEvent_t e1, int n_chains) {
@@ -840,6 +889,12 @@ static const void *res_fn(int nt, int g) {
                           : (const void *)k_hc_chain_resident<M, 512, false, B, 7>);
 }
 template <int M>
+static const void *res_fn_pair(int g) {
+  return g == 2 ? (const void *)k_hc_chain_resident<M, 512, false, true, 2, false, true>
+                : (g == 4 ? (const void *)k_hc_chain_resident<M, 512, false, true, 4, false, true>
+                          : (const void *)k_hc_chain_resident<M, 512, false, true, 7, false, true>);
+}
+template <int M>
 static const void *res_fn_win(int nt) {
   return nt == 1024 ? (const void *)k_hc_chain_resident<M, 1024, false, false, 4, true>
                     : (nt == 256 ? (const void *)k_hc_chain_resident<M, 256, false, false, 4, true>
@@ -852,8 +907,8 @@ static const void *res_fn_win(int nt) {
 // above 80 SGPRs; this kernel's waves also need <= 128 VGPRs at 1024 threads), minus ONE CU's worth of workgroups of
 // margin -- a grid that needs every slot of the chip waits for any other kernel's last workgroup to leave.
 hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window, int n_beams, bool lds_consts, int max_inst,
-                                int *out_wgs, int *out_per_cu) {
-  const size_t lds_bytes = hc_resident_lds_bytes(nt, n_beams, lds_consts, max_inst);
+                                int *out_wgs, int *out_per_cu, bool pair) {
+  const size_t lds_bytes = hc_resident_lds_bytes(nt, n_beams, lds_consts, max_inst, pair);
   int dev = 0, cus = 0, per_cu = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
@@ -862,6 +917,7 @@ hipError_t hc_resident_capacity(int cell_model, int nt, bool batch, bool window,
   const void *fn = nullptr;
   const int g = window ? 4 : gran_per_lane(6 * max_inst + 1);
   if (window) fn = cell_model == SLAMHIP_CELL_TBM ? res_fn_win<SLAMHIP_CELL_TBM>(nt) : res_fn_win<SLAMHIP_CELL_OCC>(nt);
+  else if (batch && pair) fn = cell_model == SLAMHIP_CELL_TBM ? res_fn_pair<SLAMHIP_CELL_TBM>(g) : res_fn_pair<SLAMHIP_CELL_OCC>(g);
   else if (batch) fn = cell_model == SLAMHIP_CELL_TBM ? res_fn<SLAMHIP_CELL_TBM, true>(nt, g) : res_fn<SLAMHIP_CELL_OCC, true>(nt, g);
   else fn = cell_model == SLAMHIP_CELL_TBM ? res_fn<SLAMHIP_CELL_TBM, false>(nt, g) : res_fn<SLAMHIP_CELL_OCC, false>(nt, g);
   if (!fn) return hipErrorInvalidValue;

@@ -284,7 +284,7 @@ unsigned spin_limit_for(double us_max) {
 }
 void note_resident_time(double *us_max, double us) { *us_max = std::max(0.98 * *us_max, us); }
 
-// form: 0 a lone chain, 1 a batch (job table), 2 a window OOPE, 3 Monte Carlo
+// form: 0 a lone chain, 1 a batch (job table), 2 a window OOPE, 3 Monte Carlo, 4 a batch whose workgroups score two poses
 int resident_capacity(slamhip_matcher *m, int cell_model, int nt, int form, int n_beams, bool lds_consts, int max_inst,
                       int *wgs, int *per_cu = nullptr) {
   for (const auto &c : m->resident_caps)
@@ -296,7 +296,8 @@ int resident_capacity(slamhip_matcher *m, int cell_model, int nt, int form, int 
     }
   int cap = 0, pc = 0;
   if (form == 3) SLAMHIP_CHECK(mc_resident_capacity(cell_model, nt, n_beams, lds_consts, &cap, &pc));
-  else SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, form == 1, form == 2, n_beams, lds_consts, max_inst, &cap, &pc));
+  else SLAMHIP_CHECK(hc_resident_capacity(cell_model, nt, form == 1 || form == 4, form == 2, n_beams, lds_consts, max_inst, &cap,
+                                          &pc, form == 4));
   if (cap < 0) cap = 0;
   if (m->resident_caps.size() >= 64) m->resident_caps.clear();  // (scans of ever-changing lengths: start over)
   m->resident_caps.push_back({cell_model, nt, form, n_beams, lds_consts ? 1 : 0, max_inst, cap, pc});
@@ -573,6 +574,8 @@ struct HcBatch {
   size_t scan_cap = 0;                     // doubles
   slamhip::HcShape *d_shapes = nullptr;
   int built_inst = 0, max_inst = 1, nt = 256;
+  bool pair = false;  // the co-resident launch's workgroups (512 threads) score two poses per super-step
+  int cus = 0;        // CUs of the device (sizes the pair form's trees)
   int shape_n_inst[slamhip::kHcShapes] = {0};
   unsigned *d_n_done = nullptr, *h_done_count = nullptr;
   slamhip::HcResidentCtl *d_rctl = nullptr;  // co-resident form: one exchange block per chain (cap of them)
@@ -632,7 +635,19 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     SLAMHIP_CHECK(hipHostMalloc(&b->h_done_count, sizeof(unsigned), pinned));
   }
   {
-    const int want = std::min(kHcDefaultInst, std::max(1, kBatchWgs / (6 * n)));
+    // Trees and workgroups.  Up to two chains: one pose per workgroup of 1024 / 512 threads (a lone chain's form).
+    // More: the chains' poses in PAIRS -- 512 threads, two poses per workgroup and super-step, which sweep, replay
+    // and tabulate once for the two (hc_resident.hip) --, two workgroups per CU, the trees sized so that all chains'
+    // workgroups are resident together with one CU to spare.
+    if (!b->cus) SLAMHIP_CHECK(hipDeviceGetAttribute(&b->cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    int want = std::min(kHcDefaultInst, std::max(1, kBatchWgs / (6 * n)));
+    // (measured, ms per call, pairs / one pose per 256-thread workgroup: K = 4 0.170 / 0.179, 8: 0.191 / 0.193, 16: 0.288 /
+    // 0.276 -- a pair's super-step is 7 % shorter (7.4 against 8.0 us at K = 8: the beam constants fit in LDS again and
+    // the sweep, the replay and the table are made once for two poses), but two workgroups per CU with a CU to spare
+    // leave room for 20 instead of 21 round instances per chain at K = 8 and 10 instead of 10 at K = 16, where the
+    // narrower workgroups' finer interleaving wins: pairs up to eight chains)
+    b->pair = n * (6 * want + 1) > 512 && n <= 8 && resident_wanted(m) && m->cfg.sum_order != SLAMHIP_SUM_SEQUENTIAL;
+    if (b->pair) want = std::min(kHcDefaultInst, std::max(1, (2 * (b->cus - 1) / n - 1) / 3));
     if (want != b->built_inst) {
       SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
       std::vector<HcShape> shapes(kHcShapes);
@@ -807,11 +822,14 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   b->ran_resident = false;
   if (resident_wanted(m) && !a.seq) {
     int cap_wgs = 0, per_cu = 0;
-    int rc0 = resident_capacity_pick(m, cell_model, b->nt, 1, max_n, b->max_inst, n * (6 * b->max_inst + 1), true,
+    const int res_nt = b->pair ? 512 : b->nt;
+    const int res_wgs = n * (b->pair ? 3 * b->max_inst + 1 : 6 * b->max_inst + 1);
+    int rc0 = resident_capacity_pick(m, cell_model, res_nt, b->pair ? 4 : 1, max_n, b->max_inst, res_wgs, true,
                                      &a.lds_consts, &cap_wgs, &per_cu);
     if (rc0) return rc0;
     ResidentLease lease;  // (the device's resident slots may be another context's: the kernel chains at once then)
-    if (n * (6 * b->max_inst + 1) <= cap_wgs && lease.take(m->device, n * (6 * b->max_inst + 1), per_cu)) {
+    if (res_wgs <= cap_wgs && lease.take(m->device, res_wgs, per_cu)) {
+      a.pair = b->pair ? 1 : 0;
       const double t_res0 = MatchJob::now_us();
       a.spin_limit = spin_limit_for(m->resident_us_max);
       if (!b->d_rctl) {
@@ -835,7 +853,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
       hipEvent_t e0, e1;
       rc0 = profile_event_pair(ctx, &e0, &e1);
       if (rc0) return rc0;
-      SLAMHIP_CHECK(launch_hc_chain_resident(a, cell_model, b->nt, st, e0, e1, n));
+      SLAMHIP_CHECK(launch_hc_chain_resident(a, cell_model, res_nt, st, e0, e1, n));
       launched = 1;
       ++m->resident_matches;
       volatile unsigned *all_done = b->h_all_done;
