@@ -5,7 +5,7 @@
 # in its own pass with --kernel-trace only, as MI355X_MICROARCH.md prescribes.  Output: gpurun_out/<tag>/;
 # tools/summarize_profiles.py <tag> then copies the summaries into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -57,6 +57,9 @@ run cfg5 --legs cfg5 --steps 3 --warmup 1 --no-cpu
 run world --legs world --steps 3 --warmup 1 --no-cpu
 run replicas --legs replicas --steps 3 --warmup 1 --no-cpu
 run bf --legs bf --steps 3 --warmup 1 --no-cpu
+run mc_leg --legs mc --steps 3 --warmup 1 --no-cpu
+run world_viny --legs world_viny --steps 3 --warmup 1 --no-cpu
+python3 $ROOT/tools/hc_batch_stamps.py 2> /dev/null > $OUT/batch_stamps.txt
 python3 $ROOT/tools/hc_chain_stamps.py > $OUT/chain_stamps.txt 2>&1
 python3 $ROOT/tools/hc_resident_stamps.py 2> /dev/null > $OUT/resident_stamps.txt
 ls $OUT | head -80

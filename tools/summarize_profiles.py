@@ -19,7 +19,7 @@ CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); SQ_BUSY_CYCLE
 # dominant kernel of each leg (substring of the rocprof kernel name)
 LEG_KERNEL = {"hc": "k_hc_chain_resident", "sweep": "k_score_point", "mc": "k_mc_chain_resident", "pf": "k_hc_chain_resident_gm",
               "pf_update": "k_hc_chain_step", "pf_maps": "k_mu_", "cfg5": "k_mu_", "world": "k_hc_chain_resident",
-              "replicas": "k_hc_chain_resident", "bf": "k_score_point"}
+              "replicas": "k_hc_chain_resident", "bf": "k_score_point", "mc_leg": "k_mc_chain_resident", "world_viny": "k_mu_cells"}
 lines = ["# rocprofv3 summaries, round tag `%s`\n" % tag,
          "Commands: `tools/profile.sh %s` -- one `rocprofv3 --kernel-trace --stats` run per leg of `bench.py` "
          "(`--legs none` = the headline alone, `--workload sweep`, `--workload mc`, `--legs pf`, `pf_update`, `pf_maps`, "
@@ -30,7 +30,7 @@ def short(name):
     return name.replace("void ", "").replace("slamhip::", "").replace("(anonymous namespace)::", "")[:72]
 
 
-for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world", "replicas", "bf"):
+for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world", "replicas", "bf", "mc_leg", "world_viny"):
     st = os.path.join(src, name, "%s_kernel_stats.csv" % name)
     if not os.path.exists(st):
         continue
@@ -60,8 +60,9 @@ for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world",
                                 d["ms_per_step"]))
             else:
                 leg = {"pf": None, "pf_update": "with_map_update", "pf_maps": "with_particle_maps"}.get(name, name)
-                if name in ("cfg5", "world", "replicas", "bf"):
-                    obj = pd_.get({"world": "world_loop", "bf": "brute_force"}.get(name, name), {})
+                if name in ("cfg5", "world", "replicas", "bf", "mc_leg", "world_viny"):
+                    obj = pd_.get({"world": "world_loop", "bf": "brute_force", "mc_leg": "monte_carlo",
+                                   "world_viny": "world_loop_viny"}.get(name, name), {})
                     if name == "replicas":
                         lines.append("\nun-profiled replicas leg (`%s_%s_bench_unprofiled.json`): " % (tag, name) + "; ".join(
                             "K=%d %.3f ms/call = %.3g units/s (kernel frac %.3f)" %
@@ -87,6 +88,10 @@ rs_ = os.path.join(src, "resident_stamps.txt")
 if os.path.exists(rs_):
     shutil.copy(rs_, os.path.join(dst, "%s_resident_stamps.txt" % tag))
     lines.append("In-kernel timeline of the co-resident chain's super-step (`tools/hc_resident_stamps.py`): `%s_resident_stamps.txt`.\n" % tag)
+bs_ = os.path.join(src, "batch_stamps.txt")
+if os.path.exists(bs_):
+    shutil.copy(bs_, os.path.join(dst, "%s_batch_stamps.txt" % tag))
+    lines.append("In-kernel timeline of chain 0 of a co-resident batch (`tools/hc_batch_stamps.py`): `%s_batch_stamps.txt`.\n" % tag)
 cs = os.path.join(src, "chain_stamps.txt")
 if os.path.exists(cs):
     shutil.copy(cs, os.path.join(dst, "%s_chain_stamps.txt" % tag))
