@@ -69,6 +69,17 @@ def test_default_bench_line_contract():
     c5 = d["cfg5"]
     assert "8000x8000" in c5["workload"] and "500 particles" in c5["workload"] and c5["unit"] == "particles/s"
     assert c5["roofline"]["bytes_per_unit"] == 64 and c5["roofline"]["units_launched"] > 1e8
+    # r05: BASELINE configs[2] and the vinySLAM world loop are in the driver's line, each leg
+    # has its own sample, and the per-particle-maps leg states what its sharded form should cost
+    mc = d["monte_carlo"]
+    assert "cfg3" in mc["workload"] and mc["roofline"]["kernel"] == "k_mc_chain_resident" and mc["roofline"]["bytes_per_unit"] == 56
+    assert mc["roofline"]["frac"] >= 0.40 and mc["resident"]["gave_up"] == 0 and mc["steps"] >= 32
+    assert mc["parity"]["scenes"] >= 8 and mc["parity"]["traces_equal"] == mc["parity"]["scenes"] == mc["parity"]["filtered_counts_equal"]
+    assert mc["cpu_baseline"]["kind"] == "reference" and mc["cpu_baseline"]["cores"] == 1 and mc["value"] > 1000 * mc["cpu_baseline"]["value"]
+    assert "vinySLAM" in d["world_loop_viny"]["preset"] and d["world_loop_viny"]["ms_per_scan"] > 0
+    assert all(r_["calls"] >= 32 for r_ in rep) and c5["steps"] >= 8
+    sm2 = pf["with_particle_maps"]["scaling_model"]["by_ranks"]
+    assert [m_["ranks"] for m_ in sm2] == [1, 2, 4, 8] and sum(m_["resamplings"] for m_ in sm2) >= 1
 
 
 @pytest.mark.skipif(not HEADLINE, reason="no committed bench line yet")
