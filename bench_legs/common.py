@@ -75,7 +75,8 @@ HC_LATENCY_STAMPS_US = {"boundary": 1.85, "staged": 1.61, "replayed": 1.88, "pos
 # granules: one write-through store, one hop (MI355X_MICROARCH.md handoff-1to1, idle: 0.8 us) and half a poll period;
 # stamps: tools/hc_resident_stamps.py (profiles/r04_resident_stamps.txt)
 HC_RESIDENT_MODEL_US = {"gather": 1.05, "replayed": 0.52, "pose": 0.50, "terms": 0.25, "sum_publish": 0.30}
-HC_RESIDENT_STAMPS_US = {"gather": 1.51, "replayed": 1.69, "pose": 0.67, "terms": 1.07, "sum_publish": 0.91, "loop": 0.32}
+# (r05 stamps, profiles/r05_resident_stamps.txt: the pose comes out of the table the idle waves made)
+HC_RESIDENT_STAMPS_US = {"gather": 1.39, "replayed": 1.31, "pose": 0.38, "terms": 0.80, "sum_publish": 0.93, "loop": 0.32}
 
 
 def latency_model(ms_per_match, super_steps, resident=False):
