@@ -515,7 +515,10 @@ def main():
         for k_, v_ in extra_legs.items():
             if v_ is not None:
                 out[k_] = v_
-        print(json.dumps(out))
+        # RCCL's banner sits in C stdio's buffer when stdout is a pipe: push it out first, so that the line is the last one
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
     # The secondary legs run AFTER the headline is complete.  With more than one rank the particle-filter leg joins
     # an RCCL group inside the library: should that ever block (a fabric problem is not this benchmark's to sit
