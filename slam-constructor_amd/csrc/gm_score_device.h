@@ -140,8 +140,53 @@ struct GmWindowCell {
   }
 };
 
+// The same window through the NEIGHBOURHOOD MASK of its centre cell (MapView::nbr_ok, dense windows): one 4-byte load
+// says which of the nine cells are full, and only those cells' obstacle means are fetched -- one to three next to a
+// wall, none in free space -- instead of nine occupancies first.  The phase is bound by what a beam makes the CU
+// issue (nine address computations, nine loads, nine tests), not by bytes: 0.57 -> 0.47 ms per 100-particle step.
+// A centre cell on the window's rim (or outside) has no complete mask: the nine-cell form above.  The selection is
+// the same minimum over the same full cells.
+__device__ __forceinline__ double gm_fresh_value_w1_nbr(const MapView &m, const double *unk, const GmParams &gp, int cx,
+                                                        int cy, double ox, double oy) {
+  const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+  const bool inner = ix0 >= 1 && iy0 >= 1 && ix0 + 1 < m.width && iy0 + 1 < m.height;
+  if (!inner) {
+    GmWindow1 w;
+    w.issue_occ(m, unk, nullptr, cx, cy);
+    w.issue_obst(m, unk, gp);
+    return w.finish(gp, ox, oy);
+  }
+  const double *pay = m.payload;
+  const size_t row = 4 * (size_t)m.pitch;
+  const double *c0 = pay + row * (size_t)(iy0 - 1) + 4 * (size_t)(ix0 - 1);  // cell (-1, -1)
+  const unsigned m9 = reinterpret_cast<const unsigned *>(c0 + row + 4 + 3)[0];
+  double obx9[9], oby9[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    obx9[i] = 0.0;
+    oby9[i] = 0.0;
+    if ((m9 & (1u << i)) != 0u) {
+      const double *c = c0 + (i % 3) * row + 4 * (i / 3);  // dx outer, dy inner like the reference
+      obx9[i] = c[1];
+      oby9[i] = c[2];
+    }
+  }
+  double best_d2 = __builtin_inf();
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double ddx = obx9[i] - ox, ddy = oby9[i] - oy;
+    const double d2 = ddx * ddx + ddy * ddy;
+    const bool better = (m9 & (1u << i)) != 0u && d2 < best_d2;  // (a NaN distance never wins)
+    best_d2 = better ? d2 : best_d2;
+    any |= better;
+  }
+  return gm_value_of(best_d2, any);
+}
+
 __device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
                                                     const GmParams &gp, int cx, int cy, double ox, double oy) {
+  if (m.nbr_ok && !tiles) return gm_fresh_value_w1_nbr(m, unk, gp, cx, cy, ox, oy);
   GmWindow1 w;
   w.issue_occ(m, unk, tiles, cx, cy);
   w.issue_obst(m, unk, gp);
@@ -222,7 +267,7 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
   // next to their own beam's nine and in the same two round trips; the beam's value is made from their nine
   // distances behind the barrier (the same selection: the smallest distance to a full cell).
   const int surplus = n - NT;
-  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT;
+  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT && !(map.nbr_ok && !tiles);
   if (helpers) {
     const double c = cs * ca0 - sn * sa0;
     const double s = sn * ca0 + cs * sa0;

@@ -40,6 +40,8 @@ __device__ __forceinline__ MapView load_view(MapViewCP p) {
   m.scale = p->scale;
   m.inv_scale = p->inv_scale;
   for (int k = 0; k < 4; ++k) m.unknown[k] = p->unknown[k];
+  m.nbr_ok = p->nbr_ok;
+  m.reserved_ = 0;
   return m;
 }
 __device__ __forceinline__ ScanView load_view(ScanViewCP p) {

@@ -69,6 +69,9 @@ struct MuArgs {
   // batch, free-space fast path (k_mu_classify): one bit per sort key, set by k_mu_emit for every cell a beam may
   // observe as occupied (its end cell and the cells inside the blur distance)
   unsigned *special;
+  // dense GMAPPING window whose cells' pads hold neighbourhood masks for threshold nbr_th (MapView, mu_cell_store)
+  int nbr_on;
+  double nbr_th;
   double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
   int fresh_ok;
   // ... with LAZY keys: a beam whose closed form holds writes no keys at all (k_mu_classify evaluates the form again,
@@ -1137,7 +1140,26 @@ __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const 
                       __double_as_longlong(c.c1) == __double_as_longlong(was.c1) &&
                       __double_as_longlong(c.c2) == __double_as_longlong(was.c2) &&
                       __double_as_longlong(c.c3) == __double_as_longlong(was.c3);
-    if (!same) reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
+    if (!same) {
+      if (a.nbr_on) {
+        // the pad holds this cell's neighbourhood mask, which the neighbours' threads change with atomics while this
+        // one stores: the pad is not written here.  A cell that changes sides flips its bit in the nine masks it is in
+        // (the cell at (+dx, +dy) sees this one at (-dx, -dy): bit 8 - i).
+        reinterpret_cast<double2 *>(a.payload)[2 * at] = make_double2(c.c0, c.c1);
+        a.payload[4 * at + 2] = c.c2;
+        if ((c.c0 < a.nbr_th) != (was.c0 < a.nbr_th)) {
+          const int iy = (int)(at / (size_t)a.pitch), ix = (int)(at - (size_t)iy * a.pitch);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const int x = ix + i / 3 - 1, y = iy + i % 3 - 1;
+            if ((unsigned)x < (unsigned)a.width && (unsigned)y < (unsigned)a.height)
+              atomicXor(reinterpret_cast<unsigned *>(a.payload + 4 * ((size_t)y * a.pitch + x) + 3), 1u << (8 - i));
+          }
+        }
+      } else {
+        reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
+      }
+    }
   } else if (RULE == 3) {
     reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
   } else {

@@ -2021,6 +2021,25 @@ int slamhip_matcher_debug_resident_mute(slamhip_matcher *m, int slot_plus_1) {
   m->debug_resident_mute = slot_plus_1;
   return SLAMHIP_OK;
 }
+// testing aid: the state of a dense GMAPPING window's neighbourhood masks (MapView) -- *valid: whether the map holds
+// masks at all; *mismatches: cells whose stored mask differs from the one the occupancies around them give
+int slamhip_map_debug_nbr_masks(slamhip_ctx *ctx, int map_id, int *valid, long long *mismatches) {
+  if (!ctx || map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound) return invalid_arg("unknown map id");
+  DeviceMap &dm = ctx->maps[map_id];
+  if (valid) *valid = dm.nbr_ok ? 1 : 0;
+  if (mismatches) *mismatches = 0;
+  if (!dm.nbr_ok || !mismatches) return SLAMHIP_OK;
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  unsigned long long *d_count = nullptr, h_count = 0;
+  SLAMHIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
+  SLAMHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+  SLAMHIP_CHECK(launch_nbr_check(dm.d_payload, dm.width, dm.height, dm.pitch, dm.nbr_th, d_count, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(h_count), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_count);
+  *mismatches = (long long)h_count;
+  return SLAMHIP_OK;
+}
 #endif  // SLAMHIP_TESTING
 
 int slamhip_matcher_resident_stats(slamhip_matcher *m, long long *matches, long long *gave_up) {

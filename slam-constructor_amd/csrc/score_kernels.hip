@@ -662,7 +662,7 @@ __global__ void k_repack_window(double *dst, int dst_pitch, int cell_dbl, const 
     const int yy = (int)(i / w), xx = (int)(i % w);
     double *d = dst + ((size_t)(y0 + yy) * dst_pitch + (x0 + xx)) * cell_dbl;
     const double *s = src + i * stride_host;
-    for (int k = 0; k < cell_dbl; ++k) d[k] = k < stride_host ? s[k] : 0.0;
+    for (int k = 0; k < stride_host && k < cell_dbl; ++k) d[k] = s[k];
   }
 }
 
@@ -671,7 +671,83 @@ __global__ void k_scatter_cells(double *payload, int pitch, int cell_dbl, int st
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double *d = payload + ((size_t)coords[2 * i + 1] * pitch + coords[2 * i]) * cell_dbl;
-  for (int k = 0; k < cell_dbl; ++k) d[k] = k < stride_host ? vals[(size_t)i * stride_host + k] : 0.0;
+  for (int k = 0; k < stride_host && k < cell_dbl; ++k) d[k] = vals[(size_t)i * stride_host + k];
+}
+
+// ---- neighbourhood masks of a dense GMAPPING window (MapView) ------------------------------------------------
+__device__ __forceinline__ unsigned nbr_mask_of(const double *payload, int width, int height, int pitch, double th, int ix,
+                                                int iy) {
+  unsigned m9 = 0u;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int x = ix + i / 3 - 1, y = iy + i % 3 - 1;
+    if ((unsigned)x < (unsigned)width && (unsigned)y < (unsigned)height && !(payload[4 * ((size_t)y * pitch + x)] < th))
+      m9 |= 1u << i;
+  }
+  return m9;
+}
+
+__global__ __launch_bounds__(256) void k_nbr_build(double *payload, int width, int height, int pitch, double th, int x0, int y0,
+                                                   int w, int h) {
+  const size_t total = (size_t)w * h;
+  for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (size_t)gridDim.x * 256) {
+    const int iy = y0 + (int)(c / w), ix = x0 + (int)(c % w);
+    reinterpret_cast<unsigned *>(payload + 4 * ((size_t)iy * pitch + ix) + 3)[0] =
+        nbr_mask_of(payload, width, height, pitch, th, ix, iy);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nbr_cells(double *payload, int width, int height, int pitch, double th, int n,
+                                                   const int *coords) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= 9 * n) return;
+  const int c = j / 9, i = j - 9 * c;
+  const int ix = coords[2 * c] + i / 3 - 1, iy = coords[2 * c + 1] + i % 3 - 1;
+  if ((unsigned)ix >= (unsigned)width || (unsigned)iy >= (unsigned)height) return;
+  // (two listed cells next to each other re-derive the same mask twice: the same value both times)
+  reinterpret_cast<unsigned *>(payload + 4 * ((size_t)iy * pitch + ix) + 3)[0] =
+      nbr_mask_of(payload, width, height, pitch, th, ix, iy);
+}
+
+__global__ __launch_bounds__(256) void k_nbr_check(const double *payload, int width, int height, int pitch, double th,
+                                                   unsigned long long *count) {
+  const size_t total = (size_t)width * height;
+  unsigned long long bad = 0;
+  for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (size_t)gridDim.x * 256) {
+    const int iy = (int)(c / width), ix = (int)(c % width);
+    const unsigned have = reinterpret_cast<const unsigned *>(payload + 4 * ((size_t)iy * pitch + ix) + 3)[0];
+    if (have != nbr_mask_of(payload, width, height, pitch, th, ix, iy)) ++bad;
+  }
+  if (bad) atomicAdd(count, bad);
+}
+
+hipError_t launch_nbr_build(double *payload, int width, int height, int pitch, double th, int x0, int y0, int w, int h,
+                            hipStream_t stream) {
+  const int x1 = std::min(width, x0 + w), y1 = std::min(height, y0 + h);
+  x0 = std::max(0, x0);
+  y0 = std::max(0, y0);
+  if (x1 <= x0 || y1 <= y0) return hipSuccess;
+  const size_t total = (size_t)(x1 - x0) * (y1 - y0);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)65536);
+  hipLaunchKernelGGL(k_nbr_build, dim3(blocks), dim3(256), 0, stream, payload, width, height, pitch, th, x0, y0, x1 - x0,
+                     y1 - y0);
+  return hipGetLastError();
+}
+
+hipError_t launch_nbr_cells(double *payload, int width, int height, int pitch, double th, int n, const int *d_coords,
+                            hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_nbr_cells, dim3((9 * n + 255) / 256), dim3(256), 0, stream, payload, width, height, pitch, th, n,
+                     d_coords);
+  return hipGetLastError();
+}
+
+hipError_t launch_nbr_check(const double *payload, int width, int height, int pitch, double th, unsigned long long *d_count,
+                            hipStream_t stream) {
+  const size_t total = (size_t)width * height;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)65536);
+  hipLaunchKernelGGL(k_nbr_check, dim3(blocks ? blocks : 1), dim3(256), 0, stream, payload, width, height, pitch, th, d_count);
+  return hipGetLastError();
 }
 
 hipError_t launch_fill_cells(double *dst, size_t n_cells, int cell_dbl, const double *u,

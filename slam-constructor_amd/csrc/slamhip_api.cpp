@@ -114,7 +114,20 @@ static int check_cfg(const DeviceMap &m, const slamhip_spe_cfg *cfg) {
   return SLAMHIP_OK;
 }
 
-static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg *cfg, int n_poses,
+// The neighbourhood masks of a dense GMAPPING window for threshold th (MapView::nbr_ok), derived on the context's stream
+// by the first GMapping scorer call that finds none (or finds another threshold's); from then on the map's writers
+// keep them.  The pass reads nine occupancies per cell (0.5 GB of cells: a fraction of a millisecond) and is waited
+// for: the scorer's second launch lane and the chains' own streams are not ordered behind this one.
+static int map_nbr_masks(slamhip_ctx *ctx, DeviceMap &m, double th) {
+  if (m.nbr_ok && m.nbr_th == th) return SLAMHIP_OK;
+  SLAMHIP_CHECK(launch_nbr_build(m.d_payload, m.width, m.height, m.pitch, th, 0, 0, m.width, m.height, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  m.nbr_th = th;
+  m.nbr_ok = true;
+  return SLAMHIP_OK;
+}
+
+static int fill_args(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cfg, int n_poses,
                      const double *d_poses, const double *d_pose_sc, double *d_scores,
                      ScoreArgs *a) {
   if (ctx->scan_n <= 0) {
@@ -131,6 +144,12 @@ static int fill_args(slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg
   a->map.scale = m.scale;
   a->map.inv_scale = 1.0 / m.scale;
   for (int k = 0; k < 4; ++k) a->map.unknown[k] = m.unknown[k];
+  if (cfg->oope == SLAMHIP_OOPE_GMAPPING && m.cell_model == SLAMHIP_CELL_GMAPPING && m.bytes > 0 && cfg->gm_window == 1 &&
+      m.width >= 3 && m.height >= 3) {  // (bytes: a dense window -- the view of a tile pool has none)
+    const int rc = map_nbr_masks(ctx, m, cfg->gm_fullness_th);
+    if (rc) return rc;
+    a->map.nbr_ok = 1;
+  }
   const size_t c = ctx->scan_stride;
   a->scan.range = ctx->scan_ptr;
   a->scan.cos_a = ctx->scan_ptr + c;
@@ -716,6 +735,8 @@ int slamhip_map_upload_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int 
   hipError_t e = hipMemcpyAsync(d_tmp, payload, bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess)
     e = launch_repack_window(m->d_payload, m->pitch, cd, d_tmp, sh, x0, y0, w, h, ctx->stream);
+  if (e == hipSuccess && m->nbr_ok)  // the masks of the written cells and of the ring around them
+    e = launch_nbr_build(m->d_payload, m->width, m->height, m->pitch, m->nbr_th, x0 - 1, y0 - 1, w + 2, h + 2, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   hipFree(d_tmp);
   if (e != hipSuccess) return hip_fail(e, "map_upload_window");
@@ -769,6 +790,8 @@ int slamhip_map_apply_dirty(slamhip_ctx *ctx, int map_id, int n, const int *coor
                                hipMemcpyHostToDevice, ctx->stream));
   SLAMHIP_CHECK(launch_scatter_cells(m->d_payload, m->pitch, cd, sh, n, ctx->d_dirty_xy,
                                      ctx->d_dirty_val, ctx->stream));
+  if (m->nbr_ok)
+    SLAMHIP_CHECK(launch_nbr_cells(m->d_payload, m->width, m->height, m->pitch, m->nbr_th, n, ctx->d_dirty_xy, ctx->stream));
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   return SLAMHIP_OK;
 }

@@ -26,12 +26,19 @@ namespace slamhip {
 // ---- views passed to kernels by value -----------------------------------------------------
 // Map window in HBM: row-major [height][pitch] cells, each cell CELL_DOUBLES(model) doubles
 // (OCC 1, TBM 4, GMAPPING 4 = prob_occ, obst.x, obst.y, pad -> 32-byte aligned gathers).
+// The pad of a GMAPPING cell of a DENSE window holds, in its low dword, the cell's NEIGHBOURHOOD MASK once a GMapping
+// scorer has asked for it (nbr_ok): bit 3 (dx + 1) + (dy + 1) = "the cell at (+dx, +dy) is inside the window and full",
+// full = !(prob_occ < fullness_th) -- the scorer's own test.  One 4-byte load then tells a beam which of the nine
+// cells of its 3 x 3 window it has to look at (gm_score_device.h); writers keep the masks (mu_cell_store flips the
+// nine neighbours' bits when a cell changes sides; uploads re-derive them) or drop them (DeviceMap::nbr_ok).
 struct MapView {
   const double *payload;
   int width, height, pitch;
   int origin_x, origin_y;
   double scale, inv_scale;  // inv_scale = RN(1 / scale), see to_cell()
   double unknown[4];
+  int nbr_ok;  // the neighbourhood masks of this (dense, GMAPPING) window are valid for the scorer's threshold
+  int reserved_;
 };
 
 // Filtered scan, structure-of-arrays (coalesced per-beam loads), tot_w = sequential sum of
@@ -104,6 +111,7 @@ hipError_t launch_stall(int ms, hipStream_t stream);  // testing
 hipError_t launch_block_pull(const void *h_src, void *d_dst, size_t bytes, hipStream_t stream);
 hipError_t launch_scan_pull(const double *h_src, double *d_dst, size_t n_doubles, unsigned *counter, unsigned *h_flag,
                             unsigned seq, hipStream_t stream);
+// (both uploads write the host's stride_host doubles of a cell and leave the rest of it alone -- a GMAPPING cell's pad)
 hipError_t launch_scatter_cells(double *payload, int pitch, int cell_dbl, int stride_host, int n,
                                 const int *d_coords, const double *d_vals, hipStream_t stream);
 hipError_t launch_repack_window(double *dst, int dst_pitch, int cell_dbl, const double *src,
@@ -129,7 +137,19 @@ struct DeviceMap {
   // unbounded maps grow inside update(), plain_grid_map.h:133-173)
   bool auto_grow = false;
   long grown = 0;  // number of such re-binds
+  // neighbourhood masks in the cells' pads (MapView): valid for threshold nbr_th; built by map_nbr_masks()
+  bool nbr_ok = false;
+  double nbr_th = 0.0;
 };
+// (re)derives the masks of the cells of [x0, x0 + w) x [y0, y0 + h) (clipped to the window) from the occupancies
+hipError_t launch_nbr_build(double *payload, int width, int height, int pitch, double th, int x0, int y0, int w, int h,
+                            hipStream_t stream);
+// ... and of the 3 x 3 neighbourhoods of n listed cells (d_coords: x, y pairs)
+hipError_t launch_nbr_cells(double *payload, int width, int height, int pitch, double th, int n, const int *d_coords,
+                            hipStream_t stream);
+// cells whose stored mask differs from the one their neighbours' occupancies give (testing), added to *d_count
+hipError_t launch_nbr_check(const double *payload, int width, int height, int pitch, double th, unsigned long long *d_count,
+                            hipStream_t stream);
 
 void mu_allow_scan_reuse(slamhip_ctx *ctx, bool on);  // map_update.hip
 bool mu_set_deferred(slamhip_ctx *ctx, bool on);      // map_update.hip: queue plain updates without waiting (returns the old setting)
