@@ -235,12 +235,114 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const double 
   return 0.0 < v ? v : 0.0;
 }
 
-// One pose scored by ONE workgroup of NT threads (NT >= 256): phase A (end point, nine gathers, exp) over all
-// threads -- beam b goes to thread b % NT --, run resolution (Q19: every maximal run of equal end cells takes
-// the value of its first beam) and the canonical sum by the first 256 threads.  s_dyn: val[256 KB] | grp_cell
-// int2 [4 KB] | grp_start int [4 KB] | cx, cy int [256 KB]; *s_run0 must hold n (set before a barrier).
-// Thread 0 leaves the score in *score_out (its own copy) and the side outputs of the cross-pose cache in *gi_out.
-// r0 / ca0 / sa0: the constants of beam `threadIdx.x`, loaded by the caller ahead of the pose.
+// The mask form in stages of independent loads (see GmWindow1), for callers that interleave two windows: the mask ->
+// the obstacle means of the full cells -> the value.  A centre cell on the window's rim has no complete mask: its
+// value is made at once, the nine-cell way.
+struct GmWindowN {
+  unsigned m9;
+  bool done;
+  double v;
+  const double *c0;
+  size_t row;
+  double obx9[9], oby9[9];
+  __device__ __forceinline__ void issue_mask(const MapView &m, const double *unk, const GmParams &gp, int cx, int cy, double ox,
+                                             double oy) {
+    const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+    done = !(ix0 >= 1 && iy0 >= 1 && ix0 + 1 < m.width && iy0 + 1 < m.height);
+    m9 = 0u;
+    v = 0.0;
+    row = 4 * (size_t)m.pitch;
+    c0 = m.payload;
+    if (done) {
+      GmWindow1 w;
+      w.issue_occ(m, unk, nullptr, cx, cy);
+      w.issue_obst(m, unk, gp);
+      v = w.finish(gp, ox, oy);
+    } else {
+      c0 = m.payload + row * (size_t)(iy0 - 1) + 4 * (size_t)(ix0 - 1);
+      m9 = reinterpret_cast<const unsigned *>(c0 + row + 4 + 3)[0];
+    }
+  }
+  __device__ __forceinline__ void issue_obst() {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      obx9[i] = 0.0;
+      oby9[i] = 0.0;
+      if ((m9 & (1u << i)) != 0u) {
+        const double *c = c0 + (i % 3) * row + 4 * (i / 3);
+        obx9[i] = c[1];
+        oby9[i] = c[2];
+      }
+    }
+  }
+  __device__ __forceinline__ double finish(double ox, double oy) const {
+    if (done) return v;
+    double best_d2 = __builtin_inf();
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double ddx = obx9[i] - ox, ddy = oby9[i] - oy;
+      const double d2 = ddx * ddx + ddy * ddy;
+      const bool better = (m9 & (1u << i)) != 0u && d2 < best_d2;
+      best_d2 = better ? d2 : best_d2;
+      any |= better;
+    }
+    return gm_value_of(best_d2, any);
+  }
+};
+
+// ... and ONE cell of such a window, for a helper lane (GmWindowCell)
+struct GmWindowCellN {
+  bool full, done;
+  double dv;
+  const double *c;
+  __device__ __forceinline__ void issue_mask(const MapView &m, const double *unk, const GmParams &gp, int cx, int cy, int i,
+                                             double ox, double oy) {
+    const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+    done = !(ix0 >= 1 && iy0 >= 1 && ix0 + 1 < m.width && iy0 + 1 < m.height);
+    full = false;
+    dv = __builtin_inf();
+    c = m.payload;
+    if (done) {
+      GmWindowCell w;
+      w.issue_occ(m, unk, nullptr, cx, cy, i);
+      w.issue_obst(m, unk, gp);
+      dv = w.d2(gp, ox, oy);
+    } else {
+      const size_t row = 4 * (size_t)m.pitch;
+      const unsigned m9 = reinterpret_cast<const unsigned *>(m.payload + row * (size_t)iy0 + 4 * (size_t)ix0 + 3)[0];
+      full = ((m9 >> i) & 1u) != 0u;
+      c = m.payload + row * (size_t)(iy0 + i % 3 - 1) + 4 * (size_t)(ix0 + i / 3 - 1);
+    }
+  }
+  double obx, oby;
+  __device__ __forceinline__ void issue_obst() {
+    obx = 0.0;
+    oby = 0.0;
+    if (full) {
+      obx = c[1];
+      oby = c[2];
+    }
+  }
+  __device__ __forceinline__ double d2(double ox, double oy) const {
+    if (done) return dv;
+    const double ddx = obx - ox, ddy = oby - oy;
+    const double v = ddx * ddx + ddy * ddy;
+    return (full && v < __builtin_inf()) ? v : __builtin_inf();
+  }
+};
+
+// One pose scored by ONE workgroup of NT threads (NT >= 256): phase A (end point, window, exp) over all threads --
+// beam b goes to thread b % NT --, run resolution (Q19: every maximal run of equal end cells takes the value of its
+// first beam) by the beams' own threads, and the canonical sum by the first 256 threads (thread t adds the terms of
+// beams t, t + 256, ... in that order, then the wave's tree, then the four waves' partial sums: the one order every
+// GMapping path uses).  s_dyn: val[256 KB] | grp_cell int2 [4 KB] | grp_start int [4 KB] | 256 KB doubles: the terms
+// (in front of them, during phase A, the cells of the helpers' beams) | NT doubles (NT >= 512); *s_run0 must hold n
+// (set before a barrier).  Thread 0 leaves the score in *score_out (its own copy) and the side outputs of the
+// cross-pose cache in *gi_out.  r0 / ca0 / sa0: the constants of beam `threadIdx.x`, loaded by the caller ahead of the
+// pose.
+// (r05: the run resolution used to be the first 256 threads' too, KB beams one after the other with an LDS round
+// trip or three in each: 2.7 of a 1024-thread workgroup's 14 us per pose.)
 template <int KB, int NT>
 __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const ScanView &scan, const GmParams &gm,
                                                    const int *tiles, const double *s_unknown, double x, double y, double sn,
@@ -253,21 +355,25 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
   const int lane = t & 63, wave = t >> 6;
   const int n = scan.n;
   const int G = (n + 63) >> 6;
+  constexpr int R = (KB * kGmBlock + NT - 1) / NT;  // beams per thread: b = t + NT r
   double *s_val = s_dyn;
   int2 *s_grp_cell = reinterpret_cast<int2 *>(s_dyn + (size_t)KB * kGmBlock);
   int *s_grp_start = reinterpret_cast<int *>(s_grp_cell + 4 * KB);
-  int *s_cx = s_grp_start + 4 * KB;
-  int *s_cy = s_cx + KB * kGmBlock;
-  double *s_sur = reinterpret_cast<double *>(s_cy + KB * kGmBlock);  // NT doubles (kGmHelperDoubles<NT>)
+  double *s_term = reinterpret_cast<double *>(s_grp_start + 4 * KB);
+  int2 *s_hcell = reinterpret_cast<int2 *>(s_term);  // (phase A only: the helpers' beams' cells)
+  double *s_sur = s_term + (size_t)KB * kGmBlock;    // NT doubles (kGmHelperDoubles<NT>)
   int &s_run0_len = *s_run0;
   const double scale = map.scale, inv_scale = map.inv_scale;
+  int cxr[R], cyr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) cxr[r] = cyr[r] = 0;
   // phase A over all threads.  A scan a little longer than the workgroup -- 1080 beams on 1024 threads -- would send
-  // the first wave through the phase TWICE for its 56 surplus beams (2.4 of the phase's 6.6 us: another end point,
-  // another two round trips of gathers).  Instead nine HELPER lanes per surplus beam fetch one cell of its window each,
-  // next to their own beam's nine and in the same two round trips; the beam's value is made from their nine
-  // distances behind the barrier (the same selection: the smallest distance to a full cell).
+  // the first wave through the phase TWICE for its 56 surplus beams (another end point, another two round trips of
+  // gathers).  Instead nine HELPER lanes per surplus beam fetch one cell of its window each, next to their own beam's
+  // window and in the same round trips; the beam's value is made from their nine distances behind the barrier (the
+  // same selection: the smallest distance to a full cell).
   const int surplus = n - NT;
-  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT && !(map.nbr_ok && !tiles);
+  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT;
   if (helpers) {
     const double c = cs * ca0 - sn * sa0;
     const double s = sn * ca0 + cs * sa0;
@@ -287,86 +393,105 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
       hcx = to_cell(hwx, scale, inv_scale);
       hcy = to_cell(hwy, scale, inv_scale);
     }
-    GmWindow1 own;
-    GmWindowCell cell;
-    own.issue_occ(map, s_unknown, tiles, cx, cy);
-    if (hlp) cell.issue_occ(map, s_unknown, tiles, hcx, hcy, hi);
-    own.issue_obst(map, s_unknown, gm);
-    if (hlp) cell.issue_obst(map, s_unknown, gm);
-    s_val[t] = own.finish(gm, wx, wy);
-    s_cx[t] = cx;
-    s_cy[t] = cy;
+    double own_v, sur_d2 = __builtin_inf();
+    if (map.nbr_ok && !tiles) {
+      GmWindowN own;
+      GmWindowCellN cell;
+      own.issue_mask(map, s_unknown, gm, cx, cy, wx, wy);
+      if (hlp) cell.issue_mask(map, s_unknown, gm, hcx, hcy, hi, hwx, hwy);
+      own.issue_obst();
+      if (hlp) cell.issue_obst();
+      own_v = own.finish(wx, wy);
+      if (hlp) sur_d2 = cell.d2(hwx, hwy);
+    } else {
+      GmWindow1 own;
+      GmWindowCell cell;
+      own.issue_occ(map, s_unknown, tiles, cx, cy);
+      if (hlp) cell.issue_occ(map, s_unknown, tiles, hcx, hcy, hi);
+      own.issue_obst(map, s_unknown, gm);
+      if (hlp) cell.issue_obst(map, s_unknown, gm);
+      own_v = own.finish(gm, wx, wy);
+      if (hlp) sur_d2 = cell.d2(gm, hwx, hwy);
+    }
+    s_val[t] = own_v;
+    cxr[0] = cx;
+    cyr[0] = cy;
+    if (lane == 63) s_grp_cell[wave] = make_int2(cx, cy);  // (NT < n: beam t is never the last one)
     if (hlp) {
-      s_sur[t] = cell.d2(gm, hwx, hwy);
-      if (hi == 0) {
-        s_cx[hb] = hcx;
-        s_cy[hb] = hcy;
-      }
+      s_sur[t] = sur_d2;
+      if (hi == 0) s_hcell[hb - NT] = make_int2(hcx, hcy);
     }
   } else {
-    for (int b = t; b < n; b += NT) {
-      const double r = b == t ? r0 : scan.range[b], ca = b == t ? ca0 : scan.cos_a[b], sa = b == t ? sa0 : scan.sin_a[b];
-      const double c = cs * ca - sn * sa;
-      const double s = sn * ca + cs * sa;
-      const double wx = x + r * c;
-      const double wy = y + r * s;
-      const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
-      s_val[b] = gm_fresh_value(map, s_unknown, tiles, gm, cx, cy, wx, wy);
-      s_cx[b] = cx;
-      s_cy[b] = cy;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int b = t + NT * r;
+      if (b < n) {
+        const double rr = r == 0 ? r0 : scan.range[b], ca = r == 0 ? ca0 : scan.cos_a[b], sa = r == 0 ? sa0 : scan.sin_a[b];
+        const double c = cs * ca - sn * sa;
+        const double s = sn * ca + cs * sa;
+        const double wx = x + rr * c;
+        const double wy = y + rr * s;
+        const int cx = to_cell(wx, scale, inv_scale), cy = to_cell(wy, scale, inv_scale);
+        s_val[b] = gm_fresh_value(map, s_unknown, tiles, gm, cx, cy, wx, wy);
+        cxr[r] = cx;
+        cyr[r] = cy;
+        if (lane == 63 || b == n - 1) s_grp_cell[b >> 6] = make_int2(cx, cy);
+      }
     }
   }
   __syncthreads();
   if (stamp_a) *stamp_a = wall_clock64();  // (tools/hc_chain_stamps.py: the end of phase A)
-  if (helpers && t < surplus) {  // (read two barriers further down, in phase C)
+  // ---- runs: which beams start one.  Beam b's group = b >> 6 = its wave in its round; the cell in front of a
+  // group's first beam is the last one of the group before (s_grp_cell).  The weights and factors of this thread's
+  // beams are asked for here, two barriers ahead of their use.
+  double bw[R], bf[R];
+  unsigned long long mask[R];
+  if (R >= 2 && helpers && t < surplus) {
+    const int2 hc = s_hcell[t];
+    cxr[R >= 2 ? 1 : 0] = hc.x;
+    cyr[R >= 2 ? 1 : 0] = hc.y;
     double best_d2 = __builtin_inf();
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       const double d2 = s_sur[9 * t + i];
       best_d2 = d2 < best_d2 ? d2 : best_d2;
     }
-    s_val[NT + t] = gm_value_of(best_d2, best_d2 < __builtin_inf());
+    s_val[NT + t] = gm_value_of(best_d2, best_d2 < __builtin_inf());  // (read behind the next barrier)
   }
-  // canonical layout from here on; waves 4..7 only keep the barriers company
-  const bool act = t < kGmBlock;
-  int ccx[KB], ccy[KB];
 #pragma unroll
-  for (int k = 0; k < KB; ++k) {
-    const int b = t + kGmBlock * k;
-    ccx[k] = 0;
-    ccy[k] = 0;
-    if (act && b < n) {
-      ccx[k] = s_cx[b];
-      ccy[k] = s_cy[b];
-      if (lane == 63 || b == n - 1) s_grp_cell[4 * k + wave] = make_int2(ccx[k], ccy[k]);
+  for (int r = 0; r < R; ++r) {
+    const int b = t + NT * r;
+    bw[r] = bf[r] = 0.0;
+    if (b < n) {
+      bw[r] = scan.weight[b];
+      bf[r] = scan.factor[b];
     }
   }
-  __syncthreads();
-  unsigned long long mask[KB];
 #pragma unroll
-  for (int k = 0; k < KB; ++k) {
-    const int b = t + kGmBlock * k;
-    const int g = 4 * k + wave;
-    int pcx = __shfl_up(ccx[k], 1, 64), pcy = __shfl_up(ccy[k], 1, 64);
-    if (act && lane == 0 && g > 0 && b < n) {
-      const int2 pc = s_grp_cell[g - 1];
+  for (int r = 0; r < R; ++r) {
+    const int b = t + NT * r;
+    const int g = b >> 6;
+    int pcx = __shfl_up(cxr[r], 1, 64), pcy = __shfl_up(cyr[r], 1, 64);
+    const int2 pc = s_grp_cell[(g > 0 && g < G) ? g - 1 : 0];  // (one address per wave)
+    if (lane == 0 && g > 0) {
       pcx = pc.x;
       pcy = pc.y;
     }
-    const bool start = act && (b < n) && (b == 0 || pcx != ccx[k] || pcy != ccy[k]);
-    mask[k] = __ballot(start);
-    if (act && lane == 0 && g < G) s_grp_start[g] = mask[k] ? (64 * g + 63 - __clzll(mask[k])) : -1;
-    const unsigned long long later = g == 0 ? mask[k] & ~1ull : mask[k];  // see k_score_gmapping
+    const bool start = (b < n) && (b == 0 || pcx != cxr[r] || pcy != cyr[r]);
+    mask[r] = __ballot(start);
+    if (lane == 0 && g < G) s_grp_start[g] = mask[r] ? (64 * g + 63 - __clzll(mask[r])) : -1;
+    const unsigned long long later = g == 0 ? mask[r] & ~1ull : mask[r];  // see k_score_gmapping
     if (lane == 0 && later) atomicMin(&s_run0_len, 64 * g + __ffsll((long long)later) - 1);
   }
   __syncthreads();
+  // ---- every beam's term: the value of its run's first beam x weight x factor
   double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < KB; ++k) {
-    const int b = t + kGmBlock * k;
-    if (act && b < n) {
-      const int g = 4 * k + wave;
-      const unsigned long long upto = mask[k] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  for (int r = 0; r < R; ++r) {
+    const int b = t + NT * r;
+    if (b < n) {
+      const int g = b >> 6;
+      const unsigned long long upto = mask[r] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
       int head;
       if (upto) {
         head = 64 * g + 63 - __clzll(upto);
@@ -376,20 +501,32 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
         while (head < 0) head = s_grp_start[--gg];  // beam 0 is always a start
       }
       const double v = s_val[head];
-      const double term = v * scan.weight[b] * scan.factor[b];
-      acc = acc + term;
+      const double term = v * bw[r] * bf[r];
+      if (NT == kGmBlock) acc = acc + term;  // (this thread's beams ARE its canonical ones, in order)
+      else s_term[b] = term;
       if (b == n - 1 && gi_out) {
         GmPoseInfo &gi = *gi_out;
-        gi.last_cx = ccx[k];
-        gi.last_cy = ccy[k];
+        gi.last_cx = cxr[r];
+        gi.last_cy = cyr[r];
         gi.last_v = v;
         gi.last_head = head;
       }
       if (b == 0 && gi_out) {
         GmPoseInfo &gi = *gi_out;
-        gi.first_cx = ccx[k];
-        gi.first_cy = ccy[k];
+        gi.first_cx = cxr[r];
+        gi.first_cy = cyr[r];
         gi.v0 = v;
+      }
+    }
+  }
+  const bool act = t < kGmBlock;
+  if (NT != kGmBlock) {
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const int b = t + kGmBlock * k;
+        if (b < n) acc = acc + s_term[b];
       }
     }
   }

@@ -76,8 +76,8 @@ __device__ __forceinline__ void gm_gran_store(HcGranule *p, int q, double score,
 
 }  // namespace
 
-// NT threads per pose (256 / 512 / 1024), KB = ceil(beams / 256), G = granules of one kind a sweeping lane looks
-// after (the grid has at most 64 G workgroups: 1 for the filter's many small trees, 4 for a lone chain's 253);
+// NT threads per pose (256 / 512 / 1024), KB = ceil(beams / 256), G = sweeping waves, a slot per lane (the grid has
+// at most 64 G workgroups: 1 for the filter's many small trees, 4 for a lone chain's 253);
 // gran4: [2][kHcSlots + 7][4] granules per chain
 // (256-thread workgroups -- the filter's hundred small trees -- get three waves per SIMD, 168 VGPRs: K3's one-pose body
 // spills 27 registers at four, and 3 x 256 workgroups per CU still hold the 700 of a 100-particle step)
@@ -233,47 +233,36 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       // super-step, so nobody is ever more than one super-step behind: hc_resident.hip)
       gm_gran_store(mine4 + tt, tt, 0.0, GmPoseInfo{}, tag);
     }
-    // ---- waves 0..3: one granule kind each, all slots of the tree, into LDS
-    if (wave < 4) {
+    // ---- waves 0..G-1: the four granules of one slot per lane -- one 64-byte line --, all slots of the tree, into LDS.
+    // (r04 had one granule KIND per wave: every line of the exchange block was asked for by four waves of every
+    // workgroup in every poll, and "publish -> all here" of a lone chain was 3.8 us against the 1-cell form's 1.4.)
+    if (wave < G) {
       const int n_grid = (int)gridDim.x - 1;  // (+ the bookkeeping workgroup)
-      const HcGranule *g0 = gran + (size_t)pk * kRow * 4 + wave;
+      const int i = lane + 64 * wave;
+      const int j = i < n_grid ? i : kHcSlots - 1;
+      const HcGranule *const g0 = gran + ((size_t)pk * kRow + j) * 4;
       unsigned spins = 0;
       bool failed = false;
       for (;;) {
-        u32x4 g[G];
-        const HcGranule *gp[G];
+        u32x4 g[4];
+        const HcGranule *gp[4] = {g0, g0 + 1, g0 + 2, g0 + 3};
+        gran_fetch(g, gp);
         bool ok = true;
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-          const int i = lane + 64 * q;
-          gp[q] = g0 + 4 * (size_t)(i < n_grid ? i : kHcSlots - 1);
-        }
-        gran_fetch(g, gp);
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-          const int i = lane + 64 * q;
-          const int j = i < n_grid ? i : kHcSlots - 1;
-          const bool here = gran_tag(g[q]) == (tag & 0xffffu);
-          ok = ok && here;
-          if (here) {
-            const double d = gran_score(g[q]);
-            GmPoseInfo &gi = s_info[j];
-            if (wave == 0) {
-              s_sc[j] = d;
-              gi.run0_len = (int)g[q].z;
-            } else if (wave == 1) {
-              gi.v0 = d;
-              gi.last_head = (int)g[q].z;
-            } else if (wave == 2) {
-              gi.last_v = d;
-              gi.first_cx = (int)g[q].z;
-            } else {
-              const unsigned long long w = (unsigned long long)__double_as_longlong(d);
-              gi.first_cy = (int)(unsigned)w;
-              gi.last_cx = (int)(unsigned)(w >> 32);
-              gi.last_cy = (int)g[q].z;
-            }
-          }
+        for (int q = 0; q < 4; ++q) ok = ok && gran_tag(g[q]) == (tag & 0xffffu);
+        if (ok) {
+          GmPoseInfo gi;
+          s_sc[j] = gran_score(g[0]);
+          gi.run0_len = (int)g[0].z;
+          gi.v0 = gran_score(g[1]);
+          gi.last_head = (int)g[1].z;
+          gi.last_v = gran_score(g[2]);
+          gi.first_cx = (int)g[2].z;
+          const unsigned long long w = (unsigned long long)__double_as_longlong(gran_score(g[3]));
+          gi.first_cy = (int)(unsigned)w;
+          gi.last_cx = (int)(unsigned)(w >> 32);
+          gi.last_cy = (int)g[3].z;
+          s_info[j] = gi;
         }
         if (__all(ok)) break;
         ++spins;
