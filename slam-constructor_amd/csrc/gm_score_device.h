@@ -184,9 +184,83 @@ __device__ __forceinline__ double gm_fresh_value_w1_nbr(const MapView &m, const 
   return gm_value_of(best_d2, any);
 }
 
+// ... and through the tiles of a pool (tile_pool.h): a tile's masks know the cells of their own tile only -- a tile is
+// shared by maps whose neighbouring tiles differ.  A centre cell on its tile's rim (3 % of them) asks the cells across
+// the rim for THEIR masks: the one next to it in x gives the three cells of that column, the one in y the three of
+// that row, the one across the corner itself -- at most three more 4-byte loads, predicated, next to the centre's own.
+__device__ __forceinline__ unsigned gm_tile_mask(const double *pay, int tile, int lx, int ly) {
+  return reinterpret_cast<const unsigned *>(pay + 4 * (((size_t)tile << (2 * kTileShift)) + ((size_t)ly << kTileShift) + lx) + 3)[0];
+}
+__device__ __forceinline__ double gm_fresh_value_w1_nbr_tiled(const MapView &m, const double *unk, const int *tiles,
+                                                              const GmParams &gp, int cx, int cy, double ox, double oy) {
+  const int ix0 = cx + m.origin_x, iy0 = cy + m.origin_y;
+  const bool inner = ix0 >= 1 && iy0 >= 1 && ix0 + 1 < m.width && iy0 + 1 < m.height;  // (m.width / height: the extent)
+  if (!inner) {
+    GmWindow1 w;
+    w.issue_occ(m, unk, tiles, cx, cy);
+    w.issue_obst(m, unk, gp);
+    return w.finish(gp, ox, oy);
+  }
+  const int txl = (ix0 - 1) >> kTileShift, txh = (ix0 + 1) >> kTileShift, txc = ix0 >> kTileShift;
+  const int tyl = (iy0 - 1) >> kTileShift, tyh = (iy0 + 1) >> kTileShift, tyc = iy0 >> kTileShift;
+  const int t00 = tiles[tyl * m.pitch + txl], t01 = tiles[tyl * m.pitch + txh];
+  const int t10 = tiles[tyh * m.pitch + txl], t11 = tiles[tyh * m.pitch + txh];
+  const int lx = ix0 & kTileMask, ly = iy0 & kTileMask;
+  const bool cx_lo = txc == txl, cy_lo = tyc == tyl;  // which of the corner tiles holds the centre
+  const int tc = cy_lo ? (cx_lo ? t00 : t01) : (cx_lo ? t10 : t11);
+  const double *pay = m.payload;
+  unsigned m9 = gm_tile_mask(pay, tc, lx, ly);
+  const bool rim_x = txl != txh, rim_y = tyl != tyh;  // (the window reaches into another tile column / row)
+  // the other tile column / row: the one the centre is NOT in
+  unsigned mx = 0u, my = 0u, md = 0u;
+  const int tx_other = cy_lo ? (cx_lo ? t01 : t00) : (cx_lo ? t11 : t10);
+  const int ty_other = cy_lo ? (cx_lo ? t10 : t11) : (cx_lo ? t00 : t01);
+  const int td_other = cy_lo ? (cx_lo ? t11 : t10) : (cx_lo ? t01 : t00);
+  const int ox_lx = cx_lo ? 0 : kTileMask, oy_ly = cy_lo ? 0 : kTileMask;  // the cell across: first or last column / row
+  if (rim_x) mx = gm_tile_mask(pay, tx_other, ox_lx, ly);
+  if (rim_y) my = gm_tile_mask(pay, ty_other, lx, oy_ly);
+  if (rim_x && rim_y) md = gm_tile_mask(pay, td_other, ox_lx, oy_ly);
+  // that cell's own column (bits 3..5: dy = -1, 0, +1) is this window's column dx = +1 (centre in the low tile) or -1
+  if (rim_x) m9 |= ((mx >> 3) & 7u) << (cx_lo ? 6 : 0);
+  // ... its own row (bits 1, 4, 7: dx = -1, 0, +1) this window's row dy = +1 or -1 (bits 2, 5, 8 / 0, 3, 6)
+  if (rim_y) {
+    const unsigned r3 = ((my >> 1) & 1u) | (((my >> 4) & 1u) << 3) | (((my >> 7) & 1u) << 6);
+    m9 |= r3 << (cy_lo ? 2 : 0);
+  }
+  if (rim_x && rim_y) m9 |= ((md >> 4) & 1u) << ((cx_lo ? 6 : 0) + (cy_lo ? 2 : 0));
+  double obx9[9], oby9[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    obx9[i] = 0.0;
+    oby9[i] = 0.0;
+    if ((m9 & (1u << i)) != 0u) {
+      const int ix = ix0 + i / 3 - 1, iy = iy0 + i % 3 - 1;  // dx outer, dy inner like the reference
+      const bool lo_x = (ix >> kTileShift) == txl, lo_y = (iy >> kTileShift) == tyl;
+      const int tile = lo_y ? (lo_x ? t00 : t01) : (lo_x ? t10 : t11);
+      const double *c = pay + 4 * (((size_t)tile << (2 * kTileShift)) + ((size_t)(iy & kTileMask) << kTileShift) + (ix & kTileMask));
+      obx9[i] = c[1];
+      oby9[i] = c[2];
+    }
+  }
+  double best_d2 = __builtin_inf();
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const double ddx = obx9[i] - ox, ddy = oby9[i] - oy;
+    const double d2 = ddx * ddx + ddy * ddy;
+    const bool better = (m9 & (1u << i)) != 0u && d2 < best_d2;  // (a NaN distance never wins)
+    best_d2 = better ? d2 : best_d2;
+    any |= better;
+  }
+  return gm_value_of(best_d2, any);
+}
+
 __device__ __forceinline__ double gm_fresh_value_w1(const MapView &m, const double *unk, const int *tiles,
                                                     const GmParams &gp, int cx, int cy, double ox, double oy) {
-  if (m.nbr_ok && !tiles) return gm_fresh_value_w1_nbr(m, unk, gp, cx, cy, ox, oy);
+  if (m.nbr_ok) {
+    return tiles ? gm_fresh_value_w1_nbr_tiled(m, unk, tiles, gp, cx, cy, ox, oy)
+                 : gm_fresh_value_w1_nbr(m, unk, gp, cx, cy, ox, oy);
+  }
   GmWindow1 w;
   w.issue_occ(m, unk, tiles, cx, cy);
   w.issue_obst(m, unk, gp);
@@ -373,7 +447,8 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
   // window and in the same round trips; the beam's value is made from their nine distances behind the barrier (the
   // same selection: the smallest distance to a full cell).
   const int surplus = n - NT;
-  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT;
+  // (through a pool's tiles with masks the surplus beams take a second round of the first wave instead)
+  const bool helpers = NT >= 512 && gm.window == 1 && surplus > 0 && 9 * surplus <= NT && !(map.nbr_ok && tiles);
   if (helpers) {
     const double c = cs * ca0 - sn * sa0;
     const double s = sn * ca0 + cs * sa0;

@@ -200,7 +200,11 @@ void raw_trig(slamhip_gmapping *g, int n_raw, const double *angle) {
 // the scoring view of the filter's per-particle maps as they are now
 void bind_tiled_target(slamhip_gmapping *g) {
   TiledTarget &t = g->tt;
-  const TilePool *tp = g->tp;
+  TilePool *tp = g->tp;
+  // (the tiles' neighbourhood masks: derived once, kept by the writers; a failure here leaves the nine-cell scorer)
+  if (g->cfg.gm_window == 1 && tile_pool_nbr_masks(tp, g->cfg.gm_fullness_th) != SLAMHIP_OK) tp->nbr_ok = false;
+  t.nbr_ok = (tp->nbr_ok && g->cfg.gm_window == 1 && tp->nbr_th == g->cfg.gm_fullness_th) ? 1 : 0;
+  t.nbr_th = tp->nbr_th;
   t.pool = tp->d_pool;
   t.tables = tp->d_table();
   t.table_stride = tp->table_stride();
@@ -1439,6 +1443,16 @@ int slamhip_gmapping_debug_fail(slamhip_gmapping *g, int where, int nth_call) {
   g->debug_fail_where = where;
   g->debug_fail_countdown = nth_call;
   return SLAMHIP_OK;
+}
+// testing aid: the in-tile neighbourhood masks of the filter's per-particle maps (tile_pool.h) -- *valid: whether the
+// pool holds masks; *mismatches: cells whose stored mask differs from the one the cells of their tile give
+int slamhip_gmapping_debug_nbr_masks(slamhip_gmapping *g, int *valid, long long *mismatches) {
+  if (!g || !g->tp) return bad("no per-particle maps");
+  if (valid) *valid = g->tp->nbr_ok ? 1 : 0;
+  long long n = 0;
+  const int rc = tile_pool_nbr_check(g->tp, &n);
+  if (mismatches) *mismatches = n;
+  return rc;
 }
 #endif  // SLAMHIP_TESTING
 

@@ -1054,6 +1054,8 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   bind_extent();
   a.payload = tp->d_pool;
   a.aux = tp->d_aux;
+  a.nbr_on = tp->nbr_ok ? 1 : 0;  // (in-tile masks: mu_cell_store)
+  a.nbr_th = tp->nbr_th;
   a.cell_dbl = 4;
   a.aux_stride = 2;
   a.scale = scale;

@@ -1148,12 +1148,23 @@ __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const 
         reinterpret_cast<double2 *>(a.payload)[2 * at] = make_double2(c.c0, c.c1);
         a.payload[4 * at + 2] = c.c2;
         if ((c.c0 < a.nbr_th) != (was.c0 < a.nbr_th)) {
-          const int iy = (int)(at / (size_t)a.pitch), ix = (int)(at - (size_t)iy * a.pitch);
+          if (a.tables) {  // a tile of a pool: the masks know the cells of their own tile only (tile_pool.h)
+            const int lx = (int)(at & kTileMask), ly = (int)((at >> kTileShift) & kTileMask);
+            const size_t base = at & ~(size_t)(kTileCells - 1);
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            const int x = ix + i / 3 - 1, y = iy + i % 3 - 1;
-            if ((unsigned)x < (unsigned)a.width && (unsigned)y < (unsigned)a.height)
-              atomicXor(reinterpret_cast<unsigned *>(a.payload + 4 * ((size_t)y * a.pitch + x) + 3), 1u << (8 - i));
+            for (int i = 0; i < 9; ++i) {
+              const int x = lx + i / 3 - 1, y = ly + i % 3 - 1;
+              if ((unsigned)x < (unsigned)kTileSide && (unsigned)y < (unsigned)kTileSide)
+                atomicXor(reinterpret_cast<unsigned *>(a.payload + 4 * (base + ((size_t)y << kTileShift) + x) + 3), 1u << (8 - i));
+            }
+          } else {
+            const int iy = (int)(at / (size_t)a.pitch), ix = (int)(at - (size_t)iy * a.pitch);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+              const int x = ix + i / 3 - 1, y = iy + i % 3 - 1;
+              if ((unsigned)x < (unsigned)a.width && (unsigned)y < (unsigned)a.height)
+                atomicXor(reinterpret_cast<unsigned *>(a.payload + 4 * ((size_t)y * a.pitch + x) + 3), 1u << (8 - i));
+            }
           }
         }
       } else {

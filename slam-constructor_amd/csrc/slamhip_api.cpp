@@ -149,6 +149,9 @@ static int fill_args(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cfg,
     const int rc = map_nbr_masks(ctx, m, cfg->gm_fullness_th);
     if (rc) return rc;
     a->map.nbr_ok = 1;
+  } else if (cfg->oope == SLAMHIP_OOPE_GMAPPING && m.cell_model == SLAMHIP_CELL_GMAPPING && m.bytes == 0 && cfg->gm_window == 1 &&
+             m.nbr_ok && m.nbr_th == cfg->gm_fullness_th) {
+    a->map.nbr_ok = 1;  // a tile pool whose owner derived the masks (tile_pool_nbr_masks)
   }
   const size_t c = ctx->scan_stride;
   a->scan.range = ctx->scan_ptr;
@@ -231,6 +234,8 @@ static void tiled_device_map(const TiledTarget *tiled, DeviceMap *v) {
   v->scale = tiled->scale;
   for (int k = 0; k < 4; ++k) v->unknown[k] = tiled->unknown[k];
   v->d_payload = const_cast<double *>(tiled->pool);
+  v->nbr_ok = tiled->nbr_ok != 0;
+  v->nbr_th = tiled->nbr_th;
 }
 
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,

@@ -259,6 +259,8 @@ struct TiledTarget {
   int table_stride, tiles_x, width, height, origin_x, origin_y;
   double scale;
   double unknown[4];
+  int nbr_ok;  // the tiles' in-tile neighbourhood masks are valid for threshold nbr_th (tile_pool.h)
+  double nbr_th;
 };
 int ensure_pose_capacity(slamhip_ctx *ctx, int n);
 // scores n poses whose (x,y,theta) sit in ctx->h_poses; results land in ctx->h_scores (synchronous)

@@ -43,6 +43,11 @@ struct TilePool {
   // can name them by ordinal instead of carrying their 768 KiB -- every rank builds the same ancestor
   std::vector<int> ancestor;       // ordinal -> tile id
   std::vector<int> ancestor_of;    // tile id -> ordinal or -1
+  // neighbourhood masks in the cells' pads (slamhip_internal.h MapView), IN-TILE neighbours only: a tile is shared by
+  // maps whose neighbouring tiles differ, so a cell on a tile's rim cannot know the cells across it -- the scorer asks
+  // the cell across the rim for its own mask instead (gm_score_device.h).  Valid for threshold nbr_th.
+  bool nbr_ok = false;
+  double nbr_th = 0.0;
 
   int table_stride() const { return tiles_x * tiles_y; }
   int width() const { return tiles_x * kTileSide; }
@@ -88,6 +93,11 @@ int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, con
 // external window [x0, x0+w) x [y0, y0+h) of a slot: payload (3 doubles per cell: prob, obst.x, obst.y)
 // and counters (2 per cell: hits, tries); either may be null
 int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, double *payload3, double *aux2);
+// derives the masks of every tile in use for threshold th, unless they are there (waited for).  Leaves nbr_ok false
+// where the masks cannot be kept by the writers: th <= 0 or an unknown cell that counts as full.
+int tile_pool_nbr_masks(TilePool *tp, double th);
+// (testing) cells whose stored mask differs from the one their in-tile neighbours give
+int tile_pool_nbr_check(TilePool *tp, long long *mismatches);
 void tile_pool_stats(const TilePool *tp, long long *tiles_in_use, long long *tiles_shared, long long *bytes,
                      long long *cow_copies);
 

@@ -70,6 +70,32 @@ __global__ __launch_bounds__(256) void k_tiles_from_dense(double *pool, double *
   reinterpret_cast<double2 *>(aux)[at] = c;
 }
 
+// in-tile neighbourhood masks of tiles first .. first + n - 1 (tile_pool.h): 64 workgroups per tile
+__device__ __forceinline__ unsigned tile_nbr_mask_of(const double *tile, double th, int lx, int ly) {
+  unsigned m9 = 0u;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int x = lx + i / 3 - 1, y = ly + i % 3 - 1;
+    if ((unsigned)x < (unsigned)kTileSide && (unsigned)y < (unsigned)kTileSide && !(tile[4 * ((size_t)y * kTileSide + x)] < th))
+      m9 |= 1u << i;
+  }
+  return m9;
+}
+__global__ __launch_bounds__(256) void k_tile_nbr_build(double *pool, int first, double th) {
+  const int tile = first + blockIdx.x / kChunksPerTile, chunk = blockIdx.x % kChunksPerTile;
+  const int in_tile = chunk * 256 + threadIdx.x;
+  double *base = pool + (size_t)tile * kTileCells * 4;
+  reinterpret_cast<unsigned *>(base + 4 * (size_t)in_tile + 3)[0] =
+      tile_nbr_mask_of(base, th, in_tile & kTileMask, in_tile >> kTileShift);
+}
+__global__ __launch_bounds__(256) void k_tile_nbr_check(const double *pool, int first, double th, unsigned long long *count) {
+  const int tile = first + blockIdx.x / kChunksPerTile, chunk = blockIdx.x % kChunksPerTile;
+  const int in_tile = chunk * 256 + threadIdx.x;
+  const double *base = pool + (size_t)tile * kTileCells * 4;
+  const unsigned have = reinterpret_cast<const unsigned *>(base + 4 * (size_t)in_tile + 3)[0];
+  if (have != tile_nbr_mask_of(base, th, in_tile & kTileMask, in_tile >> kTileShift)) atomicAdd(count, 1ull);
+}
+
 __global__ void k_tiles_to_dense(const double *pool, const double *aux, const int *table, int tiles_x, int tiles_y,
                                  int vx0, int vy0, int w, int h, double *payload3, double *aux2, double u0,
                                  double u1, double u2) {
@@ -196,7 +222,40 @@ void tile_pool_destroy(TilePool *tp) {
   delete tp;
 }
 
+int tile_pool_nbr_masks(TilePool *tp, double th) {
+  if (tp->nbr_ok && tp->nbr_th == th) return SLAMHIP_OK;
+  tp->nbr_ok = false;
+  // the writers keep the masks by flipping bits when a cell changes sides; two writers do not look: a fresh tile is
+  // filled with the unknown cell (mask 0: nothing full) and a never-observed cell's first free observation takes its
+  // mean from the unknown one's to +0 (k_mu_classify) -- neither may be full
+  if (!(th > 0.0) || !(tp->unknown[0] < th)) return SLAMHIP_OK;
+  if (tp->next_unused > 0) {
+    hipLaunchKernelGGL(k_tile_nbr_build, dim3(tp->next_unused * kChunksPerTile), dim3(256), 0, tp->ctx->stream, tp->d_pool, 0, th);
+    SLAMHIP_CHECK(hipGetLastError());
+    SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  }
+  tp->nbr_th = th;
+  tp->nbr_ok = true;
+  return SLAMHIP_OK;
+}
+
+int tile_pool_nbr_check(TilePool *tp, long long *mismatches) {
+  *mismatches = 0;
+  if (!tp->nbr_ok || tp->next_unused <= 0) return SLAMHIP_OK;
+  unsigned long long *d_count = nullptr, h_count = 0;
+  SLAMHIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
+  SLAMHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), tp->ctx->stream));
+  hipLaunchKernelGGL(k_tile_nbr_check, dim3(tp->next_unused * kChunksPerTile), dim3(256), 0, tp->ctx->stream, tp->d_pool, 0,
+                     tp->nbr_th, d_count);
+  SLAMHIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(h_count), hipMemcpyDeviceToHost, tp->ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  hipFree(d_count);
+  *mismatches = (long long)h_count;
+  return SLAMHIP_OK;
+}
+
 int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m) {
+  tp->nbr_ok = false;  // (the dense window's pads hold ITS masks or none: the next scorer call derives the tiles')
   if (m.cell_model != SLAMHIP_CELL_GMAPPING) return tp_fail("particle maps need a SLAMHIP_CELL_GMAPPING window");
   if (m.aux_stride != 0 && m.aux_stride != 2) return tp_fail("unexpected counter layout");
   // virtual position of the dense window: same external coordinates
@@ -551,6 +610,10 @@ int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, con
       p += kTilePayloadBytes;
       SLAMHIP_CHECK(hipMemcpyAsync(tp->d_aux + (size_t)fresh * kTileCells * 2, p, kTileAuxBytes, hipMemcpyDefault, st));
       p += kTileAuxBytes;
+      if (tp->nbr_ok) {  // (whatever state the sender's masks were in)
+        hipLaunchKernelGGL(k_tile_nbr_build, dim3(kChunksPerTile), dim3(256), 0, st, tp->d_pool, fresh, tp->nbr_th);
+        SLAMHIP_CHECK(hipGetLastError());
+      }
       imported[r][ti] = fresh;
     }
   }

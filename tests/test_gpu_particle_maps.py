@@ -26,7 +26,7 @@ def pkg():
     return ge.load_package()
 
 
-def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None, options=()):
+def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None, options=(), check_masks=False):
     import pyoracle as po
     from pyoracle_mapupdate import (RULE_GMAPPING, append_scan_ex, gmapping_enable_particle_maps,
                                     gmapping_particle_map)
@@ -39,7 +39,7 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None,
     ox, oy = [int(v) for v in g["origin"]]
     r0, a0, pose0 = g["step0_range"], g["step0_angle"], g["step0_delta"]
     # HIP side: dense ancestor (K6, pinned to the reference elsewhere) -> tile pool
-    ctx = pkg.Context(0)
+    ctx = pkg.Context(0, testing=check_masks)  # (check_masks: tests/test_gpu_nbr_masks.py, a hook of the testing library)
     for opt, val in options:
         ctx.set_option(opt, val)
     ctx.map_bind(4, 2, w, h, g["origin"], scale, unknown)
@@ -82,6 +82,11 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None,
             np.testing.assert_array_equal(got_p[..., 0], want_p[..., 0], err_msg="step %d particle %d" % (it, i))
             np.testing.assert_allclose(got_p[..., 1:], want_p[..., 1:], rtol=1e-12, atol=1e-14)
             np.testing.assert_array_equal(got_a, want_a)
+        if check_masks:
+            import ctypes as C
+            valid, bad = C.c_int(-1), C.c_longlong(-1)
+            assert ctx.L.slamhip_gmapping_debug_nbr_masks(pf.h, C.byref(valid), C.byref(bad)) == 0
+            assert (valid.value, bad.value) == (1, 0), "step %d" % it
         log.append((res, pf.particle_map_stats()))
     return pf, log, (ox, oy, w, h)
 
