@@ -1454,6 +1454,11 @@ int slamhip_gmapping_debug_nbr_masks(slamhip_gmapping *g, int *valid, long long 
   if (mismatches) *mismatches = n;
   return rc;
 }
+// ... and of the pool's settle states (tile_pool.h TilePool::d_state): words that differ from what the payloads give
+int slamhip_gmapping_debug_settle_states(slamhip_gmapping *g, long long *mismatches) {
+  if (!g || !g->tp || !mismatches) return bad("no per-particle maps");
+  return tile_pool_state_check(g->tp, mismatches);
+}
 #endif  // SLAMHIP_TESTING
 
 int slamhip_gmapping_migration_stats(slamhip_gmapping *g, long long *maps_received, long long *tile_bytes_sent) {

@@ -74,6 +74,7 @@ struct MuArgs {
   double nbr_th;
   double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
   int fresh_ok;
+  unsigned *state;  // batch: the pool's settle states (tile_pool.h), two bits per cell; null = none (dense window)
   // ... with LAZY keys: a beam whose closed form holds writes no keys at all (k_mu_classify evaluates the form again,
   // step by step, instead of reading 4 bytes per record back); walk_flag[b] = 1 names the beams whose keys the
   // sequential walk wrote
@@ -1043,9 +1044,16 @@ __global__ __launch_bounds__(64 * kClassifyBeams, 8) void k_mu_classify(MuArgs a
       slow = true;
     } else {
       at = mu_cell_index<unsigned>(a, key);
-      const double c0 = a.payload[4 * at];
-      bits = __double_as_longlong(c0);
-      if (!(c0 == 0.0 || (a.fresh_ok && bits == unknown_bits))) {
+      // what the cell holds: its settle state (two bits of a plane that stays in the L2) where the pool keeps one,
+      // else its payload -- 32 bytes of HBM per record, a third of this kernel's traffic in cfg5
+      unsigned cls;
+      if (a.state) {
+        cls = (a.state[at >> 4] >> (2u * (unsigned)(at & 15))) & 3u;
+      } else {
+        cls = mu_settle_class(a.payload[4 * at], unknown_bits, a.fresh_ok);
+      }
+      bits = cls == 3u ? 1ll : 0ll;  // (non-zero: the cell still holds the never-observed value)
+      if (cls == 0u) {
         slow = true;
       } else {
         // const estimator: (base_empty.prob, base_empty.qual), checked by the host.  Area estimator: the record is
@@ -1080,7 +1088,10 @@ __global__ __launch_bounds__(64 * kClassifyBeams, 8) void k_mu_classify(MuArgs a
     }
     if (settle) {
       unsafeAtomicAdd(&a.aux[2 * at + 1], add);
-      if (bits != 0ll) a.payload[4 * at] = 0.0;
+      if (bits != 0ll) {
+        a.payload[4 * at] = 0.0;
+        if (a.state) atomicAnd(&a.state[at >> 4], ~(2u << (2u * (unsigned)(at & 15))));  // 3 -> 1
+      }
     }
     // (every key of this round was read before the first store below, and a store lands at or before its own key)
     const unsigned long long mask = __ballot(slow);
@@ -1135,6 +1146,13 @@ __device__ __forceinline__ MuCell mu_cell_load(const MuArgs &a, size_t at) {
 // 32-byte sector that write is a third of the kernel's HBM bytes.
 template <int RULE>
 __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const MuCell &c, const MuCell &was) {
+  if (RULE == 4 && a.state) {
+    // the pool's settle states follow the mean (bits are only ever cleared: tile_pool.h)
+    const long long ub = __double_as_longlong(a.unknown_c0);
+    const unsigned now = mu_settle_class(c.c0, ub, a.fresh_ok), before = mu_settle_class(was.c0, ub, a.fresh_ok);
+    const unsigned gone = before & ~now;
+    if (gone) atomicAnd(&a.state[at >> 4], ~(gone << (2u * (unsigned)(at & 15))));
+  }
   if (RULE == 4) {
     const bool same = __double_as_longlong(c.c0) == __double_as_longlong(was.c0) &&
                       __double_as_longlong(c.c1) == __double_as_longlong(was.c1) &&

@@ -93,6 +93,14 @@ constexpr int kTileShift = 7;
 constexpr int kTileSide = 1 << kTileShift;
 constexpr int kTileMask = kTileSide - 1;
 constexpr int kTileCells = kTileSide * kTileSide;
+// the settle state of a pool cell (tile_pool.h TilePool::d_state): 1 = its mean is +0; 3 = a free observation leaves +0
+// but has to WRITE it -- the never-observed value (a negative unknown[0], bit for bit), or -0; 0 = anything else
+constexpr int kTileStateWords = kTileCells / 16;
+__host__ __device__ inline unsigned mu_settle_class(double c0, long long unknown_bits, int fresh_ok) {
+  long long bits;
+  __builtin_memcpy(&bits, &c0, 8);
+  return bits == 0ll ? 1u : ((c0 == 0.0 || (fresh_ok && bits == unknown_bits)) ? 3u : 0u);
+}
 
 inline int cell_doubles(int model) { return model == SLAMHIP_CELL_OCC ? 1 : 4; }
 inline int cell_stride_host(int model) {

@@ -26,6 +26,12 @@ struct TilePool {
   int capacity = 0;                // tiles
   double *d_pool = nullptr;        // [capacity][kTileCells][4]
   double *d_aux = nullptr;         // [capacity][kTileCells][2]
+  // two bits per cell, sixteen cells per word: what the batched map update's free-space fast path (k_mu_classify)
+  // has to know of a cell before it settles an observation with one atomic -- 1: the mean is +0, 3: the cell holds
+  // the never-observed value (unknown[0] < 0; or -0), 0: anything else (the sorted chains).  4 KB per tile that stay in the
+  // L2, read INSTEAD of the cell's payload (32 bytes of HBM per record: a third of that kernel's traffic).  Bits are only
+  // ever cleared (3 -> 1 by the first settled observation, -> 0 by a cell store that leaves another mean): no races.
+  unsigned *d_state = nullptr;     // [capacity][kTileCells / 16]
   int *d_tables[2] = {nullptr, nullptr};  // [n_slots][tiles_x * tiles_y]; double-buffered for resampling
   int cur = 0;
   std::vector<int> h_tables;       // host mirror of d_tables[cur]
@@ -98,6 +104,8 @@ int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, dou
 int tile_pool_nbr_masks(TilePool *tp, double th);
 // (testing) cells whose stored mask differs from the one their in-tile neighbours give
 int tile_pool_nbr_check(TilePool *tp, long long *mismatches);
+// (testing) words of the settle-state plane that differ from what the cells' payloads give (tiles in use)
+int tile_pool_state_check(TilePool *tp, long long *mismatches);
 void tile_pool_stats(const TilePool *tp, long long *tiles_in_use, long long *tiles_shared, long long *bytes,
                      long long *cow_copies);
 

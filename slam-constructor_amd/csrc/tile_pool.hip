@@ -13,9 +13,12 @@ namespace {
 constexpr int kChunksPerTile = 64;  // workgroups per tile copy: 256 cells each
 
 // one (src, dst) pair per 64 workgroups: payload 512 KB + counters 256 KB, 16-byte accesses
-__global__ __launch_bounds__(256) void k_tile_copy(double *pool, double *aux, const int *pairs, int n_pairs) {
+__global__ __launch_bounds__(256) void k_tile_copy(double *pool, double *aux, unsigned *state, const int *pairs, int n_pairs) {
   const int pair = blockIdx.x / kChunksPerTile, chunk = blockIdx.x % kChunksPerTile;
   if (pair >= n_pairs) return;
+  if (chunk < kTileStateWords / 256)
+    state[(size_t)pairs[2 * pair + 1] * kTileStateWords + chunk * 256 + threadIdx.x] =
+        state[(size_t)pairs[2 * pair] * kTileStateWords + chunk * 256 + threadIdx.x];
   const size_t src = (size_t)pairs[2 * pair] * kTileCells, dst = (size_t)pairs[2 * pair + 1] * kTileCells;
   const size_t cell = (size_t)chunk * 256 + threadIdx.x;
   const double4 *ps = reinterpret_cast<const double4 *>(pool) + src;
@@ -68,6 +71,28 @@ __global__ __launch_bounds__(256) void k_tiles_from_dense(double *pool, double *
   const size_t at = (size_t)tile_ids[t] * kTileCells + in_tile;
   reinterpret_cast<double4 *>(pool)[at] = v;
   reinterpret_cast<double2 *>(aux)[at] = c;
+}
+
+// the settle states (tile_pool.h) of tiles first .. first + n - 1 from their payloads: a thread per word, 4 workgroups per tile
+__global__ __launch_bounds__(256) void k_tile_state_build(const double *pool, unsigned *state, int first, long long unknown_bits,
+                                                          int fresh_ok) {
+  const int tile = first + blockIdx.x / (kTileStateWords / 256);
+  const int word = (blockIdx.x % (kTileStateWords / 256)) * 256 + threadIdx.x;
+  const double *base = pool + ((size_t)tile * kTileCells + (size_t)word * 16) * 4;
+  unsigned w = 0u;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w |= mu_settle_class(base[4 * c], unknown_bits, fresh_ok) << (2 * c);
+  state[(size_t)tile * kTileStateWords + word] = w;
+}
+__global__ __launch_bounds__(256) void k_tile_state_check(const double *pool, const unsigned *state, int first,
+                                                          long long unknown_bits, int fresh_ok, unsigned long long *count) {
+  const int tile = first + blockIdx.x / (kTileStateWords / 256);
+  const int word = (blockIdx.x % (kTileStateWords / 256)) * 256 + threadIdx.x;
+  const double *base = pool + ((size_t)tile * kTileCells + (size_t)word * 16) * 4;
+  unsigned w = 0u;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w |= mu_settle_class(base[4 * c], unknown_bits, fresh_ok) << (2 * c);
+  if (state[(size_t)tile * kTileStateWords + word] != w) atomicAdd(count, 1ull);
 }
 
 // in-tile neighbourhood masks of tiles first .. first + n - 1 (tile_pool.h): 64 workgroups per tile
@@ -125,6 +150,17 @@ __global__ void k_tiles_to_dense(const double *pool, const double *aux, const in
 int tp_fail(const char *msg, int code = SLAMHIP_ERR_INVALID) {
   set_error(msg);
   return code;
+}
+
+// settle states of tiles first .. first + n - 1 from their payloads, queued on the context's stream
+int tile_state_build(TilePool *tp, int first, int n) {
+  if (n <= 0) return SLAMHIP_OK;
+  long long ub;
+  std::memcpy(&ub, &tp->unknown[0], 8);
+  hipLaunchKernelGGL(k_tile_state_build, dim3(n * (kTileStateWords / 256)), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_state,
+                     first, ub, tp->unknown[0] < 0.0 ? 1 : 0);
+  SLAMHIP_CHECK(hipGetLastError());
+  return SLAMHIP_OK;
 }
 
 int alloc_tile(TilePool *tp, int *out) {
@@ -190,6 +226,7 @@ int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, do
   const size_t tab = (size_t)n_slots * tiles_x * tiles_y;
   hipError_t e = hipMalloc(&tp->d_pool, cells * 4 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&tp->d_aux, cells * 2 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&tp->d_state, (size_t)capacity * kTileStateWords * sizeof(unsigned));
   if (e == hipSuccess) e = hipMalloc(&tp->d_tables[0], tab * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&tp->d_tables[1], tab * sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&tp->h_assign, sizeof(int) * n_slots, hipHostMallocMapped | hipHostMallocCoherent);
@@ -205,6 +242,13 @@ int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, do
   hipLaunchKernelGGL(k_tile_fill_unknown, dim3(kTileCells / 256), dim3(256), 0, ctx->stream, tp->d_pool, tp->d_aux, 0,
                      unknown[0], unknown[1], unknown[2], unknown[3]);
   SLAMHIP_CHECK(hipGetLastError());
+  {
+    const int rcs = tile_state_build(tp, 0, 1);
+    if (rcs) {
+      tile_pool_destroy(tp);
+      return rcs;
+    }
+  }
   *out = tp;
   return SLAMHIP_OK;
 }
@@ -214,6 +258,7 @@ void tile_pool_destroy(TilePool *tp) {
   if (tp->ctx) hipStreamSynchronize(tp->ctx->stream);
   if (tp->d_pool) hipFree(tp->d_pool);
   if (tp->d_aux) hipFree(tp->d_aux);
+  if (tp->d_state) hipFree(tp->d_state);
   if (tp->d_tables[0]) hipFree(tp->d_tables[0]);
   if (tp->d_tables[1]) hipFree(tp->d_tables[1]);
   if (tp->h_pairs) hipHostFree(tp->h_pairs);
@@ -236,6 +281,23 @@ int tile_pool_nbr_masks(TilePool *tp, double th) {
   }
   tp->nbr_th = th;
   tp->nbr_ok = true;
+  return SLAMHIP_OK;
+}
+
+int tile_pool_state_check(TilePool *tp, long long *mismatches) {
+  *mismatches = 0;
+  if (tp->next_unused <= 0) return SLAMHIP_OK;
+  unsigned long long *d_count = nullptr, h_count = 0;
+  long long ub;
+  std::memcpy(&ub, &tp->unknown[0], 8);
+  SLAMHIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
+  SLAMHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), tp->ctx->stream));
+  hipLaunchKernelGGL(k_tile_state_check, dim3(tp->next_unused * (kTileStateWords / 256)), dim3(256), 0, tp->ctx->stream, tp->d_pool,
+                     tp->d_state, 0, ub, tp->unknown[0] < 0.0 ? 1 : 0, d_count);
+  SLAMHIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(h_count), hipMemcpyDeviceToHost, tp->ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(tp->ctx->stream));
+  hipFree(d_count);
+  *mismatches = (long long)h_count;
   return SLAMHIP_OK;
 }
 
@@ -279,6 +341,15 @@ int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m) {
   hipLaunchKernelGGL(k_tiles_from_dense, dim3(nt * kChunksPerTile), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_aux,
                      d_ids, tx0, ty0, ntx, m.d_payload, m.aux_stride == 2 ? m.d_aux : nullptr, m.pitch, m.width,
                      m.height, vx0, vy0, tp->unknown[0], tp->unknown[1], tp->unknown[2], tp->unknown[3]);
+  {  // the settle states of the new tiles (runs of consecutive ids in one launch each)
+    int k0 = 0;
+    for (int k = 1; k <= nt; ++k)
+      if (k == nt || ids[k] != ids[k - 1] + 1) {
+        const int rcs = tile_state_build(tp, ids[k0], k - k0);
+        if (rcs) return rcs;
+        k0 = k;
+      }
+  }
   const int stride = tp->table_stride();
   for (int s = 0; s < tp->n_slots; ++s)
     for (int k = 0; k < nt; ++k)
@@ -380,7 +451,7 @@ int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y
 int tile_pool_flush(TilePool *tp) {
   hipStream_t st = tp->ctx->stream;
   if (tp->n_pairs) {
-    hipLaunchKernelGGL(k_tile_copy, dim3(tp->n_pairs * kChunksPerTile), dim3(256), 0, st, tp->d_pool, tp->d_aux,
+    hipLaunchKernelGGL(k_tile_copy, dim3(tp->n_pairs * kChunksPerTile), dim3(256), 0, st, tp->d_pool, tp->d_aux, tp->d_state,
                        tp->h_pairs, tp->n_pairs);
     tp->cow_copies += tp->n_pairs;
   }
@@ -610,6 +681,10 @@ int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, con
       p += kTilePayloadBytes;
       SLAMHIP_CHECK(hipMemcpyAsync(tp->d_aux + (size_t)fresh * kTileCells * 2, p, kTileAuxBytes, hipMemcpyDefault, st));
       p += kTileAuxBytes;
+      {
+        const int rcs = tile_state_build(tp, fresh, 1);
+        if (rcs) return rcs;
+      }
       if (tp->nbr_ok) {  // (whatever state the sender's masks were in)
         hipLaunchKernelGGL(k_tile_nbr_build, dim3(kChunksPerTile), dim3(256), 0, st, tp->d_pool, fresh, tp->nbr_th);
         SLAMHIP_CHECK(hipGetLastError());

@@ -190,10 +190,11 @@ def test_scores_with_masks_equal_the_oracles(pkg, tctx, oracle, po):
 
 
 @pytest.mark.parametrize("mode", ["fast", "sorted"])
-def test_tile_pool_masks_follow_the_filter(pkg, oracle, mode):
+def test_tile_pool_masks_and_settle_states_follow_the_filter(pkg, oracle, mode):
     """Per-particle copy-on-write maps (tile_pool.h): a tile's masks know the cells of their own tile; the batched map
-    update, copy-on-write clones and resampling keep them.  The filter of test_gpu_particle_maps.py (every step against
-    the oracle: poses, weights, every particle's map) with the masks checked after every step."""
+    update, copy-on-write clones and resampling keep them -- and the pool's settle states (two bits per cell that the
+    update's free-space fast path reads instead of the cell).  The filter of test_gpu_particle_maps.py (every step
+    against the oracle: poses, weights, every particle's map) with masks and states checked after every step."""
     from test_gpu_particle_maps import run_both
     options = {"fast": (), "sorted": ((pkg.OPT_K6_BATCH_FAST, 0),)}[mode]
     pf, log, _ = run_both(pkg, oracle, n=8, n_steps_extra=4, options=options, check_masks=True)

@@ -87,6 +87,8 @@ def run_both(pkg, oracle, n_steps_extra=0, n=8, seed0=2000, gp=None, adder=None,
             valid, bad = C.c_int(-1), C.c_longlong(-1)
             assert ctx.L.slamhip_gmapping_debug_nbr_masks(pf.h, C.byref(valid), C.byref(bad)) == 0
             assert (valid.value, bad.value) == (1, 0), "step %d" % it
+            assert ctx.L.slamhip_gmapping_debug_settle_states(pf.h, C.byref(bad)) == 0
+            assert bad.value == 0, "settle states, step %d" % it
         log.append((res, pf.particle_map_stats()))
     return pf, log, (ox, oy, w, h)
 
