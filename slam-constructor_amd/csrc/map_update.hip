@@ -1057,6 +1057,7 @@ int mu_append_batch(slamhip_ctx *ctx, TilePool *tp, const slamhip_scan_adder_cfg
   a.nbr_on = tp->nbr_ok ? 1 : 0;  // (in-tile masks: mu_cell_store)
   a.nbr_th = tp->nbr_th;
   a.state = tp->d_state;  // (settle states: read by k_mu_classify, kept by mu_cell_store in every batch mode)
+  a.pend = tp->d_pend;    // (pending free observations: added to by k_mu_classify, folded in by mu_cell_load / _store)
   a.unknown_c0 = tp->unknown[0];
   a.fresh_ok = tp->unknown[0] < 0.0 ? 1 : 0;
   a.cell_dbl = 4;

@@ -75,6 +75,7 @@ struct MuArgs {
   double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
   int fresh_ok;
   unsigned *state;  // batch: the pool's settle states (tile_pool.h), two bits per cell; null = none (dense window)
+  unsigned *pend;   // batch: the pool's pending free observations per cell (tile_pool.h); null = none
   // ... with LAZY keys: a beam whose closed form holds writes no keys at all (k_mu_classify evaluates the form again,
   // step by step, instead of reading 4 bytes per record back); walk_flag[b] = 1 names the beams whose keys the
   // sequential walk wrote
@@ -874,6 +875,7 @@ __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs
 // int arithmetic converted to double)
 struct MuCell {
   double c0, c1, c2, c3, x0, x1;
+  unsigned pn;  // pending observations that mu_cell_load folded into x1 (a pool's cells: MuArgs::pend)
 };
 
 // one observation applied to one cell: the reference's `cell += aoo` for the five cell kinds
@@ -1087,7 +1089,8 @@ __global__ __launch_bounds__(64 * kClassifyBeams, 8) void k_mu_classify(MuArgs a
       }
     }
     if (settle) {
-      unsafeAtomicAdd(&a.aux[2 * at + 1], add);
+      if (a.pend) atomicAdd(&a.pend[at], (unsigned)add);
+      else unsafeAtomicAdd(&a.aux[2 * at + 1], add);
       if (bits != 0ll) {
         a.payload[4 * at] = 0.0;
         if (a.state) atomicAnd(&a.state[at >> 4], ~(2u << (2u * (unsigned)(at & 15))));  // 3 -> 1
@@ -1137,6 +1140,10 @@ __device__ __forceinline__ MuCell mu_cell_load(const MuArgs &a, size_t at) {
     const double2 x = reinterpret_cast<const double2 *>(a.aux)[at];
     c.x0 = x.x;
     c.x1 = x.y;
+    if (a.pend) {  // tries = the counter + what the fast path has settled since it was last written
+      c.pn = a.pend[at];
+      c.x1 = c.x1 + (double)c.pn;
+    }
   }
   return c;
 }
@@ -1195,7 +1202,10 @@ __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const 
     a.payload[at] = c.c0;
   }
   if (RULE == 2) a.aux[at] = c.x0;
-  if (RULE == 4) reinterpret_cast<double2 *>(a.aux)[at] = make_double2(c.x0, c.x1);
+  if (RULE == 4) {
+    reinterpret_cast<double2 *>(a.aux)[at] = make_double2(c.x0, c.x1);
+    if (was.pn) a.pend[at] = 0u;  // (folded into x1 by the load; no fast path runs beside a cell store)
+  }
 }
 
 __device__ __forceinline__ double mu_readlane(double v, int lane) {  // lane is wave-uniform

@@ -32,6 +32,11 @@ struct TilePool {
   // L2, read INSTEAD of the cell's payload (32 bytes of HBM per record: a third of that kernel's traffic).  Bits are only
   // ever cleared (3 -> 1 by the first settled observation, -> 0 by a cell store that leaves another mean): no races.
   unsigned *d_state = nullptr;     // [capacity][kTileCells / 16]
+  // free observations settled by that fast path and not yet added to the cells' `tries` counters: one 4-byte word per
+  // cell, so that the fast path's 195 M atomics per cfg5 step land sixteen cells to a 64-byte line instead of four
+  // (the counters' read-modify-write was 1.8 of the kernel's 3.6 ms).  A cell's tries = aux tries + pending: whoever
+  // reads the counters adds it (mu_cell_load -- which also folds it in --, clones, downloads, exports).
+  unsigned *d_pend = nullptr;      // [capacity][kTileCells]
   int *d_tables[2] = {nullptr, nullptr};  // [n_slots][tiles_x * tiles_y]; double-buffered for resampling
   int cur = 0;
   std::vector<int> h_tables;       // host mirror of d_tables[cur]

@@ -13,7 +13,8 @@ namespace {
 constexpr int kChunksPerTile = 64;  // workgroups per tile copy: 256 cells each
 
 // one (src, dst) pair per 64 workgroups: payload 512 KB + counters 256 KB, 16-byte accesses
-__global__ __launch_bounds__(256) void k_tile_copy(double *pool, double *aux, unsigned *state, const int *pairs, int n_pairs) {
+__global__ __launch_bounds__(256) void k_tile_copy(double *pool, double *aux, unsigned *state, unsigned *pend, const int *pairs,
+                                                   int n_pairs) {
   const int pair = blockIdx.x / kChunksPerTile, chunk = blockIdx.x % kChunksPerTile;
   if (pair >= n_pairs) return;
   if (chunk < kTileStateWords / 256)
@@ -26,7 +27,20 @@ __global__ __launch_bounds__(256) void k_tile_copy(double *pool, double *aux, un
   pd[cell] = ps[cell];
   const double2 *as = reinterpret_cast<const double2 *>(aux) + src;
   double2 *ad = reinterpret_cast<double2 *>(aux) + dst;
-  ad[cell] = as[cell];
+  // (the clone starts with its pending observations folded into its counters: the source stays as it is)
+  const double2 c = as[cell];
+  ad[cell] = make_double2(c.x, c.y + (double)pend[src + cell]);
+  pend[dst + cell] = 0u;
+}
+
+// pending observations of one tile into its counters (before the tile's counters are read raw: exports)
+__global__ __launch_bounds__(256) void k_tile_fold(double *aux, unsigned *pend, int tile) {
+  const size_t cell = (size_t)tile * kTileCells + (size_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned p = pend[cell];
+  if (p) {
+    aux[2 * cell + 1] += (double)p;
+    pend[cell] = 0u;
+  }
 }
 
 __global__ void k_table_patch(int *tables, int stride, const int *patches, int n) {
@@ -53,7 +67,7 @@ __global__ void k_tile_fill_unknown(double *pool, double *aux, int tile, double 
 }
 
 // tiles (tx0.., ty0..) x (ntx, nty) of the pool <- dense window placed at virtual (vx0, vy0)
-__global__ __launch_bounds__(256) void k_tiles_from_dense(double *pool, double *aux, const int *tile_ids, int tx0,
+__global__ __launch_bounds__(256) void k_tiles_from_dense(double *pool, double *aux, unsigned *pend, const int *tile_ids, int tx0,
                                                           int ty0, int ntx, const double *dense,
                                                           const double *dense_aux, int pitch, int w, int h, int vx0,
                                                           int vy0, double u0, double u1, double u2, double u3) {
@@ -71,6 +85,7 @@ __global__ __launch_bounds__(256) void k_tiles_from_dense(double *pool, double *
   const size_t at = (size_t)tile_ids[t] * kTileCells + in_tile;
   reinterpret_cast<double4 *>(pool)[at] = v;
   reinterpret_cast<double2 *>(aux)[at] = c;
+  pend[at] = 0u;
 }
 
 // the settle states (tile_pool.h) of tiles first .. first + n - 1 from their payloads: a thread per word, 4 workgroups per tile
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(256) void k_tile_nbr_check(const double *pool, int 
   if (have != tile_nbr_mask_of(base, th, in_tile & kTileMask, in_tile >> kTileShift)) atomicAdd(count, 1ull);
 }
 
-__global__ void k_tiles_to_dense(const double *pool, const double *aux, const int *table, int tiles_x, int tiles_y,
+__global__ void k_tiles_to_dense(const double *pool, const double *aux, const unsigned *pend, const int *table, int tiles_x, int tiles_y,
                                  int vx0, int vy0, int w, int h, double *payload3, double *aux2, double u0,
                                  double u1, double u2) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -133,7 +148,7 @@ __global__ void k_tiles_to_dense(const double *pool, const double *aux, const in
     const size_t at = (size_t)tile * kTileCells + ((size_t)(vy & kTileMask) << kTileShift) + (vx & kTileMask);
     const double4 v = reinterpret_cast<const double4 *>(pool)[at];
     const double2 c = reinterpret_cast<const double2 *>(aux)[at];
-    p0 = v.x; p1 = v.y; p2 = v.z; a0 = c.x; a1 = c.y;
+    p0 = v.x; p1 = v.y; p2 = v.z; a0 = c.x; a1 = c.y + (double)pend[at];
   }
   const size_t o = (size_t)y * w + x;
   if (payload3) {
@@ -227,6 +242,8 @@ int tile_pool_create(slamhip_ctx *ctx, int n_slots, int tiles_x, int tiles_y, do
   hipError_t e = hipMalloc(&tp->d_pool, cells * 4 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&tp->d_aux, cells * 2 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&tp->d_state, (size_t)capacity * kTileStateWords * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(&tp->d_pend, cells * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemsetAsync(tp->d_pend, 0, cells * sizeof(unsigned), ctx->stream);
   if (e == hipSuccess) e = hipMalloc(&tp->d_tables[0], tab * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&tp->d_tables[1], tab * sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&tp->h_assign, sizeof(int) * n_slots, hipHostMallocMapped | hipHostMallocCoherent);
@@ -259,6 +276,7 @@ void tile_pool_destroy(TilePool *tp) {
   if (tp->d_pool) hipFree(tp->d_pool);
   if (tp->d_aux) hipFree(tp->d_aux);
   if (tp->d_state) hipFree(tp->d_state);
+  if (tp->d_pend) hipFree(tp->d_pend);
   if (tp->d_tables[0]) hipFree(tp->d_tables[0]);
   if (tp->d_tables[1]) hipFree(tp->d_tables[1]);
   if (tp->h_pairs) hipHostFree(tp->h_pairs);
@@ -339,7 +357,7 @@ int tile_pool_init_from_dense(TilePool *tp, const DeviceMap &m) {
   SLAMHIP_CHECK(hipMalloc(&d_ids, sizeof(int) * nt));
   SLAMHIP_CHECK(hipMemcpyAsync(d_ids, ids.data(), sizeof(int) * nt, hipMemcpyHostToDevice, tp->ctx->stream));
   hipLaunchKernelGGL(k_tiles_from_dense, dim3(nt * kChunksPerTile), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_aux,
-                     d_ids, tx0, ty0, ntx, m.d_payload, m.aux_stride == 2 ? m.d_aux : nullptr, m.pitch, m.width,
+                     tp->d_pend, d_ids, tx0, ty0, ntx, m.d_payload, m.aux_stride == 2 ? m.d_aux : nullptr, m.pitch, m.width,
                      m.height, vx0, vy0, tp->unknown[0], tp->unknown[1], tp->unknown[2], tp->unknown[3]);
   {  // the settle states of the new tiles (runs of consecutive ids in one launch each)
     int k0 = 0;
@@ -451,7 +469,7 @@ int tile_pool_make_private(TilePool *tp, int slot, int x0, int y0, int x1, int y
 int tile_pool_flush(TilePool *tp) {
   hipStream_t st = tp->ctx->stream;
   if (tp->n_pairs) {
-    hipLaunchKernelGGL(k_tile_copy, dim3(tp->n_pairs * kChunksPerTile), dim3(256), 0, st, tp->d_pool, tp->d_aux, tp->d_state,
+    hipLaunchKernelGGL(k_tile_copy, dim3(tp->n_pairs * kChunksPerTile), dim3(256), 0, st, tp->d_pool, tp->d_aux, tp->d_state, tp->d_pend,
                        tp->h_pairs, tp->n_pairs);
     tp->cow_copies += tp->n_pairs;
   }
@@ -547,6 +565,8 @@ int tile_pool_export_split(TilePool *tp, int slot, void *header_host, void *body
     // from where RCCL sends it over xGMI)
     SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_pool + tile * kTileCells * 4, kTilePayloadBytes, hipMemcpyDefault, tp->ctx->stream));
     p += kTilePayloadBytes;
+    hipLaunchKernelGGL(k_tile_fold, dim3(kTileCells / 256), dim3(256), 0, tp->ctx->stream, tp->d_aux, tp->d_pend, (int)tile);
+    SLAMHIP_CHECK(hipGetLastError());
     SLAMHIP_CHECK(hipMemcpyAsync(p, tp->d_aux + tile * kTileCells * 2, kTileAuxBytes, hipMemcpyDefault, tp->ctx->stream));
     p += kTileAuxBytes;
   }
@@ -681,6 +701,7 @@ int tile_pool_assign_mixed_split(TilePool *tp, const int *src, int n_remote, con
       p += kTilePayloadBytes;
       SLAMHIP_CHECK(hipMemcpyAsync(tp->d_aux + (size_t)fresh * kTileCells * 2, p, kTileAuxBytes, hipMemcpyDefault, st));
       p += kTileAuxBytes;
+      SLAMHIP_CHECK(hipMemsetAsync(tp->d_pend + (size_t)fresh * kTileCells, 0, kTileCells * sizeof(unsigned), st));
       {
         const int rcs = tile_state_build(tp, fresh, 1);
         if (rcs) return rcs;
@@ -713,7 +734,7 @@ int tile_pool_download(TilePool *tp, int slot, int x0, int y0, int w, int h, dou
   const size_t cells = (size_t)w * h;
   if (payload3) SLAMHIP_CHECK(hipMalloc(&d_p, cells * 3 * sizeof(double)));
   if (aux2) SLAMHIP_CHECK(hipMalloc(&d_a, cells * 2 * sizeof(double)));
-  hipLaunchKernelGGL(k_tiles_to_dense, dim3((w + 255) / 256, h), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_aux,
+  hipLaunchKernelGGL(k_tiles_to_dense, dim3((w + 255) / 256, h), dim3(256), 0, tp->ctx->stream, tp->d_pool, tp->d_aux, tp->d_pend,
                      tp->d_table() + (size_t)slot * tp->table_stride(), tp->tiles_x, tp->tiles_y, x0 + tp->origin_x,
                      y0 + tp->origin_y, w, h, d_p, d_a, tp->unknown[0], tp->unknown[1], tp->unknown[2]);
   hipError_t e = hipGetLastError();
