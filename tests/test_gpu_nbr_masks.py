@@ -200,3 +200,29 @@ def test_tile_pool_masks_and_settle_states_follow_the_filter(pkg, oracle, mode):
     pf, log, _ = run_both(pkg, oracle, n=8, n_steps_extra=4, options=options, check_masks=True)
     assert any(res for res, _ in log) or True  # (resampling, when the scenario has one, goes through the same check)
     assert log[-1][1]["cow_copies"] > 0
+
+
+@pytest.mark.parametrize("th", [0.1, 0.0, -2.0, 0.5])
+def test_masks_at_odd_thresholds_and_cells(pkg, tctx, oracle, po, th):
+    """What `full` means is the scorer's own test, !(prob_occ < th): a NaN occupancy is full, at th <= 0 free and
+    never-observed cells are full too (every mask is all ones), the rim of the window and the cells beyond it take the
+    nine-cell form.  Scores through the masks against the CPU restatement, poses near the window's rim included."""
+    from synth import make_scene
+    sc = make_scene(cell_model=2, size=400, scale=0.05, n_beams=540, seed=8)
+    m, scan = sc["map"], sc["scan"]
+    r = np.random.default_rng(21)
+    holes = r.integers(0, m.width, (400, 2))
+    m.payload[holes[:, 1], holes[:, 0], 0] = np.nan  # NaN occupancies (their obstacle means stay finite)
+    m.payload[:3, :, 0] = 0.9   # walls on the window's rim
+    m.payload[:, -2:, 0] = 0.9
+    cfg = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING, gm_th=th, pose_trig=1)
+    c, s = pkg.beam_trig(scan.angle)
+    poses = np.concatenate([poses_around(sc["true_pose"], n=24, seed=4),
+                            poses_around(sc["true_pose"] + [6.0, -7.5, 0.4], n=8, seed=5)])  # beams that leave the window
+    tctx.upload_map(0, m)
+    tctx.scan_upload(scan.range, c, s, scan.weight)
+    got = score(tctx, 0, cfg, poses)
+    assert masks(tctx, 0) == (1, 0)
+    want = oracle.score_poses(m, scan, po.make_cfg(oope=po.OOPE_GMAPPING, gm_th=th), poses, po.Oracle.new_gm_cache())
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    tctx.map_release(0)
