@@ -266,6 +266,10 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
                        "kernel_note": "one hill-climbing chain per particle on the device (GMapping OOPE: K3's one-pose "
                                       "body): ONE co-resident launch per step when all chains' workgroups fit the device "
                                       "(csrc/hc_resident_gm.hip), else shared launches per super-step (csrc/hc_chain.hip)",
+                       "bytes_note": "algorithmic bytes = SURVEY 8d's 232 per (pose, beam): the beam record and the nine "
+                                     "32-byte cells of the GMapping window.  Since r05 the kernel reads ONE 4-byte "
+                                     "neighbourhood mask per beam and the obstacle means of the full cells only (DESIGN 3, "
+                                     "K3): `traffic` is what it really moves",
                        "bytes_per_unit": bpu, "launches": g_launches, "units_launched": g_units,
                        "avg_launch_us": 1e3 * g_ms / max(g_launches, 1),
                        "kernel_busy_frac": g_ms / (1e3 * dt_instr) if dt_instr > 0 else None,
