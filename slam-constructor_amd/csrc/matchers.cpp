@@ -228,9 +228,10 @@ bool chain_eligible(slamhip_matcher *m) {
 // hand side outputs of every pose to the replay: kernel chain), and the grid must fit the device at once.
 bool resident_wanted(slamhip_matcher *m) {
   // A LONE chain over the GMapping OOPE is co-resident only when asked for (mode 2 set explicitly): measured on
-  // MI355X it is no faster than the chain of kernels -- four granules per pose instead of one, a second workgroup
-  // barrier per super-step, K3's one-pose body at the 128-VGPR limit (profiles/r04_resident_stamps.txt) -- while a
-  // filter step's MANY chains in one launch are (gm_multi_chain_run: 0.71 -> 0.59 ms per 100 particles).
+  // MI355X it is no faster than the chain of kernels (r05: 12.46 against 12.40 us per super-step,
+  // profiles/r05_resident_stamps.txt / r05_chain_stamps.txt; the shared-map filter step 12.9 against 13.0 ms) -- four
+  // granules per pose instead of one, a second workgroup barrier per super-step -- while a filter step's MANY chains
+  // in one launch are (gm_multi_chain_run: 0.58 -> 0.44 ms per 100 particles).
   const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING && m->chain_mode_explicit;
   if (m->resident_gave_up_row >= 3 && ++m->chain_matches_since_off >= kResidentRearmAfter) {
     m->resident_gave_up_row = 0;  // (re-armed: the device may be ours again)
