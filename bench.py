@@ -109,6 +109,8 @@ def parse():
                          "shards -- block split, all-gathers, identical resampling, the map-migration plan with dummy "
                          "maps point to point, barrier + max-over-ranks timing -- checking every rank against an "
                          "unsharded filter.  So that the first multi-GPU run is not also the first multi-rank run.")
+    ap.add_argument("--replica-ks", default="1,2,4,8,16,32,64",
+                    help="the `replicas` leg's K values (matches per call)")
     ap.add_argument("--batch", type=int, default=0,
                     help="slamhip_matcher_set_batch on the headline's matcher (Monte Carlo: candidates per super-step, A/B runs)")
     ap.add_argument("--no-tie-check", action="store_true",
@@ -579,7 +581,8 @@ def main():
 
     if "replicas" in args.leg_set and world == 1 and args.workload == "hc" and not args.strict and not args.seq_sum:
         try:
-            replicas_out = replicas_leg(args, pkg, ctx, cfg, params, scenes, BYTES_PER_UNIT[bkey])
+            replicas_out = replicas_leg(args, pkg, ctx, cfg, params, scenes, BYTES_PER_UNIT[bkey],
+                                        ks=tuple(int(v) for v in args.replica_ks.split(",")))
         except pkg.SlamHipError as e:
             replicas_out = {"error": str(e)}
 

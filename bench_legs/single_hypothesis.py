@@ -154,7 +154,7 @@ def mc_leg(args, pkg, ctx, sc, scenes, params, cpu_mc, matches=32):
     return out
 
 
-def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16)):
+def replicas_leg(args, pkg, ctx, cfg, params, scenes, bpu, ks=(1, 2, 4, 8, 16, 32, 64)):
     """K independent matches per call (slamhip_matcher_process_scan_batch; SURVEY 8e: single-hypothesis matchers
     replicate, they do not shard): the headline's matcher on K of the rotating scenes at once, all K accept chains
     advancing in shared launches (grid.y = match).  Scans are resident in HBM (the slots the headline stored); K = 1

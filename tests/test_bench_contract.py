@@ -47,7 +47,7 @@ def test_default_bench_line_contract():
     lm = d["latency_model"]
     assert lm["bound"] == "latency" and abs(lm["frac"] - lm["model"] / lm["achieved"]) < 1e-12 and 0.0 < lm["frac"] <= 1.0
     rep = d["replicas"]["by_K"]
-    assert [r_["K"] for r_ in rep] == [1, 2, 4, 8, 16] and all(r_["matches_on_shared_launches"] == r_["K"] for r_ in rep[1:])  # (a batch of one is the lone chain)
+    assert [r_["K"] for r_ in rep][:5] == [1, 2, 4, 8, 16] and all(r_["matches_on_shared_launches"] == r_["K"] for r_ in rep[1:])  # (a batch of one is the lone chain)
     assert d["world_loop"]["cpu_baseline"]["kind"] == "reference"
     pf = d["particle_filter"]
     assert pf["unit"] == "particles/s" and pf["scaling"] == "strong"
