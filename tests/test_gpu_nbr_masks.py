@@ -228,3 +228,21 @@ def test_masks_at_odd_thresholds_and_cells(pkg, tctx, oracle, po, th):
     want = oracle.score_poses(m, scan, po.make_cfg(oope=po.OOPE_GMAPPING, gm_th=th), poses, po.Oracle.new_gm_cache())
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
     tctx.map_release(0)
+
+
+@pytest.mark.parametrize("window", [0, 2])
+def test_other_window_sizes_take_the_cell_loop(pkg, tctx, oracle, po, window):
+    """slam/scmtch/oope/window other than 1 (no shipped configuration has one): the generic loop over (2 w + 1)^2 cells, no
+    masks -- against the CPU restatement, on a map whose masks exist (a window-1 scorer ran before)."""
+    from synth import make_scene
+    sc = make_scene(cell_model=2, size=400, scale=0.05, n_beams=540, seed=9)
+    m, scan = sc["map"], sc["scan"]
+    c, s = pkg.beam_trig(scan.angle)
+    poses = poses_around(sc["true_pose"], n=24, seed=6)
+    tctx.upload_map(0, m)
+    tctx.scan_upload(scan.range, c, s, scan.weight)
+    score(tctx, 0, pkg.spe_cfg(oope=pkg.OOPE_GMAPPING, pose_trig=1), poses)  # (masks derived)
+    got = score(tctx, 0, pkg.spe_cfg(oope=pkg.OOPE_GMAPPING, gm_window=window, pose_trig=1), poses)
+    want = oracle.score_poses(m, scan, po.make_cfg(oope=po.OOPE_GMAPPING, gm_window=window), poses, po.Oracle.new_gm_cache())
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    tctx.map_release(0)
