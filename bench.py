@@ -43,8 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from bench_legs.common import (BYTES_PER_UNIT, HBM_PEAK_GBS, WORKLOADS, latency_model, load_traffic,  # noqa: E402
-                               roofline_valu, rotating_scenes, sweep_ceiling)
+from bench_legs.common import (BYTES_PER_UNIT, HBM_PEAK_GBS, WORKLOADS, compact_line, latency_model,  # noqa: E402
+                               load_traffic, roofline_valu, rotating_scenes, sweep_ceiling)
 from bench_legs.cpu_baselines import cpu_baseline, mc_reference_baseline, pf_cpu_baselines, world_cpu_baseline  # noqa: E402
 from bench_legs.dry_ranks import dry_ranks_main  # noqa: E402
 from bench_legs.particle_filter import cfg5_leg, cfg5_sharded_leg, join_shard_group, particle_filter_leg  # noqa: E402
@@ -113,6 +113,9 @@ def parse():
                     help="the `replicas` leg's K values (matches per call)")
     ap.add_argument("--batch", type=int, default=0,
                     help="slamhip_matcher_set_batch on the headline's matcher (Monte Carlo: candidates per super-step, A/B runs)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where rank 0 writes the FULL record (every leg's roofline, samples, notes); stdout carries one "
+                         "digest line of it, <= 8 KB (the driver keeps the last 8 KB of stdout and parses the last line)")
     ap.add_argument("--no-tie-check", action="store_true",
                     help="default mode without the check of comparisons the tree sum cannot settle")
     args = ap.parse_args()
@@ -454,6 +457,9 @@ def main():
         achieved = (k_units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = load_traffic(args.workload)
         avg_us = 1e3 * k_ms / max(k_launches, 1)
+        # the same kernel time priced with the REFERENCE's scorer calls only (speculative poses the replay discards
+        # carry no useful bytes): units of the timed pass = the instrumented pass's (same K steps, same scenes)
+        useful = (units * bpu) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "pose-candidates*beams/sec (1080-beam scan, 2000^2 grid)",
             "value": units_all / t_max,
@@ -479,7 +485,8 @@ def main():
                        "backend": args.backend if world > 1 else None,
                        **extra},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "achieved_useful": useful, "frac_useful": useful / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "bytes_per_unit": bpu,
                          "launches": k_launches, "units_launched": k_units,
                          "avg_launch_us": avg_us,
@@ -517,10 +524,21 @@ def main():
         for k_, v_ in extra_legs.items():
             if v_ is not None:
                 out[k_] = v_
+        # the full record goes to the sidecar; stdout gets ONE digest line of it (<= 8 KB: bench_legs/common.py)
+        detail = None
+        try:
+            with open(args.detail_out, "w") as f:
+                json.dump(out, f)
+                f.write("\n")
+            detail = os.path.relpath(args.detail_out, ROOT) if args.detail_out.startswith(ROOT) else args.detail_out
+        except OSError as e:
+            print("bench.py: cannot write %s (%s)" % (args.detail_out, e), file=sys.stderr)
+        line = compact_line(out, detail)
         # RCCL's banner sits in C stdio's buffer when stdout is a pipe: push it out first, so that the line is the last one
         import ctypes
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        sys.stderr.flush()
+        print(line, flush=True)
 
     # The secondary legs run AFTER the headline is complete.  With more than one rank the particle-filter leg joins
     # an RCCL group inside the library: should that ever block (a fabric problem is not this benchmark's to sit

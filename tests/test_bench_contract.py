@@ -85,6 +85,53 @@ def test_default_bench_line_contract():
     assert pf["ms_per_step"] <= 0.50 and pf["with_map_update"]["ms_per_step"] <= 13.5 and c5["ms_per_step"] <= 7.5
 
 
+@pytest.mark.skipif(not DEFAULT, reason="no committed bench line yet")
+def test_the_stdout_line_is_a_digest_of_at_most_8_kb():
+    """BENCH_r05.parsed was null -- the single stdout line had grown to 23.5 KB and the driver keeps the
+    last 8 KB of stdout.  The line is now a fixed-shape digest of the full record (bench_legs.common.compact_line; the
+    record itself goes to the --detail-out sidecar), held here to <= 8192 bytes on EVERY committed full record, with the
+    driver's keys, `roofline` and `cpu_baseline` in it and the driver's own figures digit for digit."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from bench_legs.common import LINE_LIMIT, compact_line
+    assert LINE_LIMIT == 8192
+    for path in DEFAULT:
+        full = json.load(open(path))
+        line = compact_line(full, "bench_detail.json")
+        assert "\n" not in line and len(line.encode()) <= 8192, (path, len(line))
+        d = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data"):
+            assert d[k] == full[k], (path, k)
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in d["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in d["cpu_baseline"], k
+        assert "workload" in d["config"] and "model" not in d["config"]
+        assert set(d["legs"]) >= {"particle_filter", "cfg5"} and d["detail"] == "bench_detail.json"
+        for leg in d["legs"].values():
+            assert "error" in leg or "value" in leg or "by_K" in leg, leg
+    # a record whose legs have grown is trimmed, never over the limit, never without the contract keys
+    full = json.load(open(DEFAULT[-1]))
+    full["replicas"]["by_K"] = full["replicas"]["by_K"] * 40
+    full["particle_filter"]["scaling_model"]["by_ranks"] = full["particle_filter"]["scaling_model"]["by_ranks"] * 200
+    line = compact_line(full, None)
+    assert len(line.encode()) <= 8192 and json.loads(line)["roofline"]["frac"] > 0
+
+
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_default_bench_line.json")))
+
+
+@pytest.mark.skipif(not LINES, reason="no committed stdout line yet (r06 on)")
+def test_committed_stdout_line_of_the_drivers_command():
+    raw = open(LINES[-1]).read()
+    assert len(raw.encode()) <= 8192 and raw.count("\n") <= 1
+    d = json.loads(raw)
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1  # the driver's own command
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["kind"] == "reference" and d["parity"]["traces_equal"] == 16
+    assert "frac_useful" in d["roofline"] and d["roofline"]["frac_useful"] <= d["roofline"]["frac"]
+
+
 @pytest.mark.skipif(not HEADLINE, reason="no committed bench line yet")
 def test_rocprof_summary_agrees_with_the_live_kernel_time():
     """The committed rocprofv3 --kernel-trace --stats average of the headline's kernel and the HIP-event average of

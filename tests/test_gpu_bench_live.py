@@ -12,13 +12,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+DRIVER_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+               "vs_baseline", "dtype", "data", "config", "roofline")
+
+
 def run_bench(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
-                       cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, "exactly one JSON line on stdout"
-    return json.loads(lines[0])
+    """-> the FULL record (the sidecar of --detail-out), after holding the stdout line to what the driver needs of it:
+    ONE JSON line, the last non-empty line of stdout, at most 8 KB (r05's 23.5 KB line came back
+    unparsed), carrying the driver's keys with the sidecar's values."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        side = os.path.join(tmp, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail-out", side, *args],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        lines = [ln for ln in out_lines if ln.startswith("{")]
+        assert len(lines) == 1, "exactly one JSON line on stdout"
+        assert out_lines[-1] == lines[0], "the JSON line is the last non-empty line of stdout (nothing after it)"
+        assert len(lines[0].encode()) <= 8192, len(lines[0])
+        line = json.loads(lines[0])
+        full = json.load(open(side))
+    for k in DRIVER_KEYS:
+        assert k in line, k
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "vs_baseline"):
+        assert line[k] == full[k], k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) <= 1e-6 * full["roofline"]["frac"]
+    assert "workload" in line["config"] and "legs" in line
+    return full
 
 
 def test_headline_line_from_a_live_run():

@@ -5,23 +5,23 @@
 # in its own pass with --kernel-trace only, as MI355X_MICROARCH.md prescribes.  Output: gpurun_out/<tag>/;
 # tools/summarize_profiles.py <tag> then copies the summaries into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 run() { # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $ROOT/bench.py "$@" > $OUT/$name.bench.log 2>&1
-  grep '^{"metric' $OUT/$name.bench.log | tail -1 > $OUT/$name.bench.json
-  python3 $ROOT/bench.py "$@" 2> /dev/null | grep '^{"metric' | tail -1 > $OUT/$name.plain.json
+  # (r06: stdout carries a digest line <= 8 KB, the full record is the --detail-out sidecar: that is what profiles/ keeps)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $ROOT/bench.py --detail-out $OUT/$name.bench.json "$@" > $OUT/$name.bench.log 2>&1
+  python3 $ROOT/bench.py --detail-out $OUT/$name.plain.json "$@" 2> /dev/null | grep '^{"metric' | tail -1 > $OUT/$name.line.json
 }
 pmc() { # workload-name, pass-name, counters..., then "--", bench args
   local wl=$1 pass=$2; shift 2
   local ctrs=()
   while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
   shift
-  rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $OUT/pmc_${wl}_$pass -o pmc -- python3 $ROOT/bench.py "$@" > $OUT/pmc_${wl}_$pass.log 2>&1
+  rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $OUT/pmc_${wl}_$pass -o pmc -- python3 $ROOT/bench.py --detail-out $OUT/pmc_${wl}_$pass.detail.json "$@" > $OUT/pmc_${wl}_$pass.log 2>&1
 }
 # 1. PMC passes first: their summary (HBM bytes and VALU instructions per launch) is what the bench lines of
 #    step 2 quote as roofline.traffic / roofline_valu, so it has to exist -- in THIS copy of the repo -- before them
@@ -46,7 +46,9 @@ pmc pf sq $SQ -- --legs pf --steps 3 --warmup 1 --no-cpu --pf-steps 4
 python3 $ROOT/tools/summarize_profiles.py $TAG > /dev/null 2>&1   # writes profiles/${TAG}_traffic.json here
 # 2. kernel traces and the un-profiled lines
 # the driver's command (all legs, CPU baselines): un-profiled only -- this is the line BENCH_rNN will hold
-python3 $ROOT/bench.py 2> $OUT/default.err | grep '^{"metric' | tail -1 > $OUT/default.plain.json
+# (stdout kept whole: default.stdout's LAST line is what the driver parses -- default.line.json; the sidecar is the record)
+python3 $ROOT/bench.py --steps 20 --warmup 5 --detail-out $OUT/default.plain.json > $OUT/default.stdout 2> $OUT/default.err
+tail -n 1 $OUT/default.stdout > $OUT/default.line.json
 run hc --legs none --steps 50 --warmup 5 --no-cpu
 run sweep --workload sweep --steps 200 --warmup 10 --no-cpu
 run mc --workload mc --legs none --steps 20 --warmup 3 --no-cpu

@@ -82,7 +82,13 @@ for name in ("hc", "sweep", "mc", "pf", "pf_update", "pf_maps", "cfg5", "world",
 dj = os.path.join(src, "default.plain.json")
 if os.path.exists(dj) and os.path.getsize(dj) > 2:
     shutil.copy(dj, os.path.join(dst, "%s_default_bench_unprofiled.json" % tag))
-    lines.append("The driver's command (`python bench.py`, every leg, CPU baselines): `%s_default_bench_unprofiled.json`.\n" % tag)
+    lines.append("The driver's command (`python bench.py --steps 20 --warmup 5`, every leg, CPU baselines): full record "
+                 "(the `--detail-out` sidecar) `%s_default_bench_unprofiled.json`.\n" % tag)
+lj = os.path.join(src, "default.line.json")
+if os.path.exists(lj) and os.path.getsize(lj) > 2:
+    shutil.copy(lj, os.path.join(dst, "%s_default_bench_line.json" % tag))
+    lines.append("... and the LAST stdout line of that run, what the driver parses (%d bytes): `%s_default_bench_line.json`.\n"
+                 % (os.path.getsize(lj), tag))
 
 rs_ = os.path.join(src, "resident_stamps.txt")
 if os.path.exists(rs_):
