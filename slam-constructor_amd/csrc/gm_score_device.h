@@ -547,7 +547,12 @@ __device__ __forceinline__ void gm_score_pose_wide(const MapView &map, const Sca
     const int b = t + NT * r;
     const int g = b >> 6;
     int pcx = __shfl_up(cxr[r], 1, 64), pcy = __shfl_up(cyr[r], 1, 64);
-    const int2 pc = s_grp_cell[(g > 0 && g < G) ? g - 1 : 0];  // (one address per wave)
+    int2 pc = s_grp_cell[(g > 0 && g < G) ? g - 1 : 0];  // (one address per wave)
+    // (the helpers' branch of phase A writes s_grp_cell for the workgroup's OWN beams only -- groups
+    // 0 .. NT / 64 - 1.  With more than 64 surplus beams, 1089 .. 1137 beams on 1024 threads, the first beam of a later
+    // surplus group found no cell in front of it there.  The cell of the surplus beam before it is in s_hcell, written in
+    // phase A in front of the first barrier and not overwritten before the next one.)
+    if (helpers && lane == 0 && b > NT && b < n) pc = s_hcell[b - NT - 1];
     if (lane == 0 && g > 0) {
       pcx = pc.x;
       pcy = pc.y;

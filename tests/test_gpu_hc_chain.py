@@ -457,6 +457,49 @@ def test_gmapping_oope_chain_equals_host_driven_matcher(pkg, ctx, mode):
                 assert dev.resident_stats()["matches"] == 4 and dev.resident_stats()["gave_up"] == 0
 
 
+@pytest.mark.parametrize("n_beams", [1089, 1100, 1137, 1138])
+def test_gmapping_oope_scans_with_more_than_64_surplus_beams(pkg, ctx, po, oracle, n_beams):
+    """a 1024-thread workgroup scoring 1089 .. 1137 beams gives its surplus beams to helper lanes
+    (gm_score_pose_wide); r05's run resolution left the cell in front of the SECOND surplus group's first beam
+    (beam 1088) unwritten, so that beam started a run -- or not -- against uninitialised LDS (Q19: a beam in its
+    predecessor's cell takes the run head's value).  Every form that scores a pose with 1024 threads -- K3 wide
+    (launches of at most 160 poses), the chain of kernels and the co-resident launch at 1024 threads -- against the
+    ORACLE (the host-driven matcher shares the kernel): scores to 1e-11, the cross-pose cache left behind, the accept
+    trace of a match.  1138 beams: the first count that takes the helper-less form (9 x surplus > 1024)."""
+    from synth import CELL_GMAPPING
+    # close walls: consecutive beams share end cells, so runs cross the group boundaries
+    sc = make_scene(cell_model=CELL_GMAPPING, size=400, scale=0.1, n_beams=n_beams, seed=900 + n_beams)
+    assert sc["scan"].n == n_beams
+    upload(pkg, ctx, sc)
+    cfg = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING, pose_trig=1)
+    ocfg = po.make_cfg(oope=po.OOPE_GMAPPING)
+    rs = np.random.RandomState(n_beams)
+    poses = sc["init_pose"] + rs.randn(48, 3) * [0.05, 0.05, 0.01]
+    poses[1::4] = poses[0::4]  # repeated poses: the cache hands over across the whole scan
+    for chunk in (48, 1, 7):  # one wide launch, lone poses, ragged calls
+        ctx.gm_cache_reset()
+        got = np.concatenate([ctx.score_poses(0, cfg, poses[i:i + chunk]) for i in range(0, len(poses), chunk)])
+        cache = po.Oracle.new_gm_cache()
+        want = oracle.score_poses(sc["map"], sc["scan"], ocfg, poses, cache)
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-300)
+        cx, cy, pr = ctx.gm_cache_get()
+        assert (cx, cy) == (cache.cx, cache.cy) and abs(pr - cache.prob) <= 1e-11 * max(pr, 1e-300)
+    # how many beams sit in their predecessor's cell at the group boundary the bug was about (the test must see some)
+    prm = [6, 0.1, 0.1]
+    for mode, nt in ((1, 1024), (2, 1024), (2, 0), (0, 0)):
+        m = pkg.Matcher(ctx, "HC", pkg.spe_cfg(oope=pkg.OOPE_GMAPPING), prm)
+        m.set_device_chain(mode, nt)
+        for init in (sc["init_pose"], sc["true_pose"] + np.array([0.03, -0.02, 0.01])):
+            b = oracle.process_scan(oracle.enumerator(po.SM_HC, prm), sc["map"], sc["scan"], ocfg, init,
+                                    cache=po.Oracle.new_gm_cache())
+            ctx.gm_cache_reset()
+            a = m.process_scan(0, init, trace=True)
+            assert a["n_calls"] == b["n_calls"] and np.array_equal(a["accepted"], b["accepted"]), (mode, nt)
+            np.testing.assert_allclose(a["scores"], b["scores"], rtol=1e-10, atol=1e-300)
+            np.testing.assert_allclose(a["poses"], b["poses"], rtol=0, atol=1e-12)
+        m.close()
+
+
 @pytest.mark.parametrize("mode", CHAIN_MODES)
 def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, tctx, mode):
     """with an observer attached the chain writes its trace into a fixed pinned buffer; a match with more
