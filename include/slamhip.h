@@ -61,7 +61,13 @@ enum { SLAMHIP_SUM_TREE256 = 0, SLAMHIP_SUM_SEQUENTIAL = 1 };
 /* Where sin/cos of the pose heading come from (TrigonometryProvider::set_base_angle,
  * src/core/trigonometry_utils.h:31-33,57-60): host libm (bit-exact with the reference) or the
  * device's sincos (default for throughput; differs from glibc in the last ulp at most). */
-enum { SLAMHIP_POSE_TRIG_DEVICE = 0, SLAMHIP_POSE_TRIG_HOST = 1 };
+enum { SLAMHIP_POSE_TRIG_DEVICE = 0, SLAMHIP_POSE_TRIG_HOST = 1,
+       /* RAW_EXACT: the reference's DEFAULT provider bit for bit -- RawTrigonometryProvider evaluates std::cos / std::sin
+        * (theta + a) per beam and pose (trigonometry_utils.h:17-35; use_trig_cache = false, src/ros/init_utils.h:56-58).
+        * The device evaluates glibc 2.35's sin / cos restated operation for operation (csrc/libm_exact.h: the build of
+        * them this host's libm runs, slamhip_libm_variant) on theta + a; needs the beam angles (slamhip_scan_set_angles
+        * or slamhip_scan_filter_upload).  Host-driven and slow: the mode results are checked against, not a fast path. */
+       SLAMHIP_POSE_TRIG_RAW_EXACT = 2 };
 enum { SLAMHIP_TRIG_RAW = 0, SLAMHIP_TRIG_CACHED = 1 };
 
 typedef struct slamhip_ctx slamhip_ctx;
@@ -218,6 +224,17 @@ int slamhip_scan_upload(slamhip_ctx *ctx, int n, const double *range, const doub
 int slamhip_scan_store(slamhip_ctx *ctx, int slot, int n, const double *range, const double *cos_a,
                        const double *sin_a, const double *weight, const double *factor);
 int slamhip_scan_select(slamhip_ctx *ctx, int slot);
+/* The angles of the CURRENT scan's points (ScanPoint2D::angle, sensor_data.h:60-70), n = its point count: what
+ * SLAMHIP_POSE_TRIG_RAW_EXACT adds the pose heading to.  Dropped by the next upload / select; slamhip_scan_filter_upload
+ * sets them itself. */
+int slamhip_scan_set_angles(slamhip_ctx *ctx, int n, const double *angle);
+/* Which build of glibc's sin / cos / exp this host's libm runs, found by calling it on arguments where the builds
+ * differ: 1 = the FMA build (x86-64 with AVX2 + FMA usable), 0 = the plain build, -1 = neither (another libm): the
+ * exact modes (RAW_EXACT, the GMapping OOPE under SLAMHIP_SUM_SEQUENTIAL) then fail with SLAMHIP_ERR_UNSUPPORTED. */
+int slamhip_libm_variant(int *variant);
+/* the restated functions evaluated ON THE DEVICE (fn 0 sin, 1 cos, 2 exp; variant as above), host arrays in and out:
+ * lets a caller (and the tests) confirm device == host libm on its own arguments */
+int slamhip_libm_eval(slamhip_ctx *ctx, int variant, int fn, int n, const double *x, double *out);
 /* host helpers building cos_a/sin_a: RawTrigonometryProvider (trigonometry_utils.h:17-35) ... */
 int slamhip_beam_trig_raw(int n, const double *angle, double *cos_out, double *sin_out);
 /* ... and CachedTrigonometryProvider::update + index lookup (trigonometry_utils.h:45-78) */

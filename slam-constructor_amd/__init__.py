@@ -26,7 +26,7 @@ CELL_OCC, CELL_TBM, CELL_GMAPPING = 0, 1, 2
 OOPE_OBSTACLE, OOPE_MAX, OOPE_MEAN, OOPE_OVERLAP, OOPE_GMAPPING = range(5)
 OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
 SUM_TREE256, SUM_SEQUENTIAL = 0, 1
-POSE_TRIG_DEVICE, POSE_TRIG_HOST = 0, 1
+POSE_TRIG_DEVICE, POSE_TRIG_HOST, POSE_TRIG_RAW_EXACT = 0, 1, 2
 (OPT_LOW_LATENCY, OPT_STAGE_POSES, OPT_FILTER_CHAINS, OPT_K6_PATH, OPT_K6_BATCH_FAST, OPT_K6_BATCH_KEY64,
  OPT_RESIDENT_CHAINS) = range(7)
 TRIG_RAW, TRIG_CACHED = 0, 1
@@ -53,7 +53,8 @@ slamhip_shard_stats slamhip_gmapping_set_shard_chain slamhip_gmapping_match_begi
 slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_finish
 slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select
 slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_shard_set_timeout slamhip_gmapping_match_abort
-slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality slamhip_scan_filter_upload""".split()
+slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality slamhip_scan_filter_upload
+slamhip_scan_set_angles slamhip_libm_variant slamhip_libm_eval""".split()
 
 SHARD_ID_BYTES = 128
 
@@ -342,6 +343,13 @@ def filter_scan(rng, ang, is_occ, pose, geom, skip_rate=0, max_range=-1.0, trig_
     return kept[:n.value].copy()
 
 
+def libm_variant():
+    """1: the host's libm runs glibc's FMA build of sin / cos / exp, 0: the plain build, -1: neither (no exact modes)"""
+    v = C.c_int(-2)
+    _check(load().slamhip_libm_variant(C.byref(v)))
+    return v.value
+
+
 def scan_weights(kind, rng, ang):
     L = load()
     rng, ang = _f64(rng), _f64(ang)
@@ -546,6 +554,20 @@ class Context:
                 _check(rc)
             return n_kept.value
         return upload
+
+    def scan_set_angles(self, angle):
+        """the angles of the current scan's points: what POSE_TRIG_RAW_EXACT adds the pose heading to"""
+        angle = _f64(angle)
+        self.L.slamhip_scan_set_angles.argtypes = [C.c_void_p, C.c_int, _dp]
+        _check(self.L.slamhip_scan_set_angles(self.h, angle.size, _d(angle)))
+
+    def libm_eval(self, variant, fn, x):
+        """glibc's sin (fn 0) / cos (1) / exp (2) as restated in csrc/libm_exact.h, evaluated on the device"""
+        x = _f64(x).ravel()
+        out = np.zeros(x.size)
+        self.L.slamhip_libm_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp]
+        _check(self.L.slamhip_libm_eval(self.h, int(variant), int(fn), x.size, _d(x), _d(out)))
+        return out
 
     def scan_store(self, slot, rng, cos_a, sin_a, weight, factor=None):
         """Keeps a filtered scan resident in HBM (slot 0..4095); scan_select / match jobs refer to it."""

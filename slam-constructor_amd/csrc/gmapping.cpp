@@ -446,8 +446,18 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
     slamhip_scan_weights(0, nk, fr.data(), fa.data(), fw.data());
     rc = slamhip_scan_upload(ctx, nk, fr.data(), fc.data(), fs.data(), fw.data(), nullptr);
     if (rc) return rc;
+    // SLAMHIP_POSE_TRIG_RAW_EXACT (the reference's default provider bit for bit, exact_kernels.hip): the scorer adds the
+    // pose heading to the kept points' angles itself, and the reference's ONE cache object lives on the device and is
+    // applied in call order -- particle after particle, candidate after candidate: the sequential loop below, whether
+    // or not the map is updated
+    const bool exact = g->cfg.pose_trig == SLAMHIP_POSE_TRIG_RAW_EXACT;
+    if (exact) {
+      if (g->tp) return bad("SLAMHIP_POSE_TRIG_RAW_EXACT with per-particle maps is not built: use the shared map");
+      rc = slamhip_scan_set_angles(ctx, nk, fa.data());
+      if (rc) return rc;
+    }
 
-    if (g->update) {
+    if (g->update || exact) {
       // The reference's full step: every matching particle appends its scan to the ONE shared map
       // before the next particle matches (gmapping_world.h:88-99, Q20), so the particles are
       // strictly sequential: match on the GPU (lone-matcher speculation), then K6 on the same map.
@@ -493,7 +503,9 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
         g->poses_evaluated += evaluated;
         g->launches += launches;
         for (int c = 0; c < 3; ++c) p.pose[c] += dl[c];
-        if (0.0 < best_prob || p.scan_is_first) {
+        if (!g->update) {
+          p.scan_is_first = 0;
+        } else if (0.0 < best_prob || p.scan_is_first) {
           slamhip_scan_adder_cfg cfg = g->upd;
           cfg.rule = SLAMHIP_RULE_GMAPPING;
           cfg.scan_quality = 1.0;  // scan.quality handed to append_scan (gmapping_world.h:95)

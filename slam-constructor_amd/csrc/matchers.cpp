@@ -2079,8 +2079,14 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
     const int crc = bf_device_process_scan(m, map_id, init_pose, out_delta, out_prob);
     if (crc != kChainNeedsHost) return crc;
   }
-  const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
-  const int budget = m->max_batch > 0 ? m->max_batch : 256;
+  // The GMapping OOPE in its exact mode (beam-order sum and / or the raw provider's per-beam trig: exact_kernels.hip) keeps
+  // the reference's ONE cache object on the device and applies it pose after pose in CALL order -- so the poses have to be
+  // scored in call order: one certain candidate per batch, no speculation, no replayed side outputs (the job runs as a
+  // plain one; ctx->gm_* is kept by the scoring call itself).  Slow by design: the mode results are checked against.
+  const bool gm_exact = m->cfg.oope == SLAMHIP_OOPE_GMAPPING &&
+                        (m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL || m->cfg.pose_trig == SLAMHIP_POSE_TRIG_RAW_EXACT);
+  const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING && !gm_exact;
+  const int budget = gm_exact ? 1 : (m->max_batch > 0 ? m->max_batch : 256);
   int rc = ensure_pose_capacity(ctx, budget + 2);  // + the initial pose, + the best pose of a batch scored twice
   if (rc) return rc;
   m->t_stage_us = m->t_score_us = 0;

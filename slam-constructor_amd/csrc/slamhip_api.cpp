@@ -13,6 +13,7 @@
 #include <random>
 
 #include "slamhip_internal.h"
+#include "libm_exact.h"
 
 namespace slamhip {
 
@@ -87,13 +88,9 @@ static int check_cfg(const DeviceMap &m, const slamhip_spe_cfg *cfg) {
     if (m.cell_model != SLAMHIP_CELL_GMAPPING)
       return invalid("GMAPPING OOPE needs a SLAMHIP_CELL_GMAPPING map");
     if (cfg->gm_window < 0 || cfg->gm_window > 4) return invalid("gm_window out of range");
-    if (cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL) {
-      // K3 sums in the canonical tree order and patches cross-pose cache hits afterwards: neither is the
-      // reference's beam-order sum, so a caller asking for the bit-exact order is told instead of served
-      // something else
-      g_last_error = "the GMapping OOPE has no beam-order (SLAMHIP_SUM_SEQUENTIAL) path: use SLAMHIP_SUM_TREE256";
-      return SLAMHIP_ERR_UNSUPPORTED;
-    }
+    // (SLAMHIP_SUM_SEQUENTIAL: K3 sums in the canonical tree order and patches cross-pose cache hits afterwards --
+    // neither is the reference's beam-order sum; since r06 that order is served by k_score_gmapping_exact, the plain
+    // restatement with glibc's exp and the cache on the device: score_exact below)
     return SLAMHIP_OK;
   }
   if (cfg->oope < SLAMHIP_OOPE_OBSTACLE || cfg->oope > SLAMHIP_OOPE_GMAPPING)
@@ -318,6 +315,7 @@ static int profile_resolve(slamhip_ctx *ctx) {
 // pose whose first beam lands in the cell the previous call ended in re-uses that cached value
 // for its whole first run.  Applied in call order on the host.
 static void gm_carry_fixup(slamhip_ctx *ctx, int n_poses) {
+  if (ctx->gm_exact_last) return;  // (k_score_gmapping_exact applied the cache itself, pose after pose)
   const double tot_w = ctx->scan_tot_w;
   for (int p = 0; p < n_poses; ++p) {
     GmPoseInfo &gi = ctx->h_gm_info[p];
@@ -372,6 +370,165 @@ int score_wait(slamhip_ctx *ctx, unsigned seq, int lane) {
   return SLAMHIP_OK;
 }
 
+// Which build of glibc's sin / cos / exp the host's libm runs (libm_exact.h): the two restated builds are evaluated
+// on pseudo-random arguments until each function has eight where they differ, and libm -- called through volatile
+// pointers, sin and cos one at a time (the compiler would fuse a pair into sincos(), which has no FMA build) -- has to
+// agree with one of them on all of those.  Process-wide, computed once.
+int libm_variant() {
+  static const int variant = [] {
+    double (*volatile p_sin)(double) = ::sin;
+    double (*volatile p_cos)(double) = ::cos;
+    double (*volatile p_exp)(double) = ::exp;
+    unsigned long long st = 0x243f6a8885a308d3ull;
+    auto next = [&st]() {
+      st += 0x9e3779b97f4a7c15ull;
+      unsigned long long z = st;
+      z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+      return (double)((z ^ (z >> 31)) >> 11) * 0x1p-53;
+    };
+    int votes_fma = 0, votes_plain = 0, probes = 0;
+    int found[3] = {0, 0, 0};
+    for (long it = 0; it < 4000000 && (found[0] < 8 || found[1] < 8 || found[2] < 8); ++it) {
+      const double xt = 0.2 + 6.0 * next(), xe = -2.0 * next();
+      for (int f = 0; f < 3; ++f) {
+        if (found[f] >= 8) continue;
+        const double x = f == 2 ? xe : xt;
+        const double a = f == 0 ? libm_exact::sin_<true>(x) : (f == 1 ? libm_exact::cos_<true>(x) : libm_exact::exp_<true>(x));
+        const double b = f == 0 ? libm_exact::sin_<false>(x) : (f == 1 ? libm_exact::cos_<false>(x) : libm_exact::exp_<false>(x));
+        if (a == b) continue;
+        const double l = f == 0 ? p_sin(x) : (f == 1 ? p_cos(x) : p_exp(x));
+        ++found[f];
+        ++probes;
+        votes_fma += l == a;
+        votes_plain += l == b;
+      }
+    }
+    if (probes < 24) return -1;
+    if (votes_fma == probes) return 1;
+    if (votes_plain == probes) return 0;
+    return -1;
+  }();
+  return variant;
+}
+
+// the beam angles of the current scan in HBM (uploaded on first use)
+static int exact_angles(slamhip_ctx *ctx, const double **d_angle) {
+  const int n = ctx->scan_n;
+  if ((int)ctx->h_scan_angle.size() != n) {
+    set_error("SLAMHIP_POSE_TRIG_RAW_EXACT needs the angles of the current scan's points: slamhip_scan_set_angles (or "
+              "slamhip_scan_filter_upload) after the scan upload");
+    return SLAMHIP_ERR_STATE;
+  }
+  if (!ctx->scan_angle_on_device) {
+    if (n > ctx->scan_angle_cap) {
+      SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (ctx->d_scan_angle) hipFree(ctx->d_scan_angle);
+      ctx->d_scan_angle = nullptr;
+      ctx->scan_angle_cap = 0;
+      const int cap = (n + 2047) & ~2047;
+      SLAMHIP_CHECK(hipMalloc(&ctx->d_scan_angle, sizeof(double) * cap));
+      ctx->scan_angle_cap = cap;
+    }
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));  // (an earlier exact call may still read the old angles)
+    SLAMHIP_CHECK(hipMemcpy(ctx->d_scan_angle, ctx->h_scan_angle.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    ctx->scan_angle_on_device = true;
+  }
+  *d_angle = ctx->d_scan_angle;
+  return SLAMHIP_OK;
+}
+
+// The libm-exact modes of a staged batch (exact_kernels.hip), synchronous: results are in h_scores on return.
+//   * GMapping OOPE + (SLAMHIP_SUM_SEQUENTIAL or RAW_EXACT): ONE launch of k_score_gmapping_exact walks the poses in
+//     order with the reference's cache on the device (ctx->gm_* in, ctx->gm_* out: no host fix-up afterwards);
+//   * RAW_EXACT over the other OOPEs: cos / sin(theta_p + a_b) tabulated for the batch, then the ordinary scoring
+//     kernels pose by pose over the pose's own table with the identity as pose rotation.
+static int score_exact(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cfg, int n_poses, const TiledTarget *tiled,
+                       int off) {
+  const int variant = libm_variant();
+  if (variant < 0) {
+    set_error("this host's libm matches neither build of glibc's sin / cos / exp restated in csrc/libm_exact.h: the exact "
+              "modes are not available here");
+    return SLAMHIP_ERR_UNSUPPORTED;
+  }
+  const bool fma = variant == 1;
+  const bool raw = cfg->pose_trig == SLAMHIP_POSE_TRIG_RAW_EXACT;
+  const bool gm = cfg->oope == SLAMHIP_OOPE_GMAPPING;
+  const double *d_angle = nullptr;
+  if (raw) {
+    const int rc = exact_angles(ctx, &d_angle);
+    if (rc) return rc;
+  }
+  const double *poses_src = ctx->h_poses + 3 * (size_t)off;
+  const double *sc_src = cfg->pose_trig == SLAMHIP_POSE_TRIG_HOST ? ctx->h_pose_sc + 2 * (size_t)off : nullptr;
+  ScoreArgs a;
+  int rc = fill_args(ctx, m, cfg, n_poses, poses_src, sc_src, ctx->h_scores + off, &a);
+  if (rc) return rc;
+  const int n = ctx->scan_n;
+  if (gm) {
+    if (tiled) {
+      a.tables = tiled->tables;
+      a.pose_slot = ctx->h_pose_slot + off;
+      a.table_stride = tiled->table_stride;
+    }
+    if (!ctx->d_gm_exact_cache) SLAMHIP_CHECK(hipMalloc(&ctx->d_gm_exact_cache, 16));
+    struct {
+      int cx, cy;
+      double prob;
+    } c = {ctx->gm_cx, ctx->gm_cy, ctx->gm_prob};
+    SLAMHIP_CHECK(hipMemcpyAsync(ctx->d_gm_exact_cache, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = launch_score_gmapping_exact(fma, a, d_angle, raw ? 1 : 0, ctx->d_gm_exact_cache, ctx->stream);
+    if (e != hipSuccess) {
+      if (e == hipErrorInvalidValue) return invalid("the exact GMapping kernel holds at most 3840 filtered beams per scan");
+      return hip_fail(e, "k_score_gmapping_exact");
+    }
+    SLAMHIP_CHECK(hipMemcpyAsync(&c, ctx->d_gm_exact_cache, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->gm_cx = c.cx;
+    ctx->gm_cy = c.cy;
+    ctx->gm_prob = c.prob;
+    ctx->gm_exact_last = true;
+    // (no per-pose side outputs: a caller that replays them finds "no carry-in, nothing to fix")
+    for (int p = 0; p < n_poses; ++p) std::memset(&ctx->h_gm_info[off + p], 0, sizeof(GmPoseInfo));
+    if (ctx->profile) {
+      ctx->prof_launches += 1;
+      ctx->prof_units += (long long)n_poses * n;
+    }
+    return SLAMHIP_OK;
+  }
+  const size_t stride = (size_t)((n + 7) & ~7);
+  const size_t need = 2 * stride * (size_t)n_poses + 2 * (size_t)n_poses;
+  if (need > ctx->exact_trig_cap) {
+    SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_exact_trig) hipFree(ctx->d_exact_trig);
+    ctx->d_exact_trig = nullptr;
+    ctx->exact_trig_cap = 0;
+    SLAMHIP_CHECK(hipMalloc(&ctx->d_exact_trig, sizeof(double) * need));
+    ctx->exact_trig_cap = need;
+  }
+  double *d_cos = ctx->d_exact_trig, *d_sin = d_cos + stride * (size_t)n_poses, *d_id = d_sin + stride * (size_t)n_poses;
+  SLAMHIP_CHECK(launch_exact_beam_trig(fma, poses_src, n_poses, d_angle, n, stride, d_cos, d_sin, d_id, ctx->stream));
+  if (ctx->want_fprints && cfg->sum_order == SLAMHIP_SUM_TREE256) a.fprints = ctx->h_fprints + off;
+  for (int p = 0; p < n_poses; ++p) {
+    ScoreArgs ap = a;
+    ap.n_poses = 1;
+    ap.poses = a.poses + 3 * (size_t)p;
+    ap.pose_sc = d_id + 2 * (size_t)p;
+    ap.scores = a.scores + p;
+    ap.scan.cos_a = d_cos + stride * (size_t)p;
+    ap.scan.sin_a = d_sin + stride * (size_t)p;
+    if (a.terms) ap.terms = a.terms + (size_t)p * n;
+    if (a.fprints) ap.fprints = a.fprints + p;
+    SLAMHIP_CHECK(launch_score(ap, m.cell_model, cfg->oope, cfg->sum_order, ctx->stream));
+  }
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->profile) {
+    ctx->prof_launches += n_poses;
+    ctx->prof_units += (long long)n_poses * n;
+  }
+  return SLAMHIP_OK;
+}
+
 int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n_poses,
                  const TiledTarget *tiled, int off, unsigned *async_seq, int lane) {
   if (async_seq) *async_seq = 0;
@@ -392,7 +549,11 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
   if (rc) return rc;
   if (n_poses <= 0) return SLAMHIP_OK;
   const bool host_trig = cfg->pose_trig == SLAMHIP_POSE_TRIG_HOST;
+  if (cfg->pose_trig != SLAMHIP_POSE_TRIG_DEVICE && cfg->pose_trig != SLAMHIP_POSE_TRIG_HOST &&
+      cfg->pose_trig != SLAMHIP_POSE_TRIG_RAW_EXACT)
+    return invalid("unknown pose_trig");
   if (off < 0 || off + n_poses > ctx->pose_cap) return invalid("staging window outside the pose capacity");
+  ctx->gm_exact_last = false;
   if (off != 0 && (!ctx->low_latency || ctx->stage_poses))
     return invalid("staging windows need the zero-copy path");
   if (host_trig) {
@@ -404,6 +565,11 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
     }
   }
   const bool gm = cfg->oope == SLAMHIP_OOPE_GMAPPING;
+  // the libm-exact modes (synchronous; the host-driven callers find *async_seq == 0 = "nothing to wait for")
+  if (cfg->pose_trig == SLAMHIP_POSE_TRIG_RAW_EXACT || (gm && cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL)) {
+    if (lane) return invalid("the exact modes run on the context's first launch lane");
+    return score_exact(ctx, *m, cfg, n_poses, tiled, off);
+  }
   ScoreArgs a;
   if (ctx->low_latency) {
     // zero-copy: the kernel reads poses from / writes scores to the pinned staging buffers; a
@@ -555,6 +721,9 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
     if (m.d_aux) hipFree(m.d_aux);
   }
   if (ctx->d_scan) hipFree(ctx->d_scan);
+  if (ctx->d_scan_angle) hipFree(ctx->d_scan_angle);
+  if (ctx->d_exact_trig) hipFree(ctx->d_exact_trig);
+  if (ctx->d_gm_exact_cache) hipFree(ctx->d_gm_exact_cache);
   for (auto &sl : ctx->scan_slots)
     if (sl.d) hipFree(sl.d);
   for (int k = 0; k < 2; ++k) {
@@ -870,6 +1039,8 @@ static int scan_stage_commit(slamhip_ctx *ctx, int n, double *st, size_t stride)
   ctx->scan_n = n;
   ctx->scan_ptr = ctx->d_scan;
   ctx->scan_stride = stride;
+  ctx->h_scan_angle.clear();  // (the angles of the scan before: slamhip_scan_set_angles)
+  ctx->scan_angle_on_device = false;
   const int turn = ctx->scan_stage_turn;
   ctx->scan_stage_turn ^= 1;
   unsigned seq = ++ctx->scan_pull_next;
@@ -955,6 +1126,8 @@ int slamhip_scan_select(slamhip_ctx *ctx, int slot) {
   ctx->scan_ptr = sl.d;
   ctx->scan_stride = (size_t)sl.cap;
   ctx->scan_n = sl.n;
+  ctx->h_scan_angle.clear();
+  ctx->scan_angle_on_device = false;
   ctx->scan_tot_w = sl.tot_w;
   ctx->h_weight.assign(sl.w.begin(), sl.w.end());
   ctx->h_factor.assign(sl.f.begin(), sl.f.end());
@@ -1192,7 +1365,42 @@ int slamhip_scan_filter_upload(slamhip_ctx *ctx, int map_id, int n, const double
     if (rc) return rc;
     std::memcpy(w_, sp.w.data(), sizeof(double) * k);
   }
-  return scan_stage_commit(ctx, k, st, c);
+  rc = scan_stage_commit(ctx, k, st, c);
+  if (rc) return rc;
+  // the kept points' angles, for SLAMHIP_POSE_TRIG_RAW_EXACT (host side only: they go to HBM when an exact call asks)
+  ctx->h_scan_angle.resize(k);
+  for (int q = 0; q < k; ++q) ctx->h_scan_angle[q] = angle[sp.kept[q]];
+  return SLAMHIP_OK;
+}
+
+int slamhip_scan_set_angles(slamhip_ctx *ctx, int n, const double *angle) {
+  if (!ctx || !angle) return invalid("bad arguments");
+  if (n != ctx->scan_n || n <= 0) return invalid("slamhip_scan_set_angles: n is not the current scan's point count");
+  ctx->h_scan_angle.assign(angle, angle + n);
+  ctx->scan_angle_on_device = false;
+  return SLAMHIP_OK;
+}
+
+int slamhip_libm_variant(int *variant) {
+  if (!variant) return invalid("null variant");
+  *variant = libm_variant();
+  return SLAMHIP_OK;
+}
+
+int slamhip_libm_eval(slamhip_ctx *ctx, int variant, int fn, int n, const double *x, double *out) {
+  if (!ctx || n < 0 || (n > 0 && (!x || !out)) || fn < 0 || fn > 2 || (variant != 0 && variant != 1))
+    return invalid("bad arguments");
+  if (n == 0) return SLAMHIP_OK;
+  SLAMHIP_CHECK(hipSetDevice(ctx->device));
+  double *d = nullptr;
+  SLAMHIP_CHECK(hipMalloc(&d, sizeof(double) * 2 * (size_t)n));
+  hipError_t e = hipMemcpyAsync(d, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = launch_libm_eval(variant == 1, fn, d, d + n, n, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d + n, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  if (e != hipSuccess) return hip_fail(e, "slamhip_libm_eval");
+  return SLAMHIP_OK;
 }
 
 // ObservationMappingQualityEstimator::quality (grid_map_scan_adders.h:17-43): IdleOMQE, or

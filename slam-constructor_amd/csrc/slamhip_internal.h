@@ -113,6 +113,16 @@ hipError_t launch_score(const ScoreArgs &a, int cell_model, int oope, int sum_or
                         hipStream_t stream, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
 hipError_t launch_publish(unsigned *flag, unsigned seq, hipStream_t stream);
+// ---- the libm-exact modes (exact_kernels.hip; csrc/libm_exact.h) ----
+// cos / sin(theta_p + a_b) with the host glibc's bits for n_poses poses x n beams ([p * stride + b]) + (0, 1) per pose
+hipError_t launch_exact_beam_trig(bool fma, const double *poses, int n_poses, const double *d_angle, int n, size_t stride,
+                                  double *d_cos, double *d_sin, double *d_identity_sc, hipStream_t stream);
+// the GMapping OOPE restated the plain way (exp per full cell, cache beam after beam and pose after pose, beam-order sum)
+hipError_t launch_score_gmapping_exact(bool fma, const ScoreArgs &a, const double *d_angle, int raw_trig, void *d_cache,
+                                       hipStream_t stream);
+hipError_t launch_libm_eval(bool fma, int fn, const double *d_x, double *d_out, int n, hipStream_t stream);
+// which build of sin / cos / exp the host's libm runs: 1 = glibc's FMA build, 0 = the plain one, -1 = neither matches
+int libm_variant();
 hipError_t launch_stall(int ms, hipStream_t stream);  // testing
 // n_doubles (rounded up to two) from pinned host memory to HBM by a kernel; *h_flag = seq once the source has been read
 // bytes rounded up to 16: both blocks must be that long
@@ -214,6 +224,17 @@ struct slamhip_ctx {
     std::vector<int> kept;
   } scan_prep;
   std::vector<double> h_weight, h_factor;  // host copies for GMapping carry-in fix-ups
+  // the libm-exact modes (exact_kernels.hip): the beam ANGLES of the current scan (slamhip_scan_set_angles, or the kept
+  // angles of slamhip_scan_filter_upload) -- on the host until an exact scoring call needs them in HBM --, the
+  // per-pose trig tables, the reference's one GMapping cache object on the device
+  std::vector<double> h_scan_angle;
+  double *d_scan_angle = nullptr;
+  int scan_angle_cap = 0;
+  bool scan_angle_on_device = false;
+  double *d_exact_trig = nullptr;
+  size_t exact_trig_cap = 0;
+  void *d_gm_exact_cache = nullptr;
+  bool gm_exact_last = false;  // the last scoring call applied the GMapping cache itself: no host fix-up after it
   // pose / score staging
   double *d_poses = nullptr, *d_scores = nullptr, *d_pose_sc = nullptr;
   double *h_poses = nullptr, *h_scores = nullptr, *h_pose_sc = nullptr;  // pinned
