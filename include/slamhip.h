@@ -189,6 +189,13 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
 int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,
                               const double pose[3], int n, const double *range, const double *cos_a,
                               const double *sin_a, const int *is_occ, const double *quality, long long *n_updates);
+/* The same from the points' ANGLES, with the reference's DEFAULT trig provider bit for bit: RawTrigonometryProvider
+ * evaluates std::cos / std::sin(pose heading + angle) per point (trigonometry_utils.h:17-35; append_scan sets the base
+ * angle to the pose's, grid_map_scan_adders.h:61).  The host's libm makes the 2 n values once per scan; the other two
+ * entry points take the provider's own table (cos a, sin a) and add the heading by the cached provider's formulas. */
+int slamhip_map_append_scan_raw(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg, const double pose[3],
+                                int n, const double *range, const double *angle, const int *is_occ,
+                                const double *quality, long long *n_updates);
 /* host helper: ObservationMappingQualityEstimator::quality of every point of a scan (n values): kind 0 IdleOMQE,
  * 1 AngleHistogramResiprocalOMQE = 1 / AngleHistogram::value (grid_map_scan_adders.h:24-43,
  * src/core/features/angle_histogram.h:17-96), over the scan append_scan is given (all its points) */

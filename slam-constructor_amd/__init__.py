@@ -54,7 +54,7 @@ slamhip_gmapping_carry_fix slamhip_gmapping_carry_commit slamhip_gmapping_match_
 slamhip_gmapping_step_sharded slamhip_matcher_process_scan_batch slamhip_matcher_batch_stats slamhip_scan_store slamhip_scan_select
 slamhip_shard_attach slamhip_shard_exchange slamhip_shard_p2p_stats slamhip_shard_set_timeout slamhip_gmapping_match_abort
 slamhip_gmapping_migration_stats slamhip_map_append_scan_q slamhip_omqe_quality slamhip_scan_filter_upload
-slamhip_scan_set_angles slamhip_libm_variant slamhip_libm_eval""".split()
+slamhip_scan_set_angles slamhip_libm_variant slamhip_libm_eval slamhip_map_append_scan_raw""".split()
 
 SHARD_ID_BYTES = 128
 
@@ -468,6 +468,24 @@ class Context:
                                                 _d(cos_a), _d(sin_a),
                                                 occ.ctypes.data_as(_ip) if occ is not None else None,
                                                 _d(bq) if bq is not None else None, C.byref(nu)))
+        return nu.value
+
+    def map_append_scan_raw(self, map_id, rule, pose, rng, angle, is_occ=None, quality=1.0,
+                            base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), estimator=0,
+                            shift_amount=0.0, beam_quality=None):
+        """append_scan with the reference's default RawTrigonometryProvider, bit for bit (slamhip_map_append_scan_raw)"""
+        cfg = ScanAdderCfg(rule, quality, base[0], base[1], base[2], base[3], blur, max_range,
+                           estimator, shift_amount)
+        rng, angle, pose = _f64(rng), _f64(angle), _f64(pose)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        bq = _f64(beam_quality) if beam_quality is not None else None
+        assert bq is None or bq.size == rng.size
+        nu = C.c_longlong(0)
+        self.L.slamhip_map_append_scan_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _dp, C.c_int, _dp, _dp, _ip, _dp,
+                                                       C.POINTER(C.c_longlong)]
+        _check(self.L.slamhip_map_append_scan_raw(self.h, map_id, C.byref(cfg), _d(pose), rng.size, _d(rng), _d(angle),
+                                                  occ.ctypes.data_as(_ip) if occ is not None else None,
+                                                  _d(bq) if bq is not None else None, C.byref(nu)))
         return nu.value
 
     def map_download_aux(self, map_id, x0, y0, w, h, stride):

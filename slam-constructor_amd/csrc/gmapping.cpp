@@ -510,8 +510,9 @@ int slamhip_gmapping_match_begin(slamhip_gmapping *g, int map_id, int n_raw, con
           cfg.rule = SLAMHIP_RULE_GMAPPING;
           cfg.scan_quality = 1.0;  // scan.quality handed to append_scan (gmapping_world.h:95)
           long long nu = 0;
-          rc = slamhip_map_append_scan(ctx, map_id, &cfg, p.pose, n_raw, range, rc_all.data(), rs_all.data(),
-                                       is_occ, &nu);
+          rc = exact ? slamhip_map_append_scan_raw(ctx, map_id, &cfg, p.pose, n_raw, range, angle, is_occ, nullptr, &nu)
+                     : slamhip_map_append_scan(ctx, map_id, &cfg, p.pose, n_raw, range, rc_all.data(), rs_all.data(),
+                                               is_occ, &nu);
           if (rc) return rc;
           if (nu >= 0) g->cell_updates += nu;  // (deferred: counted by mu_drain below)
           p.scan_is_first = 0;

@@ -117,6 +117,7 @@ struct MuScratch {
   unsigned long long *d_ring_pad = nullptr;
   // scan re-use (see slamhip_map_append_scan)
   bool reuse_ok = false;
+  std::vector<double> raw_cos, raw_sin;  // slamhip_map_append_scan_raw: cos / sin(theta + a) of the call
   const double *last_range = nullptr, *last_cos = nullptr, *last_sin = nullptr;
   const int *last_occ = nullptr;
   const double *last_quality = nullptr;
@@ -286,6 +287,34 @@ int slamhip_map_append_scan(slamhip_ctx *ctx, int map_id, const slamhip_scan_add
                             const double pose[3], int n, const double *range, const double *cos_a,
                             const double *sin_a, const int *is_occ, long long *n_updates_out) {
   return slamhip_map_append_scan_q(ctx, map_id, cfg, pose, n, range, cos_a, sin_a, is_occ, nullptr, n_updates_out);
+}
+
+// The reference's DEFAULT trig provider for the map update: append_scan sets the provider's base
+// angle to the pose heading and moves every point with tp->cos / sin(angle) (grid_map_scan_adders.h:61-66,
+// sensor_data.h:83-88) -- with RawTrigonometryProvider std::cos / std::sin(theta + a) per point
+// (trigonometry_utils.h:17-35).  One call per scan: the HOST's libm evaluates them -- the reference's bits by
+// definition, sin and cos one call each like the provider's two virtual functions (a fused sincos() is another
+// build of the functions in glibc: csrc/libm_exact.h) -- and the update runs from the heading-free pose over the
+// rotated directions: c = 1 c_b - 0 s_b = c_b, s = 0 c_b + 1 s_b = s_b exactly.
+int slamhip_map_append_scan_raw(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg, const double pose[3],
+                                int n, const double *range, const double *angle, const int *is_occ, const double *quality,
+                                long long *n_updates_out) {
+  if (!ctx || !cfg || !pose || !range || !angle) return fail("null argument");
+  if (n <= 0) return slamhip_map_append_scan_q(ctx, map_id, cfg, pose, n, range, angle, angle, is_occ, quality, n_updates_out);
+  double (*volatile p_sin)(double) = ::sin;
+  double (*volatile p_cos)(double) = ::cos;
+  MuScratch &sc = scratch_of(ctx);
+  sc.raw_cos.resize(n);
+  sc.raw_sin.resize(n);
+  for (int b = 0; b < n; ++b) {
+    const double x = pose[2] + angle[b];  // _base_angle + angle_rad
+    sc.raw_cos[b] = p_cos(x);
+    sc.raw_sin[b] = p_sin(x);
+  }
+  sc.last_range = nullptr;  // (the arrays are rewritten in place per call: never "the scan of the call before")
+  const double flat[3] = {pose[0], pose[1], 0.0};
+  return slamhip_map_append_scan_q(ctx, map_id, cfg, flat, n, range, sc.raw_cos.data(), sc.raw_sin.data(), is_occ, quality,
+                                   n_updates_out);
 }
 
 int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_adder_cfg *cfg,

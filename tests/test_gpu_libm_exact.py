@@ -165,3 +165,66 @@ def test_exact_modes_say_what_they_need(pkg, ctx, variant):
         ctx.score_poses(0, pkg.spe_cfg(pose_trig=pkg.POSE_TRIG_RAW_EXACT), g["poses"][:2])
     with pytest.raises(pkg.SlamHipError):
         ctx.scan_set_angles(scan.angle[:-1])
+
+
+# ---- the map update with the raw provider (slamhip_map_append_scan_raw) ------------------------------------------------
+MODELS = {"mean": (0, 2), "affine": (0, 1), "last": (0, 0), "tbm": (1, 3), "gmapping": (2, 4)}  # (cell model, rule)
+STRIDE = {0: 1, 1: 4, 2: 3}
+AUX = {2: 1, 4: 2}
+K6_PATHS = {"gather": 0, "counting": 1, "radix": 2}
+
+
+@pytest.mark.parametrize("path", list(K6_PATHS))
+@pytest.mark.parametrize("name", list(MODELS))
+@pytest.mark.parametrize("golden,estimator", [("map_update.npz", 0), ("map_update_area.npz", 1)])
+def test_append_scan_with_the_raw_provider_bit_for_bit(pkg, ctx, variant, golden, estimator, name, path):
+    """tests/golden/map_update.npz and map_update_area.npz hold the compiled reference's maps after every append_scan
+    with its default RawTrigonometryProvider.  tests/test_gpu_mapupdate.py meets them to 1e-11 .. 1e-13 with the cached
+    provider's angle addition (obstacle means and the area estimator's split depend continuously on the end point);
+    with the raw provider's own cos / sin(theta + a): every payload double and every counter, assert_array_equal."""
+    g = load(golden)
+    if name + "_size" not in g:
+        pytest.skip("%s holds no %s map" % (golden, name))
+    ctx.set_option(pkg.OPT_K6_PATH, K6_PATHS[path])
+    try:
+        cell_model, rule = MODELS[name]
+        w, h = [int(v) for v in g[name + "_size"]]
+        st = STRIDE[cell_model]
+        ctx.map_bind(2, cell_model, w, h, g[name + "_origin"], float(g["scale"]), g[name + "_unknown"][:st])
+        lo, hi = [int(v) for v in g["crop"]]
+        for k in range(int(g["n_steps"])):
+            q, blur, max_range = g["step%d_params" % k]
+            extra = dict(estimator=1, shift_amount=float(g["shift_amount"])) if estimator else {}
+            ctx.map_append_scan_raw(2, rule, g["step%d_pose" % k], g["step%d_range" % k], g["step%d_angle" % k],
+                                    g["step%d_occ" % k], quality=q, base=g[name + "_base"], blur=blur, max_range=max_range,
+                                    **extra)
+            got = ctx.map_download_window(2, lo, lo, hi - lo, hi - lo, st)
+            np.testing.assert_array_equal(got, g["%s_step%d_payload" % (name, k)], err_msg="%s step %d" % (name, k))
+            if rule in AUX:
+                np.testing.assert_array_equal(ctx.map_download_aux(2, lo, lo, hi - lo, hi - lo, AUX[rule]),
+                                              g["%s_step%d_aux" % (name, k)])
+        ctx.map_release(2)
+    finally:
+        ctx.set_option(pkg.OPT_K6_PATH, 0)
+
+
+def test_full_gmapping_step_with_map_update_bit_for_bit(pkg, ctx, variant):
+    """tests/golden/gmapping_pf_update.npz: the reference's FULL GMapping step -- every matching particle appends its scan
+    to the one shared map before the next particle matches -- over several scans: poses, weights, the whole map and
+    its counters after every step, assert_array_equal."""
+    g = load("gmapping_pf_update.npz")
+    w, h = [int(v) for v in g["size"]]
+    ctx.map_bind(4, 2, w, h, g["origin"], float(g["scale"]), g["unknown"][:3])
+    n = len(g["seeds"])
+    pf = pkg.GmappingFilter(ctx, pkg.gmapping_params(gp8=g["gp"], skip_rate=3, pose_trig=pkg.POSE_TRIG_RAW_EXACT), n, g["seeds"])
+    pf.set_map_update(True)
+    for k in range(int(g["n_steps"])):
+        res, _ = pf.step(4, g["step%d_range" % k], g["step%d_angle" % k], None, g["step%d_delta" % k], 7 + k)
+        poses, wts, ms = pf.state()
+        assert res == bool(int(g["step%d_resampled" % k]))
+        np.testing.assert_array_equal(ms, g["step%d_master" % k])
+        np.testing.assert_array_equal(poses, g["step%d_poses" % k])
+        np.testing.assert_array_equal(wts, g["step%d_weights" % k])
+        np.testing.assert_array_equal(ctx.map_download_window(4, 0, 0, w, h, 3), g["step%d_payload" % k])
+        np.testing.assert_array_equal(ctx.map_download_aux(4, 0, 0, w, h, 2), g["step%d_aux" % k])
+    ctx.map_release(4)
