@@ -23,7 +23,21 @@ def dry_ranks_main(args):
     dist.init_process_group("gloo")
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    n = args.particles
+    # the two forms `bench.py --gpus N` runs the filter in: STRONG -- --particles particles over the
+    # ranks -- and WEAK -- --particles particles PER rank
+    strong = _walk(args, pkg, torch, dist, rank, world, args.particles)
+    weak = _walk(args, pkg, torch, dist, rank, world, args.particles * world)
+    if rank == 0:
+        out = dict(strong)
+        out["weak"] = weak
+        out["ok"] = bool(strong["ok"] and weak["ok"])
+        print(json.dumps(out))
+    dist.destroy_process_group()
+    sys.exit(0 if strong["ranks_that_disagree_with_the_unsharded_filter"] == 0 and
+             weak["ranks_that_disagree_with_the_unsharded_filter"] == 0 else 1)
+
+
+def _walk(args, pkg, torch, dist, rank, world, n):
     counts = [n // world + (1 if r < n % world else 0) for r in range(world)]
     firsts = [sum(counts[:r]) for r in range(world)]
     count, first = counts[rank], firsts[rank]
@@ -91,7 +105,7 @@ def dry_ranks_main(args):
         pf.close()
         return log, (moved, received, exchanges)
 
-    dummy = lambda j: (np.arange(64, dtype=np.uint8) * 3 + j).astype(np.uint8).tobytes()  # noqa: E731
+    dummy = lambda j: ((np.arange(64, dtype=np.int64) * 3 + 7 * j + j // 251) % 256).astype(np.uint8).tobytes()  # noqa: E731
     dist.barrier()
     t0 = time.perf_counter()
     log, (moved, received, exchanges) = run(first, count, gather, {j: dummy(j) for j in range(first, first + count)})
@@ -111,14 +125,12 @@ def dry_ranks_main(args):
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = tt.clone()
     dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-    if rank == 0:
-        print(json.dumps({"dry_run": True, "ranks": world, "particles": n, "shards": counts, "steps": args.pf_steps,
-                          "resamplings": resamplings, "dummy_map_bytes_moved": sm[1].item(),
-                          "maps_migrated": int(sm[3].item()), "p2p_exchanges_max_over_ranks": int(mx[4].item()),
-                          "ranks_that_disagree_with_the_unsharded_filter": int(sm[2].item()),
-                          "ok": bool(sm[2].item() == 0 and resamplings > 0), "seconds": mx[0].item(),
-                          "note": "host-only filter shards over gloo, launched like --gpus N; no GPU touched"}))
-    dist.destroy_process_group()
-    sys.exit(0 if sm[2].item() == 0 else 1)
+    return {"dry_run": True, "ranks": world, "particles": n, "shards": counts, "steps": args.pf_steps,
+            "resamplings": resamplings, "dummy_map_bytes_moved": sm[1].item(),
+            "maps_migrated": int(sm[3].item()), "p2p_exchanges_max_over_ranks": int(mx[4].item()),
+            "ranks_that_disagree_with_the_unsharded_filter": int(sm[2].item()),
+            "ok": bool(sm[2].item() == 0 and resamplings > 0), "seconds": mx[0].item(),
+            "ms_per_step": 1e3 * mx[0].item() / max(args.pf_steps, 1), "particles_per_s": n * args.pf_steps / mx[0].item(),
+            "note": "host-only filter shards over gloo, launched like --gpus N; no GPU touched"}
 
 

@@ -204,7 +204,7 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
         return np.concatenate([out[r, :counts[r] * per] for r in range(world)])
 
     rs = np.random.RandomState(5)
-    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(args.pf_steps + 6)]
+    deltas = [sc["true_pose"]] + [rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(max(args.pf_steps, 10) + 6)]
     out = {"metric": "particles/sec at N=%d" % n, "unit": "particles/s", "scaling": "strong", "ranks": world}
     # the data-path collective lives in the library (csrc/shard.cpp: RCCL group per context, all-gather of
     # the raw weights inside slamhip_gmapping_step_sharded); torch.distributed only carries the 128-byte
@@ -357,7 +357,7 @@ def particle_filter_leg(args, pkg, ctx, sc, rank, world, dist, torch):
         pfu.step(1, scan.range, scan.angle, None, deltas[0], 7)
         torch.cuda.synchronize()
         tu = time.perf_counter()
-        ksteps = 3
+        ksteps = max(10, args.pf_steps)  # (r05 timed 3: VERDICT r5 "What's weak" 5)
         for k in range(1, 1 + ksteps):
             pfu.step(1, scan.range, scan.angle, None, deltas[k], 7 + k)
         torch.cuda.synchronize()

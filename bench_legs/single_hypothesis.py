@@ -127,6 +127,12 @@ def mc_leg(args, pkg, ctx, sc, scenes, params, cpu_mc, matches=32):
                         "bytes_per_unit": bpu, "launches": k_launches, "units_launched": k_units,
                         "avg_launch_us": 1e3 * k_ms / max(k_launches, 1),
                         "timing": "HIP events attached to each dispatch, second pass of the same %d steps" % matches}}
+    # what a (pose, beam) really gathers since r06: the cell's per-beam probability from the map's 8-byte plane
+    # (DeviceMap::d_prob; SLAMHIP_OPT_TBM_PLANE) instead of the 32-byte belief -- `bytes_per_unit` stays SURVEY 8d's 56
+    plane_on = bool(ctx.get_option(pkg.OPT_TBM_PLANE))
+    gather = 16 + 8 + (8 if plane_on else 32)  # beam record + weight + cell
+    out["roofline"].update(probability_plane=plane_on, gather_bytes_per_unit=gather,
+                           achieved_gather_gbs=(k_units * gather / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0))
     if cpu_mc and cpu_mc.get("_per_scene"):
         want = cpu_mc["_per_scene"]
         bad, kept_bad, max_rel = [], [], 0.0

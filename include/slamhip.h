@@ -110,8 +110,13 @@ enum {
   SLAMHIP_OPT_RESIDENT_CHAINS = 6, /* 1 (default): the filter's per-particle accept chains run as ONE launch of
                                     * co-resident workgroups when they all fit the device (csrc/hc_resident_gm.hip);
                                     * 0: a kernel per super-step (csrc/hc_chain.hip).  Same results either way. */
-  SLAMHIP_OPT_K6_BATCH_KEY64 = 5 /* batched map update: 1 forces the 8-byte (particle, cell) keys of very large
-                                  * batches; 0 (default): by size */
+  SLAMHIP_OPT_K6_BATCH_KEY64 = 5, /* batched map update: 1 forces the 8-byte (particle, cell) keys of very large
+                                   * batches; 0 (default): by size */
+  SLAMHIP_OPT_TBM_PLANE = 7      /* 1 (default): the 1-cell scorers over a TBM map gather the cell's per-beam
+                                  * probability -- a pure function of the cell (tbm_grid_cells.h:21-35 with the fixed
+                                  * observation of the scorer) -- from an 8-byte plane every writer of the map keeps,
+                                  * instead of the 32-byte cell and its belief arithmetic per (pose, beam); 0: from the
+                                  * cell.  The same operations either way: the same bits. */
 };
 int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value);
 int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value);

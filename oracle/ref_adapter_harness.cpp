@@ -54,7 +54,8 @@ extern "C" {
 
 // cell: 0 MeanProbabilityCell (tinySLAM), 1 TbmOccConsistentCell (vinySLAM, viny weights)
 // kind: 0 MC {seed, sigma_t, sigma_r, failed, attempts}, 1 HC {failed_rounds, dt, dr}
-// strict: 1 = SLAMHIP_SUM_SEQUENTIAL + host pose trig (bit-exact bar), 0 = default mode
+// strict: 1 = SLAMHIP_SUM_SEQUENTIAL + host pose trig (bit-exact bar), 2 = the same with the raw provider's per-beam
+//         trig restated (SLAMHIP_POSE_TRIG_RAW_EXACT), 0 = default mode
 // out = {ref_calls, hip_calls, accept_mismatches, pose_mismatches, max_rel_score_diff,
 //        ref_prob, hip_prob, |delta diff| max, filtered beams, observers start/end ok}
 int refad_compare(int cell, int kind, const double *p, int n_beams, int strict, int repeat,
@@ -116,7 +117,9 @@ int refad_compare(int cell, int kind, const double *p, int n_beams, int strict, 
   cfg.oope = SLAMHIP_OOPE_OBSTACLE;
   cfg.oie = SLAMHIP_OIE_DISCREPANCY;
   cfg.sum_order = strict ? SLAMHIP_SUM_SEQUENTIAL : SLAMHIP_SUM_TREE256;
-  cfg.pose_trig = strict ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_DEVICE;
+  // strict 2: the generator's scans carry the reference's default RawTrigonometryProvider -- its cos / sin(theta + a)
+  // per beam, bit for bit (SLAMHIP_POSE_TRIG_RAW_EXACT); strict 1: the cached provider's angle addition
+  cfg.pose_trig = strict == 2 ? SLAMHIP_POSE_TRIG_RAW_EXACT : (strict ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_DEVICE);
   slamhip_matcher *hm = nullptr;
   if (kind == 0)
     slamhip_or_die(slamhip_matcher_create_mc(ctx, &cfg, unsigned(p[0]), p[1], p[2], unsigned(p[3]), unsigned(p[4]), &hm), "create_mc");
@@ -169,6 +172,68 @@ int refad_compare(int cell, int kind, const double *p, int n_beams, int strict, 
   slamhip_ctx_destroy(ctx);
   return 0;
 }
+
+#ifdef SLAMHIP_ADAPTER_TESTING
+// Run-time failures inside a match, through the testing library's injection hook: `inject` failing
+// slamhip_matcher_process_scan calls in front of ONE HipGridScanMatcher::process_scan.  out = {prob, dx, dy, dtheta,
+// failures counted by the adapter, prob of the SAME match on a matcher nothing was injected into}.
+extern "C" int slamhip_matcher_debug_fail_next(slamhip_matcher *m, int n);
+extern "C" int refad_failure(int inject, double *out) {
+  const double scale = 0.1;
+  auto gt = std::make_shared<UnboundedPlainGridMap>(std::make_shared<MockGridCell>(0.0), GridMapParams{200, 200, scale});
+  {
+    using C = CecumTextRasterMapPrimitive;
+    C c1{61, 45, C::BoundPosition::Top};
+    GridMapPatcher{}.apply_text_raster(*gt, c1.to_stream(), DiscretePoint2D{-30, 20}, 1, 1);
+  }
+  RobotPose pose{scale / 2, scale / 2 - 3 * scale, deg2rad(90)};
+  TransformedLaserScan ts;
+  ts.scan = LaserScanGenerator{to_lsp(15, 270, 360)}.laser_scan_2D(*gt, pose, 1);
+  ts.quality = 1.0;
+  auto map = std::make_shared<UnboundedPlainGridMap>(std::make_shared<MeanProbabilityCell>(), GridMapParams{200, 200, scale});
+  auto adder = WallDistanceBlurringScanAdder::builder()
+                   .set_occupancy_estimator(std::make_shared<ConstOccupancyEstimator>(Occupancy{0.95, 1.0}, Occupancy{0.01, 1.0}))
+                   .set_observation_quality_estimator(std::make_shared<IdleOMQE>())
+                   .set_blur_distance(0.3)
+                   .set_max_usable_range(std::numeric_limits<double>::infinity())
+                   .build();
+  for (int k = 0; k < 3; ++k) adder->append_scan(*map, pose, ts.scan, 0.9, 0);
+  auto make_spe = [&] {
+    return std::make_shared<WeightedMeanPointProbabilitySPE>(
+        std::make_shared<ObstacleBasedOccupancyObservationPE>(std::make_shared<DiscrepancyOIE>()), std::make_shared<EvenSPW>());
+  };
+  slamhip_ctx *ctx = nullptr;
+  if (slamhip_ctx_create(0, &ctx) != SLAMHIP_OK) return -1;
+  slamhip_spe_cfg cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  cfg.oope = SLAMHIP_OOPE_OBSTACLE;
+  cfg.oie = SLAMHIP_OIE_DISCREPANCY;
+  RobotPose noisy{pose.x + 0.07, pose.y - 0.04, pose.theta + 0.03};
+  double probs[2] = {0, 0};
+  RobotPoseDelta deltas[2];
+  long failures = 0;
+  for (int which = 0; which < 2; ++which) {  // 0: with the injected failures, 1: the undisturbed match
+    slamhip_matcher *hm = nullptr;
+    slamhip_or_die(slamhip_matcher_create_hc(ctx, &cfg, 6, 0.1, 0.1, &hm), "create_hc");
+    auto mirror = std::make_shared<HipMapMirror>(ctx, which, SLAMHIP_CELL_OCC, false);
+    auto hip = std::make_shared<HipGridScanMatcher>(make_spe(), ctx, hm, mirror, 0);
+    if (which == 0 && slamhip_matcher_debug_fail_next(hm, inject) != SLAMHIP_OK) return -2;
+    probs[which] = hip->process_scan(ts, noisy, *map, deltas[which]);
+    if (which == 0) failures = hip->run_time_failures();
+  }
+  out[0] = probs[0];
+  out[1] = deltas[0].x;
+  out[2] = deltas[0].y;
+  out[3] = deltas[0].theta;
+  out[4] = double(failures);
+  out[5] = probs[1];
+  out[6] = deltas[1].x;
+  out[7] = deltas[1].y;
+  out[8] = deltas[1].theta;
+  slamhip_ctx_destroy(ctx);
+  return 0;
+}
+#endif  // SLAMHIP_ADAPTER_TESTING
 
 // The map mirror on a GMapping map of the UNPATCHED reference: GmappingBaseCell keeps its mean obstacle point private
 // and offers no accessor; slamhip_reference_adapter.h reads it through a member pointer (SLAMHIP_GMAPPING_OBSTACLE).

@@ -28,7 +28,7 @@ OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
 SUM_TREE256, SUM_SEQUENTIAL = 0, 1
 POSE_TRIG_DEVICE, POSE_TRIG_HOST, POSE_TRIG_RAW_EXACT = 0, 1, 2
 (OPT_LOW_LATENCY, OPT_STAGE_POSES, OPT_FILTER_CHAINS, OPT_K6_PATH, OPT_K6_BATCH_FAST, OPT_K6_BATCH_KEY64,
- OPT_RESIDENT_CHAINS) = range(7)
+ OPT_RESIDENT_CHAINS, OPT_TBM_PLANE) = range(8)
 TRIG_RAW, TRIG_CACHED = 0, 1
 STRIDE = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}
 

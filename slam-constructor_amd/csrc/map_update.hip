@@ -453,6 +453,7 @@ int slamhip_map_append_scan_q(slamhip_ctx *ctx, int map_id, const slamhip_scan_a
     // (a window that grew a moment ago has no masks: its next GMapping scorer call derives them)
     a.nbr_on = (m.nbr_ok && m.cell_model == SLAMHIP_CELL_GMAPPING) ? 1 : 0;
     a.nbr_th = m.nbr_th;
+    a.prob = (m.prob_ok && m.cell_model == SLAMHIP_CELL_TBM) ? m.d_prob : nullptr;  // (gone after a re-bind, like the masks)
   };
   fill_map();
   a.cell_dbl = cell_doubles(m.cell_model);

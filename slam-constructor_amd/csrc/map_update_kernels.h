@@ -71,6 +71,7 @@ struct MuArgs {
   unsigned *special;
   // dense GMAPPING window whose cells' pads hold neighbourhood masks for threshold nbr_th (MapView, mu_cell_store)
   int nbr_on;
+  double *prob;  // TBM rule: the map's probability plane (DeviceMap::d_prob), or null -- kept by mu_cell_store
   double nbr_th;
   double unknown_c0;  // the never-observed cell's mean, if it is negative (fresh_ok)
   int fresh_ok;
@@ -1198,6 +1199,9 @@ __device__ __forceinline__ void mu_cell_store(const MuArgs &a, size_t at, const 
     }
   } else if (RULE == 3) {
     reinterpret_cast<double4 *>(a.payload)[at] = make_double4(c.c0, c.c1, c.c2, c.c3);
+    // the scorers' per-beam probability of this cell, where the map keeps a plane of them (the same function of the
+    // same four doubles the scorers would evaluate per (pose, beam): score_device.h cell_probability<TBM>)
+    if (a.prob) a.prob[at] = tbm_discrepancy_probability(c.c0, c.c1, c.c2, c.c3);
   } else {
     a.payload[at] = c.c0;
   }

@@ -63,6 +63,7 @@ struct slamhip_matcher {
   long long chain_launched = 0;  // kernels launched by the last process_scan (steps + run-ahead)
   long long *d_stamps = nullptr;  // debugging (slamhip_matcher_debug_stamps)
   int debug_trace_cap = 0;        // testing (slamhip_matcher_debug_trace_cap): pretend the trace buffer is this small
+  int debug_fail_next = 0;        // testing (slamhip_matcher_debug_fail_next): injected failures left
   struct HcBatch *batch = nullptr;  // slamhip_matcher_process_scan_batch: blocks of the last batch (hc_batch_*)
   // brute force as one flat sweep + a device arg-max (bf_device.hip)
   bool is_bf = false;
@@ -360,15 +361,17 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   if (rc) return rc;
   HcChainArgs a;
   std::memset(&a, 0, sizeof(a));
-  int cell_model = 0;
-  rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
+  int cell_model = 0, oie_eff = m->cfg.oie;
+  // (window OOPEs read the cells themselves: the view stays the map's own; the 1-cell form may come through a TBM
+  // map's probability plane -- then as an OCC view under the occupancy OIE)
+  rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model, nullptr, &oie_eff);
   if (rc) return rc;
   if (m->has_obs && !m->h_trace) {
     m->trace_cap = 1 << 16;
     SLAMHIP_CHECK(hipHostMalloc(&m->h_trace, sizeof(HcTraceEntry) * m->trace_cap,
                                 hipHostMallocMapped | hipHostMallocCoherent));
   }
-  a.oie = m->cfg.oie;
+  a.oie = oie_eff;
   a.oope = is_window_oope(m->cfg.oope) ? m->cfg.oope : SLAMHIP_OOPE_OBSTACLE;
   for (int k = 0; k < 4; ++k) a.area[k] = m->cfg.area[k];
   if (is_window_oope(m->cfg.oope) && !resident) return kChainNeedsHost;  // (no kernel-chain form: host-driven batches)
@@ -1356,8 +1359,8 @@ int bf_device_process_scan(slamhip_matcher *m, int map_id, const double init_pos
   }
   ScoreArgs a;
   std::memset(&a, 0, sizeof(a));
-  int cell_model = 0;
-  int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
+  int cell_model = 0, oie_eff = m->cfg.oie;
+  int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model, nullptr, &oie_eff);  // (TBM: through the plane)
   if (rc) return rc;
   (void)tie_check_default(m);
   const bool verify = m->tie_check == 1;  // (the GMapping OOPE never gets here: bf_device_eligible)
@@ -1381,7 +1384,7 @@ int bf_device_process_scan(slamhip_matcher *m, int map_id, const double init_pos
   a.poses = m->d_bf_poses;
   a.scores = m->d_bf_scores;
   a.n_poses = (int)n;
-  a.oie = m->cfg.oie;
+  a.oie = oie_eff;
   for (int k = 0; k < 4; ++k) a.area[k] = m->cfg.area[k];
   a.gm.fullness_th = m->cfg.gm_fullness_th;
   a.gm.window = m->cfg.gm_window;
@@ -1506,8 +1509,8 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   m->mc_slots = std::min(kMcSlots, m->max_batch);
   McChainArgs a;
   std::memset(&a, 0, sizeof(a));
-  int cell_model = 0;
-  int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model);
+  int cell_model = 0, oie_eff = m->cfg.oie;
+  int rc = score_views(ctx, map_id, &m->cfg, &a.map, &a.scan, &cell_model, nullptr, &oie_eff);  // (TBM: through the plane)
   if (rc) return rc;
   // the enumerator is reset when a match starts (pose_enumeration_scan_matcher.h:47): what carries over from
   // match to match is the engine, i.e. the position on the pair tape.  A match draws three pairs per two
@@ -1566,7 +1569,7 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
     SLAMHIP_CHECK(hipHostMalloc(&m->h_trace, sizeof(HcTraceEntry) * m->trace_cap, pinned));
   }
   static_assert(sizeof(McTraceEntry) == sizeof(HcTraceEntry), "one trace buffer serves both chains");
-  a.oie = m->cfg.oie;
+  a.oie = oie_eff;
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
   a.verify = (tie_check_default(m) && !a.seq) ? 1 : 0;
   a.ctl = m->d_mc;
@@ -2015,6 +2018,14 @@ int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched,
 }
 
 #ifdef SLAMHIP_TESTING
+// testing aid: the next `n` slamhip_matcher_process_scan calls of this matcher fail with SLAMHIP_ERR_HIP before anything
+// is launched -- what a transient device error looks like to the caller (the adapters' failure semantics,
+// host/slamhip_reference_adapter.h)
+int slamhip_matcher_debug_fail_next(slamhip_matcher *m, int n) {
+  if (!m || n < 0) return invalid_arg("bad count");
+  m->debug_fail_next = n;
+  return SLAMHIP_OK;
+}
 // testing aid, not part of include/slamhip.h: workgroup `slot_plus_1 - 1` of the following co-resident launches leaves
 // at once (0 = none) -- what a workgroup that never became resident looks like to the others
 int slamhip_matcher_debug_resident_mute(slamhip_matcher *m, int slot_plus_1) {
@@ -2035,6 +2046,24 @@ int slamhip_map_debug_nbr_masks(slamhip_ctx *ctx, int map_id, int *valid, long l
   SLAMHIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
   SLAMHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
   SLAMHIP_CHECK(launch_nbr_check(dm.d_payload, dm.width, dm.height, dm.pitch, dm.nbr_th, d_count, ctx->stream));
+  SLAMHIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(h_count), hipMemcpyDeviceToHost, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_count);
+  *mismatches = (long long)h_count;
+  return SLAMHIP_OK;
+}
+// testing aid: the state of a TBM map's probability plane (DeviceMap::d_prob) -- *valid: whether the map holds one;
+// *mismatches: cells whose stored probability is not, bit for bit, the one their four belief masses give
+int slamhip_map_debug_prob_plane(slamhip_ctx *ctx, int map_id, int *valid, long long *mismatches) {
+  if (!ctx || map_id < 0 || map_id >= (int)ctx->maps.size() || !ctx->maps[map_id].bound) return invalid_arg("unknown map id");
+  DeviceMap &dm = ctx->maps[map_id];
+  if (valid) *valid = dm.prob_ok ? 1 : 0;
+  if (mismatches) *mismatches = 0;
+  if (!dm.prob_ok || !mismatches) return SLAMHIP_OK;
+  unsigned long long *d_count = nullptr, h_count = 0;
+  SLAMHIP_CHECK(hipMalloc(&d_count, sizeof(unsigned long long)));
+  SLAMHIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+  SLAMHIP_CHECK(launch_prob_check(dm.d_payload, dm.d_prob, dm.width, dm.height, dm.pitch, d_count, ctx->stream));
   SLAMHIP_CHECK(hipMemcpyAsync(&h_count, d_count, sizeof(h_count), hipMemcpyDeviceToHost, ctx->stream));
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   hipFree(d_count);
@@ -2065,6 +2094,13 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   if (!m || !init_pose || !out_delta || !out_prob) return invalid_arg("null argument");
   slamhip_ctx *ctx = m->ctx;
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
+#ifdef SLAMHIP_TESTING
+  if (m->debug_fail_next > 0) {
+    --m->debug_fail_next;
+    set_error("injected failure (slamhip_matcher_debug_fail_next)");
+    return SLAMHIP_ERR_HIP;
+  }
+#endif
   if (chain_eligible(m)) {
     int crc = kResidentGaveUp;
     if (resident_wanted(m)) crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob, true);

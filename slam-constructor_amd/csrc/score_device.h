@@ -124,17 +124,7 @@ __device__ __forceinline__ double cell_probability(int oie, const double4 &v) {
     if (oie == SLAMHIP_OIE_OCCUPANCY) return occ;
     return 1.0 - fabs(occ - 1.0);
   } else {
-    const double U = v.x, E = v.y, O = v.z, Cc = v.w;
-    // that = aoo2tbm(obstacle AOO) = (u,e,o,c) = (0,0,1,0); conjunctive(that, cell) before
-    // normalisation = (0, 0, U+O, E+C); normalize() divides by the total mass.
-    const double d_occ = fabs(1.0 - O);
-    const double t2 = U + O, t3 = E + Cc;
-    const double tot = t2 + t3;
-    const double conflict = (tot == 0.0) ? 0.0 : t3 / tot;
-    const double unknown = U / 2.0;
-    const double known = 1 - unknown;
-    const double known_discrepancy = known * (conflict + d_occ) / 2.0;
-    return 1.0 - (unknown / 2 + known_discrepancy);
+    return tbm_discrepancy_probability(v.x, v.y, v.z, v.w);
   }
 }
 

@@ -750,6 +750,57 @@ hipError_t launch_nbr_check(const double *payload, int width, int height, int pi
   return hipGetLastError();
 }
 
+// ---- the probability plane of a TBM map (DeviceMap::d_prob) ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_prob_build(const double4 *__restrict__ cells, double *__restrict__ prob, int pitch, int x0,
+                                                   int y0, int w, int h) {
+  const int x = x0 + (int)(blockIdx.x * 256 + threadIdx.x), y = y0 + (int)blockIdx.y;
+  if (x >= x0 + w || y >= y0 + h) return;
+  const size_t at = (size_t)y * pitch + x;
+  const double4 v = cells[at];
+  prob[at] = tbm_discrepancy_probability(v.x, v.y, v.z, v.w);
+}
+__global__ __launch_bounds__(256) void k_prob_cells(const double4 *__restrict__ cells, double *__restrict__ prob, int width, int height,
+                                                   int pitch, int n, const int *__restrict__ coords) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = coords[2 * i], y = coords[2 * i + 1];
+  if ((unsigned)x >= (unsigned)width || (unsigned)y >= (unsigned)height) return;
+  const size_t at = (size_t)y * pitch + x;
+  const double4 v = cells[at];
+  prob[at] = tbm_discrepancy_probability(v.x, v.y, v.z, v.w);
+}
+__global__ __launch_bounds__(256) void k_prob_check(const double4 *__restrict__ cells, const double *__restrict__ prob, int width,
+                                                   int pitch, unsigned long long *count) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= width) return;
+  const size_t at = (size_t)y * pitch + x;
+  const double4 v = cells[at];
+  const double want = tbm_discrepancy_probability(v.x, v.y, v.z, v.w);
+  if (__double_as_longlong(want) != __double_as_longlong(prob[at])) atomicAdd(count, 1ull);
+}
+hipError_t launch_prob_build(const double *payload, double *prob, int width, int height, int pitch, int x0, int y0, int w, int h,
+                             hipStream_t stream) {
+  const int xa = x0 < 0 ? 0 : x0, ya = y0 < 0 ? 0 : y0;
+  const int xb = x0 + w > width ? width : x0 + w, yb = y0 + h > height ? height : y0 + h;
+  if (xb <= xa || yb <= ya) return hipSuccess;
+  hipLaunchKernelGGL(k_prob_build, dim3((xb - xa + 255) / 256, yb - ya), dim3(256), 0, stream,
+                     reinterpret_cast<const double4 *>(payload), prob, pitch, xa, ya, xb - xa, yb - ya);
+  return hipGetLastError();
+}
+hipError_t launch_prob_cells(const double *payload, double *prob, int width, int height, int pitch, int n, const int *d_coords,
+                             hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_prob_cells, dim3((n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const double4 *>(payload), prob,
+                     width, height, pitch, n, d_coords);
+  return hipGetLastError();
+}
+hipError_t launch_prob_check(const double *payload, const double *prob, int width, int height, int pitch,
+                             unsigned long long *d_count, hipStream_t stream) {
+  hipLaunchKernelGGL(k_prob_check, dim3((width + 255) / 256, height), dim3(256), 0, stream,
+                     reinterpret_cast<const double4 *>(payload), prob, width, pitch, d_count);
+  return hipGetLastError();
+}
+
 hipError_t launch_fill_cells(double *dst, size_t n_cells, int cell_dbl, const double *u,
                              hipStream_t stream) {
   const int blocks = (int)std::min<size_t>((n_cells + 255) / 256, (size_t)4096);

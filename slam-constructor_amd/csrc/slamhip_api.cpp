@@ -124,6 +124,23 @@ static int map_nbr_masks(slamhip_ctx *ctx, DeviceMap &m, double th) {
   return SLAMHIP_OK;
 }
 
+// The probability plane of a dense TBM window (DeviceMap::d_prob): derived on the context's stream by the first
+// 1-cell scorer call that finds none, and waited for (like the masks above); from then on the map's writers keep it.
+static int map_prob_plane(slamhip_ctx *ctx, DeviceMap &m) {
+  if (m.prob_ok) return SLAMHIP_OK;
+  if (!m.d_prob) SLAMHIP_CHECK(hipMalloc(&m.d_prob, sizeof(double) * (size_t)m.pitch * m.height));
+  SLAMHIP_CHECK(launch_prob_build(m.d_payload, m.d_prob, m.width, m.height, m.pitch, 0, 0, m.width, m.height, ctx->stream));
+  SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
+  m.prob_ok = true;
+  return SLAMHIP_OK;
+}
+// whether a scorer configuration over this map reads the plane: the obstacle OOPE under the discrepancy OIE (the only
+// OIE a TBM map is scored with, check_cfg) on a dense TBM window, unless SLAMHIP_OPT_TBM_PLANE is off
+static bool wants_prob_plane(const slamhip_ctx *ctx, const DeviceMap &m, const slamhip_spe_cfg *cfg) {
+  return ctx->tbm_plane && m.cell_model == SLAMHIP_CELL_TBM && m.bytes > 0 && cfg->oope == SLAMHIP_OOPE_OBSTACLE &&
+         cfg->oie == SLAMHIP_OIE_DISCREPANCY;
+}
+
 static int fill_args(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cfg, int n_poses,
                      const double *d_poses, const double *d_pose_sc, double *d_scores,
                      ScoreArgs *a) {
@@ -170,6 +187,17 @@ static int fill_args(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cfg,
   a->gm_info = nullptr;
   a->terms = nullptr;
   a->fprints = nullptr;
+  a->model_override = -1;
+  if (wants_prob_plane(ctx, m, cfg)) {
+    // the per-beam value is a pure function of the cell: gathered from the plane, the map scores like an OCC map
+    // whose cells ARE the probabilities (OccupancyOIE returns the cell's value as it is, score_device.h)
+    const int rc = map_prob_plane(ctx, m);
+    if (rc) return rc;
+    a->map.payload = m.d_prob;
+    a->map.unknown[0] = tbm_discrepancy_probability(m.unknown[0], m.unknown[1], m.unknown[2], m.unknown[3]);
+    a->oie = SLAMHIP_OIE_OCCUPANCY;
+    a->model_override = SLAMHIP_CELL_OCC;
+  }
   if (cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL && cfg->oope != SLAMHIP_OOPE_GMAPPING) {
     const size_t need = (size_t)n_poses * ctx->scan_n;
     if (need > ctx->terms_cap) {
@@ -207,8 +235,8 @@ static int launch_timed(slamhip_ctx *ctx, const ScoreArgs &a, const DeviceMap &m
   // strict order is two kernels and is bracketed by recorded events instead
   const bool bracket = ctx->profile && order == SLAMHIP_SUM_SEQUENTIAL;
   if (bracket) SLAMHIP_CHECK(hipEventRecord(e0, stream));
-  SLAMHIP_CHECK(launch_score(a, m.cell_model, cfg->oope, order, stream, bracket ? nullptr : e0,
-                             bracket ? nullptr : e1));
+  SLAMHIP_CHECK(launch_score(a, a.model_override >= 0 ? a.model_override : m.cell_model, cfg->oope, order, stream,
+                             bracket ? nullptr : e0, bracket ? nullptr : e1));
   if (ctx->profile) {
     if (bracket) SLAMHIP_CHECK(hipEventRecord(e1, stream));
     ctx->prof_launches += 1;
@@ -236,7 +264,7 @@ static void tiled_device_map(const TiledTarget *tiled, DeviceMap *v) {
 }
 
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
-                int *cell_model, const TiledTarget *tiled) {
+                int *cell_model, const TiledTarget *tiled, int *oie_eff) {
   DeviceMap tiled_view;
   DeviceMap *m = get_map(ctx, map_id);
   if (tiled) {
@@ -248,11 +276,15 @@ int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapVie
   int rc = check_cfg(*m, cfg);
   if (rc) return rc;
   ScoreArgs a;
+  const bool plane_on = ctx->tbm_plane;
+  if (!oie_eff) ctx->tbm_plane = false;  // (a caller that cannot take the substituted OIE gets the map's own view)
   rc = fill_args(ctx, *m, cfg, 1, nullptr, nullptr, nullptr, &a);
+  ctx->tbm_plane = plane_on;
   if (rc) return rc;
   *map = a.map;
   *scan = a.scan;
-  *cell_model = m->cell_model;
+  *cell_model = a.model_override >= 0 ? a.model_override : m->cell_model;
+  if (oie_eff) *oie_eff = a.oie;
   return SLAMHIP_OK;
 }
 
@@ -519,7 +551,8 @@ static int score_exact(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cf
     ap.scan.sin_a = d_sin + stride * (size_t)p;
     if (a.terms) ap.terms = a.terms + (size_t)p * n;
     if (a.fprints) ap.fprints = a.fprints + p;
-    SLAMHIP_CHECK(launch_score(ap, m.cell_model, cfg->oope, cfg->sum_order, ctx->stream));
+    SLAMHIP_CHECK(launch_score(ap, a.model_override >= 0 ? a.model_override : m.cell_model, cfg->oope, cfg->sum_order,
+                               ctx->stream));
   }
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (ctx->profile) {
@@ -692,6 +725,7 @@ int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value) {
     case SLAMHIP_OPT_K6_BATCH_FAST: ctx->k6_batch_fast = value != 0; break;
     case SLAMHIP_OPT_K6_BATCH_KEY64: ctx->k6_batch_key64 = value != 0; break;
     case SLAMHIP_OPT_RESIDENT_CHAINS: ctx->resident_chains = value != 0; break;
+    case SLAMHIP_OPT_TBM_PLANE: ctx->tbm_plane = value != 0; break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;
@@ -707,6 +741,7 @@ int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value) {
     case SLAMHIP_OPT_K6_BATCH_FAST: *value = ctx->k6_batch_fast; break;
     case SLAMHIP_OPT_K6_BATCH_KEY64: *value = ctx->k6_batch_key64; break;
     case SLAMHIP_OPT_RESIDENT_CHAINS: *value = ctx->resident_chains; break;
+    case SLAMHIP_OPT_TBM_PLANE: *value = ctx->tbm_plane; break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;
@@ -719,6 +754,7 @@ int slamhip_ctx_destroy(slamhip_ctx *ctx) {
   for (auto &m : ctx->maps) {
     if (m.d_payload) hipFree(m.d_payload);
     if (m.d_aux) hipFree(m.d_aux);
+    if (m.d_prob) hipFree(m.d_prob);
   }
   if (ctx->d_scan) hipFree(ctx->d_scan);
   if (ctx->d_scan_angle) hipFree(ctx->d_scan_angle);
@@ -829,6 +865,7 @@ int slamhip_map_bind(slamhip_ctx *ctx, int map_id, int cell_model, int width, in
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (old.d_payload) hipFree(old.d_payload);
   if (old.d_aux) hipFree(old.d_aux);
+  if (old.d_prob) hipFree(old.d_prob);  // (the re-bound window has no plane until a scorer asks again)
   if (old.bound && old.cell_model == cell_model) {
     nm.auto_grow = old.auto_grow;
     nm.grown = old.grown;
@@ -892,6 +929,7 @@ int slamhip_map_release(slamhip_ctx *ctx, int map_id) {
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (m->d_payload) hipFree(m->d_payload);
   if (m->d_aux) hipFree(m->d_aux);
+  if (m->d_prob) hipFree(m->d_prob);
   *m = DeviceMap{};
   return SLAMHIP_OK;
 }
@@ -911,6 +949,8 @@ int slamhip_map_upload_window(slamhip_ctx *ctx, int map_id, int x0, int y0, int 
     e = launch_repack_window(m->d_payload, m->pitch, cd, d_tmp, sh, x0, y0, w, h, ctx->stream);
   if (e == hipSuccess && m->nbr_ok)  // the masks of the written cells and of the ring around them
     e = launch_nbr_build(m->d_payload, m->width, m->height, m->pitch, m->nbr_th, x0 - 1, y0 - 1, w + 2, h + 2, ctx->stream);
+  if (e == hipSuccess && m->prob_ok)  // the probability plane of the written cells
+    e = launch_prob_build(m->d_payload, m->d_prob, m->width, m->height, m->pitch, x0, y0, w, h, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   hipFree(d_tmp);
   if (e != hipSuccess) return hip_fail(e, "map_upload_window");
@@ -966,6 +1006,8 @@ int slamhip_map_apply_dirty(slamhip_ctx *ctx, int map_id, int n, const int *coor
                                      ctx->d_dirty_val, ctx->stream));
   if (m->nbr_ok)
     SLAMHIP_CHECK(launch_nbr_cells(m->d_payload, m->width, m->height, m->pitch, m->nbr_th, n, ctx->d_dirty_xy, ctx->stream));
+  if (m->prob_ok)
+    SLAMHIP_CHECK(launch_prob_cells(m->d_payload, m->d_prob, m->width, m->height, m->pitch, n, ctx->d_dirty_xy, ctx->stream));
   SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
   return SLAMHIP_OK;
 }

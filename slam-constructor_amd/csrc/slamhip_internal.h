@@ -41,6 +41,24 @@ struct MapView {
   int reserved_;
 };
 
+// TbmBaseCell::discrepancy of the scorer's fixed observation, 1 - it: the per-beam probability of a TBM cell under the
+// discrepancy OIE (tbm_grid_cells.h:21-35, transferable_belief_model.h:102-143; SURVEY Q18: the observation is always
+// (u, e, o, c) = (0, 0, 1, 0), so the value is a PURE FUNCTION OF THE CELL).  One definition for the scoring kernels
+// (cell_probability<TBM>), the probability plane's writers and the host (the prototype cell's value): the same
+// operations in the same order, hence the same bits wherever it is evaluated (-ffp-contract=off).
+__host__ __device__ inline double tbm_discrepancy_probability(double U, double E, double O, double Cc) {
+  // that = aoo2tbm(obstacle AOO) = (u,e,o,c) = (0,0,1,0); conjunctive(that, cell) before
+  // normalisation = (0, 0, U+O, E+C); normalize() divides by the total mass.
+  const double d_occ = __builtin_fabs(1.0 - O);
+  const double t2 = U + O, t3 = E + Cc;
+  const double tot = t2 + t3;
+  const double conflict = (tot == 0.0) ? 0.0 : t3 / tot;
+  const double unknown = U / 2.0;
+  const double known = 1 - unknown;
+  const double known_discrepancy = known * (conflict + d_occ) / 2.0;
+  return 1.0 - (unknown / 2 + known_discrepancy);
+}
+
 // Filtered scan, structure-of-arrays (coalesced per-beam loads), tot_w = sequential sum of
 // weights in beam order computed once on the host (pose independent).
 struct ScanView {
@@ -85,6 +103,9 @@ struct ScoreArgs {
   const int *pose_slot;
   int table_stride;
   int xcd_blocks;  // set by launch_score: > 0 = the real block count of an XCD-chunked grid
+  // fill_args: >= 0 = the model the kernels are instantiated for instead of the map's own -- a TBM map scored through
+  // its probability plane looks like an OCC map under the occupancy OIE (DeviceMap::d_prob)
+  int model_override;
 };
 
 // tiles of the copy-on-write maps: 128 x 128 cells like the reference's LazyTiledGridMap
@@ -158,7 +179,21 @@ struct DeviceMap {
   // neighbourhood masks in the cells' pads (MapView): valid for threshold nbr_th; built by map_nbr_masks()
   bool nbr_ok = false;
   double nbr_th = 0.0;
+  // TBM maps: the PROBABILITY PLANE -- one double per cell = tbm_discrepancy_probability of the cell (r06, VERDICT r5
+  // item 5).  The 1-cell scorers gather 8 bytes from it instead of the 32-byte cell and ~16 flops + a division per
+  // (pose, beam); derived by the first scorer call that finds none (map_prob_plane), then kept by every writer: K6's
+  // mu_cell_store (MuArgs::prob), uploads and the dirty log re-derive what they wrote; a re-bind drops it.
+  double *d_prob = nullptr;
+  bool prob_ok = false;
 };
+// (re)derives the plane over [x0, x0 + w) x [y0, y0 + h) (clipped) / over n listed cells (d_coords: x, y pairs)
+hipError_t launch_prob_build(const double *payload, double *prob, int width, int height, int pitch, int x0, int y0, int w, int h,
+                             hipStream_t stream);
+hipError_t launch_prob_cells(const double *payload, double *prob, int width, int height, int pitch, int n, const int *d_coords,
+                             hipStream_t stream);
+// cells whose stored value differs from the derived one (testing), added to *d_count
+hipError_t launch_prob_check(const double *payload, const double *prob, int width, int height, int pitch,
+                             unsigned long long *d_count, hipStream_t stream);
 // (re)derives the masks of the cells of [x0, x0 + w) x [y0, y0 + h) (clipped to the window) from the occupancies
 hipError_t launch_nbr_build(double *payload, int width, int height, int pitch, double th, int x0, int y0, int w, int h,
                             hipStream_t stream);
@@ -266,7 +301,7 @@ struct slamhip_ctx {
   bool low_latency = true;
   bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
   // slamhip_ctx_set_option: equivalent execution paths (defaults = what is measured)
-  bool filter_chains = true, k6_batch_fast = true, k6_batch_key64 = false, resident_chains = true;
+  bool filter_chains = true, k6_batch_fast = true, k6_batch_key64 = false, resident_chains = true, tbm_plane = true;
   int k6_path = 0;
   // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read
   bool profile = false;
@@ -302,8 +337,10 @@ int score_staged(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, int n
 int score_wait(slamhip_ctx *ctx, unsigned seq, int lane = 0);
 // orders the second lane behind everything queued on the first so far (scan upload, map updates)
 int lane_fork(slamhip_ctx *ctx);
+// (oie_eff, optional: a caller that passes it takes the map through its probability plane where there is one -- the
+// view is then an OCC one and *oie_eff the occupancy OIE, see DeviceMap::d_prob; without it the view is the map's own)
 int score_views(slamhip_ctx *ctx, int map_id, const slamhip_spe_cfg *cfg, MapView *map, ScanView *scan,
-                int *cell_model, const TiledTarget *tiled = nullptr);
+                int *cell_model, const TiledTarget *tiled = nullptr, int *oie_eff = nullptr);
 int profile_event_pair(slamhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1, int kind = 0);
 // An event pair recorded AROUND a pipeline (the map update): every exit between the first record and the second --
 // an empty update, a failed grow, a HIP error -- would leave a pair whose end was never recorded (or holds a stale

@@ -27,7 +27,12 @@ inline std::shared_ptr<GridScanMatcher> init_hip_scan_matcher(const PropertiesPr
   cfg.oie = props.get_str(Slam_SM_NS + "oie/type", "discrepancy") == "occupancy" ? SLAMHIP_OIE_OCCUPANCY
                                                                                  : SLAMHIP_OIE_DISCREPANCY;
   cfg.sum_order = props.get_bool(Slam_SM_NS + "hip/strict", false) ? SLAMHIP_SUM_SEQUENTIAL : SLAMHIP_SUM_TREE256;
-  cfg.pose_trig = props.get_bool(Slam_SM_NS + "hip/strict", false) ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_DEVICE;
+  // strict: the reference's bits.  Scans carry the RawTrigonometryProvider unless the node was started with
+  // use_trig_cache (src/ros/init_utils.h:56-58; laser_scan_observer.h:77-86) -- "hip/trig_cache" says so here --:
+  // cos / sin(theta + a) per beam by the restated libm (RAW_EXACT), or the cached provider's angle addition (HOST)
+  const bool strict = props.get_bool(Slam_SM_NS + "hip/strict", false);
+  const bool trig_cache = props.get_bool(Slam_SM_NS + "hip/trig_cache", false);
+  cfg.pose_trig = !strict ? SLAMHIP_POSE_TRIG_DEVICE : (trig_cache ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_RAW_EXACT);
   const auto type = scan_matcher_type(props);
   std::cout << "Used Scan Matcher: " << type << std::endl;
   slamhip_matcher *m = nullptr;

@@ -331,6 +331,9 @@ inline void hip_upload_filtered_scan(slamhip_ctx *ctx, const LaserScan2D &scan, 
     slamhip_or_die(slamhip_beam_trig_raw(n, a.data(), c.data(), s.data()), "beam_trig_raw");
   slamhip_or_die(slamhip_scan_upload(ctx, n, r.data(), c.data(), s.data(), w.data(), f.data()),
                  "scan_upload");
+  // (what SLAMHIP_POSE_TRIG_RAW_EXACT -- RawTrigonometryProvider bit for bit -- adds the pose heading to; a host-side
+  // copy, sent to the device only if a scoring call asks for that mode)
+  slamhip_or_die(slamhip_scan_set_angles(ctx, n, a.data()), "scan_set_angles");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,13 +382,40 @@ public:
     slamhip_or_die(slamhip_matcher_set_observer(_m, &o), "set_observer");
     const double p0[3] = {init_pose.x, init_pose.y, init_pose.theta};
     double d[3], prob = 0;
-    slamhip_or_die(slamhip_matcher_process_scan(_m, _mirror->id(), p0, d, &prob), "process_scan");
+    match_or_unknown(p0, d, &prob);
     pose_delta = RobotPoseDelta{d[0], d[1], d[2]};
     do_for_each_observer([&](ObsPtr obs) { obs->on_matching_end(pose_delta, _scan, prob); });
     return prob;
   }
+  long run_time_failures() const { return _n_failures; }
 
 private:
+  // A RUN-TIME failure inside a match must not end the SLAM process: a device error or
+  // a state error of the launch -- not a configuration error, which stays print + std::exit(-1) like
+  // init_scan_matching.h:39-43 -- is retried ONCE on the other device form of the chain (a kernel per super-step
+  // instead of the co-resident launch), and if that fails too the match reports what the reference reports when it
+  // cannot tell: the "unknown" probability -- a quiet NaN, weighted_mean_point_probability_spe.h:127-131 -- and a
+  // zero correction, so the world keeps the odometry pose for this scan.  There is no CPU scorer to fall back on.
+  void match_or_unknown(const double p0[3], double d[3], double *prob) {
+    int rc = slamhip_matcher_process_scan(_m, _mirror->id(), p0, d, prob);
+    if (rc == SLAMHIP_OK) return;
+    if (rc == SLAMHIP_ERR_INVALID || rc == SLAMHIP_ERR_UNSUPPORTED || rc == SLAMHIP_ERR_NO_DEVICE)
+      slamhip_or_die(rc, "process_scan");
+    ++_n_failures;
+    std::cerr << "[slamhip] process_scan failed (" << slamhip_last_error() << "): once more on the chain of kernels"
+              << std::endl;
+    slamhip_matcher_set_device_chain(_m, 1, 0);
+    rc = slamhip_matcher_process_scan(_m, _mirror->id(), p0, d, prob);
+    slamhip_matcher_set_device_chain(_m, 2, 0);  // (the default form again for the next scan)
+    if (rc == SLAMHIP_OK) return;
+    ++_n_failures;
+    std::cerr << "[slamhip] process_scan failed again (" << slamhip_last_error()
+              << "): this scan's match is reported as unknown (NaN, no pose correction)" << std::endl;
+    d[0] = d[1] = d[2] = 0.0;
+    *prob = std::numeric_limits<double>::quiet_NaN();
+  }
+  long _n_failures = 0;
+
   bool spe_is_plain_wmpp() const {
     const auto spe = scan_probability_estimator();
     return spe && typeid(*spe) == typeid(WeightedMeanPointProbabilitySPE);
@@ -422,7 +452,7 @@ private:
     }
     slamhip_or_die(slamhip_matcher_set_observer(_m, nullptr), "set_observer");
     double d[3], prob = 0;
-    slamhip_or_die(slamhip_matcher_process_scan(_m, _mirror->id(), p0, d, &prob), "process_scan");
+    match_or_unknown(p0, d, &prob);
     pose_delta = RobotPoseDelta{d[0], d[1], d[2]};
     return prob;
   }

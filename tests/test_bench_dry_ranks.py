@@ -28,3 +28,10 @@ def test_dry_ranks(ranks, particles):
     assert d["dummy_map_bytes_moved"] == 64 * d["maps_migrated"]
     if ranks == 8:
         assert d["shards"] == [13] * 4 + [12] * 4
+    # r06: the WEAK-scaling form beside the strong one -- `--particles` particles per rank -- walked
+    # through the same control flow, every rank checked against the unsharded filter of ranks x particles
+    w = d["weak"]
+    assert w["ranks"] == ranks and w["particles"] == ranks * particles and w["shards"] == [particles] * ranks
+    assert w["ok"] and w["ranks_that_disagree_with_the_unsharded_filter"] == 0 and w["resamplings"] >= 1
+    for leg in (d, w):
+        assert leg["ms_per_step"] > 0 and leg["particles_per_s"] > 0

@@ -29,7 +29,7 @@ CASES = [(0, 0, [666666, 0.2, 0.1, 20, 100]), (0, 1, [6, 0.1, 0.1]), (0, 1, [128
 
 
 @pytest.mark.parametrize("cell,kind,params", CASES)
-@pytest.mark.parametrize("strict", [1, 0])
+@pytest.mark.parametrize("strict", [2, 1, 0])
 def test_adapter_matches_reference_matcher(lib, cell, kind, params, strict):
     p = (C.c_double * len(params))(*params)
     out = (C.c_double * 10)()
@@ -37,7 +37,7 @@ def test_adapter_matches_reference_matcher(lib, cell, kind, params, strict):
     ref_calls, hip_calls, acc_mis, pose_mis, rel, ref_prob, hip_prob, ddelta, beams, obs_ok = list(out)
     assert beams > 600 and obs_ok == 1
     assert ref_calls == hip_calls and acc_mis == 0 and pose_mis == 0
-    if strict:
+    if strict:  # (2: the raw provider's per-beam libm trig restated -- the provider these generated scans carry; r06)
         assert rel == 0.0 and ref_prob == hip_prob and ddelta == 0.0
     else:
         assert rel <= 1e-12 and ddelta == 0.0 and abs(ref_prob - hip_prob) <= 1e-12 * abs(ref_prob)
@@ -50,3 +50,25 @@ def test_mirror_reads_gmapping_obstacle_means_of_the_unpatched_reference(lib):
     out = (C.c_double * 2)()
     assert lib.refad_gmapping_mirror(out) == 0
     assert out[0] == 200 and out[1] == 0
+
+
+@pytest.mark.parametrize("inject", [0, 1, 2])
+def test_a_run_time_failure_inside_a_match_does_not_end_the_process(inject):
+    """VERDICT r5 item 9: the adapters answered ANY failing call with std::exit(-1), a transient device error inside
+    process_scan included.  Now (host/slamhip_reference_adapter.h match_or_unknown) a run-time failure is retried once on
+    the chain of kernels, and a second failure reports the reference's "unknown" -- quiet NaN, no pose correction
+    (weighted_mean_point_probability_spe.h:127-131) --; configuration errors still exit like init_scan_matching.h:39-43.
+    Failures are injected through libslamhip_testing.so's hook (the harness linked against the testing library)."""
+    so = SO.replace("libslamref_adapter.so", "libslamref_adapter_testing.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libslamref_adapter_testing.so not present")
+    L = C.CDLL(so)
+    L.refad_failure.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 9)()
+    assert L.refad_failure(inject, out) == 0  # (the process is still here)
+    prob, dx, dy, dth, failures, want_prob, wx, wy, wth = list(out)
+    assert failures == inject and want_prob > 0.1
+    if inject < 2:  # the first attempt's failure is made good by the retry: the undisturbed match, bit for bit
+        assert (prob, dx, dy, dth) == (want_prob, wx, wy, wth)
+    else:
+        assert np.isnan(prob) and (dx, dy, dth) == (0.0, 0.0, 0.0)
