@@ -363,12 +363,18 @@ int slamhip_matcher_resident_stats(slamhip_matcher *m, long long *matches, long 
  * scores stay the canonical sums.  on = 0: decisions from the tree sums as they are (ties between mathematically
  * equal candidates can then fall the other way: 4 of 200 fuzzed matches over the 1-cell OOPE, 2 of 200 over `max`,
  * tests/test_gpu_hc_chain.py).
- * NOT checked: the GMapping OOPE.  Its per-beam value is exp() of a distance and the device's exp is not glibc's, so
- * there is no bit-exact sum to fall back on; its chains decide from the canonical sums.  Measured against the
- * oracle's strict loop (reference order, libm): 0 of 200 fuzzed matches part from it at failed-round limits 6 (what
- * GMapping hard-wires, init_gmapping.h:58-60), 10 and 14; at limit 27 -- steps of 7e-10 m around an optimum, where
- * the candidates' scores differ by less than the last bits of ANY double-precision evaluation -- 17 of 20 do, each
- * at a comparison whose two strict-mode scores lie within 16 ulps (the same test file). */
+ * The GMapping OOPE (r06): a lone matcher's default mode is checked too, by another mechanism -- its per-beam value is
+ * exp() of a distance and the fast paths use the device's exp, so there are no beam-order sums of the SAME terms to
+ * re-decide from.  A comparison on the walked path whose two scores lie within 2^-40 of each other (two zero scores
+ * excepted) is reported before anything has been shown to an observer (device chains: error 7; host-driven batches:
+ * MatchJob::gm_unsettled), and the whole match is redone in the EXACT mode: call order, beam-order sums, glibc's exp
+ * restated (csrc/libm_exact.h, exact_kernels.hip), with the reference's default RawTrigonometryProvider where the
+ * context knows the scan's angles (slamhip_scan_set_angles / slamhip_scan_filter_upload), else the cached provider's
+ * angle addition.  Redone matches are counted in slamhip_matcher_chain_stats' steps_rescored.  At the limits GMapping
+ * uses (6 failed rounds, init_gmapping.h:58-60) no comparison comes that close and nothing is redone; at limit 27 --
+ * steps of 7e-10 m around an optimum -- nearly every match is, and takes the reference's accept path
+ * (tests/test_gpu_hc_chain.py).  The filter's per-particle chains (slamhip_gmapping_*) are not checked: they run
+ * GMapping's hard-wired limit, and their exact form is SLAMHIP_POSE_TRIG_RAW_EXACT. */
 int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],

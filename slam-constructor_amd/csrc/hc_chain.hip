@@ -308,12 +308,22 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         run_hash = hb;
       } else {
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-          if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections
+        for (int c = 0; c < 6; ++c) {
+          const bool live = c == 0 || !trailing;
+          if (GM && a.verify && live) {
+            // checked default mode over the GMapping OOPE (r06): see hc_resident_gm.hip -- a comparison within 2^-40 is
+            // reported (error 7) and the host redoes the match in the exact mode
+            const double s = s6[c];
+            const double diff = __builtin_fabs(s - run);
+            const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
+            ambiguous = ambiguous || (diff <= (as > ab ? as : ab) * 9.094947017729282e-13 && !(s == 0.0 && run == 0.0));
+          }
+          if (live && run < s6[c]) {  // strict: ties are rejections
             run = s6[c];
             out = c + 1;
-              accmask |= 1u << c;
+            accmask |= 1u << c;
           }
+        }
       }
       bool valid = reach;
 #pragma unroll
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         next.carry_cy = bcast_i(fin.cy, tl);
         next.carry_prob = bcast(fin.prob, tl);
         if (__ballot(valid && degenerate) != 0ull && init_slot && lane == 0) host->error = 3;
+        if (__ballot(valid && ambiguous) != 0ull && init_slot && lane == 0) host->error = 7;
       }
       if (tmask == 0ull) {  // cannot happen (the root round is always on the path): stop instead of looping
         next.done = 1;

@@ -60,6 +60,11 @@ struct HcNextEntryT {
   // from the two counts)
 };
 static_assert(sizeof(HcNextEntryT<1>) == 64 && sizeof(HcNextEntryT<2>) == 96, "HcNextEntry layout");
+// (16 bits of failed rounds, 12 of scorer calls, 4 of accepted rounds -- what they have to hold: the device
+// forms run matchers of at most 1000 failed rounds (hc_limit_on_device, matchers.cpp), a walked path makes at most
+// 6 x 42 + 6 scorer calls and accepts in at most kHcMaxSeg + 1 rounds)
+static_assert(kHcMaxSeg + 1 <= 15, "HcNextEntry::counts: accepted rounds of a path in 4 bits");
+static_assert(6 * kHcMaxInst + 6 < 4096, "HcNextEntry::counts: scorer calls of a path in 12 bits");
 __device__ __forceinline__ unsigned hc_entry_counts(const HcNextCore &c, int rounds_acc) {
   return (c.failed & 0xffffu) | (((unsigned)c.batch_calls & 0xfffu) << 16) | (((unsigned)rounds_acc & 0xfu) << 28);
 }

@@ -336,13 +336,26 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
       double run = enter;
       int out = 0;
       unsigned accmask = 0u;
+      // checked default mode (r06): a comparison whose two canonical sums lie within 2^-40 (relative) of each other is one
+      // the tree sum with the device's exp cannot settle the way the reference's beam-order sum with glibc's exp would
+      // -- reported (error 7), and the host redoes the match in the exact mode (exact_kernels.hip).  Two zero scores
+      // are sums of zeros in any order: settled.
+      bool unsettled = false;
 #pragma unroll
-      for (int c = 0; c < 6; ++c)
-        if ((c == 0 || !trailing) && run < s6[c]) {  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
-          run = s6[c];
+      for (int c = 0; c < 6; ++c) {
+        const bool live = c == 0 || !trailing;
+        const double s = s6[c];
+        if (ap->verify && live) {
+          const double diff = __builtin_fabs(s - run);
+          const double as = __builtin_fabs(s), ab = __builtin_fabs(run);
+          unsettled = unsettled || (diff <= (as > ab ? as : ab) * 9.094947017729282e-13 && !(s == 0.0 && run == 0.0));
+        }
+        if (live && run < s) {  // strict: ties are rejections (pose_enumeration_scan_matcher.h:58)
+          run = s;
           out = c + 1;
           accmask |= 1u << c;
         }
+      }
       bool valid = reach;
 #pragma unroll
       for (int o = 0; o < 7; ++o) {
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_hc_chain_resident_g
         // a pose whose whole scan is one run sat on the path: what it leaves in the cache depends on what it met --
         // the host-driven path redoes the match (error 3)
         if (__ballot(valid && degenerate) != 0ull && init_slot && lane == 0) host->error = 3;
+        if (__ballot(valid && unsettled) != 0ull && init_slot && lane == 0) host->error = 7;
       }
       if (tmask == 0ull) {
         next.done = 1;

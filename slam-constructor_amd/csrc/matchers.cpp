@@ -126,6 +126,9 @@ namespace {
 
 constexpr int kChainNeedsHost = 1;  // internal: positive, never leaves the library
 constexpr int kResidentGaveUp = 2;  // internal: the co-resident launch left without a result, the kernel chain redoes the match
+// internal: a GMapping-OOPE chain met a comparison its tree sums (device exp) cannot settle the reference's way; nothing
+// has been reported: the match is redone in the exact mode (call order, beam-order sums, glibc's exp: exact_kernels.hip)
+constexpr int kChainUnsettled = 3;
 constexpr int kChainDefaultMode = 2;  // device chains: 1 = a kernel per super-step, 2 = one co-resident launch where it applies
 // after three give-ups in a row a matcher stops asking for the co-resident form; 64 matches later it asks again (the
 // other tenant of the device may be gone)
@@ -190,7 +193,7 @@ int chain_release(slamhip_matcher *m) {
 // no intermediate is subnormal, i.e. as long as step * 2^-(limit + 1) is a normal double (limit <= 1000 keeps 2^-f
 // itself representable).  r01-r03 stopped at 250 for no better reason than the size of a byte.
 bool hc_limit_on_device(const slamhip_matcher *m) {
-  if (m->hc_max_failed == 0 || m->hc_max_failed > 1000) return false;
+  if (m->hc_max_failed == 0 || m->hc_max_failed > 1000) return false;  // (also: 16 bits in HcNextEntry::counts)
   for (double step : {m->hc_dt, m->hc_dr}) {
     if (step == 0.0) continue;  // (a zero step stays zero either way)
     int e = 0;
@@ -384,7 +387,9 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   a.seq = m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL ? 1 : 0;
   // (the 1-cell AND the window OOPEs: `max` is as discrete as the 1-cell value, so mathematically tied candidates
   // are as likely -- VERDICT r4 item 2; the GMapping OOPE's chains decide from the tree sums: include/slamhip.h)
-  a.verify = (tie_check_default(m) && !a.seq && m->cfg.oope != SLAMHIP_OOPE_GMAPPING) ? 1 : 0;
+  // (the 1-cell OOPE: unsettled comparisons re-decided on the device from beam-order sums; the GMapping OOPE, r06: reported
+  // -- error 7 -- and the match redone in the exact mode)
+  a.verify = (tie_check_default(m) && !a.seq) ? 1 : 0;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
   a.n_inst = 0;
@@ -509,6 +514,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   // 2: the observer's trace outgrew its buffer (65536 scorer calls), 3: a one-run scan sat on the path.  Nothing has
   // been reported to the observer or stored in the matcher yet, so the host-driven path -- which has neither limit --
   // redoes the match.
+  if (h->error == 7) return kChainUnsettled;
   if (h->error == 2 || h->error == 3) return kChainNeedsHost;
   if (m->cfg.oope == SLAMHIP_OOPE_GMAPPING) {
     ctx->gm_cx = h->gm_cx;
@@ -573,6 +579,7 @@ struct HcBatch {
   char *h_stage = nullptr, *d_stage = nullptr;
   size_t stage_jobs_at = 0;
   slamhip::HcJobView *h_jobs = nullptr, *d_jobs = nullptr;  // pinned staging / HBM
+  bool resident_call = false;  // resident_wanted() of the call in flight, asked once
   double *h_inits = nullptr, *d_inits = nullptr;
   double *h_scan = nullptr, *d_scan = nullptr;  // the batch's scans: per match five arrays of its beam count
   size_t scan_cap = 0;                     // doubles
@@ -650,7 +657,10 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     // the sweep, the replay and the table are made once for two poses), but two workgroups per CU with a CU to spare
     // leave room for 20 instead of 21 round instances per chain at K = 8 and 10 instead of 10 at K = 16, where the
     // narrower workgroups' finer interleaving wins: pairs up to eight chains)
-    b->pair = n * (6 * want + 1) > 512 && n <= 8 && resident_wanted(m) && m->cfg.sum_order != SLAMHIP_SUM_SEQUENTIAL;
+    // (resident_wanted counts the matches towards its re-arm, so it is asked ONCE per call: the trees are sized
+    // for the form the call will run in)
+    b->resident_call = resident_wanted(m);
+    b->pair = n * (6 * want + 1) > 512 && n <= 8 && b->resident_call && m->cfg.sum_order != SLAMHIP_SUM_SEQUENTIAL;
     if (b->pair) want = std::min(kHcDefaultInst, std::max(1, (2 * (b->cus - 1) / n - 1) / 3));
     if (want != b->built_inst) {
       SLAMHIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -824,7 +834,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   // ---- ONE launch for the whole batch (hc_resident.hip) when all chains' workgroups fit the device at once: the
   // chains then advance independently -- no chain waits at a kernel boundary for the slowest one of its super-step
   b->ran_resident = false;
-  if (resident_wanted(m) && !a.seq) {
+  if (b->resident_call && !a.seq) {
     int cap_wgs = 0, per_cu = 0;
     const int res_nt = b->pair ? 512 : b->nt;
     const int res_wgs = n * (b->pair ? 3 * b->max_inst + 1 : 6 * b->max_inst + 1);
@@ -2101,17 +2111,21 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
     return SLAMHIP_ERR_HIP;
   }
 #endif
+  // (r06) the GMapping OOPE's checked default mode: a chain that met a comparison its sums cannot settle reports it
+  // before anything has been shown to an observer; the match is then redone below in the exact mode
+  bool force_exact = false;
   if (chain_eligible(m)) {
     int crc = kResidentGaveUp;
     if (resident_wanted(m)) crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob, true);
     if (crc == kResidentGaveUp) crc = chain_process_scan(m, map_id, init_pose, out_delta, out_prob, false);
-    if (crc != kChainNeedsHost) return crc;
+    if (crc == kChainUnsettled) force_exact = true;
+    else if (crc != kChainNeedsHost) return crc;
   }
-  if (mc_chain_eligible(m)) {
+  if (!force_exact && mc_chain_eligible(m)) {
     const int crc = mc_chain_process_scan(m, map_id, init_pose, out_delta, out_prob);
     if (crc != kChainNeedsHost) return crc;
   }
-  if (bf_device_eligible(m)) {
+  if (!force_exact && bf_device_eligible(m)) {
     const int crc = bf_device_process_scan(m, map_id, init_pose, out_delta, out_prob);
     if (crc != kChainNeedsHost) return crc;
   }
@@ -2119,69 +2133,136 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   // the reference's ONE cache object on the device and applies it pose after pose in CALL order -- so the poses have to be
   // scored in call order: one certain candidate per batch, no speculation, no replayed side outputs (the job runs as a
   // plain one; ctx->gm_* is kept by the scoring call itself).  Slow by design: the mode results are checked against.
-  const bool gm_exact = m->cfg.oope == SLAMHIP_OOPE_GMAPPING &&
-                        (m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL || m->cfg.pose_trig == SLAMHIP_POSE_TRIG_RAW_EXACT);
-  const bool gm = m->cfg.oope == SLAMHIP_OOPE_GMAPPING && !gm_exact;
-  const int budget = gm_exact ? 1 : (m->max_batch > 0 ? m->max_batch : 256);
-  int rc = ensure_pose_capacity(ctx, budget + 2);  // + the initial pose, + the best pose of a batch scored twice
-  if (rc) return rc;
-  m->t_stage_us = m->t_score_us = 0;
-  // the checked default mode of the host-driven batches (the device chain has its own, csrc/hc_chain.hip)
-  (void)tie_check_default(m);
-  const bool checked = m->tie_check == 1 && !gm && m->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->low_latency &&
-                       !ctx->stage_poses;
+  const bool gm_cfg = m->cfg.oope == SLAMHIP_OOPE_GMAPPING;
+  const bool gm_exact_cfg = gm_cfg && (m->cfg.sum_order == SLAMHIP_SUM_SEQUENTIAL || m->cfg.pose_trig == SLAMHIP_POSE_TRIG_RAW_EXACT);
+  // ... and its CHECKED default mode on the host-driven batches: a comparison on the walked path whose two scores lie
+  // within 2^-40 of each other (the canonical sum with the device's exp against the reference's beam-order sum with
+  // glibc's) ends the speculative run -- the enumerator and the cache go back to where the match started and the match
+  // is redone in the exact mode.  An observer's events of the speculative run are held back until it is known to stand
+  // (the device chains report their trace at the end of a match as well), so a redone match shows it ONE trace: the exact one
+  const bool gm_checked = gm_cfg && !gm_exact_cfg && tie_check_default(m);
+  std::unique_ptr<PoseEnumerator> pe_at_start;
+  if (gm_checked && !force_exact) pe_at_start = m->pe->clone();
+  const GmCarry carry_at_start{ctx->gm_cx, ctx->gm_cy, ctx->gm_prob};
+  struct BufferingObserver {  // holds a speculative run's events back until the run is known to stand
+    const slamhip_observer *to;
+    bool hold;
+    struct Ev {
+      int kind;
+      double p[3], s;
+    };
+    std::vector<Ev> held;
+    static void test(void *u, const double p[3], double s) {
+      auto *o = static_cast<BufferingObserver *>(u);
+      if (o->hold) o->held.push_back(Ev{0, {p[0], p[1], p[2]}, s});
+      else if (o->to->on_scan_test) o->to->on_scan_test(o->to->user, p, s);
+    }
+    static void update(void *u, const double p[3], double s) {
+      auto *o = static_cast<BufferingObserver *>(u);
+      if (o->hold) o->held.push_back(Ev{1, {p[0], p[1], p[2]}, s});
+      else if (o->to->on_pose_update) o->to->on_pose_update(o->to->user, p, s);
+    }
+    void flush() {
+      for (const Ev &e : held) {
+        if (e.kind == 0 && to->on_scan_test) to->on_scan_test(to->user, e.p, e.s);
+        if (e.kind == 1 && to->on_pose_update) to->on_pose_update(to->user, e.p, e.s);
+      }
+      held.clear();
+    }
+  } buffering{&m->obs, false, {}};
+  const slamhip_observer obs_wrap{&buffering, &BufferingObserver::test, &BufferingObserver::update, nullptr};
   m->chain_rescored = 0;
-  GmCarry carry;
-  carry.cx = ctx->gm_cx;
-  carry.cy = ctx->gm_cy;
-  carry.prob = ctx->gm_prob;
-  MatchJob &job = m->job;
-  job.start(m->pe.get(), Pose{init_pose[0], init_pose[1], init_pose[2]}, gm, m->has_obs ? &m->obs : nullptr,
-            carry, m->p_accept0);
-  while (!job.done) {
-    const int n = job.plan(budget, ctx->h_poses);
-    if (n == 0) break;
-    const double t0 = MatchJob::now_us();
-    unsigned seq = 0;
-    ctx->want_fprints = checked;
-    rc = score_staged(ctx, map_id, &m->cfg, n, nullptr, 0, &seq);
-    ctx->want_fprints = false;
+  m->t_stage_us = m->t_score_us = 0;
+  for (;;) {
+    const bool gm_exact = gm_exact_cfg || force_exact;
+    const bool gm = gm_cfg && !gm_exact;
+    slamhip_spe_cfg run_cfg = m->cfg;
+    if (force_exact) {
+      // the redo decides the way the REFERENCE would: beam-order sums, glibc's exp, and the reference's trigonometry --
+      // its default RawTrigonometryProvider (cos / sin(theta + a) per beam, restated) where the scan's angles are known
+      // to the context (slamhip_scan_set_angles / slamhip_scan_filter_upload), else the cached provider's angle addition
+      // with the host's sincos of the heading
+      run_cfg.sum_order = SLAMHIP_SUM_SEQUENTIAL;
+      run_cfg.pose_trig = (int)ctx->h_scan_angle.size() == ctx->scan_n ? SLAMHIP_POSE_TRIG_RAW_EXACT : SLAMHIP_POSE_TRIG_HOST;
+    }
+    const int budget = gm_exact ? 1 : (m->max_batch > 0 ? m->max_batch : 256);
+    int rc = ensure_pose_capacity(ctx, budget + 2);  // + the initial pose, + the best pose of a batch scored twice
     if (rc) return rc;
-    m->pe->idle_work();  // outcome-independent host work while the batch is on the GPU (MC: polar pairs)
-    rc = score_wait(ctx, seq);
-    if (rc) return rc;
-    m->t_score_us += MatchJob::now_us() - t0;
-    if (checked && job.ambiguous(ctx->h_scores, ctx->h_fprints)) {
-      // a comparison the tree sums cannot settle: the same batch (and the pose that is the best so far) once more,
-      // summed in the reference's beam order; those sums decide, the canonical sums stay what is reported
-      m->keep_scores.assign(ctx->h_scores, ctx->h_scores + n);
-      m->keep_fprints.assign(ctx->h_fprints, ctx->h_fprints + n);
-      ctx->h_poses[3 * n] = job.best.x;
-      ctx->h_poses[3 * n + 1] = job.best.y;
-      ctx->h_poses[3 * n + 2] = job.best.theta;
-      slamhip_spe_cfg seq_cfg = m->cfg;
-      seq_cfg.sum_order = SLAMHIP_SUM_SEQUENTIAL;
-      rc = score_staged(ctx, map_id, &seq_cfg, n + 1, nullptr, 0, &seq);
+    // the checked default mode of the host-driven batches (the device chain has its own, csrc/hc_chain.hip)
+    (void)tie_check_default(m);
+    const bool checked = m->tie_check == 1 && !gm_cfg && m->cfg.sum_order == SLAMHIP_SUM_TREE256 && ctx->low_latency &&
+                         !ctx->stage_poses;
+    GmCarry carry;
+    carry.cx = ctx->gm_cx;
+    carry.cy = ctx->gm_cy;
+    carry.prob = ctx->gm_prob;
+    MatchJob &job = m->job;
+    buffering.hold = gm && gm_checked && pe_at_start != nullptr;
+    job.start(m->pe.get(), Pose{init_pose[0], init_pose[1], init_pose[2]}, gm, m->has_obs ? &obs_wrap : nullptr,
+              carry, m->p_accept0);
+    bool redo = false;
+    while (!job.done) {
+      const int n = job.plan(budget, ctx->h_poses);
+      if (n == 0) break;
+      const double t0 = MatchJob::now_us();
+      unsigned seq = 0;
+      ctx->want_fprints = checked;
+      rc = score_staged(ctx, map_id, &run_cfg, n, nullptr, 0, &seq);
+      ctx->want_fprints = false;
       if (rc) return rc;
+      m->pe->idle_work();  // outcome-independent host work while the batch is on the GPU (MC: polar pairs)
       rc = score_wait(ctx, seq);
       if (rc) return rc;
-      ++m->chain_rescored;
-      m->rescored_poses += n + 1;
-      rc = job.consume(m->keep_scores.data(), ctx->h_gm_info, ctx, m->keep_fprints.data(), ctx->h_scores, ctx->h_scores[n]);
-    } else {
-      rc = job.consume(ctx->h_scores, ctx->h_gm_info, ctx, checked ? ctx->h_fprints : nullptr);
+      m->t_score_us += MatchJob::now_us() - t0;
+      if (gm && gm_checked && pe_at_start && job.gm_unsettled(ctx->h_scores, ctx->h_gm_info, ctx)) {
+        redo = true;
+        break;
+      }
+      if (checked && job.ambiguous(ctx->h_scores, ctx->h_fprints)) {
+        // a comparison the tree sums cannot settle: the same batch (and the pose that is the best so far) once more,
+        // summed in the reference's beam order; those sums decide, the canonical sums stay what is reported
+        m->keep_scores.assign(ctx->h_scores, ctx->h_scores + n);
+        m->keep_fprints.assign(ctx->h_fprints, ctx->h_fprints + n);
+        ctx->h_poses[3 * n] = job.best.x;
+        ctx->h_poses[3 * n + 1] = job.best.y;
+        ctx->h_poses[3 * n + 2] = job.best.theta;
+        slamhip_spe_cfg seq_cfg = m->cfg;
+        seq_cfg.sum_order = SLAMHIP_SUM_SEQUENTIAL;
+        rc = score_staged(ctx, map_id, &seq_cfg, n + 1, nullptr, 0, &seq);
+        if (rc) return rc;
+        rc = score_wait(ctx, seq);
+        if (rc) return rc;
+        ++m->chain_rescored;
+        m->rescored_poses += n + 1;
+        rc = job.consume(m->keep_scores.data(), ctx->h_gm_info, ctx, m->keep_fprints.data(), ctx->h_scores, ctx->h_scores[n]);
+      } else {
+        rc = job.consume(ctx->h_scores, ctx->h_gm_info, ctx, checked ? ctx->h_fprints : nullptr);
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
+    if (redo) {
+      // back to the start of the match, in the exact mode; the observer has been shown nothing yet
+      m->pe->assign(*pe_at_start);
+      pe_at_start.reset();
+      ctx->gm_cx = carry_at_start.cx;
+      ctx->gm_cy = carry_at_start.cy;
+      ctx->gm_prob = carry_at_start.prob;
+      buffering.held.clear();
+      force_exact = true;
+      continue;
+    }
+    buffering.flush();
+    if (force_exact) ++m->chain_rescored;  // (GMapping OOPE: matches redone in the exact mode)
+    if (gm) {
+      ctx->gm_cx = job.carry.cx;
+      ctx->gm_cy = job.carry.cy;
+      ctx->gm_prob = job.carry.prob;
+    }
+    job.delta(out_delta);
+    *out_prob = job.best_prob;
+    if (m->has_obs && m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, out_delta, job.best_prob);
+    return SLAMHIP_OK;
   }
-  if (gm) {
-    ctx->gm_cx = job.carry.cx;
-    ctx->gm_cy = job.carry.cy;
-    ctx->gm_prob = job.carry.prob;
-  }
-  job.delta(out_delta);
-  *out_prob = job.best_prob;
-  if (m->has_obs && m->obs.on_matching_end) m->obs.on_matching_end(m->obs.user, out_delta, job.best_prob);
-  return SLAMHIP_OK;
 }
 
 }  // extern "C"

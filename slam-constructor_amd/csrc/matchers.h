@@ -763,6 +763,24 @@ public:
     }
     return false;
   }
+  // Checked default mode over the GMapping OOPE (r06): would the walk over this batch meet a `best < candidate` whose
+  // two scores -- the cache applied in call order, on a copy -- lie within 2^-40 (relative) of each other?  The canonical
+  // sums with the device's exp cannot settle such a comparison the way the reference's beam-order sums with glibc's exp
+  // would (two zero scores are sums of zeros: settled).  Nothing is consumed.
+  bool gm_unsettled(const double *sc, const GmPoseInfo *gi, const slamhip_ctx *ctx) const {
+    GmCarry c = carry;
+    double b = first ? gm_apply_carry(c, gi[0], sc[0], ctx) : best_prob;
+    int node = tree.root;
+    while (node >= 0) {
+      const SpecTree::Node &nd = tree.nodes[node];
+      const double s = gm_apply_carry(c, gi[lead_ + nd.eval], sc[lead_ + nd.eval], ctx);
+      if (std::fabs(s - b) <= std::max(std::fabs(s), std::fabs(b)) * 9.094947017729282e-13 && !(s == 0.0 && b == 0.0)) return true;
+      const bool ok = b < s;
+      if (ok) b = s;
+      node = nd.child[ok ? 1 : 0];
+    }
+    return false;
+  }
   int planned() const { return planned_; }
   unsigned long long best_fp = 0;  // fingerprint of the best pose's term vector (checked default mode)
 

@@ -8,7 +8,9 @@
 namespace slamhip {
 
 // Most candidates a super-step speculates on: kMcPerLane per lane of the replaying wave, one short of 64 x 8 so that
-// candidates + the bookkeeping workgroup are 512 workgroups of 512 threads -- two on EVERY CU of an MI355X (r04 ran
+// candidates + the bookkeeping workgroup are 512 workgroups of 512 threads -- two on EVERY CU of an MI355X; the launch
+// itself keeps one CU's worth of workgroups spare (mc_resident_capacity, ADVICE r4: per_cu x (cus - 1), minus the
+// bookkeeping workgroup), so what runs on 256 CUs is 509 candidates + the bookkeeping workgroup (r04 ran
 // 384 + 1: half the CUs scored two poses per super-step and set the pace, the other half one; the extra 127
 // candidates cost no time per super-step and a Monte-Carlo chain is mostly long runs of rejections).
 constexpr int kMcPerLane = 8;

@@ -5,7 +5,8 @@
 //   PoseEnumerationScanMatcher::process_scan      src/core/scan_matchers/pose_enumeration_scan_matcher.h:31-77
 //   MonteCarloScanMatcher + GaussianPoseEnumerator src/core/scan_matchers/monte_carlo_scan_matcher.h:10-100
 //
-// The n_slots + 1 one-pose workgroups (511 candidates + the bookkeeping workgroup, 512 threads each: two on every CU)
+// The n_slots + 1 one-pose workgroups (at most 511 candidates + the bookkeeping workgroup, 512 threads each, two on a CU:
+// 509 + 1 on an MI355X, where the launch leaves one CU's worth of workgroups spare)
 // are launched ONCE and loop over the super-steps.  A workgroup scores its candidate of the current state (mc_chain.h's
 // closed forms: every candidate hangs off the same best pose under "all rejected so far"), publishes {score,
 // fingerprint, tag} as one 16-byte write-through granule, and its wave 0 gathers the granules of the candidates the

@@ -160,9 +160,17 @@ static int fill_args(slamhip_ctx *ctx, DeviceMap &m, const slamhip_spe_cfg *cfg,
   for (int k = 0; k < 4; ++k) a->map.unknown[k] = m.unknown[k];
   if (cfg->oope == SLAMHIP_OOPE_GMAPPING && m.cell_model == SLAMHIP_CELL_GMAPPING && m.bytes > 0 && cfg->gm_window == 1 &&
       m.width >= 3 && m.height >= 3) {  // (bytes: a dense window -- the view of a tile pool has none)
-    const int rc = map_nbr_masks(ctx, m, cfg->gm_fullness_th);
-    if (rc) return rc;
-    a->map.nbr_ok = 1;
+    // (the window holds the masks of ONE threshold.  A second scorer configuration with another threshold
+    // on the same map does not re-derive them -- a pass over the whole window and a stream stall per alternating call --:
+    // it takes the nine-cell form for its calls; the masks follow a threshold that stays, i.e. that asks twice in a row)
+    if (m.nbr_ok && m.nbr_th != cfg->gm_fullness_th && m.nbr_other_th != cfg->gm_fullness_th) {
+      m.nbr_other_th = cfg->gm_fullness_th;  // first call with this threshold: served without masks
+    } else {
+      const int rc = map_nbr_masks(ctx, m, cfg->gm_fullness_th);
+      if (rc) return rc;
+      m.nbr_other_th = m.nbr_th;
+      a->map.nbr_ok = 1;
+    }
   } else if (cfg->oope == SLAMHIP_OOPE_GMAPPING && m.cell_model == SLAMHIP_CELL_GMAPPING && m.bytes == 0 && cfg->gm_window == 1 &&
              m.nbr_ok && m.nbr_th == cfg->gm_fullness_th) {
     a->map.nbr_ok = 1;  // a tile pool whose owner derived the masks (tile_pool_nbr_masks)

@@ -179,6 +179,7 @@ struct DeviceMap {
   // neighbourhood masks in the cells' pads (MapView): valid for threshold nbr_th; built by map_nbr_masks()
   bool nbr_ok = false;
   double nbr_th = 0.0;
+  double nbr_other_th = 0.0;  // the last threshold a scorer asked for that was NOT the masks' (fill_args)
   // TBM maps: the PROBABILITY PLANE -- one double per cell = tbm_discrepancy_probability of the cell (r06, VERDICT r5
   // item 5).  The 1-cell scorers gather 8 bytes from it instead of the 32-byte cell and ~16 flops + a division per
   // (pose, beam); derived by the first scorer call that finds none (map_prob_plane), then kept by every writer: K6's

@@ -131,11 +131,18 @@ def test_masks_follow_every_writer(pkg, tctx, fresh):
     got = score(tctx, 0, cfg, poses)
     np.testing.assert_array_equal(got, scores_of_fresh_upload(pkg, fresh, tctx, 0, scan, cfg, poses, m.unknown))
 
-    # another threshold: the masks are derived again
+    # another threshold: its FIRST call is served by the nine-cell form (the window keeps the masks it has: two scorer
+    # configurations alternating on one map must not re-derive 0.5 GB of masks per call); a threshold that
+    # stays -- asks again -- takes the masks over.  The same scores all three ways.
     cfg2 = pkg.spe_cfg(oope=pkg.OOPE_GMAPPING, gm_th=0.5)
     got = score(tctx, 0, cfg2, poses)
     assert masks(tctx, 0) == (1, 0)
-    np.testing.assert_array_equal(got, scores_of_fresh_upload(pkg, fresh, tctx, 0, scan, cfg2, poses, m.unknown))
+    want2 = scores_of_fresh_upload(pkg, fresh, tctx, 0, scan, cfg2, poses, m.unknown)
+    np.testing.assert_array_equal(got, want2)
+    np.testing.assert_array_equal(score(tctx, 0, cfg, poses), scores_of_fresh_upload(pkg, fresh, tctx, 0, scan, cfg, poses, m.unknown))
+    for _ in range(2):
+        np.testing.assert_array_equal(score(tctx, 0, cfg2, poses), want2)
+        assert masks(tctx, 0) == (1, 0)
     tctx.map_release(0)
 
 
