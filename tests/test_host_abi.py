@@ -134,7 +134,8 @@ def test_shipped_library_exports_no_test_hooks():
     assert debug_syms(pkg.LIB_PATH) == []
     assert debug_syms(pkg.TESTING_LIB_PATH) == ["slamhip_debug_stall", "slamhip_gmapping_debug_fail",
                                                 "slamhip_gmapping_debug_nbr_masks", "slamhip_gmapping_debug_settle_states",
-                                                "slamhip_map_debug_nbr_masks",
+                                                "slamhip_map_debug_nbr_masks", "slamhip_map_debug_prob_plane",
+                                                "slamhip_matcher_debug_fail_next",
                                                 "slamhip_matcher_debug_resident_mute", "slamhip_matcher_debug_stamps",
                                                 "slamhip_matcher_debug_trace_cap"]
     # ... and everything include/slamhip.h declares is in both
