@@ -83,6 +83,19 @@ def test_default_bench_line_contract():
     # r05, second half: the GMapping legs after the neighbourhood masks, the settle states and
     # the pending plane -- likelihood step <= 0.50 ms, shared-map step <= 13.5 ms (13 asked for; boxes differ), cfg5 <= 7.5 ms
     assert pf["ms_per_step"] <= 0.50 and pf["with_map_update"]["ms_per_step"] <= 13.5 and c5["ms_per_step"] <= 7.5
+    # r06: cfg3 through the TBM probability plane -- a margin over 0.40 on the HIP-event clock (0.42 on
+    # rocprofv3's, profiles/r06_mc_leg_kernel_stats.csv) --; like beside like in the filter's CPU pairs; the weak-scaling
+    # model beside the strong one; frac_useful beside frac
+    assert mc["roofline"]["frac"] >= 0.44 and mc["roofline"]["avg_launch_us"] <= 118.0 and mc["roofline"]["probability_plane"] is True
+    assert mc["roofline"]["gather_bytes_per_unit"] == 32
+    assert "scan adder switched off" in pf["cpu_baseline"]["sample"] and pf["cpu_baseline"]["cores"] == 1
+    assert pf["with_map_update"]["steps"] >= 10 and pf["with_map_update"]["cpu_baseline"]["kind"] == "reference"
+    assert "map update inside the step" in pf["with_map_update"]["cpu_baseline"]["sample"]
+    assert pf["value"] / pf["cpu_baseline"]["value"] > 1000 and 50 < pf["with_map_update"]["value"] / pf["with_map_update"]["cpu_baseline"]["value"] < 300
+    wm = pf["weak_scaling_model"]["by_ranks"]
+    assert [m_["ranks"] for m_ in wm] == [1, 2, 4, 8] and [m_["particles"] for m_ in wm] == [100, 200, 400, 800]
+    assert wm[3]["predicted_particles_per_s"] > 6 * wm[0]["predicted_particles_per_s"]
+    assert 0.0 < d["roofline"]["frac_useful"] < d["roofline"]["frac"]
 
 
 @pytest.mark.skipif(not DEFAULT, reason="no committed bench line yet")
