@@ -278,6 +278,11 @@ def _leg_digest(leg, ms_key="ms_per_step"):
         out.update(_pick(r, ("frac", "frac_useful", "kernel", "avg_launch_us")))
     if "steps" in leg:
         out["steps"] = leg["steps"]
+    # what really binds the kernel, beside the algorithmic-bytes fraction (cache hits counted as bytes flatter it:
+    # VERDICT r5 "What's weak" 4): VALU issue share and measured HBM utilisation from the committed PMC passes
+    rv = leg.get("roofline_valu")
+    if isinstance(rv, dict):
+        out.update({k: rv[k] for k in ("valu_issue_frac", "hbm_utilisation") if rv.get(k) is not None})
     c = leg.get("cpu_baseline")
     if isinstance(c, dict) and "value" in c:
         out["cpu"] = _pick(c, ("value", "cores", "kind"))
@@ -311,6 +316,8 @@ def compact_line(full, detail_path=None):
     rs = full.get("roofline_sweep")
     if isinstance(rs, dict):
         out["roofline_sweep"] = _pick(rs, ("achieved", "frac", "kernel", "avg_launch_us", "poses_per_launch"))
+        if isinstance(rs.get("valu"), dict):
+            out["roofline_sweep"].update({k: rs["valu"][k] for k in ("valu_issue_frac", "hbm_utilisation") if rs["valu"].get(k) is not None})
     c = _cpu_digest(full.get("cpu_baseline"))
     if c is not None:
         out["cpu_baseline"] = c

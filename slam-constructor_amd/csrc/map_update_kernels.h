@@ -850,6 +850,13 @@ __global__ void k_mu_rank(MuArgs a, const uint2 *srec, const unsigned *offs, uns
   srt_prob[at] = pq.x;
 }
 
+// NO_CONFLICT (r06): the caller has established l3 = r3 = +-0 and finite, non-negative masses on both sides -- a cell's
+// own conflict is +0 after every update (normalize_conflict, tbm_grid_cells.h:15-16) and an observation's always is
+// (aoo2tbm, :57-66).  Seven of the conflict mass's nine products are then +-0 and adding them changes nothing (x + (+-0) =
+// x for the non-negative partial sums here), so t3 = fl(fl(l1 r2) + fl(l2 r1)): the same bits, ONE dependent addition
+// instead of eight -- the longest chain of the update.  (Tested per update inside the chain the shortcut LOST: 378 -> 460
+// us for the robot cell's 1080 updates; established once per 64 updates by mu_wave_apply it is free.)
+template <bool NO_CONFLICT = false>
 __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs, double *out) {
   // tmp[i | j] += lhs[i] * rhs[j] for i, j = 0..3 in that order (transferable_belief_model.h:102-143), written out
   // per target so that nothing is indexed dynamically (the loop form left 24 bytes of scratch per lane)
@@ -858,7 +865,9 @@ __device__ __forceinline__ void mu_tbm_conj(const double *lhs, const double *rhs
   const double t0 = 0.0 + l0 * r0;
   const double t1 = ((0.0 + l0 * r1) + l1 * r0) + l1 * r1;
   const double t2 = ((0.0 + l0 * r2) + l2 * r0) + l2 * r2;
-  const double t3 = ((((((((0.0 + l0 * r3) + l1 * r2) + l1 * r3) + l2 * r1) + l2 * r3) + l3 * r0) + l3 * r1) + l3 * r2) + l3 * r3;
+  double t3;
+  if (NO_CONFLICT) t3 = l1 * r2 + l2 * r1;
+  else t3 = ((((((((0.0 + l0 * r3) + l1 * r2) + l1 * r3) + l2 * r1) + l2 * r3) + l3 * r0) + l3 * r1) + l3 * r2) + l3 * r3;
   const double tot = t0 + t1 + t2 + t3;
   if (tot == 0.0) {
     out[0] = 1.0;
@@ -879,6 +888,30 @@ struct MuCell {
   unsigned pn;  // pending observations that mu_cell_load folded into x1 (a pool's cells: MuArgs::pend)
 };
 
+// TbmBaseCell::operator+= (tbm_grid_cells.h:12-19): conjunctive combination with the observation's belief, then
+// normalize_conflict.  NO_CONFLICT: see mu_tbm_conj -- the caller vouches for a zero conflict mass and finite,
+// non-negative masses of the cell and the observation (which the update preserves: quotients of non-negative sums).
+template <bool NO_CONFLICT>
+__device__ __forceinline__ void mu_step_tbm(double quality, MuCell &c, double prob, double qual) {
+  if (!NO_CONFLICT && (isnan(prob) || isnan(qual))) return;
+  const double eq = qual * quality;
+  const double occupied = prob * eq, empty = (1 - prob) * eq;
+  const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
+  const double cur[4] = {c.c0, c.c1, c.c2, c.c3};
+  double nb[4];
+  mu_tbm_conj<NO_CONFLICT>(cur, that, nb);
+  const double weight = nb[0] + nb[1] + nb[2];
+  if (weight == 0.0) {
+    c.c0 = 1.0;
+    c.c1 = c.c2 = c.c3 = 0.0;
+  } else {
+    c.c0 = nb[0] / weight;
+    c.c1 = nb[1] / weight;
+    c.c2 = nb[2] / weight;
+    c.c3 = 0.0;
+  }
+}
+
 // one observation applied to one cell: the reference's `cell += aoo` for the five cell kinds
 // (GridCell grid_cell.h:27-30, AffineQualityMergeCell / MeanProbabilityCell naive_grid_cells.h:14-20,33-40,
 // TbmBaseCell tbm_grid_cells.h:57-66, GmappingBaseCell gmapping_grid_cell.h:20-33).  `qual` is read for
@@ -898,23 +931,7 @@ __device__ __forceinline__ void mu_step(double quality, MuCell &c, double prob, 
     c.c0 = (c.c0 * c.x0 + that_p) / n1;
     c.x0 = n1;
   } else if (RULE == 3) {  // TbmBaseCell
-    if (isnan(prob) || isnan(qual)) return;
-    const double eq = qual * quality;
-    const double occupied = prob * eq, empty = (1 - prob) * eq;
-    const double that[4] = {1.0 - occupied - empty, empty, occupied, 0.0};
-    const double cur[4] = {c.c0, c.c1, c.c2, c.c3};
-    double nb[4];
-    mu_tbm_conj(cur, that, nb);
-    const double weight = nb[0] + nb[1] + nb[2];
-    if (weight == 0.0) {
-      c.c0 = 1.0;
-      c.c1 = c.c2 = c.c3 = 0.0;
-    } else {
-      c.c0 = nb[0] / weight;
-      c.c1 = nb[1] / weight;
-      c.c2 = nb[2] / weight;
-      c.c3 = 0.0;
-    }
+    mu_step_tbm<false>(quality, c, prob, qual);
   } else {  // GmappingBaseCell: x0 = _hits, x1 = _tries
     if (isnan(prob)) return;
     const double tries = c.x1 + 1;
@@ -1230,6 +1247,13 @@ __device__ __forceinline__ double mu_refined_rcp(double y) {
   const double f2 = __builtin_fma(-y, r1, 1.0);
   return __builtin_fma(r1, f2, r1);
 }
+// x / y from y's refined reciprocal with NO scaling or fix-up step: exact where those steps do nothing (the callers
+// establish the operand ranges; tools/probes/div_probe.hip, tbm_div_probe.hip)
+__device__ __forceinline__ double mu_div_nofix(double x, double y, double r) {
+  const double q = x * r;
+  const double e = __builtin_fma(-y, q, x);
+  return __builtin_fma(e, r, q);
+}
 __device__ __forceinline__ bool mu_div_safe(double x) {
   const double ax = fabs(x);
   return ax > 0x1p-500 && ax < 0x1p500;
@@ -1308,6 +1332,61 @@ __device__ __forceinline__ void mu_wave_apply(const MuArgs &a, MuCell &c, int la
         c.x0 = n1;
         r = r_next;
       }
+    }
+  }
+  if (RULE == 3) {
+    // TbmBaseCell chains (r06).  The robot's own cell takes one update per beam -- 1080 of them, one after the other,
+    // 350 ns each: conjunctive combination (the conflict mass alone eight dependent additions), normalize (four
+    // divisions by the total), normalize_conflict (three by the weight).  A round of up to 64 observations first
+    // establishes, each lane looking at its own observation and all at the cell,
+    //   * observation: unknown mass >= 0.5, empty and occupied mass +0 or in [2^-40, 1] (aoo2tbm of any probability and
+    //     quality in [0, 1] with quality <= 0.5), conflict +0 by construction;
+    //   * cell: conflict +-0 ... +0, the other masses +0 or in [2^-300, 2], their sum in [0.5, 2];
+    // which every update of the round preserves well enough (a mass shrinks by at most ~2^-2.2 per update: 2^-141 over a
+    // round; sums stay within a few ulps of 1 after the first) for the round to run WITHOUT per-update tests:
+    //   * conflict mass t3 = fl(fl(l1 r2) + fl(l2 r1)): seven of its nine products are +0 and adding +0 to a
+    //     non-negative sum changes nothing -- the same bits, one dependent addition (the leading `0.0 +` of every mass
+    //     likewise);
+    //   * the quotients from two reciprocals refined ahead, q = x r, e = fma(-y, q, x), q' = fma(e, r, q) -- the IEEE
+    //     division sequence without its scaling and fix-up steps, which do nothing for numerators 0 or >= 2^-600 over
+    //     denominators in [0.2, 2.5] (tools/probes/tbm_div_probe.hip: 33.5 M divisions, all bit-equal); total and weight
+    //     are >= 0.45 here, so neither the `== 0` branches nor the unused fourth quotient (the conflict share) exist.
+    // Anything else takes mu_step's plain form below.  (The same tests made PER UPDATE lost: 378 -> 460 us for the robot's
+    // cell; per round they are free: 378 -> 329 with the conflict shortcut alone, -> LOG r06 with the quotients.)
+    const double qmine = (kReadsQuality && a.beam_quality) ? ql : a.quality;
+    const double eq = q * qmine;
+    const double occupied = p * eq, empty = (1 - p) * eq, unknown = 1.0 - occupied - empty;
+    auto zero_or = [](double x, double lo, double hi) { return __double_as_longlong(x) == 0ll || (x >= lo && x <= hi); };
+    const bool obs_ok = !in || (unknown >= 0.5 && unknown <= 1.0 && zero_or(empty, 0x1p-40, 1.0) && zero_or(occupied, 0x1p-40, 1.0));
+    const double csum = (c.c0 + c.c1) + c.c2;
+    const bool cell_ok = __double_as_longlong(c.c3) == 0ll && zero_or(c.c0, 0x1p-300, 2.0) && zero_or(c.c1, 0x1p-300, 2.0) &&
+                         zero_or(c.c2, 0x1p-300, 2.0) && csum >= 0.5 && csum <= 2.0;
+    if (__all(obs_ok) && cell_ok) {  // (cell_ok is wave-uniform: every lane holds the same cell state)
+      double l0 = c.c0, l1 = c.c1, l2 = c.c2;
+      for (; t < n_here; ++t) {
+        const double qt = (kReadsQuality && a.beam_quality) ? mu_readlane(ql, t) : a.quality;
+        const double pt = mu_readlane(p, t);
+        const double eqt = mu_readlane(q, t) * qt;
+        const double r2 = pt * eqt, r1 = (1 - pt) * eqt;
+        const double r0 = 1.0 - r2 - r1;
+        const double t0 = l0 * r0;
+        const double t1 = (l0 * r1 + l1 * r0) + l1 * r1;
+        const double t2 = (l0 * r2 + l2 * r0) + l2 * r2;
+        const double t3 = l1 * r2 + l2 * r1;
+        const double tot = t0 + t1 + t2 + t3;
+        const double rt = mu_refined_rcp(tot);
+        const double n0 = mu_div_nofix(t0, tot, rt), n1 = mu_div_nofix(t1, tot, rt), n2 = mu_div_nofix(t2, tot, rt);
+        const double weight = n0 + n1 + n2;
+        const double rw = mu_refined_rcp(weight);
+        l0 = mu_div_nofix(n0, weight, rw);
+        l1 = mu_div_nofix(n1, weight, rw);
+        l2 = mu_div_nofix(n2, weight, rw);
+      }
+      c.c0 = l0;
+      c.c1 = l1;
+      c.c2 = l2;
+      c.c3 = 0.0;
+      return;
     }
   }
   while (t < n_here) {

@@ -413,3 +413,58 @@ def test_queued_updates_equal_awaited_updates(pkg, ctx, name):
     ctx.map_set_deferred(False)
     ctx.map_release(3)
     ctx.map_release(4)
+
+
+@pytest.mark.parametrize("path", list(K6_PATHS))
+def test_long_tbm_chains_through_every_regime_vs_oracle(pkg, ctx, path):
+    """r06: a TbmBaseCell chain of a wave's round (up to 64 observations of one cell, mu_wave_apply) runs WITHOUT per-update
+    tests once the round has established a zero conflict mass, observation unknown >= 0.5 and masses away from the
+    subnormal range -- the conflict mass as one addition, the seven quotients of normalize / normalize_conflict from two
+    reciprocals refined ahead (no scaling, no fix-up: tools/probes/tbm_div_probe.hip).  Here the robot's own cell and its
+    neighbours take ~1000 updates per scan, scan after scan from ONE pose, through every regime the tests separate:
+      * small qualities (the fast round), the unknown mass decaying geometrically -- 0.955^n: below 2^-300 after ~4500
+        updates, where the round hands over to the plain form, and on through the subnormals to an exact zero;
+      * qualities above 0.5 (observation unknown < 0.5: the plain form from the start);
+      * occupied and empty observations mixed on the same cells (a conflict share in every update), a beam quality per
+        point, an uploaded cell that carries a conflict mass and one with a negative zero.
+    After every scan: all four belief masses of every cell, bit for bit with the oracle's (map_update_oracle.c)."""
+    import pyoracle as po
+    from pyoracle_mapupdate import RULE_TBM, append_scan_q
+    set_k6_path(pkg, ctx, path)
+    O = po.Oracle()
+    size = 120
+    unknown = [1.0, 0.0, 0.0, 0.0]
+    payload = np.empty((size, size, 4))
+    payload[:] = unknown
+    rs = np.random.RandomState(17)
+    # a few cells near the robot start from something else: a conflict mass, a negative zero, a tiny mass
+    payload[60, 61] = [0.2, 0.3, 0.4, 0.1]
+    payload[61, 60] = [1.0, -0.0, 0.0, 0.0]
+    payload[59, 60] = [1e-200, 0.5, 0.5 - 1e-200, 0.0]
+    m = po.GridMapData(1, payload, (size // 2, size // 2), SCALE, unknown)
+    ctx.upload_map(3, m)
+    n = 1000
+    ang = np.linspace(-np.pi, np.pi, n, endpoint=False)
+    pose = np.array([SCALE / 2, SCALE / 2, 0.3])
+    c, s = pkg.beam_trig(ang)
+    regimes = [("small qualities", (0.95, 0.04, 0.01, 0.045), 1.0, 12), ("high quality", (0.95, 0.9, 0.01, 0.8), 1.0, 2),
+               ("mid", (0.9, 0.45, 0.05, 0.5), 1.0, 3), ("small again", (0.95, 0.04, 0.01, 0.045), 1.0, 6)]
+    k = 0
+    for name, base, quality, scans in regimes:
+        for _ in range(scans):
+            rng = 0.3 + 2.5 * rs.rand(n)  # end points at every distance: hits and passes mix on the cells around the robot
+            occ = (rs.rand(n) < 0.8).astype(np.int32)
+            bq = rs.uniform(0.5, 1.0, n) if k % 3 == 2 else None
+            tr = po.ScanData(rng, np.arange(n, dtype=np.float64), None, None, po.TRIG_CACHED, 0.0, 1.0, s, c)
+            nu_o = append_scan_q(O, m, None, RULE_TBM, pose, rng, tr.angle, bq if bq is not None else np.ones(n), occ,
+                                 quality=quality, base=base, blur=0.05, trig=tr)
+            nu = ctx.map_append_scan(3, pkg.RULE_TBM, pose, rng, c, s, occ, quality=quality, base=base, blur=0.05,
+                                     beam_quality=bq)
+            assert nu == nu_o
+            got = ctx.map_download_window(3, 0, 0, size, size, 4)
+            bad = np.nonzero(got.view(np.uint64) != m.payload.view(np.uint64))
+            assert len(bad[0]) == 0, (name, k, bad[0][:4], bad[1][:4], got[bad][:4], m.payload[bad][:4])
+            k += 1
+    robot = m.payload[60, 60]
+    assert robot[3] == 0.0 and robot[0] < 1e-60 and abs(robot.sum() - 1.0) < 1e-12  # (the unknown mass did decay)
+    ctx.map_release(3)
