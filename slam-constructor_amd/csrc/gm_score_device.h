@@ -29,9 +29,14 @@ constexpr size_t kGmHelperDoubles = NT >= 512 ? (size_t)NT : 0;
 // the whole kernel, and the compiler parked two of its doubles in SCRATCH (24 bytes per lane written at
 // entry and read back before the gathers: the kernel's only scratch, 1.7 MB of HBM writes per launch).
 // value of a window whose smallest squared distance to a full cell's obstacle mean is best_d2 (any: there is one)
+// (r06, measured and left alone: glibc's exp restated -- csrc/libm_exact.h, a 128-entry table + a degree-5 polynomial, fewer
+// instructions than the device library's generic exp and the reference's bits per beam -- made the phase SLOWER: its table
+// gather is one more dependent load per beam; lone chain phase A 3.56 -> 3.67 us, 100-particle step 0.450 -> 0.475 ms.
+// The exact modes use it, exact_kernels.hip; the fast paths keep the device's exp.)
+__device__ __forceinline__ double gm_exp(double x) { return exp(x); }
 __device__ __forceinline__ double gm_value_of(double best_d2, bool any) {
   if (!any) return 0.0;
-  const double similarity = exp(-best_d2 / 0.05);
+  const double similarity = gm_exp(-best_d2 / 0.05);
   const double r = 1.0 - (1.0 - similarity);
   return 0.0 < r ? r : 0.0;
 }
@@ -304,7 +309,7 @@ __device__ __forceinline__ double gm_fresh_value(const MapView &m, const double 
     }
   }
   if (!any) return 0.0;
-  const double similarity = exp(-best_d2 / 0.05);
+  const double similarity = gm_exp(-best_d2 / 0.05);
   const double v = 1.0 - (1.0 - similarity);
   return 0.0 < v ? v : 0.0;
 }
