@@ -1491,8 +1491,10 @@ int slamhip_score_poses_device(slamhip_ctx *ctx, int map_id, const slamhip_spe_c
   if (rc) return rc;
   if (n_poses <= 0) return SLAMHIP_OK;
   if (!d_poses_xyt || !d_scores_out) return invalid("null device buffers");
-  if (cfg->pose_trig == SLAMHIP_POSE_TRIG_HOST)
-    return invalid("device-resident poses use device sincos (pose_trig = DEVICE)");
+  if (cfg->pose_trig != SLAMHIP_POSE_TRIG_DEVICE)
+    return invalid("device-resident poses use device sincos (pose_trig = DEVICE): the host-trig and exact modes take host poses");
+  if (cfg->oope == SLAMHIP_OOPE_GMAPPING && cfg->sum_order == SLAMHIP_SUM_SEQUENTIAL)
+    return invalid("the GMapping OOPE's beam-order mode keeps the reference's cache in call order: slamhip_score_poses");
   SLAMHIP_CHECK(hipSetDevice(ctx->device));
   ScoreArgs a;
   rc = fill_args(ctx, *m, cfg, n_poses, d_poses_xyt, nullptr, d_scores_out, &a);
