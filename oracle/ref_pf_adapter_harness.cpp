@@ -125,7 +125,8 @@ void *refpf_create(unsigned n, int w, int h, double scale, const double *gp, con
   c.filter.sp_max_usable_range = -1.0;
   c.filter.oope_fullness_th = 0.1;
   c.filter.oope_window = 1;
-  c.filter.pose_trig = strict ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_DEVICE;
+  // strict 2 (r06): the reference's default raw trig provider and its exp bit for bit (SLAMHIP_POSE_TRIG_RAW_EXACT)
+  c.filter.pose_trig = strict == 2 ? SLAMHIP_POSE_TRIG_RAW_EXACT : (strict ? SLAMHIP_POSE_TRIG_HOST : SLAMHIP_POSE_TRIG_DEVICE);
   c.adder.rule = SLAMHIP_RULE_GMAPPING;
   c.adder.scan_quality = 1.0;
   c.adder.base_occupied_prob = 0.95;

@@ -135,3 +135,37 @@ def test_world_adapter_runs_with_particle_maps(lib):
             assert np.count_nonzero(occ != -1.0) > 1000
     finally:
         lib.refpf_destroy(pair)
+
+
+def test_world_adapter_in_the_exact_mode_is_the_reference_filter_bit_for_bit(lib):
+    """r06: the adapter world with `pose_trig = SLAMHIP_POSE_TRIG_RAW_EXACT` -- the reference's default raw trig provider and
+    its exp restated on the device, the shared map updated through the host's own libm -- next to the reference's
+    GmappingParticleFilter, live, on the same scans: every particle's pose and weight, World::pose() and the occupancy
+    of World::map() after every scan, assert_array_equal (the fast modes above: 1e-10 / 1e-9)."""
+    g = load("gmapping_pf_update.npz")
+    n = len(g["seeds"])
+    w, h = [int(v) for v in g["size"]]
+    gp = np.ascontiguousarray(g["gp"], dtype=np.float64)
+    seeds = np.ascontiguousarray(g["seeds"], dtype=np.uint32)
+    pair = lib.refpf_create(n, w, h, float(g["scale"]), _d(gp), seeds.ctypes.data_as(_up), 3, 0, 2)
+    assert pair
+    try:
+        for k in range(int(g["n_steps"])):
+            r = np.ascontiguousarray(g["step%d_range" % k])
+            a = np.ascontiguousarray(g["step%d_angle" % k])
+            d = g["step%d_delta" % k]
+            extra = np.arange(9000 + 100 * k, 9000 + 100 * k + n, dtype=np.uint32)
+            rp, rw, hp, hw = np.zeros((n, 3)), np.zeros(n), np.zeros((n, 3)), np.zeros(n)
+            wp, fl = np.zeros(6), np.zeros(4, np.int32)
+            lib.refpf_step(pair, r.size, _d(r), _d(a), d[0], d[1], d[2], 7 + k, n, extra.ctypes.data_as(_up),
+                           _d(rp), _d(rw), _d(hp), _d(hw), _d(wp), fl.ctypes.data_as(_ip))
+            assert fl[0] == fl[1] == int(g["step%d_resampled" % k])
+            np.testing.assert_array_equal(hp, rp)
+            np.testing.assert_array_equal(hw, rw)
+            np.testing.assert_array_equal(wp[3:], wp[:3])
+            occ_ref, occ_hip = np.zeros((h, w)), np.zeros((h, w))
+            lib.refpf_map_occupancy(pair, 0, -w // 2, -h // 2, w, h, _d(occ_ref))
+            lib.refpf_map_occupancy(pair, 1, -w // 2, -h // 2, w, h, _d(occ_hip))
+            np.testing.assert_array_equal(occ_hip, occ_ref)
+    finally:
+        lib.refpf_destroy(pair)
