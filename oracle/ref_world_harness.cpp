@@ -34,8 +34,11 @@ namespace {
 // preset 1: config/slams/viny_slam_base.properties
 // presets 2, 3: the same two with the `ahr` observation quality estimator (AngleHistogramResiprocalOMQE,
 // init_occupancy_mapping.h:64-80 -- the key really is ".../typetype")
+// presets 4, 5: presets 0, 1 with slam/occupancy_estimator/type = area (init_occupancy_mapping.h:38-62)
 void fill_props(MapPropertiesProvider &p, int preset, int matcher, unsigned seed, int strict, double size_m) {
   auto S = [&](const char *k, const std::string &v) { p.set_property(k, v); };
+  const bool area = preset >= 4;  // presets 4, 5: tinySLAM / vinySLAM with the AreaOccupancyEstimator (see below)
+  if (area) preset -= 4;
   if (preset >= 2) {
     S("slam/mapping/observation_quality_estimator/typetype", "ahr");
     preset -= 2;
@@ -61,6 +64,9 @@ void fill_props(MapPropertiesProvider &p, int preset, int matcher, unsigned seed
     S("slam/mapping/raw_pose_quality", "0.6");
     S("slam/scmtch/spe/wmpp/weighting/type", "viny");
   }
+  // (the occupancy a beam leaves in a cell is then a continuous function of the beam's end point, i.e. of
+  // cos / sin(pose heading + beam angle): only the reference's libm bits keep the map bit-equal)
+  if (area) S("slam/occupancy_estimator/type", "area");
   S("slam/mapping/grid/type", "unbounded_plain");
   S("slam/map/height_in_meters", std::to_string(size_m));
   S("slam/map/width_in_meters", std::to_string(size_m));

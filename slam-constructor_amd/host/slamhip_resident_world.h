@@ -36,6 +36,7 @@ public:
     int tbm_kind = 0;  // TBM cells: 0 tbm_consistent, 1 tbm_unknown_even_occ (what map() reports as occupancy)
     int omqe = 0;      // observation quality estimator (init_omqe): 0 idle, 1 ahr (AngleHistogramResiprocalOMQE)
     HipScanTrig trig{};
+    bool raw_exact = false;  // slam/scmtch/hip/strict with the raw trig provider: see handle_observation
   };
   HipResidentWorld(slamhip_ctx *ctx, std::shared_ptr<HipGridScanMatcher> gsm, const Config &cfg)
       : _ctx{ctx}, _gsm{std::move(gsm)}, _cfg{cfg} {
@@ -114,8 +115,15 @@ public:
     const RobotPose p = pose();
     const double p3[3] = {p.x, p.y, p.theta};
     long long nu = 0;
-    slamhip_or_die(slamhip_map_append_scan_q(_ctx, _cfg.map_id, &adder, p3, n, r.data(), c.data(), s.data(), occ.data(),
-                                             _cfg.omqe ? q.data() : nullptr, &nu), "map_append_scan");
+    // strict with the raw provider (the reference's default): the scan adder's end points are cos / sin(theta + a) by the
+    // host's libm, the reference's bits -- what the area estimator's occupancies and TBM / GMapping payloads depend on
+    // continuously (slamhip_map_append_scan_raw); else the provider's table and the cached provider's angle addition
+    if (_cfg.raw_exact && _cfg.trig.mode != SLAMHIP_TRIG_CACHED)
+      slamhip_or_die(slamhip_map_append_scan_raw(_ctx, _cfg.map_id, &adder, p3, n, r.data(), a.data(), occ.data(),
+                                                 _cfg.omqe ? q.data() : nullptr, &nu), "map_append_scan_raw");
+    else
+      slamhip_or_die(slamhip_map_append_scan_q(_ctx, _cfg.map_id, &adder, p3, n, r.data(), c.data(), s.data(), occ.data(),
+                                               _cfg.omqe ? q.data() : nullptr, &nu), "map_append_scan");
     if (nu > 0) _cell_updates += nu;  // (-1: queued, counted by cell_updates())
     _view->invalidate();
   }
@@ -185,6 +193,7 @@ inline std::shared_ptr<HipResidentWorld> init_hip_resident_1h_slam(const Propert
   cfg.adder.blur = props.get_dbl("slam/mapping/blur", 0.0);
   cfg.adder.max_range = props.get_dbl("slam/mapping/max_range", std::numeric_limits<double>::infinity());
   cfg.adder.scan_quality = 1.0;
+  cfg.raw_exact = props.get_bool(Slam_SM_NS + "hip/strict", false) && !props.get_bool(Slam_SM_NS + "hip/trig_cache", false);
   auto gsm = std::dynamic_pointer_cast<HipGridScanMatcher>(init_hip_scan_matcher(props, ctx, map_id));
   gsm->set_resident_map(true);
   return std::make_shared<HipResidentWorld>(ctx, gsm, cfg);

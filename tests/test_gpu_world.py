@@ -106,3 +106,26 @@ def test_resident_world_without_observers_filters_the_raw_scan_itself(lib, prese
 def test_resident_world_longer_run(lib):
     r, _ = run_resident(lib, 1, 1, 0, n_scans=30, n_beams=720)
     assert r["pose_mis"] == 0 and r["cell_mis"] == 0 and r["ref_calls"] == r["hip_calls"] and r["view_mis"] == 0
+
+
+@pytest.mark.parametrize("preset,matcher", [(4, 0), (5, 1), (5, 0)])
+def test_resident_world_area_estimator_strict_is_the_reference_bit_for_bit(lib, preset, matcher):
+    """r06: the AreaOccupancyEstimator's occupancy is a continuous function of a beam's end point -- of
+    cos / sin(pose heading + beam angle), which the reference's RawTrigonometryProvider takes from libm per point
+    (trigonometry_utils.h:17-35) and which the device's angle addition reproduces only to the last place or two.  A
+    strict resident world therefore hands the map update the host libm's values (slamhip_map_append_scan_raw): same
+    trajectory and same payloads as the reference's world, assert-equal, with this estimator too.  (Default mode, for
+    the record: printed below.)"""
+    r, poses = run_resident(lib, preset, matcher, 1)
+    assert r["ref_calls"] > 12 * 20 and np.ptp(poses[:, 1]) > 0.5 and r["cell_updates"] > 12 * 360 * 10
+    assert r["ref_calls"] == r["hip_calls"] and r["ref_acc"] == r["hip_acc"]
+    assert r["pose_mis"] == 0, "trajectories differ by up to %g" % r["worst_pose"]
+    assert r["cells"] == r["ref_w"] * r["ref_h"]
+    assert r["cell_mis"] == 0, "final maps differ in %d cells (max %g)" % (r["cell_mis"], r["worst_payload"])
+    assert r["view_mis"] == 0
+    d, _ = run_resident(lib, preset, matcher, 0)
+    print("default mode, area estimator: pose_mis %d cell_mis %d of %d worst %g" % (d["pose_mis"], d["cell_mis"], d["cells"],
+                                                                                  d["worst_payload"]))
+    # (measured: same trajectory, ~1 cell in 7 differs, most in the last places; the estimator is not continuous where a
+    # last place moves an end point over a cell edge -- worst 0.03 -- so no bound is asserted: strict is the claim here)
+    assert d["ref_calls"] > 12 * 20
