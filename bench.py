@@ -281,6 +281,7 @@ def main():
         beams_of = [s_["range"].size for s_ in scenes]
         step_i = [0]
         evaluated, plain_calls, super_steps = [0], [0], [0]
+        closed_calls, closed_units = [0], [0]  # scorer calls (x beams) the chain reported in closed form (the inert tail)
         # The timed step is the reference's process_scan (pose_enumeration_scan_matcher.h:31-77): the RAW scan comes in
         # from host memory, filter_scan (:38), the scan-point weights, the beam trigonometry and the copy to HBM are
         # INSIDE the step (slamhip_scan_filter_upload), then the match.  (`--resident-scan`: the r01-r03 form, the
@@ -297,11 +298,13 @@ def main():
         def account(k, kept):
             if k not in per_scene_stats or kind != "HC":  # (a Monte-Carlo matcher's engine runs on: no table)
                 st_ = m.stats()
-                per_scene_stats[k] = (st_["scorer_calls"], st_["poses_evaluated"], st_["launches"])
-            c_, e_, l_ = per_scene_stats[k]
+                per_scene_stats[k] = (st_["scorer_calls"], st_["poses_evaluated"], st_["launches"], st_["calls_closed_form"])
+            c_, e_, l_, t_ = per_scene_stats[k]
             evaluated[0] += e_
             plain_calls[0] += c_
             super_steps[0] += l_
+            closed_calls[0] += t_
+            closed_units[0] += t_ * kept
             return c_ * kept
 
         def step_resident():
@@ -329,6 +332,7 @@ def main():
     if m is not None:
         step_i[0] = 0
         evaluated[0] = plain_calls[0] = super_steps[0] = 0
+        closed_calls[0] = closed_units[0] = 0
     # Pass 1 -- the timed region: exactly K steps, no instrumentation.
     ctx.profile_enable(False)
     barrier()
@@ -345,6 +349,8 @@ def main():
         print("step_ms:", " ".join("%.3f" % x for x in step_ms), file=sys.stderr)
     timed_evaluated, timed_calls = (evaluated[0], plain_calls[0]) if m is not None else (0, 0)
     timed_super_steps = super_steps[0] if m is not None else 0
+    timed_closed_calls, timed_closed_units = (closed_calls[0], closed_units[0]) if m is not None else (0, 0)
+    units_timed_scored = calls - timed_closed_units  # (matcher steps return calls x beams)
     if m is not None:
         k_last = (step_i[0] - 1) % len(scenes)
         st_chk = m.stats()
@@ -378,6 +384,23 @@ def main():
         ms_other = 1e3 * (time.perf_counter() - t2) / args.steps
         extra.update(includes_filter_and_upload=not args.resident_scan,
                      **{"ms_per_step_raw_scan_in" if args.resident_scan else "ms_per_step_resident": ms_other})
+        if kind == "HC" and timed_closed_calls > 0:
+            # the same K steps with SLAMHIP_OPT_INERT_TAIL off: every scorer call of the tail scored, as in r01 - r05
+            ctx.set_option(pkg.OPT_INERT_TAIL, 0)
+            try:
+                for _ in range(len(scenes)):
+                    step()
+                barrier()
+                t3 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                barrier()
+                extra["ms_per_step_every_call_scored"] = 1e3 * (time.perf_counter() - t3) / args.steps
+            finally:
+                ctx.set_option(pkg.OPT_INERT_TAIL, 1)
+            per_scene_stats.clear()
+            for _ in range(len(scenes)):
+                step()
         # ---- parity gate on the benchmarked inputs (outside every timed region): the result of every rotating scene
         # through the timed path against what the CPU baseline's reference run returned for the same scene
         want = (cpu_out or {}).pop("_per_scene", None) if rank == 0 else None
@@ -414,6 +437,13 @@ def main():
                             % len(scenes),
                      ms_per_match={"min": float(sm[0]), "median": float(np.median(sm)), "max": float(sm[-1])},
                      scorer_calls_per_step=timed_calls / args.steps,
+                     scorer_calls_closed_form_per_step=timed_closed_calls / args.steps,
+                     closed_form=("the tail of a hill-climbing match whose steps are below half an ulp of the pose: every "
+                                  "candidate IS the best pose, bit for bit; the reference scores it again each time (a tie, "
+                                  "rejected), the chain reports those calls to the observer without scoring them "
+                                  "(SLAMHIP_OPT_INERT_TAIL).  `value` counts them (units = the reference's scorer calls x "
+                                  "beams, as in every round); value_scored_calls_only does not") if timed_closed_calls else None,
+                     value_scored_calls_only=(units_timed_scored / dt) if timed_closed_calls else None,
                      poses_evaluated_per_step=timed_evaluated / args.steps,
                      speculation_ratio=timed_evaluated / max(timed_calls, 1),
                      launches_per_step=st["launches"],

@@ -112,11 +112,17 @@ enum {
                                     * 0: a kernel per super-step (csrc/hc_chain.hip).  Same results either way. */
   SLAMHIP_OPT_K6_BATCH_KEY64 = 5, /* batched map update: 1 forces the 8-byte (particle, cell) keys of very large
                                    * batches; 0 (default): by size */
-  SLAMHIP_OPT_TBM_PLANE = 7      /* 1 (default): the 1-cell scorers over a TBM map gather the cell's per-beam
+  SLAMHIP_OPT_TBM_PLANE = 7,     /* 1 (default): the 1-cell scorers over a TBM map gather the cell's per-beam
                                   * probability -- a pure function of the cell (tbm_grid_cells.h:21-35 with the fixed
                                   * observation of the scorer) -- from an 8-byte plane every writer of the map keeps,
                                   * instead of the 32-byte cell and its belief arithmetic per (pose, beam); 0: from the
                                   * cell.  The same operations either way: the same bits. */
+  SLAMHIP_OPT_INERT_TAIL = 8     /* 1 (default): a co-resident hill-climbing chain whose steps have been halved below
+                                  * half an ulp of every pose coordinate -- every candidate of every further round IS
+                                  * the best pose, bit for bit, so its score is the best score and it is rejected
+                                  * (pose_enumeration_scan_matcher.h:58: strict) -- ends there: the remaining
+                                  * 6 x (limit - failed rounds) + 1 scorer calls (hill_climbing_scan_matcher.h:83-101)
+                                  * are reported to the observer and counted, not scored again; 0: scored */
 };
 int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value);
 int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value);
@@ -415,6 +421,10 @@ int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long
  * found the chain finished) and super-steps the checked default mode scored a second time in beam order because
  * a comparison on the path was too close for the canonical tree sum to settle */
 int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched, long long *steps_rescored);
+/* last process_scan / batch: scorer calls (of slamhip_matcher_stats' count) that were reported in closed form instead
+ * of being scored -- the tail of a hill-climbing match whose candidates have all become the best pose itself
+ * (SLAMHIP_OPT_INERT_TAIL; hill_climbing_scan_matcher.h:83-101).  0 on every other path. */
+int slamhip_matcher_tail_stats(slamhip_matcher *m, long long *calls_closed_form);
 
 /* host-side time split of the last process_scan in microseconds: building the speculation DAG,
  * staging poses, launch + wait for scores, replay of the accept chain */

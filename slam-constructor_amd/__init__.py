@@ -28,7 +28,7 @@ OIE_DISCREPANCY, OIE_OCCUPANCY = 0, 1
 SUM_TREE256, SUM_SEQUENTIAL = 0, 1
 POSE_TRIG_DEVICE, POSE_TRIG_HOST, POSE_TRIG_RAW_EXACT = 0, 1, 2
 (OPT_LOW_LATENCY, OPT_STAGE_POSES, OPT_FILTER_CHAINS, OPT_K6_PATH, OPT_K6_BATCH_FAST, OPT_K6_BATCH_KEY64,
- OPT_RESIDENT_CHAINS, OPT_TBM_PLANE) = range(8)
+ OPT_RESIDENT_CHAINS, OPT_TBM_PLANE, OPT_INERT_TAIL) = range(9)
 TRIG_RAW, TRIG_CACHED = 0, 1
 STRIDE = {CELL_OCC: 1, CELL_TBM: 4, CELL_GMAPPING: 3}
 
@@ -40,7 +40,7 @@ slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_map_set_auto_grow slamhip_map_info slamhip_map_set_deferred slamhip_map_drain slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_set_tie_check slamhip_matcher_process_scan
-slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_resident_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
+slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_tail_stats slamhip_matcher_resident_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
@@ -210,6 +210,7 @@ def load(testing=False):
     L.slamhip_matcher_stats.argtypes = [vp] + [C.POINTER(C.c_longlong)] * 3
     L.slamhip_matcher_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.slamhip_matcher_chain_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.slamhip_matcher_tail_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.slamhip_matcher_resident_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.slamhip_pf_normalize.argtypes = [i, _dp]
     L.slamhip_pf_resampling_is_required.argtypes = [i, _dp, _ip]
@@ -869,9 +870,11 @@ class Matcher:
         _check(self.L.slamhip_matcher_stats(self.h, ra[0], ra[1], ra[2]))
         _check(self.L.slamhip_matcher_timing(self.h, rt[0], rt[1], rt[2], rt[3]))
         _check(self.L.slamhip_matcher_chain_stats(self.h, ra[3], ra[4]))
+        tc = C.c_longlong()
+        _check(self.L.slamhip_matcher_tail_stats(self.h, C.byref(tc)))
         return dict(scorer_calls=a.value, poses_evaluated=b.value, launches=c.value,
                     kernels_launched=kl.value, steps_rescored=rs.value, build_us=t[0].value, stage_us=t[1].value, score_us=t[2].value,
-                    replay_us=t[3].value)
+                    replay_us=t[3].value, calls_closed_form=tc.value)
 
     def resident_stats(self):
         """Matches launched in the co-resident form, and how many of them gave up and were redone by the kernel chain."""

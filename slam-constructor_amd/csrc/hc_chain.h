@@ -159,6 +159,30 @@ HC_HD void hc_candidate(double x, double y, double theta, double dt, double dr, 
   *ot = axis == 2 ? t2 : theta;
 }
 
+// A round whose six candidates ARE its base pose, bit for bit: the steps have been halved below half an ulp of every
+// coordinate (0.1 x 2^-k against poses of metres and radians: k ~ 47 ... 57).  The reference scores each of them all
+// the same -- the same pose, so the same score as the best one's, a tie, a rejection (pose_enumeration_scan_matcher.h:58)
+// -- and every later round is the same round with smaller steps: from here on the match is 6 x (limit - failed) + 1
+// scorer calls that return the best score, and then the result.  The co-resident chain ends there in closed form
+// (hc_resident.hip, HcChainArgs::inert_tail); the other forms of the chain score the tail -- same traces.
+HC_HD bool hc_inert(double x, double y, double theta, double dt, double dr) {
+  union U {
+    double d;
+    unsigned long long u;
+  };
+  U bx, by, bt;
+  bx.d = x;
+  by.d = y;
+  bt.d = theta;
+  bool same = true;
+  for (int c = 0; c < 6; ++c) {
+    U cx, cy, ct;
+    hc_candidate(x, y, theta, dt, dr, c, &cx.d, &cy.d, &ct.d);
+    same = same && cx.u == bx.u && cy.u == by.u && ct.u == bt.u;
+  }
+  return same;
+}
+
 // 2^-k as a double (k < 1000): halving a normal double k times is one exact multiplication by it
 HC_HD double hc_pow_half(unsigned k) {
   union {

@@ -55,7 +55,8 @@ struct HcNextEntryT {
   double x, y, theta;  // base of the next tree's root round (HcNextCore)
   double p[H][4];      // x, y, sin, cos of the pose(s) this workgroup scores in the next tree
   unsigned counts;     // failed rounds (16 bits) | scorer calls of the walked path (12) | its accepted rounds (4)
-  unsigned flags;      // shape of the next tree (3 bits) | done (bit 3) | pose h is scored (bit 4 + h)
+  unsigned flags;      // shape of the next tree (3 bits) | done (bit 3) | pose h is scored (bit 4 + h) | the chain ends
+                       // on an inert root (bit 6: hc_inert -- `done` is set as well)
   // (the steps follow from the failed rounds -- one exact halving each: hc_round_of --, the acceptance-rate estimate
   // from the two counts)
 };
@@ -292,6 +293,22 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           s_cur_go[hh] = (int)((flags >> (4 + hh)) & 1u);
         }
       }
+      // ---- an inert root (hc_inert): what the reference still does from here is score this very pose
+      // 6 x (limit - failed) + 1 more times, each a tie with the best score, each rejected.  Nobody scores them: the
+      // bookkeeping workgroup writes those scorer calls into the observer's trace and adds them to the count
+      long long tail_calls = 0;
+      if (done && (flags & 64u)) tail_calls = 6ll * (long long)(ap->max_failed - (e.counts & 0xffffu)) + 1ll;
+      if (done && init_slot && tail_calls > 0 && ap->trace) {  // (uniform: the whole workgroup is the bookkeeping one)
+        HcTraceEntry *const trace = ap->trace + (size_t)blockIdx.y * (size_t)ap->trace_stride;
+        const long long at0 = s_st.calls;  // (written by the replay, before barrier (A))
+        const HcTraceEntry te{e.x, e.y, e.theta, s_st.best_prob, 0, 0};
+        for (long long q = t; q < tail_calls; q += NT) {
+          if (at0 + q < ap->trace_cap) trace[at0 + q] = te;
+          else host->error = 2;
+        }
+        __threadfence_system();
+        __syncthreads();
+      }
       if (done && init_slot && t == 0) {
         // ---- the chain is over: the last workgroup reports (every lane's trace stores first, then the result, then
         // the flag the host spins on)
@@ -302,7 +319,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         h->pose[1] = e.y;
         h->pose[2] = e.theta;
         h->best_prob = w.best_prob;
-        h->calls = w.calls;
+        h->calls = w.calls + tail_calls;
+        h->tail_calls = tail_calls;
         h->evaluated = w.evaluated;
         h->steps = w.steps;
         h->rescored = w.rescored;
@@ -504,12 +522,13 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           w.theta = c.theta;
           w.counts = hc_entry_counts(c, hc_nseg(in) + (out > 0 ? 1 : 0));
           // this workgroup's pose(s) in the tree hanging off that root (the bookkeeping workgroup scores nothing there)
-          unsigned flags = (unsigned)c.shape | (c.done ? 8u : 0u);
+          const bool inert = !c.done && ap->inert_tail && hc_inert(c.x, c.y, c.theta, c.dt, c.dr);
+          unsigned flags = (unsigned)c.shape | (c.done || inert ? 8u : 0u) | (inert ? 64u : 0u);
 #pragma unroll
           for (int hh = 0; hh < H; ++hh) {
             const int slot_h = PAIR ? 2 * (int)blockIdx.x + hh : slot;
             const int inst_h = slot_h / 6, cand_h = slot_h - 6 * inst_h;
-            bool go = !c.done && !init_slot && slot_h < 6 * ap->max_inst;
+            bool go = !c.done && !inert && !init_slot && slot_h < 6 * ap->max_inst;
             double px_ = c.x, py_ = c.y, pth_ = c.theta;
             if (go) {
               HcInst mine;

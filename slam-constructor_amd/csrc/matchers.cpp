@@ -57,6 +57,7 @@ struct slamhip_matcher {
   int chain_max_inst = slamhip::kHcMaxInst;  // instances of the largest shape (grid size of a super-step)
   int tie_check = -1;  // checked default mode: -1 = not set yet (on), 0, 1 (slamhip_matcher_set_tie_check)
   long long chain_rescored = 0;  // super-steps (device chain) / batches (host-driven) of the last match scored twice
+  long long tail_calls = 0;      // scorer calls of the last match / batch the co-resident chain reported in closed form
   long long rescored_poses = 0;
   std::vector<double> keep_scores;
   std::vector<unsigned long long> keep_fprints;
@@ -390,6 +391,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   // (the 1-cell OOPE: unsettled comparisons re-decided on the device from beam-order sums; the GMapping OOPE, r06: reported
   // -- error 7 -- and the match redone in the exact mode)
   a.verify = (tie_check_default(m) && !a.seq) ? 1 : 0;
+  a.inert_tail = ctx->inert_tail ? 1 : 0;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
   a.n_inst = 0;
@@ -410,6 +412,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   volatile HcHostOut *h = m->h_chain;
   h->error = 0;
   h->progress = 0;
+  h->tail_calls = 0;
   const double t0 = MatchJob::now_us();
   int launched = 0;
   if (resident) {
@@ -528,6 +531,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   job.t_build_us = job.t_replay_us = 0;
   m->chain_launched = launched;
   m->chain_rescored = h->rescored;
+  m->tail_calls = h->tail_calls;
   m->chain_steps_avg = 0.75 * m->chain_steps_avg + 0.25 * (double)h->steps;
   if (ctx->profile) {
     // every kernel launched carries an event pair, the run-ahead ones that found the chain finished too
@@ -808,6 +812,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   a.gm_cx = a.gm_cy = -1;
   a.gm_prob = -1.0;
   a.verify = tie_check_default(m) ? 1 : 0;
+  a.inert_tail = ctx->inert_tail ? 1 : 0;
   a.ctl = b->d_ctl;
   a.inits = b->d_inits;
   a.n_done = b->d_n_done;
@@ -829,7 +834,9 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   for (int c = 0; c < n; ++c) {
     ((volatile HcHostOut *)b->h_out)[c].error = 0;
     ((volatile HcHostOut *)b->h_out)[c].progress = 0;
+    ((volatile HcHostOut *)b->h_out)[c].tail_calls = 0;
   }
+  m->tail_calls = 0;
   int launched = 0;
   // ---- ONE launch for the whole batch (hc_resident.hip) when all chains' workgroups fit the device at once: the
   // chains then advance independently -- no chain waits at a kernel boundary for the slowest one of its super-step
@@ -964,6 +971,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     r.evaluated = h->evaluated;
     r.rescored = h->rescored;
     r.steps = h->steps;
+    m->tail_calls += h->tail_calls;
     max_steps = std::max(max_steps, (int)h->steps);
     units += h->evaluated * (long long)beams_of(jobs[c]);
   }
@@ -1464,6 +1472,7 @@ int bf_device_process_scan(slamhip_matcher *m, int map_id, const double init_pos
   job.t_build_us = job.t_replay_us = 0;
   m->chain_launched = 4;  // poses, sweep, scan, decide
   m->chain_rescored = 0;
+  m->tail_calls = 0;
   m->t_stage_us = 0;
   m->t_score_us = MatchJob::now_us() - t0;
   if (m->has_obs) {
@@ -1754,6 +1763,7 @@ int mc_chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose
   job.t_build_us = job.t_replay_us = 0;
   m->chain_launched = launched;
   m->chain_rescored = h->rescored;
+  m->tail_calls = 0;
   m->chain_steps_avg = 0.75 * m->chain_steps_avg + 0.25 * (double)h->steps;
   if (ctx->profile) {
     ctx->prof_launches += launched;
@@ -2020,6 +2030,12 @@ int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long
   return SLAMHIP_OK;
 }
 
+int slamhip_matcher_tail_stats(slamhip_matcher *m, long long *calls_closed_form) {
+  if (!m || !calls_closed_form) return invalid_arg("null argument");
+  *calls_closed_form = m->tail_calls;
+  return SLAMHIP_OK;
+}
+
 int slamhip_matcher_chain_stats(slamhip_matcher *m, long long *kernels_launched, long long *steps_rescored) {
   if (!m) return invalid_arg("null matcher");
   if (kernels_launched) *kernels_launched = m->chain_launched;
@@ -2172,6 +2188,7 @@ int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double in
   } buffering{&m->obs, false, {}};
   const slamhip_observer obs_wrap{&buffering, &BufferingObserver::test, &BufferingObserver::update, nullptr};
   m->chain_rescored = 0;
+  m->tail_calls = 0;
   m->t_stage_us = m->t_score_us = 0;
   for (;;) {
     const bool gm_exact = gm_exact_cfg || force_exact;

@@ -734,6 +734,7 @@ int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value) {
     case SLAMHIP_OPT_K6_BATCH_KEY64: ctx->k6_batch_key64 = value != 0; break;
     case SLAMHIP_OPT_RESIDENT_CHAINS: ctx->resident_chains = value != 0; break;
     case SLAMHIP_OPT_TBM_PLANE: ctx->tbm_plane = value != 0; break;
+    case SLAMHIP_OPT_INERT_TAIL: ctx->inert_tail = value != 0; break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;
@@ -750,6 +751,7 @@ int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value) {
     case SLAMHIP_OPT_K6_BATCH_KEY64: *value = ctx->k6_batch_key64; break;
     case SLAMHIP_OPT_RESIDENT_CHAINS: *value = ctx->resident_chains; break;
     case SLAMHIP_OPT_TBM_PLANE: *value = ctx->tbm_plane; break;
+    case SLAMHIP_OPT_INERT_TAIL: *value = ctx->inert_tail; break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;

@@ -592,3 +592,47 @@ def test_window_oopes_on_the_resident_chain_equal_the_host_driven_matcher(pkg, c
             init = init + np.array([0.013, -0.007, 0.004])
         assert dev.resident_stats() == dict(matches=3, gave_up=0) and dev.stats()["kernels_launched"] == 1
         assert host.stats()["kernels_launched"] == 0
+
+
+@pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
+@pytest.mark.parametrize("prm", [[128, 0.1, 0.1], [60, 0.1, 0.1], [1000, 0.2, 0.1], [300, 1e-9, 1e-9]])
+def test_inert_tail_ends_the_chain_in_closed_form_with_the_same_trace(pkg, ctx, po, oracle, cell, weighting, prm):
+    """r06.  Once the hill climber's steps are below half an ulp of every pose coordinate, every
+    candidate of every further round IS the best pose bit for bit -- the reference goes on scoring it, 6 x (limit -
+    failed) + 1 times, a tie and a rejection each time (hill_climbing_scan_matcher.h:83-101,
+    pose_enumeration_scan_matcher.h:58).  The co-resident chain ends there (SLAMHIP_OPT_INERT_TAIL, default on): the
+    observer still sees every one of those scorer calls -- same poses, same scores, same count -- but nothing is scored
+    for them.  Against the same matcher with the option off, the host-driven matcher and the oracle's strict loop."""
+    sc = make_scene(cell_model=cell, size=600, scale=0.05, n_beams=720, seed=11, weighting=weighting)
+    upload(pkg, ctx, sc)
+    on = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    ton = [on.process_scan(0, sc["init_pose"] + k * np.array([0.011, -0.006, 0.003]), trace=True) for k in range(3)]
+    son = on.stats()
+    quiet = on.process_scan(0, sc["init_pose"] + 2 * np.array([0.011, -0.006, 0.003]))
+    assert quiet["prob"] == ton[2]["prob"] and np.array_equal(quiet["delta"], ton[2]["delta"])
+    assert on.resident_stats()["gave_up"] == 0
+    ctx.set_option(pkg.OPT_INERT_TAIL, 0)
+    try:
+        off = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+        toff = [off.process_scan(0, sc["init_pose"] + k * np.array([0.011, -0.006, 0.003]), trace=True) for k in range(3)]
+        soff = off.stats()
+    finally:
+        ctx.set_option(pkg.OPT_INERT_TAIL, 1)
+    host = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    host.set_device_chain(0)
+    for a, b in zip(ton, toff):
+        assert_trace_equal(a, b)
+        assert a["n_calls"] == b["n_calls"] and a["prob"] == b["prob"] and np.array_equal(a["delta"], b["delta"])
+    assert_trace_equal(ton[0], host.process_scan(0, sc["init_pose"], trace=True))
+    assert son["scorer_calls"] == soff["scorer_calls"] == ton[2]["n_calls"]
+    if prm[0] >= 100:  # the limit lies behind the point where the steps vanish: fewer poses scored, fewer super-steps
+        assert son["poses_evaluated"] < soff["poses_evaluated"] and son["launches"] < soff["launches"]
+        # ... and the trace ends in the best pose, scored as often as the reference scores it
+        t = ton[2]
+        tail = 0
+        while tail < t["n_calls"] and np.array_equal(t["poses"][-1 - tail], t["poses"][-1]) and not t["accepted"][-1 - tail]:
+            tail += 1
+        assert tail >= 6 * (prm[0] - 70) + 1 and len(set(t["scores"][-tail:])) == 1
+    e = oracle.enumerator(po.SM_HC, prm)
+    r = oracle.process_scan(e, sc["map"], sc["scan"], po.make_cfg(), sc["init_pose"])
+    assert_trace_equal(ton[0], r, exact_scores=False, rtol=1e-12)
