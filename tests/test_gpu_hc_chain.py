@@ -628,11 +628,45 @@ def test_inert_tail_ends_the_chain_in_closed_form_with_the_same_trace(pkg, ctx, 
     if prm[0] >= 100:  # the limit lies behind the point where the steps vanish: fewer poses scored, fewer super-steps
         assert son["poses_evaluated"] < soff["poses_evaluated"] and son["launches"] < soff["launches"]
         # ... and the trace ends in the best pose, scored as often as the reference scores it
-        t = ton[2]
-        tail = 0
-        while tail < t["n_calls"] and np.array_equal(t["poses"][-1 - tail], t["poses"][-1]) and not t["accepted"][-1 - tail]:
-            tail += 1
-        assert tail >= 6 * (prm[0] - 70) + 1 and len(set(t["scores"][-tail:])) == 1
+        t, tail = ton[2], son["calls_closed_form"]
+        assert tail >= 6 * (prm[0] - 100) + 1 and soff["calls_closed_form"] == 0
+        assert len(set(t["scores"][-tail:])) == 1 and not np.any(t["accepted"][-tail:])
+        assert all(np.array_equal(t["poses"][-1 - q], t["poses"][-1]) for q in range(tail))
     e = oracle.enumerator(po.SM_HC, prm)
     r = oracle.process_scan(e, sc["map"], sc["scan"], po.make_cfg(), sc["init_pose"])
     assert_trace_equal(ton[0], r, exact_scores=False, rtol=1e-12)
+
+
+def test_inert_tail_fuzz_against_every_call_scored(pkg, ctx):
+    """160 matches over scenes, cell models, beam counts, limits and step sizes (tiny steps included: chains that are
+    inert from the first round on), each run with every call scored as well (SLAMHIP_OPT_INERT_TAIL 0): traces, results
+    and counts assert-equal."""
+    rs = np.random.RandomState(77)
+    n_closed = 0
+    for it in range(40):
+        cell = CELL_OCC if it % 2 == 0 else CELL_TBM
+        scale = [0.05, 0.1, 0.025, 0.2][it % 4]
+        sc = make_scene(cell_model=cell, size=[600, 400, 800, 200][it % 4], scale=scale, n_beams=[720, 360, 1080, 200][(it // 4) % 4],
+                        seed=300 + it, weighting="viny" if cell == CELL_TBM else "even")
+        upload(pkg, ctx, sc)
+        prm = [int(rs.choice([70, 128, 200, 400])), float(rs.choice([0.3, 0.1, 0.02, 1e-12])), float(rs.choice([0.1, 0.05, 1e-3, 1e-14]))]
+        poses = [sc["init_pose"] + rs.randn(3) * [0.05, 0.05, 0.02] for _ in range(4)]
+        res = {}
+        for level in (1, 0):
+            ctx.set_option(pkg.OPT_INERT_TAIL, level)
+            try:
+                m = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+                res[level] = []
+                for p in poses:
+                    t = m.process_scan(0, p, trace=True)
+                    res[level].append((t, m.stats()))
+                assert m.resident_stats()["gave_up"] == 0
+                m.close()
+            finally:
+                ctx.set_option(pkg.OPT_INERT_TAIL, 1)
+        for (a, sa), (b, sb) in zip(res[1], res[0]):
+            assert_trace_equal(a, b)
+            assert a["prob"] == b["prob"] and np.array_equal(a["delta"], b["delta"]) and a["n_calls"] == b["n_calls"]
+            assert sa["scorer_calls"] == sb["scorer_calls"] and sb["calls_closed_form"] == 0
+            n_closed += sa["calls_closed_form"] > 0
+    assert n_closed >= 100  # (the shortcut really was taken in most of them)
