@@ -314,11 +314,15 @@ def main():
             m.process_scan(0, scenes[k]["init_pose"])
             return account(k, beams_of[k])
 
+        # (r06: ONE C call per step -- slamhip_matcher_process_raw_scan, the reference's process_scan signature: raw scan
+        # and initial pose in, pose delta and probability out; r05 made two, slamhip_scan_filter_upload + _process_scan)
+        raw_match = [m.make_raw_process_scan(0, s_["raw_range"], s_["raw_angle"], is_occ=s_["is_occ"], weighting=weighting)
+                     for s_ in scenes]
+
         def step_raw():
             k = step_i[0] % len(scenes)
             step_i[0] += 1
-            kept = raw_upload[k](scenes[k]["init_pose"])
-            m.process_scan(0, scenes[k]["init_pose"])
+            kept, _ = raw_match[k](scenes[k]["init_pose"])
             return account(k, kept)
 
         step = step_resident if args.resident_scan else step_raw

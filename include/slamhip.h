@@ -385,6 +385,26 @@ int slamhip_matcher_set_tie_check(slamhip_matcher *m, int on);
 /* process_scan on the currently uploaded (filtered) scan; out_delta = best - init */
 int slamhip_matcher_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3],
                                  double out_delta[3], double *out_prob);
+/* GridScanMatcher::process_scan as the reference declares it (grid_scan_matcher.h:153-156,
+ * pose_enumeration_scan_matcher.h:31-77): the RAW scan in -- filter_scan against init_pose (:38), the scan-point weights
+ * and the beam trigonometry, the copy to HBM (everything slamhip_scan_filter_upload does, same arguments, gathered in
+ * slamhip_raw_scan) -- and the match, in one call.  *kept_n (may be NULL) = points filter_scan kept.  With no point
+ * kept the reference's scorer returns 0 / 0 for every candidate and nothing is ever accepted: *out_prob = NaN,
+ * out_delta = 0, no launch (observers are not called for such a scan). */
+typedef struct slamhip_raw_scan {
+  int n;
+  const double *range, *angle;
+  const int *is_occ;     /* NULL: every point occupied */
+  const double *factor;  /* NULL: all 1.0 */
+  int trig_mode;         /* SLAMHIP_TRIG_RAW / _CACHED (+ a_min, a_max, a_inc of the cached provider) */
+  double a_min, a_max, a_inc;
+  unsigned skip_rate;
+  double max_range;
+  int bounded;           /* see slamhip_scan_filter_upload */
+  int weighting;         /* 0 even, 1 viny, 2 ahr */
+} slamhip_raw_scan;
+int slamhip_matcher_process_raw_scan(slamhip_matcher *m, int map_id, const slamhip_raw_scan *scan,
+                                     const double init_pose[3], double out_delta[3], double *out_prob, int *kept_n);
 /* K independent matches in shared launches -- PoseEnumerationScanMatcher::process_scan
  * (pose_enumeration_scan_matcher.h:31-77) once per robot / replica (the single-hypothesis matchers do not
  * shard, they replicate): match k = (filtered scan k, initial pose k, map k).  Every match gets the result, the

@@ -40,7 +40,7 @@ slamhip_score_poses slamhip_score_poses_device slamhip_gm_cache_reset slamhip_gm
 slamhip_profile_enable slamhip_profile_read slamhip_profile_read_map_update slamhip_matcher_create_mc slamhip_matcher_create_hc
 slamhip_matcher_create_bf slamhip_matcher_destroy slamhip_matcher_reset_state
 slamhip_map_set_auto_grow slamhip_map_info slamhip_map_set_deferred slamhip_map_drain slamhip_matcher_set_observer slamhip_matcher_set_batch slamhip_matcher_set_device_chain slamhip_matcher_set_tie_check slamhip_matcher_process_scan
-slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_tail_stats slamhip_matcher_resident_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
+slamhip_matcher_process_raw_scan slamhip_matcher_stats slamhip_matcher_chain_stats slamhip_matcher_tail_stats slamhip_matcher_resident_stats slamhip_matcher_timing slamhip_pf_normalize slamhip_pf_resampling_is_required slamhip_pf_resample
 slamhip_pf_heaviest slamhip_gmapping_create slamhip_gmapping_destroy slamhip_gmapping_predict_match
 slamhip_gmapping_plan_resample slamhip_gmapping_blob_size slamhip_gmapping_export
 slamhip_gmapping_import slamhip_gmapping_step slamhip_gmapping_set slamhip_gmapping_get
@@ -821,6 +821,37 @@ class Matcher:
             arr[k].factor = _d(f) if f is not None else None
         return dict(arr=arr, keep=keep, n=len(jobs), deltas=np.zeros((len(jobs), 3)), probs=np.zeros(len(jobs)))
 
+    def make_raw_process_scan(self, map_id, rng, ang, is_occ=None, factor=None, trig_mode=TRIG_RAW, a_min=0.0, a_max=0.0,
+                              a_inc=1.0, skip_rate=0, max_range=-1.0, bounded=False, weighting="even"):
+        """slamhip_matcher_process_raw_scan with its argument block made once for a raw scan (a caller that holds its scans
+        in C arrays pays no conversions per call): returns match(pose) -> (points kept, prob); the pose delta of the
+        last match is in match.delta (a ctypes array of 3)."""
+        rng, ang = _f64(rng), _f64(ang)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        fac = _f64(factor) if factor is not None else None
+        blk = RawScan(rng.size, _d(rng), _d(ang), occ.ctypes.data_as(_ip) if occ is not None else None,
+                      _d(fac) if fac is not None else None, int(trig_mode), a_min, a_max, a_inc, int(skip_rate),
+                      float(max_range), int(bool(bounded)), {"even": 0, "viny": 1, "ahr": 2}[weighting])
+        kept, prob = C.c_int(0), C.c_double(0.0)
+        pose3, d3 = (C.c_double * 3)(), (C.c_double * 3)()
+        fn = self.L.slamhip_matcher_process_raw_scan
+        fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(RawScan), _dp, _dp, _dp, C.POINTER(C.c_int)]
+        args = (self.h, int(map_id), C.pointer(blk), C.cast(pose3, _dp), C.cast(d3, _dp), C.cast(C.pointer(prob), _dp),
+                C.pointer(kept))
+        keep = (rng, ang, occ, fac, blk)
+
+        def match(pose, _keep=keep):
+            pose3[0], pose3[1], pose3[2] = float(pose[0]), float(pose[1]), float(pose[2])
+            if not self._obs_cleared:
+                _check(self.L.slamhip_matcher_set_observer(self.h, None))
+                self._obs_cleared = True
+            rc = fn(*args)
+            if rc:
+                _check(rc)
+            return kept.value, prob.value
+        match.delta = d3
+        return match
+
     def process_scan_batch(self, jobs, trace=False):
         """K independent matches in shared launches (slamhip_matcher_process_scan_batch).  jobs: a list of dicts (see
         make_batch) or a block make_batch returned.  Returns a list of dicts like process_scan's, one per job."""
@@ -881,6 +912,13 @@ class Matcher:
         a, b = C.c_longlong(), C.c_longlong()
         _check(self.L.slamhip_matcher_resident_stats(self.h, C.byref(a), C.byref(b)))
         return dict(matches=a.value, gave_up=b.value)
+
+
+class RawScan(C.Structure):
+    """slamhip_raw_scan (include/slamhip.h)"""
+    _fields_ = [("n", C.c_int), ("range", _dp), ("angle", _dp), ("is_occ", _ip), ("factor", _dp), ("trig_mode", C.c_int),
+                ("a_min", C.c_double), ("a_max", C.c_double), ("a_inc", C.c_double), ("skip_rate", C.c_uint),
+                ("max_range", C.c_double), ("bounded", C.c_int), ("weighting", C.c_int)]
 
 
 class GmappingFilter:

@@ -2,6 +2,7 @@
 // speculative drivers of matchers.h.
 
 #include <cstdlib>
+#include <limits>
 #include <mutex>
 
 #include "bf_device.h"
@@ -2028,6 +2029,23 @@ int slamhip_matcher_stats(slamhip_matcher *m, long long *scorer_calls, long long
   if (poses_evaluated) *poses_evaluated = m->job.poses_evaluated;
   if (launches) *launches = m->job.launches;
   return SLAMHIP_OK;
+}
+
+int slamhip_matcher_process_raw_scan(slamhip_matcher *m, int map_id, const slamhip_raw_scan *scan, const double init_pose[3],
+                                     double out_delta[3], double *out_prob, int *kept_n) {
+  if (!m || !scan || !init_pose || !out_delta || !out_prob) return invalid_arg("null argument");
+  int kept = 0;
+  const int rc = slamhip_scan_filter_upload(m->ctx, map_id, scan->n, scan->range, scan->angle, scan->is_occ, scan->factor,
+                                            scan->trig_mode, scan->a_min, scan->a_max, scan->a_inc, init_pose, scan->skip_rate,
+                                            scan->max_range, scan->bounded, scan->weighting, &kept, nullptr);
+  if (kept_n) *kept_n = kept;
+  if (rc) return rc;
+  if (kept == 0) {  // 0 / 0 for every candidate (weighted_mean_point_probability_spe.h:126-132): nothing is accepted
+    out_delta[0] = out_delta[1] = out_delta[2] = 0.0;
+    *out_prob = std::numeric_limits<double>::quiet_NaN();
+    return SLAMHIP_OK;
+  }
+  return slamhip_matcher_process_scan(m, map_id, init_pose, out_delta, out_prob);
 }
 
 int slamhip_matcher_tail_stats(slamhip_matcher *m, long long *calls_closed_form) {

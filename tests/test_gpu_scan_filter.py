@@ -62,3 +62,36 @@ def test_scan_filter_upload_equals_the_separate_steps(pkg, weighting, trig, boun
         got = ctx.score_poses(0, cfg, poses)
         np.testing.assert_array_equal(got, want, err_msg="rep %d" % rep)
     ctx.close()
+
+
+def test_process_raw_scan_is_filter_upload_plus_process_scan(pkg):
+    """r06: slamhip_matcher_process_raw_scan -- the reference's process_scan signature (raw scan and initial pose in, pose
+    delta and probability out; grid_scan_matcher.h:153-156) -- against slamhip_scan_filter_upload + slamhip_matcher_process_scan
+    on the same raw scans: same points kept, same result bit for bit, for the three matcher kinds; a scan of which
+    filter_scan keeps nothing comes back as the reference's NaN with a zero delta."""
+    from synth import cast_scan
+    ctx = pkg.Context(0)
+    try:
+        sc = make_scene(cell_model=0, size=600, scale=0.05, n_beams=720, seed=21)
+        ctx.upload_map(0, sc["map"])
+        rng, ang, occ = cast_scan(sc["gt"], sc["map"].scale, sc["true_pose"], 720, seed=5, raw=True)
+        for kind, prm in (("HC", [20, 0.1, 0.1]), ("MC", [7, 0.2, 0.1, 20, 100]),
+                          ("BF", [-0.1, 0.1, 0.05, -0.1, 0.1, 0.05, -0.05, 0.05, 0.025])):
+            two, one = pkg.Matcher(ctx, kind, pkg.spe_cfg(), prm), pkg.Matcher(ctx, kind, pkg.spe_cfg(), prm)
+            up = ctx.make_raw_scan(0, rng, ang, is_occ=occ, skip_rate=2, max_range=20.0)
+            match = one.make_raw_process_scan(0, rng, ang, is_occ=occ, skip_rate=2, max_range=20.0)
+            for k in range(3):
+                pose = sc["init_pose"] + k * np.array([0.01, -0.02, 0.005])
+                kept2 = up(pose)
+                r2 = two.process_scan(0, pose)
+                kept1, prob1 = match(pose)
+                assert kept1 == kept2 and 0 < kept1 < 720
+                assert prob1 == r2["prob"] and np.array_equal(np.array(list(match.delta)), r2["delta"])
+                assert one.stats()["scorer_calls"] == two.stats()["scorer_calls"]
+            empty = one.make_raw_process_scan(0, rng, ang, is_occ=np.zeros_like(occ))
+            kept, prob = empty(sc["init_pose"])
+            assert kept == 0 and np.isnan(prob) and list(empty.delta) == [0.0, 0.0, 0.0]
+            two.close()
+            one.close()
+    finally:
+        ctx.close()
