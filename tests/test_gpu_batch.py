@@ -208,3 +208,32 @@ def test_resident_batch_gives_up_when_a_workgroup_is_missing(pkg, tctx):
     for g, a in zip(got, again):
         assert_trace_equal(g, a)
     assert mb.resident_stats() == dict(matches=2, gave_up=1) and mb.stats()["kernels_launched"] == 1
+
+
+@pytest.mark.parametrize("k", [2, 8])
+def test_batch_inert_tails_equal_lone_matches_with_every_call_scored(pkg, ctx, k):
+    """r06: the chains of a batch end on their inert roots too (csrc/hc_resident.hip: the closed-form tail of a
+    hill-climbing match, SLAMHIP_OPT_INERT_TAIL) -- each chain's bookkeeping workgroup writes its tail into its own
+    stretch of the observers' trace buffer.  k matches at limit 128 (k = 8: the pair form, two poses per workgroup) against
+    lone matches on the kernel chain, which scores every call: traces bit for bit, counts equal, and the batch's
+    closed-form calls are what its chains did not score."""
+    jobs = scenes(pkg, ctx, CELL_OCC, "even", k, beams=(720, 360, 1080))
+    prm = [128, 0.1, 0.1]
+    mb = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    mb.set_device_chain(2)
+    ml = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+    ml.set_device_chain(1)
+    got = mb.process_scan_batch(jobs, trace=True)
+    sb = mb.stats()
+    assert mb.resident_stats() == dict(matches=1, gave_up=0)
+    evaluated = 0
+    for j, (g, job) in enumerate(zip(got, jobs)):
+        want = lone(pkg, ctx, ml, job)
+        assert_trace_equal(g, want)
+        st = mb.batch_stats(j)
+        assert st["scorer_calls"] == want["n_calls"] == ml.stats()["scorer_calls"]
+        assert ml.stats()["calls_closed_form"] == 0
+        evaluated += st["poses_evaluated"]
+    assert sb["calls_closed_form"] >= k * 6 * 20 and sb["calls_closed_form"] < sb["scorer_calls"]
+    mb.close()
+    ml.close()
