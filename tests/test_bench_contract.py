@@ -96,6 +96,14 @@ def test_default_bench_line_contract():
     assert [m_["ranks"] for m_ in wm] == [1, 2, 4, 8] and [m_["particles"] for m_ in wm] == [100, 200, 400, 800]
     assert wm[3]["predicted_particles_per_s"] > 6 * wm[0]["predicted_particles_per_s"]
     assert 0.0 < d["roofline"]["frac_useful"] < d["roofline"]["frac"]
+    # r06: the lone match's inert tail is reported in closed form -- disclosed in the line (how many
+    # of a step's scorer calls, `value` without them, the same steps with every call scored), and what it buys
+    c = d["config"]
+    assert 200 < c["scorer_calls_closed_form_per_step"] < 0.5 * c["scorer_calls_per_step"]
+    assert 0.5 * d["value"] < c["value_scored_calls_only"] < d["value"]
+    assert abs(c["value_scored_calls_only"] / d["value"] - (1.0 - c["scorer_calls_closed_form_per_step"] / c["scorer_calls_per_step"])) < 0.01
+    assert d["ms_per_step"] < 0.95 * c["ms_per_step_every_call_scored"] and d["ms_per_step"] <= 0.088
+    assert d["roofline"]["avg_launch_us"] <= 68.0 and c["super_steps_per_match"] <= 12.5
 
 
 @pytest.mark.skipif(not DEFAULT, reason="no committed bench line yet")

@@ -532,6 +532,20 @@ def test_trace_buffer_overflow_falls_back_to_the_host_driven_matcher(pkg, tctx, 
     assert L.slamhip_matcher_debug_trace_cap(dev.h, 0) == 0
     again = dev.process_scan(0, sc["init_pose"], trace=True)
     assert_trace_equal(again, want)
+    if mode == 2:
+        # r06: ... and when the buffer ends inside the closed-form tail of the co-resident chain (limit 128: the climb's
+        # ~250 calls fit, the tail's 250+ do not) -- written by the bookkeeping workgroup's threads side by side
+        dev2, host2 = matchers(pkg, ctx, [128, 0.1, 0.1], mode=2)
+        want2 = host2.process_scan(0, sc["init_pose"], trace=True)
+        full = dev2.process_scan(0, sc["init_pose"], trace=True)
+        tail = dev2.stats()["calls_closed_form"]
+        assert tail > 100 and want2["n_calls"] - tail > 100
+        assert L.slamhip_matcher_debug_trace_cap(dev2.h, want2["n_calls"] - tail // 2) == 0
+        got2 = dev2.process_scan(0, sc["init_pose"], trace=True)
+        assert_trace_equal(got2, want2)
+        assert_trace_equal(full, want2)
+        assert dev2.stats()["calls_closed_form"] == 0  # (the host-driven matcher made this trace)
+        assert L.slamhip_matcher_debug_trace_cap(dev2.h, 0) == 0
 
 
 def test_resident_chain_gives_up_when_a_workgroup_is_missing(pkg, tctx):
