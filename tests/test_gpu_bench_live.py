@@ -58,7 +58,8 @@ def test_headline_line_from_a_live_run():
     # weights + beam trig + upload inside), the resident-scan figure rides along
     assert r["kernel"] == "k_hc_chain_resident" and r["launches"] > 0 and 0.0 < r["frac"] < 1.0
     assert c["resident"]["matches"] > 0 and c["resident"]["gave_up"] == 0
-    assert c["includes_filter_and_upload"] is True and 0.05 < c["ms_per_step_resident"] <= d["ms_per_step"] * 1.05
+    # (8 timed steps each: a sanity bound, not a measurement -- one slow step moves either figure by 10 %)
+    assert c["includes_filter_and_upload"] is True and 0.05 < c["ms_per_step_resident"] <= d["ms_per_step"] * 1.5
     assert d["parity"]["scenes"] == 0 and "--no-cpu" in d["parity"]["note"]
     assert abs(r["achieved"] - r["units_launched"] * r["bytes_per_unit"] / (r["avg_launch_us"] * 1e-6 * r["launches"]) / 1e9) \
         <= 1e-6 * r["achieved"]
