@@ -24,6 +24,18 @@ for j, s_ in enumerate(scenes):
     ctx.scan_store(j, s_["range"], c_, s__, s_["weight"])
 vals = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,1,2,3").split(",")]
 N = 320
+ref = {}
+for v in vals:
+    os.environ["SLAMHIP_EXP"] = str(v)
+    for k in range(16):
+        ctx.scan_select(k)
+        r = m.process_scan(0, scenes[k]["init_pose"], trace=True)
+        key = (r["prob"], tuple(r["delta"]), r["n_calls"], tuple(r["scores"]))
+        if k in ref:
+            assert ref[k] == key, ("exp %d differs on scene %d" % (v, k))
+        else:
+            ref[k] = key
+print("results identical over", vals)
 res = {v: [] for v in vals}
 pc = time.perf_counter
 for rnd in range(6):
