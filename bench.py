@@ -401,7 +401,7 @@ def main():
                 barrier()
                 extra["ms_per_step_every_call_scored"] = 1e3 * (time.perf_counter() - t3) / args.steps
             finally:
-                ctx.set_option(pkg.OPT_INERT_TAIL, 1)
+                ctx.set_option(pkg.OPT_INERT_TAIL, 2)
             per_scene_stats.clear()
             for _ in range(len(scenes)):
                 step()

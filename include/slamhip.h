@@ -117,12 +117,20 @@ enum {
                                   * observation of the scorer) -- from an 8-byte plane every writer of the map keeps,
                                   * instead of the 32-byte cell and its belief arithmetic per (pose, beam); 0: from the
                                   * cell.  The same operations either way: the same bits. */
-  SLAMHIP_OPT_INERT_TAIL = 8     /* 1 (default): a co-resident hill-climbing chain whose steps have been halved below
-                                  * half an ulp of every pose coordinate -- every candidate of every further round IS
-                                  * the best pose, bit for bit, so its score is the best score and it is rejected
-                                  * (pose_enumeration_scan_matcher.h:58: strict) -- ends there: the remaining
-                                  * 6 x (limit - failed rounds) + 1 scorer calls (hill_climbing_scan_matcher.h:83-101)
-                                  * are reported to the observer and counted, not scored again; 0: scored */
+  SLAMHIP_OPT_INERT_TAIL = 8     /* the tail of a co-resident hill-climbing chain (1-cell OOPE).  The reference's enumerator
+                                  * stops at a count of failed rounds, not at convergence
+                                  * (hill_climbing_scan_matcher.h:83-101), the steps halved at every failure.
+                                  * 1: once the steps are below half an ulp of every pose coordinate, every candidate
+                                  * of every further round IS the best pose, bit for bit: the same score, `best < score`
+                                  * false (pose_enumeration_scan_matcher.h:58) -- the chain ends there; the remaining
+                                  * 6 x (limit - failed rounds) + 1 scorer calls are reported to the observer and
+                                  * counted, not scored again.  2 (default): also once a tree's walk has accepted
+                                  * nothing and the steps have become so small that every beam of every further
+                                  * candidate provably ends in the same cell as under the best pose (a per-beam bound
+                                  * on the end point's movement against its distance from the cell's edges, made by the
+                                  * chain's idle bookkeeping workgroup: csrc/hc_resident.hip "certificate"): the same
+                                  * cells, the same terms, the same score.  What that buys is the chains of a BATCH.
+                                  * 0: every call scored.  Same traces, results and counts in all three. */
 };
 int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value);
 int slamhip_ctx_get_option(slamhip_ctx *ctx, int option, int *value);

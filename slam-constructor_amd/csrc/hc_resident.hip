@@ -70,6 +70,18 @@ __device__ __forceinline__ unsigned hc_entry_counts(const HcNextCore &c, int rou
   return (c.failed & 0xffffu) | (((unsigned)c.batch_calls & 0xfffu) << 16) | (((unsigned)rounds_acc & 0xfu) << 28);
 }
 
+// minima of two values over a wave (every lane ends with both)
+__device__ __forceinline__ void wave_min2(double &a, double &b) {
+#define HCR_MIN_STEP(OFF)                              \
+  {                                                    \
+    const double oa = lane_xor_f64<OFF>(a), ob = lane_xor_f64<OFF>(b); \
+    a = a < oa ? a : oa;                               \
+    b = b < ob ? b : ob;                               \
+  }
+  HCR_MIN_STEP(32) HCR_MIN_STEP(16) HCR_MIN_STEP(8) HCR_MIN_STEP(4) HCR_MIN_STEP(2) HCR_MIN_STEP(1)
+#undef HCR_MIN_STEP
+}
+
 // s_sel: what the pose of the next super-step is read from
 constexpr int kSelRescore = -1;  // the same tree once more (an unsettled comparison): the poses just scored
 constexpr int kSelFirst = -2;    // the first super-step: the prologue's pose
@@ -89,6 +101,7 @@ template <int MODEL, int NT, bool SEQ, bool BATCH, int G, bool WIN = false, bool
 __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   constexpr int H = PAIR ? 2 : 1;    // poses per workgroup
   constexpr int NTH = NT / H;        // threads per pose
+  constexpr bool CERT = !WIN;        // the 1-cell OOPE: a beam's term is a function of its cell alone (see "certificate")
   typedef HcNextEntryT<H> HcNextEntry;
   extern __shared__ double s_term[];  // one term per beam; behind them, for workgroups narrower than the scan: range,
                                       // cosine, sine of every further beam; then the table of next poses
@@ -103,6 +116,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
   __shared__ HcState s_st;              // root state of the super-step being scored
   __shared__ double s_part[H][4];
   __shared__ unsigned long long s_hpart[H][4];
+  __shared__ double s_cert[2][16];  // the bookkeeping workgroup's certificate: per-wave minima (see "certificate" below)
+  __shared__ int s_cert_end;        // the replay's verdict: the chain ends on a certified root
   const int t = threadIdx.x, wave = t >> 6;
   const int half = PAIR ? (t >= NTH ? 1 : 0) : 0;  // which of the workgroup's poses this thread works on
   const int tl = t - half * NTH, lwave = tl >> 6;  // ... and its place among that pose's threads
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     st.carry_prob = -1.0;
     s_st = st;
     s_sel = kSelFirst;
+    s_cert_end = 0;
   }
   __syncthreads();  // s_mine, s_stop, s_st
   if (s_stop) return;  // started after the others gave up (uniform)
@@ -259,7 +275,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     if (sel >= 0) {
       const HcNextEntry &e = s_tab[sel];
       const unsigned flags = e.flags;
-      const int done = (int)((flags >> 3) & 1u);
+      const bool cert_end = CERT && s_cert_end != 0;  // (written with s_sel, before barrier (A))
+      const int done = (int)((flags >> 3) & 1u) | (cert_end ? 1 : 0);
       go = (int)((flags >> (4 + half)) & 1u);
       px = e.p[half][0];
       py = e.p[half][1];
@@ -296,13 +313,23 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       // ---- an inert root (hc_inert): what the reference still does from here is score this very pose
       // 6 x (limit - failed) + 1 more times, each a tie with the best score, each rejected.  Nobody scores them: the
       // bookkeeping workgroup writes those scorer calls into the observer's trace and adds them to the count
+      // ... or a CERTIFIED root (see "certificate" below): the candidates differ from the best pose, but every beam of
+      // every one of them ends in the best pose's cell -- the same terms, the same score, rejected all the same
       long long tail_calls = 0;
-      if (done && (flags & 64u)) tail_calls = 6ll * (long long)(ap->max_failed - (e.counts & 0xffffu)) + 1ll;
+      if (done && ((flags & 64u) || cert_end)) tail_calls = 6ll * (long long)(ap->max_failed - (e.counts & 0xffffu)) + 1ll;
       if (done && init_slot && tail_calls > 0 && ap->trace) {  // (uniform: the whole workgroup is the bookkeeping one)
+        __syncthreads();  // (s_st: the root state the tail starts from, completed just above by the last wave)
         HcTraceEntry *const trace = ap->trace + (size_t)blockIdx.y * (size_t)ap->trace_stride;
-        const long long at0 = s_st.calls;  // (written by the replay, before barrier (A))
-        const HcTraceEntry te{e.x, e.y, e.theta, s_st.best_prob, 0, 0};
+        const long long at0 = s_st.calls;
+        const double best = s_st.best_prob, dt_e = s_st.dt, dr_e = s_st.dr;
         for (long long q = t; q < tail_calls; q += NT) {
+          // scorer call q of the tail: candidate q % 6 of its round q / 6, whose steps were halved that often
+          const double hlf = hc_pow_half((unsigned)(q / 6));
+          HcTraceEntry te;
+          hc_candidate(e.x, e.y, e.theta, dt_e * hlf, dr_e * hlf, (int)(q % 6), &te.x, &te.y, &te.theta);
+          te.score = best;
+          te.accepted = 0;
+          te.pad = 0;
           if (at0 + q < ap->trace_cap) trace[at0 + q] = te;
           else host->error = 2;
         }
@@ -422,7 +449,61 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
         }
       }
     }
+    // ---- certificate (r06; the bookkeeping workgroup, idle behind the first super-step).  A match does not end when
+    // it has converged but at its count of failed rounds; between the last acceptance (failed round ~10) and the inert
+    // threshold (~50) lie rounds whose candidates differ from the best pose by less than any beam's distance from its
+    // cell's edge: the same cells, the same terms, the same sum -- a tie with the best score, a rejection
+    // (pose_enumeration_scan_matcher.h:58), in the canonical and in the beam-order sum alike.  A lone chain's tree of 42
+    // round instances crosses that stretch in the one super-step it needs anyway; the chains of a batch, with trees of a
+    // few instances, spend twenty super-steps there.  So: for the ROOT pose of this super-step, how small do the steps
+    // have to be for every candidate of a round based on it to end, beam by beam, in its own cells?  A beam's end point
+    // moves by at most 1.01 dt (a translation candidate) or 1.5 r dr (a rotation candidate) plus rounding -- 2^-44 of
+    // every magnitude involved, three orders above what the operations can lose; the distance from the nearest cell
+    // edge is computed with the same slack against the true quotient's rounding.  t_t / t_r: the largest dt / dr all
+    // beams allow (0: none).  They travel in this workgroup's granule; the replay (below) ends the chain when the walk
+    // accepted nothing and the next root's steps are below them.
+    double cert_t = 0.0, cert_r = 0.0;
+    const bool cert_here = CERT && init_slot && half == 0 && sel >= 0 && !go && ap->inert_tail > 1;
+    if (cert_here) {
+      const double theta_abs = __builtin_fabs(s_tab[sel].theta);
+      double tt = __builtin_inf(), tr = __builtin_inf();
+      for (int b = tl; b < n; b += NTH) {
+        double r_ = br, ca = bc, sa = bs;
+        if (b != tl) {
+          r_ = ldsc ? s_r[b] : scan.range[b];
+          ca = ldsc ? s_ca[b] : scan.cos_a[b];
+          sa = ldsc ? s_sa[b] : scan.sin_a[b];
+        }
+        const double c = cs * ca - sn * sa;
+        const double s_ = sn * ca + cs * sa;
+        const double wx = px + r_ * c, wy = py + r_ * s_;
+        const double qx = wx * map.inv_scale, qy = wy * map.inv_scale;
+        const double fx = qx - floor(qx), fy = qy - floor(qy);
+        const double mx = fx < 1.0 - fx ? fx : 1.0 - fx, my = fy < 1.0 - fy ? fy : 1.0 - fy;
+        const double edge = (mx < my ? mx : my) * map.scale;
+        const double ar = __builtin_fabs(r_);
+        const double slack = (ar * (1.0 + theta_abs) + __builtin_fabs(wx) + __builtin_fabs(wy) + __builtin_fabs(px) +
+                              __builtin_fabs(py) + 1.0) * 0x1p-44;
+        const double avail = edge - slack;
+        const bool ok = avail > 0.0;  // (false for a NaN)
+        const double t1 = ok ? avail * 0.99 : 0.0;
+        const double t2 = ok ? (ar > 0.0 ? avail / (1.5 * ar) : __builtin_inf()) : 0.0;
+        tt = tt < t1 ? tt : t1;
+        tr = tr < t2 ? tr : t2;
+      }
+      wave_min2(tt, tr);
+      if (lane == 0) {
+        s_cert[0][lwave] = tt;
+        s_cert[1][lwave] = tr;
+      }
+    }
     __syncthreads();  // (B)
+    if (cert_here && tl < 64) {
+      double tt = tl < NTH / 64 ? s_cert[0][tl] : __builtin_inf(), tr = tl < NTH / 64 ? s_cert[1][tl] : __builtin_inf();
+      wave_min2(tt, tr);
+      cert_t = tt;
+      cert_r = tr;
+    }
     if (stamp && k < 64) ap->stamps[8 * k + 4] = wall_clock64();
     if (go) {
       if (SEQ) {
@@ -489,7 +570,10 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
       // workgroup of the grid in every super-step, so nobody -- the bookkeeping workgroup streaming an observer's
       // trace over PCIe least of all -- is ever more than one super-step behind the others, whose next-but-one
       // granules would overwrite what it still has to read
-      gran_store(&gran[pk * kGranRow + slot], 0.0, 0ull, tag);
+      // (the bookkeeping workgroup's granule carries its certificate: t_t where a score sits, the upper 48 bits of t_r
+      // -- rounded down -- where a fingerprint does)
+      gran_store(&gran[pk * kGranRow + slot], cert_here ? cert_t : 0.0,
+                 cert_here ? (unsigned long long)__double_as_longlong(cert_r) >> 16 : 0ull, tag);
       if (verify && mode) gran_store(&gseq[pk * kGranRow + slot], 0.0, 0ull, tag);
     }
 
@@ -543,7 +627,9 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
               }
             }
             double sn_ = 0.0, cs_ = 1.0;
-            if (go) sincos(pth_, &sn_, &cs_);
+            // (the bookkeeping workgroup scores nothing there: px_, py_, pth_ are the next ROOT's pose -- whose cells its
+            // certificate is about, hence the sine and cosine)
+            if (go || (CERT && init_slot && hh == 0 && ap->inert_tail > 1)) sincos(pth_, &sn_, &cs_);
             w.p[hh][0] = px_;
             w.p[hh][1] = py_;
             w.p[hh][2] = sn_;
@@ -745,8 +831,23 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
             }
           }
         }
+        // ---- the certificate's verdict (every workgroup reads the same granule, every replay decides alike): the walk
+        // accepted nothing (it ends on the root's own line of failed rounds: the next root is the same pose with smaller
+        // steps), and those steps are below what the bookkeeping workgroup certified for this pose -- the chain is over
+        bool cert_end = false;
+        if (CERT && ap->inert_tail > 1 && !sp.first && sp.mode == 0 && !dirty && tmask != 0ull) {
+          const int nseg_t = bcast_i(hc_nseg(me), tl), nfail_t = bcast_i((int)hc_nfail(me), tl);
+          const unsigned failed_next = sp.failed + (unsigned)nfail_t + 1u;
+          if (nseg_t == 0 && out_t == 0 && !trailing_t && failed_next < ap->max_failed) {
+            const double hlf = hc_pow_half((unsigned)nfail_t + 1u);
+            const double t_t = s_sc[kHcSlots - 1];
+            const double t_r = __longlong_as_double((long long)(s_hash[kHcSlots - 1] << 16));
+            cert_end = sp.dt * hlf < t_t && sp.dr * hlf < t_r;
+          }
+        }
         if (stamp && k < 64) ap->stamps[8 * k + 2] = wall_clock64();
         if (lane == 0) {
+          s_cert_end = cert_end ? 1 : 0;
           // the bookkeeping half of the next root state (`sp` above is this very object: the trace was written from
           // the old state first); the other half -- pose, steps, shape -- is copied from the table behind the barrier
           HcState &w = s_st;

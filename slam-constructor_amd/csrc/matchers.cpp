@@ -392,7 +392,7 @@ int chain_process_scan(slamhip_matcher *m, int map_id, const double init_pose[3]
   // (the 1-cell OOPE: unsettled comparisons re-decided on the device from beam-order sums; the GMapping OOPE, r06: reported
   // -- error 7 -- and the match redone in the exact mode)
   a.verify = (tie_check_default(m) && !a.seq) ? 1 : 0;
-  a.inert_tail = ctx->inert_tail ? 1 : 0;
+  a.inert_tail = ctx->inert_tail;
   a.ctl = m->d_chain;
   a.shapes = m->d_shapes;
   a.n_inst = 0;
@@ -813,7 +813,7 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
   a.gm_cx = a.gm_cy = -1;
   a.gm_prob = -1.0;
   a.verify = tie_check_default(m) ? 1 : 0;
-  a.inert_tail = ctx->inert_tail ? 1 : 0;
+  a.inert_tail = ctx->inert_tail;
   a.ctl = b->d_ctl;
   a.inits = b->d_inits;
   a.n_done = b->d_n_done;

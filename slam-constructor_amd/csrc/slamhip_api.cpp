@@ -734,7 +734,10 @@ int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value) {
     case SLAMHIP_OPT_K6_BATCH_KEY64: ctx->k6_batch_key64 = value != 0; break;
     case SLAMHIP_OPT_RESIDENT_CHAINS: ctx->resident_chains = value != 0; break;
     case SLAMHIP_OPT_TBM_PLANE: ctx->tbm_plane = value != 0; break;
-    case SLAMHIP_OPT_INERT_TAIL: ctx->inert_tail = value != 0; break;
+    case SLAMHIP_OPT_INERT_TAIL:
+      if (value < 0 || value > 2) return invalid("SLAMHIP_OPT_INERT_TAIL: 0 (off), 1 (identical poses) or 2 (default: certified poses too)");
+      ctx->inert_tail = value;
+      break;
     default: return invalid("unknown option");
   }
   return SLAMHIP_OK;

@@ -302,7 +302,8 @@ struct slamhip_ctx {
   bool low_latency = true;
   bool stage_poses = false;  // copy poses to HBM first instead of reading them over PCIe
   // slamhip_ctx_set_option: equivalent execution paths (defaults = what is measured)
-  bool filter_chains = true, k6_batch_fast = true, k6_batch_key64 = false, resident_chains = true, tbm_plane = true, inert_tail = true;
+  bool filter_chains = true, k6_batch_fast = true, k6_batch_key64 = false, resident_chains = true, tbm_plane = true;
+  int inert_tail = 2;  // SLAMHIP_OPT_INERT_TAIL
   int k6_path = 0;
   // profiling: event pairs recorded around scoring launches, resolved lazily in profile_read
   bool profile = false;

@@ -237,3 +237,45 @@ def test_batch_inert_tails_equal_lone_matches_with_every_call_scored(pkg, ctx, k
     assert sb["calls_closed_form"] >= k * 6 * 20 and sb["calls_closed_form"] < sb["scorer_calls"]
     mb.close()
     ml.close()
+
+
+@pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
+def test_batch_certified_tails_fuzz_against_every_call_scored(pkg, ctx, cell, weighting):
+    """r06: a batch's chains also end on CERTIFIED poses (SLAMHIP_OPT_INERT_TAIL 2, the default; csrc/hc_resident.hip
+    "certificate"): a workgroup says beside its score from which failed-round count on no candidate of a round based on
+    its pose can leave the pose's cells -- an argument about rounding, so: batches of 2 ... 32 matches over limits, step
+    sizes and beam counts, each run at levels 2, 1 (identical poses only) and 0 (every call scored); traces, results and
+    counts assert-equal, and level 2 really ends chains earlier than level 1."""
+    rs = np.random.RandomState(5)
+    closed = {1: 0, 2: 0}
+    steps = {0: 0, 1: 0, 2: 0}
+    for it, k in enumerate([2, 3, 8, 16, 32, 5, 12, 24]):
+        jobs = scenes(pkg, ctx, cell, weighting, k, beams=(720, 360, 1080))
+        prm = [int(rs.choice([70, 128, 200])), float(rs.choice([0.2, 0.1, 0.02])), float(rs.choice([0.1, 0.05, 0.005]))]
+        res = {}
+        for level in (2, 1, 0):
+            ctx.set_option(pkg.OPT_INERT_TAIL, level)
+            try:
+                mb = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+                mb.set_device_chain(2)
+                got = mb.process_scan_batch(jobs, trace=True)
+                st = [mb.batch_stats(j) for j in range(k)]
+                res[level] = (got, st, mb.stats())
+                # (k = 24: trees of that batch do not fit the device together -- kernel chains, which score every call)
+                assert mb.resident_stats() == dict(matches=0 if k == 24 else 1, gave_up=0), (k, level, prm)
+                quiet = mb.process_scan_batch(jobs)
+                for g, q in zip(got, quiet):
+                    assert g["prob"] == q["prob"] and np.array_equal(g["delta"], q["delta"])
+                mb.close()
+            finally:
+                ctx.set_option(pkg.OPT_INERT_TAIL, 2)
+        for lv in (2, 1):
+            for (a, sa), (b, sb) in zip(zip(res[lv][0], res[lv][1]), zip(res[0][0], res[0][1])):
+                assert_trace_equal(a, b)
+                assert a["prob"] == b["prob"] and np.array_equal(a["delta"], b["delta"]) and a["n_calls"] == b["n_calls"]
+                assert sa["scorer_calls"] == sb["scorer_calls"]
+            closed[lv] += res[lv][2]["calls_closed_form"]
+        for lv in (0, 1, 2):
+            steps[lv] += res[lv][2]["launches"]
+        assert res[0][2]["calls_closed_form"] == 0
+    assert closed[2] > closed[1] > 0 and steps[2] < steps[1] < steps[0]

@@ -1,4 +1,4 @@
-"""Per-scene counters of the cfg2 match at SLAMHIP_OPT_INERT_TAIL = 0 / 1 (diagnostic)."""
+"""Per-job super-steps of a K-match batch of the bench scenes at SLAMHIP_OPT_INERT_TAIL 0 / 1 / 2 (diagnostic)."""
 import os
 import sys
 
@@ -20,20 +20,19 @@ ctx.upload_map(0, sc["map"])
 for j, s_ in enumerate(scenes):
     c_, s__ = pkg.beam_trig(s_["angle"])
     ctx.scan_store(j, s_["range"], c_, s__, s_["weight"])
-tot = {}
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+rows = {}
 for level in (0, 1, 2):
     ctx.set_option(pkg.OPT_INERT_TAIL, level)
     m = pkg.Matcher(ctx, kind, pkg.spe_cfg(), params)
-    rows = []
-    for k in range(len(scenes)):
-        ctx.scan_select(k)
-        r = m.process_scan(0, scenes[k]["init_pose"])
-        st = m.stats()
-        rows.append((st["scorer_calls"], st["poses_evaluated"], st["launches"], st["calls_closed_form"], r["prob"]))
-    tot[level] = rows
+    m.set_device_chain(2)
+    blk = m.make_batch([dict(map_id=0, scan_slot=k % 16, init_pose=scenes[k % 16]["init_pose"]) for k in range(K)])
+    m.process_scan_batch(blk)
+    r = m.process_scan_batch(blk)
+    rows[level] = ([m.batch_stats(j) for j in range(K)], m.stats(), m.resident_stats(), [x["prob"] for x in r])
     m.close()
-for k in range(len(scenes)):
-    print(k, " | ".join("calls %d eval %d steps %d closed %d" % tot[l][k][:4] for l in (0, 1, 2)),
-          "same" if tot[0][k][4] == tot[1][k][4] == tot[2][k][4] else "DIFFERENT")
+for j in range(min(K, 16)):
+    print(j, " | ".join("steps %d eval %d" % (rows[l][0][j]["super_steps"], rows[l][0][j]["poses_evaluated"]) for l in (0, 1, 2)),
+          "same" if rows[0][3][j] == rows[1][3][j] == rows[2][3][j] else "DIFFERENT")
 for l in (0, 1, 2):
-    print("level", l, "mean steps %.2f" % np.mean([r[2] for r in tot[l]]))
+    print("level", l, "longest", rows[l][1]["launches"], "closed", rows[l][1]["calls_closed_form"], rows[l][2])
