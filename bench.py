@@ -442,11 +442,14 @@ def main():
                      ms_per_match={"min": float(sm[0]), "median": float(np.median(sm)), "max": float(sm[-1])},
                      scorer_calls_per_step=timed_calls / args.steps,
                      scorer_calls_closed_form_per_step=timed_closed_calls / args.steps,
-                     closed_form=("the tail of a hill-climbing match whose steps are below half an ulp of the pose: every "
-                                  "candidate IS the best pose, bit for bit; the reference scores it again each time (a tie, "
-                                  "rejected), the chain reports those calls to the observer without scoring them "
-                                  "(SLAMHIP_OPT_INERT_TAIL).  `value` counts them (units = the reference's scorer calls x "
-                                  "beams, as in every round); value_scored_calls_only does not") if timed_closed_calls else None,
+                     closed_form=("the tail of a hill-climbing match: rounds whose candidates can no longer differ from the "
+                                  "best pose in any beam's CELL (the steps are below every beam's distance from its cell's "
+                                  "edge, certified per root pose with rounding slack; from failed round ~50 on the "
+                                  "candidates ARE the best pose bit for bit).  The reference scores them all the same -- "
+                                  "the same terms, the same score, a tie, rejected; the chain reports those calls to the "
+                                  "observer without scoring them (SLAMHIP_OPT_INERT_TAIL, csrc/hc_resident.hip).  `value` "
+                                  "counts them (units = the reference's scorer calls x beams, as in every round); "
+                                  "value_scored_calls_only does not") if timed_closed_calls else None,
                      value_scored_calls_only=(units_timed_scored / dt) if timed_closed_calls else None,
                      poses_evaluated_per_step=timed_evaluated / args.steps,
                      speculation_ratio=timed_evaluated / max(timed_calls, 1),
