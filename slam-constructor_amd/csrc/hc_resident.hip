@@ -454,8 +454,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
     // threshold (~50) lie rounds whose candidates differ from the best pose by less than any beam's distance from its
     // cell's edge: the same cells, the same terms, the same sum -- a tie with the best score, a rejection
     // (pose_enumeration_scan_matcher.h:58), in the canonical and in the beam-order sum alike.  A lone chain's tree of 42
-    // round instances crosses that stretch in the one super-step it needs anyway; the chains of a batch, with trees of a
-    // few instances, spend twenty super-steps there.  So: for the ROOT pose of this super-step, how small do the steps
+    // round instances spends one super-step too many there (cfg2: 11.9 -> 10.5), the chains of a batch, with trees of a
+    // few instances, twenty (K = 64: 56 -> 38).  So: for the ROOT pose of this super-step, how small do the steps
     // have to be for every candidate of a round based on it to end, beam by beam, in its own cells?  A beam's end point
     // moves by at most 1.01 dt (a translation candidate) or 1.5 r dr (a rotation candidate) plus rounding -- 2^-44 of
     // every magnitude involved, three orders above what the operations can lose; the distance from the nearest cell
