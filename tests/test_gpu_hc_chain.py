@@ -691,3 +691,56 @@ def test_inert_tail_fuzz_against_every_call_scored(pkg, ctx):
                 closed[lv] += sa["calls_closed_form"]
     assert n_closed[1] >= 100 and n_closed[2] >= n_closed[1]  # (the shortcuts really were taken in most of them)
     assert closed[2] >= closed[1]  # (a lone chain's workgroups make no certificates: tests/test_gpu_batch.py has the batches)
+
+
+def test_certificate_with_end_points_placed_next_to_cell_edges(pkg, ctx):
+    """The certificate's bound, provoked: a map of random occupancies (every cell differs from its neighbours, so a
+    beam that changes cells changes the score), scans of 1 ... 12 beams whose end points are PLACED at a distance
+    1e-13 ... 1e-3 m from a cell edge under the initial pose -- on either side, in x or in y, at ranges up to 25 m --
+    and hill climbers that start with steps of 1e-2 ... 1e-7, i.e. on either side of that distance: which candidates
+    cross the edge, and are accepted, depends on the last digits of the geometry.  A certificate made for the wrong
+    pose or the wrong steps, or one that held too early, would end a chain where the reference goes on to accept: 300
+    matches at SLAMHIP_OPT_INERT_TAIL 2 and 0, traces assert-equal; the shortcut is taken in most of them."""
+    from synth import MapData
+    rs = np.random.RandomState(2024)
+    scale = 0.1
+    m = MapData(CELL_OCC, rs.rand(300, 300), (150, 150), scale, [0.5])
+    ctx.upload_map(0, m)
+    n_closed = n_acc_late = 0
+    for it in range(300):
+        nb = int(rs.choice([1, 2, 3, 6, 12]))
+        pose = np.array([rs.uniform(-3, 3), rs.uniform(-3, 3), rs.uniform(-3.1, 3.1)])
+        ang = rs.uniform(-2.3, 2.3, nb)
+        rng = rs.uniform(0.5, 12.0, nb)
+        if it % 3 == 0:
+            rng[0] = rs.uniform(10.0, 25.0)  # (a long beam: the rotation candidates' lever)
+        # beam 0 (and beam 1, if there is one): the end point a distance d from a cell edge, on either side
+        for b in range(min(nb, 2)):
+            d = 10.0 ** rs.uniform(-13, -3) * rs.choice([-1.0, 1.0])
+            c, s = np.cos(pose[2] + ang[b]), np.sin(pose[2] + ang[b])
+            if rs.rand() < 0.5 and abs(c) > 0.2:
+                edge = np.round((pose[0] + rng[b] * c) / scale) * scale
+                rng[b] = (edge + d - pose[0]) / c
+            elif abs(s) > 0.2:
+                edge = np.round((pose[1] + rng[b] * s) / scale) * scale
+                rng[b] = (edge + d - pose[1]) / s
+            rng[b] = abs(rng[b])
+        cos_a, sin_a = pkg.beam_trig(ang)
+        ctx.scan_upload(rng, cos_a, sin_a, np.full(nb, 1.0 / nb), np.ones(nb))
+        prm = [int(rs.choice([60, 128])), 10.0 ** rs.uniform(-7, -2), 10.0 ** rs.uniform(-7, -2)]
+        res = {}
+        for level in (2, 0):
+            ctx.set_option(pkg.OPT_INERT_TAIL, level)
+            try:
+                mm = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+                res[level] = (mm.process_scan(0, pose, trace=True), mm.stats())
+                assert mm.resident_stats()["gave_up"] == 0
+                mm.close()
+            finally:
+                ctx.set_option(pkg.OPT_INERT_TAIL, 2)
+        (a, sa), (b_, sb) = res[2], res[0]
+        assert_trace_equal(a, b_)
+        assert a["prob"] == b_["prob"] and np.array_equal(a["delta"], b_["delta"]) and a["n_calls"] == b_["n_calls"]
+        n_closed += sa["calls_closed_form"] > 0
+        n_acc_late += int(np.count_nonzero(a["accepted"]) > 0)  # (a candidate did cross an edge and was accepted)
+    assert n_closed >= 200 and n_acc_late >= 60
