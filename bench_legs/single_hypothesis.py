@@ -27,13 +27,18 @@ def world_leg(args, pkg, ctx, sc, cfg, kind, params, scenes, preset="tiny", map_
     rule = pkg.RULE_TBM if viny else pkg.RULE_MEAN
     adder = dict(quality=0.9, base=(0.95, 0.04, 0.01, 0.003), blur=0.3) if viny else {}
 
+    # (argument blocks made once per scan: what a caller that holds its scans in C arrays passes -- r06; the three calls
+    # and what they do are unchanged)
+    uploads = [ctx.make_scan_upload(s["range"], trig[k][0], trig[k][1], s["weight"]) for k, s in enumerate(scenes)]
+    appends = [ctx.make_map_append_scan(5, rule, s["range"], trig[k][0], trig[k][1], **adder) for k, s in enumerate(scenes)]
+
     def one_scan():
         k = it[0] % len(scenes)
         it[0] += 1
-        s, (cos_a, sin_a) = scenes[k], trig[k]
-        ctx.scan_upload(s["range"], cos_a, sin_a, s["weight"], None)
+        s = scenes[k]
+        uploads[k]()
         r = m.process_scan(5, s["init_pose"])
-        ctx.map_append_scan(5, rule, s["init_pose"] + r["delta"], s["range"], cos_a, sin_a, **adder)
+        appends[k](s["init_pose"] + r["delta"])
 
     for _ in range(len(scenes)):
         one_scan()

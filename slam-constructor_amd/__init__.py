@@ -529,6 +529,45 @@ class Context:
         _check(self.L.slamhip_scan_upload(self.h, rng.size, _d(rng), _d(cos_a), _d(sin_a),
                                           _d(weight), _d(fac)))
 
+    def make_scan_upload(self, rng, cos_a, sin_a, weight, factor=None):
+        """Argument block of slamhip_scan_upload made once for a filtered scan (a caller that holds its scans in C arrays
+        pays no conversions per call): returns upload()."""
+        rng, cos_a, sin_a, weight = _f64(rng), _f64(cos_a), _f64(sin_a), _f64(weight)
+        fac = _f64(factor) if factor is not None else np.ones(rng.size)
+        fn = self.L.slamhip_scan_upload
+        args = (self.h, rng.size, _d(rng), _d(cos_a), _d(sin_a), _d(weight), _d(fac))
+        keep = (rng, cos_a, sin_a, weight, fac)
+
+        def upload(_keep=keep):
+            rc = fn(*args)
+            if rc:
+                _check(rc)
+        return upload
+
+    def make_map_append_scan(self, map_id, rule, rng, cos_a, sin_a, is_occ=None, quality=1.0,
+                             base=(0.95, 1.0, 0.01, 1.0), blur=0.0, max_range=float("inf"), estimator=0,
+                             shift_amount=0.0, beam_quality=None):
+        """Argument block of slamhip_map_append_scan_q made once for a scan: returns append(pose) -> cell updates (-1
+        while updates are deferred)."""
+        cfg = ScanAdderCfg(rule, quality, base[0], base[1], base[2], base[3], blur, max_range, estimator, shift_amount)
+        rng, cos_a, sin_a = _f64(rng), _f64(cos_a), _f64(sin_a)
+        occ = np.ascontiguousarray(is_occ, dtype=np.int32) if is_occ is not None else None
+        bq = _f64(beam_quality) if beam_quality is not None else None
+        nu = C.c_longlong(0)
+        pose3 = (C.c_double * 3)()
+        fn = self.L.slamhip_map_append_scan_q
+        args = (self.h, map_id, C.pointer(cfg), C.cast(pose3, _dp), rng.size, _d(rng), _d(cos_a), _d(sin_a),
+                occ.ctypes.data_as(_ip) if occ is not None else None, _d(bq) if bq is not None else None, C.pointer(nu))
+        keep = (cfg, rng, cos_a, sin_a, occ, bq)
+
+        def append(pose, _keep=keep):
+            pose3[0], pose3[1], pose3[2] = float(pose[0]), float(pose[1]), float(pose[2])
+            rc = fn(*args)
+            if rc:
+                _check(rc)
+            return nu.value
+        return append
+
     def scan_filter_upload(self, map_id, rng, ang, pose, is_occ=None, factor=None, trig_mode=TRIG_RAW, a_min=0.0,
                            a_max=0.0, a_inc=1.0, skip_rate=0, max_range=-1.0, bounded=False, weighting="even"):
         """slamhip_scan_filter_upload: the RAW scan in -- filter_scan, weighting, beam trig and the upload in one call.
