@@ -656,7 +656,9 @@ int hc_batch_run(slamhip_matcher *m, int n, const slamhip_match_job *jobs) {
     // and tabulate once for the two (hc_resident.hip) --, two workgroups per CU, the trees sized so that all chains'
     // workgroups are resident together with one CU to spare.
     if (!b->cus) SLAMHIP_CHECK(hipDeviceGetAttribute(&b->cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    int want = std::min(kHcDefaultInst, std::max(1, kBatchWgs / (6 * n)));
+    // (a chain is 6 x instances + 1 workgroups: r05 sized by 6 x instances alone, and batches of 10, 24 ... 28 matches --
+    // 1030 ... 1036 workgroups against 1020 resident ones at 1080 beams -- fell back to the kernel chains)
+    int want = std::min(kHcDefaultInst, std::max(1, (kBatchWgs / n - 1) / 6));
     // (measured, ms per call, pairs / one pose per 256-thread workgroup: K = 4 0.170 / 0.179, 8: 0.191 / 0.193, 16: 0.288 /
     // 0.276 -- a pair's super-step is 7 % shorter (7.4 against 8.0 us at K = 8: the beam constants fit in LDS again and
     // the sweep, the replay and the table are made once for two poses), but two workgroups per CU with a CU to spare

@@ -261,8 +261,9 @@ def test_batch_certified_tails_fuzz_against_every_call_scored(pkg, ctx, cell, we
                 got = mb.process_scan_batch(jobs, trace=True)
                 st = [mb.batch_stats(j) for j in range(k)]
                 res[level] = (got, st, mb.stats())
-                # (k = 24: trees of that batch do not fit the device together -- kernel chains, which score every call)
-                assert mb.resident_stats() == dict(matches=0 if k == 24 else 1, gave_up=0), (k, level, prm)
+                # (k = 24 included: r05's tree sizing left batches of 10 and 24 ... 28 matches a few workgroups over what
+                # is resident together, and they ran as kernel chains)
+                assert mb.resident_stats() == dict(matches=1, gave_up=0), (k, level, prm)
                 quiet = mb.process_scan_batch(jobs)
                 for g, q in zip(got, quiet):
                     assert g["prob"] == q["prob"] and np.array_equal(g["delta"], q["delta"])
