@@ -28,8 +28,8 @@ struct HcHostOut {
   // GMapping OOPE: side outputs and raw score of the INITIAL pose (the filter's cross-particle cache check)
   GmPoseInfo first_info;
   double first_raw;
-  long long tail_calls;  // co-resident 1-cell / window form: scorer calls of `calls` reported in closed form (an inert
-                         // root's tail: hc_inert), i.e. not scored
+  long long tail_calls;  // co-resident 1-cell / window form: scorer calls of `calls` reported in closed form (the tail
+                         // behind an inert or certified root), i.e. not scored
 };
 
 // device memory of one matcher
@@ -126,8 +126,10 @@ struct HcChainArgs {
                          // (set by the launcher: hc_resident_tab_offset)
   int oope;              // SLAMHIP_OOPE_OBSTACLE (0), or a window OOPE (max / mean / overlap) with its analysis area
   double area[4];
-  int inert_tail;        // co-resident 1-cell / window form: a root whose rounds only repeat its own pose (hc_inert) ends
-                         // the chain in closed form instead of being scored 6 x (limit - failed) + 1 more times
+  int inert_tail;        // co-resident 1-cell / window form (SLAMHIP_OPT_INERT_TAIL): >= 1: a root whose rounds only repeat
+                         // its own pose (hc_inert) ends the chain in closed form instead of being scored
+                         // 6 x (limit - failed) + 1 more times; 2: so does a root the bookkeeping workgroup has CERTIFIED
+                         // for the next steps (1-cell form; hc_resident.hip "certificate")
 };
 
 // threads per workgroup: 256, 512 or 1024; n_chains > 1: the multi-chain form (see HcChainArgs::inits)
