@@ -184,6 +184,34 @@ HC_HD bool hc_inert(double x, double y, double theta, double dt, double dr) {
   return same;
 }
 
+// The CERTIFICATE of a pose (hc_resident.hip): the largest steps for which no candidate of a round based on the pose
+// (px, py, theta; sn / cs its sine and cosine) can move THIS beam's end point out of the cell it ends in -- so that the
+// 1-cell scorer's term, a function of the cell alone, cannot change.  A translation candidate moves the end point by at
+// most 1.01 dt, a rotation candidate by at most 1.5 r dr (sqrt(2) r dr, the error of two sincos, roundings), plus
+// rounding bounded by 2^-44 of every magnitude involved -- r (1 + |theta|), the end point, the pose: ~500 x what the
+// operations can lose --; that has to stay below the end point's distance from the nearest edge of its cell, computed
+// with the same slack against the rounding of the true quotient world_to_cell takes the floor of.  *t_t / *t_r: the
+// beam's bounds on dt / dr (0: none -- the end point sits on an edge, or something is not finite).  The minimum over the
+// beams certifies the pose.  One definition for the kernel and for tests/native/hc_chain_test.cpp, which holds it
+// against the plain accept loop.
+HC_HD void hc_cert_beam(double px, double py, double sn, double cs, double theta_abs, double r_, double ca, double sa,
+                        double scale, double inv_scale, double *t_t, double *t_r) {
+  const double c = cs * ca - sn * sa;
+  const double s_ = sn * ca + cs * sa;
+  const double wx = px + r_ * c, wy = py + r_ * s_;
+  const double qx = wx * inv_scale, qy = wy * inv_scale;
+  const double fx = qx - __builtin_floor(qx), fy = qy - __builtin_floor(qy);
+  const double mx = fx < 1.0 - fx ? fx : 1.0 - fx, my = fy < 1.0 - fy ? fy : 1.0 - fy;
+  const double edge = (mx < my ? mx : my) * scale;
+  const double ar = __builtin_fabs(r_);
+  const double slack = (ar * (1.0 + theta_abs) + __builtin_fabs(wx) + __builtin_fabs(wy) + __builtin_fabs(px) +
+                        __builtin_fabs(py) + 1.0) * 0x1p-44;
+  const double avail = edge - slack;
+  const bool ok = avail > 0.0;  // (false for a NaN)
+  *t_t = ok ? avail * 0.99 : 0.0;
+  *t_r = ok ? (ar > 0.0 ? avail / (1.5 * ar) : __builtin_inf()) : 0.0;
+}
+
 // 2^-k as a double (k < 1000): halving a normal double k times is one exact multiplication by it
 HC_HD double hc_pow_half(unsigned k) {
   union {

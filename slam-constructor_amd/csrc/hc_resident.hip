@@ -474,20 +474,8 @@ __global__ __launch_bounds__(NT, 4) void k_hc_chain_resident(HcChainArgs a) {
           ca = ldsc ? s_ca[b] : scan.cos_a[b];
           sa = ldsc ? s_sa[b] : scan.sin_a[b];
         }
-        const double c = cs * ca - sn * sa;
-        const double s_ = sn * ca + cs * sa;
-        const double wx = px + r_ * c, wy = py + r_ * s_;
-        const double qx = wx * map.inv_scale, qy = wy * map.inv_scale;
-        const double fx = qx - floor(qx), fy = qy - floor(qy);
-        const double mx = fx < 1.0 - fx ? fx : 1.0 - fx, my = fy < 1.0 - fy ? fy : 1.0 - fy;
-        const double edge = (mx < my ? mx : my) * map.scale;
-        const double ar = __builtin_fabs(r_);
-        const double slack = (ar * (1.0 + theta_abs) + __builtin_fabs(wx) + __builtin_fabs(wy) + __builtin_fabs(px) +
-                              __builtin_fabs(py) + 1.0) * 0x1p-44;
-        const double avail = edge - slack;
-        const bool ok = avail > 0.0;  // (false for a NaN)
-        const double t1 = ok ? avail * 0.99 : 0.0;
-        const double t2 = ok ? (ar > 0.0 ? avail / (1.5 * ar) : __builtin_inf()) : 0.0;
+        double t1, t2;
+        hc_cert_beam(px, py, sn, cs, theta_abs, r_, ca, sa, map.scale, map.inv_scale, &t1, &t2);
         tt = tt < t1 ? tt : t1;
         tr = tr < t2 ? tr : t2;
       }

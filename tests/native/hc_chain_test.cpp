@@ -60,7 +60,8 @@ std::vector<Entry> reference_loop(unsigned max_failed, double dt, double dr, con
 // one process_scan the way the chain of kernels runs it
 std::vector<Entry> chain_loop(const std::vector<HcShape> &shapes, unsigned max_failed, double dt, double dr,
                               const Pose &init, const ScoreFn &f, double p_accept0, Pose *best_out, double *prob_out,
-                              int *steps_out, long long *evaluated_out) {
+                              int *steps_out, long long *evaluated_out, bool inert_tail = false,
+                              long long *tail_calls_out = nullptr) {
   std::vector<Entry> tr;
   HcState st{};
   st.x = init.x;
@@ -142,6 +143,22 @@ std::vector<Entry> chain_loop(const std::vector<HcShape> &shapes, unsigned max_f
     const HcRound r = hc_round_of(st, tm);
     hc_advance(st, tm, r, out[terminal], run[terminal], max_failed, 6ll * sh.n_inst + (st.first ? 1 : 0), &next);
     st = next;
+    // r06: the inert tail (hc_inert; hc_resident.hip tabulates it per next root): every candidate of every further round
+    // IS the root pose -- the chain ends, the remaining 6 x (limit - failed) + 1 scorer calls are written in closed form
+    if (inert_tail && !st.done && hc_inert(st.x, st.y, st.theta, st.dt, st.dr)) {
+      const long long tail = 6ll * (long long)(max_failed - st.failed) + 1ll;
+      for (long long q = 0; q < tail; ++q) {
+        const double hlf = hc_pow_half((unsigned)(q / 6));
+        Entry e;
+        hc_candidate(st.x, st.y, st.theta, st.dt * hlf, st.dr * hlf, (int)(q % 6), &e.x, &e.y, &e.theta);
+        e.score = st.best_prob;
+        e.accepted = 0;
+        tr.push_back(e);
+      }
+      st.calls += tail;
+      st.done = 1;
+      if (tail_calls_out) *tail_calls_out = tail;
+    }
   }
   *best_out = Pose{st.x, st.y, st.theta};
   *prob_out = st.best_prob;
@@ -159,7 +176,7 @@ std::vector<Entry> chain_loop(const std::vector<HcShape> &shapes, unsigned max_f
 int main() {
   std::mt19937 rng(11);
   std::uniform_real_distribution<double> u(-1.0, 1.0);
-  long long cases = 0, calls = 0, steps = 0, evaluated = 0;
+  long long cases = 0, calls = 0, steps = 0, evaluated = 0, tails = 0;
   for (int variant = 0; variant < 4; ++variant) {
     // shapes as the matcher builds them, plus small / boosted ones (a small shape walks off early and often)
     std::vector<HcShape> shapes(kHcShapes);
@@ -191,6 +208,26 @@ int main() {
           }
         return 1;
       }
+      // ... and with the inert tail in closed form: the same trace, fewer super-steps where the limit lies behind the
+      // point at which the steps vanish (0.1 x 2^-k against poses of a few metres: k ~ 52 ... 57)
+      {
+        Pose b2;
+        double p2;
+        int st2;
+        long long ev2, tail = 0;
+        const auto got2 = chain_loop(shapes, max_failed, dt, dr, init, f, 0.1, &b2, &p2, &st2, &ev2, true, &tail);
+        if (ref.size() != got2.size() || std::memcmp(ref.data(), got2.data(), ref.size() * sizeof(Entry)) != 0 ||
+            std::memcmp(&b0, &b2, sizeof(Pose)) != 0 || std::memcmp(&p0, &p2, sizeof(double)) != 0) {
+          std::printf("FAIL: inert tail, variant %d case %d (max_failed %u): %zu reference calls, %zu chain calls\n", variant,
+                      rep, max_failed, ref.size(), got2.size());
+          return 1;
+        }
+        if (max_failed >= 128 && (tail < 6 + 1 || ev2 >= ev)) {
+          std::printf("FAIL: inert tail not taken, variant %d case %d (max_failed %u): tail %lld\n", variant, rep, max_failed, tail);
+          return 1;
+        }
+        tails += tail > 0;
+      }
       ++cases;
       calls += (long long)ref.size();
       steps += st;
@@ -199,5 +236,6 @@ int main() {
   }
   std::printf("ok %lld matches, %lld scorer calls in %lld super-steps (%.1f calls per step, %.2f evaluations per call)\n",
               cases, calls, steps, (double)calls / steps, (double)evaluated / calls);
+  std::printf("inert tails taken in %lld of them, same traces\n", tails);
   return 0;
 }
