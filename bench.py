@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--cpu-procs", type=int, default=0,
                     help="worker processes of the all-cores CPU context lines (0 = one per physical core of the host)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-tail-ab", action="store_true",
+                    help="skip the headline's second measurement with SLAMHIP_OPT_INERT_TAIL off (config."
+                         "ms_per_step_every_call_scored): profiler runs use it, so that a kernel's dispatches in their trace "
+                         "are all of the default path")
     ap.add_argument("--particles", type=int, default=100)
     ap.add_argument("--pf-size", type=int, default=4000)
     ap.add_argument("--pf-steps", type=int, default=10)
@@ -388,7 +392,7 @@ def main():
         ms_other = 1e3 * (time.perf_counter() - t2) / args.steps
         extra.update(includes_filter_and_upload=not args.resident_scan,
                      **{"ms_per_step_raw_scan_in" if args.resident_scan else "ms_per_step_resident": ms_other})
-        if kind == "HC" and timed_closed_calls > 0:
+        if kind == "HC" and timed_closed_calls > 0 and not args.no_tail_ab:
             # the same K steps with SLAMHIP_OPT_INERT_TAIL off: every scorer call of the tail scored, as in r01 - r05
             ctx.set_option(pkg.OPT_INERT_TAIL, 0)
             try:

@@ -13,7 +13,9 @@ cd /tmp; export TMPDIR=/tmp
 run() { # name, bench args...
   local name=$1; shift
   # (r06: stdout carries a digest line <= 8 KB, the full record is the --detail-out sidecar: that is what profiles/ keeps)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $ROOT/bench.py --detail-out $OUT/$name.bench.json "$@" > $OUT/$name.bench.log 2>&1
+  # (--no-tail-ab: the headline's every-call-scored comparison is not run under the profiler -- its 72 us launches would be
+  # averaged into the default path's in the kernel stats)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 $ROOT/bench.py --no-tail-ab --detail-out $OUT/$name.bench.json "$@" > $OUT/$name.bench.log 2>&1
   python3 $ROOT/bench.py --detail-out $OUT/$name.plain.json "$@" 2> /dev/null | grep '^{"metric' | tail -1 > $OUT/$name.line.json
 }
 pmc() { # workload-name, pass-name, counters..., then "--", bench args
@@ -21,7 +23,7 @@ pmc() { # workload-name, pass-name, counters..., then "--", bench args
   local ctrs=()
   while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
   shift
-  rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $OUT/pmc_${wl}_$pass -o pmc -- python3 $ROOT/bench.py --detail-out $OUT/pmc_${wl}_$pass.detail.json "$@" > $OUT/pmc_${wl}_$pass.log 2>&1
+  rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $OUT/pmc_${wl}_$pass -o pmc -- python3 $ROOT/bench.py --no-tail-ab --detail-out $OUT/pmc_${wl}_$pass.detail.json "$@" > $OUT/pmc_${wl}_$pass.log 2>&1
 }
 # 1. PMC passes first: their summary (HBM bytes and VALU instructions per launch) is what the bench lines of
 #    step 2 quote as roofline.traffic / roofline_valu, so it has to exist -- in THIS copy of the repo -- before them
