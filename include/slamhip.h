@@ -117,7 +117,7 @@ enum {
                                   * observation of the scorer) -- from an 8-byte plane every writer of the map keeps,
                                   * instead of the 32-byte cell and its belief arithmetic per (pose, beam); 0: from the
                                   * cell.  The same operations either way: the same bits. */
-  SLAMHIP_OPT_INERT_TAIL = 8     /* the tail of a co-resident hill-climbing chain (1-cell OOPE).  The reference's enumerator
+  SLAMHIP_OPT_INERT_TAIL = 8     /* the tail of a hill-climbing chain on the device (1-cell OOPE).  The reference's enumerator
                                   * stops at a count of failed rounds, not at convergence
                                   * (hill_climbing_scan_matcher.h:83-101), the steps halved at every failure.
                                   * 1: once the steps are below half an ulp of every pose coordinate, every candidate
@@ -129,7 +129,8 @@ enum {
                                   * candidate provably ends in the same cell as under the best pose (a per-beam bound
                                   * on the end point's movement against its distance from the cell's edges, made by the
                                   * chain's idle bookkeeping workgroup: csrc/hc_resident.hip "certificate"): the same
-                                  * cells, the same terms, the same score.  What that buys is the chains of a BATCH.
+                                  * cells, the same terms, the same score (co-resident form only; the chain of kernels
+                                  * stays at 1).
                                   * 0: every call scored.  Same traces, results and counts in all three. */
 };
 int slamhip_ctx_set_option(slamhip_ctx *ctx, int option, int value);

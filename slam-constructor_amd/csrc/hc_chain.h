@@ -164,8 +164,8 @@ HC_HD void hc_candidate(double x, double y, double theta, double dt, double dr, 
 // the same -- the same pose, so the same score as the best one's, a tie, a rejection (pose_enumeration_scan_matcher.h:58)
 // -- and every later round is the same round with smaller steps: from here on the match is 6 x (limit - failed) + 1
 // scorer calls that return the best score, and then the result.  The co-resident chain ends there in closed form
-// (hc_resident.hip, HcChainArgs::inert_tail; long before that it ends on a CERTIFIED root, see there); the other forms
-// of the chain score the tail -- same traces.
+// (hc_resident.hip, HcChainArgs::inert_tail; long before that it ends on a CERTIFIED root, see there), and so does the
+// chain of kernels (hc_chain.hip); the host-driven form scores the tail -- same traces.
 HC_HD bool hc_inert(double x, double y, double theta, double dt, double dr) {
   union U {
     double d;

@@ -385,6 +385,15 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
         next.done = 1;
         if (init_slot && lane == 0) host->error = 1;
       }
+      // r06: the inert tail (hc_inert, hc_chain.h) -- a next root whose six candidates ARE that root, bit for bit: what the
+      // reference still does is score that pose 6 x (limit - failed) + 1 more times, a tie and a rejection each.  The
+      // chain ends here; the bookkeeping workgroup writes those scorer calls into the trace (below).  (The co-resident
+      // form also ends on CERTIFIED roots, long before: hc_resident.hip.)
+      long long tail_calls = 0;
+      if (!GM && a.inert_tail && !dirty && !next.done && hc_inert(next.x, next.y, next.theta, next.dt, next.dr)) {
+        tail_calls = 6ll * (long long)(a.max_failed - next.failed) + 1ll;
+        next.done = 1;
+      }
       st = next;
       if (init_slot) {
         // ---- the last workgroup keeps the books (it scores nothing after the first super-step, so the
@@ -411,6 +420,21 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             }
           }
         }
+        if (tail_calls > 0 && a.trace) {
+          HcTraceEntry *const trace = a.trace + (size_t)blockIdx.y * (size_t)a.trace_stride;
+          for (long long q = lane; q < tail_calls; q += 64) {
+            // scorer call q of the tail: candidate q % 6 of its round q / 6, whose steps were halved that often
+            const double hlf = hc_pow_half((unsigned)(q / 6));
+            HcTraceEntry e;
+            hc_candidate(next.x, next.y, next.theta, next.dt * hlf, next.dr * hlf, (int)(q % 6), &e.x, &e.y, &e.theta);
+            e.score = next.best_prob;
+            e.accepted = 0;
+            e.pad = 0;
+            if (next.calls + q < a.trace_cap) trace[next.calls + q] = e;
+            else host->error = 2;
+          }
+        }
+        next.calls += tail_calls;
         if (lane == 0) ctl->state[k & 1] = next;
         if (!next.done) ctl->walk[k & 1][lane] = a.shapes[next.shape].inst[lane];
         if (next.done) {
@@ -424,6 +448,7 @@ __global__ __launch_bounds__(NT) void k_hc_chain_step(HcChainArgs a, int k) {
             h->pose[2] = next.theta;
             h->best_prob = next.best_prob;
             h->calls = next.calls;
+            h->tail_calls = tail_calls;
             h->evaluated = next.evaluated;
             h->steps = next.steps;
             h->rescored = next.rescored;

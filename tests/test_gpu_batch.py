@@ -215,7 +215,7 @@ def test_batch_inert_tails_equal_lone_matches_with_every_call_scored(pkg, ctx, k
     """r06: the chains of a batch end on their inert roots too (csrc/hc_resident.hip: the closed-form tail of a
     hill-climbing match, SLAMHIP_OPT_INERT_TAIL) -- each chain's bookkeeping workgroup writes its tail into its own
     stretch of the observers' trace buffer.  k matches at limit 128 (k = 8: the pair form, two poses per workgroup) against
-    lone matches on the kernel chain, which scores every call: traces bit for bit, counts equal, and the batch's
+    lone matches on the kernel chain with every call scored (option 0): traces bit for bit, counts equal, and the batch's
     closed-form calls are what its chains did not score."""
     jobs = scenes(pkg, ctx, CELL_OCC, "even", k, beams=(720, 360, 1080))
     prm = [128, 0.1, 0.1]
@@ -228,7 +228,11 @@ def test_batch_inert_tails_equal_lone_matches_with_every_call_scored(pkg, ctx, k
     assert mb.resident_stats() == dict(matches=1, gave_up=0)
     evaluated = 0
     for j, (g, job) in enumerate(zip(got, jobs)):
-        want = lone(pkg, ctx, ml, job)
+        ctx.set_option(pkg.OPT_INERT_TAIL, 0)  # (the lone matches: every call scored)
+        try:
+            want = lone(pkg, ctx, ml, job)
+        finally:
+            ctx.set_option(pkg.OPT_INERT_TAIL, 2)
         assert_trace_equal(g, want)
         st = mb.batch_stats(j)
         assert st["scorer_calls"] == want["n_calls"] == ml.stats()["scorer_calls"]

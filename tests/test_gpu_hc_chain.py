@@ -610,8 +610,8 @@ def test_window_oopes_on_the_resident_chain_equal_the_host_driven_matcher(pkg, c
 
 @pytest.mark.parametrize("cell,weighting", [(CELL_OCC, "even"), (CELL_TBM, "viny")])
 @pytest.mark.parametrize("prm", [[128, 0.1, 0.1], [60, 0.1, 0.1], [1000, 0.2, 0.1], [300, 1e-9, 1e-9]])
-@pytest.mark.parametrize("level", [1, 2])
-def test_inert_tail_ends_the_chain_in_closed_form_with_the_same_trace(pkg, ctx, po, oracle, cell, weighting, prm, level):
+@pytest.mark.parametrize("level,mode", [(1, 2), (2, 2), (2, 1)])  # (mode 1, the chain of kernels: identical poses only)
+def test_inert_tail_ends_the_chain_in_closed_form_with_the_same_trace(pkg, ctx, po, oracle, cell, weighting, prm, level, mode):
     """r06.  Once the hill climber's steps are below half an ulp of every pose coordinate, every
     candidate of every further round IS the best pose bit for bit -- the reference goes on scoring it, 6 x (limit -
     failed) + 1 times, a tie and a rejection each time (hill_climbing_scan_matcher.h:83-101,
@@ -623,13 +623,15 @@ def test_inert_tail_ends_the_chain_in_closed_form_with_the_same_trace(pkg, ctx, 
     ctx.set_option(pkg.OPT_INERT_TAIL, level)
     try:
         on = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+        on.set_device_chain(mode)
         ton = [on.process_scan(0, sc["init_pose"] + k * np.array([0.011, -0.006, 0.003]), trace=True) for k in range(3)]
         son = on.stats()
         quiet = on.process_scan(0, sc["init_pose"] + 2 * np.array([0.011, -0.006, 0.003]))
         assert quiet["prob"] == ton[2]["prob"] and np.array_equal(quiet["delta"], ton[2]["delta"])
-        assert on.resident_stats()["gave_up"] == 0
+        assert on.resident_stats()["gave_up"] == 0 and (on.resident_stats()["matches"] > 0) == (mode == 2)
         ctx.set_option(pkg.OPT_INERT_TAIL, 0)
         off = pkg.Matcher(ctx, "HC", pkg.spe_cfg(), prm)
+        off.set_device_chain(mode)
         toff = [off.process_scan(0, sc["init_pose"] + k * np.array([0.011, -0.006, 0.003]), trace=True) for k in range(3)]
         soff = off.stats()
     finally:
@@ -647,7 +649,7 @@ def test_inert_tail_ends_the_chain_in_closed_form_with_the_same_trace(pkg, ctx, 
         t, tail = ton[2], son["calls_closed_form"]
         assert tail >= 6 * (prm[0] - 100) + 1 and soff["calls_closed_form"] == 0
         assert len(set(t["scores"][-tail:])) == 1 and not np.any(t["accepted"][-tail:])
-        if level == 1:  # (identical poses only: the whole tail is the best pose itself)
+        if level == 1 or mode == 1:  # (identical poses only: the whole tail is the best pose itself)
             assert all(np.array_equal(t["poses"][-1 - q], t["poses"][-1]) for q in range(tail))
     e = oracle.enumerator(po.SM_HC, prm)
     r = oracle.process_scan(e, sc["map"], sc["scan"], po.make_cfg(), sc["init_pose"])
