@@ -400,10 +400,13 @@ def main():
                     step()
                 barrier()
                 t3 = time.perf_counter()
+                u3 = 0
                 for _ in range(args.steps):
-                    step()
+                    u3 += step()
                 barrier()
-                extra["ms_per_step_every_call_scored"] = 1e3 * (time.perf_counter() - t3) / args.steps
+                dt3 = time.perf_counter() - t3
+                extra["ms_per_step_every_call_scored"] = 1e3 * dt3 / args.steps
+                extra["value_every_call_scored"] = float(u3) / dt3  # (what `value` is with the option off)
             finally:
                 ctx.set_option(pkg.OPT_INERT_TAIL, 2)
             per_scene_stats.clear()

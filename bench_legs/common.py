@@ -302,7 +302,7 @@ def compact_line(full, detail_path=None):
                                 "includes_filter_and_upload", "ms_per_step_resident", "ms_per_step_raw_scan_in",
                                 "scorer_calls_per_step", "poses_evaluated_per_step", "speculation_ratio",
                                 "super_steps_per_match", "kernel_busy_frac", "scorer_calls_closed_form_per_step",
-                                "value_scored_calls_only", "ms_per_step_every_call_scored"))
+                                "value_scored_calls_only", "ms_per_step_every_call_scored", "value_every_call_scored"))
     out["config"]["mode"] = _short(cfg.get("mode", ""), 48)
     if "resident" in cfg:
         out["config"]["resident"] = _pick(cfg["resident"], ("matches", "gave_up"))
