@@ -455,8 +455,9 @@ def main():
                                   "candidates ARE the best pose bit for bit).  The reference scores them all the same -- "
                                   "the same terms, the same score, a tie, rejected; the chain reports those calls to the "
                                   "observer without scoring them (SLAMHIP_OPT_INERT_TAIL, csrc/hc_resident.hip).  `value` "
-                                  "counts them (units = the reference's scorer calls x beams, as in every round); "
-                                  "value_scored_calls_only does not") if timed_closed_calls else None,
+                                  "counts them (SURVEY 8d Metric 1: scorer calls = on_scan_test events x beams, as in every "
+                                  "round and in cpu_baseline); value_scored_calls_only does not; value_every_call_scored is "
+                                  "the same steps with the option off") if timed_closed_calls else None,
                      value_scored_calls_only=(units_timed_scored / dt) if timed_closed_calls else None,
                      poses_evaluated_per_step=timed_evaluated / args.steps,
                      speculation_ratio=timed_evaluated / max(timed_calls, 1),
